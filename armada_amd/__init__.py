@@ -1,0 +1,24 @@
+"""armada_amd — MI355X-native implementation of Armada's scheduling-round hot path.
+
+The product is the C-ABI shared library ``armada_amd/csrc/libarmada_sched.so`` (hand-written HIP for
+gfx950, declared in ``include/armada_sched.h``).  This Python package is the host-side harness around
+it: the ctypes binding, a mirror of the reference's NodeDb / PreemptingQueueScheduler interface and the
+synthetic workload generators of BASELINE.json.  There is no CPU fallback: loading fails loudly when
+the HIP library has not been built.
+"""
+import os
+
+from .binding import Config, Library, Scheduler, SchedError  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libarmada_sched.so")
+
+_lib = None
+
+
+def load_library() -> Library:
+    """Load the HIP implementation (prefix ``asched_``). Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        _lib = Library(LIB_PATH, "asched_")
+    return _lib

@@ -1,0 +1,610 @@
+"""ctypes binding of the C ABI declared in include/armada_sched.h.
+
+The binding is generic over (shared library path, symbol prefix): the product loads
+``armada_amd/csrc/libarmada_sched.so`` with prefix ``asched_`` (the HIP implementation); the test
+suite loads the CPU oracle with prefix ``oracle_`` through the same class so that both backends are
+driven by identical code.  Nothing in this package references the oracle.
+
+Struct layouts mirror include/armada_sched.h field for field.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+MAX_RESOURCES = 8
+MAX_INDEXED = 6
+MAX_PRIORITIES = 16
+EVICTED_PRIORITY = -2
+CROSS_POOL_PRIORITY = -1
+
+OK = 0
+ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_INTERNAL = -1, -2, -3, -4
+
+EFFECT_NONE, EFFECT_NO_SCHEDULE, EFFECT_PREFER_NO_SCHEDULE, EFFECT_NO_EXECUTE = 0, 1, 2, 3
+TOL_EQUAL, TOL_EXISTS = 0, 1
+
+METHOD_NONE, METHOD_RESCHEDULED, METHOD_NO_PREEMPTION, METHOD_FAIRSHARE, METHOD_URGENCY, METHOD_AWAY = range(6)
+
+REASONS = {
+    0: "",
+    1: "maximum resources scheduled",
+    2: "maximum total resources for this queue exceeded",
+    3: "global scheduling rate limit exceeded",
+    4: "queue scheduling rate limit exceeded",
+    5: "queue cordoned",
+    6: "gang would exceed global scheduling rate limit",
+    7: "gang would exceed queue scheduling rate limit",
+    8: "gang cardinality too large: exceeds global max burst size",
+    9: "gang cardinality too large: exceeds queue max burst size",
+    10: "unable to schedule gang since minimum cardinality not met",
+    11: "job does not fit on any node",
+    12: "resource limit exceeded",
+    13: "uniformity label is not indexed",
+    14: "no nodes with uniformity label",
+    15: "at least one job in the gang does not fit on any node",
+    16: "no remaining candidate jobs",
+    17: "skipped: scheduling key known to be unfeasible",
+}
+
+_i32p = C.POINTER(C.c_int32)
+_u32p = C.POINTER(C.c_uint32)
+_i64p = C.POINTER(C.c_int64)
+_u64p = C.POINTER(C.c_uint64)
+_u8p = C.POINTER(C.c_uint8)
+_f64p = C.POINTER(C.c_double)
+
+
+class CConfig(C.Structure):
+    _fields_ = [
+        ("num_resources", C.c_int32), ("num_indexed", C.c_int32),
+        ("indexed_col", _i32p), ("indexed_resolution", _i64p),
+        ("num_priority_classes", C.c_int32),
+        ("pc_priority", _i32p), ("pc_preemptible", _u8p),
+        ("pc_away_off", _i32p), ("away_priority", _i32p), ("away_well_known", _i32p),
+        ("num_well_known_types", C.c_int32),
+        ("wkt_taint_off", _i32p), ("wkt_taint_key", _i32p), ("wkt_taint_value", _i32p), ("wkt_taint_effect", _i32p),
+        ("drf_multiplier", _f64p),
+        ("num_indexed_taints", C.c_int32), ("indexed_taint_keys", _i32p),
+        ("num_indexed_labels", C.c_int32), ("indexed_label_keys", _i32p),
+        ("prefer_large_job_ordering", C.c_uint8), ("protect_uncapped_adjusted_fair_share", C.c_uint8),
+        ("disable_home_scheduling", C.c_uint8), ("disable_away_scheduling", C.c_uint8),
+        ("disable_gang_away_scheduling", C.c_uint8), ("disable_fairshare_scheduling", C.c_uint8),
+        ("disable_urgency_scheduling", C.c_uint8), ("pad_", C.c_uint8),
+        ("protected_fraction_of_fair_share", C.c_double),
+        ("max_queue_lookback", C.c_uint32), ("pad2_", C.c_uint32),
+        ("max_fraction_to_schedule", _f64p), ("disallowed_resource", _u8p),
+    ]
+
+
+class CNodes(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("index", _u64p), ("id_rank", _i32p), ("total", _i64p), ("allocatable", _i64p),
+        ("alloc_by_prio", _i64p), ("unschedulable", _u8p), ("over_allocated", _u8p),
+        ("taint_off", _i32p), ("taint_key", _i32p), ("taint_value", _i32p), ("taint_effect", _i32p),
+        ("label_off", _i32p), ("label_key", _i32p), ("label_value", _i32p),
+        ("node_type_override", _i64p),
+    ]
+
+
+class CReqClasses(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("tol_off", _i32p), ("tol_key", _i32p), ("tol_op", _i32p), ("tol_value", _i32p),
+        ("tol_effect", _i32p), ("sel_off", _i32p), ("sel_key", _i32p), ("sel_value", _i32p),
+    ]
+
+
+class CJobs(C.Structure):
+    _fields_ = [
+        ("m", C.c_int32), ("queue", _i32p), ("pc", _i32p), ("queue_priority", _u32p), ("submit_time", _i64p),
+        ("req", _i64p), ("req_class", _i32p), ("gang_id", _i32p), ("gang_cardinality", _i32p),
+        ("gang_uniformity_label", _i32p), ("node", _i32p), ("scheduled_at_priority", _i32p), ("run_timestamp", _i64p),
+    ]
+
+
+class CQueues(C.Structure):
+    _fields_ = [
+        ("q", C.c_int32), ("name_rank", _i32p), ("weight", _f64p), ("allocated_by_pc", _i64p), ("demand", _i64p),
+        ("short_job_penalty", _i64p), ("cordoned", _u8p), ("pc_resource_limit_fraction", _f64p),
+        ("global_tokens", C.c_double), ("global_burst", C.c_int64), ("global_rate_inf", C.c_uint8), ("pad_", C.c_uint8 * 7),
+        ("queue_tokens", _f64p), ("queue_burst", _i64p), ("queue_rate_inf", _u8p),
+        ("has_fairshare_preemption_limiter", C.c_uint8), ("pad2_", C.c_uint8 * 7),
+        ("fairshare_preemption_tokens", C.c_double),
+        ("queued_off", _i32p), ("queued_jobs", _i32p),
+    ]
+
+
+class CPodResult(C.Structure):
+    _fields_ = [("node", C.c_int32), ("scheduled_at_priority", C.c_int32), ("preempted_at_priority", C.c_int32), ("method", C.c_int32)]
+
+
+class CRoundResult(C.Structure):
+    _fields_ = [
+        ("num_scheduled", C.c_int32), ("num_preempted", C.c_int32), ("termination_reason", C.c_int32),
+        ("num_evicted_phase1", C.c_int32), ("num_evicted_phase3", C.c_int32), ("num_node_queries", C.c_int32),
+        ("num_loop_iterations", C.c_int32), ("pad_", C.c_int32),
+        ("scheduled_job", _i32p), ("scheduled_node", _i32p), ("scheduled_priority", _i32p), ("scheduled_method", _i32p),
+        ("preempted_job", _i32p), ("preempted_node", _i32p),
+        ("queue_allocated_by_pc", _i64p), ("queue_fair_share", _f64p),
+        ("queue_demand_capped_adjusted_fair_share", _f64p), ("queue_uncapped_adjusted_fair_share", _f64p),
+        ("job_unschedulable_reason", _i32p), ("global_tokens_after", C.c_double), ("queue_tokens_after", _f64p),
+    ]
+
+
+ALL_SYMBOLS = [
+    "create", "destroy", "last_error", "priorities", "nodes_upsert", "jobs_set", "txn_begin", "txn_commit",
+    "txn_abort", "select_node", "schedule_many", "bind", "evict", "unbind", "add_evicted", "reset_evicted",
+    "get_alloc", "get_scheduled_at_priority", "iterate_nodes", "fit_select_batch", "drf_cost", "fair_shares",
+    "round_prepare", "schedule_round", "schedule_queues", "gang_schedule", "round_counters", "job_key_unfeasible",
+]
+
+
+class SchedError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"asched error {code}: {msg}")
+        self.code = code
+
+
+def _arr(a, dtype):
+    if a is None:
+        return None
+    return np.ascontiguousarray(np.asarray(a, dtype=dtype))
+
+
+def _ptr(a, ctype):
+    if a is None:
+        return C.cast(None, C.POINTER(ctype))
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def _csr(lists: Sequence[Sequence[Sequence[int]]], width: int):
+    """lists[i] = list of width-tuples -> (off, [col arrays])"""
+    off = np.zeros(len(lists) + 1, dtype=np.int32)
+    cols: List[List[int]] = [[] for _ in range(width)]
+    for i, l in enumerate(lists):
+        off[i + 1] = off[i] + len(l)
+        for t in l:
+            for k in range(width):
+                cols[k].append(t[k])
+    return off, [np.asarray(c, dtype=np.int32) if len(c) else np.zeros(1, dtype=np.int32) for c in cols]
+
+
+@dataclass
+class PodResult:
+    node: int
+    scheduled_at_priority: int
+    preempted_at_priority: int
+    method: int
+
+
+@dataclass
+class RoundResult:
+    scheduled: Dict[int, int]            # job -> node
+    scheduled_priority: Dict[int, int]   # job -> nodeDb.GetScheduledAtPriority
+    scheduled_method: Dict[int, int]
+    preempted: Dict[int, int]            # job -> node it was preempted from
+    termination_reason: int
+    num_evicted_phase1: int
+    num_evicted_phase3: int
+    num_node_queries: int
+    num_loop_iterations: int
+    queue_allocated_by_pc: np.ndarray
+    fair_share: np.ndarray
+    demand_capped_adjusted_fair_share: np.ndarray
+    uncapped_adjusted_fair_share: np.ndarray
+    job_unschedulable_reason: np.ndarray
+    global_tokens_after: float
+    queue_tokens_after: np.ndarray
+
+
+class Library:
+    """A loaded implementation of the C ABI (one per .so)."""
+
+    def __init__(self, path: str, prefix: str = "asched_"):
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                f"{path} is missing: the native library must be built first "
+                f"(python -c 'import __graft_entry__ as g; g.build()'); there is no fallback path")
+        self.path, self.prefix = path, prefix
+        self.lib = C.CDLL(path)
+        f = self._fn
+        f("create", C.c_void_p, [C.POINTER(CConfig)])
+        f("destroy", None, [C.c_void_p])
+        f("last_error", C.c_char_p, [C.c_void_p])
+        f("priorities", C.c_int32, [C.c_void_p, _i32p])
+        f("nodes_upsert", C.c_int32, [C.c_void_p, C.POINTER(CNodes)])
+        f("jobs_set", C.c_int32, [C.c_void_p, C.POINTER(CJobs), C.POINTER(CReqClasses)])
+        for n in ("txn_begin", "txn_commit", "txn_abort", "reset_evicted"):
+            f(n, C.c_int32, [C.c_void_p])
+        f("select_node", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(CPodResult), _i32p, C.c_int32, _i32p])
+        f("schedule_many", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i32p, C.POINTER(CPodResult), _i32p, _i32p, C.c_int32, _i32p])
+        f("bind", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32])
+        f("evict", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32])
+        f("unbind", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32])
+        f("add_evicted", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32])
+        f("get_alloc", C.c_int32, [C.c_void_p, C.c_int32, _i64p])
+        f("get_scheduled_at_priority", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i32p])
+        f("iterate_nodes", C.c_int32, [C.c_void_p, _i64p, C.c_int32, C.c_int32, _i64p, _i32p, C.c_int32, _i32p])
+        f("fit_select_batch", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int32, _i32p])
+        f("drf_cost", C.c_double, [C.c_void_p, _i64p, _i64p])
+        f("fair_shares", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _f64p, _f64p, _f64p, _f64p, _f64p])
+        f("round_prepare", C.c_int32, [C.c_void_p, C.POINTER(CQueues)])
+        f("schedule_round", C.c_int32, [C.c_void_p, C.POINTER(CRoundResult)])
+        f("schedule_queues", C.c_int32, [C.c_void_p, C.POINTER(CRoundResult)])
+        f("gang_schedule", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i32p, _i32p, C.POINTER(CPodResult)])
+        f("round_counters", C.c_int32, [C.c_void_p, _i32p])
+        f("job_key_unfeasible", C.c_int32, [C.c_void_p, C.c_int32, _i32p])
+
+    def _fn(self, name, restype, argtypes):
+        fn = getattr(self.lib, self.prefix + name)
+        fn.restype, fn.argtypes = restype, argtypes
+        setattr(self, name, fn)
+
+    def exported(self) -> List[str]:
+        return [s for s in ALL_SYMBOLS if hasattr(self.lib, self.prefix + s)]
+
+
+@dataclass
+class Config:
+    """Hot-path subset of configuration.SchedulingConfig (see asched_config)."""
+    num_resources: int
+    indexed_col: Sequence[int]
+    indexed_resolution: Sequence[int]
+    pc_priority: Sequence[int]
+    pc_preemptible: Sequence[int]
+    drf_multiplier: Sequence[float]
+    pc_away: Optional[Sequence[Sequence[Sequence[int]]]] = None   # per pc: list of (priority, well-known-type)
+    wkt_taints: Sequence[Sequence[Sequence[int]]] = ()             # per well-known type: list of (key, value, effect)
+    indexed_taint_keys: Optional[Sequence[int]] = ()                # None = index all
+    indexed_label_keys: Sequence[int] = ()
+    prefer_large_job_ordering: bool = True
+    protect_uncapped_adjusted_fair_share: bool = False
+    disable_home_scheduling: bool = False
+    disable_away_scheduling: bool = False
+    disable_gang_away_scheduling: bool = False
+    disable_fairshare_scheduling: bool = False
+    disable_urgency_scheduling: bool = False
+    protected_fraction_of_fair_share: float = 0.0
+    max_queue_lookback: int = 0
+    max_fraction_to_schedule: Optional[Sequence[float]] = None
+    disallowed_resource: Optional[Sequence[int]] = None
+
+
+class Scheduler:
+    """One handle == one reference NodeDb + SchedulingContext pair (one pool, one round at a time)."""
+
+    def __init__(self, lib: Library, cfg: Config):
+        self.lib, self.cfg = lib, cfg
+        self._keep: List[np.ndarray] = []
+        c = CConfig()
+        k = self._k
+        c.num_resources = cfg.num_resources
+        c.num_indexed = len(cfg.indexed_col)
+        c.indexed_col = _ptr(k(cfg.indexed_col, np.int32), C.c_int32)
+        c.indexed_resolution = _ptr(k(cfg.indexed_resolution, np.int64), C.c_int64)
+        c.num_priority_classes = len(cfg.pc_priority)
+        c.pc_priority = _ptr(k(cfg.pc_priority, np.int32), C.c_int32)
+        c.pc_preemptible = _ptr(k(cfg.pc_preemptible, np.uint8), C.c_uint8)
+        if cfg.pc_away is not None:
+            off, (ap, aw) = _csr(cfg.pc_away, 2)
+            c.pc_away_off = _ptr(k(off, np.int32), C.c_int32)
+            c.away_priority = _ptr(k(ap, np.int32), C.c_int32)
+            c.away_well_known = _ptr(k(aw, np.int32), C.c_int32)
+        c.num_well_known_types = len(cfg.wkt_taints)
+        off, (tk, tv, te) = _csr(cfg.wkt_taints, 3)
+        c.wkt_taint_off = _ptr(k(off, np.int32), C.c_int32)
+        c.wkt_taint_key = _ptr(k(tk, np.int32), C.c_int32)
+        c.wkt_taint_value = _ptr(k(tv, np.int32), C.c_int32)
+        c.wkt_taint_effect = _ptr(k(te, np.int32), C.c_int32)
+        c.drf_multiplier = _ptr(k(cfg.drf_multiplier, np.float64), C.c_double)
+        if cfg.indexed_taint_keys is None:
+            c.num_indexed_taints = -1
+        else:
+            c.num_indexed_taints = len(cfg.indexed_taint_keys)
+            c.indexed_taint_keys = _ptr(k(list(cfg.indexed_taint_keys) or [0], np.int32), C.c_int32)
+        c.num_indexed_labels = len(cfg.indexed_label_keys)
+        c.indexed_label_keys = _ptr(k(list(cfg.indexed_label_keys) or [0], np.int32), C.c_int32)
+        c.prefer_large_job_ordering = int(cfg.prefer_large_job_ordering)
+        c.protect_uncapped_adjusted_fair_share = int(cfg.protect_uncapped_adjusted_fair_share)
+        c.disable_home_scheduling = int(cfg.disable_home_scheduling)
+        c.disable_away_scheduling = int(cfg.disable_away_scheduling)
+        c.disable_gang_away_scheduling = int(cfg.disable_gang_away_scheduling)
+        c.disable_fairshare_scheduling = int(cfg.disable_fairshare_scheduling)
+        c.disable_urgency_scheduling = int(cfg.disable_urgency_scheduling)
+        c.protected_fraction_of_fair_share = float(cfg.protected_fraction_of_fair_share)
+        c.max_queue_lookback = int(cfg.max_queue_lookback)
+        if cfg.max_fraction_to_schedule is not None:
+            c.max_fraction_to_schedule = _ptr(k(cfg.max_fraction_to_schedule, np.float64), C.c_double)
+        if cfg.disallowed_resource is not None:
+            c.disallowed_resource = _ptr(k(cfg.disallowed_resource, np.uint8), C.c_uint8)
+        self.h = lib.create(C.byref(c))
+        if not self.h:
+            raise SchedError(ERR_INVALID, "create failed (invalid config, or no gfx950 device for the HIP backend)")
+        pr = (C.c_int32 * MAX_PRIORITIES)()
+        self.P = lib.priorities(self.h, pr)
+        self.priorities = [pr[i] for i in range(self.P)]
+        self.R = cfg.num_resources
+        self.K = len(cfg.indexed_col)
+        self.num_nodes = 0
+        self.num_jobs = 0
+        self.num_queues = 0
+        self._keep = []
+
+    def _k(self, a, dtype):
+        arr = _arr(a, dtype)
+        self._keep.append(arr)
+        return arr
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise SchedError(rc, (self.lib.last_error(self.h) or b"").decode())
+
+    # ---------------------------------------------------------------- NodeDb level
+    def nodes_upsert(self, total, allocatable=None, *, index=None, id_rank=None, alloc_by_prio=None, unschedulable=None,
+                     over_allocated=None, taints=None, labels=None, node_type_override=None):
+        total = _arr(total, np.int64).reshape(-1, self.R)
+        n = total.shape[0]
+        allocatable = total if allocatable is None else _arr(allocatable, np.int64).reshape(n, self.R)
+        s = CNodes()
+        s.n = n
+        keep = [total, allocatable]
+        idx = _arr(np.arange(1, n + 1) if index is None else index, np.uint64)
+        rank = _arr(np.arange(n) if id_rank is None else id_rank, np.int32)
+        keep += [idx, rank]
+        s.index, s.id_rank = _ptr(idx, C.c_uint64), _ptr(rank, C.c_int32)
+        s.total, s.allocatable = _ptr(total, C.c_int64), _ptr(allocatable, C.c_int64)
+        if alloc_by_prio is not None:
+            abp = _arr(alloc_by_prio, np.int64).reshape(n, self.P, self.R)
+            keep.append(abp)
+            s.alloc_by_prio = _ptr(abp, C.c_int64)
+        for name, val in (("unschedulable", unschedulable), ("over_allocated", over_allocated)):
+            if val is not None:
+                a = _arr(val, np.uint8)
+                keep.append(a)
+                setattr(s, name, _ptr(a, C.c_uint8))
+        if taints is not None:
+            off, (tk, tv, te) = _csr(taints, 3)
+            keep += [off, tk, tv, te]
+            s.taint_off, s.taint_key, s.taint_value, s.taint_effect = (_ptr(x, C.c_int32) for x in (off, tk, tv, te))
+        if labels is not None:
+            off, (lk, lv) = _csr(labels, 2)
+            keep += [off, lk, lv]
+            s.label_off, s.label_key, s.label_value = (_ptr(x, C.c_int32) for x in (off, lk, lv))
+        if node_type_override is not None:
+            o = _arr(node_type_override, np.int64)
+            keep.append(o)
+            s.node_type_override = _ptr(o, C.c_int64)
+        self._check(self.lib.nodes_upsert(self.h, C.byref(s)))
+        self.num_nodes = n
+
+    def jobs_set(self, req, *, queue=None, pc=None, queue_priority=None, submit_time=None, req_class=None, gang_id=None,
+                 gang_cardinality=None, gang_uniformity_label=None, node=None, scheduled_at_priority=None,
+                 run_timestamp=None, class_tolerations=None, class_selectors=None):
+        req = _arr(req, np.int64).reshape(-1, self.R)
+        m = req.shape[0]
+        s = CJobs()
+        s.m = m
+        keep = [req]
+        s.req = _ptr(req, C.c_int64)
+
+        def put(name, val, dtype, ctype, default=None):
+            if val is None:
+                if default is None:
+                    return
+                val = np.full(m, default)
+            a = _arr(val, dtype)
+            assert a.shape[0] == m, name
+            keep.append(a)
+            setattr(s, name, _ptr(a, ctype))
+
+        put("queue", queue, np.int32, C.c_int32, 0)
+        put("pc", pc, np.int32, C.c_int32, 0)
+        put("queue_priority", queue_priority, np.uint32, C.c_uint32)
+        put("submit_time", np.arange(m) if submit_time is None else submit_time, np.int64, C.c_int64)
+        put("req_class", req_class, np.int32, C.c_int32)
+        put("gang_id", gang_id, np.int32, C.c_int32)
+        put("gang_cardinality", gang_cardinality, np.int32, C.c_int32)
+        put("gang_uniformity_label", gang_uniformity_label, np.int32, C.c_int32)
+        put("node", node, np.int32, C.c_int32)
+        put("scheduled_at_priority", scheduled_at_priority, np.int32, C.c_int32)
+        put("run_timestamp", run_timestamp, np.int64, C.c_int64)
+        cls = CReqClasses()
+        tols = class_tolerations if class_tolerations is not None else [[]]
+        sels = class_selectors if class_selectors is not None else [[] for _ in tols]
+        assert len(tols) == len(sels)
+        cls.n = len(tols)
+        off, (tk, to, tv, te) = _csr(tols, 4)
+        keep += [off, tk, to, tv, te]
+        cls.tol_off, cls.tol_key, cls.tol_op, cls.tol_value, cls.tol_effect = (_ptr(x, C.c_int32) for x in (off, tk, to, tv, te))
+        off2, (sk, sv) = _csr(sels, 2)
+        keep += [off2, sk, sv]
+        cls.sel_off, cls.sel_key, cls.sel_value = (_ptr(x, C.c_int32) for x in (off2, sk, sv))
+        self._check(self.lib.jobs_set(self.h, C.byref(s), C.byref(cls)))
+        self.num_jobs = m
+
+    def txn_begin(self): self._check(self.lib.txn_begin(self.h))
+    def txn_commit(self): self._check(self.lib.txn_commit(self.h))
+    def txn_abort(self): self._check(self.lib.txn_abort(self.h))
+    def reset_evicted(self): self._check(self.lib.reset_evicted(self.h))
+
+    def select_node(self, job: int, pinned_node: int = -1):
+        out = CPodResult()
+        pre = (C.c_int32 * 4096)()
+        npre = C.c_int32(0)
+        self._check(self.lib.select_node(self.h, job, pinned_node, C.byref(out), pre, 4096, C.byref(npre)))
+        return PodResult(out.node, out.scheduled_at_priority, out.preempted_at_priority, out.method), [pre[i] for i in range(npre.value)]
+
+    def schedule_many(self, jobs: Sequence[int], pinned_nodes: Optional[Sequence[int]] = None):
+        n = len(jobs)
+        ja = _arr(jobs, np.int32)
+        pa = _arr(pinned_nodes, np.int32) if pinned_nodes is not None else None
+        out = (CPodResult * max(n, 1))()
+        ok = C.c_int32(0)
+        pre = (C.c_int32 * 65536)()
+        npre = C.c_int32(0)
+        self._check(self.lib.schedule_many(self.h, n, _ptr(ja, C.c_int32), _ptr(pa, C.c_int32), out, C.byref(ok), pre, 65536, C.byref(npre)))
+        res = [PodResult(o.node, o.scheduled_at_priority, o.preempted_at_priority, o.method) for o in out[:n]]
+        return bool(ok.value), res, [pre[i] for i in range(npre.value)]
+
+    def bind(self, job, node, priority): self._check(self.lib.bind(self.h, job, node, priority))
+    def evict(self, job, node): self._check(self.lib.evict(self.h, job, node))
+    def unbind(self, job, node): self._check(self.lib.unbind(self.h, job, node))
+    def add_evicted(self, index, job, node): self._check(self.lib.add_evicted(self.h, index, job, node))
+
+    def get_alloc(self, node: int) -> np.ndarray:
+        out = np.zeros((self.P, self.R), dtype=np.int64)
+        self._check(self.lib.get_alloc(self.h, node, _ptr(out, C.c_int64)))
+        return out
+
+    def get_scheduled_at_priority(self, job: int):
+        o, ok = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.get_scheduled_at_priority(self.h, job, C.byref(o), C.byref(ok)))
+        return (o.value, bool(ok.value))
+
+    def iterate_nodes(self, priority: int, indexed_req: Sequence[int], type_ids: Optional[Sequence[int]] = None) -> List[int]:
+        cap = max(self.num_nodes, 1)
+        out = np.zeros(cap, dtype=np.int32)
+        n = C.c_int32(0)
+        req = _arr(indexed_req, np.int64)
+        t = _arr(type_ids, np.int64) if type_ids is not None else None
+        self._check(self.lib.iterate_nodes(self.h, _ptr(t, C.c_int64), -1 if t is None else len(t), priority,
+                                           _ptr(req, C.c_int64), _ptr(out, C.c_int32), cap, C.byref(n)))
+        return out[: n.value].tolist()
+
+    def fit_select_batch(self, jobs: Sequence[int], priority: int = EVICTED_PRIORITY) -> np.ndarray:
+        ja = _arr(jobs, np.int32)
+        out = np.full(len(ja), -1, dtype=np.int32)
+        self._check(self.lib.fit_select_batch(self.h, len(ja), _ptr(ja, C.c_int32), priority, _ptr(out, C.c_int32)))
+        return out
+
+    def drf_cost(self, alloc, total) -> float:
+        a, t = _arr(alloc, np.int64), _arr(total, np.int64)
+        return float(self.lib.drf_cost(self.h, _ptr(a, C.c_int64), _ptr(t, C.c_int64)))
+
+    def fair_shares(self, name_rank, weight, cds):
+        q = len(weight)
+        nr, w, c = _arr(name_rank, np.int32), _arr(weight, np.float64), _arr(cds, np.float64)
+        f, dc, uc = (np.zeros(q) for _ in range(3))
+        self._check(self.lib.fair_shares(self.h, q, _ptr(nr, C.c_int32), _ptr(w, C.c_double), _ptr(c, C.c_double),
+                                         _ptr(f, C.c_double), _ptr(dc, C.c_double), _ptr(uc, C.c_double)))
+        return f, dc, uc
+
+    # ---------------------------------------------------------------- round level
+    def round_prepare(self, weight, queued: Sequence[Sequence[int]], *, name_rank=None, allocated_by_pc=None, demand=None,
+                      short_job_penalty=None, cordoned=None, pc_resource_limit_fraction=None,
+                      global_tokens=float("inf"), global_burst=2**62, global_rate_inf=True,
+                      queue_tokens=None, queue_burst=None, queue_rate_inf=None,
+                      fairshare_preemption_tokens=None):
+        q = len(weight)
+        npc = len(self.cfg.pc_priority)
+        s = CQueues()
+        s.q = q
+        keep = []
+
+        def put(name, val, dtype, ctype, shape=None):
+            if val is None:
+                return
+            a = _arr(val, dtype)
+            if shape is not None:
+                a = np.ascontiguousarray(a.reshape(shape))
+            keep.append(a)
+            setattr(s, name, _ptr(a, ctype))
+
+        put("name_rank", np.arange(q) if name_rank is None else name_rank, np.int32, C.c_int32)
+        put("weight", weight, np.float64, C.c_double)
+        put("allocated_by_pc", allocated_by_pc, np.int64, C.c_int64, (q, npc, self.R))
+        put("demand", demand, np.int64, C.c_int64, (q, self.R))
+        put("short_job_penalty", short_job_penalty, np.int64, C.c_int64, (q, self.R))
+        put("cordoned", cordoned, np.uint8, C.c_uint8)
+        put("pc_resource_limit_fraction", pc_resource_limit_fraction, np.float64, C.c_double, (q, npc, self.R))
+        # token buckets at sctx.Started; an infinite-rate limiter always reports a full bucket
+        s.global_burst = int(global_burst)
+        s.global_rate_inf = int(global_rate_inf)
+        s.global_tokens = float(global_burst) if (global_rate_inf and global_tokens == float("inf")) else float(global_tokens)
+        qb = np.full(q, 2**62, dtype=np.int64) if queue_burst is None else _arr(queue_burst, np.int64)
+        put("queue_burst", qb, np.int64, C.c_int64)
+        put("queue_rate_inf", np.ones(q) if queue_rate_inf is None else queue_rate_inf, np.uint8, C.c_uint8)
+        put("queue_tokens", qb.astype(np.float64) if queue_tokens is None else queue_tokens, np.float64, C.c_double)
+        if fairshare_preemption_tokens is not None:
+            s.has_fairshare_preemption_limiter = 1
+            s.fairshare_preemption_tokens = float(fairshare_preemption_tokens)
+        off = np.zeros(q + 1, dtype=np.int32)
+        flat: List[int] = []
+        for i, l in enumerate(queued):
+            off[i + 1] = off[i] + len(l)
+            flat.extend(int(x) for x in l)
+        qa = np.asarray(flat if flat else [0], dtype=np.int32)
+        keep += [off, qa]
+        s.queued_off, s.queued_jobs = _ptr(off, C.c_int32), _ptr(qa, C.c_int32)
+        self._check(self.lib.round_prepare(self.h, C.byref(s)))
+        self.num_queues = q
+        self._round_keep = keep
+
+    def gang_schedule(self, jobs: Sequence[int]):
+        """GangScheduler.Schedule for one gang -> (ok, reason, [PodResult])."""
+        n = len(jobs)
+        ja = _arr(jobs, np.int32)
+        out = (CPodResult * max(n, 1))()
+        ok, reason = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.gang_schedule(self.h, n, _ptr(ja, C.c_int32), C.byref(ok), C.byref(reason), out))
+        return bool(ok.value), reason.value, [PodResult(o.node, o.scheduled_at_priority, o.preempted_at_priority, o.method) for o in out[:n]]
+
+    def round_counters(self):
+        out = (C.c_int32 * 4)()
+        self._check(self.lib.round_counters(self.h, out))
+        return dict(num_scheduled_jobs=out[0], num_scheduled_gangs=out[1], num_evicted_jobs=out[2], num_unfeasible_keys=out[3])
+
+    def job_key_unfeasible(self, job: int) -> bool:
+        o = C.c_int32(0)
+        self._check(self.lib.job_key_unfeasible(self.h, job, C.byref(o)))
+        return bool(o.value)
+
+    def schedule_queues(self) -> RoundResult:
+        return self.schedule_round(queues_only=True)
+
+    def schedule_round(self, queues_only: bool = False) -> RoundResult:
+        r = CRoundResult()
+        self._check((self.lib.schedule_queues if queues_only else self.lib.schedule_round)(self.h, C.byref(r)))
+        ns, npre = r.num_scheduled, r.num_preempted
+        npc = len(self.cfg.pc_priority)
+
+        def arr(p, n, dtype):
+            if n == 0 or not p:
+                return np.zeros(0, dtype=dtype)
+            return np.ctypeslib.as_array(p, shape=(n,)).astype(dtype, copy=True)
+
+        sj, sn = arr(r.scheduled_job, ns, np.int32), arr(r.scheduled_node, ns, np.int32)
+        sp, sm = arr(r.scheduled_priority, ns, np.int32), arr(r.scheduled_method, ns, np.int32)
+        pj, pn = arr(r.preempted_job, npre, np.int32), arr(r.preempted_node, npre, np.int32)
+        q = self.num_queues
+        return RoundResult(
+            scheduled=dict(zip(sj.tolist(), sn.tolist())),
+            scheduled_priority=dict(zip(sj.tolist(), sp.tolist())),
+            scheduled_method=dict(zip(sj.tolist(), sm.tolist())),
+            preempted=dict(zip(pj.tolist(), pn.tolist())),
+            termination_reason=r.termination_reason,
+            num_evicted_phase1=r.num_evicted_phase1, num_evicted_phase3=r.num_evicted_phase3,
+            num_node_queries=r.num_node_queries, num_loop_iterations=r.num_loop_iterations,
+            queue_allocated_by_pc=arr(r.queue_allocated_by_pc, q * npc * self.R, np.int64).reshape(q, npc, self.R),
+            fair_share=arr(r.queue_fair_share, q, np.float64),
+            demand_capped_adjusted_fair_share=arr(r.queue_demand_capped_adjusted_fair_share, q, np.float64),
+            uncapped_adjusted_fair_share=arr(r.queue_uncapped_adjusted_fair_share, q, np.float64),
+            job_unschedulable_reason=arr(r.job_unschedulable_reason, self.num_jobs, np.int32),
+            global_tokens_after=r.global_tokens_after,
+            queue_tokens_after=arr(r.queue_tokens_after, q, np.float64),
+        )

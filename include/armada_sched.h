@@ -1,0 +1,311 @@
+/*
+ * armada_sched.h — C ABI of the MI355X-native Armada scheduling-round hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI seam on this path; the
+ * seam is the Go interface `SchedulingAlgo` (internal/scheduler/scheduling/scheduling_algo.go:43-47)
+ * plus the concrete `*nodedb.NodeDb` (internal/scheduler/nodedb/nodedb.go:97-191).  Every entry
+ * point below names the reference method it replaces; a cgo shim binds them 1:1.
+ *
+ * Two libraries export this ABI:
+ *   - armada_amd/csrc/libarmada_sched.so   (prefix asched_)  HIP/gfx950 implementation — the product.
+ *   - oracle/liboracle.so                  (prefix oracle_)  CPU restatement — TEST INFRASTRUCTURE ONLY.
+ * Both are generated from this one header through ASCHED_FN(), so signatures cannot drift.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no C++/torch types.  All input buffers are borrowed for the call.
+ *   - return value: 0 = ok, <0 = error (asched_last_error() gives text).  "no feasible node" is a
+ *     normal result (node = -1), exactly like the reference's (nil, nil, nil) (nodedb.go:629).
+ *   - one thread per handle; handles are independent (NodeDb is not goroutine-safe either).
+ *   - strings never cross the boundary: queue names, node ids, label/taint keys and values are
+ *     interned by the caller into dense int32 ids; where the reference orders by string
+ *     (queue name: queue_scheduler.go:797, scheduling.go:284; node id: nodeiteration.go:184) the
+ *     caller passes the *rank* of the string in lexicographic order.
+ *   - resource vectors are int64[R] in ResourceListFactory column order
+ *     (internaltypes/resource_list_factory.go:41-52), row-major [n][R] at the boundary.
+ */
+#ifndef ARMADA_SCHED_H
+#define ARMADA_SCHED_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef ASCHED_PREFIX
+#define ASCHED_PREFIX asched_
+#endif
+#define ASCHED_CAT2(a, b) a##b
+#define ASCHED_CAT(a, b) ASCHED_CAT2(a, b)
+#define ASCHED_FN(name) ASCHED_CAT(ASCHED_PREFIX, name)
+
+#define ASCHED_MAX_RESOURCES 8
+#define ASCHED_MAX_INDEXED 6
+#define ASCHED_MAX_PRIORITIES 16
+
+/* NodeDb-internal priorities (internaltypes/node.go:17-28). */
+#define ASCHED_EVICTED_PRIORITY (-2)
+#define ASCHED_CROSS_POOL_PRIORITY (-1)
+#define ASCHED_MIN_PRIORITY ASCHED_EVICTED_PRIORITY
+
+/* error codes */
+#define ASCHED_OK 0
+#define ASCHED_ERR_INVALID (-1)      /* bad argument / inconsistent input */
+#define ASCHED_ERR_UNSUPPORTED (-2)  /* feature of the reference not implemented by this backend */
+#define ASCHED_ERR_DEVICE (-3)       /* HIP runtime failure or no gfx950 device */
+#define ASCHED_ERR_INTERNAL (-4)     /* reference would return an error here (e.g. iteration loop) */
+
+/* taint effects / toleration operators (k8s core/v1), interned */
+#define ASCHED_EFFECT_NONE 0
+#define ASCHED_EFFECT_NO_SCHEDULE 1
+#define ASCHED_EFFECT_PREFER_NO_SCHEDULE 2
+#define ASCHED_EFFECT_NO_EXECUTE 3
+#define ASCHED_TOLERATION_OP_EQUAL 0 /* also the empty operator */
+#define ASCHED_TOLERATION_OP_EXISTS 1
+
+/* context.SchedulingType (scheduling/context/pod.go:13-21) */
+#define ASCHED_METHOD_NONE 0
+#define ASCHED_METHOD_RESCHEDULED 1
+#define ASCHED_METHOD_NO_PREEMPTION 2
+#define ASCHED_METHOD_FAIRSHARE 3
+#define ASCHED_METHOD_URGENCY 4
+#define ASCHED_METHOD_AWAY 5
+
+/* unschedulable / termination reasons (scheduling/constraints/constraints.go:25-58) */
+#define ASCHED_REASON_NONE 0
+#define ASCHED_REASON_MAX_RESOURCES_SCHEDULED 1      /* terminal */
+#define ASCHED_REASON_MAX_RESOURCES_PER_QUEUE 2
+#define ASCHED_REASON_GLOBAL_RATE_LIMIT 3            /* terminal */
+#define ASCHED_REASON_QUEUE_RATE_LIMIT 4             /* queue-terminal */
+#define ASCHED_REASON_QUEUE_CORDONED 5               /* queue-terminal */
+#define ASCHED_REASON_GLOBAL_RATE_LIMIT_BY_GANG 6
+#define ASCHED_REASON_QUEUE_RATE_LIMIT_BY_GANG 7
+#define ASCHED_REASON_GANG_EXCEEDS_GLOBAL_BURST 8
+#define ASCHED_REASON_GANG_EXCEEDS_QUEUE_BURST 9
+#define ASCHED_REASON_GANG_DOES_NOT_FIT 10
+#define ASCHED_REASON_JOB_DOES_NOT_FIT 11
+#define ASCHED_REASON_RESOURCE_LIMIT_EXCEEDED 12
+#define ASCHED_REASON_UNIFORMITY_LABEL_NOT_INDEXED 13
+#define ASCHED_REASON_NO_NODES_WITH_UNIFORMITY_LABEL 14
+#define ASCHED_REASON_GANG_UNIFORMITY_NO_FIT 15      /* "at least one job in the gang does not fit on any node" */
+#define ASCHED_REASON_NO_REMAINING_CANDIDATES 16      /* sctx.TerminationReason default, queue_scheduler.go:289-291 */
+#define ASCHED_REASON_SKIPPED_UNFEASIBLE_KEY 17       /* copied from the first failed job of the key, queue_scheduler.go:398-413 */
+
+typedef struct asched asched_t;
+
+/* ---- configuration: the subset of configuration.SchedulingConfig that changes hot-path results
+ *      (internal/scheduler/configuration/configuration.go:169-350; SURVEY.md §5 "Config / flags") ---- */
+typedef struct asched_config {
+  int32_t num_resources;              /* R = len(supportedResourceTypes)+floating */
+  int32_t num_indexed;                /* K = len(indexedResources), config order (nodedb.go:204) */
+  const int32_t* indexed_col;         /* [K] column of each indexed resource */
+  const int64_t* indexed_resolution;  /* [K] nodedb.go:274-295, in factory units */
+
+  int32_t num_priority_classes;       /* types.PriorityClass (internal/common/types/scheduling.go:56-76) */
+  const int32_t* pc_priority;         /* [npc] */
+  const uint8_t* pc_preemptible;      /* [npc] */
+  const int32_t* pc_away_off;         /* [npc+1] CSR into away_* (may be NULL: no away node types) */
+  const int32_t* away_priority;       /* AwayNodeType.Priority */
+  const int32_t* away_well_known;     /* AwayNodeType.WellKnownNodeTypeName as index into wkt_* */
+  int32_t num_well_known_types;       /* configuration.WellKnownNodeType */
+  const int32_t* wkt_taint_off;       /* [nwkt+1] */
+  const int32_t* wkt_taint_key;
+  const int32_t* wkt_taint_value;     /* -1 = wildcard "*" (configuration.WildCardWellKnownNodeTypeValue) */
+  const int32_t* wkt_taint_effect;
+
+  const double* drf_multiplier;       /* [R] fairness.go:69-89 (1 for considered resources, 0 otherwise) */
+
+  int32_t num_indexed_taints;         /* -1: index all taints (node_type.go:77-86) */
+  const int32_t* indexed_taint_keys;
+  int32_t num_indexed_labels;         /* node_type.go:101-109; 0: index none */
+  const int32_t* indexed_label_keys;
+
+  uint8_t prefer_large_job_ordering;  /* EnablePreferLargeJobOrdering */
+  uint8_t protect_uncapped_adjusted_fair_share;
+  uint8_t disable_home_scheduling, disable_away_scheduling, disable_gang_away_scheduling;
+  uint8_t disable_fairshare_scheduling, disable_urgency_scheduling;
+  uint8_t pad_;
+  double protected_fraction_of_fair_share;
+  uint32_t max_queue_lookback;        /* 0 = unlimited (queue_scheduler.go:434-444) */
+  uint32_t pad2_;
+  const double* max_fraction_to_schedule; /* [R] MaximumResourceFractionToSchedule, +Inf = uncapped; NULL = all +Inf */
+  const uint8_t* disallowed_resource;     /* [R] pool ExperimentalUnscheduledResources; NULL = none */
+} asched_config;
+
+/* ---- nodes (internaltypes/node.go:32-69).  Creation order = node.index order. ---- */
+typedef struct asched_nodes {
+  int32_t n;
+  const uint64_t* index;          /* [n] node.index (unique; node_factory.go:205-207) */
+  const int32_t* id_rank;         /* [n] rank of node.id string; tie-break across node types (nodeiteration.go:184) */
+  const int64_t* total;           /* [n][R] totalResources */
+  const int64_t* allocatable;     /* [n][R] allocatableResources = initial AllocatableByPriority[p] for every p (node.go:79-85) */
+  const int64_t* alloc_by_prio;   /* optional [n][P][R] explicit AllocatableByPriority (tests: WithUsedResourcesNodes); NULL = allocatable */
+  const uint8_t* unschedulable;   /* [n] (adds the unschedulable taint, node.go:127-129) */
+  const uint8_t* over_allocated;  /* [n] scheduling_algo.go:1081 */
+  const int32_t* taint_off;       /* [n+1] CSR; may be NULL (no taints) */
+  const int32_t* taint_key; const int32_t* taint_value; const int32_t* taint_effect;
+  const int32_t* label_off;       /* [n+1] CSR; may be NULL */
+  const int32_t* label_key; const int32_t* label_value;
+  const int64_t* node_type_override; /* optional [n]: explicit node-type id (tests: WithNodeTypeNodes); <0 = derive from taints/labels */
+} asched_nodes;
+
+/* ---- static requirement classes: (tolerations, node selector) sets shared by many jobs.
+ *      class 0 must exist; a job's scheduling key (internaltypes/podutils.go:52-72) is the
+ *      equivalence class of (req class, requests, priority class) and is derived internally. ---- */
+typedef struct asched_req_classes {
+  int32_t n;
+  const int32_t* tol_off;  /* [n+1] */
+  const int32_t* tol_key;  /* -1 = empty key */
+  const int32_t* tol_op;   /* ASCHED_TOLERATION_OP_* */
+  const int32_t* tol_value;
+  const int32_t* tol_effect; /* 0 = empty (matches all effects) */
+  const int32_t* sel_off;  /* [n+1] PodRequirements.NodeSelector */
+  const int32_t* sel_key; const int32_t* sel_value;
+} asched_req_classes;
+
+/* ---- jobs: the jobdb view the round needs (jobdb/job.go accessors used on the path).
+ *      Job ids are their index in this table; index order is the id-string order used as the
+ *      final tie-break of SchedulingOrderCompare (jobdb/comparison.go:99-105). ---- */
+typedef struct asched_jobs {
+  int32_t m;
+  const int32_t* queue;            /* [m] queue index */
+  const int32_t* pc;               /* [m] priority class index */
+  const uint32_t* queue_priority;  /* [m] per-queue job priority (comparison.go:74-79) */
+  const int64_t* submit_time;      /* [m] comparison.go:92-97 */
+  const int64_t* req;              /* [m][R] KubernetesResourceRequirements == AllResourceRequirements (no floating) */
+  const int32_t* req_class;        /* [m] index into asched_req_classes */
+  const int32_t* gang_id;          /* [m] -1 = not in a gang; ids are unique per (queue, gang) */
+  const int32_t* gang_cardinality; /* [m] */
+  const int32_t* gang_uniformity_label; /* [m] interned label key, -1 = none */
+  const int32_t* node;             /* [m] node (position in asched_nodes) of the active run, -1 = queued */
+  const int32_t* scheduled_at_priority; /* [m] run.ScheduledAtPriority for running jobs */
+  const int64_t* run_timestamp;    /* [m] activeRunTimestamp (comparison.go:83-89) */
+} asched_jobs;
+
+/* ---- per-queue round inputs (context.AddQueueSchedulingContext, scheduling/context/scheduling.go:114-166) ---- */
+typedef struct asched_queues {
+  int32_t q;
+  const int32_t* name_rank;        /* [q] rank of the queue name */
+  const double* weight;            /* [q] 1/priorityFactor (scheduling_algo.go:811-823) */
+  const int64_t* allocated_by_pc;  /* [q][npc][R] initialAllocatedByPriorityClass; NULL = derive from running jobs */
+  const int64_t* demand;           /* [q][R] constrainedDemand (and demand); NULL = derive (queued + running requests) */
+  const int64_t* short_job_penalty;/* [q][R] NULL = zero */
+  const uint8_t* cordoned;         /* [q] NULL = none */
+  const double* pc_resource_limit_fraction; /* [q][npc][R] per-queue per-PC MaximumResourceFraction (+Inf = none); NULL = none */
+  /* token buckets evaluated at the fixed instant sctx.Started (constraints.go:136-157):
+     tokens = limiter.TokensAt(Started); rate_inf = limiter has rate +Inf (ReserveN is a no-op) */
+  double global_tokens; int64_t global_burst; uint8_t global_rate_inf; uint8_t pad_[7];
+  const double* queue_tokens;      /* [q] */
+  const int64_t* queue_burst;      /* [q] */
+  const uint8_t* queue_rate_inf;   /* [q] */
+  uint8_t has_fairshare_preemption_limiter; uint8_t pad2_[7];
+  double fairshare_preemption_tokens;
+  /* per-queue queued jobs in SchedulingOrderCompare order (jobdb.QueuedJobs iterator, jobiteration.go:138-176) */
+  const int32_t* queued_off;       /* [q+1] */
+  const int32_t* queued_jobs;      /* job indices */
+} asched_queues;
+
+/* ---- per-job outcome of a node selection (context.PodSchedulingContext, scheduling/context/pod.go:37-58) ---- */
+typedef struct asched_pod_result {
+  int32_t node;                 /* -1 = none */
+  int32_t scheduled_at_priority;
+  int32_t preempted_at_priority;
+  int32_t method;               /* ASCHED_METHOD_* */
+} asched_pod_result;
+
+/* ---- result of a round (scheduling.SchedulingResult, scheduling/result.go:96-107) ---- */
+typedef struct asched_round_result {
+  int32_t num_scheduled;        /* len(ScheduledJobs) */
+  int32_t num_preempted;        /* len(PreemptedJobs) */
+  int32_t termination_reason;   /* sctx.TerminationReason of the first schedule() pass */
+  int32_t num_evicted_phase1;
+  int32_t num_evicted_phase3;
+  int32_t num_node_queries;     /* selectNodeForPodAtPriority-equivalents issued (roofline accounting) */
+  int32_t num_loop_iterations;  /* QueueScheduler loop iterations over both passes */
+  int32_t pad_;
+  const int32_t* scheduled_job;       /* [num_scheduled] job ids, ascending */
+  const int32_t* scheduled_node;      /* [num_scheduled] jctx.PodSchedulingContext.NodeId */
+  const int32_t* scheduled_priority;  /* [num_scheduled] nodeDb.GetScheduledAtPriority */
+  const int32_t* scheduled_method;
+  const int32_t* preempted_job;       /* [num_preempted] ascending */
+  const int32_t* preempted_node;      /* jctx.AssignedNode */
+  const int64_t* queue_allocated_by_pc; /* [q][npc][R] qctx.AllocatedByPriorityClass after the round */
+  const double* queue_fair_share;       /* [q] */
+  const double* queue_demand_capped_adjusted_fair_share; /* [q] */
+  const double* queue_uncapped_adjusted_fair_share;      /* [q] */
+  const int32_t* job_unschedulable_reason; /* [m] ASCHED_REASON_* for jobs attempted and failed (0 otherwise) */
+  double global_tokens_after;
+  const double* queue_tokens_after;   /* [q] */
+} asched_round_result;
+
+/* ------------------------------------------------------------------ lifecycle */
+asched_t* ASCHED_FN(create)(const asched_config* cfg);            /* nodedb.NewNodeDb (nodedb.go:193) + ConfigureScheduling (:386) */
+void ASCHED_FN(destroy)(asched_t*);
+const char* ASCHED_FN(last_error)(asched_t*);
+/* nodedb priorities: [-2,-1]+sorted-unique(PC ∪ away priorities) (nodedb.go:201-202). Returns P. */
+int32_t ASCHED_FN(priorities)(asched_t*, int32_t* out /*[ASCHED_MAX_PRIORITIES]*/);
+
+/* ------------------------------------------------------------------ NodeDb level */
+/* CreateAndInsert / UpsertMany (nodedb.go:57-75,1135-1175). Replaces all nodes. */
+int32_t ASCHED_FN(nodes_upsert)(asched_t*, const asched_nodes* nodes);
+/* registers the job + requirement tables referenced by job id in the calls below */
+int32_t ASCHED_FN(jobs_set)(asched_t*, const asched_jobs* jobs, const asched_req_classes* classes);
+
+int32_t ASCHED_FN(txn_begin)(asched_t*);    /* nodeDb.Txn(true) (nodedb.go:353) */
+int32_t ASCHED_FN(txn_commit)(asched_t*);
+int32_t ASCHED_FN(txn_abort)(asched_t*);
+
+/* SelectNodeForJobWithTxn (nodedb.go:538-630). pinned_node>=0 == jctx.AssignedNode set (evicted job). */
+int32_t ASCHED_FN(select_node)(asched_t*, int32_t job, int32_t pinned_node, asched_pod_result* out,
+                               int32_t* preempted /*cap*/, int32_t preempted_cap, int32_t* num_preempted);
+/* ScheduleManyWithTxn (nodedb.go:417-462): select+bind each member inside the caller's txn. ok=0 => caller aborts. */
+int32_t ASCHED_FN(schedule_many)(asched_t*, int32_t n, const int32_t* jobs, const int32_t* pinned_nodes /*NULL*/,
+                                 asched_pod_result* out /*[n]*/, int32_t* ok,
+                                 int32_t* preempted, int32_t preempted_cap, int32_t* num_preempted);
+/* BindJobToNode+Upsert (nodedb.go:1046-1068), EvictJobsFromNode (:1079), UnbindJobFromNode (:1108) */
+int32_t ASCHED_FN(bind)(asched_t*, int32_t job, int32_t node, int32_t priority);
+int32_t ASCHED_FN(evict)(asched_t*, int32_t job, int32_t node);
+int32_t ASCHED_FN(unbind)(asched_t*, int32_t job, int32_t node);
+/* AddEvictedJobSchedulingContextWithTxn (nodedb.go:1209) / Reset (:299) */
+int32_t ASCHED_FN(add_evicted)(asched_t*, int32_t index, int32_t job, int32_t node);
+int32_t ASCHED_FN(reset_evicted)(asched_t*);
+/* node.AllocatableByPriority, [P][R] */
+int32_t ASCHED_FN(get_alloc)(asched_t*, int32_t node, int64_t* out);
+int32_t ASCHED_FN(get_scheduled_at_priority)(asched_t*, int32_t job, int32_t* out, int32_t* ok); /* nodedb.go:315 */
+/* NodeTypesIterator order (nodeiteration.go:74-149) for req at a priority over node types `types`
+   (ntypes<0: all types).  Test hook for the golden orderings of nodeiteration_test.go. */
+int32_t ASCHED_FN(iterate_nodes)(asched_t*, const int64_t* type_ids, int32_t ntypes, int32_t priority,
+                                 const int64_t* indexed_req /*[K]*/, int32_t* out_nodes, int32_t cap, int32_t* n_out);
+/* First feasible node per job at `priority` against the CURRENT state, no binding: n independent
+   selectNodeForPodAtPriority calls (nodedb.go:840-879) — BASELINE config 2 ("nodedb fit kernel"). */
+int32_t ASCHED_FN(fit_select_batch)(asched_t*, int32_t n, const int32_t* jobs, int32_t priority, int32_t* out_node);
+
+/* ------------------------------------------------------------------ float helpers (goldens) */
+/* DominantResourceFairness.UnweightedCostFromAllocation (fairness/fairness.go:103-105) */
+double ASCHED_FN(drf_cost)(asched_t*, const int64_t* alloc /*[R]*/, const int64_t* total /*[R]*/);
+/* SchedulingContext.updateFairShares (context/scheduling.go:262-342). cds = constrainedDemandShare per queue. */
+int32_t ASCHED_FN(fair_shares)(asched_t*, int32_t q, const int32_t* name_rank, const double* weight, const double* cds,
+                               double* fair_share, double* demand_capped, double* uncapped);
+
+/* ------------------------------------------------------------------ round level */
+/* Builds round state: ConstructNodeDb/populateNodeDb (bind every running job, scheduling_algo.go:738-781,
+   1019-1098) + constructSchedulingContext + UpdateFairShares (:783-867).  Untimed "input build". */
+int32_t ASCHED_FN(round_prepare)(asched_t*, const asched_queues* queues);
+/* PreemptingQueueScheduler.Schedule (preempting_queue_scheduler.go:86-289) — what the metric times.
+   Result buffers are owned by the handle until the next round_prepare/destroy. */
+int32_t ASCHED_FN(schedule_round)(asched_t*, asched_round_result* out);
+
+/* QueueScheduler.Schedule (queue_scheduler.go:94-304) over the queued jobs only — no eviction phases; the entry the
+   reference's queue_scheduler_test.go drives.  `preempted_*` lists the fair-share victims (sctx.PreemptedJobIds). */
+int32_t ASCHED_FN(schedule_queues)(asched_t*, asched_round_result* out);
+/* GangScheduler.Schedule (gang_scheduler.go:100-148) for one gang of queued jobs against the current round state. */
+int32_t ASCHED_FN(gang_schedule)(asched_t*, int32_t n, const int32_t* jobs, int32_t* ok, int32_t* reason, asched_pod_result* out /*[n]*/);
+/* sctx counters: out = {NumScheduledJobs, NumScheduledGangs, NumEvictedJobs, len(UnfeasibleSchedulingKeys)} (context/scheduling.go:55-69) */
+int32_t ASCHED_FN(round_counters)(asched_t*, int32_t* out /*[4]*/);
+/* 1 if the job's scheduling key is registered in sctx.UnfeasibleSchedulingKeys (gang_scheduler.go:80-95) */
+int32_t ASCHED_FN(job_key_unfeasible)(asched_t*, int32_t job, int32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARMADA_SCHED_H */
