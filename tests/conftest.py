@@ -1,0 +1,40 @@
+"""pytest configuration.
+
+`-m "not gpu"` (runs in the build container, no GPU): the CPU oracle against the reference's golden
+vectors, host logic, and that the HIP library loads and exports every symbol of include/armada_sched.h.
+`-m gpu` (runs on the MI355X box): parity of the HIP path against the oracle and the goldens, through the C ABI.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _oracle_path():
+    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    return path
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    """The CPU oracle (test infrastructure only)."""
+    from armada_amd.binding import Library
+    return Library(_oracle_path(), "oracle_")
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """The product: the HIP implementation.  No fallback — missing library is a hard failure."""
+    import armada_amd
+    return armada_amd.load_library()

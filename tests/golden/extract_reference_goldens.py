@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json from the reference's own table-driven tests.
+
+Runs ONLY in the build container (it reads /root/reference, which does not exist on the GPU box);
+the JSON it writes is committed, and both the CPU-oracle tests and the `-m gpu` parity tests consume
+the JSON.  Every emitted case carries the reference file:line it was transcribed from.
+
+    python tests/golden/extract_reference_goldens.py
+
+Cases that use Go constructs outside goparse's subset (closures, node affinity, floating resources,
+market pricing, cross-pool "away" jobs) are skipped and listed in tests/golden/SKIPPED.txt.
+"""
+import json
+import math
+import os
+import re
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import gofixtures  # noqa: E402
+from goparse import Evaluator, Parser, Struct, Unsupported, find_matching, split_table_cases, tokenize  # noqa: E402
+
+REF = "/root/reference/internal/scheduler"
+
+
+def to_json(v):
+    if isinstance(v, Struct):
+        d = {k: to_json(x) for k, x in v.items()}
+        d["__type__"] = v.type
+        return d
+    if isinstance(v, dict):
+        return {str(k): to_json(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [to_json(x) for x in v]
+    if isinstance(v, float) and math.isinf(v):
+        return "inf" if v > 0 else "-inf"
+    return v
+
+
+def extract_table(path, func_name, env, skipped, table_var="tests"):
+    src = open(path).read()
+    fpos = src.index(f"func {func_name}(")
+    m = re.compile(table_var + r"\s*:=\s*map\[string\]struct\s*\{").search(src, fpos)
+    struct_open = m.end() - 1
+    struct_close = find_matching(src, struct_open)
+    body_open = src.index("{", struct_close + 1)
+    body_close = find_matching(src, body_open)
+
+    def line_of(pos):
+        return src.count("\n", 0, pos) + 1
+
+    cases = split_table_cases(src, body_open + 1, body_close, line_of)
+    out = []
+    rel = os.path.relpath(path, "/root/reference")
+    ev = Evaluator(env)
+    for name, lit, line in cases:
+        try:
+            p = Parser(tokenize(lit, line))
+            ast = p.parse_expr()
+            # evaluate with an anonymous struct type
+            val = ev.comp(("named", "__case__"), ast[2])
+            out.append({"name": name, "source": f"{rel}:{line}", **to_json(val)})
+        except Unsupported as e:
+            skipped.append(f"{rel}:{line} {func_name}/{name}: {e}")
+        except RecursionError:
+            skipped.append(f"{rel}:{line} {func_name}/{name}: recursion")
+    return out
+
+
+def main():
+    env = gofixtures.make_env()
+    skipped = []
+    out = {}
+    out["pqs"] = extract_table(f"{REF}/scheduling/preempting_queue_scheduler_test.go", "TestPreemptingQueueScheduler", env, skipped)
+    out["queue_scheduler"] = extract_table(f"{REF}/scheduling/queue_scheduler_test.go", "TestQueueScheduler", env, skipped)
+    out["gang_scheduler"] = extract_table(f"{REF}/scheduling/gang_scheduler_test.go", "TestGangScheduler", env, skipped)
+
+    # float goldens: fairness_test.go:62-177 and context/scheduling_test.go:89-247
+    fenv = dict(env)
+    fenv["rlFactory"] = None
+    fenv["fooBarBaz"] = lambda _f, a, b, c: {"foo": int(round(gofixtures.quantity(a) * 1000)), "bar": int(round(gofixtures.quantity(b) * 1000)),
+                                             "baz": int(round(gofixtures.quantity(c) * 1000))}
+    fenv["poolName"] = "pool"
+    out["fairness"] = extract_table(f"{REF}/scheduling/fairness/fairness_test.go", "TestDominantResourceFairness", fenv, skipped)
+    senv = dict(env)
+    for nm, v in (("zeroCpu", 0), ("oneCpu", 1), ("fortyCpu", 40), ("oneHundredCpu", 100), ("oneThousandCpu", 1000)):
+        senv[nm] = {"cpu": v * 1000}
+    out["fair_shares"] = extract_table(f"{REF}/scheduling/context/scheduling_test.go", "TestCalculateFairShares", senv, skipped)
+
+    # node iteration orderings: nodedb/nodeiteration_test.go:75-374 (one type) and :376-695 (merged types)
+    nenv = dict(env)
+    for nm, tid in (("nodeTypeA", 1), ("nodeTypeB", 2), ("nodeTypeC", 3), ("nodeTypeD", 4)):
+        nenv[nm] = tid
+        nenv[nm + ".GetId"] = (lambda t: (lambda: t))(tid)
+
+    def with_node_type(tid, nodes):
+        for n in nodes:
+            n["node_type"] = tid
+        return nodes
+    nenv["testfixtures.WithNodeTypeNodes"] = with_node_type
+    nenv["testfixtures.TestResourceListFactory.MakeAllZero"] = lambda: {}
+    out["node_type_iterator"] = extract_table(f"{REF}/nodedb/nodeiteration_test.go", "TestNodeTypeIterator", nenv, skipped)
+    out["node_types_iterator"] = extract_table(f"{REF}/nodedb/nodeiteration_test.go", "TestNodeTypesIterator", nenv, skipped)
+
+    for k, v in out.items():
+        path = os.path.join(HERE, f"{k}_cases.json")
+        with open(path, "w") as f:
+            json.dump(v, f, indent=1, sort_keys=True)
+        print(f"{k}: {len(v)} cases -> {os.path.relpath(path)}")
+    with open(os.path.join(HERE, "SKIPPED.txt"), "w") as f:
+        f.write("\n".join(skipped) + "\n")
+    print(f"skipped {len(skipped)} cases (see tests/golden/SKIPPED.txt)")
+
+
+if __name__ == "__main__":
+    main()

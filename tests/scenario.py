@@ -1,0 +1,474 @@
+"""Replays the reference's table-driven test cases (tests/golden/*.json, transcribed by
+tests/golden/extract_reference_goldens.py) through the C ABI.
+
+The same driver runs against the CPU oracle (`-m "not gpu"`) and against the HIP library (`-m gpu`),
+mirroring the Go test drivers it cites:
+  run_pqs_case   <- is/scheduling/preempting_queue_scheduler_test.go:2216-2550
+  run_qs_case    <- is/scheduling/queue_scheduler_test.go:479-600
+  run_gang_case  <- is/scheduling/gang_scheduler_test.go:560-729
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List
+
+import numpy as np
+
+from armada_amd.binding import Config, Library, Scheduler
+
+RES = ["memory", "cpu", "nvidia.com/gpu", "test-floating-resource"]  # TestResourceListFactory column order
+R = len(RES)
+EFFECTS = {"": 0, "NoSchedule": 1, "PreferNoSchedule": 2, "NoExecute": 3}
+UNSCHEDULABLE_TAINT = ["node.kubernetes.io/unschedulable", "", "NoSchedule"]
+
+
+def inf(v):
+    if v == "inf":
+        return math.inf
+    if v == "-inf":
+        return -math.inf
+    return v
+
+
+class Interner:
+    def __init__(self):
+        self.d: Dict[str, int] = {}
+
+    def __call__(self, s: str) -> int:
+        if s not in self.d:
+            self.d[s] = len(self.d)
+        return self.d[s]
+
+
+def vec(d: dict) -> List[int]:
+    return [int(d.get(r, 0)) for r in RES]
+
+
+class Case:
+    """Holds the interning tables and the Scheduler for one golden case."""
+
+    def __init__(self, lib: Library, cfg: dict, nodes: List[dict], pool_limit_key: str = "pool"):
+        self.lib = lib
+        self.cfgj = cfg
+        self.S = Interner()
+        self.pc_names = sorted(cfg["priority_classes"])
+        self.pc_index = {n: i for i, n in enumerate(self.pc_names)}
+        pcs = cfg["priority_classes"]
+        wkt_names = sorted(cfg["well_known_node_types"])
+        wkt_index = {n: i for i, n in enumerate(wkt_names)}
+        pc_away = []
+        for n in self.pc_names:
+            pc_away.append([(pr, wkt_index[w]) for pr, w in pcs[n].get("away", [])])
+        wkt_taints = [[(self.S(k), -1 if v == "*" else self.S(v), EFFECTS[e]) for k, v, e in cfg["well_known_node_types"][n]] for n in wkt_names]
+        frac = dict(cfg.get("maximum_resource_fraction_to_schedule") or {})
+        bypool = cfg.get("maximum_resource_fraction_to_schedule_by_pool") or {}
+        if pool_limit_key in bypool:
+            frac = dict(bypool[pool_limit_key])
+        self.config = Config(
+            num_resources=R,
+            indexed_col=[RES.index(n) for n, _ in cfg["indexed_resources"]],
+            indexed_resolution=[r for _, r in cfg["indexed_resources"]],
+            pc_priority=[pcs[n]["priority"] for n in self.pc_names],
+            pc_preemptible=[int(pcs[n]["preemptible"]) for n in self.pc_names],
+            drf_multiplier=[1.0 if r in cfg["drf_resources"] else 0.0 for r in RES],
+            pc_away=pc_away,
+            wkt_taints=wkt_taints,
+            indexed_taint_keys=[self.S(k) for k in cfg["indexed_taints"]],
+            indexed_label_keys=[self.S(k) for k in cfg["indexed_node_labels"]],
+            prefer_large_job_ordering=cfg["prefer_large_job_ordering"],
+            disable_home_scheduling=cfg["disable_home"], disable_away_scheduling=cfg["disable_away"],
+            disable_gang_away_scheduling=cfg["disable_gang_away"], disable_fairshare_scheduling=cfg["disable_fairshare"],
+            disable_urgency_scheduling=cfg["disable_urgency"],
+            protected_fraction_of_fair_share=cfg["protected_fraction_of_fair_share"],
+            max_queue_lookback=cfg["max_queue_lookback"],
+            max_fraction_to_schedule=[float(inf(frac.get(r, "inf"))) for r in RES],
+        )
+        self.sched = Scheduler(lib, self.config)
+        self.nodes = nodes
+        self.upsert_nodes(set())
+
+    def upsert_nodes(self, cordoned):
+        s = self.sched
+        P = s.P
+        total = np.array([vec(n["total"]) for n in self.nodes], dtype=np.int64).reshape(len(self.nodes), R)
+        abp = np.repeat(total[:, None, :], P, axis=1)
+        for i, n in enumerate(self.nodes):
+            for p_str, used in (n.get("used") or {}).items():
+                p = int(p_str)
+                for l, prio in enumerate(s.priorities):
+                    if prio <= p:  # MarkAllocated(allocatableByPriority, p, rl): internaltypes/node.go:535-549
+                        abp[i, l, :] -= np.array(vec(used), dtype=np.int64)
+        taints, labels = [], []
+        for i, n in enumerate(self.nodes):
+            ts = [list(t) for t in n["taints"]]
+            if i in cordoned:
+                ts.append(UNSCHEDULABLE_TAINT)
+            taints.append([(self.S(k), self.S(v), EFFECTS[e]) for k, v, e in ts])
+            labels.append([(self.S(k), self.S(v)) for k, v in sorted(n["labels"].items())])
+        s.nodes_upsert(total, total, index=[n["index"] for n in self.nodes], alloc_by_prio=abp, taints=taints, labels=labels)
+
+    # ---- jobs
+    def set_jobs(self, jobs: List[dict], queue_index: Dict[str, int], running: Dict[int, tuple]):
+        """jobs: list of job dicts (golden format); running: local idx -> (node, prio, run_ts)"""
+        classes: Dict[tuple, int] = {}
+        cls_tol, cls_sel = [], []
+        req_class, gang_id, gang_card, gang_uni = [], [], [], []
+        gangs: Dict[tuple, int] = {}
+        for j in jobs:
+            tol = tuple((-1 if t["key"] == "" else self.S(t["key"]), 1 if t["op"] == "Exists" else 0, self.S(t["value"]), EFFECTS[t["effect"]]) for t in j["tolerations"])
+            sel = tuple(sorted((self.S(k), self.S(v)) for k, v in j["selector"].items()))
+            key = (tol, sel)
+            if key not in classes:
+                classes[key] = len(classes)
+                cls_tol.append(list(tol))
+                cls_sel.append(list(sel))
+            req_class.append(classes[key])
+            g = j.get("gang")
+            if g:
+                gk = (j["queue"], g["id"])
+                if gk not in gangs:
+                    gangs[gk] = len(gangs)
+                gang_id.append(gangs[gk])
+                gang_card.append(g["cardinality"])
+                gang_uni.append(self.S(g["uniformity"]) if g["uniformity"] else -1)
+            else:
+                gang_id.append(-1); gang_card.append(1); gang_uni.append(-1)
+        if not classes:
+            cls_tol, cls_sel = [[]], [[]]
+        m = len(jobs)
+        node = [running[i][0] if i in running else -1 for i in range(m)]
+        sap = [running[i][1] if i in running else 0 for i in range(m)]
+        rts = [running[i][2] if i in running else 0 for i in range(m)]
+        self.sched.jobs_set(
+            np.array([vec(j["req"]) for j in jobs], dtype=np.int64).reshape(m, R),
+            queue=[queue_index.get(j["queue"], -1) for j in jobs],
+            pc=[self.pc_index[j["pc"]] for j in jobs],
+            queue_priority=[j["priority"] for j in jobs],
+            submit_time=[j["created"] for j in jobs],
+            req_class=req_class, gang_id=gang_id, gang_cardinality=gang_card, gang_uniformity_label=gang_uni,
+            node=node, scheduled_at_priority=sap, run_timestamp=rts,
+            class_tolerations=cls_tol, class_selectors=cls_sel)
+
+    def sort_queued(self, jobs: List[dict], idxs: List[int]) -> List[int]:
+        """SchedulingOrderCompare for queued (non-active) jobs: jobdb/comparison.go:49-107"""
+        pcs = self.cfgj["priority_classes"]
+        return sorted(idxs, key=lambda i: (-pcs[jobs[i]["pc"]]["priority"], jobs[i]["priority"], jobs[i]["created"], i))
+
+    def pc_limits(self, queues: List[str], queue_cfgs=None, pool="pool"):
+        """calculatePerQueueLimits (constraints.go:218-256): PC defaults, overridden per queue and per (queue, pool)."""
+        pcs = self.cfgj["priority_classes"]
+        out = np.full((len(queues), len(self.pc_names), R), math.inf)
+        any_limit = False
+        for pi, n in enumerate(self.pc_names):
+            for r, f in (pcs[n].get("max_fraction_per_queue") or {}).items():
+                out[:, pi, RES.index(r)] = float(inf(f)); any_limit = True
+        for qi, qc in enumerate(queue_cfgs or []):
+            for pc, lim in (qc.get("ResourceLimitsByPriorityClassName") or {}).items():
+                pi = self.pc_index[pc]
+                for r, f in (lim.get("MaximumResourceFraction") or {}).items():
+                    out[qi, pi, RES.index(r)] = float(inf(f)); any_limit = True
+                bypool = (lim.get("MaximumResourceFractionByPool") or {}).get(pool)
+                if bypool:
+                    for r, f in (bypool.get("MaximumResourceFraction") or {}).items():
+                        out[qi, pi, RES.index(r)] = float(inf(f)); any_limit = True
+        return out if any_limit else None
+
+    def no_oversubscription(self):
+        s = self.sched
+        for n in range(len(self.nodes)):
+            a = s.get_alloc(n)
+            for l, p in enumerate(s.priorities):
+                if p >= 0:
+                    assert (a[l] >= 0).all(), f"node {n} oversubscribed at priority {p}: {a[l]}"
+
+
+def uses_unsupported(case: dict, jobs: List[dict]) -> str:
+    pcs = case["SchedulingConfig"]["priority_classes"]
+    for j in jobs:
+        if pcs[j["pc"]].get("away_conditional"):
+            return "conditional away node types"
+        if j.get("affinity"):
+            return "node affinity"
+        if "test-floating-resource" in j["req"]:
+            return "floating resources"
+    return ""
+
+
+class Tokens:
+    """golang.org/x/time/rate limiter state as seen at sctx.Started of each round (new limiter starts full)."""
+
+    def __init__(self, rate, burst):
+        self.rate, self.burst = float(inf(rate)), int(burst)
+        self.tokens = float(self.burst)
+
+    @property
+    def rate_inf(self):
+        return math.isinf(self.rate)
+
+    def advance(self, seconds):
+        if not self.rate_inf:
+            self.tokens = min(float(self.burst), self.tokens + self.rate * seconds)
+
+
+def run_pqs_case(lib: Library, case: dict):
+    cfg = case["SchedulingConfig"]
+    nodes = case["Nodes"]
+    all_jobs = [j for r in case["Rounds"] for js in (r.get("JobsByQueue") or {}).values() for j in js]
+    all_jobs += [j for js in (case.get("InitialRunningJobs") or {}).values() for j in js]
+    why = uses_unsupported(case, all_jobs)
+    if why:
+        return "skip: " + why
+    c = Case(lib, cfg, nodes)
+    s = c.sched
+    queues = sorted(case["PriorityFactorByQueue"])
+    qidx = {q: i for i, q in enumerate(queues)}
+    Q = len(queues)
+    npc = len(c.pc_names)
+    weight = [1.0 / case["PriorityFactorByQueue"][q] for q in queues]
+    glim = Tokens(cfg["maximum_scheduling_rate"], cfg["maximum_scheduling_burst"])
+    qlim = [Tokens(cfg["maximum_per_queue_scheduling_rate"], cfg["maximum_per_queue_scheduling_burst"]) for _ in queues]
+    pcs = cfg["priority_classes"]
+
+    live: List[dict] = []  # jobs in the jobDb (running ones carry 'run')
+    run_counter = 0
+    for node_idx in sorted(case.get("InitialRunningJobs") or {}, key=int):
+        for j in case["InitialRunningJobs"][node_idx]:
+            run_counter += 1
+            j = dict(j); j["run"] = (int(node_idx), pcs[j["pc"]]["priority"], run_counter); j["round"] = -1; j["idx"] = -1
+            live.append(j)
+    allocated = np.zeros((Q, npc, R), dtype=np.int64)  # allocatedByQueueAndPriorityClass (test accounting)
+    demand = np.zeros((Q, R), dtype=np.int64)
+    node_by_job: Dict[int, int] = {}
+    cordoned = set()
+    for ri, rnd in enumerate(case["Rounds"]):
+        assert not rnd.get("IndicesToUnbind"), "IndicesToUnbind not supported by the driver"
+        for idx in rnd.get("NodeIndicesToCordon") or []:
+            cordoned.add(int(idx))
+        c.upsert_nodes(cordoned)
+        queued_now = []
+        for q, js in (rnd.get("JobsByQueue") or {}).items():
+            for k, j in enumerate(js):
+                j = dict(j); j["round"] = ri; j["idx"] = k
+                queued_now.append(j)
+                demand[qidx[q]] += np.array(vec(j["req"]), dtype=np.int64)
+        jobs = live + queued_now
+        running = {i: j["run"] for i, j in enumerate(jobs) if "run" in j}
+        c.set_jobs(jobs, qidx, running)
+        queued = [c.sort_queued(jobs, [i for i, j in enumerate(jobs) if "run" not in j and j["queue"] == q]) for q in queues]
+        s.round_prepare(weight, queued, name_rank=list(range(Q)), allocated_by_pc=allocated, demand=demand,
+                        pc_resource_limit_fraction=c.pc_limits(queues),
+                        global_tokens=glim.tokens, global_burst=glim.burst, global_rate_inf=glim.rate_inf,
+                        queue_tokens=[t.tokens for t in qlim], queue_burst=[t.burst for t in qlim], queue_rate_inf=[t.rate_inf for t in qlim])
+        res = s.schedule_round()
+        glim.tokens = res.global_tokens_after
+        for t, v in zip(qlim, res.queue_tokens_after):
+            t.tokens = float(v)
+        glim.advance(1.0)
+        for t in qlim:
+            t.advance(1.0)
+        # resource accounting (pqs_test.go:2387-2411)
+        for job in res.preempted:
+            j = jobs[job]
+            allocated[qidx[j["queue"]], c.pc_index[j["pc"]]] -= np.array(vec(j["req"]), dtype=np.int64)
+        for job in res.scheduled:
+            j = jobs[job]
+            allocated[qidx[j["queue"]], c.pc_index[j["pc"]]] += np.array(vec(j["req"]), dtype=np.int64)
+        assert (allocated == res.queue_allocated_by_pc).all(), f"round {ri}: queue accounting differs"
+        # node mapping checks (:2413-2447)
+        for job, node in res.preempted.items():
+            assert "run" in jobs[job] and jobs[job]["run"][0] == node, f"round {ri}: job preempted from unexpected node"
+        for job, node in res.scheduled.items():
+            assert node >= 0
+            key = id(jobs[job].get("_ident", None)) if False else (jobs[job]["round"], jobs[job]["queue"], jobs[job]["idx"])
+            if key in node_by_job:
+                assert node_by_job[key] == node, f"round {ri}: job moved between nodes"
+            node_by_job[key] = node
+        # expected scheduled (:2449-2464)
+        exp_s = rnd.get("ExpectedScheduledIndices") or {}
+        got_s: Dict[str, List[int]] = {}
+        for job in res.scheduled:
+            got_s.setdefault(jobs[job]["queue"], []).append(jobs[job]["idx"])
+        for q in set(exp_s) | set(got_s):
+            assert sorted(exp_s.get(q) or []) == sorted(got_s.get(q, [])), \
+                f"round {ri}: scheduling from queue {q}: expected {sorted(exp_s.get(q) or [])} got {sorted(got_s.get(q, []))}"
+        # expected preempted (:2466-2487)
+        exp_p = rnd.get("ExpectedPreemptedIndices") or {}
+        got_p: Dict[str, Dict[int, List[int]]] = {}
+        for job in res.preempted:
+            got_p.setdefault(jobs[job]["queue"], {}).setdefault(jobs[job]["round"], []).append(jobs[job]["idx"])
+        for q in set(exp_p) | set(got_p):
+            e = {int(k): sorted(v) for k, v in (exp_p.get(q) or {}).items()}
+            g = {k: sorted(v) for k, v in got_p.get(q, {}).items()}
+            assert e == g, f"round {ri}: preempting from queue {q}: expected {e} got {g}"
+        c.no_oversubscription()
+        # jobDb update (:2499-2547): queued jobs deleted, preempted failed, scheduled get runs in submit order
+        new_live = [j for i, j in enumerate(jobs) if "run" in j and i not in res.preempted]
+        for job in sorted(res.scheduled, key=lambda i: jobs[i]["created"]):
+            run_counter += 1
+            j = jobs[job]
+            j["run"] = (res.scheduled[job], res.scheduled_priority[job], run_counter)
+            new_live.append(j)
+        live = new_live
+    return "ok"
+
+
+def run_qs_case(lib: Library, case: dict):
+    cfg = case["SchedulingConfig"]
+    jobs = case["Jobs"]
+    why = uses_unsupported(case, jobs)
+    if why:
+        return "skip: " + why
+    c = Case(lib, cfg, case["Nodes"])
+    s = c.sched
+    qs = case["Queues"]
+    queues = [q["Name"] for q in qs]
+    rank = {n: i for i, n in enumerate(sorted(queues))}
+    qidx = {q: i for i, q in enumerate(queues)}
+    Q, npc = len(queues), len(c.pc_names)
+    c.set_jobs(jobs, qidx, {})
+    allocated = np.zeros((Q, npc, R), dtype=np.int64)
+    for q, bypc in (case.get("InitialAllocatedByQueueAndPriorityClass") or {}).items():
+        for pc, rlist in bypc.items():
+            allocated[qidx[q], c.pc_index[pc]] = vec(rlist)
+    demand = np.zeros((Q, R), dtype=np.int64)
+    for j in jobs:
+        demand[qidx[j["queue"]]] += np.array(vec(j["req"]), dtype=np.int64)
+    queued = [c.sort_queued(jobs, [i for i, j in enumerate(jobs) if j["queue"] == q]) for q in queues]
+    glim = Tokens(cfg["maximum_scheduling_rate"], cfg["maximum_scheduling_burst"])
+    qlim = Tokens(cfg["maximum_per_queue_scheduling_rate"], cfg["maximum_per_queue_scheduling_burst"])
+    s.round_prepare([1.0 / float(q["PriorityFactor"]) for q in qs], queued, name_rank=[rank[n] for n in queues],
+                    allocated_by_pc=allocated, demand=demand, pc_resource_limit_fraction=c.pc_limits(queues, qs),
+                    global_tokens=glim.tokens, global_burst=glim.burst, global_rate_inf=glim.rate_inf,
+                    queue_tokens=[qlim.tokens] * Q, queue_burst=[qlim.burst] * Q, queue_rate_inf=[qlim.rate_inf] * Q)
+    res = s.schedule_queues()
+    exp = sorted(case.get("ExpectedScheduledIndices") or [])
+    assert sorted(res.scheduled) == exp, f"expected scheduled {exp} got {sorted(res.scheduled)}"
+    for i in case.get("ExpectedNeverAttemptedIndices") or []:
+        assert i not in res.scheduled and res.job_unschedulable_reason[i] == 0, f"job {i} was attempted"
+    return "ok"
+
+
+def run_gang_case(lib: Library, case: dict):
+    cfg = case["SchedulingConfig"]
+    gangs = case["Gangs"]
+    jobs = [j for g in gangs for j in g]
+    why = uses_unsupported(case, jobs)
+    if why:
+        return "skip: " + why
+    if case.get("TotalResources") and any(case["TotalResources"].values()):
+        return "skip: explicit TotalResources"
+    if case.get("AddAwayQueueContexts"):
+        return "skip: cross-pool away queues"
+    c = Case(lib, cfg, case["Nodes"])
+    s = c.sched
+    queues = sorted({j["queue"] for j in jobs})
+    qidx = {q: i for i, q in enumerate(queues)}
+    Q = len(queues)
+    c.set_jobs(jobs, qidx, {})
+    glim = Tokens(cfg["maximum_scheduling_rate"], cfg["maximum_scheduling_burst"])
+    qlim = Tokens(cfg["maximum_per_queue_scheduling_rate"], cfg["maximum_per_queue_scheduling_burst"])
+    s.round_prepare([1.0] * Q, [[] for _ in queues], demand=np.zeros((Q, R), dtype=np.int64),
+                    allocated_by_pc=np.zeros((Q, len(c.pc_names), R), dtype=np.int64), pc_resource_limit_fraction=c.pc_limits(queues),
+                    global_tokens=glim.tokens, global_burst=glim.burst, global_rate_inf=glim.rate_inf,
+                    queue_tokens=[qlim.tokens] * Q, queue_burst=[qlim.burst] * Q, queue_rate_inf=[qlim.rate_inf] * Q)
+    base = 0
+    actual = []
+    scheduled_gangs = 0
+    for gi, g in enumerate(gangs):
+        ids = list(range(base, base + len(g)))
+        base += len(g)
+        ok, reason, pods = s.gang_schedule(ids)
+        fit = sum(1 for p in pods if p.node >= 0)
+        assert fit == case["ExpectedRuntimeGangCardinality"][gi], f"gang {gi}: runtime cardinality {fit}"
+        cnt = s.round_counters()
+        if ok:
+            assert reason == 0
+            actual.append(gi)
+            scheduled_gangs += 1
+            uni = g[0]["gang"]["uniformity"] if g[0].get("gang") else ""
+            if uni:
+                vals = {case["Nodes"][p.node]["labels"].get(uni) for p in pods if p.node >= 0}
+                assert len(vals) == 1 and None not in vals, f"gang {gi}: uniformity not met {vals}"
+                expv = (case.get("ExpectedNodeUniformity") or {}).get(str(gi))
+                if expv is not None:
+                    assert vals == {expv}, f"gang {gi}: uniformity value {vals} expected {expv}"
+        else:
+            assert reason != 0
+            assert all(p.node < 0 for p in pods)
+        assert cnt["num_scheduled_gangs"] == scheduled_gangs
+        assert cnt["num_scheduled_jobs"] == case["ExpectedCumulativeScheduledJobs"][gi], f"gang {gi}: cumulative {cnt}"
+        assert cnt["num_evicted_jobs"] == 0
+    assert actual == (case.get("ExpectedScheduledIndices") or []), f"scheduled gangs {actual}"
+    exp_unf = sorted(case.get("ExpectedUnfeasibleSchedulingKeyIndices") or [])
+    starts = np.cumsum([0] + [len(g) for g in gangs])
+    for gi in exp_unf:
+        assert s.job_key_unfeasible(int(starts[gi])), f"gang {gi}: key not marked unfeasible"
+    assert s.round_counters()["num_unfeasible_keys"] == len(set(exp_unf)) or len(exp_unf) == s.round_counters()["num_unfeasible_keys"]
+    return "ok"
+
+
+def run_node_iteration_case(lib: Library, case: dict) -> List[int]:
+    """nodedb/nodeiteration_test.go:308-372 and :637-695: node ids are "0".."n-1" (string order breaks ties
+    across node types); TestNodeTypesIterator also forces node.index = i."""
+    import gofixtures_min as gf  # noqa: F401  (config only)
+    cfg = gf.test_scheduling_config()
+    nodes = case["nodes"]
+    merged = "nodeTypeIds" in case
+    c = Case.__new__(Case)
+    c.lib, c.cfgj, c.S = lib, cfg, Interner()
+    c.pc_names = sorted(cfg["priority_classes"])
+    c.pc_index = {n: i for i, n in enumerate(c.pc_names)}
+    pcs = cfg["priority_classes"]
+    c.config = Config(num_resources=R, indexed_col=[RES.index(n) for n, _ in cfg["indexed_resources"]],
+                      indexed_resolution=[r for _, r in cfg["indexed_resources"]],
+                      pc_priority=[pcs[n]["priority"] for n in c.pc_names], pc_preemptible=[int(pcs[n]["preemptible"]) for n in c.pc_names],
+                      drf_multiplier=[1.0, 1.0, 1.0, 0.0])
+    s = c.sched = Scheduler(lib, c.config)
+    n = len(nodes)
+    total = np.array([vec(x["total"]) for x in nodes], dtype=np.int64).reshape(n, R)
+    abp = np.repeat(total[:, None, :], s.P, axis=1)
+    for i, x in enumerate(nodes):
+        for p_str, used in (x.get("used") or {}).items():
+            for l, prio in enumerate(s.priorities):
+                if prio <= int(p_str):
+                    abp[i, l, :] -= np.array(vec(used), dtype=np.int64)
+    order = sorted(range(n), key=lambda i: str(i))
+    rank = [0] * n
+    for r_, i in enumerate(order):
+        rank[i] = r_
+    index = list(range(n)) if merged else [x["index"] for x in nodes]
+    s.nodes_upsert(total, total, index=[i + 1 for i in index] if merged else index, id_rank=rank, alloc_by_prio=abp,
+                   node_type_override=[x.get("node_type", 0) for x in nodes])
+    req = case.get("resourceRequests") or {}
+    ireq = [int(req.get(name, 0)) for name, _ in cfg["indexed_resources"]]
+    types = case["nodeTypeIds"] if merged else [case["nodeTypeId"]]
+    return s.iterate_nodes(int(case.get("priority", 0)), ireq, types)
+
+
+def run_fairness_case(lib: Library, case: dict):
+    cfg = case["config"]
+    if cfg.get("Pools"):
+        return None
+    names = ["foo", "bar", "baz"]
+    mult = {n: 0.0 for n in names}
+    for n in cfg.get("DominantResourceFairnessResourcesToConsider") or []:
+        mult[n] = 1.0
+    for r in cfg.get("ExperimentalDominantResourceFairnessResourcesToConsider") or []:
+        m = r.get("Multiplier", 0)
+        mult[r["Name"]] = float(m) if m > 0 else 1.0  # defaultMultiplier fairness.go:91-97
+    s = Scheduler(lib, Config(num_resources=3, indexed_col=[0], indexed_resolution=[1], pc_priority=[0], pc_preemptible=[1],
+                              drf_multiplier=[mult[n] for n in names]))
+    cost = s.drf_cost([case["allocation"][n] for n in names], [case["totalResources"][n] for n in names])
+    return cost / float(case["weight"])  # WeightedCostFromAllocation fairness.go:99-101
+
+
+def run_fair_share_case(lib: Library, case: dict):
+    s = Scheduler(lib, Config(num_resources=1, indexed_col=[0], indexed_resolution=[1], pc_priority=[0], pc_preemptible=[1], drf_multiplier=[1.0]))
+    queues = sorted(case["queueCtxs"])
+    total = [case["availableResources"].get("cpu", 0)]
+    cds = []
+    for q in queues:
+        d = [case["queueCtxs"][q]["Demand"].get("cpu", 0)]
+        cds.append(1.0 if total[0] == 0 else s.drf_cost(d, total))  # scheduling.go:267-270
+    f, dc, uc = s.fair_shares(list(range(len(queues))), [float(case["queueCtxs"][q]["Weight"]) for q in queues], cds)
+    return {q: (f[i], dc[i], uc[i]) for i, q in enumerate(queues)}
