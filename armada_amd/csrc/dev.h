@@ -1,0 +1,135 @@
+// dev.h — device-side data layout of the MI355X scheduling-round implementation.
+//
+// Everything the round touches lives in HBM as flat SoA arrays (DESIGN.md "Data layout"):
+//   alloc[P][R][Npad]  int64   AllocatableByPriority (internaltypes/node.go:64), one plane per (level, resource)
+//   keys [P][Npad]     uint64  packed order key per level: rounded indexed columns | node-index rank
+//                              (nodedb/encoding.go:37-54 restated as a single integer compare)
+//   masks[..][W]       uint64  per-node bit masks (static requirement classes, job shapes, label values)
+// plus the job table, per-queue accounting and the round's iterator state.
+#pragma once
+#include <stdint.h>
+
+#define MAXR 8
+#define MAXK 6
+#define MAXP 16
+#define MAXPC 32
+#define NO_PRIORITY INT32_MIN
+#define NONPREEMPTIBLE_CUTOFF INT32_MAX
+
+// per-job flag bits (qctx.Successful/Rescheduled/Unsuccessful/EvictedJobsById, context/queue.go:64-88)
+#define F_SUCCESSFUL 1
+#define F_RESCHEDULED 2
+#define F_UNSUCCESSFUL 4
+#define F_EVICTED 8
+
+struct DevCfg {
+  int R, K, P, npc;
+  int32_t prios[MAXP];
+  int32_t indexedCol[MAXK];
+  int64_t indexedRes[MAXK];
+  int64_t keyLo[MAXK];   // bias: field = alloc/res - keyLo
+  int32_t keyShift[MAXK];
+  int32_t keyWidth[MAXK];
+  int32_t idxBits;
+  int32_t pcPriority[MAXPC];
+  uint8_t pcPreemptible[MAXPC];
+  double drfMult[MAXR];
+  uint8_t preferLarge, protectUncapped, disableHome, disableAway, disableGangAway, disableFair, disableUrgency, hasAway;
+  double protectedFraction;
+  uint32_t maxLookback;
+  uint8_t disallowed[MAXR];
+  int N, Npad, W, M, Q, S, G, C;
+  int64_t totalResources[MAXR];
+  int64_t maxToSchedule[MAXR];
+  int evLevel;  // level index of EvictedPriority (always 0)
+};
+
+// scalars of the scheduling context (context/scheduling.go:27-77) + kernel bookkeeping
+struct RoundScalars {
+  int64_t allocated[MAXR], scheduled[MAXR], evicted[MAXR];
+  int32_t numScheduledJobs, numScheduledGangs, numEvictedJobs, terminationReason;
+  double globalTokens; int64_t globalBurst; int32_t globalRateInf;
+  int32_t hasFpLimiter; double fpTokens;
+  int32_t loopIterations, numNodeQueries, numScans;
+  int32_t error;            // first ASCHED_ERR_* raised on the device
+  int32_t errorDetail;
+  int32_t numEvictedList;   // length of the evicted list produced by an evictor kernel
+  int32_t numUnfeasible;
+  int32_t evictedTableSize; // Index counter of addEvictedJobsToNodeDb
+  int32_t undoCount;
+  int32_t txnActive;   // persists across control-kernel launches (NodeDb-level API)
+  int32_t fairStamp;
+  int32_t pad;
+};
+
+struct Dev {
+  DevCfg cfg;
+  // ---- nodes
+  int64_t* alloc;        // [P][R][Npad]
+  uint64_t* keys;        // [P][Npad]
+  int64_t* totalRes;     // [R][Npad]
+  int64_t* allocatable;  // [R][Npad]
+  int64_t* alloc0;       // [P][R][Npad] explicit initial state (alloc_by_prio) or NULL
+  uint8_t* nodeFlags;    // [N] bit0: unschedulable && overAllocated
+  int32_t* idxRank;      // [N] rank of node.index
+  int32_t* nodeByRank;   // [N]
+  // ---- masks
+  uint64_t* shapeMask;   // [S][W] static class ∧ node-type match ∧ total >= req, per scheduling-key shape
+  uint64_t* labelMask;   // [L][W] nodes carrying (uniformity label == value)
+  // ---- jobs (immutable per jobs_set)
+  int32_t *jQueue, *jPc, *jShape, *jGang, *jGangCard, *jGangUni, *jNode0, *jRunPrio, *jRankActive, *jRankInactive;
+  int64_t* jReq;         // [M][R] row-major (control path reads one job = one 8*R byte burst)
+  uint8_t* jAligned;     // [M] request is a multiple of the index resolution on every indexed column
+  int32_t *gangOff, *gangJobs;  // CSR of (queue,gang) -> member jobs (jobRepo.GetGangJobsByGangId)
+  int64_t* shapeReq;     // [S][R]
+  // ---- job dynamic state
+  int32_t* schedAtPrio;  // [M] nodeDb.scheduledAtPriorityByJobId
+  int32_t* jobNode;      // [M] node the job currently owns resources on (AllocatedByJobId), -1
+  int32_t* jobCutoff;    // [M] cutoffByJobId
+  uint8_t* jobEvictedOnNode;  // [M] EvictedJobRunIds
+  uint8_t* jobFlags;     // [M]
+  // jctx (one live JobSchedulingContext per job)
+  uint8_t* jcEvicted; int32_t* jcAssigned; int32_t* jcReason; uint8_t* jcHasPctx;
+  int32_t *pcNode, *pcSap, *pcPap, *pcMethod;
+  int32_t* jcGangCard; uint8_t* jcPreempted;  // sctx.PreemptedJobIds
+  int32_t* jcUniValue;   // additional node selector (uniformity label value mask id), -1
+  int32_t* jcStagedBy;   // staged preemption (applied on txn commit)
+  // result bookkeeping of PreemptingQueueScheduler.Schedule
+  uint8_t* inPreempted; uint8_t* inScheduled; uint8_t* inSchedAndEvicted; int32_t* preemptedNode;
+  // ---- queues
+  double *qWeight, *qFair, *qDc, *qUc, *qTokens; int32_t* qNameRank; int64_t* qBurst; uint8_t *qRateInf, *qCordoned;
+  int64_t *qAlloc, *qAllocByPc, *qSchedByPc, *qEvictedByPc, *qPenalty, *qPcLimit, *qDemand; int32_t hasPcLimit;
+  int32_t *queuedOff, *queuedJobs;
+  // ---- evicted jobs
+  int32_t* evList;       // [M] output of evictor kernels, then sorted by (queue, scheduling order)
+  uint32_t* evSortKey;   // [M]
+  int32_t* evOff;        // [Q+1] per-queue segment of the sorted list
+  int32_t* evTabJob;     // [M] evicted table: Index -> job (EvictedJobsTable, nodedb.go:1257-1281)
+  uint8_t* evTabAlive;   // [M]
+  int32_t* evIndexOfJob; // [M] job -> Index or -1
+  // ---- iterators (one set per pass)
+  int32_t *itEi, *itQi, *itStage, *itJobsSeen, *itNext, *itStashed; uint8_t *itJobOnlyEv, *itGangOnlyEv, *onlyEvByQueue;
+  int32_t* gangSeen; int32_t* gangArr; int64_t* gangTotal; uint8_t* gangAllEvicted;
+  double *pqProposed, *pqCurrent, *pqBudget, *pqSize; int32_t *pqPcPrio, *pqSchedPrio, *pqGctx; uint8_t* pqInHeap;
+  int64_t* replayAlloc;  // [Q][R] MinimalQueueRepository allocation (pqs.go:552-585)
+  uint8_t* unfeasible; int32_t* unfeasibleReason;  // [S]
+  // ---- fair preemption scratch
+  int64_t* accAvail;     // [N][R]
+  int32_t* accStamp;     // [N]
+  uint8_t* accStaticFailed;  // [N]
+  int32_t accEpoch_unused;
+  // ---- txn undo log
+  int32_t* undo;         // [cap][4]
+  int32_t undoCap;
+  // ---- misc
+  RoundScalars* rs;
+  uint64_t* scanResult;  // [8] scratch for wide scans
+  int32_t* nodeOver;     // [N] bitmask of oversubscribed levels (phase 3)
+  uint8_t* evFlag;       // [M] job selected by the current evictor
+  uint8_t* qEvictable;   // [Q] queue is above protectedFractionOfFairShare (pqs.go:124-134)
+  int32_t *ordAll, *ordAllOff;  // jobs pre-sorted by (queue, SchedulingOrderCompare): active segment then queued segment per queue
+  int32_t* uniOff;       // [slots+1] label-value mask ids per uniformity label slot
+  int32_t* preList;      // [M] staged preemptions
+  int32_t* cmdIO;        // [64 + ...] command arguments / results of the control kernel
+  int32_t *resJob, *resNode, *resPrio, *resMethod, *resPreJob, *resPreNode;  // compacted results
+};

@@ -1,0 +1,794 @@
+// round_ctl.h — the sequential part of the scheduling round, written once as "wave-uniform" code.
+//
+// On the GPU this code is executed by wave 0 of a single persistent workgroup (all 64 lanes run the
+// same control flow on the same data — stores of identical values by 64 lanes are benign), and it calls
+// workgroup-wide primitives for the data-parallel parts:
+//     wgFirstFit()  : LDS-staged argmin scan over the (level, resource) planes of `alloc` and `keys`
+//     pqTop()       : lane-per-queue DRF argmin with the reference's Less (queue_scheduler.go:738-798)
+//     wgForEach()   : block-stride loops for the bulk phases (evictors, unbind, result compaction)
+// The same file compiles for the host with -DASCHED_HOSTSIM (tests/hostsim): there the primitives
+// degrade to serial loops, which lets the control logic be debugged in a GPU-less container.  The
+// host build is test infrastructure only and is never loaded by the product.
+//
+// Each function cites the reference code it restates (is/ = internal/scheduler/).
+#pragma once
+#include "dev.h"
+#include "../../include/armada_sched.h"
+
+#ifdef ASCHED_HOSTSIM
+#include <cmath>
+#include <cstring>
+#define DEV static inline
+#define WG_THREADS 1
+#else
+#define DEV __device__ static inline
+#define WG_THREADS 1024
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// workgroup primitives (implemented differently per build)
+struct ScanArgs { int64_t req[MAXR]; const uint64_t* maskA; const uint64_t* maskB; int level; };
+
+DEV int wgFirstFit(Dev& d, const ScanArgs& a);                       // -> node or -1
+template <class F> DEV void wgForEach(Dev& d, int n, F f);           // f(i) for i in [0,n), then workgroup barrier
+DEV int wgCompact(Dev& d, const int32_t* src, int n, const uint8_t* flagByValue, int32_t* dst, const int32_t* segOff, int nseg, int32_t* outSegOff);
+DEV void atomicAddI64(int64_t* p, int64_t v);
+DEV void atomicAddI32(int32_t* p, int32_t v);
+DEV void atomicOrI32(int32_t* p, int32_t v);
+
+// ------------------------------------------------------------------------------------------------
+#define AL(d, l, r, n) ((d).alloc[((size_t)(l) * (d).cfg.R + (r)) * (d).cfg.Npad + (n)])
+#define KEY(d, l, n) ((d).keys[(size_t)(l) * (d).cfg.Npad + (n)])
+#define JREQ(d, j) ((d).jReq + (size_t)(j) * (d).cfg.R)
+
+DEV void raise(Dev& d, int code, int detail) {
+  if (d.rs->error == 0) { d.rs->error = code; d.rs->errorDetail = detail; }
+}
+
+DEV int levelOf(const DevCfg& c, int32_t prio) {
+  for (int i = 0; i < c.P; i++) if (c.prios[i] == prio) return i;
+  return -1;
+}
+
+// packed order key of node n at level l: (rounded indexed columns ..., rank of node.index)
+// == RoundedNodeIndexKeyFromResourceList (is/nodedb/encoding.go:37-54) as one integer compare.
+DEV uint64_t packKey(Dev& d, int l, int n) {
+  const DevCfg& c = d.cfg;
+  uint64_t k = (uint64_t)d.idxRank[n];
+  for (int i = 0; i < c.K; i++) {
+    int64_t q = AL(d, l, c.indexedCol[i], n) / c.indexedRes[i];  // truncation toward zero, like Go (encoding.go:56-58)
+    int64_t f = q - c.keyLo[i];
+    if (f < 0 || (c.keyWidth[i] < 63 && f >= ((int64_t)1 << c.keyWidth[i]))) { raise(d, ASCHED_ERR_UNSUPPORTED, 100 + i); f = 0; }
+    k |= (uint64_t)f << c.keyShift[i];
+  }
+  return k;
+}
+DEV void updateKeys(Dev& d, int n) { for (int l = 0; l < d.cfg.P; l++) KEY(d, l, n) = packKey(d, l, n); }
+
+DEV bool fitsAlloc(Dev& d, const int64_t* req, int level, int n) {  // DynamicJobRequirementsMet (is/nodedb/nodematching.go:194-197)
+  for (int r = 0; r < d.cfg.R; r++) if (req[r] > AL(d, level, r, n)) return false;
+  return true;
+}
+
+// ---- undo log (memdb write txn: gang attempts are aborted on failure, gang_scheduler.go:234-243)
+enum { U_ADD = 1, U_REMOVE = 2, U_EVTAB_DEL = 3, U_EVTAB_INS = 4 };
+struct Txn { int active; };
+DEV void undoPush(Dev& d, int op, int a, int b, int c) {
+  int i = d.rs->undoCount;
+  if (i >= d.undoCap) { raise(d, ASCHED_ERR_INTERNAL, 200); return; }
+  d.undo[i * 4 + 0] = op; d.undo[i * 4 + 1] = a; d.undo[i * 4 + 2] = b; d.undo[i * 4 + 3] = c;
+  d.rs->undoCount = i + 1;
+}
+
+// markAllocatable (is/internaltypes/node.go:539-549): alloc[p] += sign*req for every level p <= cutoff
+DEV void markAllocatable(Dev& d, int n, int32_t cutoff, const int64_t* req, int sign) {
+  const DevCfg& c = d.cfg;
+  for (int l = 0; l < c.P; l++)
+    if (c.prios[l] <= cutoff)
+      for (int r = 0; r < c.R; r++) AL(d, l, r, n) += sign * req[r];
+}
+DEV int32_t cutoffFor(Dev& d, int job, int32_t prio) {  // priorityCutoffFor (is/nodedb/nodedb.go:1329-1334)
+  return d.cfg.pcPreemptible[d.jPc[job]] ? prio : NONPREEMPTIBLE_CUTOFF;
+}
+
+// Node.AddJob (node.go:416-442); aux bits recorded for undo: bit0 = wasEvicted, old cutoff in c
+DEV int addJob(Dev& d, int n, int job, int32_t cutoff, bool log) {
+  bool onNode = d.jobNode[job] == n;
+  bool wasEvicted = onNode && d.jobEvictedOnNode[job];
+  if (!wasEvicted && d.jobNode[job] >= 0) { raise(d, ASCHED_ERR_INTERNAL, 300); return -1; }  // "job already has resources allocated"
+  int32_t oldCutoff = d.jobCutoff[job];
+  d.jobEvictedOnNode[job] = 0;
+  d.jobNode[job] = n;
+  const int64_t* req = JREQ(d, job);
+  markAllocatable(d, n, cutoff, req, -1);
+  if (wasEvicted) markAllocatable(d, n, ASCHED_EVICTED_PRIORITY, req, +1);
+  d.jobCutoff[job] = cutoff;
+  if (log) undoPush(d, U_ADD | (wasEvicted ? 256 : 0), job, n, oldCutoff);
+  return 0;
+}
+// Node.RemoveJob (node.go:480-506); unknown job => no-op
+DEV void removeJob(Dev& d, int n, int job, bool log) {
+  if (d.jobNode[job] != n) return;
+  const int64_t* req = JREQ(d, job);
+  bool wasEvicted = d.jobEvictedOnNode[job];
+  int32_t cutoff = d.jobCutoff[job];
+  if (wasEvicted) markAllocatable(d, n, ASCHED_EVICTED_PRIORITY, req, +1);
+  else markAllocatable(d, n, cutoff, req, +1);
+  d.jobEvictedOnNode[job] = 0;
+  d.jobNode[job] = -1;
+  if (log) undoPush(d, U_REMOVE | (wasEvicted ? 256 : 0), job, n, cutoff);
+}
+// Node.EvictJob (node.go:449-474)
+DEV int evictJobOnNode(Dev& d, int n, int job) {
+  if (d.jobNode[job] != n) { raise(d, ASCHED_ERR_INTERNAL, 301); return -1; }
+  if (d.jobEvictedOnNode[job]) { raise(d, ASCHED_ERR_INTERNAL, 302); return -1; }
+  d.jobEvictedOnNode[job] = 1;
+  const int64_t* req = JREQ(d, job);
+  markAllocatable(d, n, d.jobCutoff[job], req, +1);
+  markAllocatable(d, n, ASCHED_EVICTED_PRIORITY, req, -1);
+  return 0;
+}
+
+DEV void evTabDelete(Dev& d, int idx, bool log) {
+  if (!d.evTabAlive[idx]) return;
+  d.evTabAlive[idx] = 0;
+  d.evIndexOfJob[d.evTabJob[idx]] = -1;
+  if (log) undoPush(d, U_EVTAB_DEL, idx, 0, 0);
+}
+DEV void evTabInsert(Dev& d, int idx, int job) {
+  d.evTabJob[idx] = job; d.evTabAlive[idx] = 1; d.evIndexOfJob[job] = idx;
+  if (idx + 1 > d.rs->evictedTableSize) d.rs->evictedTableSize = idx + 1;
+}
+
+DEV void txnBegin(Dev& d, Txn& t) { t.active = 1; d.rs->undoCount = 0; }
+DEV void txnCommit(Dev& d, Txn& t) { t.active = 0; d.rs->undoCount = 0; }
+DEV void txnAbort(Dev& d, Txn& t) {
+  if (!t.active) return;
+  t.active = 0;
+  for (int i = d.rs->undoCount - 1; i >= 0; i--) {
+    int op = d.undo[i * 4], a = d.undo[i * 4 + 1], b = d.undo[i * 4 + 2], c = d.undo[i * 4 + 3];
+    int kind = op & 255; bool wasEvicted = op & 256;
+    if (kind == U_ADD) {
+      int job = a, n = b;
+      const int64_t* req = JREQ(d, job);
+      markAllocatable(d, n, d.jobCutoff[job], req, +1);
+      if (wasEvicted) { markAllocatable(d, n, ASCHED_EVICTED_PRIORITY, req, -1); d.jobEvictedOnNode[job] = 1; d.jobCutoff[job] = c; }
+      else { d.jobNode[job] = -1; d.jobCutoff[job] = c; }
+      updateKeys(d, n);
+    } else if (kind == U_REMOVE) {
+      int job = a, n = b;
+      const int64_t* req = JREQ(d, job);
+      if (wasEvicted) markAllocatable(d, n, ASCHED_EVICTED_PRIORITY, req, -1);
+      else markAllocatable(d, n, c, req, -1);
+      d.jobNode[job] = n; d.jobCutoff[job] = c; d.jobEvictedOnNode[job] = wasEvicted ? 1 : 0;
+      updateKeys(d, n);
+    } else if (kind == U_EVTAB_DEL) {
+      d.evTabAlive[a] = 1; d.evIndexOfJob[d.evTabJob[a]] = a;
+    }
+  }
+  d.rs->undoCount = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gang context references: >=0 single job; <=-2 gang (dense id g = -(ref)-2); -1 nil
+DEV int gcCount(Dev& d, int ref) { return ref >= 0 ? 1 : d.gangSeen[-ref - 2]; }
+DEV int gcJob(Dev& d, int ref, int k) { return ref >= 0 ? ref : d.gangArr[d.gangOff[-ref - 2] + k]; }
+DEV const int64_t* gcTotal(Dev& d, int ref) { return ref >= 0 ? JREQ(d, ref) : d.gangTotal + (size_t)(-ref - 2) * d.cfg.R; }
+DEV bool gcAllEvicted(Dev& d, int ref) { return ref >= 0 ? d.jcEvicted[ref] : d.gangAllEvicted[-ref - 2]; }
+DEV bool gcIsGang(Dev& d, int ref) { return d.jGang[gcJob(d, ref, 0)] >= 0; }
+DEV int gcQueue(Dev& d, int ref) { return d.jQueue[gcJob(d, ref, 0)]; }
+
+DEV double drf(Dev& d, const int64_t* a) {  // fairness.go:103-105 (float64, this operation order; -ffp-contract=off)
+  const DevCfg& c = d.cfg;
+  double m = -INFINITY;
+  for (int i = 0; i < c.R; i++) {
+    double f = 0.0;
+    if (c.totalResources[i] != 0) f = (double)a[i] / (double)c.totalResources[i];
+    double x = f * c.drfMult[i];
+    if (x > m) m = x;
+  }
+  return m > 0 ? m : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scheduling-context accounting
+#define QV(arr, q) ((arr) + (size_t)(q) * d.cfg.R)
+#define QPV(arr, q, pc) ((arr) + ((size_t)(q) * d.cfg.npc + (pc)) * d.cfg.R)
+DEV void vadd(Dev& d, int64_t* a, const int64_t* b, int sign) { for (int r = 0; r < d.cfg.R; r++) a[r] += sign * b[r]; }
+
+// qctx.addJobSchedulingContext + sctx.AddJobSchedulingContext (context/queue.go:231-265, scheduling.go:410-434)
+DEV bool sctxAddJob(Dev& d, int job) {
+  int q = d.jQueue[job], pc = d.jPc[job];
+  const int64_t* req = JREQ(d, job);
+  uint8_t f = d.jobFlags[job] & ~F_UNSUCCESSFUL;
+  bool evictedInRound = f & F_EVICTED;
+  RoundScalars& s = *d.rs;
+  if (d.jcReason[job] == 0) {
+    vadd(d, QPV(d.qAllocByPc, q, pc), req, +1);
+    vadd(d, QV(d.qAlloc, q), req, +1);
+    if (evictedInRound) {
+      f &= ~F_EVICTED; f |= F_RESCHEDULED;
+      vadd(d, QPV(d.qEvictedByPc, q, pc), req, -1);
+      vadd(d, s.evicted, req, -1); s.numEvictedJobs--;
+    } else {
+      f |= F_SUCCESSFUL;
+      vadd(d, QPV(d.qSchedByPc, q, pc), req, +1);
+      vadd(d, s.scheduled, req, +1); s.numScheduledJobs++;
+    }
+    vadd(d, s.allocated, req, +1);
+  } else {
+    f |= F_UNSUCCESSFUL;
+  }
+  d.jobFlags[job] = f;
+  return evictedInRound;
+}
+DEV void sctxAddGang(Dev& d, int ref) {  // scheduling.go:391-406
+  bool allEvicted = true, allOk = true;
+  int n = gcCount(d, ref);
+  for (int k = 0; k < n; k++) { int j = gcJob(d, ref, k); bool ev = sctxAddJob(d, j); allEvicted = allEvicted && ev; allOk = allOk && d.jcReason[j] == 0; }
+  if (allOk && !allEvicted) d.rs->numScheduledGangs++;
+}
+// qctx.evictJob + sctx.EvictJob (queue.go:351-386, scheduling.go:551-572)
+DEV bool sctxEvictJob(Dev& d, int job) {
+  int q = d.jQueue[job], pc = d.jPc[job];
+  const int64_t* req = JREQ(d, job);
+  uint8_t f = d.jobFlags[job];
+  RoundScalars& s = *d.rs;
+  if (f & (F_UNSUCCESSFUL | F_EVICTED)) { raise(d, ASCHED_ERR_INTERNAL, 400); return false; }
+  bool sched = f & F_SUCCESSFUL, resched = f & F_RESCHEDULED;
+  if (sched || resched) {
+    if (sched) { vadd(d, QPV(d.qSchedByPc, q, pc), req, -1); f &= ~F_SUCCESSFUL; }
+    if (resched) f &= ~F_RESCHEDULED;
+  } else {
+    vadd(d, QPV(d.qEvictedByPc, q, pc), req, +1);
+    f |= F_EVICTED;
+  }
+  vadd(d, QPV(d.qAllocByPc, q, pc), req, -1);
+  vadd(d, QV(d.qAlloc, q), req, -1);
+  if (sched) { vadd(d, s.scheduled, req, -1); s.numScheduledJobs--; }
+  else { vadd(d, s.evicted, req, +1); s.numEvictedJobs++; }
+  vadd(d, s.allocated, req, -1);
+  d.jobFlags[job] = f;
+  return sched;
+}
+DEV void sctxEvictGang(Dev& d, int ref) {  // scheduling.go:436-449
+  bool all = true;
+  int n = gcCount(d, ref);
+  for (int k = 0; k < n; k++) { bool s = sctxEvictJob(d, gcJob(d, ref, k)); all = all && s; }
+  if (all) d.rs->numScheduledGangs--;
+}
+
+// ------------------------------------------------------------------------------------------------
+// constraints (is/scheduling/constraints/constraints.go:113-178)
+DEV bool vexceeds(Dev& d, const int64_t* a, const int64_t* b) { for (int r = 0; r < d.cfg.R; r++) if (a[r] > b[r]) return true; return false; }
+DEV int checkRound(Dev& d) { return vexceeds(d, d.rs->scheduled, d.cfg.maxToSchedule) ? ASCHED_REASON_MAX_RESOURCES_SCHEDULED : 0; }
+DEV int checkJob(Dev& d, int ref) {
+  int q = gcQueue(d, ref), card = gcCount(d, ref);
+  if (d.qCordoned[q]) return ASCHED_REASON_QUEUE_CORDONED;
+  double tokens = d.rs->globalTokens;
+  if (tokens < 1) return ASCHED_REASON_GLOBAL_RATE_LIMIT;
+  if (d.rs->globalBurst < card) return ASCHED_REASON_GANG_EXCEEDS_GLOBAL_BURST;
+  if (tokens < (double)card) return ASCHED_REASON_GLOBAL_RATE_LIMIT_BY_GANG;
+  tokens = d.qTokens[q];
+  if (tokens < 1) return ASCHED_REASON_QUEUE_RATE_LIMIT;
+  if (d.qBurst[q] < card) return ASCHED_REASON_GANG_EXCEEDS_QUEUE_BURST;
+  if (tokens < (double)card) return ASCHED_REASON_QUEUE_RATE_LIMIT_BY_GANG;
+  int pc = d.jPc[gcJob(d, ref, 0)];
+  if (d.hasPcLimit && vexceeds(d, QPV(d.qAllocByPc, q, pc), QPV(d.qPcLimit, q, pc))) return ASCHED_REASON_RESOURCE_LIMIT_EXCEEDED;
+  return 0;
+}
+DEV bool isTerminal(int r) { return r == ASCHED_REASON_MAX_RESOURCES_SCHEDULED || r == ASCHED_REASON_GLOBAL_RATE_LIMIT; }
+DEV bool isQueueTerminal(int r) { return r == ASCHED_REASON_QUEUE_RATE_LIMIT || r == ASCHED_REASON_QUEUE_CORDONED; }
+DEV bool isPropertyOfGang(int r) { return r == ASCHED_REASON_GANG_EXCEEDS_GLOBAL_BURST || r == ASCHED_REASON_JOB_DOES_NOT_FIT || r == ASCHED_REASON_GANG_DOES_NOT_FIT; }
+DEV void reserveN(double* tokens, int64_t burst, int rateInf, int n) { if (rateInf) return; if (n > burst) return; *tokens -= (double)n; }
+
+// ------------------------------------------------------------------------------------------------
+// node selection
+struct Ctl {
+  Txn txn;
+  int skipKeyCheck;
+  int compareSchedPrio, preferLarge, useReplayAlloc, onlyEvicted;
+  int* preList;      // staged preemptions of the current gang attempt (job ids), in global memory
+  int preCount;
+  int fairStamp;
+};
+
+DEV const uint64_t* uniMask(Dev& d, int job) { int v = d.jcUniValue[job]; return v >= 0 ? d.labelMask + (size_t)v * d.cfg.W : (const uint64_t*)0; }
+
+// selectNodeForPodAtPriority + selectNodeForPodWithItAtPriority (nodedb.go:840-928): first node, in index order, passing
+// static + dynamic checks.  Under the alignment conditions checked at upload (DESIGN.md "Exactness conditions") the merged
+// iterator order of nodeiteration.go equals the order of the packed key, so this is one argmin scan.
+DEV int selectAtLevel(Dev& d, int job, int32_t prio) {
+  d.rs->numNodeQueries++;
+  int level = levelOf(d.cfg, prio);
+  if (level < 0) { raise(d, ASCHED_ERR_INTERNAL, 500); return -1; }
+  ScanArgs a;
+  const int64_t* req = JREQ(d, job);
+  for (int r = 0; r < MAXR; r++) a.req[r] = r < d.cfg.R ? req[r] : 0;
+  a.maskA = d.shapeMask + (size_t)d.jShape[job] * d.cfg.W;
+  a.maskB = uniMask(d, job);
+  a.level = level;
+  int n = wgFirstFit(d, a);
+  if (n >= 0) { d.pcNode[job] = n; d.pcPap[job] = prio; }
+  return n;
+}
+
+// selectNodeForJobWithFairPreemption (nodedb.go:935-1043), literal: evicted jobs by descending Index.
+DEV int selectWithFairPreemption(Dev& d, Ctl& c, int job) {
+  const DevCfg& cf = d.cfg;
+  c.fairStamp++;
+  int stamp = c.fairStamp;
+  const int64_t* req = JREQ(d, job);
+  const uint64_t* mA = d.shapeMask + (size_t)d.jShape[job] * cf.W;
+  const uint64_t* mB = uniMask(d, job);
+  int32_t maxPriority = ASCHED_MIN_PRIORITY;
+  for (int idx = d.rs->evictedTableSize - 1; idx >= 0; idx--) {
+    if (!d.evTabAlive[idx]) continue;
+    int ej = d.evTabJob[idx];
+    int32_t ep = d.schedAtPrio[ej];
+    if (ep == NO_PRIORITY) { raise(d, ASCHED_ERR_INTERNAL, 600); return -1; }
+    if (ep > d.pcSap[job]) continue;
+    int n = d.jcAssigned[ej];
+    if (n < 0) { raise(d, ASCHED_ERR_INTERNAL, 601); return -1; }
+    int64_t* av = d.accAvail + (size_t)n * cf.R;
+    if (d.accStamp[n] != stamp) {
+      d.accStamp[n] = stamp; d.accStaticFailed[n] = 0;
+      for (int r = 0; r < cf.R; r++) av[r] = AL(d, cf.evLevel, r, n);
+    }
+    if (d.accStaticFailed[n]) continue;
+    const int64_t* er = JREQ(d, ej);
+    bool fits = true;
+    for (int r = 0; r < cf.R; r++) { av[r] += er[r]; if (req[r] > av[r]) fits = false; }
+    if (!fits) continue;
+    bool st = (mA[n >> 6] >> (n & 63)) & 1;
+    if (st && mB) st = (mB[n >> 6] >> (n & 63)) & 1;
+    if (!st) { d.accStaticFailed[n] = 1; continue; }
+    // preempt every considered evicted job of node n (those with Index >= idx, alive, priority <= ours), in scan order
+    for (int i2 = d.rs->evictedTableSize - 1; i2 >= idx; i2--) {
+      if (!d.evTabAlive[i2]) continue;
+      int e2 = d.evTabJob[i2];
+      if (d.jcAssigned[e2] != n) continue;
+      if (d.schedAtPrio[e2] > d.pcSap[job]) continue;
+      int32_t p = d.schedAtPrio[e2];
+      evTabDelete(d, i2, true);
+      if (p > maxPriority) maxPriority = p;
+      c.preList[c.preCount++] = e2;
+    }
+    d.pcNode[job] = n; d.pcPap[job] = maxPriority;
+    return n;
+  }
+  return -1;
+}
+
+// selectNodeForJobWithTxnAtPriority (nodedb.go:724-789)
+DEV int selectAtPriority(Dev& d, Ctl& c, int job) {
+  int n = selectAtLevel(d, job, ASCHED_EVICTED_PRIORITY);
+  if (n >= 0) { d.pcMethod[job] = ASCHED_METHOD_NO_PREEMPTION; return n; }
+  n = selectAtLevel(d, job, d.pcSap[job]);  // feasibility gate
+  if (n < 0) return -1;
+  d.pcNode[job] = -1; d.pcPap[job] = ASCHED_MIN_PRIORITY;
+  if (!d.cfg.disableFair) {
+    n = selectWithFairPreemption(d, c, job);
+    if (n >= 0) { d.pcMethod[job] = ASCHED_METHOD_FAIRSHARE; return n; }
+  }
+  d.pcNode[job] = -1; d.pcPap[job] = ASCHED_MIN_PRIORITY;
+  if (!d.cfg.disableUrgency) {  // selectNodeForJobWithUrgencyPreemption :805-838
+    for (int l = 0; l < d.cfg.P; l++) {
+      int32_t pr = d.cfg.prios[l];
+      if (pr == ASCHED_EVICTED_PRIORITY) continue;
+      if (pr > d.pcSap[job]) break;
+      n = selectAtLevel(d, job, pr);
+      if (n >= 0) { d.pcMethod[job] = ASCHED_METHOD_URGENCY; return n; }
+    }
+  }
+  return -1;
+}
+
+// SelectNodeForJobWithTxn (nodedb.go:538-630)
+DEV int selectNodeForJob(Dev& d, Ctl& c, int job) {
+  if (d.jcPreempted[job]) return -1;  // :541-544 (GetPreemptingJob != nil; PreemptionDetails are set by applyPreemptions)
+  int32_t prio = d.schedAtPrio[job];
+  if (prio == NO_PRIORITY) prio = d.cfg.pcPriority[d.jPc[job]];
+  d.jcHasPctx[job] = 1;
+  d.pcNode[job] = -1; d.pcSap[job] = prio; d.pcPap[job] = ASCHED_MIN_PRIORITY; d.pcMethod[job] = ASCHED_METHOD_NONE;
+  int pinned = d.jcAssigned[job];
+  if (pinned >= 0) {  // :583-594 — evicted jobs may only return to their node; dynamic check only (:897-906)
+    int level = levelOf(d.cfg, prio);
+    if (level < 0) { raise(d, ASCHED_ERR_INTERNAL, 501); return -1; }
+    bool ok = (d.nodeFlags[pinned] & 1) || fitsAlloc(d, JREQ(d, job), level, pinned);
+    d.pcMethod[job] = ASCHED_METHOD_RESCHEDULED;
+    if (ok) { d.pcNode[job] = pinned; d.pcPap[job] = prio; return pinned; }
+    return -1;
+  }
+  const int64_t* req = JREQ(d, job);
+  for (int r = 0; r < d.cfg.R; r++) if (d.cfg.disallowed[r] && req[r] > 0) return -1;  // :596-601
+  if (!d.cfg.disableHome) {
+    int n = selectAtPriority(d, c, job);
+    if (n >= 0) return n;
+  }
+  if (d.cfg.hasAway) {
+    bool awayDisabled = d.cfg.disableAway || (d.jGang[job] >= 0 && d.cfg.disableGangAway);
+    // away node types (:613-627) need per-(class, well-known type) masks: not implemented on the device yet
+    if (!awayDisabled) { /* host refuses configs that reach this (jobs_set), see DESIGN.md */ }
+  }
+  return -1;
+}
+
+// preemptSiblingGangJobs (nodedb.go:468-525)
+DEV void preemptSiblings(Dev& d, Ctl& c, int firstPre, int lastPre) {
+  for (int i = firstPre; i < lastPre; i++) {
+    int job = c.preList[i];
+    int g = d.jGang[job];
+    if (g < 0) continue;
+    for (int k = d.gangOff[g]; k < d.gangOff[g + 1]; k++) {
+      int s = d.gangJobs[k];
+      int idx = d.evIndexOfJob[s];
+      if (idx < 0) continue;
+      int n = d.jcAssigned[s];
+      if (n < 0) { raise(d, ASCHED_ERR_INTERNAL, 700); return; }
+      removeJob(d, n, s, true);
+      updateKeys(d, n);
+      evTabDelete(d, idx, true);
+      c.preList[c.preCount++] = s;
+    }
+  }
+}
+
+// ScheduleManyWithTxn (nodedb.go:417-462)
+DEV bool scheduleMany(Dev& d, Ctl& c, int ref) {
+  int cnt = gcCount(d, ref);
+  for (int k = 0; k < cnt; k++) {
+    int job = gcJob(d, ref, k);
+    d.jcReason[job] = 0;
+    int pre0 = c.preCount;
+    int n = selectNodeForJob(d, c, job);
+    if (d.rs->error) return false;
+    if (n < 0) return false;
+    int pre1 = c.preCount;
+    for (int i = pre0; i < pre1; i++) removeJob(d, n, c.preList[i], true);  // victims leave the returned node copy (nodedb.go:1012-1023)
+    int32_t prio = d.pcSap[job];
+    if (addJob(d, n, job, cutoffFor(d, job, prio), true)) return false;     // BindJobToNode :1046-1068
+    d.schedAtPrio[job] = prio;                                              // not rolled back on abort (plain Go map)
+    updateKeys(d, n);
+    int eidx = d.evIndexOfJob[job];
+    if (eidx >= 0) evTabDelete(d, eidx, true);
+    preemptSiblings(d, c, pre0, pre1);
+    for (int i = pre0; i < c.preCount; i++) d.jcStagedBy[c.preList[i]] = job;
+  }
+  return true;
+}
+
+// applyPreemptions (gang_scheduler.go:268-273) + MarkJobPreempted (scheduling.go:508-516)
+DEV void applyPreemptions(Dev& d, Ctl& c) {
+  for (int i = 0; i < c.preCount; i++) {
+    int p = c.preList[i];
+    d.jcStagedBy[p] = -1;
+    if (!d.jcPreempted[p]) { d.jcPreempted[p] = 1; if (d.rs->hasFpLimiter) d.rs->fpTokens -= 1.0; }
+  }
+  c.preCount = 0;
+}
+DEV void unstagePreemptions(Dev& d, Ctl& c) { for (int i = 0; i < c.preCount; i++) d.jcStagedBy[c.preList[i]] = -1; c.preCount = 0; }
+
+// tryScheduleGang (gang_scheduler.go:229-262)
+DEV bool tryGang(Dev& d, Ctl& c, int ref, int* reason) {
+  c.preCount = 0;
+  txnBegin(d, c.txn);
+  bool ok = scheduleMany(d, c, ref);
+  *reason = 0;
+  if (!ok) *reason = gcCount(d, ref) > 1 ? ASCHED_REASON_GANG_DOES_NOT_FIT : ASCHED_REASON_JOB_DOES_NOT_FIT;
+  if (ok && !d.rs->error) { txnCommit(d, c.txn); applyPreemptions(d, c); }
+  else { txnAbort(d, c.txn); unstagePreemptions(d, c); }
+  return ok;
+}
+DEV void fitOf(Dev& d, int ref, int* num, double* mean) {  // gctx.Fit (context/gang.go:94-110)
+  int n = 0; int32_t tot = 0;
+  int cnt = gcCount(d, ref);
+  for (int k = 0; k < cnt; k++) { int j = gcJob(d, ref, k); if (!(d.jcHasPctx[j] && d.pcNode[j] >= 0)) continue; n++; tot += d.pcPap[j]; }
+  *num = n; *mean = n == 0 ? (double)tot : (double)tot / (double)n;
+}
+// host-built table of uniformity label values: uniOff[label slot], uniVals[] = labelMask ids in ascending value order
+struct UniTable { const int32_t* slotOfLabel; const int32_t* off; int nLabels; };
+// trySchedule (gang_scheduler.go:150-227).  jGangUni[job] holds the label *slot* (-1 none, -2 label not indexed).
+DEV bool trySchedule(Dev& d, Ctl& c, int ref, int* reason, const int32_t* uniOff) {
+  int j0 = gcJob(d, ref, 0);
+  int slot = d.jGang[j0] >= 0 ? d.jGangUni[j0] : -1;
+  if (slot == -1) return tryGang(d, c, ref, reason);
+  if (slot == -2) { *reason = ASCHED_REASON_UNIFORMITY_LABEL_NOT_INDEXED; return false; }
+  int v0 = uniOff[slot], v1 = uniOff[slot + 1];
+  if (v1 == v0) { *reason = ASCHED_REASON_NO_NODES_WITH_UNIFORMITY_LABEL; return false; }
+  int cnt = gcCount(d, ref);
+  bool haveBest = false; int bestValue = -1, bestNum = 0; double bestMean = 0;
+  for (int v = v0; v < v1; v++) {  // ascending interned value (the reference iterates a Go map: order unspecified)
+    for (int k = 0; k < cnt; k++) d.jcUniValue[gcJob(d, ref, k)] = v;
+    c.preCount = 0;
+    txnBegin(d, c.txn);
+    bool ok = scheduleMany(d, c, ref);
+    *reason = 0;
+    if (!ok) *reason = cnt > 1 ? ASCHED_REASON_GANG_DOES_NOT_FIT : ASCHED_REASON_JOB_DOES_NOT_FIT;
+    if (d.rs->error) { txnAbort(d, c.txn); return false; }
+    if (ok) {
+      int num; double mean; fitOf(d, ref, &num, &mean);
+      if (num == cnt && mean == (double)ASCHED_MIN_PRIORITY) { txnCommit(d, c.txn); applyPreemptions(d, c); *reason = 0; return true; }
+      bool better = !haveBest || (bestNum < num || (bestNum == num && bestMean > mean));
+      if (better) {
+        if (v == v1 - 1) { txnCommit(d, c.txn); applyPreemptions(d, c); *reason = 0; return true; }
+        haveBest = true; bestValue = v; bestNum = num; bestMean = mean;
+      }
+    }
+    txnAbort(d, c.txn); unstagePreemptions(d, c);
+  }
+  if (!haveBest) { *reason = ASCHED_REASON_GANG_UNIFORMITY_NO_FIT; return false; }
+  for (int k = 0; k < cnt; k++) d.jcUniValue[gcJob(d, ref, k)] = bestValue;
+  return tryGang(d, c, ref, reason);
+}
+
+DEV bool keyValid(Dev& d, int job) { return d.jcAssigned[job] < 0 && d.jcUniValue[job] < 0; }  // jctx.SchedulingKey (context/job.go:104-109)
+
+DEV void failJob(Dev& d, int job, int reason) {  // jctx.Fail (context/job.go:115-121)
+  d.jcReason[job] = reason;
+  if (d.jcHasPctx[job]) { d.pcNode[job] = -1; d.pcMethod[job] = ASCHED_METHOD_NONE; }
+}
+
+// GangScheduler.Schedule incl. deferred bookkeeping (gang_scheduler.go:46-148)
+DEV bool gangSchedule(Dev& d, Ctl& c, int ref, int* reason, const int32_t* uniOff) {
+  *reason = 0;
+  bool allEv = gcAllEvicted(d, ref);
+  if (!allEv) {
+    int r = checkRound(d);  // returns BEFORE the deferred bookkeeping is registered (:102-106)
+    if (r) { *reason = r; return false; }
+  }
+  sctxAddGang(d, ref);
+  bool ok = false;
+  int r = 0;
+  if (!allEv) r = checkJob(d, ref);
+  if (r) *reason = r;
+  else ok = trySchedule(d, c, ref, reason, uniOff);
+  if (d.rs->error) return false;
+  int cnt = gcCount(d, ref), q = gcQueue(d, ref);
+  if (ok && !allEv) {  // :118-123
+    reserveN(&d.rs->globalTokens, d.rs->globalBurst, d.rs->globalRateInf, cnt);
+    reserveN(&d.qTokens[q], d.qBurst[q], d.qRateInf[q], cnt);
+  }
+  if (ok) {  // updateGangSchedulingContextOnSuccess :46-61
+    for (int k = 0; k < cnt; k++) { int j = gcJob(d, ref, k); if (d.jcReason[j] != 0) sctxEvictJob(d, j); }
+    return true;
+  }
+  sctxEvictGang(d, ref);  // updateGangSchedulingContextOnFailure :63-98
+  for (int k = 0; k < cnt; k++) failJob(d, gcJob(d, ref, k), *reason);
+  sctxAddGang(d, ref);
+  if (!c.skipKeyCheck && cnt == 1 && isPropertyOfGang(*reason)) {
+    int j = gcJob(d, ref, 0);
+    if (keyValid(d, j)) {
+      int s = d.jShape[j];
+      if (!d.unfeasible[s]) { d.unfeasible[s] = 1; d.unfeasibleReason[s] = *reason; d.rs->numUnfeasible++; }
+    }
+  }
+  return false;
+}
+
+// ------------------------------------------------------------------------------------------------
+// job / gang iterators (is/scheduling/jobiteration.go, queue_scheduler.go:306-444)
+DEV void resetJctxForQueued(Dev& d, int job) {  // JobSchedulingContextFromJob (context/job.go:149-158)
+  d.jcEvicted[job] = 0; d.jcAssigned[job] = -1; d.jcReason[job] = 0; d.jcHasPctx[job] = 0;
+  d.jcGangCard[job] = d.jGang[job] >= 0 ? d.jGangCard[job] : 1; d.jcUniValue[job] = -1; d.jcStagedBy[job] = -1;
+}
+DEV int jobItNext(Dev& d, int q, bool withQueued) {  // MultiJobsIterator(evicted, queued) :179-228
+  if (d.itStage[q] == 0) {
+    if (d.itEi[q] < d.evOff[q + 1]) return d.evList[d.itEi[q]++];
+    d.itStage[q] = 1;
+  }
+  if (d.itJobOnlyEv[q] || !withQueued) return -1;
+  if (d.itQi[q] < d.queuedOff[q + 1]) { int job = d.queuedJobs[d.itQi[q]++]; resetJctxForQueued(d, job); return job; }
+  return -1;
+}
+DEV void gangItOnlyEvicted(Dev& d, int q) {  // :338-350
+  if (d.itGangOnlyEv[q]) return;
+  d.itGangOnlyEv[q] = 1; d.itJobOnlyEv[q] = 1;
+  int nx = d.itNext[q];
+  if (nx != -1 && !gcAllEvicted(d, nx)) { d.itStashed[q] = nx; d.itNext[q] = -1; }
+}
+DEV void gangItResume(Dev& d, int q) {  // :352-361
+  if (!d.itGangOnlyEv[q]) return;
+  d.itGangOnlyEv[q] = 0; d.itJobOnlyEv[q] = 0; d.itStage[q] = 0;
+  d.itNext[q] = d.itStashed[q]; d.itStashed[q] = -1;
+}
+DEV int gangItPeek(Dev& d, Ctl& c, int q, bool withQueued, uint32_t maxLookback, bool skipKnown) {  // :376-432
+  if (d.itNext[q] != -1) return d.itNext[q];
+  for (;;) {
+    if (maxLookback != 0 && !d.itGangOnlyEv[q] && (uint32_t)d.itJobsSeen[q] >= maxLookback) gangItOnlyEvicted(d, q);
+    int job = jobItNext(d, q, withQueued);
+    if (job < 0) return -1;
+    if (!d.jcEvicted[job]) d.itJobsSeen[q]++;
+    if (skipKnown && d.rs->numUnfeasible > 0 && keyValid(d, job)) {  // :398-413
+      int s = d.jShape[job];
+      if (d.unfeasible[s]) {
+        d.jcReason[job] = d.unfeasibleReason[s];
+        d.jcHasPctx[job] = 1; d.pcNode[job] = -1; d.pcMethod[job] = ASCHED_METHOD_NONE;
+        sctxAddJob(d, job);
+        d.jcReason[job] = ASCHED_REASON_SKIPPED_UNFEASIBLE_KEY;
+        continue;
+      }
+    }
+    int g = d.jGang[job];
+    if (g >= 0) {
+      int k = d.gangSeen[g];
+      d.gangArr[d.gangOff[g] + k] = job;
+      d.gangSeen[g] = k + 1;
+      if (k + 1 == d.jcGangCard[job]) {
+        int64_t* tot = d.gangTotal + (size_t)g * d.cfg.R;
+        bool allEv = true;
+        for (int r = 0; r < d.cfg.R; r++) tot[r] = 0;
+        for (int i = 0; i <= k; i++) { int m = d.gangArr[d.gangOff[g] + i]; vadd(d, tot, JREQ(d, m), +1); allEv = allEv && d.jcEvicted[m]; }
+        d.gangAllEvicted[g] = allEv;
+        d.itNext[q] = -(g + 2);
+        return d.itNext[q];
+      }
+    } else {
+      d.itNext[q] = job;
+      return job;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CostBasedCandidateGangIterator (queue_scheduler.go:446-699)
+struct PassCfg { bool withQueued; uint32_t maxLookback; bool skipKnown; };
+
+DEV void updateItem(Dev& d, Ctl& c, int q, const PassCfg& pc) {  // updatePQItem :636-686
+  d.pqGctx[q] = -1; d.pqProposed[q] = d.pqCurrent[q] = d.pqSize[q] = 0;
+  int ref = gangItPeek(d, c, q, pc.withQueued, pc.maxLookback, pc.skipKnown);
+  if (ref == -1) return;
+  d.pqGctx[q] = ref;
+  const DevCfg& cf = d.cfg;
+  int64_t alloc[MAXR], withGang[MAXR];
+  const int64_t* base = c.useReplayAlloc ? QV(d.replayAlloc, q) : QV(d.qAlloc, q);
+  const int64_t* tot = gcTotal(d, ref);
+  for (int r = 0; r < cf.R; r++) { alloc[r] = base[r] + QV(d.qPenalty, q)[r]; withGang[r] = alloc[r] + tot[r]; }
+  double w = d.qWeight[q];
+  d.pqProposed[q] = drf(d, withGang) / w;
+  d.pqCurrent[q] = drf(d, alloc) / w;
+  d.pqSize[q] = drf(d, tot) * w;
+  int32_t pcp = INT32_MAX, sp = INT32_MAX;
+  int cnt = gcCount(d, ref);
+  for (int k = 0; k < cnt; k++) {
+    int j = gcJob(d, ref, k);
+    int32_t p = cf.pcPriority[d.jPc[j]];
+    int32_t s = p;
+    if (d.jcHasPctx[j]) s = d.pcSap[j];
+    else if (d.jNode0[j] >= 0) s = d.jRunPrio[j];
+    if (s < sp) sp = s;
+    if (p < pcp) pcp = p;
+  }
+  d.pqPcPrio[q] = pcp; d.pqSchedPrio[q] = sp;
+}
+DEV void updateAndPush(Dev& d, Ctl& c, int q, const PassCfg& pc) { updateItem(d, c, q, pc); d.pqInHeap[q] = d.pqGctx[q] != -1; }
+
+// QueueCandidateGangIteratorPQ.Less (queue_scheduler.go:738-798); single pool => never "away"
+DEV bool pqLess(Dev& d, const Ctl& c, int a, int b) {
+  if (c.compareSchedPrio) { if (d.pqSchedPrio[a] != d.pqSchedPrio[b]) return d.pqSchedPrio[a] > d.pqSchedPrio[b]; }
+  else { if (d.pqPcPrio[a] != d.pqPcPrio[b]) return d.pqPcPrio[a] > d.pqPcPrio[b]; }
+  double pa = d.pqProposed[a], pb = d.pqProposed[b], ba = d.pqBudget[a], bb = d.pqBudget[b];
+  if (c.preferLarge) {
+    if (pa <= ba && pb <= bb) {
+      double ca = d.pqCurrent[a], cb = d.pqCurrent[b];
+      if (ca == cb && d.pqSize[a] != d.pqSize[b]) return d.pqSize[a] > d.pqSize[b];
+      if (ca != cb) return ca < cb;
+    } else if (pa > ba && pb > bb) {
+      if (pa != pb) return pa < pb;
+    } else if (pa <= ba) return true;
+    else if (pb <= bb) return false;
+  } else {
+    if (pa != pb) return pa < pb;
+  }
+  return d.qNameRank[a] < d.qNameRank[b];
+}
+DEV int pqTop(Dev& d, const Ctl& c);  // argmin over items with pqInHeap (Less is a strict total order => heap top)
+
+DEV void costItOnlyEvicted(Dev& d, Ctl& c, const PassCfg& pc) {  // :521-544
+  if (!c.onlyEvicted) {
+    for (int q = 0; q < d.cfg.Q; q++) {
+      if (!d.pqInHeap[q]) continue;
+      gangItOnlyEvicted(d, q);
+      updateItem(d, c, q, pc);
+      if (d.pqGctx[q] == -1) d.pqInHeap[q] = 0;
+    }
+  }
+  c.onlyEvicted = 1;
+}
+DEV void costItOnlyEvictedForQueue(Dev& d, Ctl& c, int q, const PassCfg& pc) {  // :546-566
+  if (!c.onlyEvicted && !d.onlyEvByQueue[q] && d.pqInHeap[q]) {
+    gangItOnlyEvicted(d, q);
+    updateItem(d, c, q, pc);
+    if (d.pqGctx[q] == -1) d.pqInHeap[q] = 0;
+  }
+  d.onlyEvByQueue[q] = 1;
+}
+DEV void costItResume(Dev& d, Ctl& c, const PassCfg& pc) {  // :572-591
+  if (!c.onlyEvicted) return;
+  c.onlyEvicted = 0;
+  for (int q = 0; q < d.cfg.Q; q++) {
+    d.pqInHeap[q] = 0;
+    if (!d.onlyEvByQueue[q]) gangItResume(d, q);
+    d.pqBudget[q] = d.qDc[q] / d.qWeight[q];
+    updateAndPush(d, c, q, pc);
+  }
+}
+DEV void costItClear(Dev& d, Ctl& c, int top, const PassCfg& pc) {  // :595-606
+  if (top < 0) return;
+  d.pqInHeap[top] = 0;
+  d.itNext[top] = -1;
+  updateAndPush(d, c, top, pc);
+}
+
+DEV void passInit(Dev& d, Ctl& c, const PassCfg& pc) {
+  int Q = d.cfg.Q;
+  for (int q = 0; q < Q; q++) {
+    d.itEi[q] = d.evOff[q]; d.itQi[q] = d.queuedOff[q]; d.itStage[q] = 0; d.itJobsSeen[q] = 0; d.itNext[q] = -1; d.itStashed[q] = -1;
+    d.itJobOnlyEv[q] = 0; d.itGangOnlyEv[q] = 0; d.onlyEvByQueue[q] = 0; d.pqInHeap[q] = 0;
+    d.pqBudget[q] = d.qDc[q] / d.qWeight[q];  // pushQueue :509-519
+  }
+  c.onlyEvicted = 0;
+  for (int q = 0; q < Q; q++) updateAndPush(d, c, q, pc);
+}
+
+// QueueScheduler.Schedule (queue_scheduler.go:94-304)
+DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff) {
+  bool limitHit = false, resumed = false;
+  for (;;) {
+    if (d.rs->error) return;
+    if (!limitHit && d.rs->hasFpLimiter && d.rs->fpTokens < 1) { limitHit = true; costItOnlyEvicted(d, c, pc); }
+    int top = pqTop(d, c);
+    int ref = top >= 0 ? d.pqGctx[top] : -1;
+    if (ref == -1) {
+      if (limitHit && !resumed && d.rs->terminationReason == 0) { resumed = true; costItResume(d, c, pc); continue; }
+      break;
+    }
+    int cnt = gcCount(d, ref);
+    if (cnt == 0) { costItClear(d, c, top, pc); continue; }
+    bool hasPre = false;
+    for (int k = 0; k < cnt; k++) if (d.jcPreempted[gcJob(d, ref, k)]) hasPre = true;
+    if (hasPre) { costItClear(d, c, top, pc); continue; }
+    int reason;
+    bool ok = gangSchedule(d, c, ref, &reason, uniOff);
+    if (d.rs->error) return;
+    costItClear(d, c, top, pc);
+    if (ok) {
+      // scheduled jobs are recorded per job (pcNode >= 0); the PQS bookkeeping below reads them
+      for (int k = 0; k < cnt; k++) {
+        int j = gcJob(d, ref, k);
+        if (d.jcHasPctx[j] && d.pcNode[j] >= 0) {  // pqs.go:160-166 / :213-220
+          if (d.inPreempted[j]) d.inPreempted[j] = 0; else d.inScheduled[j] = 1;
+          d.inSchedAndEvicted[j] = 0;
+        }
+      }
+    } else if (isTerminal(reason)) {
+      d.rs->terminationReason = reason;
+      costItOnlyEvicted(d, c, pc);
+    } else if (isQueueTerminal(reason)) {
+      costItOnlyEvictedForQueue(d, c, gcQueue(d, ref), pc);
+    }
+    d.rs->loopIterations++;
+  }
+  if (d.rs->terminationReason == 0) d.rs->terminationReason = ASCHED_REASON_NO_REMAINING_CANDIDATES;
+}
+
+// addEvictedJobsToNodeDb (preempting_queue_scheduler.go:589-639): replay the DRF order over the evicted gangs
+DEV void replayEvicted(Dev& d, Ctl& c) {
+  int Q = d.cfg.Q;
+  for (int q = 0; q < Q; q++) for (int r = 0; r < d.cfg.R; r++) QV(d.replayAlloc, q)[r] = QV(d.qAlloc, q)[r];
+  int savedCmp = c.compareSchedPrio;
+  c.compareSchedPrio = 0; c.useReplayAlloc = 1;
+  PassCfg pc{false, 0, false};
+  passInit(d, c, pc);
+  int i = 0;
+  for (;;) {
+    int top = pqTop(d, c);
+    int ref = top >= 0 ? d.pqGctx[top] : -1;
+    if (ref == -1) break;
+    int cnt = gcCount(d, ref);
+    for (int k = 0; k < cnt; k++) { evTabInsert(d, i, gcJob(d, ref, k)); i++; }
+    vadd(d, QV(d.replayAlloc, gcQueue(d, ref)), gcTotal(d, ref), +1);
+    costItClear(d, c, top, pc);
+  }
+  c.useReplayAlloc = 0; c.compareSchedPrio = savedCmp;
+}

@@ -1,0 +1,340 @@
+// round_run.h — the bulk (data-parallel) phases of PreemptingQueueScheduler.Schedule and the command
+// dispatcher of the control kernel.  Bulk phases are per-element functions run by every thread of the
+// workgroup through wgBulk(); cross-job sums use int64 atomics (integer => order independent => exact).
+#pragma once
+#include "round_ctl.h"
+
+enum BulkKind {
+  B_RESET_GANGSEEN = 1, B_FILTER1, B_NODE_OVER, B_FILTER3, B_GANG_CLOSURE, B_EVICT_APPLY1, B_EVICT_APPLY3, B_KEYS_ALL,
+  B_UNBIND, B_RESET_EVTAB, B_CLEAR_UNFEASIBLE, B_INIT_ALLOC, B_POPULATE, B_RESET_JOBS, B_GATHER_SCHED, B_GATHER_PRE,
+};
+
+DEV void wgBulk(Dev& d, int kind, int n);  // every element i in [0,n) through bulkElem(), then a workgroup barrier
+DEV int wgCompactFlagged(Dev& d, const int32_t* order, const int32_t* segOff, int nseg, int n, const uint8_t* flag, int32_t* dst, int32_t* outSegOff);
+DEV int wgCompactIota(Dev& d, int n, const uint8_t* flag, int32_t* dst);
+
+DEV void atomicMarkAllocatable(Dev& d, int n, int32_t cutoff, const int64_t* req, int sign) {
+  const DevCfg& c = d.cfg;
+  for (int l = 0; l < c.P; l++)
+    if (c.prios[l] <= cutoff)
+      for (int r = 0; r < c.R; r++) if (req[r]) atomicAddI64(&AL(d, l, r, n), sign * req[r]);
+}
+DEV void atomicVadd(Dev& d, int64_t* a, const int64_t* b, int sign) { for (int r = 0; r < d.cfg.R; r++) if (b[r]) atomicAddI64(&a[r], sign * b[r]); }
+
+// Evictor.Evict body for one job (is/scheduling/eviction.go:245-260) + sctx.EvictJob (context/scheduling.go:551-572),
+// order-independent form.  phase3: PQS bookkeeping of pqs.go:182-195.
+DEV void evictApply(Dev& d, int j, bool phase3) {
+  if (!d.evFlag[j]) return;
+  int n = d.jobNode[j];
+  if (d.schedAtPrio[j] == NO_PRIORITY) { raise(d, ASCHED_ERR_INTERNAL, 800); return; }  // EvictJobsFromNode nodedb.go:1085-1088
+  const int64_t* req = JREQ(d, j);
+  d.jobEvictedOnNode[j] = 1;  // Node.EvictJob node.go:449-474
+  atomicMarkAllocatable(d, n, d.jobCutoff[j], req, +1);
+  atomicMarkAllocatable(d, n, ASCHED_EVICTED_PRIORITY, req, -1);
+  // fresh jctx pinned to the node (eviction.go:246-253)
+  d.jcEvicted[j] = 1; d.jcAssigned[j] = n; d.jcReason[j] = 0; d.jcHasPctx[j] = 0; d.jcUniValue[j] = -1; d.jcStagedBy[j] = -1;
+  int g = d.jGang[j];
+  d.jcGangCard[j] = g >= 0 ? d.gangOff[g + 1] - d.gangOff[g] : 1;  // setEvictedGangCardinality pqs.go:462-483
+  // sctx.EvictJob
+  int q = d.jQueue[j], pc = d.jPc[j];
+  uint8_t f = d.jobFlags[j];
+  bool sched = f & F_SUCCESSFUL, resched = f & F_RESCHEDULED;
+  if (sched || resched) {
+    if (sched) { atomicVadd(d, QPV(d.qSchedByPc, q, pc), req, -1); f &= ~F_SUCCESSFUL; }
+    if (resched) f &= ~F_RESCHEDULED;
+  } else {
+    atomicVadd(d, QPV(d.qEvictedByPc, q, pc), req, +1);
+    f |= F_EVICTED;
+  }
+  atomicVadd(d, QPV(d.qAllocByPc, q, pc), req, -1);
+  atomicVadd(d, QV(d.qAlloc, q), req, -1);
+  if (sched) { atomicVadd(d, d.rs->scheduled, req, -1); atomicAddI32(&d.rs->numScheduledJobs, -1); }
+  else { atomicVadd(d, d.rs->evicted, req, +1); atomicAddI32(&d.rs->numEvictedJobs, 1); }
+  atomicVadd(d, d.rs->allocated, req, -1);
+  d.jobFlags[j] = f;
+  if (!phase3) { d.inPreempted[j] = 1; d.preemptedNode[j] = n; }
+  else if (d.inScheduled[j]) { d.inScheduled[j] = 0; d.inSchedAndEvicted[j] = 1; d.preemptedNode[j] = n; }
+  else { d.inPreempted[j] = 1; d.preemptedNode[j] = n; }
+}
+
+DEV void bulkElem(Dev& d, int kind, int i) {
+  const DevCfg& c = d.cfg;
+  switch (kind) {
+    case B_RESET_GANGSEEN: d.gangSeen[i] = 0; break;
+    case B_FILTER1: {  // NewNodeEvictor job filter (pqs.go:101-136)
+      int n = d.jobNode[i], q = d.jQueue[i];
+      d.evFlag[i] = n >= 0 && !d.jobEvictedOnNode[i] && q >= 0 && q < c.Q && c.pcPreemptible[d.jPc[i]] && d.qEvictable[q];
+    } break;
+    case B_NODE_OVER: {  // NewOversubscribedEvictor node filter (eviction.go:145-157)
+      int m = 0;
+      for (int l = 0; l < c.P; l++) {
+        if (c.prios[l] == ASCHED_EVICTED_PRIORITY) continue;
+        for (int r = 0; r < c.R; r++) if (AL(d, l, r, i) < 0) { m |= 1 << l; break; }
+      }
+      d.nodeOver[i] = m;
+    } break;
+    case B_FILTER3: {  // NewOversubscribedEvictor job filter (eviction.go:158-178)
+      int n = d.jobNode[i], q = d.jQueue[i];
+      bool f = n >= 0 && !d.jobEvictedOnNode[i] && q >= 0 && q < c.Q && c.pcPreemptible[d.jPc[i]] && d.schedAtPrio[i] != NO_PRIORITY;
+      if (f) { int l = levelOf(c, d.schedAtPrio[i]); f = l >= 0 && ((d.nodeOver[n] >> l) & 1); }
+      d.evFlag[i] = f;
+    } break;
+    case B_GANG_CLOSURE: {  // evictGangs (pqs.go:357-424): a partially evicted gang is evicted entirely
+      bool any = false;
+      for (int k = d.gangOff[i]; k < d.gangOff[i + 1]; k++) any = any || d.evFlag[d.gangJobs[k]];
+      if (any) for (int k = d.gangOff[i]; k < d.gangOff[i + 1]; k++) { int j = d.gangJobs[k]; if (d.jobNode[j] >= 0 && !d.jobEvictedOnNode[j]) d.evFlag[j] = 1; }
+    } break;
+    case B_EVICT_APPLY1: evictApply(d, i, false); break;
+    case B_EVICT_APPLY3: evictApply(d, i, true); break;
+    case B_KEYS_ALL: updateKeys(d, i); break;
+    case B_UNBIND: {  // unbindJobs (pqs.go:775-798): RemoveJob of preempted ∪ scheduled-and-evicted on their node
+      if (!(d.inPreempted[i] || d.inSchedAndEvicted[i])) break;
+      int n = d.preemptedNode[i];
+      if (d.jobNode[i] != n) break;  // RemoveJob of an unknown job is a no-op
+      const int64_t* req = JREQ(d, i);
+      if (d.jobEvictedOnNode[i]) atomicMarkAllocatable(d, n, ASCHED_EVICTED_PRIORITY, req, +1);
+      else atomicMarkAllocatable(d, n, d.jobCutoff[i], req, +1);
+      d.jobEvictedOnNode[i] = 0; d.jobNode[i] = -1;
+    } break;
+    case B_RESET_EVTAB: if (d.evTabAlive[i]) d.evIndexOfJob[d.evTabJob[i]] = -1; d.evTabAlive[i] = 0; break;
+    case B_GATHER_SCHED: { int j = d.resJob[i]; d.resNode[i] = d.pcNode[j]; d.resPrio[i] = d.schedAtPrio[j]; d.resMethod[i] = d.pcMethod[j]; } break;
+    case B_GATHER_PRE: { int j = d.resPreJob[i]; d.resPreNode[i] = d.preemptedNode[j]; } break;
+    case B_CLEAR_UNFEASIBLE: d.unfeasible[i] = 0; break;
+    case B_INIT_ALLOC: {  // fresh NodeDb (scheduling_algo.go:517): AllocatableByPriority[p] = allocatable (node.go:79-85)
+      for (int l = 0; l < c.P; l++) for (int r = 0; r < c.R; r++)
+        AL(d, l, r, i) = d.alloc0 ? d.alloc0[((size_t)l * c.R + r) * c.Npad + i] : d.allocatable[(size_t)r * c.Npad + i];
+    } break;
+    case B_RESET_JOBS: {
+      d.schedAtPrio[i] = NO_PRIORITY; d.jobNode[i] = -1; d.jobCutoff[i] = 0; d.jobEvictedOnNode[i] = 0; d.jobFlags[i] = 0;
+      d.jcEvicted[i] = 0; d.jcAssigned[i] = -1; d.jcReason[i] = 0; d.jcHasPctx[i] = 0; d.pcNode[i] = -1; d.pcSap[i] = 0; d.pcPap[i] = ASCHED_MIN_PRIORITY;
+      d.pcMethod[i] = 0; d.jcGangCard[i] = d.jGang[i] >= 0 ? d.jGangCard[i] : 1; d.jcPreempted[i] = 0; d.jcUniValue[i] = -1; d.jcStagedBy[i] = -1;
+      d.inPreempted[i] = d.inScheduled[i] = d.inSchedAndEvicted[i] = 0; d.preemptedNode[i] = -1; d.evFlag[i] = 0;
+      d.evTabAlive[i] = 0; d.evIndexOfJob[i] = -1;
+    } break;
+    case B_POPULATE: {  // populateNodeDb: bind every running job (nodedb.go:57-75, scheduling_algo.go:1019-1098)
+      int n = d.jNode0[i];
+      if (n < 0) break;
+      int32_t prio = d.jRunPrio[i];
+      int32_t cutoff = cutoffFor(d, i, prio);
+      atomicMarkAllocatable(d, n, cutoff, JREQ(d, i), -1);
+      d.jobNode[i] = n; d.jobCutoff[i] = cutoff; d.schedAtPrio[i] = prio;
+    } break;
+  }
+}
+
+// SchedulingContext.updateFairShares (context/scheduling.go:262-342): float64, queues in name order, this exact operation order.
+// Scratch: pqProposed = constrainedDemandShare, pqCurrent = spareShare, pqInHeap = achievedDemand, itNext = name order.
+DEV void updateFairShares(Dev& d, const double* givenCds) {
+  const DevCfg& cf = d.cfg;
+  int Q = cf.Q;
+  double weightSum = 0;
+  bool totalZero = true;
+  for (int r = 0; r < cf.R; r++) if (cf.totalResources[r] != 0) totalZero = false;
+  for (int q = 0; q < Q; q++) weightSum += d.qWeight[q];  // sctx.WeightSum, accumulated in AddQueueSchedulingContext order
+  for (int q = 0; q < Q; q++) d.itNext[d.qNameRank[q]] = q;  // name ranks are a permutation of 0..Q-1
+  for (int q = 0; q < Q; q++) {
+    d.pqProposed[q] = givenCds ? givenCds[q] : (totalZero ? 1.0 : drf(d, QV(d.qDemand, q)));
+    d.qFair[q] = d.qWeight[q] / weightSum; d.qDc[q] = 0; d.qUc[q] = 0; d.pqCurrent[q] = 0; d.pqInHeap[q] = 0;
+  }
+  double unallocated = 1.0;
+  for (int it = 0; it < 10 && unallocated > 0.01; it++) {
+    double totalWeight = 0.0;
+    for (int k = 0; k < Q; k++) { int q = d.itNext[k]; if (!d.pqInHeap[q]) totalWeight += d.qWeight[q]; }
+    for (int k = 0; k < Q; k++) {
+      int q = d.itNext[k];
+      double tw = totalWeight;
+      if (d.pqInHeap[q]) tw += d.qWeight[q];
+      d.qUc[q] += (d.qWeight[q] / tw) * (unallocated - d.pqCurrent[q]);
+    }
+    if (totalWeight <= 0.0) break;
+    for (int k = 0; k < Q; k++) { int q = d.itNext[k]; if (!d.pqInHeap[q]) d.qDc[q] += (d.qWeight[q] / totalWeight) * unallocated; }
+    unallocated = 0.0;
+    for (int k = 0; k < Q; k++) {
+      int q = d.itNext[k];
+      double s = d.qDc[q] - d.pqProposed[q];
+      if (s > 0) { d.qDc[q] = d.pqProposed[q]; d.pqInHeap[q] = 1; d.pqCurrent[q] = s; unallocated += s; }
+      else d.pqCurrent[q] = 0;
+    }
+  }
+  for (int q = 0; q < Q; q++) { d.itNext[q] = -1; d.pqInHeap[q] = 0; }
+}
+
+// PreemptingQueueScheduler.evict (pqs.go:291-353) for an evictor whose job filter has been evaluated into evFlag
+DEV int pqsEvict(Dev& d, Ctl& c, bool phase3) {
+  wgBulk(d, B_GANG_CLOSURE, d.cfg.G);
+  wgBulk(d, phase3 ? B_EVICT_APPLY3 : B_EVICT_APPLY1, d.cfg.M);
+  wgBulk(d, B_KEYS_ALL, d.cfg.N);
+  // InMemoryJobRepository.EnqueueMany (jobiteration.go:85-108): per-queue lists in SchedulingOrderCompare order ==
+  // order-preserving compaction of the pre-sorted job order
+  int n = wgCompactFlagged(d, d.ordAll, d.ordAllOff, d.cfg.Q, d.ordAllOff[d.cfg.Q], d.evFlag, d.evList, d.evOff);
+  d.rs->numEvictedList = n;
+  wgBulk(d, B_RESET_EVTAB, d.rs->evictedTableSize);  // nodeDb.Reset() (nodedb.go:299-313)
+  d.rs->evictedTableSize = 0;
+  wgBulk(d, B_RESET_GANGSEEN, d.cfg.G);
+  replayEvicted(d, c);  // addEvictedJobsToNodeDb
+  return n;
+}
+
+DEV void schedulePass(Dev& d, Ctl& c, bool withQueued, bool skipKey, bool cmpPrio) {  // pqs.schedule (pqs.go:712-772)
+  wgBulk(d, B_CLEAR_UNFEASIBLE, d.cfg.S);
+  d.rs->numUnfeasible = 0;
+  wgBulk(d, B_RESET_GANGSEEN, d.cfg.G);
+  c.skipKeyCheck = skipKey; c.compareSchedPrio = cmpPrio; c.useReplayAlloc = 0;
+  PassCfg pc{withQueued, d.cfg.maxLookback, true};
+  passInit(d, c, pc);
+  queueSchedule(d, c, pc, d.uniOff);
+}
+
+// PreemptingQueueScheduler.Schedule (pqs.go:86-289)
+DEV void runRound(Dev& d, Ctl& c) {
+  const DevCfg& cf = d.cfg;
+  for (int q = 0; q < cf.Q; q++) {  // balance-evictor filter inputs are the start-of-round queue allocations (pqs.go:124-134)
+    double actual = drf(d, QV(d.qAlloc, q));
+    double fair = d.qDc[q] > d.qFair[q] ? d.qDc[q] : d.qFair[q];  // math.Max
+    if (cf.protectUncapped) fair = d.qUc[q];
+    double frac = actual / fair;
+    d.qEvictable[q] = !(frac <= cf.protectedFraction);
+  }
+  wgBulk(d, B_FILTER1, cf.M);
+  int n1 = pqsEvict(d, c, false);
+  schedulePass(d, c, true, false, false);
+  if (d.rs->error) return;
+  int firstTermination = d.rs->terminationReason;
+  wgBulk(d, B_NODE_OVER, cf.N);
+  wgBulk(d, B_FILTER3, cf.M);
+  int n3 = pqsEvict(d, c, true);
+  if (n3 > 0) schedulePass(d, c, false, true, true);
+  if (d.rs->error) return;
+  wgBulk(d, B_UNBIND, cf.M);
+  wgBulk(d, B_KEYS_ALL, cf.N);
+  d.rs->terminationReason = firstTermination;
+  d.cmdIO[0] = n1; d.cmdIO[1] = n3;
+  d.cmdIO[2] = wgCompactIota(d, cf.M, d.inScheduled, d.resJob);
+  d.cmdIO[3] = wgCompactIota(d, cf.M, d.inPreempted, d.resPreJob);
+  wgBulk(d, B_GATHER_SCHED, d.cmdIO[2]);
+  wgBulk(d, B_GATHER_PRE, d.cmdIO[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// control-kernel commands (the NodeDb-level entry points of the C ABI run through the same device code as the round)
+enum Cmd {
+  CMD_PREPARE = 1, CMD_ROUND, CMD_QUEUES_ONLY, CMD_GANG_SCHEDULE, CMD_SELECT, CMD_SCHEDULE_MANY, CMD_BIND, CMD_EVICT, CMD_UNBIND,
+  CMD_ADD_EVICTED, CMD_RESET_EVICTED, CMD_TXN_BEGIN, CMD_TXN_COMMIT, CMD_TXN_ABORT, CMD_FIT_BATCH, CMD_UPSERT_RESET, CMD_RESET_JOBS,
+};
+// cmdIO layout: [0..15] results, [16..] arguments
+#define ARG(k) d.cmdIO[16 + (k)]
+
+DEV void setupPinned(Dev& d, int job, int pinned) {
+  resetJctxForQueued(d, job);
+  if (pinned >= 0) {
+    d.jcEvicted[job] = 1; d.jcAssigned[job] = pinned;
+    int g = d.jGang[job];
+    d.jcGangCard[job] = g >= 0 ? d.gangOff[g + 1] - d.gangOff[g] : 1;
+  }
+}
+
+DEV void runCommand(Dev& d, Ctl& c, int cmd) {
+  const DevCfg& cf = d.cfg;
+  switch (cmd) {
+    case CMD_UPSERT_RESET:  // nodes_upsert: node state only
+      wgBulk(d, B_INIT_ALLOC, cf.N);
+      wgBulk(d, B_KEYS_ALL, cf.N);
+      break;
+    case CMD_RESET_JOBS:
+      wgBulk(d, B_RESET_JOBS, cf.M);
+      d.rs->evictedTableSize = 0; d.rs->txnActive = 0; d.rs->undoCount = 0;
+      break;
+    case CMD_PREPARE:
+      wgBulk(d, B_INIT_ALLOC, cf.N);
+      wgBulk(d, B_RESET_JOBS, cf.M);
+      wgBulk(d, B_POPULATE, cf.M);
+      wgBulk(d, B_KEYS_ALL, cf.N);
+      d.rs->evictedTableSize = 0;
+      wgBulk(d, B_CLEAR_UNFEASIBLE, cf.S);
+      updateFairShares(d, (const double*)0);
+      break;
+    case CMD_ROUND: runRound(d, c); break;
+    case CMD_QUEUES_ONLY: {
+      // no evicted jobs: empty per-queue evicted segments
+      for (int q = 0; q <= cf.Q; q++) d.evOff[q] = 0;
+      schedulePass(d, c, true, false, false);
+      d.cmdIO[2] = wgCompactIota(d, cf.M, d.inScheduled, d.resJob);
+      d.cmdIO[3] = wgCompactIota(d, cf.M, d.jcPreempted, d.resPreJob);
+      wgBulk(d, B_GATHER_SCHED, d.cmdIO[2]);
+      wgBulk(d, B_GATHER_PRE, d.cmdIO[3]);
+    } break;
+    case CMD_GANG_SCHEDULE: {
+      int n = ARG(0);
+      int ref;
+      if (n == 1 && d.jGang[ARG(1)] < 0) { ref = ARG(1); resetJctxForQueued(d, ref); }
+      else {
+        int g = d.jGang[ARG(1)];
+        int64_t* tot = d.gangTotal + (size_t)g * cf.R;
+        for (int r = 0; r < cf.R; r++) tot[r] = 0;
+        for (int k = 0; k < n; k++) { int j = ARG(1 + k); resetJctxForQueued(d, j); d.gangArr[d.gangOff[g] + k] = j; vadd(d, tot, JREQ(d, j), +1); }
+        d.gangSeen[g] = n; d.gangAllEvicted[g] = 0;
+        ref = -(g + 2);
+      }
+      c.skipKeyCheck = 0;
+      int reason = 0;
+      bool ok = gangSchedule(d, c, ref, &reason, d.uniOff);
+      d.cmdIO[0] = ok; d.cmdIO[1] = reason;
+    } break;
+    case CMD_SELECT: {
+      int job = ARG(0);
+      setupPinned(d, job, ARG(1));
+      c.preCount = 0;
+      selectNodeForJob(d, c, job);
+      d.cmdIO[0] = c.preCount;
+      c.preCount = 0;
+    } break;
+    case CMD_SCHEDULE_MANY: {
+      int n = ARG(0);
+      // members are passed explicitly: use the scratch gang slot G (one past the real gangs)
+      int g = cf.G;
+      int64_t* tot = d.gangTotal + (size_t)g * cf.R;
+      for (int r = 0; r < cf.R; r++) tot[r] = 0;
+      for (int k = 0; k < n; k++) {
+        int j = ARG(1 + 2 * k), pin = ARG(2 + 2 * k);
+        if (!(pin >= 0 && d.evIndexOfJob[j] >= 0)) setupPinned(d, j, pin);  // reuse the evicted jctx when the job is in the evicted table
+        d.gangArr[d.gangOff[g] + k] = j;
+      }
+      d.gangSeen[g] = n;
+      c.preCount = 0;
+      if (!c.txn.active) d.rs->undoCount = 0;
+      bool ok = scheduleMany(d, c, -(g + 2));
+      if (!c.txn.active) d.rs->undoCount = 0;
+      d.cmdIO[0] = ok; d.cmdIO[1] = c.preCount;
+      for (int i = 0; i < c.preCount; i++) d.jcStagedBy[c.preList[i]] = -1;
+      c.preCount = 0;
+    } break;
+    case CMD_BIND: {
+      int job = ARG(0), n = ARG(1), prio = ARG(2);
+      if (addJob(d, n, job, cutoffFor(d, job, prio), c.txn.active) == 0) {
+        d.schedAtPrio[job] = prio;
+        updateKeys(d, n);
+        int e = d.evIndexOfJob[job];
+        if (e >= 0) evTabDelete(d, e, c.txn.active);
+      }
+    } break;
+    case CMD_EVICT: {
+      int job = ARG(0), n = ARG(1);
+      if (d.schedAtPrio[job] == NO_PRIORITY) { raise(d, ASCHED_ERR_INTERNAL, 801); break; }
+      if (evictJobOnNode(d, n, job) == 0) updateKeys(d, n);
+    } break;
+    case CMD_UNBIND: { removeJob(d, ARG(1), ARG(0), c.txn.active); updateKeys(d, ARG(1)); } break;
+    case CMD_ADD_EVICTED: {
+      int idx = ARG(0), job = ARG(1), n = ARG(2);
+      if (d.evIndexOfJob[job] >= 0) { raise(d, ASCHED_ERR_INTERNAL, 802); break; }
+      setupPinned(d, job, n);
+      evTabInsert(d, idx, job);
+    } break;
+    case CMD_RESET_EVICTED:
+      wgBulk(d, B_RESET_EVTAB, cf.M);
+      d.rs->evictedTableSize = 0;
+      break;
+    case CMD_TXN_BEGIN: txnBegin(d, c.txn); break;
+    case CMD_TXN_COMMIT: txnCommit(d, c.txn); break;
+    case CMD_TXN_ABORT: txnAbort(d, c.txn); break;
+  }
+}

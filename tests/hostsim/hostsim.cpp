@@ -1,0 +1,113 @@
+// hostsim.cpp — TEST INFRASTRUCTURE ONLY.
+//
+// Compiles the device control code (armada_amd/csrc/round_ctl.h, round_run.h) and the host marshalling
+// (asched_host.inc) for the CPU, replacing the workgroup primitives by serial loops.  Purpose: debug the
+// *logic* of the device code against the golden vectors in a container without a GPU.  It is never loaded
+// by armada_amd (the product loads only armada_amd/csrc/libarmada_sched.so, built by hipcc for gfx950) and
+// it proves nothing about the kernels' parallel primitives — the `-m gpu` tests do that on the MI355X.
+#define ASCHED_HOSTSIM 1
+#define ASCHED_PREFIX asched_
+#include <cstdlib>
+#include <string>
+#include <vector>
+#include "../../armada_amd/csrc/round_run.h"
+
+// ---- serial versions of the workgroup primitives
+DEV void atomicAddI64(int64_t* p, int64_t v) { *p += v; }
+DEV void atomicAddI32(int32_t* p, int32_t v) { *p += v; }
+DEV void atomicOrI32(int32_t* p, int32_t v) { *p |= v; }
+
+DEV int wgFirstFit(Dev& d, const ScanArgs& a) {
+  const DevCfg& c = d.cfg;
+  uint64_t best = ~0ull;
+  d.rs->numScans++;
+  for (int n = 0; n < c.N; n++) {
+    if (!((a.maskA[n >> 6] >> (n & 63)) & 1)) continue;
+    if (a.maskB && !((a.maskB[n >> 6] >> (n & 63)) & 1)) continue;
+    uint64_t k = KEY(d, a.level, n);
+    if (k >= best) continue;
+    if (!fitsAlloc(d, a.req, a.level, n)) continue;
+    best = k;
+  }
+  if (best == ~0ull) return -1;
+  return d.nodeByRank[best & ((1ull << c.idxBits) - 1)];
+}
+DEV void wgBulk(Dev& d, int kind, int n) { for (int i = 0; i < n; i++) bulkElem(d, kind, i); }
+DEV int wgCompactFlagged(Dev& d, const int32_t* order, const int32_t* segOff, int nseg, int n, const uint8_t* flag, int32_t* dst, int32_t* outSegOff) {
+  int cnt = 0, q = 0;
+  for (int p = 0; p <= n; p++) {
+    while (q <= nseg && segOff[q] == p) outSegOff[q++] = cnt;
+    if (p < n && flag[order[p]]) dst[cnt++] = order[p];
+  }
+  while (q <= nseg) outSegOff[q++] = cnt;
+  return cnt;
+}
+DEV int wgCompactIota(Dev&, int n, const uint8_t* flag, int32_t* dst) { int c = 0; for (int i = 0; i < n; i++) if (flag[i]) dst[c++] = i; return c; }
+DEV int pqTop(Dev& d, const Ctl& c) {
+  int best = -1;
+  for (int q = 0; q < d.cfg.Q; q++) if (d.pqInHeap[q] && (best < 0 || pqLess(d, c, q, best))) best = q;
+  return best;
+}
+
+// ---- platform layer
+static std::string g_err;
+static void* plat_malloc(size_t n) { return malloc(n); }
+static void plat_free(void* p) { free(p); }
+static void plat_memset(void* p, int v, size_t n) { memset(p, v, n); }
+static void plat_h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+static void plat_d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+static bool plat_init(std::string&) { return true; }
+static const char* plat_last_error() { return g_err.c_str(); }
+static int plat_run_control(Dev& dev, int cmd) {
+  Dev d = dev;
+  Ctl c; memset(&c, 0, sizeof c);
+  c.txn.active = d.rs->txnActive; c.fairStamp = d.rs->fairStamp; c.preList = d.preList; c.preferLarge = d.cfg.preferLarge;
+  runCommand(d, c, cmd);
+  d.rs->txnActive = c.txn.active; d.rs->fairStamp = c.fairStamp;
+  return 0;
+}
+static int plat_run_shape_mask(Dev& d, const uint64_t* classMask, const int32_t* shapeClass) {
+  const DevCfg& c = d.cfg;
+  for (int s = 0; s < c.S; s++) for (int w = 0; w < c.W; w++) {
+    uint64_t m = 0;
+    for (int b = 0; b < 64; b++) {
+      int n = w * 64 + b;
+      if (n >= c.N) break;
+      if (!((classMask[(size_t)shapeClass[s] * c.W + w] >> b) & 1)) continue;
+      bool ok = true;
+      for (int r = 0; r < c.R; r++) if (d.shapeReq[(size_t)s * c.R + r] > d.totalRes[(size_t)r * c.Npad + n]) ok = false;  // nodematching.go:184
+      if (ok) m |= 1ull << b;
+    }
+    d.shapeMask[(size_t)s * c.W + w] = m;
+  }
+  return 0;
+}
+static int plat_run_fit_batch(Dev& d, const std::vector<int32_t>& shapes, int level, std::vector<int32_t>& out) {
+  for (size_t i = 0; i < shapes.size(); i++) {
+    ScanArgs a; memset(&a, 0, sizeof a);
+    for (int r = 0; r < d.cfg.R; r++) a.req[r] = d.shapeReq[(size_t)shapes[i] * d.cfg.R + r];
+    a.maskA = d.shapeMask + (size_t)shapes[i] * d.cfg.W; a.maskB = nullptr; a.level = level;
+    out[i] = wgFirstFit(d, a);
+  }
+  return 0;
+}
+static int plat_run_drf(Dev& dev, const std::vector<int64_t>& a, const std::vector<int64_t>& t, double* out) {
+  Dev d = dev;
+  for (int r = 0; r < d.cfg.R; r++) d.cfg.totalResources[r] = t[r];
+  *out = drf(d, a.data());
+  return 0;
+}
+static int plat_run_fair_shares(Dev& dev, int q, const int32_t* nameRank, const double* weight, const double* cds, double* fair, double* dc, double* uc) {
+  Dev d = dev;
+  d.cfg.Q = q;
+  std::vector<double> w(weight, weight + q), f(q), c1(q), c2(q), pp(q), pc(q);
+  std::vector<int32_t> nr(nameRank, nameRank + q), nx(q);
+  std::vector<uint8_t> ih(q);
+  d.qWeight = w.data(); d.qNameRank = nr.data(); d.qFair = f.data(); d.qDc = c1.data(); d.qUc = c2.data();
+  d.pqProposed = pp.data(); d.pqCurrent = pc.data(); d.pqInHeap = ih.data(); d.itNext = nx.data();
+  updateFairShares(d, cds);
+  for (int i = 0; i < q; i++) { fair[i] = f[i]; dc[i] = c1[i]; uc[i] = c2[i]; }
+  return 0;
+}
+
+#include "../../armada_amd/csrc/asched_host.inc"

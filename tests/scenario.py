@@ -472,3 +472,19 @@ def run_fair_share_case(lib: Library, case: dict):
         cds.append(1.0 if total[0] == 0 else s.drf_cost(d, total))  # scheduling.go:267-270
     f, dc, uc = s.fair_shares(list(range(len(queues))), [float(case["queueCtxs"][q]["Weight"]) for q in queues], cds)
     return {q: (f[i], dc[i], uc[i]) for i, q in enumerate(queues)}
+
+
+def assert_same_round(a, b):
+    """bit-exact equality of two RoundResults (job->node, priorities, methods, preemptions, queue accounting, reasons)"""
+    assert a.scheduled == b.scheduled, "job->node assignments differ"
+    assert a.scheduled_priority == b.scheduled_priority
+    assert a.scheduled_method == b.scheduled_method
+    assert a.preempted == b.preempted, "preempted sets differ"
+    assert a.termination_reason == b.termination_reason
+    assert a.num_evicted_phase1 == b.num_evicted_phase1 and a.num_evicted_phase3 == b.num_evicted_phase3
+    assert (a.queue_allocated_by_pc == b.queue_allocated_by_pc).all()
+    assert (a.job_unschedulable_reason == b.job_unschedulable_reason).all()
+    # float64 DRF / fair shares: the stated tolerance is zero (same operation order, -ffp-contract=off)
+    assert (a.fair_share == b.fair_share).all() and (a.demand_capped_adjusted_fair_share == b.demand_capped_adjusted_fair_share).all()
+    assert (a.uncapped_adjusted_fair_share == b.uncapped_adjusted_fair_share).all()
+    assert a.global_tokens_after == b.global_tokens_after and (a.queue_tokens_after == b.queue_tokens_after).all()

@@ -1,0 +1,61 @@
+"""The device control code (armada_amd/csrc/round_ctl.h, round_run.h) compiled for the CPU (tests/hostsim) must agree
+with the oracle: this debugs the *logic* of the kernels in a GPU-less container.  The parallel primitives themselves
+(scan / compaction / atomics) are only exercised by the `-m gpu` tests."""
+import os
+import subprocess
+
+import pytest
+
+import scenario
+from armada_amd import workloads as W
+from armada_amd.binding import Library, SchedError
+from golden_io import ids, load
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="session")
+def hostsim_lib():
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "hostsim")])
+    return Library(os.path.join(HERE, "hostsim", "libhostsim.so"), "asched_")
+
+
+def _run(fn, lib, case):
+    try:
+        r = fn(lib, case)
+    except SchedError as e:
+        if e.code == -2:
+            pytest.skip(str(e))
+        raise
+    if r != "ok":
+        pytest.skip(r)
+
+
+PQS, QS, GANG = load("pqs"), load("queue_scheduler"), load("gang_scheduler")
+
+
+@pytest.mark.parametrize("case", PQS, ids=ids(PQS))
+def test_pqs_goldens(hostsim_lib, case):
+    _run(scenario.run_pqs_case, hostsim_lib, case)
+
+
+@pytest.mark.parametrize("case", QS, ids=ids(QS))
+def test_qs_goldens(hostsim_lib, case):
+    _run(scenario.run_qs_case, hostsim_lib, case)
+
+
+@pytest.mark.parametrize("case", GANG, ids=ids(GANG))
+def test_gang_goldens(hostsim_lib, case):
+    _run(scenario.run_gang_case, hostsim_lib, case)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_rounds_match_oracle(hostsim_lib, oracle_lib, seed):
+    wl = W.small_random(n_nodes=8 + seed * 9, n_jobs=300 + seed * 50, n_queues=2 + seed % 6, seed=seed, occupied=[0.3, 0.6, 0.9, 1.0][seed % 4],
+                        gangs=seed % 5, burst=None if seed % 3 else (150 + seed * 5, 60 + seed))
+    res = []
+    for lib in (oracle_lib, hostsim_lib):
+        s = W.load(lib, wl)
+        W.prepare(s, wl)
+        res.append(s.schedule_round())
+    scenario.assert_same_round(res[0], res[1])
