@@ -78,6 +78,7 @@ class CConfig(C.Structure):
         ("protected_fraction_of_fair_share", C.c_double),
         ("max_queue_lookback", C.c_uint32), ("pad2_", C.c_uint32),
         ("max_fraction_to_schedule", _f64p), ("disallowed_resource", _u8p),
+        ("device", C.c_int32), ("pad3_", C.c_int32),
     ]
 
 
@@ -139,7 +140,7 @@ ALL_SYMBOLS = [
     "create", "destroy", "last_error", "priorities", "nodes_upsert", "jobs_set", "txn_begin", "txn_commit",
     "txn_abort", "select_node", "schedule_many", "bind", "evict", "unbind", "add_evicted", "reset_evicted",
     "get_alloc", "get_scheduled_at_priority", "iterate_nodes", "fit_select_batch", "drf_cost", "fair_shares",
-    "round_prepare", "schedule_round", "schedule_queues", "gang_schedule", "round_counters", "job_key_unfeasible",
+    "round_prepare", "schedule_round", "schedule_queues", "gang_schedule", "round_counters", "job_key_unfeasible", "kernel_times",
 ]
 
 
@@ -238,6 +239,7 @@ class Library:
         f("gang_schedule", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i32p, _i32p, C.POINTER(CPodResult)])
         f("round_counters", C.c_int32, [C.c_void_p, _i32p])
         f("job_key_unfeasible", C.c_int32, [C.c_void_p, C.c_int32, _i32p])
+        f("kernel_times", C.c_int32, [C.c_void_p, _f64p])
 
     def _fn(self, name, restype, argtypes):
         fn = getattr(self.lib, self.prefix + name)
@@ -272,6 +274,7 @@ class Config:
     max_queue_lookback: int = 0
     max_fraction_to_schedule: Optional[Sequence[float]] = None
     disallowed_resource: Optional[Sequence[int]] = None
+    device: int = -1
 
 
 class Scheduler:
@@ -321,6 +324,7 @@ class Scheduler:
             c.max_fraction_to_schedule = _ptr(k(cfg.max_fraction_to_schedule, np.float64), C.c_double)
         if cfg.disallowed_resource is not None:
             c.disallowed_resource = _ptr(k(cfg.disallowed_resource, np.uint8), C.c_uint8)
+        c.device = int(cfg.device)
         self.h = lib.create(C.byref(c))
         if not self.h:
             raise SchedError(ERR_INVALID, "create failed (invalid config, or no gfx950 device for the HIP backend)")
@@ -568,6 +572,12 @@ class Scheduler:
         out = (C.c_int32 * 4)()
         self._check(self.lib.round_counters(self.h, out))
         return dict(num_scheduled_jobs=out[0], num_scheduled_gangs=out[1], num_evicted_jobs=out[2], num_unfeasible_keys=out[3])
+
+    def kernel_times(self):
+        """device-side durations (HIP events on the launch stream) of the kernels behind the last round / fit batch"""
+        out = (C.c_double * 4)()
+        self._check(self.lib.kernel_times(self.h, out))
+        return dict(round_ms=out[0], fit_batch_ms=out[1], round_launches=int(out[2]))
 
     def job_key_unfeasible(self, job: int) -> bool:
         o = C.c_int32(0)

@@ -239,12 +239,15 @@ static bool hipOk(hipError_t e, const char* what) {
   return false;
 }
 static const char* plat_last_error() { return g_err.c_str(); }
-static bool plat_init(std::string& err) {
-  if (g_inited) return true;
+static bool plat_init(std::string& err, int device) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { err = "no HIP device: libarmada_sched.so is the gfx950 implementation and has no CPU path"; return false; }
+  if (device >= n) { err = "device ordinal out of range"; return false; }
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) { err = "hipSetDevice failed"; return false; }
+  if (g_inited) return true;
+  int cur = 0; (void)hipGetDevice(&cur);
   hipDeviceProp_t p;
-  if (hipGetDeviceProperties(&p, 0) != hipSuccess) { err = "hipGetDeviceProperties failed"; return false; }
+  if (hipGetDeviceProperties(&p, cur) != hipSuccess) { err = "hipGetDeviceProperties failed"; return false; }
   if (std::string(p.gcnArchName).find("gfx950") == std::string::npos) { err = std::string("device is ") + p.gcnArchName + ", this library is built for gfx950 only"; return false; }
   if (hipStreamCreate(&g_stream) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
   g_inited = true;
@@ -256,10 +259,22 @@ static void plat_memset(void* p, int v, size_t n) { (void)hipMemsetAsync(p, v, n
 static void plat_h2d(void* d, const void* s, size_t n) { (void)hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, g_stream); (void)hipStreamSynchronize(g_stream); }
 static void plat_d2h(void* d, const void* s, size_t n) { (void)hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, g_stream); (void)hipStreamSynchronize(g_stream); }
 
+// device time of the last control-kernel launch (HIP events recorded on the launch stream) — bench.py's roofline input
+static float g_lastControlMs = 0.f;
+static int g_lastControlLaunches = 0;
+static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+static double plat_last_control_ms() { return (double)g_lastControlMs; }
+static int plat_last_control_launches() { return g_lastControlLaunches; }
+
 static int plat_run_control(Dev& dev, int cmd) {
+  if (!g_ev0) { (void)hipEventCreate(&g_ev0); (void)hipEventCreate(&g_ev1); }
+  (void)hipEventRecord(g_ev0, g_stream);
   hipLaunchKernelGGL(k_control, dim3(1), dim3(1024), 0, g_stream, dev, cmd);
+  (void)hipEventRecord(g_ev1, g_stream);
   if (!hipOk(hipGetLastError(), "k_control launch")) return -1;
   if (!hipOk(hipStreamSynchronize(g_stream), "k_control")) return -1;
+  (void)hipEventElapsedTime(&g_lastControlMs, g_ev0, g_ev1);
+  g_lastControlLaunches = 1;
   return 0;
 }
 static int plat_run_shape_mask(Dev& d, const uint64_t* classMask, const int32_t* shapeClass) {
@@ -271,9 +286,9 @@ static int plat_run_shape_mask(Dev& d, const uint64_t* classMask, const int32_t*
   return 0;
 }
 
-// exposed for bench.py: stream + kernel duration of the last fit batch, measured with HIP events on the launch stream
+// kernel duration of the last fit batch, measured with HIP events on the launch stream
 static float g_lastFitMs = 0.f;
-extern "C" double asched_last_fit_kernel_ms() { return (double)g_lastFitMs; }
+static double plat_last_fit_ms() { return (double)g_lastFitMs; }
 
 static int plat_run_fit_batch(Dev& d, const std::vector<int32_t>& shapes, int level, std::vector<int32_t>& out) {
   int ns = (int)shapes.size();

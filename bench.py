@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — scheduling rounds/sec (+ p99 round latency) of the MI355X scheduling-round hot path.
+
+A "step" is one scheduling round = one PreemptingQueueScheduler.Schedule-equivalent call
+(`asched_schedule_round`, phases 1-6 of SURVEY.md §3.2) on an already built NodeDb + SchedulingContext — the region
+the reference's BenchmarkPreemptingQueueScheduler times (preempting_queue_scheduler_test.go:2762-2796).  The round
+input (nodes, jobs, queues) is resident in HBM when the timed region starts; `round_prepare` (the reference's
+newFairSchedulingAlgoContext analogue: fresh NodeDb, bind running jobs, fair shares) runs before every step, untimed.
+
+Workload at N=1: BASELINE.json configs[2] — 100k nodes x 64 queues x 1M queued jobs, DRF weights + rate limits
+(the configuration the metric "100k nodes x 1M jobs" is quoted on).  Smaller sizes via --nodes/--jobs/--queues.
+
+Multi-GPU (--gpus N under torch.distributed.run): the path shards by *pool* — the reference builds one NodeDb per
+pool and schedules pools one after the other (scheduling_algo.go:165); here pool g lives on GPU g, no data-path
+collective (DESIGN.md "Multi-GPU").  Each rank schedules its own pool of the full per-GPU size (weak scaling),
+value = pools-rounds of all ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(n_nodes, R, queries, binds, fair_scan_rows=0):
+    """one node-selection query must examine, for every candidate node, its allocatable vector at one
+    priority level and its order key: N x (R x 8 + 8) B; a bind is a read-modify-write of <= P buckets (~256 B)."""
+    return queries * n_nodes * (R * 8 + 8) + binds * 256 + fair_scan_rows * (R * 8 + 16)
+
+
+def cpu_baseline(wl, budget_s, full_iters):
+    """The CPU oracle (C++ restatement of the reference algorithm, oracle/) timed on this box's host cores, 1 thread.
+    Bounded sample: the SAME nodes/jobs/queues, but the round's global rate-limit burst is cut so that the round does a
+    fraction of the full round's loop iterations; rounds/s is scaled by the iteration ratio (the loop dominates)."""
+    from armada_amd import workloads as W
+    from armada_amd.binding import Library
+    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(path):
+        return None
+    oracle = Library(path, "oracle_")
+    import copy
+    s = W.load(oracle, wl)
+    frac = 1.0
+    sample = copy.copy(wl)
+    # pilot: 1/64 of the burst, then pick the largest power-of-two fraction that fits the budget
+    for frac in (1 / 64.0,):
+        sample.global_burst = max(1, int(wl.global_burst * frac)) if not wl.rate_inf else wl.global_burst
+        W.prepare(s, sample)
+        t0 = time.perf_counter(); r = s.schedule_round(); pilot = time.perf_counter() - t0
+    pilot_iters = max(1, r.num_loop_iterations)
+    per_iter = pilot / pilot_iters
+    target_iters = min(full_iters, max(pilot_iters, int(budget_s / max(per_iter, 1e-9))))
+    # iterations ~ evicted reschedules (fixed) + burst-limited new jobs: choose the burst that yields ~target_iters
+    fixed = max(0, pilot_iters - sample.global_burst)
+    burst = int(min(wl.global_burst, max(sample.global_burst, target_iters - fixed)))
+    if wl.rate_inf:
+        burst = wl.global_burst
+    sample.global_burst = burst
+    W.prepare(s, sample)
+    t0 = time.perf_counter(); r = s.schedule_round(); dt = time.perf_counter() - t0
+    iters = max(1, r.num_loop_iterations)
+    scaled = dt * (full_iters / iters) if full_iters > iters else dt
+    s.close()
+    return {"value": 1.0 / scaled, "unit": "rounds/s", "cores": 1, "kind": "port",
+            "sample": f"oracle (C++ restatement, 1 thread) on the same {wl.num_nodes}-node/{wl.num_jobs}-job input with the global burst cut to {burst} "
+                      f"({iters} of {full_iters} loop iterations, {dt:.2f} s measured, scaled by the iteration ratio)",
+            "measured_s": dt, "measured_iterations": iters}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nodes", type=int, default=100_000)
+    ap.add_argument("--jobs", type=int, default=1_000_000)
+    ap.add_argument("--queues", type=int, default=64)
+    ap.add_argument("--gangs", type=int, default=0)
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU path)"
+    torch.cuda.set_device(local_rank)
+
+    import numpy as np
+    import armada_amd
+    from armada_amd import workloads as W
+    hip = armada_amd.load_library()
+
+    # one pool per rank; seeds differ per pool
+    wl = W.config3(n_nodes=args.nodes, n_jobs=args.jobs, n_queues=args.queues, seed=W.SEED + rank, gangs=args.gangs)
+    scale = args.jobs / 1_000_000.0
+    if args.jobs != 1_000_000:  # keep "limits bite" at reduced sizes
+        wl.global_burst, wl.queue_burst = max(1, int(200_000 * scale)), max(1, int(20_000 * scale))
+    wl.config.device = local_rank
+    t0 = time.perf_counter()
+    s = W.load(hip, wl)
+    build_s = time.perf_counter() - t0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    lat, dev_ms, res = [], [], None
+    prep_s = 0.0
+    for i in range(args.warmup + args.steps):
+        tp = time.perf_counter()
+        W.prepare(s, wl)          # untimed input build (fresh NodeDb + bind running jobs + fair shares)
+        prep_s += time.perf_counter() - tp
+        barrier()
+        t0 = time.perf_counter()
+        res = s.schedule_round()  # synchronous: returns after the device finished and the result lists are on the host
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if i >= args.warmup:
+            lat.append(dt)
+            dev_ms.append(s.kernel_times()["round_ms"])
+    barrier()
+    total = float(sum(lat))
+    if dist is not None:
+        t = torch.tensor([total], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        total = float(t.item())
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    lat_ms = np.array(lat) * 1e3
+    queries, iters = res.num_node_queries, res.num_loop_iterations
+    binds = len(res.scheduled) + res.num_evicted_phase1  # new binds + rescheduled evicted jobs (upper bound)
+    alg = algorithmic_bytes(wl.num_nodes, W.R, queries, binds)
+    kern_ms = float(np.mean(dev_ms))
+    achieved = alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    out = {
+        "metric": "scheduling rounds/sec (p99 round latency in p99_ms), 100k nodes x 1M jobs",
+        "value": world * args.steps / total, "unit": "rounds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": total / args.steps * 1e3, "p50_ms": float(np.percentile(lat_ms, 50)), "p99_ms": float(np.percentile(lat_ms, 99)),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[2]: {wl.num_nodes} nodes x {wl.num_queues} queues x {args.jobs} queued jobs (+{wl.num_jobs - args.jobs} running), "
+                               f"R=4, 3 priority classes, DRF weights, global burst {wl.global_burst}, queue burst {wl.queue_burst}, protectedFractionOfFairShare 0.5",
+                   "nodes": wl.num_nodes, "queued_jobs": args.jobs, "running_jobs": wl.num_jobs - args.jobs, "queues": wl.num_queues,
+                   "parallelism": f"pool-per-gpu x{world}" if world > 1 else "1 pool on 1 gpu", "seed": W.SEED},
+        "round": {"scheduled": len(res.scheduled), "preempted": len(res.preempted), "evicted_phase1": res.num_evicted_phase1,
+                  "evicted_phase3": res.num_evicted_phase3, "loop_iterations": iters, "node_queries_issued": queries,
+                  "termination_reason": res.termination_reason, "device_ms": kern_ms, "host_ms": float(np.mean(lat_ms))},
+        "input_build_s": build_s, "round_prepare_s": prep_s / (args.warmup + args.steps),
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "k_control", "algorithmic_bytes_per_launch": alg,
+                     "note": "algorithmic bytes = node_queries_issued x N x (R*8+8) + binds x 256 (SURVEY 8d); kernel ms from HIP events on the launch stream"},
+    }
+    if args.cpu_budget > 0:
+        try:
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_budget, iters)
+        except Exception as e:  # the checker must never take the bench line down
+            out["cpu_baseline"] = {"error": str(e)}
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

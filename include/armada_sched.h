@@ -130,6 +130,8 @@ typedef struct asched_config {
   uint32_t pad2_;
   const double* max_fraction_to_schedule; /* [R] MaximumResourceFractionToSchedule, +Inf = uncapped; NULL = all +Inf */
   const uint8_t* disallowed_resource;     /* [R] pool ExperimentalUnscheduledResources; NULL = none */
+  int32_t device;                         /* HIP device ordinal this handle (one pool) lives on; <0 = the calling thread's current device */
+  int32_t pad3_;
 } asched_config;
 
 /* ---- nodes (internaltypes/node.go:32-69).  Creation order = node.index order. ---- */
@@ -302,6 +304,11 @@ int32_t ASCHED_FN(schedule_queues)(asched_t*, asched_round_result* out);
 int32_t ASCHED_FN(gang_schedule)(asched_t*, int32_t n, const int32_t* jobs, int32_t* ok, int32_t* reason, asched_pod_result* out /*[n]*/);
 /* sctx counters: out = {NumScheduledJobs, NumScheduledGangs, NumEvictedJobs, len(UnfeasibleSchedulingKeys)} (context/scheduling.go:55-69) */
 int32_t ASCHED_FN(round_counters)(asched_t*, int32_t* out /*[4]*/);
+/* Measurement hook (no reference counterpart): device time of the kernels behind the last call, taken with HIP events
+   on the stream the kernels were launched on.  out[0] = ms of the last schedule_round/schedule_queues device work,
+   out[1] = ms of the last fit_select_batch kernel, out[2] = kernel launches behind out[0], out[3] = reserved.
+   The CPU oracle reports zeros. */
+int32_t ASCHED_FN(kernel_times)(asched_t*, double* out /*[4]*/);
 /* 1 if the job's scheduling key is registered in sctx.UnfeasibleSchedulingKeys (gang_scheduler.go:80-95) */
 int32_t ASCHED_FN(job_key_unfeasible)(asched_t*, int32_t job, int32_t* out);
 

@@ -56,7 +56,10 @@ static void plat_free(void* p) { free(p); }
 static void plat_memset(void* p, int v, size_t n) { memset(p, v, n); }
 static void plat_h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
 static void plat_d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
-static bool plat_init(std::string&) { return true; }
+static bool plat_init(std::string&, int) { return true; }
+static double plat_last_control_ms() { return 0; }
+static int plat_last_control_launches() { return 0; }
+static double plat_last_fit_ms() { return 0; }
 static const char* plat_last_error() { return g_err.c_str(); }
 static int plat_run_control(Dev& dev, int cmd) {
   Dev d = dev;
