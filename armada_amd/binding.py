@@ -140,7 +140,7 @@ ALL_SYMBOLS = [
     "create", "destroy", "last_error", "priorities", "nodes_upsert", "jobs_set", "txn_begin", "txn_commit",
     "txn_abort", "select_node", "schedule_many", "bind", "evict", "unbind", "add_evicted", "reset_evicted",
     "get_alloc", "get_scheduled_at_priority", "iterate_nodes", "fit_select_batch", "drf_cost", "fair_shares",
-    "round_prepare", "schedule_round", "schedule_queues", "gang_schedule", "round_counters", "job_key_unfeasible", "kernel_times",
+    "round_prepare", "schedule_round", "schedule_queues", "gang_schedule", "round_counters", "job_key_unfeasible", "kernel_times", "round_stats",
 ]
 
 
@@ -240,6 +240,7 @@ class Library:
         f("round_counters", C.c_int32, [C.c_void_p, _i32p])
         f("job_key_unfeasible", C.c_int32, [C.c_void_p, C.c_int32, _i32p])
         f("kernel_times", C.c_int32, [C.c_void_p, _f64p])
+        f("round_stats", C.c_int32, [C.c_void_p, _i32p])
 
     def _fn(self, name, restype, argtypes):
         fn = getattr(self.lib, self.prefix + name)
@@ -578,6 +579,12 @@ class Scheduler:
         out = (C.c_double * 4)()
         self._check(self.lib.kernel_times(self.h, out))
         return dict(round_ms=out[0], fit_batch_ms=out[1], round_launches=int(out[2]))
+
+    def round_stats(self):
+        out = (C.c_int32 * 16)()
+        self._check(self.lib.round_stats(self.h, out))
+        names = ["fast_iterations", "generic_iterations", "base_scan_steps", "window_refills", "l0_max", "fast_replay_steps", "l0_overflows", "fast_active"]
+        return {k: out[i] for i, k in enumerate(names)}
 
     def job_key_unfeasible(self, job: int) -> bool:
         o = C.c_int32(0)

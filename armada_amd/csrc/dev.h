@@ -13,6 +13,11 @@
 #define MAXK 6
 #define MAXP 16
 #define MAXPC 32
+#define MAXE 2        // non-indexed resource columns the level-0 fast structure carries per entry
+#define SMAX 512      // scheduling-key shapes with a cached base candidate (LDS)
+#define L0CAP 1024    // live dirty nodes held in LDS
+#define QCAPF 64      // queues the fast iteration handles (one lane per queue)
+#define WIN 4         // job records prefetched per queue and refill
 #define NO_PRIORITY INT32_MIN
 #define NONPREEMPTIBLE_CUTOFF INT32_MAX
 
@@ -44,6 +49,24 @@ struct DevCfg {
   int evLevel;  // level index of EvictedPriority (always 0)
 };
 
+// One job as the fast path reads it: a single 128-byte burst (16 lanes x 8 B) instead of 12 dependent array reads.
+struct JobRec {
+  int64_t req[MAXR];   // AllResourceRequirements
+  uint64_t keyDelta;   // packed (req_c / resolution_c) per indexed column: what a bind subtracts from a node's order key
+  uint64_t fieldMin;   // packed (req_c / resolution_c - keyLo_c): smallest key fields of a node the job fits on
+  int32_t pc, shape, gang, node0, runPrio, cls, never, pad;
+  int64_t pad2[2];
+};
+
+// Level-0 ("fit without preemption", priority -2) fast structure, DESIGN.md "Sorted base + LDS delta".
+struct FastCfg {
+  int structOk, iterOk;       // host-verified exactness conditions (asched_host.inc: fastConditions)
+  int E; int extraCol[MAXE];  // non-indexed columns
+  uint64_t fieldMask[MAXK];   // in-place mask of each packed key field
+  uint64_t minFieldMin;       // per-field minimum of fieldMin over all shapes (liveness of a dirty node)
+  int64_t minExtra[MAXE];
+};
+
 // scalars of the scheduling context (context/scheduling.go:27-77) + kernel bookkeeping
 struct RoundScalars {
   int64_t allocated[MAXR], scheduled[MAXR], evicted[MAXR];
@@ -59,6 +82,14 @@ struct RoundScalars {
   int32_t undoCount;
   int32_t txnActive;   // persists across control-kernel launches (NodeDb-level API)
   int32_t fairStamp;
+  // ---- fast path (round_fast.h)
+  int32_t fastActive;        // the sorted base + removed flags + L0 list describe the current level-0 state
+  int32_t apiDirty;          // NodeDb-level commands changed per-job state since round_prepare: fast iterations off
+  int32_t numPreemptedMarks; // |sctx.PreemptedJobIds|
+  int32_t lvl0NonNeg;        // no node has a negative level-0 (priority -2) allocatable column
+  int32_t l0SaveCount;       // L0 entries saved to HBM between launches
+  int32_t fastOverflow;      // L0 overflowed: structure dropped for the rest of the round
+  int32_t statFastIters, statGenericIters, statScanSteps, statRefills, statL0Max, statFastReplay;
   int32_t pad;
 };
 
@@ -132,4 +163,18 @@ struct Dev {
   int32_t* preList;      // [M] staged preemptions
   int32_t* cmdIO;        // [64 + ...] command arguments / results of the control kernel
   int32_t *resJob, *resNode, *resPrio, *resMethod, *resPreJob, *resPreNode;  // compacted results
+  // ---- level-0 fast structure (HBM side; L0 + candidate cache live in LDS)
+  FastCfg f;
+  uint64_t* baseKey;     // [Npad] level-0 keys in ascending order as of the last build
+  int32_t* baseNode;     // [Npad]
+  int64_t* baseExtra;    // [MAXE][Npad]
+  uint64_t* baseCls;     // [Npad] static requirement classes the node satisfies (bit per class)
+  uint8_t* baseRemoved;  // [Npad] entry is stale: the node changed since the build (it is in L0 or dead)
+  int32_t* posOf;        // [N] node -> base position
+  int32_t* l0Slot;       // [N] node -> L0 slot or -1
+  uint64_t* nodeCls;     // [N]
+  JobRec* jrec;          // [M]
+  int32_t* evIdxByPos;   // [M] evicted-table Index of evList[p]
+  int32_t* l0Save;       // [L0CAP]
+  int32_t* candPosSave;  // [SMAX]
 };

@@ -36,6 +36,20 @@ DEV void atomicAddI64(int64_t* p, int64_t v);
 DEV void atomicAddI32(int32_t* p, int32_t v);
 DEV void atomicOrI32(int32_t* p, int32_t v);
 
+// fast path (round_fast.h): level-0 sorted base + LDS delta, LDS-resident heads, key-based queue argmin
+struct Ctl; struct PassCfg;
+DEV void fastTouch(Dev& d, int n);                 // node n's allocatable changed through the generic code
+DEV int fastSelectLevel0(Dev& d, int job);         // first fit at priority -2 through the fast structure (-2 = structure not usable)
+DEV int pqTopAny(Dev& d, const Ctl& c);
+DEV void fastItemKeys(Dev& d, const Ctl& c, int q);
+DEV void fastHeadInvalidate(int q);
+DEV void fastPassReset();
+DEV bool fastOn(Dev& d, const Ctl& c);
+DEV void fastAdvance(Dev& d, Ctl& c, int q, const PassCfg& pc);
+DEV bool fastIter(Dev& d, Ctl& c, const PassCfg& pc, int top);
+DEV bool fastReplayStep(Dev& d, Ctl& c, const PassCfg& pc, int top, int* counter);
+DEV void fastEnterGeneric(Dev& d, Ctl& c);         // make the fast path's fire-and-forget HBM updates visible to plain loads
+
 // ------------------------------------------------------------------------------------------------
 #define AL(d, l, r, n) ((d).alloc[((size_t)(l) * (d).cfg.R + (r)) * (d).cfg.Npad + (n)])
 #define KEY(d, l, n) ((d).keys[(size_t)(l) * (d).cfg.Npad + (n)])
@@ -64,6 +78,7 @@ DEV uint64_t packKey(Dev& d, int l, int n) {
   return k;
 }
 DEV void updateKeys(Dev& d, int n) { for (int l = 0; l < d.cfg.P; l++) KEY(d, l, n) = packKey(d, l, n); }
+DEV void updateKeysCtl(Dev& d, int n) { updateKeys(d, n); fastTouch(d, n); }  // control-flow call sites (not the bulk rebuild)
 
 DEV bool fitsAlloc(Dev& d, const int64_t* req, int level, int n) {  // DynamicJobRequirementsMet (is/nodedb/nodematching.go:194-197)
   for (int r = 0; r < d.cfg.R; r++) if (req[r] > AL(d, level, r, n)) return false;
@@ -154,14 +169,14 @@ DEV void txnAbort(Dev& d, Txn& t) {
       markAllocatable(d, n, d.jobCutoff[job], req, +1);
       if (wasEvicted) { markAllocatable(d, n, ASCHED_EVICTED_PRIORITY, req, -1); d.jobEvictedOnNode[job] = 1; d.jobCutoff[job] = c; }
       else { d.jobNode[job] = -1; d.jobCutoff[job] = c; }
-      updateKeys(d, n);
+      updateKeysCtl(d, n);
     } else if (kind == U_REMOVE) {
       int job = a, n = b;
       const int64_t* req = JREQ(d, job);
       if (wasEvicted) markAllocatable(d, n, ASCHED_EVICTED_PRIORITY, req, -1);
       else markAllocatable(d, n, c, req, -1);
       d.jobNode[job] = n; d.jobCutoff[job] = c; d.jobEvictedOnNode[job] = wasEvicted ? 1 : 0;
-      updateKeys(d, n);
+      updateKeysCtl(d, n);
     } else if (kind == U_EVTAB_DEL) {
       d.evTabAlive[a] = 1; d.evIndexOfJob[d.evTabJob[a]] = a;
     }
@@ -291,6 +306,9 @@ struct Ctl {
   int* preList;      // staged preemptions of the current gang attempt (job ids), in global memory
   int preCount;
   int fairStamp;
+  int fastEnabled;     // this launch may run fast iterations (host conditions hold, no NodeDb-level API calls since prepare)
+  int fastEvStatic;    // evicted jobs of the current pass are phase-1 evictions: node / priority are the job's static run
+  int l1Dirty;         // fire-and-forget atomics outstanding: plain loads of alloc/keys need an L1 invalidate first
 };
 
 DEV const uint64_t* uniMask(Dev& d, int job) { int v = d.jcUniValue[job]; return v >= 0 ? d.labelMask + (size_t)v * d.cfg.W : (const uint64_t*)0; }
@@ -302,6 +320,10 @@ DEV int selectAtLevel(Dev& d, int job, int32_t prio) {
   d.rs->numNodeQueries++;
   int level = levelOf(d.cfg, prio);
   if (level < 0) { raise(d, ASCHED_ERR_INTERNAL, 500); return -1; }
+  if (level == 0 && d.jcUniValue[job] < 0) {
+    int fn = fastSelectLevel0(d, job);
+    if (fn != -2) { if (fn >= 0) { d.pcNode[job] = fn; d.pcPap[job] = prio; } return fn; }
+  }
   ScanArgs a;
   const int64_t* req = JREQ(d, job);
   for (int r = 0; r < MAXR; r++) a.req[r] = r < d.cfg.R ? req[r] : 0;
@@ -427,7 +449,7 @@ DEV void preemptSiblings(Dev& d, Ctl& c, int firstPre, int lastPre) {
       int n = d.jcAssigned[s];
       if (n < 0) { raise(d, ASCHED_ERR_INTERNAL, 700); return; }
       removeJob(d, n, s, true);
-      updateKeys(d, n);
+      updateKeysCtl(d, n);
       evTabDelete(d, idx, true);
       c.preList[c.preCount++] = s;
     }
@@ -449,7 +471,8 @@ DEV bool scheduleMany(Dev& d, Ctl& c, int ref) {
     int32_t prio = d.pcSap[job];
     if (addJob(d, n, job, cutoffFor(d, job, prio), true)) return false;     // BindJobToNode :1046-1068
     d.schedAtPrio[job] = prio;                                              // not rolled back on abort (plain Go map)
-    updateKeys(d, n);
+    if (d.pcMethod[job] != ASCHED_METHOD_NO_PREEMPTION && d.pcMethod[job] != ASCHED_METHOD_RESCHEDULED) d.rs->lvl0NonNeg = 0;  // preemption may overdraw priority -2
+    updateKeysCtl(d, n);
     int eidx = d.evIndexOfJob[job];
     if (eidx >= 0) evTabDelete(d, eidx, true);
     preemptSiblings(d, c, pre0, pre1);
@@ -463,7 +486,7 @@ DEV void applyPreemptions(Dev& d, Ctl& c) {
   for (int i = 0; i < c.preCount; i++) {
     int p = c.preList[i];
     d.jcStagedBy[p] = -1;
-    if (!d.jcPreempted[p]) { d.jcPreempted[p] = 1; if (d.rs->hasFpLimiter) d.rs->fpTokens -= 1.0; }
+    if (!d.jcPreempted[p]) { d.jcPreempted[p] = 1; d.rs->numPreemptedMarks++; if (d.rs->hasFpLimiter) d.rs->fpTokens -= 1.0; }
   }
   c.preCount = 0;
 }
@@ -635,6 +658,7 @@ DEV int gangItPeek(Dev& d, Ctl& c, int q, bool withQueued, uint32_t maxLookback,
 struct PassCfg { bool withQueued; uint32_t maxLookback; bool skipKnown; };
 
 DEV void updateItem(Dev& d, Ctl& c, int q, const PassCfg& pc) {  // updatePQItem :636-686
+  fastHeadInvalidate(q);
   d.pqGctx[q] = -1; d.pqProposed[q] = d.pqCurrent[q] = d.pqSize[q] = 0;
   int ref = gangItPeek(d, c, q, pc.withQueued, pc.maxLookback, pc.skipKnown);
   if (ref == -1) return;
@@ -660,6 +684,7 @@ DEV void updateItem(Dev& d, Ctl& c, int q, const PassCfg& pc) {  // updatePQItem
     if (p < pcp) pcp = p;
   }
   d.pqPcPrio[q] = pcp; d.pqSchedPrio[q] = sp;
+  fastItemKeys(d, c, q);
 }
 DEV void updateAndPush(Dev& d, Ctl& c, int q, const PassCfg& pc) { updateItem(d, c, q, pc); d.pqInHeap[q] = d.pqGctx[q] != -1; }
 
@@ -715,6 +740,7 @@ DEV void costItResume(Dev& d, Ctl& c, const PassCfg& pc) {  // :572-591
 }
 DEV void costItClear(Dev& d, Ctl& c, int top, const PassCfg& pc) {  // :595-606
   if (top < 0) return;
+  if (fastOn(d, c)) { fastAdvance(d, c, top, pc); return; }
   d.pqInHeap[top] = 0;
   d.itNext[top] = -1;
   updateAndPush(d, c, top, pc);
@@ -722,13 +748,14 @@ DEV void costItClear(Dev& d, Ctl& c, int top, const PassCfg& pc) {  // :595-606
 
 DEV void passInit(Dev& d, Ctl& c, const PassCfg& pc) {
   int Q = d.cfg.Q;
+  fastPassReset();
   for (int q = 0; q < Q; q++) {
     d.itEi[q] = d.evOff[q]; d.itQi[q] = d.queuedOff[q]; d.itStage[q] = 0; d.itJobsSeen[q] = 0; d.itNext[q] = -1; d.itStashed[q] = -1;
     d.itJobOnlyEv[q] = 0; d.itGangOnlyEv[q] = 0; d.onlyEvByQueue[q] = 0; d.pqInHeap[q] = 0;
     d.pqBudget[q] = d.qDc[q] / d.qWeight[q];  // pushQueue :509-519
   }
   c.onlyEvicted = 0;
-  for (int q = 0; q < Q; q++) updateAndPush(d, c, q, pc);
+  for (int q = 0; q < Q; q++) { if (fastOn(d, c)) fastAdvance(d, c, q, pc); else updateAndPush(d, c, q, pc); }
 }
 
 // QueueScheduler.Schedule (queue_scheduler.go:94-304)
@@ -737,8 +764,11 @@ DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff)
   for (;;) {
     if (d.rs->error) return;
     if (!limitHit && d.rs->hasFpLimiter && d.rs->fpTokens < 1) { limitHit = true; costItOnlyEvicted(d, c, pc); }
-    int top = pqTop(d, c);
+    int top = pqTopAny(d, c);
     int ref = top >= 0 ? d.pqGctx[top] : -1;
+    if (ref >= 0 && fastOn(d, c) && fastIter(d, c, pc, top)) { d.rs->loopIterations++; d.rs->statFastIters++; continue; }
+    fastEnterGeneric(d, c);
+    d.rs->statGenericIters++;
     if (ref == -1) {
       if (limitHit && !resumed && d.rs->terminationReason == 0) { resumed = true; costItResume(d, c, pc); continue; }
       break;
@@ -782,9 +812,10 @@ DEV void replayEvicted(Dev& d, Ctl& c) {
   passInit(d, c, pc);
   int i = 0;
   for (;;) {
-    int top = pqTop(d, c);
+    int top = pqTopAny(d, c);
     int ref = top >= 0 ? d.pqGctx[top] : -1;
     if (ref == -1) break;
+    if (ref >= 0 && fastOn(d, c) && fastReplayStep(d, c, pc, top, &i)) continue;
     int cnt = gcCount(d, ref);
     for (int k = 0; k < cnt; k++) { evTabInsert(d, i, gcJob(d, ref, k)); i++; }
     vadd(d, QV(d.replayAlloc, gcQueue(d, ref)), gcTotal(d, ref), +1);

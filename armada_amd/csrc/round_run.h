@@ -3,10 +3,12 @@
 // workgroup through wgBulk(); cross-job sums use int64 atomics (integer => order independent => exact).
 #pragma once
 #include "round_ctl.h"
+#include "round_fast.h"
 
 enum BulkKind {
   B_RESET_GANGSEEN = 1, B_FILTER1, B_NODE_OVER, B_FILTER3, B_GANG_CLOSURE, B_EVICT_APPLY1, B_EVICT_APPLY3, B_KEYS_ALL,
   B_UNBIND, B_RESET_EVTAB, B_CLEAR_UNFEASIBLE, B_INIT_ALLOC, B_POPULATE, B_RESET_JOBS, B_GATHER_SCHED, B_GATHER_PRE,
+  B_EVIDX, B_LVL0,
 };
 
 DEV void wgBulk(Dev& d, int kind, int n);  // every element i in [0,n) through bulkElem(), then a workgroup barrier
@@ -100,6 +102,8 @@ DEV void bulkElem(Dev& d, int kind, int i) {
     case B_GATHER_SCHED: { int j = d.resJob[i]; d.resNode[i] = d.pcNode[j]; d.resPrio[i] = d.schedAtPrio[j]; d.resMethod[i] = d.pcMethod[j]; } break;
     case B_GATHER_PRE: { int j = d.resPreJob[i]; d.resPreNode[i] = d.preemptedNode[j]; } break;
     case B_CLEAR_UNFEASIBLE: d.unfeasible[i] = 0; break;
+    case B_EVIDX: if (d.evIdxByPos) d.evIdxByPos[i] = d.evIndexOfJob[d.evList[i]]; break;  // evicted-table Index per evicted-list position (fast path)
+    case B_LVL0: { bool neg = false; for (int r = 0; r < c.R; r++) neg = neg || AL(d, 0, r, i) < 0; if (neg) d.rs->lvl0NonNeg = 0; } break;
     case B_INIT_ALLOC: {  // fresh NodeDb (scheduling_algo.go:517): AllocatableByPriority[p] = allocatable (node.go:79-85)
       for (int l = 0; l < c.P; l++) for (int r = 0; r < c.R; r++)
         AL(d, l, r, i) = d.alloc0 ? d.alloc0[((size_t)l * c.R + r) * c.Npad + i] : d.allocatable[(size_t)r * c.Npad + i];
@@ -172,6 +176,7 @@ DEV int pqsEvict(Dev& d, Ctl& c, bool phase3) {
   d.rs->evictedTableSize = 0;
   wgBulk(d, B_RESET_GANGSEEN, d.cfg.G);
   replayEvicted(d, c);  // addEvictedJobsToNodeDb
+  wgBulk(d, B_EVIDX, n);
   return n;
 }
 
@@ -196,8 +201,12 @@ DEV void runRound(Dev& d, Ctl& c) {
     d.qEvictable[q] = !(frac <= cf.protectedFraction);
   }
   wgBulk(d, B_FILTER1, cf.M);
+  c.fastEvStatic = 1;
   int n1 = pqsEvict(d, c, false);
+  d.rs->lvl0NonNeg = 1;
+  wgBulk(d, B_LVL0, cf.N);
   schedulePass(d, c, true, false, false);
+  c.fastEvStatic = 0;
   if (d.rs->error) return;
   int firstTermination = d.rs->terminationReason;
   wgBulk(d, B_NODE_OVER, cf.N);
@@ -207,6 +216,7 @@ DEV void runRound(Dev& d, Ctl& c) {
   if (d.rs->error) return;
   wgBulk(d, B_UNBIND, cf.M);
   wgBulk(d, B_KEYS_ALL, cf.N);
+  d.rs->fastActive = 0;  // unbinding changed priority -2 allocatable behind the fast structure: next round_prepare rebuilds it
   d.rs->terminationReason = firstTermination;
   d.cmdIO[0] = n1; d.cmdIO[1] = n3;
   d.cmdIO[2] = wgCompactIota(d, cf.M, d.inScheduled, d.resJob);
@@ -237,6 +247,7 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
   const DevCfg& cf = d.cfg;
   switch (cmd) {
     case CMD_UPSERT_RESET:  // nodes_upsert: node state only
+      d.rs->fastActive = 0;
       wgBulk(d, B_INIT_ALLOC, cf.N);
       wgBulk(d, B_KEYS_ALL, cf.N);
       break;
@@ -245,6 +256,7 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
       d.rs->evictedTableSize = 0; d.rs->txnActive = 0; d.rs->undoCount = 0;
       break;
     case CMD_PREPARE:
+      d.rs->fastActive = 0;
       wgBulk(d, B_INIT_ALLOC, cf.N);
       wgBulk(d, B_RESET_JOBS, cf.M);
       wgBulk(d, B_POPULATE, cf.M);
@@ -257,6 +269,9 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
     case CMD_QUEUES_ONLY: {
       // no evicted jobs: empty per-queue evicted segments
       for (int q = 0; q <= cf.Q; q++) d.evOff[q] = 0;
+      c.fastEvStatic = 1;
+      d.rs->lvl0NonNeg = 1;
+      wgBulk(d, B_LVL0, cf.N);
       schedulePass(d, c, true, false, false);
       d.cmdIO[2] = wgCompactIota(d, cf.M, d.inScheduled, d.resJob);
       d.cmdIO[3] = wgCompactIota(d, cf.M, d.jcPreempted, d.resPreJob);
@@ -264,6 +279,7 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
       wgBulk(d, B_GATHER_PRE, d.cmdIO[3]);
     } break;
     case CMD_GANG_SCHEDULE: {
+      d.rs->apiDirty = 1;
       int n = ARG(0);
       int ref;
       if (n == 1 && d.jGang[ARG(1)] < 0) { ref = ARG(1); resetJctxForQueued(d, ref); }
@@ -281,6 +297,7 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
       d.cmdIO[0] = ok; d.cmdIO[1] = reason;
     } break;
     case CMD_SELECT: {
+      d.rs->apiDirty = 1;
       int job = ARG(0);
       setupPinned(d, job, ARG(1));
       c.preCount = 0;
@@ -289,6 +306,7 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
       c.preCount = 0;
     } break;
     case CMD_SCHEDULE_MANY: {
+      d.rs->apiDirty = 1;
       int n = ARG(0);
       // members are passed explicitly: use the scratch gang slot G (one past the real gangs)
       int g = cf.G;
@@ -309,27 +327,32 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
       c.preCount = 0;
     } break;
     case CMD_BIND: {
+      d.rs->apiDirty = 1;
       int job = ARG(0), n = ARG(1), prio = ARG(2);
       if (addJob(d, n, job, cutoffFor(d, job, prio), c.txn.active) == 0) {
         d.schedAtPrio[job] = prio;
-        updateKeys(d, n);
+        updateKeysCtl(d, n);
         int e = d.evIndexOfJob[job];
         if (e >= 0) evTabDelete(d, e, c.txn.active);
       }
     } break;
     case CMD_EVICT: {
+      d.rs->apiDirty = 1;
       int job = ARG(0), n = ARG(1);
       if (d.schedAtPrio[job] == NO_PRIORITY) { raise(d, ASCHED_ERR_INTERNAL, 801); break; }
-      if (evictJobOnNode(d, n, job) == 0) updateKeys(d, n);
+      if (evictJobOnNode(d, n, job) == 0) updateKeysCtl(d, n);
     } break;
-    case CMD_UNBIND: { removeJob(d, ARG(1), ARG(0), c.txn.active); updateKeys(d, ARG(1)); } break;
+    case CMD_UNBIND: {
+      d.rs->apiDirty = 1; removeJob(d, ARG(1), ARG(0), c.txn.active); updateKeysCtl(d, ARG(1)); } break;
     case CMD_ADD_EVICTED: {
+      d.rs->apiDirty = 1;
       int idx = ARG(0), job = ARG(1), n = ARG(2);
       if (d.evIndexOfJob[job] >= 0) { raise(d, ASCHED_ERR_INTERNAL, 802); break; }
       setupPinned(d, job, n);
       evTabInsert(d, idx, job);
     } break;
     case CMD_RESET_EVICTED:
+      d.rs->apiDirty = 1;
       wgBulk(d, B_RESET_EVTAB, cf.M);
       d.rs->evictedTableSize = 0;
       break;
@@ -337,4 +360,19 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
     case CMD_TXN_COMMIT: txnCommit(d, c.txn); break;
     case CMD_TXN_ABORT: txnAbort(d, c.txn); break;
   }
+}
+
+// body of the control kernel's wave 0 (and of the hostsim debug build): one command with the fast path's LDS side
+// restored from / saved to HBM around it
+DEV void controlMain(Dev& d, int cmd) {
+  Ctl c;
+  c.txn.active = d.rs->txnActive; c.fairStamp = d.rs->fairStamp; c.preList = d.preList; c.preCount = 0;
+  c.skipKeyCheck = 0; c.compareSchedPrio = 0; c.preferLarge = d.cfg.preferLarge; c.useReplayAlloc = 0; c.onlyEvicted = 0;
+  c.fastEnabled = d.f.iterOk && !d.rs->apiDirty && (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY);
+  c.fastEvStatic = 0; c.l1Dirty = 0;
+  fastLoad(d);
+  runCommand(d, c, cmd);
+  fastEnterGeneric(d, c);
+  fastSave(d);
+  d.rs->txnActive = c.txn.active; d.rs->fairStamp = c.fairStamp;
 }

@@ -309,6 +309,10 @@ int32_t ASCHED_FN(round_counters)(asched_t*, int32_t* out /*[4]*/);
    out[1] = ms of the last fit_select_batch kernel, out[2] = kernel launches behind out[0], out[3] = reserved.
    The CPU oracle reports zeros. */
 int32_t ASCHED_FN(kernel_times)(asched_t*, double* out /*[4]*/);
+/* Measurement hook (no reference counterpart): how the last round ran on the device.  out = {fast iterations, generic
+   iterations, base scan steps, window refills, max live dirty nodes (L0), fast replay steps, L0 overflows,
+   fast structure active at the end, 0...}.  The CPU oracle reports zeros. */
+int32_t ASCHED_FN(round_stats)(asched_t*, int32_t* out /*[16]*/);
 /* 1 if the job's scheduling key is registered in sctx.UnfeasibleSchedulingKeys (gang_scheduler.go:80-95) */
 int32_t ASCHED_FN(job_key_unfeasible)(asched_t*, int32_t job, int32_t* out);
 

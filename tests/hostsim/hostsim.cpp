@@ -7,6 +7,7 @@
 // it proves nothing about the kernels' parallel primitives — the `-m gpu` tests do that on the MI355X.
 #define ASCHED_HOSTSIM 1
 #define ASCHED_PREFIX asched_
+#include <algorithm>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -63,10 +64,22 @@ static double plat_last_fit_ms() { return 0; }
 static const char* plat_last_error() { return g_err.c_str(); }
 static int plat_run_control(Dev& dev, int cmd) {
   Dev d = dev;
-  Ctl c; memset(&c, 0, sizeof c);
-  c.txn.active = d.rs->txnActive; c.fairStamp = d.rs->fairStamp; c.preList = d.preList; c.preferLarge = d.cfg.preferLarge;
-  runCommand(d, c, cmd);
-  d.rs->txnActive = c.txn.active; d.rs->fairStamp = c.fairStamp;
+  controlMain(d, cmd);
+  return 0;
+}
+// sorted base of the level-0 fast structure (round_fast.h): the device build sorts with a bitonic network
+static int plat_build_base(Dev& d) {
+  const DevCfg& c = d.cfg;
+  int N = c.N;
+  std::vector<uint64_t> keys(N);
+  for (int i = 0; i < N; i++) keys[i] = KEY(d, 0, i);
+  std::sort(keys.begin(), keys.end());
+  uint64_t mask = (1ull << c.idxBits) - 1;
+  for (int i = 0; i < N; i++) {
+    int node = d.nodeByRank[keys[i] & mask];
+    d.baseKey[i] = keys[i]; d.baseNode[i] = node; d.posOf[node] = i; d.baseRemoved[i] = 0; d.baseCls[i] = d.nodeCls[node]; d.l0Slot[node] = -1;
+    for (int e = 0; e < d.f.E; e++) d.baseExtra[(size_t)e * c.Npad + i] = AL(d, 0, d.f.extraCol[e], node);
+  }
   return 0;
 }
 static int plat_run_shape_mask(Dev& d, const uint64_t* classMask, const int32_t* shapeClass) {
