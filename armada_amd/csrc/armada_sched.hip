@@ -148,8 +148,245 @@ __device__ static inline int pqTop(Dev& d, const Ctl& c) {
   return best;
 }
 
+
+// ------------------------------------------------------------------------------------------------ fast-path primitives (round_fast.h contracts)
+// All of these run on wave 0 only (the control wave); results are wave-uniform.  LDS state is reached through the
+// __shared__ objects themselves (ds_* instructions), HBM through explicit global-address-space pointers (FastK): no flat
+// accesses, so LDS work never waits for the outstanding HBM stores/atomics and vice versa.
+__device__ static inline int pqTopFast(int Q) {
+  int lane = threadIdx.x & 63;
+  uint32_t A = ~0u, N = ~0u; unsigned long long X = ~0ull, Y = ~0ull; int best = -1;
+  if (lane < Q && g_fl.inHeap[lane]) { A = g_fl.kA[lane]; X = g_fl.kX[lane]; Y = g_fl.kY[lane]; N = (uint32_t)g_fl.nameRank[lane]; best = lane; }
+  for (int off = 32; off; off >>= 1) {
+    uint32_t oA = __shfl_xor(A, off, 64), oN = __shfl_xor(N, off, 64);
+    unsigned long long oX = __shfl_xor(X, off, 64), oY = __shfl_xor(Y, off, 64);
+    int ob = __shfl_xor(best, off, 64);
+    bool less = oA != A ? oA < A : oX != X ? oX < X : oY != Y ? oY < Y : oN < N;
+    bool take = ob >= 0 && (best < 0 || less);
+    if (take) { A = oA; X = oX; Y = oY; N = oN; best = ob; }
+  }
+  return best;
+}
+
+// fairness.go:99-105 three times (alloc+req, alloc, req): lane (8*which + r) evaluates one float64 ratio, the max over a
+// group of 8 lanes is the dominant share; identical IEEE operations to drf() in round_ctl.h, evaluated side by side.
+// Operands come straight from LDS (the queue's resource vectors and the window record), one lane-indexed read each.
+__device__ static inline void drf3(Dev& d, int q, int k, bool replay, double w, double* proposed, double* current, double* size) {
+  int lane = threadIdx.x & 63;
+  int which = lane >> 3, r = lane & 7;
+  double x = -INFINITY;
+  if (which < 3 && r < d.cfg.R) {
+    int64_t a = (replay ? g_fl.qReplay[q][r] : g_fl.qAlloc[q][r]) + g_fl.qPenalty[q][r];
+    int64_t rq = g_fl.winRec[q][k].req[r];
+    int64_t v = which == 0 ? a + rq : which == 1 ? a : rq;
+    int64_t t = d.cfg.totalResources[r];
+    double f = 0.0;
+    if (t != 0) f = (double)v / (double)t;
+    x = f * d.cfg.drfMult[r];
+  }
+  for (int off = 4; off; off >>= 1) { double o = __shfl_xor(x, off, 64); x = o > x ? o : x; }
+  double m = x > 0 ? x : 0.0;
+  double res = which == 2 ? m * w : m / w;
+  *proposed = __shfl(res, 0, 64); *current = __shfl(res, 8, 64); *size = __shfl(res, 16, 64);
+}
+
+__device__ static inline void fastFence(Ctl& c) {
+  if (c.l1Dirty) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); c.l1Dirty = 0; }  // vmcnt(0) + L1 invalidate: the no-return atomics are now what plain loads see
+}
+
+// 64 base positions per step, coalesced (keys, removed flags, extras, class bits all stored in base order)
+__device__ static inline void baseScan(const FastK& k, FastS& S, const JobTail& r) {
+  int lane = threadIdx.x & 63;
+  int s = r.shape;
+  int p0 = g_fl.cand[s].pos;
+  int N = k.N; size_t Npad = k.Npad; int E = k.E;
+  for (;;) {
+    if (p0 >= N) { g_fl.cand[s].pos = N; g_fl.cand[s].node = -1; return; }
+    int p = p0 + lane;
+    bool ok = false;
+    unsigned long long key = 0, cls = 0; long long ex0 = 0, ex1 = 0; int node = -1;
+    if (p < N) {
+      key = k.baseKey[p]; cls = k.baseCls[p]; node = k.baseNode[p];
+      uint8_t rem = k.baseRemoved[p];
+      if (E > 0) ex0 = k.baseExtra[p];
+      if (E > 1) ex1 = k.baseExtra[Npad + p];
+      ok = !rem && entryFits(k, r, key, ex0, ex1, cls);
+    }
+    unsigned long long b = __ballot(ok);
+    S.statScanSteps++;
+    if (b) {
+      int f = __ffsll((long long)b) - 1;
+      CandRec c;
+      c.pos = p0 + f; c.node = __shfl(node, f, 64); c.key = __shfl(key, f, 64); c.cls = __shfl(cls, f, 64); c.ex0 = __shfl(ex0, f, 64); c.ex1 = __shfl(ex1, f, 64); c.pad = 0;
+      g_fl.cand[s] = c;
+      return;
+    }
+    p0 += 64;
+  }
+}
+
+__device__ static inline uint64_t l0Search(const FastK& k, const JobTail& r, int* slot) {
+  int lane = threadIdx.x & 63;
+  unsigned long long best = ~0ull; int bs = -1;
+  int cnt = g_fl.l0Count;
+  for (int i = lane; i < cnt; i += 64) {
+    unsigned long long key = g_fl.l0Key[i];
+    if (key < best && entryFits(k, r, key, g_fl.l0Ex0[i], g_fl.l0Ex1[i], g_fl.l0Cls[i])) { best = key; bs = i; }
+  }
+  for (int off = 32; off; off >>= 1) {
+    unsigned long long ok = __shfl_xor(best, off, 64); int os = __shfl_xor(bs, off, 64);
+    if (ok < best) { best = ok; bs = os; }
+  }
+  *slot = bs;
+  return best;
+}
+
+// WIN(=4) records x 16 lanes x 8 bytes: one coalesced 128-byte burst per job record
+__device__ static inline void winRefill(const FastK& k, int q, int kind, int pos, int cnt) {
+  int lane = threadIdx.x & 63;
+  int i = lane >> 4, part = lane & 15;
+  if (i < cnt) {
+    int job = kind == 0 ? k.evList[pos + i] : k.queuedJobs[pos + i];
+    int idx = kind == 0 ? k.evIdxByPos[pos + i] : -1;
+    unsigned long long v = k.jrec[(size_t)job * (sizeof(JobRec) / 8) + part];
+    ((unsigned long long*)&g_fl.winRec[q][i])[part] = v;
+    if (part == 0) { g_fl.winJob[q][i] = job; g_fl.winIdx[q][i] = idx; }
+  }
+}
+__device__ static inline void loadHeadRec(const FastK& k, int q, int job) {
+  int lane = threadIdx.x & 63;
+  if (lane < 16) {
+    unsigned long long v = k.jrec[(size_t)job * (sizeof(JobRec) / 8) + lane];
+    if (lane < 8) ((unsigned long long*)g_fl.headReq[q])[lane] = v; else ((unsigned long long*)&g_fl.headTail[q])[lane - 8] = v;
+  }
+}
+__device__ static inline void headFromWindow(int q, int w) {
+  int lane = threadIdx.x & 63;
+  if (lane < 16) {
+    unsigned long long v = ((const unsigned long long*)&g_fl.winRec[q][w])[lane];
+    if (lane < 8) ((unsigned long long*)g_fl.headReq[q])[lane] = v; else ((unsigned long long*)&g_fl.headTail[q])[lane - 8] = v;
+  }
+}
+
+// markAllocatable (node.go:539-549) for levels [lo, nl) as no-return HBM atomics, one (level, resource) per lane
+__device__ static inline void bindUpdate(const FastK& k, int n, int lo, int nl, int q, uint64_t keyDelta) {
+  int lane = threadIdx.x & 63;
+  int R = k.R, cnt = (nl - lo) * R;
+  for (int i = lane; i < cnt; i += 64) {
+    int l = lo + i / R, x = i % R;
+    int64_t v = g_fl.headReq[q][x];
+    if (v) __hip_atomic_fetch_add(&KAL(k, l, x, n), -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (lane < nl - lo && keyDelta) __hip_atomic_fetch_add(&KKEY(k, lo + lane, n), 0ull - keyDelta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// sctx / qctx resource vectors for the head job of queue q: accumulate-only, lane x handles resource x;
+// LDS vectors through ds_add_u64, HBM by-priority-class vectors through global atomics, all without a return value
+__device__ static inline void accountVectors(Dev& d, const FastK& k, int q, int pc, bool ev, bool replay) {
+  (void)d;
+  int lane = threadIdx.x & 63;
+  if (lane < k.R) {
+    int64_t v = g_fl.headReq[q][lane];
+    if (v) {
+      if (replay) { LDS_ADD64(g_fl.qReplay[q][lane], v); return; }
+      LDS_ADD64(g_fl.qAlloc[q][lane], v); LDS_ADD64(g_rs.allocated[lane], v);
+      if (ev) LDS_ADD64(g_rs.evicted[lane], -v); else LDS_ADD64(g_rs.scheduled[lane], v);
+      size_t i = ((size_t)q * k.npc + pc) * k.R + lane;
+      __hip_atomic_fetch_add(&k.qAllocByPc[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ev) __hip_atomic_fetch_add(&k.qEvictedByPc[i], -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_fetch_add(&k.qSchedByPc[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+__device__ static inline bool roundLimitExceeded(Dev& d, const FastK& k) {
+  (void)d;
+  int lane = threadIdx.x & 63;
+  bool ex = lane < k.R && g_rs.scheduled[lane] > k.maxToSchedule[lane];
+  return __ballot(ex) != 0;
+}
+__device__ static inline bool headRequestsDisallowed(const FastK& k, int q) {
+  int lane = threadIdx.x & 63;
+  bool bad = lane < k.R && k.disallowed[lane] && g_fl.headReq[q][lane] > 0;
+  return __ballot(bad) != 0;
+}
+
+// ------------------------------------------------------------------------------------------------ LDS residency of the round's small state
+// Every per-queue array and the scheduling-context scalars are moved into LDS for the duration of the launch by
+// re-pointing the Dev descriptor (which itself lives in LDS): generic and fast code alike then pay LDS latency for them.
+#define ARENA_BYTES (16 * 1024)
+__shared__ unsigned long long g_arena[ARENA_BYTES / 8];
+struct Reloc { void** pp; void* global; int bytes; };
+#define MAX_RELOC 48
+__shared__ Reloc g_reloc[MAX_RELOC];
+__shared__ int g_nreloc;
+__shared__ RoundScalars* g_rsGlobal;
+
+__device__ static void relocateIn(Dev& d, int cmd) {
+  // executed by every thread; the table is built by thread 0
+  if (threadIdx.x == 0) {
+    g_nreloc = 0;
+    g_rsGlobal = d.rs;
+    int Q = d.cfg.Q, R = d.cfg.R, npc = d.cfg.npc;
+    bool want = (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY) && Q > 0 && d.qWeight != nullptr;
+    if (want) {
+      int off = 0, n = 0; bool fits = true;
+      auto add = [&](void** pp, int bytes) {
+        if (!*pp || !fits) return;
+        int b = (bytes + 7) & ~7;
+        if (off + b > ARENA_BYTES || n >= MAX_RELOC) { fits = false; return; }
+        g_reloc[n].pp = pp; g_reloc[n].global = *pp; g_reloc[n].bytes = bytes; n++; off += b;
+      };
+      int q1 = Q + 1;
+      add((void**)&d.qWeight, Q * 8); add((void**)&d.qNameRank, Q * 4); add((void**)&d.qTokens, Q * 8); add((void**)&d.qBurst, Q * 8);
+      add((void**)&d.qRateInf, Q); add((void**)&d.qCordoned, Q); add((void**)&d.qAlloc, Q * R * 8); add((void**)&d.qPenalty, Q * R * 8);
+      // qAllocByPc / qSchedByPc / qEvictedByPc stay in HBM: the fast path accumulates into them with global atomics
+      add((void**)&d.queuedOff, q1 * 4); add((void**)&d.evOff, (Q + 2) * 4);
+      add((void**)&d.itEi, q1 * 4); add((void**)&d.itQi, q1 * 4); add((void**)&d.itStage, q1 * 4); add((void**)&d.itJobsSeen, q1 * 4);
+      add((void**)&d.itNext, q1 * 4); add((void**)&d.itStashed, q1 * 4);
+      add((void**)&d.itJobOnlyEv, q1); add((void**)&d.itGangOnlyEv, q1); add((void**)&d.onlyEvByQueue, q1); add((void**)&d.qEvictable, q1);
+      add((void**)&d.pqProposed, q1 * 8); add((void**)&d.pqCurrent, q1 * 8); add((void**)&d.pqBudget, q1 * 8); add((void**)&d.pqSize, q1 * 8);
+      add((void**)&d.pqPcPrio, q1 * 4); add((void**)&d.pqSchedPrio, q1 * 4); add((void**)&d.pqGctx, q1 * 4); add((void**)&d.pqInHeap, q1);
+      add((void**)&d.replayAlloc, q1 * R * 8);
+      g_nreloc = fits ? n : 0;
+    }
+  }
+  __syncthreads();
+  // scalars
+  {
+    const int* src = (const int*)g_rsGlobal; int* dst = (int*)&g_rs;
+    for (int i = threadIdx.x; i < (int)(sizeof(RoundScalars) / sizeof(int)); i += blockDim.x) dst[i] = src[i];
+  }
+  int off = 0;
+  for (int k = 0; k < g_nreloc; k++) {
+    const unsigned char* src = (const unsigned char*)g_reloc[k].global; unsigned char* dst = (unsigned char*)g_arena + off;
+    for (int i = threadIdx.x; i < g_reloc[k].bytes; i += blockDim.x) dst[i] = src[i];
+    off += (g_reloc[k].bytes + 7) & ~7;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int o = 0;
+    for (int k = 0; k < g_nreloc; k++) { *g_reloc[k].pp = (unsigned char*)g_arena + o; o += (g_reloc[k].bytes + 7) & ~7; }
+    d.rs = &g_rs;
+  }
+  __syncthreads();
+}
+__device__ static void relocateOut() {
+  __syncthreads();
+  {
+    int* dst = (int*)g_rsGlobal; const int* src = (const int*)&g_rs;
+    for (int i = threadIdx.x; i < (int)(sizeof(RoundScalars) / sizeof(int)); i += blockDim.x) dst[i] = src[i];
+  }
+  int off = 0;
+  for (int k = 0; k < g_nreloc; k++) {
+    unsigned char* dst = (unsigned char*)g_reloc[k].global; const unsigned char* src = (const unsigned char*)g_arena + off;
+    for (int i = threadIdx.x; i < g_reloc[k].bytes; i += blockDim.x) dst[i] = src[i];
+    off += (g_reloc[k].bytes + 7) & ~7;
+  }
+  __threadfence();
+}
+
 // ------------------------------------------------------------------------------------------------ kernels
-__global__ __launch_bounds__(1024) void k_control(Dev dev, int cmd) {
+#define CTL_THREADS 256
+__global__ __launch_bounds__(CTL_THREADS) void k_control(Dev dev, int cmd) {
   // the Dev descriptor (pointers + config) is staged in LDS once; every wave reads it from there
   {
     const int* src = (const int*)&dev; int* dst = (int*)&g_dev;
@@ -157,6 +394,7 @@ __global__ __launch_bounds__(1024) void k_control(Dev dev, int cmd) {
   }
   __syncthreads();
   Dev& d = g_dev;
+  relocateIn(d, cmd);
   if (threadIdx.x >= 64) {  // worker waves: serve mailbox requests until OP_EXIT
     for (;;) {
       __syncthreads();
@@ -172,16 +410,14 @@ __global__ __launch_bounds__(1024) void k_control(Dev dev, int cmd) {
       }
       __syncthreads();
     }
+    relocateOut();
     return;
   }
-  Ctl c;
-  c.txn.active = d.rs->txnActive; c.fairStamp = d.rs->fairStamp; c.preList = d.preList; c.preCount = 0;
-  c.skipKeyCheck = 0; c.compareSchedPrio = 0; c.preferLarge = d.cfg.preferLarge; c.useReplayAlloc = 0; c.onlyEvicted = 0;
-  runCommand(d, c, cmd);
-  d.rs->txnActive = c.txn.active; d.rs->fairStamp = c.fairStamp;
+  controlMain(d, cmd);
   __threadfence();
   if ((threadIdx.x & 63) == 0) g_mb.op = OP_EXIT;
   __syncthreads();
+  relocateOut();
 }
 
 __global__ void k_shape_mask(Dev d, const uint64_t* classMask, const int32_t* shapeClass) {
@@ -223,6 +459,51 @@ __global__ __launch_bounds__(FIT_TILE) void k_fit_batch(Dev d, const int32_t* sh
     unsigned long long v = waveMin64(f ? key : ~0ull);
     if ((threadIdx.x & 63) == 0 && v != ~0ull) atomicMin(&out[i], v);
   }
+}
+
+// ---- sorted base of the level-0 fast structure: the ordered index of the fresh NodeDb (nodedb.go:1164-1175), built in round_prepare
+__global__ void k_base_fill(Dev d, int nb2) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nb2) d.baseKey[i] = i < d.cfg.N ? d.keys[i] : ~0ull;  // level 0 plane of keys
+}
+__global__ void k_bitonic_step(unsigned long long* a, int j, int k) {
+  unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned l = i ^ (unsigned)j;
+  if (l > i) {
+    unsigned long long x = a[i], y = a[l];
+    bool up = (i & (unsigned)k) == 0;
+    if (up ? x > y : x < y) { a[i] = y; a[l] = x; }
+  }
+}
+// the in-LDS part of the network: every (k, j) step with j < 2048 for one 4096-key tile, 1024 threads
+__global__ __launch_bounds__(1024) void k_bitonic_tile(unsigned long long* a, int kStart, int kEnd, int jStart) {
+  __shared__ unsigned long long t[4096];
+  unsigned base = blockIdx.x * 4096u;
+  for (int i = threadIdx.x; i < 4096; i += 1024) t[i] = a[base + i];
+  __syncthreads();
+  for (int k = kStart; k <= kEnd; k <<= 1) {
+    for (int j = (k == kStart ? jStart : k >> 1); j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < 4096; i += 1024) {
+        unsigned l = (unsigned)i ^ (unsigned)j;
+        if (l > (unsigned)i) {
+          unsigned long long x = t[i], y = t[l];
+          bool up = ((base + i) & (unsigned)k) == 0;
+          if (up ? x > y : x < y) { t[i] = y; t[l] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < 4096; i += 1024) a[base + i] = t[i];
+}
+__global__ void k_base_finish(Dev d) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const DevCfg& c = d.cfg;
+  if (i >= c.N) return;
+  unsigned long long key = d.baseKey[i];
+  int node = d.nodeByRank[key & ((1ull << c.idxBits) - 1)];
+  d.baseNode[i] = node; d.posOf[node] = i; d.baseRemoved[i] = 0; d.baseCls[i] = d.nodeCls[node]; d.l0Slot[node] = -1;
+  for (int e = 0; e < d.f.E; e++) d.baseExtra[(size_t)e * c.Npad + i] = d.alloc[(size_t)d.f.extraCol[e] * c.Npad + node];  // level 0 planes
 }
 
 __global__ void k_drf(Dev d, const int64_t* alloc, double* out) { if (threadIdx.x == 0) *out = drf(d, alloc); }
@@ -269,12 +550,34 @@ static int plat_last_control_launches() { return g_lastControlLaunches; }
 static int plat_run_control(Dev& dev, int cmd) {
   if (!g_ev0) { (void)hipEventCreate(&g_ev0); (void)hipEventCreate(&g_ev1); }
   (void)hipEventRecord(g_ev0, g_stream);
-  hipLaunchKernelGGL(k_control, dim3(1), dim3(1024), 0, g_stream, dev, cmd);
+  hipLaunchKernelGGL(k_control, dim3(1), dim3(CTL_THREADS), 0, g_stream, dev, cmd);
   (void)hipEventRecord(g_ev1, g_stream);
   if (!hipOk(hipGetLastError(), "k_control launch")) return -1;
   if (!hipOk(hipStreamSynchronize(g_stream), "k_control")) return -1;
   (void)hipEventElapsedTime(&g_lastControlMs, g_ev0, g_ev1);
   g_lastControlLaunches = 1;
+  return 0;
+}
+static int plat_build_base(Dev& d) {
+  int N = d.cfg.N;
+  int nb2 = 64; while (nb2 < N) nb2 <<= 1;
+  hipLaunchKernelGGL(k_base_fill, dim3((nb2 + 255) / 256), dim3(256), 0, g_stream, d, nb2);
+  unsigned long long* a = (unsigned long long*)d.baseKey;
+  if (nb2 <= 4096) {
+    // pad region beyond nb2 is never touched: the tile kernel is only used when the array is a multiple of 4096
+    for (int k = 2; k <= nb2; k <<= 1) for (int j = k >> 1; j > 0; j >>= 1) hipLaunchKernelGGL(k_bitonic_step, dim3((nb2 + 255) / 256), dim3(256), 0, g_stream, a, j, k);
+  } else {
+    int tiles = nb2 / 4096;
+    hipLaunchKernelGGL(k_bitonic_tile, dim3(tiles), dim3(1024), 0, g_stream, a, 2, 4096, 1);  // all steps with k <= 4096
+    for (int k = 8192; k <= nb2; k <<= 1) {
+      int j = k >> 1;
+      for (; j >= 4096; j >>= 1) hipLaunchKernelGGL(k_bitonic_step, dim3((nb2 + 255) / 256), dim3(256), 0, g_stream, a, j, k);
+      hipLaunchKernelGGL(k_bitonic_tile, dim3(tiles), dim3(1024), 0, g_stream, a, k, k, 2048);      // remaining steps j = 2048..1 inside tiles
+    }
+  }
+  hipLaunchKernelGGL(k_base_finish, dim3((N + 255) / 256), dim3(256), 0, g_stream, d);
+  if (!hipOk(hipGetLastError(), "base build launch")) return -1;
+  if (!hipOk(hipStreamSynchronize(g_stream), "base build")) return -1;
   return 0;
 }
 static int plat_run_shape_mask(Dev& d, const uint64_t* classMask, const int32_t* shapeClass) {

@@ -51,11 +51,12 @@ struct DevCfg {
 
 // One job as the fast path reads it: a single 128-byte burst (16 lanes x 8 B) instead of 12 dependent array reads.
 struct JobRec {
-  int64_t req[MAXR];   // AllResourceRequirements
+  int64_t req[MAXR];   // AllResourceRequirements (zero beyond R)
   uint64_t keyDelta;   // packed (req_c / resolution_c) per indexed column: what a bind subtracts from a node's order key
   uint64_t fieldMin;   // packed (req_c / resolution_c - keyLo_c): smallest key fields of a node the job fits on
-  int32_t pc, shape, gang, node0, runPrio, cls, never, pad;
-  int64_t pad2[2];
+  int32_t pc, shape, gang, node0, runPrio, cls, pcPrio;
+  uint8_t never, preemptible, pad8[2];
+  int64_t ex0, ex1;    // requests on the (<= MAXE) non-indexed columns
 };
 
 // Level-0 ("fit without preemption", priority -2) fast structure, DESIGN.md "Sorted base + LDS delta".
@@ -91,6 +92,8 @@ struct RoundScalars {
   int32_t fastOverflow;      // L0 overflowed: structure dropped for the rest of the round
   int32_t statFastIters, statGenericIters, statScanSteps, statRefills, statL0Max, statFastReplay;
   int32_t pad;
+  int64_t statSeg[8];        // (profiling builds) shader-clock ticks per segment of a fast iteration
+  int64_t statClk[8];        // shader-clock ticks per phase of the round (device builds): evict, replay, pass 1, oversub evict, pass 2, unbind+results
 };
 
 struct Dev {

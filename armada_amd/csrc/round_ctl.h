@@ -16,6 +16,7 @@
 #include "../../include/armada_sched.h"
 
 #ifdef ASCHED_HOSTSIM
+#define CLK() 0ll
 #include <cmath>
 #include <cstring>
 #define DEV static inline
@@ -23,6 +24,7 @@
 #else
 #define DEV __device__ static inline
 #define WG_THREADS 1024
+#define CLK() ((long long)__builtin_readcyclecounter())
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -40,15 +42,16 @@ DEV void atomicOrI32(int32_t* p, int32_t v);
 struct Ctl; struct PassCfg;
 DEV void fastTouch(Dev& d, int n);                 // node n's allocatable changed through the generic code
 DEV int fastSelectLevel0(Dev& d, int job);         // first fit at priority -2 through the fast structure (-2 = structure not usable)
-DEV int pqTopAny(Dev& d, const Ctl& c);
+#ifdef ASCHED_HOSTSIM
+static int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* counter);  // fast iterations until one needs the generic code
+#else
+__device__ static int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* counter);
+#endif
 DEV void fastItemKeys(Dev& d, const Ctl& c, int q);
 DEV void fastHeadInvalidate(int q);
 DEV void fastPassReset();
 DEV bool fastOn(Dev& d, const Ctl& c);
-DEV void fastAdvance(Dev& d, Ctl& c, int q, const PassCfg& pc);
-DEV bool fastIter(Dev& d, Ctl& c, const PassCfg& pc, int top);
-DEV bool fastReplayStep(Dev& d, Ctl& c, const PassCfg& pc, int top, int* counter);
-DEV void fastEnterGeneric(Dev& d, Ctl& c);         // make the fast path's fire-and-forget HBM updates visible to plain loads
+DEV void fastEnterGeneric(Dev& d, Ctl& c);         // leave fast mode: LDS queue state back into the generic arrays, HBM updates visible
 
 // ------------------------------------------------------------------------------------------------
 #define AL(d, l, r, n) ((d).alloc[((size_t)(l) * (d).cfg.R + (r)) * (d).cfg.Npad + (n)])
@@ -309,6 +312,7 @@ struct Ctl {
   int fastEnabled;     // this launch may run fast iterations (host conditions hold, no NodeDb-level API calls since prepare)
   int fastEvStatic;    // evicted jobs of the current pass are phase-1 evictions: node / priority are the job's static run
   int l1Dirty;         // fire-and-forget atomics outstanding: plain loads of alloc/keys need an L1 invalidate first
+  int fqLive;          // the LDS copy of the per-queue state (round_fast.h FastQueues) is the authoritative one
 };
 
 DEV const uint64_t* uniMask(Dev& d, int job) { int v = d.jcUniValue[job]; return v >= 0 ? d.labelMask + (size_t)v * d.cfg.W : (const uint64_t*)0; }
@@ -740,7 +744,6 @@ DEV void costItResume(Dev& d, Ctl& c, const PassCfg& pc) {  // :572-591
 }
 DEV void costItClear(Dev& d, Ctl& c, int top, const PassCfg& pc) {  // :595-606
   if (top < 0) return;
-  if (fastOn(d, c)) { fastAdvance(d, c, top, pc); return; }
   d.pqInHeap[top] = 0;
   d.itNext[top] = -1;
   updateAndPush(d, c, top, pc);
@@ -748,6 +751,7 @@ DEV void costItClear(Dev& d, Ctl& c, int top, const PassCfg& pc) {  // :595-606
 
 DEV void passInit(Dev& d, Ctl& c, const PassCfg& pc) {
   int Q = d.cfg.Q;
+  fastEnterGeneric(d, c);
   fastPassReset();
   for (int q = 0; q < Q; q++) {
     d.itEi[q] = d.evOff[q]; d.itQi[q] = d.queuedOff[q]; d.itStage[q] = 0; d.itJobsSeen[q] = 0; d.itNext[q] = -1; d.itStashed[q] = -1;
@@ -755,7 +759,7 @@ DEV void passInit(Dev& d, Ctl& c, const PassCfg& pc) {
     d.pqBudget[q] = d.qDc[q] / d.qWeight[q];  // pushQueue :509-519
   }
   c.onlyEvicted = 0;
-  for (int q = 0; q < Q; q++) { if (fastOn(d, c)) fastAdvance(d, c, q, pc); else updateAndPush(d, c, q, pc); }
+  for (int q = 0; q < Q; q++) updateAndPush(d, c, q, pc);
 }
 
 // QueueScheduler.Schedule (queue_scheduler.go:94-304)
@@ -763,11 +767,14 @@ DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff)
   bool limitHit = false, resumed = false;
   for (;;) {
     if (d.rs->error) return;
-    if (!limitHit && d.rs->hasFpLimiter && d.rs->fpTokens < 1) { limitHit = true; costItOnlyEvicted(d, c, pc); }
-    int top = pqTopAny(d, c);
+    if (!limitHit && d.rs->hasFpLimiter && d.rs->fpTokens < 1) { fastEnterGeneric(d, c); limitHit = true; costItOnlyEvicted(d, c, pc); }
+    if (fastOn(d, c)) {
+      int pend = fastRun(d, c, pc, 0, (int*)0);
+      fastEnterGeneric(d, c);
+      if (pend >= 0) { updateAndPush(d, c, pend, pc); continue; }
+    }
+    int top = pqTop(d, c);
     int ref = top >= 0 ? d.pqGctx[top] : -1;
-    if (ref >= 0 && fastOn(d, c) && fastIter(d, c, pc, top)) { d.rs->loopIterations++; d.rs->statFastIters++; continue; }
-    fastEnterGeneric(d, c);
     d.rs->statGenericIters++;
     if (ref == -1) {
       if (limitHit && !resumed && d.rs->terminationReason == 0) { resumed = true; costItResume(d, c, pc); continue; }
@@ -812,10 +819,14 @@ DEV void replayEvicted(Dev& d, Ctl& c) {
   passInit(d, c, pc);
   int i = 0;
   for (;;) {
-    int top = pqTopAny(d, c);
+    if (fastOn(d, c)) {
+      int pend = fastRun(d, c, pc, 1, &i);
+      fastEnterGeneric(d, c);
+      if (pend >= 0) { updateAndPush(d, c, pend, pc); continue; }
+    }
+    int top = pqTop(d, c);
     int ref = top >= 0 ? d.pqGctx[top] : -1;
     if (ref == -1) break;
-    if (ref >= 0 && fastOn(d, c) && fastReplayStep(d, c, pc, top, &i)) continue;
     int cnt = gcCount(d, ref);
     for (int k = 0; k < cnt; k++) { evTabInsert(d, i, gcJob(d, ref, k)); i++; }
     vadd(d, QV(d.replayAlloc, gcQueue(d, ref)), gcTotal(d, ref), +1);

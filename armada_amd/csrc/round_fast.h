@@ -1,407 +1,625 @@
 // round_fast.h — the fast path of the scheduling round (DESIGN.md "Fast path").
 //
-// The generic control code (round_ctl.h) restates the reference statement by statement with every piece of state in
-// HBM: ~100 dependent memory round trips per QueueScheduler iteration and one O(N) scan of the allocatable planes per
-// node selection.  This file removes both for the overwhelmingly common iteration — a single (non-gang) job that is
-// either a queued job fitting without preemption or a phase-1-evicted job returning to its node — and hands anything
-// else to the generic code, which sees exactly the state it would have produced itself.
+// The generic control code (round_ctl.h) restates the reference statement by statement with every piece of state behind
+// generic pointers in HBM: ~100 dependent memory round trips per QueueScheduler iteration and one O(N) scan of the
+// allocatable planes per node selection.  This file removes both for the overwhelmingly common iteration — a single
+// (non-gang) job that is either a queued job fitting without preemption or a phase-1-evicted job returning to its node —
+// and hands anything else to the generic code, which then sees exactly the state it would have produced itself.
 //
 //  1. Level-0 fast structure (first fit at priority -2, nodedb.go:737 → 840-879).  Nodes are kept in HBM sorted by
 //     their level-0 order key as of round_prepare ("base", == the reference's memdb index, nodedb.go:1164-1175).
 //     A node whose allocatable changes is flagged removed in the base and, while it can still host some shape, lives in
 //     an LDS list ("L0").  First fit = min(first clean feasible base entry from a per-shape cursor, min over L0).  Both
 //     candidates are exact: clean entries are unchanged since the sort, L0 holds current values, and keys are unique.
-//  2. Per-queue head job records and small prefetch windows in LDS; a job is one 128-byte JobRec burst.
+//  2. One LDS record per queue (QRec: iterator + cost state, array-of-structs so that one burst of wide LDS reads
+//     fetches it), the head job record and a small prefetch window per queue; a job is one 128-byte JobRec burst.  While
+//     fast iterations run these are the authoritative copy of that state; they are written back to the generic arrays
+//     before any generic code runs (fastEnterGeneric) and re-read afterwards (fastEnsureLive).
 //  3. DRF cost (fairness.go:99-105) evaluated across lanes: the 3 x R float64 divisions of one updatePQItem
 //     (queue_scheduler.go:636-686) issue together; same IEEE operations, same results.
 //  4. Queue selection by a packed total-order key equivalent to QueueCandidateGangIteratorPQ.Less
 //     (queue_scheduler.go:738-798) for finite costs.
-//  5. Binds as no-return HBM atomics (node.go:416-442 arithmetic), nothing waits on them.
+//  5. Binds and accounting as no-return HBM atomics / plain stores with explicit global address space (node.go:416-442
+//     arithmetic): nothing waits on them; LDS traffic uses ds_* instructions, so the two never serialise on each other.
+//  6. The loop (fastRun) is a separate, non-inlined function whose constants (FastK) and scheduling-context scalars
+//     (FastS) live in registers: an iteration is ~4 dependent LDS round trips instead of ~150.
 //
-// Lane-parallel primitives have a device and a host (tests/hostsim) implementation with the same contract.
+// Lane-parallel primitives have a device (armada_sched.hip) and a host (tests/hostsim) implementation, same contract.
 #pragma once
 #include "round_ctl.h"
+
+// Per-queue scalars of CostBasedCandidateGangIterator + QueuedGangIterator (authoritative in fast mode).  The fast loop
+// reads the fields it needs of one queue (independent LDS reads, one round trip) and stores back only what it changes.
+struct alignas(16) QHot {
+  double weight, tokens, budget, proposed, current, size;
+  int64_t burst;
+  int32_t itEi, itQi, itStage, itJobsSeen, itNext, gctx, evEnd, qEnd, pcPrio, schedPrio;
+  int32_t rateInf, cordoned, itJobOnlyEv, itGangOnlyEv;
+  int32_t headFast, headKind, headIdx;      // head job: record cached in head*, 0 evicted / 1 queued, evicted-table Index
+  int32_t winKind, winStart, winCount;      // prefetch window: stream (0 evicted list, 1 queued list) and position range
+};
+struct alignas(16) JobTail {  // second half of a JobRec
+  uint64_t keyDelta, fieldMin;
+  int32_t pc, shape, gang, node0, runPrio, cls, pcPrio;
+  uint8_t never, preemptible, pad8[2];
+  int64_t ex0, ex1;
+};
+static_assert(sizeof(JobTail) == 64 && sizeof(JobRec) == 128 && __builtin_offsetof(JobRec, keyDelta) == 64, "JobRec = request vector + JobTail");
+struct alignas(16) CandRec { int32_t pos, node; uint64_t key, cls; int64_t ex0, ex1; int64_t pad; };  // node: >=0, -1 exhausted, -2 scan from pos
 
 struct FastLds {
   // L0: live dirty nodes (current level-0 key / non-indexed columns / class bits)
   int l0Count;
-  uint64_t l0Key[L0CAP]; int32_t l0Node[L0CAP]; int64_t l0Extra[MAXE][L0CAP]; uint64_t l0Cls[L0CAP];
-  // per-shape base cursor + validated candidate (candNode: >=0 node, -1 exhausted, -2 needs a scan from candPos)
-  int32_t candPos[SMAX]; int32_t candNode[SMAX]; uint64_t candKey[SMAX]; int64_t candExtra[MAXE][SMAX]; uint64_t candCls[SMAX];
-  // queue heads + prefetch windows
-  uint8_t headFast[QCAPF]; uint8_t headKind[QCAPF]; int32_t headIdx[QCAPF]; JobRec headRec[QCAPF];
-  int32_t winKind[QCAPF]; int32_t winStart[QCAPF]; int32_t winCount[QCAPF]; int32_t winJob[QCAPF][WIN]; int32_t winIdx[QCAPF][WIN];
+  uint64_t l0Key[L0CAP]; int32_t l0Node[L0CAP]; int64_t l0Ex0[L0CAP], l0Ex1[L0CAP]; uint64_t l0Cls[L0CAP];
+  CandRec cand[SMAX];   // per-shape base cursor + validated candidate
+  QHot hot[QCAPF];
+  int64_t qAlloc[QCAPF][MAXR], qPenalty[QCAPF][MAXR], qReplay[QCAPF][MAXR];  // resource vectors: one lane per resource
+  int64_t headReq[QCAPF][MAXR]; JobTail headTail[QCAPF];
+  int32_t winJob[QCAPF][WIN]; int32_t winIdx[QCAPF][WIN];
   JobRec winRec[QCAPF][WIN];
-  // packed queue-order keys
-  uint32_t kA[QCAPF]; uint64_t kX[QCAPF]; uint64_t kY[QCAPF];
+  // queue order: packed keys + heap membership + name rank, one lane per queue
+  uint32_t kA[QCAPF]; uint64_t kX[QCAPF]; uint64_t kY[QCAPF]; int32_t inHeap[QCAPF]; int32_t nameRank[QCAPF];
 };
 
 #ifdef ASCHED_HOSTSIM
+#define FK_STORAGE static
 static FastLds g_fl;
 #define FLANE 0
+#define GA(T, p) (p)   // a pointer known to address HBM (explicit global address space on the device)
+#define GP(T) T*
+#define RS (*d.rs)
+#define FOR_LANES(i, n) for (int i = 0; i < (n); i++)
+#define LDS_ADD64(ref, v) ((ref) += (v))
+#define DEV_NOINLINE static __attribute__((noinline))
 #else
+#define FK_STORAGE __shared__
 __shared__ FastLds g_fl;
+__shared__ RoundScalars g_rs;  // d.rs points here for the whole launch (relocateIn, armada_sched.hip)
 #define FLANE ((int)(threadIdx.x & 63))
+#define GA(T, p) ((__attribute__((address_space(1))) T*)(p))
+#define GP(T) __attribute__((address_space(1))) T*
+#define RS g_rs
+#define FOR_LANES(i, n) for (int i = FLANE; i < (n); i += 64)
+#define LDS_ADD64(ref, v) ((void)__hip_atomic_fetch_add(&(ref), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))  // ds_add_u64, no return: nothing waits
+#define DEV_NOINLINE __device__ static __attribute__((noinline))
 #endif
 #define FL g_fl
 
+#ifdef ASCHED_FASTPROF
+#define SEG_BEGIN() S.segT = CLK()
+#define SEG(i) do { long long _n = CLK(); if (FLANE == 0) RS.statSeg[i] += _n - S.segT; S.segT = _n; } while (0)
+#else
+#define SEG_BEGIN() do {} while (0)
+#define SEG(i) do {} while (0)
+#endif
 struct FitHandle { int src; int slot; };  // src 0: base candidate of the shape, 1: L0 slot
+// what the fast loop needs of Ctl + PassCfg, by value
+struct FastCtx { int withQueued; uint32_t maxLookback; int skipKnown, compareSchedPrio, preferLarge, replay, evStatic; };
+
+// loop constants: configuration and array bases, read once per fastRun (registers for the whole run)
+struct FastK {
+  int R, K, P, E, ex0col, ex1col, N, npc, S, disableHome, hasPcLimit, anyDisallowed;
+  size_t Npad;
+  uint64_t fieldMask[MAXK]; uint64_t minFieldMin; int64_t minEx0, minEx1;
+  int64_t maxToSchedule[MAXR]; int32_t prios[MAXP]; uint8_t disallowed[MAXR];
+  GP(uint64_t) baseKey; GP(int32_t) baseNode; GP(int64_t) baseExtra; GP(uint64_t) baseCls; GP(uint8_t) baseRemoved; GP(int32_t) l0Slot;
+  GP(int64_t) alloc; GP(uint64_t) keys; GP(unsigned long long) jrec; GP(int32_t) evList; GP(int32_t) queuedJobs; GP(int32_t) evIdxByPos;
+  GP(uint8_t) jcEvicted; GP(int32_t) jcAssigned; GP(int32_t) jcReason; GP(uint8_t) jcHasPctx; GP(int32_t) jcGangCard; GP(int32_t) jcUniValue; GP(int32_t) jcStagedBy;
+  GP(int32_t) pcNode; GP(int32_t) pcSap; GP(int32_t) pcPap; GP(int32_t) pcMethod; GP(int32_t) jobNode; GP(int32_t) jobCutoff; GP(uint8_t) jobEvictedOnNode;
+  GP(int32_t) schedAtPrio; GP(uint8_t) inSchedAndEvicted; GP(uint8_t) inPreempted; GP(uint8_t) inScheduled; GP(uint8_t) jobFlags;
+  GP(uint8_t) evTabAlive; GP(int32_t) evTabJob; GP(int32_t) evIndexOfJob; GP(uint8_t) unfeasible;
+  GP(int64_t) qAllocByPc; GP(int64_t) qSchedByPc; GP(int64_t) qEvictedByPc;
+};
+// scheduling-context scalars the loop reads and writes (context/scheduling.go:27-77), written back to RS at the end of a run
+struct FastS {
+  double globalTokens; int64_t globalBurst; int32_t globalRateInf;
+  int32_t numScheduledJobs, numScheduledGangs, numEvictedJobs, numNodeQueries, loopIterations, evictedTableSize;
+  int32_t numUnfeasible, numPreemptedMarks, fastActive, lvl0NonNeg;
+  int32_t statFastIters, statScanSteps, statRefills, statL0Max, statFastReplay;
+  long long segT;
+};
+
+FK_STORAGE FastK g_fk;  // the loop's constants, filled at the start of every fastRun (LDS on the device: read at use, not held in registers)
+
+DEV void fastKInit(Dev& d, FastK& k) {
+  const DevCfg& c = d.cfg;
+  k.R = c.R; k.K = c.K; k.P = c.P; k.E = d.f.E; k.ex0col = d.f.extraCol[0]; k.ex1col = d.f.extraCol[1]; k.N = c.N; k.npc = c.npc; k.S = c.S;
+  k.disableHome = c.disableHome; k.hasPcLimit = d.hasPcLimit; k.Npad = (size_t)c.Npad;
+  k.anyDisallowed = 0;
+  for (int i = 0; i < MAXR; i++) { k.maxToSchedule[i] = c.maxToSchedule[i]; k.disallowed[i] = i < c.R ? c.disallowed[i] : 0; if (k.disallowed[i]) k.anyDisallowed = 1; }
+  for (int i = 0; i < MAXK; i++) k.fieldMask[i] = i < c.K ? d.f.fieldMask[i] : 0;
+  for (int i = 0; i < MAXP; i++) k.prios[i] = c.prios[i];
+  k.minFieldMin = d.f.minFieldMin; k.minEx0 = d.f.minExtra[0]; k.minEx1 = d.f.minExtra[1];
+  k.baseKey = GA(uint64_t, d.baseKey); k.baseNode = GA(int32_t, d.baseNode); k.baseExtra = GA(int64_t, d.baseExtra); k.baseCls = GA(uint64_t, d.baseCls);
+  k.baseRemoved = GA(uint8_t, d.baseRemoved); k.l0Slot = GA(int32_t, d.l0Slot);
+  k.alloc = GA(int64_t, d.alloc); k.keys = GA(uint64_t, d.keys); k.jrec = GA(unsigned long long, (unsigned long long*)d.jrec);
+  k.evList = GA(int32_t, d.evList); k.queuedJobs = GA(int32_t, d.queuedJobs); k.evIdxByPos = GA(int32_t, d.evIdxByPos);
+  k.jcEvicted = GA(uint8_t, d.jcEvicted); k.jcAssigned = GA(int32_t, d.jcAssigned); k.jcReason = GA(int32_t, d.jcReason); k.jcHasPctx = GA(uint8_t, d.jcHasPctx);
+  k.jcGangCard = GA(int32_t, d.jcGangCard); k.jcUniValue = GA(int32_t, d.jcUniValue); k.jcStagedBy = GA(int32_t, d.jcStagedBy);
+  k.pcNode = GA(int32_t, d.pcNode); k.pcSap = GA(int32_t, d.pcSap); k.pcPap = GA(int32_t, d.pcPap); k.pcMethod = GA(int32_t, d.pcMethod);
+  k.jobNode = GA(int32_t, d.jobNode); k.jobCutoff = GA(int32_t, d.jobCutoff); k.jobEvictedOnNode = GA(uint8_t, d.jobEvictedOnNode);
+  k.schedAtPrio = GA(int32_t, d.schedAtPrio); k.inSchedAndEvicted = GA(uint8_t, d.inSchedAndEvicted); k.inPreempted = GA(uint8_t, d.inPreempted);
+  k.inScheduled = GA(uint8_t, d.inScheduled); k.jobFlags = GA(uint8_t, d.jobFlags);
+  k.evTabAlive = GA(uint8_t, d.evTabAlive); k.evTabJob = GA(int32_t, d.evTabJob); k.evIndexOfJob = GA(int32_t, d.evIndexOfJob); k.unfeasible = GA(uint8_t, d.unfeasible);
+  k.qAllocByPc = GA(int64_t, d.qAllocByPc); k.qSchedByPc = GA(int64_t, d.qSchedByPc); k.qEvictedByPc = GA(int64_t, d.qEvictedByPc);
+}
+#define KAL(k, l, r, n) ((k).alloc[((size_t)(l) * (k).R + (r)) * (k).Npad + (n)])
+#define KKEY(k, l, n) ((k).keys[(size_t)(l) * (k).Npad + (n)])
 
 // ------------------------------------------------------------------------------------------------ small helpers
 DEV uint64_t dbits(double x) { return __builtin_bit_cast(uint64_t, x); }
 
-DEV bool fieldsGE(const Dev& d, uint64_t key, uint64_t fmin) {  // every packed field of key >= the same field of fmin
-  for (int i = 0; i < d.cfg.K; i++) { uint64_t m = d.f.fieldMask[i]; if ((key & m) < (fmin & m)) return false; }
-  return true;
+DEV bool fieldsGE(const FastK& k, uint64_t key, uint64_t fmin) {  // every packed field of key >= the same field of fmin
+  bool ok = true;
+  for (int i = 0; i < MAXK; i++) { uint64_t m = k.fieldMask[i]; ok = ok && (key & m) >= (fmin & m); }  // unused fields have mask 0
+  return ok;
 }
-DEV bool entryFits(const Dev& d, const JobRec& r, uint64_t key, int64_t ex0, int64_t ex1, uint64_t cls) {
-  if (!((cls >> r.cls) & 1)) return false;          // StaticJobRequirementsMet via the requirement class (nodematching.go:161-183)
-  if (!fieldsGE(d, key, r.fieldMin)) return false;  // indexed columns: alloc/res >= req/res (both resolution-aligned)
-  if (d.f.E > 0 && r.req[d.f.extraCol[0]] > ex0) return false;  // non-indexed columns (nodematching.go:194-197)
-  if (d.f.E > 1 && r.req[d.f.extraCol[1]] > ex1) return false;
-  return true;
+DEV bool entryFits(const FastK& k, const JobTail& r, uint64_t key, int64_t ex0, int64_t ex1, uint64_t cls) {
+  bool ok = ((cls >> r.cls) & 1) != 0;      // StaticJobRequirementsMet via the requirement class (nodematching.go:161-183)
+  ok = ok && fieldsGE(k, key, r.fieldMin);  // indexed columns: alloc/res >= req/res (both resolution-aligned)
+  ok = ok && r.ex0 <= ex0 && r.ex1 <= ex1;  // non-indexed columns (nodematching.go:194-197); unused extras are 0 vs 0
+  return ok;
 }
-DEV bool entryLive(const Dev& d, uint64_t key, int64_t ex0, int64_t ex1) {  // could still host the smallest request of some shape
-  if (!fieldsGE(d, key, d.f.minFieldMin)) return false;
-  if (d.f.E > 0 && d.f.minExtra[0] > ex0) return false;
-  if (d.f.E > 1 && d.f.minExtra[1] > ex1) return false;
-  return true;
+DEV bool entryLive(const FastK& k, uint64_t key, int64_t ex0, int64_t ex1) {  // could still host the smallest request of some shape
+  return fieldsGE(k, key, k.minFieldMin) && k.minEx0 <= ex0 && k.minEx1 <= ex1;
 }
 DEV bool fastOn(Dev& d, const Ctl& c) { return c.fastEnabled && d.f.iterOk; }
-DEV void fastHeadInvalidate(int q) { if (q < QCAPF) FL.headFast[q] = 0; }
-DEV void fastPassReset() { for (int q = 0; q < QCAPF; q++) { FL.headFast[q] = 0; FL.winCount[q] = 0; FL.winKind[q] = -1; } }
+DEV void fastHeadInvalidate(int q) { if (q < QCAPF) FL.hot[q].headFast = 0; }
+DEV void fastPassReset() { for (int q = 0; q < QCAPF; q++) { FL.hot[q].headFast = 0; FL.hot[q].winCount = 0; FL.hot[q].winKind = -1; } }
 
 // Less (queue_scheduler.go:738-798) as a lexicographic key (kA, kX, kY, name rank); exact for finite, non-negative costs
-DEV void fastItemKeys(Dev& d, const Ctl& c, int q) {
-  if (!d.f.iterOk || q >= QCAPF) return;
-  int32_t prio = c.compareSchedPrio ? d.pqSchedPrio[q] : d.pqPcPrio[q];
+DEV void packItemKeys(int preferLarge, int q, int32_t prio, double proposed, double current, double size, double budget) {
   FL.kA[q] = ~((uint32_t)prio ^ 0x80000000u);  // higher priority first
-  double pa = d.pqProposed[q];
-  if (c.preferLarge) {
-    if (pa <= d.pqBudget[q]) { FL.kX[q] = dbits(d.pqCurrent[q]); FL.kY[q] = ~dbits(d.pqSize[q]); }  // under budget: lower current cost, then larger item
-    else { FL.kX[q] = dbits(pa) | (1ull << 63); FL.kY[q] = 0; }                                       // over budget: after every under-budget item, lower proposed cost
-  } else { FL.kX[q] = dbits(pa); FL.kY[q] = 0; }
+  if (preferLarge) {
+    if (proposed <= budget) { FL.kX[q] = dbits(current); FL.kY[q] = ~dbits(size); }  // under budget: lower current cost, then larger item
+    else { FL.kX[q] = dbits(proposed) | (1ull << 63); FL.kY[q] = 0; }                 // over budget: after every under-budget item, lower proposed cost
+  } else { FL.kX[q] = dbits(proposed); FL.kY[q] = 0; }
 }
+DEV void fastItemKeys(Dev& d, const Ctl& c, int q) {  // from the generic arrays (generic updatePQItem)
+  if (!d.f.iterOk || q >= QCAPF) return;
+  packItemKeys(c.preferLarge, q, c.compareSchedPrio ? d.pqSchedPrio[q] : d.pqPcPrio[q], d.pqProposed[q], d.pqCurrent[q], d.pqSize[q], d.pqBudget[q]);
+}
+
+// ------------------------------------------------------------------------------------------------ fast <-> generic state hand-over
+DEV void fastQLoad(Dev& d) {
+  int R = d.cfg.R;
+  FOR_LANES(q, d.cfg.Q) {
+    QHot& f = FL.hot[q];
+    f.weight = d.qWeight[q]; f.tokens = d.qTokens[q]; f.budget = d.pqBudget[q];
+    f.proposed = d.pqProposed[q]; f.current = d.pqCurrent[q]; f.size = d.pqSize[q];
+    f.burst = d.qBurst[q];
+    for (int x = 0; x < MAXR; x++) { bool in = x < R; FL.qAlloc[q][x] = in ? QV(d.qAlloc, q)[x] : 0; FL.qPenalty[q][x] = in ? QV(d.qPenalty, q)[x] : 0; FL.qReplay[q][x] = in ? QV(d.replayAlloc, q)[x] : 0; }
+    f.itEi = d.itEi[q]; f.itQi = d.itQi[q]; f.itStage = d.itStage[q]; f.itJobsSeen = d.itJobsSeen[q];
+    f.itNext = d.itNext[q]; f.gctx = d.pqGctx[q]; f.evEnd = d.evOff[q + 1]; f.qEnd = d.queuedOff[q + 1];
+    f.pcPrio = d.pqPcPrio[q]; f.schedPrio = d.pqSchedPrio[q];
+    f.rateInf = d.qRateInf[q]; f.cordoned = d.qCordoned[q]; f.itJobOnlyEv = d.itJobOnlyEv[q]; f.itGangOnlyEv = d.itGangOnlyEv[q];
+    FL.inHeap[q] = d.pqInHeap[q]; FL.nameRank[q] = d.qNameRank[q];
+  }
+}
+DEV void fastQFlush(Dev& d) {
+  int R = d.cfg.R;
+  FOR_LANES(q, d.cfg.Q) {
+    const QHot& f = FL.hot[q];
+    d.qTokens[q] = f.tokens;
+    d.pqProposed[q] = f.proposed; d.pqCurrent[q] = f.current; d.pqSize[q] = f.size;
+    for (int x = 0; x < R; x++) { QV(d.qAlloc, q)[x] = FL.qAlloc[q][x]; QV(d.replayAlloc, q)[x] = FL.qReplay[q][x]; }
+    d.itEi[q] = f.itEi; d.itQi[q] = f.itQi; d.itStage[q] = f.itStage; d.itJobsSeen[q] = f.itJobsSeen;
+    d.itNext[q] = f.itNext; d.pqGctx[q] = f.gctx; d.pqPcPrio[q] = f.pcPrio; d.pqSchedPrio[q] = f.schedPrio;
+    d.pqInHeap[q] = (uint8_t)FL.inHeap[q];
+  }
+}
+DEV void fastEnsureLive(Dev& d, Ctl& c) { if (!c.fqLive) { fastQLoad(d); c.fqLive = 1; } }
 
 // ------------------------------------------------------------------------------------------------ lane-parallel primitives
 #ifdef ASCHED_HOSTSIM
-DEV int pqTopFast(Dev& d) {
+DEV int pqTopFast(int Q) {
   int best = -1;
-  for (int q = 0; q < d.cfg.Q; q++) {
-    if (!d.pqInHeap[q]) continue;
+  for (int q = 0; q < Q; q++) {
+    if (!FL.inHeap[q]) continue;
     if (best < 0) { best = q; continue; }
     bool less;
     if (FL.kA[q] != FL.kA[best]) less = FL.kA[q] < FL.kA[best];
     else if (FL.kX[q] != FL.kX[best]) less = FL.kX[q] < FL.kX[best];
     else if (FL.kY[q] != FL.kY[best]) less = FL.kY[q] < FL.kY[best];
-    else less = d.qNameRank[q] < d.qNameRank[best];
+    else less = FL.nameRank[q] < FL.nameRank[best];
     if (less) best = q;
   }
   return best;
 }
-// DRF costs of one updatePQItem: proposed = drf(alloc+req)/w, current = drf(alloc)/w, size = drf(req)*w
-DEV void drf3(Dev& d, const int64_t* base, const int64_t* pen, const int64_t* req, double w, double* proposed, double* current, double* size) {
+// DRF costs of one updatePQItem for queue q and the job record in window slot k (the LDS vectors must be current):
+// proposed = drf(alloc+req)/w, current = drf(alloc)/w, size = drf(req)*w
+DEV void drf3(Dev& d, int q, int k, bool replay, double w, double* proposed, double* current, double* size) {
   int64_t alloc[MAXR], with[MAXR];
-  for (int r = 0; r < d.cfg.R; r++) { alloc[r] = base[r] + pen[r]; with[r] = alloc[r] + req[r]; }
+  const int64_t* req = FL.winRec[q][k].req;
+  for (int r = 0; r < d.cfg.R; r++) { alloc[r] = (replay ? FL.qReplay[q][r] : FL.qAlloc[q][r]) + FL.qPenalty[q][r]; with[r] = alloc[r] + req[r]; }
   *proposed = drf(d, with) / w; *current = drf(d, alloc) / w; *size = drf(d, req) * w;
 }
-DEV void fastEnterGeneric(Dev&, Ctl&) {}
+DEV void fastFence(Ctl&) {}
 // advance the base cursor of shape r.shape to the next clean entry the job fits on
-DEV void baseScan(Dev& d, const JobRec& r) {
-  int s = r.shape, N = d.cfg.N;
-  for (int p = FL.candPos[s]; p < N; p++) {
-    if (d.baseRemoved[p]) continue;
-    int64_t ex[MAXE] = {0, 0};
-    for (int e = 0; e < d.f.E; e++) ex[e] = d.baseExtra[(size_t)e * d.cfg.Npad + p];
-    if (!entryFits(d, r, d.baseKey[p], ex[0], ex[1], d.baseCls[p])) continue;
-    FL.candPos[s] = p; FL.candNode[s] = d.baseNode[p]; FL.candKey[s] = d.baseKey[p]; FL.candCls[s] = d.baseCls[p];
-    for (int e = 0; e < MAXE; e++) FL.candExtra[e][s] = ex[e];
-    d.rs->statScanSteps++;
+DEV void baseScan(const FastK& k, FastS& S, const JobTail& r) {
+  int s = r.shape;
+  for (int p = FL.cand[s].pos; p < k.N; p++) {
+    if (k.baseRemoved[p]) continue;
+    int64_t ex0 = k.E > 0 ? k.baseExtra[p] : 0, ex1 = k.E > 1 ? k.baseExtra[k.Npad + p] : 0;
+    if (!entryFits(k, r, k.baseKey[p], ex0, ex1, k.baseCls[p])) continue;
+    CandRec& c = FL.cand[s];
+    c.pos = p; c.node = k.baseNode[p]; c.key = k.baseKey[p]; c.cls = k.baseCls[p]; c.ex0 = ex0; c.ex1 = ex1;
+    S.statScanSteps++;
     return;
   }
-  FL.candPos[s] = N; FL.candNode[s] = -1;
+  FL.cand[s].pos = k.N; FL.cand[s].node = -1;
 }
-DEV uint64_t l0Search(Dev& d, const JobRec& r, int* slot) {
+DEV uint64_t l0Search(const FastK& k, const JobTail& r, int* slot) {
   uint64_t best = ~0ull; *slot = -1;
-  for (int i = 0; i < FL.l0Count; i++) {
-    if (FL.l0Key[i] < best && entryFits(d, r, FL.l0Key[i], FL.l0Extra[0][i], FL.l0Extra[1][i], FL.l0Cls[i])) { best = FL.l0Key[i]; *slot = i; }
-  }
+  for (int i = 0; i < FL.l0Count; i++)
+    if (FL.l0Key[i] < best && entryFits(k, r, FL.l0Key[i], FL.l0Ex0[i], FL.l0Ex1[i], FL.l0Cls[i])) { best = FL.l0Key[i]; *slot = i; }
   return best;
 }
-DEV void candInvalidate(Dev& d, int n) { for (int s = 0; s < d.cfg.S; s++) if (FL.candNode[s] == n) FL.candNode[s] = -2; }
-DEV void candResetAll(Dev& d, const int32_t* pos) { for (int s = 0; s < d.cfg.S && s < SMAX; s++) { FL.candNode[s] = -2; FL.candPos[s] = pos ? pos[s] : 0; } }
-DEV void candSaveAll(Dev& d, int32_t* pos) { for (int s = 0; s < d.cfg.S && s < SMAX; s++) pos[s] = FL.candPos[s]; }
 // load jobs [pos, pos+cnt) of a queue stream (kind 0: evicted list, 1: queued list) into the queue's window
-DEV void winRefill(Dev& d, int q, int kind, int pos, int cnt) {
-  const int32_t* stream = kind == 0 ? d.evList : d.queuedJobs;
-  for (int k = 0; k < cnt; k++) {
-    int job = stream[pos + k];
-    FL.winJob[q][k] = job; FL.winIdx[q][k] = kind == 0 ? d.evIdxByPos[pos + k] : -1; FL.winRec[q][k] = d.jrec[job];
+DEV void winRefill(const FastK& k, int q, int kind, int pos, int cnt) {
+  GP(int32_t) stream = kind == 0 ? k.evList : k.queuedJobs;
+  for (int i = 0; i < cnt; i++) {
+    int job = stream[pos + i];
+    FL.winJob[q][i] = job; FL.winIdx[q][i] = kind == 0 ? k.evIdxByPos[pos + i] : -1;
+    memcpy(&FL.winRec[q][i], (const char*)k.jrec + (size_t)job * sizeof(JobRec), sizeof(JobRec));
   }
-  FL.winKind[q] = kind; FL.winStart[q] = pos; FL.winCount[q] = cnt;
-  d.rs->statRefills++;
 }
-// alloc[l][r][n] -= req[r], keys[l][n] -= keyDelta for levels l in [lo, nl)  (markAllocatable, node.go:539-549)
-DEV void bindUpdate(Dev& d, int n, int lo, int nl, const JobRec& r) {
-  for (int l = lo; l < nl; l++) { for (int x = 0; x < d.cfg.R; x++) AL(d, l, x, n) -= r.req[x]; KEY(d, l, n) -= r.keyDelta; }
+// the head record of queue q := JobRec of `job` from HBM / := window slot w
+DEV void loadHeadRec(const FastK& k, int q, int job) {
+  JobRec r; memcpy(&r, (const char*)k.jrec + (size_t)job * sizeof(JobRec), sizeof(JobRec));
+  memcpy(FL.headReq[q], r.req, sizeof r.req); memcpy(&FL.headTail[q], &r.keyDelta, sizeof(JobTail));
 }
-DEV void loadJobRec(Dev& d, int job, JobRec* out) { *out = d.jrec[job]; }
+DEV void headFromWindow(int q, int w) { memcpy(FL.headReq[q], FL.winRec[q][w].req, sizeof(int64_t) * MAXR); memcpy(&FL.headTail[q], &FL.winRec[q][w].keyDelta, sizeof(JobTail)); }
+// alloc[l][r][n] -= req[r], keys[l][n] -= keyDelta for levels l in [lo, nl)  (markAllocatable, node.go:539-549); req = head of queue q
+DEV void bindUpdate(const FastK& k, int n, int lo, int nl, int q, uint64_t keyDelta) {
+  for (int l = lo; l < nl; l++) { for (int x = 0; x < k.R; x++) KAL(k, l, x, n) -= FL.headReq[q][x]; KKEY(k, l, n) -= keyDelta; }
+}
+// sctx / qctx resource vectors (context/scheduling.go:410-434, context/queue.go:231-265) for the head job of queue q:
+// accumulate-only, one lane per resource
+DEV void accountVectors(Dev& d, const FastK& k, int q, int pc, bool ev, bool replay) {
+  for (int x = 0; x < k.R; x++) {
+    int64_t v = FL.headReq[q][x];
+    if (replay) { FL.qReplay[q][x] += v; continue; }
+    FL.qAlloc[q][x] += v; RS.allocated[x] += v;
+    if (ev) RS.evicted[x] -= v; else RS.scheduled[x] += v;
+    size_t i = ((size_t)q * k.npc + pc) * k.R + x;
+    k.qAllocByPc[i] += v;
+    if (ev) k.qEvictedByPc[i] -= v; else k.qSchedByPc[i] += v;
+  }
+}
+DEV bool roundLimitExceeded(Dev& d, const FastK& k) { for (int x = 0; x < k.R; x++) if (RS.scheduled[x] > k.maxToSchedule[x]) return true; return false; }  // constraints.go:113-119
+DEV bool headRequestsDisallowed(const FastK& k, int q) { for (int x = 0; x < k.R; x++) if (k.disallowed[x] && FL.headReq[q][x] > 0) return true; return false; }  // nodedb.go:596-601
 #else  // device versions: armada_sched.hip
-DEV int pqTopFast(Dev& d);
-DEV void drf3(Dev& d, const int64_t* base, const int64_t* pen, const int64_t* req, double w, double* proposed, double* current, double* size);
-DEV void fastEnterGeneric(Dev& d, Ctl& c);
-DEV void baseScan(Dev& d, const JobRec& r);
-DEV uint64_t l0Search(Dev& d, const JobRec& r, int* slot);
-DEV void candInvalidate(Dev& d, int n);
-DEV void candResetAll(Dev& d, const int32_t* pos);
-DEV void candSaveAll(Dev& d, int32_t* pos);
-DEV void winRefill(Dev& d, int q, int kind, int pos, int cnt);
-DEV void bindUpdate(Dev& d, int n, int lo, int nl, const JobRec& r);
-DEV void loadJobRec(Dev& d, int job, JobRec* out);
+DEV int pqTopFast(int Q);
+DEV void drf3(Dev& d, int q, int k, bool replay, double w, double* proposed, double* current, double* size);
+DEV void fastFence(Ctl& c);
+DEV void baseScan(const FastK& k, FastS& S, const JobTail& r);
+DEV uint64_t l0Search(const FastK& k, const JobTail& r, int* slot);
+DEV void winRefill(const FastK& k, int q, int kind, int pos, int cnt);
+DEV void loadHeadRec(const FastK& k, int q, int job);
+DEV void headFromWindow(int q, int w);
+DEV void bindUpdate(const FastK& k, int n, int lo, int nl, int q, uint64_t keyDelta);
+DEV void accountVectors(Dev& d, const FastK& k, int q, int pc, bool ev, bool replay);
+DEV bool roundLimitExceeded(Dev& d, const FastK& k);
+DEV bool headRequestsDisallowed(const FastK& k, int q);
 #endif
+DEV void candInvalidate(int S, int n) { FOR_LANES(s, S) if (FL.cand[s].node == n) FL.cand[s].node = -2; }
+DEV void candResetAll(Dev& d, const int32_t* pos) { FOR_LANES(s, d.cfg.S < SMAX ? d.cfg.S : SMAX) { FL.cand[s].node = -2; FL.cand[s].pos = pos ? pos[s] : 0; } }
+DEV void candSaveAll(Dev& d, int32_t* pos) { FOR_LANES(s, d.cfg.S < SMAX ? d.cfg.S : SMAX) pos[s] = FL.cand[s].pos; }
+
+// Before generic code runs: the LDS queue records back into the generic arrays, and the fast path's no-return atomics
+// made visible to plain loads
+DEV void fastEnterGeneric(Dev& d, Ctl& c) {
+  if (c.fqLive) { fastQFlush(d); c.fqLive = 0; }
+  fastFence(c);
+}
 
 // ------------------------------------------------------------------------------------------------ L0 maintenance
-DEV void fastDrop(Dev& d) { d.rs->fastActive = 0; d.rs->fastOverflow++; FL.l0Count = 0; }
-DEV void l0Insert(Dev& d, int n, uint64_t key, int64_t ex0, int64_t ex1, uint64_t cls) {
+DEV bool l0Insert(const FastK& k, int n, uint64_t key, int64_t ex0, int64_t ex1, uint64_t cls) {
   int i = FL.l0Count;
-  if (i >= L0CAP) { fastDrop(d); return; }
-  FL.l0Key[i] = key; FL.l0Node[i] = n; FL.l0Cls[i] = cls;
-  FL.l0Extra[0][i] = ex0; FL.l0Extra[1][i] = ex1;
+  if (i >= L0CAP) return false;
+  FL.l0Key[i] = key; FL.l0Node[i] = n; FL.l0Cls[i] = cls; FL.l0Ex0[i] = ex0; FL.l0Ex1[i] = ex1;
   FL.l0Count = i + 1;
-  if (i + 1 > d.rs->statL0Max) d.rs->statL0Max = i + 1;
-  if (FLANE == 0) d.l0Slot[n] = i;
+  if (FLANE == 0) k.l0Slot[n] = i;
+  return true;
 }
-DEV void l0Remove(Dev& d, int slot) {
+DEV void l0Remove(const FastK& k, int slot) {
   int last = FL.l0Count - 1;
   int n = FL.l0Node[slot];
-  if (FLANE == 0) d.l0Slot[n] = -1;
+  if (FLANE == 0) k.l0Slot[n] = -1;
   if (slot != last) {
     FL.l0Key[slot] = FL.l0Key[last]; FL.l0Node[slot] = FL.l0Node[last]; FL.l0Cls[slot] = FL.l0Cls[last];
-    FL.l0Extra[0][slot] = FL.l0Extra[0][last]; FL.l0Extra[1][slot] = FL.l0Extra[1][last];
-    if (FLANE == 0) d.l0Slot[FL.l0Node[slot]] = slot;
+    FL.l0Ex0[slot] = FL.l0Ex0[last]; FL.l0Ex1[slot] = FL.l0Ex1[last];
+    if (FLANE == 0) k.l0Slot[FL.l0Node[slot]] = slot;
   }
   FL.l0Count = last;
 }
+DEV void fastDrop(Dev& d) { RS.fastActive = 0; RS.fastOverflow++; FL.l0Count = 0; }  // L0 overflow: the generic full scan takes over for the rest of the round
 
 // node n's level-0 allocatable was changed by the generic code: bring base flags / L0 / candidates in line
 DEV void fastTouch(Dev& d, int n) {
-  if (!d.f.structOk || !d.rs->fastActive) return;
-  uint64_t key = KEY(d, 0, n);
-  int64_t ex0 = d.f.E > 0 ? AL(d, 0, d.f.extraCol[0], n) : 0, ex1 = d.f.E > 1 ? AL(d, 0, d.f.extraCol[1], n) : 0;
-  int pos = d.posOf[n], slot = d.l0Slot[n];
-  if (FLANE == 0) d.baseRemoved[pos] = 1;
-  candInvalidate(d, n);
-  bool live = entryLive(d, key, ex0, ex1);
+  if (!d.f.structOk || !RS.fastActive) return;
+  FastK k; fastKInit(d, k);
+  uint64_t key = KKEY(k, 0, n);
+  int64_t ex0 = k.E > 0 ? KAL(k, 0, k.ex0col, n) : 0, ex1 = k.E > 1 ? KAL(k, 0, k.ex1col, n) : 0;
+  int pos = GA(int32_t, d.posOf)[n], slot = k.l0Slot[n];
+  if (FLANE == 0) k.baseRemoved[pos] = 1;
+  candInvalidate(k.S, n);
+  bool live = entryLive(k, key, ex0, ex1);
   if (slot >= 0) {
-    if (live) { FL.l0Key[slot] = key; FL.l0Extra[0][slot] = ex0; FL.l0Extra[1][slot] = ex1; }
-    else l0Remove(d, slot);
-  } else if (live) l0Insert(d, n, key, ex0, ex1, d.nodeCls[n]);
+    if (live) { FL.l0Key[slot] = key; FL.l0Ex0[slot] = ex0; FL.l0Ex1[slot] = ex1; }
+    else l0Remove(k, slot);
+  } else if (live && !l0Insert(k, n, key, ex0, ex1, GA(uint64_t, d.nodeCls)[n])) fastDrop(d);
 }
 
 // first fit at priority -2 for a job record; -1 none; handle says where the winner came from
-DEV int fastFirstFit(Dev& d, const JobRec& r, FitHandle* h) {
+DEV int fastFirstFit(const FastK& k, FastS& S, const JobTail& r, FitHandle* h, CandRec* cOut) {
   if (r.never) return -1;
   int s = r.shape;
-  if (FL.candNode[s] == -2) baseScan(d, r);
-  uint64_t bk = FL.candNode[s] >= 0 ? FL.candKey[s] : ~0ull;
+  if (FL.cand[s].node == -2) baseScan(k, S, r);
+  CandRec c = FL.cand[s];
+  *cOut = c;
+  uint64_t bk = c.node >= 0 ? c.key : ~0ull;
   int slot;
-  uint64_t lk = l0Search(d, r, &slot);
+  uint64_t lk = l0Search(k, r, &slot);
   if (lk < bk) { h->src = 1; h->slot = slot; return FL.l0Node[slot]; }
   if (bk == ~0ull) return -1;
   h->src = 0; h->slot = -1;
-  return FL.candNode[s];
+  return c.node;
 }
 DEV int fastSelectLevel0(Dev& d, int job) {
-  if (!d.f.structOk || !d.rs->fastActive) return -2;
-  JobRec r;
-  loadJobRec(d, job, &r);
-  FitHandle h;
-  return fastFirstFit(d, r, &h);
+  if (!d.f.structOk || !RS.fastActive) return -2;
+  FastK k; fastKInit(d, k);
+  FastS S; S.statScanSteps = 0;
+  JobRec jr = d.jrec[job];
+  JobTail r; memcpy(&r, &jr.keyDelta, sizeof r);
+  FitHandle h; CandRec c;
+  int n = fastFirstFit(k, S, r, &h, &c);
+  RS.statScanSteps += S.statScanSteps;
+  return n;
 }
-// the job of record r was bound to node n found through handle h: level-0 bookkeeping of the fast structure
-DEV void fastAfterBind(Dev& d, const JobRec& r, int n, const FitHandle& h) {
-  int64_t q0 = d.f.E > 0 ? r.req[d.f.extraCol[0]] : 0, q1 = d.f.E > 1 ? r.req[d.f.extraCol[1]] : 0;
+// the job of record r was bound to node n found through handle h: level-0 bookkeeping of the fast structure.
+// Returns false when L0 overflowed (the caller drops the structure).
+DEV bool fastAfterBind(const FastK& k, FastS& S, const JobTail& r, int n, const FitHandle& h, const CandRec& c) {
   if (h.src == 0) {
-    int s = r.shape;
-    uint64_t key = FL.candKey[s] - r.keyDelta, cls = FL.candCls[s];
-    int64_t ex0 = FL.candExtra[0][s] - q0, ex1 = FL.candExtra[1][s] - q1;
-    if (FLANE == 0) d.baseRemoved[FL.candPos[s]] = 1;
-    candInvalidate(d, n);
-    if (entryLive(d, key, ex0, ex1)) l0Insert(d, n, key, ex0, ex1, cls);
+    uint64_t key = c.key - r.keyDelta;
+    int64_t ex0 = c.ex0 - r.ex0, ex1 = c.ex1 - r.ex1;
+    if (FLANE == 0) k.baseRemoved[c.pos] = 1;
+    candInvalidate(k.S, n);
+    if (entryLive(k, key, ex0, ex1)) {
+      if (!l0Insert(k, n, key, ex0, ex1, c.cls)) return false;
+      if (FL.l0Count > S.statL0Max) S.statL0Max = FL.l0Count;
+    }
   } else {
     int slot = h.slot;
     uint64_t key = FL.l0Key[slot] - r.keyDelta;
-    int64_t ex0 = FL.l0Extra[0][slot] - q0, ex1 = FL.l0Extra[1][slot] - q1;
-    if (entryLive(d, key, ex0, ex1)) { FL.l0Key[slot] = key; FL.l0Extra[0][slot] = ex0; FL.l0Extra[1][slot] = ex1; }
-    else l0Remove(d, slot);
+    int64_t ex0 = FL.l0Ex0[slot] - r.ex0, ex1 = FL.l0Ex1[slot] - r.ex1;
+    if (entryLive(k, key, ex0, ex1)) { FL.l0Key[slot] = key; FL.l0Ex0[slot] = ex0; FL.l0Ex1[slot] = ex1; }
+    else l0Remove(k, slot);
   }
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------------ launch persistence
 DEV void fastLoad(Dev& d) {  // kernel start: rebuild the LDS side from HBM
   FL.l0Count = 0;
-  for (int q = 0; q < QCAPF; q++) { FL.headFast[q] = 0; FL.winCount[q] = 0; FL.winKind[q] = -1; }
-  if (!d.f.structOk || !d.rs->fastActive) return;
+  fastPassReset();
+  if (!d.f.structOk || !RS.fastActive) return;
+  FastK k; fastKInit(d, k);
   candResetAll(d, d.candPosSave);
-  int cnt = d.rs->l0SaveCount;
+  int cnt = RS.l0SaveCount;
   for (int i = 0; i < cnt; i++) {
     int n = d.l0Save[i];
-    l0Insert(d, n, KEY(d, 0, n), d.f.E > 0 ? AL(d, 0, d.f.extraCol[0], n) : 0, d.f.E > 1 ? AL(d, 0, d.f.extraCol[1], n) : 0, d.nodeCls[n]);
+    l0Insert(k, n, KKEY(k, 0, n), k.E > 0 ? KAL(k, 0, k.ex0col, n) : 0, k.E > 1 ? KAL(k, 0, k.ex1col, n) : 0, d.nodeCls[n]);
   }
 }
 DEV void fastSave(Dev& d) {  // kernel end
-  if (!d.f.structOk || !d.rs->fastActive) { d.rs->l0SaveCount = 0; return; }
+  if (!d.f.structOk || !RS.fastActive) { RS.l0SaveCount = 0; return; }
   candSaveAll(d, d.candPosSave);
   for (int i = 0; i < FL.l0Count; i++) d.l0Save[i] = FL.l0Node[i];
-  d.rs->l0SaveCount = FL.l0Count;
+  RS.l0SaveCount = FL.l0Count;
 }
 
 // ------------------------------------------------------------------------------------------------ queue iterator, fast
-DEV int pqTopAny(Dev& d, const Ctl& c) {
-  if (!fastOn(d, c)) return pqTop(d, c);
-  int t = pqTopFast(d);
-#ifdef ASCHED_HOSTSIM
-  if (t != pqTop(d, c)) { fprintf(stderr, "hostsim: packed queue key disagrees with Less (fast %d, generic %d)\n", t, pqTop(d, c)); abort(); }
-#endif
-  return t;
-}
-
 // costItClear(top) (queue_scheduler.go:595-606) + QueuedGangIterator.Peek (:376-432) + updatePQItem (:636-686) for the
 // next single job of queue q, from the prefetch window; gang members and rare iterator states go to the generic code.
-DEV void fastAdvance(Dev& d, Ctl& c, int q, const PassCfg& pc) {
-  d.pqInHeap[q] = 0; d.itNext[q] = -1;
-  if (q >= QCAPF) { updateAndPush(d, c, q, pc); return; }
-  FL.headFast[q] = 0;
+// `f` is the caller's register copy of FL.hot[q]; changed fields are stored back here.  Returns false when the generic
+// updateAndPush must continue for queue q (state left exactly where costItClear leaves it).
+DEV bool fastAdvance(Dev& d, const FastK& k, FastS& S, const FastCtx& fc, int q, QHot& f) {
+  FL.inHeap[q] = 0; f.itNext = -1; f.headFast = 0;
+  bool ok = true, haveHead = false;
   for (;;) {
-    if (pc.maxLookback != 0 && !d.itGangOnlyEv[q] && (uint32_t)d.itJobsSeen[q] >= pc.maxLookback) gangItOnlyEvicted(d, q);
+    bool generic = fc.maxLookback != 0 && !f.itGangOnlyEv && (uint32_t)f.itJobsSeen >= fc.maxLookback;  // queue_scheduler.go:434-444
     int kind = -1, pos = 0, end = 0;  // what jobItNext (jobiteration.go:179-228) yields next, not yet consumed
-    if (d.itStage[q] == 0) {
-      if (d.itEi[q] < d.evOff[q + 1]) { kind = 0; pos = d.itEi[q]; end = d.evOff[q + 1]; }
-      else d.itStage[q] = 1;
+    if (!generic) {
+      if (f.itStage == 0) {
+        if (f.itEi < f.evEnd) { kind = 0; pos = f.itEi; end = f.evEnd; }
+        else f.itStage = 1;
+      }
+      if (kind < 0 && !(f.itJobOnlyEv || !fc.withQueued) && f.itQi < f.qEnd) { kind = 1; pos = f.itQi; end = f.qEnd; }
+      if (kind < 0) { f.gctx = -1; f.proposed = f.current = f.size = 0; break; }
+      if (kind == 0 && !fc.evStatic && !fc.replay) generic = true;  // evicted this round after being scheduled: node / priority are not the job's static run
     }
-    if (kind < 0 && !(d.itJobOnlyEv[q] || !pc.withQueued) && d.itQi[q] < d.queuedOff[q + 1]) { kind = 1; pos = d.itQi[q]; end = d.queuedOff[q + 1]; }
-    if (kind < 0) { d.pqGctx[q] = -1; d.pqProposed[q] = d.pqCurrent[q] = d.pqSize[q] = 0; return; }
-    if (kind == 0 && !c.fastEvStatic) { updateAndPush(d, c, q, pc); return; }
-    if (!(FL.winKind[q] == kind && pos >= FL.winStart[q] && pos < FL.winStart[q] + FL.winCount[q])) {
-      int cnt = end - pos; if (cnt > WIN) cnt = WIN;
-      winRefill(d, q, kind, pos, cnt);
+    int w = 0;
+    if (!generic) {
+      if (!(f.winKind == kind && pos >= f.winStart && pos < f.winStart + f.winCount)) {
+        int cnt = end - pos; if (cnt > WIN) cnt = WIN;
+        winRefill(k, q, kind, pos, cnt);
+        f.winKind = kind; f.winStart = pos; f.winCount = cnt;
+        S.statRefills++;
+      }
+      w = pos - f.winStart;
+      if (FL.winRec[q][w].gang >= 0) generic = true;
     }
-    int k = pos - FL.winStart[q];
-    const JobRec& r = FL.winRec[q][k];
-    int job = FL.winJob[q][k];
-    if (r.gang >= 0) { updateAndPush(d, c, q, pc); return; }  // the generic iterator continues from the same state
-    if (kind == 0) d.itEi[q] = pos + 1;
-    else { d.itQi[q] = pos + 1; if (FLANE == 0) resetJctxForQueued(d, job); d.itJobsSeen[q]++; }
-    if (pc.skipKnown && d.rs->numUnfeasible > 0 && kind == 1 && d.unfeasible[r.shape]) {  // queue_scheduler.go:398-413
-      fastEnterGeneric(d, c);
-      d.jcReason[job] = d.unfeasibleReason[r.shape];
-      d.jcHasPctx[job] = 1; d.pcNode[job] = -1; d.pcMethod[job] = ASCHED_METHOD_NONE;
-      sctxAddJob(d, job);
-      d.jcReason[job] = ASCHED_REASON_SKIPPED_UNFEASIBLE_KEY;
+    if (generic) { ok = false; break; }  // the generic iterator continues from the same state
+    int job = FL.winJob[q][w], shape = FL.winRec[q][w].shape;
+    if (kind == 0) f.itEi = pos + 1;
+    else {
+      f.itQi = pos + 1; f.itJobsSeen++;
+      if (FLANE == 0) {  // JobSchedulingContextFromJob (context/job.go:149-158)
+        k.jcEvicted[job] = 0; k.jcAssigned[job] = -1; k.jcReason[job] = 0; k.jcHasPctx[job] = 0;
+        k.jcGangCard[job] = 1; k.jcUniValue[job] = -1; k.jcStagedBy[job] = -1;
+      }
+    }
+    if (fc.skipKnown && S.numUnfeasible > 0 && kind == 1 && k.unfeasible[shape]) {  // queue_scheduler.go:398-413
+      if (FLANE == 0) {
+        k.jcHasPctx[job] = 1; k.pcNode[job] = -1; k.pcMethod[job] = ASCHED_METHOD_NONE;
+        k.jobFlags[job] = (uint8_t)(k.jobFlags[job] | F_UNSUCCESSFUL);  // sctx.AddJobSchedulingContext of a failed job
+        k.jcReason[job] = ASCHED_REASON_SKIPPED_UNFEASIBLE_KEY;
+      }
       continue;
     }
-    d.itNext[q] = job; d.pqGctx[q] = job;
-    FL.headRec[q] = r; FL.headKind[q] = (uint8_t)kind; FL.headIdx[q] = FL.winIdx[q][k]; FL.headFast[q] = 1;
-    const int64_t* base = c.useReplayAlloc ? QV(d.replayAlloc, q) : QV(d.qAlloc, q);
+    f.itNext = job; f.gctx = job;
+    f.headKind = kind; f.headIdx = FL.winIdx[q][w]; f.headFast = 1;
+    headFromWindow(q, w);
+    SEG(4);
     double pr, cu, sz;
-    drf3(d, base, QV(d.qPenalty, q), FL.headRec[q].req, d.qWeight[q], &pr, &cu, &sz);
-    d.pqProposed[q] = pr; d.pqCurrent[q] = cu; d.pqSize[q] = sz;
-    int32_t p = d.cfg.pcPriority[r.pc];
-    d.pqPcPrio[q] = p; d.pqSchedPrio[q] = kind == 0 ? r.runPrio : p;  // evicted: run.ScheduledAtPriority (queue_scheduler.go:660-672)
-    fastItemKeys(d, c, q);
-    d.pqInHeap[q] = 1;
-    return;
+    drf3(d, q, w, fc.replay != 0, f.weight, &pr, &cu, &sz);
+    SEG(5);
+    int32_t p = FL.winRec[q][w].pcPrio;
+    int32_t sp = kind == 0 ? FL.winRec[q][w].runPrio : p;  // evicted: run.ScheduledAtPriority (queue_scheduler.go:660-672)
+    f.proposed = pr; f.current = cu; f.size = sz; f.pcPrio = p; f.schedPrio = sp;
+    packItemKeys(fc.preferLarge, q, fc.compareSchedPrio ? sp : p, pr, cu, sz, f.budget);
+    haveHead = true;
+    break;
   }
+  // store back what this iteration may have changed
+  QHot& o = FL.hot[q];
+  o.tokens = f.tokens; o.proposed = f.proposed; o.current = f.current; o.size = f.size;
+  o.itEi = f.itEi; o.itQi = f.itQi; o.itStage = f.itStage; o.itJobsSeen = f.itJobsSeen; o.itNext = f.itNext; o.gctx = f.gctx;
+  o.pcPrio = f.pcPrio; o.schedPrio = f.schedPrio; o.headFast = f.headFast; o.headKind = f.headKind; o.headIdx = f.headIdx;
+  o.winKind = f.winKind; o.winStart = f.winStart; o.winCount = f.winCount;
+  if (haveHead) FL.inHeap[q] = 1;
+  SEG(6);
+  return ok;
 }
 
-DEV int levelsUpTo(const DevCfg& c, int32_t cutoff) { int nl = 0; while (nl < c.P && c.prios[nl] <= cutoff) nl++; return nl; }  // prios ascend
+// head of queue q was peeked by the generic code: fetch its record (one burst) and classify it
+DEV void fastLoadHead(const FastK& k, int q, int job, QHot& f) {
+  loadHeadRec(k, q, job);
+  int ev = k.jcEvicted[job];
+  f.headKind = ev ? 0 : 1;
+  f.headIdx = ev ? k.evIndexOfJob[job] : -1;
+  f.headFast = 1;
+}
+
+DEV int levelsUpTo(const FastK& k, int32_t cutoff) { int nl = 0; while (nl < k.P && k.prios[nl] <= cutoff) nl++; return nl; }  // prios ascend
 
 // One QueueScheduler iteration (queue_scheduler.go:94-304 body) for the head of queue `top` when it is a single job that
-// (a) is queued and fits at priority -2 or (b) is a phase-1-evicted job returning to its node.  Returns false WITHOUT side
-// effects when the iteration needs the generic code (any constraint failing, preemption, gangs, ...).
-DEV bool fastIter(Dev& d, Ctl& c, const PassCfg& pc, int top) {
+// (a) is queued and fits at priority -2 or (b) is a phase-1-evicted job returning to its node.  Returns 0 WITHOUT side
+// effects when the iteration needs the generic code (any constraint failing, preemption, gangs, ...); 1 = done;
+// 2 = done, but the queue's next head must be produced by the generic updateAndPush.  Fast mode only.
+DEV int fastIter(Dev& d, const FastK& k, FastS& S, const FastCtx& fc, int top) {
   int q = top;
-  if (q >= QCAPF || !FL.headFast[q]) return false;
-  const JobRec& r = FL.headRec[q];
-  int job = d.pqGctx[q], kind = FL.headKind[q], R = d.cfg.R;
-  RoundScalars& s = *d.rs;
-  if (s.numPreemptedMarks != 0) return false;  // queue_scheduler.go:150-156 needs the per-job flag: generic
-  bool ev = kind == 0;
+  if (S.numPreemptedMarks != 0 || k.hasPcLimit) return 0;  // per-job preempted flags / per-queue caps: generic
+  QHot f = FL.hot[q];
+  int job = f.gctx;
+  if (!f.headFast) { fastLoadHead(k, q, job, f); FL.hot[q].headFast = 1; FL.hot[q].headKind = f.headKind; FL.hot[q].headIdx = f.headIdx; }
+  JobTail r = FL.headTail[q];
+  bool ev = f.headKind == 0;
+  SEG(1);
   int pcx = r.pc;
   int32_t prio;
   int n;
   FitHandle h; h.src = 0; h.slot = -1;
+  CandRec cand; cand.pos = 0; cand.node = -1; cand.key = 0; cand.cls = 0; cand.ex0 = cand.ex1 = 0; cand.pad = 0;
   if (!ev) {
-    if (!s.fastActive) return false;
-    if (vexceeds(d, s.scheduled, d.cfg.maxToSchedule)) return false;  // CheckRoundConstraints (constraints.go:113-119)
-    if (d.qCordoned[q] || s.globalTokens < 1 || s.globalBurst < 1 || d.qTokens[q] < 1 || d.qBurst[q] < 1) return false;  // CheckJobConstraints (:121-157)
-    if (d.hasPcLimit) { const int64_t* a = QPV(d.qAllocByPc, q, pcx); const int64_t* lim = QPV(d.qPcLimit, q, pcx); for (int x = 0; x < R; x++) if (a[x] + r.req[x] > lim[x]) return false; }
-    for (int x = 0; x < R; x++) if (d.cfg.disallowed[x] && r.req[x] > 0) return false;  // nodedb.go:596-601
-    if (d.cfg.disableHome) return false;
-    prio = d.cfg.pcPriority[pcx];
-    n = fastFirstFit(d, r, &h);
-    if (n < 0) return false;  // the generic cascade (gate, fair-share, urgency) decides
-    s.numNodeQueries++;
+    if (!S.fastActive) return 0;
+    if (roundLimitExceeded(d, k)) return 0;  // CheckRoundConstraints (constraints.go:113-119)
+    if (f.cordoned || S.globalTokens < 1 || S.globalBurst < 1 || f.tokens < 1 || f.burst < 1) return 0;  // CheckJobConstraints (:121-157)
+    if (k.anyDisallowed && headRequestsDisallowed(k, q)) return 0;
+    if (k.disableHome) return 0;
+    prio = r.pcPrio;
+    n = fastFirstFit(k, S, r, &h, &cand);
+    if (n < 0) return 0;  // the generic cascade (gate, fair-share, urgency) decides
+    S.numNodeQueries++;
   } else {
-    if (!c.fastEvStatic) return false;
+    // nodedb.go:897-906: alloc[level] >= alloc[-2] + req >= req on every column while no priority -2 column is negative
+    // (bucket arithmetic, DESIGN.md "Evicted jobs always return")
+    if (!fc.evStatic || !S.lvl0NonNeg) return 0;
     prio = r.runPrio; n = r.node0;
-    if (!s.lvl0NonNeg) {  // nodedb.go:897-906
-      fastEnterGeneric(d, c);
-      int level = levelOf(d.cfg, prio);
-      if (level < 0) return false;
-      if (!((d.nodeFlags[n] & 1) || fitsAlloc(d, r.req, level, n))) return false;
-    }
-    // else: alloc[level] >= alloc[-2] + req >= req on every column (bucket arithmetic, DESIGN.md "Evicted jobs always return")
   }
+  SEG(2);
   // ---- commit: sctx.AddGangSchedulingContext (scheduling.go:391-434)
-  int64_t* qa = QV(d.qAlloc, q); int64_t* qap = QPV(d.qAllocByPc, q, pcx);
-  for (int x = 0; x < R; x++) { qa[x] += r.req[x]; qap[x] += r.req[x]; s.allocated[x] += r.req[x]; }
-  if (ev) {
-    int64_t* qe = QPV(d.qEvictedByPc, q, pcx);
-    for (int x = 0; x < R; x++) { qe[x] -= r.req[x]; s.evicted[x] -= r.req[x]; }
-    s.numEvictedJobs--;
-  } else {
-    int64_t* qs = QPV(d.qSchedByPc, q, pcx);
-    for (int x = 0; x < R; x++) { qs[x] += r.req[x]; s.scheduled[x] += r.req[x]; }
-    s.numScheduledJobs++; s.numScheduledGangs++;
-  }
+  accountVectors(d, k, q, pcx, ev, false);
+  if (ev) S.numEvictedJobs--; else { S.numScheduledJobs++; S.numScheduledGangs++; }
   // ---- SelectNodeForJobWithTxn result + BindJobToNode (nodedb.go:538-630, 1046-1068)
-  int32_t cutoff = d.cfg.pcPreemptible[pcx] ? prio : NONPREEMPTIBLE_CUTOFF;
-  int nl = levelsUpTo(d.cfg, cutoff);
-  bindUpdate(d, n, ev ? 1 : 0, nl, r);  // evicted job: level -2 gets -req (bind) and +req (un-evict): unchanged (node.go:416-442)
-  c.l1Dirty = 1;
+  int32_t cutoff = r.preemptible ? prio : NONPREEMPTIBLE_CUTOFF;
+  int nl = levelsUpTo(k, cutoff);
+  bindUpdate(k, n, ev ? 1 : 0, nl, q, r.keyDelta);  // evicted job: level -2 gets -req (bind) and +req (un-evict): unchanged (node.go:416-442)
   if (FLANE == 0) {
-    d.jcReason[job] = 0; d.jcHasPctx[job] = 1; d.pcNode[job] = n; d.pcSap[job] = prio;
-    d.jobNode[job] = n; d.jobCutoff[job] = cutoff; d.jobEvictedOnNode[job] = 0; d.schedAtPrio[job] = prio; d.inSchedAndEvicted[job] = 0;
+    k.jcReason[job] = 0; k.jcHasPctx[job] = 1; k.pcNode[job] = n; k.pcSap[job] = prio;
+    k.jobNode[job] = n; k.jobCutoff[job] = cutoff; k.jobEvictedOnNode[job] = 0; k.schedAtPrio[job] = prio; k.inSchedAndEvicted[job] = 0;
     if (ev) {
-      d.pcPap[job] = prio; d.pcMethod[job] = ASCHED_METHOD_RESCHEDULED; d.jobFlags[job] = F_RESCHEDULED; d.inPreempted[job] = 0;
-      int idx = FL.headIdx[q];
-      d.evTabAlive[idx] = 0; d.evIndexOfJob[job] = -1;  // nodedb.go:441-446
+      k.pcPap[job] = prio; k.pcMethod[job] = ASCHED_METHOD_RESCHEDULED; k.jobFlags[job] = F_RESCHEDULED; k.inPreempted[job] = 0;
+      k.evTabAlive[f.headIdx] = 0; k.evIndexOfJob[job] = -1;  // nodedb.go:441-446
     } else {
-      d.pcPap[job] = ASCHED_EVICTED_PRIORITY; d.pcMethod[job] = ASCHED_METHOD_NO_PREEMPTION; d.jobFlags[job] = F_SUCCESSFUL; d.inScheduled[job] = 1;
+      k.pcPap[job] = ASCHED_EVICTED_PRIORITY; k.pcMethod[job] = ASCHED_METHOD_NO_PREEMPTION; k.jobFlags[job] = F_SUCCESSFUL; k.inScheduled[job] = 1;
     }
   }
   if (!ev) {
-    fastAfterBind(d, r, n, h);
-    reserveN(&s.globalTokens, s.globalBurst, s.globalRateInf, 1);  // gang_scheduler.go:118-123
-    reserveN(&d.qTokens[q], d.qBurst[q], d.qRateInf[q], 1);
+    if (!fastAfterBind(k, S, r, n, h, cand)) { S.fastActive = 0; fastDrop(d); }
+    if (!S.globalRateInf && 1 <= S.globalBurst) S.globalTokens -= 1.0;  // gang_scheduler.go:118-123, rate.Limiter.ReserveN
+    if (!f.rateInf && 1 <= f.burst) f.tokens -= 1.0;
   }
-  fastAdvance(d, c, q, pc);
-  return true;
+  SEG(3);
+  return fastAdvance(d, k, S, fc, q, f) ? 1 : 2;
 }
 
-// one step of addEvictedJobsToNodeDb (preempting_queue_scheduler.go:589-639) for a single evicted job
-DEV bool fastReplayStep(Dev& d, Ctl& c, const PassCfg& pc, int top, int* counter) {
+// one step of addEvictedJobsToNodeDb (preempting_queue_scheduler.go:589-639) for a single evicted job.  Fast mode only.
+DEV int fastReplayStep(Dev& d, const FastK& k, FastS& S, const FastCtx& fc, int top, int* counter) {
   int q = top;
-  if (q >= QCAPF || !FL.headFast[q]) return false;
-  const JobRec& r = FL.headRec[q];
-  int job = d.pqGctx[q], i = *counter;
-  if (FLANE == 0) { d.evTabJob[i] = job; d.evTabAlive[i] = 1; d.evIndexOfJob[job] = i; }
-  if (i + 1 > d.rs->evictedTableSize) d.rs->evictedTableSize = i + 1;
+  QHot f = FL.hot[q];
+  int job = f.gctx, i = *counter;
+  if (!f.headFast) fastLoadHead(k, q, job, f);
+  if (FLANE == 0) { k.evTabJob[i] = job; k.evTabAlive[i] = 1; k.evIndexOfJob[job] = i; }
+  if (i + 1 > S.evictedTableSize) S.evictedTableSize = i + 1;
   *counter = i + 1;
-  int64_t* ra = QV(d.replayAlloc, q);
-  for (int x = 0; x < d.cfg.R; x++) ra[x] += r.req[x];
-  d.rs->statFastReplay++;
-  fastAdvance(d, c, q, pc);
-  return true;
+  SEG(1);
+  accountVectors(d, k, q, 0, true, true);
+  S.statFastReplay++;
+  SEG(3);
+  return fastAdvance(d, k, S, fc, q, f) ? 1 : 2;
+}
+
+// Run fast iterations of the QueueScheduler loop (mode 0) or of the eviction-order replay (mode 1) until one needs the
+// generic code.  Returns the queue whose next head the generic updateAndPush must produce, or -1.  Leaves fast mode live.
+DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* counter) {
+  FastCtx fc;
+  fc.withQueued = pc.withQueued; fc.maxLookback = pc.maxLookback; fc.skipKnown = pc.skipKnown; fc.compareSchedPrio = c.compareSchedPrio;
+  fc.preferLarge = c.preferLarge; fc.replay = mode; fc.evStatic = c.fastEvStatic;
+  fastEnsureLive(d, c);
+  c.l1Dirty = 1;
+  fastKInit(d, g_fk);
+  const FastK& k = g_fk;
+  FastS S;
+  S.globalTokens = RS.globalTokens; S.globalBurst = RS.globalBurst; S.globalRateInf = RS.globalRateInf;
+  S.numScheduledJobs = RS.numScheduledJobs; S.numScheduledGangs = RS.numScheduledGangs; S.numEvictedJobs = RS.numEvictedJobs;
+  S.numNodeQueries = RS.numNodeQueries; S.loopIterations = RS.loopIterations; S.evictedTableSize = RS.evictedTableSize;
+  S.numUnfeasible = RS.numUnfeasible; S.numPreemptedMarks = RS.numPreemptedMarks; S.fastActive = RS.fastActive; S.lvl0NonNeg = RS.lvl0NonNeg;
+  S.statFastIters = RS.statFastIters; S.statScanSteps = RS.statScanSteps; S.statRefills = RS.statRefills; S.statL0Max = RS.statL0Max; S.statFastReplay = RS.statFastReplay;
+  int Q = d.cfg.Q;
+  int cnt = counter ? *counter : 0, pend = -1;
+  SEG_BEGIN();
+  for (;;) {
+    int t = pqTopFast(Q);
+    SEG(0);
+#ifdef ASCHED_HOSTSIM
+    fastQFlush(d);
+    if (t != pqTop(d, c)) { fprintf(stderr, "hostsim: packed queue key disagrees with Less (fast %d, generic %d)\n", t, pqTop(d, c)); abort(); }
+#endif
+    if (t < 0) break;
+    if (FL.hot[t].gctx < 0) break;  // a gang: generic
+    int st = mode ? fastReplayStep(d, k, S, fc, t, &cnt) : fastIter(d, k, S, fc, t);
+    SEG(7);
+    if (st == 0) break;
+    if (!mode) { S.loopIterations++; S.statFastIters++; }
+    if (st == 2) { pend = t; break; }
+  }
+  if (counter) *counter = cnt;
+  RS.globalTokens = S.globalTokens;
+  RS.numScheduledJobs = S.numScheduledJobs; RS.numScheduledGangs = S.numScheduledGangs; RS.numEvictedJobs = S.numEvictedJobs;
+  RS.numNodeQueries = S.numNodeQueries; RS.loopIterations = S.loopIterations; RS.evictedTableSize = S.evictedTableSize;
+  RS.statFastIters = S.statFastIters; RS.statScanSteps = S.statScanSteps; RS.statRefills = S.statRefills; RS.statL0Max = S.statL0Max; RS.statFastReplay = S.statFastReplay;
+  return pend;
 }

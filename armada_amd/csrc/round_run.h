@@ -165,6 +165,7 @@ DEV void updateFairShares(Dev& d, const double* givenCds) {
 
 // PreemptingQueueScheduler.evict (pqs.go:291-353) for an evictor whose job filter has been evaluated into evFlag
 DEV int pqsEvict(Dev& d, Ctl& c, bool phase3) {
+  long long t0 = CLK();
   wgBulk(d, B_GANG_CLOSURE, d.cfg.G);
   wgBulk(d, phase3 ? B_EVICT_APPLY3 : B_EVICT_APPLY1, d.cfg.M);
   wgBulk(d, B_KEYS_ALL, d.cfg.N);
@@ -175,8 +176,11 @@ DEV int pqsEvict(Dev& d, Ctl& c, bool phase3) {
   wgBulk(d, B_RESET_EVTAB, d.rs->evictedTableSize);  // nodeDb.Reset() (nodedb.go:299-313)
   d.rs->evictedTableSize = 0;
   wgBulk(d, B_RESET_GANGSEEN, d.cfg.G);
+  long long t1 = CLK();
   replayEvicted(d, c);  // addEvictedJobsToNodeDb
   wgBulk(d, B_EVIDX, n);
+  long long t2 = CLK();
+  d.rs->statClk[phase3 ? 3 : 0] += t1 - t0; d.rs->statClk[1] += t2 - t1;
   return n;
 }
 
@@ -200,20 +204,28 @@ DEV void runRound(Dev& d, Ctl& c) {
     double frac = actual / fair;
     d.qEvictable[q] = !(frac <= cf.protectedFraction);
   }
+  long long ta = CLK();
   wgBulk(d, B_FILTER1, cf.M);
+  d.rs->statClk[0] += CLK() - ta;
   c.fastEvStatic = 1;
   int n1 = pqsEvict(d, c, false);
   d.rs->lvl0NonNeg = 1;
   wgBulk(d, B_LVL0, cf.N);
+  long long tb = CLK();
   schedulePass(d, c, true, false, false);
+  long long tc = CLK();
+  d.rs->statClk[2] += tc - tb;
   c.fastEvStatic = 0;
   if (d.rs->error) return;
   int firstTermination = d.rs->terminationReason;
   wgBulk(d, B_NODE_OVER, cf.N);
   wgBulk(d, B_FILTER3, cf.M);
   int n3 = pqsEvict(d, c, true);
+  long long td = CLK();
   if (n3 > 0) schedulePass(d, c, false, true, true);
   if (d.rs->error) return;
+  long long te = CLK();
+  d.rs->statClk[4] += te - td;
   wgBulk(d, B_UNBIND, cf.M);
   wgBulk(d, B_KEYS_ALL, cf.N);
   d.rs->fastActive = 0;  // unbinding changed priority -2 allocatable behind the fast structure: next round_prepare rebuilds it
@@ -223,6 +235,7 @@ DEV void runRound(Dev& d, Ctl& c) {
   d.cmdIO[3] = wgCompactIota(d, cf.M, d.inPreempted, d.resPreJob);
   wgBulk(d, B_GATHER_SCHED, d.cmdIO[2]);
   wgBulk(d, B_GATHER_PRE, d.cmdIO[3]);
+  d.rs->statClk[5] += CLK() - te;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -369,7 +382,7 @@ DEV void controlMain(Dev& d, int cmd) {
   c.txn.active = d.rs->txnActive; c.fairStamp = d.rs->fairStamp; c.preList = d.preList; c.preCount = 0;
   c.skipKeyCheck = 0; c.compareSchedPrio = 0; c.preferLarge = d.cfg.preferLarge; c.useReplayAlloc = 0; c.onlyEvicted = 0;
   c.fastEnabled = d.f.iterOk && !d.rs->apiDirty && (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY);
-  c.fastEvStatic = 0; c.l1Dirty = 0;
+  c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0;
   fastLoad(d);
   runCommand(d, c, cmd);
   fastEnterGeneric(d, c);

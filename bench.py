@@ -161,7 +161,7 @@ def main():
                    "parallelism": f"pool-per-gpu x{world}" if world > 1 else "1 pool on 1 gpu", "seed": W.SEED},
         "round": {"scheduled": len(res.scheduled), "preempted": len(res.preempted), "evicted_phase1": res.num_evicted_phase1,
                   "evicted_phase3": res.num_evicted_phase3, "loop_iterations": iters, "node_queries_issued": queries,
-                  "termination_reason": res.termination_reason, "device_ms": kern_ms, "host_ms": float(np.mean(lat_ms))},
+                  "termination_reason": res.termination_reason, "device_ms": kern_ms, "host_ms": float(np.mean(lat_ms)), "stats": s.round_stats()},
         "input_build_s": build_s, "round_prepare_s": prep_s / (args.warmup + args.steps),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "kernel": "k_control", "algorithmic_bytes_per_launch": alg,
