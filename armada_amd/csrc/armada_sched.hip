@@ -153,19 +153,49 @@ __device__ static inline int pqTop(Dev& d, const Ctl& c) {
 // All of these run on wave 0 only (the control wave); results are wave-uniform.  LDS state is reached through the
 // __shared__ objects themselves (ds_* instructions), HBM through explicit global-address-space pointers (FastK): no flat
 // accesses, so LDS work never waits for the outstanding HBM stores/atomics and vice versa.
-__device__ static inline int pqTopFast(int Q) {
+__device__ static inline bool keyLess(uint32_t A, unsigned long long X, unsigned long long Y, uint32_t N, uint32_t oA, unsigned long long oX, unsigned long long oY, uint32_t oN) {
+  return A != oA ? A < oA : X != oX ? X < oX : Y != oY ? Y < oY : N < oN;
+}
+// sort the queues in the heap by key across the lanes (rank by counting; Q <= 64, done once per fastRun)
+__device__ static inline void pqBuild(PQState& s, int Q) {
   int lane = threadIdx.x & 63;
-  uint32_t A = ~0u, N = ~0u; unsigned long long X = ~0ull, Y = ~0ull; int best = -1;
-  if (lane < Q && g_fl.inHeap[lane]) { A = g_fl.kA[lane]; X = g_fl.kX[lane]; Y = g_fl.kY[lane]; N = (uint32_t)g_fl.nameRank[lane]; best = lane; }
-  for (int off = 32; off; off >>= 1) {
-    uint32_t oA = __shfl_xor(A, off, 64), oN = __shfl_xor(N, off, 64);
-    unsigned long long oX = __shfl_xor(X, off, 64), oY = __shfl_xor(Y, off, 64);
-    int ob = __shfl_xor(best, off, 64);
-    bool less = oA != A ? oA < A : oX != X ? oX < X : oY != Y ? oY < Y : oN < N;
-    bool take = ob >= 0 && (best < 0 || less);
-    if (take) { A = oA; X = oX; Y = oY; N = oN; best = ob; }
+  bool in = lane < Q && g_fl.inHeap[lane];
+  uint32_t A = in ? g_fl.kA[lane] : ~0u, N = lane < Q ? (uint32_t)g_fl.nameRank[lane] : ~0u;
+  unsigned long long X = in ? g_fl.kX[lane] : ~0ull, Y = in ? g_fl.kY[lane] : ~0ull;
+  int rank = 0;
+  for (int j = 0; j < 64; j++) {
+    uint32_t jA = __shfl(A, j, 64), jN = __shfl(N, j, 64); unsigned long long jX = __shfl(X, j, 64), jY = __shfl(Y, j, 64);
+    int jin = __shfl((int)in, j, 64);
+    bool before = jin && !in ? true : (!jin && in ? false : (keyLess(jA, jX, jY, jN, A, X, Y, N) || (jA == A && jX == X && jY == Y && jN == N && j < lane)));
+    if (j != lane && before) rank++;
   }
-  return best;
+  // scatter by rank through LDS, gather in lane order
+  g_fl.tmpA[rank] = A; g_fl.tmpN[rank] = N; g_fl.tmpX[rank] = X; g_fl.tmpY[rank] = Y; g_fl.tmpQ[rank] = in ? lane : -1;
+  s.A = g_fl.tmpA[lane]; s.N = g_fl.tmpN[lane]; s.X = g_fl.tmpX[lane]; s.Y = g_fl.tmpY[lane]; s.q = g_fl.tmpQ[lane];
+  s.count = __popcll(__ballot(in));
+}
+__device__ static inline int pqHead(PQState& s, int Q) {
+  int q = __builtin_amdgcn_readfirstlane(s.q);
+  return (s.count > 0 && q >= 0 && q < Q) ? q : -1;
+}
+// the head (queue q) was served: drop it and, if it still has a candidate gang, insert it again under its new key
+__device__ static inline void pqPopPush(PQState& s, const KeyOut& ko, int q) {
+  int lane = threadIdx.x & 63;
+  uint32_t hN = __builtin_amdgcn_readfirstlane(s.N);  // the name rank travels with the entry
+  // everything after the head moves up one lane
+  uint32_t dA = __shfl_down(s.A, 1, 64), dN = __shfl_down(s.N, 1, 64);
+  unsigned long long dX = __shfl_down(s.X, 1, 64), dY = __shfl_down(s.Y, 1, 64);
+  int dq = __shfl_down(s.q, 1, 64);
+  int cnt = s.count - 1;  // entries other than the head
+  if (lane >= cnt) { dA = ~0u; dN = ~0u; dX = ~0ull; dY = ~0ull; dq = -1; }
+  if (!ko.valid) { s.A = dA; s.N = dN; s.X = dX; s.Y = dY; s.q = dq; s.count = cnt; return; }
+  // position of the new key among the others = number of them that order before it
+  bool before = lane < cnt && keyLess(dA, dX, dY, dN, ko.A, ko.X, ko.Y, hN);
+  int pos = __popcll(__ballot(before));
+  // lanes < pos take the shifted entry, lane pos the new key, lanes > pos keep their own (shift up and down cancel)
+  if (lane < pos) { s.A = dA; s.N = dN; s.X = dX; s.Y = dY; s.q = dq; }
+  else if (lane == pos) { s.A = ko.A; s.N = hN; s.X = ko.X; s.Y = ko.Y; s.q = q; }
+  s.count = cnt + 1;
 }
 
 // fairness.go:99-105 three times (alloc+req, alloc, req): lane (8*which + r) evaluates one float64 ratio, the max over a
@@ -195,7 +225,7 @@ __device__ static inline void fastFence(Ctl& c) {
 }
 
 // 64 base positions per step, coalesced (keys, removed flags, extras, class bits all stored in base order)
-__device__ static inline void baseScan(const FastK& k, FastS& S, const JobTail& r) {
+__device__ static inline void baseScan(KREF k, FastS& S, const JobTail& r) {
   int lane = threadIdx.x & 63;
   int s = r.shape;
   int p0 = g_fl.cand[s].pos;
@@ -225,7 +255,7 @@ __device__ static inline void baseScan(const FastK& k, FastS& S, const JobTail& 
   }
 }
 
-__device__ static inline uint64_t l0Search(const FastK& k, const JobTail& r, int* slot) {
+__device__ static inline uint64_t l0Search(KREF k, const JobTail& r, int* slot) {
   int lane = threadIdx.x & 63;
   unsigned long long best = ~0ull; int bs = -1;
   int cnt = g_fl.l0Count;
@@ -237,12 +267,12 @@ __device__ static inline uint64_t l0Search(const FastK& k, const JobTail& r, int
     unsigned long long ok = __shfl_xor(best, off, 64); int os = __shfl_xor(bs, off, 64);
     if (ok < best) { best = ok; bs = os; }
   }
-  *slot = bs;
-  return best;
+  *slot = UNI32(bs);
+  return UNI64(best);
 }
 
 // WIN(=4) records x 16 lanes x 8 bytes: one coalesced 128-byte burst per job record
-__device__ static inline void winRefill(const FastK& k, int q, int kind, int pos, int cnt) {
+__device__ static inline void winRefill(KREF k, int q, int kind, int pos, int cnt) {
   int lane = threadIdx.x & 63;
   int i = lane >> 4, part = lane & 15;
   if (i < cnt) {
@@ -253,7 +283,7 @@ __device__ static inline void winRefill(const FastK& k, int q, int kind, int pos
     if (part == 0) { g_fl.winJob[q][i] = job; g_fl.winIdx[q][i] = idx; }
   }
 }
-__device__ static inline void loadHeadRec(const FastK& k, int q, int job) {
+__device__ static inline void loadHeadRec(KREF k, int q, int job) {
   int lane = threadIdx.x & 63;
   if (lane < 16) {
     unsigned long long v = k.jrec[(size_t)job * (sizeof(JobRec) / 8) + lane];
@@ -269,7 +299,7 @@ __device__ static inline void headFromWindow(int q, int w) {
 }
 
 // markAllocatable (node.go:539-549) for levels [lo, nl) as no-return HBM atomics, one (level, resource) per lane
-__device__ static inline void bindUpdate(const FastK& k, int n, int lo, int nl, int q, uint64_t keyDelta) {
+__device__ static inline void bindUpdate(KREF k, int n, int lo, int nl, int q, uint64_t keyDelta) {
   int lane = threadIdx.x & 63;
   int R = k.R, cnt = (nl - lo) * R;
   for (int i = lane; i < cnt; i += 64) {
@@ -281,7 +311,7 @@ __device__ static inline void bindUpdate(const FastK& k, int n, int lo, int nl, 
 }
 // sctx / qctx resource vectors for the head job of queue q: accumulate-only, lane x handles resource x;
 // LDS vectors through ds_add_u64, HBM by-priority-class vectors through global atomics, all without a return value
-__device__ static inline void accountVectors(Dev& d, const FastK& k, int q, int pc, bool ev, bool replay) {
+__device__ static inline void accountVectors(Dev& d, KREF k, int q, int pc, bool ev, bool replay) {
   (void)d;
   int lane = threadIdx.x & 63;
   if (lane < k.R) {
@@ -297,13 +327,13 @@ __device__ static inline void accountVectors(Dev& d, const FastK& k, int q, int 
     }
   }
 }
-__device__ static inline bool roundLimitExceeded(Dev& d, const FastK& k) {
+__device__ static inline bool roundLimitExceeded(Dev& d, KREF k) {
   (void)d;
   int lane = threadIdx.x & 63;
   bool ex = lane < k.R && g_rs.scheduled[lane] > k.maxToSchedule[lane];
-  return __ballot(ex) != 0;
+  return __ballot(ex) != 0;  // ballot results are scalar
 }
-__device__ static inline bool headRequestsDisallowed(const FastK& k, int q) {
+__device__ static inline bool headRequestsDisallowed(KREF k, int q) {
   int lane = threadIdx.x & 63;
   bool bad = lane < k.R && k.disallowed[lane] && g_fl.headReq[q][lane] > 0;
   return __ballot(bad) != 0;

@@ -180,4 +180,5 @@ struct Dev {
   int32_t* evIdxByPos;   // [M] evicted-table Index of evList[p]
   int32_t* l0Save;       // [L0CAP]
   int32_t* candPosSave;  // [SMAX]
+  const struct FastK* fk; // the fast loop's constants (round_fast.h), filled by the host at round_prepare
 };

@@ -59,31 +59,59 @@ struct FastLds {
   JobRec winRec[QCAPF][WIN];
   // queue order: packed keys + heap membership + name rank, one lane per queue
   uint32_t kA[QCAPF]; uint64_t kX[QCAPF]; uint64_t kY[QCAPF]; int32_t inHeap[QCAPF]; int32_t nameRank[QCAPF];
+  uint32_t tmpA[64], tmpN[64]; uint64_t tmpX[64], tmpY[64]; int32_t tmpQ[64];  // scatter space of pqBuild
 };
 
 #ifdef ASCHED_HOSTSIM
-#define FK_STORAGE static
 static FastLds g_fl;
 #define FLANE 0
 #define GA(T, p) (p)   // a pointer known to address HBM (explicit global address space on the device)
 #define GP(T) T*
+#define KREF const FastK&   // the loop constants: scalar (constant address space) loads on the device
+#define HD static inline
 #define RS (*d.rs)
 #define FOR_LANES(i, n) for (int i = 0; i < (n); i++)
 #define LDS_ADD64(ref, v) ((ref) += (v))
 #define DEV_NOINLINE static __attribute__((noinline))
 #else
-#define FK_STORAGE __shared__
 __shared__ FastLds g_fl;
 __shared__ RoundScalars g_rs;  // d.rs points here for the whole launch (relocateIn, armada_sched.hip)
 #define FLANE ((int)(threadIdx.x & 63))
+#define HD __host__ __device__ static inline
+#if defined(__HIP_DEVICE_COMPILE__)
 #define GA(T, p) ((__attribute__((address_space(1))) T*)(p))
 #define GP(T) __attribute__((address_space(1))) T*
+#define KREF const __attribute__((address_space(4))) FastK&
+#else  // host pass of hipcc: same layout, plain pointers (the host fills FastK for upload)
+#define GA(T, p) (p)
+#define GP(T) T*
+#define KREF const FastK&
+#endif
 #define RS g_rs
 #define FOR_LANES(i, n) for (int i = FLANE; i < (n); i += 64)
 #define LDS_ADD64(ref, v) ((void)__hip_atomic_fetch_add(&(ref), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))  // ds_add_u64, no return: nothing waits
 #define DEV_NOINLINE __device__ static __attribute__((noinline))
 #endif
 #define FL g_fl
+
+// A value every lane of the control wave holds identically, moved to scalar registers: branches on it become scalar
+// branches (no exec-mask bookkeeping) and arithmetic on it runs on the scalar unit.
+#if defined(ASCHED_HOSTSIM) || !defined(__HIP_DEVICE_COMPILE__)
+#define UNI32(x) (x)
+#define UNI64(x) (x)
+#define UNID(x) (x)
+#else
+__device__ static inline int uni32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ static inline unsigned long long uni64(unsigned long long v) {
+  unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+template <class T> __device__ static inline T uniT32(T v) { return (T)uni32((int)v); }
+template <class T> __device__ static inline T uniT64(T v) { return (T)uni64((unsigned long long)v); }
+#define UNI32(x) uniT32(x)
+#define UNI64(x) uniT64(x)
+#define UNID(x) (__builtin_bit_cast(double, uni64(__builtin_bit_cast(unsigned long long, (double)(x)))))
+#endif
 
 #ifdef ASCHED_FASTPROF
 #define SEG_BEGIN() S.segT = CLK()
@@ -92,6 +120,22 @@ __shared__ RoundScalars g_rs;  // d.rs points here for the whole launch (relocat
 #define SEG_BEGIN() do {} while (0)
 #define SEG(i) do {} while (0)
 #endif
+DEV void uniQHot(QHot& f) {
+  f.weight = UNID(f.weight); f.tokens = UNID(f.tokens); f.budget = UNID(f.budget); f.proposed = UNID(f.proposed); f.current = UNID(f.current); f.size = UNID(f.size);
+  f.burst = UNI64(f.burst);
+  f.itEi = UNI32(f.itEi); f.itQi = UNI32(f.itQi); f.itStage = UNI32(f.itStage); f.itJobsSeen = UNI32(f.itJobsSeen); f.itNext = UNI32(f.itNext); f.gctx = UNI32(f.gctx);
+  f.evEnd = UNI32(f.evEnd); f.qEnd = UNI32(f.qEnd); f.pcPrio = UNI32(f.pcPrio); f.schedPrio = UNI32(f.schedPrio);
+  f.rateInf = UNI32(f.rateInf); f.cordoned = UNI32(f.cordoned); f.itJobOnlyEv = UNI32(f.itJobOnlyEv); f.itGangOnlyEv = UNI32(f.itGangOnlyEv);
+  f.headFast = UNI32(f.headFast); f.headKind = UNI32(f.headKind); f.headIdx = UNI32(f.headIdx);
+  f.winKind = UNI32(f.winKind); f.winStart = UNI32(f.winStart); f.winCount = UNI32(f.winCount);
+}
+DEV void uniJobTail(JobTail& r) {
+  r.keyDelta = UNI64(r.keyDelta); r.fieldMin = UNI64(r.fieldMin);
+  r.pc = UNI32(r.pc); r.shape = UNI32(r.shape); r.gang = UNI32(r.gang); r.node0 = UNI32(r.node0); r.runPrio = UNI32(r.runPrio); r.cls = UNI32(r.cls); r.pcPrio = UNI32(r.pcPrio);
+  int fl = r.never | (r.preemptible << 8); fl = UNI32(fl); r.never = (uint8_t)(fl & 255); r.preemptible = (uint8_t)(fl >> 8);
+  r.ex0 = UNI64(r.ex0); r.ex1 = UNI64(r.ex1);
+}
+DEV void uniCand(CandRec& c) { c.pos = UNI32(c.pos); c.node = UNI32(c.node); c.key = UNI64(c.key); c.cls = UNI64(c.cls); c.ex0 = UNI64(c.ex0); c.ex1 = UNI64(c.ex1); }
 struct FitHandle { int src; int slot; };  // src 0: base candidate of the shape, 1: L0 slot
 // what the fast loop needs of Ctl + PassCfg, by value
 struct FastCtx { int withQueued; uint32_t maxLookback; int skipKnown, compareSchedPrio, preferLarge, replay, evStatic; };
@@ -119,9 +163,10 @@ struct FastS {
   long long segT;
 };
 
-FK_STORAGE FastK g_fk;  // the loop's constants, filled at the start of every fastRun (LDS on the device: read at use, not held in registers)
-
-DEV void fastKInit(Dev& d, FastK& k) {
+// The loop's constants are built once per round_prepare on the host (every value is a config field or a device pointer the
+// host allocated) and live in HBM; the device reads them through the constant address space: uniform scalar loads into
+// SGPRs, batched by the compiler, no LDS traffic and no vector registers.
+HD void fastKInit(const Dev& d, FastK& k) {
   const DevCfg& c = d.cfg;
   k.R = c.R; k.K = c.K; k.P = c.P; k.E = d.f.E; k.ex0col = d.f.extraCol[0]; k.ex1col = d.f.extraCol[1]; k.N = c.N; k.npc = c.npc; k.S = c.S;
   k.disableHome = c.disableHome; k.hasPcLimit = d.hasPcLimit; k.Npad = (size_t)c.Npad;
@@ -143,24 +188,29 @@ DEV void fastKInit(Dev& d, FastK& k) {
   k.evTabAlive = GA(uint8_t, d.evTabAlive); k.evTabJob = GA(int32_t, d.evTabJob); k.evIndexOfJob = GA(int32_t, d.evIndexOfJob); k.unfeasible = GA(uint8_t, d.unfeasible);
   k.qAllocByPc = GA(int64_t, d.qAllocByPc); k.qSchedByPc = GA(int64_t, d.qSchedByPc); k.qEvictedByPc = GA(int64_t, d.qEvictedByPc);
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ static inline KREF fastKRef(const Dev& d) { return *(const __attribute__((address_space(4))) FastK*)d.fk; }
+#else
+HD const FastK& fastKRef(const Dev& d) { return *d.fk; }
+#endif
 #define KAL(k, l, r, n) ((k).alloc[((size_t)(l) * (k).R + (r)) * (k).Npad + (n)])
 #define KKEY(k, l, n) ((k).keys[(size_t)(l) * (k).Npad + (n)])
 
 // ------------------------------------------------------------------------------------------------ small helpers
 DEV uint64_t dbits(double x) { return __builtin_bit_cast(uint64_t, x); }
 
-DEV bool fieldsGE(const FastK& k, uint64_t key, uint64_t fmin) {  // every packed field of key >= the same field of fmin
+DEV bool fieldsGE(KREF k, uint64_t key, uint64_t fmin) {  // every packed field of key >= the same field of fmin
   bool ok = true;
   for (int i = 0; i < MAXK; i++) { uint64_t m = k.fieldMask[i]; ok = ok && (key & m) >= (fmin & m); }  // unused fields have mask 0
   return ok;
 }
-DEV bool entryFits(const FastK& k, const JobTail& r, uint64_t key, int64_t ex0, int64_t ex1, uint64_t cls) {
+DEV bool entryFits(KREF k, const JobTail& r, uint64_t key, int64_t ex0, int64_t ex1, uint64_t cls) {
   bool ok = ((cls >> r.cls) & 1) != 0;      // StaticJobRequirementsMet via the requirement class (nodematching.go:161-183)
   ok = ok && fieldsGE(k, key, r.fieldMin);  // indexed columns: alloc/res >= req/res (both resolution-aligned)
   ok = ok && r.ex0 <= ex0 && r.ex1 <= ex1;  // non-indexed columns (nodematching.go:194-197); unused extras are 0 vs 0
   return ok;
 }
-DEV bool entryLive(const FastK& k, uint64_t key, int64_t ex0, int64_t ex1) {  // could still host the smallest request of some shape
+DEV bool entryLive(KREF k, uint64_t key, int64_t ex0, int64_t ex1) {  // could still host the smallest request of some shape
   return fieldsGE(k, key, k.minFieldMin) && k.minEx0 <= ex0 && k.minEx1 <= ex1;
 }
 DEV bool fastOn(Dev& d, const Ctl& c) { return c.fastEnabled && d.f.iterOk; }
@@ -168,12 +218,16 @@ DEV void fastHeadInvalidate(int q) { if (q < QCAPF) FL.hot[q].headFast = 0; }
 DEV void fastPassReset() { for (int q = 0; q < QCAPF; q++) { FL.hot[q].headFast = 0; FL.hot[q].winCount = 0; FL.hot[q].winKind = -1; } }
 
 // Less (queue_scheduler.go:738-798) as a lexicographic key (kA, kX, kY, name rank); exact for finite, non-negative costs
-DEV void packItemKeys(int preferLarge, int q, int32_t prio, double proposed, double current, double size, double budget) {
-  FL.kA[q] = ~((uint32_t)prio ^ 0x80000000u);  // higher priority first
+struct KeyOut { int valid; uint32_t A; uint64_t X, Y; };
+DEV KeyOut packItemKeys(int preferLarge, int q, int32_t prio, double proposed, double current, double size, double budget) {
+  KeyOut o; o.valid = 1;
+  o.A = ~((uint32_t)prio ^ 0x80000000u);  // higher priority first
   if (preferLarge) {
-    if (proposed <= budget) { FL.kX[q] = dbits(current); FL.kY[q] = ~dbits(size); }  // under budget: lower current cost, then larger item
-    else { FL.kX[q] = dbits(proposed) | (1ull << 63); FL.kY[q] = 0; }                 // over budget: after every under-budget item, lower proposed cost
-  } else { FL.kX[q] = dbits(proposed); FL.kY[q] = 0; }
+    if (proposed <= budget) { o.X = dbits(current); o.Y = ~dbits(size); }  // under budget: lower current cost, then larger item
+    else { o.X = dbits(proposed) | (1ull << 63); o.Y = 0; }                 // over budget: after every under-budget item, lower proposed cost
+  } else { o.X = dbits(proposed); o.Y = 0; }
+  FL.kA[q] = o.A; FL.kX[q] = o.X; FL.kY[q] = o.Y;
+  return o;
 }
 DEV void fastItemKeys(Dev& d, const Ctl& c, int q) {  // from the generic arrays (generic updatePQItem)
   if (!d.f.iterOk || q >= QCAPF) return;
@@ -211,7 +265,14 @@ DEV void fastQFlush(Dev& d) {
 DEV void fastEnsureLive(Dev& d, Ctl& c) { if (!c.fqLive) { fastQLoad(d); c.fqLive = 1; } }
 
 // ------------------------------------------------------------------------------------------------ lane-parallel primitives
+// The queue heap of CostBasedCandidateGangIterator as the fast loop sees it.  Device: the queues sorted by key across the
+// lanes of the control wave (registers); serving the head re-inserts it with one lane shift.  Host: argmin over the keys.
 #ifdef ASCHED_HOSTSIM
+struct PQState { int unused; };
+DEV int pqTopFast(int Q);
+DEV void pqBuild(PQState&, int) {}
+DEV int pqHead(PQState&, int Q) { return pqTopFast(Q); }
+DEV void pqPopPush(PQState&, const KeyOut&, int) {}
 DEV int pqTopFast(int Q) {
   int best = -1;
   for (int q = 0; q < Q; q++) {
@@ -236,7 +297,7 @@ DEV void drf3(Dev& d, int q, int k, bool replay, double w, double* proposed, dou
 }
 DEV void fastFence(Ctl&) {}
 // advance the base cursor of shape r.shape to the next clean entry the job fits on
-DEV void baseScan(const FastK& k, FastS& S, const JobTail& r) {
+DEV void baseScan(KREF k, FastS& S, const JobTail& r) {
   int s = r.shape;
   for (int p = FL.cand[s].pos; p < k.N; p++) {
     if (k.baseRemoved[p]) continue;
@@ -249,14 +310,14 @@ DEV void baseScan(const FastK& k, FastS& S, const JobTail& r) {
   }
   FL.cand[s].pos = k.N; FL.cand[s].node = -1;
 }
-DEV uint64_t l0Search(const FastK& k, const JobTail& r, int* slot) {
+DEV uint64_t l0Search(KREF k, const JobTail& r, int* slot) {
   uint64_t best = ~0ull; *slot = -1;
   for (int i = 0; i < FL.l0Count; i++)
     if (FL.l0Key[i] < best && entryFits(k, r, FL.l0Key[i], FL.l0Ex0[i], FL.l0Ex1[i], FL.l0Cls[i])) { best = FL.l0Key[i]; *slot = i; }
   return best;
 }
 // load jobs [pos, pos+cnt) of a queue stream (kind 0: evicted list, 1: queued list) into the queue's window
-DEV void winRefill(const FastK& k, int q, int kind, int pos, int cnt) {
+DEV void winRefill(KREF k, int q, int kind, int pos, int cnt) {
   GP(int32_t) stream = kind == 0 ? k.evList : k.queuedJobs;
   for (int i = 0; i < cnt; i++) {
     int job = stream[pos + i];
@@ -265,18 +326,18 @@ DEV void winRefill(const FastK& k, int q, int kind, int pos, int cnt) {
   }
 }
 // the head record of queue q := JobRec of `job` from HBM / := window slot w
-DEV void loadHeadRec(const FastK& k, int q, int job) {
+DEV void loadHeadRec(KREF k, int q, int job) {
   JobRec r; memcpy(&r, (const char*)k.jrec + (size_t)job * sizeof(JobRec), sizeof(JobRec));
   memcpy(FL.headReq[q], r.req, sizeof r.req); memcpy(&FL.headTail[q], &r.keyDelta, sizeof(JobTail));
 }
 DEV void headFromWindow(int q, int w) { memcpy(FL.headReq[q], FL.winRec[q][w].req, sizeof(int64_t) * MAXR); memcpy(&FL.headTail[q], &FL.winRec[q][w].keyDelta, sizeof(JobTail)); }
 // alloc[l][r][n] -= req[r], keys[l][n] -= keyDelta for levels l in [lo, nl)  (markAllocatable, node.go:539-549); req = head of queue q
-DEV void bindUpdate(const FastK& k, int n, int lo, int nl, int q, uint64_t keyDelta) {
+DEV void bindUpdate(KREF k, int n, int lo, int nl, int q, uint64_t keyDelta) {
   for (int l = lo; l < nl; l++) { for (int x = 0; x < k.R; x++) KAL(k, l, x, n) -= FL.headReq[q][x]; KKEY(k, l, n) -= keyDelta; }
 }
 // sctx / qctx resource vectors (context/scheduling.go:410-434, context/queue.go:231-265) for the head job of queue q:
 // accumulate-only, one lane per resource
-DEV void accountVectors(Dev& d, const FastK& k, int q, int pc, bool ev, bool replay) {
+DEV void accountVectors(Dev& d, KREF k, int q, int pc, bool ev, bool replay) {
   for (int x = 0; x < k.R; x++) {
     int64_t v = FL.headReq[q][x];
     if (replay) { FL.qReplay[q][x] += v; continue; }
@@ -287,21 +348,24 @@ DEV void accountVectors(Dev& d, const FastK& k, int q, int pc, bool ev, bool rep
     if (ev) k.qEvictedByPc[i] -= v; else k.qSchedByPc[i] += v;
   }
 }
-DEV bool roundLimitExceeded(Dev& d, const FastK& k) { for (int x = 0; x < k.R; x++) if (RS.scheduled[x] > k.maxToSchedule[x]) return true; return false; }  // constraints.go:113-119
-DEV bool headRequestsDisallowed(const FastK& k, int q) { for (int x = 0; x < k.R; x++) if (k.disallowed[x] && FL.headReq[q][x] > 0) return true; return false; }  // nodedb.go:596-601
+DEV bool roundLimitExceeded(Dev& d, KREF k) { for (int x = 0; x < k.R; x++) if (RS.scheduled[x] > k.maxToSchedule[x]) return true; return false; }  // constraints.go:113-119
+DEV bool headRequestsDisallowed(KREF k, int q) { for (int x = 0; x < k.R; x++) if (k.disallowed[x] && FL.headReq[q][x] > 0) return true; return false; }  // nodedb.go:596-601
 #else  // device versions: armada_sched.hip
-DEV int pqTopFast(int Q);
+struct PQState { uint32_t A, N; unsigned long long X, Y; int q; int count; };  // lane i: the i-th queue in heap order
+DEV void pqBuild(PQState& s, int Q);
+DEV int pqHead(PQState& s, int Q);
+DEV void pqPopPush(PQState& s, const KeyOut& ko, int q);
 DEV void drf3(Dev& d, int q, int k, bool replay, double w, double* proposed, double* current, double* size);
 DEV void fastFence(Ctl& c);
-DEV void baseScan(const FastK& k, FastS& S, const JobTail& r);
-DEV uint64_t l0Search(const FastK& k, const JobTail& r, int* slot);
-DEV void winRefill(const FastK& k, int q, int kind, int pos, int cnt);
-DEV void loadHeadRec(const FastK& k, int q, int job);
+DEV void baseScan(KREF k, FastS& S, const JobTail& r);
+DEV uint64_t l0Search(KREF k, const JobTail& r, int* slot);
+DEV void winRefill(KREF k, int q, int kind, int pos, int cnt);
+DEV void loadHeadRec(KREF k, int q, int job);
 DEV void headFromWindow(int q, int w);
-DEV void bindUpdate(const FastK& k, int n, int lo, int nl, int q, uint64_t keyDelta);
-DEV void accountVectors(Dev& d, const FastK& k, int q, int pc, bool ev, bool replay);
-DEV bool roundLimitExceeded(Dev& d, const FastK& k);
-DEV bool headRequestsDisallowed(const FastK& k, int q);
+DEV void bindUpdate(KREF k, int n, int lo, int nl, int q, uint64_t keyDelta);
+DEV void accountVectors(Dev& d, KREF k, int q, int pc, bool ev, bool replay);
+DEV bool roundLimitExceeded(Dev& d, KREF k);
+DEV bool headRequestsDisallowed(KREF k, int q);
 #endif
 DEV void candInvalidate(int S, int n) { FOR_LANES(s, S) if (FL.cand[s].node == n) FL.cand[s].node = -2; }
 DEV void candResetAll(Dev& d, const int32_t* pos) { FOR_LANES(s, d.cfg.S < SMAX ? d.cfg.S : SMAX) { FL.cand[s].node = -2; FL.cand[s].pos = pos ? pos[s] : 0; } }
@@ -315,7 +379,7 @@ DEV void fastEnterGeneric(Dev& d, Ctl& c) {
 }
 
 // ------------------------------------------------------------------------------------------------ L0 maintenance
-DEV bool l0Insert(const FastK& k, int n, uint64_t key, int64_t ex0, int64_t ex1, uint64_t cls) {
+DEV bool l0Insert(KREF k, int n, uint64_t key, int64_t ex0, int64_t ex1, uint64_t cls) {
   int i = FL.l0Count;
   if (i >= L0CAP) return false;
   FL.l0Key[i] = key; FL.l0Node[i] = n; FL.l0Cls[i] = cls; FL.l0Ex0[i] = ex0; FL.l0Ex1[i] = ex1;
@@ -323,7 +387,7 @@ DEV bool l0Insert(const FastK& k, int n, uint64_t key, int64_t ex0, int64_t ex1,
   if (FLANE == 0) k.l0Slot[n] = i;
   return true;
 }
-DEV void l0Remove(const FastK& k, int slot) {
+DEV void l0Remove(KREF k, int slot) {
   int last = FL.l0Count - 1;
   int n = FL.l0Node[slot];
   if (FLANE == 0) k.l0Slot[n] = -1;
@@ -339,7 +403,7 @@ DEV void fastDrop(Dev& d) { RS.fastActive = 0; RS.fastOverflow++; FL.l0Count = 0
 // node n's level-0 allocatable was changed by the generic code: bring base flags / L0 / candidates in line
 DEV void fastTouch(Dev& d, int n) {
   if (!d.f.structOk || !RS.fastActive) return;
-  FastK k; fastKInit(d, k);
+  KREF k = fastKRef(d);
   uint64_t key = KKEY(k, 0, n);
   int64_t ex0 = k.E > 0 ? KAL(k, 0, k.ex0col, n) : 0, ex1 = k.E > 1 ? KAL(k, 0, k.ex1col, n) : 0;
   int pos = GA(int32_t, d.posOf)[n], slot = k.l0Slot[n];
@@ -353,23 +417,24 @@ DEV void fastTouch(Dev& d, int n) {
 }
 
 // first fit at priority -2 for a job record; -1 none; handle says where the winner came from
-DEV int fastFirstFit(const FastK& k, FastS& S, const JobTail& r, FitHandle* h, CandRec* cOut) {
+DEV int fastFirstFit(KREF k, FastS& S, const JobTail& r, FitHandle* h, CandRec* cOut) {
   if (r.never) return -1;
   int s = r.shape;
-  if (FL.cand[s].node == -2) baseScan(k, S, r);
+  if (UNI32(FL.cand[s].node) == -2) baseScan(k, S, r);
   CandRec c = FL.cand[s];
+  uniCand(c);
   *cOut = c;
   uint64_t bk = c.node >= 0 ? c.key : ~0ull;
   int slot;
   uint64_t lk = l0Search(k, r, &slot);
-  if (lk < bk) { h->src = 1; h->slot = slot; return FL.l0Node[slot]; }
+  if (lk < bk) { h->src = 1; h->slot = slot; return UNI32(FL.l0Node[slot]); }
   if (bk == ~0ull) return -1;
   h->src = 0; h->slot = -1;
   return c.node;
 }
 DEV int fastSelectLevel0(Dev& d, int job) {
   if (!d.f.structOk || !RS.fastActive) return -2;
-  FastK k; fastKInit(d, k);
+  KREF k = fastKRef(d);
   FastS S; S.statScanSteps = 0;
   JobRec jr = d.jrec[job];
   JobTail r; memcpy(&r, &jr.keyDelta, sizeof r);
@@ -380,7 +445,7 @@ DEV int fastSelectLevel0(Dev& d, int job) {
 }
 // the job of record r was bound to node n found through handle h: level-0 bookkeeping of the fast structure.
 // Returns false when L0 overflowed (the caller drops the structure).
-DEV bool fastAfterBind(const FastK& k, FastS& S, const JobTail& r, int n, const FitHandle& h, const CandRec& c) {
+DEV bool fastAfterBind(KREF k, FastS& S, const JobTail& r, int n, const FitHandle& h, const CandRec& c) {
   if (h.src == 0) {
     uint64_t key = c.key - r.keyDelta;
     int64_t ex0 = c.ex0 - r.ex0, ex1 = c.ex1 - r.ex1;
@@ -405,7 +470,7 @@ DEV void fastLoad(Dev& d) {  // kernel start: rebuild the LDS side from HBM
   FL.l0Count = 0;
   fastPassReset();
   if (!d.f.structOk || !RS.fastActive) return;
-  FastK k; fastKInit(d, k);
+  KREF k = fastKRef(d);
   candResetAll(d, d.candPosSave);
   int cnt = RS.l0SaveCount;
   for (int i = 0; i < cnt; i++) {
@@ -425,8 +490,9 @@ DEV void fastSave(Dev& d) {  // kernel end
 // next single job of queue q, from the prefetch window; gang members and rare iterator states go to the generic code.
 // `f` is the caller's register copy of FL.hot[q]; changed fields are stored back here.  Returns false when the generic
 // updateAndPush must continue for queue q (state left exactly where costItClear leaves it).
-DEV bool fastAdvance(Dev& d, const FastK& k, FastS& S, const FastCtx& fc, int q, QHot& f) {
+DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f, KeyOut* ko) {
   FL.inHeap[q] = 0; f.itNext = -1; f.headFast = 0;
+  ko->valid = 0;
   bool ok = true, haveHead = false;
   for (;;) {
     bool generic = fc.maxLookback != 0 && !f.itGangOnlyEv && (uint32_t)f.itJobsSeen >= fc.maxLookback;  // queue_scheduler.go:434-444
@@ -449,10 +515,10 @@ DEV bool fastAdvance(Dev& d, const FastK& k, FastS& S, const FastCtx& fc, int q,
         S.statRefills++;
       }
       w = pos - f.winStart;
-      if (FL.winRec[q][w].gang >= 0) generic = true;
+      if (UNI32(FL.winRec[q][w].gang) >= 0) generic = true;
     }
     if (generic) { ok = false; break; }  // the generic iterator continues from the same state
-    int job = FL.winJob[q][w], shape = FL.winRec[q][w].shape;
+    int job = UNI32(FL.winJob[q][w]), shape = UNI32(FL.winRec[q][w].shape);
     if (kind == 0) f.itEi = pos + 1;
     else {
       f.itQi = pos + 1; f.itJobsSeen++;
@@ -470,16 +536,17 @@ DEV bool fastAdvance(Dev& d, const FastK& k, FastS& S, const FastCtx& fc, int q,
       continue;
     }
     f.itNext = job; f.gctx = job;
-    f.headKind = kind; f.headIdx = FL.winIdx[q][w]; f.headFast = 1;
+    f.headKind = kind; f.headIdx = UNI32(FL.winIdx[q][w]); f.headFast = 1;
     headFromWindow(q, w);
     SEG(4);
     double pr, cu, sz;
     drf3(d, q, w, fc.replay != 0, f.weight, &pr, &cu, &sz);
+    pr = UNID(pr); cu = UNID(cu); sz = UNID(sz);
     SEG(5);
-    int32_t p = FL.winRec[q][w].pcPrio;
-    int32_t sp = kind == 0 ? FL.winRec[q][w].runPrio : p;  // evicted: run.ScheduledAtPriority (queue_scheduler.go:660-672)
+    int32_t p = UNI32(FL.winRec[q][w].pcPrio);
+    int32_t sp = kind == 0 ? UNI32(FL.winRec[q][w].runPrio) : p;  // evicted: run.ScheduledAtPriority (queue_scheduler.go:660-672)
     f.proposed = pr; f.current = cu; f.size = sz; f.pcPrio = p; f.schedPrio = sp;
-    packItemKeys(fc.preferLarge, q, fc.compareSchedPrio ? sp : p, pr, cu, sz, f.budget);
+    *ko = packItemKeys(fc.preferLarge, q, fc.compareSchedPrio ? sp : p, pr, cu, sz, f.budget);
     haveHead = true;
     break;
   }
@@ -495,27 +562,29 @@ DEV bool fastAdvance(Dev& d, const FastK& k, FastS& S, const FastCtx& fc, int q,
 }
 
 // head of queue q was peeked by the generic code: fetch its record (one burst) and classify it
-DEV void fastLoadHead(const FastK& k, int q, int job, QHot& f) {
+DEV void fastLoadHead(KREF k, int q, int job, QHot& f) {
   loadHeadRec(k, q, job);
-  int ev = k.jcEvicted[job];
+  int ev = UNI32((int)k.jcEvicted[job]);
   f.headKind = ev ? 0 : 1;
-  f.headIdx = ev ? k.evIndexOfJob[job] : -1;
+  f.headIdx = ev ? UNI32(k.evIndexOfJob[job]) : -1;
   f.headFast = 1;
 }
 
-DEV int levelsUpTo(const FastK& k, int32_t cutoff) { int nl = 0; while (nl < k.P && k.prios[nl] <= cutoff) nl++; return nl; }  // prios ascend
+DEV int levelsUpTo(KREF k, int32_t cutoff) { int nl = 0; while (nl < k.P && k.prios[nl] <= cutoff) nl++; return nl; }  // prios ascend
 
 // One QueueScheduler iteration (queue_scheduler.go:94-304 body) for the head of queue `top` when it is a single job that
 // (a) is queued and fits at priority -2 or (b) is a phase-1-evicted job returning to its node.  Returns 0 WITHOUT side
 // effects when the iteration needs the generic code (any constraint failing, preemption, gangs, ...); 1 = done;
 // 2 = done, but the queue's next head must be produced by the generic updateAndPush.  Fast mode only.
-DEV int fastIter(Dev& d, const FastK& k, FastS& S, const FastCtx& fc, int top) {
+DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* ko) {
   int q = top;
   if (S.numPreemptedMarks != 0 || k.hasPcLimit) return 0;  // per-job preempted flags / per-queue caps: generic
   QHot f = FL.hot[q];
+  uniQHot(f);
   int job = f.gctx;
   if (!f.headFast) { fastLoadHead(k, q, job, f); FL.hot[q].headFast = 1; FL.hot[q].headKind = f.headKind; FL.hot[q].headIdx = f.headIdx; }
   JobTail r = FL.headTail[q];
+  uniJobTail(r);
   bool ev = f.headKind == 0;
   SEG(1);
   int pcx = r.pc;
@@ -563,13 +632,14 @@ DEV int fastIter(Dev& d, const FastK& k, FastS& S, const FastCtx& fc, int top) {
     if (!f.rateInf && 1 <= f.burst) f.tokens -= 1.0;
   }
   SEG(3);
-  return fastAdvance(d, k, S, fc, q, f) ? 1 : 2;
+  return fastAdvance(d, k, S, fc, q, f, ko) ? 1 : 2;
 }
 
 // one step of addEvictedJobsToNodeDb (preempting_queue_scheduler.go:589-639) for a single evicted job.  Fast mode only.
-DEV int fastReplayStep(Dev& d, const FastK& k, FastS& S, const FastCtx& fc, int top, int* counter) {
+DEV int fastReplayStep(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, int* counter, KeyOut* ko) {
   int q = top;
   QHot f = FL.hot[q];
+  uniQHot(f);
   int job = f.gctx, i = *counter;
   if (!f.headFast) fastLoadHead(k, q, job, f);
   if (FLANE == 0) { k.evTabJob[i] = job; k.evTabAlive[i] = 1; k.evIndexOfJob[job] = i; }
@@ -579,7 +649,7 @@ DEV int fastReplayStep(Dev& d, const FastK& k, FastS& S, const FastCtx& fc, int 
   accountVectors(d, k, q, 0, true, true);
   S.statFastReplay++;
   SEG(3);
-  return fastAdvance(d, k, S, fc, q, f) ? 1 : 2;
+  return fastAdvance(d, k, S, fc, q, f, ko) ? 1 : 2;
 }
 
 // Run fast iterations of the QueueScheduler loop (mode 0) or of the eviction-order replay (mode 1) until one needs the
@@ -590,29 +660,35 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   fc.preferLarge = c.preferLarge; fc.replay = mode; fc.evStatic = c.fastEvStatic;
   fastEnsureLive(d, c);
   c.l1Dirty = 1;
-  fastKInit(d, g_fk);
-  const FastK& k = g_fk;
+  KREF k = fastKRef(d);
   FastS S;
-  S.globalTokens = RS.globalTokens; S.globalBurst = RS.globalBurst; S.globalRateInf = RS.globalRateInf;
-  S.numScheduledJobs = RS.numScheduledJobs; S.numScheduledGangs = RS.numScheduledGangs; S.numEvictedJobs = RS.numEvictedJobs;
-  S.numNodeQueries = RS.numNodeQueries; S.loopIterations = RS.loopIterations; S.evictedTableSize = RS.evictedTableSize;
-  S.numUnfeasible = RS.numUnfeasible; S.numPreemptedMarks = RS.numPreemptedMarks; S.fastActive = RS.fastActive; S.lvl0NonNeg = RS.lvl0NonNeg;
-  S.statFastIters = RS.statFastIters; S.statScanSteps = RS.statScanSteps; S.statRefills = RS.statRefills; S.statL0Max = RS.statL0Max; S.statFastReplay = RS.statFastReplay;
-  int Q = d.cfg.Q;
-  int cnt = counter ? *counter : 0, pend = -1;
+  S.globalTokens = UNID(RS.globalTokens); S.globalBurst = UNI64(RS.globalBurst); S.globalRateInf = UNI32(RS.globalRateInf);
+  S.numScheduledJobs = UNI32(RS.numScheduledJobs); S.numScheduledGangs = UNI32(RS.numScheduledGangs); S.numEvictedJobs = UNI32(RS.numEvictedJobs);
+  S.numNodeQueries = UNI32(RS.numNodeQueries); S.loopIterations = UNI32(RS.loopIterations); S.evictedTableSize = UNI32(RS.evictedTableSize);
+  S.numUnfeasible = UNI32(RS.numUnfeasible); S.numPreemptedMarks = UNI32(RS.numPreemptedMarks); S.fastActive = UNI32(RS.fastActive); S.lvl0NonNeg = UNI32(RS.lvl0NonNeg);
+  S.statFastIters = UNI32(RS.statFastIters); S.statScanSteps = UNI32(RS.statScanSteps); S.statRefills = UNI32(RS.statRefills); S.statL0Max = UNI32(RS.statL0Max); S.statFastReplay = UNI32(RS.statFastReplay);
+  int Q = UNI32(d.cfg.Q);
+  fc.withQueued = UNI32(fc.withQueued); fc.maxLookback = UNI32(fc.maxLookback); fc.skipKnown = UNI32(fc.skipKnown); fc.compareSchedPrio = UNI32(fc.compareSchedPrio);
+  fc.preferLarge = UNI32(fc.preferLarge); fc.evStatic = UNI32(fc.evStatic);
+  mode = UNI32(mode);
+  int cnt = counter ? UNI32(*counter) : 0, pend = -1;
+  PQState pq;
+  pqBuild(pq, Q);
   SEG_BEGIN();
   for (;;) {
-    int t = pqTopFast(Q);
+    int t = pqHead(pq, Q);
     SEG(0);
 #ifdef ASCHED_HOSTSIM
     fastQFlush(d);
     if (t != pqTop(d, c)) { fprintf(stderr, "hostsim: packed queue key disagrees with Less (fast %d, generic %d)\n", t, pqTop(d, c)); abort(); }
 #endif
     if (t < 0) break;
-    if (FL.hot[t].gctx < 0) break;  // a gang: generic
-    int st = mode ? fastReplayStep(d, k, S, fc, t, &cnt) : fastIter(d, k, S, fc, t);
-    SEG(7);
+    if (UNI32(FL.hot[t].gctx) < 0) break;  // a gang: generic
+    KeyOut ko; ko.valid = 0; ko.A = 0; ko.X = ko.Y = 0;
+    int st = mode ? fastReplayStep(d, k, S, fc, t, &cnt, &ko) : fastIter(d, k, S, fc, t, &ko);
     if (st == 0) break;
+    pqPopPush(pq, ko, t);
+    SEG(7);
     if (!mode) { S.loopIterations++; S.statFastIters++; }
     if (st == 2) { pend = t; break; }
   }
