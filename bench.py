@@ -36,41 +36,32 @@ def algorithmic_bytes(n_nodes, R, queries, binds, fair_scan_rows=0):
 
 
 def cpu_baseline(wl, budget_s, full_iters):
-    """The CPU oracle (C++ restatement of the reference algorithm, oracle/) timed on this box's host cores, 1 thread.
-    Bounded sample: the SAME nodes/jobs/queues, but the round's global rate-limit burst is cut so that the round does a
-    fraction of the full round's loop iterations; rounds/s is scaled by the iteration ratio (the loop dominates)."""
+    """The CPU oracle (C++ restatement of the reference algorithm, oracle/) timed on this box's host cores, 1 thread
+    (the reference's round is single-goroutine).  Bounded sample: ONE round on the SAME nodes/jobs/queues.  A round of
+    BASELINE configs[2] is ~1 minute of oracle time, dominated by the eviction pass + loop over the evicted jobs, which a
+    smaller burst cannot shorten; when the estimate exceeds the budget the global burst is cut and the rate is scaled by
+    the loop-iteration ratio."""
     from armada_amd import workloads as W
     from armada_amd.binding import Library
+    import copy
     path = os.path.join(ROOT, "oracle", "liboracle.so")
     if not os.path.exists(path):
         return None
     oracle = Library(path, "oracle_")
-    import copy
     s = W.load(oracle, wl)
-    frac = 1.0
     sample = copy.copy(wl)
-    # pilot: 1/64 of the burst, then pick the largest power-of-two fraction that fits the budget
-    for frac in (1 / 64.0,):
-        sample.global_burst = max(1, int(wl.global_burst * frac)) if not wl.rate_inf else wl.global_burst
-        W.prepare(s, sample)
-        t0 = time.perf_counter(); r = s.schedule_round(); pilot = time.perf_counter() - t0
-    pilot_iters = max(1, r.num_loop_iterations)
-    per_iter = pilot / pilot_iters
-    target_iters = min(full_iters, max(pilot_iters, int(budget_s / max(per_iter, 1e-9))))
-    # iterations ~ evicted reschedules (fixed) + burst-limited new jobs: choose the burst that yields ~target_iters
-    fixed = max(0, pilot_iters - sample.global_burst)
-    burst = int(min(wl.global_burst, max(sample.global_burst, target_iters - fixed)))
-    if wl.rate_inf:
-        burst = wl.global_burst
-    sample.global_burst = burst
+    est = full_iters * 170e-6 * (wl.num_nodes / 100_000.0) ** 0.5   # measured: ~165 us per loop iteration at 100k nodes, ~40 us at 10k
+    if est > budget_s and not wl.rate_inf:
+        new_jobs = max(1, len([1 for _ in range(0)]) + int(wl.global_burst * max(0.02, (budget_s / est))))
+        sample.global_burst = min(wl.global_burst, new_jobs)
     W.prepare(s, sample)
     t0 = time.perf_counter(); r = s.schedule_round(); dt = time.perf_counter() - t0
     iters = max(1, r.num_loop_iterations)
     scaled = dt * (full_iters / iters) if full_iters > iters else dt
     s.close()
     return {"value": 1.0 / scaled, "unit": "rounds/s", "cores": 1, "kind": "port",
-            "sample": f"oracle (C++ restatement, 1 thread) on the same {wl.num_nodes}-node/{wl.num_jobs}-job input with the global burst cut to {burst} "
-                      f"({iters} of {full_iters} loop iterations, {dt:.2f} s measured, scaled by the iteration ratio)",
+            "sample": f"oracle (C++ restatement of the reference algorithm, 1 thread) on the same {wl.num_nodes}-node/{wl.num_jobs}-job input, one round with global burst "
+                      f"{sample.global_burst} ({iters} of {full_iters} loop iterations, {dt:.2f} s measured" + (", scaled by the iteration ratio)" if full_iters > iters else ")"),
             "measured_s": dt, "measured_iterations": iters}
 
 
@@ -83,7 +74,7 @@ def main():
     ap.add_argument("--jobs", type=int, default=1_000_000)
     ap.add_argument("--queues", type=int, default=64)
     ap.add_argument("--gangs", type=int, default=0)
-    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle work for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-budget", type=float, default=75.0, help="seconds of CPU-oracle work allowed for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,7 +95,8 @@ def main():
     hip = armada_amd.load_library()
 
     # one pool per rank; seeds differ per pool
-    wl = W.config3(n_nodes=args.nodes, n_jobs=args.jobs, n_queues=args.queues, seed=W.SEED + rank, gangs=args.gangs)
+    from armada_amd.multipool import pool_seed
+    wl = W.config3(n_nodes=args.nodes, n_jobs=args.jobs, n_queues=args.queues, seed=pool_seed(W.SEED, rank), gangs=args.gangs)
     scale = args.jobs / 1_000_000.0
     if args.jobs != 1_000_000:  # keep "limits bite" at reduced sizes
         wl.global_burst, wl.queue_burst = max(1, int(200_000 * scale)), max(1, int(20_000 * scale))
@@ -119,26 +111,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    lat, dev_ms, res = [], [], None
-    prep_s = 0.0
-    for i in range(args.warmup + args.steps):
-        tp = time.perf_counter()
-        W.prepare(s, wl)          # untimed input build (fresh NodeDb + bind running jobs + fair shares)
-        prep_s += time.perf_counter() - tp
-        barrier()
-        t0 = time.perf_counter()
-        res = s.schedule_round()  # synchronous: returns after the device finished and the result lists are on the host
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if i >= args.warmup:
-            lat.append(dt)
-            dev_ms.append(s.kernel_times()["round_ms"])
-    barrier()
-    total = float(sum(lat))
-    if dist is not None:
-        t = torch.tensor([total], dtype=torch.float64, device="cuda")
+    from armada_amd import multipool
+    tp = time.perf_counter()
+    lat, dev_ms, res = multipool.timed_rounds(s, wl, args.steps, args.warmup, barrier, torch.cuda.synchronize)
+    wall = time.perf_counter() - tp
+    prep_s = wall - sum(lat)  # untimed input build (fresh NodeDb + bind running jobs + fair shares + sorted base), incl. warm-up rounds
+
+    def amax(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        total = float(t.item())
+        return float(t.item())
+    value, total = multipool.aggregate(world, args.steps, float(sum(lat)), amax if dist is not None else None)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -152,7 +135,7 @@ def main():
     achieved = alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     out = {
         "metric": "scheduling rounds/sec (p99 round latency in p99_ms), 100k nodes x 1M jobs",
-        "value": world * args.steps / total, "unit": "rounds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "rounds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": total / args.steps * 1e3, "p50_ms": float(np.percentile(lat_ms, 50)), "p99_ms": float(np.percentile(lat_ms, 99)),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[2]: {wl.num_nodes} nodes x {wl.num_queues} queues x {args.jobs} queued jobs (+{wl.num_jobs - args.jobs} running), "
