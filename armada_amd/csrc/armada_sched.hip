@@ -328,14 +328,13 @@ __device__ static inline void accountVectors(Dev& d, KREF k, int q, int pc, bool
   }
 }
 __device__ static inline bool roundLimitExceeded(Dev& d, KREF k) {
-  (void)d;
   int lane = threadIdx.x & 63;
-  bool ex = lane < k.R && g_rs.scheduled[lane] > k.maxToSchedule[lane];
+  bool ex = lane < k.R && g_rs.scheduled[lane] > d.cfg.maxToSchedule[lane];
   return __ballot(ex) != 0;  // ballot results are scalar
 }
-__device__ static inline bool headRequestsDisallowed(KREF k, int q) {
+__device__ static inline bool headRequestsDisallowed(Dev& d, KREF k, int q) {
   int lane = threadIdx.x & 63;
-  bool bad = lane < k.R && k.disallowed[lane] && g_fl.headReq[q][lane] > 0;
+  bool bad = lane < k.R && d.cfg.disallowed[lane] && g_fl.headReq[q][lane] > 0;
   return __ballot(bad) != 0;
 }
 

@@ -55,7 +55,8 @@ struct JobRec {
   uint64_t keyDelta;   // packed (req_c / resolution_c) per indexed column: what a bind subtracts from a node's order key
   uint64_t fieldMin;   // packed (req_c / resolution_c - keyLo_c): smallest key fields of a node the job fits on
   int32_t pc, shape, gang, node0, runPrio, cls, pcPrio;
-  uint8_t never, preemptible, pad8[2];
+  uint8_t never, preemptible;
+  uint8_t nlPc, nlRun; // number of priority levels a bind at pcPrio / at runPrio subtracts from (levels with priority <= cutoff, nodedb.go:1321-1334)
   int64_t ex0, ex1;    // requests on the (<= MAXE) non-indexed columns
 };
 

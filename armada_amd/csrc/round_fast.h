@@ -41,7 +41,7 @@ struct alignas(16) QHot {
 struct alignas(16) JobTail {  // second half of a JobRec
   uint64_t keyDelta, fieldMin;
   int32_t pc, shape, gang, node0, runPrio, cls, pcPrio;
-  uint8_t never, preemptible, pad8[2];
+  uint8_t never, preemptible, nlPc, nlRun;
   int64_t ex0, ex1;
 };
 static_assert(sizeof(JobTail) == 64 && sizeof(JobRec) == 128 && __builtin_offsetof(JobRec, keyDelta) == 64, "JobRec = request vector + JobTail");
@@ -81,7 +81,7 @@ __shared__ RoundScalars g_rs;  // d.rs points here for the whole launch (relocat
 #if defined(__HIP_DEVICE_COMPILE__)
 #define GA(T, p) ((__attribute__((address_space(1))) T*)(p))
 #define GP(T) __attribute__((address_space(1))) T*
-#define KREF const __attribute__((address_space(4))) FastK&
+#define KREF const FastK&
 #else  // host pass of hipcc: same layout, plain pointers (the host fills FastK for upload)
 #define GA(T, p) (p)
 #define GP(T) T*
@@ -132,7 +132,8 @@ DEV void uniQHot(QHot& f) {
 DEV void uniJobTail(JobTail& r) {
   r.keyDelta = UNI64(r.keyDelta); r.fieldMin = UNI64(r.fieldMin);
   r.pc = UNI32(r.pc); r.shape = UNI32(r.shape); r.gang = UNI32(r.gang); r.node0 = UNI32(r.node0); r.runPrio = UNI32(r.runPrio); r.cls = UNI32(r.cls); r.pcPrio = UNI32(r.pcPrio);
-  int fl = r.never | (r.preemptible << 8); fl = UNI32(fl); r.never = (uint8_t)(fl & 255); r.preemptible = (uint8_t)(fl >> 8);
+  int fl = r.never | (r.preemptible << 8) | (r.nlPc << 16) | (r.nlRun << 24); fl = UNI32(fl);
+  r.never = (uint8_t)(fl & 255); r.preemptible = (uint8_t)((fl >> 8) & 255); r.nlPc = (uint8_t)((fl >> 16) & 255); r.nlRun = (uint8_t)((fl >> 24) & 255);
   r.ex0 = UNI64(r.ex0); r.ex1 = UNI64(r.ex1);
 }
 DEV void uniCand(CandRec& c) { c.pos = UNI32(c.pos); c.node = UNI32(c.node); c.key = UNI64(c.key); c.cls = UNI64(c.cls); c.ex0 = UNI64(c.ex0); c.ex1 = UNI64(c.ex1); }
@@ -145,7 +146,6 @@ struct FastK {
   int R, K, P, E, ex0col, ex1col, N, npc, S, disableHome, hasPcLimit, anyDisallowed;
   size_t Npad;
   uint64_t fieldMask[MAXK]; uint64_t minFieldMin; int64_t minEx0, minEx1;
-  int64_t maxToSchedule[MAXR]; int32_t prios[MAXP]; uint8_t disallowed[MAXR];
   GP(uint64_t) baseKey; GP(int32_t) baseNode; GP(int64_t) baseExtra; GP(uint64_t) baseCls; GP(uint8_t) baseRemoved; GP(int32_t) l0Slot;
   GP(int64_t) alloc; GP(uint64_t) keys; GP(unsigned long long) jrec; GP(int32_t) evList; GP(int32_t) queuedJobs; GP(int32_t) evIdxByPos;
   GP(uint8_t) jcEvicted; GP(int32_t) jcAssigned; GP(int32_t) jcReason; GP(uint8_t) jcHasPctx; GP(int32_t) jcGangCard; GP(int32_t) jcUniValue; GP(int32_t) jcStagedBy;
@@ -171,9 +171,8 @@ HD void fastKInit(const Dev& d, FastK& k) {
   k.R = c.R; k.K = c.K; k.P = c.P; k.E = d.f.E; k.ex0col = d.f.extraCol[0]; k.ex1col = d.f.extraCol[1]; k.N = c.N; k.npc = c.npc; k.S = c.S;
   k.disableHome = c.disableHome; k.hasPcLimit = d.hasPcLimit; k.Npad = (size_t)c.Npad;
   k.anyDisallowed = 0;
-  for (int i = 0; i < MAXR; i++) { k.maxToSchedule[i] = c.maxToSchedule[i]; k.disallowed[i] = i < c.R ? c.disallowed[i] : 0; if (k.disallowed[i]) k.anyDisallowed = 1; }
+  for (int i = 0; i < MAXR; i++) if (i < c.R && c.disallowed[i]) k.anyDisallowed = 1;
   for (int i = 0; i < MAXK; i++) k.fieldMask[i] = i < c.K ? d.f.fieldMask[i] : 0;
-  for (int i = 0; i < MAXP; i++) k.prios[i] = c.prios[i];
   k.minFieldMin = d.f.minFieldMin; k.minEx0 = d.f.minExtra[0]; k.minEx1 = d.f.minExtra[1];
   k.baseKey = GA(uint64_t, d.baseKey); k.baseNode = GA(int32_t, d.baseNode); k.baseExtra = GA(int64_t, d.baseExtra); k.baseCls = GA(uint64_t, d.baseCls);
   k.baseRemoved = GA(uint8_t, d.baseRemoved); k.l0Slot = GA(int32_t, d.l0Slot);
@@ -188,10 +187,11 @@ HD void fastKInit(const Dev& d, FastK& k) {
   k.evTabAlive = GA(uint8_t, d.evTabAlive); k.evTabJob = GA(int32_t, d.evTabJob); k.evIndexOfJob = GA(int32_t, d.evIndexOfJob); k.unfeasible = GA(uint8_t, d.unfeasible);
   k.qAllocByPc = GA(int64_t, d.qAllocByPc); k.qSchedByPc = GA(int64_t, d.qSchedByPc); k.qEvictedByPc = GA(int64_t, d.qEvictedByPc);
 }
+// a register copy of the constants: one burst of scalar loads (constant address space) per call, then no memory traffic
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ static inline KREF fastKRef(const Dev& d) { return *(const __attribute__((address_space(4))) FastK*)d.fk; }
+__device__ static inline FastK fastKRef(const Dev& d) { return *(const __attribute__((address_space(4))) FastK*)d.fk; }
 #else
-HD const FastK& fastKRef(const Dev& d) { return *d.fk; }
+HD FastK fastKRef(const Dev& d) { return *d.fk; }
 #endif
 #define KAL(k, l, r, n) ((k).alloc[((size_t)(l) * (k).R + (r)) * (k).Npad + (n)])
 #define KKEY(k, l, n) ((k).keys[(size_t)(l) * (k).Npad + (n)])
@@ -348,8 +348,8 @@ DEV void accountVectors(Dev& d, KREF k, int q, int pc, bool ev, bool replay) {
     if (ev) k.qEvictedByPc[i] -= v; else k.qSchedByPc[i] += v;
   }
 }
-DEV bool roundLimitExceeded(Dev& d, KREF k) { for (int x = 0; x < k.R; x++) if (RS.scheduled[x] > k.maxToSchedule[x]) return true; return false; }  // constraints.go:113-119
-DEV bool headRequestsDisallowed(KREF k, int q) { for (int x = 0; x < k.R; x++) if (k.disallowed[x] && FL.headReq[q][x] > 0) return true; return false; }  // nodedb.go:596-601
+DEV bool roundLimitExceeded(Dev& d, KREF k) { for (int x = 0; x < k.R; x++) if (RS.scheduled[x] > d.cfg.maxToSchedule[x]) return true; return false; }  // constraints.go:113-119
+DEV bool headRequestsDisallowed(Dev& d, KREF k, int q) { for (int x = 0; x < k.R; x++) if (d.cfg.disallowed[x] && FL.headReq[q][x] > 0) return true; return false; }  // nodedb.go:596-601
 #else  // device versions: armada_sched.hip
 struct PQState { uint32_t A, N; unsigned long long X, Y; int q; int count; };  // lane i: the i-th queue in heap order
 DEV void pqBuild(PQState& s, int Q);
@@ -365,7 +365,7 @@ DEV void headFromWindow(int q, int w);
 DEV void bindUpdate(KREF k, int n, int lo, int nl, int q, uint64_t keyDelta);
 DEV void accountVectors(Dev& d, KREF k, int q, int pc, bool ev, bool replay);
 DEV bool roundLimitExceeded(Dev& d, KREF k);
-DEV bool headRequestsDisallowed(KREF k, int q);
+DEV bool headRequestsDisallowed(Dev& d, KREF k, int q);
 #endif
 DEV void candInvalidate(int S, int n) { FOR_LANES(s, S) if (FL.cand[s].node == n) FL.cand[s].node = -2; }
 DEV void candResetAll(Dev& d, const int32_t* pos) { FOR_LANES(s, d.cfg.S < SMAX ? d.cfg.S : SMAX) { FL.cand[s].node = -2; FL.cand[s].pos = pos ? pos[s] : 0; } }
@@ -403,7 +403,7 @@ DEV void fastDrop(Dev& d) { RS.fastActive = 0; RS.fastOverflow++; FL.l0Count = 0
 // node n's level-0 allocatable was changed by the generic code: bring base flags / L0 / candidates in line
 DEV void fastTouch(Dev& d, int n) {
   if (!d.f.structOk || !RS.fastActive) return;
-  KREF k = fastKRef(d);
+  const FastK k = fastKRef(d);
   uint64_t key = KKEY(k, 0, n);
   int64_t ex0 = k.E > 0 ? KAL(k, 0, k.ex0col, n) : 0, ex1 = k.E > 1 ? KAL(k, 0, k.ex1col, n) : 0;
   int pos = GA(int32_t, d.posOf)[n], slot = k.l0Slot[n];
@@ -434,7 +434,7 @@ DEV int fastFirstFit(KREF k, FastS& S, const JobTail& r, FitHandle* h, CandRec* 
 }
 DEV int fastSelectLevel0(Dev& d, int job) {
   if (!d.f.structOk || !RS.fastActive) return -2;
-  KREF k = fastKRef(d);
+  const FastK k = fastKRef(d);
   FastS S; S.statScanSteps = 0;
   JobRec jr = d.jrec[job];
   JobTail r; memcpy(&r, &jr.keyDelta, sizeof r);
@@ -470,7 +470,7 @@ DEV void fastLoad(Dev& d) {  // kernel start: rebuild the LDS side from HBM
   FL.l0Count = 0;
   fastPassReset();
   if (!d.f.structOk || !RS.fastActive) return;
-  KREF k = fastKRef(d);
+  const FastK k = fastKRef(d);
   candResetAll(d, d.candPosSave);
   int cnt = RS.l0SaveCount;
   for (int i = 0; i < cnt; i++) {
@@ -570,7 +570,6 @@ DEV void fastLoadHead(KREF k, int q, int job, QHot& f) {
   f.headFast = 1;
 }
 
-DEV int levelsUpTo(KREF k, int32_t cutoff) { int nl = 0; while (nl < k.P && k.prios[nl] <= cutoff) nl++; return nl; }  // prios ascend
 
 // One QueueScheduler iteration (queue_scheduler.go:94-304 body) for the head of queue `top` when it is a single job that
 // (a) is queued and fits at priority -2 or (b) is a phase-1-evicted job returning to its node.  Returns 0 WITHOUT side
@@ -596,7 +595,7 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
     if (!S.fastActive) return 0;
     if (roundLimitExceeded(d, k)) return 0;  // CheckRoundConstraints (constraints.go:113-119)
     if (f.cordoned || S.globalTokens < 1 || S.globalBurst < 1 || f.tokens < 1 || f.burst < 1) return 0;  // CheckJobConstraints (:121-157)
-    if (k.anyDisallowed && headRequestsDisallowed(k, q)) return 0;
+    if (k.anyDisallowed && headRequestsDisallowed(d, k, q)) return 0;
     if (k.disableHome) return 0;
     prio = r.pcPrio;
     n = fastFirstFit(k, S, r, &h, &cand);
@@ -614,7 +613,7 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
   if (ev) S.numEvictedJobs--; else { S.numScheduledJobs++; S.numScheduledGangs++; }
   // ---- SelectNodeForJobWithTxn result + BindJobToNode (nodedb.go:538-630, 1046-1068)
   int32_t cutoff = r.preemptible ? prio : NONPREEMPTIBLE_CUTOFF;
-  int nl = levelsUpTo(k, cutoff);
+  int nl = ev ? r.nlRun : r.nlPc;
   bindUpdate(k, n, ev ? 1 : 0, nl, q, r.keyDelta);  // evicted job: level -2 gets -req (bind) and +req (un-evict): unchanged (node.go:416-442)
   if (FLANE == 0) {
     k.jcReason[job] = 0; k.jcHasPctx[job] = 1; k.pcNode[job] = n; k.pcSap[job] = prio;
@@ -660,7 +659,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   fc.preferLarge = c.preferLarge; fc.replay = mode; fc.evStatic = c.fastEvStatic;
   fastEnsureLive(d, c);
   c.l1Dirty = 1;
-  KREF k = fastKRef(d);
+  const FastK k = fastKRef(d);
   FastS S;
   S.globalTokens = UNID(RS.globalTokens); S.globalBurst = UNI64(RS.globalBurst); S.globalRateInf = UNI32(RS.globalRateInf);
   S.numScheduledJobs = UNI32(RS.numScheduledJobs); S.numScheduledGangs = UNI32(RS.numScheduledGangs); S.numEvictedJobs = UNI32(RS.numEvictedJobs);
