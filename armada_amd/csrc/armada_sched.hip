@@ -327,6 +327,42 @@ __device__ static inline void accountVectors(Dev& d, KREF k, int q, int pc, bool
     }
   }
 }
+// WIN EvKey records (32 B each) of queue q's evicted stream: 4 lanes x 8 bytes per record
+__device__ static inline void evWinRefill(KREF k, int q, int pos, int cnt) {
+  int lane = threadIdx.x & 63;
+  if (lane < cnt * 4) ((unsigned long long*)&g_fl.evWin[q][0])[lane] = k.evKey[(size_t)pos * 4 + lane];
+}
+// Deferred commits of evicted jobs [p0, p1) of queue q returning to their nodes, one job per lane: the evicted branch of
+// fastIter's commit (node.go:416-442 arithmetic, sctx/qctx accounting) as no-return atomics and plain stores.
+__device__ static inline void applyEvictedRange(Dev& d, KREF k, int q, int p0, int p1) {
+  (void)d;
+  int lane = threadIdx.x & 63;
+  int R = k.R;
+  for (int p = p0 + lane; p < p1; p += 64) {
+    int job = k.evList[p];
+    GP(unsigned long long) rec = k.jrec + (size_t)job * (sizeof(JobRec) / 8);
+    unsigned long long keyDelta = rec[8];
+    unsigned long long w10 = rec[10], w11 = rec[11], w12 = rec[12], w13 = rec[13];
+    int pcx = (int)(unsigned)w10, n = (int)(unsigned)(w11 >> 32), prio = (int)(unsigned)w12;
+    unsigned flags = (unsigned)(w13 >> 32);
+    int preemptible = (flags >> 8) & 255, nlRun = (flags >> 24) & 255;
+    int32_t cutoff = preemptible ? prio : NONPREEMPTIBLE_CUTOFF;
+    for (int x = 0; x < R; x++) {
+      int64_t v = (int64_t)rec[x];
+      if (!v) continue;
+      LDS_ADD64(g_fl.qAlloc[q][x], v); LDS_ADD64(g_rs.allocated[x], v); LDS_ADD64(g_rs.evicted[x], -v);
+      size_t i = ((size_t)q * k.npc + pcx) * R + x;
+      __hip_atomic_fetch_add(&k.qAllocByPc[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&k.qEvictedByPc[i], -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int l = 1; l < nlRun; l++) __hip_atomic_fetch_add(&KAL(k, l, x, n), -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (keyDelta) for (int l = 1; l < nlRun; l++) __hip_atomic_fetch_add(&KKEY(k, l, n), 0ull - keyDelta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    k.jcReason[job] = 0; k.jcHasPctx[job] = 1; k.pcNode[job] = n; k.pcSap[job] = prio;
+    k.jobNode[job] = n; k.jobCutoff[job] = cutoff; k.jobEvictedOnNode[job] = 0; k.schedAtPrio[job] = prio; k.inSchedAndEvicted[job] = 0;
+    k.pcPap[job] = prio; k.pcMethod[job] = ASCHED_METHOD_RESCHEDULED; k.jobFlags[job] = F_RESCHEDULED; k.inPreempted[job] = 0;
+    k.evTabAlive[k.evIdxByPos[p]] = 0; k.evIndexOfJob[job] = -1;
+  }
+}
 __device__ static inline bool roundLimitExceeded(Dev& d, KREF k) {
   int lane = threadIdx.x & 63;
   bool ex = lane < k.R && g_rs.scheduled[lane] > d.cfg.maxToSchedule[lane];

@@ -60,6 +60,10 @@ struct JobRec {
   int64_t ex0, ex1;    // requests on the (<= MAXE) non-indexed columns
 };
 
+// Queue-order inputs of one evicted job in its queue's eviction-order stream, computed for the whole stream in one bulk
+// pass (round_run.h B_EVKEYS): the DRF costs updatePQItem would compute when the job becomes the queue's head.
+struct EvKey { double proposed, current, size; int32_t pcPrio; int32_t job; };
+
 // Level-0 ("fit without preemption", priority -2) fast structure, DESIGN.md "Sorted base + LDS delta".
 struct FastCfg {
   int structOk, iterOk;       // host-verified exactness conditions (asched_host.inc: fastConditions)
@@ -179,6 +183,10 @@ struct Dev {
   uint64_t* nodeCls;     // [N]
   JobRec* jrec;          // [M]
   int32_t* evIdxByPos;   // [M] evicted-table Index of evList[p]
+  EvKey* evKey;          // [M] per evicted-list position (queues with evCheap)
+  uint8_t* evCheap;      // [Q+1] the queue's evicted stream has precomputed keys (no gang members)
+  int64_t* evPart;       // [evChunks][2*MAXR+4] partial request sums of the chunked prefix pass (B_EVSUM)
+  int32_t evChunks;
   int32_t* l0Save;       // [L0CAP]
   int32_t* candPosSave;  // [SMAX]
   const struct FastK* fk; // the fast loop's constants (round_fast.h), filled by the host at round_prepare

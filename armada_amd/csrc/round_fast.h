@@ -37,6 +37,8 @@ struct alignas(16) QHot {
   int32_t rateInf, cordoned, itJobOnlyEv, itGangOnlyEv;
   int32_t headFast, headKind, headIdx;      // head job: record cached in head*, 0 evicted / 1 queued, evicted-table Index
   int32_t winKind, winStart, winCount;      // prefetch window: stream (0 evicted list, 1 queued list) and position range
+  int32_t evCheap, evApplied, evDone, ewStart, ewCount, headPos;  // evicted stream with precomputed keys: served up to evDone, commits applied up to evApplied; key window; stream position of an evicted head
+  int32_t pad2[2];
 };
 struct alignas(16) JobTail {  // second half of a JobRec
   uint64_t keyDelta, fieldMin;
@@ -57,6 +59,7 @@ struct FastLds {
   int64_t headReq[QCAPF][MAXR]; JobTail headTail[QCAPF];
   int32_t winJob[QCAPF][WIN]; int32_t winIdx[QCAPF][WIN];
   JobRec winRec[QCAPF][WIN];
+  EvKey evWin[QCAPF][WIN];
   // queue order: packed keys + heap membership + name rank, one lane per queue
   uint32_t kA[QCAPF]; uint64_t kX[QCAPF]; uint64_t kY[QCAPF]; int32_t inHeap[QCAPF]; int32_t nameRank[QCAPF];
   uint32_t tmpA[64], tmpN[64]; uint64_t tmpX[64], tmpY[64]; int32_t tmpQ[64];  // scatter space of pqBuild
@@ -128,6 +131,7 @@ DEV void uniQHot(QHot& f) {
   f.rateInf = UNI32(f.rateInf); f.cordoned = UNI32(f.cordoned); f.itJobOnlyEv = UNI32(f.itJobOnlyEv); f.itGangOnlyEv = UNI32(f.itGangOnlyEv);
   f.headFast = UNI32(f.headFast); f.headKind = UNI32(f.headKind); f.headIdx = UNI32(f.headIdx);
   f.winKind = UNI32(f.winKind); f.winStart = UNI32(f.winStart); f.winCount = UNI32(f.winCount);
+  f.evCheap = UNI32(f.evCheap); f.evApplied = UNI32(f.evApplied); f.evDone = UNI32(f.evDone); f.ewStart = UNI32(f.ewStart); f.ewCount = UNI32(f.ewCount); f.headPos = UNI32(f.headPos);
 }
 DEV void uniJobTail(JobTail& r) {
   r.keyDelta = UNI64(r.keyDelta); r.fieldMin = UNI64(r.fieldMin);
@@ -147,7 +151,7 @@ struct FastK {
   size_t Npad;
   uint64_t fieldMask[MAXK]; uint64_t minFieldMin; int64_t minEx0, minEx1;
   GP(uint64_t) baseKey; GP(int32_t) baseNode; GP(int64_t) baseExtra; GP(uint64_t) baseCls; GP(uint8_t) baseRemoved; GP(int32_t) l0Slot;
-  GP(int64_t) alloc; GP(uint64_t) keys; GP(unsigned long long) jrec; GP(int32_t) evList; GP(int32_t) queuedJobs; GP(int32_t) evIdxByPos;
+  GP(int64_t) alloc; GP(uint64_t) keys; GP(unsigned long long) jrec; GP(int32_t) evList; GP(int32_t) queuedJobs; GP(int32_t) evIdxByPos; GP(unsigned long long) evKey;
   GP(uint8_t) jcEvicted; GP(int32_t) jcAssigned; GP(int32_t) jcReason; GP(uint8_t) jcHasPctx; GP(int32_t) jcGangCard; GP(int32_t) jcUniValue; GP(int32_t) jcStagedBy;
   GP(int32_t) pcNode; GP(int32_t) pcSap; GP(int32_t) pcPap; GP(int32_t) pcMethod; GP(int32_t) jobNode; GP(int32_t) jobCutoff; GP(uint8_t) jobEvictedOnNode;
   GP(int32_t) schedAtPrio; GP(uint8_t) inSchedAndEvicted; GP(uint8_t) inPreempted; GP(uint8_t) inScheduled; GP(uint8_t) jobFlags;
@@ -177,7 +181,7 @@ HD void fastKInit(const Dev& d, FastK& k) {
   k.baseKey = GA(uint64_t, d.baseKey); k.baseNode = GA(int32_t, d.baseNode); k.baseExtra = GA(int64_t, d.baseExtra); k.baseCls = GA(uint64_t, d.baseCls);
   k.baseRemoved = GA(uint8_t, d.baseRemoved); k.l0Slot = GA(int32_t, d.l0Slot);
   k.alloc = GA(int64_t, d.alloc); k.keys = GA(uint64_t, d.keys); k.jrec = GA(unsigned long long, (unsigned long long*)d.jrec);
-  k.evList = GA(int32_t, d.evList); k.queuedJobs = GA(int32_t, d.queuedJobs); k.evIdxByPos = GA(int32_t, d.evIdxByPos);
+  k.evList = GA(int32_t, d.evList); k.queuedJobs = GA(int32_t, d.queuedJobs); k.evIdxByPos = GA(int32_t, d.evIdxByPos); k.evKey = GA(unsigned long long, (unsigned long long*)d.evKey);
   k.jcEvicted = GA(uint8_t, d.jcEvicted); k.jcAssigned = GA(int32_t, d.jcAssigned); k.jcReason = GA(int32_t, d.jcReason); k.jcHasPctx = GA(uint8_t, d.jcHasPctx);
   k.jcGangCard = GA(int32_t, d.jcGangCard); k.jcUniValue = GA(int32_t, d.jcUniValue); k.jcStagedBy = GA(int32_t, d.jcStagedBy);
   k.pcNode = GA(int32_t, d.pcNode); k.pcSap = GA(int32_t, d.pcSap); k.pcPap = GA(int32_t, d.pcPap); k.pcMethod = GA(int32_t, d.pcMethod);
@@ -215,7 +219,7 @@ DEV bool entryLive(KREF k, uint64_t key, int64_t ex0, int64_t ex1) {  // could s
 }
 DEV bool fastOn(Dev& d, const Ctl& c) { return c.fastEnabled && d.f.iterOk; }
 DEV void fastHeadInvalidate(int q) { if (q < QCAPF) FL.hot[q].headFast = 0; }
-DEV void fastPassReset() { for (int q = 0; q < QCAPF; q++) { FL.hot[q].headFast = 0; FL.hot[q].winCount = 0; FL.hot[q].winKind = -1; } }
+DEV void fastPassReset() { for (int q = 0; q < QCAPF; q++) { FL.hot[q].headFast = 0; FL.hot[q].winCount = 0; FL.hot[q].winKind = -1; FL.hot[q].ewCount = 0; FL.hot[q].ewStart = 0; } }
 
 // Less (queue_scheduler.go:738-798) as a lexicographic key (kA, kX, kY, name rank); exact for finite, non-negative costs
 struct KeyOut { int valid; uint32_t A; uint64_t X, Y; };
@@ -247,6 +251,8 @@ DEV void fastQLoad(Dev& d) {
     f.itNext = d.itNext[q]; f.gctx = d.pqGctx[q]; f.evEnd = d.evOff[q + 1]; f.qEnd = d.queuedOff[q + 1];
     f.pcPrio = d.pqPcPrio[q]; f.schedPrio = d.pqSchedPrio[q];
     f.rateInf = d.qRateInf[q]; f.cordoned = d.qCordoned[q]; f.itJobOnlyEv = d.itJobOnlyEv[q]; f.itGangOnlyEv = d.itGangOnlyEv[q];
+    { int g = f.gctx; bool headEv = g >= 0 && d.jcEvicted[g];  // an evicted head was yielded from evList[itEi-1] and is not served yet
+      f.evCheap = d.evCheap ? d.evCheap[q] : 0; f.evDone = f.evApplied = headEv ? f.itEi - 1 : f.itEi; f.headPos = headEv ? f.itEi - 1 : -1; }
     FL.inHeap[q] = d.pqInHeap[q]; FL.nameRank[q] = d.qNameRank[q];
   }
 }
@@ -348,6 +354,29 @@ DEV void accountVectors(Dev& d, KREF k, int q, int pc, bool ev, bool replay) {
     if (ev) k.qEvictedByPc[i] -= v; else k.qSchedByPc[i] += v;
   }
 }
+DEV void evWinRefill(KREF k, int q, int pos, int cnt) { for (int i = 0; i < cnt; i++) memcpy(&FL.evWin[q][i], (const char*)k.evKey + (size_t)(pos + i) * sizeof(EvKey), sizeof(EvKey)); }
+// Deferred commits of evicted jobs [p0, p1) of queue q's eviction list returning to their nodes: exactly the evicted branch of
+// fastIter's commit, applied to many jobs at once (all updates are integer adds or per-job stores: order independent).
+DEV void applyEvictedRange(Dev& d, KREF k, int q, int p0, int p1) {
+  for (int p = p0; p < p1; p++) {
+    int job = k.evList[p];
+    const JobRec& r = d.jrec[job];
+    int n = r.node0, pcx = r.pc; int32_t prio = r.runPrio;
+    int32_t cutoff = r.preemptible ? prio : NONPREEMPTIBLE_CUTOFF;
+    for (int x = 0; x < k.R; x++) {
+      int64_t v = r.req[x];
+      FL.qAlloc[q][x] += v; RS.allocated[x] += v; RS.evicted[x] -= v;
+      size_t i = ((size_t)q * k.npc + pcx) * k.R + x;
+      k.qAllocByPc[i] += v; k.qEvictedByPc[i] -= v;
+      for (int l = 1; l < r.nlRun; l++) KAL(k, l, x, n) -= v;
+    }
+    for (int l = 1; l < r.nlRun; l++) KKEY(k, l, n) -= r.keyDelta;
+    k.jcReason[job] = 0; k.jcHasPctx[job] = 1; k.pcNode[job] = n; k.pcSap[job] = prio;
+    k.jobNode[job] = n; k.jobCutoff[job] = cutoff; k.jobEvictedOnNode[job] = 0; k.schedAtPrio[job] = prio; k.inSchedAndEvicted[job] = 0;
+    k.pcPap[job] = prio; k.pcMethod[job] = ASCHED_METHOD_RESCHEDULED; k.jobFlags[job] = F_RESCHEDULED; k.inPreempted[job] = 0;
+    k.evTabAlive[k.evIdxByPos[p]] = 0; k.evIndexOfJob[job] = -1;
+  }
+}
 DEV bool roundLimitExceeded(Dev& d, KREF k) { for (int x = 0; x < k.R; x++) if (RS.scheduled[x] > d.cfg.maxToSchedule[x]) return true; return false; }  // constraints.go:113-119
 DEV bool headRequestsDisallowed(Dev& d, KREF k, int q) { for (int x = 0; x < k.R; x++) if (d.cfg.disallowed[x] && FL.headReq[q][x] > 0) return true; return false; }  // nodedb.go:596-601
 #else  // device versions: armada_sched.hip
@@ -364,6 +393,8 @@ DEV void loadHeadRec(KREF k, int q, int job);
 DEV void headFromWindow(int q, int w);
 DEV void bindUpdate(KREF k, int n, int lo, int nl, int q, uint64_t keyDelta);
 DEV void accountVectors(Dev& d, KREF k, int q, int pc, bool ev, bool replay);
+DEV void evWinRefill(KREF k, int q, int pos, int cnt);
+DEV void applyEvictedRange(Dev& d, KREF k, int q, int p0, int p1);
 DEV bool roundLimitExceeded(Dev& d, KREF k);
 DEV bool headRequestsDisallowed(Dev& d, KREF k, int q);
 #endif
@@ -373,8 +404,15 @@ DEV void candSaveAll(Dev& d, int32_t* pos) { FOR_LANES(s, d.cfg.S < SMAX ? d.cfg
 
 // Before generic code runs: the LDS queue records back into the generic arrays, and the fast path's no-return atomics
 // made visible to plain loads
+DEV void fastFlushEvicted(Dev& d) {  // apply every queue's deferred evicted-job commits
+  const FastK k = fastKRef(d);
+  for (int q = 0; q < d.cfg.Q; q++) {
+    int p0 = UNI32(FL.hot[q].evApplied), p1 = UNI32(FL.hot[q].evDone);
+    if (p0 < p1) { applyEvictedRange(d, k, q, p0, p1); FL.hot[q].evApplied = p1; RS.numEvictedJobs -= p1 - p0; }
+  }
+}
 DEV void fastEnterGeneric(Dev& d, Ctl& c) {
-  if (c.fqLive) { fastQFlush(d); c.fqLive = 0; }
+  if (c.fqLive) { fastFlushEvicted(d); fastQFlush(d); c.fqLive = 0; }
   fastFence(c);
 }
 
@@ -506,6 +544,26 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
       if (kind < 0) { f.gctx = -1; f.proposed = f.current = f.size = 0; break; }
       if (kind == 0 && !fc.evStatic && !fc.replay) generic = true;  // evicted this round after being scheduled: node / priority are not the job's static run
     }
+    if (!generic && kind == 1 && f.evApplied < f.evDone) {  // first queued job after cheap evicted ones: their commits feed the queue's allocation
+      applyEvictedRange(d, k, q, f.evApplied, f.evDone);
+      S.numEvictedJobs -= f.evDone - f.evApplied; f.evApplied = f.evDone;
+    }
+    if (!generic && kind == 0 && f.evCheap) {  // costs precomputed for the whole evicted stream (B_EVKEYS): no job record, no DRF evaluation
+      if (!(pos >= f.ewStart && pos < f.ewStart + f.ewCount)) {
+        int cnt = end - pos; if (cnt > WIN) cnt = WIN;
+        evWinRefill(k, q, pos, cnt);
+        f.ewStart = pos; f.ewCount = cnt;
+        S.statRefills++;
+      }
+      EvKey e = FL.evWin[q][pos - f.ewStart];
+      e.proposed = UNID(e.proposed); e.current = UNID(e.current); e.size = UNID(e.size); e.pcPrio = UNI32(e.pcPrio); e.job = UNI32(e.job);
+      f.itEi = pos + 1;
+      f.itNext = e.job; f.gctx = e.job; f.headKind = 2; f.headIdx = -1; f.headPos = pos; f.headFast = 1;
+      f.proposed = e.proposed; f.current = e.current; f.size = e.size; f.pcPrio = e.pcPrio; f.schedPrio = e.pcPrio;
+      *ko = packItemKeys(fc.preferLarge, q, e.pcPrio, e.proposed, e.current, e.size, f.budget);
+      haveHead = true;
+      break;
+    }
     int w = 0;
     if (!generic) {
       if (!(f.winKind == kind && pos >= f.winStart && pos < f.winStart + f.winCount)) {
@@ -536,7 +594,7 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
       continue;
     }
     f.itNext = job; f.gctx = job;
-    f.headKind = kind; f.headIdx = UNI32(FL.winIdx[q][w]); f.headFast = 1;
+    f.headKind = kind; f.headIdx = UNI32(FL.winIdx[q][w]); f.headPos = kind == 0 ? pos : -1; f.headFast = 1;
     headFromWindow(q, w);
     SEG(4);
     double pr, cu, sz;
@@ -556,6 +614,7 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
   o.itEi = f.itEi; o.itQi = f.itQi; o.itStage = f.itStage; o.itJobsSeen = f.itJobsSeen; o.itNext = f.itNext; o.gctx = f.gctx;
   o.pcPrio = f.pcPrio; o.schedPrio = f.schedPrio; o.headFast = f.headFast; o.headKind = f.headKind; o.headIdx = f.headIdx;
   o.winKind = f.winKind; o.winStart = f.winStart; o.winCount = f.winCount;
+  o.evApplied = f.evApplied; o.evDone = f.evDone; o.ewStart = f.ewStart; o.ewCount = f.ewCount; o.headPos = f.headPos;
   if (haveHead) FL.inHeap[q] = 1;
   SEG(6);
   return ok;
@@ -567,6 +626,7 @@ DEV void fastLoadHead(KREF k, int q, int job, QHot& f) {
   int ev = UNI32((int)k.jcEvicted[job]);
   f.headKind = ev ? 0 : 1;
   f.headIdx = ev ? UNI32(k.evIndexOfJob[job]) : -1;
+  f.headPos = ev ? f.itEi - 1 : -1;
   f.headFast = 1;
 }
 
@@ -581,7 +641,12 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
   QHot f = FL.hot[q];
   uniQHot(f);
   int job = f.gctx;
-  if (!f.headFast) { fastLoadHead(k, q, job, f); FL.hot[q].headFast = 1; FL.hot[q].headKind = f.headKind; FL.hot[q].headIdx = f.headIdx; }
+  if (f.headFast && f.headKind == 2) {  // evicted job with precomputed costs
+    if (!(fc.evStatic && S.lvl0NonNeg)) return 0;  // generic (it re-reads everything from HBM; pending commits are flushed on the way)
+    f.evDone = f.headPos + 1;  // served; its commit is deferred (applyEvictedRange)
+    return fastAdvance(d, k, S, fc, q, f, ko) ? 1 : 2;
+  }
+  if (!f.headFast) { fastLoadHead(k, q, job, f); FL.hot[q].headFast = 1; FL.hot[q].headKind = f.headKind; FL.hot[q].headIdx = f.headIdx; FL.hot[q].headPos = f.headPos; }
   JobTail r = FL.headTail[q];
   uniJobTail(r);
   bool ev = f.headKind == 0;
@@ -606,6 +671,8 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
     // (bucket arithmetic, DESIGN.md "Evicted jobs always return")
     if (!fc.evStatic || !S.lvl0NonNeg) return 0;
     prio = r.runPrio; n = r.node0;
+    if (f.evApplied < f.evDone) { applyEvictedRange(d, k, q, f.evApplied, f.evDone); S.numEvictedJobs -= f.evDone - f.evApplied; }
+    f.evApplied = f.evDone = f.headPos + 1;  // committed right here
   }
   SEG(2);
   // ---- commit: sctx.AddGangSchedulingContext (scheduling.go:391-434)
@@ -640,12 +707,14 @@ DEV int fastReplayStep(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, int
   QHot f = FL.hot[q];
   uniQHot(f);
   int job = f.gctx, i = *counter;
+  bool cheap = f.headFast && f.headKind == 2;
   if (!f.headFast) fastLoadHead(k, q, job, f);
   if (FLANE == 0) { k.evTabJob[i] = job; k.evTabAlive[i] = 1; k.evIndexOfJob[job] = i; }
   if (i + 1 > S.evictedTableSize) S.evictedTableSize = i + 1;
   *counter = i + 1;
   SEG(1);
-  accountVectors(d, k, q, 0, true, true);
+  if (f.headPos >= 0) f.evApplied = f.evDone = f.headPos + 1;  // nothing is deferred in the replay: it only assigns evicted-table indices
+  if (!cheap) accountVectors(d, k, q, 0, true, true);
   S.statFastReplay++;
   SEG(3);
   return fastAdvance(d, k, S, fc, q, f, ko) ? 1 : 2;

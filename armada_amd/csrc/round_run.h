@@ -8,7 +8,7 @@
 enum BulkKind {
   B_RESET_GANGSEEN = 1, B_FILTER1, B_NODE_OVER, B_FILTER3, B_GANG_CLOSURE, B_EVICT_APPLY1, B_EVICT_APPLY3, B_KEYS_ALL,
   B_UNBIND, B_RESET_EVTAB, B_CLEAR_UNFEASIBLE, B_INIT_ALLOC, B_POPULATE, B_RESET_JOBS, B_GATHER_SCHED, B_GATHER_PRE,
-  B_EVIDX, B_LVL0,
+  B_EVIDX, B_LVL0, B_EVKEYS, B_EVKEYS_OFF, B_EVKEYS_ON, B_EVSUM,
 };
 
 DEV void wgBulk(Dev& d, int kind, int n);  // every element i in [0,n) through bulkElem(), then a workgroup barrier
@@ -103,6 +103,52 @@ DEV void bulkElem(Dev& d, int kind, int i) {
     case B_GATHER_PRE: { int j = d.resPreJob[i]; d.resPreNode[i] = d.preemptedNode[j]; } break;
     case B_CLEAR_UNFEASIBLE: d.unfeasible[i] = 0; break;
     case B_EVIDX: if (d.evIdxByPos) d.evIdxByPos[i] = d.evIndexOfJob[d.evList[i]]; break;  // evicted-table Index per evicted-list position (fast path)
+    case B_EVKEYS_OFF: d.evCheap[i] = 0; break;
+    case B_EVKEYS_ON: d.evCheap[i] = 1; break;
+    // Queue-order costs of every evicted job, in eviction-list order (pqs.go:589-639 replays exactly these; pass 1 re-reads
+    // them).  The list is ordered by queue; thread i owns positions [i*C, (i+1)*C): pass A sums the requests of its range per
+    // queue segment and flags gang members, one thread stitches the carries, pass B evaluates the DRF costs.
+    case B_EVSUM: {
+      int n = d.rs->numEvictedList, T = d.evChunks, C = (n + T - 1) / T;
+      int p0 = i * C, p1 = p0 + C < n ? p0 + C : n;
+      int64_t* part = d.evPart + (size_t)i * (2 * MAXR + 4);
+      int64_t head[MAXR], tail[MAXR];
+      for (int r = 0; r < MAXR; r++) head[r] = tail[r] = 0;
+      int q = 0, qFirst = -1, qLast = -1; bool crossed = false;
+      if (p0 < p1) { while (d.evOff[q + 1] <= p0) q++; qFirst = q; }
+      for (int p = p0; p < p1; p++) {
+        while (d.evOff[q + 1] <= p) { q++; crossed = true; for (int r = 0; r < c.R; r++) tail[r] = 0; }
+        int job = d.evList[p];
+        if (d.jGang[job] >= 0) d.evCheap[q] = 0;
+        const int64_t* req = JREQ(d, job);
+        for (int r = 0; r < c.R; r++) { tail[r] += req[r]; if (!crossed) head[r] += req[r]; }
+        qLast = q;
+      }
+      for (int r = 0; r < MAXR; r++) { part[r] = head[r]; part[MAXR + r] = tail[r]; }
+      part[2 * MAXR] = qFirst; part[2 * MAXR + 1] = qLast; part[2 * MAXR + 2] = crossed;
+    } break;
+    case B_EVKEYS: {
+      int n = d.rs->numEvictedList, T = d.evChunks, C = (n + T - 1) / T;
+      int p0 = i * C, p1 = p0 + C < n ? p0 + C : n;
+      if (p0 >= p1) break;
+      const int64_t* carry = d.evPart + (size_t)i * (2 * MAXR + 4) + 0;  // rewritten by the stitch step: carry-in of this range
+      int q = 0;
+      while (d.evOff[q + 1] <= p0) q++;
+      int64_t a[MAXR], with[MAXR];
+      for (int r = 0; r < c.R; r++) a[r] = QV(d.qAlloc, q)[r] + QV(d.qPenalty, q)[r] + carry[r];
+      for (int p = p0; p < p1; p++) {
+        while (d.evOff[q + 1] <= p) { q++; for (int r = 0; r < c.R; r++) a[r] = QV(d.qAlloc, q)[r] + QV(d.qPenalty, q)[r]; }
+        int job = d.evList[p];
+        const int64_t* req = JREQ(d, job);
+        for (int r = 0; r < c.R; r++) with[r] = a[r] + req[r];
+        double w = d.qWeight[q];
+        EvKey e;
+        e.proposed = drf(d, with) / w; e.current = drf(d, a) / w; e.size = drf(d, req) * w;
+        e.pcPrio = c.pcPriority[d.jPc[job]]; e.job = job;
+        d.evKey[p] = e;
+        for (int r = 0; r < c.R; r++) a[r] = with[r];
+      }
+    } break;
     case B_LVL0: { bool neg = false; for (int r = 0; r < c.R; r++) neg = neg || AL(d, 0, r, i) < 0; if (neg) d.rs->lvl0NonNeg = 0; } break;
     case B_INIT_ALLOC: {  // fresh NodeDb (scheduling_algo.go:517): AllocatableByPriority[p] = allocatable (node.go:79-85)
       for (int l = 0; l < c.P; l++) for (int r = 0; r < c.R; r++)
@@ -176,6 +222,27 @@ DEV int pqsEvict(Dev& d, Ctl& c, bool phase3) {
   wgBulk(d, B_RESET_EVTAB, d.rs->evictedTableSize);  // nodeDb.Reset() (nodedb.go:299-313)
   d.rs->evictedTableSize = 0;
   wgBulk(d, B_RESET_GANGSEEN, d.cfg.G);
+  if (d.evCheap) {
+    if (!phase3 && fastOn(d, c) && n > 0) {
+      wgBulk(d, B_EVKEYS_ON, d.cfg.Q);
+      wgBulk(d, B_EVSUM, d.evChunks);
+      // stitch: carry-in of range i = requests of the same queue summed over the ranges before it (sequential over evChunks entries)
+      int64_t run[MAXR]; int runQ = -1;
+      for (int r = 0; r < MAXR; r++) run[r] = 0;
+      for (int i = 0; i < d.evChunks; i++) {
+        int64_t* part = d.evPart + (size_t)i * (2 * MAXR + 4);
+        int qFirst = (int)part[2 * MAXR], qLast = (int)part[2 * MAXR + 1]; bool crossed = part[2 * MAXR + 2] != 0;
+        int64_t carry[MAXR];
+        for (int r = 0; r < MAXR; r++) carry[r] = (qFirst >= 0 && qFirst == runQ) ? run[r] : 0;
+        if (qFirst >= 0) {
+          if (!crossed) { for (int r = 0; r < MAXR; r++) run[r] = carry[r] + part[r]; runQ = qFirst; }   // whole range in one queue
+          else { for (int r = 0; r < MAXR; r++) run[r] = part[MAXR + r]; runQ = qLast; }
+        }
+        for (int r = 0; r < MAXR; r++) part[r] = carry[r];
+      }
+      wgBulk(d, B_EVKEYS, d.evChunks);
+    } else wgBulk(d, B_EVKEYS_OFF, d.cfg.Q);
+  }
   long long t1 = CLK();
   replayEvicted(d, c);  // addEvictedJobsToNodeDb
   wgBulk(d, B_EVIDX, n);
@@ -282,6 +349,7 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
     case CMD_QUEUES_ONLY: {
       // no evicted jobs: empty per-queue evicted segments
       for (int q = 0; q <= cf.Q; q++) d.evOff[q] = 0;
+      if (d.evCheap) wgBulk(d, B_EVKEYS_OFF, cf.Q);
       c.fastEvStatic = 1;
       d.rs->lvl0NonNeg = 1;
       wgBulk(d, B_LVL0, cf.N);
