@@ -224,34 +224,42 @@ __device__ static inline void fastFence(Ctl& c) {
   if (c.l1Dirty) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); c.l1Dirty = 0; }  // vmcnt(0) + L1 invalidate: the no-return atomics are now what plain loads see
 }
 
-// 64 base positions per step, coalesced (keys, removed flags, extras, class bits all stored in base order)
+// 64 base positions per step, coalesced (keys, removed flags, extras, class bits all stored in base order).  The tile read
+// last stays in registers (FastS::t*): the rescans that follow a bind start at the removed position, i.e. inside it.
+__device__ static inline void baseTileLoad(KREF k, FastS& S, int p0) {
+  int lane = threadIdx.x & 63;
+  int p = p0 + lane;
+  S.tP0 = p0; S.tKey = 0; S.tCls = 0; S.tNode = -1; S.tRem = 1; S.tEx0 = 0; S.tEx1 = 0;
+  if (p < k.N) {
+    S.tKey = k.baseKey[p]; S.tCls = k.baseCls[p]; S.tNode = k.baseNode[p]; S.tRem = k.baseRemoved[p];
+    if (k.E > 0) S.tEx0 = k.baseExtra[p];
+    if (k.E > 1) S.tEx1 = k.baseExtra[k.Npad + p];
+  }
+}
+__device__ static inline void baseTileRemoved(KREF k, FastS& S, int pos) {
+  int lane = threadIdx.x & 63;
+  if (S.tP0 >= 0 && pos >= S.tP0 && pos < S.tP0 + 64) { if (lane == pos - S.tP0) S.tRem = 1; }
+  else baseTileLoad(k, S, pos);  // issued now, consumed by the next scan: the HBM latency overlaps the rest of the iteration
+}
 __device__ static inline void baseScan(KREF k, FastS& S, const JobTail& r) {
   int lane = threadIdx.x & 63;
   int s = r.shape;
-  int p0 = g_fl.cand[s].pos;
-  int N = k.N; size_t Npad = k.Npad; int E = k.E;
+  int p0 = UNI32(g_fl.cand[s].pos);
+  int N = k.N;
   for (;;) {
     if (p0 >= N) { g_fl.cand[s].pos = N; g_fl.cand[s].node = -1; return; }
-    int p = p0 + lane;
-    bool ok = false;
-    unsigned long long key = 0, cls = 0; long long ex0 = 0, ex1 = 0; int node = -1;
-    if (p < N) {
-      key = k.baseKey[p]; cls = k.baseCls[p]; node = k.baseNode[p];
-      uint8_t rem = k.baseRemoved[p];
-      if (E > 0) ex0 = k.baseExtra[p];
-      if (E > 1) ex1 = k.baseExtra[Npad + p];
-      ok = !rem && entryFits(k, r, key, ex0, ex1, cls);
-    }
+    if (!(S.tP0 >= 0 && p0 >= S.tP0 && p0 < S.tP0 + 64)) baseTileLoad(k, S, p0);
+    bool ok = S.tP0 + lane >= p0 && !S.tRem && entryFits(k, r, S.tKey, S.tEx0, S.tEx1, S.tCls);
     unsigned long long b = __ballot(ok);
     S.statScanSteps++;
     if (b) {
       int f = __ffsll((long long)b) - 1;
       CandRec c;
-      c.pos = p0 + f; c.node = __shfl(node, f, 64); c.key = __shfl(key, f, 64); c.cls = __shfl(cls, f, 64); c.ex0 = __shfl(ex0, f, 64); c.ex1 = __shfl(ex1, f, 64); c.pad = 0;
+      c.pos = S.tP0 + f; c.node = __shfl(S.tNode, f, 64); c.key = __shfl(S.tKey, f, 64); c.cls = __shfl(S.tCls, f, 64); c.ex0 = __shfl(S.tEx0, f, 64); c.ex1 = __shfl(S.tEx1, f, 64); c.pad = 0;
       g_fl.cand[s] = c;
       return;
     }
-    p0 += 64;
+    p0 = S.tP0 + 64;
   }
 }
 
@@ -299,13 +307,18 @@ __device__ static inline void headFromWindow(int q, int w) {
 }
 
 // markAllocatable (node.go:539-549) for levels [lo, nl) as no-return HBM atomics, one (level, resource) per lane
-__device__ static inline void bindUpdate(KREF k, int n, int lo, int nl, int q, uint64_t keyDelta) {
+__device__ static inline void bindUpdate(KREF k, FastS& S, int n, int lo, int nl, int q, uint64_t keyDelta) {
   int lane = threadIdx.x & 63;
-  int R = k.R, cnt = (nl - lo) * R;
-  for (int i = lane; i < cnt; i += 64) {
-    int l = lo + i / R, x = i % R;
+  int l = lo + S.laneL;
+  if (l < nl) {  // (nl - lo) * R <= 64 lanes whenever P * R <= 64; larger configurations take the second round below
+    int64_t v = g_fl.headReq[q][S.laneX];
+    if (v) __hip_atomic_fetch_add(&KAL(k, l, S.laneX, n), -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  int R = k.R;
+  for (int i = lane + 64; i < (nl - lo) * R; i += 64) {
+    int l2 = lo + i / R, x = i % R;
     int64_t v = g_fl.headReq[q][x];
-    if (v) __hip_atomic_fetch_add(&KAL(k, l, x, n), -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v) __hip_atomic_fetch_add(&KAL(k, l2, x, n), -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (lane < nl - lo && keyDelta) __hip_atomic_fetch_add(&KKEY(k, lo + lane, n), 0ull - keyDelta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -338,6 +351,7 @@ __device__ static inline void applyEvictedRange(Dev& d, KREF k, int q, int p0, i
   (void)d;
   int lane = threadIdx.x & 63;
   int R = k.R;
+  int pending = g_rs.replayPending;
   for (int p = p0 + lane; p < p1; p += 64) {
     int job = k.evList[p];
     GP(unsigned long long) rec = k.jrec + (size_t)job * (sizeof(JobRec) / 8);
@@ -360,7 +374,7 @@ __device__ static inline void applyEvictedRange(Dev& d, KREF k, int q, int p0, i
     k.jcReason[job] = 0; k.jcHasPctx[job] = 1; k.pcNode[job] = n; k.pcSap[job] = prio;
     k.jobNode[job] = n; k.jobCutoff[job] = cutoff; k.jobEvictedOnNode[job] = 0; k.schedAtPrio[job] = prio; k.inSchedAndEvicted[job] = 0;
     k.pcPap[job] = prio; k.pcMethod[job] = ASCHED_METHOD_RESCHEDULED; k.jobFlags[job] = F_RESCHEDULED; k.inPreempted[job] = 0;
-    k.evTabAlive[k.evIdxByPos[p]] = 0; k.evIndexOfJob[job] = -1;
+    if (!pending) { k.evTabAlive[k.evIdxByPos[p]] = 0; k.evIndexOfJob[job] = -1; }
   }
 }
 __device__ static inline bool roundLimitExceeded(Dev& d, KREF k) {

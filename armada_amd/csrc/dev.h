@@ -95,10 +95,18 @@ struct RoundScalars {
   int32_t lvl0NonNeg;        // no node has a negative level-0 (priority -2) allocatable column
   int32_t l0SaveCount;       // L0 entries saved to HBM between launches
   int32_t fastOverflow;      // L0 overflowed: structure dropped for the rest of the round
+  int32_t replayPending;     // the eviction-order replay (evicted-table Index assignment) has been deferred: nothing has read it yet
   int32_t statFastIters, statGenericIters, statScanSteps, statRefills, statL0Max, statFastReplay;
   int32_t pad;
   int64_t statSeg[8];        // (profiling builds) shader-clock ticks per segment of a fast iteration
   int64_t statClk[8];        // shader-clock ticks per phase of the round (device builds): evict, replay, pass 1, oversub evict, pass 2, unbind+results
+};
+
+// the per-queue iterator / heap arrays a QueueScheduler-style loop owns; a second set lets the eviction-order replay run
+// in the middle of a scheduling pass without disturbing it (lazy replay, round_run.h ensureReplay)
+struct QueueLoopArrays {
+  int32_t *itEi, *itQi, *itStage, *itJobsSeen, *itNext, *itStashed; uint8_t *itJobOnlyEv, *itGangOnlyEv, *onlyEvByQueue;
+  double *pqProposed, *pqCurrent, *pqBudget, *pqSize; int32_t *pqPcPrio, *pqSchedPrio, *pqGctx; uint8_t* pqInHeap;
 };
 
 struct Dev {
@@ -190,4 +198,6 @@ struct Dev {
   int32_t* l0Save;       // [L0CAP]
   int32_t* candPosSave;  // [SMAX]
   const struct FastK* fk; // the fast loop's constants (round_fast.h), filled by the host at round_prepare
+  QueueLoopArrays alt;    // second set for the lazy replay
+  int64_t* qAllocSnap;    // [Q][R] queue allocations right after an evictor ran: what addEvictedJobsToNodeDb starts from
 };

@@ -51,7 +51,8 @@ DEV void fastItemKeys(Dev& d, const Ctl& c, int q);
 DEV void fastHeadInvalidate(int q);
 DEV void fastPassReset();
 DEV bool fastOn(Dev& d, const Ctl& c);
-DEV void fastEnterGeneric(Dev& d, Ctl& c);         // leave fast mode: LDS queue state back into the generic arrays, HBM updates visible
+DEV void fastEnterGeneric(Dev& d, Ctl& c);
+DEV void ensureReplay(Dev& d, Ctl& c);             // run the deferred eviction-order replay before anything reads the evicted table         // leave fast mode: LDS queue state back into the generic arrays, HBM updates visible
 
 // ------------------------------------------------------------------------------------------------
 #define AL(d, l, r, n) ((d).alloc[((size_t)(l) * (d).cfg.R + (r)) * (d).cfg.Npad + (n)])
@@ -341,6 +342,7 @@ DEV int selectAtLevel(Dev& d, int job, int32_t prio) {
 
 // selectNodeForJobWithFairPreemption (nodedb.go:935-1043), literal: evicted jobs by descending Index.
 DEV int selectWithFairPreemption(Dev& d, Ctl& c, int job) {
+  ensureReplay(d, c);
   const DevCfg& cf = d.cfg;
   c.fairStamp++;
   int stamp = c.fairStamp;
@@ -442,6 +444,7 @@ DEV int selectNodeForJob(Dev& d, Ctl& c, int job) {
 
 // preemptSiblingGangJobs (nodedb.go:468-525)
 DEV void preemptSiblings(Dev& d, Ctl& c, int firstPre, int lastPre) {
+  if (firstPre < lastPre) ensureReplay(d, c);
   for (int i = firstPre; i < lastPre; i++) {
     int job = c.preList[i];
     int g = d.jGang[job];
@@ -812,7 +815,7 @@ DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff)
 // addEvictedJobsToNodeDb (preempting_queue_scheduler.go:589-639): replay the DRF order over the evicted gangs
 DEV void replayEvicted(Dev& d, Ctl& c) {
   int Q = d.cfg.Q;
-  for (int q = 0; q < Q; q++) for (int r = 0; r < d.cfg.R; r++) QV(d.replayAlloc, q)[r] = QV(d.qAlloc, q)[r];
+  for (int q = 0; q < Q; q++) for (int r = 0; r < d.cfg.R; r++) QV(d.replayAlloc, q)[r] = QV(d.qAllocSnap, q)[r];  // allocations as the evictor left them
   int savedCmp = c.compareSchedPrio;
   c.compareSchedPrio = 0; c.useReplayAlloc = 1;
   PassCfg pc{false, 0, false};

@@ -118,7 +118,7 @@ template <class T> __device__ static inline T uniT64(T v) { return (T)uni64((uns
 
 #ifdef ASCHED_FASTPROF
 #define SEG_BEGIN() S.segT = CLK()
-#define SEG(i) do { long long _n = CLK(); if (FLANE == 0) RS.statSeg[i] += _n - S.segT; S.segT = _n; } while (0)
+#define SEG(i) do { long long _n = CLK(); if (FLANE == 0 && fc.replay) RS.statSeg[i] += _n - S.segT; S.segT = _n; } while (0)
 #else
 #define SEG_BEGIN() do {} while (0)
 #define SEG(i) do {} while (0)
@@ -162,9 +162,13 @@ struct FastK {
 struct FastS {
   double globalTokens; int64_t globalBurst; int32_t globalRateInf;
   int32_t numScheduledJobs, numScheduledGangs, numEvictedJobs, numNodeQueries, loopIterations, evictedTableSize;
-  int32_t numUnfeasible, numPreemptedMarks, fastActive, lvl0NonNeg;
+  int32_t numUnfeasible, numPreemptedMarks, fastActive, lvl0NonNeg, replayPending;
   int32_t statFastIters, statScanSteps, statRefills, statL0Max, statFastReplay;
   long long segT;
+  // device only: the last base tile read (64 consecutive entries, one per lane), kept in registers; a removal inside it is
+  // patched in place, a removal outside re-targets it, so the rescans that follow a bind find their entries without a load
+  int tP0; int tNode, tRem; unsigned long long tKey, tCls; long long tEx0, tEx1;
+  int laneL, laneX;  // device only: this lane's (level offset, resource) in a bind: lane = laneL * R + laneX
 };
 
 // The loop's constants are built once per round_prepare on the host (every value is a config field or a device pointer the
@@ -302,6 +306,7 @@ DEV void drf3(Dev& d, int q, int k, bool replay, double w, double* proposed, dou
   *proposed = drf(d, with) / w; *current = drf(d, alloc) / w; *size = drf(d, req) * w;
 }
 DEV void fastFence(Ctl&) {}
+DEV void baseTileRemoved(KREF, FastS&, int) {}
 // advance the base cursor of shape r.shape to the next clean entry the job fits on
 DEV void baseScan(KREF k, FastS& S, const JobTail& r) {
   int s = r.shape;
@@ -338,7 +343,7 @@ DEV void loadHeadRec(KREF k, int q, int job) {
 }
 DEV void headFromWindow(int q, int w) { memcpy(FL.headReq[q], FL.winRec[q][w].req, sizeof(int64_t) * MAXR); memcpy(&FL.headTail[q], &FL.winRec[q][w].keyDelta, sizeof(JobTail)); }
 // alloc[l][r][n] -= req[r], keys[l][n] -= keyDelta for levels l in [lo, nl)  (markAllocatable, node.go:539-549); req = head of queue q
-DEV void bindUpdate(KREF k, int n, int lo, int nl, int q, uint64_t keyDelta) {
+DEV void bindUpdate(KREF k, FastS&, int n, int lo, int nl, int q, uint64_t keyDelta) {
   for (int l = lo; l < nl; l++) { for (int x = 0; x < k.R; x++) KAL(k, l, x, n) -= FL.headReq[q][x]; KKEY(k, l, n) -= keyDelta; }
 }
 // sctx / qctx resource vectors (context/scheduling.go:410-434, context/queue.go:231-265) for the head job of queue q:
@@ -374,7 +379,7 @@ DEV void applyEvictedRange(Dev& d, KREF k, int q, int p0, int p1) {
     k.jcReason[job] = 0; k.jcHasPctx[job] = 1; k.pcNode[job] = n; k.pcSap[job] = prio;
     k.jobNode[job] = n; k.jobCutoff[job] = cutoff; k.jobEvictedOnNode[job] = 0; k.schedAtPrio[job] = prio; k.inSchedAndEvicted[job] = 0;
     k.pcPap[job] = prio; k.pcMethod[job] = ASCHED_METHOD_RESCHEDULED; k.jobFlags[job] = F_RESCHEDULED; k.inPreempted[job] = 0;
-    k.evTabAlive[k.evIdxByPos[p]] = 0; k.evIndexOfJob[job] = -1;
+    if (!RS.replayPending) { k.evTabAlive[k.evIdxByPos[p]] = 0; k.evIndexOfJob[job] = -1; }
   }
 }
 DEV bool roundLimitExceeded(Dev& d, KREF k) { for (int x = 0; x < k.R; x++) if (RS.scheduled[x] > d.cfg.maxToSchedule[x]) return true; return false; }  // constraints.go:113-119
@@ -387,11 +392,12 @@ DEV void pqPopPush(PQState& s, const KeyOut& ko, int q);
 DEV void drf3(Dev& d, int q, int k, bool replay, double w, double* proposed, double* current, double* size);
 DEV void fastFence(Ctl& c);
 DEV void baseScan(KREF k, FastS& S, const JobTail& r);
+DEV void baseTileRemoved(KREF k, FastS& S, int pos);
 DEV uint64_t l0Search(KREF k, const JobTail& r, int* slot);
 DEV void winRefill(KREF k, int q, int kind, int pos, int cnt);
 DEV void loadHeadRec(KREF k, int q, int job);
 DEV void headFromWindow(int q, int w);
-DEV void bindUpdate(KREF k, int n, int lo, int nl, int q, uint64_t keyDelta);
+DEV void bindUpdate(KREF k, FastS& S, int n, int lo, int nl, int q, uint64_t keyDelta);
 DEV void accountVectors(Dev& d, KREF k, int q, int pc, bool ev, bool replay);
 DEV void evWinRefill(KREF k, int q, int pos, int cnt);
 DEV void applyEvictedRange(Dev& d, KREF k, int q, int p0, int p1);
@@ -473,7 +479,7 @@ DEV int fastFirstFit(KREF k, FastS& S, const JobTail& r, FitHandle* h, CandRec* 
 DEV int fastSelectLevel0(Dev& d, int job) {
   if (!d.f.structOk || !RS.fastActive) return -2;
   const FastK k = fastKRef(d);
-  FastS S; S.statScanSteps = 0;
+  FastS S; S.statScanSteps = 0; S.tP0 = -1;
   JobRec jr = d.jrec[job];
   JobTail r; memcpy(&r, &jr.keyDelta, sizeof r);
   FitHandle h; CandRec c;
@@ -488,6 +494,7 @@ DEV bool fastAfterBind(KREF k, FastS& S, const JobTail& r, int n, const FitHandl
     uint64_t key = c.key - r.keyDelta;
     int64_t ex0 = c.ex0 - r.ex0, ex1 = c.ex1 - r.ex1;
     if (FLANE == 0) k.baseRemoved[c.pos] = 1;
+    baseTileRemoved(k, S, c.pos);
     candInvalidate(k.S, n);
     if (entryLive(k, key, ex0, ex1)) {
       if (!l0Insert(k, n, key, ex0, ex1, c.cls)) return false;
@@ -555,6 +562,7 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
         f.ewStart = pos; f.ewCount = cnt;
         S.statRefills++;
       }
+      SEG(2);
       EvKey e = FL.evWin[q][pos - f.ewStart];
       e.proposed = UNID(e.proposed); e.current = UNID(e.current); e.size = UNID(e.size); e.pcPrio = UNI32(e.pcPrio); e.job = UNI32(e.job);
       f.itEi = pos + 1;
@@ -562,6 +570,7 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
       f.proposed = e.proposed; f.current = e.current; f.size = e.size; f.pcPrio = e.pcPrio; f.schedPrio = e.pcPrio;
       *ko = packItemKeys(fc.preferLarge, q, e.pcPrio, e.proposed, e.current, e.size, f.budget);
       haveHead = true;
+      SEG(3);
       break;
     }
     int w = 0;
@@ -580,10 +589,8 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
     if (kind == 0) f.itEi = pos + 1;
     else {
       f.itQi = pos + 1; f.itJobsSeen++;
-      if (FLANE == 0) {  // JobSchedulingContextFromJob (context/job.go:149-158)
-        k.jcEvicted[job] = 0; k.jcAssigned[job] = -1; k.jcReason[job] = 0; k.jcHasPctx[job] = 0;
-        k.jcGangCard[job] = 1; k.jcUniValue[job] = -1; k.jcStagedBy[job] = -1;
-      }
+      // JobSchedulingContextFromJob (context/job.go:149-158): a queued non-gang job still has exactly the jctx that
+      // round_prepare's reset gave it (fast iterations are off once a NodeDb-level call touched per-job state): nothing to store
     }
     if (fc.skipKnown && S.numUnfeasible > 0 && kind == 1 && k.unfeasible[shape]) {  // queue_scheduler.go:398-413
       if (FLANE == 0) {
@@ -642,6 +649,7 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
   uniQHot(f);
   int job = f.gctx;
   if (f.headFast && f.headKind == 2) {  // evicted job with precomputed costs
+    SEG(1);
     if (!(fc.evStatic && S.lvl0NonNeg)) return 0;  // generic (it re-reads everything from HBM; pending commits are flushed on the way)
     f.evDone = f.headPos + 1;  // served; its commit is deferred (applyEvictedRange)
     return fastAdvance(d, k, S, fc, q, f, ko) ? 1 : 2;
@@ -681,14 +689,15 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
   // ---- SelectNodeForJobWithTxn result + BindJobToNode (nodedb.go:538-630, 1046-1068)
   int32_t cutoff = r.preemptible ? prio : NONPREEMPTIBLE_CUTOFF;
   int nl = ev ? r.nlRun : r.nlPc;
-  bindUpdate(k, n, ev ? 1 : 0, nl, q, r.keyDelta);  // evicted job: level -2 gets -req (bind) and +req (un-evict): unchanged (node.go:416-442)
+  bindUpdate(k, S, n, ev ? 1 : 0, nl, q, r.keyDelta);  // evicted job: level -2 gets -req (bind) and +req (un-evict): unchanged (node.go:416-442)
   if (FLANE == 0) {
-    k.jcReason[job] = 0; k.jcHasPctx[job] = 1; k.pcNode[job] = n; k.pcSap[job] = prio;
-    k.jobNode[job] = n; k.jobCutoff[job] = cutoff; k.jobEvictedOnNode[job] = 0; k.schedAtPrio[job] = prio; k.inSchedAndEvicted[job] = 0;
+    k.jcHasPctx[job] = 1; k.pcNode[job] = n; k.pcSap[job] = prio;
+    k.jobNode[job] = n; k.jobCutoff[job] = cutoff; k.schedAtPrio[job] = prio;
     if (ev) {
+      k.jcReason[job] = 0; k.jobEvictedOnNode[job] = 0; k.inSchedAndEvicted[job] = 0;
       k.pcPap[job] = prio; k.pcMethod[job] = ASCHED_METHOD_RESCHEDULED; k.jobFlags[job] = F_RESCHEDULED; k.inPreempted[job] = 0;
-      k.evTabAlive[f.headIdx] = 0; k.evIndexOfJob[job] = -1;  // nodedb.go:441-446
-    } else {
+      if (!S.replayPending) { k.evTabAlive[f.headIdx] = 0; k.evIndexOfJob[job] = -1; }  // nodedb.go:441-446 (a deferred replay marks it dead itself)
+    } else {  // jcReason, jobEvictedOnNode, inSchedAndEvicted are still 0 for a queued job
       k.pcPap[job] = ASCHED_EVICTED_PRIORITY; k.pcMethod[job] = ASCHED_METHOD_NO_PREEMPTION; k.jobFlags[job] = F_SUCCESSFUL; k.inScheduled[job] = 1;
     }
   }
@@ -716,7 +725,7 @@ DEV int fastReplayStep(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, int
   if (f.headPos >= 0) f.evApplied = f.evDone = f.headPos + 1;  // nothing is deferred in the replay: it only assigns evicted-table indices
   if (!cheap) accountVectors(d, k, q, 0, true, true);
   S.statFastReplay++;
-  SEG(3);
+  SEG(4);
   return fastAdvance(d, k, S, fc, q, f, ko) ? 1 : 2;
 }
 
@@ -730,10 +739,12 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   c.l1Dirty = 1;
   const FastK k = fastKRef(d);
   FastS S;
+  S.tP0 = -1;
+  S.laneL = FLANE / (d.cfg.R > 0 ? d.cfg.R : 1); S.laneX = FLANE % (d.cfg.R > 0 ? d.cfg.R : 1);
   S.globalTokens = UNID(RS.globalTokens); S.globalBurst = UNI64(RS.globalBurst); S.globalRateInf = UNI32(RS.globalRateInf);
   S.numScheduledJobs = UNI32(RS.numScheduledJobs); S.numScheduledGangs = UNI32(RS.numScheduledGangs); S.numEvictedJobs = UNI32(RS.numEvictedJobs);
   S.numNodeQueries = UNI32(RS.numNodeQueries); S.loopIterations = UNI32(RS.loopIterations); S.evictedTableSize = UNI32(RS.evictedTableSize);
-  S.numUnfeasible = UNI32(RS.numUnfeasible); S.numPreemptedMarks = UNI32(RS.numPreemptedMarks); S.fastActive = UNI32(RS.fastActive); S.lvl0NonNeg = UNI32(RS.lvl0NonNeg);
+  S.numUnfeasible = UNI32(RS.numUnfeasible); S.numPreemptedMarks = UNI32(RS.numPreemptedMarks); S.fastActive = UNI32(RS.fastActive); S.lvl0NonNeg = UNI32(RS.lvl0NonNeg); S.replayPending = UNI32(RS.replayPending);
   S.statFastIters = UNI32(RS.statFastIters); S.statScanSteps = UNI32(RS.statScanSteps); S.statRefills = UNI32(RS.statRefills); S.statL0Max = UNI32(RS.statL0Max); S.statFastReplay = UNI32(RS.statFastReplay);
   int Q = UNI32(d.cfg.Q);
   fc.withQueued = UNI32(fc.withQueued); fc.maxLookback = UNI32(fc.maxLookback); fc.skipKnown = UNI32(fc.skipKnown); fc.compareSchedPrio = UNI32(fc.compareSchedPrio);

@@ -8,7 +8,7 @@
 enum BulkKind {
   B_RESET_GANGSEEN = 1, B_FILTER1, B_NODE_OVER, B_FILTER3, B_GANG_CLOSURE, B_EVICT_APPLY1, B_EVICT_APPLY3, B_KEYS_ALL,
   B_UNBIND, B_RESET_EVTAB, B_CLEAR_UNFEASIBLE, B_INIT_ALLOC, B_POPULATE, B_RESET_JOBS, B_GATHER_SCHED, B_GATHER_PRE,
-  B_EVIDX, B_LVL0, B_EVKEYS, B_EVKEYS_OFF, B_EVKEYS_ON, B_EVSUM,
+  B_EVIDX, B_LVL0, B_EVKEYS, B_EVKEYS_OFF, B_EVKEYS_ON, B_EVSUM, B_SNAP, B_EVALIVE,
 };
 
 DEV void wgBulk(Dev& d, int kind, int n);  // every element i in [0,n) through bulkElem(), then a workgroup barrier
@@ -103,6 +103,13 @@ DEV void bulkElem(Dev& d, int kind, int i) {
     case B_GATHER_PRE: { int j = d.resPreJob[i]; d.resPreNode[i] = d.preemptedNode[j]; } break;
     case B_CLEAR_UNFEASIBLE: d.unfeasible[i] = 0; break;
     case B_EVIDX: if (d.evIdxByPos) d.evIdxByPos[i] = d.evIndexOfJob[d.evList[i]]; break;  // evicted-table Index per evicted-list position (fast path)
+    case B_SNAP: d.qAllocSnap[i] = d.qAlloc[i]; break;
+    case B_EVALIVE: {  // a table entry of the deferred replay is alive iff its job is still evicted on its node (not rescheduled, not preempted since)
+      int j = d.evTabJob[i];
+      bool alive = d.jobEvictedOnNode[j] != 0;
+      d.evTabAlive[i] = alive;
+      if (!alive) d.evIndexOfJob[j] = -1;
+    } break;
     case B_EVKEYS_OFF: d.evCheap[i] = 0; break;
     case B_EVKEYS_ON: d.evCheap[i] = 1; break;
     // Queue-order costs of every evicted job, in eviction-list order (pqs.go:589-639 replays exactly these; pass 1 re-reads
@@ -222,6 +229,9 @@ DEV int pqsEvict(Dev& d, Ctl& c, bool phase3) {
   wgBulk(d, B_RESET_EVTAB, d.rs->evictedTableSize);  // nodeDb.Reset() (nodedb.go:299-313)
   d.rs->evictedTableSize = 0;
   wgBulk(d, B_RESET_GANGSEEN, d.cfg.G);
+  d.rs->replayPending = 0;
+  wgBulk(d, B_SNAP, d.cfg.Q * d.cfg.R);
+  bool lazy = false;
   if (d.evCheap) {
     if (!phase3 && fastOn(d, c) && n > 0) {
       wgBulk(d, B_EVKEYS_ON, d.cfg.Q);
@@ -241,11 +251,13 @@ DEV int pqsEvict(Dev& d, Ctl& c, bool phase3) {
         for (int r = 0; r < MAXR; r++) part[r] = carry[r];
       }
       wgBulk(d, B_EVKEYS, d.evChunks);
+      lazy = true;  // every queue's evicted stream is gang-free: the replay is a pure merge of precomputed costs and can wait
+      for (int q = 0; q < d.cfg.Q; q++) if (!d.evCheap[q]) lazy = false;
     } else wgBulk(d, B_EVKEYS_OFF, d.cfg.Q);
   }
   long long t1 = CLK();
-  replayEvicted(d, c);  // addEvictedJobsToNodeDb
-  wgBulk(d, B_EVIDX, n);
+  if (lazy) d.rs->replayPending = 1;  // the evicted-table Index is only read by fair-share preemption (nodedb.go:935-1043): assign it on first use
+  else { replayEvicted(d, c); wgBulk(d, B_EVIDX, n); }  // addEvictedJobsToNodeDb
   long long t2 = CLK();
   d.rs->statClk[phase3 ? 3 : 0] += t1 - t0; d.rs->statClk[1] += t2 - t1;
   return n;
@@ -259,6 +271,35 @@ DEV void schedulePass(Dev& d, Ctl& c, bool withQueued, bool skipKey, bool cmpPri
   PassCfg pc{withQueued, d.cfg.maxLookback, true};
   passInit(d, c, pc);
   queueSchedule(d, c, pc, d.uniOff);
+}
+
+DEV void swapLoopArrays(Dev& d) {
+  QueueLoopArrays t;
+  t.itEi = d.itEi; t.itQi = d.itQi; t.itStage = d.itStage; t.itJobsSeen = d.itJobsSeen; t.itNext = d.itNext; t.itStashed = d.itStashed;
+  t.itJobOnlyEv = d.itJobOnlyEv; t.itGangOnlyEv = d.itGangOnlyEv; t.onlyEvByQueue = d.onlyEvByQueue;
+  t.pqProposed = d.pqProposed; t.pqCurrent = d.pqCurrent; t.pqBudget = d.pqBudget; t.pqSize = d.pqSize; t.pqPcPrio = d.pqPcPrio; t.pqSchedPrio = d.pqSchedPrio; t.pqGctx = d.pqGctx; t.pqInHeap = d.pqInHeap;
+  d.itEi = d.alt.itEi; d.itQi = d.alt.itQi; d.itStage = d.alt.itStage; d.itJobsSeen = d.alt.itJobsSeen; d.itNext = d.alt.itNext; d.itStashed = d.alt.itStashed;
+  d.itJobOnlyEv = d.alt.itJobOnlyEv; d.itGangOnlyEv = d.alt.itGangOnlyEv; d.onlyEvByQueue = d.alt.onlyEvByQueue;
+  d.pqProposed = d.alt.pqProposed; d.pqCurrent = d.alt.pqCurrent; d.pqBudget = d.alt.pqBudget; d.pqSize = d.alt.pqSize; d.pqPcPrio = d.alt.pqPcPrio; d.pqSchedPrio = d.alt.pqSchedPrio; d.pqGctx = d.alt.pqGctx; d.pqInHeap = d.alt.pqInHeap;
+  d.alt = t;
+}
+// The deferred addEvictedJobsToNodeDb (pqs.go:589-639): its result — the evicted-table Index of every evicted job — is a pure
+// function of the state the evictor left (qAllocSnap, the eviction lists), so it can be computed at first use.  It runs on its
+// own set of iterator / heap arrays; entries of jobs that have been rescheduled or preempted in the meantime come out dead.
+DEV void ensureReplay(Dev& d, Ctl& c) {
+  if (!d.rs->replayPending) return;
+  d.rs->replayPending = 0;
+  fastEnterGeneric(d, c);
+  int sOnly = c.onlyEvicted, sCmp = c.compareSchedPrio, sUse = c.useReplayAlloc, sSkip = c.skipKeyCheck, sEv = c.fastEvStatic;
+  swapLoopArrays(d);
+  replayEvicted(d, c);
+  fastEnterGeneric(d, c);
+  wgBulk(d, B_EVIDX, d.rs->numEvictedList);
+  wgBulk(d, B_EVALIVE, d.rs->evictedTableSize);
+  swapLoopArrays(d);
+  c.onlyEvicted = sOnly; c.compareSchedPrio = sCmp; c.useReplayAlloc = sUse; c.skipKeyCheck = sSkip; c.fastEvStatic = sEv;
+  fastPassReset();
+  for (int q = 0; q < d.cfg.Q; q++) if (d.pqGctx[q] != -1) fastItemKeys(d, c, q);  // the pass's own heads again
 }
 
 // PreemptingQueueScheduler.Schedule (pqs.go:86-289)
