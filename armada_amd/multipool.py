@@ -21,8 +21,11 @@ def pool_seed(base_seed: int, rank: int) -> int:
 def timed_rounds(s, wl, steps: int, warmup: int, barrier: Callable[[], None], sync: Callable[[], None] = lambda: None) -> Tuple[List[float], List[float], object]:
     """`warmup` untimed + `steps` timed rounds of one pool.  round_prepare (input build) is outside the timed region."""
     lat, dev_ms, res = [], [], None
+    timed_rounds.prepare_s = 0.0
     for i in range(warmup + steps):
+        tp = time.perf_counter()
         W.prepare(s, wl)
+        timed_rounds.prepare_s += time.perf_counter() - tp
         barrier()
         t0 = time.perf_counter()
         res = s.schedule_round()

@@ -68,7 +68,7 @@ def cpu_baseline(wl, budget_s, full_iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nodes", type=int, default=100_000)
     ap.add_argument("--jobs", type=int, default=1_000_000)
@@ -114,8 +114,7 @@ def main():
     from armada_amd import multipool
     tp = time.perf_counter()
     lat, dev_ms, res = multipool.timed_rounds(s, wl, args.steps, args.warmup, barrier, torch.cuda.synchronize)
-    wall = time.perf_counter() - tp
-    prep_s = wall - sum(lat)  # untimed input build (fresh NodeDb + bind running jobs + fair shares + sorted base), incl. warm-up rounds
+    prep_s = multipool.timed_rounds.prepare_s  # untimed input build (fresh NodeDb + bind running jobs + fair shares + sorted base)
 
     def amax(x):
         t = torch.tensor([x], dtype=torch.float64, device="cuda")
@@ -150,6 +149,18 @@ def main():
                      "traffic": None, "kernel": "k_control", "algorithmic_bytes_per_launch": alg,
                      "note": "algorithmic bytes = node_queries_issued x N x (R*8+8) + binds x 256 (SURVEY 8d); kernel ms from HIP events on the launch stream"},
     }
+    # HBM bytes actually moved by one round launch: rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
+    # collected once per round of work on this exact workload and committed under profiles/ (rocprofv3 cannot run inside bench.py)
+    pmc = os.path.join(ROOT, "profiles", "r01d_pmc_hbm_traffic.json")
+    if os.path.exists(pmc) and args.nodes == 100_000 and args.jobs == 1_000_000 and args.queues == 64 and not args.gangs:
+        try:
+            c = json.load(open(pmc))["counters"]
+            fetch = max(x["max_kb"] for x in c["FETCH_SIZE"] if x["kernel"].startswith("k_control"))
+            write = max(x["max_kb"] for x in c["WRITE_SIZE"] if x["kernel"].startswith("k_control"))
+            out["roofline"]["traffic"] = (2 * fetch + write) * 1024
+            out["roofline"]["traffic_source"] = "profiles/r01d_pmc_hbm_traffic.json (2*FETCH_SIZE + WRITE_SIZE of the round launch)"
+        except Exception:
+            pass
     if args.cpu_budget > 0:
         try:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_budget, iters)
