@@ -346,12 +346,24 @@ __device__ static inline void evWinRefill(KREF k, int q, int pos, int cnt) {
   if (lane < cnt * 4) ((unsigned long long*)&g_fl.evWin[q][0])[lane] = k.evKey[(size_t)pos * 4 + lane];
 }
 // Deferred commits of evicted jobs [p0, p1) of queue q returning to their nodes, one job per lane: the evicted branch of
-// fastIter's commit (node.go:416-442 arithmetic, sctx/qctx accounting) as no-return atomics and plain stores.
-__device__ static inline void applyEvictedRange(Dev& d, KREF k, int q, int p0, int p1) {
-  (void)d;
+// fastIter's commit (node.go:416-442 arithmetic, sctx/qctx accounting) as no-return atomics and plain stores.  Node planes are
+// hit at distinct addresses; the per-queue / per-priority-class sums are accumulated per lane and reduced across the wave once,
+// so that 64 lanes do not serialise on one counter.  Not inlined: a cold, register-hungry path next to the hot loop.
+__device__ static inline int64_t waveSum64(int64_t v) {
+  for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+#define APPLY_PCS 4
+__device__ static __attribute__((noinline)) void applyEvictedRange(Dev& d, int q, int p0, int p1, int sign) {
+  const FastK k = fastKRef(d);
   int lane = threadIdx.x & 63;
   int R = k.R;
   int pending = g_rs.replayPending;
+  int64_t accQ[MAXR], accPc[APPLY_PCS][MAXR];
+#pragma unroll
+  for (int x = 0; x < MAXR; x++) { accQ[x] = 0;
+#pragma unroll
+    for (int c = 0; c < APPLY_PCS; c++) accPc[c][x] = 0; }
   for (int p = p0 + lane; p < p1; p += 64) {
     int job = k.evList[p];
     GP(unsigned long long) rec = k.jrec + (size_t)job * (sizeof(JobRec) / 8);
@@ -361,20 +373,49 @@ __device__ static inline void applyEvictedRange(Dev& d, KREF k, int q, int p0, i
     unsigned flags = (unsigned)(w13 >> 32);
     int preemptible = (flags >> 8) & 255, nlRun = (flags >> 24) & 255;
     int32_t cutoff = preemptible ? prio : NONPREEMPTIBLE_CUTOFF;
-    for (int x = 0; x < R; x++) {
-      int64_t v = (int64_t)rec[x];
+#pragma unroll
+    for (int x = 0; x < MAXR; x++) {
+      if (x >= R) break;
+      int64_t v = sign * (int64_t)rec[x];
       if (!v) continue;
-      LDS_ADD64(g_fl.qAlloc[q][x], v); LDS_ADD64(g_rs.allocated[x], v); LDS_ADD64(g_rs.evicted[x], -v);
-      size_t i = ((size_t)q * k.npc + pcx) * R + x;
-      __hip_atomic_fetch_add(&k.qAllocByPc[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(&k.qEvictedByPc[i], -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      accQ[x] += v;
+      if (pcx < APPLY_PCS) {
+#pragma unroll
+        for (int c = 0; c < APPLY_PCS; c++) if (c == pcx) accPc[c][x] += v;
+      } else {
+        size_t i = ((size_t)q * k.npc + pcx) * R + x;
+        __hip_atomic_fetch_add(&k.qAllocByPc[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&k.qEvictedByPc[i], -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       for (int l = 1; l < nlRun; l++) __hip_atomic_fetch_add(&KAL(k, l, x, n), -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (keyDelta) for (int l = 1; l < nlRun; l++) __hip_atomic_fetch_add(&KKEY(k, l, n), 0ull - keyDelta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (keyDelta) for (int l = 1; l < nlRun; l++) __hip_atomic_fetch_add(&KKEY(k, l, n), sign > 0 ? 0ull - keyDelta : keyDelta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sign < 0) {  // taken back: the job is evicted again, exactly as the evictor left it (eviction.go:245-260, evictApply)
+      k.jcHasPctx[job] = 0; k.pcNode[job] = -1; k.pcSap[job] = 0; k.pcPap[job] = ASCHED_MIN_PRIORITY; k.pcMethod[job] = ASCHED_METHOD_NONE;
+      k.jobEvictedOnNode[job] = 1; k.jobFlags[job] = F_EVICTED; k.inPreempted[job] = 1;
+      if (!pending) { int idx = k.evIdxByPos[p]; k.evTabAlive[idx] = 1; k.evIndexOfJob[job] = idx; }
+      continue;
+    }
     k.jcReason[job] = 0; k.jcHasPctx[job] = 1; k.pcNode[job] = n; k.pcSap[job] = prio;
     k.jobNode[job] = n; k.jobCutoff[job] = cutoff; k.jobEvictedOnNode[job] = 0; k.schedAtPrio[job] = prio; k.inSchedAndEvicted[job] = 0;
     k.pcPap[job] = prio; k.pcMethod[job] = ASCHED_METHOD_RESCHEDULED; k.jobFlags[job] = F_RESCHEDULED; k.inPreempted[job] = 0;
     if (!pending) { k.evTabAlive[k.evIdxByPos[p]] = 0; k.evIndexOfJob[job] = -1; }
+  }
+#pragma unroll
+  for (int x = 0; x < MAXR; x++) {
+    if (x >= R) break;
+    int64_t v = waveSum64(accQ[x]);
+    if (lane == 0 && v) { LDS_ADD64(g_fl.qAlloc[q][x], v); LDS_ADD64(g_rs.allocated[x], v); LDS_ADD64(g_rs.evicted[x], -v); }
+#pragma unroll
+    for (int c = 0; c < APPLY_PCS; c++) {
+      if (c >= k.npc) break;
+      int64_t w = waveSum64(accPc[c][x]);
+      if (lane == 0 && w) {
+        size_t i = ((size_t)q * k.npc + c) * R + x;
+        __hip_atomic_fetch_add(&k.qAllocByPc[i], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&k.qEvictedByPc[i], -w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 __device__ static inline bool roundLimitExceeded(Dev& d, KREF k) {

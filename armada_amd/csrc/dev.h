@@ -194,6 +194,8 @@ struct Dev {
   EvKey* evKey;          // [M] per evicted-list position (queues with evCheap)
   uint8_t* evCheap;      // [Q+1] the queue's evicted stream has precomputed keys (no gang members)
   int64_t* evPart;       // [evChunks][2*MAXR+4] partial request sums of the chunked prefix pass (B_EVSUM)
+  uint8_t* evMono;       // [Q+1] the queue's evicted stream has non-decreasing queue-order keys (heap merge == sort by key)
+  uint64_t* evEdge;      // [evChunks][8] first / last packed key of each chunk (monotonicity across chunk borders)
   int32_t evChunks;
   int32_t* l0Save;       // [L0CAP]
   int32_t* candPosSave;  // [SMAX]

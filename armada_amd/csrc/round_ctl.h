@@ -314,7 +314,23 @@ struct Ctl {
   int fastEvStatic;    // evicted jobs of the current pass are phase-1 evictions: node / priority are the job's static run
   int l1Dirty;         // fire-and-forget atomics outstanding: plain loads of alloc/keys need an L1 invalidate first
   int fqLive;          // the LDS copy of the per-queue state (round_fast.h FastQueues) is the authoritative one
+  int skipEnter;       // the next fast run may fold the gang-free evicted streams out of the loop (round_fast.h "skip mode")
+  int skipActive;
 };
+// Less (queue_scheduler.go:738-798) as a lexicographic key (A, X, Y, then the queue-name rank); exact for finite, non-negative costs
+struct PackedKey { uint32_t A; uint64_t X, Y; };
+DEV PackedKey packKey3(int preferLarge, int32_t prio, double proposed, double current, double size, double budget) {
+  PackedKey o;
+  o.A = ~((uint32_t)prio ^ 0x80000000u);  // higher priority first
+  if (preferLarge) {
+    if (proposed <= budget) { o.X = __builtin_bit_cast(uint64_t, current); o.Y = ~__builtin_bit_cast(uint64_t, size); }  // under budget: lower current cost, then larger item
+    else { o.X = __builtin_bit_cast(uint64_t, proposed) | (1ull << 63); o.Y = 0; }                                     // over budget: after every under-budget item, lower proposed cost
+  } else { o.X = __builtin_bit_cast(uint64_t, proposed); o.Y = 0; }
+  return o;
+}
+DEV bool packedLess(const PackedKey& a, uint32_t an, const PackedKey& b, uint32_t bn) {
+  return a.A != b.A ? a.A < b.A : a.X != b.X ? a.X < b.X : a.Y != b.Y ? a.Y < b.Y : an < bn;
+}
 
 DEV const uint64_t* uniMask(Dev& d, int job) { int v = d.jcUniValue[job]; return v >= 0 ? d.labelMask + (size_t)v * d.cfg.W : (const uint64_t*)0; }
 

@@ -38,7 +38,7 @@ struct alignas(16) QHot {
   int32_t headFast, headKind, headIdx;      // head job: record cached in head*, 0 evicted / 1 queued, evicted-table Index
   int32_t winKind, winStart, winCount;      // prefetch window: stream (0 evicted list, 1 queued list) and position range
   int32_t evCheap, evApplied, evDone, ewStart, ewCount, headPos;  // evicted stream with precomputed keys: served up to evDone, commits applied up to evApplied; key window; stream position of an evicted head
-  int32_t pad2[2];
+  int32_t effValid, skipStart;  // skip mode: the queue's evicted stream [skipStart, evEnd) was folded out of the loop; its head key is a running maximum
 };
 struct alignas(16) JobTail {  // second half of a JobRec
   uint64_t keyDelta, fieldMin;
@@ -63,6 +63,7 @@ struct FastLds {
   // queue order: packed keys + heap membership + name rank, one lane per queue
   uint32_t kA[QCAPF]; uint64_t kX[QCAPF]; uint64_t kY[QCAPF]; int32_t inHeap[QCAPF]; int32_t nameRank[QCAPF];
   uint32_t tmpA[64], tmpN[64]; uint64_t tmpX[64], tmpY[64]; int32_t tmpQ[64];  // scatter space of pqBuild
+  uint32_t effA[QCAPF]; uint64_t effX[QCAPF], effY[QCAPF];  // skip mode: running maximum of the queue's keys
 };
 
 #ifdef ASCHED_HOSTSIM
@@ -132,6 +133,7 @@ DEV void uniQHot(QHot& f) {
   f.headFast = UNI32(f.headFast); f.headKind = UNI32(f.headKind); f.headIdx = UNI32(f.headIdx);
   f.winKind = UNI32(f.winKind); f.winStart = UNI32(f.winStart); f.winCount = UNI32(f.winCount);
   f.evCheap = UNI32(f.evCheap); f.evApplied = UNI32(f.evApplied); f.evDone = UNI32(f.evDone); f.ewStart = UNI32(f.ewStart); f.ewCount = UNI32(f.ewCount); f.headPos = UNI32(f.headPos);
+  f.effValid = UNI32(f.effValid); f.skipStart = UNI32(f.skipStart);
 }
 DEV void uniJobTail(JobTail& r) {
   r.keyDelta = UNI64(r.keyDelta); r.fieldMin = UNI64(r.fieldMin);
@@ -228,12 +230,8 @@ DEV void fastPassReset() { for (int q = 0; q < QCAPF; q++) { FL.hot[q].headFast 
 // Less (queue_scheduler.go:738-798) as a lexicographic key (kA, kX, kY, name rank); exact for finite, non-negative costs
 struct KeyOut { int valid; uint32_t A; uint64_t X, Y; };
 DEV KeyOut packItemKeys(int preferLarge, int q, int32_t prio, double proposed, double current, double size, double budget) {
-  KeyOut o; o.valid = 1;
-  o.A = ~((uint32_t)prio ^ 0x80000000u);  // higher priority first
-  if (preferLarge) {
-    if (proposed <= budget) { o.X = dbits(current); o.Y = ~dbits(size); }  // under budget: lower current cost, then larger item
-    else { o.X = dbits(proposed) | (1ull << 63); o.Y = 0; }                 // over budget: after every under-budget item, lower proposed cost
-  } else { o.X = dbits(proposed); o.Y = 0; }
+  PackedKey pk = packKey3(preferLarge, prio, proposed, current, size, budget);
+  KeyOut o; o.valid = 1; o.A = pk.A; o.X = pk.X; o.Y = pk.Y;
   FL.kA[q] = o.A; FL.kX[q] = o.X; FL.kY[q] = o.Y;
   return o;
 }
@@ -256,7 +254,8 @@ DEV void fastQLoad(Dev& d) {
     f.pcPrio = d.pqPcPrio[q]; f.schedPrio = d.pqSchedPrio[q];
     f.rateInf = d.qRateInf[q]; f.cordoned = d.qCordoned[q]; f.itJobOnlyEv = d.itJobOnlyEv[q]; f.itGangOnlyEv = d.itGangOnlyEv[q];
     { int g = f.gctx; bool headEv = g >= 0 && d.jcEvicted[g];  // an evicted head was yielded from evList[itEi-1] and is not served yet
-      f.evCheap = d.evCheap ? d.evCheap[q] : 0; f.evDone = f.evApplied = headEv ? f.itEi - 1 : f.itEi; f.headPos = headEv ? f.itEi - 1 : -1; }
+      f.evCheap = d.evCheap ? d.evCheap[q] : 0; f.evDone = f.evApplied = headEv ? f.itEi - 1 : f.itEi; f.headPos = headEv ? f.itEi - 1 : -1;
+      f.effValid = 0; f.skipStart = 0; }
     FL.inHeap[q] = d.pqInHeap[q]; FL.nameRank[q] = d.qNameRank[q];
   }
 }
@@ -362,20 +361,28 @@ DEV void accountVectors(Dev& d, KREF k, int q, int pc, bool ev, bool replay) {
 DEV void evWinRefill(KREF k, int q, int pos, int cnt) { for (int i = 0; i < cnt; i++) memcpy(&FL.evWin[q][i], (const char*)k.evKey + (size_t)(pos + i) * sizeof(EvKey), sizeof(EvKey)); }
 // Deferred commits of evicted jobs [p0, p1) of queue q's eviction list returning to their nodes: exactly the evicted branch of
 // fastIter's commit, applied to many jobs at once (all updates are integer adds or per-job stores: order independent).
-DEV void applyEvictedRange(Dev& d, KREF k, int q, int p0, int p1) {
+// sign = -1 takes the commits back (skip mode left before these jobs' turn): the jobs are evicted again, exactly as the evictor left them.
+DEV void applyEvictedRange(Dev& d, int q, int p0, int p1, int sign = 1) {
+  const FastK k = fastKRef(d);
   for (int p = p0; p < p1; p++) {
     int job = k.evList[p];
     const JobRec& r = d.jrec[job];
     int n = r.node0, pcx = r.pc; int32_t prio = r.runPrio;
     int32_t cutoff = r.preemptible ? prio : NONPREEMPTIBLE_CUTOFF;
     for (int x = 0; x < k.R; x++) {
-      int64_t v = r.req[x];
+      int64_t v = sign * r.req[x];
       FL.qAlloc[q][x] += v; RS.allocated[x] += v; RS.evicted[x] -= v;
       size_t i = ((size_t)q * k.npc + pcx) * k.R + x;
       k.qAllocByPc[i] += v; k.qEvictedByPc[i] -= v;
       for (int l = 1; l < r.nlRun; l++) KAL(k, l, x, n) -= v;
     }
-    for (int l = 1; l < r.nlRun; l++) KKEY(k, l, n) -= r.keyDelta;
+    for (int l = 1; l < r.nlRun; l++) { if (sign > 0) KKEY(k, l, n) -= r.keyDelta; else KKEY(k, l, n) += r.keyDelta; }
+    if (sign < 0) {  // state of a job the evictor has just evicted (eviction.go:245-260, evictApply)
+      k.jcHasPctx[job] = 0; k.pcNode[job] = -1; k.pcSap[job] = 0; k.pcPap[job] = ASCHED_MIN_PRIORITY; k.pcMethod[job] = ASCHED_METHOD_NONE;
+      k.jobEvictedOnNode[job] = 1; k.jobFlags[job] = F_EVICTED; k.inPreempted[job] = 1;
+      if (!RS.replayPending) { int idx = k.evIdxByPos[p]; k.evTabAlive[idx] = 1; k.evIndexOfJob[job] = idx; }
+      continue;
+    }
     k.jcReason[job] = 0; k.jcHasPctx[job] = 1; k.pcNode[job] = n; k.pcSap[job] = prio;
     k.jobNode[job] = n; k.jobCutoff[job] = cutoff; k.jobEvictedOnNode[job] = 0; k.schedAtPrio[job] = prio; k.inSchedAndEvicted[job] = 0;
     k.pcPap[job] = prio; k.pcMethod[job] = ASCHED_METHOD_RESCHEDULED; k.jobFlags[job] = F_RESCHEDULED; k.inPreempted[job] = 0;
@@ -400,7 +407,7 @@ DEV void headFromWindow(int q, int w);
 DEV void bindUpdate(KREF k, FastS& S, int n, int lo, int nl, int q, uint64_t keyDelta);
 DEV void accountVectors(Dev& d, KREF k, int q, int pc, bool ev, bool replay);
 DEV void evWinRefill(KREF k, int q, int pos, int cnt);
-DEV void applyEvictedRange(Dev& d, KREF k, int q, int p0, int p1);
+__device__ static void applyEvictedRange(Dev& d, int q, int p0, int p1, int sign = 1);  // not inlined, reads the constants itself: nothing of the hot loop has to live in memory for it
 DEV bool roundLimitExceeded(Dev& d, KREF k);
 DEV bool headRequestsDisallowed(Dev& d, KREF k, int q);
 #endif
@@ -414,7 +421,7 @@ DEV void fastFlushEvicted(Dev& d) {  // apply every queue's deferred evicted-job
   const FastK k = fastKRef(d);
   for (int q = 0; q < d.cfg.Q; q++) {
     int p0 = UNI32(FL.hot[q].evApplied), p1 = UNI32(FL.hot[q].evDone);
-    if (p0 < p1) { applyEvictedRange(d, k, q, p0, p1); FL.hot[q].evApplied = p1; RS.numEvictedJobs -= p1 - p0; }
+    if (p0 < p1) { applyEvictedRange(d, q, p0, p1); FL.hot[q].evApplied = p1; RS.numEvictedJobs -= p1 - p0; }
   }
 }
 DEV void fastEnterGeneric(Dev& d, Ctl& c) {
@@ -552,7 +559,7 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
       if (kind == 0 && !fc.evStatic && !fc.replay) generic = true;  // evicted this round after being scheduled: node / priority are not the job's static run
     }
     if (!generic && kind == 1 && f.evApplied < f.evDone) {  // first queued job after cheap evicted ones: their commits feed the queue's allocation
-      applyEvictedRange(d, k, q, f.evApplied, f.evDone);
+      applyEvictedRange(d, q, f.evApplied, f.evDone);
       S.numEvictedJobs -= f.evDone - f.evApplied; f.evApplied = f.evDone;
     }
     if (!generic && kind == 0 && f.evCheap) {  // costs precomputed for the whole evicted stream (B_EVKEYS): no job record, no DRF evaluation
@@ -612,6 +619,11 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
     int32_t sp = kind == 0 ? UNI32(FL.winRec[q][w].runPrio) : p;  // evicted: run.ScheduledAtPriority (queue_scheduler.go:660-672)
     f.proposed = pr; f.current = cu; f.size = sz; f.pcPrio = p; f.schedPrio = sp;
     *ko = packItemKeys(fc.preferLarge, q, fc.compareSchedPrio ? sp : p, pr, cu, sz, f.budget);
+    if (f.effValid) {  // skip mode: a head cannot be served before anything that precedes it in its queue (heap merge == order by running maximum)
+      PackedKey own, eff; own.A = ko->A; own.X = ko->X; own.Y = ko->Y; eff.A = UNI32(FL.effA[q]); eff.X = UNI64(FL.effX[q]); eff.Y = UNI64(FL.effY[q]);
+      if (packedLess(own, 0, eff, 0)) { ko->A = eff.A; ko->X = eff.X; ko->Y = eff.Y; FL.kA[q] = eff.A; FL.kX[q] = eff.X; FL.kY[q] = eff.Y; }
+      else { FL.effA[q] = own.A; FL.effX[q] = own.X; FL.effY[q] = own.Y; }
+    }
     haveHead = true;
     break;
   }
@@ -622,6 +634,7 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
   o.pcPrio = f.pcPrio; o.schedPrio = f.schedPrio; o.headFast = f.headFast; o.headKind = f.headKind; o.headIdx = f.headIdx;
   o.winKind = f.winKind; o.winStart = f.winStart; o.winCount = f.winCount;
   o.evApplied = f.evApplied; o.evDone = f.evDone; o.ewStart = f.ewStart; o.ewCount = f.ewCount; o.headPos = f.headPos;
+  o.effValid = f.effValid; o.skipStart = f.skipStart;
   if (haveHead) FL.inHeap[q] = 1;
   SEG(6);
   return ok;
@@ -679,7 +692,7 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
     // (bucket arithmetic, DESIGN.md "Evicted jobs always return")
     if (!fc.evStatic || !S.lvl0NonNeg) return 0;
     prio = r.runPrio; n = r.node0;
-    if (f.evApplied < f.evDone) { applyEvictedRange(d, k, q, f.evApplied, f.evDone); S.numEvictedJobs -= f.evDone - f.evApplied; }
+    if (f.evApplied < f.evDone) { applyEvictedRange(d, q, f.evApplied, f.evDone); S.numEvictedJobs -= f.evDone - f.evApplied; }
     f.evApplied = f.evDone = f.headPos + 1;  // committed right here
   }
   SEG(2);
@@ -729,6 +742,120 @@ DEV int fastReplayStep(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, int
   return fastAdvance(d, k, S, fc, q, f, ko) ? 1 : 2;
 }
 
+// ---- skip mode.  In a pass whose evicted jobs all return to their nodes (fastIter's evicted branch: no node read, nothing a
+// queued job's placement depends on), the heap merge of the per-queue streams [evicted..., queued...] equals the order by each
+// entry's running-maximum key, so the evicted entries need not be stepped through one by one: their commits are applied in
+// bulk up front, every queue enters the heap with its first queued job under max(own key, last evicted key), and the loop
+// visits queued jobs only.  The first iteration that needs the generic code ends the mode: evicted entries ordering after the
+// current head are taken back (applyEvictedRange sign -1) and become ordinary heads again, which reproduces the exact state.
+struct SkipDelta { int evicted, iters, refills; };  // what a cold helper changed of the scheduling-context scalars the loop keeps in registers
+DEV void coldS(Dev& d, FastS& S) {
+  S.tP0 = -1; S.laneL = 0; S.laneX = 0; S.numEvictedJobs = 0; S.loopIterations = 0; S.statRefills = 0; S.statScanSteps = 0; S.statL0Max = 0;
+  S.numUnfeasible = RS.numUnfeasible; S.numPreemptedMarks = RS.numPreemptedMarks; S.fastActive = RS.fastActive; S.lvl0NonNeg = RS.lvl0NonNeg; S.replayPending = RS.replayPending;
+  S.globalTokens = 0; S.globalBurst = 0; S.globalRateInf = 1; S.numScheduledJobs = S.numScheduledGangs = S.numNodeQueries = S.evictedTableSize = 0; S.statFastIters = S.statFastReplay = 0; S.segT = 0;
+}
+DEV_NOINLINE SkipDelta fastEnterSkip(Dev& d, FastCtx fc, int Q) {
+  const FastK k = fastKRef(d);
+  FastS S; coldS(d, S);
+  for (int q = 0; q < Q; q++) {
+    QHot f = FL.hot[q];
+    uniQHot(f);
+#ifdef ASCHED_HOSTSIM
+    if (getenv("SKIPDBG")) fprintf(stderr, "enterSkip q%d cheap %d mono %d eff %d evDone %d evApplied %d evEnd %d gctx %d headPos %d\n", q, f.evCheap, d.evMono[q], f.effValid, f.evDone, f.evApplied, f.evEnd, f.gctx, f.headPos);
+#endif
+    if (!f.evCheap || !UNI32((int)d.evMono[q]) || f.effValid) continue;
+    int p0 = f.evDone, p1 = f.evEnd;
+    if (p0 >= p1 || p0 != f.evApplied) continue;
+    if (f.gctx < 0 || f.headPos != p0) continue;  // expected: the head is the first evicted job, peeked by the generic passInit
+    applyEvictedRange(d, q, p0, p1);
+    S.numEvictedJobs -= p1 - p0;
+    EvKey e; memcpy(&e, (const char*)k.evKey + (size_t)(p1 - 1) * sizeof(EvKey), sizeof(EvKey));
+    PackedKey last = packKey3(fc.preferLarge, UNI32(e.pcPrio), UNID(e.proposed), UNID(e.current), UNID(e.size), f.budget);
+    FL.effA[q] = last.A; FL.effX[q] = last.X; FL.effY[q] = last.Y;
+    f.effValid = 1; f.skipStart = p0; f.itEi = p1; f.evApplied = f.evDone = p1;
+    KeyOut ko;
+    if (!fastAdvance(d, k, S, fc, q, f, &ko)) {  // first queued job is a gang member / needs the generic iterator: leave this queue alone
+      applyEvictedRange(d, q, p0, p1, -1);
+      S.numEvictedJobs += p1 - p0;
+      QHot g = FL.hot[q]; uniQHot(g);
+      g.effValid = 0; g.itEi = p0; g.itStage = 0; g.evApplied = g.evDone = p0;
+      fastAdvance(d, k, S, fc, q, g, &ko);  // the evicted head again (cheap path: cannot fail)
+    }
+  }
+  SkipDelta r; r.evicted = S.numEvictedJobs; r.iters = S.loopIterations; r.refills = S.statRefills;
+  return r;
+}
+// `top` / (tk, tn): the entry the exact state is rebuilt around — the current head about to go to the generic code, or the entry
+// just served (every evicted entry ordering before it has been served, none after it); top < 0: everything has been served.
+DEV_NOINLINE SkipDelta fastExitSkip(Dev& d, FastCtx fc, int Q, int top, PackedKey tk, uint32_t tn) {
+  const FastK k = fastKRef(d);
+  FastS S; coldS(d, S);
+  if (top < 0) { tn = ~0u; tk.A = ~0u; tk.X = ~0ull; tk.Y = ~0ull; }
+  for (int q = 0; q < Q; q++) {
+    QHot f = FL.hot[q];
+    uniQHot(f);
+    if (!f.effValid) continue;
+    f.effValid = 0;
+    int b0 = f.skipStart, b1 = f.evEnd;
+    uint32_t qn = (uint32_t)UNI32(FL.nameRank[q]);
+    int lo = b0, hi = b1;  // first evicted entry that does NOT order before the current head (keys are non-decreasing)
+    if (q == top) lo = b1;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      EvKey e; memcpy(&e, (const char*)k.evKey + (size_t)mid * sizeof(EvKey), sizeof(EvKey));
+      PackedKey pk = packKey3(fc.preferLarge, UNI32(e.pcPrio), UNID(e.proposed), UNID(e.current), UNID(e.size), f.budget);
+      if (packedLess(pk, qn, tk, tn)) lo = mid + 1; else hi = mid;
+    }
+#ifdef ASCHED_HOSTSIM
+    if (getenv("SKIPDBG")) fprintf(stderr, "exitSkip q%d top %d ref A %08x X %016llx n %u | b0 %d b1 %d lo %d gctx %d kA %08x kX %016llx inHeap %d\n", q, top, tk.A, (unsigned long long)tk.X, tn, b0, b1, lo, f.gctx, FL.kA[q], (unsigned long long)FL.kX[q], FL.inHeap[q]);
+#endif
+    S.loopIterations += lo - b0;  // the reference spent one loop iteration on each of them
+    if (lo == b1) { FL.hot[q].effValid = 0; continue; }
+    applyEvictedRange(d, q, lo, b1, -1);
+    S.numEvictedJobs += b1 - lo;
+    if (f.gctx >= 0) { f.itQi -= 1; f.itJobsSeen -= 1; }  // the queued head goes back into its stream
+    f.itStage = 0; f.itEi = lo; f.evApplied = f.evDone = lo;
+    KeyOut ko;
+    fastAdvance(d, k, S, fc, q, f, &ko);  // head = evicted entry `lo` (cheap path)
+  }
+  SkipDelta r; r.evicted = S.numEvictedJobs; r.iters = S.loopIterations; r.refills = S.statRefills;
+  return r;
+}
+
+// ---- drain.  After a terminal reason (queue_scheduler.go:205-212) every queue yields evicted jobs only and nothing can bring
+// the queued jobs back (resuming needs an empty termination reason, :125-142).  If all that is left are gang-free evicted
+// streams of a pass in which evicted jobs always return, the remaining iterations are order-independent: apply them in bulk.
+DEV_NOINLINE SkipDelta fastDrain(Dev& d, int Q) {
+  FastS S; coldS(d, S);
+  SkipDelta r; r.evicted = r.iters = r.refills = 0;
+  for (int q = 0; q < Q; q++) {  // eligibility first: all or nothing
+    QHot f = FL.hot[q];
+    uniQHot(f);
+    bool headEv = f.gctx >= 0 && f.headPos >= 0;
+    if (f.gctx != -1 && !headEv) return r;                       // a queued job or a gang at the head
+    int p0 = headEv ? f.headPos : f.itEi;
+    if (p0 < f.evEnd && !f.evCheap) return r;                      // gang members among the remaining evicted jobs
+    if (!UNI32(FL.inHeap[q]) && f.gctx != -1) return r;
+  }
+  for (int q = 0; q < Q; q++) {
+    QHot f = FL.hot[q];
+    uniQHot(f);
+    bool headEv = f.gctx >= 0 && f.headPos >= 0;
+    int p0 = headEv ? f.headPos : f.itEi, p1 = f.evEnd;
+    if (f.evApplied < f.evDone) { applyEvictedRange(d, q, f.evApplied, f.evDone); S.numEvictedJobs -= f.evDone - f.evApplied; }
+    if (p0 < p1) {
+      applyEvictedRange(d, q, p0, p1);
+      S.numEvictedJobs -= p1 - p0; S.loopIterations += p1 - p0;
+    }
+    QHot& o = FL.hot[q];
+    o.itEi = p1; o.itStage = 1; o.evApplied = o.evDone = p1; o.gctx = -1; o.itNext = -1; o.headFast = 0; o.headPos = -1;
+    o.proposed = o.current = o.size = 0;
+    FL.inHeap[q] = 0;
+  }
+  r.evicted = S.numEvictedJobs; r.iters = S.loopIterations;
+  return r;
+}
+
 // Run fast iterations of the QueueScheduler loop (mode 0) or of the eviction-order replay (mode 1) until one needs the
 // generic code.  Returns the queue whose next head the generic updateAndPush must produce, or -1.  Leaves fast mode live.
 DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* counter) {
@@ -750,7 +877,11 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   fc.withQueued = UNI32(fc.withQueued); fc.maxLookback = UNI32(fc.maxLookback); fc.skipKnown = UNI32(fc.skipKnown); fc.compareSchedPrio = UNI32(fc.compareSchedPrio);
   fc.preferLarge = UNI32(fc.preferLarge); fc.evStatic = UNI32(fc.evStatic);
   mode = UNI32(mode);
-  int cnt = counter ? UNI32(*counter) : 0, pend = -1;
+  int cnt = counter ? UNI32(*counter) : 0, pend = -1, lastTop = -1;
+  PackedKey refK; refK.A = ~0u; refK.X = refK.Y = ~0ull; uint32_t refN = ~0u;
+  if (!mode && c.onlyEvicted && RS.terminationReason != 0 && S.lvl0NonNeg && S.numPreemptedMarks == 0 && fc.evStatic && fc.withQueued) { SkipDelta dl = fastDrain(d, Q); S.numEvictedJobs += dl.evicted; S.loopIterations += dl.iters; }
+  if (c.skipEnter && !mode && S.lvl0NonNeg && S.numPreemptedMarks == 0 && fc.evStatic) { SkipDelta dl = fastEnterSkip(d, fc, Q); S.numEvictedJobs += dl.evicted; S.loopIterations += dl.iters; S.statRefills += dl.refills; c.skipActive = 1; }
+  c.skipEnter = 0;
   PQState pq;
   pqBuild(pq, Q);
   SEG_BEGIN();
@@ -758,18 +889,37 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
     int t = pqHead(pq, Q);
     SEG(0);
 #ifdef ASCHED_HOSTSIM
-    fastQFlush(d);
-    if (t != pqTop(d, c)) { fprintf(stderr, "hostsim: packed queue key disagrees with Less (fast %d, generic %d)\n", t, pqTop(d, c)); abort(); }
+    if (!c.skipActive) {  // in skip mode heads carry running-maximum keys the generic Less knows nothing about
+      fastQFlush(d);
+      if (t != pqTop(d, c)) {
+        int g = pqTop(d, c);
+        fprintf(stderr, "hostsim: packed queue key disagrees with Less (fast %d, generic %d) mode %d\n", t, g, mode);
+        for (int q : {t, g}) if (q >= 0) { const QHot& h = FL.hot[q];
+          fprintf(stderr, " q%d A %08x X %016llx Y %016llx prop %.17g cur %.17g size %.17g budget %.17g pcPrio %d eff %d kind %d gctx %d itEi %d evEnd %d itQi %d stage %d inHeap %d/%d\n", q, FL.kA[q],
+            (unsigned long long)FL.kX[q], (unsigned long long)FL.kY[q], h.proposed, h.current, h.size, h.budget, h.pcPrio, h.effValid, h.headKind, h.gctx, h.itEi, h.evEnd, h.itQi, h.itStage, FL.inHeap[q], d.pqInHeap[q]); }
+        abort();
+      }
+    }
 #endif
+    lastTop = t;
+    if (t >= 0) { refK.A = UNI32(FL.kA[t]); refK.X = UNI64(FL.kX[t]); refK.Y = UNI64(FL.kY[t]); refN = (uint32_t)UNI32(FL.nameRank[t]); }
     if (t < 0) break;
     if (UNI32(FL.hot[t].gctx) < 0) break;  // a gang: generic
     KeyOut ko; ko.valid = 0; ko.A = 0; ko.X = ko.Y = 0;
     int st = mode ? fastReplayStep(d, k, S, fc, t, &cnt, &ko) : fastIter(d, k, S, fc, t, &ko);
+#ifdef ASCHED_HOSTSIM
+    if (st == 0 && getenv("SKIPDBG")) fprintf(stderr, "fastRun break st0 top %d gctx %d headFast %d kind %d fastActive %d tokens %g gtok %g iters %d\n", t, FL.hot[t].gctx, FL.hot[t].headFast, FL.hot[t].headKind, S.fastActive, FL.hot[t].tokens, S.globalTokens, S.statFastIters);
+#endif
     if (st == 0) break;
     pqPopPush(pq, ko, t);
     SEG(7);
     if (!mode) { S.loopIterations++; S.statFastIters++; }
-    if (st == 2) { pend = t; break; }
+    if (st == 2) { pend = t; break; }  // refK / refN: the entry just served
+  }
+  if (c.skipActive) {  // generic code comes next: rebuild the exact interleaved state
+    SkipDelta dl = fastExitSkip(d, fc, Q, lastTop, refK, refN);
+    S.numEvictedJobs += dl.evicted; S.loopIterations += dl.iters; S.statRefills += dl.refills;
+    c.skipActive = 0;
   }
   if (counter) *counter = cnt;
   RS.globalTokens = S.globalTokens;

@@ -110,8 +110,8 @@ DEV void bulkElem(Dev& d, int kind, int i) {
       d.evTabAlive[i] = alive;
       if (!alive) d.evIndexOfJob[j] = -1;
     } break;
-    case B_EVKEYS_OFF: d.evCheap[i] = 0; break;
-    case B_EVKEYS_ON: d.evCheap[i] = 1; break;
+    case B_EVKEYS_OFF: d.evCheap[i] = 0; d.evMono[i] = 0; break;
+    case B_EVKEYS_ON: d.evCheap[i] = 1; d.evMono[i] = 1; break;
     // Queue-order costs of every evicted job, in eviction-list order (pqs.go:589-639 replays exactly these; pass 1 re-reads
     // them).  The list is ordered by queue; thread i owns positions [i*C, (i+1)*C): pass A sums the requests of its range per
     // queue segment and flags gang members, one thread stitches the carries, pass B evaluates the DRF costs.
@@ -143,8 +143,10 @@ DEV void bulkElem(Dev& d, int kind, int i) {
       while (d.evOff[q + 1] <= p0) q++;
       int64_t a[MAXR], with[MAXR];
       for (int r = 0; r < c.R; r++) a[r] = QV(d.qAlloc, q)[r] + QV(d.qPenalty, q)[r] + carry[r];
+      PackedKey prev; bool havePrev = false;
+      uint64_t* edge = d.evEdge + (size_t)i * 8;
       for (int p = p0; p < p1; p++) {
-        while (d.evOff[q + 1] <= p) { q++; for (int r = 0; r < c.R; r++) a[r] = QV(d.qAlloc, q)[r] + QV(d.qPenalty, q)[r]; }
+        while (d.evOff[q + 1] <= p) { q++; havePrev = false; for (int r = 0; r < c.R; r++) a[r] = QV(d.qAlloc, q)[r] + QV(d.qPenalty, q)[r]; }
         int job = d.evList[p];
         const int64_t* req = JREQ(d, job);
         for (int r = 0; r < c.R; r++) with[r] = a[r] + req[r];
@@ -153,8 +155,13 @@ DEV void bulkElem(Dev& d, int kind, int i) {
         e.proposed = drf(d, with) / w; e.current = drf(d, a) / w; e.size = drf(d, req) * w;
         e.pcPrio = c.pcPriority[d.jPc[job]]; e.job = job;
         d.evKey[p] = e;
+        PackedKey pk = packKey3(c.preferLarge, e.pcPrio, e.proposed, e.current, e.size, d.qDc[q] / w);
+        if (havePrev && packedLess(pk, 0, prev, 0)) d.evMono[q] = 0;  // a later evicted job orders before an earlier one: heap merge != key sort
+        if (p == p0) { edge[0] = pk.A; edge[1] = pk.X; edge[2] = pk.Y; edge[3] = (uint64_t)q; }
+        prev = pk; havePrev = true;
         for (int r = 0; r < c.R; r++) a[r] = with[r];
       }
+      edge[4] = prev.A; edge[5] = prev.X; edge[6] = prev.Y; edge[7] = (uint64_t)q;
     } break;
     case B_LVL0: { bool neg = false; for (int r = 0; r < c.R; r++) neg = neg || AL(d, 0, r, i) < 0; if (neg) d.rs->lvl0NonNeg = 0; } break;
     case B_INIT_ALLOC: {  // fresh NodeDb (scheduling_algo.go:517): AllocatableByPriority[p] = allocatable (node.go:79-85)
@@ -251,6 +258,15 @@ DEV int pqsEvict(Dev& d, Ctl& c, bool phase3) {
         for (int r = 0; r < MAXR; r++) part[r] = carry[r];
       }
       wgBulk(d, B_EVKEYS, d.evChunks);
+      {  // monotonicity across chunk borders
+        int C = (n + d.evChunks - 1) / d.evChunks, nc = (n + C - 1) / C;
+        for (int i = 1; i < nc; i++) {
+          const uint64_t* a = d.evEdge + (size_t)(i - 1) * 8; const uint64_t* b = d.evEdge + (size_t)i * 8;
+          if (a[7] != b[3]) continue;
+          PackedKey last, first; last.A = (uint32_t)a[4]; last.X = a[5]; last.Y = a[6]; first.A = (uint32_t)b[0]; first.X = b[1]; first.Y = b[2];
+          if (packedLess(first, 0, last, 0)) d.evMono[(int)b[3]] = 0;
+        }
+      }
       lazy = true;  // every queue's evicted stream is gang-free: the replay is a pure merge of precomputed costs and can wait
       for (int q = 0; q < d.cfg.Q; q++) if (!d.evCheap[q]) lazy = false;
     } else wgBulk(d, B_EVKEYS_OFF, d.cfg.Q);
@@ -320,7 +336,9 @@ DEV void runRound(Dev& d, Ctl& c) {
   d.rs->lvl0NonNeg = 1;
   wgBulk(d, B_LVL0, cf.N);
   long long tb = CLK();
+  c.skipEnter = fastOn(d, c) && d.evMono != nullptr && d.rs->lvl0NonNeg && n1 > 0;
   schedulePass(d, c, true, false, false);
+  c.skipEnter = 0;
   long long tc = CLK();
   d.rs->statClk[2] += tc - tb;
   c.fastEvStatic = 0;
@@ -491,7 +509,7 @@ DEV void controlMain(Dev& d, int cmd) {
   c.txn.active = d.rs->txnActive; c.fairStamp = d.rs->fairStamp; c.preList = d.preList; c.preCount = 0;
   c.skipKeyCheck = 0; c.compareSchedPrio = 0; c.preferLarge = d.cfg.preferLarge; c.useReplayAlloc = 0; c.onlyEvicted = 0;
   c.fastEnabled = d.f.iterOk && !d.rs->apiDirty && (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY);
-  c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0;
+  c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0;
   fastLoad(d);
   runCommand(d, c, cmd);
   fastEnterGeneric(d, c);
