@@ -269,6 +269,7 @@ DEV void fastQFlush(Dev& d) {
     d.itEi[q] = f.itEi; d.itQi[q] = f.itQi; d.itStage[q] = f.itStage; d.itJobsSeen[q] = f.itJobsSeen;
     d.itNext[q] = f.itNext; d.pqGctx[q] = f.gctx; d.pqPcPrio[q] = f.pcPrio; d.pqSchedPrio[q] = f.schedPrio;
     d.pqInHeap[q] = (uint8_t)FL.inHeap[q];
+    d.itJobOnlyEv[q] = (uint8_t)f.itJobOnlyEv; d.itGangOnlyEv[q] = (uint8_t)f.itGangOnlyEv;
   }
 }
 DEV void fastEnsureLive(Dev& d, Ctl& c) { if (!c.fqLive) { fastQLoad(d); c.fqLive = 1; } }
@@ -634,7 +635,7 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
   o.pcPrio = f.pcPrio; o.schedPrio = f.schedPrio; o.headFast = f.headFast; o.headKind = f.headKind; o.headIdx = f.headIdx;
   o.winKind = f.winKind; o.winStart = f.winStart; o.winCount = f.winCount;
   o.evApplied = f.evApplied; o.evDone = f.evDone; o.ewStart = f.ewStart; o.ewCount = f.ewCount; o.headPos = f.headPos;
-  o.effValid = f.effValid; o.skipStart = f.skipStart;
+  o.effValid = f.effValid; o.skipStart = f.skipStart; o.itJobOnlyEv = f.itJobOnlyEv; o.itGangOnlyEv = f.itGangOnlyEv;
   if (haveHead) FL.inHeap[q] = 1;
   SEG(6);
   return ok;
@@ -650,6 +651,8 @@ DEV void fastLoadHead(KREF k, int q, int job, QHot& f) {
   f.headFast = 1;
 }
 
+
+DEV void qlPutWin(int q, const QHot& f) { QHot& o = FL.hot[q]; o.winKind = f.winKind; o.winStart = f.winStart; o.winCount = f.winCount; }
 
 // One QueueScheduler iteration (queue_scheduler.go:94-304 body) for the head of queue `top` when it is a single job that
 // (a) is queued and fits at priority -2 or (b) is a phase-1-evicted job returning to its node.  Returns 0 WITHOUT side
@@ -680,7 +683,39 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
   if (!ev) {
     if (!S.fastActive) return 0;
     if (roundLimitExceeded(d, k)) return 0;  // CheckRoundConstraints (constraints.go:113-119)
-    if (f.cordoned || S.globalTokens < 1 || S.globalBurst < 1 || f.tokens < 1 || f.burst < 1) return 0;  // CheckJobConstraints (:121-157)
+    if (f.cordoned || S.globalTokens < 1 || S.globalBurst < 1 || f.burst < 1) return 0;  // CheckJobConstraints (:121-157)
+    if (f.tokens < 1) {
+      // QueueRateLimitExceeded: a queue-terminal reason (constraints.go:25-58).  The reference adds the gang to the context, fails the
+      // constraint check, takes it out again and records it as failed (gang_scheduler.go:63-98: net effect = the job's reason and
+      // "unsuccessful" flag), pops the queue's item, which peeks the next job, and then restricts the queue to evicted jobs: the
+      // peeked job is stashed and the queue leaves the heap (queue_scheduler.go:213-220, 338-350, 546-566).
+      if (S.numUnfeasible > 0 || f.itStage == 0) return 0;
+      bool lookback = fc.maxLookback != 0 && !f.itGangOnlyEv && (uint32_t)f.itJobsSeen >= fc.maxLookback;
+      int nextJob = -1;
+      if (!lookback && !f.itJobOnlyEv && f.itQi < f.qEnd) {
+        int pos = f.itQi;
+        if (!(f.winKind == 1 && pos >= f.winStart && pos < f.winStart + f.winCount)) {
+          int cnt = f.qEnd - pos; if (cnt > WIN) cnt = WIN;
+          winRefill(k, q, 1, pos, cnt);
+          f.winKind = 1; f.winStart = pos; f.winCount = cnt;
+          S.statRefills++;
+        }
+        int w = pos - f.winStart;
+        if (UNI32(FL.winRec[q][w].gang) >= 0) { qlPutWin(q, f); return 0; }  // the generic iterator assembles gangs (only the window moved: harmless)
+        nextJob = UNI32(FL.winJob[q][w]);
+        f.itQi = pos + 1; f.itJobsSeen++;
+      }
+      if (FLANE == 0) { k.jcReason[job] = ASCHED_REASON_QUEUE_RATE_LIMIT; k.jobFlags[job] = F_UNSUCCESSFUL; }
+      d.itStashed[q] = nextJob; d.onlyEvByQueue[q] = 1;
+      f.itGangOnlyEv = 1; f.itJobOnlyEv = 1;
+      f.itNext = -1; f.gctx = -1; f.headFast = 0; f.proposed = f.current = f.size = 0;
+      FL.inHeap[q] = 0;
+      QHot& o = FL.hot[q];
+      o.itQi = f.itQi; o.itJobsSeen = f.itJobsSeen; o.itNext = -1; o.gctx = -1; o.headFast = 0; o.proposed = o.current = o.size = 0;
+      o.itGangOnlyEv = 1; o.itJobOnlyEv = 1; o.winKind = f.winKind; o.winStart = f.winStart; o.winCount = f.winCount;
+      ko->valid = 0;
+      return 1;
+    }
     if (k.anyDisallowed && headRequestsDisallowed(d, k, q)) return 0;
     if (k.disableHome) return 0;
     prio = r.pcPrio;
