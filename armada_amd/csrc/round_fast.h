@@ -149,7 +149,7 @@ struct FastCtx { int withQueued; uint32_t maxLookback; int skipKnown, compareSch
 
 // loop constants: configuration and array bases, read once per fastRun (registers for the whole run)
 struct FastK {
-  int R, K, P, E, ex0col, ex1col, N, npc, S, disableHome, hasPcLimit, anyDisallowed;
+  int R, K, P, E, ex0col, ex1col, N, npc, S, disableHome, hasPcLimit, anyDisallowed, anyRoundLimit;
   size_t Npad;
   uint64_t fieldMask[MAXK]; uint64_t minFieldMin; int64_t minEx0, minEx1;
   GP(uint64_t) baseKey; GP(int32_t) baseNode; GP(int64_t) baseExtra; GP(uint64_t) baseCls; GP(uint8_t) baseRemoved; GP(int32_t) l0Slot;
@@ -180,7 +180,8 @@ HD void fastKInit(const Dev& d, FastK& k) {
   const DevCfg& c = d.cfg;
   k.R = c.R; k.K = c.K; k.P = c.P; k.E = d.f.E; k.ex0col = d.f.extraCol[0]; k.ex1col = d.f.extraCol[1]; k.N = c.N; k.npc = c.npc; k.S = c.S;
   k.disableHome = c.disableHome; k.hasPcLimit = d.hasPcLimit; k.Npad = (size_t)c.Npad;
-  k.anyDisallowed = 0;
+  k.anyDisallowed = 0; k.anyRoundLimit = 0;
+  for (int i = 0; i < MAXR; i++) if (i < c.R && c.maxToSchedule[i] != INT64_MAX) k.anyRoundLimit = 1;  // MaximumResourceFractionToSchedule unset: +Inf x total saturates (resource_list.go:312-331)
   for (int i = 0; i < MAXR; i++) if (i < c.R && c.disallowed[i]) k.anyDisallowed = 1;
   for (int i = 0; i < MAXK; i++) k.fieldMask[i] = i < c.K ? d.f.fieldMask[i] : 0;
   k.minFieldMin = d.f.minFieldMin; k.minEx0 = d.f.minExtra[0]; k.minEx1 = d.f.minExtra[1];
@@ -682,7 +683,7 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
   CandRec cand; cand.pos = 0; cand.node = -1; cand.key = 0; cand.cls = 0; cand.ex0 = cand.ex1 = 0; cand.pad = 0;
   if (!ev) {
     if (!S.fastActive) return 0;
-    if (roundLimitExceeded(d, k)) return 0;  // CheckRoundConstraints (constraints.go:113-119)
+    if (k.anyRoundLimit && roundLimitExceeded(d, k)) return 0;  // CheckRoundConstraints (constraints.go:113-119)
     if (f.cordoned || S.globalTokens < 1 || S.globalBurst < 1 || f.burst < 1) return 0;  // CheckJobConstraints (:121-157)
     if (f.tokens < 1) {
       // QueueRateLimitExceeded: a queue-terminal reason (constraints.go:25-58).  The reference adds the gang to the context, fails the
