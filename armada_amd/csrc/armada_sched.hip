@@ -16,17 +16,20 @@
 // There is no CPU compute path in this library: without a gfx950 device asched_create() fails.
 #include <hip/hip_runtime.h>
 #include <string>
+#include <unistd.h>
 #include <vector>
 
 #define ASCHED_PREFIX asched_
 #include "round_run.h"
 
 // ------------------------------------------------------------------------------------------------ device primitives
-enum { OP_EXIT = 0, OP_SCAN = 1, OP_BULK = 2, OP_COMPACT = 3 };
+#define CTL_THREADS 256
+enum { OP_EXIT = 0, OP_SCAN = 1, OP_BULK = 2, OP_COMPACT = 3, OP_FAIR = 4, OP_HELPERS_EXIT = 9 };
 
 struct Mailbox {
   int op, kind, n;
   ScanArgs scan;
+  FairArgs fair;
   unsigned long long partial[16];
   const int32_t* order; const uint8_t* flag; int32_t* dst; uint32_t* prefix;
   int waveCount[16];
@@ -35,9 +38,53 @@ struct Mailbox {
 __shared__ Mailbox g_mb;
 __shared__ Dev g_dev;
 
+// Helper workgroups.  A round launch carries H extra workgroups (one per CU) that spin on a mailbox in HBM and take a share of
+// the two read-only full-width queries of the generic path: the first-fit plane scan (OP_SCAN) and the per-node evaluation of
+// fair-share preemption (OP_FAIR).  They read only HBM state (never the control workgroup's LDS); the hand-shake is a
+// generation counter (release store by the control wave, relaxed polls + acquire fence by the helpers) and a completion
+// counter (release increments, acquire poll) at agent scope, so it is correct across XCDs (separate L2s).
+struct HelpBox {
+  unsigned long long cmd;      // (generation << 8) | op, published with ONE release store: a helper can never pair a new generation with an old op
+  unsigned int done, pad;
+  unsigned long long result;   // OP_SCAN: min packed key; OP_FAIR: max (Index + 1)
+  unsigned long long args[16]; // ScanArgs / FairArgs image, read by the helpers with agent-scope loads
+};
+static_assert(sizeof(ScanArgs) <= 16 * 8 && sizeof(FairArgs) <= 16 * 8 && sizeof(ScanArgs) % 8 == 0 && sizeof(FairArgs) % 8 == 0, "HelpBox args image");
+__shared__ HelpBox* g_box;
+__shared__ int g_H;
+__shared__ unsigned int g_gen;
+
+template <class A> __device__ static inline void helpIssue(int op, const A* args) {  // one lane of the control wave
+  HelpBox* b = g_box;
+  if (args) {
+    const unsigned long long* src = (const unsigned long long*)args;
+    for (int i = 0; i < (int)(sizeof(A) / 8); i++) __hip_atomic_store(&b->args[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __hip_atomic_store(&b->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&b->result, op == OP_SCAN ? ~0ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  g_gen++;
+  __hip_atomic_store(&b->cmd, ((unsigned long long)g_gen << 8) | (unsigned)op, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ static inline unsigned long long helpWait() {  // whole control wave, uniformly (no lane-divergent spin)
+  HelpBox* b = g_box;
+  unsigned int want = (unsigned)g_H * (CTL_THREADS / 64), spins = 0;
+  for (;;) {
+    unsigned int dn = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&b->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+    if (dn == want) break;
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 0xffff) == 0 && g_dev.progress) { g_dev.progress[5] = (int)dn; g_dev.progress[6] = g_H; g_dev.progress[7] = (int)g_gen; g_dev.progress[8] = (int)(b->cmd >> 8); g_dev.progress[9] = (int)(b->cmd & 255); }
+  }
+  return __hip_atomic_load(&b->result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ static inline void atomicAddI64(int64_t* p, int64_t v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
 __device__ static inline void atomicAddI32(int32_t* p, int32_t v) { atomicAdd(p, v); }
 __device__ static inline void atomicOrI32(int32_t* p, int32_t v) { atomicOr(p, v); }
+__device__ static inline int atomicFetchAddI32(int32_t* p, int32_t v) { return atomicAdd(p, v); }
+__device__ static inline int waveMax32(int v) {
+  for (int off = 32; off; off >>= 1) { int o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+  return v;
+}
 
 __device__ static inline unsigned long long waveMin64(unsigned long long v) {
   for (int off = 32; off; off >>= 1) {
@@ -48,12 +95,12 @@ __device__ static inline unsigned long long waveMin64(unsigned long long v) {
 }
 
 // one thread per node (block-stride): reject by mask bit and key first, touch the alloc planes only for improving candidates
-__device__ static unsigned long long scanPart(const Dev& d, const ScanArgs& a) {
+__device__ static unsigned long long scanPart(const Dev& d, const ScanArgs& a, int tid, int nthreads) {
   const DevCfg& c = d.cfg;
   const uint64_t* keys = d.keys + (size_t)a.level * c.Npad;
   const int64_t* plane = d.alloc + (size_t)a.level * c.R * c.Npad;
   unsigned long long best = ~0ull;
-  for (int n = threadIdx.x; n < c.N; n += blockDim.x) {
+  for (int n = tid; n < c.N; n += nthreads) {
     uint64_t w = a.maskA[n >> 6];
     if (a.maskB) w &= a.maskB[n >> 6];
     if (!((w >> (n & 63)) & 1)) continue;
@@ -68,17 +115,45 @@ __device__ static unsigned long long scanPart(const Dev& d, const ScanArgs& a) {
 
 __device__ static inline int wgFirstFit(Dev& d, const ScanArgs& a) {
   int lane = threadIdx.x & 63;
-  if (lane == 0) { g_mb.op = OP_SCAN; g_mb.scan = a; }
+  if (lane == 0) { g_mb.op = OP_SCAN; g_mb.scan = a; if (g_H) helpIssue(OP_SCAN, &a); }
   __syncthreads();
-  unsigned long long v = scanPart(d, g_mb.scan);
+  unsigned long long v = scanPart(d, g_mb.scan, threadIdx.x, (g_H + 1) * (int)blockDim.x);
   if (lane == 0) g_mb.partial[threadIdx.x >> 6] = v;
   __syncthreads();
   unsigned long long best = ~0ull;
   int nw = blockDim.x >> 6;
   for (int w = 0; w < nw; w++) { unsigned long long p = g_mb.partial[w]; best = p < best ? p : best; }
+  if (g_H) {
+    unsigned long long hb = helpWait();
+    best = hb < best ? hb : best;
+  }
   d.rs->numScans++;
   if (best == ~0ull) return -1;
   return d.nodeByRank[best & ((1ull << d.cfg.idxBits) - 1)];
+}
+
+// one thread per node (grid-stride over the participating workgroups): highest evicted-table Index at which a node covers the request
+__device__ static int fairPart(const Dev& d, const FairArgs& a, int tid, int nthreads) {
+  int best = -1;
+  for (int n = tid; n < d.cfg.N; n += nthreads) { int v = fairNodeBest(d, a, n, best); best = v > best ? v : best; }
+  return waveMax32(best);
+}
+__device__ static inline int wgFairSelect(Dev& d, const FairArgs& a) {
+  int lane = threadIdx.x & 63;
+  if (lane == 0) { g_mb.op = OP_FAIR; g_mb.fair = a; if (g_H) helpIssue(OP_FAIR, &a); }
+  __syncthreads();
+  int v = fairPart(d, g_mb.fair, threadIdx.x, (g_H + 1) * (int)blockDim.x);
+  if (lane == 0) g_mb.waveCount[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int best = -1;
+  int nw = blockDim.x >> 6;
+  for (int w = 0; w < nw; w++) { int p = g_mb.waveCount[w]; best = p > best ? p : best; }
+  if (g_H) {
+    unsigned long long hb = helpWait();
+    int h = (int)(unsigned int)hb - 1;
+    best = h > best ? h : best;
+  }
+  return best;
 }
 
 __device__ static void bulkPart(Dev& d, int kind, int n) {
@@ -505,8 +580,49 @@ __device__ static void relocateOut() {
 }
 
 // ------------------------------------------------------------------------------------------------ kernels
-#define CTL_THREADS 256
-__global__ __launch_bounds__(CTL_THREADS) void k_control(Dev dev, int cmd) {
+template <class A> __device__ static inline A helpArgs(HelpBox* b) {
+  union { A a; unsigned long long w[sizeof(A) / 8]; } u;
+  for (int i = 0; i < (int)(sizeof(A) / 8); i++) u.w[i] = __hip_atomic_load(&b->args[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return u.a;
+}
+// Every wave of a helper workgroup runs this loop on its own: all lanes poll the command word together (one uniform load,
+// the loop branch is scalar), take the wave's share of the nodes and add 1 to the completion counter.  There is no
+// workgroup barrier and no lane-divergent loop in here on purpose: a "thread 0 polls, the others wait at the barrier" loop
+// gets rotated by the compiler so that the polling lane's tail and head merge across the back edge, and the rest of its wave
+// then runs ahead through the barriers without it.
+__device__ static void helperMain(const Dev& d, HelpBox* b, int H) {
+  unsigned long long seen = 0;
+  int tid = (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x, nthreads = (H + 1) * (int)blockDim.x;
+  int lane = threadIdx.x & 63;
+  for (;;) {
+    unsigned long long g;
+    for (;;) {
+      unsigned long long v = __hip_atomic_load(&b->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      g = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+      if (g != seen) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the round state written before the command was published
+    seen = g;
+    unsigned int op = (unsigned int)(seen & 255);
+    if (d.progress && threadIdx.x == 0 && blockIdx.x < 40) d.progress[16 + blockIdx.x] = (int)((seen >> 8) * 16 + op);
+    if (op == OP_HELPERS_EXIT) return;
+    if (op == OP_SCAN) {
+      ScanArgs a = helpArgs<ScanArgs>(b);
+      unsigned long long v = scanPart(d, a, tid, nthreads);
+      if (lane == 0 && v != ~0ull) __hip_atomic_fetch_min(&b->result, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (op == OP_FAIR) {
+      FairArgs a = helpArgs<FairArgs>(b);
+      int v = fairPart(d, a, tid, nthreads);
+      if (lane == 0 && v >= 0) __hip_atomic_fetch_max(&b->result, (unsigned long long)(v + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) __hip_atomic_fetch_add(&b->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(CTL_THREADS) void k_control(Dev dev, int cmd, HelpBox* box, int H) {
+  if (blockIdx.x != 0) { helperMain(dev, box, H); return; }
+  if (threadIdx.x == 0) { g_box = box; g_H = H; g_gen = 0; }
   // the Dev descriptor (pointers + config) is staged in LDS once; every wave reads it from there
   {
     const int* src = (const int*)&dev; int* dst = (int*)&g_dev;
@@ -521,8 +637,11 @@ __global__ __launch_bounds__(CTL_THREADS) void k_control(Dev dev, int cmd) {
       int op = g_mb.op;
       if (op == OP_EXIT) break;
       if (op == OP_SCAN) {
-        unsigned long long v = scanPart(d, g_mb.scan);
+        unsigned long long v = scanPart(d, g_mb.scan, threadIdx.x, (g_H + 1) * (int)blockDim.x);
         if ((threadIdx.x & 63) == 0) g_mb.partial[threadIdx.x >> 6] = v;
+      } else if (op == OP_FAIR) {
+        int v = fairPart(d, g_mb.fair, threadIdx.x, (g_H + 1) * (int)blockDim.x);
+        if ((threadIdx.x & 63) == 0) g_mb.waveCount[threadIdx.x >> 6] = v;
       } else if (op == OP_BULK) {
         bulkPart(d, g_mb.kind, g_mb.n);
       } else if (op == OP_COMPACT) {
@@ -535,7 +654,7 @@ __global__ __launch_bounds__(CTL_THREADS) void k_control(Dev dev, int cmd) {
   }
   controlMain(d, cmd);
   __threadfence();
-  if ((threadIdx.x & 63) == 0) g_mb.op = OP_EXIT;
+  if ((threadIdx.x & 63) == 0) { g_mb.op = OP_EXIT; if (g_H) helpIssue(OP_HELPERS_EXIT, (const ScanArgs*)nullptr); }
   __syncthreads();
   relocateOut();
 }
@@ -667,12 +786,41 @@ static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 static double plat_last_control_ms() { return (double)g_lastControlMs; }
 static int plat_last_control_launches() { return g_lastControlLaunches; }
 
+static HelpBox* g_helpBox = nullptr;
+static int g_helpers = -1;
 static int plat_run_control(Dev& dev, int cmd) {
   if (!g_ev0) { (void)hipEventCreate(&g_ev0); (void)hipEventCreate(&g_ev1); }
+  if (g_helpers < 0) {  // helper workgroups of a round launch: one per CU, a quarter of the device by default (ASCHED_HELPERS overrides; 0 = none)
+    int cus = 0, dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
+    g_helpers = cus >= 8 ? cus / 4 - 1 : 0;
+    if (const char* e = getenv("ASCHED_HELPERS")) g_helpers = atoi(e);
+    if (g_helpers > cus - 1) g_helpers = cus - 1;
+    if (g_helpers < 0) g_helpers = 0;
+    // the mailbox is written from both sides across XCDs: it must not live in an XCD-private L2 -> fine-grained (uncached, device-coherent) memory
+    if (!hipOk(hipExtMallocWithFlags((void**)&g_helpBox, sizeof(HelpBox), hipDeviceMallocFinegrained), "help box")) return -1;
+  }
+  int H = (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY) ? g_helpers : 0;
+  static int32_t* progress = nullptr;   // ASCHED_PROGRESS=1: host-visible heartbeat of the round kernel, printed once a second (debugging aid)
+  static bool wantProgress = getenv("ASCHED_PROGRESS") != nullptr;
+  if (wantProgress && !progress) {
+    if (hipHostMalloc((void**)&progress, 64 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) progress = nullptr;
+    if (progress) for (int i = 0; i < 64; i++) progress[i] = 0;
+  }
+  dev.progress = (cmd == CMD_ROUND && progress) ? progress : nullptr;
+  if (!hipOk(hipMemsetAsync(g_helpBox, 0, sizeof(HelpBox), g_stream), "help box reset")) return -1;
   (void)hipEventRecord(g_ev0, g_stream);
-  hipLaunchKernelGGL(k_control, dim3(1), dim3(CTL_THREADS), 0, g_stream, dev, cmd);
+  hipLaunchKernelGGL(k_control, dim3(1 + H), dim3(CTL_THREADS), 0, g_stream, dev, cmd, g_helpBox, H);
   (void)hipEventRecord(g_ev1, g_stream);
   if (!hipOk(hipGetLastError(), "k_control launch")) return -1;
+  if (dev.progress) {
+    int ticks = 0;
+    while (hipStreamQuery(g_stream) == hipErrorNotReady) {
+      usleep(100000);
+      if (++ticks % 10 == 0) { fprintf(stderr, "[asched progress] t=%ds iterations=%d generic=%d phase=%d op=%d ops=%d | wait: done=%d H=%d gen=%d box.gen=%d box.op=%d | helpers:", ticks / 10, progress[0], progress[4], progress[1], progress[2], progress[3], progress[5], progress[6], progress[7], progress[8], progress[9]); for (int i = 17; i < 56; i++) fprintf(stderr, " %x", progress[i]); fprintf(stderr, "\n"); }
+    }
+  }
   if (!hipOk(hipStreamSynchronize(g_stream), "k_control")) return -1;
   (void)hipEventElapsedTime(&g_lastControlMs, g_ev0, g_ev1);
   g_lastControlLaunches = 1;

@@ -97,7 +97,7 @@ struct RoundScalars {
   int32_t fastOverflow;      // L0 overflowed: structure dropped for the rest of the round
   int32_t replayPending;     // the eviction-order replay (evicted-table Index assignment) has been deferred: nothing has read it yet
   int32_t statFastIters, statGenericIters, statScanSteps, statRefills, statL0Max, statFastReplay;
-  int32_t pad;
+  int32_t fairIndexValid;    // the per-node index of the evicted table (fairOff/fairEnt) describes the current table
   int64_t statSeg[8];        // (profiling builds) shader-clock ticks per segment of a fast iteration
   int64_t statClk[8];        // shader-clock ticks per phase of the round (device builds): evict, replay, pass 1, oversub evict, pass 2, unbind+results
 };
@@ -165,6 +165,11 @@ struct Dev {
   int32_t* accStamp;     // [N]
   uint8_t* accStaticFailed;  // [N]
   int32_t accEpoch_unused;
+  // per-node index of the evicted table for fair-share preemption (round_run.h ensureFairIndex): CSR node -> table Indexes, descending
+  int32_t* fairOff;      // [Npad+2]
+  int32_t* fairEnt;      // [M] evicted-table Index
+  int32_t* fairEntJob;   // [M] its job
+  int32_t* fairPart;     // [FAIR_CHUNKS+1] chunk sums of the offset scan
   // ---- txn undo log
   int32_t* undo;         // [cap][4]
   int32_t undoCap;
@@ -202,4 +207,5 @@ struct Dev {
   const struct FastK* fk; // the fast loop's constants (round_fast.h), filled by the host at round_prepare
   QueueLoopArrays alt;    // second set for the lazy replay
   int64_t* qAllocSnap;    // [Q][R] queue allocations right after an evictor ran: what addEvictedJobsToNodeDb starts from
+  volatile int32_t* progress;  // optional host-visible heartbeat (ASCHED_PROGRESS=1): [0] loop iterations, [1] phase, [2] current wide op, [3] wide ops issued
 };

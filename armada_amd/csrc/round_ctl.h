@@ -31,7 +31,13 @@
 // workgroup primitives (implemented differently per build)
 struct ScanArgs { int64_t req[MAXR]; const uint64_t* maskA; const uint64_t* maskB; int level; };
 
+struct FairArgs { int64_t req[MAXR]; const uint64_t* maskA; const uint64_t* maskB; int32_t prio; int32_t pad; };
+#define FAIR_CHUNKS 256
+#define FAIR_BAD_ENTRY 0x7ffffff0   // an alive table entry without a scheduled-at priority was met (nodedb.go:950-953)
+
 DEV int wgFirstFit(Dev& d, const ScanArgs& a);                       // -> node or -1
+DEV int wgFairSelect(Dev& d, const FairArgs& a);                     // -> evicted-table Index or -1 (max over nodes of fairNodeBest)
+DEV int atomicFetchAddI32(int32_t* p, int32_t v);
 template <class F> DEV void wgForEach(Dev& d, int n, F f);           // f(i) for i in [0,n), then workgroup barrier
 DEV int wgCompact(Dev& d, const int32_t* src, int n, const uint8_t* flagByValue, int32_t* dst, const int32_t* segOff, int nseg, int32_t* outSegOff);
 DEV void atomicAddI64(int64_t* p, int64_t v);
@@ -155,6 +161,7 @@ DEV void evTabDelete(Dev& d, int idx, bool log) {
   if (log) undoPush(d, U_EVTAB_DEL, idx, 0, 0);
 }
 DEV void evTabInsert(Dev& d, int idx, int job) {
+  d.rs->fairIndexValid = 0;
   d.evTabJob[idx] = job; d.evTabAlive[idx] = 1; d.evIndexOfJob[job] = idx;
   if (idx + 1 > d.rs->evictedTableSize) d.rs->evictedTableSize = idx + 1;
 }
@@ -351,57 +358,81 @@ DEV int selectAtLevel(Dev& d, int job, int32_t prio) {
   a.maskA = d.shapeMask + (size_t)d.jShape[job] * d.cfg.W;
   a.maskB = uniMask(d, job);
   a.level = level;
+  long long t0 = CLK();
+  if (d.progress) { d.progress[2] = 1; d.progress[3]++; }
   int n = wgFirstFit(d, a);
+  if (d.progress) d.progress[2] = 0;
+  d.rs->statClk[6] += CLK() - t0;
   if (n >= 0) { d.pcNode[job] = n; d.pcPap[job] = prio; }
   return n;
 }
 
-// selectNodeForJobWithFairPreemption (nodedb.go:935-1043), literal: evicted jobs by descending Index.
-DEV int selectWithFairPreemption(Dev& d, Ctl& c, int job) {
-  ensureReplay(d, c);
+// selectNodeForJobWithFairPreemption (nodedb.go:935-1043).  The reference walks the evicted jobs by descending Index, adds
+// each one's request to a per-node running total (starting from the node's allocatable at the evicted priority) and
+// returns the node of the first entry at which the total covers the request and the static requirements hold; a node whose
+// static check fails once is skipped from then on (:1000-1004).  Entries of different nodes never interact, so that walk
+// is the maximum, over statically matching nodes, of "the Index at which this node's own entries first cover the request"
+// — fairNodeBest() for one node, evaluated for all nodes at once over a per-node index of the table (ensureFairIndex).
+DEV int fairNodeBest(const Dev& d, const FairArgs& a, int n, int floorIdx) {
   const DevCfg& cf = d.cfg;
-  c.fairStamp++;
-  int stamp = c.fairStamp;
-  const int64_t* req = JREQ(d, job);
-  const uint64_t* mA = d.shapeMask + (size_t)d.jShape[job] * cf.W;
-  const uint64_t* mB = uniMask(d, job);
-  int32_t maxPriority = ASCHED_MIN_PRIORITY;
-  for (int idx = d.rs->evictedTableSize - 1; idx >= 0; idx--) {
+  int k0 = d.fairOff[n], k1 = d.fairOff[n + 1];
+  if (k0 == k1) return -1;
+  uint64_t w = a.maskA[n >> 6];
+  if (a.maskB) w &= a.maskB[n >> 6];
+  if (!((w >> (n & 63)) & 1)) return -1;
+  int64_t av[MAXR];
+  for (int r = 0; r < MAXR; r++) av[r] = r < cf.R ? AL(d, cf.evLevel, r, n) : 0;
+  for (int k = k0; k < k1; k++) {
+    int idx = d.fairEnt[k];
+    if (idx <= floorIdx) return -1;  // descending: cannot beat what the caller already has
     if (!d.evTabAlive[idx]) continue;
-    int ej = d.evTabJob[idx];
+    int ej = d.fairEntJob[k];
     int32_t ep = d.schedAtPrio[ej];
-    if (ep == NO_PRIORITY) { raise(d, ASCHED_ERR_INTERNAL, 600); return -1; }
-    if (ep > d.pcSap[job]) continue;
-    int n = d.jcAssigned[ej];
-    if (n < 0) { raise(d, ASCHED_ERR_INTERNAL, 601); return -1; }
-    int64_t* av = d.accAvail + (size_t)n * cf.R;
-    if (d.accStamp[n] != stamp) {
-      d.accStamp[n] = stamp; d.accStaticFailed[n] = 0;
-      for (int r = 0; r < cf.R; r++) av[r] = AL(d, cf.evLevel, r, n);
-    }
-    if (d.accStaticFailed[n]) continue;
+    if (ep == NO_PRIORITY) return FAIR_BAD_ENTRY;
+    if (ep > a.prio) continue;
     const int64_t* er = JREQ(d, ej);
     bool fits = true;
-    for (int r = 0; r < cf.R; r++) { av[r] += er[r]; if (req[r] > av[r]) fits = false; }
-    if (!fits) continue;
-    bool st = (mA[n >> 6] >> (n & 63)) & 1;
-    if (st && mB) st = (mB[n >> 6] >> (n & 63)) & 1;
-    if (!st) { d.accStaticFailed[n] = 1; continue; }
-    // preempt every considered evicted job of node n (those with Index >= idx, alive, priority <= ours), in scan order
-    for (int i2 = d.rs->evictedTableSize - 1; i2 >= idx; i2--) {
-      if (!d.evTabAlive[i2]) continue;
-      int e2 = d.evTabJob[i2];
-      if (d.jcAssigned[e2] != n) continue;
-      if (d.schedAtPrio[e2] > d.pcSap[job]) continue;
-      int32_t p = d.schedAtPrio[e2];
-      evTabDelete(d, i2, true);
-      if (p > maxPriority) maxPriority = p;
-      c.preList[c.preCount++] = e2;
-    }
-    d.pcNode[job] = n; d.pcPap[job] = maxPriority;
-    return n;
+    for (int r = 0; r < MAXR; r++) if (r < cf.R) { av[r] += er[r]; if (a.req[r] > av[r]) fits = false; }
+    if (fits) return idx;
   }
   return -1;
+}
+DEV void ensureFairIndex(Dev& d);
+DEV int selectWithFairPreemption(Dev& d, Ctl& c, int job) {
+  ensureReplay(d, c);
+  long long t0 = CLK();
+  if (d.progress) { d.progress[2] = 2; d.progress[3]++; }
+  ensureFairIndex(d);
+  if (d.progress) d.progress[2] = 3;
+  const DevCfg& cf = d.cfg;
+  FairArgs a;
+  const int64_t* req = JREQ(d, job);
+  for (int r = 0; r < MAXR; r++) a.req[r] = r < cf.R ? req[r] : 0;
+  a.maskA = d.shapeMask + (size_t)d.jShape[job] * cf.W;
+  a.maskB = uniMask(d, job);
+  a.prio = d.pcSap[job]; a.pad = 0;
+  int idx = wgFairSelect(d, a);
+  if (d.progress) d.progress[2] = 0;
+  d.rs->statClk[7] += CLK() - t0;
+  if (idx < 0) return -1;
+  if (idx >= d.rs->evictedTableSize) { raise(d, ASCHED_ERR_INTERNAL, 600); return -1; }
+  int n = d.jcAssigned[d.evTabJob[idx]];
+  if (n < 0) { raise(d, ASCHED_ERR_INTERNAL, 601); return -1; }
+  // preempt every considered evicted job of node n (Index >= idx, alive, priority <= ours), in scan order (:1012-1023)
+  int32_t maxPriority = ASCHED_MIN_PRIORITY;
+  for (int k = d.fairOff[n]; k < d.fairOff[n + 1]; k++) {
+    int i2 = d.fairEnt[k];
+    if (i2 < idx) break;
+    if (!d.evTabAlive[i2]) continue;
+    int e2 = d.fairEntJob[k];
+    int32_t p = d.schedAtPrio[e2];
+    if (p > a.prio) continue;
+    evTabDelete(d, i2, true);
+    if (p > maxPriority) maxPriority = p;
+    c.preList[c.preCount++] = e2;
+  }
+  d.pcNode[job] = n; d.pcPap[job] = maxPriority;
+  return n;
 }
 
 // selectNodeForJobWithTxnAtPriority (nodedb.go:724-789)
@@ -795,6 +826,7 @@ DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff)
     int top = pqTop(d, c);
     int ref = top >= 0 ? d.pqGctx[top] : -1;
     d.rs->statGenericIters++;
+    if (d.progress) { d.progress[0] = d.rs->loopIterations; d.progress[4] = d.rs->statGenericIters; }
     if (ref == -1) {
       if (limitHit && !resumed && d.rs->terminationReason == 0) { resumed = true; costItResume(d, c, pc); continue; }
       break;

@@ -960,7 +960,9 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   if (counter) *counter = cnt;
   RS.globalTokens = S.globalTokens;
   RS.numScheduledJobs = S.numScheduledJobs; RS.numScheduledGangs = S.numScheduledGangs; RS.numEvictedJobs = S.numEvictedJobs;
-  RS.numNodeQueries = S.numNodeQueries; RS.loopIterations = S.loopIterations; RS.evictedTableSize = S.evictedTableSize;
+  RS.numNodeQueries = S.numNodeQueries; RS.loopIterations = S.loopIterations;
+  if (RS.evictedTableSize != S.evictedTableSize) RS.fairIndexValid = 0;  // the replay added table entries
+  RS.evictedTableSize = S.evictedTableSize;
   RS.statFastIters = S.statFastIters; RS.statScanSteps = S.statScanSteps; RS.statRefills = S.statRefills; RS.statL0Max = S.statL0Max; RS.statFastReplay = S.statFastReplay;
   return pend;
 }

@@ -9,6 +9,7 @@ enum BulkKind {
   B_RESET_GANGSEEN = 1, B_FILTER1, B_NODE_OVER, B_FILTER3, B_GANG_CLOSURE, B_EVICT_APPLY1, B_EVICT_APPLY3, B_KEYS_ALL,
   B_UNBIND, B_RESET_EVTAB, B_CLEAR_UNFEASIBLE, B_INIT_ALLOC, B_POPULATE, B_RESET_JOBS, B_GATHER_SCHED, B_GATHER_PRE,
   B_EVIDX, B_LVL0, B_EVKEYS, B_EVKEYS_OFF, B_EVKEYS_ON, B_EVSUM, B_SNAP, B_EVALIVE,
+  B_FAIR_ZERO, B_FAIR_COUNT, B_FAIR_PSUM, B_FAIR_POFF, B_FAIR_SCATTER, B_FAIR_SORT,
 };
 
 DEV void wgBulk(Dev& d, int kind, int n);  // every element i in [0,n) through bulkElem(), then a workgroup barrier
@@ -163,6 +164,30 @@ DEV void bulkElem(Dev& d, int kind, int i) {
       }
       edge[4] = prev.A; edge[5] = prev.X; edge[6] = prev.Y; edge[7] = (uint64_t)q;
     } break;
+    // per-node index of the evicted table (ensureFairIndex): count -> offsets -> scatter -> per-node sort by descending Index
+    case B_FAIR_ZERO: d.accStamp[i] = 0; break;
+    case B_FAIR_COUNT: { int n = d.jcAssigned[d.evTabJob[i]]; if (n >= 0) atomicAddI32(&d.accStamp[n], 1); } break;
+    case B_FAIR_PSUM: {
+      int C = (c.N + FAIR_CHUNKS - 1) / FAIR_CHUNKS, n0 = i * C, n1 = n0 + C < c.N ? n0 + C : c.N;
+      int sum = 0;
+      for (int n = n0; n < n1; n++) sum += d.accStamp[n];
+      d.fairPart[i] = sum;
+    } break;
+    case B_FAIR_POFF: {
+      int C = (c.N + FAIR_CHUNKS - 1) / FAIR_CHUNKS, n0 = i * C, n1 = n0 + C < c.N ? n0 + C : c.N;
+      int run = d.fairPart[i];
+      for (int n = n0; n < n1; n++) { int cnt = d.accStamp[n]; d.fairOff[n] = run; d.accStamp[n] = run; run += cnt; }
+    } break;
+    case B_FAIR_SCATTER: { int n = d.jcAssigned[d.evTabJob[i]]; if (n >= 0) d.fairEnt[atomicFetchAddI32(&d.accStamp[n], 1)] = i; } break;
+    case B_FAIR_SORT: {
+      int k0 = d.fairOff[i], k1 = d.fairOff[i + 1];
+      for (int a = k0 + 1; a < k1; a++) {
+        int v = d.fairEnt[a], b = a - 1;
+        while (b >= k0 && d.fairEnt[b] < v) { d.fairEnt[b + 1] = d.fairEnt[b]; b--; }
+        d.fairEnt[b + 1] = v;
+      }
+      for (int k = k0; k < k1; k++) d.fairEntJob[k] = d.evTabJob[d.fairEnt[k]];
+    } break;
     case B_LVL0: { bool neg = false; for (int r = 0; r < c.R; r++) neg = neg || AL(d, 0, r, i) < 0; if (neg) d.rs->lvl0NonNeg = 0; } break;
     case B_INIT_ALLOC: {  // fresh NodeDb (scheduling_algo.go:517): AllocatableByPriority[p] = allocatable (node.go:79-85)
       for (int l = 0; l < c.P; l++) for (int r = 0; r < c.R; r++)
@@ -234,7 +259,7 @@ DEV int pqsEvict(Dev& d, Ctl& c, bool phase3) {
   int n = wgCompactFlagged(d, d.ordAll, d.ordAllOff, d.cfg.Q, d.ordAllOff[d.cfg.Q], d.evFlag, d.evList, d.evOff);
   d.rs->numEvictedList = n;
   wgBulk(d, B_RESET_EVTAB, d.rs->evictedTableSize);  // nodeDb.Reset() (nodedb.go:299-313)
-  d.rs->evictedTableSize = 0;
+  d.rs->evictedTableSize = 0; d.rs->fairIndexValid = 0;
   wgBulk(d, B_RESET_GANGSEEN, d.cfg.G);
   d.rs->replayPending = 0;
   wgBulk(d, B_SNAP, d.cfg.Q * d.cfg.R);
@@ -289,6 +314,26 @@ DEV void schedulePass(Dev& d, Ctl& c, bool withQueued, bool skipKey, bool cmpPri
   queueSchedule(d, c, pc, d.uniOff);
 }
 
+// Per-node index of the evicted table (CSR node -> table Indexes, descending) for fair-share preemption.  Every entry below
+// evictedTableSize is indexed, dead or alive (a transaction abort can bring an entry back); rebuilt when the table has grown.
+DEV void ensureFairIndex(Dev& d) {
+  if (d.rs->fairIndexValid) return;
+  int E = d.rs->evictedTableSize, N = d.cfg.N;
+#ifdef ASCHED_HOSTSIM
+  if (getenv("SKIPDBG")) fprintf(stderr, "fair index rebuild E=%d\n", E);
+#endif
+  wgBulk(d, B_FAIR_ZERO, N);
+  wgBulk(d, B_FAIR_COUNT, E);
+  wgBulk(d, B_FAIR_PSUM, FAIR_CHUNKS);
+  int run = 0;
+  for (int i = 0; i < FAIR_CHUNKS; i++) { int v = d.fairPart[i]; d.fairPart[i] = run; run += v; }
+  d.fairOff[N] = run;
+  wgBulk(d, B_FAIR_POFF, FAIR_CHUNKS);
+  wgBulk(d, B_FAIR_SCATTER, E);
+  wgBulk(d, B_FAIR_SORT, N);
+  d.rs->fairIndexValid = 1;
+}
+
 DEV void swapLoopArrays(Dev& d) {
   QueueLoopArrays t;
   t.itEi = d.itEi; t.itQi = d.itQi; t.itStage = d.itStage; t.itJobsSeen = d.itJobsSeen; t.itNext = d.itNext; t.itStashed = d.itStashed;
@@ -329,6 +374,7 @@ DEV void runRound(Dev& d, Ctl& c) {
     d.qEvictable[q] = !(frac <= cf.protectedFraction);
   }
   long long ta = CLK();
+  if (d.progress) d.progress[1] = 1;
   wgBulk(d, B_FILTER1, cf.M);
   d.rs->statClk[0] += CLK() - ta;
   c.fastEvStatic = 1;
@@ -336,6 +382,7 @@ DEV void runRound(Dev& d, Ctl& c) {
   d.rs->lvl0NonNeg = 1;
   wgBulk(d, B_LVL0, cf.N);
   long long tb = CLK();
+  if (d.progress) d.progress[1] = 2;
   c.skipEnter = fastOn(d, c) && d.evMono != nullptr && d.rs->lvl0NonNeg && n1 > 0;
   schedulePass(d, c, true, false, false);
   c.skipEnter = 0;
@@ -344,14 +391,17 @@ DEV void runRound(Dev& d, Ctl& c) {
   c.fastEvStatic = 0;
   if (d.rs->error) return;
   int firstTermination = d.rs->terminationReason;
+  if (d.progress) d.progress[1] = 3;
   wgBulk(d, B_NODE_OVER, cf.N);
   wgBulk(d, B_FILTER3, cf.M);
   int n3 = pqsEvict(d, c, true);
   long long td = CLK();
+  if (d.progress) d.progress[1] = 4;
   if (n3 > 0) schedulePass(d, c, false, true, true);
   if (d.rs->error) return;
   long long te = CLK();
   d.rs->statClk[4] += te - td;
+  if (d.progress) d.progress[1] = 5;
   wgBulk(d, B_UNBIND, cf.M);
   wgBulk(d, B_KEYS_ALL, cf.N);
   d.rs->fastActive = 0;  // unbinding changed priority -2 allocatable behind the fast structure: next round_prepare rebuilds it
@@ -392,7 +442,7 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
       break;
     case CMD_RESET_JOBS:
       wgBulk(d, B_RESET_JOBS, cf.M);
-      d.rs->evictedTableSize = 0; d.rs->txnActive = 0; d.rs->undoCount = 0;
+      d.rs->evictedTableSize = 0; d.rs->fairIndexValid = 0; d.rs->txnActive = 0; d.rs->undoCount = 0;
       break;
     case CMD_PREPARE:
       d.rs->fastActive = 0;
@@ -400,7 +450,7 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
       wgBulk(d, B_RESET_JOBS, cf.M);
       wgBulk(d, B_POPULATE, cf.M);
       wgBulk(d, B_KEYS_ALL, cf.N);
-      d.rs->evictedTableSize = 0;
+      d.rs->evictedTableSize = 0; d.rs->fairIndexValid = 0;
       wgBulk(d, B_CLEAR_UNFEASIBLE, cf.S);
       updateFairShares(d, (const double*)0);
       break;
@@ -494,7 +544,7 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
     case CMD_RESET_EVICTED:
       d.rs->apiDirty = 1;
       wgBulk(d, B_RESET_EVTAB, cf.M);
-      d.rs->evictedTableSize = 0;
+      d.rs->evictedTableSize = 0; d.rs->fairIndexValid = 0;
       break;
     case CMD_TXN_BEGIN: txnBegin(d, c.txn); break;
     case CMD_TXN_COMMIT: txnCommit(d, c.txn); break;

@@ -11,14 +11,32 @@
 #include <cstdlib>
 #include <string>
 #include <vector>
+#include <chrono>
 #include "../../armada_amd/csrc/round_run.h"
+// optional per-primitive wall-clock profile of the serial build (HOSTSIM_PROF=1): where would a wide device primitive matter?
+struct HsProf { double t[40]; long n[40]; bool on; HsProf() : on(getenv("HOSTSIM_PROF") != nullptr) { for (int i = 0; i < 40; i++) { t[i] = 0; n[i] = 0; } }
+  ~HsProf() { if (on) for (int i = 0; i < 40; i++) if (n[i]) fprintf(stderr, "hsprof[%d] calls=%ld total=%.3fs\n", i, n[i], t[i]); } };
+static HsProf g_prof;
+struct HsScope { int k; std::chrono::steady_clock::time_point t0; HsScope(int k_) : k(k_) { if (g_prof.on) t0 = std::chrono::steady_clock::now(); }
+  ~HsScope() { if (g_prof.on) { g_prof.t[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); g_prof.n[k]++; } } };
 
 // ---- serial versions of the workgroup primitives
 DEV void atomicAddI64(int64_t* p, int64_t v) { *p += v; }
 DEV void atomicAddI32(int32_t* p, int32_t v) { *p += v; }
 DEV void atomicOrI32(int32_t* p, int32_t v) { *p |= v; }
+DEV int atomicFetchAddI32(int32_t* p, int32_t v) { int o = *p; *p += v; return o; }
+DEV int wgFairSelect(Dev& d, const FairArgs& a) {
+  HsScope prof(39);
+  int best = -1;
+  static long calls = 0, maxSeg = 0, sumMax = 0;
+  long callMax = 0;
+  for (int n = 0; n < d.cfg.N; n++) { int v = fairNodeBest(d, a, n, -1); if (v > best) best = v; long L = d.fairOff[n + 1] - d.fairOff[n]; if (L > callMax) callMax = L; }
+  if (g_prof.on) { calls++; sumMax += callMax; if (callMax > maxSeg) maxSeg = callMax; if ((calls & 4095) == 0) fprintf(stderr, "fair calls=%ld max segment=%ld avg max=%.1f E=%d\n", calls, maxSeg, (double)sumMax / calls, d.rs->evictedTableSize); }
+  return best;
+}
 
 DEV int wgFirstFit(Dev& d, const ScanArgs& a) {
+  HsScope prof(38);
   const DevCfg& c = d.cfg;
   uint64_t best = ~0ull;
   d.rs->numScans++;
@@ -33,7 +51,7 @@ DEV int wgFirstFit(Dev& d, const ScanArgs& a) {
   if (best == ~0ull) return -1;
   return d.nodeByRank[best & ((1ull << c.idxBits) - 1)];
 }
-DEV void wgBulk(Dev& d, int kind, int n) { for (int i = 0; i < n; i++) bulkElem(d, kind, i); }
+DEV void wgBulk(Dev& d, int kind, int n) { HsScope prof(kind); for (int i = 0; i < n; i++) bulkElem(d, kind, i); }
 DEV int wgCompactFlagged(Dev& d, const int32_t* order, const int32_t* segOff, int nseg, int n, const uint8_t* flag, int32_t* dst, int32_t* outSegOff) {
   int cnt = 0, q = 0;
   for (int p = 0; p <= n; p++) {
