@@ -67,7 +67,7 @@ template <class A> __device__ static inline void helpIssue(int op, const A* args
 }
 __device__ static inline unsigned long long helpWait() {  // whole control wave, uniformly (no lane-divergent spin)
   HelpBox* b = g_box;
-  unsigned int want = (unsigned)g_H * (CTL_THREADS / 64), spins = 0;
+  unsigned int want = (unsigned)g_H, spins = 0;
   for (;;) {
     unsigned int dn = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&b->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
     if (dn == want) break;
@@ -585,22 +585,42 @@ template <class A> __device__ static inline A helpArgs(HelpBox* b) {
   for (int i = 0; i < (int)(sizeof(A) / 8); i++) u.w[i] = __hip_atomic_load(&b->args[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return u.a;
 }
-// Every wave of a helper workgroup runs this loop on its own: all lanes poll the command word together (one uniform load,
-// the loop branch is scalar), take the wave's share of the nodes and add 1 to the completion counter.  There is no
-// workgroup barrier and no lane-divergent loop in here on purpose: a "thread 0 polls, the others wait at the barrier" loop
-// gets rotated by the compiler so that the polling lane's tail and head merge across the back edge, and the rest of its wave
+// Helper workgroup.  Wave 0 polls the command word in HBM (backing off to ~30 us between polls when the round has not asked
+// for anything for a while, so an idle helper costs no measurable fabric traffic) and republishes it in LDS; the other waves
+// poll that LDS word.  Each wave takes its share of the nodes, folds its result into an LDS word, and the wave that
+// arrives last sends the workgroup's result and ONE completion increment to HBM.  Every loop in here is wave-uniform and
+// there is no workgroup barrier inside the loop on purpose: a "thread 0 polls, the others wait at the barrier" loop gets
+// rotated by the compiler so that the polling lane's tail and head merge across the back edge, and the rest of its wave
 // then runs ahead through the barriers without it.
+__shared__ unsigned long long g_hCmd, g_hMin, g_hMax;
+__shared__ unsigned int g_hArrived;
+__device__ static inline unsigned long long waveUniform64(unsigned long long v) {
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
 __device__ static void helperMain(const Dev& d, HelpBox* b, int H) {
+  if (threadIdx.x == 0) { g_hCmd = 0; g_hMin = ~0ull; g_hMax = 0; g_hArrived = 0; }
+  __syncthreads();
   unsigned long long seen = 0;
   int tid = (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x, nthreads = (H + 1) * (int)blockDim.x;
-  int lane = threadIdx.x & 63;
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
   for (;;) {
     unsigned long long g;
-    for (;;) {
-      unsigned long long v = __hip_atomic_load(&b->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      g = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-      if (g != seen) break;
-      __builtin_amdgcn_s_sleep(2);
+    if (wave == 0) {
+      unsigned int idle = 0;
+      for (;;) {
+        g = waveUniform64(__hip_atomic_load(&b->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (g != seen) break;
+        idle++;
+        if (idle < 2048) __builtin_amdgcn_s_sleep(2);
+        else for (int k = 0; k < 8; k++) __builtin_amdgcn_s_sleep(127);
+      }
+      if (lane == 0) __hip_atomic_store(&g_hCmd, g, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      for (;;) {
+        g = waveUniform64(__hip_atomic_load(&g_hCmd, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (g != seen) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the round state written before the command was published
     seen = g;
@@ -610,13 +630,25 @@ __device__ static void helperMain(const Dev& d, HelpBox* b, int H) {
     if (op == OP_SCAN) {
       ScanArgs a = helpArgs<ScanArgs>(b);
       unsigned long long v = scanPart(d, a, tid, nthreads);
-      if (lane == 0 && v != ~0ull) __hip_atomic_fetch_min(&b->result, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0 && v != ~0ull) __hip_atomic_fetch_min(&g_hMin, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (op == OP_FAIR) {
       FairArgs a = helpArgs<FairArgs>(b);
       int v = fairPart(d, a, tid, nthreads);
-      if (lane == 0 && v >= 0) __hip_atomic_fetch_max(&b->result, (unsigned long long)(v + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0 && v >= 0) __hip_atomic_fetch_max(&g_hMax, (unsigned long long)(v + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    if (lane == 0) __hip_atomic_fetch_add(&b->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) {
+      unsigned int before = __hip_atomic_fetch_add(&g_hArrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (before == (unsigned)(nw - 1)) {  // last wave of the workgroup: forward the folded result, reset the LDS words for the next command
+        unsigned long long mn = __hip_atomic_load(&g_hMin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        unsigned long long mx = __hip_atomic_load(&g_hMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&g_hMin, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&g_hMax, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&g_hArrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (op == OP_SCAN && mn != ~0ull) __hip_atomic_fetch_min(&b->result, mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (op == OP_FAIR && mx != 0) __hip_atomic_fetch_max(&b->result, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&b->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 
@@ -790,11 +822,11 @@ static HelpBox* g_helpBox = nullptr;
 static int g_helpers = -1;
 static int plat_run_control(Dev& dev, int cmd) {
   if (!g_ev0) { (void)hipEventCreate(&g_ev0); (void)hipEventCreate(&g_ev1); }
-  if (g_helpers < 0) {  // helper workgroups of a round launch: one per CU, a quarter of the device by default (ASCHED_HELPERS overrides; 0 = none)
+  if (g_helpers < 0) {  // helper workgroups of a round launch: one per CU, an eighth of the device by default — measured flat between 15 and 63 (ASCHED_HELPERS overrides; 0 = none)
     int cus = 0, dev_id = 0;
     (void)hipGetDevice(&dev_id);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
-    g_helpers = cus >= 8 ? cus / 4 - 1 : 0;
+    g_helpers = cus >= 16 ? cus / 8 - 1 : 0;
     if (const char* e = getenv("ASCHED_HELPERS")) g_helpers = atoi(e);
     if (g_helpers > cus - 1) g_helpers = cus - 1;
     if (g_helpers < 0) g_helpers = 0;
