@@ -8,7 +8,7 @@ import sys
 def main(db, out=None):
     c = sqlite3.connect(db)
     rows = c.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), max(vgpr_count), max(sgpr_count), max(lds_size), max(grid_x), max(workgroup_x) "
-                     "from kernels group by name order by sum(duration) desc").fetchall()
+                     "from kernels group by name, grid_x order by sum(duration) desc").fetchall()  # per (kernel, grid): the round launch of k_control (1 + helpers workgroups) apart from its 1-workgroup command launches
     tot = sum(r[2] for r in rows) or 1
     lines = ["# rocprofv3 --kernel-trace --stats summary (durations in ms)",
              f"# source: {db}", "name,calls,total_ms,avg_ms,min_ms,max_ms,pct,vgpr,sgpr,lds_bytes,grid_x,wg_x"]
