@@ -13,6 +13,7 @@
 #define MAXK 6
 #define MAXP 16
 #define MAXPC 32
+#define MAXAWAY 32     // away node types over all priority classes
 #define MAXE 2        // non-indexed resource columns the level-0 fast structure carries per entry
 #define SMAX 512      // scheduling-key shapes with a cached base candidate (LDS)
 #define L0CAP 1024    // live dirty nodes held in LDS
@@ -47,6 +48,10 @@ struct DevCfg {
   int64_t totalResources[MAXR];
   int64_t maxToSchedule[MAXR];
   int evLevel;  // level index of EvictedPriority (always 0)
+  // away node types (nodedb.go:613-627): CSR per priority class; an entry whose well-known node type has no taints is skipped (:703-706)
+  int32_t pcAwayOff[MAXPC + 1];
+  int32_t awayPrio[MAXAWAY];
+  uint8_t awayUsable[MAXAWAY];
 };
 
 // One job as the fast path reads it: a single 128-byte burst (16 lanes x 8 B) instead of 12 dependent array reads.
@@ -97,6 +102,7 @@ struct RoundScalars {
   int32_t fastOverflow;      // L0 overflowed: structure dropped for the rest of the round
   int32_t replayPending;     // the eviction-order replay (evicted-table Index assignment) has been deferred: nothing has read it yet
   int32_t statFastIters, statGenericIters, statScanSteps, statRefills, statL0Max, statFastReplay;
+  int32_t awayRowPlus1;      // an away attempt is in progress: static mask row (+1) that replaces the job's home shape row
   int32_t fairIndexValid;    // the per-node index of the evicted table (fairOff/fairEnt) describes the current table
   int64_t statSeg[8];        // (profiling builds) shader-clock ticks per segment of a fast iteration
   int64_t statClk[8];        // shader-clock ticks per phase of the round (device builds): evict, replay, pass 1, oversub evict, pass 2, unbind+results
@@ -129,6 +135,7 @@ struct Dev {
   uint8_t* jAligned;     // [M] request is a multiple of the index resolution on every indexed column
   int32_t *gangOff, *gangJobs;  // CSR of (queue,gang) -> member jobs (jobRepo.GetGangJobsByGangId)
   int64_t* shapeReq;     // [S][R]
+  int32_t* awayRowOff;   // [S+1] rows S + awayRowOff[s] + k of shapeMask: shape s with the tolerations of its class's k-th away node type added
   // ---- job dynamic state
   int32_t* schedAtPrio;  // [M] nodeDb.scheduledAtPriorityByJobId
   int32_t* jobNode;      // [M] node the job currently owns resources on (AllocatedByJobId), -1

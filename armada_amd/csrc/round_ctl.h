@@ -339,6 +339,8 @@ DEV bool packedLess(const PackedKey& a, uint32_t an, const PackedKey& b, uint32_
   return a.A != b.A ? a.A < b.A : a.X != b.X ? a.X < b.X : a.Y != b.Y ? a.Y < b.Y : an < bn;
 }
 
+// static mask of the job's scheduling-key shape; during an away attempt the row with the away node type's tolerations added
+DEV const uint64_t* shapeMaskOf(Dev& d, int job) { int row = d.rs->awayRowPlus1 ? d.rs->awayRowPlus1 - 1 : d.jShape[job]; return d.shapeMask + (size_t)row * d.cfg.W; }
 DEV const uint64_t* uniMask(Dev& d, int job) { int v = d.jcUniValue[job]; return v >= 0 ? d.labelMask + (size_t)v * d.cfg.W : (const uint64_t*)0; }
 
 // selectNodeForPodAtPriority + selectNodeForPodWithItAtPriority (nodedb.go:840-928): first node, in index order, passing
@@ -348,14 +350,14 @@ DEV int selectAtLevel(Dev& d, int job, int32_t prio) {
   d.rs->numNodeQueries++;
   int level = levelOf(d.cfg, prio);
   if (level < 0) { raise(d, ASCHED_ERR_INTERNAL, 500); return -1; }
-  if (level == 0 && d.jcUniValue[job] < 0) {
+  if (level == 0 && d.jcUniValue[job] < 0 && !d.rs->awayRowPlus1) {
     int fn = fastSelectLevel0(d, job);
     if (fn != -2) { if (fn >= 0) { d.pcNode[job] = fn; d.pcPap[job] = prio; } return fn; }
   }
   ScanArgs a;
   const int64_t* req = JREQ(d, job);
   for (int r = 0; r < MAXR; r++) a.req[r] = r < d.cfg.R ? req[r] : 0;
-  a.maskA = d.shapeMask + (size_t)d.jShape[job] * d.cfg.W;
+  a.maskA = shapeMaskOf(d, job);
   a.maskB = uniMask(d, job);
   a.level = level;
   long long t0 = CLK();
@@ -408,7 +410,7 @@ DEV int selectWithFairPreemption(Dev& d, Ctl& c, int job) {
   FairArgs a;
   const int64_t* req = JREQ(d, job);
   for (int r = 0; r < MAXR; r++) a.req[r] = r < cf.R ? req[r] : 0;
-  a.maskA = d.shapeMask + (size_t)d.jShape[job] * cf.W;
+  a.maskA = shapeMaskOf(d, job);
   a.maskB = uniMask(d, job);
   a.prio = d.pcSap[job]; a.pad = 0;
   int idx = wgFairSelect(d, a);
@@ -483,8 +485,18 @@ DEV int selectNodeForJob(Dev& d, Ctl& c, int job) {
   }
   if (d.cfg.hasAway) {
     bool awayDisabled = d.cfg.disableAway || (d.jGang[job] >= 0 && d.cfg.disableGangAway);
-    // away node types (:613-627) need per-(class, well-known type) masks: not implemented on the device yet
-    if (!awayDisabled) { /* host refuses configs that reach this (jobs_set), see DESIGN.md */ }
+    if (!awayDisabled) {
+      int pc = d.jPc[job], s = d.jShape[job];
+      for (int k = d.cfg.pcAwayOff[pc]; k < d.cfg.pcAwayOff[pc + 1]; k++) {  // selectNodeForJobWithTxnAndAwayNodeType :677-722
+        if (!d.cfg.awayUsable[k]) continue;  // no extra taints to tolerate (:703-706)
+        d.rs->awayRowPlus1 = d.cfg.S + d.awayRowOff[s] + (k - d.cfg.pcAwayOff[pc]) + 1;
+        d.pcSap[job] = d.cfg.awayPrio[k];      // :719 (stays at the last away priority when every attempt fails)
+        int n = selectAtPriority(d, c, job);
+        d.rs->awayRowPlus1 = 0;
+        if (d.rs->error) return -1;
+        if (n >= 0) { d.pcMethod[job] = ASCHED_METHOD_AWAY; return n; }
+      }
+    }
   }
   return -1;
 }

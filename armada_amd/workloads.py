@@ -44,6 +44,7 @@ class Workload:
     queue_burst: int = 2 ** 62
     rate_inf: bool = True
     meta: dict = field(default_factory=dict)
+    node_taints: Optional[list] = None   # per node: list of (key, value, effect)
 
     @property
     def num_nodes(self):
@@ -157,8 +158,9 @@ def config3(n_nodes=100_000, n_jobs=1_000_000, n_queues=64, seed=SEED, gangs=0, 
     return wl
 
 
-def small_random(n_nodes=64, n_jobs=600, n_queues=5, seed=1, occupied=0.6, gangs=4, burst=None) -> Workload:
-    """a small adversarially mixed workload for HIP-vs-oracle differential tests (preemption, gangs, limits)"""
+def small_random(n_nodes=64, n_jobs=600, n_queues=5, seed=1, occupied=0.6, gangs=4, burst=None, away=False) -> Workload:
+    """a small adversarially mixed workload for HIP-vs-oracle differential tests (preemption, gangs, limits; away=True: a quarter
+    of the nodes carry a well-known node type's taint and two priority classes may run there at a reduced priority)"""
     rng = np.random.Generator(np.random.PCG64(seed))
     pcs = [(0, True), (1, True), (3, False)]
     pc_prio = np.array([p for p, _ in pcs])
@@ -176,6 +178,11 @@ def small_random(n_nodes=64, n_jobs=600, n_queues=5, seed=1, occupied=0.6, gangs
                    q_req, q_queue, q_pc, pc_prio, weight, {}, gangs=gangs, rng=rng)
     if burst:
         wl.global_burst, wl.queue_burst, wl.rate_inf = burst[0], burst[1], False
+    if away:
+        tainted = rng.random(n_nodes) < 0.25
+        wl.node_taints = [[(7, 1, 1)] if t else [] for t in tainted]      # (key, value, NoSchedule)
+        wl.config.wkt_taints = [[(7, 1, 1)], [(7, -1, 1)]]                 # type 0: exact value, type 1: wildcard value
+        wl.config.pc_away = [[], [(0, 0)], [(2, 1), (1, 0)]]                # pc1 away at priority 0; pc2 away at 2 then at 1
     return wl
 
 
@@ -223,7 +230,7 @@ def _assemble(name, cfg, node_total, run_req, run_node, run_queue, run_pc, run_p
 def load(lib, wl: Workload) -> Scheduler:
     """create a handle, upload nodes and jobs (untimed input build)"""
     s = Scheduler(lib, wl.config)
-    s.nodes_upsert(wl.node_total)
+    s.nodes_upsert(wl.node_total, taints=wl.node_taints)
     s.jobs_set(wl.job_req, queue=wl.job_queue, pc=wl.job_pc, submit_time=wl.job_submit, node=wl.job_node,
                scheduled_at_priority=wl.job_run_prio, run_timestamp=wl.job_run_ts, gang_id=wl.job_gang, gang_cardinality=wl.job_gang_card)
     return s

@@ -68,6 +68,19 @@ def test_random_rounds_match_oracle(hip_lib, oracle_lib, seed):
         res.append(s.schedule_round())
     scenario.assert_same_round(res[0], res[1])
 
+@pytest.mark.parametrize("seed", range(8))
+def test_random_rounds_with_away_node_types_match_oracle(hip_lib, oracle_lib, seed):
+    """away node types (nodedb.go:613-627, 677-722): tainted nodes reachable only through a priority class's AwayNodeTypes"""
+    wl = W.small_random(n_nodes=16 + seed * 7, n_jobs=300 + seed * 40, n_queues=2 + seed % 4, seed=100 + seed, occupied=[0.5, 0.9, 1.0][seed % 3],
+                        gangs=seed % 3, away=True)
+    res = []
+    for lib in (oracle_lib, hip_lib):
+        s = W.load(lib, wl)
+        W.prepare(s, wl)
+        res.append(s.schedule_round())
+    scenario.assert_same_round(res[0], res[1])
+    assert any(m == 5 for m in res[0].scheduled_method.values()) or seed % 3 == 0  # ASCHED_METHOD_AWAY exercised
+
 
 def test_fit_select_batch_config2(hip_lib, oracle_lib):
     """BASELINE config 2: 10k nodes, 100k jobs, first feasible node per job against a fixed state, bit-exact node ids."""
