@@ -105,9 +105,9 @@ __device__ static unsigned long long scanPart(const Dev& d, const ScanArgs& a, i
     if (a.maskB) w &= a.maskB[n >> 6];
     if (!((w >> (n & 63)) & 1)) continue;
     unsigned long long k = keys[n];
-    if (k >= best) continue;
+    if (k >= best || k < a.lowBound) continue;
     bool fits = true;
-    for (int r = 0; r < c.R; r++) fits = fits && (a.req[r] <= plane[(size_t)r * c.Npad + n]);
+    if (!a.noFit) for (int r = 0; r < c.R; r++) fits = fits && (a.req[r] <= plane[(size_t)r * c.Npad + n]);
     if (fits) best = k;
   }
   return waveMin64(best);

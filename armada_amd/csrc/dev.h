@@ -13,6 +13,7 @@
 #define MAXK 6
 #define MAXP 16
 #define MAXPC 32
+#define LIT_TMAX 64     // node types one requirement class may match on the literal iteration path
 #define MAXAWAY 32     // away node types over all priority classes
 #define MAXE 2        // non-indexed resource columns the level-0 fast structure carries per entry
 #define SMAX 512      // scheduling-key shapes with a cached base candidate (LDS)
@@ -115,6 +116,9 @@ struct QueueLoopArrays {
   double *pqProposed, *pqCurrent, *pqBudget, *pqSize; int32_t *pqPcPrio, *pqSchedPrio, *pqGctx; uint8_t* pqInHeap;
 };
 
+// NodeTypeIterator state (nodeiteration.go:211-251): current lower bound (raw quantities), its packed form, the node it yielded last
+struct LitIt { int64_t lb[MAXK]; uint64_t bound; int32_t head; int32_t type; };
+
 struct Dev {
   DevCfg cfg;
   // ---- nodes
@@ -135,6 +139,13 @@ struct Dev {
   uint8_t* jAligned;     // [M] request is a multiple of the index resolution on every indexed column
   int32_t *gangOff, *gangJobs;  // CSR of (queue,gang) -> member jobs (jobRepo.GetGangJobsByGangId)
   int64_t* shapeReq;     // [S][R]
+  // literal node iteration (round_ctl.h selectAtLevelLiteral) for mask rows whose merged iteration order is not the packed-key order
+  uint8_t* rowLiteral;   // [S + away rows]
+  int32_t* rowTypeOff;   // [S + away rows + 1] CSR: populated node types matching the row's requirement class
+  int32_t* rowTypes;
+  uint64_t* typeMask;    // [T][W] nodes of each node type
+  int32_t* nodeIdRank;   // [N] lexicographic rank of the node id (nodeTypesIteratorPQ.less tie-break)
+  struct LitIt* lit;     // [LIT_TMAX] per-type iterator state of the query in progress
   int32_t* awayRowOff;   // [S+1] rows S + awayRowOff[s] + k of shapeMask: shape s with the tolerations of its class's k-th away node type added
   // ---- job dynamic state
   int32_t* schedAtPrio;  // [M] nodeDb.scheduledAtPriorityByJobId

@@ -29,7 +29,7 @@
 
 // ------------------------------------------------------------------------------------------------
 // workgroup primitives (implemented differently per build)
-struct ScanArgs { int64_t req[MAXR]; const uint64_t* maskA; const uint64_t* maskB; int level; };
+struct ScanArgs { int64_t req[MAXR]; const uint64_t* maskA; const uint64_t* maskB; int level; int noFit; uint64_t lowBound; };  // min key >= lowBound among masked nodes (that fit req at level, unless noFit)
 
 struct FairArgs { int64_t req[MAXR]; const uint64_t* maskA; const uint64_t* maskB; int32_t prio; int32_t pad; };
 #define FAIR_CHUNKS 256
@@ -346,10 +346,105 @@ DEV const uint64_t* uniMask(Dev& d, int job) { int v = d.jcUniValue[job]; return
 // selectNodeForPodAtPriority + selectNodeForPodWithItAtPriority (nodedb.go:840-928): first node, in index order, passing
 // static + dynamic checks.  Under the alignment conditions checked at upload (DESIGN.md "Exactness conditions") the merged
 // iterator order of nodeiteration.go equals the order of the packed key, so this is one argmin scan.
+// ---- literal node iteration.  When a request is not a multiple of the index resolution the skip-scan of NodeTypeIterator
+// (nodeiteration.go:318-382) can jump over fitting nodes, and when a class matches several node types whose allocatable is not
+// resolution-aligned the heap merge of NodeTypesIterator (:74-185, raw quantities then node id) is not the packed-key order.
+// For such mask rows the iterators are restated step by step; the only data-parallel piece is "next node of this type at or
+// after a key" (one plane pass through wgFirstFit with noFit).
+DEV int64_t litCeilDiv(int64_t a, int64_t b) { int64_t q = a / b; return (a % b != 0 && a > 0) ? q + 1 : q; }  // b > 0
+// packed form of memdb LowerBound(NodeIndexKey(type, b)) within one node type: first packed key whose raw quantity tuple is >= b
+DEV uint64_t litBound(const DevCfg& c, const int64_t* b) {
+  uint64_t acc = 0; int bits = 0; bool stop = false;
+  for (int i = 0; i < c.K; i++) {
+    int w = c.keyWidth[i];
+    if (stop) { acc <<= w; bits += w; continue; }
+    int64_t res = c.indexedRes[i];
+    bool aligned = b[i] % res == 0;
+    int64_t f = (aligned ? b[i] / res : litCeilDiv(b[i], res)) - c.keyLo[i];
+    if (f < 0) { f = 0; stop = true; }                       // every node is above b at this column: later columns do not matter
+    else if (w < 63 && f >= ((int64_t)1 << w)) {             // no node reaches b here with this prefix: the prefix has to be larger
+      if (bits == 0) return ~0ull;
+      acc += 1;
+      if (bits < 64 && acc >= (1ull << bits)) return ~0ull;
+      f = 0; stop = true;
+    } else if (!aligned) stop = true;                        // a key column (multiple of the resolution) is never equal to an unaligned b
+    acc = (acc << w) | (uint64_t)f; bits += w;
+  }
+  return acc << c.idxBits;
+}
+DEV bool litLbLess(const DevCfg& c, const int64_t* a, const int64_t* b) {  // bytes.Compare(it.key, it.newKey) == -1 (:364)
+  for (int i = 0; i < c.K; i++) { if (a[i] < b[i]) return true; if (a[i] > b[i]) return false; }
+  return false;
+}
+// NodeTypeIterator.NextNode (:318-382)
+DEV void litAdvance(Dev& d, int level, LitIt& it, const int64_t* ireq) {
+  const DevCfg& c = d.cfg;
+  for (;;) {
+    if (it.bound == ~0ull) { it.head = -1; return; }
+    ScanArgs a;
+    for (int r = 0; r < MAXR; r++) a.req[r] = 0;
+    a.maskA = d.typeMask + (size_t)it.type * c.W; a.maskB = nullptr; a.level = level; a.noFit = 1; a.lowBound = it.bound;
+    int n = wgFirstFit(d, a);
+    if (n < 0) { it.head = -1; return; }
+    uint64_t key = KEY(d, level, n);
+    int64_t nlb[MAXK];
+    bool yielded = false, sought = false;
+    for (int i = 0; i < c.K; i++) {
+      int64_t nodeQ = AL(d, level, c.indexedCol[i], n);
+      nlb[i] = (nodeQ / c.indexedRes[i]) * c.indexedRes[i];  // roundQuantityToResolution (encoding.go:56-58)
+      if (nodeQ < ireq[i]) {
+        for (int j = i; j < c.K; j++) nlb[j] = ireq[j];
+        if (litLbLess(c, it.lb, nlb)) { for (int j = 0; j < c.K; j++) it.lb[j] = nlb[j]; it.bound = litBound(c, nlb); sought = true; }
+        break;  // else: "new lower-bound is not greater than current bound" (:371-376): keep scanning linearly
+      } else if (i == c.K - 1) yielded = true;
+    }
+    if (!sought) it.bound = key == ~0ull ? ~0ull : key + 1;  // memdbIterator.Next(): strictly after this node
+    if (yielded) { it.head = n; return; }
+  }
+}
+DEV bool litNodeLess(Dev& d, int level, int a, int b) {  // nodeTypesIteratorPQ.less (:170-185)
+  for (int i = 0; i < d.cfg.K; i++) {
+    int64_t qa = AL(d, level, d.cfg.indexedCol[i], a), qb = AL(d, level, d.cfg.indexedCol[i], b);
+    if (qa < qb) return true;
+    if (qa > qb) return false;
+  }
+  return d.nodeIdRank[a] < d.nodeIdRank[b];
+}
+// selectNodeForPodAtPriority + selectNodeForPodWithItAtPriority (nodedb.go:840-928) over the literal iterators
+DEV int selectAtLevelLiteral(Dev& d, int job, int32_t prio, int level, int row) {
+  const DevCfg& c = d.cfg;
+  const int64_t* req = JREQ(d, job);
+  int64_t ireq[MAXK];
+  for (int i = 0; i < c.K; i++) ireq[i] = req[c.indexedCol[i]];
+  int t0 = d.rowTypeOff[row], nT = d.rowTypeOff[row + 1] - t0;
+  if (nT > LIT_TMAX) { raise(d, ASCHED_ERR_UNSUPPORTED, 510); return -1; }
+  for (int k = 0; k < nT; k++) {  // NewNodeTypesIterator (:84-123)
+    LitIt& it = d.lit[k];
+    it.type = d.rowTypes[t0 + k];
+    for (int i = 0; i < MAXK; i++) it.lb[i] = i < c.K ? ireq[i] : 0;
+    it.bound = litBound(c, it.lb);
+    litAdvance(d, level, it, ireq);
+  }
+  const uint64_t* mA = shapeMaskOf(d, job);
+  const uint64_t* mB = uniMask(d, job);
+  for (;;) {
+    int best = -1;
+    for (int k = 0; k < nT; k++) if (d.lit[k].head >= 0 && (best < 0 || litNodeLess(d, level, d.lit[k].head, d.lit[best].head))) best = k;
+    if (best < 0) return -1;
+    int n = d.lit[best].head;
+    litAdvance(d, level, d.lit[best], ireq);  // NextNode (:134-149) advances the popped iterator before returning the node
+    bool st = (mA[n >> 6] >> (n & 63)) & 1;
+    if (st && mB) st = (mB[n >> 6] >> (n & 63)) & 1;
+    if (st && fitsAlloc(d, req, level, n)) { d.pcNode[job] = n; d.pcPap[job] = prio; return n; }
+  }
+}
+
 DEV int selectAtLevel(Dev& d, int job, int32_t prio) {
   d.rs->numNodeQueries++;
   int level = levelOf(d.cfg, prio);
   if (level < 0) { raise(d, ASCHED_ERR_INTERNAL, 500); return -1; }
+  int row = d.rs->awayRowPlus1 ? d.rs->awayRowPlus1 - 1 : d.jShape[job];
+  if (d.rowLiteral && d.rowLiteral[row]) return selectAtLevelLiteral(d, job, prio, level, row);
   if (level == 0 && d.jcUniValue[job] < 0 && !d.rs->awayRowPlus1) {
     int fn = fastSelectLevel0(d, job);
     if (fn != -2) { if (fn >= 0) { d.pcNode[job] = fn; d.pcPap[job] = prio; } return fn; }
@@ -359,7 +454,7 @@ DEV int selectAtLevel(Dev& d, int job, int32_t prio) {
   for (int r = 0; r < MAXR; r++) a.req[r] = r < d.cfg.R ? req[r] : 0;
   a.maskA = shapeMaskOf(d, job);
   a.maskB = uniMask(d, job);
-  a.level = level;
+  a.level = level; a.noFit = 0; a.lowBound = 0;
   long long t0 = CLK();
   if (d.progress) { d.progress[2] = 1; d.progress[3]++; }
   int n = wgFirstFit(d, a);

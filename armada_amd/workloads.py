@@ -45,6 +45,12 @@ class Workload:
     rate_inf: bool = True
     meta: dict = field(default_factory=dict)
     node_taints: Optional[list] = None   # per node: list of (key, value, effect)
+    node_labels: Optional[list] = None   # per node: list of (key, value)
+    node_allocatable: Optional[np.ndarray] = None
+    node_id_rank: Optional[np.ndarray] = None
+    job_req_class: Optional[np.ndarray] = None
+    class_tolerations: Optional[list] = None   # per class: list of (key, op, value, effect)
+    class_selectors: Optional[list] = None     # per class: list of (key, value)
 
     @property
     def num_nodes(self):
@@ -158,7 +164,7 @@ def config3(n_nodes=100_000, n_jobs=1_000_000, n_queues=64, seed=SEED, gangs=0, 
     return wl
 
 
-def small_random(n_nodes=64, n_jobs=600, n_queues=5, seed=1, occupied=0.6, gangs=4, burst=None, away=False) -> Workload:
+def small_random(n_nodes=64, n_jobs=600, n_queues=5, seed=1, occupied=0.6, gangs=4, burst=None, away=False, ragged=False) -> Workload:
     """a small adversarially mixed workload for HIP-vs-oracle differential tests (preemption, gangs, limits; away=True: a quarter
     of the nodes carry a well-known node type's taint and two priority classes may run there at a reduced priority)"""
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -178,6 +184,35 @@ def small_random(n_nodes=64, n_jobs=600, n_queues=5, seed=1, occupied=0.6, gangs
                    q_req, q_queue, q_pc, pc_prio, weight, {}, gangs=gangs, rng=rng)
     if burst:
         wl.global_burst, wl.queue_burst, wl.rate_inf = burst[0], burst[1], False
+    if ragged:
+        # nothing resolution-aligned: several node types (an indexed label, a taint), allocatable below total by odd amounts, node ids
+        # in a different order than node indexes, requests off the index grid, classes with tolerations / selectors.  Exercises
+        # the literal NodeTypeIterator / NodeTypesIterator restatement (nodeiteration.go) instead of the packed-key argmin.
+        wl.config.indexed_label_keys = [3]
+        lab = rng.integers(0, 4, size=n_nodes)
+        wl.node_labels = [[(3, int(v))] if v < 3 else [] for v in lab]
+        taint = rng.random(n_nodes) < 0.2
+        wl.node_taints = [[(9, 1, 1)] if t else [] for t in taint]
+        alloc = wl.node_total.copy()
+        alloc[:, CPU] -= rng.integers(0, 24, size=n_nodes) * 137
+        alloc[:, MEM] -= rng.integers(0, 1000, size=n_nodes) * 1000003
+        wl.node_allocatable = np.maximum(alloc, 0)
+        wl.node_id_rank = rng.permutation(n_nodes).astype(np.int32)
+        m = wl.num_jobs
+        odd = rng.random(m) < 0.5
+        wl.job_req[odd, CPU] += rng.integers(1, 8, size=int(odd.sum())) * 125
+        oddm = rng.random(m) < 0.3
+        wl.job_req[oddm, MEM] += rng.integers(1, 100, size=int(oddm.sum())) * 1000
+        for g in np.unique(wl.job_gang[wl.job_gang >= 0]):      # gang members share one shape
+            mem = np.nonzero(wl.job_gang == g)[0]
+            wl.job_req[mem] = wl.job_req[mem[0]]
+        wl.class_tolerations = [[], [(9, 1, 0, 0)], [], [(9, 0, 1, 1)]]           # class 1: Exists on key 9; class 3: key 9 == 1, NoSchedule
+        wl.class_selectors = [[], [], [(3, 1)], [(3, 2)]]
+        cls = rng.choice(4, size=m, p=[0.5, 0.25, 0.15, 0.1]).astype(np.int32)
+        for g in np.unique(wl.job_gang[wl.job_gang >= 0]):
+            mem = np.nonzero(wl.job_gang == g)[0]
+            cls[mem] = cls[mem[0]]
+        wl.job_req_class = cls
     if away:
         tainted = rng.random(n_nodes) < 0.25
         wl.node_taints = [[(7, 1, 1)] if t else [] for t in tainted]      # (key, value, NoSchedule)
@@ -230,9 +265,10 @@ def _assemble(name, cfg, node_total, run_req, run_node, run_queue, run_pc, run_p
 def load(lib, wl: Workload) -> Scheduler:
     """create a handle, upload nodes and jobs (untimed input build)"""
     s = Scheduler(lib, wl.config)
-    s.nodes_upsert(wl.node_total, taints=wl.node_taints)
+    s.nodes_upsert(wl.node_total, wl.node_allocatable, taints=wl.node_taints, labels=wl.node_labels, id_rank=wl.node_id_rank)
     s.jobs_set(wl.job_req, queue=wl.job_queue, pc=wl.job_pc, submit_time=wl.job_submit, node=wl.job_node,
-               scheduled_at_priority=wl.job_run_prio, run_timestamp=wl.job_run_ts, gang_id=wl.job_gang, gang_cardinality=wl.job_gang_card)
+               scheduled_at_priority=wl.job_run_prio, run_timestamp=wl.job_run_ts, gang_id=wl.job_gang, gang_cardinality=wl.job_gang_card,
+               req_class=wl.job_req_class, class_tolerations=wl.class_tolerations, class_selectors=wl.class_selectors)
     return s
 
 

@@ -44,8 +44,8 @@ DEV int wgFirstFit(Dev& d, const ScanArgs& a) {
     if (!((a.maskA[n >> 6] >> (n & 63)) & 1)) continue;
     if (a.maskB && !((a.maskB[n >> 6] >> (n & 63)) & 1)) continue;
     uint64_t k = KEY(d, a.level, n);
-    if (k >= best) continue;
-    if (!fitsAlloc(d, a.req, a.level, n)) continue;
+    if (k >= best || k < a.lowBound) continue;
+    if (!a.noFit && !fitsAlloc(d, a.req, a.level, n)) continue;
     best = k;
   }
   if (best == ~0ull) return -1;

@@ -81,6 +81,20 @@ def test_random_rounds_with_away_node_types_match_oracle(hip_lib, oracle_lib, se
     scenario.assert_same_round(res[0], res[1])
     assert any(m == 5 for m in res[0].scheduled_method.values()) or seed % 3 == 0  # ASCHED_METHOD_AWAY exercised
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_rounds_off_the_index_grid_match_oracle(hip_lib, oracle_lib, seed):
+    """requests / allocatable that are not multiples of the index resolution, several node types, id order != index order: the
+    reference's skip-scan and heap merge (nodeiteration.go:74-185, 318-382) are restated literally on the device for these"""
+    wl = W.small_random(n_nodes=12 + seed * 8, n_jobs=250 + seed * 40, n_queues=2 + seed % 4, seed=200 + seed, occupied=[0.4, 0.8, 0.95][seed % 3],
+                        gangs=seed % 3, ragged=True, away=seed % 2 == 1)
+    res = []
+    for lib in (oracle_lib, hip_lib):
+        s = W.load(lib, wl)
+        W.prepare(s, wl)
+        res.append(s.schedule_round())
+    scenario.assert_same_round(res[0], res[1])
+    assert len(res[0].scheduled) > 0
+
 
 def test_fit_select_batch_config2(hip_lib, oracle_lib):
     """BASELINE config 2: 10k nodes, 100k jobs, first feasible node per job against a fixed state, bit-exact node ids."""
