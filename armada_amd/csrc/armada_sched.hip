@@ -156,8 +156,36 @@ __device__ static inline int wgFairSelect(Dev& d, const FairArgs& a) {
   return best;
 }
 
+// Most elements of the per-job passes do nothing (queued jobs have no node, few jobs are flagged for eviction): read the one
+// field that decides that for BULK_U elements at once — independent loads, all in flight together — and run the body only for
+// the survivors.  The bodies themselves are unchanged (round_run.h bulkElem).
+#define BULK_U 8
+__device__ static inline int bulkGate(Dev& d, int kind, int i) {
+  switch (kind) {
+    case B_EVICT_APPLY1: case B_EVICT_APPLY3: return d.evFlag[i];
+    case B_UNBIND: return d.inPreempted[i] | d.inSchedAndEvicted[i];
+    case B_FILTER1: case B_FILTER3: return d.jobNode[i] >= 0;
+  }
+  return 1;
+}
 __device__ static void bulkPart(Dev& d, int kind, int n) {
-  for (int i = threadIdx.x; i < n; i += blockDim.x) bulkElem(d, kind, i);
+  int stride = blockDim.x;
+  if (kind == B_EVICT_APPLY1 || kind == B_EVICT_APPLY3 || kind == B_UNBIND || kind == B_FILTER1 || kind == B_FILTER3) {
+    bool filter = kind == B_FILTER1 || kind == B_FILTER3;
+    for (int base = threadIdx.x; base < n; base += stride * BULK_U) {
+      int gate[BULK_U];
+#pragma unroll
+      for (int u = 0; u < BULK_U; u++) { int i = base + u * stride; gate[u] = i < n ? bulkGate(d, kind, i) : -1; }
+#pragma unroll
+      for (int u = 0; u < BULK_U; u++) {
+        int i = base + u * stride;
+        if (gate[u] > 0) bulkElem(d, kind, i);
+        else if (gate[u] == 0 && filter) d.evFlag[i] = 0;  // a job without a node is never evicted (pqs.go:101-136, eviction.go:158-178)
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += stride) bulkElem(d, kind, i);
+  }
   __threadfence();  // int64 atomics land in L2: make them (and the plain stores) visible to the control wave
 }
 __device__ static inline void wgBulk(Dev& d, int kind, int n) {
@@ -176,20 +204,31 @@ __device__ static int compactPart(Dev& d) {
   const int32_t* order = g_mb.order; const uint8_t* flag = g_mb.flag; int32_t* dst = g_mb.dst; uint32_t* prefix = g_mb.prefix;
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   int base = 0;
-  for (int start = 0; start < n; start += blockDim.x) {
-    int p = start + threadIdx.x;
-    int v = p < n ? (order ? order[p] : p) : 0;
-    bool f = p < n && flag[v];
-    unsigned long long b = __ballot(f);
-    int rank = __popcll(b & ((1ull << lane) - 1));
-    if (lane == 0) g_mb.waveCount[wave] = __popcll(b);
-    __syncthreads();
-    int off = 0, tot = 0;
-    for (int w = 0; w < nw; w++) { int cw = g_mb.waveCount[w]; if (w < wave) off += cw; tot += cw; }
-    if (p < n && prefix) prefix[p] = base + off + rank;
-    if (f) dst[base + off + rank] = v;
-    base += tot;
-    __syncthreads();
+  const int U = 4;  // element / flag loads of U consecutive tiles are issued together; the ordered prefix then runs tile by tile
+  for (int start0 = 0; start0 < n; start0 += blockDim.x * U) {
+    int vv[U]; bool ff[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { int p = start0 + u * (int)blockDim.x + (int)threadIdx.x; vv[u] = p < n ? (order ? order[p] : p) : 0; }
+#pragma unroll
+    for (int u = 0; u < U; u++) { int p = start0 + u * (int)blockDim.x + (int)threadIdx.x; ff[u] = p < n && flag[vv[u]]; }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      int start = start0 + u * (int)blockDim.x;
+      if (start >= n) break;
+      int p = start + threadIdx.x;
+      int v = vv[u];
+      bool f = ff[u];
+      unsigned long long b = __ballot(f);
+      int rank = __popcll(b & ((1ull << lane) - 1));
+      if (lane == 0) g_mb.waveCount[wave] = __popcll(b);
+      __syncthreads();
+      int off = 0, tot = 0;
+      for (int w = 0; w < nw; w++) { int cw = g_mb.waveCount[w]; if (w < wave) off += cw; tot += cw; }
+      if (p < n && prefix) prefix[p] = base + off + rank;
+      if (f) dst[base + off + rank] = v;
+      base += tot;
+      __syncthreads();
+    }
   }
   __threadfence();
   return base;

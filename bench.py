@@ -161,7 +161,7 @@ def main():
             out["roofline"]["traffic_source"] = "profiles/r01e_pmc_hbm_traffic.json (2*FETCH_SIZE + WRITE_SIZE of the round launch)"
         except Exception:
             pass
-    if args.cpu_budget > 0:
+    if args.cpu_budget > 0 and world == 1:  # rank 0 at N=1 only
         try:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_budget, iters)
         except Exception as e:  # the checker must never take the bench line down

@@ -95,6 +95,22 @@ def test_random_rounds_off_the_index_grid_match_oracle(hip_lib, oracle_lib, seed
     scenario.assert_same_round(res[0], res[1])
     assert len(res[0].scheduled) > 0
 
+def test_two_live_handles_interleaved(hip_lib, oracle_lib):
+    """two pools (handles) alive in one process, rounds interleaved — the Go scheduler walks its pools one after another
+    (scheduling_algo.go:165) — each must equal its own oracle run"""
+    wls = [W.small_random(n_nodes=40, n_jobs=500, n_queues=4, seed=31, occupied=0.9, gangs=2),
+           W.small_random(n_nodes=70, n_jobs=700, n_queues=5, seed=32, occupied=0.6, gangs=1, away=True)]
+    want = []
+    for wl in wls:
+        s = W.load(oracle_lib, wl); W.prepare(s, wl); want.append(s.schedule_round())
+    hs = [W.load(hip_lib, wl) for wl in wls]
+    for rep in range(2):
+        for i in (0, 1):
+            W.prepare(hs[i], wls[i])
+        got = [hs[1].schedule_round(), hs[0].schedule_round()][::-1]
+        for i in (0, 1):
+            scenario.assert_same_round(want[i], got[i])
+
 
 def test_fit_select_batch_config2(hip_lib, oracle_lib):
     """BASELINE config 2: 10k nodes, 100k jobs, first feasible node per job against a fixed state, bit-exact node ids."""
