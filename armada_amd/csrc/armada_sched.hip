@@ -1,13 +1,15 @@
 // armada_sched.hip — MI355X (gfx950) implementation of the C ABI in include/armada_sched.h.
 //
 // Kernels in this file:
-//   k_control     persistent single-workgroup "round" kernel: wave 0 runs the sequential DRF/gang control flow
-//                 (round_ctl.h), all 16 waves serve its data-parallel requests through an LDS mailbox:
+//   k_control     persistent "round" kernel.  Workgroup 0: wave 0 runs the sequential DRF/gang control flow (round_ctl.h,
+//                 round_fast.h), its 4 waves serve the data-parallel requests through an LDS mailbox; workgroups 1..H
+//                 (round launches only) are helpers that share OP_SCAN / OP_FAIR through a mailbox in fine-grained HBM:
 //                   OP_SCAN    first feasible node = argmin of the packed order key over nodes whose
 //                              alloc[level][r][n] >= req[r]  (coalesced SoA planes, wave shuffle + LDS reduction)
 //                   OP_BULK    evictors / unbind / populate / key rebuild as block-stride loops with int64 atomics
 //                   OP_COMPACT order-preserving stream compaction (wave ballot + LDS prefix) for the per-queue
 //                              evicted lists and the result lists
+//                   OP_FAIR    fair-share preemption: per-node first covering Index over the evicted-table index, max
 //   k_fit_batch   wide kernel: first feasible node for many (shape, level) queries against a fixed node state
 //                 (BASELINE config 2, "nodedb fit kernel"): node tile in registers, wave-level min, one atomicMin/wave
 //   k_shape_mask  per-shape static mask = requirement-class mask ∧ (total >= request)

@@ -796,9 +796,6 @@ DEV_NOINLINE SkipDelta fastEnterSkip(Dev& d, FastCtx fc, int Q) {
   for (int q = 0; q < Q; q++) {
     QHot f = FL.hot[q];
     uniQHot(f);
-#ifdef ASCHED_HOSTSIM
-    if (getenv("SKIPDBG")) fprintf(stderr, "enterSkip q%d cheap %d mono %d eff %d evDone %d evApplied %d evEnd %d gctx %d headPos %d\n", q, f.evCheap, d.evMono[q], f.effValid, f.evDone, f.evApplied, f.evEnd, f.gctx, f.headPos);
-#endif
     if (!f.evCheap || !UNI32((int)d.evMono[q]) || f.effValid) continue;
     int p0 = f.evDone, p1 = f.evEnd;
     if (p0 >= p1 || p0 != f.evApplied) continue;
@@ -842,9 +839,6 @@ DEV_NOINLINE SkipDelta fastExitSkip(Dev& d, FastCtx fc, int Q, int top, PackedKe
       PackedKey pk = packKey3(fc.preferLarge, UNI32(e.pcPrio), UNID(e.proposed), UNID(e.current), UNID(e.size), f.budget);
       if (packedLess(pk, qn, tk, tn)) lo = mid + 1; else hi = mid;
     }
-#ifdef ASCHED_HOSTSIM
-    if (getenv("SKIPDBG")) fprintf(stderr, "exitSkip q%d top %d ref A %08x X %016llx n %u | b0 %d b1 %d lo %d gctx %d kA %08x kX %016llx inHeap %d\n", q, top, tk.A, (unsigned long long)tk.X, tn, b0, b1, lo, f.gctx, FL.kA[q], (unsigned long long)FL.kX[q], FL.inHeap[q]);
-#endif
     S.loopIterations += lo - b0;  // the reference spent one loop iteration on each of them
     if (lo == b1) { FL.hot[q].effValid = 0; continue; }
     applyEvictedRange(d, q, lo, b1, -1);
@@ -943,9 +937,6 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
     if (UNI32(FL.hot[t].gctx) < 0) break;  // a gang: generic
     KeyOut ko; ko.valid = 0; ko.A = 0; ko.X = ko.Y = 0;
     int st = mode ? fastReplayStep(d, k, S, fc, t, &cnt, &ko) : fastIter(d, k, S, fc, t, &ko);
-#ifdef ASCHED_HOSTSIM
-    if (st == 0 && getenv("SKIPDBG")) fprintf(stderr, "fastRun break st0 top %d gctx %d headFast %d kind %d fastActive %d tokens %g gtok %g iters %d\n", t, FL.hot[t].gctx, FL.hot[t].headFast, FL.hot[t].headKind, S.fastActive, FL.hot[t].tokens, S.globalTokens, S.statFastIters);
-#endif
     if (st == 0) break;
     pqPopPush(pq, ko, t);
     SEG(7);

@@ -319,9 +319,6 @@ DEV void schedulePass(Dev& d, Ctl& c, bool withQueued, bool skipKey, bool cmpPri
 DEV void ensureFairIndex(Dev& d) {
   if (d.rs->fairIndexValid) return;
   int E = d.rs->evictedTableSize, N = d.cfg.N;
-#ifdef ASCHED_HOSTSIM
-  if (getenv("SKIPDBG")) fprintf(stderr, "fair index rebuild E=%d\n", E);
-#endif
   wgBulk(d, B_FAIR_ZERO, N);
   wgBulk(d, B_FAIR_COUNT, E);
   wgBulk(d, B_FAIR_PSUM, FAIR_CHUNKS);
