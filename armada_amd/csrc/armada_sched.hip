@@ -26,7 +26,7 @@
 
 // ------------------------------------------------------------------------------------------------ device primitives
 #define CTL_THREADS 256
-enum { OP_EXIT = 0, OP_SCAN = 1, OP_BULK = 2, OP_COMPACT = 3, OP_FAIR = 4, OP_HELPERS_EXIT = 9 };
+enum { OP_EXIT = 0, OP_SCAN = 1, OP_BULK = 2, OP_COMPACT = 3, OP_FAIR = 4, OP_ENGINE = 5, OP_HELPERS_EXIT = 9 };
 
 struct Mailbox {
   int op, kind, n;
@@ -456,6 +456,137 @@ __device__ static inline void accountVectors(Dev& d, KREF k, int q, int pc, bool
     }
   }
 }
+// ---- two-wave iteration (round_fast.h): LDS mailbox between the control wave (0) and the node engine (wave 1).
+// LDS executes one wave's accesses in issue order, so "payload, then sequence number" needs no hardware fence — only the
+// compiler must keep the order (wavefront-scope fences emit nothing).  No s_waitcnt vmcnt anywhere on this path: neither wave
+// ever waits for its own outstanding HBM atomics.
+#define LDS_ORDER() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+__device__ static inline void bindUpdateEng(KREF k, FastS& S, int n, int nl, uint64_t keyDelta) {
+  int lane = threadIdx.x & 63;
+  int l = S.laneL;
+  if (l < nl) {
+    int64_t v = g_fl.eng.req[S.laneX];
+    if (v) __hip_atomic_fetch_add(&KAL(k, l, S.laneX, n), -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  int R = k.R;
+  for (int i = lane + 64; i < nl * R; i += 64) {
+    int l2 = i / R, x = i % R;
+    int64_t v = g_fl.eng.req[x];
+    if (v) __hip_atomic_fetch_add(&KAL(k, l2, x, n), -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (lane < nl && keyDelta) __hip_atomic_fetch_add(&KKEY(k, lane, n), 0ull - keyDelta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ static inline void accountVectorsBk(Dev& d, KREF k, int q, int pc, int sign) {
+  (void)d;
+  int lane = threadIdx.x & 63;
+  if (lane < k.R) {
+    int64_t v = sign * g_fl.bk.req[lane];
+    if (v) {
+      LDS_ADD64(g_fl.qAlloc[q][lane], v); LDS_ADD64(g_rs.allocated[lane], v); LDS_ADD64(g_rs.scheduled[lane], v);
+      size_t i = ((size_t)q * k.npc + pc) * k.R + lane;
+      __hip_atomic_fetch_add(&k.qAllocByPc[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&k.qSchedByPc[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+// FL.bk := queue q's record, head job record and keys (8-byte words, one per lane)
+__device__ static inline void engineBackup(int q, int pc, double globalTokens) {
+  int lane = threadIdx.x & 63;
+  constexpr int HW = sizeof(QHot) / 8, TW = sizeof(JobTail) / 8;
+  static_assert(sizeof(QHot) % 8 == 0 && HW + TW + MAXR <= 64, "backup copy fits one wave");
+  if (lane < HW) ((unsigned long long*)&g_fl.bk.hot)[lane] = ((const unsigned long long*)&g_fl.hot[q])[lane];
+  else if (lane < HW + TW) ((unsigned long long*)&g_fl.bk.tail)[lane - HW] = ((const unsigned long long*)&g_fl.headTail[q])[lane - HW];
+  else if (lane < HW + TW + MAXR) g_fl.bk.req[lane - HW - TW] = g_fl.headReq[q][lane - HW - TW];
+  if (lane == 0) {
+    g_fl.bk.kA = g_fl.kA[q]; g_fl.bk.kX = g_fl.kX[q]; g_fl.bk.kY = g_fl.kY[q];
+    g_fl.bk.effA = g_fl.effA[q]; g_fl.bk.effX = g_fl.effX[q]; g_fl.bk.effY = g_fl.effY[q];
+    g_fl.bk.globalTokens = globalTokens; g_fl.bk.pc = pc; g_fl.bk.inHeap = g_fl.inHeap[q];
+  }
+}
+__device__ static inline void engineRestore(int q) {
+  int lane = threadIdx.x & 63;
+  constexpr int HW = sizeof(QHot) / 8, TW = sizeof(JobTail) / 8;
+  if (lane < HW) ((unsigned long long*)&g_fl.hot[q])[lane] = ((const unsigned long long*)&g_fl.bk.hot)[lane];
+  else if (lane < HW + TW) ((unsigned long long*)&g_fl.headTail[q])[lane - HW] = ((const unsigned long long*)&g_fl.bk.tail)[lane - HW];
+  else if (lane < HW + TW + MAXR) g_fl.headReq[q][lane - HW - TW] = g_fl.bk.req[lane - HW - TW];
+  if (lane == 0) {
+    g_fl.kA[q] = g_fl.bk.kA; g_fl.kX[q] = g_fl.bk.kX; g_fl.kY[q] = g_fl.bk.kY;
+    g_fl.effA[q] = g_fl.bk.effA; g_fl.effX[q] = g_fl.bk.effX; g_fl.effY[q] = g_fl.bk.effY;
+    g_fl.inHeap[q] = g_fl.bk.inHeap;
+  }
+}
+__shared__ int g_engSeq;  // control wave's count of commands posted in this engine session
+__device__ static inline void enginePost(Dev& d, KREF k, int job, int q, int32_t prio, int32_t cutoff, int nl) {
+  (void)d; (void)k;
+  int lane = threadIdx.x & 63;
+  constexpr int TW = sizeof(JobTail) / 8;
+  if (lane < TW) ((unsigned long long*)&g_fl.eng.tail)[lane] = ((const unsigned long long*)&g_fl.headTail[q])[lane];
+  else if (lane < TW + MAXR) g_fl.eng.req[lane - TW] = g_fl.headReq[q][lane - TW];
+  if (lane == 0) { g_fl.eng.job = job; g_fl.eng.prio = prio; g_fl.eng.cutoff = cutoff; g_fl.eng.nl = nl; g_fl.eng.cmd = ENG_JOB; }
+  LDS_ORDER();
+  if (lane == 0) { int sq = g_engSeq + 1; g_engSeq = sq; __hip_atomic_store(&g_fl.eng.seq, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+}
+__device__ static inline int engineWait() {
+  int want = __builtin_amdgcn_readfirstlane(g_engSeq);
+  for (;;) {
+    int a = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if (a == want) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  LDS_ORDER();
+  return __builtin_amdgcn_readfirstlane(g_fl.eng.status);
+}
+// the engine session is one mailbox op of the control workgroup: wave 1 serves jobs until ENG_QUIT, waves 2.. wait at the end barrier
+__device__ static inline void engineStart(Dev& d, FastS& S) {
+  (void)d;
+  if ((threadIdx.x & 63) == 0) { g_fl.eng.seq = 0; g_fl.eng.ack = 0; g_engSeq = 0; g_fl.eng.statScan = 0; g_fl.eng.statL0Max = S.statL0Max; g_mb.op = OP_ENGINE; }
+  __syncthreads();
+}
+__device__ static inline void engineStop(Dev& d, FastS& S) {
+  (void)d;
+  int lane = threadIdx.x & 63;
+  if (lane == 0) g_fl.eng.cmd = ENG_QUIT;
+  LDS_ORDER();
+  if (lane == 0) { int sq = g_engSeq + 1; g_engSeq = sq; __hip_atomic_store(&g_fl.eng.seq, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  (void)engineWait();
+  S.statScanSteps += __builtin_amdgcn_readfirstlane(g_fl.eng.statScan);
+  int m = __builtin_amdgcn_readfirstlane(g_fl.eng.statL0Max);
+  if (m > S.statL0Max) S.statL0Max = m;
+  __syncthreads();  // end barrier of the OP_ENGINE op
+}
+__device__ static void engineLoop(Dev& d) {  // wave 1
+  const FastK k = fastKRef(d);
+  int lane = threadIdx.x & 63;
+  FastS ES;
+  ES.tP0 = -1; ES.engLive = 0; ES.engPend = -1;
+  ES.laneL = lane / (k.R > 0 ? k.R : 1); ES.laneX = lane % (k.R > 0 ? k.R : 1);
+  ES.statScanSteps = 0; ES.statL0Max = __builtin_amdgcn_readfirstlane(g_fl.eng.statL0Max);
+  ES.fastActive = 1;
+  int seen = 0;
+  for (;;) {
+    int sq;
+    for (;;) {
+      sq = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      if (sq != seen) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    seen = sq;
+    LDS_ORDER();
+    int cmd = __builtin_amdgcn_readfirstlane(g_fl.eng.cmd);
+    if (cmd == ENG_QUIT) {
+      if (lane == 0) { g_fl.eng.statScan = ES.statScanSteps; g_fl.eng.statL0Max = ES.statL0Max; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this wave's binds and result stores are complete before the generic code reads them
+      LDS_ORDER();
+      if (lane == 0) __hip_atomic_store(&g_fl.eng.ack, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      return;
+    }
+    int st = engineServe(d, k, ES);
+    if (lane == 0) g_fl.eng.status = st;
+    LDS_ORDER();
+    if (lane == 0) __hip_atomic_store(&g_fl.eng.ack, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+
 // WIN EvKey records (32 B each) of queue q's evicted stream: 4 lanes x 8 bytes per record
 __device__ static inline void evWinRefill(KREF k, int q, int pos, int cnt) {
   int lane = threadIdx.x & 63;
@@ -719,6 +850,8 @@ __global__ __launch_bounds__(CTL_THREADS) void k_control(Dev dev, int cmd, HelpB
         bulkPart(d, g_mb.kind, g_mb.n);
       } else if (op == OP_COMPACT) {
         compactPart(d);
+      } else if (op == OP_ENGINE) {
+        if ((threadIdx.x >> 6) == 1) engineLoop(d);
       }
       __syncthreads();
     }

@@ -73,6 +73,7 @@ struct EvKey { double proposed, current, size; int32_t pcPrio; int32_t job; };
 // Level-0 ("fit without preemption", priority -2) fast structure, DESIGN.md "Sorted base + LDS delta".
 struct FastCfg {
   int structOk, iterOk;       // host-verified exactness conditions (asched_host.inc: fastConditions)
+  int engine;                 // queued-job iterations run on two waves (round_fast.h "two-wave iteration"); ASCHED_ENGINE=0 turns it off
   int E; int extraCol[MAXE];  // non-indexed columns
   uint64_t fieldMask[MAXK];   // in-place mask of each packed key field
   uint64_t minFieldMin;       // per-field minimum of fieldMin over all shapes (liveness of a dirty node)

@@ -49,6 +49,24 @@ struct alignas(16) JobTail {  // second half of a JobRec
 static_assert(sizeof(JobTail) == 64 && sizeof(JobRec) == 128 && __builtin_offsetof(JobRec, keyDelta) == 64, "JobRec = request vector + JobTail");
 struct alignas(16) CandRec { int32_t pos, node; uint64_t key, cls; int64_t ex0, ex1; int64_t pad; };  // node: >=0, -1 exhausted, -2 scan from pos
 
+// ---- two-wave iteration.  A queued-job iteration has a queue side (constraints, accounting, the queue's next head, DRF costs,
+// heap) and a node side (first fit at priority -2, bind, per-job results, L0 upkeep) that meet only in "did the job fit".  The
+// control wave posts the job to a second wave (the node engine) and carries on with the queue side assuming it fits; the verdict
+// is collected before the next iteration starts.  On a miss the queue side of that one iteration is taken back (IterBackup) and
+// the generic code runs it from exactly the state it would have found.
+enum { ENG_JOB = 1, ENG_QUIT = 2 };
+struct alignas(16) EngineBox {
+  JobTail tail; int64_t req[MAXR];          // the job: its record as fastIter read it
+  int32_t job, prio, cutoff, nl, cmd, status;
+  int32_t seq, ack;                          // command n is ready when seq == n; served when ack == n
+  int32_t statScan, statL0Max;               // engine counters, handed over at ENG_QUIT
+};
+struct alignas(16) IterBackup {
+  QHot hot; JobTail tail; int64_t req[MAXR];
+  uint64_t kX, kY, effX, effY; double globalTokens;
+  uint32_t kA, effA; int32_t pc, inHeap;
+};
+
 struct FastLds {
   // L0: live dirty nodes (current level-0 key / non-indexed columns / class bits)
   int l0Count;
@@ -64,6 +82,7 @@ struct FastLds {
   uint32_t kA[QCAPF]; uint64_t kX[QCAPF]; uint64_t kY[QCAPF]; int32_t inHeap[QCAPF]; int32_t nameRank[QCAPF];
   uint32_t tmpA[64], tmpN[64]; uint64_t tmpX[64], tmpY[64]; int32_t tmpQ[64];  // scatter space of pqBuild
   uint32_t effA[QCAPF]; uint64_t effX[QCAPF], effY[QCAPF];  // skip mode: running maximum of the queue's keys
+  EngineBox eng; IterBackup bk;
 };
 
 #ifdef ASCHED_HOSTSIM
@@ -145,7 +164,7 @@ DEV void uniJobTail(JobTail& r) {
 DEV void uniCand(CandRec& c) { c.pos = UNI32(c.pos); c.node = UNI32(c.node); c.key = UNI64(c.key); c.cls = UNI64(c.cls); c.ex0 = UNI64(c.ex0); c.ex1 = UNI64(c.ex1); }
 struct FitHandle { int src; int slot; };  // src 0: base candidate of the shape, 1: L0 slot
 // what the fast loop needs of Ctl + PassCfg, by value
-struct FastCtx { int withQueued; uint32_t maxLookback; int skipKnown, compareSchedPrio, preferLarge, replay, evStatic; };
+struct FastCtx { int withQueued; uint32_t maxLookback; int skipKnown, compareSchedPrio, preferLarge, replay, evStatic, engine; };
 
 // loop constants: configuration and array bases, read once per fastRun (registers for the whole run)
 struct FastK {
@@ -171,6 +190,7 @@ struct FastS {
   // patched in place, a removal outside re-targets it, so the rescans that follow a bind find their entries without a load
   int tP0; int tNode, tRem; unsigned long long tKey, tCls; long long tEx0, tEx1;
   int laneL, laneX;  // device only: this lane's (level offset, resource) in a bind: lane = laneL * R + laneX
+  int engLive, engPend;  // node engine started for this run; queue whose speculative iteration awaits the engine's verdict (-1 none)
 };
 
 // The loop's constants are built once per round_prepare on the host (every value is a config field or a device pointer the
@@ -393,6 +413,30 @@ DEV void applyEvictedRange(Dev& d, int q, int p0, int p1, int sign = 1) {
 }
 DEV bool roundLimitExceeded(Dev& d, KREF k) { for (int x = 0; x < k.R; x++) if (RS.scheduled[x] > d.cfg.maxToSchedule[x]) return true; return false; }  // constraints.go:113-119
 DEV bool headRequestsDisallowed(Dev& d, KREF k, int q) { for (int x = 0; x < k.R; x++) if (d.cfg.disallowed[x] && FL.headReq[q][x] > 0) return true; return false; }  // nodedb.go:596-601
+// two-wave iteration: the engine's bind takes the request from its mailbox; the rollback's accounting from the backup
+DEV void bindUpdateEng(KREF k, FastS&, int n, int nl, uint64_t keyDelta) {
+  for (int l = 0; l < nl; l++) { for (int x = 0; x < k.R; x++) KAL(k, l, x, n) -= FL.eng.req[x]; KKEY(k, l, n) -= keyDelta; }
+}
+DEV void accountVectorsBk(Dev& d, KREF k, int q, int pc, int sign) {
+  for (int x = 0; x < k.R; x++) {
+    int64_t v = sign * FL.bk.req[x];
+    FL.qAlloc[q][x] += v; RS.allocated[x] += v; RS.scheduled[x] += v;
+    size_t i = ((size_t)q * k.npc + pc) * k.R + x;
+    k.qAllocByPc[i] += v; k.qSchedByPc[i] += v;
+  }
+}
+DEV void engineBackup(int q, int pc, double globalTokens) {
+  IterBackup& b = FL.bk;
+  b.hot = FL.hot[q]; b.tail = FL.headTail[q]; memcpy(b.req, FL.headReq[q], sizeof b.req);
+  b.kA = FL.kA[q]; b.kX = FL.kX[q]; b.kY = FL.kY[q]; b.effA = FL.effA[q]; b.effX = FL.effX[q]; b.effY = FL.effY[q];
+  b.globalTokens = globalTokens; b.pc = pc; b.inHeap = FL.inHeap[q];
+}
+DEV void engineRestore(int q) {
+  const IterBackup& b = FL.bk;
+  FL.hot[q] = b.hot; FL.headTail[q] = b.tail; memcpy(FL.headReq[q], b.req, sizeof b.req);
+  FL.kA[q] = b.kA; FL.kX[q] = b.kX; FL.kY[q] = b.kY; FL.effA[q] = b.effA; FL.effX[q] = b.effX; FL.effY[q] = b.effY;
+  FL.inHeap[q] = b.inHeap;
+}
 #else  // device versions: armada_sched.hip
 struct PQState { uint32_t A, N; unsigned long long X, Y; int q; int count; };  // lane i: the i-th queue in heap order
 DEV void pqBuild(PQState& s, int Q);
@@ -411,6 +455,14 @@ DEV void accountVectors(Dev& d, KREF k, int q, int pc, bool ev, bool replay);
 DEV void evWinRefill(KREF k, int q, int pos, int cnt);
 __device__ static void applyEvictedRange(Dev& d, int q, int p0, int p1, int sign = 1);  // not inlined, reads the constants itself: nothing of the hot loop has to live in memory for it
 DEV bool roundLimitExceeded(Dev& d, KREF k);
+DEV void bindUpdateEng(KREF k, FastS& S, int n, int nl, uint64_t keyDelta);
+DEV void accountVectorsBk(Dev& d, KREF k, int q, int pc, int sign);
+DEV void engineBackup(int q, int pc, double globalTokens);
+DEV void engineRestore(int q);
+DEV void enginePost(Dev& d, KREF k, int job, int q, int32_t prio, int32_t cutoff, int nl);
+DEV int engineWait();
+DEV void engineStart(Dev& d, FastS& S);
+DEV void engineStop(Dev& d, FastS& S);
 DEV bool headRequestsDisallowed(Dev& d, KREF k, int q);
 #endif
 DEV void candInvalidate(int S, int n) { FOR_LANES(s, S) if (FL.cand[s].node == n) FL.cand[s].node = -2; }
@@ -642,6 +694,41 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
   return ok;
 }
 
+// Node side of one queued-job iteration (the second wave on the device): first fit at priority -2 for the job in the mailbox,
+// BindJobToNode (nodedb.go:1046-1068), the job's result fields, level-0 bookkeeping.  0 = does not fit (nothing touched),
+// 1 = bound, 2 = bound and the L0 list overflowed (the caller drops the structure).
+DEV int engineServe(Dev& d, KREF k, FastS& ES) {
+  (void)d;
+  JobTail r = FL.eng.tail;
+  uniJobTail(r);
+  int job = UNI32(FL.eng.job), nl = UNI32(FL.eng.nl);
+  int32_t prio = UNI32(FL.eng.prio), cutoff = UNI32(FL.eng.cutoff);
+  FitHandle h; h.src = 0; h.slot = -1;
+  CandRec cand; cand.pos = 0; cand.node = -1; cand.key = 0; cand.cls = 0; cand.ex0 = cand.ex1 = 0; cand.pad = 0;
+  int n = fastFirstFit(k, ES, r, &h, &cand);
+  if (n < 0) return 0;
+  bindUpdateEng(k, ES, n, nl, r.keyDelta);
+  if (FLANE == 0) {  // jcReason, jobEvictedOnNode, inSchedAndEvicted are still 0 for a queued job
+    k.jcHasPctx[job] = 1; k.pcNode[job] = n; k.pcSap[job] = prio;
+    k.jobNode[job] = n; k.jobCutoff[job] = cutoff; k.schedAtPrio[job] = prio;
+    k.pcPap[job] = ASCHED_EVICTED_PRIORITY; k.pcMethod[job] = ASCHED_METHOD_NO_PREEMPTION; k.jobFlags[job] = F_SUCCESSFUL; k.inScheduled[job] = 1;
+  }
+  return fastAfterBind(k, ES, r, n, h, cand) ? 1 : 2;
+}
+#ifdef ASCHED_HOSTSIM
+// serial build: the engine runs at post time; the control code still proceeds on the assumption that the job fits and takes the
+// iteration back at the next settle point when it did not — the same control flow as on the device
+static FastS g_engS;
+DEV void engineStart(Dev&, FastS& S) { g_engS = S; g_engS.statScanSteps = 0; }
+DEV void engineStop(Dev&, FastS& S) { S.statScanSteps += g_engS.statScanSteps; if (g_engS.statL0Max > S.statL0Max) S.statL0Max = g_engS.statL0Max; }
+DEV void enginePost(Dev& d, KREF k, int job, int q, int32_t prio, int32_t cutoff, int nl) {
+  FL.eng.tail = FL.headTail[q]; memcpy(FL.eng.req, FL.headReq[q], sizeof FL.eng.req);
+  FL.eng.job = job; FL.eng.prio = prio; FL.eng.cutoff = cutoff; FL.eng.nl = nl;
+  FL.eng.status = engineServe(d, k, g_engS);
+}
+DEV int engineWait() { return FL.eng.status; }
+#endif
+
 // head of queue q was peeked by the generic code: fetch its record (one burst) and classify it
 DEV void fastLoadHead(KREF k, int q, int job, QHot& f) {
   loadHeadRec(k, q, job);
@@ -720,8 +807,21 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
     if (k.anyDisallowed && headRequestsDisallowed(d, k, q)) return 0;
     if (k.disableHome) return 0;
     prio = r.pcPrio;
-    n = fastFirstFit(k, S, r, &h, &cand);
-    if (n < 0) return 0;  // the generic cascade (gate, fair-share, urgency) decides
+    if (fc.engine) {
+      // two-wave iteration: the node engine takes first fit + bind; this wave goes on with the queue side assuming the job fits
+      if (!S.engLive) { engineStart(d, S); S.engLive = 1; }
+      engineBackup(q, pcx, S.globalTokens);  // FL.hot[q] still holds the queue's state as of the start of this iteration
+      enginePost(d, k, job, q, prio, r.preemptible ? prio : NONPREEMPTIBLE_CUTOFF, r.nlPc);
+      n = -1;
+      if (fc.skipKnown && S.numUnfeasible > 0) {  // fastAdvance may record skipped jobs, which cannot be taken back: wait for the verdict
+        int v = engineWait();
+        if (v == 0) return 0;
+        if (v == 2) { S.fastActive = 0; fastDrop(d); }
+      } else S.engPend = q;
+    } else {
+      n = fastFirstFit(k, S, r, &h, &cand);
+      if (n < 0) return 0;  // the generic cascade (gate, fair-share, urgency) decides
+    }
     S.numNodeQueries++;
   } else {
     // nodedb.go:897-906: alloc[level] >= alloc[-2] + req >= req on every column while no priority -2 column is negative
@@ -738,8 +838,9 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
   // ---- SelectNodeForJobWithTxn result + BindJobToNode (nodedb.go:538-630, 1046-1068)
   int32_t cutoff = r.preemptible ? prio : NONPREEMPTIBLE_CUTOFF;
   int nl = ev ? r.nlRun : r.nlPc;
-  bindUpdate(k, S, n, ev ? 1 : 0, nl, q, r.keyDelta);  // evicted job: level -2 gets -req (bind) and +req (un-evict): unchanged (node.go:416-442)
-  if (FLANE == 0) {
+  bool nodeSideHere = ev || !fc.engine;  // a queued job's bind, result fields and L0 upkeep are the node engine's in two-wave mode
+  if (nodeSideHere) bindUpdate(k, S, n, ev ? 1 : 0, nl, q, r.keyDelta);  // evicted job: level -2 gets -req (bind) and +req (un-evict): unchanged (node.go:416-442)
+  if (nodeSideHere && FLANE == 0) {
     k.jcHasPctx[job] = 1; k.pcNode[job] = n; k.pcSap[job] = prio;
     k.jobNode[job] = n; k.jobCutoff[job] = cutoff; k.schedAtPrio[job] = prio;
     if (ev) {
@@ -751,12 +852,29 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
     }
   }
   if (!ev) {
-    if (!fastAfterBind(k, S, r, n, h, cand)) { S.fastActive = 0; fastDrop(d); }
+    if (nodeSideHere && !fastAfterBind(k, S, r, n, h, cand)) { S.fastActive = 0; fastDrop(d); }
     if (!S.globalRateInf && 1 <= S.globalBurst) S.globalTokens -= 1.0;  // gang_scheduler.go:118-123, rate.Limiter.ReserveN
     if (!f.rateInf && 1 <= f.burst) f.tokens -= 1.0;
   }
   SEG(3);
   return fastAdvance(d, k, S, fc, q, f, ko) ? 1 : 2;
+}
+
+// The node engine found no node for the job of queue q's last (speculative) iteration: take the queue side of that iteration
+// back — accounting, counters, tokens, the queue's head / iterator / key — so that the generic code meets the state fastIter
+// would have left by returning 0.  The heap lanes are rebuilt by the caller.
+DEV void fastRollback(Dev& d, KREF k, FastS& S, int q) {
+#ifdef ASCHED_HOSTSIM
+  if (getenv("HOSTSIM_TRACE_ROLLBACK")) fprintf(stderr, "rollback q%d\n", q);
+#endif
+  int curApplied = UNI32(FL.hot[q].evApplied), bkApplied = UNI32(FL.bk.hot.evApplied);
+  if (curApplied > bkApplied) { applyEvictedRange(d, q, bkApplied, curApplied, -1); S.numEvictedJobs += curApplied - bkApplied; }
+  accountVectorsBk(d, k, q, UNI32(FL.bk.pc), -1);
+  S.numScheduledJobs--; S.numScheduledGangs--; S.numNodeQueries--;
+  S.globalTokens = UNID(FL.bk.globalTokens);
+  engineRestore(q);
+  FL.hot[q].winKind = -1; FL.hot[q].ewCount = 0;  // the windows may have moved on: refill on demand
+  S.loopIterations--; S.statFastIters--;
 }
 
 // one step of addEvictedJobsToNodeDb (preempting_queue_scheduler.go:589-639) for a single evicted job.  Fast mode only.
@@ -891,12 +1009,12 @@ DEV_NOINLINE SkipDelta fastDrain(Dev& d, int Q) {
 DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* counter) {
   FastCtx fc;
   fc.withQueued = pc.withQueued; fc.maxLookback = pc.maxLookback; fc.skipKnown = pc.skipKnown; fc.compareSchedPrio = c.compareSchedPrio;
-  fc.preferLarge = c.preferLarge; fc.replay = mode; fc.evStatic = c.fastEvStatic;
+  fc.preferLarge = c.preferLarge; fc.replay = mode; fc.evStatic = c.fastEvStatic; fc.engine = !mode && d.f.engine;
   fastEnsureLive(d, c);
   c.l1Dirty = 1;
   const FastK k = fastKRef(d);
   FastS S;
-  S.tP0 = -1;
+  S.tP0 = -1; S.engLive = 0; S.engPend = -1;
   S.laneL = FLANE / (d.cfg.R > 0 ? d.cfg.R : 1); S.laneX = FLANE % (d.cfg.R > 0 ? d.cfg.R : 1);
   S.globalTokens = UNID(RS.globalTokens); S.globalBurst = UNI64(RS.globalBurst); S.globalRateInf = UNI32(RS.globalRateInf);
   S.numScheduledJobs = UNI32(RS.numScheduledJobs); S.numScheduledGangs = UNI32(RS.numScheduledGangs); S.numEvictedJobs = UNI32(RS.numEvictedJobs);
@@ -905,7 +1023,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   S.statFastIters = UNI32(RS.statFastIters); S.statScanSteps = UNI32(RS.statScanSteps); S.statRefills = UNI32(RS.statRefills); S.statL0Max = UNI32(RS.statL0Max); S.statFastReplay = UNI32(RS.statFastReplay);
   int Q = UNI32(d.cfg.Q);
   fc.withQueued = UNI32(fc.withQueued); fc.maxLookback = UNI32(fc.maxLookback); fc.skipKnown = UNI32(fc.skipKnown); fc.compareSchedPrio = UNI32(fc.compareSchedPrio);
-  fc.preferLarge = UNI32(fc.preferLarge); fc.evStatic = UNI32(fc.evStatic);
+  fc.preferLarge = UNI32(fc.preferLarge); fc.evStatic = UNI32(fc.evStatic); fc.engine = UNI32(fc.engine);
   mode = UNI32(mode);
   int cnt = counter ? UNI32(*counter) : 0, pend = -1, lastTop = -1;
   PackedKey refK; refK.A = ~0u; refK.X = refK.Y = ~0ull; uint32_t refN = ~0u;
@@ -915,7 +1033,22 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   PQState pq;
   pqBuild(pq, Q);
   SEG_BEGIN();
+  // collect the node engine's verdict on the speculative iteration in flight; on a miss take it back and stop (the generic code redoes it)
+#define ENGINE_SETTLE(onMiss) \
+  if (S.engPend >= 0) { \
+    int sq = S.engPend, sv = engineWait(); \
+    S.engPend = -1; \
+    if (sv == 2) { S.fastActive = 0; fastDrop(d); } \
+    if (sv == 0) { \
+      fastRollback(d, k, S, sq); \
+      pqBuild(pq, Q); \
+      lastTop = sq; refK.A = UNI32(FL.kA[sq]); refK.X = UNI64(FL.kX[sq]); refK.Y = UNI64(FL.kY[sq]); refN = (uint32_t)UNI32(FL.nameRank[sq]); \
+      pend = -1; \
+      onMiss; \
+    } \
+  }
   for (;;) {
+    ENGINE_SETTLE(break)
     int t = pqHead(pq, Q);
     SEG(0);
 #ifdef ASCHED_HOSTSIM
@@ -943,6 +1076,9 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
     if (!mode) { S.loopIterations++; S.statFastIters++; }
     if (st == 2) { pend = t; break; }  // refK / refN: the entry just served
   }
+  ENGINE_SETTLE((void)0)
+#undef ENGINE_SETTLE
+  if (S.engLive) { engineStop(d, S); S.engLive = 0; }
   if (c.skipActive) {  // generic code comes next: rebuild the exact interleaved state
     SkipDelta dl = fastExitSkip(d, fc, Q, lastTop, refK, refN);
     S.numEvictedJobs += dl.evicted; S.loopIterations += dl.iters; S.statRefills += dl.refills;
