@@ -480,7 +480,7 @@ __device__ static inline void accountVectorsBk(Dev& d, KREF k, int q, int pc, in
   (void)d;
   int lane = threadIdx.x & 63;
   if (lane < k.R) {
-    int64_t v = sign * g_fl.bk.req[lane];
+    int64_t v = sign * g_fl.eng.req[lane];
     if (v) {
       LDS_ADD64(g_fl.qAlloc[q][lane], v); LDS_ADD64(g_rs.allocated[lane], v); LDS_ADD64(g_rs.scheduled[lane], v);
       size_t i = ((size_t)q * k.npc + pc) * k.R + lane;
@@ -489,45 +489,37 @@ __device__ static inline void accountVectorsBk(Dev& d, KREF k, int q, int pc, in
     }
   }
 }
-// FL.bk := queue q's record, head job record and keys (8-byte words, one per lane)
-__device__ static inline void engineBackup(int q, int pc, double globalTokens) {
+// One LDS pass, one word per lane: FL.bk := queue q's record and keys (what a rollback restores), FL.eng := the job (record, request,
+// parameters); then the sequence number.  The job's record and request are not duplicated in the backup: the engine only reads them.
+__device__ static inline void enginePost(Dev& d, KREF k, FastS& S, int job, int q, int pc, int32_t prio, int32_t cutoff, int nl) {
+  (void)d; (void)k;
   int lane = threadIdx.x & 63;
-  constexpr int HW = sizeof(QHot) / 8, TW = sizeof(JobTail) / 8;
-  static_assert(sizeof(QHot) % 8 == 0 && HW + TW + MAXR <= 64, "backup copy fits one wave");
+  constexpr int HW = sizeof(QHot) / 8, TW = sizeof(JobTail) / 8, B = HW + TW + MAXR;
+  static_assert(sizeof(QHot) % 8 == 0 && B + 9 <= 64, "backup + post fit one wave");
   if (lane < HW) ((unsigned long long*)&g_fl.bk.hot)[lane] = ((const unsigned long long*)&g_fl.hot[q])[lane];
-  else if (lane < HW + TW) ((unsigned long long*)&g_fl.bk.tail)[lane - HW] = ((const unsigned long long*)&g_fl.headTail[q])[lane - HW];
-  else if (lane < HW + TW + MAXR) g_fl.bk.req[lane - HW - TW] = g_fl.headReq[q][lane - HW - TW];
+  else if (lane < HW + TW) ((unsigned long long*)&g_fl.eng.tail)[lane - HW] = ((const unsigned long long*)&g_fl.headTail[q])[lane - HW];
+  else if (lane < B) g_fl.eng.req[lane - HW - TW] = g_fl.headReq[q][lane - HW - TW];
   if (lane == 0) {
     g_fl.bk.kA = g_fl.kA[q]; g_fl.bk.kX = g_fl.kX[q]; g_fl.bk.kY = g_fl.kY[q];
     g_fl.bk.effA = g_fl.effA[q]; g_fl.bk.effX = g_fl.effX[q]; g_fl.bk.effY = g_fl.effY[q];
-    g_fl.bk.globalTokens = globalTokens; g_fl.bk.pc = pc; g_fl.bk.inHeap = g_fl.inHeap[q];
+    g_fl.bk.inHeap = g_fl.inHeap[q]; g_fl.bk.globalTokens = S.globalTokens; g_fl.bk.pc = pc;
+    g_fl.eng.job = job; g_fl.eng.prio = prio; g_fl.eng.cutoff = cutoff; g_fl.eng.nl = nl; g_fl.eng.cmd = ENG_JOB;
   }
+  S.engSeq++;
+  LDS_ORDER();
+  if (lane == 0) __hip_atomic_store(&g_fl.eng.seq, S.engSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ static inline void engineRestore(int q) {
   int lane = threadIdx.x & 63;
-  constexpr int HW = sizeof(QHot) / 8, TW = sizeof(JobTail) / 8;
+  constexpr int HW = sizeof(QHot) / 8, TW = sizeof(JobTail) / 8, B = HW + TW + MAXR;
   if (lane < HW) ((unsigned long long*)&g_fl.hot[q])[lane] = ((const unsigned long long*)&g_fl.bk.hot)[lane];
-  else if (lane < HW + TW) ((unsigned long long*)&g_fl.headTail[q])[lane - HW] = ((const unsigned long long*)&g_fl.bk.tail)[lane - HW];
-  else if (lane < HW + TW + MAXR) g_fl.headReq[q][lane - HW - TW] = g_fl.bk.req[lane - HW - TW];
-  if (lane == 0) {
-    g_fl.kA[q] = g_fl.bk.kA; g_fl.kX[q] = g_fl.bk.kX; g_fl.kY[q] = g_fl.bk.kY;
-    g_fl.effA[q] = g_fl.bk.effA; g_fl.effX[q] = g_fl.bk.effX; g_fl.effY[q] = g_fl.bk.effY;
-    g_fl.inHeap[q] = g_fl.bk.inHeap;
-  }
+  else if (lane < HW + TW) ((unsigned long long*)&g_fl.headTail[q])[lane - HW] = ((const unsigned long long*)&g_fl.eng.tail)[lane - HW];
+  else if (lane < B) g_fl.headReq[q][lane - HW - TW] = g_fl.eng.req[lane - HW - TW];
+  else if (lane == B) { g_fl.kA[q] = g_fl.bk.kA; g_fl.kX[q] = g_fl.bk.kX; g_fl.kY[q] = g_fl.bk.kY; }
+  else if (lane == B + 1) { g_fl.effA[q] = g_fl.bk.effA; g_fl.effX[q] = g_fl.bk.effX; g_fl.effY[q] = g_fl.bk.effY; g_fl.inHeap[q] = g_fl.bk.inHeap; }
 }
-__shared__ int g_engSeq;  // control wave's count of commands posted in this engine session
-__device__ static inline void enginePost(Dev& d, KREF k, int job, int q, int32_t prio, int32_t cutoff, int nl) {
-  (void)d; (void)k;
-  int lane = threadIdx.x & 63;
-  constexpr int TW = sizeof(JobTail) / 8;
-  if (lane < TW) ((unsigned long long*)&g_fl.eng.tail)[lane] = ((const unsigned long long*)&g_fl.headTail[q])[lane];
-  else if (lane < TW + MAXR) g_fl.eng.req[lane - TW] = g_fl.headReq[q][lane - TW];
-  if (lane == 0) { g_fl.eng.job = job; g_fl.eng.prio = prio; g_fl.eng.cutoff = cutoff; g_fl.eng.nl = nl; g_fl.eng.cmd = ENG_JOB; }
-  LDS_ORDER();
-  if (lane == 0) { int sq = g_engSeq + 1; g_engSeq = sq; __hip_atomic_store(&g_fl.eng.seq, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-}
-__device__ static inline int engineWait() {
-  int want = __builtin_amdgcn_readfirstlane(g_engSeq);
+__device__ static inline int engineWait(const FastS& S) {
+  int want = S.engSeq;
   for (;;) {
     int a = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     if (a == want) break;
@@ -536,10 +528,20 @@ __device__ static inline int engineWait() {
   LDS_ORDER();
   return __builtin_amdgcn_readfirstlane(g_fl.eng.status);
 }
+// key and name rank of the heap's head entry (queue t): lane 0 of the heap lanes, no LDS access
+__device__ static inline void pqHeadKey(PQState& s, int t, PackedKey* key, uint32_t* nameRank) {
+  if (__builtin_amdgcn_readfirstlane(s.q) == t) {
+    key->A = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.A); *nameRank = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.N);
+    key->X = UNI64(s.X); key->Y = UNI64(s.Y);
+  } else {
+    key->A = UNI32(g_fl.kA[t]); key->X = UNI64(g_fl.kX[t]); key->Y = UNI64(g_fl.kY[t]); *nameRank = (uint32_t)UNI32(g_fl.nameRank[t]);
+  }
+}
 // the engine session is one mailbox op of the control workgroup: wave 1 serves jobs until ENG_QUIT, waves 2.. wait at the end barrier
 __device__ static inline void engineStart(Dev& d, FastS& S) {
   (void)d;
-  if ((threadIdx.x & 63) == 0) { g_fl.eng.seq = 0; g_fl.eng.ack = 0; g_engSeq = 0; g_fl.eng.statScan = 0; g_fl.eng.statL0Max = S.statL0Max; g_mb.op = OP_ENGINE; }
+  S.engSeq = 0;
+  if ((threadIdx.x & 63) == 0) { g_fl.eng.seq = 0; g_fl.eng.ack = 0; g_fl.eng.statScan = 0; g_fl.eng.statL0Max = S.statL0Max; g_fl.eng.busyClk = 0; g_fl.eng.jobs = 0; g_mb.op = OP_ENGINE; }
   __syncthreads();
 }
 __device__ static inline void engineStop(Dev& d, FastS& S) {
@@ -547,11 +549,15 @@ __device__ static inline void engineStop(Dev& d, FastS& S) {
   int lane = threadIdx.x & 63;
   if (lane == 0) g_fl.eng.cmd = ENG_QUIT;
   LDS_ORDER();
-  if (lane == 0) { int sq = g_engSeq + 1; g_engSeq = sq; __hip_atomic_store(&g_fl.eng.seq, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-  (void)engineWait();
+  S.engSeq++;
+  if (lane == 0) __hip_atomic_store(&g_fl.eng.seq, S.engSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  (void)engineWait(S);
   S.statScanSteps += __builtin_amdgcn_readfirstlane(g_fl.eng.statScan);
   int m = __builtin_amdgcn_readfirstlane(g_fl.eng.statL0Max);
   if (m > S.statL0Max) S.statL0Max = m;
+#ifndef ASCHED_FASTPROF
+  if (lane == 0) { g_rs.statSeg[1] += g_fl.eng.busyClk; g_rs.statSeg[2] += g_fl.eng.jobs; }
+#endif
   __syncthreads();  // end barrier of the OP_ENGINE op
 }
 __device__ static void engineLoop(Dev& d) {  // wave 1
@@ -562,6 +568,7 @@ __device__ static void engineLoop(Dev& d) {  // wave 1
   ES.laneL = lane / (k.R > 0 ? k.R : 1); ES.laneX = lane % (k.R > 0 ? k.R : 1);
   ES.statScanSteps = 0; ES.statL0Max = __builtin_amdgcn_readfirstlane(g_fl.eng.statL0Max);
   ES.fastActive = 1;
+  long long busy = 0; int jobs = 0;
   int seen = 0;
   for (;;) {
     int sq;
@@ -574,13 +581,15 @@ __device__ static void engineLoop(Dev& d) {  // wave 1
     LDS_ORDER();
     int cmd = __builtin_amdgcn_readfirstlane(g_fl.eng.cmd);
     if (cmd == ENG_QUIT) {
-      if (lane == 0) { g_fl.eng.statScan = ES.statScanSteps; g_fl.eng.statL0Max = ES.statL0Max; }
+      if (lane == 0) { g_fl.eng.statScan = ES.statScanSteps; g_fl.eng.statL0Max = ES.statL0Max; g_fl.eng.busyClk = busy; g_fl.eng.jobs = jobs; }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this wave's binds and result stores are complete before the generic code reads them
       LDS_ORDER();
       if (lane == 0) __hip_atomic_store(&g_fl.eng.ack, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       return;
     }
+    long long b0 = (long long)__builtin_readcyclecounter();
     int st = engineServe(d, k, ES);
+    busy += (long long)__builtin_readcyclecounter() - b0; jobs++;
     if (lane == 0) g_fl.eng.status = st;
     LDS_ORDER();
     if (lane == 0) __hip_atomic_store(&g_fl.eng.ack, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -60,9 +60,10 @@ struct alignas(16) EngineBox {
   int32_t job, prio, cutoff, nl, cmd, status;
   int32_t seq, ack;                          // command n is ready when seq == n; served when ack == n
   int32_t statScan, statL0Max;               // engine counters, handed over at ENG_QUIT
+  int64_t busyClk; int32_t jobs, pad_;       // shader-clock ticks the engine spent serving jobs, and how many
 };
-struct alignas(16) IterBackup {
-  QHot hot; JobTail tail; int64_t req[MAXR];
+struct alignas(16) IterBackup {  // the job's record and request stay in the mailbox (the engine only reads them)
+  QHot hot;
   uint64_t kX, kY, effX, effY; double globalTokens;
   uint32_t kA, effA; int32_t pc, inHeap;
 };
@@ -138,7 +139,7 @@ template <class T> __device__ static inline T uniT64(T v) { return (T)uni64((uns
 
 #ifdef ASCHED_FASTPROF
 #define SEG_BEGIN() S.segT = CLK()
-#define SEG(i) do { long long _n = CLK(); if (FLANE == 0 && fc.replay) RS.statSeg[i] += _n - S.segT; S.segT = _n; } while (0)
+#define SEG(i) do { long long _n = CLK(); if (FLANE == 0 && _n - S.segT < (1ll << 32)) RS.statSeg[i] += _n - S.segT; S.segT = _n; } while (0)  // cold helpers start their own clock at 0: skip those
 #else
 #define SEG_BEGIN() do {} while (0)
 #define SEG(i) do {} while (0)
@@ -190,6 +191,8 @@ struct FastS {
   // patched in place, a removal outside re-targets it, so the rescans that follow a bind find their entries without a load
   int tP0; int tNode, tRem; unsigned long long tKey, tCls; long long tEx0, tEx1;
   int laneL, laneX;  // device only: this lane's (level offset, resource) in a bind: lane = laneL * R + laneX
+  long long engWaitClk;  // ticks this wave spent waiting for the engine's verdict
+  int engSeq;            // commands posted to the engine in this session
   int engLive, engPend;  // node engine started for this run; queue whose speculative iteration awaits the engine's verdict (-1 none)
 };
 
@@ -419,24 +422,19 @@ DEV void bindUpdateEng(KREF k, FastS&, int n, int nl, uint64_t keyDelta) {
 }
 DEV void accountVectorsBk(Dev& d, KREF k, int q, int pc, int sign) {
   for (int x = 0; x < k.R; x++) {
-    int64_t v = sign * FL.bk.req[x];
+    int64_t v = sign * FL.eng.req[x];
     FL.qAlloc[q][x] += v; RS.allocated[x] += v; RS.scheduled[x] += v;
     size_t i = ((size_t)q * k.npc + pc) * k.R + x;
     k.qAllocByPc[i] += v; k.qSchedByPc[i] += v;
   }
 }
-DEV void engineBackup(int q, int pc, double globalTokens) {
-  IterBackup& b = FL.bk;
-  b.hot = FL.hot[q]; b.tail = FL.headTail[q]; memcpy(b.req, FL.headReq[q], sizeof b.req);
-  b.kA = FL.kA[q]; b.kX = FL.kX[q]; b.kY = FL.kY[q]; b.effA = FL.effA[q]; b.effX = FL.effX[q]; b.effY = FL.effY[q];
-  b.globalTokens = globalTokens; b.pc = pc; b.inHeap = FL.inHeap[q];
-}
 DEV void engineRestore(int q) {
   const IterBackup& b = FL.bk;
-  FL.hot[q] = b.hot; FL.headTail[q] = b.tail; memcpy(FL.headReq[q], b.req, sizeof b.req);
+  FL.hot[q] = b.hot; FL.headTail[q] = FL.eng.tail; memcpy(FL.headReq[q], FL.eng.req, sizeof FL.eng.req);
   FL.kA[q] = b.kA; FL.kX[q] = b.kX; FL.kY[q] = b.kY; FL.effA[q] = b.effA; FL.effX[q] = b.effX; FL.effY[q] = b.effY;
   FL.inHeap[q] = b.inHeap;
 }
+DEV void pqHeadKey(PQState&, int t, PackedKey* key, uint32_t* nameRank) { key->A = FL.kA[t]; key->X = FL.kX[t]; key->Y = FL.kY[t]; *nameRank = (uint32_t)FL.nameRank[t]; }
 #else  // device versions: armada_sched.hip
 struct PQState { uint32_t A, N; unsigned long long X, Y; int q; int count; };  // lane i: the i-th queue in heap order
 DEV void pqBuild(PQState& s, int Q);
@@ -457,10 +455,10 @@ __device__ static void applyEvictedRange(Dev& d, int q, int p0, int p1, int sign
 DEV bool roundLimitExceeded(Dev& d, KREF k);
 DEV void bindUpdateEng(KREF k, FastS& S, int n, int nl, uint64_t keyDelta);
 DEV void accountVectorsBk(Dev& d, KREF k, int q, int pc, int sign);
-DEV void engineBackup(int q, int pc, double globalTokens);
 DEV void engineRestore(int q);
-DEV void enginePost(Dev& d, KREF k, int job, int q, int32_t prio, int32_t cutoff, int nl);
-DEV int engineWait();
+DEV void enginePost(Dev& d, KREF k, FastS& S, int job, int q, int pc, int32_t prio, int32_t cutoff, int nl);  // backup of queue q + the job, one LDS pass
+DEV int engineWait(const FastS& S);
+DEV void pqHeadKey(PQState& s, int t, PackedKey* key, uint32_t* nameRank);
 DEV void engineStart(Dev& d, FastS& S);
 DEV void engineStop(Dev& d, FastS& S);
 DEV bool headRequestsDisallowed(Dev& d, KREF k, int q);
@@ -645,6 +643,7 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
       w = pos - f.winStart;
       if (UNI32(FL.winRec[q][w].gang) >= 0) generic = true;
     }
+    SEG(10);
     if (generic) { ok = false; break; }  // the generic iterator continues from the same state
     int job = UNI32(FL.winJob[q][w]), shape = UNI32(FL.winRec[q][w].shape);
     if (kind == 0) f.itEi = pos + 1;
@@ -721,12 +720,17 @@ DEV int engineServe(Dev& d, KREF k, FastS& ES) {
 static FastS g_engS;
 DEV void engineStart(Dev&, FastS& S) { g_engS = S; g_engS.statScanSteps = 0; }
 DEV void engineStop(Dev&, FastS& S) { S.statScanSteps += g_engS.statScanSteps; if (g_engS.statL0Max > S.statL0Max) S.statL0Max = g_engS.statL0Max; }
-DEV void enginePost(Dev& d, KREF k, int job, int q, int32_t prio, int32_t cutoff, int nl) {
+DEV void enginePost(Dev& d, KREF k, FastS& S, int job, int q, int pc, int32_t prio, int32_t cutoff, int nl) {
+  IterBackup& b = FL.bk;
+  b.hot = FL.hot[q];
+  b.kA = FL.kA[q]; b.kX = FL.kX[q]; b.kY = FL.kY[q]; b.effA = FL.effA[q]; b.effX = FL.effX[q]; b.effY = FL.effY[q];
+  b.globalTokens = S.globalTokens; b.pc = pc; b.inHeap = FL.inHeap[q];
   FL.eng.tail = FL.headTail[q]; memcpy(FL.eng.req, FL.headReq[q], sizeof FL.eng.req);
   FL.eng.job = job; FL.eng.prio = prio; FL.eng.cutoff = cutoff; FL.eng.nl = nl;
+  S.engSeq++;
   FL.eng.status = engineServe(d, k, g_engS);
 }
-DEV int engineWait() { return FL.eng.status; }
+DEV int engineWait(const FastS&) { return FL.eng.status; }
 #endif
 
 // head of queue q was peeked by the generic code: fetch its record (one burst) and classify it
@@ -807,14 +811,15 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
     if (k.anyDisallowed && headRequestsDisallowed(d, k, q)) return 0;
     if (k.disableHome) return 0;
     prio = r.pcPrio;
+    SEG(8);
     if (fc.engine) {
       // two-wave iteration: the node engine takes first fit + bind; this wave goes on with the queue side assuming the job fits
       if (!S.engLive) { engineStart(d, S); S.engLive = 1; }
-      engineBackup(q, pcx, S.globalTokens);  // FL.hot[q] still holds the queue's state as of the start of this iteration
-      enginePost(d, k, job, q, prio, r.preemptible ? prio : NONPREEMPTIBLE_CUTOFF, r.nlPc);
+      SEG(9);
+      enginePost(d, k, S, job, q, pcx, prio, r.preemptible ? prio : NONPREEMPTIBLE_CUTOFF, r.nlPc);  // also saves queue q's state: FL.hot[q] is still as of the start of this iteration
       n = -1;
       if (fc.skipKnown && S.numUnfeasible > 0) {  // fastAdvance may record skipped jobs, which cannot be taken back: wait for the verdict
-        int v = engineWait();
+        int v = engineWait(S);
         if (v == 0) return 0;
         if (v == 2) { S.fastActive = 0; fastDrop(d); }
       } else S.engPend = q;
@@ -1014,7 +1019,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   c.l1Dirty = 1;
   const FastK k = fastKRef(d);
   FastS S;
-  S.tP0 = -1; S.engLive = 0; S.engPend = -1;
+  S.tP0 = -1; S.engLive = 0; S.engPend = -1; S.engWaitClk = 0; S.engSeq = 0;
   S.laneL = FLANE / (d.cfg.R > 0 ? d.cfg.R : 1); S.laneX = FLANE % (d.cfg.R > 0 ? d.cfg.R : 1);
   S.globalTokens = UNID(RS.globalTokens); S.globalBurst = UNI64(RS.globalBurst); S.globalRateInf = UNI32(RS.globalRateInf);
   S.numScheduledJobs = UNI32(RS.numScheduledJobs); S.numScheduledGangs = UNI32(RS.numScheduledGangs); S.numEvictedJobs = UNI32(RS.numEvictedJobs);
@@ -1036,13 +1041,15 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   // collect the node engine's verdict on the speculative iteration in flight; on a miss take it back and stop (the generic code redoes it)
 #define ENGINE_SETTLE(onMiss) \
   if (S.engPend >= 0) { \
-    int sq = S.engPend, sv = engineWait(); \
+    long long w0_ = CLK(); \
+    int sq = S.engPend, sv = engineWait(S); \
+    S.engWaitClk += CLK() - w0_; \
     S.engPend = -1; \
     if (sv == 2) { S.fastActive = 0; fastDrop(d); } \
     if (sv == 0) { \
       fastRollback(d, k, S, sq); \
       pqBuild(pq, Q); \
-      lastTop = sq; refK.A = UNI32(FL.kA[sq]); refK.X = UNI64(FL.kX[sq]); refK.Y = UNI64(FL.kY[sq]); refN = (uint32_t)UNI32(FL.nameRank[sq]); \
+      lastTop = sq; pqHeadKey(pq, sq, &refK, &refN); \
       pend = -1; \
       onMiss; \
     } \
@@ -1065,7 +1072,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
     }
 #endif
     lastTop = t;
-    if (t >= 0) { refK.A = UNI32(FL.kA[t]); refK.X = UNI64(FL.kX[t]); refK.Y = UNI64(FL.kY[t]); refN = (uint32_t)UNI32(FL.nameRank[t]); }
+    if (t >= 0) pqHeadKey(pq, t, &refK, &refN);  // lane 0 of the heap lanes
     if (t < 0) break;
     if (UNI32(FL.hot[t].gctx) < 0) break;  // a gang: generic
     KeyOut ko; ko.valid = 0; ko.A = 0; ko.X = ko.Y = 0;
@@ -1079,6 +1086,9 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   ENGINE_SETTLE((void)0)
 #undef ENGINE_SETTLE
   if (S.engLive) { engineStop(d, S); S.engLive = 0; }
+#ifndef ASCHED_FASTPROF
+  if (FLANE == 0 && S.engWaitClk) RS.statSeg[0] += S.engWaitClk;
+#endif
   if (c.skipActive) {  // generic code comes next: rebuild the exact interleaved state
     SkipDelta dl = fastExitSkip(d, fc, Q, lastTop, refK, refN);
     S.numEvictedJobs += dl.evicted; S.loopIterations += dl.iters; S.statRefills += dl.refills;
