@@ -151,14 +151,14 @@ def main():
     }
     # HBM bytes actually moved by one round launch: rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
     # collected once per round of work on this exact workload and committed under profiles/ (rocprofv3 cannot run inside bench.py)
-    pmc = os.path.join(ROOT, "profiles", "r01e_pmc_hbm_traffic.json")
+    pmc = os.path.join(ROOT, "profiles", "r01f_pmc_hbm_traffic.json")
     if os.path.exists(pmc) and args.nodes == 100_000 and args.jobs == 1_000_000 and args.queues == 64 and not args.gangs:
         try:
             c = json.load(open(pmc))["counters"]
             fetch = max(x["max_kb"] for x in c["FETCH_SIZE"] if x["kernel"].startswith("k_control"))
             write = max(x["max_kb"] for x in c["WRITE_SIZE"] if x["kernel"].startswith("k_control"))
             out["roofline"]["traffic"] = (2 * fetch + write) * 1024
-            out["roofline"]["traffic_source"] = "profiles/r01e_pmc_hbm_traffic.json (2*FETCH_SIZE + WRITE_SIZE of the round launch)"
+            out["roofline"]["traffic_source"] = "profiles/r01f_pmc_hbm_traffic.json (2*FETCH_SIZE + WRITE_SIZE of the round launch)"
         except Exception:
             pass
     if args.cpu_budget > 0 and world == 1:  # rank 0 at N=1 only
