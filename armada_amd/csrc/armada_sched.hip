@@ -245,7 +245,10 @@ __device__ static inline int wgCompactRun(Dev& d, const int32_t* order, int n, c
 }
 __device__ static inline int wgCompactFlagged(Dev& d, const int32_t* order, const int32_t* segOff, int nseg, int n, const uint8_t* flag, int32_t* dst, int32_t* outSegOff) {
   int total = wgCompactRun(d, order, n, flag, dst, d.evSortKey);
-  for (int q = threadIdx.x & 63; q <= nseg; q += 64) outSegOff[q] = segOff[q] < n ? (int32_t)d.evSortKey[segOff[q]] : total;
+  for (int base = 0; base <= nseg; base += 64) {  // same trip count on every lane
+    int q = base + (int)(threadIdx.x & 63);
+    if (q <= nseg) outSegOff[q] = segOff[q] < n ? (int32_t)d.evSortKey[segOff[q]] : total;
+  }
   __threadfence();
   return total;
 }
@@ -255,8 +258,12 @@ __device__ static inline int wgCompactIota(Dev& d, int n, const uint8_t* flag, i
 __device__ static inline int pqTop(Dev& d, const Ctl& c) {
   int lane = threadIdx.x & 63;
   int best = -1;
-  for (int q = lane; q < d.cfg.Q; q += 64)
-    if (d.pqInHeap[q] && (best < 0 || pqLess(d, c, q, best))) best = q;
+  int Q = d.cfg.Q;
+  for (int base = 0; base < Q; base += 64) {  // same trip count on every lane: the wave stays converged for the shuffles below
+    int q = base + lane;
+    bool in = q < Q && d.pqInHeap[q < Q ? q : 0];
+    if (in && (best < 0 || pqLess(d, c, q, best))) best = q;
+  }
   for (int off = 32; off; off >>= 1) {
     int o = __shfl_xor(best, off, 64);
     if (o >= 0 && (best < 0 || pqLess(d, c, o, best))) best = o;
@@ -702,7 +709,7 @@ __device__ static void relocateIn(Dev& d, int cmd) {
     g_nreloc = 0;
     g_rsGlobal = d.rs;
     int Q = d.cfg.Q, R = d.cfg.R, npc = d.cfg.npc;
-    bool want = (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY) && Q > 0 && d.qWeight != nullptr;
+    bool want = (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY) && Q > 0 && d.qWeight != nullptr && (Q <= QCAPF || d.f.relocAll);
     if (want) {
       int off = 0, n = 0; bool fits = true;
       auto add = [&](void** pp, int bytes) {

@@ -65,6 +65,16 @@ DEV int wgCompactIota(Dev&, int n, const uint8_t* flag, int32_t* dst) { int c = 
 DEV int pqTop(Dev& d, const Ctl& c) {
   int best = -1;
   for (int q = 0; q < d.cfg.Q; q++) if (d.pqInHeap[q] && (best < 0 || pqLess(d, c, q, best))) best = q;
+  if (getenv("HOSTSIM_TOURNAMENT")) {  // the device's lane tournament (armada_sched.hip pqTop), emulated: must pick the same queue
+    int lb[64];
+    for (int lane = 0; lane < 64; lane++) { lb[lane] = -1; for (int q = lane; q < d.cfg.Q; q += 64) if (d.pqInHeap[q] && (lb[lane] < 0 || pqLess(d, c, q, lb[lane]))) lb[lane] = q; }
+    for (int off = 32; off; off >>= 1) {
+      int nb[64];
+      for (int lane = 0; lane < 64; lane++) { int o = lb[lane ^ off], b = lb[lane]; if (o >= 0 && (b < 0 || pqLess(d, c, o, b))) b = o; nb[lane] = b; }
+      for (int lane = 0; lane < 64; lane++) lb[lane] = nb[lane];
+    }
+    if (lb[0] != best) { fprintf(stderr, "hostsim: lane tournament picks queue %d, serial argmin %d (Q=%d)\n", lb[0], best, d.cfg.Q); abort(); }
+  }
   return best;
 }
 

@@ -111,6 +111,41 @@ def test_two_live_handles_interleaved(hip_lib, oracle_lib):
         for i in (0, 1):
             scenario.assert_same_round(want[i], got[i])
 
+def _subset(wl, keep):
+    import copy
+    wl = copy.deepcopy(wl)
+    idx = np.nonzero(keep)[0]
+    remap = -np.ones(wl.num_jobs, dtype=np.int64); remap[idx] = np.arange(len(idx))
+    for f in ("job_req", "job_queue", "job_pc", "job_submit", "job_node", "job_run_prio", "job_run_ts", "job_gang", "job_gang_card"):
+        setattr(wl, f, getattr(wl, f)[idx])
+    wl.queued = [np.array([remap[j] for j in q if remap[j] >= 0], dtype=np.int32) for q in wl.queued]
+    return wl
+
+
+def _degenerate_cases():
+    import copy
+    base = W.small_random(n_nodes=12, n_jobs=80, n_queues=3, seed=5, occupied=0.5, gangs=1)
+    cases = {"no-queued": _subset(base, base.job_node >= 0), "no-running": _subset(base, base.job_node < 0),
+             "no-jobs": _subset(base, np.zeros(base.num_jobs, dtype=bool))}
+    wl = copy.deepcopy(base); wl.queued[1] = np.zeros(0, np.int32); cases["empty-queue"] = wl
+    cases["one-node-one-job"] = W.small_random(n_nodes=1, n_jobs=1, n_queues=1, seed=9, occupied=0.0, gangs=0)
+    wl = copy.deepcopy(base); wl.job_req[wl.job_node < 0, 1] = 10 ** 9; cases["nothing-fits"] = wl
+    wl = copy.deepcopy(base); wl.global_burst, wl.queue_burst, wl.rate_inf = 0, 0, False; cases["zero-burst"] = wl
+    cases["70-queues"] = W.small_random(n_nodes=30, n_jobs=700, n_queues=70, seed=13, occupied=0.7, gangs=2)  # > 64: queue loop off the fast path
+    return cases
+
+
+@pytest.mark.parametrize("name", ["no-queued", "no-running", "no-jobs", "empty-queue", "one-node-one-job", "nothing-fits", "zero-burst", "70-queues"])
+def test_degenerate_rounds_match_oracle(hip_lib, oracle_lib, name):
+    """empty and ragged inputs: no queued / running / any jobs, an empty queue, 1x1, unschedulable requests, exhausted limiters, Q > 64"""
+    wl = _degenerate_cases()[name]
+    res = []
+    for lib in (oracle_lib, hip_lib):
+        s = W.load(lib, wl)
+        W.prepare(s, wl)
+        res.append(s.schedule_round())
+    scenario.assert_same_round(res[0], res[1])
+
 
 def test_fit_select_batch_config2(hip_lib, oracle_lib):
     """BASELINE config 2: 10k nodes, 100k jobs, first feasible node per job against a fixed state, bit-exact node ids."""
