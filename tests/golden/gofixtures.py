@@ -75,8 +75,74 @@ TEST_PRIORITY_CLASSES = {  # testfixtures.go:78-105
 TestPriorities = [0, 1, 2, 3, 28000, 29000, 30000]
 
 
+class GoConfig(dict):
+    """configuration.SchedulingConfig as the fixtures model it, plus the Go field assignments the test tables make in func literals"""
+
+    def __setitem__(self, k, v):
+        if k == "DefaultPriorityClassName":
+            dict.__setitem__(self, "default_priority_class", v)
+        elif k == "WellKnownNodeTypes":
+            dict.__setitem__(self, "well_known_node_types",
+                             {t["Name"]: [[x["Key"], x.get("Value", ""), x.get("Effect", "")] for x in t.get("Taints", [])] for t in v})
+        elif k == "PriorityClasses":  # map[string]types.PriorityClass{name: {Priority, Preemptible, AwayNodeTypes: [{Priority, WellKnownNodeTypeName}]}}
+            out = {}
+            for name, pc in v.items():
+                extra = set(pc) - {"Priority", "Preemptible", "AwayNodeTypes"}
+                if extra:
+                    raise Unsupported(f"PriorityClass fields {sorted(extra)}")
+                e = {"priority": int(pc.get("Priority", 0)), "preemptible": bool(pc.get("Preemptible", False))}
+                away = []
+                for a in pc.get("AwayNodeTypes") or []:
+                    if set(a) - {"Priority", "WellKnownNodeTypeName"}:
+                        raise Unsupported(f"AwayNodeType fields {sorted(a)}")
+                    away.append([int(a["Priority"]), a["WellKnownNodeTypeName"]])
+                if away:
+                    e["away"] = away
+                out[name] = e
+            dict.__setitem__(self, "priority_classes", out)
+        elif k == "ProtectedFractionOfFairShare":
+            dict.__setitem__(self, "protected_fraction_of_fair_share", float(v))
+        elif k == "MaximumPerQueueSchedulingBurst":
+            dict.__setitem__(self, "maximum_per_queue_scheduling_burst", int(v))
+        elif k == "MaximumPerQueueSchedulingRate":
+            dict.__setitem__(self, "maximum_per_queue_scheduling_rate", float(v))
+        elif k == "MaximumSchedulingBurst":
+            dict.__setitem__(self, "maximum_scheduling_burst", int(v))
+        elif k == "MaximumSchedulingRate":
+            dict.__setitem__(self, "maximum_scheduling_rate", float(v))
+        elif k[:1].isupper():
+            raise Unsupported(f"assignment to SchedulingConfig.{k}")
+        else:
+            dict.__setitem__(self, k, v)
+
+
+def _norm_toleration(t):
+    if isinstance(t, dict) and "Key" in t:  # v1.Toleration{Key, Operator, Value, Effect}
+        return {"key": t.get("Key", ""), "op": t.get("Operator") or "Equal", "value": t.get("Value", ""), "effect": t.get("Effect", "")}
+    return t
+
+
+class PodReqs(dict):
+    """PodRequirements as the fixtures model them; the Go field names the tables read / assign map onto the fixture keys"""
+    ALIAS = {"Tolerations": "tolerations", "NodeSelector": "selector"}
+
+    def __contains__(self, k):
+        return dict.__contains__(self, self.ALIAS.get(k, k))
+
+    def __getitem__(self, k):
+        return dict.__getitem__(self, self.ALIAS.get(k, k))
+
+    def __setitem__(self, k, v):
+        k2 = self.ALIAS.get(k, k)
+        if k2 != k and k2 == "tolerations":
+            v = [_norm_toleration(t) for t in v]
+        elif k2 == k and k[:1].isupper():
+            raise Unsupported(f"assignment to PodRequirements.{k}")
+        dict.__setitem__(self, k2, v)
+
+
 def TestSchedulingConfig():  # testfixtures.go:225-249
-    return {
+    return GoConfig({
         "priority_classes": copy.deepcopy(TEST_PRIORITY_CLASSES),
         "maximum_scheduling_rate": math.inf, "maximum_scheduling_burst": 2**62,
         "maximum_per_queue_scheduling_rate": math.inf, "maximum_per_queue_scheduling_burst": 2**62,
@@ -91,7 +157,7 @@ def TestSchedulingConfig():  # testfixtures.go:225-249
         "maximum_resource_fraction_to_schedule": {},
         "disable_home": False, "disable_away": False, "disable_gang_away": False, "disable_fairshare": False, "disable_urgency": False,
         "disallowed_resources": [],
-    }
+    })
 
 
 def _cfg(fn):
@@ -153,7 +219,7 @@ def ResourceType(**kw):
 
 # ------------------------------------------------------------------ pod requirements / jobs
 def _podreqs(requests, tolerations=None):
-    return {"req": rl(requests, round_up=True), "tolerations": tolerations or [], "selector": {}, "affinity": None}
+    return PodReqs({"req": rl(requests, round_up=True), "tolerations": tolerations or [], "selector": {}, "affinity": None})
 
 
 def Test1Cpu4GiPodReqs(): return _podreqs({"cpu": "1", "memory": "4Gi"})

@@ -6,12 +6,14 @@ into the JSON fixtures committed under tests/golden/.
 It parses expressions (identifiers, selectors, calls, composite literals with elided inner types,
 basic literals, unary/binary arithmetic) into an AST and evaluates them against an environment of
 Python callables that re-implement the reference's test fixtures (see gofixtures.py).
-Anything outside the subset (func literals, statements) raises Unsupported so the case is skipped
-and reported rather than silently mis-transcribed.
+Immediately-invoked func literals (`func() T { ... }()`) are supported for the statement forms the tables use: `var x T`,
+`x := e`, `x = e` / `x.F = e`, three-clause `for` loops with `i++`, expression statements and `return e`.
+Anything outside the subset raises Unsupported so the case is skipped and reported rather than silently mis-transcribed.
 """
 from __future__ import annotations
 
 import re
+from collections import ChainMap
 from typing import Any, List, Optional, Tuple
 
 
@@ -119,6 +121,8 @@ class Parser:
         PREC = {"||": 1, "&&": 2, "==": 3, "!=": 3, "<": 3, ">": 3, "<=": 3, ">=": 3, "+": 4, "-": 4, "*": 5, "/": 5}
         while True:
             k, t, _ = self.peek()
+            if t == "+" and self.peek(1)[1] == "+":  # i++ (statement), not a binary plus
+                return left
             if k == "op" and t in PREC and PREC[t] > prec:
                 self.next()
                 right = self.parse_expr(PREC[t])
@@ -152,7 +156,7 @@ class Parser:
             self.expect(")")
             return e
         if t == "func":
-            raise Unsupported(f"line {ln}: func literal")
+            return self.parse_funclit()
         if t == "{":  # elided-type composite literal
             return self.parse_composite(None)
         if self.looks_like_type():
@@ -173,6 +177,65 @@ class Parser:
                 return ("lit", None)
             return ("name", t)
         raise Unsupported(f"line {ln}: unexpected token {t!r}")
+
+    # ---- func literals: func() T { stmts }
+    def parse_funclit(self):
+        ln = self.peek()[2]
+        self.expect("func")
+        self.expect("(")
+        if self.peek()[1] != ")":
+            raise Unsupported(f"line {ln}: func literal with parameters")
+        self.expect(")")
+        if self.peek()[1] != "{":
+            self.parse_type()  # result type
+        return ("funclit", self.parse_block())
+
+    def parse_block(self):
+        self.expect("{")
+        stmts = []
+        while self.peek()[1] != "}":
+            stmts.append(self.parse_stmt())
+            self.accept(";")
+        self.expect("}")
+        return stmts
+
+    def parse_simple_stmt(self):
+        e = self.parse_expr()
+        if self.accept(":="):
+            return ("assign", e, self.parse_expr(), True)
+        if self.accept("="):
+            return ("assign", e, self.parse_expr(), False)
+        if self.peek()[1] == "+" and self.peek(1)[1] == "+":
+            self.next(); self.next()
+            return ("inc", e)
+        return ("expr", e)
+
+    def parse_stmt(self):
+        k, t, ln = self.peek()
+        if t == "var":
+            self.next()
+            name = self.next()[1]
+            ty = self.parse_type()
+            init = None
+            if self.accept("="):
+                init = self.parse_expr()
+            return ("var", name, ty, init)
+        if t == "return":
+            self.next()
+            if self.peek()[1] == "}":
+                return ("return", None)
+            return ("return", self.parse_expr())
+        if t == "for":
+            self.next()
+            init = self.parse_simple_stmt()
+            self.expect(";")
+            cond = self.parse_expr()
+            self.expect(";")
+            post = self.parse_simple_stmt()
+            return ("for", init, cond, post, self.parse_block())
+        if t in ("if", "switch", "go", "defer", "range"):
+            raise Unsupported(f"line {ln}: statement {t}")
+        return self.parse_simple_stmt()
 
     def parse_postfix(self, e):
         while True:
@@ -254,7 +317,21 @@ class Evaluator:
             name = node[1]
             if name in self.env:
                 return self.env[name]
+            parts = name.split(".")
+            for cut in range(len(parts) - 1, 0, -1):  # a local variable followed by field selectors
+                head = ".".join(parts[:cut])
+                if head in self.env:
+                    v = self.env[head]
+                    for f in parts[cut:]:
+                        if isinstance(v, dict) and f in v:
+                            v = v[f]
+                        else:
+                            raise Unsupported(f"selector .{f} on {head}")
+                    return v
             raise Unsupported(f"unknown name {name}")
+        if kind == "funclit":
+            body = node[1]
+            return lambda: Evaluator(self._child_env()).run_block(body)[1]
         if kind == "unary":
             v = self.ev(node[2])
             if node[1] == "-":
@@ -275,6 +352,18 @@ class Evaluator:
                 if isinstance(a, int) and isinstance(b, int):
                     return a // b
                 return a / b
+            if op == "<":
+                return a < b
+            if op == "<=":
+                return a <= b
+            if op == ">":
+                return a > b
+            if op == ">=":
+                return a >= b
+            if op == "==":
+                return a == b
+            if op == "!=":
+                return a != b
             raise Unsupported(f"binary op {op}")
         if kind == "conv":
             return self.ev(node[2])
@@ -303,6 +392,78 @@ class Evaluator:
             t = node[1] if node[1] is not None else ty
             return self.comp(t, node[2])
         raise Unsupported(f"node {kind}")
+
+    # ---- statements (func literal bodies)
+    class _Return(Exception):
+        pass
+
+    def _child_env(self):  # a flat chain: assignments must reach the scope that declared the variable
+        return self.env.new_child() if isinstance(self.env, ChainMap) else ChainMap({}, self.env)
+
+    def _scope_of(self, name):
+        if isinstance(self.env, ChainMap):
+            for m in self.env.maps:
+                if name in m:
+                    return m
+        return None
+
+    def assign(self, target, value, define):
+        if target[0] == "name":
+            parts = target[1].split(".")
+            if len(parts) == 1:
+                m = None if define else self._scope_of(parts[0])
+                if m is None:
+                    m = self.env.maps[0] if isinstance(self.env, ChainMap) else self.env
+                m[parts[0]] = value
+                return
+            obj = self.ev(("name", ".".join(parts[:-1])))
+            if not isinstance(obj, dict):
+                raise Unsupported(f"assignment to field of non-struct {target[1]}")
+            obj[parts[-1]] = value
+            return
+        if target[0] == "sel":
+            obj = self.ev(target[1])
+            if not isinstance(obj, dict):
+                raise Unsupported("assignment to field of non-struct")
+            obj[target[2]] = value
+            return
+        if target[0] == "index":
+            self.ev(target[1])[self.ev(target[2])] = value
+            return
+        raise Unsupported(f"assignment target {target[0]}")
+
+    def run_block(self, stmts):
+        """returns (returned?, value)"""
+        for st in stmts:
+            k = st[0]
+            if k == "var":
+                ty = st[2]
+                zero = [] if ty[0] == "slice" else ({} if ty[0] == "map" else None)
+                self.assign(("name", st[1]), self.ev(st[3], ty) if st[3] is not None else zero, True)
+            elif k == "assign":
+                self.assign(st[1], self.ev(st[2]), st[3])
+            elif k == "inc":
+                self.assign(st[1], self.ev(st[1]) + 1, False)
+            elif k == "expr":
+                self.ev(st[1])
+            elif k == "return":
+                return True, (self.ev(st[1]) if st[1] is not None else None)
+            elif k == "for":
+                _, init, cond, post, body = st
+                loop = Evaluator(self._child_env())
+                loop.run_block([init])
+                guard = 0
+                while loop.ev(cond):
+                    r = Evaluator(loop._child_env()).run_block(body)
+                    if r[0]:
+                        return r
+                    loop.run_block([post])
+                    guard += 1
+                    if guard > 100000:
+                        raise Unsupported("loop does not terminate")
+            else:
+                raise Unsupported(f"statement {k}")
+        return False, None
 
     def comp(self, ty, elems):
         while ty is not None and ty[0] == "ptr":
