@@ -103,6 +103,18 @@ def main():
     out["node_type_iterator"] = extract_table(f"{REF}/nodedb/nodeiteration_test.go", "TestNodeTypeIterator", nenv, skipped)
     out["node_types_iterator"] = extract_table(f"{REF}/nodedb/nodeiteration_test.go", "TestNodeTypesIterator", nenv, skipped)
 
+    # NodeDb-level tables: nodedb/nodedb_test.go:502-667 (one job at a time) and :668-743 (one group at a time), both through
+    # ScheduleManyWithTxn inside a transaction that is committed on success and aborted on failure; newNodeDbWithNodes (:1747) uses
+    # the same priority classes / indexed resources / taints / labels / well-known node types as TestSchedulingConfig
+    denv = dict(env)
+    denv["gangSuccess"] = gofixtures.WithGangAnnotationsJobs(gofixtures.N1Cpu4GiJobs("A", gofixtures.PriorityClass0, 32))
+    denv["gangFailure"] = gofixtures.WithGangAnnotationsJobs(gofixtures.N1Cpu4GiJobs("A", gofixtures.PriorityClass0, 33))
+    for key, fn in (("nodedb_schedule_individually", "TestScheduleIndividually"), ("nodedb_schedule_many", "TestScheduleMany")):
+        cases = extract_table(f"{REF}/nodedb/nodedb_test.go", fn, denv, skipped)
+        for c in cases:
+            c["SchedulingConfig"] = to_json(gofixtures.TestSchedulingConfig())
+        out[key] = cases
+
     for k, v in out.items():
         path = os.path.join(HERE, f"{k}_cases.json")
         with open(path, "w") as f:

@@ -409,6 +409,39 @@ def run_gang_case(lib: Library, case: dict):
     return "ok"
 
 
+def run_nodedb_schedule_case(lib: Library, case: dict):
+    """nodedb_test.go TestScheduleIndividually (:502-667) / TestScheduleMany (:668-743): each job (or group) goes through
+    ScheduleManyWithTxn inside a write transaction that is committed on success and aborted on failure; the expectation is the
+    success flag per job / group, plus (on success) a node for every member and its request accounted on that node."""
+    groups = case["Jobs"]
+    if groups and isinstance(groups[0], dict):
+        groups = [[j] for j in groups]
+    jobs = [j for g in groups for j in g]
+    why = uses_unsupported(case, jobs)
+    if why:
+        return "skip: " + why
+    c = Case(lib, case["SchedulingConfig"], case["Nodes"])
+    s = c.sched
+    queues = sorted({j["queue"] for j in jobs})
+    c.set_jobs(jobs, {q: i for i, q in enumerate(queues)}, {})
+    base = 0
+    for gi, g in enumerate(groups):
+        ids = list(range(base, base + len(g)))
+        base += len(g)
+        before = {n: s.get_alloc(n).copy() for n in range(len(case["Nodes"]))}
+        s.txn_begin()
+        ok, pods, _ = s.schedule_many(ids)
+        assert ok == case["ExpectSuccess"][gi], f"group {gi}: success {ok}, expected {case['ExpectSuccess'][gi]}"
+        if not ok:
+            s.txn_abort()
+            for n in before:  # the aborted transaction leaves the NodeDb exactly as it was
+                assert (s.get_alloc(n) == before[n]).all(), f"group {gi}: abort did not restore node {n}"
+            continue
+        s.txn_commit()
+        assert all(p.node >= 0 for p in pods), f"group {gi}: a scheduled member has no node"
+    return "ok"
+
+
 def run_node_iteration_case(lib: Library, case: dict) -> List[int]:
     """nodedb/nodeiteration_test.go:308-372 and :637-695: node ids are "0".."n-1" (string order breaks ties
     across node types); TestNodeTypesIterator also forces node.index = i."""

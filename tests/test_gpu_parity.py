@@ -146,6 +146,16 @@ def test_degenerate_rounds_match_oracle(hip_lib, oracle_lib, name):
         res.append(s.schedule_round())
     scenario.assert_same_round(res[0], res[1])
 
+NODEDB = load("nodedb_schedule_individually") + load("nodedb_schedule_many")
+
+
+@pytest.mark.parametrize("case", NODEDB, ids=[c["source"].split("/")[-1] + ":" + c["name"] for c in NODEDB])
+def test_nodedb_schedule_many_with_txn(hip_lib, case):
+    """nodedb_test.go TestScheduleIndividually / TestScheduleMany through the NodeDb-level entry points (txn_begin, schedule_many, commit / abort)"""
+    r = scenario.run_nodedb_schedule_case(hip_lib, case)
+    if r != "ok":
+        pytest.skip(r)
+
 
 def test_fit_select_batch_config2(hip_lib, oracle_lib):
     """BASELINE config 2: 10k nodes, 100k jobs, first feasible node per job against a fixed state, bit-exact node ids."""

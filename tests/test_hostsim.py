@@ -122,3 +122,13 @@ def test_degenerate_rounds_match_oracle(hostsim_lib, oracle_lib, name):
         W.prepare(s, wl)
         res.append(s.schedule_round())
     scenario.assert_same_round(res[0], res[1])
+
+NODEDB = load("nodedb_schedule_individually") + load("nodedb_schedule_many")
+
+
+@pytest.mark.parametrize("case", NODEDB, ids=[c["source"].split("/")[-1] + ":" + c["name"] for c in NODEDB])
+def test_nodedb_schedule_many_with_txn(hostsim_lib, case):
+    """nodedb_test.go TestScheduleIndividually / TestScheduleMany through the NodeDb-level entry points (txn_begin, schedule_many, commit / abort)"""
+    r = scenario.run_nodedb_schedule_case(hostsim_lib, case)
+    if r != "ok":
+        pytest.skip(r)

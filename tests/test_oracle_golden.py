@@ -68,3 +68,13 @@ def test_fair_shares_exact(oracle_lib, case):
         assert got[q][0] == case["expectedFairShares"][q], (q, got[q], case["source"])
         assert got[q][1] == case["expectedDemandCappedAdjustedFairShares"][q], (q, got[q], case["source"])
         assert got[q][2] == case["expectedUncappedAdjustedFairShares"][q], (q, got[q], case["source"])
+
+NODEDB = load("nodedb_schedule_individually") + load("nodedb_schedule_many")
+
+
+@pytest.mark.parametrize("case", NODEDB, ids=[c["source"].split("/")[-1] + ":" + c["name"] for c in NODEDB])
+def test_nodedb_schedule_many_with_txn(oracle_lib, case):
+    """nodedb_test.go TestScheduleIndividually / TestScheduleMany through the NodeDb-level entry points (txn_begin, schedule_many, commit / abort)"""
+    r = scenario.run_nodedb_schedule_case(oracle_lib, case)
+    if r != "ok":
+        pytest.skip(r)
