@@ -115,6 +115,23 @@ def main():
             c["SchedulingConfig"] = to_json(gofixtures.TestSchedulingConfig())
         out[key] = cases
 
+    # nodedb_test.go:1293-1432 TestAwayNodeScheduling: the table holds parameters, the test body builds the NodeDb, node and job from
+    # them; that body is restated here (same fixtures) so that the case carries config / nodes / jobs like the other NodeDb-level cases
+    import copy
+    away = []
+    for r in extract_table(f"{REF}/nodedb/nodedb_test.go", "TestAwayNodeScheduling", env, skipped):
+        cfg = gofixtures.TestSchedulingConfig()
+        t = r["wellKnownNodeTypeTaint"]
+        cfg["well_known_node_types"] = {"gpu": [[t["Key"], t["Value"], t["Effect"]]], "large": [["large", "true", "NoSchedule"]]}  # :1361-1364
+        cfg["disable_away"] = bool(r.get("disableAwayScheduling")); cfg["disable_gang_away"] = bool(r.get("disableGangAwayScheduling"))  # :1368-1371
+        node = gofixtures.AddTaints([gofixtures.Test32CpuNode([29000, 30000])], [r["nodeTaint"]])[0]      # :1374-1378
+        job = gofixtures.TestJob("testQueue", None, "armada-preemptible-away", gofixtures.Test1Cpu4GiPodReqs())  # :1380-1385
+        if r.get("shouldSubmitGang"):
+            job = gofixtures.WithGangAnnotationsJobs([copy.deepcopy(job), copy.deepcopy(job)])[0]         # :1386-1388
+        away.append({"name": r["name"], "source": r["source"], "SchedulingConfig": to_json(cfg), "Nodes": to_json([node]), "Jobs": to_json([job]),
+                     "ExpectSuccess": [bool(r["expectSuccess"])], "ExpectAway": {"node": 0, "priority": 29000}})       # :1399-1427
+    out["nodedb_away_node_scheduling"] = away
+
     for k, v in out.items():
         path = os.path.join(HERE, f"{k}_cases.json")
         with open(path, "w") as f:

@@ -439,6 +439,9 @@ def run_nodedb_schedule_case(lib: Library, case: dict):
             continue
         s.txn_commit()
         assert all(p.node >= 0 for p in pods), f"group {gi}: a scheduled member has no node"
+        exp = case.get("ExpectAway")
+        if exp:  # TestAwayNodeScheduling :1399-1404: the node, ScheduledAsAwayJob, the away type's priority
+            assert pods[0].node == exp["node"] and pods[0].method == 5 and pods[0].scheduled_at_priority == exp["priority"], f"away result {pods[0]}"
     return "ok"
 
 

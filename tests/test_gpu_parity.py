@@ -198,3 +198,16 @@ def test_round_is_idempotent_under_reprepare(hip_lib):
     for n in range(0, wl.num_nodes, 97):
         al = s.get_alloc(n)
         assert (al[2:] >= 0).all()
+
+
+NODEDB_AWAY = load("nodedb_away_node_scheduling")
+
+
+@pytest.mark.parametrize("case", NODEDB_AWAY, ids=[c["name"] for c in NODEDB_AWAY])
+def test_nodedb_away_node_scheduling(hip_lib, case):
+    """nodedb_test.go TestAwayNodeScheduling (:1293-1432): away scheduling through ScheduleManyWithTxn, wildcard well-known taint,
+    DisableAwayScheduling / DisableGangAwayScheduling"""
+    r = scenario.run_nodedb_schedule_case(hip_lib, case)
+    if r != "ok":
+        pytest.skip(r)
+

@@ -123,7 +123,7 @@ def test_degenerate_rounds_match_oracle(hostsim_lib, oracle_lib, name):
         res.append(s.schedule_round())
     scenario.assert_same_round(res[0], res[1])
 
-NODEDB = load("nodedb_schedule_individually") + load("nodedb_schedule_many")
+NODEDB = load("nodedb_schedule_individually") + load("nodedb_schedule_many") + load("nodedb_away_node_scheduling")
 
 
 @pytest.mark.parametrize("case", NODEDB, ids=[c["source"].split("/")[-1] + ":" + c["name"] for c in NODEDB])

@@ -69,7 +69,7 @@ def test_fair_shares_exact(oracle_lib, case):
         assert got[q][1] == case["expectedDemandCappedAdjustedFairShares"][q], (q, got[q], case["source"])
         assert got[q][2] == case["expectedUncappedAdjustedFairShares"][q], (q, got[q], case["source"])
 
-NODEDB = load("nodedb_schedule_individually") + load("nodedb_schedule_many")
+NODEDB = load("nodedb_schedule_individually") + load("nodedb_schedule_many") + load("nodedb_away_node_scheduling")
 
 
 @pytest.mark.parametrize("case", NODEDB, ids=[c["source"].split("/")[-1] + ":" + c["name"] for c in NODEDB])
