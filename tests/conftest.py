@@ -38,3 +38,13 @@ def hip_lib():
     """The product: the HIP implementation.  No fallback — missing library is a hard failure."""
     import armada_amd
     return armada_amd.load_library()
+
+
+@pytest.fixture(scope="session")
+def hostsim_lib():
+    """The device control code compiled for the CPU (tests/hostsim): logic checks without a GPU, never shipped."""
+    from armada_amd.binding import Library
+    here = os.path.join(ROOT, "tests", "hostsim")
+    subprocess.check_call(["make", "-C", here])
+    return Library(os.path.join(here, "libhostsim.so"), "asched_")
+

@@ -15,12 +15,6 @@ from golden_io import ids, load
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.fixture(scope="session")
-def hostsim_lib():
-    subprocess.check_call(["make", "-C", os.path.join(HERE, "hostsim")])
-    return Library(os.path.join(HERE, "hostsim", "libhostsim.so"), "asched_")
-
-
 def _run(fn, lib, case):
     try:
         r = fn(lib, case)
