@@ -84,6 +84,7 @@ class Case:
             protected_fraction_of_fair_share=cfg["protected_fraction_of_fair_share"],
             max_queue_lookback=cfg["max_queue_lookback"],
             max_fraction_to_schedule=[float(inf(frac.get(r, "inf"))) for r in RES],
+            disallowed_resource=[int(r in (cfg.get("disallowed_resources") or [])) for r in RES],
         )
         self.sched = Scheduler(lib, self.config)
         self.nodes = nodes

@@ -115,3 +115,84 @@ def test_fair_share_preemption_respects_priority_order(lib, evicted_pc, new_pc, 
         assert pods[0].node == 0 and pods[0].method == METHOD_FAIRSHARE   # :1092-1095
     else:
         assert pods[0].node < 0                                            # :1097-1098
+
+
+METHOD_URGENCY = 4  # ASCHED_METHOD_URGENCY
+
+
+@pytest.mark.parametrize("register_evicted,disable_fair,disable_urgency,expect,method", [
+    (False, False, False, True, METHOD_URGENCY),     # urgency-based preemption by default
+    (False, False, True, False, None),               # no urgency-based preemption when disabled
+    (True, False, False, True, METHOD_FAIRSHARE),    # fair-share preemption by default
+    (True, True, False, True, METHOD_URGENCY),       # falls through to urgency-based preemption when fair-share disabled
+    (True, False, True, True, METHOD_FAIRSHARE),     # fair-share preemption when urgency disabled
+    (True, True, True, False, None),                 # no preemption when both strategies disabled
+])
+def test_preemption_scheduling(lib, register_evicted, disable_fair, disable_urgency, expect, method):
+    """nodedb_test.go:930-1023 TestPreemptionScheduling: a node filled with 32 priority-0 jobs and one incoming priority-1 job;
+    which preemption strategy places it depends on whether the incumbents are registered as evicted and on the two switches."""
+    node = F.Test32CpuNode(F.TestPriorities)
+    bound = F.N1Cpu4GiJobs("A", F.PriorityClass0, 32)
+    incoming = F.N1Cpu4GiJobs("B", F.PriorityClass1, 1)[0]
+    c = _case(lib, [node], bound + [incoming], disable_fairshare=disable_fair, disable_urgency=disable_urgency)
+    s = c.sched
+    for i in range(32):                                  # :984-986
+        s.bind(i, 0, 0)
+    if register_evicted:                                 # :988-1001
+        for i in range(32):
+            s.evict(i, 0)
+            s.add_evicted(i, i, 0)
+    s.txn_begin()
+    ok, pods, _ = s.schedule_many([32])
+    s.txn_abort()
+    assert ok == expect                                  # :1011
+    if expect:
+        assert pods[0].node == 0 and pods[0].method == method   # :1013-1016
+    else:
+        assert pods[0].node < 0
+
+
+def test_eviction_bucket_values(lib):
+    """nodedb_test.go:438-498 TestEviction: explicit AllocatableByPriority of a 32-cpu node holding a preemptible priority-0 job and a
+    non-preemptible priority-3 job (debited at every level), before and after both are evicted."""
+    node = F.Test32CpuNode(F.TestPriorities)
+    jobs = [F.Test1Cpu4GiJob("queue-alice", F.PriorityClass0), F.Test1Cpu4GiJob("queue-alice", F.PriorityClass3)]
+    c = _case(lib, [node], jobs)
+    s = c.sched
+    s.bind(0, 0, 0)
+    s.bind(1, 0, 3)
+
+    def cpu_mem(cpu, mem):
+        return np.array(scenario.vec(F.rl({"cpu": cpu, "memory": mem})), dtype=np.int64)
+
+    want = {-2: cpu_mem("30", "248Gi"), -1: cpu_mem("30", "248Gi"), 0: cpu_mem("30", "248Gi")}   # :463-473
+    for p in (1, 2, 3, 28000, 29000, 30000):
+        want[p] = cpu_mem("31", "252Gi")
+    got = s.get_alloc(0)
+    for l, p in enumerate(s.priorities):
+        assert (got[l] == want[p]).all(), f"bound: priority {p}: {got[l]} != {want[p]}"
+    s.evict(0, 0)
+    s.evict(1, 0)
+    want = {p: cpu_mem("32", "256Gi") for p in s.priorities}                                      # :488-498
+    want[-2] = cpu_mem("30", "248Gi")
+    got = s.get_alloc(0)
+    for l, p in enumerate(s.priorities):
+        assert (got[l] == want[p]).all(), f"evicted: priority {p}: {got[l]} != {want[p]}"
+
+
+@pytest.mark.parametrize("disallowed,evicted,expect", [
+    ([], False, True),          # scheduled - only using allowed resources
+    (["cpu"], False, False),    # not scheduled - using disallowed resources
+    (["cpu"], True, True),      # scheduled - reschedules even if using disallowed resources
+])
+def test_disallowed_job_resources(lib, disallowed, evicted, expect):
+    """nodedb_test.go:745-798 TestDisallowedJobResources through SelectNodeForJobWithTxn: a job requesting a disallowed resource is
+    refused unless it is an evicted job returning to its node."""
+    node = F.Test32CpuNode(F.TestPriorities)
+    job = F.Test1Cpu4GiJob("A", F.PriorityClass0)
+    c = _case(lib, [node], [job], disallowed_resources=disallowed)
+    s = c.sched
+    s.txn_begin()
+    pod, _ = s.select_node(0, 0 if evicted else -1)
+    s.txn_abort()
+    assert (pod.node == 0) == expect
