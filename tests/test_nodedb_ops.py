@@ -196,3 +196,46 @@ def test_disallowed_job_resources(lib, disallowed, evicted, expect):
     pod, _ = s.select_node(0, 0 if evicted else -1)
     s.txn_abort()
     assert (pod.node == 0) == expect
+
+
+def _gang_sibling_cases():
+    g1 = F.WithGangJobDetails(F.N16Cpu128GiJobs("A", F.PriorityClass0, 3), "gang-1", 3, "")
+    g2 = F.WithGangJobDetails(F.N32Cpu256GiJobs("A", F.PriorityClass0, 3), "gang-1", 2, "")
+    filler = lambda: F.Test16Cpu128GiJob("A", F.PriorityClass0)  # noqa: E731
+    return {
+        # name: (per node: its jobs in eviction order, new jobs, preempted, preempted via sibling)     nodedb_test.go:1836-1899
+        "preempt sibling on another node": ([[g2[1]], [g2[0]]], [F.Test32Cpu256GiJob("B", F.PriorityClass0)], [g2[0]], [g2[1]]),
+        "preempt sibling on another node - 2 jobs on same node": ([[filler(), g1[1]], [g1[2], g1[0]]], [F.Test32Cpu256GiJob("B", F.PriorityClass0)],
+                                                                  [g1[0], g1[2]], [g1[1]]),
+        "preempted sibling - makes space for next scheduled job": ([[g1[1], filler()], [g1[2], g1[0]]],
+                                                                   [F.Test32Cpu256GiJob("B", F.PriorityClass0), F.Test16Cpu128GiJob("B", F.PriorityClass0)],
+                                                                   [g1[0], g1[2]], [g1[1]]),
+    }
+
+
+@pytest.mark.parametrize("name", list(_gang_sibling_cases()))
+def test_fairshare_preemption_preempts_gang_siblings(lib, name):
+    """nodedb_test.go:1811-1951 TestFairsharePreemption_PreemptGangSiblings: fair-share preemption of one gang member takes its evicted
+    siblings on other nodes with it (preemptSiblingGangJobs, nodedb.go:468-525); every preempted job leaves the evicted table."""
+    setup, new_jobs, exp_pre, exp_sib = _gang_sibling_cases()[name]
+    nodes = [F.Test32CpuNode(F.TestPriorities) for _ in setup]
+    jobs = [j for node_jobs in setup for j in node_jobs] + new_jobs
+    ident = {id(j): i for i, j in enumerate(jobs)}
+    c = _case(lib, nodes, jobs, disable_urgency=True)                 # :1907
+    s = c.sched
+    ev = 0
+    for n, node_jobs in enumerate(setup):                             # :1909-1916
+        for j in node_jobs:
+            s.bind(ident[id(j)], n, 0)
+        for j in node_jobs:
+            s.evict(ident[id(j)], n)
+            s.add_evicted(ev, ident[id(j)], n)
+            ev += 1
+    preempted = []
+    for j in new_jobs:                                                # :1921-1937
+        s.txn_begin()
+        ok, pods, pre = s.schedule_many([ident[id(j)]])
+        assert ok and pods[0].node >= 0
+        preempted += pre
+        s.txn_commit()
+    assert sorted(preempted) == sorted(ident[id(j)] for j in exp_pre + exp_sib)   # :1938-1944 (the ABI does not tell the two causes apart)
