@@ -239,3 +239,53 @@ def test_fairshare_preemption_preempts_gang_siblings(lib, name):
         preempted += pre
         s.txn_commit()
     assert sorted(preempted) == sorted(ident[id(j)] for j in exp_pre + exp_sib)   # :1938-1944 (the ABI does not tell the two causes apart)
+
+
+_TOL_FOO = [{"key": "foo", "op": "Equal", "value": "foo", "effect": ""}]
+_TAINT_FOO = [["foo", "foo", "NoSchedule"]]
+
+
+@pytest.mark.parametrize("name,taints,labels,tolerations,selector,expect", [
+    # nodematching_test.go:80-270 TestNodeSchedulingRequirementsMet, the cases without node affinity (which the ABI does not model)
+    ("tolerated taints", _TAINT_FOO, {}, _TOL_FOO, {}, True),
+    ("untolerated taints", _TAINT_FOO, {}, [], {}, False),
+    ("matched node selector", [], {"bar": "bar"}, [], {"bar": "bar"}, True),
+    ("unmatched node selector", [], {}, [], {"bar": "bar"}, False),
+    ("tolerated taints and matched node selector", _TAINT_FOO, {"bar": "bar"}, _TOL_FOO, {"bar": "bar"}, True),
+    ("untolerated taints and matched node selector", _TAINT_FOO, {"bar": "bar"}, [], {"bar": "bar"}, False),
+    ("tolerated taints and unmatched node selector", _TAINT_FOO, {}, _TOL_FOO, {"bar": "bar"}, False),
+])
+def test_static_node_requirements(lib, name, taints, labels, tolerations, selector, expect):
+    """StaticJobRequirementsMet (nodematching.go:161-190) through node selection on a one-node NodeDb: taints vs tolerations
+    (empty effect and operator as in the reference's table), node selector vs labels."""
+    node = F.Test32CpuNode(F.TestPriorities)
+    node["taints"] = [list(t) for t in taints]
+    node["labels"] = dict(labels)
+    job = F.Test1Cpu4GiJob("A", F.PriorityClass0)
+    job["tolerations"] = [dict(t) for t in tolerations]
+    job["selector"] = dict(selector)
+    c = _case(lib, [node], [job])
+    s = c.sched
+    s.txn_begin()
+    pod, _ = s.select_node(0)
+    s.txn_abort()
+    assert (pod.node == 0) == expect
+
+
+def test_remove_job_of_unbound_job_is_a_noop(lib):
+    """internaltypes/node_test.go:357-364 TestNode_RemoveJob_AlreadyUnboundIsNoop, and :366-380: the cutoff stored at add decides which
+    buckets a removal credits."""
+    node = F.Test32CpuNode(F.TestPriorities)
+    job = F.Test1Cpu4GiJob("queue-a", F.PriorityClass1)
+    c = _case(lib, [node], [job])
+    s = c.sched
+    before = s.get_alloc(0).copy()
+    s.unbind(0, 0)                                        # not bound: no error, nothing changes
+    assert (s.get_alloc(0) == before).all()
+    s.bind(0, 0, 1)
+    after = s.get_alloc(0)
+    req = np.array(scenario.vec(job["req"]), dtype=np.int64)
+    for l, p in enumerate(s.priorities):                  # preemptible at priority 1: buckets <= 1 debited, the others untouched
+        assert (after[l] == (before[l] - req if p <= 1 else before[l])).all()
+    s.unbind(0, 0)
+    assert (s.get_alloc(0) == before).all()
