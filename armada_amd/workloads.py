@@ -120,6 +120,19 @@ def _shapes64(gpu_frac_rows=True):
     return np.array(rows, dtype=np.int64)
 
 
+def config1(n_nodes=100, n_jobs=1_000, seed=SEED) -> Workload:
+    """100 nodes, 1 queue, 1k single-pod jobs on an empty cluster — the shape of the reference's cmd/simulator basic input
+    (BASELINE config 1: the CPU-runnable case); 32-core nodes, jobs of 1-8 cores, everything that fits is scheduled in one round."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pcs = [(0, True)]
+    node_total = np.tile(np.array([256 * Gi, 32000, 1024 * Gi, 0], dtype=np.int64), (n_nodes, 1))
+    shapes = _shapes16()
+    q_req = shapes[rng.integers(0, len(shapes), size=n_jobs)]
+    none = np.zeros(0, np.int32)
+    return _assemble("config1", _config(pcs), node_total, np.zeros((0, R), np.int64), none, none, none, none,
+                     q_req, np.zeros(n_jobs, np.int32), np.zeros(n_jobs, np.int32), np.array([0]), np.ones(1), {})
+
+
 def config2(n_nodes=10_000, n_jobs=100_000, n_queues=8, seed=SEED) -> Workload:
     """10k nodes, 8 queues, 100k jobs, 4 resource dims — the nodedb fit kernel (BASELINE config 2)."""
     rng = np.random.Generator(np.random.PCG64(seed))

@@ -211,3 +211,14 @@ def test_nodedb_away_node_scheduling(hip_lib, case):
     if r != "ok":
         pytest.skip(r)
 
+def test_config1_simulator_shape_round_matches_oracle(hip_lib, oracle_lib):
+    """BASELINE configs[0]: 100 nodes, 1 queue, 1k single-pod jobs on an empty cluster (the cmd/simulator basic shape)"""
+    wl = W.config1()
+    res = []
+    for lib in (oracle_lib, hip_lib):
+        s = W.load(lib, wl)
+        W.prepare(s, wl)
+        res.append(s.schedule_round())
+    scenario.assert_same_round(res[0], res[1])
+    assert len(res[0].scheduled) > 800 and not res[0].preempted
+
