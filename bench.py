@@ -73,7 +73,8 @@ def main():
     ap.add_argument("--nodes", type=int, default=100_000)
     ap.add_argument("--jobs", type=int, default=1_000_000)
     ap.add_argument("--queues", type=int, default=64)
-    ap.add_argument("--gangs", type=int, default=0)
+    ap.add_argument("--gangs", type=int, default=0, help="queued gangs of size 2-64 (BASELINE configs[3] shape)")
+    ap.add_argument("--occupied", type=float, default=0.5, help="fraction of every node filled with running jobs (0.95: the preemption-heavy configs[4] shape)")
     ap.add_argument("--cpu-budget", type=float, default=75.0, help="seconds of CPU-oracle work allowed for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -96,7 +97,7 @@ def main():
 
     # one pool per rank; seeds differ per pool
     from armada_amd.multipool import pool_seed
-    wl = W.config3(n_nodes=args.nodes, n_jobs=args.jobs, n_queues=args.queues, seed=pool_seed(W.SEED, rank), gangs=args.gangs)
+    wl = W.config3(n_nodes=args.nodes, n_jobs=args.jobs, n_queues=args.queues, seed=pool_seed(W.SEED, rank), gangs=args.gangs, occupied=args.occupied)
     scale = args.jobs / 1_000_000.0
     if args.jobs != 1_000_000:  # keep "limits bite" at reduced sizes
         wl.global_burst, wl.queue_burst = max(1, int(200_000 * scale)), max(1, int(20_000 * scale))
@@ -137,8 +138,9 @@ def main():
         "value": value, "unit": "rounds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": total / args.steps * 1e3, "p50_ms": float(np.percentile(lat_ms, 50)), "p99_ms": float(np.percentile(lat_ms, 99)),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[2]: {wl.num_nodes} nodes x {wl.num_queues} queues x {args.jobs} queued jobs (+{wl.num_jobs - args.jobs} running), "
-                               f"R=4, 3 priority classes, DRF weights, global burst {wl.global_burst}, queue burst {wl.queue_burst}, protectedFractionOfFairShare 0.5",
+        "config": {"workload": f"BASELINE configs[{3 if args.gangs else 4 if args.occupied >= 0.9 else 2}]{' shape' if (args.gangs or args.occupied != 0.5) else ''}: {wl.num_nodes} nodes x {wl.num_queues} queues x {args.jobs} queued jobs (+{wl.num_jobs - args.jobs} running), "
+                               f"R=4, 3 priority classes, DRF weights, global burst {wl.global_burst}, queue burst {wl.queue_burst}, protectedFractionOfFairShare 0.5"
+                               + (f", {args.gangs} gangs" if args.gangs else "") + (f", nodes {args.occupied:.0%} occupied" if args.occupied != 0.5 else ""),
                    "nodes": wl.num_nodes, "queued_jobs": args.jobs, "running_jobs": wl.num_jobs - args.jobs, "queues": wl.num_queues,
                    "parallelism": f"pool-per-gpu x{world}" if world > 1 else "1 pool on 1 gpu", "seed": W.SEED},
         "round": {"scheduled": len(res.scheduled), "preempted": len(res.preempted), "evicted_phase1": res.num_evicted_phase1,
@@ -152,7 +154,7 @@ def main():
     # HBM bytes actually moved by one round launch: rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
     # collected once per round of work on this exact workload and committed under profiles/ (rocprofv3 cannot run inside bench.py)
     pmc = os.path.join(ROOT, "profiles", "r01f_pmc_hbm_traffic.json")
-    if os.path.exists(pmc) and args.nodes == 100_000 and args.jobs == 1_000_000 and args.queues == 64 and not args.gangs:
+    if os.path.exists(pmc) and args.nodes == 100_000 and args.jobs == 1_000_000 and args.queues == 64 and not args.gangs and args.occupied == 0.5:
         try:
             c = json.load(open(pmc))["counters"]
             fetch = max(x["max_kb"] for x in c["FETCH_SIZE"] if x["kernel"].startswith("k_control"))
