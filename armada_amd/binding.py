@@ -79,6 +79,8 @@ class CConfig(C.Structure):
         ("max_queue_lookback", C.c_uint32), ("pad2_", C.c_uint32),
         ("max_fraction_to_schedule", _f64p), ("disallowed_resource", _u8p),
         ("device", C.c_int32), ("pad3_", C.c_int32),
+        ("away_nt_off", _i32p), ("away_nt_well_known", _i32p), ("away_nt_cond_off", _i32p),
+        ("away_cond_resource", _i32p), ("away_cond_op", _i32p), ("away_cond_value", _i64p), ("resource_unit", _i64p),
     ]
 
 
@@ -123,6 +125,13 @@ class CPodResult(C.Structure):
     _fields_ = [("node", C.c_int32), ("scheduled_at_priority", C.c_int32), ("preempted_at_priority", C.c_int32), ("method", C.c_int32)]
 
 
+class CSubmitResult(C.Structure):
+    _fields_ = [("ok", C.c_int32), ("scheduled_away", C.c_int32), ("num_schedulable", C.c_int32), ("first_node", C.c_int32)]
+
+
+SUBMIT_STRIP_GANG = 1
+
+
 class CRoundResult(C.Structure):
     _fields_ = [
         ("num_scheduled", C.c_int32), ("num_preempted", C.c_int32), ("termination_reason", C.c_int32),
@@ -141,6 +150,7 @@ ALL_SYMBOLS = [
     "txn_abort", "select_node", "schedule_many", "bind", "evict", "unbind", "add_evicted", "reset_evicted",
     "get_alloc", "get_scheduled_at_priority", "iterate_nodes", "fit_select_batch", "drf_cost", "fair_shares",
     "round_prepare", "schedule_round", "schedule_queues", "gang_schedule", "round_counters", "job_key_unfeasible", "kernel_times", "round_stats",
+    "clear_allocated", "submit_check",
 ]
 
 
@@ -219,7 +229,8 @@ class Library:
         f("priorities", C.c_int32, [C.c_void_p, _i32p])
         f("nodes_upsert", C.c_int32, [C.c_void_p, C.POINTER(CNodes)])
         f("jobs_set", C.c_int32, [C.c_void_p, C.POINTER(CJobs), C.POINTER(CReqClasses)])
-        for n in ("txn_begin", "txn_commit", "txn_abort", "reset_evicted"):
+        f("submit_check", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i32p, _i32p, C.POINTER(CSubmitResult)])
+        for n in ("txn_begin", "txn_commit", "txn_abort", "reset_evicted", "clear_allocated"):
             f(n, C.c_int32, [C.c_void_p])
         f("select_node", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(CPodResult), _i32p, C.c_int32, _i32p])
         f("schedule_many", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i32p, C.POINTER(CPodResult), _i32p, _i32p, C.c_int32, _i32p])
@@ -276,6 +287,12 @@ class Config:
     max_fraction_to_schedule: Optional[Sequence[float]] = None
     disallowed_resource: Optional[Sequence[int]] = None
     device: int = -1
+    # AwayNodeType.NodeTypes: per pc, per away entry (same order as pc_away): list of (well-known type, [(resource col, op, value)])
+    pc_away_node_types: Optional[Sequence[Sequence[Sequence]]] = None
+    resource_unit: Optional[Sequence[int]] = None                  # factory units per whole unit (cpu 1000, memory 1)
+
+
+AWAY_COND_OPS = {">": 0, "<": 1, "==": 2}
 
 
 class Scheduler:
@@ -326,6 +343,25 @@ class Scheduler:
         if cfg.disallowed_resource is not None:
             c.disallowed_resource = _ptr(k(cfg.disallowed_resource, np.uint8), C.c_uint8)
         c.device = int(cfg.device)
+        if cfg.pc_away_node_types is not None and cfg.pc_away is not None:
+            nt_off, nt_wkt, cond_off, c_res, c_op, c_val = [0], [], [0], [], [], []
+            for pi, entries in enumerate(cfg.pc_away):
+                per_pc = cfg.pc_away_node_types[pi] if pi < len(cfg.pc_away_node_types) else []
+                for ei in range(len(entries)):
+                    for wkt, conds in (per_pc[ei] if ei < len(per_pc) else []):
+                        nt_wkt.append(wkt)
+                        for res, op, val in conds:
+                            c_res.append(res); c_op.append(op); c_val.append(val)
+                        cond_off.append(len(c_res))
+                    nt_off.append(len(nt_wkt))
+            c.away_nt_off = _ptr(k(nt_off, np.int32), C.c_int32)
+            c.away_nt_well_known = _ptr(k(nt_wkt or [0], np.int32), C.c_int32)
+            c.away_nt_cond_off = _ptr(k(cond_off, np.int32), C.c_int32)
+            c.away_cond_resource = _ptr(k(c_res or [0], np.int32), C.c_int32)
+            c.away_cond_op = _ptr(k(c_op or [0], np.int32), C.c_int32)
+            c.away_cond_value = _ptr(k(c_val or [0], np.int64), C.c_int64)
+        if cfg.resource_unit is not None:
+            c.resource_unit = _ptr(k(cfg.resource_unit, np.int64), C.c_int64)
         self.h = lib.create(C.byref(c))
         if not self.h:
             raise SchedError(ERR_INVALID, "create failed (invalid config, or no gfx950 device for the HIP backend)")
@@ -446,6 +482,21 @@ class Scheduler:
     def txn_commit(self): self._check(self.lib.txn_commit(self.h))
     def txn_abort(self): self._check(self.lib.txn_abort(self.h))
     def reset_evicted(self): self._check(self.lib.reset_evicted(self.h))
+
+    def clear_allocated(self): self._check(self.lib.clear_allocated(self.h))
+
+    def submit_check(self, units: Sequence[Sequence[int]], strip_gang: Optional[Sequence[bool]] = None):
+        """One batch of submit-check units (submitcheck.go:342-371); returns [(ok, scheduled_away, num_schedulable, first_node)]."""
+        nu = len(units)
+        if nu == 0:
+            return []
+        off = np.zeros(nu + 1, dtype=np.int32)
+        off[1:] = np.cumsum([len(u) for u in units])
+        jobs = _arr([j for u in units for j in u], np.int32)
+        flags = _arr([SUBMIT_STRIP_GANG if (strip_gang is not None and strip_gang[i]) else 0 for i in range(nu)], np.int32)
+        out = (CSubmitResult * nu)()
+        self._check(self.lib.submit_check(self.h, nu, _ptr(off, C.c_int32), _ptr(jobs, C.c_int32), _ptr(flags, C.c_int32), out))
+        return [(bool(o.ok), bool(o.scheduled_away), int(o.num_schedulable), int(o.first_node)) for o in out]
 
     def select_node(self, job: int, pinned_node: int = -1):
         out = CPodResult()

@@ -840,6 +840,7 @@ __device__ static void helperMain(const Dev& d, HelpBox* b, int H) {
   }
 }
 
+#ifndef ASCHED_AUX_TU
 __global__ __launch_bounds__(CTL_THREADS) void k_control(Dev dev, int cmd, HelpBox* box, int H) {
   if (blockIdx.x != 0) { helperMain(dev, box, H); return; }
   if (threadIdx.x == 0) { g_box = box; g_H = H; g_gen = 0; }
@@ -1010,6 +1011,7 @@ static int plat_last_control_launches() { return g_lastControlLaunches; }
 
 static HelpBox* g_helpBox = nullptr;
 static int g_helpers = -1;
+extern "C" int asched_internal_aux_launch(const Dev* dev, int cmd, hipStream_t stream, void* helpBox);  // armada_sched_aux.hip
 static int plat_run_control(Dev& dev, int cmd) {
   if (!g_ev0) { (void)hipEventCreate(&g_ev0); (void)hipEventCreate(&g_ev1); }
   if (g_helpers < 0) {  // helper workgroups of a round launch: one per CU, an eighth of the device by default — measured flat between 15 and 63 (ASCHED_HELPERS overrides; 0 = none)
@@ -1033,6 +1035,9 @@ static int plat_run_control(Dev& dev, int cmd) {
   dev.progress = (cmd == CMD_ROUND && progress) ? progress : nullptr;
   if (!hipOk(hipMemsetAsync(g_helpBox, 0, sizeof(HelpBox), g_stream), "help box reset")) return -1;
   (void)hipEventRecord(g_ev0, g_stream);
+  if (cmd >= CMD_AUX_FIRST) {  // submit-check commands: their kernel lives in its own code object (armada_sched_aux.hip)
+    if (asched_internal_aux_launch(&dev, cmd, g_stream, g_helpBox)) { g_err = "k_control_aux launch failed"; return -1; }
+  } else
   hipLaunchKernelGGL(k_control, dim3(1 + H), dim3(CTL_THREADS), 0, g_stream, dev, cmd, g_helpBox, H);
   (void)hipEventRecord(g_ev1, g_stream);
   if (!hipOk(hipGetLastError(), "k_control launch")) return -1;
@@ -1141,3 +1146,53 @@ static int plat_run_fair_shares(Dev& dev, int q, const int32_t* nameRank, const 
 }
 
 #include "asched_host.inc"
+
+#else  // ASCHED_AUX_TU ----------------------------------------------------------------------------------------------------
+// armada_sched_aux.hip compiles this file a second time with ASCHED_AUX_TU defined: the device code above, ONE kernel
+// (k_control_aux: the submit-check commands, round_run.h runAuxCommand) and no host ABI.  A separate translation unit = a
+// separate code object: whatever is added to the auxiliary commands can never move a register, an LDS offset or an inlining
+// decision in the round kernel, whose code is the measured one.
+__global__ __launch_bounds__(CTL_THREADS) void k_control_aux(Dev dev, int cmd, HelpBox* box) {
+  // workgroup 0 of k_control without helper workgroups: wave 0 runs the command, the other waves serve its mailbox
+  if (threadIdx.x == 0) { g_box = box; g_H = 0; g_gen = 0; }
+  {
+    const int* src = (const int*)&dev; int* dst = (int*)&g_dev;
+    for (int i = threadIdx.x; i < (int)(sizeof(Dev) / sizeof(int)); i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  Dev& d = g_dev;
+  relocateIn(d, cmd);
+  if (threadIdx.x >= 64) {
+    for (;;) {
+      __syncthreads();
+      int op = g_mb.op;
+      if (op == OP_EXIT) break;
+      if (op == OP_SCAN) {
+        unsigned long long v = scanPart(d, g_mb.scan, threadIdx.x, (int)blockDim.x);
+        if ((threadIdx.x & 63) == 0) g_mb.partial[threadIdx.x >> 6] = v;
+      } else if (op == OP_FAIR) {
+        int v = fairPart(d, g_mb.fair, threadIdx.x, (int)blockDim.x);
+        if ((threadIdx.x & 63) == 0) g_mb.waveCount[threadIdx.x >> 6] = v;
+      } else if (op == OP_BULK) {
+        bulkPart(d, g_mb.kind, g_mb.n);
+      } else if (op == OP_COMPACT) {
+        compactPart(d);
+      } else if (op == OP_ENGINE) {
+        if ((threadIdx.x >> 6) == 1) engineLoop(d);
+      }
+      __syncthreads();
+    }
+    relocateOut();
+    return;
+  }
+  controlMainAux(d, cmd);
+  __threadfence();
+  if ((threadIdx.x & 63) == 0) g_mb.op = OP_EXIT;
+  __syncthreads();
+  relocateOut();
+}
+extern "C" __attribute__((visibility("hidden"))) int asched_internal_aux_launch(const Dev* dev, int cmd, hipStream_t stream, void* helpBox) {
+  hipLaunchKernelGGL(k_control_aux, dim3(1), dim3(CTL_THREADS), 0, stream, *dev, cmd, (HelpBox*)helpBox);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+#endif  // ASCHED_AUX_TU

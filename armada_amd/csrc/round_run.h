@@ -416,7 +416,9 @@ DEV void runRound(Dev& d, Ctl& c) {
 enum Cmd {
   CMD_PREPARE = 1, CMD_ROUND, CMD_QUEUES_ONLY, CMD_GANG_SCHEDULE, CMD_SELECT, CMD_SCHEDULE_MANY, CMD_BIND, CMD_EVICT, CMD_UNBIND,
   CMD_ADD_EVICTED, CMD_RESET_EVICTED, CMD_TXN_BEGIN, CMD_TXN_COMMIT, CMD_TXN_ABORT, CMD_FIT_BATCH, CMD_UPSERT_RESET, CMD_RESET_JOBS,
+  CMD_SUBMIT_CHECK,  // first command of the auxiliary kernel (k_control_aux, armada_sched_aux.hip)
 };
+#define CMD_AUX_FIRST CMD_SUBMIT_CHECK
 // cmdIO layout: [0..15] results, [16..] arguments
 #define ARG(k) d.cmdIO[16 + (k)]
 
@@ -549,8 +551,61 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
   }
 }
 
+// Commands of the submit check.  They run in their own kernel, in their own code object (k_control_aux,
+// armada_sched_aux.hip), so that the round kernel's code — everything above is inlined into it — stays exactly what was measured.
+struct SubmitArgs { int32_t nu, pad; int32_t* off; int32_t* jobs; int32_t* flags; int32_t* out; };  // at cmdIO + 16, written by the host
+DEV void runAuxCommand(Dev& d, Ctl& c, int cmd) {
+  const DevCfg& cf = d.cfg;
+  switch (cmd) {
+    case CMD_SUBMIT_CHECK: {
+      // SubmitChecker.getSchedulingResult, per-pool core (submitcheck.go:342-371), for a whole batch of units in one launch:
+      // copyGangContext (fresh jctxs), nodeDb.Txn, ScheduleManyWithTxn, txn.Abort — every unit meets the same NodeDb state
+      d.rs->apiDirty = 1;
+      SubmitArgs a = *(const SubmitArgs*)(d.cmdIO + 16);
+      int g = cf.G;
+      if (c.txn.active) { raise(d, ASCHED_ERR_INVALID, 810); break; }
+      for (int u = 0; u < a.nu && !d.rs->error; u++) {
+        int o0 = a.off[u], n = a.off[u + 1] - o0;
+        // individual check: the job is re-made with job.WithGangInfo(BasicJobGangInfo()) (:274) — for the duration of the unit the
+        // job's gang id reads "none" wherever the device code asks IsInGang (away scheduling :613, gang cardinality)
+        bool strip = (a.flags[u] & ASCHED_SUBMIT_STRIP_GANG) != 0;
+        int j0 = a.jobs[o0];
+        int savedGang = d.jGang[j0];
+        if (strip) { if (n != 1) { raise(d, ASCHED_ERR_INVALID, 811); break; } d.jGang[j0] = -1; }
+        for (int k = 0; k < n; k++) {
+          int j = a.jobs[o0 + k];
+          setupPinned(d, j, -1);
+          d.gangArr[d.gangOff[g] + k] = j;
+        }
+        d.gangSeen[g] = n;
+        c.preCount = 0;
+        txnBegin(d, c.txn);
+        bool ok = scheduleMany(d, c, -(g + 2));
+        txnAbort(d, c.txn);
+        unstagePreemptions(d, c);
+        if (strip) d.jGang[j0] = savedGang;
+        int ns = 0;
+        for (int k = 0; k < n; k++) { int j = a.jobs[o0 + k]; if (d.jcHasPctx[j] && d.pcNode[j] >= 0) ns++; }  // pctx.IsSuccessful
+        a.out[4 * u] = ok; a.out[4 * u + 1] = d.jcHasPctx[j0] && d.pcMethod[j0] == ASCHED_METHOD_AWAY;
+        a.out[4 * u + 2] = ns; a.out[4 * u + 3] = d.jcHasPctx[j0] ? d.pcNode[j0] : -1;
+      }
+    } break;
+  }
+}
+
 // body of the control kernel's wave 0 (and of the hostsim debug build): one command with the fast path's LDS side
 // restored from / saved to HBM around it
+DEV void controlMainAux(Dev& d, int cmd) {
+  Ctl c;
+  c.txn.active = d.rs->txnActive; c.fairStamp = d.rs->fairStamp; c.preList = d.preList; c.preCount = 0;
+  c.skipKeyCheck = 0; c.compareSchedPrio = 0; c.preferLarge = d.cfg.preferLarge; c.useReplayAlloc = 0; c.onlyEvicted = 0;
+  c.fastEnabled = 0; c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0;
+  fastLoad(d);
+  runAuxCommand(d, c, cmd);
+  fastEnterGeneric(d, c);
+  fastSave(d);
+  d.rs->txnActive = c.txn.active; d.rs->fairStamp = c.fairStamp;
+}
 DEV void controlMain(Dev& d, int cmd) {
   Ctl c;
   c.txn.active = d.rs->txnActive; c.fairStamp = d.rs->fairStamp; c.preList = d.preList; c.preCount = 0;

@@ -1,0 +1,203 @@
+"""Host-side mirror of the reference's SubmitChecker (internal/scheduler/submitcheck.go) over the C ABI.
+
+The reference answers "could this newly submitted job / gang ever be scheduled?" by running ScheduleManyWithTxn on a
+NodeDb that was built without jobs and cleared (submitcheck.go:180-188), one job at a time, inside a transaction it
+aborts (:345-349).  Because every attempt is aborted, each one meets the *same* NodeDb state: the attempts are
+independent, and that is what this mirror exploits — the whole batch of a `Check` call becomes ONE `asched_submit_check`
+launch per pool for the individual checks (one unit per distinct scheduling key) and one more for the gangs, instead of
+one transaction round trip per job.  The pool loop of getSchedulingResult (:309-394: submission groups, away pools,
+per-queue limits, floating resources) is pure bookkeeping over those per-pool answers and runs on the host.
+
+Equality with the reference's sequential flow is what tests/test_submitcheck.py checks: against the expectations of
+submitcheck_test.go (tests/golden/submitcheck_cases.json) and against a literal one-transaction-at-a-time restatement of
+`Check` (tests/submitcheck_literal.py) on seeded inputs.
+
+Nothing here computes a placement: `PoolNodeDb.submit_check` must be backed by the native library
+(armada_amd.binding.Scheduler.submit_check); there is no Python fallback.
+"""
+from dataclasses import dataclass, field
+from typing import Callable, Dict, Hashable, List, Optional, Sequence, Tuple
+
+
+@dataclass
+class SubmitJob:
+    """The jobdb.Job accessors the submit check reads."""
+    id: str
+    queue: str
+    priority_class: str
+    scheduling_key: Hashable                 # job.SchedulingKey() (internaltypes/podutils.go:52-72)
+    request: Sequence[int]                   # AllResourceRequirements in ResourceListFactory column order
+    gang_id: Optional[str] = None            # job.GetGangInfo().Id() when job.IsInGang()
+    floating_request: Dict[str, int] = field(default_factory=dict)  # floating resources only (gctx.RequestsFloatingResources)
+
+
+@dataclass
+class PoolConfig:
+    """configuration.PoolConfig fields the submit check reads (configuration.go:430-468)."""
+    name: str
+    away_pools: Sequence[str] = ()
+    submission_group: str = ""               # ExperimentalSubmissionGroup
+
+    def get_submission_group(self) -> str:   # configuration.go:463-468
+        return self.submission_group or self.name
+
+
+@dataclass
+class SchedulingResult:                       # submitcheck.go:28-32
+    is_schedulable: bool
+    pools: List[str] = field(default_factory=list)
+    reason: str = ""
+
+
+class PoolNodeDb:
+    """What the checker needs from one pool's cleared NodeDb (schedulerState.nodeDbByPool + constraintsByPool,
+    submitcheck.go:47-51).  Implemented by the caller on top of binding.Scheduler."""
+
+    def load_jobs(self, jobs: Sequence[SubmitJob]) -> None:
+        """asched_jobs_set: job i of every later call is jobs[i]"""
+        raise NotImplementedError
+
+    def submit_check(self, units: Sequence[Sequence[int]], strip_gang: Sequence[bool]) -> List[Tuple[bool, bool, int, int]]:
+        """asched_submit_check: [(ok, scheduled_away, num_schedulable, first_node)] per unit"""
+        raise NotImplementedError
+
+    def queue_resource_limit(self, queue: str, priority_class: str) -> Optional[Sequence[int]]:
+        """constraints.GetQueueResourceLimit (constraints.go:180-185); None = empty ResourceList"""
+        return None
+
+    def floating_available(self) -> Dict[str, int]:
+        """floatingResourceTypes.GetTotalAvailableForPool"""
+        return {}
+
+
+class _Deadline:                               # submitcheck.go:34-45
+    def __init__(self, limit: float, now: float):
+        self.t = None if limit <= 0 else now + limit
+
+    def exceeded(self, now: float) -> bool:
+        return self.t is not None and now > self.t
+
+
+class SubmitChecker:
+    """SubmitChecker.Check (submitcheck.go:225-269) with the NodeDb work batched per pool."""
+
+    def __init__(self, pools: Sequence[PoolConfig], node_db_by_pool: Dict[str, PoolNodeDb], *, max_duration: float = 0.0,
+                 max_duration_per_queue: float = 0.0, now: Optional[Callable[[], float]] = None):
+        self.pools = list(pools)
+        self.node_db_by_pool = node_db_by_pool
+        self.max_duration, self.max_duration_per_queue = max_duration, max_duration_per_queue
+        self.now = now or (lambda: 0.0)
+        self.pools_by_submission_group: Dict[str, List[str]] = {}   # NewSubmitChecker :75-81
+        for p in self.pools:
+            self.pools_by_submission_group.setdefault(p.get_submission_group(), []).append(p.name)
+        self.launches = 0   # native calls issued by the last check() (the reference issues one transaction per job per pool)
+
+    # ---- which jobs a Check call reaches before its deadlines (the clock is read exactly where the reference reads it)
+    def _select(self, jobs: Sequence[SubmitJob]):
+        start = self.now()
+        global_deadline = _Deadline(self.max_duration, start)
+        by_queue: Dict[str, List[int]] = {}
+        for i, j in enumerate(jobs):                     # armadaslices.GroupByFunc; queues visited in first-appearance order
+            by_queue.setdefault(j.queue, []).append(i)   # (the reference ranges over a Go map: its own order is unspecified)
+        singles: List[int] = []
+        gangs: List[List[int]] = []
+        for _, idxs in by_queue.items():
+            if global_deadline.exceeded(self.now()):
+                break
+            queue_deadline = _Deadline(self.max_duration_per_queue, self.now())
+            by_gang: Dict[str, List[int]] = {}
+            for i in idxs:
+                if jobs[i].gang_id is not None:
+                    by_gang.setdefault(jobs[i].gang_id, []).append(i)
+            processed = set()
+            for i in idxs:
+                if queue_deadline.exceeded(self.now()) or global_deadline.exceeded(self.now()):
+                    break
+                if jobs[i].gang_id is None:
+                    singles.append(i)
+                elif jobs[i].gang_id not in processed:
+                    gangs.append(by_gang[jobs[i].gang_id])
+                    processed.add(jobs[i].gang_id)
+        return singles, gangs
+
+    # ---- getSchedulingResult's pool loop (:309-394) over per-pool answers that are already known
+    def _pool_loop(self, rep: SubmitJob, members: Sequence[SubmitJob], raw: Dict[str, Tuple[bool, bool, int, int]]) -> SchedulingResult:
+        successful: Dict[str, bool] = {}
+        reason: List[str] = []
+        total = [sum(m.request[r] for m in members) for r in range(len(rep.request))]        # gctx.TotalResourceRequests
+        floating: Dict[str, int] = {}
+        for m in members:
+            for k, v in m.floating_request.items():
+                floating[k] = floating.get(k, 0) + v
+        for pool in self.pools:
+            if successful.get(pool.name):
+                continue
+            if any(successful.get(a) for a in pool.away_pools):
+                continue
+            reason.append(f"pool {pool.name}:\n")
+            db = self.node_db_by_pool[pool.name]
+            if any(v > 0 for v in floating.values()):      # :326-333, floatingresources WithinLimits :60-72
+                avail = db.floating_available()
+                if not any(v != 0 for v in avail.values()) or any(v > avail.get(k, 0) for k, v in floating.items()):
+                    reason.append("job/gang requests floating resources it cannot get in this pool\n---\n")
+                    continue
+            limit = db.queue_resource_limit(rep.queue, rep.priority_class)                    # :335-343
+            if limit is not None and any(t > l for t, l in zip(total, limit)):
+                reason.append("job/gang requests resources which exceed the total limit for its queue/priority class\n---\n")
+                continue
+            ok, away, nsched, _ = raw[pool.name]
+            if ok:
+                if not away or len(pool.away_pools) > 0:                                      # :357-363
+                    for p in self.pools_by_submission_group[pool.get_submission_group()]:
+                        successful[p] = True
+                continue
+            reason.append("job does not fit on any node\n---\n" if len(members) == 1 else f": {nsched} out of {len(members)} pods schedulable\n")
+        if successful:
+            return SchedulingResult(True, list(successful.keys()))
+        return SchedulingResult(False, [], "".join(reason))
+
+    def check(self, jobs: Sequence[SubmitJob]) -> Dict[str, SchedulingResult]:
+        """Results by job id for the jobs reached before the deadlines (jobs not reached are absent, like the reference)."""
+        self.launches = 0
+        singles, gangs = self._select(jobs)
+        if not singles and not gangs:
+            return {}
+        needed = list(singles) + [i for g in gangs for i in g]
+        # getIndividualSchedulingResult (:272-290): one check per distinct scheduling key — the reference's LRU cache keyed by
+        # jctx.Job.SchedulingKey() returns the stored answer for later jobs with the same key, and the answer is a pure function of
+        # the key because every attempt is aborted
+        first_of_key: Dict[Hashable, int] = {}
+        for i in needed:
+            first_of_key.setdefault(jobs[i].scheduling_key, i)
+        reps = list(first_of_key.values())
+        for db in self.node_db_by_pool.values():
+            db.load_jobs(jobs)
+        raw_ind: Dict[str, list] = {}
+        for pool in self.pools:
+            raw_ind[pool.name] = self.node_db_by_pool[pool.name].submit_check([[i] for i in reps], [True] * len(reps))
+            self.launches += 1
+        individual: Dict[Hashable, SchedulingResult] = {}
+        for u, i in enumerate(reps):
+            individual[jobs[i].scheduling_key] = self._pool_loop(jobs[i], [jobs[i]], {p.name: raw_ind[p.name][u] for p in self.pools})
+        results: Dict[str, SchedulingResult] = {}
+        for i in singles:
+            results[jobs[i].id] = individual[jobs[i].scheduling_key]
+        # getGangSchedulingResult (:292-302): the first member that is not schedulable on its own decides; else the gang as a unit
+        todo: List[List[int]] = []
+        for g in gangs:
+            bad = next((individual[jobs[i].scheduling_key] for i in g if not individual[jobs[i].scheduling_key].is_schedulable), None)
+            if bad is not None:
+                for i in g:
+                    results[jobs[i].id] = bad
+            else:
+                todo.append(g)
+        if todo:
+            raw_gang: Dict[str, list] = {}
+            for pool in self.pools:
+                raw_gang[pool.name] = self.node_db_by_pool[pool.name].submit_check(todo, [False] * len(todo))
+                self.launches += 1
+            for u, g in enumerate(todo):
+                r = self._pool_loop(jobs[g[0]], [jobs[i] for i in g], {p.name: raw_gang[p.name][u] for p in self.pools})
+                for i in g:
+                    results[jobs[i].id] = r
+        return results

@@ -106,7 +106,7 @@ typedef struct asched_config {
   const uint8_t* pc_preemptible;      /* [npc] */
   const int32_t* pc_away_off;         /* [npc+1] CSR into away_* (may be NULL: no away node types) */
   const int32_t* away_priority;       /* AwayNodeType.Priority */
-  const int32_t* away_well_known;     /* AwayNodeType.WellKnownNodeTypeName as index into wkt_* */
+  const int32_t* away_well_known;     /* AwayNodeType.WellKnownNodeTypeName as index into wkt_*; -1 = "" (only NodeTypes entries) */
   int32_t num_well_known_types;       /* configuration.WellKnownNodeType */
   const int32_t* wkt_taint_off;       /* [nwkt+1] */
   const int32_t* wkt_taint_key;
@@ -132,7 +132,23 @@ typedef struct asched_config {
   const uint8_t* disallowed_resource;     /* [R] pool ExperimentalUnscheduledResources; NULL = none */
   int32_t device;                         /* HIP device ordinal this handle (one pool) lives on; <0 = the calling thread's current device */
   int32_t pad3_;
+  /* AwayNodeType.NodeTypes (types.AwayTypeEntry, internal/common/types/scheduling.go:29-51): further well-known node types whose
+     taints an away attempt tolerates when the entry's conditions hold for the job's requests (getEffectiveAwayNodeTaints,
+     nodedb.go:650-675).  All optional: away_nt_off == NULL means no entry has NodeTypes. */
+  const int32_t* away_nt_off;             /* [number of away entries + 1] CSR over the away entries (the order of away_priority) */
+  const int32_t* away_nt_well_known;      /* AwayTypeEntry.Name as index into wkt_* */
+  const int32_t* away_nt_cond_off;        /* [number of NodeTypes entries + 1] CSR: AwayTypeEntry.Conditions */
+  const int32_t* away_cond_resource;      /* AwayNodeTypeCondition.Resource as column; -1 = not a resource of the factory (reads 0) */
+  const int32_t* away_cond_op;            /* ASCHED_AWAY_COND_* ; any other value = an operator matchesCondition does not know */
+  const int64_t* away_cond_value;         /* c.Value.Value(): whole units, rounded up */
+  const int64_t* resource_unit;           /* [R] factory units per whole unit (cpu: 1000, memory: 1) — jobVal.Value() rounds up to whole
+                                             units (nodedb.go:634-635); NULL = 1 for every resource */
 } asched_config;
+
+/* types.AwayNodeTypeConditionOperator (internal/common/types/scheduling.go:12-16) */
+#define ASCHED_AWAY_COND_GT 0
+#define ASCHED_AWAY_COND_LT 1
+#define ASCHED_AWAY_COND_EQ 2
 
 /* ---- nodes (internaltypes/node.go:32-69).  Creation order = node.index order. ---- */
 typedef struct asched_nodes {
@@ -215,6 +231,16 @@ typedef struct asched_pod_result {
   int32_t method;               /* ASCHED_METHOD_* */
 } asched_pod_result;
 
+/* ---- one unit of a submit check: SubmitChecker.getSchedulingResult's per-pool core (internal/scheduler/submitcheck.go:345-349):
+ *      txn := nodeDb.Txn(true); ok, _, err := nodeDb.ScheduleManyWithTxn(txn, gctx); txn.Abort() ---- */
+typedef struct asched_submit_result {
+  int32_t ok;               /* ScheduleManyWithTxn's bool */
+  int32_t scheduled_away;   /* gctx.JobSchedulingContexts[0].PodSchedulingContext.ScheduledAway (submitcheck.go:358) */
+  int32_t num_schedulable;  /* members whose PodSchedulingContext.IsSuccessful() (submitcheck.go:366-371) */
+  int32_t first_node;       /* node of member 0, -1 = none (diagnostic; the reference only prints it) */
+} asched_submit_result;
+#define ASCHED_SUBMIT_STRIP_GANG 1 /* unit flag: members checked as job.WithGangInfo(BasicJobGangInfo()) (submitcheck.go:274) */
+
 /* ---- result of a round (scheduling.SchedulingResult, scheduling/result.go:96-107) ---- */
 typedef struct asched_round_result {
   int32_t num_scheduled;        /* len(ScheduledJobs) */
@@ -274,6 +300,16 @@ int32_t ASCHED_FN(reset_evicted)(asched_t*);
 /* node.AllocatableByPriority, [P][R] */
 int32_t ASCHED_FN(get_alloc)(asched_t*, int32_t node, int64_t* out);
 int32_t ASCHED_FN(get_scheduled_at_priority)(asched_t*, int32_t job, int32_t* out, int32_t* ok); /* nodedb.go:315 */
+/* ClearAllocated (nodedb.go:1178-1199): AllocatableByPriority[p] = allocatableResources for every p on every node; the
+   nodes' job bookkeeping is left as it is (DeepCopyNilKeys clones the maps, internaltypes/node.go:344-372). */
+int32_t ASCHED_FN(clear_allocated)(asched_t*);
+/* A batch of submit-check units against the CURRENT NodeDb state (the submit checker's NodeDb is built without jobs and
+   cleared, submitcheck.go:180-188).  Unit u = jobs unit_jobs[unit_off[u] .. unit_off[u+1]) as one gang context; each unit
+   runs inside its own transaction which is aborted, so units never see each other's binds (submitcheck.go:345-349).
+   unit_flags[u] & ASCHED_SUBMIT_STRIP_GANG: the individual check of getIndividualSchedulingResult (submitcheck.go:272-290).
+   One device launch serves the whole batch. */
+int32_t ASCHED_FN(submit_check)(asched_t*, int32_t n_units, const int32_t* unit_off /*[n_units+1]*/, const int32_t* unit_jobs,
+                                const int32_t* unit_flags /*[n_units] or NULL*/, asched_submit_result* out /*[n_units]*/);
 /* NodeTypesIterator order (nodeiteration.go:74-149) for req at a priority over node types `types`
    (ntypes<0: all types).  Test hook for the golden orderings of nodeiteration_test.go. */
 int32_t ASCHED_FN(iterate_nodes)(asched_t*, const int64_t* type_ids, int32_t ntypes, int32_t priority,

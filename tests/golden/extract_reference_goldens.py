@@ -68,6 +68,69 @@ def extract_table(path, func_name, env, skipped, table_var="tests"):
     return out
 
 
+def extract_submitcheck(base_env, skipped):
+    """submitcheck_test.go:28-456 TestSubmitChecker_CheckJobDbJobs.  The table refers to jobs and nodes built by the statements and
+    helper functions around it (:32-58 jobs and pools, :516-544 Executor / GpuNode, :553-573 cordon / SmallNode); those are restated
+    here with the same fixtures, the table itself is evaluated mechanically.  Job ids are creation-order labels (the reference's are
+    random ULIDs and only key the expectation map)."""
+    import copy
+    import itertools
+    G = gofixtures
+    env = dict(base_env)
+    ids = itertools.count(1)
+
+    def with_id(j):
+        jid = f"job-{next(ids):04d}"
+        j["id"] = jid
+        j["Id"] = (lambda s: (lambda: s))(jid)  # job.Id()
+        return j
+
+    env["smallJob1"] = with_id(G.Test1Cpu4GiJob("queue", G.PriorityClass1))                                   # :32
+    env["smallJob2"] = with_id(G.Test1Cpu4GiJob("queue", G.PriorityClass1))                                   # :33
+    env["smallGpuJob"] = with_id(G.Test1GpuJob("queue", G.PriorityClass4PreemptibleAway))                     # :34
+    env["smallAwayJob"] = with_id(G.Test1Cpu4GiJob("queue", G.PriorityClass4PreemptibleAway))                 # :35
+    env["largeJob1"] = with_id(G.Test32Cpu256GiJobWithLargeJobToleration("queue", G.PriorityClass1))          # :36
+    env["smallGangJob"] = [with_id(j) for j in G.WithGangAnnotationsJobs(G.N1Cpu4GiJobs("queue", G.PriorityClass1, 2))]  # :39-40
+    env["largeGangJob"] = [with_id(j) for j in G.WithGangAnnotationsJobs(G.N1Cpu4GiJobs("queue", G.PriorityClass1, 4))]  # :43-44
+    env["batchJobs"] = [with_id(j) for j in G.N1Cpu4GiJobs("queue", G.PriorityClass1, 20)]                    # :46
+
+    def small_node(pool):  # :563-573
+        n = G.TestNode(None, {"cpu": "2", "memory": "64Gi"})
+        n["pool"] = pool
+        return n
+
+    def gpu_node(pool):    # :527-544
+        n = G.TestNode(None, {"cpu": "30", "memory": "512Gi", "nvidia.com/gpu": "8"})
+        n["taints"] = [["gpu", "true", "NoSchedule"]]
+        n["pool"] = pool
+        return n
+
+    def cordon(n):         # :553-561 (node.Unschedulable + the taint kubectl adds)
+        n["unschedulable"] = True
+        n["taints"].append(["node.kubernetes.io/unschedulable", "", "NoSchedule"])
+        return n
+
+    env.update({"SmallNode": small_node, "GpuNode": gpu_node, "cordon": cordon, "Executor": lambda *nodes: list(nodes),
+                "defaultTimeout": 900, "time.Second": 1, "pointer.MustParseResource": G.MustParse,
+                "testfixtures.WithNodeSelectorJob": lambda sel, j: G.WithNodeSelectorJobs(sel, [copy.copy(j)])[0]})
+    cases = extract_table(f"{REF}/submitcheck_test.go", "TestSubmitChecker_CheckJobDbJobs", env, skipped)
+    pools = [  # schedulingConfig.Pools, :49-58
+        {"name": "cpu"}, {"name": "cpu2"}, {"name": "cpu-disallowed-resources", "disallowed_resources": ["cpu"]}, {"name": "gpu"},
+        {"name": "cpu-away", "away_pools": ["gpu"]}, {"name": "cpu-grouped-1", "submission_group": "group-1"},
+        {"name": "cpu-grouped-2", "submission_group": "group-1"},
+    ]
+    out = []
+    for c in cases:
+        c = to_json(c)
+        for j in c["jobs"]:
+            j.pop("Id", None)
+        c["SchedulingConfig"] = to_json(G.TestSchedulingConfig())
+        c["Pools"] = pools
+        c["Queues"] = [c.pop("queue")] if c.get("queue") else [{"Name": "queue"}]   # :400-405
+        out.append(c)
+    return out
+
+
 def main():
     env = gofixtures.make_env()
     skipped = []
@@ -131,6 +194,30 @@ def main():
         away.append({"name": r["name"], "source": r["source"], "SchedulingConfig": to_json(cfg), "Nodes": to_json([node]), "Jobs": to_json([job]),
                      "ExpectSuccess": [bool(r["expectSuccess"])], "ExpectAway": {"node": 0, "priority": 29000}})       # :1399-1427
     out["nodedb_away_node_scheduling"] = away
+
+    out["submitcheck"] = extract_submitcheck(env, skipped)
+
+    # nodedb_test.go:1236-1291 TestConditionalAwayNodeScheduling: one node, one job of armada-preemptible-away-conditional, through
+    # SelectNodeForJobWithTxn; the job built before the table (:1237-1241) is restated with the same fixtures
+    cenv = dict(env)
+    cenv["gpuJobWithoutGpuToleration"] = gofixtures.TestJob("A", None, gofixtures.PriorityClass7PreemptibleAwayConditional,
+                                                            gofixtures.TestPodReqs({"cpu": "8", "memory": "128Gi", "nvidia.com/gpu": "1"}))
+    cond = []
+    for r in extract_table(f"{REF}/nodedb/nodedb_test.go", "TestConditionalAwayNodeScheduling", cenv, skipped):
+        cond.append({"name": r["name"], "source": r["source"], "SchedulingConfig": to_json(gofixtures.TestSchedulingConfig()),
+                     "Nodes": to_json([r["node"]]), "Jobs": to_json([r["job"]]), "ExpectScheduled": bool(r["expectScheduled"])})
+    out["nodedb_conditional_away"] = cond
+
+    # nodedb_test.go:1150-1234 TestMatchesConditions: matchesCondition is internal to the NodeDb; each case is kept as data (conditions,
+    # job resources, expected verdict) and the tests drive it end to end through an away entry whose only taints come from a
+    # conditional NodeTypes entry (tests/test_away_conditions.py)
+    menv = dict(env)
+    for nm, v in (("cpu0", 0), ("cpu2", 2), ("cpu4", 4)):
+        menv[nm] = v
+    menv["types.AwayNodeTypeConditionOpGreaterThan"] = ">"
+    menv["types.AwayNodeTypeConditionOpLessThan"] = "<"
+    menv["types.AwayNodeTypeConditionOpEqual"] = "=="
+    out["matches_conditions"] = extract_table(f"{REF}/nodedb/nodedb_test.go", "TestMatchesConditions", menv, skipped)
 
     for k, v in out.items():
         path = os.path.join(HERE, f"{k}_cases.json")

@@ -70,7 +70,9 @@ TEST_PRIORITY_CLASSES = {  # testfixtures.go:78-105
     PriorityClass4PreemptibleAway: {"priority": 30000, "preemptible": True, "away": [[29000, "gpu"], [29000, "large"]]},
     PriorityClass5PreemptibleAwayLowPriority: {"priority": 30000, "preemptible": True, "away": [[28000, "gpu"], [28000, "large"]]},
     PriorityClass6Preemptible: {"priority": 30000, "preemptible": True},
-    PriorityClass7PreemptibleAwayConditional: {"priority": 30000, "preemptible": True, "away_conditional": True},
+    # an away entry is [priority, WellKnownNodeTypeName, NodeTypes]; NodeTypes = [[name, [[resource, operator, c.Value.Value()], ...]], ...]
+    PriorityClass7PreemptibleAwayConditional: {"priority": 30000, "preemptible": True,
+                                               "away": [[29000, "large", [["gpu", [["nvidia.com/gpu", "==", 0]]]]]]},
 }
 TestPriorities = [0, 1, 2, 3, 28000, 29000, 30000]
 
@@ -93,9 +95,13 @@ class GoConfig(dict):
                 e = {"priority": int(pc.get("Priority", 0)), "preemptible": bool(pc.get("Preemptible", False))}
                 away = []
                 for a in pc.get("AwayNodeTypes") or []:
-                    if set(a) - {"Priority", "WellKnownNodeTypeName"}:
+                    if set(a) - {"Priority", "WellKnownNodeTypeName", "NodeTypes"}:
                         raise Unsupported(f"AwayNodeType fields {sorted(a)}")
-                    away.append([int(a["Priority"]), a["WellKnownNodeTypeName"]])
+                    ent = [int(a["Priority"]), a.get("WellKnownNodeTypeName", "")]
+                    if a.get("NodeTypes"):
+                        ent.append([[t["Name"], [[c["Resource"], c["Operator"], int(math.ceil(quantity(c["Value"]) - 1e-9))] for c in t.get("Conditions") or []]]
+                                    for t in a["NodeTypes"]])
+                    away.append(ent)
                 if away:
                     e["away"] = away
                 out[name] = e
@@ -337,6 +343,11 @@ def AddLabels(nodes, labels):
     for n in nodes:
         n["labels"].update(labels)
     return nodes
+
+
+def WithGpuTaint(node): return AddTaints([node], [{"Key": "gpu", "Value": "true", "Effect": "NoSchedule"}])[0]                 # testfixtures.go:1059-1068
+def WithLargeJobsOnlyTaint(node): return AddTaints([node], [{"Key": "largeJobsOnly", "Value": "true", "Effect": "NoSchedule"}])[0]  # :1070-1079
+def TestPodReqs(requests): return _podreqs(requests)                                                                              # :810-816
 
 
 def AddTaints(nodes, taints):

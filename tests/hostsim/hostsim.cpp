@@ -92,7 +92,7 @@ static double plat_last_fit_ms() { return 0; }
 static const char* plat_last_error() { return g_err.c_str(); }
 static int plat_run_control(Dev& dev, int cmd) {
   Dev d = dev;
-  controlMain(d, cmd);
+  if (cmd >= CMD_AUX_FIRST) controlMainAux(d, cmd); else controlMain(d, cmd);
   return 0;
 }
 // sorted base of the level-0 fast structure (round_fast.h): the device build sorts with a bitonic network

@@ -14,10 +14,11 @@ from typing import Dict, List
 
 import numpy as np
 
-from armada_amd.binding import Config, Library, Scheduler
+from armada_amd.binding import AWAY_COND_OPS, Config, Library, Scheduler
 
 RES = ["memory", "cpu", "nvidia.com/gpu", "test-floating-resource"]  # TestResourceListFactory column order
 R = len(RES)
+RES_UNIT = {"memory": 1, "cpu": 1000, "nvidia.com/gpu": 1000, "test-floating-resource": 1000}  # factory units per whole unit (gofixtures.SCALE)
 EFFECTS = {"": 0, "NoSchedule": 1, "PreferNoSchedule": 2, "NoExecute": 3}
 UNSCHEDULABLE_TAINT = ["node.kubernetes.io/unschedulable", "", "NoSchedule"]
 
@@ -56,11 +57,15 @@ class Case:
         pcs = cfg["priority_classes"]
         wkt_names = sorted(cfg["well_known_node_types"])
         wkt_index = {n: i for i, n in enumerate(wkt_names)}
-        pc_away = []
+        pc_away, pc_away_nt = [], []
         for n in self.pc_names:
             # an away entry naming a well-known node type the config does not define makes the reference return an error if it is ever
             # tried (nodedb.go:653-657); the tables that redefine WellKnownNodeTypes never reach such an entry: leave it out
-            pc_away.append([(pr, wkt_index[w]) for pr, w in pcs[n].get("away", []) if w in wkt_index])
+            ents = [e for e in pcs[n].get("away", []) if e[1] == "" or e[1] in wkt_index]
+            pc_away.append([(e[0], wkt_index.get(e[1], -1)) for e in ents])
+            # AwayNodeType.NodeTypes: [[name, [[resource, operator, whole-unit value], ...]], ...] as the entry's optional third element
+            pc_away_nt.append([[(wkt_index[name], [(RES.index(r) if r in RES else -1, AWAY_COND_OPS.get(op, 99), int(v)) for r, op, v in conds])
+                                for name, conds in (e[2] if len(e) > 2 else [])] for e in ents])
         wkt_taints = [[(self.S(k), -1 if v == "*" else self.S(v), EFFECTS[e]) for k, v, e in cfg["well_known_node_types"][n]] for n in wkt_names]
         frac = dict(cfg.get("maximum_resource_fraction_to_schedule") or {})
         bypool = cfg.get("maximum_resource_fraction_to_schedule_by_pool") or {}
@@ -73,7 +78,7 @@ class Case:
             pc_priority=[pcs[n]["priority"] for n in self.pc_names],
             pc_preemptible=[int(pcs[n]["preemptible"]) for n in self.pc_names],
             drf_multiplier=[1.0 if r in cfg["drf_resources"] else 0.0 for r in RES],
-            pc_away=pc_away,
+            pc_away=pc_away, pc_away_node_types=pc_away_nt, resource_unit=[RES_UNIT[r] for r in RES],
             wkt_taints=wkt_taints,
             indexed_taint_keys=[self.S(k) for k in cfg["indexed_taints"]],
             indexed_label_keys=[self.S(k) for k in cfg["indexed_node_labels"]],
@@ -188,8 +193,6 @@ class Case:
 def uses_unsupported(case: dict, jobs: List[dict]) -> str:
     pcs = case["SchedulingConfig"]["priority_classes"]
     for j in jobs:
-        if pcs[j["pc"]].get("away_conditional"):
-            return "conditional away node types"
         if j.get("affinity"):
             return "node affinity"
         if "test-floating-resource" in j["req"]:

@@ -1,0 +1,253 @@
+"""Test scaffolding for the submit check (internal/scheduler/submitcheck.go).
+
+* `build_state` restates SubmitChecker.updateExecutors (:128-219): one cleared NodeDb per pool over the pool's own nodes plus the
+  nodes of its away pools, cordon taints removed, and the per-queue limits of constraints.NewSchedulingConstraints.
+* `literal_check` restates SubmitChecker.Check / getIndividualSchedulingResult / getGangSchedulingResult / getSchedulingResult
+  (:225-394) line by line — LRU cache included — with ONE transaction per attempt through the NodeDb-level entry points
+  (txn_begin / schedule_many / txn_abort).  It is the sequential flow the batched product path
+  (armada_amd/submitcheck.py -> asched_submit_check) must reproduce.
+"""
+import collections
+import math
+from typing import Dict, List
+
+from armada_amd.binding import Library
+from armada_amd.submitcheck import PoolConfig, PoolNodeDb, SchedulingResult, SubmitChecker, SubmitJob
+from scenario import RES, Case, inf, vec
+
+CORDON_TAINT_KEYS = ("armadaproject.io/unschedulable", "node.kubernetes.io/unschedulable")  # internaltypes/unschedulable.go:28-30
+
+
+def scheduling_key(j: dict):
+    """job.SchedulingKey() (internaltypes/podutils.go:52-72): selector, tolerations, requests, priority class (affinity unmodelled)"""
+    return (tuple(sorted(j["selector"].items())), tuple(sorted((t["key"], t["op"], t["value"], t["effect"]) for t in j["tolerations"])),
+            tuple(vec(j["req"])), j["pc"])
+
+
+def to_submit_job(j: dict) -> SubmitJob:
+    return SubmitJob(id=j["id"], queue=j["queue"], priority_class=j["pc"], scheduling_key=scheduling_key(j), request=vec(j["req"]),
+                     gang_id=j["gang"]["id"] if j.get("gang") else None)
+
+
+class CasePoolDb(PoolNodeDb):
+    """One pool's NodeDb: a scenario.Case (config + nodes -> binding.Scheduler), cleared."""
+
+    def __init__(self, lib: Library, cfg: dict, pool: dict, nodes: List[dict], queues: List[dict], jobs_by_id: Dict[str, dict]):
+        cfg = dict(cfg)
+        cfg["disallowed_resources"] = list(pool.get("disallowed_resources") or [])   # ConstructNodeDb: scheduling_algo.go:772
+        clean = []
+        for n in nodes:                                                              # RemoveCordonTaint: node_factory.go:171-203
+            n = dict(n)
+            n["taints"] = [t for t in n["taints"] if t[0] not in CORDON_TAINT_KEYS]
+            n["unschedulable"] = False
+            clean.append(n)
+        self.pool, self.nodes, self.jobs_by_id, self.queues = pool["name"], clean, jobs_by_id, queues
+        self.case = Case(lib, cfg, clean, pool_limit_key=pool["name"]) if clean else None
+        self.cfg = cfg
+        if self.case:
+            self.case.sched.clear_allocated()                                        # :185
+        self.total = [sum(vec(n["total"])[r] for n in clean) for r in range(len(RES))]   # nodeDb.TotalKubernetesResources()
+        self.loaded: List[dict] = []
+
+    # ---- PoolNodeDb
+    def load_jobs(self, jobs):
+        self.set_job_dicts([self.jobs_by_id[j.id] for j in jobs])
+
+    def set_job_dicts(self, dicts: List[dict]):
+        self.loaded = dicts
+        if self.case:
+            queues = sorted({j["queue"] for j in dicts})
+            self.case.set_jobs(dicts, {q: i for i, q in enumerate(queues)}, {})
+
+    def submit_check(self, units, strip_gang):
+        if not self.case:  # a pool without nodes: nothing is schedulable (the reference's empty NodeDb yields no node)
+            return [(False, False, 0, -1) for _ in units]
+        return self.case.sched.submit_check(units, strip_gang)
+
+    def queue_resource_limit(self, queue, pc):
+        """calculatePerQueueLimits (constraints.go:218-256) -> GetQueueResourceLimit (:180-185)"""
+        if not any(self.total):              # totalResources.IsEmpty(): no limits at all (:226-228)
+            return None
+        qc = next((q for q in self.queues if q["Name"] == queue), None)
+        if qc is None:
+            return None
+        pcs = self.cfg["priority_classes"]
+        fr = dict(pcs[pc].get("max_fraction_per_queue") or {})
+        lim = (qc.get("ResourceLimitsByPriorityClassName") or {}).get(pc)
+        if lim:
+            fr.update(lim.get("MaximumResourceFraction") or {})
+            bypool = (lim.get("MaximumResourceFractionByPool") or {}).get(self.pool)
+            if bypool:
+                fr.update(bypool.get("MaximumResourceFraction") or {})
+        out = []
+        for r, name in enumerate(RES):       # totalResources.Multiply(fractions, default +Inf): resource_list.go:312-331
+            m = float(inf(fr.get(name, "inf")))
+            if m == 1.0:
+                out.append(self.total[r])
+            elif math.isinf(m):
+                out.append(2**63 - 1 if (m < 0) == (self.total[r] < 0) else -2**63)
+            else:
+                out.append(int(float(self.total[r]) * m))
+        return out
+
+
+def build_state(lib: Library, case: dict):
+    """SubmitChecker.updateExecutors (:128-219)"""
+    jobs_by_id = {j["id"]: j for j in case["jobs"]}
+    all_nodes = [n for ex in case["executors"] for n in ex]
+    by_pool: Dict[str, List[dict]] = collections.defaultdict(list)
+    for n in all_nodes:
+        by_pool[n["pool"]].append(n)
+    pools = [PoolConfig(p["name"], tuple(p.get("away_pools") or ()), p.get("submission_group", "")) for p in case["Pools"]]
+    dbs = {}
+    for p, pc in zip(case["Pools"], pools):
+        nodes = list(by_pool.get(pc.name, []))
+        for a in pc.away_pools:
+            nodes += by_pool.get(a, [])
+        dbs[pc.name] = CasePoolDb(lib, case["SchedulingConfig"], p, nodes, case["Queues"], jobs_by_id)
+    return pools, dbs
+
+
+class SteppingClock:
+    """testfixtures.SteppingClock (testfixtures.go:1177-1201): Now() returns the current time, then advances it"""
+
+    def __init__(self, step):
+        self.t, self.step = 0.0, step
+
+    def __call__(self):
+        t = self.t
+        self.t += self.step
+        return t
+
+
+def make_clock(case: dict):
+    return SteppingClock(case.get("clockStep") or 0)
+
+
+def batched_check(lib: Library, case: dict) -> Dict[str, SchedulingResult]:
+    """the product flow: armada_amd.submitcheck.SubmitChecker over asched_submit_check"""
+    pools, dbs = build_state(lib, case)
+    cfg = case.get("submitCheckConfig") or {}
+    chk = SubmitChecker(pools, dbs, max_duration=cfg.get("MaxDuration", 0), max_duration_per_queue=cfg.get("MaxDurationPerQueue", 0),
+                        now=make_clock(case))
+    return chk.check([to_submit_job(j) for j in case["jobs"]])
+
+
+# ------------------------------------------------------------------------------------------------ literal sequential restatement
+class _LRU:
+    """hashicorp/golang-lru Cache as the reference uses it (lru.New(10000), Get / Add): submitcheck.go:137,279-288"""
+
+    def __init__(self, size=10000):
+        self.size, self.d = size, collections.OrderedDict()
+
+    def get(self, k):
+        if k in self.d:
+            self.d.move_to_end(k)
+            return self.d[k]
+        return None
+
+    def add(self, k, v):
+        self.d[k] = v
+        self.d.move_to_end(k)
+        while len(self.d) > self.size:
+            self.d.popitem(last=False)
+
+
+def literal_check(lib: Library, case: dict, cache_size=10000) -> Dict[str, SchedulingResult]:
+    pools, dbs = build_state(lib, case)
+    jobs = case["jobs"]
+    m = len(jobs)
+    # job table: i = the job as submitted; m + i = job.WithGangInfo(jobdb.BasicJobGangInfo()) (:274)
+    table = list(jobs) + [dict(j, gang=None) for j in jobs]
+    for db in dbs.values():
+        db.set_job_dicts(table)
+    cfg = case.get("submitCheckConfig") or {}
+    now = make_clock(case)
+    cache = _LRU(cache_size)
+
+    def deadline(limit, t):
+        return None if limit <= 0 else t + limit
+
+    def exceeded(d, t):
+        return d is not None and t > d
+
+    def get_scheduling_result(members: List[int], stripped: bool) -> SchedulingResult:   # getSchedulingResult :309-394
+        successful: Dict[str, bool] = {}
+        rep = jobs[members[0]]
+        total = [sum(vec(jobs[i]["req"])[r] for i in members) for r in range(len(RES))]
+        for pool in pools:
+            if successful.get(pool.name):
+                continue
+            if any(successful.get(a) for a in pool.away_pools):
+                continue
+            db = dbs[pool.name]
+            limit = db.queue_resource_limit(rep["queue"], rep["pc"])
+            if limit is not None and any(t > l for t, l in zip(total, limit)):
+                continue
+            if db.case is None:
+                continue
+            s = db.case.sched
+            ids = [m + i if stripped else i for i in members]
+            s.txn_begin()                                    # txn := nodeDb.Txn(true)
+            ok, pods, _ = s.schedule_many(ids)               # nodeDb.ScheduleManyWithTxn(txn, gctx)
+            s.txn_abort()                                    # txn.Abort()
+            if ok:
+                if pods[0].method != 5 or len(pool.away_pools) > 0:   # !ScheduledAway || len(pool.AwayPools) > 0
+                    for p in [q.name for q in pools if q.get_submission_group() == pool.get_submission_group()]:
+                        successful[p] = True
+                continue
+        if successful:
+            return SchedulingResult(True, list(successful.keys()))
+        return SchedulingResult(False, [])
+
+    def individual(i: int) -> SchedulingResult:              # getIndividualSchedulingResult :272-290
+        key = scheduling_key(jobs[i])
+        hit = cache.get(key)
+        if hit is not None:
+            return hit
+        r = get_scheduling_result([i], True)
+        cache.add(key, r)
+        return r
+
+    def gang(members: List[int]) -> SchedulingResult:         # getGangSchedulingResult :292-302
+        for i in members:
+            r = individual(i)
+            if not r.is_schedulable:
+                return r
+        return get_scheduling_result(members, False)
+
+    results: Dict[str, SchedulingResult] = {}
+    start = now()
+    gdl = deadline(cfg.get("MaxDuration", 0), start)
+    by_queue: Dict[str, List[int]] = {}
+    for i, j in enumerate(jobs):
+        by_queue.setdefault(j["queue"], []).append(i)
+    for _, idxs in by_queue.items():
+        if exceeded(gdl, now()):
+            break
+        qdl = deadline(cfg.get("MaxDurationPerQueue", 0), now())
+        by_gang: Dict[str, List[int]] = {}
+        for i in idxs:
+            if jobs[i].get("gang"):
+                by_gang.setdefault(jobs[i]["gang"]["id"], []).append(i)
+        processed = set()
+        for i in idxs:
+            if exceeded(qdl, now()) or exceeded(gdl, now()):
+                break
+            if not jobs[i].get("gang"):
+                results[jobs[i]["id"]] = individual(i)
+            else:
+                gid = jobs[i]["gang"]["id"]
+                if gid in processed:
+                    continue
+                r = gang(by_gang[gid])
+                for k in by_gang[gid]:
+                    results[jobs[k]["id"]] = r
+                processed.add(gid)
+    return results
+
+
+def same_results(a: Dict[str, SchedulingResult], b: Dict[str, SchedulingResult]):
+    assert set(a) == set(b), f"different jobs checked: {sorted(set(a) ^ set(b))}"
+    for k in a:
+        assert a[k].is_schedulable == b[k].is_schedulable and sorted(a[k].pools) == sorted(b[k].pools), f"{k}: {a[k]} vs {b[k]}"
