@@ -98,7 +98,12 @@ class CReqClasses(C.Structure):
     _fields_ = [
         ("n", C.c_int32), ("tol_off", _i32p), ("tol_key", _i32p), ("tol_op", _i32p), ("tol_value", _i32p),
         ("tol_effect", _i32p), ("sel_off", _i32p), ("sel_key", _i32p), ("sel_value", _i32p),
+        ("has_affinity", _u8p), ("aff_term_off", _i32p), ("aff_expr_off", _i32p), ("aff_expr_key", _i32p), ("aff_expr_op", _i32p),
+        ("aff_value_off", _i32p), ("aff_values", _i32p),
     ]
+
+
+AFFINITY_OPS = {"In": 0, "NotIn": 1, "Exists": 2, "DoesNotExist": 3}
 
 
 class CJobs(C.Structure):
@@ -435,7 +440,8 @@ class Scheduler:
 
     def jobs_set(self, req, *, queue=None, pc=None, queue_priority=None, submit_time=None, req_class=None, gang_id=None,
                  gang_cardinality=None, gang_uniformity_label=None, node=None, scheduled_at_priority=None,
-                 run_timestamp=None, class_tolerations=None, class_selectors=None):
+                 run_timestamp=None, class_tolerations=None, class_selectors=None, class_affinities=None):
+        """class_affinities: per class None (no required node affinity) or a list of terms, a term = list of (key, op, [values])"""
         req = _arr(req, np.int64).reshape(-1, self.R)
         m = req.shape[0]
         s = CJobs()
@@ -475,6 +481,20 @@ class Scheduler:
         off2, (sk, sv) = _csr(sels, 2)
         keep += [off2, sk, sv]
         cls.sel_off, cls.sel_key, cls.sel_value = (_ptr(x, C.c_int32) for x in (off2, sk, sv))
+        if class_affinities is not None and any(a is not None for a in class_affinities):
+            assert len(class_affinities) == len(tols)
+            has, term_off, expr_off, ekey, eop, val_off, vals = [], [0], [0], [], [], [0], []
+            for a in class_affinities:
+                has.append(0 if a is None else 1)
+                for term in (a or []):
+                    for key, op, values in term:
+                        ekey.append(key); eop.append(op); vals.extend(values); val_off.append(len(vals))
+                    expr_off.append(len(ekey))
+                term_off.append(len(expr_off) - 1)
+            arrs = [_arr(has, np.uint8)] + [_arr(x or [0], np.int32) for x in (term_off, expr_off, ekey, eop, val_off, vals)]
+            keep += arrs
+            cls.has_affinity = _ptr(arrs[0], C.c_uint8)
+            (cls.aff_term_off, cls.aff_expr_off, cls.aff_expr_key, cls.aff_expr_op, cls.aff_value_off, cls.aff_values) = (_ptr(x, C.c_int32) for x in arrs[1:])
         self._check(self.lib.jobs_set(self.h, C.byref(s), C.byref(cls)))
         self.num_jobs = m
 

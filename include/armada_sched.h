@@ -179,7 +179,24 @@ typedef struct asched_req_classes {
   const int32_t* tol_effect; /* 0 = empty (matches all effects) */
   const int32_t* sel_off;  /* [n+1] PodRequirements.NodeSelector */
   const int32_t* sel_key; const int32_t* sel_value;
+  /* PodRequirements.GetAffinityNodeSelector(): Affinity.NodeAffinity.RequiredDuringSchedulingIgnoredDuringExecution, checked per node by
+     NodeAffinityRequirementsMet (nodematching.go:242-255, not at node-type level :127-139).  Optional: has_affinity == NULL = no class has
+     one.  Terms are ORed, the expressions of a term ANDed, a term without expressions matches no node (k8s.io/component-helpers
+     v0.32.11 scheduling/corev1/nodeaffinity).  MatchFields and the Gt / Lt operators are not representable: ASCHED_ERR_UNSUPPORTED. */
+  const uint8_t* has_affinity;   /* [n] 0 = nil NodeSelector: every node matches */
+  const int32_t* aff_term_off;   /* [n+1] CSR: NodeSelectorTerms of each class */
+  const int32_t* aff_expr_off;   /* [number of terms + 1] CSR: MatchExpressions of each term */
+  const int32_t* aff_expr_key;   /* interned label key */
+  const int32_t* aff_expr_op;    /* ASCHED_AFFINITY_OP_* */
+  const int32_t* aff_value_off;  /* [number of expressions + 1] CSR into aff_values */
+  const int32_t* aff_values;     /* interned label values (In / NotIn) */
 } asched_req_classes;
+
+/* v1.NodeSelectorOperator */
+#define ASCHED_AFFINITY_OP_IN 0
+#define ASCHED_AFFINITY_OP_NOT_IN 1
+#define ASCHED_AFFINITY_OP_EXISTS 2
+#define ASCHED_AFFINITY_OP_DOES_NOT_EXIST 3
 
 /* ---- jobs: the jobdb view the round needs (jobdb/job.go accessors used on the path).
  *      Job ids are their index in this table; index order is the id-string order used as the

@@ -303,8 +303,15 @@ def WithRequestsJobs(rlist, jobs):
     return jobs
 
 
-def WithNodeAffinityJobs(*a):
-    raise Unsupported("node affinity is not modelled")
+def WithNodeAffinityJobs(terms, jobs):  # testfixtures.go:476-494: appends to RequiredDuringSchedulingIgnoredDuringExecution.NodeSelectorTerms
+    for j in jobs:
+        cur = list(j.get("affinity") or [])
+        for t in terms:
+            if t.get("MatchFields"):
+                raise Unsupported("node affinity MatchFields")
+            cur.append([[e["Key"], e["Operator"], list(e.get("Values") or [])] for e in t.get("MatchExpressions") or []])
+        j["affinity"] = cur   # list of terms; a term = list of [key, operator, values]
+    return jobs
 
 
 def WithAnnotationsJobs(annotations, jobs):
@@ -413,6 +420,8 @@ def make_env():
     env["armadaslices.Concatenate"] = Concatenate
     env["util.ULID"] = ULID
     env["resource.MustParse"] = MustParse
+    for op in ("In", "NotIn", "Exists", "DoesNotExist", "Gt", "Lt"):
+        env["v1.NodeSelectorOp" + op] = op
     env["v1.TaintEffectNoSchedule"] = "NoSchedule"
     env["v1.TaintEffectNoExecute"] = "NoExecute"
     env["v1.TaintEffectPreferNoSchedule"] = "PreferNoSchedule"

@@ -14,7 +14,7 @@ from typing import Dict, List
 
 import numpy as np
 
-from armada_amd.binding import AWAY_COND_OPS, Config, Library, Scheduler
+from armada_amd.binding import AFFINITY_OPS, AWAY_COND_OPS, Config, Library, Scheduler
 
 RES = ["memory", "cpu", "nvidia.com/gpu", "test-floating-resource"]  # TestResourceListFactory column order
 R = len(RES)
@@ -119,17 +119,21 @@ class Case:
     def set_jobs(self, jobs: List[dict], queue_index: Dict[str, int], running: Dict[int, tuple]):
         """jobs: list of job dicts (golden format); running: local idx -> (node, prio, run_ts)"""
         classes: Dict[tuple, int] = {}
-        cls_tol, cls_sel = [], []
+        cls_tol, cls_sel, cls_aff = [], [], []
         req_class, gang_id, gang_card, gang_uni = [], [], [], []
         gangs: Dict[tuple, int] = {}
         for j in jobs:
             tol = tuple((-1 if t["key"] == "" else self.S(t["key"]), 1 if t["op"] == "Exists" else 0, self.S(t["value"]), EFFECTS[t["effect"]]) for t in j["tolerations"])
             sel = tuple(sorted((self.S(k), self.S(v)) for k, v in j["selector"].items()))
-            key = (tol, sel)
+            aff = None
+            if j.get("affinity") is not None:  # required node affinity: list of terms, a term = list of [key, operator, values]
+                aff = tuple(tuple((self.S(k), AFFINITY_OPS[op], tuple(self.S(v) for v in vals)) for k, op, vals in term) for term in j["affinity"])
+            key = (tol, sel, aff)
             if key not in classes:
                 classes[key] = len(classes)
                 cls_tol.append(list(tol))
                 cls_sel.append(list(sel))
+                cls_aff.append(None if aff is None else [[(k, op, list(vals)) for k, op, vals in term] for term in aff])
             req_class.append(classes[key])
             g = j.get("gang")
             if g:
@@ -142,7 +146,7 @@ class Case:
             else:
                 gang_id.append(-1); gang_card.append(1); gang_uni.append(-1)
         if not classes:
-            cls_tol, cls_sel = [[]], [[]]
+            cls_tol, cls_sel, cls_aff = [[]], [[]], [None]
         m = len(jobs)
         node = [running[i][0] if i in running else -1 for i in range(m)]
         sap = [running[i][1] if i in running else 0 for i in range(m)]
@@ -155,7 +159,7 @@ class Case:
             submit_time=[j["created"] for j in jobs],
             req_class=req_class, gang_id=gang_id, gang_cardinality=gang_card, gang_uniformity_label=gang_uni,
             node=node, scheduled_at_priority=sap, run_timestamp=rts,
-            class_tolerations=cls_tol, class_selectors=cls_sel)
+            class_tolerations=cls_tol, class_selectors=cls_sel, class_affinities=cls_aff)
 
     def sort_queued(self, jobs: List[dict], idxs: List[int]) -> List[int]:
         """SchedulingOrderCompare for queued (non-active) jobs: jobdb/comparison.go:49-107"""
@@ -193,8 +197,8 @@ class Case:
 def uses_unsupported(case: dict, jobs: List[dict]) -> str:
     pcs = case["SchedulingConfig"]["priority_classes"]
     for j in jobs:
-        if j.get("affinity"):
-            return "node affinity"
+        if any(op not in AFFINITY_OPS for term in (j.get("affinity") or []) for _, op, _ in term):
+            return "node affinity operator Gt / Lt"
         if "test-floating-resource" in j["req"]:
             return "floating resources"
     return ""

@@ -19,9 +19,9 @@ CORDON_TAINT_KEYS = ("armadaproject.io/unschedulable", "node.kubernetes.io/unsch
 
 
 def scheduling_key(j: dict):
-    """job.SchedulingKey() (internaltypes/podutils.go:52-72): selector, tolerations, requests, priority class (affinity unmodelled)"""
+    """job.SchedulingKey() (internaltypes/podutils.go:52-72): selector, tolerations, node affinity, requests, priority class"""
     return (tuple(sorted(j["selector"].items())), tuple(sorted((t["key"], t["op"], t["value"], t["effect"]) for t in j["tolerations"])),
-            tuple(vec(j["req"])), j["pc"])
+            tuple(vec(j["req"])), j["pc"], repr(j.get("affinity")))
 
 
 def to_submit_job(j: dict) -> SubmitJob:
