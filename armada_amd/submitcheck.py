@@ -8,9 +8,9 @@ launch per pool for the individual checks (one unit per distinct scheduling key)
 one transaction round trip per job.  The pool loop of getSchedulingResult (:309-394: submission groups, away pools,
 per-queue limits, floating resources) is pure bookkeeping over those per-pool answers and runs on the host.
 
-Equality with the reference's sequential flow is what tests/test_submitcheck.py checks: against the expectations of
+Equality with the reference's sequential flow is what tests/test_z_submitcheck.py checks: against the expectations of
 submitcheck_test.go (tests/golden/submitcheck_cases.json) and against a literal one-transaction-at-a-time restatement of
-`Check` (tests/submitcheck_literal.py) on seeded inputs.
+`Check` (tests/submitcheck_harness.py: literal_check) on seeded inputs.
 
 Nothing here computes a placement: `PoolNodeDb.submit_check` must be backed by the native library
 (armada_amd.binding.Scheduler.submit_check); there is no Python fallback.

@@ -210,7 +210,7 @@ def main():
 
     # nodedb_test.go:1150-1234 TestMatchesConditions: matchesCondition is internal to the NodeDb; each case is kept as data (conditions,
     # job resources, expected verdict) and the tests drive it end to end through an away entry whose only taints come from a
-    # conditional NodeTypes entry (tests/test_away_conditions.py)
+    # conditional NodeTypes entry (tests/test_z_away_conditions.py)
     menv = dict(env)
     for nm, v in (("cpu0", 0), ("cpu2", 2), ("cpu4", 4)):
         menv[nm] = v
