@@ -197,6 +197,14 @@ def main():
 
     out["submitcheck"] = extract_submitcheck(env, skipped)
 
+    # queue_scheduler_test.go:804-946 TestQueueScheduler_PreemptionRateLimit: one node, existing jobs of queues A / B (all evicted and
+    # registered as fair-share preemption candidates by the test body), new jobs of queue B, sctx.FairsharePreemptionLimiter
+    renv = dict(env)
+    renv["rate.Limit"] = float
+    renv["rate.NewLimiter"] = lambda r, b: {"rate": float(r), "burst": int(b)}
+    out["preemption_rate_limit"] = [dict(to_json(r), SchedulingConfig=to_json(gofixtures.TestSchedulingConfig()))
+                                    for r in extract_table(f"{REF}/scheduling/queue_scheduler_test.go", "TestQueueScheduler_PreemptionRateLimit", renv, skipped)]
+
     # nodedb_test.go:1236-1291 TestConditionalAwayNodeScheduling: one node, one job of armada-preemptible-away-conditional, through
     # SelectNodeForJobWithTxn; the job built before the table (:1237-1241) is restated with the same fixtures
     cenv = dict(env)
