@@ -1,0 +1,127 @@
+"""Round-input builder: what round_prepare derives when the caller does not hand over the aggregates.
+
+calculateJobSchedulingInfo (scheduling_algo.go:591-698) sums, per queue and priority class, the requests of every non-terminal job of
+the pool (queued jobs of a cordoned queue excepted) and the requests of its running jobs; constructSchedulingContext (:783-867) caps the
+demand of each class by the queue's per-class limit (constraints.CapResources, constraints.go:187-197) and sums over classes.  Here the
+same aggregates are computed independently with numpy and handed over explicitly; a second run lets the library derive them
+(demand = NULL, allocated_by_pc = NULL).  Both runs must produce the same round, fair shares included, bit for bit.
+"""
+import copy
+import math
+
+import numpy as np
+import pytest
+
+import scenario
+from golden_io import load
+
+CFG = load("nodedb_conditional_away")[0]["SchedulingConfig"]
+GI = 2**30
+R = scenario.R
+
+
+def build(seed):
+    rng = np.random.default_rng(100 + seed)
+    cfg = copy.deepcopy(CFG)
+    cfg["protected_fraction_of_fair_share"] = 0.5
+    nodes = [{"index": i + 1, "total": {"cpu": 32000, "memory": 256 * GI}, "taints": [], "labels": {}, "used": {}, "unschedulable": False} for i in range(10)]
+    queues = ["qa", "qb", "qc", "qd"]
+    pcs = ["priority-0", "priority-1", "priority-2-non-preemptible"]
+    jobs, running = [], {}
+    free = [32000] * 10
+    for i in range(260):
+        q = int(rng.integers(0, 4))
+        cpu = int(rng.integers(1, 5)) * 1000
+        j = {"created": i + 1, "queue": queues[q], "pc": "priority-0" if q == 0 else str(rng.choice(pcs)), "priority": 1000, "gang": None, "tolerations": [], "selector": {},
+             "affinity": None, "req": {"cpu": cpu, "memory": int(rng.integers(1, 9)) * GI}}
+        if i < 90:
+            n = int(rng.integers(0, 10))
+            if free[n] >= cpu:
+                free[n] -= cpu
+                running[len(jobs)] = (n, cfg["priority_classes"][j["pc"]]["priority"], i + 1)
+        jobs.append(j)
+    cordoned = [0, 0, 1, 0]
+    frac = np.full((4, len(cfg["priority_classes"]), R), math.inf)   # per-queue per-class MaximumResourceFraction
+    pc_names = sorted(cfg["priority_classes"])
+    frac[0, pc_names.index("priority-0"), :] = 0.02                              # these bite: qa may only ever hold 2 % of the pool
+    frac[1, pc_names.index("priority-1"), scenario.RES.index("memory")] = 0.02
+    frac[3, :, scenario.RES.index("cpu")] = 0.5
+    return cfg, nodes, queues, jobs, running, cordoned, frac, pc_names
+
+
+def expected_aggregates(cfg, nodes, queues, jobs, running, cordoned, frac, pc_names):
+    total = np.array([sum(scenario.vec(n["total"])[r] for n in nodes) for r in range(R)], dtype=np.int64)
+    npc = len(pc_names)
+    by_pc = np.zeros((len(queues), npc, R), dtype=np.int64)
+    alloc = np.zeros((len(queues), npc, R), dtype=np.int64)
+    for i, j in enumerate(jobs):
+        q, p = queues.index(j["queue"]), pc_names.index(j["pc"])
+        v = np.array(scenario.vec(j["req"]), dtype=np.int64)
+        if i in running:
+            alloc[q, p] += v
+            by_pc[q, p] += v
+        elif not cordoned[q]:
+            by_pc[q, p] += v
+    limit = np.zeros_like(by_pc)
+    for q in range(len(queues)):
+        for p in range(npc):
+            for r in range(R):
+                m = frac[q, p, r]
+                limit[q, p, r] = 2**63 - 1 if math.isinf(m) else (total[r] if m == 1.0 else int(float(total[r]) * m))   # multiplyResource
+    demand = np.minimum(by_pc, limit).sum(axis=1)
+    return demand, alloc
+
+
+def run(lib, seed, explicit):
+    cfg, nodes, queues, jobs, running, cordoned, frac, pc_names = build(seed)
+    c = scenario.Case(lib, cfg, nodes)
+    assert c.pc_names == pc_names
+    qidx = {q: i for i, q in enumerate(queues)}
+    c.set_jobs(jobs, qidx, running)
+    queued = [c.sort_queued(jobs, [i for i, j in enumerate(jobs) if i not in running and j["queue"] == q]) for q in queues]
+    kw = {}
+    if explicit:
+        demand, alloc = expected_aggregates(cfg, nodes, queues, jobs, running, cordoned, frac, pc_names)
+        kw = dict(demand=demand, allocated_by_pc=alloc)
+    c.sched.round_prepare([1.0, 0.5, 1.0, 2.0], queued, name_rank=list(range(4)), cordoned=cordoned, pc_resource_limit_fraction=frac, **kw)
+    return c.sched.schedule_round()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_derived_equals_explicit_oracle(oracle_lib, seed):
+    a, b = run(oracle_lib, seed, True), run(oracle_lib, seed, False)
+    scenario.assert_same_round(a, b)
+    assert len(a.scheduled) > 10
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_derived_equals_explicit_hostsim(hostsim_lib, oracle_lib, seed):
+    a, b = run(oracle_lib, seed, True), run(hostsim_lib, seed, False)
+    scenario.assert_same_round(a, b)
+
+
+def test_the_cap_and_the_cordon_rule_matter(oracle_lib):
+    """negative control: the aggregates without the per-class cap, or counting a cordoned queue's queued jobs, are different numbers and
+    give different demand-capped fair shares (so the equality above is not vacuous)"""
+    cfg, nodes, queues, jobs, running, cordoned, frac, pc_names = build(0)
+    demand, _ = expected_aggregates(cfg, nodes, queues, jobs, running, cordoned, frac, pc_names)
+    uncapped, _ = expected_aggregates(cfg, nodes, queues, jobs, running, cordoned, np.full_like(frac, math.inf), pc_names)
+    uncordoned, _ = expected_aggregates(cfg, nodes, queues, jobs, running, [0, 0, 0, 0], frac, pc_names)
+    assert (uncapped != demand).any() and (uncordoned != demand).any()
+    good = run(oracle_lib, 0, False)
+
+    def with_demand(dm):
+        c = scenario.Case(oracle_lib, cfg, nodes)
+        c.set_jobs(jobs, {q: i for i, q in enumerate(queues)}, running)
+        queued = [c.sort_queued(jobs, [i for i, j in enumerate(jobs) if i not in running and j["queue"] == q]) for q in queues]
+        c.sched.round_prepare([1.0, 0.5, 1.0, 2.0], queued, name_rank=list(range(4)), cordoned=cordoned, pc_resource_limit_fraction=frac, demand=dm)
+        return c.sched.schedule_round()
+    assert (with_demand(uncapped).demand_capped_adjusted_fair_share != good.demand_capped_adjusted_fair_share).any()
+    assert (with_demand(uncordoned).demand_capped_adjusted_fair_share != good.demand_capped_adjusted_fair_share).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(4))
+def test_derived_equals_explicit_gpu(hip_lib, oracle_lib, seed):
+    a, b = run(oracle_lib, seed, True), run(hip_lib, seed, False)
+    scenario.assert_same_round(a, b)
