@@ -130,6 +130,11 @@ class CPodResult(C.Structure):
     _fields_ = [("node", C.c_int32), ("scheduled_at_priority", C.c_int32), ("preempted_at_priority", C.c_int32), ("method", C.c_int32)]
 
 
+class CPqItem(C.Structure):
+    _fields_ = [("proposed_cost", C.c_double), ("current_cost", C.c_double), ("budget", C.c_double), ("item_size", C.c_double),
+                ("pc_priority", C.c_int32), ("scheduling_priority", C.c_int32), ("name_rank", C.c_int32), ("pad_", C.c_int32)]
+
+
 class CSubmitResult(C.Structure):
     _fields_ = [("ok", C.c_int32), ("scheduled_away", C.c_int32), ("num_schedulable", C.c_int32), ("first_node", C.c_int32)]
 
@@ -155,7 +160,7 @@ ALL_SYMBOLS = [
     "txn_abort", "select_node", "schedule_many", "bind", "evict", "unbind", "add_evicted", "reset_evicted",
     "get_alloc", "get_scheduled_at_priority", "iterate_nodes", "fit_select_batch", "drf_cost", "fair_shares",
     "round_prepare", "schedule_round", "schedule_queues", "gang_schedule", "round_counters", "job_key_unfeasible", "kernel_times", "round_stats",
-    "clear_allocated", "submit_check",
+    "clear_allocated", "submit_check", "pq_order",
 ]
 
 
@@ -234,6 +239,7 @@ class Library:
         f("priorities", C.c_int32, [C.c_void_p, _i32p])
         f("nodes_upsert", C.c_int32, [C.c_void_p, C.POINTER(CNodes)])
         f("jobs_set", C.c_int32, [C.c_void_p, C.POINTER(CJobs), C.POINTER(CReqClasses)])
+        f("pq_order", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(CPqItem), C.c_int32, C.c_int32, _i32p, _i32p])
         f("submit_check", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i32p, _i32p, C.POINTER(CSubmitResult)])
         for n in ("txn_begin", "txn_commit", "txn_abort", "reset_evicted", "clear_allocated"):
             f(n, C.c_int32, [C.c_void_p])
@@ -505,6 +511,21 @@ class Scheduler:
 
     def clear_allocated(self): self._check(self.lib.clear_allocated(self.h))
 
+    def pq_order(self, items: Sequence[dict], prioritise_larger_jobs: bool, compare_scheduling_priority: bool):
+        """sort.Sort over QueueCandidateGangIteratorPQ.Less; items: dicts with proposed_cost, current_cost, budget, item_size, pc_priority,
+        scheduling_priority, name_rank -> (order, packed_key_agrees)"""
+        n = len(items)
+        arr = (CPqItem * max(n, 1))()
+        for i, it in enumerate(items):
+            for k in ("proposed_cost", "current_cost", "budget", "item_size"):
+                setattr(arr[i], k, float(it.get(k, 0.0)))
+            for k in ("pc_priority", "scheduling_priority", "name_rank"):
+                setattr(arr[i], k, int(it.get(k, 0)))
+        order = (C.c_int32 * max(n, 1))()
+        agrees = C.c_int32(0)
+        self._check(self.lib.pq_order(self.h, n, arr, int(prioritise_larger_jobs), int(compare_scheduling_priority), order, C.byref(agrees)))
+        return [order[i] for i in range(n)], bool(agrees.value)
+
     def submit_check(self, units: Sequence[Sequence[int]], strip_gang: Optional[Sequence[bool]] = None):
         """One batch of submit-check units (submitcheck.go:342-371); returns [(ok, scheduled_away, num_schedulable, first_node)]."""
         nu = len(units)
@@ -649,7 +670,7 @@ class Scheduler:
         """device-side durations (HIP events on the launch stream) of the kernels behind the last round / fit batch"""
         out = (C.c_double * 4)()
         self._check(self.lib.kernel_times(self.h, out))
-        return dict(round_ms=out[0], fit_batch_ms=out[1], round_launches=int(out[2]))
+        return dict(round_ms=out[0], fit_batch_ms=out[1], round_launches=int(out[2]), submit_check_ms=out[3])
 
     def round_stats(self):
         out = (C.c_int32 * 16)()

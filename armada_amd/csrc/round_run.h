@@ -417,6 +417,7 @@ enum Cmd {
   CMD_PREPARE = 1, CMD_ROUND, CMD_QUEUES_ONLY, CMD_GANG_SCHEDULE, CMD_SELECT, CMD_SCHEDULE_MANY, CMD_BIND, CMD_EVICT, CMD_UNBIND,
   CMD_ADD_EVICTED, CMD_RESET_EVICTED, CMD_TXN_BEGIN, CMD_TXN_COMMIT, CMD_TXN_ABORT, CMD_FIT_BATCH, CMD_UPSERT_RESET, CMD_RESET_JOBS,
   CMD_SUBMIT_CHECK,  // first command of the auxiliary kernel (k_control_aux, armada_sched_aux.hip)
+  CMD_PQ_ORDER,
 };
 #define CMD_AUX_FIRST CMD_SUBMIT_CHECK
 // cmdIO layout: [0..15] results, [16..] arguments
@@ -554,9 +555,33 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
 // Commands of the submit check.  They run in their own kernel, in their own code object (k_control_aux,
 // armada_sched_aux.hip), so that the round kernel's code — everything above is inlined into it — stays exactly what was measured.
 struct SubmitArgs { int32_t nu, pad; int32_t* off; int32_t* jobs; int32_t* flags; int32_t* out; };  // at cmdIO + 16, written by the host
+struct PqOrderArgs { int32_t n, preferLarge, compareSchedPrio, pad; int32_t* out; };  // at cmdIO + 16; out = [n] order, then 1 flag
 DEV void runAuxCommand(Dev& d, Ctl& c, int cmd) {
   const DevCfg& cf = d.cfg;
   switch (cmd) {
+    case CMD_PQ_ORDER: {
+      // sort.Sort over QueueCandidateGangIteratorPQ.Less (queue_scheduler.go:738-798) — the float goldens of queue_scheduler_test.go:995-1164.
+      // The items sit in the per-queue arrays the round uses (the host points d.pq* / d.qNameRank at a scratch copy for this launch),
+      // so this is the round's own pqLess; the packed key of the fast path (packKey3 / packedLess) is checked pair by pair against it.
+      PqOrderArgs a = *(const PqOrderArgs*)(d.cmdIO + 16);
+      c.preferLarge = a.preferLarge; c.compareSchedPrio = a.compareSchedPrio;
+      int ord[64];
+      for (int i = 0; i < a.n; i++) ord[i] = i;
+      for (int i = 1; i < a.n; i++) {   // insertion sort: Less is a strict total order, the result is the unique sorted order
+        int x = ord[i], k = i - 1;
+        while (k >= 0 && pqLess(d, c, x, ord[k])) { ord[k + 1] = ord[k]; k--; }
+        ord[k + 1] = x;
+      }
+      for (int i = 0; i < a.n; i++) a.out[i] = ord[i];
+      int agrees = 1;
+      for (int x = 0; x < a.n; x++) for (int y = 0; y < a.n; y++) {
+        if (x == y) continue;
+        PackedKey kx = packKey3(a.preferLarge, a.compareSchedPrio ? d.pqSchedPrio[x] : d.pqPcPrio[x], d.pqProposed[x], d.pqCurrent[x], d.pqSize[x], d.pqBudget[x]);
+        PackedKey ky = packKey3(a.preferLarge, a.compareSchedPrio ? d.pqSchedPrio[y] : d.pqPcPrio[y], d.pqProposed[y], d.pqCurrent[y], d.pqSize[y], d.pqBudget[y]);
+        if (packedLess(kx, (uint32_t)d.qNameRank[x], ky, (uint32_t)d.qNameRank[y]) != pqLess(d, c, x, y)) agrees = 0;
+      }
+      a.out[a.n] = agrees;
+    } break;
     case CMD_SUBMIT_CHECK: {
       // SubmitChecker.getSchedulingResult, per-pool core (submitcheck.go:342-371), for a whole batch of units in one launch:
       // copyGangContext (fresh jctxs), nodeDb.Txn, ScheduleManyWithTxn, txn.Abort — every unit meets the same NodeDb state

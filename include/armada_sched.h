@@ -342,6 +342,17 @@ double ASCHED_FN(drf_cost)(asched_t*, const int64_t* alloc /*[R]*/, const int64_
 int32_t ASCHED_FN(fair_shares)(asched_t*, int32_t q, const int32_t* name_rank, const double* weight, const double* cds,
                                double* fair_share, double* demand_capped, double* uncapped);
 
+/* QueueCandidateGangIteratorPQ ordering (queue_scheduler.go:738-798): out_order = the item indices as sort.Sort leaves them
+   (queue_scheduler_test.go:995-1164 drive Less exactly this way).  n <= 64.  Cross-pool "away" items do not exist within one pool.
+   packed_agrees (may be NULL): 1 when, for every pair of items, the lexicographic key the fast path orders queues by (DESIGN 3.1
+   item 4) gives the same verdict as Less; the CPU oracle reports 1. */
+typedef struct asched_pq_item {
+  double proposed_cost, current_cost, budget, item_size;   /* proposedQueueCost, currentQueueCost, queueBudget, itemSize */
+  int32_t pc_priority, scheduling_priority, name_rank, pad_; /* priorityClassPriority, schedulingPriority, rank of the queue name */
+} asched_pq_item;
+int32_t ASCHED_FN(pq_order)(asched_t*, int32_t n, const asched_pq_item* items, int32_t prioritise_larger_jobs, int32_t compare_scheduling_priority,
+                            int32_t* out_order /*[n]*/, int32_t* packed_agrees);
+
 /* ------------------------------------------------------------------ round level */
 /* Builds round state: ConstructNodeDb/populateNodeDb (bind every running job, scheduling_algo.go:738-781,
    1019-1098) + constructSchedulingContext + UpdateFairShares (:783-867).  Untimed "input build". */
@@ -359,7 +370,7 @@ int32_t ASCHED_FN(gang_schedule)(asched_t*, int32_t n, const int32_t* jobs, int3
 int32_t ASCHED_FN(round_counters)(asched_t*, int32_t* out /*[4]*/);
 /* Measurement hook (no reference counterpart): device time of the kernels behind the last call, taken with HIP events
    on the stream the kernels were launched on.  out[0] = ms of the last schedule_round/schedule_queues device work,
-   out[1] = ms of the last fit_select_batch kernel, out[2] = kernel launches behind out[0], out[3] = reserved.
+   out[1] = ms of the last fit_select_batch kernel, out[2] = kernel launches behind out[0], out[3] = ms of the last submit_check launch.
    The CPU oracle reports zeros. */
 int32_t ASCHED_FN(kernel_times)(asched_t*, double* out /*[4]*/);
 /* Measurement hook (no reference counterpart): how the last round ran on the device.  out = {fast iterations, generic

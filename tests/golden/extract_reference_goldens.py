@@ -131,6 +131,64 @@ def extract_submitcheck(base_env, skipped):
     return out
 
 
+def extract_pq_ordering(skipped):
+    """queue_scheduler_test.go:995-1164: six stand-alone tests that sort.Sort a QueueCandidateGangIteratorPQ and compare the item order.
+    They are functions, not tables: each `x := &QueueCandidateGangIteratorItem{...}`, the `pq := &QueueCandidateGangIteratorPQ{...}`
+    literal and the `expectedOrder` slice are evaluated mechanically from the function body.  (TestQueueCandidateGangIteratorPQ_HomeBeforeAway
+    :698-716 needs cross-pool "away" items, which one pool never has: listed in SKIPPED.txt.)"""
+    path = f"{REF}/scheduling/queue_scheduler_test.go"
+    src = open(path).read()
+    rel = os.path.relpath(path, "/root/reference")
+    out = []
+
+    def body_of(fn):
+        pos = src.index(f"func {fn}(")
+        o = src.index("{", pos)
+        return o, find_matching(src, o)
+
+    def ev_at(pos, env):  # evaluate the expression starting at src[pos]
+        line = src.count("\n", 0, pos) + 1
+        close = find_matching(src, src.index("{", pos))
+        p = Parser(tokenize(src[pos:close + 1], line))
+        return Evaluator(env).ev(p.parse_expr()), line
+
+    def items_of(o, c):
+        env = {}
+        for m in re.finditer(r"(\w+)\s*:=\s*(&QueueCandidateGangIteratorItem\{)", src[o:c]):
+            v, _ = ev_at(o + m.start(2), {})
+            v = dict(v); v["_var"] = m.group(1)
+            env[m.group(1)] = v
+        return env
+
+    def emit(name, line, pq, expected, env):
+        item = lambda v: {"queue": v.get("queue", ""), "proposedQueueCost": float(v.get("proposedQueueCost", 0)), "currentQueueCost": float(v.get("currentQueueCost", 0)),
+                          "queueBudget": float(v.get("queueBudget", 0)), "itemSize": float(v.get("itemSize", 0)),
+                          "priorityClassPriority": int(v.get("priorityClassPriority", 0)), "schedulingPriority": int(v.get("schedulingPriority", 0)), "var": v["_var"]}
+        out.append({"name": name, "source": f"{rel}:{line}", "prioritiseLargerJobs": bool(pq.get("prioritiseLargerJobs", False)),
+                    "compareSchedulingPriority": bool(pq.get("compareSchedulingPriority", False)),
+                    "items": [item(v) for v in pq["items"]], "expectedOrder": [v["_var"] for v in expected]})
+
+    for fn in ("TestQueueCandidateGangIteratorPQ_Ordering_BelowFairShare_EvenCurrentCost", "TestQueueCandidateGangIteratorPQ_Ordering_BelowFairShare_UnevenCurrentCost",
+               "TestQueueCandidateGangIteratorPQ_Ordering_AboveFairShare", "TestQueueCandidateGangIteratorPQ_Ordering_MixedFairShare",
+               "TestQueueCandidateGangIteratorPQ_Fallback"):
+        o, c = body_of(fn)
+        env = items_of(o, c)
+        m = re.search(r"pq\s*:=\s*(&QueueCandidateGangIteratorPQ\{)", src[o:c])
+        pq, line = ev_at(o + m.start(1), env)
+        m = re.search(r"expectedOrder\s*:=\s*(\[\]\*QueueCandidateGangIteratorItem\{)", src[o:c])
+        exp, _ = ev_at(o + m.start(1), env)
+        emit(fn, src.count("\n", 0, o) + 1, pq, exp, env)
+    fn = "TestQueueCandidateGangIteratorPQ_Ordering_SchedulingPriority"   # a table over two shared items; the pq literal sits in the loop body (:1150-1154)
+    o, c = body_of(fn)
+    env = items_of(o, c)
+    for r in extract_table(path, fn, env, skipped):
+        emit(f"{fn}/{r['name']}", int(r["source"].rsplit(":", 1)[1]),
+             {"prioritiseLargerJobs": True, "compareSchedulingPriority": bool(r["shouldCompareSchedulingPriority"]), "items": [env["queueA"], env["queueB"]]},
+             r["expectedOrder"], env)
+    skipped.append(f"{rel}:698 TestQueueCandidateGangIteratorPQ_HomeBeforeAway: cross-pool away items (preemptCrossPoolJobsFirst) do not exist within one pool")
+    return out
+
+
 def main():
     env = gofixtures.make_env()
     skipped = []
@@ -196,6 +254,7 @@ def main():
     out["nodedb_away_node_scheduling"] = away
 
     out["submitcheck"] = extract_submitcheck(env, skipped)
+    out["pq_ordering"] = extract_pq_ordering(skipped)
 
     # queue_scheduler_test.go:804-946 TestQueueScheduler_PreemptionRateLimit: one node, existing jobs of queues A / B (all evicted and
     # registered as fair-share preemption candidates by the test body), new jobs of queue B, sctx.FairsharePreemptionLimiter
