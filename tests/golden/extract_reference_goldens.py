@@ -264,6 +264,18 @@ def main():
     out["preemption_rate_limit"] = [dict(to_json(r), SchedulingConfig=to_json(gofixtures.TestSchedulingConfig()))
                                     for r in extract_table(f"{REF}/scheduling/queue_scheduler_test.go", "TestQueueScheduler_PreemptionRateLimit", renv, skipped)]
 
+    # constraints/constraints_test.go:452-575 TestCheckJobConstraints_RateLimit: token-bucket states (tokens at sctx.Started, burst) and
+    # a gang cardinality -> the unschedulable reason of CheckJobConstraints
+    kenv = dict(env)
+    for nm, txt in (("GlobalRateLimitExceededUnschedulableReason", "global scheduling rate limit exceeded"),
+                    ("QueueRateLimitExceededUnschedulableReason", "queue scheduling rate limit exceeded"),
+                    ("GlobalRateLimitExceededByGangUnschedulableReason", "gang would exceed global scheduling rate limit"),
+                    ("QueueRateLimitExceededByGangUnschedulableReason", "gang would exceed queue scheduling rate limit"),
+                    ("GangExceedsGlobalBurstSizeUnschedulableReason", "gang cardinality too large: exceeds global max burst size"),
+                    ("GangExceedsQueueBurstSizeUnschedulableReason", "gang cardinality too large: exceeds queue max burst size")):
+        kenv[nm] = txt   # constraints.go:34-49
+    out["constraints_rate_limit"] = extract_table(f"{REF}/scheduling/constraints/constraints_test.go", "TestCheckJobConstraints_RateLimit", kenv, skipped)
+
     # nodedb_test.go:1236-1291 TestConditionalAwayNodeScheduling: one node, one job of armada-preemptible-away-conditional, through
     # SelectNodeForJobWithTxn; the job built before the table (:1237-1241) is restated with the same fixtures
     cenv = dict(env)
