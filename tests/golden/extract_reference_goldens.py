@@ -276,6 +276,29 @@ def main():
         kenv[nm] = txt   # constraints.go:34-49
     out["constraints_rate_limit"] = extract_table(f"{REF}/scheduling/constraints/constraints_test.go", "TestCheckJobConstraints_RateLimit", kenv, skipped)
 
+    # nodedb/nodematching_test.go:19-410 TestNodeSchedulingRequirementsMet: JobRequirementsMet(node, priority, jctx) = static requirements
+    # (taints / tolerations, node selector, required node affinity, total resources) + resources at one priority, on hand-built nodes
+    # (makeTestNodeTaintsLabels :713-737, makeTestNodeResources :739-763)
+    jenv = dict(env)
+    jenv["makeTestNodeTaintsLabels"] = lambda taints, labels: {"taints": [[x["Key"], x.get("Value", ""), x.get("Effect", "")] for x in (taints or [])],
+                                                                 "labels": dict(labels or {}), "total": {}, "alloc_by_priority": None}
+    jenv["makeTestNodeResources"] = lambda t, abp, total: {"taints": [], "labels": {}, "total": total, "alloc_by_priority": {str(k): v for k, v in abp.items()}}
+    jenv["t"] = None
+    jenv["rlFactory.FromJobResourceListIgnoreUnknown"] = lambda m: gofixtures.rl(m)
+    met = []
+    for r in extract_table(f"{REF}/nodedb/nodematching_test.go", "TestNodeSchedulingRequirementsMet", jenv, skipped):
+        req = r.get("req") or {}
+        job = gofixtures.TestJob("A", None, gofixtures.PriorityClass0, gofixtures._podreqs((req.get("ResourceRequirements") or {}).get("Requests") or {}))
+        job["tolerations"] = [gofixtures._norm_toleration(x) for x in req.get("Tolerations") or []]
+        job["selector"] = dict(req.get("NodeSelector") or {})
+        sel = ((req.get("Affinity") or {}).get("NodeAffinity") or {}).get("RequiredDuringSchedulingIgnoredDuringExecution")
+        if sel is not None:
+            job = gofixtures.WithNodeAffinityJobs(sel.get("NodeSelectorTerms") or [], [job])[0]
+            job["affinity"] = job.get("affinity") or []
+        met.append({"name": r["name"], "source": r["source"], "node": to_json(r["node"]), "job": to_json(job), "priority": int(r.get("priority") or 0),
+                    "expectSuccess": bool(r["expectSuccess"]), "SchedulingConfig": to_json(gofixtures.TestSchedulingConfig())})
+    out["node_requirements_met"] = met
+
     # nodedb_test.go:1236-1291 TestConditionalAwayNodeScheduling: one node, one job of armada-preemptible-away-conditional, through
     # SelectNodeForJobWithTxn; the job built before the table (:1237-1241) is restated with the same fixtures
     cenv = dict(env)

@@ -169,6 +169,13 @@ class Parser:
                 self.expect(")")
                 return ("conv", ty, e)
             raise Unsupported(f"line {ln}: type without literal")
+        if k == "ident" and t == "make" and self.peek(1)[1] == "(":   # make([]T, n) / make(map[K]V): an empty container
+            self.next(); self.next()
+            ty = self.parse_type()
+            while self.peek()[1] != ")":
+                self.next()
+            self.expect(")")
+            return ("comp", ty, [])
         if k == "ident":
             self.next()
             if t in ("true", "false"):
@@ -477,6 +484,8 @@ class Evaluator:
             for k, v in elems:
                 out[self.ev(k, ty[1])] = self.ev(v, ty[2])
             return out
+        if ty[0] == "named" and ty[1] in self.MAP_TYPES:   # a named map type written as a keyed literal (v1.ResourceList{"cpu": ...})
+            return {self.ev(k): self.ev(v) for k, v in elems}
         if ty[0] == "named":
             fields = {}
             for k, v in elems:
@@ -492,6 +501,7 @@ class Evaluator:
 
     # elided-type hints for struct fields we care about
     FIELD_TYPES = {}
+    MAP_TYPES = {"v1.ResourceList"}
 
     def ev_field(self, struct_name, field, v):
         hint = self.FIELD_TYPES.get((struct_name.split(".")[-1], field))
