@@ -125,3 +125,17 @@ def test_the_cap_and_the_cordon_rule_matter(oracle_lib):
 def test_derived_equals_explicit_gpu(hip_lib, oracle_lib, seed):
     a, b = run(oracle_lib, seed, True), run(hip_lib, seed, False)
     scenario.assert_same_round(a, b)
+
+
+def test_threaded_input_build_round_equals_oracle(hostsim_lib, oracle_lib):
+    """137k jobs: above the sizes at which jobs_set sorts the queues' buckets and fills the JobRec table on several host threads
+    (asched_host.inc parallelChunks / the scheduling-order sort); the round must still be the oracle's, job for job"""
+    from armada_amd import workloads as W
+    wl = W.config3(n_nodes=3000, n_jobs=120000, n_queues=24)
+    res = []
+    for lib in (oracle_lib, hostsim_lib):
+        s = W.load(lib, wl)
+        W.prepare(s, wl)
+        res.append(s.schedule_round())
+    scenario.assert_same_round(res[0], res[1])
+    assert len(res[0].scheduled) > 10000 and len(res[0].preempted) > 1000
