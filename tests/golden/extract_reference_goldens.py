@@ -299,6 +299,13 @@ def main():
                     "expectSuccess": bool(r["expectSuccess"]), "SchedulingConfig": to_json(gofixtures.TestSchedulingConfig())})
     out["node_requirements_met"] = met
 
+    # preempting_queue_scheduler_test.go:3196-3397 TestPreemptingQueueScheduler_RespectNodePodLimits: the table holds the parameters; the
+    # test body (one 10-cpu node with a pod capacity, incumbents running on it, priority-3 challengers queued, a whole round) is restated
+    # by tests/test_z_pqs_scenarios.py
+    out["pqs_pod_limits"] = extract_table(f"{REF}/scheduling/preempting_queue_scheduler_test.go", "TestPreemptingQueueScheduler_RespectNodePodLimits", env, skipped)
+    for c in out["pqs_pod_limits"]:
+        c["SchedulingConfig"] = to_json(gofixtures.TestSchedulingConfig())
+
     # nodedb_test.go:1236-1291 TestConditionalAwayNodeScheduling: one node, one job of armada-preemptible-away-conditional, through
     # SelectNodeForJobWithTxn; the job built before the table (:1237-1241) is restated with the same fixtures
     cenv = dict(env)
