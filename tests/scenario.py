@@ -493,13 +493,15 @@ def run_node_iteration_case(lib: Library, case: dict) -> List[int]:
 
 def run_fairness_case(lib: Library, case: dict):
     cfg = case["config"]
-    if cfg.get("Pools"):
-        return None
     names = ["foo", "bar", "baz"]
     mult = {n: 0.0 for n in names}
+    experimental = cfg.get("ExperimentalDominantResourceFairnessResourcesToConsider") or []
+    for pool in cfg.get("Pools") or []:   # NewDominantResourceFairness (fairness.go:50-56): the pool's own list replaces the experimental one
+        if pool.get("Name") == "pool" and pool.get("DominantResourceFairnessResourcesToConsider"):
+            experimental = pool["DominantResourceFairnessResourcesToConsider"]
     for n in cfg.get("DominantResourceFairnessResourcesToConsider") or []:
         mult[n] = 1.0
-    for r in cfg.get("ExperimentalDominantResourceFairnessResourcesToConsider") or []:
+    for r in experimental:
         m = r.get("Multiplier", 0)
         mult[r["Name"]] = float(m) if m > 0 else 1.0  # defaultMultiplier fairness.go:91-97
     s = Scheduler(lib, Config(num_resources=3, indexed_col=[0], indexed_resolution=[1], pc_priority=[0], pc_preemptible=[1],
