@@ -297,9 +297,14 @@ def WithNodeSelectorJobs(selector, jobs):
     return jobs
 
 
-def WithRequestsJobs(rlist, jobs):
+def WithRequestsJobs(rlist, jobs):  # testfixtures.go:496-511; the job's vector comes from FromJobResourceListIgnoreUnknown: unknown names are dropped
+    if isinstance(rlist, dict) and "Resources" in rlist:   # schedulerobjects.ResourceList{Resources: ...}
+        rlist = rlist["Resources"]
+    if "test-floating-resource" in rlist:
+        raise Unsupported("floating resources are not modelled")
+    known = {k: v for k, v in rlist.items() if k in SCALE}
     for j in jobs:
-        j["req"].update(rl(rlist, round_up=True))
+        j["req"].update(rl(known, round_up=True))
     return jobs
 
 
@@ -420,6 +425,7 @@ def make_env():
     env["armadaslices.Concatenate"] = Concatenate
     env["util.ULID"] = ULID
     env["resource.MustParse"] = MustParse
+    env["pointer.MustParseResource"] = MustParse
     for op in ("In", "NotIn", "Exists", "DoesNotExist", "Gt", "Lt"):
         env["v1.NodeSelectorOp" + op] = op
     env["v1.TaintEffectNoSchedule"] = "NoSchedule"
