@@ -101,3 +101,35 @@ def test_non_preemptible_over_pack_hostsim(hostsim_lib, oracle_lib):
 @pytest.mark.gpu
 def test_non_preemptible_over_pack_gpu(hip_lib, oracle_lib):
     scenario.assert_same_round(run_overpack(oracle_lib), run_overpack(hip_lib))
+
+
+def _releases_pod_slot(lib):
+    """nodedb_test.go:315-387 TestNodeBindingEvictionUnbinding_ReleasesPodSlot: bind consumes the node's only pod slot, evict + unbind
+    frees it, a second job can then bind (the pods column is an ordinary resource column of the NodeDb arithmetic)."""
+    cfg = copy.deepcopy(POD[0]["SchedulingConfig"])
+    cfg["indexed_resources"] = cfg["indexed_resources"] + [[PODS, 1]]
+    node = {"index": 1, "total": {"cpu": 10000, "memory": 64 * GI, PODS: 1}, "taints": [], "labels": {}, "used": {}, "unschedulable": False}
+    mk = lambda i: {"created": i, "queue": "queue", "pc": "priority-0", "priority": 1, "gang": None, "tolerations": [], "selector": {}, "affinity": None,  # noqa: E731
+                    "req": {"cpu": 1000, "memory": GI, PODS: 1}}
+    c = scenario.Case(lib, cfg, [node])
+    c.set_jobs([mk(1), mk(2)], {"queue": 0}, {})
+    s = c.sched
+    prio = cfg["priority_classes"]["priority-0"]["priority"]
+    lv, col = list(s.priorities).index(prio), scenario.RES.index(PODS)
+    s.bind(0, 0, prio)
+    assert s.get_alloc(0)[lv, col] == 0, "bind should consume the pod slot"                 # :365-366
+    s.evict(0, 0)
+    s.unbind(0, 0)
+    assert s.get_alloc(0)[lv, col] == 1, "evict+unbind should free the pod slot"            # :372-373
+    s.bind(1, 0, prio)                                                                      # :376-377 second job binds after the slot is freed
+    assert s.get_alloc(0)[lv, col] == 0
+    return s.get_alloc(0).tolist()
+
+
+def test_releases_pod_slot(oracle_lib, hostsim_lib):
+    assert _releases_pod_slot(oracle_lib) == _releases_pod_slot(hostsim_lib)
+
+
+@pytest.mark.gpu
+def test_releases_pod_slot_gpu(oracle_lib, hip_lib):
+    assert _releases_pod_slot(oracle_lib) == _releases_pod_slot(hip_lib)
