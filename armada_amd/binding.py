@@ -160,7 +160,7 @@ ALL_SYMBOLS = [
     "txn_abort", "select_node", "schedule_many", "bind", "evict", "unbind", "add_evicted", "reset_evicted",
     "get_alloc", "get_scheduled_at_priority", "iterate_nodes", "fit_select_batch", "drf_cost", "fair_shares",
     "round_prepare", "schedule_round", "schedule_queues", "gang_schedule", "round_counters", "job_key_unfeasible", "kernel_times", "round_stats",
-    "clear_allocated", "submit_check", "pq_order",
+    "clear_allocated", "submit_check", "pq_order", "submit_stats",
 ]
 
 
@@ -240,6 +240,7 @@ class Library:
         f("nodes_upsert", C.c_int32, [C.c_void_p, C.POINTER(CNodes)])
         f("jobs_set", C.c_int32, [C.c_void_p, C.POINTER(CJobs), C.POINTER(CReqClasses)])
         f("pq_order", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(CPqItem), C.c_int32, C.c_int32, _i32p, _i32p])
+        f("submit_stats", C.c_int32, [C.c_void_p, _i32p])
         f("submit_check", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i32p, _i32p, C.POINTER(CSubmitResult)])
         for n in ("txn_begin", "txn_commit", "txn_abort", "reset_evicted", "clear_allocated"):
             f(n, C.c_int32, [C.c_void_p])
@@ -538,6 +539,11 @@ class Scheduler:
         out = (CSubmitResult * nu)()
         self._check(self.lib.submit_check(self.h, nu, _ptr(off, C.c_int32), _ptr(jobs, C.c_int32), _ptr(flags, C.c_int32), out))
         return [(bool(o.ok), bool(o.scheduled_away), int(o.num_schedulable), int(o.first_node)) for o in out]
+
+    def submit_stats(self):
+        out = (C.c_int32 * 4)()
+        self._check(self.lib.submit_stats(self.h, out))
+        return dict(wide_units=out[0], wide_passes=out[1], sequential_units=out[2])
 
     def select_node(self, job: int, pinned_node: int = -1):
         out = CPodResult()

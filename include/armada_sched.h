@@ -327,6 +327,9 @@ int32_t ASCHED_FN(clear_allocated)(asched_t*);
    One device launch serves the whole batch. */
 int32_t ASCHED_FN(submit_check)(asched_t*, int32_t n_units, const int32_t* unit_off /*[n_units+1]*/, const int32_t* unit_jobs,
                                 const int32_t* unit_flags /*[n_units] or NULL*/, asched_submit_result* out /*[n_units]*/);
+/* Measurement hook (no reference counterpart): how the last submit_check ran.  out = {units answered by the wide fit kernel (individual
+   checks on a pristine NodeDb), fit-kernel passes, units through the sequential control launch (gangs, or a NodeDb holding jobs), 0}. */
+int32_t ASCHED_FN(submit_stats)(asched_t*, int32_t* out /*[4]*/);
 /* NodeTypesIterator order (nodeiteration.go:74-149) for req at a priority over node types `types`
    (ntypes<0: all types).  Test hook for the golden orderings of nodeiteration_test.go. */
 int32_t ASCHED_FN(iterate_nodes)(asched_t*, const int64_t* type_ids, int32_t ntypes, int32_t priority,

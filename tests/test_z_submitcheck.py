@@ -206,3 +206,75 @@ def test_submit_check_argument_errors(hostsim_lib, oracle_lib):
             db.case.sched.submit_check([[5]], [False])      # job index out of range
         with pytest.raises(SchedError):
             db.case.sched.submit_check([[]], [False])       # empty unit
+
+
+# ------------------------------------------------------------------------------------------------ wide path (fit kernel) vs sequential path
+def _wide_equals_sequential(lib, seed, monkeypatch):
+    case = random_case(seed)
+    pools, dbs = H.build_state(lib, case)
+    n = len(case["jobs"])
+    units, strip = [[i] for i in range(n)], [True] * n
+    used_wide = 0
+    for name, db in dbs.items():
+        if not db.case:
+            continue
+        db.set_job_dicts(case["jobs"])
+        s = db.case.sched
+        monkeypatch.delenv("ASCHED_SUBMIT_WIDE", raising=False)
+        a, st = s.submit_check(units, strip), s.submit_stats()
+        monkeypatch.setenv("ASCHED_SUBMIT_WIDE", "0")
+        b, st0 = s.submit_check(units, strip), s.submit_stats()
+        monkeypatch.delenv("ASCHED_SUBMIT_WIDE", raising=False)
+        assert a == b, f"pool {name}: the fit-kernel answers differ from one transaction per job"
+        assert st0["wide_units"] == 0 and st0["sequential_units"] == n
+        assert st["wide_units"] == n and st["sequential_units"] == 0 and 1 <= st["wide_passes"] <= 3, st   # home + up to two away entries
+        used_wide += st["wide_units"]
+    assert used_wide > 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_wide_path_equals_sequential_hostsim(hostsim_lib, seed, monkeypatch):
+    _wide_equals_sequential(hostsim_lib, seed, monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_wide_path_equals_sequential_gpu(hip_lib, seed, monkeypatch):
+    _wide_equals_sequential(hip_lib, seed, monkeypatch)
+
+
+def _pristine_tracking(lib, oracle):
+    """ClearAllocated is persistent (a later jobs_set starts from allocatable, not from the upsert's alloc_by_prio table), and a NodeDb
+    that holds a job is not pristine: its individual checks take the sequential path and see the occupancy."""
+    cfg = copy.deepcopy(CASES[0]["SchedulingConfig"])
+    nodes = [{"index": 1, "total": {"cpu": 4000, "memory": 64 * GI}, "taints": [], "labels": {}, "used": {"0": {"cpu": 3000}}, "unschedulable": False}]
+    jobs = [{"created": i + 1, "queue": "q", "pc": "priority-0", "priority": 1000, "gang": None, "tolerations": [], "selector": {}, "affinity": None,
+             "req": {"cpu": c, "memory": GI}} for i, c in enumerate((2000, 4000, 1000, 2000))]
+    out = []
+    for l in (lib, oracle):
+        c = H.Case(l, cfg, nodes)
+        s = c.sched
+        c.set_jobs(jobs, {"q": 0}, {})
+        before = s.submit_check([[0], [1], [2]], [True] * 3)          # 3 of 4 cpus used at priority 0 and below: only the 1-cpu job fits
+        st_before = s.submit_stats()
+        s.clear_allocated()
+        c.set_jobs(jobs, {"q": 0}, {})                                # jobs_set after the clear: the clear must survive it
+        assert (s.get_alloc(0) == np.array(H.vec(nodes[0]["total"]))[None, :]).all()
+        cleared = s.submit_check([[0], [1], [2]], [True] * 3)
+        st_cleared = s.submit_stats()
+        s.bind(3, 0, 0)                                               # 2 cpus taken: the 4-cpu job no longer fits, and the NodeDb is not pristine
+        occupied = s.submit_check([[0], [1], [2]], [True] * 3)
+        st_occ = s.submit_stats()
+        out.append(([x[0] for x in before], [x[0] for x in cleared], [x[0] for x in occupied]))
+        if l is lib:
+            assert st_before["wide_units"] == 0 and st_cleared["wide_units"] == 3 and st_occ["wide_units"] == 0, (st_before, st_cleared, st_occ)
+    assert out[0] == out[1] == ([False, False, True], [True, True, True], [True, False, True]), out
+
+
+def test_pristine_tracking_hostsim(hostsim_lib, oracle_lib):
+    _pristine_tracking(hostsim_lib, oracle_lib)
+
+
+@pytest.mark.gpu
+def test_pristine_tracking_gpu(hip_lib, oracle_lib):
+    _pristine_tracking(hip_lib, oracle_lib)

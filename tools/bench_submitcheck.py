@@ -6,8 +6,9 @@
     python tools/bench_submitcheck.py                      # HIP library on cuda:0 (needs the MI355X)
     python tools/bench_submitcheck.py --lib hostsim        # CPU build of the device code: checks the tool itself, not a measurement
 
-Prints one JSON line.  `roofline.achieved` prices every node query at N x (8R + 8) bytes like bench.py; the submit
-check issues one query per distinct scheduling key and per gang member, all on the generic path (full-plane scans).
+Prints one JSON line.  `roofline.achieved` prices every node query at N x (8R + 8) bytes like bench.py: one query per distinct
+scheduling key (answered by the wide fit kernel, a handful of passes over the planes for all keys together — `how` says how many) and
+one per gang member (sequential path, full-plane scans).
 """
 import argparse
 import json
@@ -33,6 +34,7 @@ class ArrayPoolDb(PoolNodeDb):
         self.s.clear_allocated()
         self.req, self.pc, self.gang, self.gang_card = req, pc, gang, gang_card
         self.launch_ms = []
+        self.stats = []
 
     def load_jobs(self, jobs):
         self.s.jobs_set(self.req, queue=np.zeros(len(self.req), np.int32), pc=self.pc, gang_id=self.gang, gang_cardinality=self.gang_card)
@@ -40,6 +42,7 @@ class ArrayPoolDb(PoolNodeDb):
     def submit_check(self, units, strip_gang):
         out = self.s.submit_check(units, strip_gang)
         self.launch_ms.append(self.s.kernel_times()["submit_check_ms"])
+        self.stats.append(self.s.submit_stats())
         return out
 
 
@@ -91,7 +94,7 @@ def main():
     db = ArrayPoolDb(lib, wl, req, pc, gang, card)
     chk = SubmitChecker([PoolConfig("pool")], {"pool": db})
     chk.check(jobs[:64])                                # warm-up (first launch, allocations)
-    db.launch_ms.clear()
+    db.launch_ms.clear(); db.stats.clear()
     t0 = time.perf_counter()
     res = chk.check(jobs)
     dt = time.perf_counter() - t0
@@ -110,7 +113,7 @@ def main():
     line = {
         "metric": "submit checks/s (jobs of one Check call, one pool)", "value": a.jobs / dt, "unit": "jobs/s", "lib": a.lib,
         "config": {"workload": f"{a.nodes} nodes, {a.jobs} submitted jobs, {a.shapes} scheduling keys, {int((gang >= 0).sum())} gang members"},
-        "schedulable": sum(r.is_schedulable for r in res.values()), "units": n_units, "launches": chk.launches,
+        "schedulable": sum(r.is_schedulable for r in res.values()), "units": n_units, "launches": chk.launches, "how": db.stats,
         "wall_s": dt, "device_s": dev_s, "dtype": "int64", "data": "synthetic",
         "roofline": {"bound": "hbm", "achieved": queries * bytes_per_query / max(dev_s, 1e-9) / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": queries * bytes_per_query / max(dev_s, 1e-9) / 8e12, "traffic": None, "node_queries": queries},
