@@ -278,3 +278,25 @@ def test_pristine_tracking_hostsim(hostsim_lib, oracle_lib):
 @pytest.mark.gpu
 def test_pristine_tracking_gpu(hip_lib, oracle_lib):
     _pristine_tracking(hip_lib, oracle_lib)
+
+
+def _empty_nodedb(lib):
+    """a pool no executor has reported nodes for: every check answers "not schedulable", on both paths, without touching a kernel"""
+    from armada_amd.binding import Config, Scheduler
+    s = Scheduler(lib, Config(num_resources=2, indexed_col=[0], indexed_resolution=[1], pc_priority=[0], pc_preemptible=[1], drf_multiplier=[1.0, 1.0]))
+    s.nodes_upsert(np.zeros((0, 2), dtype=np.int64))
+    s.clear_allocated()
+    s.jobs_set(np.array([[1, 1], [2, 2], [2, 2]], dtype=np.int64), gang_id=[-1, 0, 0], gang_cardinality=[1, 2, 2])
+    got = s.submit_check([[0], [1, 2]], [True, False])
+    assert [g[0] for g in got] == [False, False] and got[0][3] == -1
+    assert list(s.fit_select_batch([0, 1], -2)) == [-1, -1]
+
+
+def test_empty_nodedb_oracle_and_hostsim(oracle_lib, hostsim_lib):
+    _empty_nodedb(oracle_lib)
+    _empty_nodedb(hostsim_lib)
+
+
+@pytest.mark.gpu
+def test_empty_nodedb_gpu(hip_lib):
+    _empty_nodedb(hip_lib)
