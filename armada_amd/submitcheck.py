@@ -2,11 +2,14 @@
 
 The reference answers "could this newly submitted job / gang ever be scheduled?" by running ScheduleManyWithTxn on a
 NodeDb that was built without jobs and cleared (submitcheck.go:180-188), one job at a time, inside a transaction it
-aborts (:345-349).  Because every attempt is aborted, each one meets the *same* NodeDb state: the attempts are
-independent, and that is what this mirror exploits — the whole batch of a `Check` call becomes ONE `asched_submit_check`
-launch per pool for the individual checks (one unit per distinct scheduling key) and one more for the gangs, instead of
-one transaction round trip per job.  The pool loop of getSchedulingResult (:309-394: submission groups, away pools,
-per-queue limits, floating resources) is pure bookkeeping over those per-pool answers and runs on the host.
+aborts (:345-349).  Because every attempt is aborted, each one meets the *same* NodeDb state: what the NodeDb answers
+depends on the scheduling key alone, and that is what this mirror exploits — the NodeDb work of a whole `Check` call becomes
+ONE `asched_submit_check` call per pool for the individual checks (one unit per distinct scheduling key) and one more for the
+gangs, instead of one transaction round trip per job.  Everything else of `Check` is bookkeeping over those answers and is
+replayed on the host in the reference's own order: the pool loop of getSchedulingResult (:309-394: submission groups, away
+pools, per-queue limits, floating resources), the LRU cache of individual results — keyed by scheduling key only, so a hit
+hands a job the result computed with the queue limits of whichever job filled the entry (:279-288) — and the
+first-failing-member rule for gangs (:293-297).
 
 Equality with the reference's sequential flow is what tests/test_z_submitcheck.py checks: against the expectations of
 submitcheck_test.go (tests/golden/submitcheck_cases.json) and against a literal one-transaction-at-a-time restatement of
@@ -15,6 +18,7 @@ submitcheck_test.go (tests/golden/submitcheck_cases.json) and against a literal 
 Nothing here computes a placement: `PoolNodeDb.submit_check` must be backed by the native library
 (armada_amd.binding.Scheduler.submit_check); there is no Python fallback.
 """
+import collections
 from dataclasses import dataclass, field
 from typing import Callable, Dict, Hashable, List, Optional, Sequence, Tuple
 
@@ -91,6 +95,8 @@ class SubmitChecker:
         for p in self.pools:
             self.pools_by_submission_group.setdefault(p.get_submission_group(), []).append(p.name)
         self.launches = 0   # native calls issued by the last check() (the reference issues one transaction per job per pool)
+        self.cache_size = 10000
+        self._cache: "collections.OrderedDict[Hashable, SchedulingResult]" = collections.OrderedDict()   # jobSchedulingResultsCache (:50, :137)
 
     # ---- which jobs a Check call reaches before its deadlines (the clock is read exactly where the reference reads it)
     def _select(self, jobs: Sequence[SubmitJob]):
@@ -99,8 +105,7 @@ class SubmitChecker:
         by_queue: Dict[str, List[int]] = {}
         for i, j in enumerate(jobs):                     # armadaslices.GroupByFunc; queues visited in first-appearance order
             by_queue.setdefault(j.queue, []).append(i)   # (the reference ranges over a Go map: its own order is unspecified)
-        singles: List[int] = []
-        gangs: List[List[int]] = []
+        events: List[List[int]] = []          # in the reference's processing order: [job] or the members of a gang at its first member
         for _, idxs in by_queue.items():
             if global_deadline.exceeded(self.now()):
                 break
@@ -114,11 +119,11 @@ class SubmitChecker:
                 if queue_deadline.exceeded(self.now()) or global_deadline.exceeded(self.now()):
                     break
                 if jobs[i].gang_id is None:
-                    singles.append(i)
+                    events.append([i])
                 elif jobs[i].gang_id not in processed:
-                    gangs.append(by_gang[jobs[i].gang_id])
+                    events.append(by_gang[jobs[i].gang_id])
                     processed.add(jobs[i].gang_id)
-        return singles, gangs
+        return events
 
     # ---- getSchedulingResult's pool loop (:309-394) over per-pool answers that are already known
     def _pool_loop(self, rep: SubmitJob, members: Sequence[SubmitJob], raw: Dict[str, Tuple[bool, bool, int, int]]) -> SchedulingResult:
@@ -156,41 +161,75 @@ class SubmitChecker:
             return SchedulingResult(True, list(successful.keys()))
         return SchedulingResult(False, [], "".join(reason))
 
+    def update_executors(self) -> None:
+        """SubmitChecker.updateExecutors swaps in a fresh state, cache included (submitcheck.go:137, 213-217); call it after the pools'
+        NodeDbs have been rebuilt"""
+        self._cache.clear()
+
+    def _cache_get(self, key):            # lru.Cache.Get: a hit becomes the most recently used entry
+        if key in self._cache:
+            self._cache.move_to_end(key)
+            return self._cache[key]
+        return None
+
+    def _cache_add(self, key, value):     # lru.Cache.Add (size 10 000, :137)
+        self._cache[key] = value
+        self._cache.move_to_end(key)
+        while len(self._cache) > self.cache_size:
+            self._cache.popitem(last=False)
+
     def check(self, jobs: Sequence[SubmitJob]) -> Dict[str, SchedulingResult]:
-        """Results by job id for the jobs reached before the deadlines (jobs not reached are absent, like the reference)."""
+        """Results by job id for the jobs reached before the deadlines (jobs not reached are absent, like the reference).
+
+        Three steps: (1) the NodeDb answers for every scheduling key that occurs, all pools, one native call per pool — they depend on
+        the key alone; (2) the reference's control flow replayed job by job over those answers: the LRU cache keyed by scheduling key
+        (a hit returns the result computed for whichever job — of whichever queue — filled it, :279-288), the queue / priority-class
+        limit of the job that fills it (:335-343), the first failing member deciding a gang (:293-297); (3) the gangs whose members
+        all passed, one more native call per pool."""
         self.launches = 0
-        singles, gangs = self._select(jobs)
-        if not singles and not gangs:
+        events = self._select(jobs)
+        if not events:
             return {}
-        needed = list(singles) + [i for g in gangs for i in g]
-        # getIndividualSchedulingResult (:272-290): one check per distinct scheduling key — the reference's LRU cache keyed by
-        # jctx.Job.SchedulingKey() returns the stored answer for later jobs with the same key, and the answer is a pure function of
-        # the key because every attempt is aborted
-        first_of_key: Dict[Hashable, int] = {}
-        for i in needed:
-            first_of_key.setdefault(jobs[i].scheduling_key, i)
-        reps = list(first_of_key.values())
+        keys: Dict[Hashable, int] = {}
+        for ev in events:
+            for i in ev:
+                keys.setdefault(jobs[i].scheduling_key, i)
+        reps = list(keys.values())
+        unit_of_key = {k: u for u, k in enumerate(keys)}
         for db in self.node_db_by_pool.values():
             db.load_jobs(jobs)
         raw_ind: Dict[str, list] = {}
         for pool in self.pools:
             raw_ind[pool.name] = self.node_db_by_pool[pool.name].submit_check([[i] for i in reps], [True] * len(reps))
             self.launches += 1
-        individual: Dict[Hashable, SchedulingResult] = {}
-        for u, i in enumerate(reps):
-            individual[jobs[i].scheduling_key] = self._pool_loop(jobs[i], [jobs[i]], {p.name: raw_ind[p.name][u] for p in self.pools})
+
+        def individual(i: int) -> SchedulingResult:          # getIndividualSchedulingResult :272-290
+            key = jobs[i].scheduling_key
+            hit = self._cache_get(key)
+            if hit is not None:
+                return hit
+            u = unit_of_key[key]
+            r = self._pool_loop(jobs[i], [jobs[i]], {p.name: raw_ind[p.name][u] for p in self.pools})
+            self._cache_add(key, r)
+            return r
+
         results: Dict[str, SchedulingResult] = {}
-        for i in singles:
-            results[jobs[i].id] = individual[jobs[i].scheduling_key]
-        # getGangSchedulingResult (:292-302): the first member that is not schedulable on its own decides; else the gang as a unit
         todo: List[List[int]] = []
-        for g in gangs:
-            bad = next((individual[jobs[i].scheduling_key] for i in g if not individual[jobs[i].scheduling_key].is_schedulable), None)
+        for ev in events:
+            if jobs[ev[0]].gang_id is None:
+                results[jobs[ev[0]].id] = individual(ev[0])
+                continue
+            bad = None                                        # getGangSchedulingResult :292-302
+            for i in ev:
+                r = individual(i)
+                if not r.is_schedulable:
+                    bad = r
+                    break
             if bad is not None:
-                for i in g:
+                for i in ev:
                     results[jobs[i].id] = bad
             else:
-                todo.append(g)
+                todo.append(ev)
         if todo:
             raw_gang: Dict[str, list] = {}
             for pool in self.pools:

@@ -124,12 +124,13 @@ def make_clock(case: dict):
     return SteppingClock(case.get("clockStep") or 0)
 
 
-def batched_check(lib: Library, case: dict) -> Dict[str, SchedulingResult]:
+def batched_check(lib: Library, case: dict, cache_size: int = 10000) -> Dict[str, SchedulingResult]:
     """the product flow: armada_amd.submitcheck.SubmitChecker over asched_submit_check"""
     pools, dbs = build_state(lib, case)
     cfg = case.get("submitCheckConfig") or {}
     chk = SubmitChecker(pools, dbs, max_duration=cfg.get("MaxDuration", 0), max_duration_per_queue=cfg.get("MaxDurationPerQueue", 0),
                         now=make_clock(case))
+    chk.cache_size = cache_size
     return chk.check([to_submit_job(j) for j in case["jobs"]])
 
 

@@ -131,10 +131,33 @@ def test_random_batched_on_hostsim_equals_literal_on_oracle(oracle_lib, hostsim_
     assert any(r.is_schedulable for r in lit.values()) and any(not r.is_schedulable for r in lit.values())
 
 
-def test_lru_eviction_does_not_change_results(oracle_lib):
-    """the reference's cache holds 10 000 keys; a cache of 3 forces evictions and re-computation: same answers"""
-    case = random_case(2)
-    H.same_results(H.literal_check(oracle_lib, case), H.literal_check(oracle_lib, case, cache_size=3))
+def test_cache_hit_carries_the_limits_of_the_job_that_filled_it(oracle_lib, hostsim_lib):
+    """the reference's cache is keyed by scheduling key only (submitcheck.go:279-288): a job of queue q0 that hits the entry filled by a job
+    of queue q1 inherits q1's verdict although q1's per-queue limit does not apply to q0 — the batched flow reproduces that, in both orders
+    (seed 198 of the seeded cases found it)"""
+    base = copy.deepcopy(CASES[0])
+    node = {"index": 1, "total": {"cpu": 8000, "memory": 64 * GI}, "taints": [], "labels": {}, "used": {}, "unschedulable": False, "pool": "cpu"}
+    mk = lambda i, q: {"id": f"job-{i}", "created": i, "queue": q, "pc": "priority-1", "priority": 1000, "gang": None, "tolerations": [], "selector": {},  # noqa: E731
+                       "affinity": None, "req": {"cpu": 4000, "memory": 4 * GI}}
+    queues = [{"Name": "q0"}, {"Name": "q1", "ResourceLimitsByPriorityClassName": {"priority-1": {"MaximumResourceFraction": {"cpu": 0.2}}}}]
+    for order, expect in ((("q1", "q0"), [False, False]), (("q0", "q1"), [True, True])):
+        case = {"name": "x", "SchedulingConfig": base["SchedulingConfig"], "Pools": [{"name": "cpu"}], "Queues": queues, "executors": [[node]],
+                "jobs": [mk(1, order[0]), mk(2, order[1])]}
+        for got in (H.literal_check(oracle_lib, case), H.batched_check(oracle_lib, case), H.batched_check(hostsim_lib, case)):
+            assert [got["job-1"].is_schedulable, got["job-2"].is_schedulable] == expect, (order, got)
+
+
+def test_seed_198(oracle_lib, hostsim_lib):
+    case = random_case(198)
+    H.same_results(H.literal_check(oracle_lib, case), H.batched_check(hostsim_lib, case))
+
+
+@pytest.mark.parametrize("seed", [2, 5, 198, 77])
+def test_small_lru_cache_is_emulated_exactly(oracle_lib, hostsim_lib, seed):
+    """the reference's cache holds 10 000 keys; with room for 3 it evicts and re-computes all the time — and since a re-computation uses the
+    limits of the job at hand, the answers may change with the cache size.  The batched flow replays the same Get / Add sequence."""
+    case = random_case(seed)
+    H.same_results(H.literal_check(oracle_lib, case, cache_size=3), H.batched_check(hostsim_lib, case, cache_size=3))
 
 
 def test_literal_on_hostsim_equals_literal_on_oracle(oracle_lib, hostsim_lib):
