@@ -311,7 +311,8 @@ int32_t ASCHED_FN(schedule_many)(asched_t*, int32_t n, const int32_t* jobs, cons
 int32_t ASCHED_FN(bind)(asched_t*, int32_t job, int32_t node, int32_t priority);
 int32_t ASCHED_FN(evict)(asched_t*, int32_t job, int32_t node);
 int32_t ASCHED_FN(unbind)(asched_t*, int32_t job, int32_t node);
-/* AddEvictedJobSchedulingContextWithTxn (nodedb.go:1209) / Reset (:299) */
+/* AddEvictedJobSchedulingContextWithTxn (nodedb.go:1209) / Reset (:299).  index in [0, m): the table holds at most one entry per
+   job of the job table, and the round numbers its entries 0, 1, 2 ... in eviction order (pqs.go:589-639). */
 int32_t ASCHED_FN(add_evicted)(asched_t*, int32_t index, int32_t job, int32_t node);
 int32_t ASCHED_FN(reset_evicted)(asched_t*);
 /* node.AllocatableByPriority, [P][R] */
@@ -320,6 +321,9 @@ int32_t ASCHED_FN(get_scheduled_at_priority)(asched_t*, int32_t job, int32_t* ou
 /* ClearAllocated (nodedb.go:1178-1199): AllocatableByPriority[p] = allocatableResources for every p on every node; the
    nodes' job bookkeeping is left as it is (DeepCopyNilKeys clones the maps, internaltypes/node.go:344-372). */
 int32_t ASCHED_FN(clear_allocated)(asched_t*);
+/* (The HIP backend orders nodes by a packed key sized for allocatable: unbinding, after a clear, a job that was bound before it lifts a
+   bucket above allocatable and is refused with ASCHED_ERR_UNSUPPORTED when the key field overflows; the submit checker's NodeDbs hold
+   no jobs, submitcheck.go:180, so the reference never does that.) */
 /* A batch of submit-check units against the CURRENT NodeDb state (the submit checker's NodeDb is built without jobs and
    cleared, submitcheck.go:180-188).  Unit u = jobs unit_jobs[unit_off[u] .. unit_off[u+1]) as one gang context; each unit
    runs inside its own transaction which is aborted, so units never see each other's binds (submitcheck.go:345-349).
