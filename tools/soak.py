@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Differential soaks, CPU only: the oracle against the CPU build of the device code (tests/hostsim) on many more seeds than the suite runs.
+
+    python tools/soak.py rounds 3000        # workloads.small_random rounds, random sizes / occupancy / gangs / bursts / away / ragged
+    python tools/soak.py features 400       # tests/test_z_feature_mix.py rounds (affinity, conditional away, extra column, limits ...)
+    python tools/soak.py ops 3000           # tests/test_z_nodedb_op_sequences.py NodeDb-level operation sequences
+    python tools/soak.py submitcheck 400    # batched SubmitChecker vs the literal sequential restatement (and 3-entry cache)
+    python tools/soak.py fit 600            # fit_select_batch at every priority on occupied NodeDbs
+
+Prints one line per divergence and a summary; exit code 1 if anything diverged.  (Round 1: all clean after the submit-check fix.)
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+from armada_amd import workloads as W  # noqa: E402
+from armada_amd.binding import Library, SchedError  # noqa: E402
+
+
+def libs():
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hostsim")])
+    return Library(os.path.join(ROOT, "oracle", "liboracle.so"), "oracle_"), Library(os.path.join(ROOT, "tests", "hostsim", "libhostsim.so"), "asched_")
+
+
+def main():
+    kind, n = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    orc, hs = libs()
+    import scenario
+    bad, t0 = 0, time.time()
+    for seed in range(100_000, 100_000 + n):
+        try:
+            if kind == "rounds":
+                rng = np.random.default_rng(seed)
+                wl = W.small_random(n_nodes=int(rng.integers(4, 300)), n_jobs=int(rng.integers(50, 6000)), n_queues=int(rng.integers(1, 12)), seed=seed,
+                                    occupied=float(rng.choice([0.0, 0.3, 0.6, 0.9, 1.0])), gangs=int(rng.integers(0, 12)),
+                                    burst=None if rng.random() < 0.4 else (int(rng.integers(10, 2000)), int(rng.integers(5, 500))),
+                                    away=bool(rng.random() < 0.3), ragged=bool(rng.random() < 0.2))
+                res = []
+                for lib in (orc, hs):
+                    s = W.load(lib, wl); W.prepare(s, wl); res.append(s.schedule_round())
+                scenario.assert_same_round(res[0], res[1])
+            elif kind == "features":
+                import test_z_feature_mix as T
+                scenario.assert_same_round(T.run(orc, seed), T.run(hs, seed))
+            elif kind == "ops":
+                import test_z_nodedb_op_sequences as T
+                assert T.run_ops(orc, seed) == T.run_ops(hs, seed), "operation traces differ"
+            elif kind == "submitcheck":
+                import submitcheck_harness as H
+                import test_z_submitcheck as T
+                c = T.random_case(seed)
+                H.same_results(H.literal_check(orc, c), H.batched_check(hs, c))
+                H.same_results(H.literal_check(orc, c, cache_size=3), H.batched_check(hs, c, cache_size=3))
+            elif kind == "fit":
+                rng = np.random.default_rng(seed)
+                wl = W.small_random(n_nodes=int(rng.integers(4, 200)), n_jobs=int(rng.integers(50, 2000)), n_queues=int(rng.integers(1, 8)), seed=seed,
+                                    occupied=float(rng.choice([0.0, 0.5, 0.9])), gangs=0, away=bool(rng.random() < 0.3))
+                out = []
+                for lib in (orc, hs):
+                    s = W.load(lib, wl); W.prepare(s, wl)
+                    queued = [int(j) for q in wl.queued for j in q][:400]
+                    out.append({p: s.fit_select_batch(queued, p).tolist() for p in s.priorities})
+                assert out[0] == out[1], "fit_select_batch differs"
+            else:
+                raise SystemExit(__doc__)
+        except SchedError as e:
+            if e.code != -2:   # ASCHED_ERR_UNSUPPORTED: a documented refusal (e.g. fit_select_batch on literal-iteration rows)
+                bad += 1; print("seed", seed, e)
+        except AssertionError as e:
+            bad += 1; print("seed", seed, str(e)[:300])
+    print(f"{kind}: {n} seeds, {bad} divergences, {time.time() - t0:.0f} s")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
