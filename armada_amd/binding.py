@@ -160,7 +160,7 @@ ALL_SYMBOLS = [
     "txn_abort", "select_node", "schedule_many", "bind", "evict", "unbind", "add_evicted", "reset_evicted",
     "get_alloc", "get_scheduled_at_priority", "iterate_nodes", "fit_select_batch", "drf_cost", "fair_shares",
     "round_prepare", "schedule_round", "schedule_queues", "gang_schedule", "round_counters", "job_key_unfeasible", "kernel_times", "round_stats",
-    "clear_allocated", "submit_check", "pq_order", "submit_stats",
+    "clear_allocated", "submit_check", "pq_order", "submit_stats", "num_nodes", "total_resources", "node_types_matching_job",
 ]
 
 
@@ -241,6 +241,9 @@ class Library:
         f("jobs_set", C.c_int32, [C.c_void_p, C.POINTER(CJobs), C.POINTER(CReqClasses)])
         f("pq_order", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(CPqItem), C.c_int32, C.c_int32, _i32p, _i32p])
         f("submit_stats", C.c_int32, [C.c_void_p, _i32p])
+        f("num_nodes", C.c_int32, [C.c_void_p])
+        f("total_resources", C.c_int32, [C.c_void_p, _i64p])
+        f("node_types_matching_job", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i32p])
         f("submit_check", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i32p, _i32p, C.POINTER(CSubmitResult)])
         for n in ("txn_begin", "txn_commit", "txn_abort", "reset_evicted", "clear_allocated"):
             f(n, C.c_int32, [C.c_void_p])
@@ -539,6 +542,17 @@ class Scheduler:
         out = (CSubmitResult * nu)()
         self._check(self.lib.submit_check(self.h, nu, _ptr(off, C.c_int32), _ptr(jobs, C.c_int32), _ptr(flags, C.c_int32), out))
         return [(bool(o.ok), bool(o.scheduled_away), int(o.num_schedulable), int(o.first_node)) for o in out]
+
+    def total_resources(self) -> np.ndarray:
+        out = np.zeros(self.R, dtype=np.int64)
+        self._check(self.lib.total_resources(self.h, _ptr(out, C.c_int64)))
+        return out
+
+    def node_types_matching_job(self, job: int):
+        """NodeTypesMatchingJob -> (number of matching node types, number of nodes of the other types)"""
+        a, b = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.node_types_matching_job(self.h, job, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def submit_stats(self):
         out = (C.c_int32 * 4)()

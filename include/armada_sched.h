@@ -315,6 +315,12 @@ int32_t ASCHED_FN(unbind)(asched_t*, int32_t job, int32_t node);
    job of the job table, and the round numbers its entries 0, 1, 2 ... in eviction order (pqs.go:589-639). */
 int32_t ASCHED_FN(add_evicted)(asched_t*, int32_t index, int32_t job, int32_t node);
 int32_t ASCHED_FN(reset_evicted)(asched_t*);
+/* NumNodes (nodedb.go:345), TotalKubernetesResources (:349: the sum of the nodes' allocatable resources, addNodeToStats :44-55) and
+   NodeTypesMatchingJob (:1118-1133): how many node types the job's static requirements admit (NodeTypeJobRequirementsMet) and how many
+   nodes the other types hold (the reference keys that count by a reason string; the reasons are not modelled). */
+int32_t ASCHED_FN(num_nodes)(asched_t*);
+int32_t ASCHED_FN(total_resources)(asched_t*, int64_t* out /*[R]*/);
+int32_t ASCHED_FN(node_types_matching_job)(asched_t*, int32_t job, int32_t* num_matching_types, int32_t* num_excluded_nodes);
 /* node.AllocatableByPriority, [P][R] */
 int32_t ASCHED_FN(get_alloc)(asched_t*, int32_t node, int64_t* out);
 int32_t ASCHED_FN(get_scheduled_at_priority)(asched_t*, int32_t job, int32_t* out, int32_t* ok); /* nodedb.go:315 */
