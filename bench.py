@@ -65,6 +65,115 @@ def cpu_baseline(wl, budget_s, full_iters):
             "measured_s": dt, "measured_iterations": iters}
 
 
+# ------------------------------------------------------------------------------------------------ --submit-check
+def _submit_check_helpers():
+    import numpy as np
+    from armada_amd import workloads as W
+    from armada_amd.binding import Scheduler
+    from armada_amd.submitcheck import PoolNodeDb
+
+    class ArrayPoolDb(PoolNodeDb):
+        """one pool's cleared NodeDb over array-shaped job tables (the shape a cgo shim would hand over)"""
+
+        def __init__(self, lib, wl, req, pc, gang, gang_card):
+            self.s = Scheduler(lib, wl.config)
+            self.s.nodes_upsert(wl.node_total, wl.node_allocatable)
+            self.s.clear_allocated()
+            self.req, self.pc, self.gang, self.gang_card = req, pc, gang, gang_card
+            self.launch_ms, self.stats = [], []
+
+        def load_jobs(self, jobs):
+            self.s.jobs_set(self.req, queue=np.zeros(len(self.req), np.int32), pc=self.pc, gang_id=self.gang, gang_cardinality=self.gang_card)
+
+        def submit_check(self, units, strip_gang):
+            out = self.s.submit_check(units, strip_gang)
+            self.launch_ms.append(self.s.kernel_times()["submit_check_ms"])
+            self.stats.append(self.s.submit_stats())
+            return out
+
+    def make_jobs(rng, n_jobs, n_shapes, gang_frac):
+        cpu = rng.integers(1, 41, size=n_shapes) * 1000   # a fifth of the keys fit no node (32-core nodes)
+        mem = rng.integers(1, 257, size=n_shapes) * W.Gi
+        shape = rng.integers(0, n_shapes, size=n_jobs)
+        req = np.zeros((n_jobs, W.R), np.int64)
+        req[:, 0], req[:, 1] = mem[shape], cpu[shape]
+        gang = np.full(n_jobs, -1, np.int32)
+        card = np.ones(n_jobs, np.int32)
+        i, g = 0, 0
+        while i < n_jobs:
+            if rng.random() < gang_frac:
+                c = int(min(rng.integers(2, 17), n_jobs - i))
+                gang[i:i + c], card[i:i + c] = g, c
+                req[i:i + c] = req[i]          # uniform shape within a gang
+                shape[i:i + c] = shape[i]
+                g += 1; i += c
+            else:
+                i += 1
+        return req, shape, gang, card
+    return ArrayPoolDb, make_jobs
+
+
+def submit_check_bench(args):
+    """Submit-check throughput: jobs of one SubmitChecker.Check call per second on one pool through the batched
+    flow (armada_amd.submitcheck -> asched_submit_check), with the launch durations from the HIP events on the launch stream and, as
+    `cpu_baseline`, the reference's sequential flow (one Txn / ScheduleManyWithTxn / Abort per job) timed on the CPU oracle over a
+    bounded sample.  `roofline.achieved` prices every node query at N x (8R + 8) bytes like the round: one query per distinct scheduling
+    key (answered by the wide fit kernel in a handful of passes for all keys together, `how`) and one per gang member (sequential path)."""
+    import numpy as np
+    import torch
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU path)"
+    torch.zeros(1, device="cuda:0")
+    import armada_amd
+    from armada_amd import workloads as W
+    from armada_amd.binding import Library
+    from armada_amd.submitcheck import PoolConfig, SubmitChecker, SubmitJob
+    ArrayPoolDb, make_jobs = _submit_check_helpers()
+    lib = armada_amd.load_library()
+    rng = np.random.Generator(np.random.PCG64(W.SEED))
+    n_jobs, n_shapes = args.submit_jobs, args.submit_keys
+    wl = W.config2(n_nodes=args.nodes, n_jobs=1)          # the node set of BASELINE configs[1]/[2]: 32 cpu / 256 Gi nodes
+    req, shape, gang, card = make_jobs(rng, n_jobs, n_shapes, 0.02)
+    jobs = [SubmitJob(id=str(i), queue="q", priority_class="pc0", scheduling_key=(int(shape[i]),), request=req[i],
+                      gang_id=None if gang[i] < 0 else f"g{gang[i]}") for i in range(n_jobs)]
+    pc = np.zeros(n_jobs, np.int32)
+    db = ArrayPoolDb(lib, wl, req, pc, gang, card)
+    chk = SubmitChecker([PoolConfig("pool")], {"pool": db})
+    chk.check(jobs[:64])                                  # warm-up (first launches, allocations)
+    chk.update_executors()
+    lat = []
+    for _ in range(max(1, args.steps)):
+        db.launch_ms.clear(); db.stats.clear(); chk.update_executors()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        res = chk.check(jobs)
+        torch.cuda.synchronize(); lat.append(time.perf_counter() - t0)
+    dt = float(np.mean(lat))
+    queries = len({j.scheduling_key for j in jobs}) + int((gang >= 0).sum())
+    dev_s = sum(db.launch_ms) / 1e3
+    line = {
+        "metric": "submit checks/s (jobs of one SubmitChecker.Check call, one pool)", "value": n_jobs / dt, "unit": "jobs/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": 1, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+        "config": {"workload": f"{args.nodes} nodes (32 cpu / 256 Gi), {n_jobs} submitted jobs, {n_shapes} scheduling keys, {int((gang >= 0).sum())} gang members, one pool"},
+        "schedulable": sum(r.is_schedulable for r in res.values()), "native_calls": chk.launches, "how": db.stats, "device_s": dev_s,
+        "roofline": {"bound": "hbm", "achieved": queries * algorithmic_bytes(args.nodes, W.R, 1, 0) / max(dev_s, 1e-9) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": queries * algorithmic_bytes(args.nodes, W.R, 1, 0) / max(dev_s, 1e-9) / 1e9 / HBM_PEAK_GBS, "traffic": None, "node_queries": queries,
+                     "kernel": "k_fit_batch (individual checks) + k_control_aux (gangs)"},
+    }
+    if args.cpu_budget > 0:   # cpu_baseline leg: the reference's sequential flow on the oracle, distinct keys so that its cache cannot help
+        path = os.path.join(ROOT, "oracle", "liboracle.so")
+        if os.path.exists(path):
+            oracle = Library(path, "oracle_")
+            sample = min(300, n_jobs)
+            odb = ArrayPoolDb(oracle, wl, req[:sample], pc[:sample], np.full(sample, -1, np.int32), np.ones(sample, np.int32))
+            odb.load_jobs(None)
+            t1 = time.perf_counter()
+            for i in range(sample):
+                odb.s.txn_begin(); odb.s.schedule_many([i]); odb.s.txn_abort()
+            cpu_dt = time.perf_counter() - t1
+            line["cpu_baseline"] = {"value": sample / cpu_dt, "unit": "jobs/s", "cores": 1, "kind": "port",
+                                    "sample": f"{sample} jobs, one Txn / ScheduleManyWithTxn / Abort each on the CPU oracle, same node set"}
+    print(json.dumps(line))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,7 +185,12 @@ def main():
     ap.add_argument("--gangs", type=int, default=0, help="queued gangs of size 2-64 (BASELINE configs[3] shape)")
     ap.add_argument("--occupied", type=float, default=0.5, help="fraction of every node filled with running jobs (0.95: the preemption-heavy configs[4] shape)")
     ap.add_argument("--cpu-budget", type=float, default=75.0, help="seconds of CPU-oracle work allowed for cpu_baseline (0 = skip)")
+    ap.add_argument("--submit-check", action="store_true", help="measure the submit check (SURVEY 8f-2) instead of the round; 1 GPU")
+    ap.add_argument("--submit-jobs", type=int, default=50_000)
+    ap.add_argument("--submit-keys", type=int, default=2_000)
     args = ap.parse_args()
+    if args.submit_check:
+        return submit_check_bench(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

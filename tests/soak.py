@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Differential soaks, CPU only: the oracle against the CPU build of the device code (tests/hostsim) on many more seeds than the suite runs.
 
-    python tools/soak.py rounds 3000        # workloads.small_random rounds, random sizes / occupancy / gangs / bursts / away / ragged
-    python tools/soak.py features 400       # tests/test_z_feature_mix.py rounds (affinity, conditional away, extra column, limits ...)
-    python tools/soak.py ops 3000           # tests/test_z_nodedb_op_sequences.py NodeDb-level operation sequences
-    python tools/soak.py submitcheck 400    # batched SubmitChecker vs the literal sequential restatement (and 3-entry cache)
-    python tools/soak.py fit 600            # fit_select_batch at every priority on occupied NodeDbs
+    python tests/soak.py rounds 3000        # workloads.small_random rounds, random sizes / occupancy / gangs / bursts / away / ragged
+    python tests/soak.py features 400       # tests/test_z_feature_mix.py rounds (affinity, conditional away, extra column, limits ...)
+    python tests/soak.py ops 3000           # tests/test_z_nodedb_op_sequences.py NodeDb-level operation sequences
+    python tests/soak.py submitcheck 400    # batched SubmitChecker vs the literal sequential restatement (and 3-entry cache)
+    python tests/soak.py fit 600            # fit_select_batch at every priority on occupied NodeDbs
 
 Prints one line per divergence and a summary; exit code 1 if anything diverged.  (Round 1: all clean after the submit-check fix.)
 """
@@ -13,7 +13,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this file lives in tests/: it drives the oracle, which only test code may do)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402

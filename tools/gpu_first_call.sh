@@ -24,7 +24,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 F=$(find "$OUT/pmc_FETCH_SIZE" -name "*.db" | head -1); W=$(find "$OUT/pmc_WRITE_SIZE" -name "*.db" | head -1)
 [ -n "$F" ] && [ -n "$W" ] && python tools/pmc_summary.py "$F" "$W" "$OUT/pmc_hbm_traffic.json" > /dev/null
-timeout 600 python tools/bench_submitcheck.py > "$OUT/bench_submitcheck.json" 2> "$OUT/bench_submitcheck.err"; echo "submitcheck bench rc=$?" | tee -a "$OUT/summary.txt"
+timeout 600 python bench.py --submit-check --steps 3 > "$OUT/bench_submitcheck.json" 2> "$OUT/bench_submitcheck.err"; echo "submitcheck bench rc=$?" | tee -a "$OUT/summary.txt"
 # keep the merge-back small: the rocprof databases stay on the box
 find "$OUT" -name "*.db" -size +8M -delete
 cat "$OUT/bench_full.json" | head -c 600 | tee -a "$OUT/summary.txt"
