@@ -113,7 +113,11 @@ def extract_submitcheck(base_env, skipped):
     env.update({"SmallNode": small_node, "GpuNode": gpu_node, "cordon": cordon, "Executor": lambda *nodes: list(nodes),
                 "defaultTimeout": 900, "time.Second": 1, "pointer.MustParseResource": G.MustParse,
                 "testfixtures.WithNodeSelectorJob": lambda sel, j: G.WithNodeSelectorJobs(sel, [copy.copy(j)])[0]})
-    cases = extract_table(f"{REF}/submitcheck_test.go", "TestSubmitChecker_CheckJobDbJobs", env, skipped)
+    G.ALLOW_FLOATING_REQUESTS = True     # floating requests stay in the job's vector; the harness splits them off (they never reach a NodeDb)
+    try:
+        cases = extract_table(f"{REF}/submitcheck_test.go", "TestSubmitChecker_CheckJobDbJobs", env, skipped)
+    finally:
+        G.ALLOW_FLOATING_REQUESTS = False
     pools = [  # schedulingConfig.Pools, :49-58
         {"name": "cpu"}, {"name": "cpu2"}, {"name": "cpu-disallowed-resources", "disallowed_resources": ["cpu"]}, {"name": "gpu"},
         {"name": "cpu-away", "away_pools": ["gpu"]}, {"name": "cpu-grouped-1", "submission_group": "group-1"},
@@ -126,6 +130,7 @@ def extract_submitcheck(base_env, skipped):
             j.pop("Id", None)
         c["SchedulingConfig"] = to_json(G.TestSchedulingConfig())
         c["Pools"] = pools
+        c["FloatingResources"] = {"test-floating-resource": {"cpu": 10 * G.SCALE["test-floating-resource"]}}   # submitcheck_test.go:410-421: 10 in pool "cpu"
         c["Queues"] = [c.pop("queue")] if c.get("queue") else [{"Name": "queue"}]   # :400-405
         out.append(c)
     return out

@@ -297,15 +297,22 @@ def WithNodeSelectorJobs(selector, jobs):
     return jobs
 
 
+ALLOW_FLOATING_REQUESTS = False   # the submit check handles floating resources on the host (submitcheck.go:326-333): its extraction turns this on
+
+
 def WithRequestsJobs(rlist, jobs):  # testfixtures.go:496-511; the job's vector comes from FromJobResourceListIgnoreUnknown: unknown names are dropped
     if isinstance(rlist, dict) and "Resources" in rlist:   # schedulerobjects.ResourceList{Resources: ...}
         rlist = rlist["Resources"]
-    if "test-floating-resource" in rlist:
+    if "test-floating-resource" in rlist and not ALLOW_FLOATING_REQUESTS:
         raise Unsupported("floating resources are not modelled")
     known = {k: v for k, v in rlist.items() if k in SCALE}
-    for j in jobs:
+    out = []
+    for j in jobs:                      # job.WithJobSchedulingInfo returns a new job: the caller's job keeps its requests
+        j = copy.copy(j)
+        j["req"] = dict(j["req"])
         j["req"].update(rl(known, round_up=True))
-    return jobs
+        out.append(j)
+    return out
 
 
 def WithNodeAffinityJobs(terms, jobs):  # testfixtures.go:476-494: appends to RequiredDuringSchedulingIgnoredDuringExecution.NodeSelectorTerms

@@ -24,15 +24,26 @@ def scheduling_key(j: dict):
             tuple(vec(j["req"])), j["pc"], repr(j.get("affinity")))
 
 
+FLOATING = ("test-floating-resource",)   # floatingresources: pool-level resources, not on nodes (testfixtures.go:64-74)
+
+
+def kubernetes_view(j: dict) -> dict:
+    """the job as a NodeDb sees it: KubernetesResourceRequirements, i.e. without the floating resources (jobdb/job.go)"""
+    if not any(k in j["req"] for k in FLOATING):
+        return j
+    return dict(j, req={k: v for k, v in j["req"].items() if k not in FLOATING})
+
+
 def to_submit_job(j: dict) -> SubmitJob:
     return SubmitJob(id=j["id"], queue=j["queue"], priority_class=j["pc"], scheduling_key=scheduling_key(j), request=vec(j["req"]),
-                     gang_id=j["gang"]["id"] if j.get("gang") else None)
+                     gang_id=j["gang"]["id"] if j.get("gang") else None, floating_request={k: j["req"][k] for k in FLOATING if j["req"].get(k)})
 
 
 class CasePoolDb(PoolNodeDb):
     """One pool's NodeDb: a scenario.Case (config + nodes -> binding.Scheduler), cleared."""
 
-    def __init__(self, lib: Library, cfg: dict, pool: dict, nodes: List[dict], queues: List[dict], jobs_by_id: Dict[str, dict]):
+    def __init__(self, lib: Library, cfg: dict, pool: dict, nodes: List[dict], queues: List[dict], jobs_by_id: Dict[str, dict], floating=None):
+        self.floating = dict(floating or {})
         cfg = dict(cfg)
         cfg["disallowed_resources"] = list(pool.get("disallowed_resources") or [])   # ConstructNodeDb: scheduling_algo.go:772
         clean = []
@@ -53,7 +64,11 @@ class CasePoolDb(PoolNodeDb):
     def load_jobs(self, jobs):
         self.set_job_dicts([self.jobs_by_id[j.id] for j in jobs])
 
+    def floating_available(self):
+        return self.floating
+
     def set_job_dicts(self, dicts: List[dict]):
+        dicts = [kubernetes_view(j) for j in dicts]
         self.loaded = dicts
         if self.case:
             queues = sorted({j["queue"] for j in dicts})
@@ -104,7 +119,8 @@ def build_state(lib: Library, case: dict):
         nodes = list(by_pool.get(pc.name, []))
         for a in pc.away_pools:
             nodes += by_pool.get(a, [])
-        dbs[pc.name] = CasePoolDb(lib, case["SchedulingConfig"], p, nodes, case["Queues"], jobs_by_id)
+        floating = {name: by_pool_total[pc.name] for name, by_pool_total in (case.get("FloatingResources") or {}).items() if pc.name in by_pool_total}
+        dbs[pc.name] = CasePoolDb(lib, case["SchedulingConfig"], p, nodes, case["Queues"], jobs_by_id, floating)
     return pools, dbs
 
 
@@ -182,6 +198,11 @@ def literal_check(lib: Library, case: dict, cache_size=10000) -> Dict[str, Sched
             if any(successful.get(a) for a in pool.away_pools):
                 continue
             db = dbs[pool.name]
+            fl = {k: sum(jobs[i]["req"].get(k, 0) for i in members) for k in FLOATING}
+            if any(v > 0 for v in fl.values()):          # gctx.RequestsFloatingResources -> floatingResourceTypes.WithinLimits (:326-333)
+                avail = db.floating_available()
+                if not any(avail.values()) or any(v > avail.get(k, 0) for k, v in fl.items()):
+                    continue
             limit = db.queue_resource_limit(rep["queue"], rep["pc"])
             if limit is not None and any(t > l for t, l in zip(total, limit)):
                 continue
