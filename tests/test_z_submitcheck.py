@@ -1,7 +1,7 @@
 """Submit check (internal/scheduler/submitcheck.go): ClearAllocated + batched ScheduleManyWithTxn-and-abort.
 
 Layers, all compared on the same inputs:
-  expectations of submitcheck_test.go (tests/golden/submitcheck_cases.json, 28 cases)
+  expectations of submitcheck_test.go (tests/golden/submitcheck_cases.json, 29 cases)
     == literal one-transaction-per-attempt restatement of SubmitChecker.Check on the CPU oracle      (pins the restatement)
     == batched product flow (armada_amd.submitcheck -> asched_submit_check) on the oracle / on the CPU build of the device code
     == (-m gpu) batched product flow on the HIP library.
