@@ -160,7 +160,7 @@ ALL_SYMBOLS = [
     "txn_abort", "select_node", "schedule_many", "bind", "evict", "unbind", "add_evicted", "reset_evicted",
     "get_alloc", "get_scheduled_at_priority", "iterate_nodes", "fit_select_batch", "drf_cost", "fair_shares",
     "round_prepare", "schedule_round", "schedule_queues", "gang_schedule", "round_counters", "job_key_unfeasible", "kernel_times", "round_stats",
-    "clear_allocated", "submit_check", "pq_order", "submit_stats", "num_nodes", "total_resources", "node_types_matching_job",
+    "clear_allocated", "submit_check", "pq_order", "submit_stats", "num_nodes", "total_resources", "node_types_matching_job", "scheduling_order",
 ]
 
 
@@ -242,6 +242,7 @@ class Library:
         f("pq_order", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(CPqItem), C.c_int32, C.c_int32, _i32p, _i32p])
         f("submit_stats", C.c_int32, [C.c_void_p, _i32p])
         f("num_nodes", C.c_int32, [C.c_void_p])
+        f("scheduling_order", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int32])
         f("total_resources", C.c_int32, [C.c_void_p, _i64p])
         f("node_types_matching_job", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i32p])
         f("submit_check", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i32p, _i32p, C.POINTER(CSubmitResult)])
@@ -542,6 +543,15 @@ class Scheduler:
         out = (CSubmitResult * nu)()
         self._check(self.lib.submit_check(self.h, nu, _ptr(off, C.c_int32), _ptr(jobs, C.c_int32), _ptr(flags, C.c_int32), out))
         return [(bool(o.ok), bool(o.scheduled_away), int(o.num_schedulable), int(o.first_node)) for o in out]
+
+    def scheduling_order(self, queue: int) -> List[int]:
+        """the queue's jobs in jobdb.SchedulingOrderCompare order"""
+        cap = max(self.num_jobs, 1)
+        out = (C.c_int32 * cap)()
+        n = self.lib.scheduling_order(self.h, queue, out, cap)
+        if n < 0:
+            self._check(n)
+        return [out[i] for i in range(min(n, cap))]
 
     def total_resources(self) -> np.ndarray:
         out = np.zeros(self.R, dtype=np.int64)

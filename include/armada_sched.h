@@ -321,6 +321,10 @@ int32_t ASCHED_FN(reset_evicted)(asched_t*);
 int32_t ASCHED_FN(num_nodes)(asched_t*);
 int32_t ASCHED_FN(total_resources)(asched_t*, int64_t* out /*[R]*/);
 int32_t ASCHED_FN(node_types_matching_job)(asched_t*, int32_t job, int32_t* num_matching_types, int32_t* num_excluded_nodes);
+/* The jobs of one queue in jobdb.SchedulingOrderCompare order (jobdb/comparison.go:49-107): jobs with an active run first, then
+   priority-class priority descending, queue priority ascending, (both active: run timestamp ascending,) submit time ascending, id.
+   This is the order the round takes evicted jobs of a queue in (pqs.go:589-639); returns the number of jobs of the queue. */
+int32_t ASCHED_FN(scheduling_order)(asched_t*, int32_t queue, int32_t* out_jobs, int32_t cap);
 /* node.AllocatableByPriority, [P][R] */
 int32_t ASCHED_FN(get_alloc)(asched_t*, int32_t node, int64_t* out);
 int32_t ASCHED_FN(get_scheduled_at_priority)(asched_t*, int32_t job, int32_t* out, int32_t* ok); /* nodedb.go:315 */

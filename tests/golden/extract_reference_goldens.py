@@ -194,6 +194,47 @@ def extract_pq_ordering(skipped):
     return out
 
 
+def extract_comparer(skipped):
+    path = f"{REF}/jobdb/comparison_test.go"
+    src = open(path).read()
+    rel = os.path.relpath(path, "/root/reference")
+    pos = src.index("func TestJobPriorityComparer(")
+    m = re.compile(r"tests\s*:=\s*map\[string\]struct\s*\{").search(src, pos)
+    body_open = src.index("{", find_matching(src, m.end() - 1) + 1)
+    body_close = find_matching(src, body_open)
+    line_of = lambda p: src.count("\n", 0, p) + 1  # noqa: E731
+
+    def job_of(text):
+        """&Job{...} optionally wrapped as (&Job{...}).WithNewRun(...) / .WithUpdatedRun(&JobRun{created: N})"""
+        lit = text[text.index("&Job{") + 1:]
+        lit = lit[:find_matching(lit, lit.index("{")) + 1]
+        k = lit.find("jobDb:")                  # `jobDb: NewJobDb(...)` only gives WithNewRun something to read the default priority class from
+        if k >= 0:
+            o = lit.index("(", k)
+            lit = lit[:k] + lit[find_matching(lit, o, "(", ")") + 1:].lstrip(" ,")
+        v = Evaluator({"types.PriorityClass": None}).ev(Parser(tokenize(lit, 1)).parse_expr())
+        j = {"id": v.get("id", ""), "priority": int(v.get("priority", 0)), "pcPriority": int((v.get("priorityClass") or {}).get("Priority", 0)),
+             "submittedTime": int(v.get("submittedTime", 0)), "activeRunTimestamp": int(v.get("activeRunTimestamp", 0)), "active": False}
+        if ".WithNewRun(" in text:
+            j["active"] = True
+        mm = re.search(r"\.WithUpdatedRun\(\s*&JobRun\{created:\s*(\d+)\}", text)
+        if mm:
+            j["active"], j["activeRunTimestamp"] = True, int(mm.group(1))
+        return j
+
+    out = []
+    for name, lit, line in split_table_cases(src, body_open + 1, body_close, line_of):
+        try:
+            ma, mb, me = re.search(r"\ba:\s", lit), re.search(r"\n\s*b:\s", lit), re.search(r"\n\s*expected:\s*(-?\d+)", lit)
+            a, b = job_of(lit[ma.end():mb.start()]), job_of(lit[mb.end():me.start()])
+            if a["id"] == b["id"]:
+                continue   # "Jobs with equal id are considered equal": identity, not order
+            out.append({"name": name, "source": f"{rel}:{line}", "a": a, "b": b, "expected": int(me.group(1))})
+        except (Unsupported, AttributeError, ValueError) as e:
+            skipped.append(f"{rel}:{line} TestJobPriorityComparer/{name}: {e}")
+    return out
+
+
 def main():
     env = gofixtures.make_env()
     skipped = []
@@ -310,6 +351,11 @@ def main():
     out["pqs_pod_limits"] = extract_table(f"{REF}/scheduling/preempting_queue_scheduler_test.go", "TestPreemptingQueueScheduler_RespectNodePodLimits", env, skipped)
     for c in out["pqs_pod_limits"]:
         c["SchedulingConfig"] = to_json(gofixtures.TestSchedulingConfig())
+
+    # jobdb/comparison_test.go:13-74 TestJobPriorityComparer: pairs of jobs and the sign of SchedulingOrderCompare.  The table builds jobs
+    # with method chains ((&Job{...}).WithNewRun(...) / .WithUpdatedRun(&JobRun{created: t})): an active run whose timestamp is `created`
+    # (job.go: activeRunTimestamp = run.created); the two cases about equal ids are about jobDb identity, not order, and are dropped.
+    out["job_priority_comparer"] = extract_comparer(skipped)
 
     # nodedb_test.go:1236-1291 TestConditionalAwayNodeScheduling: one node, one job of armada-preemptible-away-conditional, through
     # SelectNodeForJobWithTxn; the job built before the table (:1237-1241) is restated with the same fixtures
