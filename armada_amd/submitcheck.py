@@ -11,7 +11,7 @@ pools, per-queue limits, floating resources), the LRU cache of individual result
 hands a job the result computed with the queue limits of whichever job filled the entry (:279-288) — and the
 first-failing-member rule for gangs (:293-297).
 
-Equality with the reference's sequential flow is what tests/test_z_submitcheck.py checks: against the expectations of
+Equality with the reference's sequential flow is what tests/test_zzz_submitcheck.py checks: against the expectations of
 submitcheck_test.go (tests/golden/submitcheck_cases.json) and against a literal one-transaction-at-a-time restatement of
 `Check` (tests/submitcheck_harness.py: literal_check) on seeded inputs.
 

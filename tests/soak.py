@@ -54,7 +54,7 @@ def main():
                 assert T.run_ops(orc, seed) == T.run_ops(hs, seed), "operation traces differ"
             elif kind == "submitcheck":
                 import submitcheck_harness as H
-                import test_z_submitcheck as T
+                import test_zzz_submitcheck as T
                 c = T.random_case(seed)
                 H.same_results(H.literal_check(orc, c), H.batched_check(hs, c))
                 H.same_results(H.literal_check(orc, c, cache_size=3), H.batched_check(hs, c, cache_size=3))
