@@ -1,0 +1,56 @@
+"""bench.py's output contract, checked without a GPU: torch.cuda and armada_amd.load_library are monkeypatched so that the CPU build of the
+device code stands in for the HIP library (test-only; bench.py itself refuses to run without the MI355X).  Guards the JSON line — the keys
+the driver and the judge read — for the round bench and for `--submit-check`, at toy sizes."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUND_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"}
+ROOFLINE_KEYS = {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+CPU_KEYS = {"value", "unit", "cores", "kind", "sample"}
+
+
+@pytest.fixture
+def fake_gpu(monkeypatch, hostsim_lib):
+    import torch
+    import armada_amd
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: None)
+    real_zeros = torch.zeros
+    monkeypatch.setattr(torch, "zeros", lambda *a, **k: real_zeros(*a, **{x: y for x, y in k.items() if x != "device"}))
+    monkeypatch.setattr(armada_amd, "load_library", lambda: hostsim_lib)
+    sys.path.insert(0, ROOT)
+    for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(v, raising=False)
+    import bench
+    return bench
+
+
+def check_line(out, metric_word):
+    line = json.loads(out.strip().splitlines()[-1])
+    assert ROUND_KEYS <= set(line), ROUND_KEYS - set(line)
+    assert metric_word in line["metric"] and line["n_gpus"] == 1 and line["higher_is_better"] is True and line["scaling"] == "weak"
+    assert line["vs_baseline"] is None and line["dtype"] == "int64" and line["data"] == "synthetic" and "workload" in line["config"]
+    assert ROOFLINE_KEYS <= set(line["roofline"]) and line["roofline"]["bound"] == "hbm" and line["roofline"]["peak"] == 8000.0
+    assert CPU_KEYS <= set(line["cpu_baseline"]) and line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
+    assert line["value"] > 0
+    return line
+
+
+def test_round_bench_line(fake_gpu, monkeypatch, capsys):
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--nodes", "500", "--jobs", "5000", "--queues", "8", "--steps", "2", "--warmup", "1", "--cpu-budget", "5"])
+    fake_gpu.main()
+    line = check_line(capsys.readouterr().out, "rounds/sec")
+    assert line["steps"] == 2 and line["warmup"] == 1 and line["unit"] == "rounds/s" and line["round"]["scheduled"] > 0
+
+
+def test_submit_check_bench_line(fake_gpu, monkeypatch, capsys):
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--submit-check", "--nodes", "500", "--submit-jobs", "1500", "--submit-keys", "120", "--steps", "1", "--cpu-budget", "5"])
+    fake_gpu.main()
+    line = check_line(capsys.readouterr().out, "submit checks")
+    assert line["unit"] == "jobs/s" and line["how"][0]["wide_units"] == 120 and line["how"][0]["sequential_units"] == 0 and line["how"][1]["sequential_units"] > 0
