@@ -54,3 +54,10 @@ def test_submit_check_bench_line(fake_gpu, monkeypatch, capsys):
     fake_gpu.main()
     line = check_line(capsys.readouterr().out, "submit checks")
     assert line["unit"] == "jobs/s" and line["how"][0]["wide_units"] == 120 and line["how"][0]["sequential_units"] == 0 and line["how"][1]["sequential_units"] > 0
+
+
+def test_smoke_entry_point(fake_gpu, capsys):
+    """__graft_entry__.smoke(): one small round through the library, checked against the oracle (here: the CPU build stands in)"""
+    import __graft_entry__ as g
+    g.smoke()
+    assert "smoke ok" in capsys.readouterr().out
