@@ -43,10 +43,33 @@ def check_line(out, metric_word):
 
 
 def test_round_bench_line(fake_gpu, monkeypatch, capsys):
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--nodes", "500", "--jobs", "5000", "--queues", "8", "--steps", "2", "--warmup", "1", "--cpu-budget", "5"])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--nodes", "500", "--jobs", "5000", "--queues", "8", "--steps", "2", "--warmup", "1", "--cpu-budget", "5", "--other-scale", "0.01"])
     fake_gpu.main()
     line = check_line(capsys.readouterr().out, "rounds/sec")
     assert line["steps"] == 2 and line["warmup"] == 1 and line["unit"] == "rounds/s" and line["round"]["scheduled"] > 0
+    # the headline is self-verifying: the timed round is compared with the oracle round of the cpu_baseline leg
+    assert line["parity"] == dict(line["parity"], checked=True, identical=True) and line["parity"]["jobs"] > 5000
+    assert line["cpu_baseline"]["rounds"] == 1 and line["cpu_baseline"]["upper_bound_extrapolation"] is False
+    # every other BASELINE config + the submit check sits in the same record, each with roofline and cpu_baseline
+    oc = {r["config"]: r for r in line["other_configs"]}
+    assert set(oc) == {"BASELINE configs[1]", "BASELINE configs[3]", "BASELINE configs[4] (reduced: the size the oracle leg runs at)", "submit check (SURVEY 8f-2)"}, set(oc)
+    for name, r in oc.items():
+        assert "error" not in r and "skipped" not in r, r
+        assert ROOFLINE_KEYS <= set(r["roofline"]) and CPU_KEYS <= set(r["cpu_baseline"]), name
+        if "parity" in r:
+            assert r["parity"]["checked"] and r["parity"]["identical"], (name, r["parity"])
+    assert oc["BASELINE configs[1]"]["roofline"]["kernel"] == "k_fit_batch" and oc["BASELINE configs[1]"]["parity"]["identical"]
+    assert oc["BASELINE configs[3]"]["reduced"]["parity"]["identical"] and oc["BASELINE configs[3]"]["round"]["generic_iterations"] > 0
+
+
+def test_round_bench_detects_a_mismatch(fake_gpu, monkeypatch, capsys):
+    """a GPU round that differs from the oracle's makes bench.py say so in the line and exit non-zero"""
+    real = fake_gpu.round_diff
+    monkeypatch.setattr(fake_gpu, "round_diff", lambda a, b: real(a, b) + ["scheduled (injected)"])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--nodes", "300", "--jobs", "3000", "--queues", "4", "--steps", "1", "--warmup", "0", "--cpu-budget", "5", "--no-other"])
+    rc = fake_gpu.main()
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert rc == 3 and line["parity"]["checked"] and not line["parity"]["identical"] and "other_configs" not in line
 
 
 def test_submit_check_bench_line(fake_gpu, monkeypatch, capsys):
