@@ -23,7 +23,7 @@ EVICTED_PRIORITY = -2
 CROSS_POOL_PRIORITY = -1
 
 OK = 0
-ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_INTERNAL = -1, -2, -3, -4
+ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_INTERNAL, ERR_TIMEOUT = -1, -2, -3, -4, -5
 
 EFFECT_NONE, EFFECT_NO_SCHEDULE, EFFECT_PREFER_NO_SCHEDULE, EFFECT_NO_EXECUTE = 0, 1, 2, 3
 TOL_EQUAL, TOL_EXISTS = 0, 1
@@ -49,6 +49,10 @@ REASONS = {
     15: "at least one job in the gang does not fit on any node",
     16: "no remaining candidate jobs",
     17: "skipped: scheduling key known to be unfeasible",
+    18: "global new job scheduling duration exceeded",
+    19: "queue new job scheduling duration exceeded",
+    20: "floating resources not configured for pool",
+    21: "not enough floating resource in pool",
 }
 
 _i32p = C.POINTER(C.c_int32)
@@ -81,6 +85,8 @@ class CConfig(C.Structure):
         ("device", C.c_int32), ("pad3_", C.c_int32),
         ("away_nt_off", _i32p), ("away_nt_well_known", _i32p), ("away_nt_cond_off", _i32p),
         ("away_cond_resource", _i32p), ("away_cond_op", _i32p), ("away_cond_value", _i64p), ("resource_unit", _i64p),
+        ("floating_resource_limit", _i64p), ("floating_counts_in_total", C.c_uint8), ("pad4_", C.c_uint8 * 7),
+        ("max_new_job_scheduling_duration_ns", C.c_int64), ("max_new_job_scheduling_duration_per_queue_ns", C.c_int64), ("clock_step_ns", C.c_int64),
     ]
 
 
@@ -161,6 +167,7 @@ ALL_SYMBOLS = [
     "get_alloc", "get_scheduled_at_priority", "iterate_nodes", "fit_select_batch", "drf_cost", "fair_shares",
     "round_prepare", "schedule_round", "schedule_queues", "gang_schedule", "round_counters", "job_key_unfeasible", "kernel_times", "round_stats",
     "clear_allocated", "submit_check", "pq_order", "submit_stats", "num_nodes", "total_resources", "node_types_matching_job", "scheduling_order",
+    "set_deadline", "cancel", "indexed_node_label_values", "get_node_jobs", "get_nodes_alloc", "node_upsert",
 ]
 
 
@@ -243,6 +250,12 @@ class Library:
         f("submit_stats", C.c_int32, [C.c_void_p, _i32p])
         f("num_nodes", C.c_int32, [C.c_void_p])
         f("scheduling_order", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int32])
+        f("set_deadline", C.c_int32, [C.c_void_p, C.c_double])
+        f("cancel", C.c_int32, [C.c_void_p])
+        f("indexed_node_label_values", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int32])
+        f("get_node_jobs", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _u8p, _i32p, C.c_int32])
+        f("get_nodes_alloc", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i64p])
+        f("node_upsert", C.c_int32, [C.c_void_p, C.c_int32, _i64p])
         f("total_resources", C.c_int32, [C.c_void_p, _i64p])
         f("node_types_matching_job", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i32p])
         f("submit_check", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i32p, _i32p, C.POINTER(CSubmitResult)])
@@ -306,6 +319,11 @@ class Config:
     # AwayNodeType.NodeTypes: per pc, per away entry (same order as pc_away): list of (well-known type, [(resource col, op, value)])
     pc_away_node_types: Optional[Sequence[Sequence[Sequence]]] = None
     resource_unit: Optional[Sequence[int]] = None                  # factory units per whole unit (cpu 1000, memory 1)
+    floating_resource_limit: Optional[Sequence[int]] = None        # [R]: pool total of a floating column, -1 = ordinary resource
+    floating_counts_in_total: bool = False
+    max_new_job_scheduling_duration_ns: int = 0
+    max_new_job_scheduling_duration_per_queue_ns: int = 0
+    clock_step_ns: int = 0
 
 
 AWAY_COND_OPS = {">": 0, "<": 1, "==": 2}
@@ -378,6 +396,12 @@ class Scheduler:
             c.away_cond_value = _ptr(k(c_val or [0], np.int64), C.c_int64)
         if cfg.resource_unit is not None:
             c.resource_unit = _ptr(k(cfg.resource_unit, np.int64), C.c_int64)
+        if cfg.floating_resource_limit is not None:
+            c.floating_resource_limit = _ptr(k(cfg.floating_resource_limit, np.int64), C.c_int64)
+        c.floating_counts_in_total = int(cfg.floating_counts_in_total)
+        c.max_new_job_scheduling_duration_ns = int(cfg.max_new_job_scheduling_duration_ns)
+        c.max_new_job_scheduling_duration_per_queue_ns = int(cfg.max_new_job_scheduling_duration_per_queue_ns)
+        c.clock_step_ns = int(cfg.clock_step_ns)
         self.h = lib.create(C.byref(c))
         if not self.h:
             raise SchedError(ERR_INVALID, "create failed (invalid config, or no gfx950 device for the HIP backend)")
@@ -597,6 +621,38 @@ class Scheduler:
         out = np.zeros((self.P, self.R), dtype=np.int64)
         self._check(self.lib.get_alloc(self.h, node, _ptr(out, C.c_int64)))
         return out
+
+    def set_deadline(self, seconds: float): self._check(self.lib.set_deadline(self.h, float(seconds)))
+    def cancel(self): self._check(self.lib.cancel(self.h))
+
+    def indexed_node_label_values(self, label_key: int):
+        """IndexedNodeLabelValues -> sorted interned values, or None when the label is not indexed"""
+        cap = max(self.num_nodes, 1)
+        out = (C.c_int32 * cap)()
+        n = self.lib.indexed_node_label_values(self.h, label_key, out, cap)
+        if n < -1:
+            self._check(n)
+        return None if n < 0 else [out[i] for i in range(min(n, cap))]
+
+    def get_node_jobs(self, node: int):
+        """GetNode: [(job, evicted, scheduled-at priority)] of the jobs holding resources on the node"""
+        cap = max(self.num_jobs, 1)
+        jobs, ev, pr = (C.c_int32 * cap)(), (C.c_uint8 * cap)(), (C.c_int32 * cap)()
+        n = self.lib.get_node_jobs(self.h, node, jobs, ev, pr, cap)
+        if n < 0:
+            self._check(n)
+        return [(jobs[i], bool(ev[i]), pr[i]) for i in range(n)]
+
+    def get_nodes_alloc(self, nodes: Optional[Sequence[int]] = None) -> np.ndarray:
+        na = None if nodes is None else _arr(nodes, np.int32)
+        n = self.num_nodes if na is None else len(na)
+        out = np.zeros((n, self.P, self.R), dtype=np.int64)
+        self._check(self.lib.get_nodes_alloc(self.h, n, _ptr(na, C.c_int32), _ptr(out, C.c_int64)))
+        return out
+
+    def node_upsert(self, node: int, alloc_by_prio):
+        a = np.ascontiguousarray(_arr(alloc_by_prio, np.int64).reshape(self.P, self.R))
+        self._check(self.lib.node_upsert(self.h, node, _ptr(a, C.c_int64)))
 
     def get_scheduled_at_priority(self, job: int):
         o, ok = C.c_int32(0), C.c_int32(0)

@@ -17,6 +17,8 @@
 //
 // There is no CPU compute path in this library: without a gfx950 device asched_create() fails.
 #include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstring>
 #include <string>
 #include <unistd.h>
 #include <vector>
@@ -74,7 +76,11 @@ __device__ static inline unsigned long long helpWait() {  // whole control wave,
     unsigned int dn = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&b->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
     if (dn == want) break;
     __builtin_amdgcn_s_sleep(1);
-    if ((++spins & 0xffff) == 0 && g_dev.progress) { g_dev.progress[5] = (int)dn; g_dev.progress[6] = g_H; g_dev.progress[7] = (int)g_gen; g_dev.progress[8] = (int)(b->cmd >> 8); g_dev.progress[9] = (int)(b->cmd & 255); }
+    if ((++spins & 0xffff) == 0 && cancelRequested(g_dev)) {  // the caller gave up (hard timeout): do not wait for a helper that may never answer
+      raise(g_dev, ASCHED_ERR_TIMEOUT, 902);
+      break;
+    }
+    if ((spins & 0xffff) == 0 && g_dev.progress) { g_dev.progress[5] = (int)dn; g_dev.progress[6] = g_H; g_dev.progress[7] = (int)g_gen; g_dev.progress[8] = (int)(b->cmd >> 8); g_dev.progress[9] = (int)(b->cmd & 255); }
   }
   return __hip_atomic_load(&b->result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -972,138 +978,186 @@ __global__ void k_drf(Dev d, const int64_t* alloc, double* out) { if (threadIdx.
 __global__ void k_fair(Dev d, const double* cds) { if (threadIdx.x == 0) updateFairShares(d, cds); }
 
 // ------------------------------------------------------------------------------------------------ platform layer
-static std::string g_err;
-static hipStream_t g_stream = nullptr;
-static bool g_inited = false;
+// Everything a handle needs from the HIP runtime lives in its PlatCtx: device ordinal, launch stream, events, the helper mailbox, the
+// host-mapped cancel word.  Handles are independent — two pools on two GPUs in one process, one thread per handle (include/armada_sched.h).
+// Every ABI entry starts with plat_enter(handle context): hipSetDevice for the calling thread (the current device is thread-local in HIP,
+// and a goroutine may run on any OS thread) and the thread-local pointer the plat_* helpers below work on.
+struct HelpBox;
+struct PlatCtx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, fitEv0 = nullptr, fitEv1 = nullptr;
+  HelpBox* helpBox = nullptr;
+  int helpers = -1, cus = 0, wallClockKHz = 100000;
+  float lastControlMs = 0.f, lastFitMs = 0.f;
+  int lastControlLaunches = 0;
+  int32_t* progress = nullptr;      // ASCHED_PROGRESS=1: host-visible heartbeat of the round kernel
+  int32_t* cancelHost = nullptr;    // host-mapped, coherent: written by the host (deadline / asched_cancel), polled by the round kernel
+  int32_t* cancelDev = nullptr;
+  double deadlineS = 0;             // maxSchedulingDuration for every following round launch; 0 = none
+  std::string err;
+  bool failed = false;              // sticky: an allocation / copy / memset failed since the last plat_take_failure()
+};
+static thread_local PlatCtx* t_ctx = nullptr;
+static std::string g_noCtxErr;
 
 static bool hipOk(hipError_t e, const char* what) {
   if (e == hipSuccess) return true;
-  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  std::string m = std::string(what) + ": " + hipGetErrorString(e);
+  if (t_ctx) { t_ctx->err = m; t_ctx->failed = true; } else g_noCtxErr = m;
   return false;
 }
-static const char* plat_last_error() { return g_err.c_str(); }
-static bool plat_init(std::string& err, int device) {
+static const char* plat_last_error() { return t_ctx ? t_ctx->err.c_str() : g_noCtxErr.c_str(); }
+// true (once) when an upload / download / memset / allocation failed since the last call: input-build entry points return ASCHED_ERR_DEVICE
+static bool plat_take_failure() { if (!t_ctx) return true; bool f = t_ctx->failed; t_ctx->failed = false; return f; }
+static void plat_enter(PlatCtx* c) { t_ctx = c; if (c) (void)hipSetDevice(c->device); }
+static PlatCtx* plat_open(std::string& err, int device) {
   int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { err = "no HIP device: libarmada_sched.so is the gfx950 implementation and has no CPU path"; return false; }
-  if (device >= n) { err = "device ordinal out of range"; return false; }
-  if (device >= 0 && hipSetDevice(device) != hipSuccess) { err = "hipSetDevice failed"; return false; }
-  if (g_inited) return true;
-  int cur = 0; (void)hipGetDevice(&cur);
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { err = "no HIP device: libarmada_sched.so is the gfx950 implementation and has no CPU path"; return nullptr; }
+  if (device >= n) { err = "device ordinal out of range"; return nullptr; }
+  if (device < 0 && hipGetDevice(&device) != hipSuccess) { err = "hipGetDevice failed"; return nullptr; }
+  if (hipSetDevice(device) != hipSuccess) { err = "hipSetDevice failed"; return nullptr; }
   hipDeviceProp_t p;
-  if (hipGetDeviceProperties(&p, cur) != hipSuccess) { err = "hipGetDeviceProperties failed"; return false; }
-  if (std::string(p.gcnArchName).find("gfx950") == std::string::npos) { err = std::string("device is ") + p.gcnArchName + ", this library is built for gfx950 only"; return false; }
-  if (hipStreamCreate(&g_stream) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
-  g_inited = true;
-  return true;
+  if (hipGetDeviceProperties(&p, device) != hipSuccess) { err = "hipGetDeviceProperties failed"; return nullptr; }
+  if (std::string(p.gcnArchName).find("gfx950") == std::string::npos) { err = std::string("device is ") + p.gcnArchName + ", this library is built for gfx950 only"; return nullptr; }
+  auto* c = new PlatCtx();
+  c->device = device;
+  c->cus = p.multiProcessorCount;
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wallClockKHz = khz;
+  bool ok = hipStreamCreate(&c->stream) == hipSuccess && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
+            hipEventCreate(&c->fitEv0) == hipSuccess && hipEventCreate(&c->fitEv1) == hipSuccess;
+  // the mailbox is written from both sides across XCDs: it must not live in an XCD-private L2 -> fine-grained (uncached, device-coherent) memory
+  ok = ok && hipExtMallocWithFlags((void**)&c->helpBox, 256, hipDeviceMallocFinegrained) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&c->cancelHost, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+  if (ok) { *c->cancelHost = 0; ok = hipHostGetDevicePointer((void**)&c->cancelDev, c->cancelHost, 0) == hipSuccess; }
+  if (!ok) { err = "HIP resource creation failed (stream / events / mailbox / cancel word)"; delete c; return nullptr; }
+  // helper workgroups of a round launch: one per CU, an eighth of the device by default — measured flat between 15 and 63 (ASCHED_HELPERS overrides; 0 = none)
+  c->helpers = c->cus >= 16 ? c->cus / 8 - 1 : 0;
+  if (const char* e = getenv("ASCHED_HELPERS")) c->helpers = atoi(e);
+  if (c->helpers > c->cus - 1) c->helpers = c->cus - 1;
+  if (c->helpers < 0) c->helpers = 0;
+  if (getenv("ASCHED_PROGRESS")) {
+    if (hipHostMalloc((void**)&c->progress, 64 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) c->progress = nullptr;
+    if (c->progress) for (int i = 0; i < 64; i++) c->progress[i] = 0;
+  }
+  t_ctx = c;
+  return c;
 }
+static void plat_close(PlatCtx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+  for (hipEvent_t e : {c->ev0, c->ev1, c->fitEv0, c->fitEv1}) if (e) (void)hipEventDestroy(e);
+  if (c->helpBox) (void)hipFree(c->helpBox);
+  if (c->cancelHost) (void)hipHostFree(c->cancelHost);
+  if (c->progress) (void)hipHostFree(c->progress);
+  if (t_ctx == c) t_ctx = nullptr;
+  delete c;
+}
+static int plat_wall_clock_khz() { return t_ctx ? t_ctx->wallClockKHz : 100000; }
+static void plat_set_deadline(double s) { if (t_ctx) t_ctx->deadlineS = s > 0 ? s : 0; }
+static void plat_cancel(PlatCtx* c) { if (c && c->cancelHost) __atomic_store_n(c->cancelHost, 1, __ATOMIC_RELEASE); }  // any thread: a plain store to host memory
 static void* plat_malloc(size_t n) { void* p = nullptr; if (!hipOk(hipMalloc(&p, n), "hipMalloc")) return nullptr; return p; }
 static void plat_free(void* p) { if (p) (void)hipFree(p); }
-static void plat_memset(void* p, int v, size_t n) { (void)hipMemsetAsync(p, v, n, g_stream); }
-static void plat_h2d(void* d, const void* s, size_t n) { (void)hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, g_stream); (void)hipStreamSynchronize(g_stream); }
-static void plat_d2h(void* d, const void* s, size_t n) { (void)hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, g_stream); (void)hipStreamSynchronize(g_stream); }
+static void plat_memset(void* p, int v, size_t n) { if (!p) { hipOk(hipErrorInvalidValue, "memset of a failed allocation"); return; } hipOk(hipMemsetAsync(p, v, n, t_ctx->stream), "hipMemsetAsync"); }
+static void plat_h2d(void* d, const void* s, size_t n) {
+  if (!d) { hipOk(hipErrorInvalidValue, "upload into a failed allocation"); return; }
+  if (hipOk(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, t_ctx->stream), "hipMemcpyAsync (h2d)")) hipOk(hipStreamSynchronize(t_ctx->stream), "h2d sync");
+}
+static void plat_d2h(void* d, const void* s, size_t n) {
+  if (!s) { hipOk(hipErrorInvalidValue, "download from a failed allocation"); std::memset(d, 0, n); return; }
+  if (hipOk(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, t_ctx->stream), "hipMemcpyAsync (d2h)")) hipOk(hipStreamSynchronize(t_ctx->stream), "d2h sync");
+}
 
 // device time of the last control-kernel launch (HIP events recorded on the launch stream) — bench.py's roofline input
-static float g_lastControlMs = 0.f;
-static int g_lastControlLaunches = 0;
-static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
-static double plat_last_control_ms() { return (double)g_lastControlMs; }
-static int plat_last_control_launches() { return g_lastControlLaunches; }
+static double plat_last_control_ms() { return t_ctx ? (double)t_ctx->lastControlMs : 0.0; }
+static int plat_last_control_launches() { return t_ctx ? t_ctx->lastControlLaunches : 0; }
 
-static HelpBox* g_helpBox = nullptr;
-static int g_helpers = -1;
 extern "C" int asched_internal_aux_launch(const Dev* dev, int cmd, hipStream_t stream, void* helpBox);  // armada_sched_aux.hip
 static int plat_run_control(Dev& dev, int cmd) {
-  if (!g_ev0) { (void)hipEventCreate(&g_ev0); (void)hipEventCreate(&g_ev1); }
-  if (g_helpers < 0) {  // helper workgroups of a round launch: one per CU, an eighth of the device by default — measured flat between 15 and 63 (ASCHED_HELPERS overrides; 0 = none)
-    int cus = 0, dev_id = 0;
-    (void)hipGetDevice(&dev_id);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
-    g_helpers = cus >= 16 ? cus / 8 - 1 : 0;
-    if (const char* e = getenv("ASCHED_HELPERS")) g_helpers = atoi(e);
-    if (g_helpers > cus - 1) g_helpers = cus - 1;
-    if (g_helpers < 0) g_helpers = 0;
-    // the mailbox is written from both sides across XCDs: it must not live in an XCD-private L2 -> fine-grained (uncached, device-coherent) memory
-    if (!hipOk(hipExtMallocWithFlags((void**)&g_helpBox, sizeof(HelpBox), hipDeviceMallocFinegrained), "help box")) return -1;
-  }
-  int H = (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY) ? g_helpers : 0;
-  static int32_t* progress = nullptr;   // ASCHED_PROGRESS=1: host-visible heartbeat of the round kernel, printed once a second (debugging aid)
-  static bool wantProgress = getenv("ASCHED_PROGRESS") != nullptr;
-  if (wantProgress && !progress) {
-    if (hipHostMalloc((void**)&progress, 64 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) progress = nullptr;
-    if (progress) for (int i = 0; i < 64; i++) progress[i] = 0;
-  }
-  dev.progress = (cmd == CMD_ROUND && progress) ? progress : nullptr;
-  if (!hipOk(hipMemsetAsync(g_helpBox, 0, sizeof(HelpBox), g_stream), "help box reset")) return -1;
-  (void)hipEventRecord(g_ev0, g_stream);
+  PlatCtx* c = t_ctx;
+  if (c->failed) return -1;  // an earlier upload failed: the kernel would read unset pointers
+  static_assert(sizeof(HelpBox) <= 256, "mailbox allocation");
+  bool isRound = cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY;
+  int H = isRound ? c->helpers : 0;
+  dev.progress = (cmd == CMD_ROUND && c->progress) ? c->progress : nullptr;
+  dev.cancel = c->cancelDev;
+  if (!hipOk(hipMemsetAsync(c->helpBox, 0, sizeof(HelpBox), c->stream), "help box reset")) return -1;
+  (void)hipEventRecord(c->ev0, c->stream);
   if (cmd >= CMD_AUX_FIRST) {  // submit-check commands: their kernel lives in its own code object (armada_sched_aux.hip)
-    if (asched_internal_aux_launch(&dev, cmd, g_stream, g_helpBox)) { g_err = "k_control_aux launch failed"; return -1; }
+    if (asched_internal_aux_launch(&dev, cmd, c->stream, c->helpBox)) { c->err = "k_control_aux launch failed"; return -1; }
   } else
-  hipLaunchKernelGGL(k_control, dim3(1 + H), dim3(CTL_THREADS), 0, g_stream, dev, cmd, g_helpBox, H);
-  (void)hipEventRecord(g_ev1, g_stream);
+  hipLaunchKernelGGL(k_control, dim3(1 + H), dim3(CTL_THREADS), 0, c->stream, dev, cmd, c->helpBox, H);
+  (void)hipEventRecord(c->ev1, c->stream);
   if (!hipOk(hipGetLastError(), "k_control launch")) return -1;
-  if (dev.progress) {
+  if (dev.progress || (isRound && c->deadlineS > 0)) {
+    // hard timeout (scheduling_algo.go:130-134): the kernel polls the cancel word; the host sets it when the deadline passes
+    auto t0 = std::chrono::steady_clock::now();
     int ticks = 0;
-    while (hipStreamQuery(g_stream) == hipErrorNotReady) {
-      usleep(100000);
-      if (++ticks % 10 == 0) { fprintf(stderr, "[asched progress] t=%ds iterations=%d generic=%d phase=%d op=%d ops=%d | wait: done=%d H=%d gen=%d box.gen=%d box.op=%d | helpers:", ticks / 10, progress[0], progress[4], progress[1], progress[2], progress[3], progress[5], progress[6], progress[7], progress[8], progress[9]); for (int i = 17; i < 56; i++) fprintf(stderr, " %x", progress[i]); fprintf(stderr, "\n"); }
+    volatile int32_t* progress = c->progress;
+    while (hipStreamQuery(c->stream) == hipErrorNotReady) {
+      usleep(dev.progress ? 100000 : 100);
+      double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (isRound && c->deadlineS > 0 && el > c->deadlineS) plat_cancel(c);
+      if (dev.progress && ++ticks % 10 == 0) { fprintf(stderr, "[asched progress] t=%ds iterations=%d generic=%d phase=%d op=%d ops=%d | wait: done=%d H=%d gen=%d box.gen=%d box.op=%d | helpers:", ticks / 10, progress[0], progress[4], progress[1], progress[2], progress[3], progress[5], progress[6], progress[7], progress[8], progress[9]); for (int i = 17; i < 56; i++) fprintf(stderr, " %x", progress[i]); fprintf(stderr, "\n"); }
     }
   }
-  if (!hipOk(hipStreamSynchronize(g_stream), "k_control")) return -1;
-  (void)hipEventElapsedTime(&g_lastControlMs, g_ev0, g_ev1);
-  g_lastControlLaunches = 1;
+  if (!hipOk(hipStreamSynchronize(c->stream), "k_control")) return -1;
+  if (isRound) __atomic_store_n(c->cancelHost, 0, __ATOMIC_RELEASE);  // a cancel request is consumed by the round it hit (or the next one, if it came between rounds)
+  (void)hipEventElapsedTime(&c->lastControlMs, c->ev0, c->ev1);
+  c->lastControlLaunches = 1;
   return 0;
 }
 static int plat_build_base(Dev& d) {
   int N = d.cfg.N;
   int nb2 = 64; while (nb2 < N) nb2 <<= 1;
-  hipLaunchKernelGGL(k_base_fill, dim3((nb2 + 255) / 256), dim3(256), 0, g_stream, d, nb2);
+  hipLaunchKernelGGL(k_base_fill, dim3((nb2 + 255) / 256), dim3(256), 0, t_ctx->stream, d, nb2);
   unsigned long long* a = (unsigned long long*)d.baseKey;
   if (nb2 <= 4096) {
     // pad region beyond nb2 is never touched: the tile kernel is only used when the array is a multiple of 4096
-    for (int k = 2; k <= nb2; k <<= 1) for (int j = k >> 1; j > 0; j >>= 1) hipLaunchKernelGGL(k_bitonic_step, dim3((nb2 + 255) / 256), dim3(256), 0, g_stream, a, j, k);
+    for (int k = 2; k <= nb2; k <<= 1) for (int j = k >> 1; j > 0; j >>= 1) hipLaunchKernelGGL(k_bitonic_step, dim3((nb2 + 255) / 256), dim3(256), 0, t_ctx->stream, a, j, k);
   } else {
     int tiles = nb2 / 4096;
-    hipLaunchKernelGGL(k_bitonic_tile, dim3(tiles), dim3(1024), 0, g_stream, a, 2, 4096, 1);  // all steps with k <= 4096
+    hipLaunchKernelGGL(k_bitonic_tile, dim3(tiles), dim3(1024), 0, t_ctx->stream, a, 2, 4096, 1);  // all steps with k <= 4096
     for (int k = 8192; k <= nb2; k <<= 1) {
       int j = k >> 1;
-      for (; j >= 4096; j >>= 1) hipLaunchKernelGGL(k_bitonic_step, dim3((nb2 + 255) / 256), dim3(256), 0, g_stream, a, j, k);
-      hipLaunchKernelGGL(k_bitonic_tile, dim3(tiles), dim3(1024), 0, g_stream, a, k, k, 2048);      // remaining steps j = 2048..1 inside tiles
+      for (; j >= 4096; j >>= 1) hipLaunchKernelGGL(k_bitonic_step, dim3((nb2 + 255) / 256), dim3(256), 0, t_ctx->stream, a, j, k);
+      hipLaunchKernelGGL(k_bitonic_tile, dim3(tiles), dim3(1024), 0, t_ctx->stream, a, k, k, 2048);      // remaining steps j = 2048..1 inside tiles
     }
   }
-  hipLaunchKernelGGL(k_base_finish, dim3((N + 255) / 256), dim3(256), 0, g_stream, d);
+  hipLaunchKernelGGL(k_base_finish, dim3((N + 255) / 256), dim3(256), 0, t_ctx->stream, d);
   if (!hipOk(hipGetLastError(), "base build launch")) return -1;
-  if (!hipOk(hipStreamSynchronize(g_stream), "base build")) return -1;
+  if (!hipOk(hipStreamSynchronize(t_ctx->stream), "base build")) return -1;
   return 0;
 }
 static int plat_run_shape_mask(Dev& d, const uint64_t* classMask, const int32_t* shapeClass) {
   size_t total = (size_t)d.cfg.S * d.cfg.W;
   if (total == 0) return 0;
-  hipLaunchKernelGGL(k_shape_mask, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, g_stream, d, classMask, shapeClass);
+  hipLaunchKernelGGL(k_shape_mask, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, t_ctx->stream, d, classMask, shapeClass);
   if (!hipOk(hipGetLastError(), "k_shape_mask launch")) return -1;
-  if (!hipOk(hipStreamSynchronize(g_stream), "k_shape_mask")) return -1;
+  if (!hipOk(hipStreamSynchronize(t_ctx->stream), "k_shape_mask")) return -1;
   return 0;
 }
 
 // kernel duration of the last fit batch, measured with HIP events on the launch stream
-static float g_lastFitMs = 0.f;
-static double plat_last_fit_ms() { return (double)g_lastFitMs; }
+static double plat_last_fit_ms() { return t_ctx ? (double)t_ctx->lastFitMs : 0.0; }
 
 static int plat_run_fit_batch(Dev& d, const std::vector<int32_t>& shapes, int level, std::vector<int32_t>& out) {
   int ns = (int)shapes.size();
   if (ns == 0) return 0;
   int32_t* dShapes = nullptr; unsigned long long* dOut = nullptr;
   if (!hipOk(hipMalloc(&dShapes, ns * sizeof(int32_t)), "hipMalloc") || !hipOk(hipMalloc(&dOut, ns * sizeof(unsigned long long)), "hipMalloc")) return -1;
-  (void)hipMemcpyAsync(dShapes, shapes.data(), ns * sizeof(int32_t), hipMemcpyHostToDevice, g_stream);
-  (void)hipMemsetAsync(dOut, 0xff, ns * sizeof(unsigned long long), g_stream);
+  (void)hipMemcpyAsync(dShapes, shapes.data(), ns * sizeof(int32_t), hipMemcpyHostToDevice, t_ctx->stream);
+  (void)hipMemsetAsync(dOut, 0xff, ns * sizeof(unsigned long long), t_ctx->stream);
   int tiles = (d.cfg.N + FIT_TILE - 1) / FIT_TILE;
   int ysplit = std::max(1, std::min(ns, (2048 + tiles - 1) / tiles));  // >= ~2048 workgroups when the node count alone cannot fill 256 CUs
-  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  (void)hipEventRecord(e0, g_stream);
-  hipLaunchKernelGGL(k_fit_batch, dim3(tiles, ysplit), dim3(FIT_TILE), 0, g_stream, d, dShapes, ns, level, dOut);
-  (void)hipEventRecord(e1, g_stream);
-  bool ok = hipOk(hipGetLastError(), "k_fit_batch launch") && hipOk(hipStreamSynchronize(g_stream), "k_fit_batch");
-  (void)hipEventElapsedTime(&g_lastFitMs, e0, e1);
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  hipEvent_t e0 = t_ctx->fitEv0, e1 = t_ctx->fitEv1;
+  (void)hipEventRecord(e0, t_ctx->stream);
+  hipLaunchKernelGGL(k_fit_batch, dim3(tiles, ysplit), dim3(FIT_TILE), 0, t_ctx->stream, d, dShapes, ns, level, dOut);
+  (void)hipEventRecord(e1, t_ctx->stream);
+  bool ok = hipOk(hipGetLastError(), "k_fit_batch launch") && hipOk(hipStreamSynchronize(t_ctx->stream), "k_fit_batch");
+  (void)hipEventElapsedTime(&t_ctx->lastFitMs, e0, e1);
   std::vector<unsigned long long> keys(ns);
   if (ok) ok = hipOk(hipMemcpy(keys.data(), dOut, ns * sizeof(unsigned long long), hipMemcpyDeviceToHost), "hipMemcpy");
   (void)hipFree(dShapes); (void)hipFree(dOut);
@@ -1120,8 +1174,8 @@ static int plat_run_drf(Dev& dev, const std::vector<int64_t>& a, const std::vect
   int64_t* da = nullptr; double* dout = nullptr;
   (void)hipMalloc(&da, MAXR * sizeof(int64_t)); (void)hipMalloc(&dout, sizeof(double));
   (void)hipMemcpy(da, a.data(), a.size() * sizeof(int64_t), hipMemcpyHostToDevice);
-  hipLaunchKernelGGL(k_drf, dim3(1), dim3(64), 0, g_stream, d, da, dout);
-  (void)hipStreamSynchronize(g_stream);
+  hipLaunchKernelGGL(k_drf, dim3(1), dim3(64), 0, t_ctx->stream, d, da, dout);
+  (void)hipStreamSynchronize(t_ctx->stream);
   (void)hipMemcpy(out, dout, sizeof(double), hipMemcpyDeviceToHost);
   (void)hipFree(da); (void)hipFree(dout);
   return 0;
@@ -1137,8 +1191,8 @@ static int plat_run_fair_shares(Dev& dev, int q, const int32_t* nameRank, const 
   (void)hipMemcpy(dw, weight, q * 8, hipMemcpyHostToDevice); (void)hipMemcpy(dcds, cds, q * 8, hipMemcpyHostToDevice);
   (void)hipMemcpy(dnr, nameRank, q * 4, hipMemcpyHostToDevice);
   d.qWeight = dw; d.qNameRank = dnr; d.qFair = df; d.qDc = ddc; d.qUc = duc; d.pqProposed = dpp; d.pqCurrent = dpc; d.pqInHeap = dih; d.itNext = dnx;
-  hipLaunchKernelGGL(k_fair, dim3(1), dim3(64), 0, g_stream, d, dcds);
-  bool ok = hipOk(hipStreamSynchronize(g_stream), "k_fair");
+  hipLaunchKernelGGL(k_fair, dim3(1), dim3(64), 0, t_ctx->stream, d, dcds);
+  bool ok = hipOk(hipStreamSynchronize(t_ctx->stream), "k_fair");
   (void)hipMemcpy(fair, df, q * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(dc, ddc, q * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(uc, duc, q * 8, hipMemcpyDeviceToHost);
   (void)hipFree(dw); (void)hipFree(df); (void)hipFree(ddc); (void)hipFree(duc); (void)hipFree(dpp); (void)hipFree(dpc); (void)hipFree(dcds);
   (void)hipFree(dnr); (void)hipFree(dnx); (void)hipFree(dih);

@@ -53,7 +53,15 @@ struct DevCfg {
   int32_t pcAwayOff[MAXPC + 1];
   int32_t awayPrio[MAXAWAY];
   uint8_t awayUsable[MAXAWAY];
+  // floating resources (floatingresources/floating_resource_types.go:60-72): pool-level quantities that are not on nodes.  A floating column
+  // never constrains a node (the node planes carry FLOATING_NODE_CAPACITY there); the gang scheduler checks sctx.Allocated against the limit
+  uint8_t isFloating[MAXR]; uint8_t anyFloating, floatingConfigured; uint8_t pad_[6];
+  int64_t floatingLimit[MAXR];
+  // soft time budgets (constraints.go:159-169): 0 = off; clockStepNs > 0 = a stepping clock (testfixtures.SteppingClock), else the device's wall clock
+  int64_t maxNewJobNs, maxNewJobPerQueueNs, clockStepNs;
+  int32_t wallClockKHz, pad2_;
 };
+#define FLOATING_NODE_CAPACITY ((int64_t)1 << 60)
 
 // One job as the fast path reads it: a single 128-byte burst (16 lanes x 8 B) instead of 12 dependent array reads.
 struct JobRec {
@@ -107,6 +115,7 @@ struct RoundScalars {
   int32_t statFastIters, statGenericIters, statScanSteps, statRefills, statL0Max, statFastReplay;
   int32_t awayRowPlus1;      // an away attempt is in progress: static mask row (+1) that replaces the job's home shape row
   int32_t fairIndexValid;    // the per-node index of the evicted table (fairOff/fairEnt) describes the current table
+  int64_t totalNewJobNs;     // sctx.TotalNewJobSchedulingTime (context/scheduling.go:212-240)
   int64_t statSeg[16];       // (profiling builds) shader-clock ticks per segment of a fast iteration
   int64_t statClk[8];        // shader-clock ticks per phase of the round (device builds): evict, replay, pass 1, oversub evict, pass 2, unbind+results
 };
@@ -227,5 +236,7 @@ struct Dev {
   const struct FastK* fk; // the fast loop's constants (round_fast.h), filled by the host at round_prepare
   QueueLoopArrays alt;    // second set for the lazy replay
   int64_t* qAllocSnap;    // [Q][R] queue allocations right after an evictor ran: what addEvictedJobsToNodeDb starts from
+  int64_t* qNewJobNs;     // [Q] qctx.TotalNewJobSchedulingTime
+  volatile int32_t* cancel;    // host-mapped word: != 0 = the caller's context is done (hard timeout / cancel, queue_scheduler.go:105-112); NULL = never
   volatile int32_t* progress;  // optional host-visible heartbeat (ASCHED_PROGRESS=1): [0] loop iterations, [1] phase, [2] current wide op, [3] wide ops issued
 };

@@ -69,6 +69,28 @@ DEV void raise(Dev& d, int code, int detail) {
   if (d.rs->error == 0) { d.rs->error = code; d.rs->errorDetail = detail; }
 }
 
+// The caller's context is done (armadacontext with maxSchedulingDuration, scheduling_algo.go:130-134; checked once per loop iteration,
+// queue_scheduler.go:105-112): the host flips a word in host-mapped memory (deadline reached, or asched_cancel from another thread).
+// A read crosses PCIe (~2 us): call sites poll it every few hundred iterations.
+DEV bool cancelRequested(const Dev& d) {
+#ifdef ASCHED_HOSTSIM
+  return d.cancel && *d.cancel != 0;
+#else
+  return d.cancel && __hip_atomic_load((const int32_t*)d.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+#endif
+}
+// sch.clock.Now() in nanoseconds for the soft time budgets (queue_scheduler.go:157, 222-228): the device's constant-rate wall clock
+DEV int64_t clockNowNs(const Dev& d) {
+#ifdef ASCHED_HOSTSIM
+  (void)d;
+  struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+#else
+  int64_t khz = d.cfg.wallClockKHz > 0 ? d.cfg.wallClockKHz : 100000;
+  return (int64_t)wall_clock64() * 1000000ll / khz;
+#endif
+}
+
 DEV int levelOf(const DevCfg& c, int32_t prio) {
   for (int i = 0; i < c.P; i++) if (c.prios[i] == prio) return i;
   return -1;
@@ -299,12 +321,28 @@ DEV int checkJob(Dev& d, int ref) {
   if (tokens < 1) return ASCHED_REASON_QUEUE_RATE_LIMIT;
   if (d.qBurst[q] < card) return ASCHED_REASON_GANG_EXCEEDS_QUEUE_BURST;
   if (tokens < (double)card) return ASCHED_REASON_QUEUE_RATE_LIMIT_BY_GANG;
+  // soft time budgets (constraints.go:159-169)
+  if (d.cfg.maxNewJobNs > 0 && d.rs->totalNewJobNs > d.cfg.maxNewJobNs) return ASCHED_REASON_GLOBAL_NEW_JOB_DURATION;
+  if (d.cfg.maxNewJobPerQueueNs > 0 && d.qNewJobNs && d.qNewJobNs[q] > d.cfg.maxNewJobPerQueueNs) return ASCHED_REASON_QUEUE_NEW_JOB_DURATION;
   int pc = d.jPc[gcJob(d, ref, 0)];
   if (d.hasPcLimit && vexceeds(d, QPV(d.qAllocByPc, q, pc), QPV(d.qPcLimit, q, pc))) return ASCHED_REASON_RESOURCE_LIMIT_EXCEEDED;
   return 0;
 }
-DEV bool isTerminal(int r) { return r == ASCHED_REASON_MAX_RESOURCES_SCHEDULED || r == ASCHED_REASON_GLOBAL_RATE_LIMIT; }
-DEV bool isQueueTerminal(int r) { return r == ASCHED_REASON_QUEUE_RATE_LIMIT || r == ASCHED_REASON_QUEUE_CORDONED; }
+// sctx.IsWithinFloatingResourceLimits (context/scheduling.go:574-597) + FloatingResourceTypes.WithinLimits (floating_resource_types.go:60-72);
+// every job of a single-pool handle is a home job
+DEV int checkFloating(Dev& d, int ref) {
+  const DevCfg& c = d.cfg;
+  if (!c.anyFloating) return 0;
+  bool requests = false;  // gctx.RequestsFloatingResources (context/gang.go:27-32)
+  int cnt = gcCount(d, ref);
+  for (int k = 0; k < cnt && !requests; k++) { const int64_t* rq = JREQ(d, gcJob(d, ref, k)); for (int r = 0; r < c.R; r++) if (c.isFloating[r] && rq[r] != 0) requests = true; }
+  if (!requests) return 0;
+  if (!c.floatingConfigured) return ASCHED_REASON_FLOATING_NOT_CONFIGURED;   // available.AllZero()
+  for (int r = 0; r < c.R; r++) if (c.isFloating[r] && d.rs->allocated[r] > c.floatingLimit[r]) return ASCHED_REASON_FLOATING_EXCEEDED;
+  return 0;
+}
+DEV bool isTerminal(int r) { return r == ASCHED_REASON_MAX_RESOURCES_SCHEDULED || r == ASCHED_REASON_GLOBAL_RATE_LIMIT || r == ASCHED_REASON_GLOBAL_NEW_JOB_DURATION; }
+DEV bool isQueueTerminal(int r) { return r == ASCHED_REASON_QUEUE_RATE_LIMIT || r == ASCHED_REASON_QUEUE_CORDONED || r == ASCHED_REASON_QUEUE_NEW_JOB_DURATION; }
 DEV bool isPropertyOfGang(int r) { return r == ASCHED_REASON_GANG_EXCEEDS_GLOBAL_BURST || r == ASCHED_REASON_JOB_DOES_NOT_FIT || r == ASCHED_REASON_GANG_DOES_NOT_FIT; }
 DEV void reserveN(double* tokens, int64_t burst, int rateInf, int n) { if (rateInf) return; if (n > burst) return; *tokens -= (double)n; }
 
@@ -323,6 +361,7 @@ struct Ctl {
   int fqLive;          // the LDS copy of the per-queue state (round_fast.h FastQueues) is the authoritative one
   int skipEnter;       // the next fast run may fold the gang-free evicted streams out of the loop (round_fast.h "skip mode")
   int skipActive;
+  int cancelSeen;      // a fast run saw the cancel word
 };
 // Less (queue_scheduler.go:738-798) as a lexicographic key (A, X, Y, then the queue-name rank); exact for finite, non-negative costs
 struct PackedKey { uint32_t A; uint64_t X, Y; };
@@ -725,6 +764,7 @@ DEV bool gangSchedule(Dev& d, Ctl& c, int ref, int* reason, const int32_t* uniOf
   bool ok = false;
   int r = 0;
   if (!allEv) r = checkJob(d, ref);
+  if (!r) r = checkFloating(d, ref);  // gang_scheduler.go:143: for evicted gangs too
   if (r) *reason = r;
   else ok = trySchedule(d, c, ref, reason, uniOff);
   if (d.rs->error) return false;
@@ -922,12 +962,16 @@ DEV void passInit(Dev& d, Ctl& c, const PassCfg& pc) {
 // QueueScheduler.Schedule (queue_scheduler.go:94-304)
 DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff) {
   bool limitHit = false, resumed = false;
+  const bool softClock = d.cfg.maxNewJobNs > 0 || d.cfg.maxNewJobPerQueueNs > 0;
+  unsigned pollCount = 0;
   for (;;) {
     if (d.rs->error) return;
+    if ((pollCount++ & 63) == 0 && cancelRequested(d)) { raise(d, ASCHED_ERR_TIMEOUT, 900); return; }  // hard timeout: abort with an error (queue_scheduler.go:105-112)
     if (!limitHit && d.rs->hasFpLimiter && d.rs->fpTokens < 1) { fastEnterGeneric(d, c); limitHit = true; costItOnlyEvicted(d, c, pc); }
     if (fastOn(d, c)) {
       int pend = fastRun(d, c, pc, 0, (int*)0);
       fastEnterGeneric(d, c);
+      if (c.cancelSeen) { raise(d, ASCHED_ERR_TIMEOUT, 901); return; }
       if (pend >= 0) { updateAndPush(d, c, pend, pc); continue; }
     }
     int top = pqTop(d, c);
@@ -944,6 +988,8 @@ DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff)
     for (int k = 0; k < cnt; k++) if (d.jcPreempted[gcJob(d, ref, k)]) hasPre = true;
     if (hasPre) { costItClear(d, c, top, pc); continue; }
     int reason;
+    bool gangAllEv = gcAllEvicted(d, ref); int gangQueue = gcQueue(d, ref);
+    int64_t tStart = (softClock && d.cfg.clockStepNs <= 0) ? clockNowNs(d) : 0;   // start := sch.clock.Now() (:157)
     bool ok = gangSchedule(d, c, ref, &reason, uniOff);
     if (d.rs->error) return;
     costItClear(d, c, top, pc);
@@ -960,7 +1006,13 @@ DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff)
       d.rs->terminationReason = reason;
       costItOnlyEvicted(d, c, pc);
     } else if (isQueueTerminal(reason)) {
-      costItOnlyEvictedForQueue(d, c, gcQueue(d, ref), pc);
+      costItOnlyEvictedForQueue(d, c, gangQueue, pc);
+    }
+    if (softClock && !gangAllEv) {  // RecordNewJobSchedulingDuration (:222-228, context/scheduling.go:212-240); a stepping clock advances once per Now()
+      int64_t dur = d.cfg.clockStepNs > 0 ? d.cfg.clockStepNs : clockNowNs(d) - tStart;
+      if (dur < 0) dur = 0;
+      d.rs->totalNewJobNs += dur;
+      if (d.qNewJobNs) d.qNewJobNs[gangQueue] += dur;
     }
     d.rs->loopIterations++;
   }

@@ -1056,6 +1056,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   }
   for (;;) {
     ENGINE_SETTLE(break)
+    if ((S.loopIterations & 511) == 0 && cancelRequested(d)) { c.cancelSeen = 1; break; }  // hard timeout / cancel: the caller raises the error
     int t = pqHead(pq, Q);
     SEG(0);
 #ifdef ASCHED_HOSTSIM

@@ -418,6 +418,7 @@ enum Cmd {
   CMD_ADD_EVICTED, CMD_RESET_EVICTED, CMD_TXN_BEGIN, CMD_TXN_COMMIT, CMD_TXN_ABORT, CMD_FIT_BATCH, CMD_UPSERT_RESET, CMD_RESET_JOBS,
   CMD_SUBMIT_CHECK,  // first command of the auxiliary kernel (k_control_aux, armada_sched_aux.hip)
   CMD_PQ_ORDER,
+  CMD_NODE_UPSERT,
 };
 #define CMD_AUX_FIRST CMD_SUBMIT_CHECK
 // cmdIO layout: [0..15] results, [16..] arguments
@@ -582,6 +583,15 @@ DEV void runAuxCommand(Dev& d, Ctl& c, int cmd) {
       }
       a.out[a.n] = agrees;
     } break;
+    case CMD_NODE_UPSERT: {  // UpsertWithTxn of one node (nodedb.go:1164-1175): new AllocatableByPriority, every order key rebuilt
+      d.rs->apiDirty = 1;
+      int n = ARG(0);
+      for (int l = 0; l < cf.P; l++) for (int r = 0; r < cf.R; r++) {
+        int k = l * cf.R + r;
+        AL(d, l, r, n) = (int64_t)(((uint64_t)(uint32_t)ARG(2 + 2 * k) << 32) | (uint32_t)ARG(1 + 2 * k));
+      }
+      updateKeysCtl(d, n);
+    } break;
     case CMD_SUBMIT_CHECK: {
       // SubmitChecker.getSchedulingResult, per-pool core (submitcheck.go:342-371), for a whole batch of units in one launch:
       // copyGangContext (fresh jctxs), nodeDb.Txn, ScheduleManyWithTxn, txn.Abort — every unit meets the same NodeDb state
@@ -624,7 +634,7 @@ DEV void controlMainAux(Dev& d, int cmd) {
   Ctl c;
   c.txn.active = d.rs->txnActive; c.fairStamp = d.rs->fairStamp; c.preList = d.preList; c.preCount = 0;
   c.skipKeyCheck = 0; c.compareSchedPrio = 0; c.preferLarge = d.cfg.preferLarge; c.useReplayAlloc = 0; c.onlyEvicted = 0;
-  c.fastEnabled = 0; c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0;
+  c.fastEnabled = 0; c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0; c.cancelSeen = 0;
   fastLoad(d);
   runAuxCommand(d, c, cmd);
   fastEnterGeneric(d, c);
@@ -636,7 +646,7 @@ DEV void controlMain(Dev& d, int cmd) {
   c.txn.active = d.rs->txnActive; c.fairStamp = d.rs->fairStamp; c.preList = d.preList; c.preCount = 0;
   c.skipKeyCheck = 0; c.compareSchedPrio = 0; c.preferLarge = d.cfg.preferLarge; c.useReplayAlloc = 0; c.onlyEvicted = 0;
   c.fastEnabled = d.f.iterOk && !d.rs->apiDirty && (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY);
-  c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0;
+  c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0; c.cancelSeen = 0;
   fastLoad(d);
   runCommand(d, c, cmd);
   fastEnterGeneric(d, c);

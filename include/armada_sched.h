@@ -54,6 +54,7 @@ extern "C" {
 #define ASCHED_ERR_UNSUPPORTED (-2)  /* feature of the reference not implemented by this backend */
 #define ASCHED_ERR_DEVICE (-3)       /* HIP runtime failure or no gfx950 device */
 #define ASCHED_ERR_INTERNAL (-4)     /* reference would return an error here (e.g. iteration loop) */
+#define ASCHED_ERR_TIMEOUT (-5)      /* the round's context was done: hard timeout or cancel (queue_scheduler.go:105-112 returns ctx.Err()); no result */
 
 /* taint effects / toleration operators (k8s core/v1), interned */
 #define ASCHED_EFFECT_NONE 0
@@ -90,6 +91,10 @@ extern "C" {
 #define ASCHED_REASON_GANG_UNIFORMITY_NO_FIT 15      /* "at least one job in the gang does not fit on any node" */
 #define ASCHED_REASON_NO_REMAINING_CANDIDATES 16      /* sctx.TerminationReason default, queue_scheduler.go:289-291 */
 #define ASCHED_REASON_SKIPPED_UNFEASIBLE_KEY 17       /* copied from the first failed job of the key, queue_scheduler.go:398-413 */
+#define ASCHED_REASON_GLOBAL_NEW_JOB_DURATION 18      /* terminal: "global new job scheduling duration exceeded" (constraints.go:39,159-163) */
+#define ASCHED_REASON_QUEUE_NEW_JOB_DURATION 19       /* queue-terminal: "queue new job scheduling duration exceeded" (constraints.go:40,165-169) */
+#define ASCHED_REASON_FLOATING_NOT_CONFIGURED 20      /* "floating resources not configured for pool" (floating_resource_types.go:62-64) */
+#define ASCHED_REASON_FLOATING_EXCEEDED 21            /* "not enough floating resource ... in pool" (floating_resource_types.go:66-69) */
 
 typedef struct asched asched_t;
 
@@ -143,6 +148,20 @@ typedef struct asched_config {
   const int64_t* away_cond_value;         /* c.Value.Value(): whole units, rounded up */
   const int64_t* resource_unit;           /* [R] factory units per whole unit (cpu: 1000, memory: 1) — jobVal.Value() rounds up to whole
                                              units (nodedb.go:634-635); NULL = 1 for every resource */
+  /* Floating resources (configuration.FloatingResourceConfig, floatingresources/floating_resource_types.go): pool-level quantities that are
+     not on nodes.  [R]: the pool's total for a floating column (>= 0), -1 for an ordinary (Kubernetes) resource; NULL = none.  Job requests
+     on a floating column count in every scheduling-context sum (AllResourceRequirements) and never constrain a node
+     (KubernetesResourceRequirements, nodematching.go:184,195); GangScheduler.Schedule checks sctx.Allocated against the limit
+     (gang_scheduler.go:143, context/scheduling.go:574-597).  A floating column cannot be indexed. */
+  const int64_t* floating_resource_limit;
+  uint8_t floating_counts_in_total;       /* 1: sctx.TotalResources = NodeDb total + floating totals (scheduling_algo.go:890); 0: NodeDb total only */
+  uint8_t pad4_[7];
+  /* Soft time budgets (constraints.go:159-169; configuration.go:190-209 MaxNewJobSchedulingDuration[PerQueue]); 0 = off.  Time spent on
+     gangs of new jobs is accumulated per round and per queue (queue_scheduler.go:222-228) from the device's wall clock; clock_step_ns > 0
+     replaces the clock by one that advances clock_step_ns per reading (testfixtures.SteppingClock, queue_scheduler_test.go:1546-1550). */
+  int64_t max_new_job_scheduling_duration_ns;
+  int64_t max_new_job_scheduling_duration_per_queue_ns;
+  int64_t clock_step_ns;
 } asched_config;
 
 /* types.AwayNodeTypeConditionOperator (internal/common/types/scheduling.go:12-16) */
@@ -207,7 +226,7 @@ typedef struct asched_jobs {
   const int32_t* pc;               /* [m] priority class index */
   const uint32_t* queue_priority;  /* [m] per-queue job priority (comparison.go:74-79) */
   const int64_t* submit_time;      /* [m] comparison.go:92-97 */
-  const int64_t* req;              /* [m][R] KubernetesResourceRequirements == AllResourceRequirements (no floating) */
+  const int64_t* req;              /* [m][R] AllResourceRequirements; floating columns (asched_config.floating_resource_limit) never reach a node */
   const int32_t* req_class;        /* [m] index into asched_req_classes */
   const int32_t* gang_id;          /* [m] -1 = not in a gang; ids are unique per (queue, gang) */
   const int32_t* gang_cardinality; /* [m] */
@@ -394,6 +413,26 @@ int32_t ASCHED_FN(kernel_times)(asched_t*, double* out /*[4]*/);
    iterations, base scan steps, window refills, max live dirty nodes (L0), fast replay steps, L0 overflows,
    fast structure active at the end, 0...}.  The CPU oracle reports zeros. */
 int32_t ASCHED_FN(round_stats)(asched_t*, int32_t* out /*[16]*/);
+/* Hard timeout of a round (maxSchedulingDuration, config/scheduler/config.yaml:83; scheduling_algo.go:130-134 wraps the context in
+   WithTimeout, queue_scheduler.go:105-112 checks ctx.Done() every loop iteration and returns ctx.Err()).  asched_set_deadline: every
+   following schedule_round / schedule_queues is cancelled `seconds` after it starts (0 = none).  asched_cancel = the context's cancel
+   function: callable from ANY thread while a round is in flight; between rounds it hits the next one ("context already done").  A
+   cancelled round returns ASCHED_ERR_TIMEOUT, delivers no result (scheduling_algo.go:262-270 applies nothing on error) and leaves the
+   handle unprepared: round_prepare builds the next round from scratch. */
+int32_t ASCHED_FN(set_deadline)(asched_t*, double seconds);
+int32_t ASCHED_FN(cancel)(asched_t*);
+/* IndexedNodeLabelValues (nodedb.go:340-343): values of an indexed node label present on the nodes (ascending interned id).
+   Returns their number, or -1 when the label is not indexed (ok == false). */
+int32_t ASCHED_FN(indexed_node_label_values)(asched_t*, int32_t label_key, int32_t* out_values, int32_t cap);
+/* GetNode / GetNodeWithTxn (nodedb.go:358-394), the mutable part of *Node: jobs holding resources on the node (AllocatedByJobId), their
+   evicted flag (EvictedJobRunIds) and scheduled-at priority; any out pointer may be NULL.  Returns the number of jobs on the node. */
+int32_t ASCHED_FN(get_node_jobs)(asched_t*, int32_t node, int32_t* out_jobs, uint8_t* out_evicted, int32_t* out_priority, int32_t cap);
+/* GetNodes / GetNodesWithTxn (nodedb.go:396-415): AllocatableByPriority of n nodes ([n][P][R]) in one download; nodes == NULL: all n == NumNodes nodes */
+int32_t ASCHED_FN(get_nodes_alloc)(asched_t*, int32_t n, const int32_t* nodes, int64_t* out);
+/* Upsert / UpsertWithTxn of one node (nodedb.go:1154-1175): replaces the node's AllocatableByPriority ([P][R]) and rebuilds its order key
+   at every priority.  Job bookkeeping travels through bind / evict / unbind. */
+int32_t ASCHED_FN(node_upsert)(asched_t*, int32_t node, const int64_t* alloc_by_prio);
+
 /* 1 if the job's scheduling key is registered in sctx.UnfeasibleSchedulingKeys (gang_scheduler.go:80-95) */
 int32_t ASCHED_FN(job_key_unfeasible)(asched_t*, int32_t job, int32_t* out);
 

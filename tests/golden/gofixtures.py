@@ -116,6 +116,9 @@ class GoConfig(dict):
             dict.__setitem__(self, "maximum_scheduling_burst", int(v))
         elif k == "MaximumSchedulingRate":
             dict.__setitem__(self, "maximum_scheduling_rate", float(v))
+        elif k == "FloatingResources":   # []configuration.FloatingResourceConfig{{Name, Pools: [{Name, Quantity}]}} -> {resource: {pool: factory units}}
+            dict.__setitem__(self, "floating_resources",
+                             {f["Name"]: {p["Name"]: int(round(quantity(p["Quantity"]) * SCALE[f["Name"]])) for p in f.get("Pools", [])} for f in v})
         elif k[:1].isupper():
             raise Unsupported(f"assignment to SchedulingConfig.{k}")
         else:
@@ -145,6 +148,9 @@ class PodReqs(dict):
         elif k2 == k and k[:1].isupper():
             raise Unsupported(f"assignment to PodRequirements.{k}")
         dict.__setitem__(self, k2, v)
+
+
+TestFloatingResourceConfig = [{"Name": "test-floating-resource", "Pools": [{"Name": "pool", "Quantity": "10"}]}]   # testfixtures.go:64-74
 
 
 def TestSchedulingConfig():  # testfixtures.go:225-249

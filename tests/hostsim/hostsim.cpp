@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <time.h>
 #include "../../armada_amd/csrc/round_run.h"
 // optional per-primitive wall-clock profile of the serial build (HOSTSIM_PROF=1): where would a wide device primitive matter?
 struct HsProf { double t[40]; long n[40]; bool on; HsProf() : on(getenv("HOSTSIM_PROF") != nullptr) { for (int i = 0; i < 40; i++) { t[i] = 0; n[i] = 0; } }
@@ -80,19 +81,32 @@ DEV int pqTop(Dev& d, const Ctl& c) {
 
 // ---- platform layer
 static std::string g_err;
+struct PlatCtx { int32_t cancelWord = 0; double deadlineS = 0; };   // per handle, like the device build's (stream / events / mailbox there)
+static thread_local PlatCtx* t_ctx = nullptr;
 static void* plat_malloc(size_t n) { return malloc(n); }
 static void plat_free(void* p) { free(p); }
 static void plat_memset(void* p, int v, size_t n) { memset(p, v, n); }
 static void plat_h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
 static void plat_d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
-static bool plat_init(std::string&, int) { return true; }
+static PlatCtx* plat_open(std::string&, int) { t_ctx = new PlatCtx(); return t_ctx; }
+static void plat_close(PlatCtx* c) { if (t_ctx == c) t_ctx = nullptr; delete c; }
+static void plat_enter(PlatCtx* c) { t_ctx = c; }
+static bool plat_take_failure() { return false; }
+static int plat_wall_clock_khz() { return 100000; }
+static void plat_set_deadline(double s) { if (t_ctx) t_ctx->deadlineS = s; }
+static void plat_cancel(PlatCtx* c) { if (c) __atomic_store_n(&c->cancelWord, 1, __ATOMIC_RELEASE); }
 static double plat_last_control_ms() { return 0; }
 static int plat_last_control_launches() { return 0; }
 static double plat_last_fit_ms() { return 0; }
 static const char* plat_last_error() { return g_err.c_str(); }
 static int plat_run_control(Dev& dev, int cmd) {
   Dev d = dev;
+  d.cancel = &t_ctx->cancelWord;
+  // the serial build cannot be interrupted from its own thread: a deadline of <= 1 us stands for "already expired" (tests), asched_cancel from
+  // another thread works as on the device
+  if ((cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY) && t_ctx->deadlineS > 0 && t_ctx->deadlineS <= 1e-6) t_ctx->cancelWord = 1;
   if (cmd >= CMD_AUX_FIRST) controlMainAux(d, cmd); else controlMain(d, cmd);
+  if (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY) t_ctx->cancelWord = 0;
   return 0;
 }
 // sorted base of the level-0 fast structure (round_fast.h): the device build sorts with a bitonic network

@@ -90,6 +90,9 @@ class Case:
             max_queue_lookback=cfg["max_queue_lookback"],
             max_fraction_to_schedule=[float(inf(frac.get(r, "inf"))) for r in RES],
             disallowed_resource=[int(r in (cfg.get("disallowed_resources") or [])) for r in RES],
+            # FloatingResources: the pool's total per floating column (the scheduling context of the Go drivers is for pool "pool"), -1 = ordinary
+            floating_resource_limit=([int((cfg["floating_resources"].get(r) or {}).get(pool_limit_key, 0)) if r in cfg["floating_resources"] else -1 for r in RES]
+                                     if cfg.get("floating_resources") else None),
         )
         self.sched = Scheduler(lib, self.config)
         self.nodes = nodes
@@ -199,8 +202,8 @@ def uses_unsupported(case: dict, jobs: List[dict]) -> str:
     for j in jobs:
         if any(op not in AFFINITY_OPS for term in (j.get("affinity") or []) for _, op, _ in term):
             return "node affinity operator Gt / Lt"
-        if "test-floating-resource" in j["req"]:
-            return "floating resources"
+        if "test-floating-resource" in j["req"] and "test-floating-resource" not in (case["SchedulingConfig"].get("floating_resources") or {}):
+            return "floating resource requested without FloatingResources in the config"
     return ""
 
 
