@@ -554,7 +554,7 @@ __device__ static inline void pqHeadKey(PQState& s, int t, PackedKey* key, uint3
 __device__ static inline void engineStart(Dev& d, FastS& S) {
   (void)d;
   S.engSeq = 0;
-  if ((threadIdx.x & 63) == 0) { g_fl.eng.seq = 0; g_fl.eng.ack = 0; g_fl.eng.statScan = 0; g_fl.eng.statL0Max = S.statL0Max; g_fl.eng.busyClk = 0; g_fl.eng.jobs = 0; g_mb.op = OP_ENGINE; }
+  if ((threadIdx.x & 63) == 0) { g_fl.eng.seq = 0; g_fl.eng.ack = 0; g_fl.eng.statScan = 0; g_fl.eng.statL0Max = S.statL0Max; g_fl.eng.busyClk = 0; g_fl.eng.jobs = 0; g_fl.eng.cancel = 0; g_mb.op = OP_ENGINE; }
   __syncthreads();
 }
 __device__ static inline void engineStop(Dev& d, FastS& S) {
@@ -580,7 +580,7 @@ __device__ static void engineLoop(Dev& d) {  // wave 1
   ES.tP0 = -1; ES.engLive = 0; ES.engPend = -1;
   ES.laneL = lane / (k.R > 0 ? k.R : 1); ES.laneX = lane % (k.R > 0 ? k.R : 1);
   ES.statScanSteps = 0; ES.statL0Max = __builtin_amdgcn_readfirstlane(g_fl.eng.statL0Max);
-  ES.fastActive = 1;
+  ES.fastActive = 1; ES.engSeq = 0;
   long long busy = 0; int jobs = 0;
   int seen = 0;
   for (;;) {

@@ -58,6 +58,9 @@ DEV void fastHeadInvalidate(int q);
 DEV void fastPassReset();
 DEV bool fastOn(Dev& d, const Ctl& c);
 DEV void fastEnterGeneric(Dev& d, Ctl& c);
+DEV bool fastGangMember(Dev& d, Ctl& c, int job);  // select (fit at priority -2) + bind of one unpinned queued gang member through the fast structure; false = not done
+DEV bool fastWorthTrying(Dev& d);                  // some head could take a fast iteration at all
+DEV void fastFence(Ctl& c);
 DEV void ensureReplay(Dev& d, Ctl& c);             // run the deferred eviction-order replay before anything reads the evicted table         // leave fast mode: LDS queue state back into the generic arrays, HBM updates visible
 
 // ------------------------------------------------------------------------------------------------
@@ -662,10 +665,15 @@ DEV bool scheduleMany(Dev& d, Ctl& c, int ref) {
   for (int k = 0; k < cnt; k++) {
     int job = gcJob(d, ref, k);
     d.jcReason[job] = 0;
+    // the common member: a queued job that fits without preemption.  SelectNodeForJobWithTxn's first step and BindJobToNode through the
+    // level-0 fast structure (lane-parallel atomics + the undo record an abort needs); anything else — no fit at priority -2, pinned,
+    // uniformity selector, away attempt — falls through to the generic cascade on the state this leaves
+    if (cnt > 1 && fastGangMember(d, c, job)) continue;
+    fastFence(c);
     int pre0 = c.preCount;
     int n = selectNodeForJob(d, c, job);
     if (d.rs->error) return false;
-    if (n < 0) return false;
+    if (n < 0) return false;   // (fenced above: the abort's undo reads what the fast members wrote)
     int pre1 = c.preCount;
     for (int i = pre0; i < pre1; i++) removeJob(d, n, c.preList[i], true);  // victims leave the returned node copy (nodedb.go:1012-1023)
     int32_t prio = d.pcSap[job];
@@ -678,6 +686,7 @@ DEV bool scheduleMany(Dev& d, Ctl& c, int ref) {
     preemptSiblings(d, c, pre0, pre1);
     for (int i = pre0; i < c.preCount; i++) d.jcStagedBy[c.preList[i]] = job;
   }
+  fastFence(c);  // the fast members' binds are no-return atomics: visible to whatever reads the planes next (commit bookkeeping, abort's undo)
   return true;
 }
 
@@ -968,7 +977,7 @@ DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff)
     if (d.rs->error) return;
     if ((pollCount++ & 63) == 0 && cancelRequested(d)) { raise(d, ASCHED_ERR_TIMEOUT, 900); return; }  // hard timeout: abort with an error (queue_scheduler.go:105-112)
     if (!limitHit && d.rs->hasFpLimiter && d.rs->fpTokens < 1) { fastEnterGeneric(d, c); limitHit = true; costItOnlyEvicted(d, c, pc); }
-    if (fastOn(d, c)) {
+    if (fastOn(d, c) && fastWorthTrying(d)) {
       int pend = fastRun(d, c, pc, 0, (int*)0);
       fastEnterGeneric(d, c);
       if (c.cancelSeen) { raise(d, ASCHED_ERR_TIMEOUT, 901); return; }

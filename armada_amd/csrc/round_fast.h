@@ -60,7 +60,7 @@ struct alignas(16) EngineBox {
   int32_t job, prio, cutoff, nl, cmd, status;
   int32_t seq, ack;                          // command n is ready when seq == n; served when ack == n
   int32_t statScan, statL0Max;               // engine counters, handed over at ENG_QUIT
-  int64_t busyClk; int32_t jobs, pad_;       // shader-clock ticks the engine spent serving jobs, and how many
+  int64_t busyClk; int32_t jobs, cancel;     // shader-clock ticks the engine spent serving jobs, and how many; cancel: the engine saw the caller's cancel word
 };
 struct alignas(16) IterBackup {  // the job's record and request stay in the mailbox (the engine only reads them)
   QHot hot;
@@ -569,6 +569,46 @@ DEV bool fastAfterBind(KREF k, FastS& S, const JobTail& r, int n, const FitHandl
   return true;
 }
 
+// scheduleMany's fast member (round_ctl.h): a queued, unpinned job of a gang attempt.  Runs on the control wave in generic mode (no node
+// engine session is live there), on the authoritative HBM state: first fit at priority -2 through base cursor + L0, bind as lane-parallel
+// no-return atomics, the job's result fields, the U_ADD undo record (a gang that does not fit is aborted, gang_scheduler.go:234-243; the
+// undo path runs fastTouch on the node, which repairs L0 / base flags), L0 upkeep.
+DEV bool fastGangMember(Dev& d, Ctl& c, int job) {
+  if (!d.f.structOk || !RS.fastActive || d.cfg.disableHome || !d.jrec) return false;
+  if (d.jcPreempted[job] || d.jcAssigned[job] >= 0 || d.jcUniValue[job] >= 0 || RS.awayRowPlus1) return false;
+  if (d.schedAtPrio[job] != NO_PRIORITY || d.jobNode[job] >= 0) return false;   // already mapped to a priority / holding resources: the generic code knows the rules
+  const FastK k = fastKRef(d);
+  JobRec jr = d.jrec[job];
+  JobTail r; memcpy(&r, &jr.keyDelta, sizeof r);
+  uniJobTail(r);
+  if (r.never) return false;
+  if (k.anyDisallowed) for (int x = 0; x < k.R; x++) if (d.cfg.disallowed[x] && jr.req[x] > 0) return false;
+  FastS S; S.statScanSteps = 0; S.tP0 = -1; S.statL0Max = RS.statL0Max;
+  S.laneL = FLANE / (k.R > 0 ? k.R : 1); S.laneX = FLANE % (k.R > 0 ? k.R : 1);
+  FitHandle h; h.src = 0; h.slot = -1;
+  CandRec cand; cand.pos = 0; cand.node = -1; cand.key = 0; cand.cls = 0; cand.ex0 = cand.ex1 = 0; cand.pad = 0;
+  int n = fastFirstFit(k, S, r, &h, &cand);
+  RS.statScanSteps += S.statScanSteps;
+  if (n < 0) return false;   // feasibility gate, preemption, away node types: the generic cascade (it counts its own queries)
+  RS.numNodeQueries++;
+  int32_t prio = r.pcPrio, cutoff = r.preemptible ? prio : NONPREEMPTIBLE_CUTOFF;
+  int32_t oldCutoff = d.jobCutoff[job];
+  FOR_LANES(x, MAXR) FL.eng.req[x] = x < k.R ? jr.req[x] : 0;   // the engine mailbox is free outside an engine session: the bind reads the request from it
+  bindUpdateEng(k, S, n, r.nlPc, r.keyDelta);
+  if (FLANE == 0) {
+    k.jcHasPctx[job] = 1; k.pcNode[job] = n; k.pcSap[job] = prio; k.pcPap[job] = ASCHED_EVICTED_PRIORITY; k.pcMethod[job] = ASCHED_METHOD_NO_PREEMPTION;
+    k.jobNode[job] = n; k.jobCutoff[job] = cutoff; k.schedAtPrio[job] = prio;
+  }
+  if (c.txn.active) undoPush(d, U_ADD, job, n, oldCutoff);
+  if (!fastAfterBind(k, S, r, n, h, cand)) fastDrop(d);
+  if (S.statL0Max > RS.statL0Max) RS.statL0Max = S.statL0Max;
+  c.l1Dirty = 1;
+  return true;
+}
+// no head can take a fast iteration once jobs carry preempted marks (evicted heads need the per-job check of the generic code) and the
+// level-0 structure is gone (queued heads need it): skip the hand-over in and out of the fast loop
+DEV bool fastWorthTrying(Dev& d) { (void)d; return !(RS.numPreemptedMarks != 0 && !RS.fastActive); }
+
 // ------------------------------------------------------------------------------------------------ launch persistence
 DEV void fastLoad(Dev& d) {  // kernel start: rebuild the LDS side from HBM
   FL.l0Count = 0;
@@ -697,7 +737,10 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
 // BindJobToNode (nodedb.go:1046-1068), the job's result fields, level-0 bookkeeping.  0 = does not fit (nothing touched),
 // 1 = bound, 2 = bound and the L0 list overflowed (the caller drops the structure).
 DEV int engineServe(Dev& d, KREF k, FastS& ES) {
-  (void)d;
+  // hard timeout / cancel (queue_scheduler.go:105-112): the node engine has the slack of the two waves, so IT reads the host-mapped word (every
+  // 256 jobs; a read crosses PCIe) and answers "no node" without touching anything: the control wave takes the iteration back, leaves the fast
+  // loop, finds the flag and raises ASCHED_ERR_TIMEOUT.  The control wave's loop carries no extra instruction for this.
+  if ((++ES.engSeq & 255) == 0 && cancelRequested(d)) { if (FLANE == 0) FL.eng.cancel = 1; return 0; }
   JobTail r = FL.eng.tail;
   uniJobTail(r);
   int job = UNI32(FL.eng.job), nl = UNI32(FL.eng.nl);
@@ -718,7 +761,7 @@ DEV int engineServe(Dev& d, KREF k, FastS& ES) {
 // serial build: the engine runs at post time; the control code still proceeds on the assumption that the job fits and takes the
 // iteration back at the next settle point when it did not — the same control flow as on the device
 static FastS g_engS;
-DEV void engineStart(Dev&, FastS& S) { g_engS = S; g_engS.statScanSteps = 0; }
+DEV void engineStart(Dev&, FastS& S) { g_engS = S; g_engS.statScanSteps = 0; g_engS.engSeq = 0; FL.eng.cancel = 0; }
 DEV void engineStop(Dev&, FastS& S) { S.statScanSteps += g_engS.statScanSteps; if (g_engS.statL0Max > S.statL0Max) S.statL0Max = g_engS.statL0Max; }
 DEV void enginePost(Dev& d, KREF k, FastS& S, int job, int q, int pc, int32_t prio, int32_t cutoff, int nl) {
   IterBackup& b = FL.bk;
@@ -752,13 +795,13 @@ DEV void qlPutWin(int q, const QHot& f) { QHot& o = FL.hot[q]; o.winKind = f.win
 // 2 = done, but the queue's next head must be produced by the generic updateAndPush.  Fast mode only.
 DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* ko) {
   int q = top;
-  if (S.numPreemptedMarks != 0 || k.hasPcLimit) return 0;  // per-job preempted flags / per-queue caps: generic
+  if (k.hasPcLimit) return 0;  // per-queue per-priority-class caps: generic
   QHot f = FL.hot[q];
   uniQHot(f);
   int job = f.gctx;
   if (f.headFast && f.headKind == 2) {  // evicted job with precomputed costs
     SEG(1);
-    if (!(fc.evStatic && S.lvl0NonNeg)) return 0;  // generic (it re-reads everything from HBM; pending commits are flushed on the way)
+    if (!(fc.evStatic && S.lvl0NonNeg) || S.numPreemptedMarks != 0) return 0;  // generic (it re-reads everything from HBM; pending commits are flushed on the way); preempted jobs are skipped there (queue_scheduler.go:150-156)
     f.evDone = f.headPos + 1;  // served; its commit is deferred (applyEvictedRange)
     return fastAdvance(d, k, S, fc, q, f, ko) ? 1 : 2;
   }
@@ -831,7 +874,7 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
   } else {
     // nodedb.go:897-906: alloc[level] >= alloc[-2] + req >= req on every column while no priority -2 column is negative
     // (bucket arithmetic, DESIGN.md "Evicted jobs always return")
-    if (!fc.evStatic || !S.lvl0NonNeg) return 0;
+    if (!fc.evStatic || !S.lvl0NonNeg || S.numPreemptedMarks != 0) return 0;   // a queued job is never in sctx.PreemptedJobIds; an evicted one may be
     prio = r.runPrio; n = r.node0;
     if (f.evApplied < f.evDone) { applyEvictedRange(d, q, f.evApplied, f.evDone); S.numEvictedJobs -= f.evDone - f.evApplied; }
     f.evApplied = f.evDone = f.headPos + 1;  // committed right here
@@ -1056,7 +1099,6 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   }
   for (;;) {
     ENGINE_SETTLE(break)
-    if ((S.loopIterations & 511) == 0 && cancelRequested(d)) { c.cancelSeen = 1; break; }  // hard timeout / cancel: the caller raises the error
     int t = pqHead(pq, Q);
     SEG(0);
 #ifdef ASCHED_HOSTSIM
@@ -1086,7 +1128,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   }
   ENGINE_SETTLE((void)0)
 #undef ENGINE_SETTLE
-  if (S.engLive) { engineStop(d, S); S.engLive = 0; }
+  if (S.engLive) { engineStop(d, S); S.engLive = 0; if (UNI32(FL.eng.cancel)) c.cancelSeen = 1; }
 #ifndef ASCHED_FASTPROF
   if (FLANE == 0 && S.engWaitClk) RS.statSeg[0] += S.engWaitClk;
 #endif

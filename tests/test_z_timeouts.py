@@ -169,3 +169,25 @@ def test_deadline_cancels_a_long_round_in_flight(hip_lib, oracle_lib):
     o = W.load(oracle_lib, wl)
     W.prepare(o, wl)
     scenario.assert_same_round(o.schedule_round(), got)
+
+
+@pytest.mark.gpu
+def test_deadline_cancels_a_fast_path_round_in_flight(hip_lib, oracle_lib):
+    """the same on a round that runs almost entirely on the fast path (BASELINE configs[2]'s shape): there the node engine wave polls the
+    cancel word, answers "no node", and the control wave leaves the fast loop through its ordinary roll-back"""
+    import time
+    wl = W.config3(n_nodes=50_000, n_jobs=500_000, n_queues=64, seed=W.SEED)
+    wl.global_burst, wl.queue_burst = 100_000, 10_000
+    s = W.load(hip_lib, wl)
+    W.prepare(s, wl)
+    t0 = time.perf_counter(); full = s.schedule_round(); t_full = time.perf_counter() - t0
+    W.prepare(s, wl)
+    s.set_deadline(t_full / 4)
+    t0 = time.perf_counter()
+    with pytest.raises(SchedError) as e:
+        s.schedule_round()
+    dt = time.perf_counter() - t0
+    assert e.value.code == ERR_TIMEOUT and dt < 0.75 * t_full, (dt, t_full)
+    s.set_deadline(0)
+    W.prepare(s, wl)
+    scenario.assert_same_round(full, s.schedule_round())
