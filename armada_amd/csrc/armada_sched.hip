@@ -698,6 +698,19 @@ __device__ static inline bool headRequestsDisallowed(Dev& d, KREF k, int q) {
   return __ballot(bad) != 0;
 }
 
+// pinned-node check of a returning evicted job against the node's current allocatable (nodedb.go:897-906): one lane per resource; the planes are
+// updated by no-return atomics that execute at L2, so the reads go there too (agent-scope atomic loads, never the L1)
+__device__ static inline bool pinnedNodeFits(KREF k, int q, int n, int level) {
+  int lane = threadIdx.x & 63;
+  if (UNI32((int)k.nodeFlags[n]) & 1) return true;
+  bool bad = false;
+  if (lane < k.R) {
+    int64_t have = __hip_atomic_load(&KAL(k, level, lane, n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bad = g_fl.headReq[q][lane] > have;
+  }
+  return __ballot(bad) == 0;
+}
+
 // ------------------------------------------------------------------------------------------------ LDS residency of the round's small state
 // Every per-queue array and the scheduling-context scalars are moved into LDS for the duration of the launch by
 // re-pointing the Dev descriptor (which itself lives in LDS): generic and fast code alike then pay LDS latency for them.

@@ -59,7 +59,6 @@ DEV void fastPassReset();
 DEV bool fastOn(Dev& d, const Ctl& c);
 DEV void fastEnterGeneric(Dev& d, Ctl& c);
 DEV bool fastGangMember(Dev& d, Ctl& c, int job);  // select (fit at priority -2) + bind of one unpinned queued gang member through the fast structure; false = not done
-DEV bool fastWorthTrying(Dev& d);                  // some head could take a fast iteration at all
 DEV void fastFence(Ctl& c);
 DEV void ensureReplay(Dev& d, Ctl& c);             // run the deferred eviction-order replay before anything reads the evicted table         // leave fast mode: LDS queue state back into the generic arrays, HBM updates visible
 
@@ -973,14 +972,22 @@ DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff)
   bool limitHit = false, resumed = false;
   const bool softClock = d.cfg.maxNewJobNs > 0 || d.cfg.maxNewJobPerQueueNs > 0;
   unsigned pollCount = 0;
+  int fastSkip = 0, fastStreak = 0;
   for (;;) {
     if (d.rs->error) return;
     if ((pollCount++ & 63) == 0 && cancelRequested(d)) { raise(d, ASCHED_ERR_TIMEOUT, 900); return; }  // hard timeout: abort with an error (queue_scheduler.go:105-112)
     if (!limitHit && d.rs->hasFpLimiter && d.rs->fpTokens < 1) { fastEnterGeneric(d, c); limitHit = true; costItOnlyEvicted(d, c, pc); }
-    if (fastOn(d, c) && fastWorthTrying(d)) {
+    // A fast run that ends without a single fast iteration (the head is a gang, a job that needs preemption, ...) costs a hand-over in and
+    // out of the fast loop for nothing: after such a run the next ones are skipped, doubling up to 32 generic iterations, until one makes
+    // progress again.  Skipping is always exact — the generic code handles every iteration.
+    if (fastOn(d, c) && fastSkip > 0) fastSkip--;
+    else if (fastOn(d, c)) {
+      int before = d.rs->statFastIters + d.rs->loopIterations;
       int pend = fastRun(d, c, pc, 0, (int*)0);
       fastEnterGeneric(d, c);
       if (c.cancelSeen) { raise(d, ASCHED_ERR_TIMEOUT, 901); return; }
+      if (d.rs->statFastIters + d.rs->loopIterations == before && pend < 0) { if (fastStreak < 5) fastStreak++; fastSkip = (1 << fastStreak) - 1; }
+      else fastStreak = 0;
       if (pend >= 0) { updateAndPush(d, c, pend, pc); continue; }
     }
     int top = pqTop(d, c);

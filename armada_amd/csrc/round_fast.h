@@ -179,6 +179,8 @@ struct FastK {
   GP(int32_t) schedAtPrio; GP(uint8_t) inSchedAndEvicted; GP(uint8_t) inPreempted; GP(uint8_t) inScheduled; GP(uint8_t) jobFlags;
   GP(uint8_t) evTabAlive; GP(int32_t) evTabJob; GP(int32_t) evIndexOfJob; GP(uint8_t) unfeasible;
   GP(int64_t) qAllocByPc; GP(int64_t) qSchedByPc; GP(int64_t) qEvictedByPc;
+  GP(uint8_t) jcPreempted; GP(uint8_t) nodeFlags;
+  int32_t prios[MAXP];
 };
 // scheduling-context scalars the loop reads and writes (context/scheduling.go:27-77), written back to RS at the end of a run
 struct FastS {
@@ -220,6 +222,8 @@ HD void fastKInit(const Dev& d, FastK& k) {
   k.inScheduled = GA(uint8_t, d.inScheduled); k.jobFlags = GA(uint8_t, d.jobFlags);
   k.evTabAlive = GA(uint8_t, d.evTabAlive); k.evTabJob = GA(int32_t, d.evTabJob); k.evIndexOfJob = GA(int32_t, d.evIndexOfJob); k.unfeasible = GA(uint8_t, d.unfeasible);
   k.qAllocByPc = GA(int64_t, d.qAllocByPc); k.qSchedByPc = GA(int64_t, d.qSchedByPc); k.qEvictedByPc = GA(int64_t, d.qEvictedByPc);
+  k.jcPreempted = GA(uint8_t, d.jcPreempted); k.nodeFlags = GA(uint8_t, d.nodeFlags);
+  for (int i = 0; i < MAXP; i++) k.prios[i] = i < c.P ? c.prios[i] : INT32_MAX;
 }
 // a register copy of the constants: one burst of scalar loads (constant address space) per call, then no memory traffic
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -434,6 +438,12 @@ DEV void engineRestore(int q) {
   FL.kA[q] = b.kA; FL.kX[q] = b.kX; FL.kY[q] = b.kY; FL.effA[q] = b.effA; FL.effX[q] = b.effX; FL.effY[q] = b.effY;
   FL.inHeap[q] = b.inHeap;
 }
+// an evicted job's pinned-node check (nodedb.go:897-906) against the node's CURRENT allocatable at the job's priority: head request of queue q
+DEV bool pinnedNodeFits(KREF k, int q, int n, int level) {
+  if (k.nodeFlags[n] & 1) return true;   // unschedulable && overAllocated: always allowed back (:902-903)
+  for (int x = 0; x < k.R; x++) if (FL.headReq[q][x] > KAL(k, level, x, n)) return false;
+  return true;
+}
 DEV void pqHeadKey(PQState&, int t, PackedKey* key, uint32_t* nameRank) { key->A = FL.kA[t]; key->X = FL.kX[t]; key->Y = FL.kY[t]; *nameRank = (uint32_t)FL.nameRank[t]; }
 #else  // device versions: armada_sched.hip
 struct PQState { uint32_t A, N; unsigned long long X, Y; int q; int count; };  // lane i: the i-th queue in heap order
@@ -462,6 +472,7 @@ DEV void pqHeadKey(PQState& s, int t, PackedKey* key, uint32_t* nameRank);
 DEV void engineStart(Dev& d, FastS& S);
 DEV void engineStop(Dev& d, FastS& S);
 DEV bool headRequestsDisallowed(Dev& d, KREF k, int q);
+DEV bool pinnedNodeFits(KREF k, int q, int n, int level);
 #endif
 DEV void candInvalidate(int S, int n) { FOR_LANES(s, S) if (FL.cand[s].node == n) FL.cand[s].node = -2; }
 DEV void candResetAll(Dev& d, const int32_t* pos) { FOR_LANES(s, d.cfg.S < SMAX ? d.cfg.S : SMAX) { FL.cand[s].node = -2; FL.cand[s].pos = pos ? pos[s] : 0; } }
@@ -574,6 +585,9 @@ DEV bool fastAfterBind(KREF k, FastS& S, const JobTail& r, int n, const FitHandl
 // no-return atomics, the job's result fields, the U_ADD undo record (a gang that does not fit is aborted, gang_scheduler.go:234-243; the
 // undo path runs fastTouch on the node, which repairs L0 / base flags), L0 upkeep.
 DEV bool fastGangMember(Dev& d, Ctl& c, int job) {
+#ifdef ASCHED_HOSTSIM
+  if (getenv("HS_NO_GANG_FAST")) return false;
+#endif
   if (!d.f.structOk || !RS.fastActive || d.cfg.disableHome || !d.jrec) return false;
   if (d.jcPreempted[job] || d.jcAssigned[job] >= 0 || d.jcUniValue[job] >= 0 || RS.awayRowPlus1) return false;
   if (d.schedAtPrio[job] != NO_PRIORITY || d.jobNode[job] >= 0) return false;   // already mapped to a priority / holding resources: the generic code knows the rules
@@ -605,10 +619,6 @@ DEV bool fastGangMember(Dev& d, Ctl& c, int job) {
   c.l1Dirty = 1;
   return true;
 }
-// no head can take a fast iteration once jobs carry preempted marks (evicted heads need the per-job check of the generic code) and the
-// level-0 structure is gone (queued heads need it): skip the hand-over in and out of the fast loop
-DEV bool fastWorthTrying(Dev& d) { (void)d; return !(RS.numPreemptedMarks != 0 && !RS.fastActive); }
-
 // ------------------------------------------------------------------------------------------------ launch persistence
 DEV void fastLoad(Dev& d) {  // kernel start: rebuild the LDS side from HBM
   FL.l0Count = 0;
@@ -648,13 +658,15 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
       }
       if (kind < 0 && !(f.itJobOnlyEv || !fc.withQueued) && f.itQi < f.qEnd) { kind = 1; pos = f.itQi; end = f.qEnd; }
       if (kind < 0) { f.gctx = -1; f.proposed = f.current = f.size = 0; break; }
-      if (kind == 0 && !fc.evStatic && !fc.replay) generic = true;  // evicted this round after being scheduled: node / priority are not the job's static run
     }
     if (!generic && kind == 1 && f.evApplied < f.evDone) {  // first queued job after cheap evicted ones: their commits feed the queue's allocation
       applyEvictedRange(d, q, f.evApplied, f.evDone);
       S.numEvictedJobs -= f.evDone - f.evApplied; f.evApplied = f.evDone;
     }
-    if (!generic && kind == 0 && f.evCheap) {  // costs precomputed for the whole evicted stream (B_EVKEYS): no job record, no DRF evaluation
+    // costs precomputed for the whole evicted stream (B_EVKEYS): no job record, no DRF evaluation.  They assume that every earlier evicted job of
+    // the queue came back — true while evicted jobs always return; after a preemption-based bind an evicted job may fail or be skipped as
+    // preempted, and the costs are evaluated from the queue's actual allocation again (window path below)
+    if (!generic && kind == 0 && f.evCheap && (fc.replay || (S.lvl0NonNeg && S.numPreemptedMarks == 0 && fc.evStatic))) {  // (the replay places every evicted job by definition)
       if (!(pos >= f.ewStart && pos < f.ewStart + f.ewCount)) {
         int cnt = end - pos; if (cnt > WIN) cnt = WIN;
         evWinRefill(k, q, pos, cnt);
@@ -709,7 +721,9 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
     pr = UNID(pr); cu = UNID(cu); sz = UNID(sz);
     SEG(5);
     int32_t p = UNI32(FL.winRec[q][w].pcPrio);
-    int32_t sp = kind == 0 ? UNI32(FL.winRec[q][w].runPrio) : p;  // evicted: run.ScheduledAtPriority (queue_scheduler.go:660-672)
+    // schedulingPriority (queue_scheduler.go:660-672): pctx.ScheduledAtPriority | run.ScheduledAtPriority | PC priority.  An evicted job's jctx is
+    // fresh (no pctx, eviction.go:246-253); it has a run unless it was scheduled in this very round (phase-3 eviction of a new job)
+    int32_t sp = (kind == 0 && UNI32(FL.winRec[q][w].node0) >= 0) ? UNI32(FL.winRec[q][w].runPrio) : p;
     f.proposed = pr; f.current = cu; f.size = sz; f.pcPrio = p; f.schedPrio = sp;
     *ko = packItemKeys(fc.preferLarge, q, fc.compareSchedPrio ? sp : p, pr, cu, sz, f.budget);
     if (f.effValid) {  // skip mode: a head cannot be served before anything that precedes it in its queue (heap merge == order by running maximum)
@@ -815,6 +829,7 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
   int n;
   FitHandle h; h.src = 0; h.slot = -1;
   CandRec cand; cand.pos = 0; cand.node = -1; cand.key = 0; cand.cls = 0; cand.ex0 = cand.ex1 = 0; cand.pad = 0;
+  bool evInRound = true, wasPre = true; int evNl = 0; int32_t evCutoff = 0; (void)evCutoff;
   if (!ev) {
     if (!S.fastActive) return 0;
     if (k.anyRoundLimit && roundLimitExceeded(d, k)) return 0;  // CheckRoundConstraints (constraints.go:113-119)
@@ -872,20 +887,43 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
     }
     S.numNodeQueries++;
   } else {
-    // nodedb.go:897-906: alloc[level] >= alloc[-2] + req >= req on every column while no priority -2 column is negative
-    // (bucket arithmetic, DESIGN.md "Evicted jobs always return")
-    if (!fc.evStatic || !S.lvl0NonNeg || S.numPreemptedMarks != 0) return 0;   // a queued job is never in sctx.PreemptedJobIds; an evicted one may be
+    // An evicted job returns to its node (nodedb.go:583-594, dynamic check only :897-906).  Phase-1 evictions while no priority -2 column
+    // is negative: alloc[level] >= alloc[-2] + req >= req on every column (bucket arithmetic, DESIGN.md "Evicted jobs always return"), no
+    // node read.  Otherwise — a preemption-based bind overdrew some priority -2 column, or the job was evicted by the oversubscribed evictor
+    // (pass 2: node / priority / bookkeeping are this round's, not the original run's) — the node's current allocatable is read.
     prio = r.runPrio; n = r.node0;
+#ifdef ASCHED_HOSTSIM
+    if (getenv("HS_NO_DYN_EV") && (!fc.evStatic || !S.lvl0NonNeg || S.numPreemptedMarks != 0)) return 0;
+    if (getenv("HS_NO_DYN_EV2") && !fc.evStatic) return 0;
+    if (getenv("HS_NO_DYN_EV3") && fc.evStatic && (!S.lvl0NonNeg || S.numPreemptedMarks != 0)) return 0;
+#endif
+    if (!fc.evStatic) {
+      n = UNI32(k.jcAssigned[job]); prio = UNI32(k.schedAtPrio[job]);
+      evInRound = (UNI32((int)k.jobFlags[job]) & F_EVICTED) != 0; wasPre = UNI32((int)k.inPreempted[job]) != 0;
+      if (n < 0 || prio == NO_PRIORITY) return 0;
+    }
+    if (S.numPreemptedMarks != 0 && UNI32((int)k.jcPreempted[job]) != 0) return 0;  // a preempted job is skipped by the generic loop (queue_scheduler.go:150-156); a queued job never carries the mark
+    if (!fc.evStatic || !S.lvl0NonNeg) {
+      int level = -1;
+      for (int l = 0; l < MAXP; l++) if (l < k.P && k.prios[l] == prio) level = l;
+      if (level < 0) return 0;
+      if (!pinnedNodeFits(k, q, n, level)) return 0;  // does not fit any more: the generic code records the failure
+      evCutoff = r.preemptible ? prio : NONPREEMPTIBLE_CUTOFF;
+      evNl = 0;
+      for (int l = 0; l < MAXP; l++) if (l < k.P && k.prios[l] <= evCutoff) evNl = l + 1;   // levels with priority <= cutoff (sorted ascending)
+    } else evNl = r.nlRun;
     if (f.evApplied < f.evDone) { applyEvictedRange(d, q, f.evApplied, f.evDone); S.numEvictedJobs -= f.evDone - f.evApplied; }
     f.evApplied = f.evDone = f.headPos + 1;  // committed right here
   }
   SEG(2);
-  // ---- commit: sctx.AddGangSchedulingContext (scheduling.go:391-434)
-  accountVectors(d, k, q, pcx, ev, false);
-  if (ev) S.numEvictedJobs--; else { S.numScheduledJobs++; S.numScheduledGangs++; }
+  // ---- commit: sctx.AddGangSchedulingContext (scheduling.go:391-434).  A job that was scheduled or rescheduled earlier in this round and then
+  // evicted by the oversubscribed evictor does not carry the "evicted in this round" mark (sctx.EvictJob, :551-572): it is accounted like a new job
+  bool evAcct = ev && evInRound;
+  accountVectors(d, k, q, pcx, evAcct, false);
+  if (evAcct) S.numEvictedJobs--; else { S.numScheduledJobs++; S.numScheduledGangs++; }
   // ---- SelectNodeForJobWithTxn result + BindJobToNode (nodedb.go:538-630, 1046-1068)
   int32_t cutoff = r.preemptible ? prio : NONPREEMPTIBLE_CUTOFF;
-  int nl = ev ? r.nlRun : r.nlPc;
+  int nl = ev ? evNl : r.nlPc;
   bool nodeSideHere = ev || !fc.engine;  // a queued job's bind, result fields and L0 upkeep are the node engine's in two-wave mode
   if (nodeSideHere) bindUpdate(k, S, n, ev ? 1 : 0, nl, q, r.keyDelta);  // evicted job: level -2 gets -req (bind) and +req (un-evict): unchanged (node.go:416-442)
   if (nodeSideHere && FLANE == 0) {
@@ -893,7 +931,8 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
     k.jobNode[job] = n; k.jobCutoff[job] = cutoff; k.schedAtPrio[job] = prio;
     if (ev) {
       k.jcReason[job] = 0; k.jobEvictedOnNode[job] = 0; k.inSchedAndEvicted[job] = 0;
-      k.pcPap[job] = prio; k.pcMethod[job] = ASCHED_METHOD_RESCHEDULED; k.jobFlags[job] = F_RESCHEDULED; k.inPreempted[job] = 0;
+      k.pcPap[job] = prio; k.pcMethod[job] = ASCHED_METHOD_RESCHEDULED; k.jobFlags[job] = evInRound ? F_RESCHEDULED : F_SUCCESSFUL;
+      if (wasPre) k.inPreempted[job] = 0; else k.inScheduled[job] = 1;   // pqs.go:160-166 / :213-220
       if (!S.replayPending) { k.evTabAlive[f.headIdx] = 0; k.evIndexOfJob[job] = -1; }  // nodedb.go:441-446 (a deferred replay marks it dead itself)
     } else {  // jcReason, jobEvictedOnNode, inSchedAndEvicted are still 0 for a queued job
       k.pcPap[job] = ASCHED_EVICTED_PRIORITY; k.pcMethod[job] = ASCHED_METHOD_NO_PREEMPTION; k.jobFlags[job] = F_SUCCESSFUL; k.inScheduled[job] = 1;
