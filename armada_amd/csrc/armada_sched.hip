@@ -105,9 +105,25 @@ __device__ static inline unsigned long long waveMin64(unsigned long long v) {
 // one thread per node (block-stride): reject by mask bit and key first, touch the alloc planes only for improving candidates
 __device__ static unsigned long long scanPart(const Dev& d, const ScanArgs& a, int tid, int nthreads) {
   const DevCfg& c = d.cfg;
+  unsigned long long best = ~0ull;
+  if (a.levelHi > a.level) {  // multi-level mode: per node the lowest level in [level, levelHi] it fits at, tagged key
+    for (int n = tid; n < c.N; n += nthreads) {
+      uint64_t w = a.maskA[n >> 6];
+      if (a.maskB) w &= a.maskB[n >> 6];
+      if (!((w >> (n & 63)) & 1)) continue;
+      for (int l = a.level; l <= a.levelHi; l++) {
+        unsigned long long v = ((unsigned long long)l << SCAN_LEVEL_SHIFT) | d.keys[(size_t)l * c.Npad + n];
+        if (v >= best) break;   // higher levels only order later
+        const int64_t* plane = d.alloc + (size_t)l * c.R * c.Npad;
+        bool fits = true;
+        for (int r = 0; r < c.R; r++) fits = fits && (a.req[r] <= plane[(size_t)r * c.Npad + n]);
+        if (fits) { best = v; break; }
+      }
+    }
+    return waveMin64(best);
+  }
   const uint64_t* keys = d.keys + (size_t)a.level * c.Npad;
   const int64_t* plane = d.alloc + (size_t)a.level * c.R * c.Npad;
-  unsigned long long best = ~0ull;
   for (int n = tid; n < c.N; n += nthreads) {
     uint64_t w = a.maskA[n >> 6];
     if (a.maskB) w &= a.maskB[n >> 6];
@@ -121,7 +137,7 @@ __device__ static unsigned long long scanPart(const Dev& d, const ScanArgs& a, i
   return waveMin64(best);
 }
 
-__device__ static inline int wgFirstFit(Dev& d, const ScanArgs& a) {
+__device__ static inline uint64_t wgFirstFitKey(Dev& d, const ScanArgs& a) {
   int lane = threadIdx.x & 63;
   if (lane == 0) { g_mb.op = OP_SCAN; g_mb.scan = a; if (g_H) helpIssue(OP_SCAN, &a); }
   __syncthreads();
@@ -136,6 +152,10 @@ __device__ static inline int wgFirstFit(Dev& d, const ScanArgs& a) {
     best = hb < best ? hb : best;
   }
   d.rs->numScans++;
+  return best;
+}
+__device__ static inline int wgFirstFit(Dev& d, const ScanArgs& a) {
+  unsigned long long best = wgFirstFitKey(d, a);
   if (best == ~0ull) return -1;
   return d.nodeByRank[best & ((1ull << d.cfg.idxBits) - 1)];
 }

@@ -82,6 +82,7 @@ struct EvKey { double proposed, current, size; int32_t pcPrio; int32_t job; };
 struct FastCfg {
   int structOk, iterOk;       // host-verified exactness conditions (asched_host.inc: fastConditions)
   int relocAll;               // ASCHED_RELOC_ALL=1: stage the per-queue arrays in LDS for any Q (default: only Q <= 64, see armada_sched.hip relocateIn)
+  int cascadeFuse;            // the gate + urgency sweep of one job may run as ONE multi-level plane pass (round_ctl.h selectAtPriority): planes are monotone in the level (no explicit alloc_by_prio, non-negative requests) and a level tag fits above the packed key
   int engine;                 // queued-job iterations run on two waves (round_fast.h "two-wave iteration"); ASCHED_ENGINE=0 turns it off
   int E; int extraCol[MAXE];  // non-indexed columns
   uint64_t fieldMask[MAXK];   // in-place mask of each packed key field

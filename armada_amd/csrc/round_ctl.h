@@ -29,13 +29,18 @@
 
 // ------------------------------------------------------------------------------------------------
 // workgroup primitives (implemented differently per build)
-struct ScanArgs { int64_t req[MAXR]; const uint64_t* maskA; const uint64_t* maskB; int level; int noFit; uint64_t lowBound; };  // min key >= lowBound among masked nodes (that fit req at level, unless noFit)
+// min key >= lowBound among masked nodes (that fit req at level, unless noFit).  levelHi > level: multi-level mode — per node the LOWEST level in
+// [level, levelHi] at which it fits, result = min over nodes of (that level << 60 | key at that level): the urgency sweep and the feasibility gate
+// of one job in one pass over the planes (selectAtPriority)
+struct ScanArgs { int64_t req[MAXR]; const uint64_t* maskA; const uint64_t* maskB; int level; int noFit; uint64_t lowBound; int32_t levelHi, pad; };
+#define SCAN_LEVEL_SHIFT 60
 
 struct FairArgs { int64_t req[MAXR]; const uint64_t* maskA; const uint64_t* maskB; int32_t prio; int32_t pad; };
 #define FAIR_CHUNKS 256
 #define FAIR_BAD_ENTRY 0x7ffffff0   // an alive table entry without a scheduled-at priority was met (nodedb.go:950-953)
 
 DEV int wgFirstFit(Dev& d, const ScanArgs& a);                       // -> node or -1
+DEV uint64_t wgFirstFitKey(Dev& d, const ScanArgs& a);               // -> the raw minimum (~0 = none): packed key, in multi-level mode tagged with the level
 DEV int wgFairSelect(Dev& d, const FairArgs& a);                     // -> evicted-table Index or -1 (max over nodes of fairNodeBest)
 DEV int atomicFetchAddI32(int32_t* p, int32_t v);
 template <class F> DEV void wgForEach(Dev& d, int n, F f);           // f(i) for i in [0,n), then workgroup barrier
@@ -424,7 +429,7 @@ DEV void litAdvance(Dev& d, int level, LitIt& it, const int64_t* ireq) {
     if (it.bound == ~0ull) { it.head = -1; return; }
     ScanArgs a;
     for (int r = 0; r < MAXR; r++) a.req[r] = 0;
-    a.maskA = d.typeMask + (size_t)it.type * c.W; a.maskB = nullptr; a.level = level; a.noFit = 1; a.lowBound = it.bound;
+    a.maskA = d.typeMask + (size_t)it.type * c.W; a.maskB = nullptr; a.level = level; a.noFit = 1; a.lowBound = it.bound; a.levelHi = 0; a.pad = 0;
     int n = wgFirstFit(d, a);
     if (n < 0) { it.head = -1; return; }
     uint64_t key = KEY(d, level, n);
@@ -495,7 +500,7 @@ DEV int selectAtLevel(Dev& d, int job, int32_t prio) {
   for (int r = 0; r < MAXR; r++) a.req[r] = r < d.cfg.R ? req[r] : 0;
   a.maskA = shapeMaskOf(d, job);
   a.maskB = uniMask(d, job);
-  a.level = level; a.noFit = 0; a.lowBound = 0;
+  a.level = level; a.noFit = 0; a.lowBound = 0; a.levelHi = 0; a.pad = 0;
   long long t0 = CLK();
   if (d.progress) { d.progress[2] = 1; d.progress[3]++; }
   int n = wgFirstFit(d, a);
@@ -574,9 +579,43 @@ DEV int selectWithFairPreemption(Dev& d, Ctl& c, int job) {
 }
 
 // selectNodeForJobWithTxnAtPriority (nodedb.go:724-789)
+//
+// The feasibility gate (fit at the job's priority) and the urgency sweep (:805-838: fit at -1, 0, ... up to the job's priority, first level with a
+// node wins) look at the same planes.  A bind subtracts a job's requests from every level up to its cutoff, so with non-negative requests and
+// no hand-written AllocatableByPriority a node's allocatable is non-decreasing in the level: a node that fits at level l fits at every level
+// above.  Hence "first level with any fitting node, then the minimum key at that level" == the minimum over nodes of (lowest level the node
+// fits at, its key at that level), and the gate is "is there any such node".  ONE multi-level pass (ScanArgs.levelHi) answers both; the
+// fair-share attempt in between changes nothing when it fails.  Query counts are kept as the level-by-level loop would have issued them.
 DEV int selectAtPriority(Dev& d, Ctl& c, int job) {
   int n = selectAtLevel(d, job, ASCHED_EVICTED_PRIORITY);
   if (n >= 0) { d.pcMethod[job] = ASCHED_METHOD_NO_PREEMPTION; return n; }
+  int row = d.rs->awayRowPlus1 ? d.rs->awayRowPlus1 - 1 : d.jShape[job];
+  int lp = levelOf(d.cfg, d.pcSap[job]);
+  if (d.f.cascadeFuse && lp >= 1 && !(d.rowLiteral && d.rowLiteral[row])) {
+    ScanArgs a;
+    const int64_t* req = JREQ(d, job);
+    for (int r = 0; r < MAXR; r++) a.req[r] = r < d.cfg.R ? req[r] : 0;
+    a.maskA = shapeMaskOf(d, job); a.maskB = uniMask(d, job);
+    a.level = 1; a.levelHi = lp; a.noFit = 0; a.lowBound = 0; a.pad = 0;
+    if (lp == 1) { a.level = 1; a.levelHi = 0; }   // one level: the plain pass
+    long long t0 = CLK();
+    uint64_t best = wgFirstFitKey(d, a);
+    d.rs->statClk[6] += CLK() - t0;
+    d.rs->numNodeQueries++;                          // the gate
+    if (best == ~0ull) return -1;
+    d.pcNode[job] = -1; d.pcPap[job] = ASCHED_MIN_PRIORITY;
+    if (!d.cfg.disableFair) {
+      n = selectWithFairPreemption(d, c, job);
+      if (n >= 0) { d.pcMethod[job] = ASCHED_METHOD_FAIRSHARE; return n; }
+    }
+    d.pcNode[job] = -1; d.pcPap[job] = ASCHED_MIN_PRIORITY;
+    if (d.cfg.disableUrgency) return -1;
+    int l = lp == 1 ? 1 : (int)(best >> SCAN_LEVEL_SHIFT);
+    d.rs->numNodeQueries += l;                       // levels 1 .. l of the sweep
+    n = d.nodeByRank[best & ((1ull << d.cfg.idxBits) - 1)];
+    d.pcNode[job] = n; d.pcPap[job] = d.cfg.prios[l]; d.pcMethod[job] = ASCHED_METHOD_URGENCY;
+    return n;
+  }
   n = selectAtLevel(d, job, d.pcSap[job]);  // feasibility gate
   if (n < 0) return -1;
   d.pcNode[job] = -1; d.pcPap[job] = ASCHED_MIN_PRIORITY;

@@ -902,12 +902,41 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
       evInRound = (UNI32((int)k.jobFlags[job]) & F_EVICTED) != 0; wasPre = UNI32((int)k.inPreempted[job]) != 0;
       if (n < 0 || prio == NO_PRIORITY) return 0;
     }
-    if (S.numPreemptedMarks != 0 && UNI32((int)k.jcPreempted[job]) != 0) return 0;  // a preempted job is skipped by the generic loop (queue_scheduler.go:150-156); a queued job never carries the mark
+    if (S.numPreemptedMarks != 0 && UNI32((int)k.jcPreempted[job]) != 0) {
+      // a job preempted earlier in this round is skipped: Clear() + continue, no scheduling attempt, not a counted iteration
+      // (queue_scheduler.go:150-156); a queued job never carries the mark
+      if (f.evApplied < f.evDone) { applyEvictedRange(d, q, f.evApplied, f.evDone); S.numEvictedJobs -= f.evDone - f.evApplied; }
+      f.evApplied = f.evDone = f.headPos + 1;
+      return (fastAdvance(d, k, S, fc, q, f, ko) ? 1 : 2) | 4;
+    }
     if (!fc.evStatic || !S.lvl0NonNeg) {
       int level = -1;
       for (int l = 0; l < MAXP; l++) if (l < k.P && k.prios[l] == prio) level = l;
       if (level < 0) return 0;
-      if (!pinnedNodeFits(k, q, n, level)) return 0;  // does not fit any more: the generic code records the failure
+      if (!pinnedNodeFits(k, q, n, level)) {
+        // The job does not fit on its node any more (urgency preemption took the space): SelectNodeForJobWithTxn returns no node,
+        // the gang fails with "job does not fit on any node" (gang_scheduler.go:229-262, 63-98).  Net effect of AddGangSchedulingContext /
+        // EvictGang / re-add-as-failed on the scheduling context (scheduling.go:391-449, 551-572; queue.go:231-265, 351-386): the job's
+        // "evicted in this round" mark goes (its requests leave EvictedResourcesByPriorityClass), it is recorded unsuccessful; every
+        // other sum is back where it was.  No unfeasible-key registration: an evicted job's key is not valid (context/job.go:104-109).
+        if (f.evApplied < f.evDone) { applyEvictedRange(d, q, f.evApplied, f.evDone); S.numEvictedJobs -= f.evDone - f.evApplied; }
+        f.evApplied = f.evDone = f.headPos + 1;
+        if (evInRound) FOR_LANES(x, k.R) {
+          int64_t v = FL.headReq[q][x];
+          if (v) {
+#ifdef ASCHED_HOSTSIM
+            k.qEvictedByPc[((size_t)q * k.npc + pcx) * k.R + x] -= v;
+#else
+            __hip_atomic_fetch_add(&k.qEvictedByPc[((size_t)q * k.npc + pcx) * k.R + x], -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+          }
+        }
+        if (FLANE == 0) {
+          k.jcHasPctx[job] = 1; k.pcNode[job] = -1; k.pcSap[job] = prio; k.pcPap[job] = ASCHED_MIN_PRIORITY; k.pcMethod[job] = ASCHED_METHOD_NONE;
+          k.jcReason[job] = ASCHED_REASON_JOB_DOES_NOT_FIT; k.jobFlags[job] = F_UNSUCCESSFUL;
+        }
+        return fastAdvance(d, k, S, fc, q, f, ko) ? 1 : 2;
+      }
       evCutoff = r.preemptible ? prio : NONPREEMPTIBLE_CUTOFF;
       evNl = 0;
       for (int l = 0; l < MAXP; l++) if (l < k.P && k.prios[l] <= evCutoff) evNl = l + 1;   // levels with priority <= cutoff (sorted ascending)
@@ -1162,8 +1191,8 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
     if (st == 0) break;
     pqPopPush(pq, ko, t);
     SEG(7);
-    if (!mode) { S.loopIterations++; S.statFastIters++; }
-    if (st == 2) { pend = t; break; }  // refK / refN: the entry just served
+    if (!mode) { if (!(st & 4)) S.loopIterations++; S.statFastIters++; }
+    if ((st & 3) == 2) { pend = t; break; }  // refK / refN: the entry just served
   }
   ENGINE_SETTLE((void)0)
 #undef ENGINE_SETTLE

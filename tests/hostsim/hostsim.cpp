@@ -36,7 +36,7 @@ DEV int wgFairSelect(Dev& d, const FairArgs& a) {
   return best;
 }
 
-DEV int wgFirstFit(Dev& d, const ScanArgs& a) {
+DEV uint64_t wgFirstFitKey(Dev& d, const ScanArgs& a) {
   HsScope prof(38);
   const DevCfg& c = d.cfg;
   uint64_t best = ~0ull;
@@ -44,13 +44,25 @@ DEV int wgFirstFit(Dev& d, const ScanArgs& a) {
   for (int n = 0; n < c.N; n++) {
     if (!((a.maskA[n >> 6] >> (n & 63)) & 1)) continue;
     if (a.maskB && !((a.maskB[n >> 6] >> (n & 63)) & 1)) continue;
+    if (a.levelHi > a.level) {   // multi-level mode
+      for (int l = a.level; l <= a.levelHi; l++) {
+        uint64_t v = ((uint64_t)l << SCAN_LEVEL_SHIFT) | KEY(d, l, n);
+        if (v >= best) break;
+        if (fitsAlloc(d, a.req, l, n)) { best = v; break; }
+      }
+      continue;
+    }
     uint64_t k = KEY(d, a.level, n);
     if (k >= best || k < a.lowBound) continue;
     if (!a.noFit && !fitsAlloc(d, a.req, a.level, n)) continue;
     best = k;
   }
+  return best;
+}
+DEV int wgFirstFit(Dev& d, const ScanArgs& a) {
+  uint64_t best = wgFirstFitKey(d, a);
   if (best == ~0ull) return -1;
-  return d.nodeByRank[best & ((1ull << c.idxBits) - 1)];
+  return d.nodeByRank[best & ((1ull << d.cfg.idxBits) - 1)];
 }
 DEV void wgBulk(Dev& d, int kind, int n) { HsScope prof(kind); for (int i = 0; i < n; i++) bulkElem(d, kind, i); }
 DEV int wgCompactFlagged(Dev& d, const int32_t* order, const int32_t* segOff, int nseg, int n, const uint8_t* flag, int32_t* dst, int32_t* outSegOff) {
@@ -144,7 +156,7 @@ static int plat_run_fit_batch(Dev& d, const std::vector<int32_t>& shapes, int le
   for (size_t i = 0; i < shapes.size(); i++) {
     ScanArgs a; memset(&a, 0, sizeof a);
     for (int r = 0; r < d.cfg.R; r++) a.req[r] = d.shapeReq[(size_t)shapes[i] * d.cfg.R + r];
-    a.maskA = d.shapeMask + (size_t)shapes[i] * d.cfg.W; a.maskB = nullptr; a.level = level;
+    a.maskA = d.shapeMask + (size_t)shapes[i] * d.cfg.W; a.maskB = nullptr; a.level = level; a.levelHi = 0;
     out[i] = wgFirstFit(d, a);
   }
   return 0;
