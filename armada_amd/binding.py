@@ -167,7 +167,7 @@ ALL_SYMBOLS = [
     "get_alloc", "get_scheduled_at_priority", "iterate_nodes", "fit_select_batch", "drf_cost", "fair_shares",
     "round_prepare", "schedule_round", "schedule_queues", "gang_schedule", "round_counters", "job_key_unfeasible", "kernel_times", "round_stats",
     "clear_allocated", "submit_check", "pq_order", "submit_stats", "num_nodes", "total_resources", "node_types_matching_job", "scheduling_order",
-    "set_deadline", "cancel", "indexed_node_label_values", "get_node_jobs", "get_nodes_alloc", "node_upsert",
+    "round_timing", "set_deadline", "cancel", "indexed_node_label_values", "get_node_jobs", "get_nodes_alloc", "node_upsert",
 ]
 
 
@@ -250,6 +250,7 @@ class Library:
         f("submit_stats", C.c_int32, [C.c_void_p, _i32p])
         f("num_nodes", C.c_int32, [C.c_void_p])
         f("scheduling_order", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int32])
+        f("round_timing", C.c_int32, [C.c_void_p, C.POINTER(C.c_double)])
         f("set_deadline", C.c_int32, [C.c_void_p, C.c_double])
         f("cancel", C.c_int32, [C.c_void_p])
         f("indexed_node_label_values", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int32])
@@ -757,6 +758,11 @@ class Scheduler:
         out = (C.c_double * 4)()
         self._check(self.lib.kernel_times(self.h, out))
         return dict(round_ms=out[0], fit_batch_ms=out[1], round_launches=int(out[2]), submit_check_ms=out[3])
+
+    def round_timing(self):
+        out = (C.c_double * 8)()
+        self._check(self.lib.round_timing(self.h, out))
+        return dict(total_ms=out[0], control_ms=out[1], launches=int(out[2]), evict1_host_ms=out[3], evict3_host_ms=out[4], final_host_ms=out[5])
 
     def round_stats(self):
         out = (C.c_int32 * 16)()

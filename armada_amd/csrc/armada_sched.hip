@@ -748,7 +748,7 @@ __device__ static void relocateIn(Dev& d, int cmd) {
     g_nreloc = 0;
     g_rsGlobal = d.rs;
     int Q = d.cfg.Q, R = d.cfg.R, npc = d.cfg.npc;
-    bool want = (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY) && Q > 0 && d.qWeight != nullptr && (Q <= QCAPF || d.f.relocAll);
+    bool want = (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY || cmd == CMD_PASS1 || cmd == CMD_PASS2) && Q > 0 && d.qWeight != nullptr && (Q <= QCAPF || d.f.relocAll);
     if (want) {
       int off = 0, n = 0; bool fits = true;
       auto add = [&](void** pp, int bytes) {
@@ -921,6 +921,130 @@ __global__ __launch_bounds__(CTL_THREADS) void k_control(Dev dev, int cmd, HelpB
   relocateOut();
 }
 
+// ---- grid-wide kernels of the split round (asched_host.inc runRoundSplit): the data-parallel phases of PreemptingQueueScheduler.Schedule over
+// all CUs.  Between launches the authoritative state is in HBM (relocateOut), so the per-element bodies of round_run.h run unchanged.
+__global__ __launch_bounds__(256) void k_bulk(Dev d, int kind, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) bulkElem(d, kind, i);
+}
+__global__ void k_round_small(Dev d, int what, int arg) { if (blockIdx.x == 0 && threadIdx.x == 0) roundSmall(d, what, arg); }
+
+// sum of v over the lanes selected by `sel` (wave-uniform mask), returned on every lane
+__device__ static inline int64_t waveSumSel(int64_t v, unsigned long long sel) {
+  int lane = threadIdx.x & 63;
+  int64_t x = ((sel >> lane) & 1) ? v : 0;
+  for (int off = 32; off; off >>= 1) x += __shfl_xor(x, off, 64);
+  return x;
+}
+// Evictor.Evict + sctx.EvictJob for every flagged job (round_run.h evictApply), grid-wide.  Jobs are walked in the pre-sorted (queue, scheduling
+// order) list, so the lanes of a wave mostly share a queue: the per-queue / per-priority-class / pool sums are reduced across the wave first and
+// leave as ONE atomic per (wave, key, resource) instead of one per job — same integer sums, ~64x fewer same-address atomics.
+__global__ __launch_bounds__(256) void k_evict_apply(Dev d, int phase3, int total) {
+  const DevCfg& c = d.cfg;
+  int lane = threadIdx.x & 63;
+  int rounds = (total + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
+  for (int it = 0; it < rounds; it++) {   // wave-uniform trip count: every lane takes part in the reductions
+    int i = (it * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    int j = i < total ? d.ordAll[i] : -1;
+    bool act = j >= 0 && d.evFlag[j];
+    int64_t A[MAXR], S[MAXR], E1[MAXR], E2[MAXR];
+    int key = -1, q = 0, pc = 0, cntSched = 0, cntEv = 0;
+#pragma unroll
+    for (int r = 0; r < MAXR; r++) { A[r] = S[r] = E1[r] = E2[r] = 0; }
+    if (act) {
+      int n = d.jobNode[j];
+      if (d.schedAtPrio[j] == NO_PRIORITY) { raise(d, ASCHED_ERR_INTERNAL, 800); act = false; }   // EvictJobsFromNode nodedb.go:1085-1088
+      else {
+        const int64_t* req = JREQ(d, j);
+        d.jobEvictedOnNode[j] = 1;  // Node.EvictJob node.go:449-474
+        atomicMarkAllocatable(d, n, d.jobCutoff[j], req, +1);
+        atomicMarkAllocatable(d, n, ASCHED_EVICTED_PRIORITY, req, -1);
+        d.jcEvicted[j] = 1; d.jcAssigned[j] = n; d.jcReason[j] = 0; d.jcHasPctx[j] = 0; d.jcUniValue[j] = -1; d.jcStagedBy[j] = -1;   // fresh jctx pinned to the node (eviction.go:246-253)
+        int g = d.jGang[j];
+        d.jcGangCard[j] = g >= 0 ? d.gangOff[g + 1] - d.gangOff[g] : 1;  // setEvictedGangCardinality pqs.go:462-483
+        q = d.jQueue[j]; pc = d.jPc[j]; key = q * c.npc + pc;
+        uint8_t f = d.jobFlags[j];
+        bool sched = f & F_SUCCESSFUL, resched = f & F_RESCHEDULED;
+        if (sched || resched) { if (sched) f &= ~F_SUCCESSFUL; if (resched) f &= ~F_RESCHEDULED; } else f |= F_EVICTED;
+        d.jobFlags[j] = f;
+        for (int r = 0; r < MAXR; r++) if (r < c.R) { A[r] = -req[r]; S[r] = sched ? -req[r] : 0; E1[r] = (!sched && !resched) ? req[r] : 0; E2[r] = !sched ? req[r] : 0; }
+        cntSched = sched ? -1 : 0; cntEv = sched ? 0 : 1;
+        if (!phase3) { d.inPreempted[j] = 1; d.preemptedNode[j] = n; }
+        else if (d.inScheduled[j]) { d.inScheduled[j] = 0; d.inSchedAndEvicted[j] = 1; d.preemptedNode[j] = n; }
+        else { d.inPreempted[j] = 1; d.preemptedNode[j] = n; }
+      }
+    }
+    unsigned long long todo = __ballot(act);
+    if (!todo) continue;
+    // pool-wide sums: every active lane
+    for (int r = 0; r < c.R; r++) {
+      int64_t a = waveSumSel(A[r], todo), s2 = waveSumSel(S[r], todo), e2 = waveSumSel(E2[r], todo);
+      if (lane == 0) { if (a) atomicAddI64(&d.rs->allocated[r], a); if (s2) atomicAddI64(&d.rs->scheduled[r], s2); if (e2) atomicAddI64(&d.rs->evicted[r], e2); }
+    }
+    { int cs = (int)waveSumSel(cntSched, todo), ce = (int)waveSumSel(cntEv, todo);
+      if (lane == 0) { if (cs) atomicAddI32(&d.rs->numScheduledJobs, cs); if (ce) atomicAddI32(&d.rs->numEvictedJobs, ce); } }
+    // per (queue, priority class): one group per distinct key in the wave
+    while (todo) {
+      int first = __ffsll((long long)todo) - 1;
+      int k0 = __shfl(key, first, 64);
+      unsigned long long sel = __ballot(act && key == k0) & todo;
+      int q0 = k0 / c.npc;
+      for (int r = 0; r < c.R; r++) {
+        int64_t a = waveSumSel(A[r], sel), s2 = waveSumSel(S[r], sel), e1 = waveSumSel(E1[r], sel);
+        if (lane == 0) {
+          size_t ix = (size_t)k0 * c.R + r;
+          if (a) { atomicAddI64(&d.qAllocByPc[ix], a); atomicAddI64(&d.qAlloc[(size_t)q0 * c.R + r], a); }
+          if (s2) atomicAddI64(&d.qSchedByPc[ix], s2);
+          if (e1) atomicAddI64(&d.qEvictedByPc[ix], e1);
+        }
+      }
+      todo &= ~sel;
+    }
+  }
+}
+
+// order-preserving compaction of {order[p] : flag[order[p]]} over the whole grid (order == NULL: identity): count per 4096-element block, scan
+// of the block counts, ordered write.  prefix[p] = number of flagged elements before p (may be NULL).
+#define CMP_CHUNK 4096
+__global__ __launch_bounds__(256) void k_cmp_count(const int32_t* order, int n, const uint8_t* flag, int32_t* blockCount) {
+  __shared__ int wsum[4];
+  int base = blockIdx.x * CMP_CHUNK, cnt = 0;
+  for (int o = threadIdx.x; o < CMP_CHUNK; o += 256) { int p = base + o; if (p < n && flag[order ? order[p] : p]) cnt++; }
+  for (int off = 32; off; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) blockCount[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ void k_cmp_scan(int32_t* blockCount, int nblocks, int32_t* totalOut) {   // one thread: a few hundred blocks at most
+  if (blockIdx.x || threadIdx.x) return;
+  int run = 0;
+  for (int b = 0; b < nblocks; b++) { int v = blockCount[b]; blockCount[b] = run; run += v; }
+  *totalOut = run;
+}
+__global__ __launch_bounds__(256) void k_cmp_write(const int32_t* order, int n, const uint8_t* flag, int32_t* dst, uint32_t* prefix, const int32_t* blockOffset) {
+  __shared__ int wcnt[4];
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int run = blockOffset[blockIdx.x];
+  for (int t = 0; t < CMP_CHUNK / 256; t++) {
+    int p = blockIdx.x * CMP_CHUNK + t * 256 + threadIdx.x;
+    int v = p < n ? (order ? order[p] : p) : 0;
+    bool f = p < n && flag[v];
+    unsigned long long b = __ballot(f);
+    if (lane == 0) wcnt[wave] = __popcll(b);
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int w = 0; w < 4; w++) { int cw = wcnt[w]; if (w < wave) off += cw; tot += cw; }
+    int rank = run + off + __popcll(b & ((1ull << lane) - 1));
+    if (p < n && prefix) prefix[p] = rank;
+    if (f) dst[rank] = v;
+    run += tot;
+    __syncthreads();
+  }
+}
+__global__ void k_seg_off(const int32_t* segOff, int nseg, int n, const uint32_t* prefix, const int32_t* total, int32_t* outSegOff) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q <= nseg) outSegOff[q] = segOff[q] < n ? (int32_t)prefix[segOff[q]] : *total;
+}
+
 __global__ void k_shape_mask(Dev d, const uint64_t* classMask, const int32_t* shapeClass) {
   const DevCfg& c = d.cfg;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1028,6 +1152,11 @@ struct PlatCtx {
   int32_t* cancelHost = nullptr;    // host-mapped, coherent: written by the host (deadline / asched_cancel), polled by the round kernel
   int32_t* cancelDev = nullptr;
   double deadlineS = 0;             // maxSchedulingDuration for every following round launch; 0 = none
+  bool inRound = false;             // between plat_round_begin / plat_round_end: the deadline runs from the begin, the cancel word is consumed at the end
+  std::chrono::steady_clock::time_point roundT0;
+  hipEvent_t rEv0 = nullptr, rEv1 = nullptr;
+  float roundTotalMs = 0.f, roundControlMs = 0.f; int roundLaunches = 0;
+  int32_t* cmpScratch = nullptr; size_t cmpScratchInts = 0;   // block counts + total of the grid-wide compaction
   std::string err;
   bool failed = false;              // sticky: an allocation / copy / memset failed since the last plat_take_failure()
 };
@@ -1059,7 +1188,7 @@ static PlatCtx* plat_open(std::string& err, int device) {
   int khz = 0;
   if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wallClockKHz = khz;
   bool ok = hipStreamCreate(&c->stream) == hipSuccess && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
-            hipEventCreate(&c->fitEv0) == hipSuccess && hipEventCreate(&c->fitEv1) == hipSuccess;
+            hipEventCreate(&c->fitEv0) == hipSuccess && hipEventCreate(&c->fitEv1) == hipSuccess && hipEventCreate(&c->rEv0) == hipSuccess && hipEventCreate(&c->rEv1) == hipSuccess;
   // the mailbox is written from both sides across XCDs: it must not live in an XCD-private L2 -> fine-grained (uncached, device-coherent) memory
   ok = ok && hipExtMallocWithFlags((void**)&c->helpBox, 256, hipDeviceMallocFinegrained) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->cancelHost, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
@@ -1081,8 +1210,9 @@ static void plat_close(PlatCtx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
-  for (hipEvent_t e : {c->ev0, c->ev1, c->fitEv0, c->fitEv1}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {c->ev0, c->ev1, c->fitEv0, c->fitEv1, c->rEv0, c->rEv1}) if (e) (void)hipEventDestroy(e);
   if (c->helpBox) (void)hipFree(c->helpBox);
+  if (c->cmpScratch) (void)hipFree(c->cmpScratch);
   if (c->cancelHost) (void)hipHostFree(c->cancelHost);
   if (c->progress) (void)hipHostFree(c->progress);
   if (t_ctx == c) t_ctx = nullptr;
@@ -1112,9 +1242,9 @@ static int plat_run_control(Dev& dev, int cmd) {
   PlatCtx* c = t_ctx;
   if (c->failed) return -1;  // an earlier upload failed: the kernel would read unset pointers
   static_assert(sizeof(HelpBox) <= 256, "mailbox allocation");
-  bool isRound = cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY;
+  bool isRound = cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY || cmd == CMD_PASS1 || cmd == CMD_PASS2;
   int H = isRound ? c->helpers : 0;
-  dev.progress = (cmd == CMD_ROUND && c->progress) ? c->progress : nullptr;
+  dev.progress = ((cmd == CMD_ROUND || cmd == CMD_PASS1 || cmd == CMD_PASS2) && c->progress) ? c->progress : nullptr;
   dev.cancel = c->cancelDev;
   if (!hipOk(hipMemsetAsync(c->helpBox, 0, sizeof(HelpBox), c->stream), "help box reset")) return -1;
   (void)hipEventRecord(c->ev0, c->stream);
@@ -1126,7 +1256,7 @@ static int plat_run_control(Dev& dev, int cmd) {
   if (!hipOk(hipGetLastError(), "k_control launch")) return -1;
   if (dev.progress || (isRound && c->deadlineS > 0)) {
     // hard timeout (scheduling_algo.go:130-134): the kernel polls the cancel word; the host sets it when the deadline passes
-    auto t0 = std::chrono::steady_clock::now();
+    auto t0 = c->inRound ? c->roundT0 : std::chrono::steady_clock::now();
     int ticks = 0;
     volatile int32_t* progress = c->progress;
     while (hipStreamQuery(c->stream) == hipErrorNotReady) {
@@ -1137,9 +1267,71 @@ static int plat_run_control(Dev& dev, int cmd) {
     }
   }
   if (!hipOk(hipStreamSynchronize(c->stream), "k_control")) return -1;
-  if (isRound) __atomic_store_n(c->cancelHost, 0, __ATOMIC_RELEASE);  // a cancel request is consumed by the round it hit (or the next one, if it came between rounds)
+  if (isRound && !c->inRound) __atomic_store_n(c->cancelHost, 0, __ATOMIC_RELEASE);  // a cancel request is consumed by the round it hit (or the next one, if it came between rounds)
   (void)hipEventElapsedTime(&c->lastControlMs, c->ev0, c->ev1);
   c->lastControlLaunches = 1;
+  if (c->inRound) { c->roundControlMs += c->lastControlMs; c->roundLaunches++; }
+  return 0;
+}
+
+// ---- the split round: grid-wide kernels between the persistent passes, all on the handle's stream (no host sync except where a count is needed)
+static void plat_round_begin() {
+  PlatCtx* c = t_ctx;
+  c->inRound = true; c->roundT0 = std::chrono::steady_clock::now(); c->roundControlMs = 0.f; c->roundLaunches = 0;
+  (void)hipEventRecord(c->rEv0, c->stream);
+}
+static void plat_round_end() {
+  PlatCtx* c = t_ctx;
+  (void)hipEventRecord(c->rEv1, c->stream);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipEventElapsedTime(&c->roundTotalMs, c->rEv0, c->rEv1);
+  c->inRound = false;
+  __atomic_store_n(c->cancelHost, 0, __ATOMIC_RELEASE);
+}
+static void plat_round_times(double* out) { PlatCtx* c = t_ctx; out[0] = c->roundTotalMs; out[1] = c->roundControlMs; out[2] = c->roundLaunches; }
+static int bulkGrid(int n) { int b = (n + 255) / 256; int cap = (t_ctx->cus > 0 ? t_ctx->cus : 256) * 8; return b < 1 ? 1 : (b > cap ? cap : b); }
+static int plat_bulk(Dev& d, int kind, int n) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_bulk, dim3(bulkGrid(n)), dim3(256), 0, t_ctx->stream, d, kind, n);
+  t_ctx->roundLaunches++;
+  return hipOk(hipGetLastError(), "k_bulk launch") ? 0 : -1;
+}
+static int plat_small(Dev& d, int what, int arg) {
+  hipLaunchKernelGGL(k_round_small, dim3(1), dim3(64), 0, t_ctx->stream, d, what, arg);
+  t_ctx->roundLaunches++;
+  return hipOk(hipGetLastError(), "k_round_small launch") ? 0 : -1;
+}
+static int plat_evict_apply(Dev& d, int phase3, int total) {
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(k_evict_apply, dim3(bulkGrid(total)), dim3(256), 0, t_ctx->stream, d, phase3, total);
+  t_ctx->roundLaunches++;
+  return hipOk(hipGetLastError(), "k_evict_apply launch") ? 0 : -1;
+}
+// grid-wide order-preserving compaction; *total comes back to the host (the next launches are sized by it)
+static int plat_compact(Dev& d, const int32_t* order, int n, const uint8_t* flag, int32_t* dst, uint32_t* prefix, const int32_t* segOff, int nseg, int32_t* outSegOff, int* total) {
+  (void)d;
+  PlatCtx* c = t_ctx;
+  *total = 0;
+  int nb = (n + CMP_CHUNK - 1) / CMP_CHUNK;
+  size_t need = (size_t)nb + 8;
+  if (c->cmpScratchInts < need) {
+    if (c->cmpScratch) (void)hipFree(c->cmpScratch);
+    c->cmpScratch = nullptr; c->cmpScratchInts = 0;
+    if (!hipOk(hipMalloc((void**)&c->cmpScratch, need * 2 * sizeof(int32_t)), "compaction scratch")) return -1;
+    c->cmpScratchInts = need * 2;
+  }
+  int32_t* blockCount = c->cmpScratch; int32_t* dTotal = c->cmpScratch + c->cmpScratchInts - 1;
+  if (nb > 0) {
+    hipLaunchKernelGGL(k_cmp_count, dim3(nb), dim3(256), 0, c->stream, order, n, flag, blockCount);
+    hipLaunchKernelGGL(k_cmp_scan, dim3(1), dim3(64), 0, c->stream, blockCount, nb, dTotal);
+    hipLaunchKernelGGL(k_cmp_write, dim3(nb), dim3(256), 0, c->stream, order, n, flag, dst, prefix, (const int32_t*)blockCount);
+    c->roundLaunches += 3;
+  } else (void)hipMemsetAsync(dTotal, 0, sizeof(int32_t), c->stream);
+  if (segOff) { hipLaunchKernelGGL(k_seg_off, dim3((nseg + 256) / 256), dim3(256), 0, c->stream, segOff, nseg, n, (const uint32_t*)prefix, (const int32_t*)dTotal, outSegOff); c->roundLaunches++; }
+  if (!hipOk(hipGetLastError(), "compaction launch")) return -1;
+  int32_t t = 0;
+  if (!hipOk(hipMemcpyAsync(&t, dTotal, sizeof t, hipMemcpyDeviceToHost, c->stream), "compaction total") || !hipOk(hipStreamSynchronize(c->stream), "compaction")) return -1;
+  *total = t;
   return 0;
 }
 static int plat_build_base(Dev& d) {

@@ -20,9 +20,13 @@
 #include <cmath>
 #include <cstring>
 #define DEV static inline
+#define DEV_COLD static
 #define WG_THREADS 1
 #else
 #define DEV __device__ static inline
+// the big generic-path functions: out of line.  Inlined into every call site they made the round kernel's code several times larger (the
+// whole cascade sits in selectNodeForJob twice — home and away), which costs compile time and instruction-cache room next to the hot loop
+#define DEV_COLD __device__ static __attribute__((noinline))
 #define WG_THREADS 1024
 #define CLK() ((long long)__builtin_readcyclecounter())
 #endif
@@ -65,7 +69,7 @@ DEV bool fastOn(Dev& d, const Ctl& c);
 DEV void fastEnterGeneric(Dev& d, Ctl& c);
 DEV bool fastGangMember(Dev& d, Ctl& c, int job);  // select (fit at priority -2) + bind of one unpinned queued gang member through the fast structure; false = not done
 DEV void fastFence(Ctl& c);
-DEV void ensureReplay(Dev& d, Ctl& c);             // run the deferred eviction-order replay before anything reads the evicted table         // leave fast mode: LDS queue state back into the generic arrays, HBM updates visible
+DEV_COLD void ensureReplay(Dev& d, Ctl& c);             // run the deferred eviction-order replay before anything reads the evicted table         // leave fast mode: LDS queue state back into the generic arrays, HBM updates visible
 
 // ------------------------------------------------------------------------------------------------
 #define AL(d, l, r, n) ((d).alloc[((size_t)(l) * (d).cfg.R + (r)) * (d).cfg.Npad + (n)])
@@ -457,7 +461,7 @@ DEV bool litNodeLess(Dev& d, int level, int a, int b) {  // nodeTypesIteratorPQ.
   return d.nodeIdRank[a] < d.nodeIdRank[b];
 }
 // selectNodeForPodAtPriority + selectNodeForPodWithItAtPriority (nodedb.go:840-928) over the literal iterators
-DEV int selectAtLevelLiteral(Dev& d, int job, int32_t prio, int level, int row) {
+DEV_COLD int selectAtLevelLiteral(Dev& d, int job, int32_t prio, int level, int row) {
   const DevCfg& c = d.cfg;
   const int64_t* req = JREQ(d, job);
   int64_t ireq[MAXK];
@@ -540,8 +544,8 @@ DEV int fairNodeBest(const Dev& d, const FairArgs& a, int n, int floorIdx) {
   }
   return -1;
 }
-DEV void ensureFairIndex(Dev& d);
-DEV int selectWithFairPreemption(Dev& d, Ctl& c, int job) {
+DEV_COLD void ensureFairIndex(Dev& d);
+DEV_COLD int selectWithFairPreemption(Dev& d, Ctl& c, int job) {
   ensureReplay(d, c);
   long long t0 = CLK();
   if (d.progress) { d.progress[2] = 2; d.progress[3]++; }
@@ -586,7 +590,7 @@ DEV int selectWithFairPreemption(Dev& d, Ctl& c, int job) {
 // above.  Hence "first level with any fitting node, then the minimum key at that level" == the minimum over nodes of (lowest level the node
 // fits at, its key at that level), and the gate is "is there any such node".  ONE multi-level pass (ScanArgs.levelHi) answers both; the
 // fair-share attempt in between changes nothing when it fails.  Query counts are kept as the level-by-level loop would have issued them.
-DEV int selectAtPriority(Dev& d, Ctl& c, int job) {
+DEV_COLD int selectAtPriority(Dev& d, Ctl& c, int job) {
   int n = selectAtLevel(d, job, ASCHED_EVICTED_PRIORITY);
   if (n >= 0) { d.pcMethod[job] = ASCHED_METHOD_NO_PREEMPTION; return n; }
   int row = d.rs->awayRowPlus1 ? d.rs->awayRowPlus1 - 1 : d.jShape[job];
@@ -698,7 +702,7 @@ DEV void preemptSiblings(Dev& d, Ctl& c, int firstPre, int lastPre) {
 }
 
 // ScheduleManyWithTxn (nodedb.go:417-462)
-DEV bool scheduleMany(Dev& d, Ctl& c, int ref) {
+DEV_COLD bool scheduleMany(Dev& d, Ctl& c, int ref) {
   int cnt = gcCount(d, ref);
   for (int k = 0; k < cnt; k++) {
     int job = gcJob(d, ref, k);
@@ -759,7 +763,7 @@ DEV void fitOf(Dev& d, int ref, int* num, double* mean) {  // gctx.Fit (context/
 // host-built table of uniformity label values: uniOff[label slot], uniVals[] = labelMask ids in ascending value order
 struct UniTable { const int32_t* slotOfLabel; const int32_t* off; int nLabels; };
 // trySchedule (gang_scheduler.go:150-227).  jGangUni[job] holds the label *slot* (-1 none, -2 label not indexed).
-DEV bool trySchedule(Dev& d, Ctl& c, int ref, int* reason, const int32_t* uniOff) {
+DEV_COLD bool trySchedule(Dev& d, Ctl& c, int ref, int* reason, const int32_t* uniOff) {
   int j0 = gcJob(d, ref, 0);
   int slot = d.jGang[j0] >= 0 ? d.jGangUni[j0] : -1;
   if (slot == -1) return tryGang(d, c, ref, reason);
@@ -800,7 +804,7 @@ DEV void failJob(Dev& d, int job, int reason) {  // jctx.Fail (context/job.go:11
 }
 
 // GangScheduler.Schedule incl. deferred bookkeeping (gang_scheduler.go:46-148)
-DEV bool gangSchedule(Dev& d, Ctl& c, int ref, int* reason, const int32_t* uniOff) {
+DEV_COLD bool gangSchedule(Dev& d, Ctl& c, int ref, int* reason, const int32_t* uniOff) {
   *reason = 0;
   bool allEv = gcAllEvicted(d, ref);
   if (!allEv) {
@@ -1075,7 +1079,7 @@ DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff)
 }
 
 // addEvictedJobsToNodeDb (preempting_queue_scheduler.go:589-639): replay the DRF order over the evicted gangs
-DEV void replayEvicted(Dev& d, Ctl& c) {
+DEV_COLD void replayEvicted(Dev& d, Ctl& c) {
   int Q = d.cfg.Q;
   for (int q = 0; q < Q; q++) for (int r = 0; r < d.cfg.R; r++) QV(d.replayAlloc, q)[r] = QV(d.qAllocSnap, q)[r];  // allocations as the evictor left them
   int savedCmp = c.compareSchedPrio;

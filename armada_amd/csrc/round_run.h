@@ -213,7 +213,7 @@ DEV void bulkElem(Dev& d, int kind, int i) {
 
 // SchedulingContext.updateFairShares (context/scheduling.go:262-342): float64, queues in name order, this exact operation order.
 // Scratch: pqProposed = constrainedDemandShare, pqCurrent = spareShare, pqInHeap = achievedDemand, itNext = name order.
-DEV void updateFairShares(Dev& d, const double* givenCds) {
+DEV_COLD void updateFairShares(Dev& d, const double* givenCds) {
   const DevCfg& cf = d.cfg;
   int Q = cf.Q;
   double weightSum = 0;
@@ -249,7 +249,7 @@ DEV void updateFairShares(Dev& d, const double* givenCds) {
 }
 
 // PreemptingQueueScheduler.evict (pqs.go:291-353) for an evictor whose job filter has been evaluated into evFlag
-DEV int pqsEvict(Dev& d, Ctl& c, bool phase3) {
+DEV_COLD int pqsEvict(Dev& d, Ctl& c, bool phase3) {
   long long t0 = CLK();
   wgBulk(d, B_GANG_CLOSURE, d.cfg.G);
   wgBulk(d, phase3 ? B_EVICT_APPLY3 : B_EVICT_APPLY1, d.cfg.M);
@@ -304,6 +304,60 @@ DEV int pqsEvict(Dev& d, Ctl& c, bool phase3) {
   return n;
 }
 
+// ---- the serial slivers of the split round (host-driven sequence): each runs as one thread of a tiny kernel between grid-wide passes
+enum SmallKind { SM_QEVICTABLE = 1, SM_EVICT_POST, SM_STITCH, SM_MONO, SM_LVL0_BEGIN, SM_FINAL };
+DEV void roundSmall(Dev& d, int what, int arg) {
+  const DevCfg& cf = d.cfg;
+  switch (what) {
+    case SM_QEVICTABLE:  // balance-evictor filter inputs: the start-of-round queue allocations (pqs.go:124-134)
+      for (int q = 0; q < cf.Q; q++) {
+        double actual = drf(d, QV(d.qAlloc, q));
+        double fair = d.qDc[q] > d.qFair[q] ? d.qDc[q] : d.qFair[q];  // math.Max
+        if (cf.protectUncapped) fair = d.qUc[q];
+        double frac = actual / fair;
+        d.qEvictable[q] = !(frac <= cf.protectedFraction);
+      }
+      break;
+    case SM_EVICT_POST:  // after the compaction of an evictor's job list: nodeDb.Reset() bookkeeping (nodedb.go:299-313)
+      d.rs->numEvictedList = arg;
+      d.rs->evictedTableSize = 0; d.rs->fairIndexValid = 0; d.rs->replayPending = 0;
+      break;
+    case SM_STITCH: {  // carry-in of range i = requests of the same queue summed over the ranges before it (B_EVSUM -> B_EVKEYS)
+      int64_t run[MAXR]; int runQ = -1;
+      for (int r = 0; r < MAXR; r++) run[r] = 0;
+      for (int i = 0; i < d.evChunks; i++) {
+        int64_t* part = d.evPart + (size_t)i * (2 * MAXR + 4);
+        int qFirst = (int)part[2 * MAXR], qLast = (int)part[2 * MAXR + 1]; bool crossed = part[2 * MAXR + 2] != 0;
+        int64_t carry[MAXR];
+        for (int r = 0; r < MAXR; r++) carry[r] = (qFirst >= 0 && qFirst == runQ) ? run[r] : 0;
+        if (qFirst >= 0) {
+          if (!crossed) { for (int r = 0; r < MAXR; r++) run[r] = carry[r] + part[r]; runQ = qFirst; }
+          else { for (int r = 0; r < MAXR; r++) run[r] = part[MAXR + r]; runQ = qLast; }
+        }
+        for (int r = 0; r < MAXR; r++) part[r] = carry[r];
+      }
+    } break;
+    case SM_MONO: {  // monotonicity across chunk borders; every stream gang-free -> the replay can wait (lazy)
+      int n = arg;
+      int C = (n + d.evChunks - 1) / d.evChunks, nc = C > 0 ? (n + C - 1) / C : 0;
+      for (int i = 1; i < nc; i++) {
+        const uint64_t* a = d.evEdge + (size_t)(i - 1) * 8; const uint64_t* b = d.evEdge + (size_t)i * 8;
+        if (a[7] != b[3]) continue;
+        PackedKey last, first; last.A = (uint32_t)a[4]; last.X = a[5]; last.Y = a[6]; first.A = (uint32_t)b[0]; first.X = b[1]; first.Y = b[2];
+        if (packedLess(first, 0, last, 0)) d.evMono[(int)b[3]] = 0;
+      }
+      bool lazy = true;
+      for (int q = 0; q < cf.Q; q++) if (!d.evCheap[q]) lazy = false;
+      if (lazy) d.rs->replayPending = 1;
+    } break;
+    case SM_LVL0_BEGIN: d.rs->lvl0NonNeg = 1; break;
+    case SM_FINAL:
+      d.rs->fastActive = 0;  // unbinding changed priority -2 allocatable behind the fast structure: next round_prepare rebuilds it
+      d.rs->terminationReason = d.cmdIO[4];
+      break;
+  }
+}
+
 DEV void schedulePass(Dev& d, Ctl& c, bool withQueued, bool skipKey, bool cmpPrio) {  // pqs.schedule (pqs.go:712-772)
   wgBulk(d, B_CLEAR_UNFEASIBLE, d.cfg.S);
   d.rs->numUnfeasible = 0;
@@ -316,7 +370,7 @@ DEV void schedulePass(Dev& d, Ctl& c, bool withQueued, bool skipKey, bool cmpPri
 
 // Per-node index of the evicted table (CSR node -> table Indexes, descending) for fair-share preemption.  Every entry below
 // evictedTableSize is indexed, dead or alive (a transaction abort can bring an entry back); rebuilt when the table has grown.
-DEV void ensureFairIndex(Dev& d) {
+DEV_COLD void ensureFairIndex(Dev& d) {
   if (d.rs->fairIndexValid) return;
   int E = d.rs->evictedTableSize, N = d.cfg.N;
   wgBulk(d, B_FAIR_ZERO, N);
@@ -344,7 +398,7 @@ DEV void swapLoopArrays(Dev& d) {
 // The deferred addEvictedJobsToNodeDb (pqs.go:589-639): its result — the evicted-table Index of every evicted job — is a pure
 // function of the state the evictor left (qAllocSnap, the eviction lists), so it can be computed at first use.  It runs on its
 // own set of iterator / heap arrays; entries of jobs that have been rescheduled or preempted in the meantime come out dead.
-DEV void ensureReplay(Dev& d, Ctl& c) {
+DEV_COLD void ensureReplay(Dev& d, Ctl& c) {
   if (!d.rs->replayPending) return;
   d.rs->replayPending = 0;
   fastEnterGeneric(d, c);
@@ -361,7 +415,7 @@ DEV void ensureReplay(Dev& d, Ctl& c) {
 }
 
 // PreemptingQueueScheduler.Schedule (pqs.go:86-289)
-DEV void runRound(Dev& d, Ctl& c) {
+DEV_COLD void runRound(Dev& d, Ctl& c) {
   const DevCfg& cf = d.cfg;
   for (int q = 0; q < cf.Q; q++) {  // balance-evictor filter inputs are the start-of-round queue allocations (pqs.go:124-134)
     double actual = drf(d, QV(d.qAlloc, q));
@@ -416,6 +470,7 @@ DEV void runRound(Dev& d, Ctl& c) {
 enum Cmd {
   CMD_PREPARE = 1, CMD_ROUND, CMD_QUEUES_ONLY, CMD_GANG_SCHEDULE, CMD_SELECT, CMD_SCHEDULE_MANY, CMD_BIND, CMD_EVICT, CMD_UNBIND,
   CMD_ADD_EVICTED, CMD_RESET_EVICTED, CMD_TXN_BEGIN, CMD_TXN_COMMIT, CMD_TXN_ABORT, CMD_FIT_BATCH, CMD_UPSERT_RESET, CMD_RESET_JOBS,
+  CMD_PASS1, CMD_PASS2,   // the two sequential passes of a round whose data-parallel phases run as grid-wide kernels between them (asched_host.inc runRoundSplit)
   CMD_SUBMIT_CHECK,  // first command of the auxiliary kernel (k_control_aux, armada_sched_aux.hip)
   CMD_PQ_ORDER,
   CMD_NODE_UPSERT,
@@ -456,6 +511,28 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
       updateFairShares(d, (const double*)0);
       break;
     case CMD_ROUND: runRound(d, c); break;
+    // The round as the host drives it by default: evictor filters, eviction, key rebuild, compaction, evicted-stream costs, unbind and the result
+    // lists run as ordinary grid-wide kernels over all CUs (armada_sched.hip k_bulk / k_evict_apply / k_cmp_*); only the two inherently
+    // sequential passes stay in this persistent kernel.  ARG(0) = number of jobs the evictor before this pass evicted.
+    case CMD_PASS1: {  // pqs.go:149-166: schedule(evicted ++ queued); before it the tail of evict(): addEvictedJobsToNodeDb unless deferred
+      long long t0 = CLK();
+      int n1 = ARG(0);
+      c.fastEvStatic = 1;
+      if (!d.rs->replayPending) { replayEvicted(d, c); wgBulk(d, B_EVIDX, n1); }
+      long long t1 = CLK();
+      c.skipEnter = fastOn(d, c) && d.evMono != nullptr && d.rs->lvl0NonNeg && n1 > 0;
+      schedulePass(d, c, true, false, false);
+      c.skipEnter = 0; c.fastEvStatic = 0;
+      d.cmdIO[4] = d.rs->terminationReason;   // the round reports the first pass's reason (pqs.go:149-166)
+      d.rs->statClk[1] += t1 - t0; d.rs->statClk[2] += CLK() - t1;
+    } break;
+    case CMD_PASS2: {  // pqs.go:199-221: schedule(evicted only; skipKeyCheck; compareSchedulingPriority)
+      long long t0 = CLK();
+      int n3 = ARG(0);
+      replayEvicted(d, c); wgBulk(d, B_EVIDX, n3);
+      schedulePass(d, c, false, true, true);
+      d.rs->statClk[4] += CLK() - t0;
+    } break;
     case CMD_QUEUES_ONLY: {
       // no evicted jobs: empty per-queue evicted segments
       for (int q = 0; q <= cf.Q; q++) d.evOff[q] = 0;
@@ -645,7 +722,7 @@ DEV void controlMain(Dev& d, int cmd) {
   Ctl c;
   c.txn.active = d.rs->txnActive; c.fairStamp = d.rs->fairStamp; c.preList = d.preList; c.preCount = 0;
   c.skipKeyCheck = 0; c.compareSchedPrio = 0; c.preferLarge = d.cfg.preferLarge; c.useReplayAlloc = 0; c.onlyEvicted = 0;
-  c.fastEnabled = d.f.iterOk && !d.rs->apiDirty && (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY);
+  c.fastEnabled = d.f.iterOk && !d.rs->apiDirty && (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY || cmd == CMD_PASS1 || cmd == CMD_PASS2);
   c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0; c.cancelSeen = 0;
   fastLoad(d);
   runCommand(d, c, cmd);

@@ -409,6 +409,10 @@ int32_t ASCHED_FN(round_counters)(asched_t*, int32_t* out /*[4]*/);
    out[1] = ms of the last fit_select_batch kernel, out[2] = kernel launches behind out[0], out[3] = ms of the last submit_check launch.
    The CPU oracle reports zeros. */
 int32_t ASCHED_FN(kernel_times)(asched_t*, double* out /*[4]*/);
+/* Measurement hook (no reference counterpart): where the device time of the last schedule_round went.  out = {whole launch sequence ms (HIP
+   events on the stream), ms inside the persistent k_control launches (the two sequential passes), kernel launches, host ms of the grid-wide
+   evict-1 / evict-3 / final phases including their count read-backs, 0, 0}.  The CPU oracle reports zeros. */
+int32_t ASCHED_FN(round_timing)(asched_t*, double* out /*[8]*/);
 /* Measurement hook (no reference counterpart): how the last round ran on the device.  out = {fast iterations, generic
    iterations, base scan steps, window refills, max live dirty nodes (L0), fast replay steps, L0 overflows,
    fast structure active at the end, 0...}.  The CPU oracle reports zeros. */

@@ -93,7 +93,7 @@ DEV int pqTop(Dev& d, const Ctl& c) {
 
 // ---- platform layer
 static std::string g_err;
-struct PlatCtx { int32_t cancelWord = 0; double deadlineS = 0; };   // per handle, like the device build's (stream / events / mailbox there)
+struct PlatCtx { int32_t cancelWord = 0; double deadlineS = 0; bool inRound = false; int launches = 0; };   // per handle, like the device build's (stream / events / mailbox there)
 static thread_local PlatCtx* t_ctx = nullptr;
 static void* plat_malloc(size_t n) { return malloc(n); }
 static void plat_free(void* p) { free(p); }
@@ -116,9 +116,32 @@ static int plat_run_control(Dev& dev, int cmd) {
   d.cancel = &t_ctx->cancelWord;
   // the serial build cannot be interrupted from its own thread: a deadline of <= 1 us stands for "already expired" (tests), asched_cancel from
   // another thread works as on the device
-  if ((cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY) && t_ctx->deadlineS > 0 && t_ctx->deadlineS <= 1e-6) t_ctx->cancelWord = 1;
+  bool isRound = cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY || cmd == CMD_PASS1 || cmd == CMD_PASS2;
+  if (isRound && t_ctx->deadlineS > 0 && t_ctx->deadlineS <= 1e-6) t_ctx->cancelWord = 1;
   if (cmd >= CMD_AUX_FIRST) controlMainAux(d, cmd); else controlMain(d, cmd);
-  if (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY) t_ctx->cancelWord = 0;
+  if (isRound && !t_ctx->inRound) t_ctx->cancelWord = 0;
+  if (t_ctx->inRound) t_ctx->launches++;
+  return 0;
+}
+// the grid-wide kernels of the split round, serially
+static void plat_round_begin() { t_ctx->inRound = true; t_ctx->launches = 0; }
+static void plat_round_end() { t_ctx->inRound = false; t_ctx->cancelWord = 0; }
+static void plat_round_times(double* out) { out[0] = 0; out[1] = 0; out[2] = t_ctx->launches; }
+static int plat_bulk(Dev& dev, int kind, int n) { Dev d = dev; for (int i = 0; i < n; i++) bulkElem(d, kind, i); t_ctx->launches++; return 0; }
+static int plat_small(Dev& dev, int what, int arg) { Dev d = dev; roundSmall(d, what, arg); t_ctx->launches++; return 0; }
+static int plat_evict_apply(Dev& dev, int phase3, int total) {
+  Dev d = dev;
+  for (int i = 0; i < total; i++) evictApply(d, d.ordAll[i], phase3 != 0);
+  t_ctx->launches++;
+  return 0;
+}
+static int plat_compact(Dev& dev, const int32_t* order, int n, const uint8_t* flag, int32_t* dst, uint32_t* prefix, const int32_t* segOff, int nseg, int32_t* outSegOff, int* total) {
+  (void)dev;
+  int cnt = 0;
+  for (int p = 0; p < n; p++) { int v = order ? order[p] : p; if (prefix) prefix[p] = (uint32_t)cnt; if (flag[v]) dst[cnt++] = v; }
+  if (segOff) for (int q = 0; q <= nseg; q++) outSegOff[q] = segOff[q] < n ? (int32_t)prefix[segOff[q]] : cnt;
+  *total = cnt;
+  t_ctx->launches++;
   return 0;
 }
 // sorted base of the level-0 fast structure (round_fast.h): the device build sorts with a bitonic network
