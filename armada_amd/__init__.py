@@ -20,5 +20,6 @@ def load_library() -> Library:
     """Load the HIP implementation (prefix ``asched_``). Raises if it has not been built."""
     global _lib
     if _lib is None:
-        _lib = Library(LIB_PATH, "asched_")
+        # ASCHED_LIB_PATH: another build of the SAME HIP sources (e.g. -DASCHED_FASTPROF, the per-segment clock profile); never a different backend
+        _lib = Library(os.environ.get("ASCHED_LIB_PATH") or LIB_PATH, "asched_")
     return _lib

@@ -109,7 +109,7 @@ class CReqClasses(C.Structure):
     ]
 
 
-AFFINITY_OPS = {"In": 0, "NotIn": 1, "Exists": 2, "DoesNotExist": 3}
+AFFINITY_OPS = {"In": 0, "NotIn": 1, "Exists": 2, "DoesNotExist": 3, "Gt": 4, "Lt": 5}
 
 
 class CJobs(C.Structure):
@@ -167,7 +167,7 @@ ALL_SYMBOLS = [
     "get_alloc", "get_scheduled_at_priority", "iterate_nodes", "fit_select_batch", "drf_cost", "fair_shares",
     "round_prepare", "schedule_round", "schedule_queues", "gang_schedule", "round_counters", "job_key_unfeasible", "kernel_times", "round_stats",
     "clear_allocated", "submit_check", "pq_order", "submit_stats", "num_nodes", "total_resources", "node_types_matching_job", "scheduling_order",
-    "round_timing", "set_deadline", "cancel", "indexed_node_label_values", "get_node_jobs", "get_nodes_alloc", "node_upsert",
+    "set_label_value_ints", "round_timing", "set_deadline", "cancel", "indexed_node_label_values", "get_node_jobs", "get_nodes_alloc", "node_upsert",
 ]
 
 
@@ -250,6 +250,7 @@ class Library:
         f("submit_stats", C.c_int32, [C.c_void_p, _i32p])
         f("num_nodes", C.c_int32, [C.c_void_p])
         f("scheduling_order", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int32])
+        f("set_label_value_ints", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i64p])
         f("round_timing", C.c_int32, [C.c_void_p, C.POINTER(C.c_double)])
         f("set_deadline", C.c_int32, [C.c_void_p, C.c_double])
         f("cancel", C.c_int32, [C.c_void_p])
@@ -623,6 +624,11 @@ class Scheduler:
         self._check(self.lib.get_alloc(self.h, node, _ptr(out, C.c_int64)))
         return out
 
+    def set_label_value_ints(self, ints: Dict[int, int]):
+        """interned label value id -> its integer value, for the values strconv.ParseInt accepts (node-affinity Gt / Lt)"""
+        ids, vals = _arr(list(ints.keys()) or [0], np.int32), _arr(list(ints.values()) or [0], np.int64)
+        self._check(self.lib.set_label_value_ints(self.h, len(ints), _ptr(ids, C.c_int32), _ptr(vals, C.c_int64)))
+
     def set_deadline(self, seconds: float): self._check(self.lib.set_deadline(self.h, float(seconds)))
     def cancel(self): self._check(self.lib.cancel(self.h))
 
@@ -728,11 +734,10 @@ class Scheduler:
             s.has_fairshare_preemption_limiter = 1
             s.fairshare_preemption_tokens = float(fairshare_preemption_tokens)
         off = np.zeros(q + 1, dtype=np.int32)
-        flat: List[int] = []
-        for i, l in enumerate(queued):
+        parts = [np.asarray(l, dtype=np.int32).reshape(-1) for l in queued]
+        for i, l in enumerate(parts):
             off[i + 1] = off[i] + len(l)
-            flat.extend(int(x) for x in l)
-        qa = np.asarray(flat if flat else [0], dtype=np.int32)
+        qa = np.ascontiguousarray(np.concatenate(parts)) if (parts and off[q] > 0) else np.zeros(1, dtype=np.int32)
         keep += [off, qa]
         s.queued_off, s.queued_jobs = _ptr(off, C.c_int32), _ptr(qa, C.c_int32)
         self._check(self.lib.round_prepare(self.h, C.byref(s)))

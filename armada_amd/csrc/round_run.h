@@ -305,7 +305,7 @@ DEV_COLD int pqsEvict(Dev& d, Ctl& c, bool phase3) {
 }
 
 // ---- the serial slivers of the split round (host-driven sequence): each runs as one thread of a tiny kernel between grid-wide passes
-enum SmallKind { SM_QEVICTABLE = 1, SM_EVICT_POST, SM_STITCH, SM_MONO, SM_LVL0_BEGIN, SM_FINAL };
+enum SmallKind { SM_QEVICTABLE = 1, SM_EVICT_POST, SM_STITCH, SM_MONO, SM_LVL0_BEGIN, SM_FINAL, SM_PREPARE_FIN };
 DEV void roundSmall(Dev& d, int what, int arg) {
   const DevCfg& cf = d.cfg;
   switch (what) {
@@ -351,6 +351,10 @@ DEV void roundSmall(Dev& d, int what, int arg) {
       if (lazy) d.rs->replayPending = 1;
     } break;
     case SM_LVL0_BEGIN: d.rs->lvl0NonNeg = 1; break;
+    case SM_PREPARE_FIN:  // tail of CMD_PREPARE: fresh evicted table, fair shares (context/scheduling.go:262-342)
+      d.rs->fastActive = 0; d.rs->evictedTableSize = 0; d.rs->fairIndexValid = 0; d.rs->numUnfeasible = 0;
+      updateFairShares(d, (const double*)0);
+      break;
     case SM_FINAL:
       d.rs->fastActive = 0;  // unbinding changed priority -2 allocatable behind the fast structure: next round_prepare rebuilds it
       d.rs->terminationReason = d.cmdIO[4];

@@ -201,7 +201,8 @@ typedef struct asched_req_classes {
   /* PodRequirements.GetAffinityNodeSelector(): Affinity.NodeAffinity.RequiredDuringSchedulingIgnoredDuringExecution, checked per node by
      NodeAffinityRequirementsMet (nodematching.go:242-255, not at node-type level :127-139).  Optional: has_affinity == NULL = no class has
      one.  Terms are ORed, the expressions of a term ANDed, a term without expressions matches no node (k8s.io/component-helpers
-     v0.32.11 scheduling/corev1/nodeaffinity).  MatchFields and the Gt / Lt operators are not representable: ASCHED_ERR_UNSUPPORTED. */
+     v0.32.11 scheduling/corev1/nodeaffinity).  Gt / Lt compare integers: asched_set_label_value_ints tells which interned values parse.
+     MatchFields is not representable: ASCHED_ERR_UNSUPPORTED. */
   const uint8_t* has_affinity;   /* [n] 0 = nil NodeSelector: every node matches */
   const int32_t* aff_term_off;   /* [n+1] CSR: NodeSelectorTerms of each class */
   const int32_t* aff_expr_off;   /* [number of terms + 1] CSR: MatchExpressions of each term */
@@ -216,6 +217,8 @@ typedef struct asched_req_classes {
 #define ASCHED_AFFINITY_OP_NOT_IN 1
 #define ASCHED_AFFINITY_OP_EXISTS 2
 #define ASCHED_AFFINITY_OP_DOES_NOT_EXIST 3
+#define ASCHED_AFFINITY_OP_GT 4   /* label value and the single requirement value parsed as integers (apimachinery labels.Requirement.Matches): */
+#define ASCHED_AFFINITY_OP_LT 5   /* needs asched_set_label_value_ints for both; anything that does not parse matches nothing */
 
 /* ---- jobs: the jobdb view the round needs (jobdb/job.go accessors used on the path).
  *      Job ids are their index in this table; index order is the id-string order used as the
@@ -312,6 +315,10 @@ int32_t ASCHED_FN(priorities)(asched_t*, int32_t* out /*[ASCHED_MAX_PRIORITIES]*
 /* ------------------------------------------------------------------ NodeDb level */
 /* CreateAndInsert / UpsertMany (nodedb.go:57-75,1135-1175). Replaces all nodes. */
 int32_t ASCHED_FN(nodes_upsert)(asched_t*, const asched_nodes* nodes);
+/* Which interned label values are integers (strconv.ParseInt(value, 10, 64) succeeds) and their value — what the Gt / Lt node-affinity
+   operators compare (k8s.io/apimachinery labels.Requirement.Matches: both sides must parse, exactly one requirement value).  Replaces the
+   table; call before jobs_set / nodes_upsert evaluate affinities (the static masks are rebuilt by whichever of the two comes last). */
+int32_t ASCHED_FN(set_label_value_ints)(asched_t*, int32_t n, const int32_t* value_ids, const int64_t* ints);
 /* registers the job + requirement tables referenced by job id in the calls below */
 int32_t ASCHED_FN(jobs_set)(asched_t*, const asched_jobs* jobs, const asched_req_classes* classes);
 

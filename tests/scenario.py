@@ -154,6 +154,15 @@ class Case:
         node = [running[i][0] if i in running else -1 for i in range(m)]
         sap = [running[i][1] if i in running else 0 for i in range(m)]
         rts = [running[i][2] if i in running else 0 for i in range(m)]
+        # the interned strings that strconv.ParseInt(s, 10, 64) accepts: what the Gt / Lt affinity operators compare
+        ints = {}
+        for text, vid in self.S.d.items():
+            try:
+                if text.strip() == text and text.lstrip("+-").isdigit() and -2 ** 63 <= int(text) < 2 ** 63:
+                    ints[vid] = int(text)
+            except ValueError:
+                pass
+        self.sched.set_label_value_ints(ints)
         self.sched.jobs_set(
             np.array([vec(j["req"]) for j in jobs], dtype=np.int64).reshape(m, R),
             queue=[queue_index.get(j["queue"], -1) for j in jobs],
@@ -201,7 +210,7 @@ def uses_unsupported(case: dict, jobs: List[dict]) -> str:
     pcs = case["SchedulingConfig"]["priority_classes"]
     for j in jobs:
         if any(op not in AFFINITY_OPS for term in (j.get("affinity") or []) for _, op, _ in term):
-            return "node affinity operator Gt / Lt"
+            return "unknown node affinity operator"
         if "test-floating-resource" in j["req"] and "test-floating-resource" not in (case["SchedulingConfig"].get("floating_resources") or {}):
             return "floating resource requested without FloatingResources in the config"
     return ""

@@ -28,7 +28,7 @@ def job(affinity, i=0, queue="A"):
             "req": {"cpu": 1000, "memory": GI}}
 
 
-NODES = [node(0, {}), node(1, {"zone": "a"}), node(2, {"zone": "b", "disk": "ssd"}), node(3, {"zone": "c", "disk": "hdd"})]
+NODES = [node(0, {}), node(1, {"zone": "a", "gen": "7"}), node(2, {"zone": "b", "disk": "ssd", "gen": "12"}), node(3, {"zone": "c", "disk": "hdd", "gen": "new"})]
 # (name, affinity terms, nodes that satisfy it)
 RULES = [
     ("nil selector matches every node", None, {0, 1, 2, 3}),
@@ -42,6 +42,14 @@ RULES = [
     ("terms are ORed", [[["zone", "In", ["a"]]], [["disk", "In", ["hdd"]]]], {1, 3}),
     ("an empty term next to a matching one", [[], [["zone", "In", ["c"]]]], {3}),
     ("value never seen on a node", [[["zone", "In", ["nowhere"]]]], set()),
+    # Gt / Lt (k8s.io/apimachinery pkg/labels Requirement.Matches): integers on both sides, exactly one requirement value
+    ("Gt compares integers, not strings", [[["gen", "Gt", ["9"]]]], {2}),                  # "12" > "9" as numbers ("12" < "9" as strings)
+    ("Lt", [[["gen", "Lt", ["9"]]]], {1}),
+    ("Gt is strict", [[["gen", "Gt", ["12"]]]], set()),
+    ("a label that does not parse matches neither", [[["gen", "Gt", ["-100"]]]], {1, 2}),  # node 3 has gen=new; node 0 has no gen
+    ("a requirement value that does not parse matches nothing", [[["gen", "Lt", ["many"]]]], set()),
+    ("two requirement values match nothing", [[["gen", "Gt", ["1", "2"]]]], set()),
+    ("Gt next to In", [[["gen", "Gt", ["5"]], ["zone", "In", ["a", "b"]]]], {1, 2}),
 ]
 
 
@@ -83,12 +91,15 @@ def _round(lib, seed):
             labels["zone"] = str(rng.choice(zones))
         if rng.random() < 0.5:
             labels["disk"] = str(rng.choice(disks))
+        if rng.random() < 0.7:
+            labels["gen"] = str(int(rng.integers(1, 20)))
         nodes.append(node(i, labels))
     jobs = []
     for i in range(200):
-        k = int(rng.integers(0, 6))
+        k = int(rng.integers(0, 8))
         aff = [None, [[["zone", "In", [str(rng.choice(zones))]]]], [[["zone", "NotIn", ["a"]], ["disk", "Exists", []]]],
-               [[["disk", "DoesNotExist", []]], [["zone", "In", ["c"]]]], [[]], [[["disk", "In", ["ssd"]]]]][k]
+               [[["disk", "DoesNotExist", []]], [["zone", "In", ["c"]]]], [[]], [[["disk", "In", ["ssd"]]]],
+               [[["gen", "Gt", ["10"]]]], [[["gen", "Lt", ["6"]], ["zone", "NotIn", ["b"]]]]][k]
         j = job(copy.deepcopy(aff), i, queue=f"q{i % 2}")
         j["req"] = {"cpu": int(rng.integers(1, 4)) * 1000, "memory": int(rng.integers(1, 9)) * GI}
         jobs.append(j)
@@ -111,7 +122,8 @@ def test_round_hostsim_equals_oracle(oracle_lib, hostsim_lib, seed):
             continue
         def holds(e):
             k, op, vals = e
-            return {"In": k in lab and lab[k] in vals, "NotIn": not (k in lab and lab[k] in vals), "Exists": k in lab, "DoesNotExist": k not in lab}[op]
+            return {"In": k in lab and lab[k] in vals, "NotIn": not (k in lab and lab[k] in vals), "Exists": k in lab, "DoesNotExist": k not in lab,
+                    "Gt": k in lab and lab[k].isdigit() and int(lab[k]) > int(vals[0]), "Lt": k in lab and lab[k].isdigit() and int(lab[k]) < int(vals[0])}[op]
         assert any(t and all(holds(e) for e in t) for t in aff), (jobs[j], nodes[n])
 
 

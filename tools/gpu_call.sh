@@ -25,3 +25,4 @@ F=$(find "$OUT/pmc_FETCH_SIZE" -name "*.db" | head -1); W=$(find "$OUT/pmc_WRITE
 [ -n "$F" ] && [ -n "$W" ] && python tools/pmc_summary.py "$F" "$W" "$OUT/pmc_hbm_traffic.json" > /dev/null
 find "$OUT" -name "*.db" -size +8M -delete
 head -c 1500 "$OUT/bench_full.json" | tee -a "$OUT/summary.txt"
+ASCHED_HOSTPROF=1 timeout 300 python bench.py --steps 1 --warmup 0 --cpu-budget 0 --no-other > "$OUT/bench_hostprof.json" 2> "$OUT/bench_hostprof.err"; grep hostprof "$OUT/bench_hostprof.err" | tail -20 | tee -a "$OUT/summary.txt"
