@@ -136,6 +136,14 @@ class CPodResult(C.Structure):
     _fields_ = [("node", C.c_int32), ("scheduled_at_priority", C.c_int32), ("preempted_at_priority", C.c_int32), ("method", C.c_int32)]
 
 
+class COptResult(C.Structure):
+    _fields_ = [("node", C.c_int32), ("num_preempted", C.c_int32), ("scheduling_cost", C.c_double), ("maximum_queue_impact", C.c_double)]
+
+
+class COptNodeScore(C.Structure):
+    _fields_ = [("scheduled", C.c_int32), ("num_preempted", C.c_int32), ("scheduling_cost", C.c_double), ("maximum_queue_impact", C.c_double)]
+
+
 class CPqItem(C.Structure):
     _fields_ = [("proposed_cost", C.c_double), ("current_cost", C.c_double), ("budget", C.c_double), ("item_size", C.c_double),
                 ("pc_priority", C.c_int32), ("scheduling_priority", C.c_int32), ("name_rank", C.c_int32), ("pad_", C.c_int32)]
@@ -167,7 +175,7 @@ ALL_SYMBOLS = [
     "get_alloc", "get_scheduled_at_priority", "iterate_nodes", "fit_select_batch", "drf_cost", "fair_shares",
     "round_prepare", "schedule_round", "schedule_queues", "gang_schedule", "round_counters", "job_key_unfeasible", "kernel_times", "round_stats",
     "clear_allocated", "submit_check", "pq_order", "submit_stats", "num_nodes", "total_resources", "node_types_matching_job", "scheduling_order",
-    "set_label_value_ints", "round_timing", "set_deadline", "cancel", "indexed_node_label_values", "get_node_jobs", "get_nodes_alloc", "node_upsert",
+    "optimiser_schedule_job", "set_label_value_ints", "round_timing", "set_deadline", "cancel", "indexed_node_label_values", "get_node_jobs", "get_nodes_alloc", "node_upsert",
 ]
 
 
@@ -251,6 +259,7 @@ class Library:
         f("num_nodes", C.c_int32, [C.c_void_p])
         f("scheduling_order", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int32])
         f("set_label_value_ints", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i64p])
+        f("optimiser_schedule_job", C.c_int32, [C.c_void_p, C.c_int32, C.c_double, _i64p, C.c_int64, C.POINTER(COptResult), _i32p, C.c_int32, C.POINTER(COptNodeScore)])
         f("round_timing", C.c_int32, [C.c_void_p, C.POINTER(C.c_double)])
         f("set_deadline", C.c_int32, [C.c_void_p, C.c_double])
         f("cancel", C.c_int32, [C.c_void_p])
@@ -623,6 +632,18 @@ class Scheduler:
         out = np.zeros((self.P, self.R), dtype=np.int64)
         self._check(self.lib.get_alloc(self.h, node, _ptr(out, C.c_int64)))
         return out
+
+    def optimiser_schedule_job(self, job: int, min_improvement_pct: float = 0.0, max_job_size_to_preempt=None, now_ms: int = 0, per_node: bool = False):
+        """scheduleOnNodes of the fairness optimiser for one job -> dict(node, cost, impact, preempted[, scores: [N] (scheduled, npre, cost, impact)])"""
+        out = COptResult()
+        pre = (C.c_int32 * 256)()
+        ms = None if max_job_size_to_preempt is None else _arr(max_job_size_to_preempt, np.int64)
+        scores = (COptNodeScore * max(self.num_nodes, 1))() if per_node else None
+        self._check(self.lib.optimiser_schedule_job(self.h, job, float(min_improvement_pct), _ptr(ms, C.c_int64), int(now_ms), C.byref(out), pre, 256, scores))
+        r = dict(node=out.node, cost=out.scheduling_cost, impact=out.maximum_queue_impact, preempted=[pre[i] for i in range(min(out.num_preempted, 256))])
+        if per_node:
+            r["scores"] = [(bool(s.scheduled), s.num_preempted, s.scheduling_cost, s.maximum_queue_impact) for s in scores[: self.num_nodes]]
+        return r
 
     def set_label_value_ints(self, ints: Dict[int, int]):
         """interned label value id -> its integer value, for the values strconv.ParseInt accepts (node-affinity Gt / Lt)"""

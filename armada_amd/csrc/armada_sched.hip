@@ -25,6 +25,7 @@
 
 #define ASCHED_PREFIX asched_
 #include "round_run.h"
+#include "round_opt.h"
 
 // ------------------------------------------------------------------------------------------------ device primitives
 #define CTL_THREADS 256
@@ -100,6 +101,30 @@ __device__ static inline unsigned long long waveMin64(unsigned long long v) {
     v = o < v ? o : v;
   }
   return v;
+}
+
+// ---- cross-lane moves on the VALU (DPP) instead of through the LDS crossbar.  __shfl_* compile to ds_bpermute_b32: an LDS round trip (>100 clocks)
+// per 32-bit word, which a lone wave cannot hide; a DPP move is one VALU instruction.  gfx9-family controls: row_shr:n = 0x110+n, wave_shl:1 = 0x130,
+// row_half_mirror = 0x141, row_bcast:15 = 0x142, row_bcast:31 = 0x143, quad_perm = 0x00..0xff.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf> __device__ static inline unsigned long long dppMove64(unsigned long long old, unsigned long long v) {
+  unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)old, (int)(unsigned)v, CTRL, ROW_MASK, BANK_MASK, false);
+  unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(old >> 32), (int)(unsigned)(v >> 32), CTRL, ROW_MASK, BANK_MASK, false);
+  return ((unsigned long long)hi << 32) | lo;
+}
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf> __device__ static inline int dppMove32(int old, int v) {
+  return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+// minimum over the 64 lanes, returned wave-uniform.  min is idempotent: a lane without a valid source keeps its own value (old = v).
+__device__ static inline unsigned long long waveMin64Dpp(unsigned long long v) {
+  unsigned long long t;
+  t = dppMove64<0x111>(v, v); v = t < v ? t : v;              // row_shr:1
+  t = dppMove64<0x112>(v, v); v = t < v ? t : v;              // row_shr:2
+  t = dppMove64<0x114>(v, v); v = t < v ? t : v;              // row_shr:4
+  t = dppMove64<0x118>(v, v); v = t < v ? t : v;              // row_shr:8  -> lane 15 of every row of 16 holds the row's minimum
+  t = dppMove64<0x142, 0xa>(v, v); v = t < v ? t : v;         // row_bcast:15 into rows 1 and 3
+  t = dppMove64<0x143, 0xc>(v, v); v = t < v ? t : v;         // row_bcast:31 into rows 2 and 3 -> lane 63 holds the minimum
+  unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
 }
 
 // one thread per node (block-stride): reject by mask bit and key first, touch the alloc planes only for improving candidates
@@ -332,9 +357,10 @@ __device__ static inline void pqPopPush(PQState& s, const KeyOut& ko, int q) {
   int lane = threadIdx.x & 63;
   uint32_t hN = __builtin_amdgcn_readfirstlane(s.N);  // the name rank travels with the entry
   // everything after the head moves up one lane
-  uint32_t dA = __shfl_down(s.A, 1, 64), dN = __shfl_down(s.N, 1, 64);
-  unsigned long long dX = __shfl_down(s.X, 1, 64), dY = __shfl_down(s.Y, 1, 64);
-  int dq = __shfl_down(s.q, 1, 64);
+  // wave_shl:1 — lane i takes lane i+1's value; lane 63 has no source and is overwritten below (lane >= cnt)
+  uint32_t dA = (uint32_t)dppMove32<0x130>((int)s.A, (int)s.A), dN = (uint32_t)dppMove32<0x130>((int)s.N, (int)s.N);
+  unsigned long long dX = dppMove64<0x130>(s.X, s.X), dY = dppMove64<0x130>(s.Y, s.Y);
+  int dq = dppMove32<0x130>(s.q, s.q);
   int cnt = s.count - 1;  // entries other than the head
   if (lane >= cnt) { dA = ~0u; dN = ~0u; dX = ~0ull; dY = ~0ull; dq = -1; }
   if (!ko.valid) { s.A = dA; s.N = dN; s.X = dX; s.Y = dY; s.q = dq; s.count = cnt; return; }
@@ -363,10 +389,19 @@ __device__ static inline void drf3(Dev& d, int q, int k, bool replay, double w, 
     if (t != 0) f = (double)v / (double)t;
     x = f * d.cfg.drfMult[r];
   }
-  for (int off = 4; off; off >>= 1) { double o = __shfl_xor(x, off, 64); x = o > x ? o : x; }
+  {  // max over each group of 8 lanes, on every lane of the group (max is idempotent): lane^1, lane^2 inside the quad, then the mirrored quad
+    unsigned long long b = __builtin_bit_cast(unsigned long long, x), t; double o;
+    t = dppMove64<0xB1>(b, b); o = __builtin_bit_cast(double, t); x = o > x ? o : x; b = __builtin_bit_cast(unsigned long long, x);   // quad_perm [1,0,3,2]
+    t = dppMove64<0x4E>(b, b); o = __builtin_bit_cast(double, t); x = o > x ? o : x; b = __builtin_bit_cast(unsigned long long, x);   // quad_perm [2,3,0,1]
+    t = dppMove64<0x141>(b, b); o = __builtin_bit_cast(double, t); x = o > x ? o : x;                                                 // row_half_mirror: lane i <-> 7-i of its half row
+  }
   double m = x > 0 ? x : 0.0;
   double res = which == 2 ? m * w : m / w;
-  *proposed = __shfl(res, 0, 64); *current = __shfl(res, 8, 64); *size = __shfl(res, 16, 64);
+  {  // lanes 0, 8, 16 hold the three results: scalar reads
+    unsigned long long rb = __builtin_bit_cast(unsigned long long, res);
+    auto rl = [&](int l) { unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)rb, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rb >> 32), l); return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo); };
+    *proposed = rl(0); *current = rl(8); *size = rl(16);
+  }
 }
 
 __device__ static inline void fastFence(Ctl& c) {
@@ -415,17 +450,19 @@ __device__ static inline void baseScan(KREF k, FastS& S, const JobTail& r) {
 __device__ static inline uint64_t l0Search(KREF k, const JobTail& r, int* slot) {
   int lane = threadIdx.x & 63;
   unsigned long long best = ~0ull; int bs = -1;
-  int cnt = g_fl.l0Count;
-  for (int i = lane; i < cnt; i += 64) {
-    unsigned long long key = g_fl.l0Key[i];
-    if (key < best && entryFits(k, r, key, g_fl.l0Ex0[i], g_fl.l0Ex1[i], g_fl.l0Cls[i])) { best = key; bs = i; }
+  int cnt = UNI32(g_fl.l0Count);
+  for (int base = 0; base < cnt; base += 64) {   // the same trip count on every lane: the cross-lane reduction below sees a converged wave
+    int i = base + lane;
+    if (i < cnt) {
+      unsigned long long key = g_fl.l0Key[i];
+      if (key < best && entryFits(k, r, key, g_fl.l0Ex0[i], g_fl.l0Ex1[i], g_fl.l0Cls[i])) { best = key; bs = i; }
+    }
   }
-  for (int off = 32; off; off >>= 1) {
-    unsigned long long ok = __shfl_xor(best, off, 64); int os = __shfl_xor(bs, off, 64);
-    if (ok < best) { best = ok; bs = os; }
-  }
-  *slot = UNI32(bs);
-  return UNI64(best);
+  unsigned long long mn = waveMin64Dpp(best);   // keys are unique (node-index rank in the low bits): the lane that holds the minimum names the slot
+  if (mn == ~0ull) { *slot = -1; return mn; }
+  unsigned long long who = __ballot(best == mn);
+  *slot = __builtin_amdgcn_readlane(bs, __ffsll((long long)who) - 1);
+  return mn;
 }
 
 // WIN(=4) records x 16 lanes x 8 bytes: one coalesced 128-byte burst per job record
@@ -1045,6 +1082,41 @@ __global__ void k_seg_off(const int32_t* segOff, int nseg, int n, const uint32_t
   if (q <= nseg) outSegOff[q] = segOff[q] < n ? (int32_t)prefix[segOff[q]] : *total;
 }
 
+// ---- fairness optimiser (round_opt.h): per-node job lists (count / scan / scatter), queue costs, then every node scored for one job at once
+__global__ __launch_bounds__(256) void k_opt_count(Dev d, int32_t* cnt) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < d.cfg.M; j += gridDim.x * blockDim.x) { int n = d.jobNode[j]; if (n >= 0) atomicAdd(&cnt[n], 1); }
+}
+__global__ __launch_bounds__(1024) void k_opt_scan(const int32_t* cnt, int32_t* off, int32_t* cursor, int N) {   // one block: chunk sums, serial scan of 1024 partials, chunk offsets
+  __shared__ int part[1024];
+  int C = (N + 1023) / 1024, n0 = threadIdx.x * C, n1 = n0 + C < N ? n0 + C : N;
+  int sum = 0;
+  for (int n = n0; n < n1; n++) sum += cnt[n];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 1024; i++) { int v = part[i]; part[i] = run; run += v; } off[N] = run; }
+  __syncthreads();
+  int run = part[threadIdx.x];
+  for (int n = n0; n < n1; n++) { off[n] = run; cursor[n] = run; run += cnt[n]; }
+}
+__global__ __launch_bounds__(256) void k_opt_scatter(Dev d, int32_t* cursor, int32_t* jobs) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < d.cfg.M; j += gridDim.x * blockDim.x) { int n = d.jobNode[j]; if (n >= 0) jobs[atomicAdd(&cursor[n], 1)] = j; }
+}
+__global__ void k_opt_qcost(Dev d, int job, double* qCost) {   // QueueContext.CurrentCost per queue (scheduling_context.go:19-24); [Q]: the job's own DRF cost
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < d.cfg.Q) {
+    int64_t a[MAXR];
+    for (int r = 0; r < MAXR; r++) a[r] = r < d.cfg.R ? QV(d.qAlloc, q)[r] + QV(d.qPenalty, q)[r] : 0;
+    qCost[q] = drf(d, a);
+  } else if (q == d.cfg.Q) qCost[q] = drf(d, JREQ(d, job));
+}
+__global__ __launch_bounds__(128) void k_opt_score(Dev d, OptArgs a, const double* qCost, const int32_t* off, const int32_t* jobs, OptNodeOut* out) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < d.cfg.N) optScoreNode(d, a, qCost, off, jobs, d.jLeaseMs, n, &out[n], nullptr);
+}
+__global__ void k_opt_detail(Dev d, OptArgs a, const double* qCost, const int32_t* off, const int32_t* jobs, int n, OptNodeOut* out, int32_t* pre) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) optScoreNode(d, a, qCost, off, jobs, d.jLeaseMs, n, out, pre);
+}
+
 __global__ void k_shape_mask(Dev d, const uint64_t* classMask, const int32_t* shapeClass) {
   const DevCfg& c = d.cfg;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1307,6 +1379,40 @@ static int plat_evict_apply(Dev& d, int phase3, int total) {
   t_ctx->roundLaunches++;
   return hipOk(hipGetLastError(), "k_evict_apply launch") ? 0 : -1;
 }
+// fairness optimiser: every node scored for one job (k_opt_score), scores downloaded; detailNode >= 0: that node's preemption list as well
+static float g_lastOptMs = 0.f;
+static int plat_opt_score(Dev& d, const OptArgs& a, std::vector<OptNodeOut>& scores, double* jobCost, int detailNode, OptNodeOut* detail, int32_t* pre) {
+  PlatCtx* c = t_ctx;
+  int N = d.cfg.N, M = d.cfg.M, Q = d.cfg.Q;
+  int32_t *cnt = nullptr, *off = nullptr, *cursor = nullptr, *jobs = nullptr, *dPre = nullptr; double* qCost = nullptr; OptNodeOut* out = nullptr;
+  bool ok = hipOk(hipMalloc((void**)&cnt, sizeof(int32_t) * (size_t)(N + 1)), "opt alloc") && hipOk(hipMalloc((void**)&off, sizeof(int32_t) * (size_t)(N + 2)), "opt alloc") &&
+            hipOk(hipMalloc((void**)&cursor, sizeof(int32_t) * (size_t)(N + 1)), "opt alloc") && hipOk(hipMalloc((void**)&jobs, sizeof(int32_t) * (size_t)std::max(M, 1)), "opt alloc") &&
+            hipOk(hipMalloc((void**)&qCost, sizeof(double) * (size_t)(Q + 1)), "opt alloc") && hipOk(hipMalloc((void**)&out, sizeof(OptNodeOut) * (size_t)(N + 1)), "opt alloc") &&
+            hipOk(hipMalloc((void**)&dPre, sizeof(int32_t) * OPT_MAXJ), "opt alloc");
+  if (ok) {
+    (void)hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(N + 1), c->stream);
+    hipLaunchKernelGGL(k_opt_count, dim3(bulkGrid(M)), dim3(256), 0, c->stream, d, cnt);
+    hipLaunchKernelGGL(k_opt_scan, dim3(1), dim3(1024), 0, c->stream, (const int32_t*)cnt, off, cursor, N);
+    hipLaunchKernelGGL(k_opt_scatter, dim3(bulkGrid(M)), dim3(256), 0, c->stream, d, cursor, jobs);
+    hipLaunchKernelGGL(k_opt_qcost, dim3((Q + 1 + 63) / 64), dim3(64), 0, c->stream, d, a.job, qCost);
+    (void)hipEventRecord(c->fitEv0, c->stream);
+    hipLaunchKernelGGL(k_opt_score, dim3((N + 127) / 128), dim3(128), 0, c->stream, d, a, (const double*)qCost, (const int32_t*)off, (const int32_t*)jobs, out);
+    (void)hipEventRecord(c->fitEv1, c->stream);
+    if (detailNode >= 0) hipLaunchKernelGGL(k_opt_detail, dim3(1), dim3(64), 0, c->stream, d, a, (const double*)qCost, (const int32_t*)off, (const int32_t*)jobs, detailNode, out + N, dPre);
+    ok = hipOk(hipGetLastError(), "optimiser launch") && hipOk(hipStreamSynchronize(c->stream), "optimiser kernels");
+    (void)hipEventElapsedTime(&g_lastOptMs, c->fitEv0, c->fitEv1);
+  }
+  if (ok) {
+    scores.resize(N);
+    if (N) ok = hipOk(hipMemcpy(scores.data(), out, sizeof(OptNodeOut) * (size_t)N, hipMemcpyDeviceToHost), "opt scores");
+    if (ok) ok = hipOk(hipMemcpy(jobCost, qCost + Q, sizeof(double), hipMemcpyDeviceToHost), "opt job cost");
+    if (ok && detailNode >= 0) ok = hipOk(hipMemcpy(detail, out + N, sizeof(OptNodeOut), hipMemcpyDeviceToHost), "opt detail") && hipOk(hipMemcpy(pre, dPre, sizeof(int32_t) * OPT_MAXJ, hipMemcpyDeviceToHost), "opt detail");
+  }
+  for (void* p : {(void*)cnt, (void*)off, (void*)cursor, (void*)jobs, (void*)qCost, (void*)out, (void*)dPre}) if (p) (void)hipFree(p);
+  return ok ? 0 : -1;
+}
+static double plat_last_opt_ms() { return (double)g_lastOptMs; }
+
 // grid-wide order-preserving compaction; *total comes back to the host (the next launches are sized by it)
 static int plat_compact(Dev& d, const int32_t* order, int n, const uint8_t* flag, int32_t* dst, uint32_t* prefix, const int32_t* segOff, int nseg, int32_t* outSegOff, int* total) {
   (void)d;

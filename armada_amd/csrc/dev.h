@@ -38,6 +38,7 @@ struct DevCfg {
   int32_t keyShift[MAXK];
   int32_t keyWidth[MAXK];
   int32_t idxBits;
+  int32_t keyGuard;      // 1: every key field has a spare zero bit above it (FastCfg.guardMask)
   int32_t pcPriority[MAXPC];
   uint8_t pcPreemptible[MAXPC];
   double drfMult[MAXR];
@@ -87,6 +88,8 @@ struct FastCfg {
   int E; int extraCol[MAXE];  // non-indexed columns
   uint64_t fieldMask[MAXK];   // in-place mask of each packed key field
   uint64_t minFieldMin;       // per-field minimum of fieldMin over all shapes (liveness of a dirty node)
+  uint64_t guardMask;         // one spare (always zero) bit above every key field when the layout has room: "every field of a >= the same field of b" is
+                              // then ONE subtraction — ((a | guards) - b) keeps a field's guard bit iff that field did not borrow (0 = no room: field loop)
   int64_t minExtra[MAXE];
 };
 
@@ -237,6 +240,7 @@ struct Dev {
   const struct FastK* fk; // the fast loop's constants (round_fast.h), filled by the host at round_prepare
   QueueLoopArrays alt;    // second set for the lazy replay
   int64_t* qAllocSnap;    // [Q][R] queue allocations right after an evictor ran: what addEvictedJobsToNodeDb starts from
+  int64_t* jLeaseMs;      // [M] lease time of the active run in ms (run_timestamp / 1e6): job ages of the fairness optimiser
   int64_t* qNewJobNs;     // [Q] qctx.TotalNewJobSchedulingTime
   volatile int32_t* cancel;    // host-mapped word: != 0 = the caller's context is done (hard timeout / cancel, queue_scheduler.go:105-112); NULL = never
   volatile int32_t* progress;  // optional host-visible heartbeat (ASCHED_PROGRESS=1): [0] loop iterations, [1] phase, [2] current wide op, [3] wide ops issued

@@ -404,10 +404,12 @@ DEV const uint64_t* uniMask(Dev& d, int job) { int v = d.jcUniValue[job]; return
 DEV int64_t litCeilDiv(int64_t a, int64_t b) { int64_t q = a / b; return (a % b != 0 && a > 0) ? q + 1 : q; }  // b > 0
 // packed form of memdb LowerBound(NodeIndexKey(type, b)) within one node type: first packed key whose raw quantity tuple is >= b
 DEV uint64_t litBound(const DevCfg& c, const int64_t* b) {
+  // (a key field occupies keyWidth + keyGuard bits: the guard bit above it is zero in every key, so a bound that carries into one is still
+  //  "after every key with the smaller prefix and before every key with the next one")
   uint64_t acc = 0; int bits = 0; bool stop = false;
   for (int i = 0; i < c.K; i++) {
-    int w = c.keyWidth[i];
-    if (stop) { acc <<= w; bits += w; continue; }
+    int w = c.keyWidth[i], ws = w + c.keyGuard;
+    if (stop) { acc <<= ws; bits += ws; continue; }
     int64_t res = c.indexedRes[i];
     bool aligned = b[i] % res == 0;
     int64_t f = (aligned ? b[i] / res : litCeilDiv(b[i], res)) - c.keyLo[i];
@@ -418,7 +420,7 @@ DEV uint64_t litBound(const DevCfg& c, const int64_t* b) {
       if (bits < 64 && acc >= (1ull << bits)) return ~0ull;
       f = 0; stop = true;
     } else if (!aligned) stop = true;                        // a key column (multiple of the resolution) is never equal to an unaligned b
-    acc = (acc << w) | (uint64_t)f; bits += w;
+    acc = (acc << ws) | (uint64_t)f; bits += ws;
   }
   return acc << c.idxBits;
 }

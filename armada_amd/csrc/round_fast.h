@@ -171,7 +171,7 @@ struct FastCtx { int withQueued; uint32_t maxLookback; int skipKnown, compareSch
 struct FastK {
   int R, K, P, E, ex0col, ex1col, N, npc, S, disableHome, hasPcLimit, anyDisallowed, anyRoundLimit;
   size_t Npad;
-  uint64_t fieldMask[MAXK]; uint64_t minFieldMin; int64_t minEx0, minEx1;
+  uint64_t fieldMask[MAXK]; uint64_t minFieldMin; uint64_t guardMask; int64_t minEx0, minEx1;
   GP(uint64_t) baseKey; GP(int32_t) baseNode; GP(int64_t) baseExtra; GP(uint64_t) baseCls; GP(uint8_t) baseRemoved; GP(int32_t) l0Slot;
   GP(int64_t) alloc; GP(uint64_t) keys; GP(unsigned long long) jrec; GP(int32_t) evList; GP(int32_t) queuedJobs; GP(int32_t) evIdxByPos; GP(unsigned long long) evKey;
   GP(uint8_t) jcEvicted; GP(int32_t) jcAssigned; GP(int32_t) jcReason; GP(uint8_t) jcHasPctx; GP(int32_t) jcGangCard; GP(int32_t) jcUniValue; GP(int32_t) jcStagedBy;
@@ -209,7 +209,7 @@ HD void fastKInit(const Dev& d, FastK& k) {
   for (int i = 0; i < MAXR; i++) if (i < c.R && c.maxToSchedule[i] != INT64_MAX) k.anyRoundLimit = 1;  // MaximumResourceFractionToSchedule unset: +Inf x total saturates (resource_list.go:312-331)
   for (int i = 0; i < MAXR; i++) if (i < c.R && c.disallowed[i]) k.anyDisallowed = 1;
   for (int i = 0; i < MAXK; i++) k.fieldMask[i] = i < c.K ? d.f.fieldMask[i] : 0;
-  k.minFieldMin = d.f.minFieldMin; k.minEx0 = d.f.minExtra[0]; k.minEx1 = d.f.minExtra[1];
+  k.minFieldMin = d.f.minFieldMin; k.guardMask = d.f.guardMask; k.minEx0 = d.f.minExtra[0]; k.minEx1 = d.f.minExtra[1];
   k.baseKey = GA(uint64_t, d.baseKey); k.baseNode = GA(int32_t, d.baseNode); k.baseExtra = GA(int64_t, d.baseExtra); k.baseCls = GA(uint64_t, d.baseCls);
   k.baseRemoved = GA(uint8_t, d.baseRemoved); k.l0Slot = GA(int32_t, d.l0Slot);
   k.alloc = GA(int64_t, d.alloc); k.keys = GA(uint64_t, d.keys); k.jrec = GA(unsigned long long, (unsigned long long*)d.jrec);
@@ -238,6 +238,9 @@ HD FastK fastKRef(const Dev& d) { return *d.fk; }
 DEV uint64_t dbits(double x) { return __builtin_bit_cast(uint64_t, x); }
 
 DEV bool fieldsGE(KREF k, uint64_t key, uint64_t fmin) {  // every packed field of key >= the same field of fmin
+  // with a guard bit above every field (host: keyGuard): set the guards, subtract; a field that is smaller borrows from ITS guard and from nothing
+  // else (fmin has zero guard and index bits, so the index bits of key never borrow)
+  if (k.guardMask) return (((key | k.guardMask) - fmin) & k.guardMask) == k.guardMask;
   bool ok = true;
   for (int i = 0; i < MAXK; i++) { uint64_t m = k.fieldMask[i]; ok = ok && (key & m) >= (fmin & m); }  // unused fields have mask 0
   return ok;
@@ -475,7 +478,7 @@ DEV bool headRequestsDisallowed(Dev& d, KREF k, int q);
 DEV bool pinnedNodeFits(KREF k, int q, int n, int level);
 #endif
 DEV void candInvalidate(int S, int n) { FOR_LANES(s, S) if (FL.cand[s].node == n) FL.cand[s].node = -2; }
-DEV void candResetAll(Dev& d, const int32_t* pos) { FOR_LANES(s, d.cfg.S < SMAX ? d.cfg.S : SMAX) { FL.cand[s].node = -2; FL.cand[s].pos = pos ? pos[s] : 0; } }
+DEV void candResetAll(Dev& d, const int32_t* pos) { FOR_LANES(s, d.cfg.S < SMAX ? d.cfg.S : SMAX) { FL.cand[s].node = -2; FL.cand[s].pos = pos ? pos[s] : 0; FL.cand[s].key = 0; } }  // key 0: no lower bound known, the first query scans
 DEV void candSaveAll(Dev& d, int32_t* pos) { FOR_LANES(s, d.cfg.S < SMAX ? d.cfg.S : SMAX) pos[s] = FL.cand[s].pos; }
 
 // Before generic code runs: the LDS queue records back into the generic arrays, and the fast path's no-return atomics
@@ -534,15 +537,19 @@ DEV void fastTouch(Dev& d, int n) {
 DEV int fastFirstFit(KREF k, FastS& S, const JobTail& r, FitHandle* h, CandRec* cOut) {
   if (r.never) return -1;
   int s = r.shape;
-  if (UNI32(FL.cand[s].node) == -2) baseScan(k, S, r);
-  CandRec c = FL.cand[s];
-  uniCand(c);
-  *cOut = c;
-  uint64_t bk = c.node >= 0 ? c.key : ~0ull;
   int slot;
   uint64_t lk = l0Search(k, r, &slot);
+  CandRec c = FL.cand[s];
+  uniCand(c);
+  // A stale candidate (node -2: the node it named changed) still carries the key it was found with, and every clean entry the cursor can
+  // still reach orders AFTER that key (the base is sorted, keys are unique, the entry itself is flagged removed).  When the best dirty node
+  // already orders before it — the usual case: the node just bound moved down in the order and still has room — the dirty node wins without
+  // looking at the base at all; the rescan (a dependent read of a base tile) waits until some job needs it.
+  if (c.node == -2 && !(lk < c.key)) { baseScan(k, S, r); c = FL.cand[s]; uniCand(c); }
+  *cOut = c;
+  uint64_t bk = c.node >= 0 ? c.key : (c.node == -2 ? c.key : ~0ull);
   if (lk < bk) { h->src = 1; h->slot = slot; return UNI32(FL.l0Node[slot]); }
-  if (bk == ~0ull) return -1;
+  if (c.node < 0) return -1;
   h->src = 0; h->slot = -1;
   return c.node;
 }

@@ -413,7 +413,7 @@ int32_t ASCHED_FN(gang_schedule)(asched_t*, int32_t n, const int32_t* jobs, int3
 int32_t ASCHED_FN(round_counters)(asched_t*, int32_t* out /*[4]*/);
 /* Measurement hook (no reference counterpart): device time of the kernels behind the last call, taken with HIP events
    on the stream the kernels were launched on.  out[0] = ms of the last schedule_round/schedule_queues device work,
-   out[1] = ms of the last fit_select_batch kernel, out[2] = kernel launches behind out[0], out[3] = ms of the last submit_check launch.
+   out[1] = ms of the last fit_select_batch (or optimiser k_opt_score) kernel, out[2] = kernel launches behind out[0], out[3] = ms of the last submit_check launch.
    The CPU oracle reports zeros. */
 int32_t ASCHED_FN(kernel_times)(asched_t*, double* out /*[4]*/);
 /* Measurement hook (no reference counterpart): where the device time of the last schedule_round went.  out = {whole launch sequence ms (HIP
@@ -443,6 +443,32 @@ int32_t ASCHED_FN(get_nodes_alloc)(asched_t*, int32_t n, const int32_t* nodes, i
 /* Upsert / UpsertWithTxn of one node (nodedb.go:1154-1175): replaces the node's AllocatableByPriority ([P][R]) and rebuilds its order key
    at every priority.  Job bookkeeping travels through bind / evict / unbind. */
 int32_t ASCHED_FN(node_upsert)(asched_t*, int32_t node, const int64_t* alloc_by_prio);
+
+/* ------------------------------------------------------------------ experimental fairness optimiser (scheduling/optimiser)
+ * One job against EVERY node: PreemptingNodeScheduler.Schedule (optimiser/node_scheduler.go:42-132) per node — static requirements, fit at
+ * the evicted priority, else the node's preemptible non-gang jobs scheduled at a priority <= the job's, ordered per queue (scheduled-at
+ * priority, cost, age, id; preemption_info.go:23-55) and globally (priority preemptions first, then the queue whose cost after the
+ * preemption stays highest; :57-91), preempted one at a time until the job fits; schedulingCost = DRF cost of the victims that bring their
+ * queue to or below its fair share (:203-232), maximumQueueImpact = largest |cost change| / current cost over the queues (:101-113) — and
+ * the candidate selection of FairnessOptimisingGangScheduler.scheduleOnNodes for that job (gang_scheduler.go:100-141): nodes in id order,
+ * the first node that needs no preemption wins outright, otherwise nodes whose fairness improvement (cost of the job / scheduling cost,
+ * in percent minus 100) exceeds the threshold, ordered by (schedulingCost, maximumQueueImpact) (scheduling_result.go:49-68).  The reference
+ * breaks remaining ties by a random ULID; here the node with the smaller id rank wins.  Queue costs / fair shares / weights are the round
+ * state of the handle (round_prepare, or whatever rounds ran since).  Nothing is applied: the caller unbinds the victims and binds the job
+ * (markJobsScheduledAndPreempted, :173-246) through asched_unbind / asched_bind.
+ * max_job_size_to_preempt: [R] or NULL, 0 = no limit on that resource (node_scheduler.go:248-268).  now_ms: the clock the job ages are taken
+ * from (age = now - asched_jobs.run_timestamp / 1e6; jobs scheduled in this round have age 0).
+ * per_node (optional, [NumNodes]): every node's result, for callers that schedule gangs member by member. */
+typedef struct asched_opt_result {
+  int32_t node;                  /* -1 = no candidate */
+  int32_t num_preempted;         /* len(jobIdsToPreempt) of the chosen node */
+  double scheduling_cost;
+  double maximum_queue_impact;
+} asched_opt_result;
+typedef struct asched_opt_node_score { int32_t scheduled; int32_t num_preempted; double scheduling_cost; double maximum_queue_impact; } asched_opt_node_score;
+int32_t ASCHED_FN(optimiser_schedule_job)(asched_t*, int32_t job, double min_fairness_improvement_pct, const int64_t* max_job_size_to_preempt,
+                                          int64_t now_ms, asched_opt_result* out, int32_t* preempted /*cap*/, int32_t preempted_cap,
+                                          asched_opt_node_score* per_node);
 
 /* 1 if the job's scheduling key is registered in sctx.UnfeasibleSchedulingKeys (gang_scheduler.go:80-95) */
 int32_t ASCHED_FN(job_key_unfeasible)(asched_t*, int32_t job, int32_t* out);

@@ -14,6 +14,7 @@
 #include <chrono>
 #include <time.h>
 #include "../../armada_amd/csrc/round_run.h"
+#include "../../armada_amd/csrc/round_opt.h"
 // optional per-primitive wall-clock profile of the serial build (HOSTSIM_PROF=1): where would a wide device primitive matter?
 struct HsProf { double t[40]; long n[40]; bool on; HsProf() : on(getenv("HOSTSIM_PROF") != nullptr) { for (int i = 0; i < 40; i++) { t[i] = 0; n[i] = 0; } }
   ~HsProf() { if (on) for (int i = 0; i < 40; i++) if (n[i]) fprintf(stderr, "hsprof[%d] calls=%ld total=%.3fs\n", i, n[i], t[i]); } };
@@ -184,6 +185,23 @@ static int plat_run_fit_batch(Dev& d, const std::vector<int32_t>& shapes, int le
   }
   return 0;
 }
+// fairness optimiser: the per-node routine of round_opt.h over all nodes, serially
+static int plat_opt_score(Dev& dev, const OptArgs& a, std::vector<OptNodeOut>& scores, double* jobCost, int detailNode, OptNodeOut* detail, int32_t* pre) {
+  Dev d = dev;
+  int N = d.cfg.N, M = d.cfg.M, Q = d.cfg.Q;
+  std::vector<int32_t> off(N + 2, 0), jobs(std::max(M, 1));
+  for (int j = 0; j < M; j++) if (d.jobNode[j] >= 0) off[d.jobNode[j] + 1]++;
+  for (int n = 0; n < N; n++) off[n + 1] += off[n];
+  { std::vector<int32_t> cur(off.begin(), off.end()); for (int j = 0; j < M; j++) if (d.jobNode[j] >= 0) jobs[cur[d.jobNode[j]]++] = j; }
+  std::vector<double> qCost(Q + 1);
+  for (int q = 0; q < Q; q++) { int64_t v[MAXR]; for (int r = 0; r < MAXR; r++) v[r] = r < d.cfg.R ? QV(d.qAlloc, q)[r] + QV(d.qPenalty, q)[r] : 0; qCost[q] = drf(d, v); }
+  *jobCost = drf(d, JREQ(d, a.job));
+  scores.resize(N);
+  for (int n = 0; n < N; n++) optScoreNode(d, a, qCost.data(), off.data(), jobs.data(), d.jLeaseMs, n, &scores[n], nullptr);
+  if (detailNode >= 0) optScoreNode(d, a, qCost.data(), off.data(), jobs.data(), d.jLeaseMs, detailNode, detail, pre);
+  return 0;
+}
+static double plat_last_opt_ms() { return 0; }
 static int plat_run_drf(Dev& dev, const std::vector<int64_t>& a, const std::vector<int64_t>& t, double* out) {
   Dev d = dev;
   for (int r = 0; r < d.cfg.R; r++) d.cfg.totalResources[r] = t[r];
