@@ -248,6 +248,59 @@ def fit_batch_record(hip, args):
     return rec
 
 
+def optimiser_record(hip, args):
+    """SURVEY 8f-3, the experimental fairness optimiser's node scoring: after a round on the preemption-heavy shape (20k nodes 95% occupied), every
+    remaining queued job of a sample is scored against EVERY node (PreemptingNodeScheduler.Schedule per node, optimiser/gang_scheduler.go:100-141)
+    by one k_opt_score launch; selections, preemption lists and all per-node scores compared with the oracle's serial loop."""
+    import numpy as np
+    import torch
+    from armada_amd import workloads as W
+    from armada_amd.binding import Library
+    sc = args.other_scale
+    wl = W.config3(seed=W.SEED, n_nodes=max(16, int(20_000 * sc)), n_jobs=max(200, int(200_000 * sc)), n_queues=32 if sc == 1.0 else 4, occupied=0.95)
+    wl.global_burst, wl.queue_burst = max(1, int(200_000 * 0.2 * sc)), max(1, int(20_000 * 0.2 * sc))
+    wl.job_run_ts = (np.arange(wl.num_jobs, dtype=np.int64) * 7919 % 100003) * 1_000_000
+    n_sample = 32
+
+    def run(lib, timed):
+        s = W.load(lib, wl); W.prepare(s, wl)
+        r = s.schedule_round()
+        done = set(int(j) for j in r.scheduled)
+        left = [int(j) for j in np.nonzero((wl.job_node < 0) & (wl.job_gang < 0))[0] if int(j) not in done][:n_sample]
+        out, host, dev = [], [], []
+        for j in left:
+            if timed: torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out.append(s.optimiser_schedule_job(j, min_improvement_pct=5.0, now_ms=200_000, per_node=True))
+            host.append(time.perf_counter() - t0)
+            if timed: dev.append(s.kernel_times()["fit_batch_ms"])
+        running = int((wl.job_node >= 0).sum()) + len(r.scheduled) - len(r.preempted)
+        s.close()
+        return out, host, dev, running
+
+    got, host, dev, running = run(hip, True)
+    R = W.R
+    direct = float(np.mean([sum(1 for x in g["scores"] if x[0] and x[1] == 0) for g in got])) if got else 0.0
+    walked_frac = 1.0 - direct / max(wl.num_nodes, 1)
+    alg = wl.num_nodes * (8 * R + 8) + walked_frac * running * (4 + 4 + 4 + 4 + 4 + 8 + 8 * R) + wl.num_nodes * 24   # node row + static bit word; per job of a walked node: list entry, pc, gang, priority, queue, lease, request; the score record written
+    dev_ms = float(np.mean(dev)) if dev else 0.0
+    ach = alg / max(dev_ms * 1e-3, 1e-12) / 1e9
+    rec = {"config": "fairness optimiser node scoring (SURVEY 8f-3)",
+           "workload": f"{wl.num_nodes} nodes (95% occupied, {running} running jobs) x {len(got)} queued jobs left over by the round, each scored against every node",
+           "metric": "jobs scored against all nodes per second (asched_optimiser_schedule_job, host call incl. per-node score download)",
+           "value": len(got) / max(sum(host), 1e-12), "unit": "jobs/s", "host_ms_per_job": float(np.mean(host)) * 1e3 if host else None, "k_opt_score_ms": dev_ms,
+           "nodes_needing_preemption_walk": walked_frac, "selected_with_preemption": sum(1 for g in got if g["preempted"]), "selected_without": sum(1 for g in got if g["node"] >= 0 and not g["preempted"]),
+           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": "k_opt_score", "algorithmic_bytes_per_launch": alg,
+                        "note": "one node per thread; the per-node job walk is data dependent (gathered rows of the job tables), so this kernel is latency rather than bandwidth bound at this size"}}
+    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if args.cpu_budget > 0 and os.path.exists(path):
+        want, chost, _, _ = run(Library(path, "oracle_"), False)
+        rec["cpu_baseline"] = {"value": len(want) / max(sum(chost), 1e-12), "unit": "jobs/s", "cores": 1, "kind": "port",
+                               "sample": f"the same {len(want)} jobs on the CPU oracle (serial loop over all nodes per job), {sum(chost):.2f} s"}
+        rec["parity"] = {"checked": True, "identical": want == got, "jobs": len(got), "against": "oracle: selected node, preempted jobs in order, cost, impact and every node's score (floats bit-equal)"}
+    return rec
+
+
 def round_shape_record(hip, args, label, kwargs, steps, note):
     """one of the other BASELINE round shapes (configs[3] gangs, configs[4] oversubscribed / preemption-heavy): GPU rounds timed like the headline,
     the oracle on the same input for the cpu_baseline and the parity verdict when its round fits the remaining budget"""
@@ -332,6 +385,7 @@ def other_configs(hip, args, t_start):
         rec["config"] = "submit check (SURVEY 8f-2)"
         return rec
     guarded("submit check", submit)
+    guarded("fairness optimiser node scoring", lambda: optimiser_record(hip, args))
     return recs
 
 
