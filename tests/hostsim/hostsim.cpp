@@ -186,7 +186,7 @@ static int plat_run_fit_batch(Dev& d, const std::vector<int32_t>& shapes, int le
   return 0;
 }
 // fairness optimiser: the per-node routine of round_opt.h over all nodes, serially
-static int plat_opt_score(Dev& dev, const OptArgs& a, std::vector<OptNodeOut>& scores, double* jobCost, int detailNode, OptNodeOut* detail, int32_t* pre) {
+static int plat_opt_score(Dev& dev, const OptArgs& a, std::vector<OptNodeOut>& scores, double* jobCost, int detailNode, OptNodeOut* detail, int32_t* pre, bool detailOnly = false) { (void)detailOnly;
   Dev d = dev;
   int N = d.cfg.N, M = d.cfg.M, Q = d.cfg.Q;
   std::vector<int32_t> off(N + 2, 0), jobs(std::max(M, 1));
