@@ -598,6 +598,74 @@ __device__ static inline int engineWait(const FastS& S) {
   LDS_ORDER();
   return __builtin_amdgcn_readfirstlane(g_fl.eng.status);
 }
+
+// ---- stream run (round_fast.h): ring between the control wave (merge + record staging) and the node engine
+__device__ static inline void qsWinRefill(KREF k, int q, int pos, int cnt) {
+  int lane = threadIdx.x & 63;
+  if (lane < cnt * 4) ((unsigned long long*)&g_fl.evWin[q][0])[lane] = k.qsKey[((size_t)q * QS_CMAX + pos) * 4 + lane];
+}
+__device__ static inline void streamBegin(int* engSeq) {
+  int lane = threadIdx.x & 63;
+  if (lane == 0) { g_fl.eng.ringPub = 0; g_fl.eng.ringAck = 0; g_fl.eng.ringEnd = 0; g_fl.eng.ringFail = 0; g_fl.eng.cmd = ENG_STREAM; }
+  (*engSeq)++;
+  LDS_ORDER();
+  if (lane == 0) __hip_atomic_store(&g_fl.eng.seq, *engSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// records of ring entries [base, base + cnt), cnt <= 4: 16 lanes x 8 bytes each, one coalesced 128-byte burst per record; the value is consumed by
+// streamStageCommit one group later, so the HBM latency runs under the merge
+__device__ static inline unsigned long long streamStageIssue(KREF k, int base, int cnt) {
+  int lane = threadIdx.x & 63;
+  int i = lane >> 4, part = lane & 15;
+  unsigned long long v = 0;
+  if (i < cnt) { int job = RJOB(base + i); v = k.jrec[(size_t)job * (sizeof(JobRec) / 8) + part]; }
+  return v;
+}
+__device__ static inline void streamStageCommit(Dev& d, KREF k, int base, int cnt, unsigned long long v) {
+  (void)d; (void)k;
+  int lane = threadIdx.x & 63;
+  int i = lane >> 4, part = lane & 15;
+  if (i < cnt) ((unsigned long long*)&RREC(base + i))[part] = v;
+  LDS_ORDER();
+  if (lane == 0) __hip_atomic_store(&g_fl.eng.ringPub, base + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ static inline void streamEnd(int engSeq) {
+  int lane = threadIdx.x & 63;
+  LDS_ORDER();
+  if (lane == 0) __hip_atomic_store(&g_fl.eng.ringEnd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (;;) {   // the engine acknowledges the ENG_STREAM command when it has left the ring
+    int a = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if (a == engSeq) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  LDS_ORDER();
+}
+__device__ static inline int streamAcked(int* fail) {
+  int a = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringAck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+  int f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringFail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+  // a failure flag read together with an older ack count: entries bound before the failing one are all counted when the flag is seen again after the ack
+  if (f) a = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringAck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+  *fail = f;
+  return a;
+}
+// sctx / qctx accounting of ring entry i once the engine has bound it (accountVectors for a new job), one lane per resource; lane q counts queue q's entries
+__device__ static inline void streamAccount(Dev& d, KREF k, int i, StreamCnt& cnt) {
+  (void)d;
+  int lane = threadIdx.x & 63;
+  int q = __builtin_amdgcn_readfirstlane(RQ(i));
+  const JobRec& r = RREC(i);
+  int pc = __builtin_amdgcn_readfirstlane(r.pc);
+  if (lane < k.R) {
+    int64_t v = r.req[lane];
+    if (v) {
+      LDS_ADD64(g_fl.qAlloc[q][lane], v); LDS_ADD64(g_rs.allocated[lane], v); LDS_ADD64(g_rs.scheduled[lane], v);
+      size_t j = ((size_t)q * k.npc + pc) * k.R + lane;
+      __hip_atomic_fetch_add(&k.qAllocByPc[j], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&k.qSchedByPc[j], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (lane == q) cnt.v++;
+}
+__device__ static inline int streamCount(const StreamCnt& cnt, int q) { return __builtin_amdgcn_readlane(cnt.v, q); }
 // key and name rank of the heap's head entry (queue t): lane 0 of the heap lanes, no LDS access
 __device__ static inline void pqHeadKey(PQState& s, int t, PackedKey* key, uint32_t* nameRank) {
   if (__builtin_amdgcn_readfirstlane(s.q) == t) {
@@ -663,6 +731,41 @@ __device__ static void engineLoop(Dev& d) {  // wave 1
       LDS_ORDER();
       if (lane == 0) __hip_atomic_store(&g_fl.eng.ack, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       return;
+    }
+    if (cmd == ENG_STREAM) {
+      // walk the ring: entry i is ready when ringPub > i; stop at the first job that finds no node (ringFail 1), after an L0 overflow (2), or when the
+      // control wave has closed the ring and everything staged is bound
+      int i = 0;
+      for (;;) {
+        int pub;
+        for (;;) {
+          pub = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringPub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+          if (pub > i) break;
+          int end = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringEnd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+          if (end) { pub = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringPub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (pub <= i) break;
+        LDS_ORDER();
+        ESEG(0);
+        long long b0 = (long long)__builtin_readcyclecounter();
+        {  // the entry's record becomes the mailbox job (the engine's own LDS writes, read back in order)
+          const JobRec& r = RREC(i);
+          if (lane < 8) ((unsigned long long*)g_fl.eng.req)[lane] = ((const unsigned long long*)&r)[lane];
+          else if (lane < 16) ((unsigned long long*)&g_fl.eng.tail)[lane - 8] = ((const unsigned long long*)&r)[lane];
+          if (lane == 0) { int32_t p = r.pcPrio; g_fl.eng.job = RJOB(i); g_fl.eng.prio = p; g_fl.eng.cutoff = r.preemptible ? p : NONPREEMPTIBLE_CUTOFF; g_fl.eng.nl = r.nlPc; }
+        }
+        int st = engineServe(d, k, ES);
+        busy += (long long)__builtin_readcyclecounter() - b0; jobs++;
+        if (st == 0) { if (lane == 0) __hip_atomic_store(&g_fl.eng.ringFail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+        i++;
+        if (lane == 0) __hip_atomic_store(&g_fl.eng.ringAck, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (st == 2) { LDS_ORDER(); if (lane == 0) __hip_atomic_store(&g_fl.eng.ringFail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+        ESEG(6);
+      }
+      LDS_ORDER();
+      if (lane == 0) __hip_atomic_store(&g_fl.eng.ack, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      continue;
     }
     ESEG(0);
     long long b0 = (long long)__builtin_readcyclecounter();

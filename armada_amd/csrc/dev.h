@@ -79,6 +79,15 @@ struct JobRec {
 // pass (round_run.h B_EVKEYS): the DRF costs updatePQItem would compute when the job becomes the queue's head.
 struct EvKey { double proposed, current, size; int32_t pcPrio; int32_t job; };
 
+// Queued-job streams (round_fast.h "stream run").  While every queued job fits without preemption the queue side of an iteration depends on
+// nothing but the queue's own allocation prefix: the same costs, for the next QS_CMAX queued jobs of every queue, are computed ahead by a
+// chunked prefix pass (round_run.h B_QSSUM -> B_QSSTITCH -> B_QSKEYS) into EvKey records; the control wave then merely merges the
+// precomputed streams through its lane heap and stages job records for the node engine.
+#define QS_CMAX 4096          // stream entries per queue and preparation
+#define QS_CHUNK 64           // entries one bulk item covers
+#define QS_CPQ (QS_CMAX / QS_CHUNK)
+struct QsIn { int32_t base, len, skipUnf, pad; int64_t a0[MAXR]; double weight; };   // per queue: position of element 0 in queuedJobs, wanted length, allocation + penalty before element 0
+
 // Level-0 ("fit without preemption", priority -2) fast structure, DESIGN.md "Sorted base + LDS delta".
 struct FastCfg {
   int structOk, iterOk;       // host-verified exactness conditions (asched_host.inc: fastConditions)
@@ -117,6 +126,7 @@ struct RoundScalars {
   int32_t fastOverflow;      // L0 overflowed: structure dropped for the rest of the round
   int32_t replayPending;     // the eviction-order replay (evicted-table Index assignment) has been deferred: nothing has read it yet
   int32_t statFastIters, statGenericIters, statScanSteps, statRefills, statL0Max, statFastReplay;
+  int32_t statStreamRuns, statStreamJobs, statStreamPrepared, statStreamEmitted;   // stream runs (round_fast.h): runs, entries bound, stream entries prepared, entries emitted by the merge
   int32_t awayRowPlus1;      // an away attempt is in progress: static mask row (+1) that replaces the job's home shape row
   int32_t fairIndexValid;    // the per-node index of the evicted table (fairOff/fairEnt) describes the current table
   int64_t totalNewJobNs;     // sctx.TotalNewJobSchedulingTime (context/scheduling.go:212-240)
@@ -235,6 +245,10 @@ struct Dev {
   uint8_t* evMono;       // [Q+1] the queue's evicted stream has non-decreasing queue-order keys (heap merge == sort by key)
   uint64_t* evEdge;      // [evChunks][8] first / last packed key of each chunk (monotonicity across chunk borders)
   int32_t evChunks;
+  EvKey* qsKey;          // [QCAPF][QS_CMAX] precomputed costs of the queued-job streams
+  QsIn* qsIn;            // [QCAPF]
+  int64_t* qsPart;       // [QCAPF * QS_CPQ][MAXR + 2] chunk sums -> carries, first barrier of the chunk
+  int32_t* qsLen;        // [QCAPF][2] usable stream length, 1 = the queue's list ends with the stream
   int32_t* l0Save;       // [L0CAP]
   int32_t* candPosSave;  // [SMAX]
   const struct FastK* fk; // the fast loop's constants (round_fast.h), filled by the host at round_prepare

@@ -373,6 +373,7 @@ struct Ctl {
   int skipEnter;       // the next fast run may fold the gang-free evicted streams out of the loop (round_fast.h "skip mode")
   int skipActive;
   int cancelSeen;      // a fast run saw the cancel word
+  int streamNextAt, streamBackoff;   // stream runs (round_fast.h): not before this many fast iterations; doubled after a run too short to pay for its preparation
 };
 // Less (queue_scheduler.go:738-798) as a lexicographic key (A, X, Y, then the queue-name rank); exact for finite, non-negative costs
 struct PackedKey { uint32_t A; uint64_t X, Y; };

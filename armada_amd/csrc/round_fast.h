@@ -39,7 +39,9 @@ struct alignas(16) QHot {
   int32_t winKind, winStart, winCount;      // prefetch window: stream (0 evicted list, 1 queued list) and position range
   int32_t evCheap, evApplied, evDone, ewStart, ewCount, headPos;  // evicted stream with precomputed keys: served up to evDone, commits applied up to evApplied; key window; stream position of an evicted head
   int32_t effValid, skipStart;  // skip mode: the queue's evicted stream [skipStart, evEnd) was folded out of the loop; its head key is a running maximum
+  int32_t sPos, sLen;           // stream run: the queue's head is element sPos of its precomputed stream of sLen entries (0: no stream)
 };
+static_assert(sizeof(QHot) == 176, "QHot: the stream fields use the tail padding");
 struct alignas(16) JobTail {  // second half of a JobRec
   uint64_t keyDelta, fieldMin;
   int32_t pc, shape, gang, node0, runPrio, cls, pcPrio;
@@ -54,14 +56,21 @@ struct alignas(16) CandRec { int32_t pos, node; uint64_t key, cls; int64_t ex0, 
 // control wave posts the job to a second wave (the node engine) and carries on with the queue side assuming it fits; the verdict
 // is collected before the next iteration starts.  On a miss the queue side of that one iteration is taken back (IterBackup) and
 // the generic code runs it from exactly the state it would have found.
-enum { ENG_JOB = 1, ENG_QUIT = 2 };
+enum { ENG_JOB = 1, ENG_QUIT = 2, ENG_STREAM = 3 };
 struct alignas(16) EngineBox {
   JobTail tail; int64_t req[MAXR];          // the job: its record as fastIter read it
   int32_t job, prio, cutoff, nl, cmd, status;
   int32_t seq, ack;                          // command n is ready when seq == n; served when ack == n
   int32_t statScan, statL0Max;               // engine counters, handed over at ENG_QUIT
   int64_t busyClk; int32_t jobs, cancel;     // shader-clock ticks the engine spent serving jobs, and how many; cancel: the engine saw the caller's cancel word
+  int32_t ringPub, ringAck, ringEnd, ringFail;   // stream run: entries staged in the ring / bound by the engine; no more entries will come; 1 = entry ringAck found no node, 2 = bound but L0 overflowed
 };
+// stream run: the job-record windows are idle and serve as the ring between the control wave and the node engine
+#define RING_N (QCAPF * WIN)
+#define RREC(i) (((JobRec*)FL.winRec)[(i) & (RING_N - 1)])
+#define RJOB(i) (((int32_t*)FL.winJob)[(i) & (RING_N - 1)])
+#define RQ(i) (((int32_t*)FL.winIdx)[(i) & (RING_N - 1)])
+static_assert((RING_N & (RING_N - 1)) == 0, "ring size");
 struct alignas(16) IterBackup {  // the job's record and request stay in the mailbox (the engine only reads them)
   QHot hot;
   uint64_t kX, kY, effX, effY; double globalTokens;
@@ -139,12 +148,19 @@ template <class T> __device__ static inline T uniT64(T v) { return (T)uni64((uns
 
 #ifdef ASCHED_FASTPROF
 #define ESEG(i) do { long long _n = CLK(); ES.eseg[i] += _n - ES.segT; ES.segT = _n; } while (0)   // node engine segments (its own FastS)
+#define FSEG(i) do { long long _n = CLK(); S.eseg[i] += _n - S.segT; S.segT = _n; } while (0)
 #define SEG_BEGIN() S.segT = CLK()
 #define SEG(i) do { long long _n = CLK(); if (FLANE == 0 && _n - S.segT < (1ll << 32)) RS.statSeg[i] += _n - S.segT; S.segT = _n; } while (0)  // cold helpers start their own clock at 0: skip those
 #else
 #define SEG_BEGIN() do {} while (0)
 #define SEG(i) do {} while (0)
 #define ESEG(i) do {} while (0)
+#define FSEG(i) do {} while (0)
+#endif
+#if defined(ASCHED_HOSTSIM) || !defined(__HIP_DEVICE_COMPILE__)
+#define STREAM_IDLE() do {} while (0)
+#else
+#define STREAM_IDLE() __builtin_amdgcn_s_sleep(2)
 #endif
 DEV void uniQHot(QHot& f) {
   f.weight = UNID(f.weight); f.tokens = UNID(f.tokens); f.budget = UNID(f.budget); f.proposed = UNID(f.proposed); f.current = UNID(f.current); f.size = UNID(f.size);
@@ -155,7 +171,7 @@ DEV void uniQHot(QHot& f) {
   f.headFast = UNI32(f.headFast); f.headKind = UNI32(f.headKind); f.headIdx = UNI32(f.headIdx);
   f.winKind = UNI32(f.winKind); f.winStart = UNI32(f.winStart); f.winCount = UNI32(f.winCount);
   f.evCheap = UNI32(f.evCheap); f.evApplied = UNI32(f.evApplied); f.evDone = UNI32(f.evDone); f.ewStart = UNI32(f.ewStart); f.ewCount = UNI32(f.ewCount); f.headPos = UNI32(f.headPos);
-  f.effValid = UNI32(f.effValid); f.skipStart = UNI32(f.skipStart);
+  f.effValid = UNI32(f.effValid); f.skipStart = UNI32(f.skipStart); f.sPos = UNI32(f.sPos); f.sLen = UNI32(f.sLen);
 }
 DEV void uniJobTail(JobTail& r) {
   r.keyDelta = UNI64(r.keyDelta); r.fieldMin = UNI64(r.fieldMin);
@@ -167,7 +183,7 @@ DEV void uniJobTail(JobTail& r) {
 DEV void uniCand(CandRec& c) { c.pos = UNI32(c.pos); c.node = UNI32(c.node); c.key = UNI64(c.key); c.cls = UNI64(c.cls); c.ex0 = UNI64(c.ex0); c.ex1 = UNI64(c.ex1); }
 struct FitHandle { int src; int slot; };  // src 0: base candidate of the shape, 1: L0 slot
 // what the fast loop needs of Ctl + PassCfg, by value
-struct FastCtx { int withQueued; uint32_t maxLookback; int skipKnown, compareSchedPrio, preferLarge, replay, evStatic, engine; };
+struct FastCtx { int withQueued; uint32_t maxLookback; int skipKnown, compareSchedPrio, preferLarge, replay, evStatic, engine, stream; };
 
 // loop constants: configuration and array bases, read once per fastRun (registers for the whole run)
 struct FastK {
@@ -182,6 +198,7 @@ struct FastK {
   GP(uint8_t) evTabAlive; GP(int32_t) evTabJob; GP(int32_t) evIndexOfJob; GP(uint8_t) unfeasible;
   GP(int64_t) qAllocByPc; GP(int64_t) qSchedByPc; GP(int64_t) qEvictedByPc;
   GP(uint8_t) jcPreempted; GP(uint8_t) nodeFlags;
+  GP(unsigned long long) qsKey;
   int32_t prios[MAXP];
 };
 // scheduling-context scalars the loop reads and writes (context/scheduling.go:27-77), written back to RS at the end of a run
@@ -228,6 +245,7 @@ HD void fastKInit(const Dev& d, FastK& k) {
   k.evTabAlive = GA(uint8_t, d.evTabAlive); k.evTabJob = GA(int32_t, d.evTabJob); k.evIndexOfJob = GA(int32_t, d.evIndexOfJob); k.unfeasible = GA(uint8_t, d.unfeasible);
   k.qAllocByPc = GA(int64_t, d.qAllocByPc); k.qSchedByPc = GA(int64_t, d.qSchedByPc); k.qEvictedByPc = GA(int64_t, d.qEvictedByPc);
   k.jcPreempted = GA(uint8_t, d.jcPreempted); k.nodeFlags = GA(uint8_t, d.nodeFlags);
+  k.qsKey = GA(unsigned long long, (unsigned long long*)d.qsKey);
   for (int i = 0; i < MAXP; i++) k.prios[i] = i < c.P ? c.prios[i] : INT32_MAX;
 }
 // a register copy of the constants: one burst of scalar loads (constant address space) per call, then no memory traffic
@@ -291,7 +309,7 @@ DEV void fastQLoad(Dev& d) {
     f.rateInf = d.qRateInf[q]; f.cordoned = d.qCordoned[q]; f.itJobOnlyEv = d.itJobOnlyEv[q]; f.itGangOnlyEv = d.itGangOnlyEv[q];
     { int g = f.gctx; bool headEv = g >= 0 && d.jcEvicted[g];  // an evicted head was yielded from evList[itEi-1] and is not served yet
       f.evCheap = d.evCheap ? d.evCheap[q] : 0; f.evDone = f.evApplied = headEv ? f.itEi - 1 : f.itEi; f.headPos = headEv ? f.itEi - 1 : -1;
-      f.effValid = 0; f.skipStart = 0; }
+      f.effValid = 0; f.skipStart = 0; f.sPos = 0; f.sLen = 0; }
     FL.inHeap[q] = d.pqInHeap[q]; FL.nameRank[q] = d.qNameRank[q];
   }
 }
@@ -453,6 +471,43 @@ DEV bool pinnedNodeFits(KREF k, int q, int n, int level) {
   return true;
 }
 DEV void pqHeadKey(PQState&, int t, PackedKey* key, uint32_t* nameRank) { key->A = FL.kA[t]; key->X = FL.kX[t]; key->Y = FL.kY[t]; *nameRank = (uint32_t)FL.nameRank[t]; }
+// ---- stream run, serial build.  The engine serves an entry when its record is staged, so that entries emitted but not yet staged when a job
+// does not fit are discarded exactly as on the device (there the engine runs behind the merge by up to a ring's worth of entries).
+struct StreamCnt { int v[QCAPF]; };
+DEV void qsWinRefill(KREF k, int q, int pos, int cnt) { for (int i = 0; i < cnt; i++) memcpy(&FL.evWin[q][i], (const char*)k.qsKey + ((size_t)q * QS_CMAX + pos + i) * sizeof(EvKey), sizeof(EvKey)); }
+DEV int engineServe(Dev& d, KREF k, FastS& ES);
+static FastS g_engS;
+DEV void streamBegin(int* engSeq) { FL.eng.ringPub = FL.eng.ringAck = FL.eng.ringEnd = FL.eng.ringFail = 0; FL.eng.cmd = ENG_STREAM; (*engSeq)++; }
+static JobRec g_hsStage[4];
+DEV unsigned long long streamStageIssue(KREF k, int base, int cnt) { for (int i = 0; i < cnt; i++) memcpy(&g_hsStage[i], (const char*)k.jrec + (size_t)RJOB(base + i) * sizeof(JobRec), sizeof(JobRec)); return 0; }
+DEV void streamServeOne(Dev& d, KREF k, int i) {
+  const JobRec& r = RREC(i);
+  memcpy(FL.eng.req, r.req, sizeof FL.eng.req); memcpy(&FL.eng.tail, &r.keyDelta, sizeof(JobTail));
+  FL.eng.job = RJOB(i); FL.eng.prio = r.pcPrio; FL.eng.cutoff = r.preemptible ? r.pcPrio : NONPREEMPTIBLE_CUTOFF; FL.eng.nl = r.nlPc; FL.eng.cmd = ENG_JOB;
+  int st = engineServe(d, k, g_engS);
+  if (st == 0) { FL.eng.ringFail = 1; return; }
+  FL.eng.ringAck = i + 1;
+  if (st == 2) FL.eng.ringFail = 2;
+}
+DEV void streamStageCommit(Dev& d, KREF k, int base, int cnt, unsigned long long) {
+  for (int i = 0; i < cnt; i++) RREC(base + i) = g_hsStage[i];
+  FL.eng.ringPub = base + cnt;
+  for (int i = base; i < base + cnt; i++) if (!FL.eng.ringFail) streamServeOne(d, k, i);
+}
+DEV void streamEnd(int) { FL.eng.ringEnd = 1; }
+DEV int streamAcked(int* fail) { *fail = FL.eng.ringFail; return FL.eng.ringAck; }
+DEV void streamAccount(Dev& d, KREF k, int i, StreamCnt& cnt) {
+  const JobRec& r = RREC(i);
+  int q = RQ(i), pc = r.pc;
+  for (int x = 0; x < k.R; x++) {
+    int64_t v = r.req[x];
+    FL.qAlloc[q][x] += v; RS.allocated[x] += v; RS.scheduled[x] += v;
+    size_t j = ((size_t)q * k.npc + pc) * k.R + x;
+    k.qAllocByPc[j] += v; k.qSchedByPc[j] += v;
+  }
+  cnt.v[q]++;
+}
+DEV int streamCount(const StreamCnt& cnt, int q) { return cnt.v[q]; }
 #else  // device versions: armada_sched.hip
 struct PQState { uint32_t A, N; unsigned long long X, Y; int q; int count; };  // lane i: the i-th queue in heap order
 DEV void pqBuild(PQState& s, int Q);
@@ -481,6 +536,16 @@ DEV void engineStart(Dev& d, FastS& S);
 DEV void engineStop(Dev& d, FastS& S);
 DEV bool headRequestsDisallowed(Dev& d, KREF k, int q);
 DEV bool pinnedNodeFits(KREF k, int q, int n, int level);
+struct StreamCnt { int v; };   // executed entries per queue: lane q counts queue q
+DEV void qsWinRefill(KREF k, int q, int pos, int cnt);
+DEV void streamBegin(int* engSeq);
+DEV unsigned long long streamStageIssue(KREF k, int base, int cnt);
+DEV void streamStageCommit(Dev& d, KREF k, int base, int cnt, unsigned long long v);
+DEV void streamEnd(int engSeq);
+DEV void streamAccount(Dev& d, KREF k, int i, StreamCnt& cnt);
+DEV int streamCount(const StreamCnt& cnt, int q);
+DEV int streamAcked(int* fail);
+DEV void wgBulk(Dev& d, int kind, int n);
 #endif
 DEV void candInvalidate(int S, int n) { FOR_LANES(s, S) if (FL.cand[s].node == n) FL.cand[s].node = -2; }
 DEV void candResetAll(Dev& d, const int32_t* pos) { FOR_LANES(s, d.cfg.S < SMAX ? d.cfg.S : SMAX) { FL.cand[s].node = -2; FL.cand[s].pos = pos ? pos[s] : 0; FL.cand[s].key = 0; } }  // key 0: no lower bound known, the first query scans
@@ -544,6 +609,7 @@ DEV int fastFirstFit(KREF k, FastS& S, const JobTail& r, FitHandle* h, CandRec* 
   int s = r.shape;
   int slot;
   uint64_t lk = l0Search(k, r, &slot);
+  FSEG(7);
   CandRec c = FL.cand[s];
   uniCand(c);
   // A stale candidate (node -2: the node it named changed) still carries the key it was found with, and every clean entry the cursor can
@@ -792,7 +858,6 @@ DEV int engineServe(Dev& d, KREF k, FastS& ES) {
 #ifdef ASCHED_HOSTSIM
 // serial build: the engine runs at post time; the control code still proceeds on the assumption that the job fits and takes the
 // iteration back at the next settle point when it did not — the same control flow as on the device
-static FastS g_engS;
 DEV void engineStart(Dev&, FastS& S) { g_engS = S; g_engS.statScanSteps = 0; g_engS.engSeq = 0; FL.eng.cancel = 0; }
 DEV void engineStop(Dev&, FastS& S) { S.statScanSteps += g_engS.statScanSteps; if (g_engS.statL0Max > S.statL0Max) S.statL0Max = g_engS.statL0Max; }
 DEV void enginePost(Dev& d, KREF k, FastS& S, int job, int q, int pc, int32_t prio, int32_t cutoff, int nl) {
@@ -1138,12 +1203,147 @@ DEV_NOINLINE SkipDelta fastDrain(Dev& d, int Q) {
   return r;
 }
 
+
+// ---- stream run.  While queued jobs fit without preemption, the queue side of an iteration — which queue is served next, with which job — depends on
+// nothing the node side produces: the costs that order the queues are functions of each queue's own allocation prefix.  They are computed ahead for the
+// next jobs of every queue (fastStreamPrepare: chunked prefix pass over the queued lists -> EvKey streams in HBM), and the control wave then only
+// MERGES: it pops the head of its lane heap, emits (job, queue) into a ring, takes the queue's next precomputed costs from a small LDS window, packs the
+// key and re-inserts the queue.  Job records are gathered four entries at a time while the merge goes on and staged in the ring (the idle prefetch
+// windows); the node engine (wave 1) walks the ring: first fit at priority -2, bind, result fields, L0 upkeep — it is now the only sequential chain
+// and never waits for the control wave.  Queue-side bookkeeping follows the engine's progress (accounting of an entry once it is bound); the queues'
+// iterator state is materialised when the run ends: each queue's head becomes the first of its elements that was not bound, produced by the
+// ordinary fastAdvance from the queue's then-current allocation.  The run ends, before any side effect that would have to be taken back, when
+//   * the head of the heap is not a stream element (an evicted job, a gang, a queue that was not eligible) — its key sits in the heap like any other,
+//     so nothing that orders after it is emitted;
+//   * a queue's stream is used up (the next element is a gang member / known-unfeasible key / beyond the prepared length / beyond its rate-limit tokens);
+//   * the global rate limiter has no token left for another job;
+//   * the engine finds no node for an entry (the generic cascade decides: that entry and everything emitted after it are simply forgotten — no
+//     accounting had been done for them — and the entry is its queue's head again).
+// Exactness: the merge is the heap of QueueCandidateGangIteratorPQ on the very keys fastAdvance would compute (same float64 operations on the same
+// prefix sums, round_run.h B_QSKEYS), the engine executes the entries in emission order, and integer accounting is order independent.
+struct StreamIn { double globalTokens; int64_t globalBurst; int32_t globalRateInf, engSeq; };
+struct StreamOut { int executed, pend, dropped, engSeq, emitted, refills, evicted; uint32_t lastA, lastN; uint64_t lastX, lastY; };
+DEV_NOINLINE int fastStreamPrepare(Dev& d, FastCtx fc, int Q, int allowed);   // round_run.h (bulk passes); returns the number of stream entries prepared
+DEV EvKey streamKey(KREF k, int q, int pos, int sLen) {
+  int ws = UNI32(FL.hot[q].ewStart), wc = UNI32(FL.hot[q].ewCount);
+  if (!(pos >= ws && pos < ws + wc)) {
+    int cnt = sLen - pos; if (cnt > WIN) cnt = WIN;
+    qsWinRefill(k, q, pos, cnt);
+    if (FLANE == 0) { FL.hot[q].ewStart = pos; FL.hot[q].ewCount = cnt; }
+    ws = pos;
+  }
+  EvKey e = FL.evWin[q][pos - ws];
+  e.proposed = UNID(e.proposed); e.current = UNID(e.current); e.size = UNID(e.size); e.pcPrio = UNI32(e.pcPrio); e.job = UNI32(e.job);
+  return e;
+}
+DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
+  const FastK k = fastKRef(d);
+  FastS S; coldS(d, S);
+  StreamOut out; out.executed = 0; out.pend = -1; out.dropped = 0; out.engSeq = in.engSeq; out.emitted = 0; out.refills = 0;
+  PQState pq;
+  pqBuild(pq, Q);
+  int allowed = INT32_MAX;
+  if (!in.globalRateInf) allowed = in.globalTokens >= 2147483000.0 ? INT32_MAX : (in.globalTokens < 1 ? 0 : (int)in.globalTokens);
+  if (in.globalBurst < 1 || in.globalTokens < 1) allowed = 0;
+  PackedKey lastK; lastK.A = ~0u; lastK.X = lastK.Y = ~0ull; uint32_t lastN = ~0u;
+  int engSeq = in.engSeq;
+  streamBegin(&engSeq);
+  int emitted = 0, acc = 0, stageBase = -1, stageCnt = 0;
+  unsigned long long stageV = 0;
+  StreamCnt cnt; memset(&cnt, 0, sizeof cnt);
+  int fail = 0;
+  for (;;) {
+    int a = streamAcked(&fail);
+    while (acc < a) { streamAccount(d, k, acc, cnt); acc++; }
+    if (fail) break;
+    if (emitted - acc >= RING_N - 8) { STREAM_IDLE(); continue; }   // the ring is full: the engine is the pace
+    if (emitted >= allowed) break;
+    int t = pqHead(pq, Q);
+    if (t < 0) break;
+    int sPos = UNI32(FL.hot[t].sPos), sLen = UNI32(FL.hot[t].sLen);
+    if (sPos >= sLen) break;                      // the head of the heap is not a stream element
+    EvKey e = streamKey(k, t, sPos, sLen);
+    pqHeadKey(pq, t, &lastK, &lastN);             // the key this entry is served under (fastExitSkip rebuilds the state around the last one)
+    if (FLANE == 0) { RJOB(emitted) = e.job; RQ(emitted) = t; }
+    emitted++;
+    if ((emitted & 3) == 0) {                     // records: gather the last four entries; the four before them have arrived by now
+      if (stageBase >= 0) streamStageCommit(d, k, stageBase, stageCnt, stageV);
+      stageBase = emitted - 4; stageCnt = 4;
+      stageV = streamStageIssue(k, stageBase, 4);
+    }
+    sPos++;
+    if (FLANE == 0) FL.hot[t].sPos = sPos;
+    KeyOut ko; ko.valid = 0; ko.A = 0; ko.X = ko.Y = 0;
+    if (sPos < sLen) {
+      EvKey n = streamKey(k, t, sPos, sLen);
+      ko = packItemKeys(fc.preferLarge, t, n.pcPrio, n.proposed, n.current, n.size, UNID(FL.hot[t].budget));
+      if (UNI32(FL.hot[t].effValid)) {   // skip mode: as fastAdvance — a head is not served before what precedes it in its queue
+        PackedKey own, eff; own.A = ko.A; own.X = ko.X; own.Y = ko.Y; eff.A = UNI32(FL.effA[t]); eff.X = UNI64(FL.effX[t]); eff.Y = UNI64(FL.effY[t]);
+        if (packedLess(own, 0, eff, 0)) { ko.A = eff.A; ko.X = eff.X; ko.Y = eff.Y; FL.kA[t] = eff.A; FL.kX[t] = eff.X; FL.kY[t] = eff.Y; }
+        else { FL.effA[t] = own.A; FL.effX[t] = own.X; FL.effY[t] = own.Y; }
+      }
+      pqPopPush(pq, ko, t);
+    } else {
+      FL.inHeap[t] = 0;
+      pqPopPush(pq, ko, t);
+      if (!UNI32(d.qsLen[2 * t + 1])) break;      // the queue goes on beyond its stream: its next key is not known here
+    }
+  }
+#ifdef ASCHED_HOSTSIM
+  if (getenv("HS_STREAM_TRACE")) { int t = pqHead(pq, Q); fprintf(stderr, "stream run end: emitted %d acc %d fail %d allowed %d top %d", emitted, acc, fail, allowed, t); if (t >= 0) fprintf(stderr, " sPos %d sLen %d kind %d gctx %d stage %d inHeap %d trueEnd %d", FL.hot[t].sPos, FL.hot[t].sLen, FL.hot[t].headKind, FL.hot[t].gctx, FL.hot[t].itStage, FL.inHeap[t], d.qsLen[2*t+1]); fprintf(stderr, "\n"); }
+#endif
+  // drain: what is still in flight, then the tail group
+  if (!fail) {
+    if (stageBase >= 0) streamStageCommit(d, k, stageBase, stageCnt, stageV);
+    int done = stageBase >= 0 ? stageBase + stageCnt : 0;
+    if (emitted > done) { stageV = streamStageIssue(k, done, emitted - done); streamStageCommit(d, k, done, emitted - done, stageV); }
+  }
+  streamEnd(engSeq);
+  { int a = streamAcked(&fail); while (acc < a) { streamAccount(d, k, acc, cnt); acc++; } }
+  int E = acc;
+  if (fail == 2) out.dropped = 1;
+  // ---- the queues' iterator state as of E bound entries
+  FOR_LANES(q, QCAPF) { FL.hot[q].winKind = -1; FL.hot[q].winCount = 0; }   // the windows served as the ring
+  for (int q = 0; q < Q; q++) {
+    QHot f = FL.hot[q];
+    uniQHot(f);
+    if (f.sLen == 0) continue;
+    int cq = streamCount(cnt, q), moved = f.sPos;
+    FL.hot[q].sLen = 0; FL.hot[q].sPos = 0; FL.hot[q].ewCount = 0; FL.hot[q].ewStart = 0;
+    f.sLen = 0; f.sPos = 0; f.ewCount = 0; f.ewStart = 0; f.winKind = -1; f.winCount = 0;
+    if (moved == 0) continue;                     // never reached the top of the heap: nothing of the queue changed
+    if (f.effValid) {                             // the running maximum restarts from the queue's last folded evicted entry (fastEnterSkip); any clamp between it and
+      EvKey e; memcpy(&e, (const char*)k.evKey + (size_t)(f.evEnd - 1) * sizeof(EvKey), sizeof(EvKey));   // the true running maximum gives the same order
+      PackedKey last = packKey3(fc.preferLarge, UNI32(e.pcPrio), UNID(e.proposed), UNID(e.current), UNID(e.size), f.budget);
+      FL.effA[q] = last.A; FL.effX[q] = last.X; FL.effY[q] = last.Y;
+    }
+    if (cq == 0) {                                // emitted, not bound: the head it had is the head again, under the key it was peeked with
+      KeyOut ko = packItemKeys(fc.preferLarge, q, fc.compareSchedPrio ? f.schedPrio : f.pcPrio, f.proposed, f.current, f.size, f.budget);
+      if (f.effValid) {
+        PackedKey own, eff; own.A = ko.A; own.X = ko.X; own.Y = ko.Y; eff.A = UNI32(FL.effA[q]); eff.X = UNI64(FL.effX[q]); eff.Y = UNI64(FL.effY[q]);
+        if (packedLess(own, 0, eff, 0)) { FL.kA[q] = eff.A; FL.kX[q] = eff.X; FL.kY[q] = eff.Y; }
+        else { FL.effA[q] = own.A; FL.effX[q] = own.X; FL.effY[q] = own.Y; }
+      }
+      FL.inHeap[q] = 1;
+      continue;
+    }
+    f.itQi = f.itQi - 1 + cq; f.itJobsSeen = f.itJobsSeen - 1 + cq;   // the next peek yields element cq (element 0 was the head: already peeked and counted)
+    if (!f.rateInf && 1 <= f.burst) f.tokens -= (double)cq;
+    KeyOut ko;
+    if (!fastAdvance(d, k, S, fc, q, f, &ko)) out.pend = q;
+  }
+  out.executed = E; out.engSeq = engSeq; out.emitted = emitted; out.refills = S.statRefills; out.evicted = S.numEvictedJobs;
+  out.lastA = lastK.A; out.lastX = lastK.X; out.lastY = lastK.Y; out.lastN = lastN;
+  return out;
+}
+
 // Run fast iterations of the QueueScheduler loop (mode 0) or of the eviction-order replay (mode 1) until one needs the
 // generic code.  Returns the queue whose next head the generic updateAndPush must produce, or -1.  Leaves fast mode live.
 DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* counter) {
   FastCtx fc;
   fc.withQueued = pc.withQueued; fc.maxLookback = pc.maxLookback; fc.skipKnown = pc.skipKnown; fc.compareSchedPrio = c.compareSchedPrio;
   fc.preferLarge = c.preferLarge; fc.replay = mode; fc.evStatic = c.fastEvStatic; fc.engine = !mode && d.f.engine;
+  fc.stream = 0;
   fastEnsureLive(d, c);
   c.l1Dirty = 1;
   const FastK k = fastKRef(d);
@@ -1160,6 +1360,9 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   fc.preferLarge = UNI32(fc.preferLarge); fc.evStatic = UNI32(fc.evStatic); fc.engine = UNI32(fc.engine);
   mode = UNI32(mode);
   int cnt = counter ? UNI32(*counter) : 0, pend = -1, lastTop = -1;
+  fc.stream = fc.engine && d.qsKey != nullptr && !k.hasPcLimit && !k.anyRoundLimit && !k.disableHome && fc.withQueued;
+  fc.stream = UNI32(fc.stream);
+  int streamNextAt = UNI32(c.streamNextAt), streamBackoff = UNI32(c.streamBackoff);
   PackedKey refK; refK.A = ~0u; refK.X = refK.Y = ~0ull; uint32_t refN = ~0u;
   if (!mode && c.onlyEvicted && RS.terminationReason != 0 && S.lvl0NonNeg && S.numPreemptedMarks == 0 && fc.evStatic && fc.withQueued) { SkipDelta dl = fastDrain(d, Q); S.numEvictedJobs += dl.evicted; S.loopIterations += dl.iters; }
   if (c.skipEnter && !mode && S.lvl0NonNeg && S.numPreemptedMarks == 0 && fc.evStatic) { SkipDelta dl = fastEnterSkip(d, fc, Q); S.numEvictedJobs += dl.evicted; S.loopIterations += dl.iters; S.statRefills += dl.refills; c.skipActive = 1; }
@@ -1204,6 +1407,37 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
     if (t >= 0) pqHeadKey(pq, t, &refK, &refN);  // lane 0 of the heap lanes
     if (t < 0) break;
     if (UNI32(FL.hot[t].gctx) < 0) break;  // a gang: generic
+    if (fc.stream && S.fastActive && S.statFastIters >= streamNextAt && UNI32(FL.hot[t].headKind) == 1 && UNI32(FL.hot[t].headFast)) {
+      // stream run: precompute the queues' next costs in bulk, then merge + stage on this wave while the node engine binds (see fastStreamRun)
+      if (S.engLive) { engineStop(d, S); S.engLive = 0; }   // the bulk passes need every wave of the workgroup at the mailbox
+      int want = INT32_MAX;
+      if (!S.globalRateInf) want = S.globalTokens >= 2147483000.0 ? INT32_MAX : (S.globalTokens < 1 ? 0 : (int)S.globalTokens);
+      int prepared = fastStreamPrepare(d, fc, Q, want);
+      int E = 0;
+      if (prepared > 0) {
+        engineStart(d, S); S.engLive = 1;
+        StreamIn in; in.globalTokens = S.globalTokens; in.globalBurst = S.globalBurst; in.globalRateInf = S.globalRateInf; in.engSeq = S.engSeq;
+        StreamOut so = fastStreamRun(d, fc, Q, in);
+        S.engSeq = so.engSeq;
+        E = so.executed;
+        S.numScheduledJobs += E; S.numScheduledGangs += E; S.numNodeQueries += E; S.loopIterations += E; S.statFastIters += E;
+        if (!S.globalRateInf && 1 <= S.globalBurst) S.globalTokens -= (double)E;
+        S.statRefills += so.refills; S.numEvictedJobs += so.evicted;
+        if (FLANE == 0) { RS.statStreamRuns++; RS.statStreamJobs += E; RS.statStreamPrepared += prepared; RS.statStreamEmitted += so.emitted; }
+        if (so.dropped) { S.fastActive = 0; fastDrop(d); }
+        S.tP0 = -1;
+        pqBuild(pq, Q);
+        if (so.pend >= 0) { pend = so.pend; lastTop = so.pend; refK.A = so.lastA; refK.X = so.lastX; refK.Y = so.lastY; refN = so.lastN; }
+      }
+      if (E >= 1024) streamBackoff = 0;
+      else streamBackoff = streamBackoff ? (streamBackoff < (1 << 20) ? streamBackoff * 2 : streamBackoff) : 2048;
+      streamNextAt = S.statFastIters + streamBackoff;
+#ifdef ASCHED_HOSTSIM
+      if (getenv("HS_STREAM_EAGER")) { streamBackoff = 0; streamNextAt = S.statFastIters + (E == 0 ? 1 : 0); }   // tests: a stream run wherever one can start
+#endif
+      if (pend >= 0) break;
+      continue;
+    }
     KeyOut ko; ko.valid = 0; ko.A = 0; ko.X = ko.Y = 0;
     int st = mode ? fastReplayStep(d, k, S, fc, t, &cnt, &ko) : fastIter(d, k, S, fc, t, &ko);
     if (st == 0) break;
@@ -1223,6 +1457,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
     S.numEvictedJobs += dl.evicted; S.loopIterations += dl.iters; S.statRefills += dl.refills;
     c.skipActive = 0;
   }
+  c.streamNextAt = streamNextAt; c.streamBackoff = streamBackoff;
   if (counter) *counter = cnt;
   RS.globalTokens = S.globalTokens;
   RS.numScheduledJobs = S.numScheduledJobs; RS.numScheduledGangs = S.numScheduledGangs; RS.numEvictedJobs = S.numEvictedJobs;

@@ -10,6 +10,7 @@ enum BulkKind {
   B_UNBIND, B_RESET_EVTAB, B_CLEAR_UNFEASIBLE, B_INIT_ALLOC, B_POPULATE, B_RESET_JOBS, B_GATHER_SCHED, B_GATHER_PRE,
   B_EVIDX, B_LVL0, B_EVKEYS, B_EVKEYS_OFF, B_EVKEYS_ON, B_EVSUM, B_SNAP, B_EVALIVE,
   B_FAIR_ZERO, B_FAIR_COUNT, B_FAIR_PSUM, B_FAIR_POFF, B_FAIR_SCATTER, B_FAIR_SORT,
+  B_QSSUM, B_QSSTITCH, B_QSKEYS,
 };
 
 DEV void wgBulk(Dev& d, int kind, int n);  // every element i in [0,n) through bulkElem(), then a workgroup barrier
@@ -163,6 +164,64 @@ DEV void bulkElem(Dev& d, int kind, int i) {
         for (int r = 0; r < c.R; r++) a[r] = with[r];
       }
       edge[4] = prev.A; edge[5] = prev.X; edge[6] = prev.Y; edge[7] = (uint64_t)q;
+    } break;
+    // Queued-job streams (dev.h QS_*, round_fast.h "stream run"): element e of queue q's stream is queuedJobs[base + e].  Item i of B_QSSUM /
+    // B_QSKEYS owns elements [c * QS_CHUNK, (c + 1) * QS_CHUNK) of queue q = i / QS_CPQ, c = i % QS_CPQ: sums of the requests and the first element the
+    // stream cannot contain — a gang member (the generic iterator assembles gangs), a job whose scheduling key is known to be unfeasible (it is skipped
+    // with a record, queue_scheduler.go:398-413), a job requesting a disallowed resource — then one item per queue turns the sums into carries and
+    // cuts the stream at the first such element, then the costs (the same float64 operations as updatePQItem, queue_scheduler.go:636-686).
+    case B_QSSUM: {
+      int q = i / QS_CPQ, ch = i % QS_CPQ;
+      const QsIn& in = d.qsIn[q];
+      int64_t* part = d.qsPart + (size_t)i * (MAXR + 2);
+      int e0 = ch * QS_CHUNK, e1 = e0 + QS_CHUNK < in.len ? e0 + QS_CHUNK : in.len;
+      int64_t sum[MAXR]; for (int r = 0; r < MAXR; r++) sum[r] = 0;
+      int barrier = INT32_MAX;
+      for (int e = e0; e < e1; e++) {
+        int job = d.queuedJobs[in.base + e];
+        const int64_t* req = JREQ(d, job);
+        bool stop = d.jGang[job] >= 0 || (e > 0 && in.skipUnf && d.unfeasible[d.jShape[job]]);
+        for (int r = 0; r < c.R; r++) if (c.disallowed[r] && req[r] > 0) stop = true;
+        if (stop) { barrier = e; break; }
+        for (int r = 0; r < c.R; r++) sum[r] += req[r];
+      }
+      for (int r = 0; r < MAXR; r++) part[r] = sum[r];
+      part[MAXR] = barrier;
+    } break;
+    case B_QSSTITCH: {
+      const QsIn& in = d.qsIn[i];
+      int64_t run[MAXR]; for (int r = 0; r < MAXR; r++) run[r] = 0;
+      int len = in.len; bool cut = false;
+      for (int ch = 0; ch < QS_CPQ && ch * QS_CHUNK < in.len; ch++) {
+        int64_t* part = d.qsPart + ((size_t)i * QS_CPQ + ch) * (MAXR + 2);
+        int barrier = (int)part[MAXR];
+        for (int r = 0; r < MAXR; r++) { int64_t s = part[r]; part[r] = run[r]; run[r] += s; }
+        if (barrier != INT32_MAX) { len = barrier; cut = true; break; }
+      }
+      d.qsLen[2 * i] = len;
+      d.qsLen[2 * i + 1] = (!cut && in.len > 0 && in.base + in.len == d.queuedOff[i + 1]) ? 1 : 0;   // the queue's list ends where the stream ends
+    } break;
+    case B_QSKEYS: {
+      int q = i / QS_CPQ, ch = i % QS_CPQ;
+      const QsIn& in = d.qsIn[q];
+      int len = d.qsLen[2 * q];
+      int e0 = ch * QS_CHUNK, e1 = e0 + QS_CHUNK < len ? e0 + QS_CHUNK : len;
+      if (e0 >= e1) break;
+      const int64_t* carry = d.qsPart + (size_t)i * (MAXR + 2);
+      int64_t a[MAXR], with[MAXR];
+      for (int r = 0; r < c.R; r++) a[r] = in.a0[r] + carry[r];
+      double w = in.weight;
+      EvKey* out = d.qsKey + (size_t)q * QS_CMAX;
+      for (int e = e0; e < e1; e++) {
+        int job = d.queuedJobs[in.base + e];
+        const int64_t* req = JREQ(d, job);
+        for (int r = 0; r < c.R; r++) with[r] = a[r] + req[r];
+        EvKey k;
+        k.proposed = drf(d, with) / w; k.current = drf(d, a) / w; k.size = drf(d, req) * w;
+        k.pcPrio = c.pcPriority[d.jPc[job]]; k.job = job;
+        out[e] = k;
+        for (int r = 0; r < c.R; r++) a[r] = with[r];
+      }
     } break;
     // per-node index of the evicted table (ensureFairIndex): count -> offsets -> scatter -> per-node sort by descending Index
     case B_FAIR_ZERO: d.accStamp[i] = 0; break;
@@ -471,6 +530,47 @@ DEV_COLD void runRound(Dev& d, Ctl& c) {
 
 // ------------------------------------------------------------------------------------------------
 // control-kernel commands (the NodeDb-level entry points of the C ABI run through the same device code as the round)
+
+// Stream preparation (round_fast.h "stream run"): which queues take part — the head is a single queued job peeked from the queue's list, the queue may
+// still schedule new jobs — how far each stream may reach (the list, QS_CMAX, the queue's rate-limit tokens, the lookback limit, the global tokens),
+// then the three bulk passes.  Runs on the control wave with the LDS copy of the queue state live; the bulk items read only what is written to d.qsIn.
+DEV_NOINLINE int fastStreamPrepare(Dev& d, FastCtx fc, int Q, int allowed) {
+#ifdef ASCHED_HOSTSIM
+  if (getenv("HS_NO_STREAM")) return 0;
+#endif
+  if (allowed < 1) return 0;
+  const FastK k = fastKRef(d);
+  int skipUnf = fc.skipKnown && RS.numUnfeasible > 0;
+  int cap = allowed < QS_CMAX ? allowed : QS_CMAX;
+  FOR_LANES(q, Q) {
+    const QHot& f = FL.hot[q];
+    QsIn in; in.base = 0; in.len = 0; in.skipUnf = skipUnf; in.pad = 0; in.weight = f.weight;
+    for (int r = 0; r < MAXR; r++) in.a0[r] = FL.qAlloc[q][r] + FL.qPenalty[q][r];
+    bool ok = FL.inHeap[q] && f.gctx >= 0 && f.headFast && f.headKind == 1 && f.itStage == 1 && !f.itJobOnlyEv && !f.cordoned && f.burst >= 1 && f.tokens >= 1 &&
+              f.evApplied == f.evDone && f.itQi >= 1 && f.itQi <= f.qEnd;
+    if (ok && k.queuedJobs[f.itQi - 1] != f.gctx) ok = false;   // the head did not come from the list position before the cursor (a stashed job)
+    if (ok) {
+      int len = f.qEnd - (f.itQi - 1);
+      if (len > cap) len = cap;
+      if (!f.rateInf && f.tokens < (double)len) len = (int)f.tokens;
+      if (fc.maxLookback != 0 && !f.itGangOnlyEv) {   // element e >= 1 is peeked when itJobsSeen = seen + e - 1 < maxLookback (queue_scheduler.go:434-444)
+        int64_t lim = (int64_t)fc.maxLookback - f.itJobsSeen + 1;
+        if (lim < 1) lim = 1;
+        if (len > lim) len = (int)lim;
+      }
+      in.base = f.itQi - 1; in.len = len;
+    }
+    d.qsIn[q] = in;
+  }
+  wgBulk(d, B_QSSUM, Q * QS_CPQ);
+  wgBulk(d, B_QSSTITCH, Q);
+  wgBulk(d, B_QSKEYS, Q * QS_CPQ);
+  int total = 0;
+  for (int q = 0; q < Q; q++) total += d.qsLen[2 * q];
+  FOR_LANES(q, Q) { int len = d.qsLen[2 * q]; FL.hot[q].sLen = len; FL.hot[q].sPos = 0; if (len > 0) { FL.hot[q].ewCount = 0; FL.hot[q].ewStart = 0; } }
+  return total;
+}
+
 enum Cmd {
   CMD_PREPARE = 1, CMD_ROUND, CMD_QUEUES_ONLY, CMD_GANG_SCHEDULE, CMD_SELECT, CMD_SCHEDULE_MANY, CMD_BIND, CMD_EVICT, CMD_UNBIND,
   CMD_ADD_EVICTED, CMD_RESET_EVICTED, CMD_TXN_BEGIN, CMD_TXN_COMMIT, CMD_TXN_ABORT, CMD_FIT_BATCH, CMD_UPSERT_RESET, CMD_RESET_JOBS,
@@ -715,7 +815,7 @@ DEV void controlMainAux(Dev& d, int cmd) {
   Ctl c;
   c.txn.active = d.rs->txnActive; c.fairStamp = d.rs->fairStamp; c.preList = d.preList; c.preCount = 0;
   c.skipKeyCheck = 0; c.compareSchedPrio = 0; c.preferLarge = d.cfg.preferLarge; c.useReplayAlloc = 0; c.onlyEvicted = 0;
-  c.fastEnabled = 0; c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0; c.cancelSeen = 0;
+  c.fastEnabled = 0; c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0; c.cancelSeen = 0; c.streamNextAt = 0; c.streamBackoff = 0;
   fastLoad(d);
   runAuxCommand(d, c, cmd);
   fastEnterGeneric(d, c);
@@ -727,7 +827,7 @@ DEV void controlMain(Dev& d, int cmd) {
   c.txn.active = d.rs->txnActive; c.fairStamp = d.rs->fairStamp; c.preList = d.preList; c.preCount = 0;
   c.skipKeyCheck = 0; c.compareSchedPrio = 0; c.preferLarge = d.cfg.preferLarge; c.useReplayAlloc = 0; c.onlyEvicted = 0;
   c.fastEnabled = d.f.iterOk && !d.rs->apiDirty && (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY || cmd == CMD_PASS1 || cmd == CMD_PASS2);
-  c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0; c.cancelSeen = 0;
+  c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0; c.cancelSeen = 0; c.streamNextAt = 0; c.streamBackoff = 0;
   fastLoad(d);
   runCommand(d, c, cmd);
   fastEnterGeneric(d, c);

@@ -423,7 +423,7 @@ int32_t ASCHED_FN(round_timing)(asched_t*, double* out /*[8]*/);
 /* Measurement hook (no reference counterpart): how the last round ran on the device.  out = {fast iterations, generic
    iterations, base scan steps, window refills, max live dirty nodes (L0), fast replay steps, L0 overflows,
    fast structure active at the end, 0...}.  The CPU oracle reports zeros. */
-int32_t ASCHED_FN(round_stats)(asched_t*, int32_t* out /*[16]*/);
+int32_t ASCHED_FN(round_stats)(asched_t*, int32_t* out /*[20]*/);
 /* Hard timeout of a round (maxSchedulingDuration, config/scheduler/config.yaml:83; scheduling_algo.go:130-134 wraps the context in
    WithTimeout, queue_scheduler.go:105-112 checks ctx.Done() every loop iteration and returns ctx.Err()).  asched_set_deadline: every
    following schedule_round / schedule_queues is cancelled `seconds` after it starts (0 = none).  asched_cancel = the context's cancel
