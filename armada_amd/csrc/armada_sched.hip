@@ -617,14 +617,14 @@ __device__ static inline unsigned long long streamStageIssue(KREF k, int base, i
   int lane = threadIdx.x & 63;
   int i = lane >> 4, part = lane & 15;
   unsigned long long v = 0;
-  if (i < cnt) { int job = RJOB(base + i); v = k.jrec[(size_t)job * (sizeof(JobRec) / 8) + part]; }
+  if (i < cnt && !(RQ(base + i) & RQ_EV)) { int job = RJOB(base + i); v = k.jrec[(size_t)job * (sizeof(JobRec) / 8) + part]; }
   return v;
 }
 __device__ static inline void streamStageCommit(Dev& d, KREF k, int base, int cnt, unsigned long long v) {
   (void)d; (void)k;
   int lane = threadIdx.x & 63;
   int i = lane >> 4, part = lane & 15;
-  if (i < cnt) ((unsigned long long*)&RREC(base + i))[part] = v;
+  if (i < cnt && !(RQ(base + i) & RQ_EV)) ((unsigned long long*)&RREC(base + i))[part] = v;
   LDS_ORDER();
   if (lane == 0) __hip_atomic_store(&g_fl.eng.ringPub, base + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -647,11 +647,14 @@ __device__ static inline int streamAcked(int* fail) {
   *fail = f;
   return a;
 }
-// sctx / qctx accounting of ring entry i once the engine has bound it (accountVectors for a new job), one lane per resource; lane q counts queue q's entries
-__device__ static inline void streamAccount(Dev& d, KREF k, int i, StreamCnt& cnt) {
+// sctx / qctx accounting of ring entry i once the engine has bound it (accountVectors for a new job), one lane per resource; lane q counts queue q's
+// entries.  An entry of an evicted stream only counts: its commit is deferred like a cheap evicted head's (applyEvictedRange)
+__device__ static inline void streamAccount(Dev& d, KREF k, int i, StreamLanes& sl) {
   (void)d;
   int lane = threadIdx.x & 63;
-  int q = __builtin_amdgcn_readfirstlane(RQ(i));
+  int rq = __builtin_amdgcn_readfirstlane(RQ(i)), q = rq & 0xff;
+  if (lane == q) sl.cnt++;
+  if (rq & RQ_EV) return;
   const JobRec& r = RREC(i);
   int pc = __builtin_amdgcn_readfirstlane(r.pc);
   if (lane < k.R) {
@@ -663,9 +666,7 @@ __device__ static inline void streamAccount(Dev& d, KREF k, int i, StreamCnt& cn
       __hip_atomic_fetch_add(&k.qSchedByPc[j], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  if (lane == q) cnt.v++;
 }
-__device__ static inline int streamCount(const StreamCnt& cnt, int q) { return __builtin_amdgcn_readlane(cnt.v, q); }
 // key and name rank of the heap's head entry (queue t): lane 0 of the heap lanes, no LDS access
 __device__ static inline void pqHeadKey(PQState& s, int t, PackedKey* key, uint32_t* nameRank) {
   if (__builtin_amdgcn_readfirstlane(s.q) == t) {
@@ -747,6 +748,11 @@ __device__ static void engineLoop(Dev& d) {  // wave 1
         }
         if (pub <= i) break;
         LDS_ORDER();
+        if (__builtin_amdgcn_readfirstlane(RQ(i)) & RQ_EV) {   // an evicted job returning to its node: nothing to select or bind here
+          i++;
+          if (lane == 0) __hip_atomic_store(&g_fl.eng.ringAck, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          continue;
+        }
         ESEG(0);
         long long b0 = (long long)__builtin_readcyclecounter();
         {  // the entry's record becomes the mailbox job (the engine's own LDS writes, read back in order)

@@ -70,6 +70,7 @@ struct alignas(16) EngineBox {
 #define RREC(i) (((JobRec*)FL.winRec)[(i) & (RING_N - 1)])
 #define RJOB(i) (((int32_t*)FL.winJob)[(i) & (RING_N - 1)])
 #define RQ(i) (((int32_t*)FL.winIdx)[(i) & (RING_N - 1)])
+#define RQ_EV 0x100   // ring entry of an evicted stream: nothing for the engine to do
 static_assert((RING_N & (RING_N - 1)) == 0, "ring size");
 struct alignas(16) IterBackup {  // the job's record and request stay in the mailbox (the engine only reads them)
   QHot hot;
@@ -93,6 +94,7 @@ struct FastLds {
   uint32_t tmpA[64], tmpN[64]; uint64_t tmpX[64], tmpY[64]; int32_t tmpQ[64];  // scatter space of pqBuild
   uint32_t effA[QCAPF]; uint64_t effX[QCAPF], effY[QCAPF];  // skip mode: running maximum of the queue's keys
   EngineBox eng; IterBackup bk;
+  uint8_t sKind[QCAPF];   // stream of queue q: 0 queued jobs (d.qsKey), 1 its evicted jobs (d.evKey)
 };
 
 #ifdef ASCHED_HOSTSIM
@@ -473,14 +475,17 @@ DEV bool pinnedNodeFits(KREF k, int q, int n, int level) {
 DEV void pqHeadKey(PQState&, int t, PackedKey* key, uint32_t* nameRank) { key->A = FL.kA[t]; key->X = FL.kX[t]; key->Y = FL.kY[t]; *nameRank = (uint32_t)FL.nameRank[t]; }
 // ---- stream run, serial build.  The engine serves an entry when its record is staged, so that entries emitted but not yet staged when a job
 // does not fit are discarded exactly as on the device (there the engine runs behind the merge by up to a ring's worth of entries).
-struct StreamCnt { int v[QCAPF]; };
+struct StreamLanes { int start[QCAPF], base[QCAPF], cnt[QCAPF]; };
+#define SL_SET(sl, f, q, v) ((sl).f[q] = (v))
+#define SL_GET(sl, f, q) ((sl).f[q])
 DEV void qsWinRefill(KREF k, int q, int pos, int cnt) { for (int i = 0; i < cnt; i++) memcpy(&FL.evWin[q][i], (const char*)k.qsKey + ((size_t)q * QS_CMAX + pos + i) * sizeof(EvKey), sizeof(EvKey)); }
 DEV int engineServe(Dev& d, KREF k, FastS& ES);
 static FastS g_engS;
 DEV void streamBegin(int* engSeq) { FL.eng.ringPub = FL.eng.ringAck = FL.eng.ringEnd = FL.eng.ringFail = 0; FL.eng.cmd = ENG_STREAM; (*engSeq)++; }
 static JobRec g_hsStage[4];
-DEV unsigned long long streamStageIssue(KREF k, int base, int cnt) { for (int i = 0; i < cnt; i++) memcpy(&g_hsStage[i], (const char*)k.jrec + (size_t)RJOB(base + i) * sizeof(JobRec), sizeof(JobRec)); return 0; }
+DEV unsigned long long streamStageIssue(KREF k, int base, int cnt) { for (int i = 0; i < cnt; i++) if (!(RQ(base + i) & RQ_EV)) memcpy(&g_hsStage[i], (const char*)k.jrec + (size_t)RJOB(base + i) * sizeof(JobRec), sizeof(JobRec)); return 0; }
 DEV void streamServeOne(Dev& d, KREF k, int i) {
+  if (RQ(i) & RQ_EV) { FL.eng.ringAck = i + 1; return; }
   const JobRec& r = RREC(i);
   memcpy(FL.eng.req, r.req, sizeof FL.eng.req); memcpy(&FL.eng.tail, &r.keyDelta, sizeof(JobTail));
   FL.eng.job = RJOB(i); FL.eng.prio = r.pcPrio; FL.eng.cutoff = r.preemptible ? r.pcPrio : NONPREEMPTIBLE_CUTOFF; FL.eng.nl = r.nlPc; FL.eng.cmd = ENG_JOB;
@@ -490,24 +495,25 @@ DEV void streamServeOne(Dev& d, KREF k, int i) {
   if (st == 2) FL.eng.ringFail = 2;
 }
 DEV void streamStageCommit(Dev& d, KREF k, int base, int cnt, unsigned long long) {
-  for (int i = 0; i < cnt; i++) RREC(base + i) = g_hsStage[i];
+  for (int i = 0; i < cnt; i++) if (!(RQ(base + i) & RQ_EV)) RREC(base + i) = g_hsStage[i];
   FL.eng.ringPub = base + cnt;
   for (int i = base; i < base + cnt; i++) if (!FL.eng.ringFail) streamServeOne(d, k, i);
 }
 DEV void streamEnd(int) { FL.eng.ringEnd = 1; }
 DEV int streamAcked(int* fail) { *fail = FL.eng.ringFail; return FL.eng.ringAck; }
-DEV void streamAccount(Dev& d, KREF k, int i, StreamCnt& cnt) {
+DEV void streamAccount(Dev& d, KREF k, int i, StreamLanes& sl) {
+  int rq = RQ(i), q = rq & 0xff;
+  sl.cnt[q]++;
+  if (rq & RQ_EV) return;
   const JobRec& r = RREC(i);
-  int q = RQ(i), pc = r.pc;
+  int pc = r.pc;
   for (int x = 0; x < k.R; x++) {
     int64_t v = r.req[x];
     FL.qAlloc[q][x] += v; RS.allocated[x] += v; RS.scheduled[x] += v;
     size_t j = ((size_t)q * k.npc + pc) * k.R + x;
     k.qAllocByPc[j] += v; k.qSchedByPc[j] += v;
   }
-  cnt.v[q]++;
 }
-DEV int streamCount(const StreamCnt& cnt, int q) { return cnt.v[q]; }
 #else  // device versions: armada_sched.hip
 struct PQState { uint32_t A, N; unsigned long long X, Y; int q; int count; };  // lane i: the i-th queue in heap order
 DEV void pqBuild(PQState& s, int Q);
@@ -536,14 +542,15 @@ DEV void engineStart(Dev& d, FastS& S);
 DEV void engineStop(Dev& d, FastS& S);
 DEV bool headRequestsDisallowed(Dev& d, KREF k, int q);
 DEV bool pinnedNodeFits(KREF k, int q, int n, int level);
-struct StreamCnt { int v; };   // executed entries per queue: lane q counts queue q
+struct StreamLanes { int start, base, cnt; };   // lane q: queue q's stream position at the start of the run, list position of element 0, entries done
+#define SL_SET(sl, f, q, v) ((sl).f = (v))
+#define SL_GET(sl, f, q) __builtin_amdgcn_readlane((sl).f, (q))
 DEV void qsWinRefill(KREF k, int q, int pos, int cnt);
 DEV void streamBegin(int* engSeq);
 DEV unsigned long long streamStageIssue(KREF k, int base, int cnt);
 DEV void streamStageCommit(Dev& d, KREF k, int base, int cnt, unsigned long long v);
 DEV void streamEnd(int engSeq);
-DEV void streamAccount(Dev& d, KREF k, int i, StreamCnt& cnt);
-DEV int streamCount(const StreamCnt& cnt, int q);
+DEV void streamAccount(Dev& d, KREF k, int i, StreamLanes& sl);
 DEV int streamAcked(int* fail);
 DEV void wgBulk(Dev& d, int kind, int n);
 #endif
@@ -895,6 +902,7 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
   if (k.hasPcLimit) return 0;  // per-queue per-priority-class caps: generic
   QHot f = FL.hot[q];
   uniQHot(f);
+  if (f.sLen) { if (FLANE == 0) { FL.hot[q].sLen = 0; FL.hot[q].sPos = 0; } f.sLen = 0; f.sPos = 0; }   // the queue is served outside a stream run: its stream no longer describes it
   int job = f.gctx;
   if (f.headFast && f.headKind == 2) {  // evicted job with precomputed costs
     SEG(1);
@@ -1222,13 +1230,16 @@ DEV_NOINLINE SkipDelta fastDrain(Dev& d, int Q) {
 // Exactness: the merge is the heap of QueueCandidateGangIteratorPQ on the very keys fastAdvance would compute (same float64 operations on the same
 // prefix sums, round_run.h B_QSKEYS), the engine executes the entries in emission order, and integer accounting is order independent.
 struct StreamIn { double globalTokens; int64_t globalBurst; int32_t globalRateInf, engSeq; };
-struct StreamOut { int executed, pend, dropped, engSeq, emitted, refills, evicted; uint32_t lastA, lastN; uint64_t lastX, lastY; };
-DEV_NOINLINE int fastStreamPrepare(Dev& d, FastCtx fc, int Q, int allowed);   // round_run.h (bulk passes); returns the number of stream entries prepared
-DEV EvKey streamKey(KREF k, int q, int pos, int sLen) {
+struct StreamOut { int executed, executedEv, pend, dropped, engSeq, emitted, refills, evicted; uint32_t lastA, lastN; uint64_t lastX, lastY; };
+// streams persist between runs: head of queue q == element sPos of its stream, elements [sPos, sLen) are still to come.  A queue's stream is dropped
+// when anything but a stream run serves the queue (fastIter) or the generic code runs (fastQLoad).  prepare: 0 = the top queue has no stream,
+// 1 = ready, 2 = some queue needs the bulk passes and allowBulk was 0 (the node engine must be stopped first: they use every wave of the workgroup)
+DEV_NOINLINE int fastStreamPrepare(Dev& d, FastCtx fc, int Q, int allowed, int allowBulk, int top);   // round_run.h
+DEV EvKey streamKey(KREF k, int q, int pos, int sLen, int kind, int base) {
   int ws = UNI32(FL.hot[q].ewStart), wc = UNI32(FL.hot[q].ewCount);
   if (!(pos >= ws && pos < ws + wc)) {
     int cnt = sLen - pos; if (cnt > WIN) cnt = WIN;
-    qsWinRefill(k, q, pos, cnt);
+    if (kind) evWinRefill(k, q, base + pos, cnt); else qsWinRefill(k, q, pos, cnt);
     if (FLANE == 0) { FL.hot[q].ewStart = pos; FL.hot[q].ewCount = cnt; }
     ws = pos;
   }
@@ -1239,33 +1250,41 @@ DEV EvKey streamKey(KREF k, int q, int pos, int sLen) {
 DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
   const FastK k = fastKRef(d);
   FastS S; coldS(d, S);
-  StreamOut out; out.executed = 0; out.pend = -1; out.dropped = 0; out.engSeq = in.engSeq; out.emitted = 0; out.refills = 0;
+  StreamOut out; memset(&out, 0, sizeof out); out.pend = -1; out.engSeq = in.engSeq;
   PQState pq;
   pqBuild(pq, Q);
   int allowed = INT32_MAX;
   if (!in.globalRateInf) allowed = in.globalTokens >= 2147483000.0 ? INT32_MAX : (in.globalTokens < 1 ? 0 : (int)in.globalTokens);
   if (in.globalBurst < 1 || in.globalTokens < 1) allowed = 0;
   PackedKey lastK; lastK.A = ~0u; lastK.X = lastK.Y = ~0ull; uint32_t lastN = ~0u;
+  StreamLanes sl; memset(&sl, 0, sizeof sl);
+  FOR_LANES(q, QCAPF) {   // per queue: stream position at the start of the run, list position of element 0 (the head is element sPos = the list entry before the cursor)
+    const QHot& f = FL.hot[q];
+    SL_SET(sl, start, q, f.sPos);
+    SL_SET(sl, base, q, (FL.sKind[q] ? f.itEi : f.itQi) - 1 - f.sPos);
+    SL_SET(sl, cnt, q, 0);
+  }
   int engSeq = in.engSeq;
   streamBegin(&engSeq);
-  int emitted = 0, acc = 0, stageBase = -1, stageCnt = 0;
+  int emitted = 0, emittedQ = 0, acc = 0, stageBase = -1, stageCnt = 0;
   unsigned long long stageV = 0;
-  StreamCnt cnt; memset(&cnt, 0, sizeof cnt);
   int fail = 0;
   for (;;) {
     int a = streamAcked(&fail);
-    while (acc < a) { streamAccount(d, k, acc, cnt); acc++; }
+    while (acc < a) { streamAccount(d, k, acc, sl); acc++; }
     if (fail) break;
     if (emitted - acc >= RING_N - 8) { STREAM_IDLE(); continue; }   // the ring is full: the engine is the pace
-    if (emitted >= allowed) break;
     int t = pqHead(pq, Q);
     if (t < 0) break;
     int sPos = UNI32(FL.hot[t].sPos), sLen = UNI32(FL.hot[t].sLen);
     if (sPos >= sLen) break;                      // the head of the heap is not a stream element
-    EvKey e = streamKey(k, t, sPos, sLen);
+    int kind = UNI32((int)FL.sKind[t]);
+    if (!kind && emittedQ >= allowed) break;      // no global token left for another new job
+    int base = SL_GET(sl, base, t);
+    EvKey e = streamKey(k, t, sPos, sLen, kind, base);
     pqHeadKey(pq, t, &lastK, &lastN);             // the key this entry is served under (fastExitSkip rebuilds the state around the last one)
-    if (FLANE == 0) { RJOB(emitted) = e.job; RQ(emitted) = t; }
-    emitted++;
+    if (FLANE == 0) { RJOB(emitted) = e.job; RQ(emitted) = t | (kind ? RQ_EV : 0); }
+    emitted++; if (!kind) emittedQ++;
     if ((emitted & 3) == 0) {                     // records: gather the last four entries; the four before them have arrived by now
       if (stageBase >= 0) streamStageCommit(d, k, stageBase, stageCnt, stageV);
       stageBase = emitted - 4; stageCnt = 4;
@@ -1275,7 +1294,7 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
     if (FLANE == 0) FL.hot[t].sPos = sPos;
     KeyOut ko; ko.valid = 0; ko.A = 0; ko.X = ko.Y = 0;
     if (sPos < sLen) {
-      EvKey n = streamKey(k, t, sPos, sLen);
+      EvKey n = streamKey(k, t, sPos, sLen, kind, base);
       ko = packItemKeys(fc.preferLarge, t, n.pcPrio, n.proposed, n.current, n.size, UNID(FL.hot[t].budget));
       if (UNI32(FL.hot[t].effValid)) {   // skip mode: as fastAdvance — a head is not served before what precedes it in its queue
         PackedKey own, eff; own.A = ko.A; own.X = ko.X; own.Y = ko.Y; eff.A = UNI32(FL.effA[t]); eff.X = UNI64(FL.effX[t]); eff.Y = UNI64(FL.effY[t]);
@@ -1286,11 +1305,11 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
     } else {
       FL.inHeap[t] = 0;
       pqPopPush(pq, ko, t);
-      if (!UNI32(d.qsLen[2 * t + 1])) break;      // the queue goes on beyond its stream: its next key is not known here
+      if (kind || !UNI32(d.qsLen[2 * t + 1])) break;   // the queue goes on beyond its stream (its queued jobs after the evicted ones / more of its list): the next key is not known here
     }
   }
 #ifdef ASCHED_HOSTSIM
-  if (getenv("HS_STREAM_TRACE")) { int t = pqHead(pq, Q); fprintf(stderr, "stream run end: emitted %d acc %d fail %d allowed %d top %d", emitted, acc, fail, allowed, t); if (t >= 0) fprintf(stderr, " sPos %d sLen %d kind %d gctx %d stage %d inHeap %d trueEnd %d", FL.hot[t].sPos, FL.hot[t].sLen, FL.hot[t].headKind, FL.hot[t].gctx, FL.hot[t].itStage, FL.inHeap[t], d.qsLen[2*t+1]); fprintf(stderr, "\n"); }
+  if (getenv("HS_STREAM_TRACE")) { int t = pqHead(pq, Q); fprintf(stderr, "stream run end: emitted %d (new %d) acc %d fail %d allowed %d top %d", emitted, emittedQ, acc, fail, allowed, t); if (t >= 0) fprintf(stderr, " sPos %d sLen %d skind %d kind %d gctx %d stage %d inHeap %d", FL.hot[t].sPos, FL.hot[t].sLen, FL.sKind[t], FL.hot[t].headKind, FL.hot[t].gctx, FL.hot[t].itStage, FL.inHeap[t]); fprintf(stderr, "\n"); }
 #endif
   // drain: what is still in flight, then the tail group
   if (!fail) {
@@ -1299,25 +1318,31 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
     if (emitted > done) { stageV = streamStageIssue(k, done, emitted - done); streamStageCommit(d, k, done, emitted - done, stageV); }
   }
   streamEnd(engSeq);
-  { int a = streamAcked(&fail); while (acc < a) { streamAccount(d, k, acc, cnt); acc++; } }
-  int E = acc;
+  { int a = streamAcked(&fail); while (acc < a) { streamAccount(d, k, acc, sl); acc++; } }
   if (fail == 2) out.dropped = 1;
-  // ---- the queues' iterator state as of E bound entries
+  // ---- the queues' iterator state as of the acc entries done: each queue's head becomes the first of its elements that was not done
   FOR_LANES(q, QCAPF) { FL.hot[q].winKind = -1; FL.hot[q].winCount = 0; }   // the windows served as the ring
+  int doneQ = 0, doneEv = 0;
   for (int q = 0; q < Q; q++) {
     QHot f = FL.hot[q];
     uniQHot(f);
     if (f.sLen == 0) continue;
-    int cq = streamCount(cnt, q), moved = f.sPos;
-    FL.hot[q].sLen = 0; FL.hot[q].sPos = 0; FL.hot[q].ewCount = 0; FL.hot[q].ewStart = 0;
-    f.sLen = 0; f.sPos = 0; f.ewCount = 0; f.ewStart = 0; f.winKind = -1; f.winCount = 0;
+    int start = SL_GET(sl, start, q), cq = SL_GET(sl, cnt, q), moved = f.sPos - start, kind = UNI32((int)FL.sKind[q]);
+    int pos = start + cq;                          // the new head
+    bool more = pos < f.sLen;
+#ifdef ASCHED_HOSTSIM
+    if (getenv("HS_NO_STREAM_KEEP")) more = false;
+#endif
+    if (FLANE == 0) { FL.hot[q].sPos = more ? pos : 0; FL.hot[q].sLen = more ? f.sLen : 0; FL.hot[q].ewCount = 0; FL.hot[q].ewStart = 0; }
+    f.sPos = more ? pos : 0; f.sLen = more ? f.sLen : 0; f.ewCount = 0; f.ewStart = 0; f.winKind = -1; f.winCount = 0;
     if (moved == 0) continue;                     // never reached the top of the heap: nothing of the queue changed
+    if (kind) doneEv += cq; else doneQ += cq;
     if (f.effValid) {                             // the running maximum restarts from the queue's last folded evicted entry (fastEnterSkip); any clamp between it and
       EvKey e; memcpy(&e, (const char*)k.evKey + (size_t)(f.evEnd - 1) * sizeof(EvKey), sizeof(EvKey));   // the true running maximum gives the same order
       PackedKey last = packKey3(fc.preferLarge, UNI32(e.pcPrio), UNID(e.proposed), UNID(e.current), UNID(e.size), f.budget);
       FL.effA[q] = last.A; FL.effX[q] = last.X; FL.effY[q] = last.Y;
     }
-    if (cq == 0) {                                // emitted, not bound: the head it had is the head again, under the key it was peeked with
+    if (cq == 0) {                                // emitted, not done: the head it had is the head again, under the key it was peeked with
       KeyOut ko = packItemKeys(fc.preferLarge, q, fc.compareSchedPrio ? f.schedPrio : f.pcPrio, f.proposed, f.current, f.size, f.budget);
       if (f.effValid) {
         PackedKey own, eff; own.A = ko.A; own.X = ko.X; own.Y = ko.Y; eff.A = UNI32(FL.effA[q]); eff.X = UNI64(FL.effX[q]); eff.Y = UNI64(FL.effY[q]);
@@ -1327,12 +1352,16 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
       FL.inHeap[q] = 1;
       continue;
     }
-    f.itQi = f.itQi - 1 + cq; f.itJobsSeen = f.itJobsSeen - 1 + cq;   // the next peek yields element cq (element 0 was the head: already peeked and counted)
-    if (!f.rateInf && 1 <= f.burst) f.tokens -= (double)cq;
+    if (kind) {   // cq evicted jobs came back to their nodes: commits deferred exactly as the cheap evicted head's (fastIter: evDone = headPos + 1)
+      f.evDone = f.itEi - 1 + cq; f.itEi = f.itEi - 1 + cq;
+    } else {      // the next peek yields element pos (the old head was already peeked and counted)
+      f.itQi = f.itQi - 1 + cq; f.itJobsSeen = f.itJobsSeen - 1 + cq;
+      if (!f.rateInf && 1 <= f.burst) f.tokens -= (double)cq;
+    }
     KeyOut ko;
     if (!fastAdvance(d, k, S, fc, q, f, &ko)) out.pend = q;
   }
-  out.executed = E; out.engSeq = engSeq; out.emitted = emitted; out.refills = S.statRefills; out.evicted = S.numEvictedJobs;
+  out.executed = doneQ; out.executedEv = doneEv; out.engSeq = engSeq; out.emitted = emitted; out.refills = S.statRefills; out.evicted = S.numEvictedJobs;
   out.lastA = lastK.A; out.lastX = lastK.X; out.lastY = lastK.Y; out.lastN = lastN;
   return out;
 }
@@ -1407,36 +1436,38 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
     if (t >= 0) pqHeadKey(pq, t, &refK, &refN);  // lane 0 of the heap lanes
     if (t < 0) break;
     if (UNI32(FL.hot[t].gctx) < 0) break;  // a gang: generic
-    if (fc.stream && S.fastActive && S.statFastIters >= streamNextAt && UNI32(FL.hot[t].headKind) == 1 && UNI32(FL.hot[t].headFast)) {
-      // stream run: precompute the queues' next costs in bulk, then merge + stage on this wave while the node engine binds (see fastStreamRun)
-      if (S.engLive) { engineStop(d, S); S.engLive = 0; }   // the bulk passes need every wave of the workgroup at the mailbox
+    if (fc.stream && S.fastActive && S.statFastIters >= streamNextAt) {
+      // stream run: the queues' next costs come precomputed (bulk passes where a queue has none left), this wave merges + stages, the node engine binds
       int want = INT32_MAX;
       if (!S.globalRateInf) want = S.globalTokens >= 2147483000.0 ? INT32_MAX : (S.globalTokens < 1 ? 0 : (int)S.globalTokens);
-      int prepared = fastStreamPrepare(d, fc, Q, want);
+      int code = fastStreamPrepare(d, fc, Q, want, !S.engLive, t);
+      if (code == 2) { engineStop(d, S); S.engLive = 0; code = fastStreamPrepare(d, fc, Q, want, 1, t); }   // the bulk passes need every wave of the workgroup at the mailbox
       int E = 0;
-      if (prepared > 0) {
-        engineStart(d, S); S.engLive = 1;
+      if (code == 1) {
+        if (!S.engLive) { engineStart(d, S); S.engLive = 1; }
         StreamIn in; in.globalTokens = S.globalTokens; in.globalBurst = S.globalBurst; in.globalRateInf = S.globalRateInf; in.engSeq = S.engSeq;
         StreamOut so = fastStreamRun(d, fc, Q, in);
         S.engSeq = so.engSeq;
         E = so.executed;
-        S.numScheduledJobs += E; S.numScheduledGangs += E; S.numNodeQueries += E; S.loopIterations += E; S.statFastIters += E;
+        S.numScheduledJobs += E; S.numScheduledGangs += E; S.numNodeQueries += E;
         if (!S.globalRateInf && 1 <= S.globalBurst) S.globalTokens -= (double)E;
+        E += so.executedEv;
+        S.loopIterations += E; S.statFastIters += E;
         S.statRefills += so.refills; S.numEvictedJobs += so.evicted;
-        if (FLANE == 0) { RS.statStreamRuns++; RS.statStreamJobs += E; RS.statStreamPrepared += prepared; RS.statStreamEmitted += so.emitted; }
+        if (FLANE == 0) { RS.statStreamRuns++; RS.statStreamJobs += E; RS.statStreamEmitted += so.emitted; }
         if (so.dropped) { S.fastActive = 0; fastDrop(d); }
         S.tP0 = -1;
         pqBuild(pq, Q);
         if (so.pend >= 0) { pend = so.pend; lastTop = so.pend; refK.A = so.lastA; refK.X = so.lastX; refK.Y = so.lastY; refN = so.lastN; }
       }
-      if (E >= 1024) streamBackoff = 0;
-      else streamBackoff = streamBackoff ? (streamBackoff < (1 << 20) ? streamBackoff * 2 : streamBackoff) : 2048;
+      if (E >= 512) streamBackoff = 0;
+      else streamBackoff = streamBackoff ? (streamBackoff < (1 << 20) ? streamBackoff * 2 : streamBackoff) : 256;
       streamNextAt = S.statFastIters + streamBackoff;
 #ifdef ASCHED_HOSTSIM
       if (getenv("HS_STREAM_EAGER")) { streamBackoff = 0; streamNextAt = S.statFastIters + (E == 0 ? 1 : 0); }   // tests: a stream run wherever one can start
 #endif
       if (pend >= 0) break;
-      continue;
+      if (code == 1) continue;
     }
     KeyOut ko; ko.valid = 0; ko.A = 0; ko.X = ko.Y = 0;
     int st = mode ? fastReplayStep(d, k, S, fc, t, &cnt, &ko) : fastIter(d, k, S, fc, t, &ko);

@@ -198,12 +198,14 @@ DEV void bulkElem(Dev& d, int kind, int i) {
         for (int r = 0; r < MAXR; r++) { int64_t s = part[r]; part[r] = run[r]; run[r] += s; }
         if (barrier != INT32_MAX) { len = barrier; cut = true; break; }
       }
+      if (in.pad) break;   // a kept stream: its length and end flag stand
       d.qsLen[2 * i] = len;
       d.qsLen[2 * i + 1] = (!cut && in.len > 0 && in.base + in.len == d.queuedOff[i + 1]) ? 1 : 0;   // the queue's list ends where the stream ends
     } break;
     case B_QSKEYS: {
       int q = i / QS_CPQ, ch = i % QS_CPQ;
       const QsIn& in = d.qsIn[q];
+      if (in.len == 0) break;   // no new stream for this queue (a kept one stays as it is)
       int len = d.qsLen[2 * q];
       int e0 = ch * QS_CHUNK, e1 = e0 + QS_CHUNK < len ? e0 + QS_CHUNK : len;
       if (e0 >= e1) break;
@@ -531,44 +533,67 @@ DEV_COLD void runRound(Dev& d, Ctl& c) {
 // ------------------------------------------------------------------------------------------------
 // control-kernel commands (the NodeDb-level entry points of the C ABI run through the same device code as the round)
 
-// Stream preparation (round_fast.h "stream run"): which queues take part — the head is a single queued job peeked from the queue's list, the queue may
-// still schedule new jobs — how far each stream may reach (the list, QS_CMAX, the queue's rate-limit tokens, the lookback limit, the global tokens),
-// then the three bulk passes.  Runs on the control wave with the LDS copy of the queue state live; the bulk items read only what is written to d.qsIn.
-DEV_NOINLINE int fastStreamPrepare(Dev& d, FastCtx fc, int Q, int allowed) {
+// Stream preparation (round_fast.h "stream run").  Per queue: a stream with elements left is kept; otherwise the queue may get
+//   * an evicted stream: its head is a phase-1-evicted job of a gang-free eviction list in a pass where evicted jobs always return — the costs are
+//     the ones B_EVKEYS computed for the whole list, nothing to prepare;
+//   * a queued stream: its head is a single queued job peeked from the queue's list and the queue may still schedule new jobs — how far the stream may
+//     reach (the list, QS_CMAX, the queue's rate-limit tokens, the lookback limit, the global tokens), then the three bulk passes over the queues
+//     that need one (they read only what is written to d.qsIn, and run on every wave of the workgroup: the node engine must not be live).
+DEV_NOINLINE int fastStreamPrepare(Dev& d, FastCtx fc, int Q, int allowed, int allowBulk, int top) {
 #ifdef ASCHED_HOSTSIM
   if (getenv("HS_NO_STREAM")) return 0;
 #endif
-  if (allowed < 1) return 0;
   const FastK k = fastKRef(d);
   int skipUnf = fc.skipKnown && RS.numUnfeasible > 0;
   int cap = allowed < QS_CMAX ? allowed : QS_CMAX;
+  bool evOk = fc.evStatic && RS.lvl0NonNeg && RS.numPreemptedMarks == 0;
+#ifdef ASCHED_HOSTSIM
+  if (getenv("HS_NO_EV_STREAM")) evOk = false;
+#endif
+  FOR_LANES(q, QCAPF) FL.tmpQ[q] = 0;
   FOR_LANES(q, Q) {
-    const QHot& f = FL.hot[q];
-    QsIn in; in.base = 0; in.len = 0; in.skipUnf = skipUnf; in.pad = 0; in.weight = f.weight;
+    QHot& f = FL.hot[q];
+    QsIn in; in.base = 0; in.len = 0; in.skipUnf = skipUnf; in.pad = 1; in.weight = f.weight;   // pad 1: the stitch pass leaves the queue's d.qsLen alone
     for (int r = 0; r < MAXR; r++) in.a0[r] = FL.qAlloc[q][r] + FL.qPenalty[q][r];
-    bool ok = FL.inHeap[q] && f.gctx >= 0 && f.headFast && f.headKind == 1 && f.itStage == 1 && !f.itJobOnlyEv && !f.cordoned && f.burst >= 1 && f.tokens >= 1 &&
-              f.evApplied == f.evDone && f.itQi >= 1 && f.itQi <= f.qEnd;
-    if (ok && k.queuedJobs[f.itQi - 1] != f.gctx) ok = false;   // the head did not come from the list position before the cursor (a stashed job)
-    if (ok) {
-      int len = f.qEnd - (f.itQi - 1);
-      if (len > cap) len = cap;
-      if (!f.rateInf && f.tokens < (double)len) len = (int)f.tokens;
-      if (fc.maxLookback != 0 && !f.itGangOnlyEv) {   // element e >= 1 is peeked when itJobsSeen = seen + e - 1 < maxLookback (queue_scheduler.go:434-444)
-        int64_t lim = (int64_t)fc.maxLookback - f.itJobsSeen + 1;
-        if (lim < 1) lim = 1;
-        if (len > lim) len = (int)lim;
+    int status = 0;
+    if (f.sLen > f.sPos) status = 1;
+    else {
+      f.sLen = 0; f.sPos = 0;
+      bool head = FL.inHeap[q] && f.gctx >= 0;
+      if (head && evOk && f.itStage == 0 && f.evCheap && !f.effValid && f.headPos >= 0 && f.headPos == f.itEi - 1 && f.headPos < f.evEnd && f.evDone == f.headPos &&
+          f.evApplied <= f.evDone && k.evList[f.headPos] == f.gctx) {
+        FL.sKind[q] = 1; f.sPos = 0; f.sLen = f.evEnd - f.headPos; f.ewCount = 0; f.ewStart = 0;
+        status = 1;
+      } else if (head && cap >= 1 && f.headFast && f.headKind == 1 && f.itStage == 1 && !f.itJobOnlyEv && !f.cordoned && f.burst >= 1 && f.tokens >= 1 &&
+                 f.evApplied == f.evDone && f.itQi >= 1 && f.itQi <= f.qEnd && k.queuedJobs[f.itQi - 1] == f.gctx) {   // (a stashed job is not at the list position before the cursor)
+        int len = f.qEnd - (f.itQi - 1);
+        if (len > cap) len = cap;
+        if (!f.rateInf && f.tokens < (double)len) len = (int)f.tokens;
+        if (fc.maxLookback != 0 && !f.itGangOnlyEv) {   // element e >= 1 is peeked when itJobsSeen = seen + e - 1 < maxLookback (queue_scheduler.go:434-444)
+          int64_t lim = (int64_t)fc.maxLookback - f.itJobsSeen + 1;
+          if (lim < 1) lim = 1;
+          if (len > lim) len = (int)lim;
+        }
+        in.base = f.itQi - 1; in.len = len; in.pad = 0;
+        status = 2;
       }
-      in.base = f.itQi - 1; in.len = len;
     }
+    FL.tmpQ[q] = status;
     d.qsIn[q] = in;
   }
-  wgBulk(d, B_QSSUM, Q * QS_CPQ);
-  wgBulk(d, B_QSSTITCH, Q);
-  wgBulk(d, B_QSKEYS, Q * QS_CPQ);
-  int total = 0;
-  for (int q = 0; q < Q; q++) total += d.qsLen[2 * q];
-  FOR_LANES(q, Q) { int len = d.qsLen[2 * q]; FL.hot[q].sLen = len; FL.hot[q].sPos = 0; if (len > 0) { FL.hot[q].ewCount = 0; FL.hot[q].ewStart = 0; } }
-  return total;
+  int bulk = 0;
+  for (int q = 0; q < Q; q++) if (UNI32(FL.tmpQ[q]) == 2) bulk++;
+  if (bulk) {
+    if (!allowBulk) return 2;
+    wgBulk(d, B_QSSUM, Q * QS_CPQ);
+    wgBulk(d, B_QSSTITCH, Q);
+    wgBulk(d, B_QSKEYS, Q * QS_CPQ);
+    int total = 0;
+    FOR_LANES(q, Q) if (FL.tmpQ[q] == 2) { int len = d.qsLen[2 * q]; FL.hot[q].sLen = len; FL.hot[q].sPos = 0; FL.sKind[q] = 0; FL.hot[q].ewCount = 0; FL.hot[q].ewStart = 0; }
+    for (int q = 0; q < Q; q++) if (UNI32(FL.tmpQ[q]) == 2) total += d.qsLen[2 * q];
+    if (FLANE == 0) RS.statStreamPrepared += total;
+  }
+  return UNI32(FL.hot[top].sLen) > UNI32(FL.hot[top].sPos) ? 1 : 0;
 }
 
 enum Cmd {
