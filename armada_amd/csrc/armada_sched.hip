@@ -451,11 +451,19 @@ __device__ static inline uint64_t l0Search(KREF k, const JobTail& r, int* slot) 
   int lane = threadIdx.x & 63;
   unsigned long long best = ~0ull; int bs = -1;
   int cnt = UNI32(g_fl.l0Count);
-  for (int base = 0; base < cnt; base += 64) {   // the same trip count on every lane: the cross-lane reduction below sees a converged wave
-    int i = base + lane;
-    if (i < cnt) {
-      unsigned long long key = g_fl.l0Key[i];
-      if (key < best && entryFits(k, r, key, g_fl.l0Ex0[i], g_fl.l0Ex1[i], g_fl.l0Cls[i])) { best = key; bs = i; }
+  int rounds = (cnt + 63) >> 6;   // the same trip count on every lane: the cross-lane reduction below sees a converged wave
+  for (int r0 = 0; r0 < rounds; r0 += 4) {
+    // four rounds of loads issued together (entries past the end read slot 0 and are masked): the LDS latency is paid once per group, not per round
+    unsigned long long key[4], cls[4]; long long e0[4], e1[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int i = ((r0 + u) << 6) + lane, j = i < cnt ? i : 0;
+      key[u] = g_fl.l0Key[j]; e0[u] = g_fl.l0Ex0[j]; e1[u] = g_fl.l0Ex1[j]; cls[u] = g_fl.l0Cls[j];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int i = ((r0 + u) << 6) + lane;
+      if (i < cnt && key[u] < best && entryFits(k, r, key[u], e0[u], e1[u], cls[u])) { best = key[u]; bs = i; }
     }
   }
   unsigned long long mn = waveMin64Dpp(best);   // keys are unique (node-index rank in the low bits): the lane that holds the minimum names the slot
@@ -531,17 +539,17 @@ __device__ static inline void accountVectors(Dev& d, KREF k, int q, int pc, bool
 // compiler must keep the order (wavefront-scope fences emit nothing).  No s_waitcnt vmcnt anywhere on this path: neither wave
 // ever waits for its own outstanding HBM atomics.
 #define LDS_ORDER() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
-__device__ static inline void bindUpdateEng(KREF k, FastS& S, int n, int nl, uint64_t keyDelta) {
+__device__ static inline void bindUpdateEng(KREF k, FastS& S, int n, int nl, uint64_t keyDelta, const int64_t* req) {
   int lane = threadIdx.x & 63;
   int l = S.laneL;
   if (l < nl) {
-    int64_t v = g_fl.eng.req[S.laneX];
+    int64_t v = req[S.laneX];
     if (v) __hip_atomic_fetch_add(&KAL(k, l, S.laneX, n), -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   int R = k.R;
   for (int i = lane + 64; i < nl * R; i += 64) {
     int l2 = i / R, x = i % R;
-    int64_t v = g_fl.eng.req[x];
+    int64_t v = req[x];
     if (v) __hip_atomic_fetch_add(&KAL(k, l2, x, n), -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (lane < nl && keyDelta) __hip_atomic_fetch_add(&KKEY(k, lane, n), 0ull - keyDelta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -606,8 +614,10 @@ __device__ static inline void qsWinRefill(KREF k, int q, int pos, int cnt) {
 }
 __device__ static inline void streamBegin(int* engSeq) {
   int lane = threadIdx.x & 63;
-  if (lane == 0) { g_fl.eng.ringPub = 0; g_fl.eng.ringAck = 0; g_fl.eng.ringEnd = 0; g_fl.eng.ringFail = 0; g_fl.eng.cmd = ENG_STREAM; }
+  if (lane == 0) { g_fl.eng.ringPub = 0; g_fl.eng.ringAck = 0; g_fl.eng.ringEnd = 0; g_fl.eng.ringFail = 0; g_fl.eng.ringClosed = 0; g_fl.eng.bindDone = 0; g_fl.eng.cmd = ENG_STREAM; }
   (*engSeq)++;
+  LDS_ORDER();
+  if (lane == 0) __hip_atomic_store(&g_fl.eng.bindGen, g_fl.eng.bindGen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   LDS_ORDER();
   if (lane == 0) __hip_atomic_store(&g_fl.eng.seq, *engSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -637,8 +647,15 @@ __device__ static inline void streamEnd(int engSeq) {
     if (a == engSeq) break;
     __builtin_amdgcn_s_sleep(1);
   }
+  int gen = __builtin_amdgcn_readfirstlane(g_fl.eng.bindGen);
+  for (;;) {   // ... and the bind wave has issued (and released) the binds of every entry placed
+    int f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.bindFin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if (f == gen) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
   LDS_ORDER();
 }
+__device__ static inline int streamBound() { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.bindDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
 __device__ static inline int streamAcked(int* fail) {
   int a = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringAck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
   int f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringFail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -647,23 +664,29 @@ __device__ static inline int streamAcked(int* fail) {
   *fail = f;
   return a;
 }
-// sctx / qctx accounting of ring entry i once the engine has bound it (accountVectors for a new job), one lane per resource; lane q counts queue q's
-// entries.  An entry of an evicted stream only counts: its commit is deferred like a cheap evicted head's (applyEvictedRange)
-__device__ static inline void streamAccount(Dev& d, KREF k, int i, StreamLanes& sl) {
+// sctx / qctx accounting of ring entries [i0, i1) once the engine has bound them (accountVectors for a new job): 4 (8 when R > 4) lanes per entry, one per
+// resource, so a batch of acknowledgements costs one pass; FL.tmpQ[q] counts queue q's entries.  An entry of an evicted stream only counts: its
+// commit is deferred like a cheap evicted head's (applyEvictedRange)
+__device__ static inline void streamAccount(Dev& d, KREF k, int i0, int i1) {
   (void)d;
   int lane = threadIdx.x & 63;
-  int rq = __builtin_amdgcn_readfirstlane(RQ(i)), q = rq & 0xff;
-  if (lane == q) sl.cnt++;
-  if (rq & RQ_EV) return;
-  const JobRec& r = RREC(i);
-  int pc = __builtin_amdgcn_readfirstlane(r.pc);
-  if (lane < k.R) {
-    int64_t v = r.req[lane];
-    if (v) {
-      LDS_ADD64(g_fl.qAlloc[q][lane], v); LDS_ADD64(g_rs.allocated[lane], v); LDS_ADD64(g_rs.scheduled[lane], v);
-      size_t j = ((size_t)q * k.npc + pc) * k.R + lane;
-      __hip_atomic_fetch_add(&k.qAllocByPc[j], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(&k.qSchedByPc[j], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int sh = k.R <= 4 ? 2 : 3, per = 64 >> sh;
+  int e = lane >> sh, x = lane & ((1 << sh) - 1);
+  for (int b = i0; b < i1; b += per) {
+    int i = b + e;
+    if (i < i1) {
+      int rq = RQ(i), q = rq & 0xff;
+      if (x == 0) (void)__hip_atomic_fetch_add(&g_fl.tmpQ[q], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (!(rq & RQ_EV) && x < k.R) {
+        const JobRec& r = RREC(i);
+        int64_t v = r.req[x];
+        if (v) {
+          LDS_ADD64(g_fl.qAlloc[q][x], v); LDS_ADD64(g_rs.allocated[x], v); LDS_ADD64(g_rs.scheduled[x], v);
+          size_t j = ((size_t)q * k.npc + r.pc) * k.R + x;
+          __hip_atomic_fetch_add(&k.qAllocByPc[j], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(&k.qSchedByPc[j], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
     }
   }
 }
@@ -680,13 +703,13 @@ __device__ static inline void pqHeadKey(PQState& s, int t, PackedKey* key, uint3
 __device__ static inline void engineStart(Dev& d, FastS& S) {
   (void)d;
   S.engSeq = 0;
-  if ((threadIdx.x & 63) == 0) { g_fl.eng.seq = 0; g_fl.eng.ack = 0; g_fl.eng.statScan = 0; g_fl.eng.statL0Max = S.statL0Max; g_fl.eng.busyClk = 0; g_fl.eng.jobs = 0; g_fl.eng.cancel = 0; g_mb.op = OP_ENGINE; }
+  if ((threadIdx.x & 63) == 0) { g_fl.eng.seq = 0; g_fl.eng.ack = 0; g_fl.eng.statScan = 0; g_fl.eng.statL0Max = S.statL0Max; g_fl.eng.busyClk = 0; g_fl.eng.jobs = 0; g_fl.eng.cancel = 0; g_fl.eng.bindQuit = 0; g_fl.eng.bindGen = 0; g_fl.eng.bindFin = 0; g_mb.op = OP_ENGINE; }
   __syncthreads();
 }
 __device__ static inline void engineStop(Dev& d, FastS& S) {
   (void)d;
   int lane = threadIdx.x & 63;
-  if (lane == 0) g_fl.eng.cmd = ENG_QUIT;
+  if (lane == 0) { g_fl.eng.cmd = ENG_QUIT; __hip_atomic_store(&g_fl.eng.bindQuit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   LDS_ORDER();
   S.engSeq++;
   if (lane == 0) __hip_atomic_store(&g_fl.eng.seq, S.engSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -755,13 +778,7 @@ __device__ static void engineLoop(Dev& d) {  // wave 1
         }
         ESEG(0);
         long long b0 = (long long)__builtin_readcyclecounter();
-        {  // the entry's record becomes the mailbox job (the engine's own LDS writes, read back in order)
-          const JobRec& r = RREC(i);
-          if (lane < 8) ((unsigned long long*)g_fl.eng.req)[lane] = ((const unsigned long long*)&r)[lane];
-          else if (lane < 16) ((unsigned long long*)&g_fl.eng.tail)[lane - 8] = ((const unsigned long long*)&r)[lane];
-          if (lane == 0) { int32_t p = r.pcPrio; g_fl.eng.job = RJOB(i); g_fl.eng.prio = p; g_fl.eng.cutoff = r.preemptible ? p : NONPREEMPTIBLE_CUTOFF; g_fl.eng.nl = r.nlPc; }
-        }
-        int st = engineServe(d, k, ES);
+        int st = engineServeRing(d, k, ES, i);
         busy += (long long)__builtin_readcyclecounter() - b0; jobs++;
         if (st == 0) { if (lane == 0) __hip_atomic_store(&g_fl.eng.ringFail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
         i++;
@@ -770,6 +787,7 @@ __device__ static void engineLoop(Dev& d) {  // wave 1
         ESEG(6);
       }
       LDS_ORDER();
+      if (lane == 0) __hip_atomic_store(&g_fl.eng.ringClosed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (lane == 0) __hip_atomic_store(&g_fl.eng.ack, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       continue;
     }
@@ -781,6 +799,55 @@ __device__ static void engineLoop(Dev& d) {  // wave 1
     LDS_ORDER();
     if (lane == 0) __hip_atomic_store(&g_fl.eng.ack, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     ESEG(6);
+  }
+}
+
+// Wave 2 during an engine session: the HBM side of a stream run's placements.  The node engine decides (first fit, L0 upkeep: LDS) and leaves the node in
+// the ring entry; this wave follows its acknowledgement counter and issues BindJobToNode's plane / key atomics and the job's result fields.  Nothing on the
+// engine's chain reads what is written here (level-0 state lives in the base flags + L0), so the two run concurrently; the release fence at the end of a
+// stream orders the writes before whatever the control wave does next.
+__device__ static void bindLoop(Dev& d) {
+  const FastK k = fastKRef(d);
+  int lane = threadIdx.x & 63;
+  FastS BS;
+  BS.tP0 = -1; BS.laneL = lane / (k.R > 0 ? k.R : 1); BS.laneX = lane % (k.R > 0 ? k.R : 1);
+#ifdef ASCHED_FASTPROF
+  for (int i = 0; i < 8; i++) BS.eseg[i] = 0;
+  BS.segT = 0;
+#endif
+  int gen = 0;
+  for (;;) {
+    for (;;) {
+      int g = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.bindGen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      if (g != gen) { gen = g; break; }
+      if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.bindQuit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) return;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    int i = 0;
+    for (;;) {
+      int ack = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringAck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      if (i >= ack) {
+        if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringClosed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
+          ack = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringAck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+          if (i >= ack) break;
+        } else { __builtin_amdgcn_s_sleep(1); continue; }
+      }
+      LDS_ORDER();
+      for (; i < ack; i++) {
+        if (__builtin_amdgcn_readfirstlane(RQ(i)) & RQ_EV) continue;
+        const JobRec& r = RREC(i);
+        int n = __builtin_amdgcn_readfirstlane(r.node0), job = __builtin_amdgcn_readfirstlane(RJOB(i));
+        int32_t p = __builtin_amdgcn_readfirstlane(r.pcPrio);
+        int32_t cutoff = __builtin_amdgcn_readfirstlane((int)r.preemptible) ? p : NONPREEMPTIBLE_CUTOFF;
+        FastS& ES = BS;
+        bindJob(k, ES, n, __builtin_amdgcn_readfirstlane((int)r.nlPc), UNI64(r.keyDelta), r.req, job, p, cutoff);
+      }
+      LDS_ORDER();
+      if (lane == 0) __hip_atomic_store(&g_fl.eng.bindDone, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    LDS_ORDER();
+    if (lane == 0) __hip_atomic_store(&g_fl.eng.bindFin, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
 }
 
@@ -1062,7 +1129,7 @@ __global__ __launch_bounds__(CTL_THREADS) void k_control(Dev dev, int cmd, HelpB
       } else if (op == OP_COMPACT) {
         compactPart(d);
       } else if (op == OP_ENGINE) {
-        if ((threadIdx.x >> 6) == 1) engineLoop(d);
+        if ((threadIdx.x >> 6) == 1) engineLoop(d); else if ((threadIdx.x >> 6) == 2) bindLoop(d);
       }
       __syncthreads();
     }
@@ -1698,7 +1765,7 @@ __global__ __launch_bounds__(CTL_THREADS) void k_control_aux(Dev dev, int cmd, H
       } else if (op == OP_COMPACT) {
         compactPart(d);
       } else if (op == OP_ENGINE) {
-        if ((threadIdx.x >> 6) == 1) engineLoop(d);
+        if ((threadIdx.x >> 6) == 1) engineLoop(d); else if ((threadIdx.x >> 6) == 2) bindLoop(d);
       }
       __syncthreads();
     }

@@ -63,7 +63,8 @@ struct alignas(16) EngineBox {
   int32_t seq, ack;                          // command n is ready when seq == n; served when ack == n
   int32_t statScan, statL0Max;               // engine counters, handed over at ENG_QUIT
   int64_t busyClk; int32_t jobs, cancel;     // shader-clock ticks the engine spent serving jobs, and how many; cancel: the engine saw the caller's cancel word
-  int32_t ringPub, ringAck, ringEnd, ringFail;   // stream run: entries staged in the ring / bound by the engine; no more entries will come; 1 = entry ringAck found no node, 2 = bound but L0 overflowed
+  int32_t ringPub, ringAck, ringEnd, ringFail;   // stream run: entries staged in the ring / placed by the engine; no more entries will come; 1 = entry ringAck found no node, 2 = placed but L0 overflowed
+  int32_t ringClosed, bindGen, bindDone, bindFin, bindQuit;   // the engine has left the ring; stream generation / entries whose bind + result fields the bind wave has issued / generation it has finished
 };
 // stream run: the job-record windows are idle and serve as the ring between the control wave and the node engine
 #define RING_N (QCAPF * WIN)
@@ -338,7 +339,10 @@ struct PQState { int unused; };
 DEV int pqTopFast(int Q);
 DEV void pqBuild(PQState&, int) {}
 DEV int pqHead(PQState&, int Q) { return pqTopFast(Q); }
-DEV void pqPopPush(PQState&, const KeyOut&, int) {}
+DEV void pqPopPush(PQState&, const KeyOut& ko, int q);
+DEV void pqPopPush(PQState&, const KeyOut& ko, int q) {   // the serial heap is the key arrays themselves
+  if (ko.valid) { FL.kA[q] = ko.A; FL.kX[q] = ko.X; FL.kY[q] = ko.Y; FL.inHeap[q] = 1; } else FL.inHeap[q] = 0;
+}
 DEV int pqTopFast(int Q) {
   int best = -1;
   for (int q = 0; q < Q; q++) {
@@ -449,8 +453,8 @@ DEV void applyEvictedRange(Dev& d, int q, int p0, int p1, int sign = 1) {
 DEV bool roundLimitExceeded(Dev& d, KREF k) { for (int x = 0; x < k.R; x++) if (RS.scheduled[x] > d.cfg.maxToSchedule[x]) return true; return false; }  // constraints.go:113-119
 DEV bool headRequestsDisallowed(Dev& d, KREF k, int q) { for (int x = 0; x < k.R; x++) if (d.cfg.disallowed[x] && FL.headReq[q][x] > 0) return true; return false; }  // nodedb.go:596-601
 // two-wave iteration: the engine's bind takes the request from its mailbox; the rollback's accounting from the backup
-DEV void bindUpdateEng(KREF k, FastS&, int n, int nl, uint64_t keyDelta) {
-  for (int l = 0; l < nl; l++) { for (int x = 0; x < k.R; x++) KAL(k, l, x, n) -= FL.eng.req[x]; KKEY(k, l, n) -= keyDelta; }
+DEV void bindUpdateEng(KREF k, FastS&, int n, int nl, uint64_t keyDelta, const int64_t* req) {
+  for (int l = 0; l < nl; l++) { for (int x = 0; x < k.R; x++) KAL(k, l, x, n) -= req[x]; KKEY(k, l, n) -= keyDelta; }
 }
 DEV void accountVectorsBk(Dev& d, KREF k, int q, int pc, int sign) {
   for (int x = 0; x < k.R; x++) {
@@ -475,21 +479,21 @@ DEV bool pinnedNodeFits(KREF k, int q, int n, int level) {
 DEV void pqHeadKey(PQState&, int t, PackedKey* key, uint32_t* nameRank) { key->A = FL.kA[t]; key->X = FL.kX[t]; key->Y = FL.kY[t]; *nameRank = (uint32_t)FL.nameRank[t]; }
 // ---- stream run, serial build.  The engine serves an entry when its record is staged, so that entries emitted but not yet staged when a job
 // does not fit are discarded exactly as on the device (there the engine runs behind the merge by up to a ring's worth of entries).
-struct StreamLanes { int start[QCAPF], base[QCAPF], cnt[QCAPF]; };
+struct StreamLanes { int start[QCAPF], base[QCAPF], pos[QCAPF], len[QCAPF], kind[QCAPF], ws[QCAPF]; double budget[QCAPF]; uint32_t effA[QCAPF]; uint64_t effX[QCAPF], effY[QCAPF]; };
 #define SL_SET(sl, f, q, v) ((sl).f[q] = (v))
 #define SL_GET(sl, f, q) ((sl).f[q])
+#define SL_GET64(sl, f, q) ((sl).f[q])
+#define SL_GETD(sl, f, q) ((sl).f[q])
 DEV void qsWinRefill(KREF k, int q, int pos, int cnt) { for (int i = 0; i < cnt; i++) memcpy(&FL.evWin[q][i], (const char*)k.qsKey + ((size_t)q * QS_CMAX + pos + i) * sizeof(EvKey), sizeof(EvKey)); }
 DEV int engineServe(Dev& d, KREF k, FastS& ES);
 static FastS g_engS;
 DEV void streamBegin(int* engSeq) { FL.eng.ringPub = FL.eng.ringAck = FL.eng.ringEnd = FL.eng.ringFail = 0; FL.eng.cmd = ENG_STREAM; (*engSeq)++; }
 static JobRec g_hsStage[4];
 DEV unsigned long long streamStageIssue(KREF k, int base, int cnt) { for (int i = 0; i < cnt; i++) if (!(RQ(base + i) & RQ_EV)) memcpy(&g_hsStage[i], (const char*)k.jrec + (size_t)RJOB(base + i) * sizeof(JobRec), sizeof(JobRec)); return 0; }
+DEV int engineServeRing(Dev& d, KREF k, FastS& ES, int i);
 DEV void streamServeOne(Dev& d, KREF k, int i) {
   if (RQ(i) & RQ_EV) { FL.eng.ringAck = i + 1; return; }
-  const JobRec& r = RREC(i);
-  memcpy(FL.eng.req, r.req, sizeof FL.eng.req); memcpy(&FL.eng.tail, &r.keyDelta, sizeof(JobTail));
-  FL.eng.job = RJOB(i); FL.eng.prio = r.pcPrio; FL.eng.cutoff = r.preemptible ? r.pcPrio : NONPREEMPTIBLE_CUTOFF; FL.eng.nl = r.nlPc; FL.eng.cmd = ENG_JOB;
-  int st = engineServe(d, k, g_engS);
+  int st = engineServeRing(d, k, g_engS, i);
   if (st == 0) { FL.eng.ringFail = 1; return; }
   FL.eng.ringAck = i + 1;
   if (st == 2) FL.eng.ringFail = 2;
@@ -501,17 +505,20 @@ DEV void streamStageCommit(Dev& d, KREF k, int base, int cnt, unsigned long long
 }
 DEV void streamEnd(int) { FL.eng.ringEnd = 1; }
 DEV int streamAcked(int* fail) { *fail = FL.eng.ringFail; return FL.eng.ringAck; }
-DEV void streamAccount(Dev& d, KREF k, int i, StreamLanes& sl) {
-  int rq = RQ(i), q = rq & 0xff;
-  sl.cnt[q]++;
-  if (rq & RQ_EV) return;
-  const JobRec& r = RREC(i);
-  int pc = r.pc;
-  for (int x = 0; x < k.R; x++) {
-    int64_t v = r.req[x];
-    FL.qAlloc[q][x] += v; RS.allocated[x] += v; RS.scheduled[x] += v;
-    size_t j = ((size_t)q * k.npc + pc) * k.R + x;
-    k.qAllocByPc[j] += v; k.qSchedByPc[j] += v;
+DEV int streamBound() { return FL.eng.ringAck; }
+DEV void streamAccount(Dev& d, KREF k, int i0, int i1) {
+  for (int i = i0; i < i1; i++) {
+    int rq = RQ(i), q = rq & 0xff;
+    FL.tmpQ[q]++;
+    if (rq & RQ_EV) continue;
+    const JobRec& r = RREC(i);
+    int pc = r.pc;
+    for (int x = 0; x < k.R; x++) {
+      int64_t v = r.req[x];
+      FL.qAlloc[q][x] += v; RS.allocated[x] += v; RS.scheduled[x] += v;
+      size_t j = ((size_t)q * k.npc + pc) * k.R + x;
+      k.qAllocByPc[j] += v; k.qSchedByPc[j] += v;
+    }
   }
 }
 #else  // device versions: armada_sched.hip
@@ -532,7 +539,7 @@ DEV void accountVectors(Dev& d, KREF k, int q, int pc, bool ev, bool replay);
 DEV void evWinRefill(KREF k, int q, int pos, int cnt);
 __device__ static void applyEvictedRange(Dev& d, int q, int p0, int p1, int sign = 1);  // not inlined, reads the constants itself: nothing of the hot loop has to live in memory for it
 DEV bool roundLimitExceeded(Dev& d, KREF k);
-DEV void bindUpdateEng(KREF k, FastS& S, int n, int nl, uint64_t keyDelta);
+DEV void bindUpdateEng(KREF k, FastS& S, int n, int nl, uint64_t keyDelta, const int64_t* req);
 DEV void accountVectorsBk(Dev& d, KREF k, int q, int pc, int sign);
 DEV void engineRestore(int q);
 DEV void enginePost(Dev& d, KREF k, FastS& S, int job, int q, int pc, int32_t prio, int32_t cutoff, int nl);  // backup of queue q + the job, one LDS pass
@@ -542,16 +549,23 @@ DEV void engineStart(Dev& d, FastS& S);
 DEV void engineStop(Dev& d, FastS& S);
 DEV bool headRequestsDisallowed(Dev& d, KREF k, int q);
 DEV bool pinnedNodeFits(KREF k, int q, int n, int level);
-struct StreamLanes { int start, base, cnt; };   // lane q: queue q's stream position at the start of the run, list position of element 0, entries done
-#define SL_SET(sl, f, q, v) ((sl).f = (v))
-#define SL_GET(sl, f, q) __builtin_amdgcn_readlane((sl).f, (q))
+// per-queue state of a stream run, held in the lanes of the control wave (lane q: queue q): position at the start of the run, list position of element 0,
+// merge cursor, length, kind (bit 0: evicted stream, bit 1: the queue's evicted list was folded (running-maximum key)), first element of the key window in
+// LDS, the queue's budget, the running-maximum key.  Reading queue t's values is a v_readlane (scalar result), no LDS round trip.
+struct StreamLanes { int start, base, pos, len, kind, ws; double budget; uint32_t effA; unsigned long long effX, effY; };
+#define SL_SET(sl, f, q, v) do { if ((int)(threadIdx.x & 63) == (q)) (sl).f = (v); } while (0)
+#define SL_GET(sl, f, q) __builtin_amdgcn_readlane((int)(sl).f, (q))
+__device__ static inline unsigned long long slGet64(unsigned long long v, int q) { unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, q), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), q); return ((unsigned long long)hi << 32) | lo; }
+#define SL_GET64(sl, f, q) slGet64((sl).f, (q))
+#define SL_GETD(sl, f, q) __builtin_bit_cast(double, slGet64(__builtin_bit_cast(unsigned long long, (sl).f), (q)))
 DEV void qsWinRefill(KREF k, int q, int pos, int cnt);
 DEV void streamBegin(int* engSeq);
 DEV unsigned long long streamStageIssue(KREF k, int base, int cnt);
 DEV void streamStageCommit(Dev& d, KREF k, int base, int cnt, unsigned long long v);
 DEV void streamEnd(int engSeq);
-DEV void streamAccount(Dev& d, KREF k, int i, StreamLanes& sl);
+DEV void streamAccount(Dev& d, KREF k, int i0, int i1);   // ring entries [i0, i1): sctx / qctx sums, FL.tmpQ[queue] counts them
 DEV int streamAcked(int* fail);
+DEV int streamBound();   // entries whose ring slot is free again (the bind wave has read them)
 DEV void wgBulk(Dev& d, int kind, int n);
 #endif
 DEV void candInvalidate(int S, int n) { FOR_LANES(s, S) if (FL.cand[s].node == n) FL.cand[s].node = -2; }
@@ -693,7 +707,7 @@ DEV bool fastGangMember(Dev& d, Ctl& c, int job) {
   int32_t prio = r.pcPrio, cutoff = r.preemptible ? prio : NONPREEMPTIBLE_CUTOFF;
   int32_t oldCutoff = d.jobCutoff[job];
   FOR_LANES(x, MAXR) FL.eng.req[x] = x < k.R ? jr.req[x] : 0;   // the engine mailbox is free outside an engine session: the bind reads the request from it
-  bindUpdateEng(k, S, n, r.nlPc, r.keyDelta);
+  bindUpdateEng(k, S, n, r.nlPc, r.keyDelta, FL.eng.req);
   if (FLANE == 0) {
     k.jcHasPctx[job] = 1; k.pcNode[job] = n; k.pcSap[job] = prio; k.pcPap[job] = ASCHED_EVICTED_PRIORITY; k.pcMethod[job] = ASCHED_METHOD_NO_PREEMPTION;
     k.jobNode[job] = n; k.jobCutoff[job] = cutoff; k.schedAtPrio[job] = prio;
@@ -835,32 +849,46 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
 // Node side of one queued-job iteration (the second wave on the device): first fit at priority -2 for the job in the mailbox,
 // BindJobToNode (nodedb.go:1046-1068), the job's result fields, level-0 bookkeeping.  0 = does not fit (nothing touched),
 // 1 = bound, 2 = bound and the L0 list overflowed (the caller drops the structure).
-DEV int engineServe(Dev& d, KREF k, FastS& ES) {
-  // hard timeout / cancel (queue_scheduler.go:105-112): the node engine has the slack of the two waves, so IT reads the host-mapped word (every
-  // 256 jobs; a read crosses PCIe) and answers "no node" without touching anything: the control wave takes the iteration back, leaves the fast
-  // loop, finds the flag and raises ASCHED_ERR_TIMEOUT.  The control wave's loop carries no extra instruction for this.
-  if ((++ES.engSeq & 255) == 0 && cancelRequested(d)) { if (FLANE == 0) FL.eng.cancel = 1; return 0; }
-  JobTail r = FL.eng.tail;
-  uniJobTail(r);
-  int job = UNI32(FL.eng.job), nl = UNI32(FL.eng.nl);
-  int32_t prio = UNI32(FL.eng.prio), cutoff = UNI32(FL.eng.cutoff);
-  FitHandle h; h.src = 0; h.slot = -1;
-  CandRec cand; cand.pos = 0; cand.node = -1; cand.key = 0; cand.cls = 0; cand.ex0 = cand.ex1 = 0; cand.pad = 0;
-  ESEG(1);
-  int n = fastFirstFit(k, ES, r, &h, &cand);
-  ESEG(2);
-  if (n < 0) return 0;
-  bindUpdateEng(k, ES, n, nl, r.keyDelta);
+// BindJobToNode (nodedb.go:1046-1068) + the job's result fields: HBM only — no-return atomics on the node's planes and keys, plain stores per job
+DEV void bindJob(KREF k, FastS& ES, int n, int nl, uint64_t keyDelta, const int64_t* req, int job, int32_t prio, int32_t cutoff) {
+  bindUpdateEng(k, ES, n, nl, keyDelta, req);
   ESEG(3);
   if (FLANE == 0) {  // jcReason, jobEvictedOnNode, inSchedAndEvicted are still 0 for a queued job
     k.jcHasPctx[job] = 1; k.pcNode[job] = n; k.pcSap[job] = prio;
     k.jobNode[job] = n; k.jobCutoff[job] = cutoff; k.schedAtPrio[job] = prio;
     k.pcPap[job] = ASCHED_EVICTED_PRIORITY; k.pcMethod[job] = ASCHED_METHOD_NO_PREEMPTION; k.jobFlags[job] = F_SUCCESSFUL; k.inScheduled[job] = 1;
   }
+}
+DEV int engineServeAt(Dev& d, KREF k, FastS& ES, const JobTail& tailSrc, const int64_t* reqSrc, int job, int32_t prio, int32_t cutoff, int nl, int ringIdx = -1) {
+  // hard timeout / cancel (queue_scheduler.go:105-112): the node engine has the slack of the two waves, so IT reads the host-mapped word (every
+  // 256 jobs; a read crosses PCIe) and answers "no node" without touching anything: the control wave takes the iteration back, leaves the fast
+  // loop, finds the flag and raises ASCHED_ERR_TIMEOUT.  The control wave's loop carries no extra instruction for this.
+  if ((++ES.engSeq & 255) == 0 && cancelRequested(d)) { if (FLANE == 0) FL.eng.cancel = 1; return 0; }
+  JobTail r = tailSrc;
+  uniJobTail(r);
+  FitHandle h; h.src = 0; h.slot = -1;
+  CandRec cand; cand.pos = 0; cand.node = -1; cand.key = 0; cand.cls = 0; cand.ex0 = cand.ex1 = 0; cand.pad = 0;
+  ESEG(1);
+  int n = fastFirstFit(k, ES, r, &h, &cand);
+  ESEG(2);
+  if (n < 0) return 0;
+#if !defined(ASCHED_HOSTSIM)
+  if (ringIdx >= 0) { if (FLANE == 0) RREC(ringIdx).node0 = n; }   // stream run: the bind wave issues the HBM side (bindJob) from the ring entry
+  else
+#endif
+  bindJob(k, ES, n, nl, r.keyDelta, reqSrc, job, prio, cutoff);
   ESEG(4);
   bool okAb = fastAfterBind(k, ES, r, n, h, cand);
   ESEG(5);
   return okAb ? 1 : 2;
+}
+DEV int engineServe(Dev& d, KREF k, FastS& ES) {   // the job in the mailbox
+  return engineServeAt(d, k, ES, FL.eng.tail, FL.eng.req, UNI32(FL.eng.job), UNI32(FL.eng.prio), UNI32(FL.eng.cutoff), UNI32(FL.eng.nl));
+}
+DEV int engineServeRing(Dev& d, KREF k, FastS& ES, int i) {   // ring entry i of a stream run, read in place
+  const JobRec& r = RREC(i);
+  int32_t p = UNI32(r.pcPrio);
+  return engineServeAt(d, k, ES, *(const JobTail*)&r.keyDelta, r.req, UNI32(RJOB(i)), p, UNI32((int)r.preemptible) ? p : NONPREEMPTIBLE_CUTOFF, UNI32((int)r.nlPc), i);
 }
 #ifdef ASCHED_HOSTSIM
 // serial build: the engine runs at post time; the control code still proceeds on the assumption that the job fits and takes the
@@ -1235,12 +1263,12 @@ struct StreamOut { int executed, executedEv, pend, dropped, engSeq, emitted, ref
 // when anything but a stream run serves the queue (fastIter) or the generic code runs (fastQLoad).  prepare: 0 = the top queue has no stream,
 // 1 = ready, 2 = some queue needs the bulk passes and allowBulk was 0 (the node engine must be stopped first: they use every wave of the workgroup)
 DEV_NOINLINE int fastStreamPrepare(Dev& d, FastCtx fc, int Q, int allowed, int allowBulk, int top);   // round_run.h
-DEV EvKey streamKey(KREF k, int q, int pos, int sLen, int kind, int base) {
-  int ws = UNI32(FL.hot[q].ewStart), wc = UNI32(FL.hot[q].ewCount);
-  if (!(pos >= ws && pos < ws + wc)) {
+DEV EvKey streamKey(KREF k, StreamLanes& sl, int q, int pos, int sLen, int kind, int base) {
+  int ws = SL_GET(sl, ws, q);
+  if (!(pos >= ws && pos < ws + WIN)) {
     int cnt = sLen - pos; if (cnt > WIN) cnt = WIN;
-    if (kind) evWinRefill(k, q, base + pos, cnt); else qsWinRefill(k, q, pos, cnt);
-    if (FLANE == 0) { FL.hot[q].ewStart = pos; FL.hot[q].ewCount = cnt; }
+    if (kind & 1) evWinRefill(k, q, base + pos, cnt); else qsWinRefill(k, q, pos, cnt);
+    SL_SET(sl, ws, q, pos);
     ws = pos;
   }
   EvKey e = FL.evWin[q][pos - ws];
@@ -1258,58 +1286,69 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
   if (in.globalBurst < 1 || in.globalTokens < 1) allowed = 0;
   PackedKey lastK; lastK.A = ~0u; lastK.X = lastK.Y = ~0ull; uint32_t lastN = ~0u;
   StreamLanes sl; memset(&sl, 0, sizeof sl);
-  FOR_LANES(q, QCAPF) {   // per queue: stream position at the start of the run, list position of element 0 (the head is element sPos = the list entry before the cursor)
+  FOR_LANES(q, QCAPF) {   // (the head of a queue is element sPos of its stream = the list entry before the queue's cursor)
     const QHot& f = FL.hot[q];
-    SL_SET(sl, start, q, f.sPos);
-    SL_SET(sl, base, q, (FL.sKind[q] ? f.itEi : f.itQi) - 1 - f.sPos);
-    SL_SET(sl, cnt, q, 0);
+    int kind = FL.sKind[q] ? 1 : 0;
+    SL_SET(sl, start, q, f.sPos); SL_SET(sl, pos, q, f.sPos); SL_SET(sl, len, q, q < Q ? f.sLen : 0);
+    SL_SET(sl, base, q, (kind ? f.itEi : f.itQi) - 1 - f.sPos);
+    SL_SET(sl, kind, q, kind | (f.effValid ? 2 : 0));
+    SL_SET(sl, ws, q, -2 * WIN);
+    SL_SET(sl, budget, q, f.budget);
+    SL_SET(sl, effA, q, FL.effA[q]); SL_SET(sl, effX, q, FL.effX[q]); SL_SET(sl, effY, q, FL.effY[q]);
+    FL.tmpQ[q] = 0;
   }
   int engSeq = in.engSeq;
   streamBegin(&engSeq);
   int emitted = 0, emittedQ = 0, acc = 0, stageBase = -1, stageCnt = 0;
   unsigned long long stageV = 0;
   int fail = 0;
+  SEG_BEGIN();
   for (;;) {
     int a = streamAcked(&fail);
-    while (acc < a) { streamAccount(d, k, acc, sl); acc++; }
+    if (a > acc) { streamAccount(d, k, acc, a); acc = a; }
     if (fail) break;
-    if (emitted - acc >= RING_N - 8) { STREAM_IDLE(); continue; }   // the ring is full: the engine is the pace
+    if (emitted - acc >= RING_N - 8 || emitted - streamBound() >= RING_N - 8) { STREAM_IDLE(); SEG(15); continue; }   // the ring is full: the engine is the pace
+    SEG(11);
     int t = pqHead(pq, Q);
     if (t < 0) break;
-    int sPos = UNI32(FL.hot[t].sPos), sLen = UNI32(FL.hot[t].sLen);
+    int sPos = SL_GET(sl, pos, t), sLen = SL_GET(sl, len, t);
     if (sPos >= sLen) break;                      // the head of the heap is not a stream element
-    int kind = UNI32((int)FL.sKind[t]);
-    if (!kind && emittedQ >= allowed) break;      // no global token left for another new job
+    int kind = SL_GET(sl, kind, t);
+    if (!(kind & 1) && emittedQ >= allowed) break;   // no global token left for another new job
     int base = SL_GET(sl, base, t);
-    EvKey e = streamKey(k, t, sPos, sLen, kind, base);
+    EvKey e = streamKey(k, sl, t, sPos, sLen, kind, base);
+    SEG(12);
     pqHeadKey(pq, t, &lastK, &lastN);             // the key this entry is served under (fastExitSkip rebuilds the state around the last one)
-    if (FLANE == 0) { RJOB(emitted) = e.job; RQ(emitted) = t | (kind ? RQ_EV : 0); }
-    emitted++; if (!kind) emittedQ++;
+    if (FLANE == 0) { RJOB(emitted) = e.job; RQ(emitted) = t | ((kind & 1) ? RQ_EV : 0); }
+    emitted++; if (!(kind & 1)) emittedQ++;
     if ((emitted & 3) == 0) {                     // records: gather the last four entries; the four before them have arrived by now
       if (stageBase >= 0) streamStageCommit(d, k, stageBase, stageCnt, stageV);
       stageBase = emitted - 4; stageCnt = 4;
       stageV = streamStageIssue(k, stageBase, 4);
     }
     sPos++;
-    if (FLANE == 0) FL.hot[t].sPos = sPos;
+    SL_SET(sl, pos, t, sPos);
+    SEG(13);
     KeyOut ko; ko.valid = 0; ko.A = 0; ko.X = ko.Y = 0;
     if (sPos < sLen) {
-      EvKey n = streamKey(k, t, sPos, sLen, kind, base);
-      ko = packItemKeys(fc.preferLarge, t, n.pcPrio, n.proposed, n.current, n.size, UNID(FL.hot[t].budget));
-      if (UNI32(FL.hot[t].effValid)) {   // skip mode: as fastAdvance — a head is not served before what precedes it in its queue
-        PackedKey own, eff; own.A = ko.A; own.X = ko.X; own.Y = ko.Y; eff.A = UNI32(FL.effA[t]); eff.X = UNI64(FL.effX[t]); eff.Y = UNI64(FL.effY[t]);
-        if (packedLess(own, 0, eff, 0)) { ko.A = eff.A; ko.X = eff.X; ko.Y = eff.Y; FL.kA[t] = eff.A; FL.kX[t] = eff.X; FL.kY[t] = eff.Y; }
-        else { FL.effA[t] = own.A; FL.effX[t] = own.X; FL.effY[t] = own.Y; }
+      EvKey n = streamKey(k, sl, t, sPos, sLen, kind, base);
+      PackedKey own = packKey3(fc.preferLarge, n.pcPrio, n.proposed, n.current, n.size, SL_GETD(sl, budget, t));
+      if (kind & 2) {   // skip mode: as fastAdvance — a head is not served before what precedes it in its queue
+        PackedKey eff; eff.A = (uint32_t)SL_GET(sl, effA, t); eff.X = SL_GET64(sl, effX, t); eff.Y = SL_GET64(sl, effY, t);
+        if (packedLess(own, 0, eff, 0)) own = eff;
+        else { SL_SET(sl, effA, t, own.A); SL_SET(sl, effX, t, own.X); SL_SET(sl, effY, t, own.Y); }
       }
+      ko.valid = 1; ko.A = own.A; ko.X = own.X; ko.Y = own.Y;
+      SEG(14);
       pqPopPush(pq, ko, t);
+      SEG(10);
     } else {
-      FL.inHeap[t] = 0;
       pqPopPush(pq, ko, t);
-      if (kind || !UNI32(d.qsLen[2 * t + 1])) break;   // the queue goes on beyond its stream (its queued jobs after the evicted ones / more of its list): the next key is not known here
+      if ((kind & 1) || !UNI32(d.qsLen[2 * t + 1])) break;   // the queue goes on beyond its stream (its queued jobs after the evicted ones / more of its list): the next key is not known here
     }
   }
 #ifdef ASCHED_HOSTSIM
-  if (getenv("HS_STREAM_TRACE")) { int t = pqHead(pq, Q); fprintf(stderr, "stream run end: emitted %d (new %d) acc %d fail %d allowed %d top %d", emitted, emittedQ, acc, fail, allowed, t); if (t >= 0) fprintf(stderr, " sPos %d sLen %d skind %d kind %d gctx %d stage %d inHeap %d", FL.hot[t].sPos, FL.hot[t].sLen, FL.sKind[t], FL.hot[t].headKind, FL.hot[t].gctx, FL.hot[t].itStage, FL.inHeap[t]); fprintf(stderr, "\n"); }
+  if (getenv("HS_STREAM_TRACE")) { int t = pqHead(pq, Q); fprintf(stderr, "stream run end: emitted %d (new %d) acc %d fail %d allowed %d top %d", emitted, emittedQ, acc, fail, allowed, t); if (t >= 0) fprintf(stderr, " sPos %d sLen %d skind %d kind %d gctx %d stage %d inHeap %d", SL_GET(sl, pos, t), SL_GET(sl, len, t), SL_GET(sl, kind, t), FL.hot[t].headKind, FL.hot[t].gctx, FL.hot[t].itStage, FL.inHeap[t]); fprintf(stderr, "\n"); }
 #endif
   // drain: what is still in flight, then the tail group
   if (!fail) {
@@ -1318,7 +1357,7 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
     if (emitted > done) { stageV = streamStageIssue(k, done, emitted - done); streamStageCommit(d, k, done, emitted - done, stageV); }
   }
   streamEnd(engSeq);
-  { int a = streamAcked(&fail); while (acc < a) { streamAccount(d, k, acc, sl); acc++; } }
+  { int a = streamAcked(&fail); if (a > acc) { streamAccount(d, k, acc, a); acc = a; } }
   if (fail == 2) out.dropped = 1;
   // ---- the queues' iterator state as of the acc entries done: each queue's head becomes the first of its elements that was not done
   FOR_LANES(q, QCAPF) { FL.hot[q].winKind = -1; FL.hot[q].winCount = 0; }   // the windows served as the ring
@@ -1327,7 +1366,7 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
     QHot f = FL.hot[q];
     uniQHot(f);
     if (f.sLen == 0) continue;
-    int start = SL_GET(sl, start, q), cq = SL_GET(sl, cnt, q), moved = f.sPos - start, kind = UNI32((int)FL.sKind[q]);
+    int start = SL_GET(sl, start, q), cq = UNI32(FL.tmpQ[q]), moved = SL_GET(sl, pos, q) - start, kind = SL_GET(sl, kind, q) & 1;
     int pos = start + cq;                          // the new head
     bool more = pos < f.sLen;
 #ifdef ASCHED_HOSTSIM
@@ -1460,8 +1499,8 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
         pqBuild(pq, Q);
         if (so.pend >= 0) { pend = so.pend; lastTop = so.pend; refK.A = so.lastA; refK.X = so.lastX; refK.Y = so.lastY; refN = so.lastN; }
       }
-      if (E >= 512) streamBackoff = 0;
-      else streamBackoff = streamBackoff ? (streamBackoff < (1 << 20) ? streamBackoff * 2 : streamBackoff) : 256;
+      if (E >= 256) streamBackoff = 0;   // an attempt that finds every stream in place costs little (no bulk pass): back off gently
+      else streamBackoff = streamBackoff ? (streamBackoff < 2048 ? streamBackoff * 2 : streamBackoff) : 32;
       streamNextAt = S.statFastIters + streamBackoff;
 #ifdef ASCHED_HOSTSIM
       if (getenv("HS_STREAM_EAGER")) { streamBackoff = 0; streamNextAt = S.statFastIters + (E == 0 ? 1 : 0); }   // tests: a stream run wherever one can start
