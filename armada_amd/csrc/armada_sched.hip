@@ -447,11 +447,36 @@ __device__ static inline void baseScan(KREF k, FastS& S, const JobTail& r) {
   }
 }
 
+// mask mode: which shapes fit a node with these level-0 key fields / extras / class bits — lane s evaluates shape s against the table in LDS
+__device__ static inline uint64_t capMask(KREF k, uint64_t clsBits, uint64_t key, int64_t ex0, int64_t ex1) {
+  int lane = threadIdx.x & 63;
+  bool ok = false;
+  if (lane < k.S) {
+    const ShapeReq q = SHT(lane);
+    ok = !q.never && ((clsBits >> q.cls) & 1) && fieldsGE(k, key, q.fieldMin) && q.ex0 <= ex0 && q.ex1 <= ex1;
+  }
+  return __ballot(ok);
+}
 __device__ static inline uint64_t l0Search(KREF k, const JobTail& r, int* slot) {
   int lane = threadIdx.x & 63;
   unsigned long long best = ~0ull; int bs = -1;
   int cnt = UNI32(g_fl.l0Count);
   int rounds = (cnt + 63) >> 6;   // the same trip count on every lane: the cross-lane reduction below sees a converged wave
+  if (k.maskMode) {   // one bit per entry says whether the job's shape fits: key + mask, nothing else
+    int sh = r.shape;
+    for (int r0 = 0; r0 < rounds; r0 += 4) {
+      unsigned long long key[4], m[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { int i = ((r0 + u) << 6) + lane, j = i < cnt ? i : 0; key[u] = g_fl.l0Key[j]; m[u] = g_fl.l0Cls[j]; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) { int i = ((r0 + u) << 6) + lane; if (i < cnt && ((m[u] >> sh) & 1) && key[u] < best) { best = key[u]; bs = i; } }
+    }
+    unsigned long long mn = waveMin64Dpp(best);
+    if (mn == ~0ull) { *slot = -1; return mn; }
+    unsigned long long who = __ballot(best == mn);
+    *slot = __builtin_amdgcn_readlane(bs, __ffsll((long long)who) - 1);
+    return mn;
+  }
   for (int r0 = 0; r0 < rounds; r0 += 4) {
     // four rounds of loads issued together (entries past the end read slot 0 and are masked): the LDS latency is paid once per group, not per round
     unsigned long long key[4], cls[4]; long long e0[4], e1[4];
@@ -1386,6 +1411,7 @@ __global__ void k_base_finish(Dev d) {
   int node = d.nodeByRank[key & ((1ull << c.idxBits) - 1)];
   d.baseNode[i] = node; d.posOf[node] = i; d.baseRemoved[i] = 0; d.baseCls[i] = d.nodeCls[node]; d.l0Slot[node] = -1;
   for (int e = 0; e < d.f.E; e++) d.baseExtra[(size_t)e * c.Npad + i] = d.alloc[(size_t)d.f.extraCol[e] * c.Npad + node];  // level 0 planes
+  if (d.f.maskMode) d.baseCls[i] = shapeFitMaskSerial(d, d.nodeCls[node], key, d.f.E > 0 ? d.alloc[(size_t)d.f.extraCol[0] * c.Npad + node] : 0, d.f.E > 1 ? d.alloc[(size_t)d.f.extraCol[1] * c.Npad + node] : 0);
 }
 
 __global__ void k_drf(Dev d, const int64_t* alloc, double* out) { if (threadIdx.x == 0) *out = drf(d, alloc); }

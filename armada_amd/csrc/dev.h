@@ -88,11 +88,17 @@ struct EvKey { double proposed, current, size; int32_t pcPrio; int32_t job; };
 #define QS_CPQ (QS_CMAX / QS_CHUNK)
 struct QsIn { int32_t base, len, skipUnf, pad; int64_t a0[MAXR]; double weight; };   // per queue: position of element 0 in queuedJobs, wanted length, allocation + penalty before element 0
 
+// What a node must offer for a job of one scheduling-key shape (the per-job JobRec fields that depend on the shape only).  With at most 64 shapes the fast
+// structure keeps, per node entry, a bit per shape "a job of this shape fits here now" instead of re-deriving it from key fields, extras and class bits
+// at every query (FastCfg.maskMode): a first-fit query then tests one bit per entry.
+struct ShapeReq { uint64_t fieldMin; int64_t ex0, ex1; int32_t cls, never; };
+
 // Level-0 ("fit without preemption", priority -2) fast structure, DESIGN.md "Sorted base + LDS delta".
 struct FastCfg {
   int structOk, iterOk;       // host-verified exactness conditions (asched_host.inc: fastConditions)
   int relocAll;               // ASCHED_RELOC_ALL=1: stage the per-queue arrays in LDS for any Q (default: only Q <= 64, see armada_sched.hip relocateIn)
   int cascadeFuse;            // the gate + urgency sweep of one job may run as ONE multi-level plane pass (round_ctl.h selectAtPriority): planes are monotone in the level (no explicit alloc_by_prio, non-negative requests) and a level tag fits above the packed key
+  int maskMode;               // <= 64 shapes: baseCls / l0Cls / CandRec.cls hold per-shape fit masks (current capacity and requirement class folded in), not class bits
   int engine;                 // queued-job iterations run on two waves (round_fast.h "two-wave iteration"); ASCHED_ENGINE=0 turns it off
   int E; int extraCol[MAXE];  // non-indexed columns
   uint64_t fieldMask[MAXK];   // in-place mask of each packed key field
@@ -237,6 +243,7 @@ struct Dev {
   int32_t* posOf;        // [N] node -> base position
   int32_t* l0Slot;       // [N] node -> L0 slot or -1
   uint64_t* nodeCls;     // [N]
+  ShapeReq* shapeTab;    // [S]
   JobRec* jrec;          // [M]
   int32_t* evIdxByPos;   // [M] evicted-table Index of evList[p]
   EvKey* evKey;          // [M] per evicted-list position (queues with evCheap)

@@ -202,6 +202,7 @@ struct FastK {
   GP(int64_t) qAllocByPc; GP(int64_t) qSchedByPc; GP(int64_t) qEvictedByPc;
   GP(uint8_t) jcPreempted; GP(uint8_t) nodeFlags;
   GP(unsigned long long) qsKey;
+  int maskMode;
   int32_t prios[MAXP];
 };
 // scheduling-context scalars the loop reads and writes (context/scheduling.go:27-77), written back to RS at the end of a run
@@ -249,6 +250,7 @@ HD void fastKInit(const Dev& d, FastK& k) {
   k.qAllocByPc = GA(int64_t, d.qAllocByPc); k.qSchedByPc = GA(int64_t, d.qSchedByPc); k.qEvictedByPc = GA(int64_t, d.qEvictedByPc);
   k.jcPreempted = GA(uint8_t, d.jcPreempted); k.nodeFlags = GA(uint8_t, d.nodeFlags);
   k.qsKey = GA(unsigned long long, (unsigned long long*)d.qsKey);
+  k.maskMode = d.f.maskMode;
   for (int i = 0; i < MAXP; i++) k.prios[i] = i < c.P ? c.prios[i] : INT32_MAX;
 }
 // a register copy of the constants: one burst of scalar loads (constant address space) per call, then no memory traffic
@@ -271,7 +273,25 @@ DEV bool fieldsGE(KREF k, uint64_t key, uint64_t fmin) {  // every packed field 
   for (int i = 0; i < MAXK; i++) { uint64_t m = k.fieldMask[i]; ok = ok && (key & m) >= (fmin & m); }  // unused fields have mask 0
   return ok;
 }
+// mask mode (FastCfg.maskMode): the shape table sits in the unused upper half of the candidate array (S <= 64 <= SMAX / 2)
+#define SHT(s) (((ShapeReq*)&FL.cand[SMAX / 2])[s])
+static_assert(sizeof(ShapeReq) == 32 && 64 * sizeof(ShapeReq) <= (SMAX / 2) * sizeof(CandRec), "shape table fits behind the candidates");
+// fit mask of a node from scratch (per-thread loop over the shapes): class bits + level-0 key and extras -> bit s = a job of shape s fits
+HD uint64_t shapeFitMaskSerial(const Dev& d, uint64_t clsBits, uint64_t key, int64_t ex0, int64_t ex1) {
+  uint64_t m = 0;
+  for (int s = 0; s < d.cfg.S && s < 64; s++) {
+    const ShapeReq q = d.shapeTab[s];
+    bool ok = !q.never && ((clsBits >> q.cls) & 1) && q.ex0 <= ex0 && q.ex1 <= ex1;
+    if (ok) {
+      if (d.f.guardMask) ok = (((key | d.f.guardMask) - q.fieldMin) & d.f.guardMask) == d.f.guardMask;
+      else for (int i = 0; i < MAXK; i++) { uint64_t fm = d.f.fieldMask[i]; ok = ok && (key & fm) >= (q.fieldMin & fm); }
+    }
+    if (ok) m |= 1ull << s;
+  }
+  return m;
+}
 DEV bool entryFits(KREF k, const JobTail& r, uint64_t key, int64_t ex0, int64_t ex1, uint64_t cls) {
+  if (k.maskMode) return ((cls >> r.shape) & 1) != 0;   // cls is the entry's fit mask: capacity and requirement class already folded in
   bool ok = ((cls >> r.cls) & 1) != 0;      // StaticJobRequirementsMet via the requirement class (nodematching.go:161-183)
   ok = ok && fieldsGE(k, key, r.fieldMin);  // indexed columns: alloc/res >= req/res (both resolution-aligned)
   ok = ok && r.ex0 <= ex0 && r.ex1 <= ex1;  // non-indexed columns (nodematching.go:194-197); unused extras are 0 vs 0
@@ -479,6 +499,11 @@ DEV bool pinnedNodeFits(KREF k, int q, int n, int level) {
 DEV void pqHeadKey(PQState&, int t, PackedKey* key, uint32_t* nameRank) { key->A = FL.kA[t]; key->X = FL.kX[t]; key->Y = FL.kY[t]; *nameRank = (uint32_t)FL.nameRank[t]; }
 // ---- stream run, serial build.  The engine serves an entry when its record is staged, so that entries emitted but not yet staged when a job
 // does not fit are discarded exactly as on the device (there the engine runs behind the merge by up to a ring's worth of entries).
+DEV uint64_t capMask(KREF k, uint64_t clsBits, uint64_t key, int64_t ex0, int64_t ex1) {
+  uint64_t m = 0;
+  for (int s = 0; s < k.S && s < 64; s++) { const ShapeReq q = SHT(s); if (!q.never && ((clsBits >> q.cls) & 1) && fieldsGE(k, key, q.fieldMin) && q.ex0 <= ex0 && q.ex1 <= ex1) m |= 1ull << s; }
+  return m;
+}
 struct StreamLanes { int start[QCAPF], base[QCAPF], pos[QCAPF], len[QCAPF], kind[QCAPF], ws[QCAPF]; double budget[QCAPF]; uint32_t effA[QCAPF]; uint64_t effX[QCAPF], effY[QCAPF]; };
 #define SL_SET(sl, f, q, v) ((sl).f[q] = (v))
 #define SL_GET(sl, f, q) ((sl).f[q])
@@ -564,6 +589,7 @@ DEV unsigned long long streamStageIssue(KREF k, int base, int cnt);
 DEV void streamStageCommit(Dev& d, KREF k, int base, int cnt, unsigned long long v);
 DEV void streamEnd(int engSeq);
 DEV void streamAccount(Dev& d, KREF k, int i0, int i1);   // ring entries [i0, i1): sctx / qctx sums, FL.tmpQ[queue] counts them
+DEV uint64_t capMask(KREF k, uint64_t clsBits, uint64_t key, int64_t ex0, int64_t ex1);   // mask mode: bit s = shape s fits (lane s evaluates shape s)
 DEV int streamAcked(int* fail);
 DEV int streamBound();   // entries whose ring slot is free again (the bind wave has read them)
 DEV void wgBulk(Dev& d, int kind, int n);
@@ -617,11 +643,14 @@ DEV void fastTouch(Dev& d, int n) {
   int pos = GA(int32_t, d.posOf)[n], slot = k.l0Slot[n];
   if (FLANE == 0) k.baseRemoved[pos] = 1;
   candInvalidate(k.S, n);
-  bool live = entryLive(k, key, ex0, ex1);
+  uint64_t cls = GA(uint64_t, d.nodeCls)[n];
+  bool live;
+  if (k.maskMode) { cls = capMask(k, cls, key, ex0, ex1); live = cls != 0; }
+  else live = entryLive(k, key, ex0, ex1);
   if (slot >= 0) {
-    if (live) { FL.l0Key[slot] = key; FL.l0Ex0[slot] = ex0; FL.l0Ex1[slot] = ex1; }
+    if (live) { FL.l0Key[slot] = key; FL.l0Ex0[slot] = ex0; FL.l0Ex1[slot] = ex1; if (k.maskMode) FL.l0Cls[slot] = cls; }
     else l0Remove(k, slot);
-  } else if (live && !l0Insert(k, n, key, ex0, ex1, GA(uint64_t, d.nodeCls)[n])) fastDrop(d);
+  } else if (live && !l0Insert(k, n, key, ex0, ex1, cls)) fastDrop(d);
 }
 
 // first fit at priority -2 for a job record; -1 none; handle says where the winner came from
@@ -665,15 +694,23 @@ DEV bool fastAfterBind(KREF k, FastS& S, const JobTail& r, int n, const FitHandl
     if (FLANE == 0) k.baseRemoved[c.pos] = 1;
     baseTileRemoved(k, S, c.pos);
     candInvalidate(k.S, n);
-    if (entryLive(k, key, ex0, ex1)) {
-      if (!l0Insert(k, n, key, ex0, ex1, c.cls)) return false;
+    uint64_t cls = c.cls;
+    bool live;
+    if (k.maskMode) { cls &= capMask(k, ~0ull, key, ex0, ex1); live = cls != 0; }   // a bind only takes capacity away: the shapes that still fit are among those that did
+    else live = entryLive(k, key, ex0, ex1);
+    if (live) {
+      if (!l0Insert(k, n, key, ex0, ex1, cls)) return false;
       if (FL.l0Count > S.statL0Max) S.statL0Max = FL.l0Count;
     }
   } else {
     int slot = h.slot;
     uint64_t key = FL.l0Key[slot] - r.keyDelta;
     int64_t ex0 = FL.l0Ex0[slot] - r.ex0, ex1 = FL.l0Ex1[slot] - r.ex1;
-    if (entryLive(k, key, ex0, ex1)) { FL.l0Key[slot] = key; FL.l0Ex0[slot] = ex0; FL.l0Ex1[slot] = ex1; }
+    uint64_t cls = 0;
+    bool live;
+    if (k.maskMode) { cls = UNI64(FL.l0Cls[slot]) & capMask(k, ~0ull, key, ex0, ex1); live = cls != 0; }
+    else live = entryLive(k, key, ex0, ex1);
+    if (live) { FL.l0Key[slot] = key; FL.l0Ex0[slot] = ex0; FL.l0Ex1[slot] = ex1; if (k.maskMode) FL.l0Cls[slot] = cls; }
     else l0Remove(k, slot);
   }
   return true;
@@ -725,10 +762,13 @@ DEV void fastLoad(Dev& d) {  // kernel start: rebuild the LDS side from HBM
   if (!d.f.structOk || !RS.fastActive) return;
   const FastK k = fastKRef(d);
   candResetAll(d, d.candPosSave);
+  if (k.maskMode) FOR_LANES(s, k.S) SHT(s) = d.shapeTab[s];
   int cnt = RS.l0SaveCount;
   for (int i = 0; i < cnt; i++) {
     int n = d.l0Save[i];
-    l0Insert(k, n, KKEY(k, 0, n), k.E > 0 ? KAL(k, 0, k.ex0col, n) : 0, k.E > 1 ? KAL(k, 0, k.ex1col, n) : 0, d.nodeCls[n]);
+    uint64_t key = KKEY(k, 0, n), cls = d.nodeCls[n]; int64_t ex0 = k.E > 0 ? KAL(k, 0, k.ex0col, n) : 0, ex1 = k.E > 1 ? KAL(k, 0, k.ex1col, n) : 0;
+    if (k.maskMode) cls = capMask(k, cls, key, ex0, ex1);
+    l0Insert(k, n, key, ex0, ex1, cls);
   }
 }
 DEV void fastSave(Dev& d) {  // kernel end
