@@ -412,6 +412,9 @@ __device__ static inline void fastFence(Ctl& c) {
 // last stays in registers (FastS::t*): the rescans that follow a bind start at the removed position, i.e. inside it.
 __device__ static inline void baseTileLoad(KREF k, FastS& S, int p0) {
   int lane = threadIdx.x & 63;
+#ifdef ASCHED_FASTPROF
+  if (lane == 0) g_rs.statSeg[4] += 1000;   // profiling: tile loads
+#endif
   int p = p0 + lane;
   S.tP0 = p0; S.tKey = 0; S.tCls = 0; S.tNode = -1; S.tRem = 1; S.tEx0 = 0; S.tEx1 = 0;
   if (p < k.N) {
@@ -427,6 +430,9 @@ __device__ static inline void baseTileRemoved(KREF k, FastS& S, int pos) {
 }
 __device__ static inline void baseScan(KREF k, FastS& S, const JobTail& r) {
   int lane = threadIdx.x & 63;
+#ifdef ASCHED_FASTPROF
+  if (lane == 0) g_rs.statSeg[3] += 1000;   // profiling: scans
+#endif
   int s = r.shape;
   int p0 = UNI32(g_fl.cand[s].pos);
   int N = k.N;
@@ -637,9 +643,9 @@ __device__ static inline void qsWinRefill(KREF k, int q, int pos, int cnt) {
   int lane = threadIdx.x & 63;
   if (lane < cnt * 4) ((unsigned long long*)&g_fl.evWin[q][0])[lane] = k.qsKey[((size_t)q * QS_CMAX + pos) * 4 + lane];
 }
-__device__ static inline void streamBegin(int* engSeq) {
+__device__ static inline void streamBegin(int* engSeq, int hold) {
   int lane = threadIdx.x & 63;
-  if (lane == 0) { g_fl.eng.ringPub = 0; g_fl.eng.ringAck = 0; g_fl.eng.ringEnd = 0; g_fl.eng.ringFail = 0; g_fl.eng.ringClosed = 0; g_fl.eng.bindDone = 0; g_fl.eng.cmd = ENG_STREAM; }
+  if (lane == 0) { g_fl.eng.bindHold = hold; g_fl.eng.ringPub = 0; g_fl.eng.ringAck = 0; g_fl.eng.ringEnd = 0; g_fl.eng.ringFail = 0; g_fl.eng.ringClosed = 0; g_fl.eng.bindDone = 0; g_fl.eng.cmd = ENG_STREAM; }
   (*engSeq)++;
   LDS_ORDER();
   if (lane == 0) __hip_atomic_store(&g_fl.eng.bindGen, g_fl.eng.bindGen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -672,8 +678,21 @@ __device__ static inline void streamEnd(int engSeq) {
     if (a == engSeq) break;
     __builtin_amdgcn_s_sleep(1);
   }
+  if (__builtin_amdgcn_readfirstlane(g_fl.eng.bindHold)) { LDS_ORDER(); return; }   // a gang: the verdict comes first (streamRelease)
   int gen = __builtin_amdgcn_readfirstlane(g_fl.eng.bindGen);
   for (;;) {   // ... and the bind wave has issued (and released) the binds of every entry placed
+    int f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.bindFin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if (f == gen) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  LDS_ORDER();
+}
+__device__ static inline void streamRelease(Dev& d, KREF k, int go) {
+  (void)d; (void)k;
+  int lane = threadIdx.x & 63;
+  if (lane == 0) __hip_atomic_store(&g_fl.eng.bindHold, go ? 2 : 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  int gen = __builtin_amdgcn_readfirstlane(g_fl.eng.bindGen);
+  for (;;) {
     int f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.bindFin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     if (f == gen) break;
     __builtin_amdgcn_s_sleep(1);
@@ -849,7 +868,17 @@ __device__ static void bindLoop(Dev& d) {
       __builtin_amdgcn_s_sleep(2);
     }
     int i = 0;
-    for (;;) {
+    bool discard = false;
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.bindHold, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {   // a gang: all members or none
+      int hmode;
+      for (;;) {
+        hmode = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.bindHold, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (hmode != 1) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      discard = hmode == 3;
+    }
+    for (; !discard;) {
       int ack = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringAck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
       if (i >= ack) {
         if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringClosed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {

@@ -86,6 +86,8 @@ struct EvKey { double proposed, current, size; int32_t pcPrio; int32_t job; };
 #define QS_CMAX 4096          // stream entries per queue and preparation
 #define QS_CHUNK 64           // entries one bulk item covers
 #define QS_CPQ (QS_CMAX / QS_CHUNK)
+// a queue's stream as of the last hand-over to the generic code (fastQFlush): taken up again at the next fastQLoad if the generic code left the queue alone
+struct QsSave { int32_t valid, sPos, sLen, itQi, gctx, numUnfeasible; double tokens; int64_t alloc[MAXR]; };
 struct QsIn { int32_t base, len, skipUnf, pad; int64_t a0[MAXR]; double weight; };   // per queue: position of element 0 in queuedJobs, wanted length, allocation + penalty before element 0
 
 // What a node must offer for a job of one scheduling-key shape (the per-job JobRec fields that depend on the shape only).  With at most 64 shapes the fast
@@ -254,6 +256,7 @@ struct Dev {
   int32_t evChunks;
   EvKey* qsKey;          // [QCAPF][QS_CMAX] precomputed costs of the queued-job streams
   QsIn* qsIn;            // [QCAPF]
+  QsSave* qsSave;        // [QCAPF]
   int64_t* qsPart;       // [QCAPF * QS_CPQ][MAXR + 2] chunk sums -> carries, first barrier of the chunk
   int32_t* qsLen;        // [QCAPF][2] usable stream length, 1 = the queue's list ends with the stream
   int32_t* l0Save;       // [L0CAP]

@@ -374,6 +374,7 @@ struct Ctl {
   int skipActive;
   int cancelSeen;      // a fast run saw the cancel word
   int streamNextAt, streamBackoff;   // stream runs (round_fast.h): not before this many fast iterations; doubled after a run too short to pay for its preparation
+  int streamCap;                     // stream entries prepared per queue: follows what the last run consumed (a short run must not be followed by a long preparation)
 };
 // Less (queue_scheduler.go:738-798) as a lexicographic key (A, X, Y, then the queue-name rank); exact for finite, non-negative costs
 struct PackedKey { uint32_t A; uint64_t X, Y; };
@@ -1008,6 +1009,7 @@ DEV void passInit(Dev& d, Ctl& c, const PassCfg& pc) {
     d.itEi[q] = d.evOff[q]; d.itQi[q] = d.queuedOff[q]; d.itStage[q] = 0; d.itJobsSeen[q] = 0; d.itNext[q] = -1; d.itStashed[q] = -1;
     d.itJobOnlyEv[q] = 0; d.itGangOnlyEv[q] = 0; d.onlyEvByQueue[q] = 0; d.pqInHeap[q] = 0;
     d.pqBudget[q] = d.qDc[q] / d.qWeight[q];  // pushQueue :509-519
+    if (d.qsSave && q < QCAPF) d.qsSave[q].valid = 0;   // a new pass: no stream carries over
   }
   c.onlyEvicted = 0;
   for (int q = 0; q < Q; q++) updateAndPush(d, c, q, pc);

@@ -64,6 +64,7 @@ struct alignas(16) EngineBox {
   int32_t statScan, statL0Max;               // engine counters, handed over at ENG_QUIT
   int64_t busyClk; int32_t jobs, cancel;     // shader-clock ticks the engine spent serving jobs, and how many; cancel: the engine saw the caller's cancel word
   int32_t ringPub, ringAck, ringEnd, ringFail;   // stream run: entries staged in the ring / placed by the engine; no more entries will come; 1 = entry ringAck found no node, 2 = placed but L0 overflowed
+  int32_t bindHold;   // 1: the bind wave waits for the verdict on the whole ring (a gang: all members or none), 2: go, 3: discard
   int32_t ringClosed, bindGen, bindDone, bindFin, bindQuit;   // the engine has left the ring; stream generation / entries whose bind + result fields the bind wave has issued / generation it has finished
 };
 // stream run: the job-record windows are idle and serve as the ring between the control wave and the node engine
@@ -332,7 +333,13 @@ DEV void fastQLoad(Dev& d) {
     f.rateInf = d.qRateInf[q]; f.cordoned = d.qCordoned[q]; f.itJobOnlyEv = d.itJobOnlyEv[q]; f.itGangOnlyEv = d.itGangOnlyEv[q];
     { int g = f.gctx; bool headEv = g >= 0 && d.jcEvicted[g];  // an evicted head was yielded from evList[itEi-1] and is not served yet
       f.evCheap = d.evCheap ? d.evCheap[q] : 0; f.evDone = f.evApplied = headEv ? f.itEi - 1 : f.itEi; f.headPos = headEv ? f.itEi - 1 : -1;
-      f.effValid = 0; f.skipStart = 0; f.sPos = 0; f.sLen = 0; }
+      f.effValid = 0; f.skipStart = 0; f.sPos = 0; f.sLen = 0;
+      if (d.qsSave && d.qsSave[q].valid) {   // the queue's stream from before the generic excursion still describes it: same head, same cursor, same allocation, same tokens
+        const QsSave& sv = d.qsSave[q];
+        bool same = sv.itQi == f.itQi && sv.gctx == f.gctx && sv.tokens == f.tokens && sv.numUnfeasible == d.rs->numUnfeasible && d.pqInHeap[q];
+        for (int x = 0; x < MAXR; x++) same = same && sv.alloc[x] == FL.qAlloc[q][x];
+        if (same) { f.sPos = sv.sPos; f.sLen = sv.sLen; FL.sKind[q] = 0; }
+      } }
     FL.inHeap[q] = d.pqInHeap[q]; FL.nameRank[q] = d.qNameRank[q];
   }
 }
@@ -347,6 +354,11 @@ DEV void fastQFlush(Dev& d) {
     d.itNext[q] = f.itNext; d.pqGctx[q] = f.gctx; d.pqPcPrio[q] = f.pcPrio; d.pqSchedPrio[q] = f.schedPrio;
     d.pqInHeap[q] = (uint8_t)FL.inHeap[q];
     d.itJobOnlyEv[q] = (uint8_t)f.itJobOnlyEv; d.itGangOnlyEv[q] = (uint8_t)f.itGangOnlyEv;
+    if (d.qsSave) {
+      QsSave sv; sv.valid = (f.sLen > f.sPos && !FL.sKind[q] && !f.effValid) ? 1 : 0; sv.sPos = f.sPos; sv.sLen = f.sLen; sv.itQi = f.itQi; sv.gctx = f.gctx; sv.numUnfeasible = d.rs->numUnfeasible; sv.tokens = f.tokens;
+      for (int x = 0; x < MAXR; x++) sv.alloc[x] = FL.qAlloc[q][x];
+      d.qsSave[q] = sv;
+    }
   }
 }
 DEV void fastEnsureLive(Dev& d, Ctl& c) { if (!c.fqLive) { fastQLoad(d); c.fqLive = 1; } }
@@ -512,7 +524,13 @@ struct StreamLanes { int start[QCAPF], base[QCAPF], pos[QCAPF], len[QCAPF], kind
 DEV void qsWinRefill(KREF k, int q, int pos, int cnt) { for (int i = 0; i < cnt; i++) memcpy(&FL.evWin[q][i], (const char*)k.qsKey + ((size_t)q * QS_CMAX + pos + i) * sizeof(EvKey), sizeof(EvKey)); }
 DEV int engineServe(Dev& d, KREF k, FastS& ES);
 static FastS g_engS;
-DEV void streamBegin(int* engSeq) { FL.eng.ringPub = FL.eng.ringAck = FL.eng.ringEnd = FL.eng.ringFail = 0; FL.eng.cmd = ENG_STREAM; (*engSeq)++; }
+DEV void streamBegin(int* engSeq, int hold = 0) { FL.eng.ringPub = FL.eng.ringAck = FL.eng.ringEnd = FL.eng.ringFail = 0; FL.eng.bindHold = hold; FL.eng.cmd = ENG_STREAM; (*engSeq)++; }
+DEV void bindJob(KREF k, FastS& ES, int n, int nl, uint64_t keyDelta, const int64_t* req, int job, int32_t prio, int32_t cutoff);
+DEV void streamRelease(Dev& d, KREF k, int go) {
+  (void)d;
+  if (go) for (int i = 0; i < FL.eng.ringAck; i++) { const JobRec& r = RREC(i); bindJob(k, g_engS, r.node0, r.nlPc, r.keyDelta, r.req, RJOB(i), r.pcPrio, r.preemptible ? r.pcPrio : NONPREEMPTIBLE_CUTOFF); }
+  FL.eng.bindHold = 0;
+}
 static JobRec g_hsStage[4];
 DEV unsigned long long streamStageIssue(KREF k, int base, int cnt) { for (int i = 0; i < cnt; i++) if (!(RQ(base + i) & RQ_EV)) memcpy(&g_hsStage[i], (const char*)k.jrec + (size_t)RJOB(base + i) * sizeof(JobRec), sizeof(JobRec)); return 0; }
 DEV int engineServeRing(Dev& d, KREF k, FastS& ES, int i);
@@ -584,7 +602,8 @@ __device__ static inline unsigned long long slGet64(unsigned long long v, int q)
 #define SL_GET64(sl, f, q) slGet64((sl).f, (q))
 #define SL_GETD(sl, f, q) __builtin_bit_cast(double, slGet64(__builtin_bit_cast(unsigned long long, (sl).f), (q)))
 DEV void qsWinRefill(KREF k, int q, int pos, int cnt);
-DEV void streamBegin(int* engSeq);
+DEV void streamBegin(int* engSeq, int hold = 0);
+DEV void streamRelease(Dev& d, KREF k, int go);   // gang: the held binds of every placed member are issued (go) or dropped
 DEV unsigned long long streamStageIssue(KREF k, int base, int cnt);
 DEV void streamStageCommit(Dev& d, KREF k, int base, int cnt, unsigned long long v);
 DEV void streamEnd(int engSeq);
@@ -915,6 +934,9 @@ DEV int engineServeAt(Dev& d, KREF k, FastS& ES, const JobTail& tailSrc, const i
 #if !defined(ASCHED_HOSTSIM)
   if (ringIdx >= 0) { if (FLANE == 0) RREC(ringIdx).node0 = n; }   // stream run: the bind wave issues the HBM side (bindJob) from the ring entry
   else
+#else
+  if (ringIdx >= 0 && FL.eng.bindHold) RREC(ringIdx).node0 = n;     // (serial build: binds at once unless they are held for a gang's verdict)
+  else
 #endif
   bindJob(k, ES, n, nl, r.keyDelta, reqSrc, job, prio, cutoff);
   ESEG(4);
@@ -1237,6 +1259,7 @@ DEV_NOINLINE SkipDelta fastExitSkip(Dev& d, FastCtx fc, int Q, int top, PackedKe
     applyEvictedRange(d, q, lo, b1, -1);
     S.numEvictedJobs += b1 - lo;
     if (f.gctx >= 0) { f.itQi -= 1; f.itJobsSeen -= 1; }  // the queued head goes back into its stream
+    if (f.sLen) { f.sLen = 0; f.sPos = 0; if (FLANE == 0) { FL.hot[q].sLen = 0; FL.hot[q].sPos = 0; } }   // its precomputed stream started at that head
     f.itStage = 0; f.itEi = lo; f.evApplied = f.evDone = lo;
     KeyOut ko;
     fastAdvance(d, k, S, fc, q, f, &ko);  // head = evicted entry `lo` (cheap path)
@@ -1298,11 +1321,11 @@ DEV_NOINLINE SkipDelta fastDrain(Dev& d, int Q) {
 // Exactness: the merge is the heap of QueueCandidateGangIteratorPQ on the very keys fastAdvance would compute (same float64 operations on the same
 // prefix sums, round_run.h B_QSKEYS), the engine executes the entries in emission order, and integer accounting is order independent.
 struct StreamIn { double globalTokens; int64_t globalBurst; int32_t globalRateInf, engSeq; };
-struct StreamOut { int executed, executedEv, pend, dropped, engSeq, emitted, refills, evicted; uint32_t lastA, lastN; uint64_t lastX, lastY; };
+struct StreamOut { int executed, executedEv, pend, dropped, engSeq, emitted, refills, evicted, maxConsumed; uint32_t lastA, lastN; uint64_t lastX, lastY; };
 // streams persist between runs: head of queue q == element sPos of its stream, elements [sPos, sLen) are still to come.  A queue's stream is dropped
 // when anything but a stream run serves the queue (fastIter) or the generic code runs (fastQLoad).  prepare: 0 = the top queue has no stream,
 // 1 = ready, 2 = some queue needs the bulk passes and allowBulk was 0 (the node engine must be stopped first: they use every wave of the workgroup)
-DEV_NOINLINE int fastStreamPrepare(Dev& d, FastCtx fc, int Q, int allowed, int allowBulk, int top);   // round_run.h
+DEV_NOINLINE int fastStreamPrepare(Dev& d, FastCtx fc, int Q, int allowed, int allowBulk, int top, int capHint);   // round_run.h
 DEV EvKey streamKey(KREF k, StreamLanes& sl, int q, int pos, int sLen, int kind, int base) {
   int ws = SL_GET(sl, ws, q);
   if (!(pos >= ws && pos < ws + WIN)) {
@@ -1415,7 +1438,7 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
     if (FLANE == 0) { FL.hot[q].sPos = more ? pos : 0; FL.hot[q].sLen = more ? f.sLen : 0; FL.hot[q].ewCount = 0; FL.hot[q].ewStart = 0; }
     f.sPos = more ? pos : 0; f.sLen = more ? f.sLen : 0; f.ewCount = 0; f.ewStart = 0; f.winKind = -1; f.winCount = 0;
     if (moved == 0) continue;                     // never reached the top of the heap: nothing of the queue changed
-    if (kind) doneEv += cq; else doneQ += cq;
+    if (kind) doneEv += cq; else { doneQ += cq; if (cq > out.maxConsumed) out.maxConsumed = cq; }
     if (f.effValid) {                             // the running maximum restarts from the queue's last folded evicted entry (fastEnterSkip); any clamp between it and
       EvKey e; memcpy(&e, (const char*)k.evKey + (size_t)(f.evEnd - 1) * sizeof(EvKey), sizeof(EvKey));   // the true running maximum gives the same order
       PackedKey last = packKey3(fc.preferLarge, UNI32(e.pcPrio), UNID(e.proposed), UNID(e.current), UNID(e.size), f.budget);
@@ -1445,6 +1468,70 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
   return out;
 }
 
+// ---- a gang through the ring.  GangScheduler.Schedule for the common gang (gang_scheduler.go:46-148, 229-262): every member a queued job, no
+// uniformity label, every member fits without preemption.  The members go through the ring like a stream run's entries — the node engine places them one
+// after the other (first fit at priority -2, L0 upkeep) — but the bind wave HOLDS the HBM side until the engine has placed them all: ScheduleManyWithTxn
+// is all or nothing.  All placed: the binds and result fields are issued, the members are accounted like cnt new jobs and ONE scheduled gang, the rate
+// limiters give up cnt tokens (ReserveN), the queue's next head is produced.  A member without a node: nothing has reached HBM but "this base entry is
+// stale" flags; the nodes the placed members went to are re-read into the level-0 structure (fastTouch) and the generic code runs the gang from the state
+// it would have found (it decides about preemption, the failure reason, the unfeasible-key registration).
+struct GangOut { int handled, cnt, pend, dropped, engSeq, refills, evicted; };
+DEV_NOINLINE GangOut fastGangRun(Dev& d, FastCtx fc, StreamIn in, int t) {
+  const FastK k = fastKRef(d);
+  FastS S; coldS(d, S);
+  GangOut out; memset(&out, 0, sizeof out); out.pend = -1; out.engSeq = in.engSeq;
+#ifdef ASCHED_HOSTSIM
+  if (getenv("HS_NO_GANG_RING")) return out;
+#endif
+  QHot f = FL.hot[t];
+  uniQHot(f);
+  int ref = f.gctx;
+  if (ref >= -1 || k.hasPcLimit || k.anyRoundLimit || k.anyDisallowed || k.disableHome || !fc.stream) return out;
+  int g = -ref - 2;
+  int cnt = UNI32(d.gangSeen[g]), off = UNI32(d.gangOff[g]);
+  if (cnt < 2 || cnt > RING_N - 16) return out;
+  // CheckJobConstraints for the gang (constraints.go:121-157): anything that fails is the generic code's to report
+  if (f.cordoned || in.globalTokens < (double)cnt || in.globalBurst < cnt || f.tokens < (double)cnt || f.burst < cnt) return out;
+  if (UNI32((int)d.gangAllEvicted[g])) return out;
+  // members: queued jobs untouched in this round (fastGangMember's conditions), no uniformity label
+  int bad = 0;
+  FOR_LANES(m, cnt) {
+    int j = d.gangArr[off + m];
+    if (d.jcEvicted[j] || d.jcPreempted[j] || d.jcAssigned[j] >= 0 || d.jcUniValue[j] >= 0 || d.schedAtPrio[j] != NO_PRIORITY || d.jobNode[j] >= 0 || d.jGangUni[j] != -1) bad = 1;
+    RJOB(m) = j; RQ(m) = t;
+  }
+  FOR_LANES(x, 64) FL.tmpQ[x] = bad; 
+  { int any = 0; for (int x = 0; x < 64; x++) any |= UNI32(FL.tmpQ[x]); if (any || RS.awayRowPlus1) return out; }
+  FOR_LANES(q, QCAPF) FL.tmpQ[q] = 0;
+  // the ring overwrites the prefetch windows of the first queues: they refill on demand
+  FOR_LANES(q, QCAPF) if (q * WIN < cnt + 4) { FL.hot[q].winKind = -1; FL.hot[q].winCount = 0; }
+  if (f.sLen) { if (FLANE == 0) { FL.hot[t].sLen = 0; FL.hot[t].sPos = 0; } f.sLen = 0; f.sPos = 0; }
+  int engSeq = in.engSeq;
+  streamBegin(&engSeq, 1);
+  for (int b = 0; b < cnt; b += 4) {
+    int n4 = cnt - b < 4 ? cnt - b : 4;
+    unsigned long long v = streamStageIssue(k, b, n4);
+    streamStageCommit(d, k, b, n4, v);
+  }
+  streamEnd(engSeq);
+  int fail = 0;
+  int placed = streamAcked(&fail);
+  out.engSeq = engSeq;
+  if (fail == 2) out.dropped = 1;
+  if (placed < cnt || fail) {
+    streamRelease(d, k, 0);
+    for (int i = 0; i < placed; i++) fastTouch(d, UNI32(RREC(i).node0));   // authoritative planes untouched: the node's level-0 entry as it was
+    return out;
+  }
+  streamRelease(d, k, 1);
+  streamAccount(d, k, 0, cnt);
+  if (!f.rateInf && cnt <= f.burst) f.tokens -= (double)cnt;   // rate.Limiter.ReserveN(cnt) (gang_scheduler.go:118-123)
+  KeyOut ko;
+  if (!fastAdvance(d, k, S, fc, t, f, &ko)) out.pend = t;
+  out.handled = 1; out.cnt = cnt; out.refills = S.statRefills; out.evicted = S.numEvictedJobs;
+  return out;
+}
+
 // Run fast iterations of the QueueScheduler loop (mode 0) or of the eviction-order replay (mode 1) until one needs the
 // generic code.  Returns the queue whose next head the generic updateAndPush must produce, or -1.  Leaves fast mode live.
 DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* counter) {
@@ -1470,7 +1557,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   int cnt = counter ? UNI32(*counter) : 0, pend = -1, lastTop = -1;
   fc.stream = fc.engine && d.qsKey != nullptr && !k.hasPcLimit && !k.anyRoundLimit && !k.disableHome && fc.withQueued;
   fc.stream = UNI32(fc.stream);
-  int streamNextAt = UNI32(c.streamNextAt), streamBackoff = UNI32(c.streamBackoff);
+  int streamNextAt = UNI32(c.streamNextAt), streamBackoff = UNI32(c.streamBackoff), streamCap = UNI32(c.streamCap);
   PackedKey refK; refK.A = ~0u; refK.X = refK.Y = ~0ull; uint32_t refN = ~0u;
   if (!mode && c.onlyEvicted && RS.terminationReason != 0 && S.lvl0NonNeg && S.numPreemptedMarks == 0 && fc.evStatic && fc.withQueued) { SkipDelta dl = fastDrain(d, Q); S.numEvictedJobs += dl.evicted; S.loopIterations += dl.iters; }
   if (c.skipEnter && !mode && S.lvl0NonNeg && S.numPreemptedMarks == 0 && fc.evStatic) { SkipDelta dl = fastEnterSkip(d, fc, Q); S.numEvictedJobs += dl.evicted; S.loopIterations += dl.iters; S.statRefills += dl.refills; c.skipActive = 1; }
@@ -1514,20 +1601,35 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
     lastTop = t;
     if (t >= 0) pqHeadKey(pq, t, &refK, &refN);  // lane 0 of the heap lanes
     if (t < 0) break;
-    if (UNI32(FL.hot[t].gctx) < 0) break;  // a gang: generic
+    if (UNI32(FL.hot[t].gctx) < 0) {  // a gang: through the ring when every member is an untouched queued job (fastGangRun), else generic
+      if (mode || !fc.stream || !S.fastActive || UNI32(FL.hot[t].gctx) == -1) break;
+      if (!S.engLive) { engineStart(d, S); S.engLive = 1; }
+      StreamIn in; in.globalTokens = S.globalTokens; in.globalBurst = S.globalBurst; in.globalRateInf = S.globalRateInf; in.engSeq = S.engSeq;
+      GangOut go = fastGangRun(d, fc, in, t);
+      S.engSeq = go.engSeq;
+      if (go.dropped) { S.fastActive = 0; fastDrop(d); }
+      S.tP0 = -1;
+      if (!go.handled) break;
+      S.numScheduledJobs += go.cnt; S.numScheduledGangs += 1; S.numNodeQueries += go.cnt; S.loopIterations++; S.statFastIters++;
+      if (!S.globalRateInf && go.cnt <= S.globalBurst) S.globalTokens -= (double)go.cnt;
+      S.statRefills += go.refills; S.numEvictedJobs += go.evicted;
+      pqBuild(pq, Q);
+      if (go.pend >= 0) { pend = go.pend; break; }
+      continue;
+    }
     if (fc.stream && S.fastActive && S.statFastIters >= streamNextAt) {
       // stream run: the queues' next costs come precomputed (bulk passes where a queue has none left), this wave merges + stages, the node engine binds
       int want = INT32_MAX;
       if (!S.globalRateInf) want = S.globalTokens >= 2147483000.0 ? INT32_MAX : (S.globalTokens < 1 ? 0 : (int)S.globalTokens);
-      int code = fastStreamPrepare(d, fc, Q, want, !S.engLive, t);
-      if (code == 2) { engineStop(d, S); S.engLive = 0; code = fastStreamPrepare(d, fc, Q, want, 1, t); }   // the bulk passes need every wave of the workgroup at the mailbox
-      int E = 0;
+      int code = fastStreamPrepare(d, fc, Q, want, !S.engLive, t, streamCap);
+      if (code == 2) { engineStop(d, S); S.engLive = 0; code = fastStreamPrepare(d, fc, Q, want, 1, t, streamCap); }   // the bulk passes need every wave of the workgroup at the mailbox
+      int E = 0, so_max = 0;
       if (code == 1) {
         if (!S.engLive) { engineStart(d, S); S.engLive = 1; }
         StreamIn in; in.globalTokens = S.globalTokens; in.globalBurst = S.globalBurst; in.globalRateInf = S.globalRateInf; in.engSeq = S.engSeq;
         StreamOut so = fastStreamRun(d, fc, Q, in);
         S.engSeq = so.engSeq;
-        E = so.executed;
+        E = so.executed; so_max = so.maxConsumed;
         S.numScheduledJobs += E; S.numScheduledGangs += E; S.numNodeQueries += E;
         if (!S.globalRateInf && 1 <= S.globalBurst) S.globalTokens -= (double)E;
         E += so.executedEv;
@@ -1539,8 +1641,9 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
         pqBuild(pq, Q);
         if (so.pend >= 0) { pend = so.pend; lastTop = so.pend; refK.A = so.lastA; refK.X = so.lastX; refK.Y = so.lastY; refN = so.lastN; }
       }
-      if (E >= 256) streamBackoff = 0;   // an attempt that finds every stream in place costs little (no bulk pass): back off gently
-      else streamBackoff = streamBackoff ? (streamBackoff < 2048 ? streamBackoff * 2 : streamBackoff) : 32;
+      (void)so_max;   // (entries prepared per queue stay at QS_CMAX: the sum pass stops at a queue's first gang member, so gang-heavy queues prepare little anyway)
+      if (E >= 256) streamBackoff = 0;   // an attempt that finds every stream in place costs little (no bulk pass): back off gently, but for good when runs stay short
+      else streamBackoff = streamBackoff ? (streamBackoff < (1 << 18) ? streamBackoff * 2 : streamBackoff) : 32;
       streamNextAt = S.statFastIters + streamBackoff;
 #ifdef ASCHED_HOSTSIM
       if (getenv("HS_STREAM_EAGER")) { streamBackoff = 0; streamNextAt = S.statFastIters + (E == 0 ? 1 : 0); }   // tests: a stream run wherever one can start
@@ -1567,7 +1670,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
     S.numEvictedJobs += dl.evicted; S.loopIterations += dl.iters; S.statRefills += dl.refills;
     c.skipActive = 0;
   }
-  c.streamNextAt = streamNextAt; c.streamBackoff = streamBackoff;
+  c.streamNextAt = streamNextAt; c.streamBackoff = streamBackoff; c.streamCap = streamCap;
   if (counter) *counter = cnt;
   RS.globalTokens = S.globalTokens;
   RS.numScheduledJobs = S.numScheduledJobs; RS.numScheduledGangs = S.numScheduledGangs; RS.numEvictedJobs = S.numEvictedJobs;

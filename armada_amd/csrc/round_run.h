@@ -539,13 +539,14 @@ DEV_COLD void runRound(Dev& d, Ctl& c) {
 //   * a queued stream: its head is a single queued job peeked from the queue's list and the queue may still schedule new jobs — how far the stream may
 //     reach (the list, QS_CMAX, the queue's rate-limit tokens, the lookback limit, the global tokens), then the three bulk passes over the queues
 //     that need one (they read only what is written to d.qsIn, and run on every wave of the workgroup: the node engine must not be live).
-DEV_NOINLINE int fastStreamPrepare(Dev& d, FastCtx fc, int Q, int allowed, int allowBulk, int top) {
+DEV_NOINLINE int fastStreamPrepare(Dev& d, FastCtx fc, int Q, int allowed, int allowBulk, int top, int capHint) {
 #ifdef ASCHED_HOSTSIM
   if (getenv("HS_NO_STREAM")) return 0;
 #endif
   const FastK k = fastKRef(d);
   int skipUnf = fc.skipKnown && RS.numUnfeasible > 0;
   int cap = allowed < QS_CMAX ? allowed : QS_CMAX;
+  if (cap > capHint) cap = capHint;
   bool evOk = fc.evStatic && RS.lvl0NonNeg && RS.numPreemptedMarks == 0;
 #ifdef ASCHED_HOSTSIM
   if (getenv("HS_NO_EV_STREAM")) evOk = false;
@@ -840,7 +841,7 @@ DEV void controlMainAux(Dev& d, int cmd) {
   Ctl c;
   c.txn.active = d.rs->txnActive; c.fairStamp = d.rs->fairStamp; c.preList = d.preList; c.preCount = 0;
   c.skipKeyCheck = 0; c.compareSchedPrio = 0; c.preferLarge = d.cfg.preferLarge; c.useReplayAlloc = 0; c.onlyEvicted = 0;
-  c.fastEnabled = 0; c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0; c.cancelSeen = 0; c.streamNextAt = 0; c.streamBackoff = 0;
+  c.fastEnabled = 0; c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0; c.cancelSeen = 0; c.streamNextAt = 0; c.streamBackoff = 0; c.streamCap = QS_CMAX;
   fastLoad(d);
   runAuxCommand(d, c, cmd);
   fastEnterGeneric(d, c);
@@ -852,7 +853,7 @@ DEV void controlMain(Dev& d, int cmd) {
   c.txn.active = d.rs->txnActive; c.fairStamp = d.rs->fairStamp; c.preList = d.preList; c.preCount = 0;
   c.skipKeyCheck = 0; c.compareSchedPrio = 0; c.preferLarge = d.cfg.preferLarge; c.useReplayAlloc = 0; c.onlyEvicted = 0;
   c.fastEnabled = d.f.iterOk && !d.rs->apiDirty && (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY || cmd == CMD_PASS1 || cmd == CMD_PASS2);
-  c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0; c.cancelSeen = 0; c.streamNextAt = 0; c.streamBackoff = 0;
+  c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0; c.cancelSeen = 0; c.streamNextAt = 0; c.streamBackoff = 0; c.streamCap = QS_CMAX;
   fastLoad(d);
   runCommand(d, c, cmd);
   fastEnterGeneric(d, c);
