@@ -138,7 +138,8 @@ struct RoundScalars {
   int32_t awayRowPlus1;      // an away attempt is in progress: static mask row (+1) that replaces the job's home shape row
   int32_t fairIndexValid;    // the per-node index of the evicted table (fairOff/fairEnt) describes the current table
   int64_t totalNewJobNs;     // sctx.TotalNewJobSchedulingTime (context/scheduling.go:212-240)
-  int64_t statSeg[24];       // (profiling builds) shader-clock ticks per segment of a fast iteration
+  int64_t statSeg[40];       // [24..39]: (profiling builds) segments of the generic iteration
+  int64_t gsT;                     // (profiling builds) shader-clock ticks per segment of a fast iteration
   int64_t statClk[8];        // shader-clock ticks per phase of the round (device builds): evict, replay, pass 1, oversub evict, pass 2, unbind+results
 };
 

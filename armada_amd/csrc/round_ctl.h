@@ -76,6 +76,13 @@ DEV_COLD void ensureReplay(Dev& d, Ctl& c);             // run the deferred evic
 #define KEY(d, l, n) ((d).keys[(size_t)(l) * (d).cfg.Npad + (n)])
 #define JREQ(d, j) ((d).jReq + (size_t)(j) * (d).cfg.R)
 
+#if defined(ASCHED_FASTPROF) && defined(__HIP_DEVICE_COMPILE__)
+#define XSEG_BEGIN() (d.rs->gsT = CLK())
+#define XSEG(i) do { long long n_ = CLK(); if ((threadIdx.x & 63) == 0) { d.rs->statSeg[i] += n_ - d.rs->gsT; d.rs->gsT = n_; } } while (0)
+#else
+#define XSEG_BEGIN() do {} while (0)
+#define XSEG(i) do {} while (0)
+#endif
 DEV void raise(Dev& d, int code, int detail) {
   if (d.rs->error == 0) { d.rs->error = code; d.rs->errorDetail = detail; }
 }
@@ -595,7 +602,9 @@ DEV_COLD int selectWithFairPreemption(Dev& d, Ctl& c, int job) {
 // fits at, its key at that level), and the gate is "is there any such node".  ONE multi-level pass (ScanArgs.levelHi) answers both; the
 // fair-share attempt in between changes nothing when it fails.  Query counts are kept as the level-by-level loop would have issued them.
 DEV_COLD int selectAtPriority(Dev& d, Ctl& c, int job) {
+  XSEG(31);
   int n = selectAtLevel(d, job, ASCHED_EVICTED_PRIORITY);
+  XSEG(32);
   if (n >= 0) { d.pcMethod[job] = ASCHED_METHOD_NO_PREEMPTION; return n; }
   int row = d.rs->awayRowPlus1 ? d.rs->awayRowPlus1 - 1 : d.jShape[job];
   int lp = levelOf(d.cfg, d.pcSap[job]);
@@ -610,10 +619,12 @@ DEV_COLD int selectAtPriority(Dev& d, Ctl& c, int job) {
     uint64_t best = wgFirstFitKey(d, a);
     d.rs->statClk[6] += CLK() - t0;
     d.rs->numNodeQueries++;                          // the gate
+    XSEG(33);
     if (best == ~0ull) return -1;
     d.pcNode[job] = -1; d.pcPap[job] = ASCHED_MIN_PRIORITY;
     if (!d.cfg.disableFair) {
       n = selectWithFairPreemption(d, c, job);
+      XSEG(34);
       if (n >= 0) { d.pcMethod[job] = ASCHED_METHOD_FAIRSHARE; return n; }
     }
     d.pcNode[job] = -1; d.pcPap[job] = ASCHED_MIN_PRIORITY;
@@ -717,13 +728,17 @@ DEV_COLD bool scheduleMany(Dev& d, Ctl& c, int ref) {
     if (cnt > 1 && fastGangMember(d, c, job)) continue;
     fastFence(c);
     int pre0 = c.preCount;
+    XSEG(30);
     int n = selectNodeForJob(d, c, job);
+    XSEG(25);
     if (d.rs->error) return false;
     if (n < 0) return false;   // (fenced above: the abort's undo reads what the fast members wrote)
     int pre1 = c.preCount;
     for (int i = pre0; i < pre1; i++) removeJob(d, n, c.preList[i], true);  // victims leave the returned node copy (nodedb.go:1012-1023)
+    XSEG(26);
     int32_t prio = d.pcSap[job];
     if (addJob(d, n, job, cutoffFor(d, job, prio), true)) return false;     // BindJobToNode :1046-1068
+    XSEG(27);
     d.schedAtPrio[job] = prio;                                              // not rolled back on abort (plain Go map)
     if (d.pcMethod[job] != ASCHED_METHOD_NO_PREEMPTION && d.pcMethod[job] != ASCHED_METHOD_RESCHEDULED) d.rs->lvl0NonNeg = 0;  // preemption may overdraw priority -2
     updateKeysCtl(d, n);
@@ -731,6 +746,7 @@ DEV_COLD bool scheduleMany(Dev& d, Ctl& c, int ref) {
     if (eidx >= 0) evTabDelete(d, eidx, true);
     preemptSiblings(d, c, pre0, pre1);
     for (int i = pre0; i < c.preCount; i++) d.jcStagedBy[c.preList[i]] = job;
+    XSEG(28);
   }
   fastFence(c);  // the fast members' binds are no-return atomics: visible to whatever reads the planes next (commit bookkeeping, abort's undo)
   return true;
@@ -815,13 +831,16 @@ DEV_COLD bool gangSchedule(Dev& d, Ctl& c, int ref, int* reason, const int32_t* 
     int r = checkRound(d);  // returns BEFORE the deferred bookkeeping is registered (:102-106)
     if (r) { *reason = r; return false; }
   }
+  XSEG_BEGIN();
   sctxAddGang(d, ref);
   bool ok = false;
   int r = 0;
   if (!allEv) r = checkJob(d, ref);
   if (!r) r = checkFloating(d, ref);  // gang_scheduler.go:143: for evicted gangs too
+  XSEG(24);
   if (r) *reason = r;
   else ok = trySchedule(d, c, ref, reason, uniOff);
+  XSEG(29);
   if (d.rs->error) return false;
   int cnt = gcCount(d, ref), q = gcQueue(d, ref);
   if (ok && !allEv) {  // :118-123
@@ -1016,6 +1035,13 @@ DEV void passInit(Dev& d, Ctl& c, const PassCfg& pc) {
 }
 
 // QueueScheduler.Schedule (queue_scheduler.go:94-304)
+#if defined(ASCHED_FASTPROF) && defined(__HIP_DEVICE_COMPILE__)
+#define GSEG_BEGIN() long long gsT_ = CLK()
+#define GSEG(i) do { long long n_ = CLK(); if ((threadIdx.x & 63) == 0) d.rs->statSeg[i] += n_ - gsT_; gsT_ = n_; } while (0)
+#else
+#define GSEG_BEGIN() do {} while (0)
+#define GSEG(i) do {} while (0)
+#endif
 DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff) {
   bool limitHit = false, resumed = false;
   const bool softClock = d.cfg.maxNewJobNs > 0 || d.cfg.maxNewJobPerQueueNs > 0;
@@ -1028,11 +1054,24 @@ DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff)
     // A fast run that ends without a single fast iteration (the head is a gang, a job that needs preemption, ...) costs a hand-over in and
     // out of the fast loop for nothing: after such a run the next ones are skipped, doubling up to 32 generic iterations, until one makes
     // progress again.  Skipping is always exact — the generic code handles every iteration.
-    if (fastOn(d, c) && fastSkip > 0) fastSkip--;
+    GSEG_BEGIN();
+    // Entering and leaving the fast loop moves every queue's state between HBM and LDS.  When the generic state is the live one and the queue at the top
+    // holds a single queued job that does not fit at priority -2 (asked of the level-0 structure, which the generic cascade would ask first anyway), the
+    // fast loop could only hand the iteration straight back: go generic directly.
+    bool headNeedsGeneric = false;
+    if (fastOn(d, c) && !c.fqLive && fastSkip == 0 && d.rs->fastActive) {
+      int t0 = pqTop(d, c);
+      int r0 = t0 >= 0 ? d.pqGctx[t0] : -1;
+      if (r0 >= 0 && !d.jcEvicted[r0] && d.jcAssigned[r0] < 0 && fastSelectLevel0(d, r0) == -1) headNeedsGeneric = true;
+    }
+    if (headNeedsGeneric) {}
+    else if (fastOn(d, c) && fastSkip > 0) fastSkip--;
     else if (fastOn(d, c)) {
       int before = d.rs->statFastIters + d.rs->loopIterations;
       int pend = fastRun(d, c, pc, 0, (int*)0);
+      GSEG(11);
       fastEnterGeneric(d, c);
+      GSEG(12);
       if (c.cancelSeen) { raise(d, ASCHED_ERR_TIMEOUT, 901); return; }
       if (d.rs->statFastIters + d.rs->loopIterations == before && pend < 0) { if (fastStreak < 5) fastStreak++; fastSkip = (1 << fastStreak) - 1; }
       else fastStreak = 0;
@@ -1054,9 +1093,12 @@ DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff)
     int reason;
     bool gangAllEv = gcAllEvicted(d, ref); int gangQueue = gcQueue(d, ref);
     int64_t tStart = (softClock && d.cfg.clockStepNs <= 0) ? clockNowNs(d) : 0;   // start := sch.clock.Now() (:157)
+    GSEG(13);
     bool ok = gangSchedule(d, c, ref, &reason, uniOff);
+    GSEG(14);
     if (d.rs->error) return;
     costItClear(d, c, top, pc);
+    GSEG(15);
     if (ok) {
       // scheduled jobs are recorded per job (pcNode >= 0); the PQS bookkeeping below reads them
       for (int k = 0; k < cnt; k++) {

@@ -1,0 +1,17 @@
+"""profiling helper: one preemption-heavy round (BASELINE configs[4] shape at 20k x 200k) on the library named by ASCHED_LIB_PATH; with ASCHED_PRINT_SEG=1 and the
+profiling build (tools/build_prof.sh) the segment clocks of the generic iteration are printed by round_stats()"""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import armada_amd
+from armada_amd import workloads as W
+kw = dict(n_nodes=20_000, n_jobs=200_000, n_queues=32, occupied=0.95)
+if len(sys.argv) > 1 and sys.argv[1] == "gangs": kw = dict(n_nodes=20_000, n_jobs=200_000, n_queues=32, gangs=2_000)
+wl = W.config3(seed=W.SEED, **kw)
+wl.global_burst, wl.queue_burst = 40_000, 4_000
+lib = armada_amd.load_library()
+s = W.load(lib, wl)
+for i in range(2):
+    W.prepare(s, wl)
+    t = time.perf_counter(); r = s.schedule_round(); dt = time.perf_counter() - t
+    st = s.round_stats()
+    print("round", i, round(dt * 1e3, 1), "ms", {k: st[k] for k in ("fast_iterations", "generic_iterations", "kclk_pass1", "kclk_pass2", "kclk_plane_scans", "kclk_fair_selects", "stream_jobs")}, len(r.scheduled), len(r.preempted), flush=True)
