@@ -146,7 +146,7 @@ class COptNodeScore(C.Structure):
 
 class CPqItem(C.Structure):
     _fields_ = [("proposed_cost", C.c_double), ("current_cost", C.c_double), ("budget", C.c_double), ("item_size", C.c_double),
-                ("pc_priority", C.c_int32), ("scheduling_priority", C.c_int32), ("name_rank", C.c_int32), ("pad_", C.c_int32)]
+                ("pc_priority", C.c_int32), ("scheduling_priority", C.c_int32), ("name_rank", C.c_int32), ("away", C.c_int32)]
 
 
 class CSubmitResult(C.Structure):
@@ -551,7 +551,7 @@ class Scheduler:
 
     def clear_allocated(self): self._check(self.lib.clear_allocated(self.h))
 
-    def pq_order(self, items: Sequence[dict], prioritise_larger_jobs: bool, compare_scheduling_priority: bool):
+    def pq_order(self, items: Sequence[dict], prioritise_larger_jobs: bool, compare_scheduling_priority: bool, preempt_cross_pool_jobs_first: bool = False):
         """sort.Sort over QueueCandidateGangIteratorPQ.Less; items: dicts with proposed_cost, current_cost, budget, item_size, pc_priority,
         scheduling_priority, name_rank -> (order, packed_key_agrees)"""
         n = len(items)
@@ -559,11 +559,11 @@ class Scheduler:
         for i, it in enumerate(items):
             for k in ("proposed_cost", "current_cost", "budget", "item_size"):
                 setattr(arr[i], k, float(it.get(k, 0.0)))
-            for k in ("pc_priority", "scheduling_priority", "name_rank"):
+            for k in ("pc_priority", "scheduling_priority", "name_rank", "away"):
                 setattr(arr[i], k, int(it.get(k, 0)))
         order = (C.c_int32 * max(n, 1))()
         agrees = C.c_int32(0)
-        self._check(self.lib.pq_order(self.h, n, arr, int(prioritise_larger_jobs), int(compare_scheduling_priority), order, C.byref(agrees)))
+        self._check(self.lib.pq_order(self.h, n, arr, int(prioritise_larger_jobs), int(bool(compare_scheduling_priority)) | (2 if preempt_cross_pool_jobs_first else 0), order, C.byref(agrees)))
         return [order[i] for i in range(n)], bool(agrees.value)
 
     def submit_check(self, units: Sequence[Sequence[int]], strip_gang: Optional[Sequence[bool]] = None):

@@ -763,7 +763,7 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
 // Commands of the submit check.  They run in their own kernel, in their own code object (k_control_aux,
 // armada_sched_aux.hip), so that the round kernel's code — everything above is inlined into it — stays exactly what was measured.
 struct SubmitArgs { int32_t nu, pad; int32_t* off; int32_t* jobs; int32_t* flags; int32_t* out; };  // at cmdIO + 16, written by the host
-struct PqOrderArgs { int32_t n, preferLarge, compareSchedPrio, pad; int32_t* out; };  // at cmdIO + 16; out = [n] order, then 1 flag
+struct PqOrderArgs { int32_t n, preferLarge, compareSchedPrio, homeFirst; int32_t* out; const int32_t* away; };  // at cmdIO + 16; out = [n] order, then 1 flag
 DEV void runAuxCommand(Dev& d, Ctl& c, int cmd) {
   const DevCfg& cf = d.cfg;
   switch (cmd) {
@@ -777,13 +777,13 @@ DEV void runAuxCommand(Dev& d, Ctl& c, int cmd) {
       for (int i = 0; i < a.n; i++) ord[i] = i;
       for (int i = 1; i < a.n; i++) {   // insertion sort: Less is a strict total order, the result is the unique sorted order
         int x = ord[i], k = i - 1;
-        while (k >= 0 && pqLess(d, c, x, ord[k])) { ord[k + 1] = ord[k]; k--; }
+        while (k >= 0 && ((a.homeFirst && a.away[x] != a.away[ord[k]]) ? !a.away[x] : pqLess(d, c, x, ord[k]))) { ord[k + 1] = ord[k]; k--; }   // :744-746: home before away
         ord[k + 1] = x;
       }
       for (int i = 0; i < a.n; i++) a.out[i] = ord[i];
       int agrees = 1;
       for (int x = 0; x < a.n; x++) for (int y = 0; y < a.n; y++) {
-        if (x == y) continue;
+        if (x == y || (a.homeFirst && a.away[x] != a.away[y])) continue;   // (the packed key orders within a group)
         PackedKey kx = packKey3(a.preferLarge, a.compareSchedPrio ? d.pqSchedPrio[x] : d.pqPcPrio[x], d.pqProposed[x], d.pqCurrent[x], d.pqSize[x], d.pqBudget[x]);
         PackedKey ky = packKey3(a.preferLarge, a.compareSchedPrio ? d.pqSchedPrio[y] : d.pqPcPrio[y], d.pqProposed[y], d.pqCurrent[y], d.pqSize[y], d.pqBudget[y]);
         if (packedLess(kx, (uint32_t)d.qNameRank[x], ky, (uint32_t)d.qNameRank[y]) != pqLess(d, c, x, y)) agrees = 0;

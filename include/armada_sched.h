@@ -391,8 +391,11 @@ int32_t ASCHED_FN(fair_shares)(asched_t*, int32_t q, const int32_t* name_rank, c
    item 4) gives the same verdict as Less; the CPU oracle reports 1. */
 typedef struct asched_pq_item {
   double proposed_cost, current_cost, budget, item_size;   /* proposedQueueCost, currentQueueCost, queueBudget, itemSize */
-  int32_t pc_priority, scheduling_priority, name_rank, pad_; /* priorityClassPriority, schedulingPriority, rank of the queue name */
+  int32_t pc_priority, scheduling_priority, name_rank, away; /* priorityClassPriority, schedulingPriority, rank of the queue name, item.away (a cross-pool job's queue context) */
 } asched_pq_item;
+/* compare_scheduling_priority: bit 0 = compareSchedulingPriority, bit 1 (ASCHED_PQ_HOME_FIRST) = preemptCrossPoolJobsFirst: home items before away items
+   (queue_scheduler.go:744-746) */
+#define ASCHED_PQ_HOME_FIRST 2
 int32_t ASCHED_FN(pq_order)(asched_t*, int32_t n, const asched_pq_item* items, int32_t prioritise_larger_jobs, int32_t compare_scheduling_priority,
                             int32_t* out_order /*[n]*/, int32_t* packed_agrees);
 

@@ -190,7 +190,7 @@ def extract_pq_ordering(skipped):
         emit(f"{fn}/{r['name']}", int(r["source"].rsplit(":", 1)[1]),
              {"prioritiseLargerJobs": True, "compareSchedulingPriority": bool(r["shouldCompareSchedulingPriority"]), "items": [env["queueA"], env["queueB"]]},
              r["expectedOrder"], env)
-    skipped.append(f"{rel}:698 TestQueueCandidateGangIteratorPQ_HomeBeforeAway: cross-pool away items (preemptCrossPoolJobsFirst) do not exist within one pool")
+    skipped.append(f"{rel}:698 TestQueueCandidateGangIteratorPQ_HomeBeforeAway: two hand-built items, no table: transcribed by hand in tests/test_zzz_pq_ordering.py (asched_pq_order, ASCHED_PQ_HOME_FIRST)")
     return out
 
 

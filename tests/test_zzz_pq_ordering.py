@@ -74,3 +74,31 @@ def test_sweep_hostsim(hostsim_lib, oracle_lib):
 @pytest.mark.gpu
 def test_sweep_gpu(hip_lib, oracle_lib):
     sweep(hip_lib, oracle_lib)
+
+
+# ---- TestQueueCandidateGangIteratorPQ_HomeBeforeAway (queue_scheduler_test.go:698-716), by hand: two items, no table.  With preemptCrossPoolJobsFirst the
+# home item sorts before the cross-pool ("away") item whatever their costs and priorities (Less :744-746); without it priority-class priority decides.
+HOME = dict(proposed_cost=100.0, pc_priority=1, name_rank=0, away=0)
+AWAY = dict(proposed_cost=1.0, pc_priority=1000, name_rank=1, away=1)   # CalculateAwayQueueName("q") = "q-away" sorts after "q"
+
+
+def home_before_away(lib):
+    s = handle(lib)
+    for items, first in (([HOME, AWAY], 0), ([AWAY, HOME], 1)):
+        order, _ = s.pq_order(items, False, True, preempt_cross_pool_jobs_first=True)
+        assert order[0] == first                        # pq.Less(home, away) and !pq.Less(away, home)
+        order, _ = s.pq_order(items, False, True, preempt_cross_pool_jobs_first=False)
+        assert order[0] == 1 - first                    # flag off: the existing ordering applies and the away item wins (equal scheduling priorities, lower proposed cost)
+
+
+def test_home_before_away_oracle(oracle_lib):
+    home_before_away(oracle_lib)
+
+
+def test_home_before_away_hostsim(hostsim_lib):
+    home_before_away(hostsim_lib)
+
+
+@pytest.mark.gpu
+def test_home_before_away_gpu(hip_lib):
+    home_before_away(hip_lib)
