@@ -198,6 +198,7 @@ struct Dev {
   // ---- queues
   double *qWeight, *qFair, *qDc, *qUc, *qTokens; int32_t* qNameRank; int64_t* qBurst; uint8_t *qRateInf, *qCordoned;
   int64_t *qAlloc, *qAllocByPc, *qSchedByPc, *qEvictedByPc, *qPenalty, *qPcLimit, *qDemand; int32_t hasPcLimit;
+  int64_t* qDemandByPc;   // [Q][npc][R] scratch of the round-input builder on the device (round_run.h B_AGG_*): demand per queue and priority class before the per-class cap
   int32_t *queuedOff, *queuedJobs;
   // ---- evicted jobs
   int32_t* evList;       // [M] output of evictor kernels, then sorted by (queue, scheduling order)

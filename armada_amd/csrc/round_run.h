@@ -11,6 +11,7 @@ enum BulkKind {
   B_EVIDX, B_LVL0, B_EVKEYS, B_EVKEYS_OFF, B_EVKEYS_ON, B_EVSUM, B_SNAP, B_EVALIVE,
   B_FAIR_ZERO, B_FAIR_COUNT, B_FAIR_PSUM, B_FAIR_POFF, B_FAIR_SCATTER, B_FAIR_SORT,
   B_QSSUM, B_QSSTITCH, B_QSKEYS,
+  B_AGG_RUN, B_AGG_QUEUED,
 };
 
 DEV void wgBulk(Dev& d, int kind, int n);  // every element i in [0,n) through bulkElem(), then a workgroup barrier
@@ -225,6 +226,27 @@ DEV void bulkElem(Dev& d, int kind, int i) {
         for (int r = 0; r < c.R; r++) a[r] = with[r];
       }
     } break;
+    // The round-input builder's per-queue aggregates on the device (scheduling_algo.go:591-698, 805; asched_round_prepare when the caller passes none):
+    // allocation per (queue, priority class) = requests of the running jobs; demand per (queue, class) = requests of the running jobs + of the queued jobs of
+    // every queue that is not cordoned.  Integer atomics: order independent.  SM_AGG_FIN caps each class by the queue's limit and sums over the classes.
+    case B_AGG_RUN: {
+      if (d.jNode0[i] < 0) break;
+      int q = d.jQueue[i];
+      if (q < 0 || q >= c.Q) break;
+      const int64_t* req = JREQ(d, i);
+      size_t o = ((size_t)q * c.npc + d.jPc[i]) * c.R;
+      for (int r = 0; r < c.R; r++) if (req[r]) { atomicAddI64(&d.qAllocByPc[o + r], req[r]); atomicAddI64(&d.qDemandByPc[o + r], req[r]); }
+    } break;
+    case B_AGG_QUEUED: {
+      int lo = 0, hi = c.Q;   // the queue whose list holds position i
+      while (lo < hi) { int mid = (lo + hi) >> 1; if (d.queuedOff[mid + 1] <= i) lo = mid + 1; else hi = mid; }
+      int q = lo;
+      if (q >= c.Q || d.qCordoned[q]) break;
+      int job = d.queuedJobs[i];
+      const int64_t* req = JREQ(d, job);
+      size_t o = ((size_t)q * c.npc + d.jPc[job]) * c.R;
+      for (int r = 0; r < c.R; r++) if (req[r]) atomicAddI64(&d.qDemandByPc[o + r], req[r]);
+    } break;
     // per-node index of the evicted table (ensureFairIndex): count -> offsets -> scatter -> per-node sort by descending Index
     case B_FAIR_ZERO: d.accStamp[i] = 0; break;
     case B_FAIR_COUNT: { int n = d.jcAssigned[d.evTabJob[i]]; if (n >= 0) atomicAddI32(&d.accStamp[n], 1); } break;
@@ -366,7 +388,7 @@ DEV_COLD int pqsEvict(Dev& d, Ctl& c, bool phase3) {
 }
 
 // ---- the serial slivers of the split round (host-driven sequence): each runs as one thread of a tiny kernel between grid-wide passes
-enum SmallKind { SM_QEVICTABLE = 1, SM_EVICT_POST, SM_STITCH, SM_MONO, SM_LVL0_BEGIN, SM_FINAL, SM_PREPARE_FIN };
+enum SmallKind { SM_QEVICTABLE = 1, SM_EVICT_POST, SM_STITCH, SM_MONO, SM_LVL0_BEGIN, SM_FINAL, SM_PREPARE_FIN, SM_AGG_FIN };
 DEV void roundSmall(Dev& d, int what, int arg) {
   const DevCfg& cf = d.cfg;
   switch (what) {
@@ -412,6 +434,20 @@ DEV void roundSmall(Dev& d, int what, int arg) {
       if (lazy) d.rs->replayPending = 1;
     } break;
     case SM_LVL0_BEGIN: d.rs->lvl0NonNeg = 1; break;
+    case SM_AGG_FIN: {   // after B_AGG_*: queue allocation, capped demand, the scheduling context's allocated total
+      const DevCfg& cf = d.cfg;
+      for (int r = 0; r < cf.R; r++) d.rs->allocated[r] = 0;
+      for (int q = 0; q < cf.Q; q++) for (int r = 0; r < cf.R; r++) {
+        int64_t a = 0, dm = 0;
+        for (int p = 0; p < cf.npc; p++) {
+          size_t i = ((size_t)q * cf.npc + p) * cf.R + r;
+          a += d.qAllocByPc[i];
+          int64_t v = d.qDemandByPc[i];
+          dm += (d.hasPcLimit && d.qPcLimit[i] < v) ? d.qPcLimit[i] : v;   // constraints.go:187-197
+        }
+        QV(d.qAlloc, q)[r] = a; QV(d.qDemand, q)[r] = dm; d.rs->allocated[r] += a;
+      }
+    } break;
     case SM_PREPARE_FIN:  // tail of CMD_PREPARE: fresh evicted table, fair shares (context/scheduling.go:262-342)
       d.rs->fastActive = 0; d.rs->evictedTableSize = 0; d.rs->fairIndexValid = 0; d.rs->numUnfeasible = 0;
       updateFairShares(d, (const double*)0);
