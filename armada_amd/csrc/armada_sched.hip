@@ -1465,6 +1465,44 @@ __global__ void k_base_finish(Dev d) {
   if (d.f.maskMode) d.baseCls[i] = shapeFitMaskSerial(d, d.nodeCls[node], key, d.f.E > 0 ? d.alloc[(size_t)d.f.extraCol[0] * c.Npad + node] : 0, d.f.E > 1 ? d.alloc[(size_t)d.f.extraCol[1] * c.Npad + node] : 0);
 }
 
+
+// The round-input builder's sums (round_run.h B_AGG_RUN / B_AGG_QUEUED) grid-wide with the wave-level pre-reduction of k_evict_apply: both walks are
+// ordered by queue (the pre-sorted job order; the queued lists), so a wave holds a handful of (queue, class) keys and leaves one atomic per key and resource.
+__global__ __launch_bounds__(256) void k_agg(Dev d, int queued, int total) {
+  const DevCfg& c = d.cfg;
+  int lane = threadIdx.x & 63;
+  int rounds = (total + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
+  for (int it = 0; it < rounds; it++) {   // wave-uniform trip count
+    int i = (it * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    bool act = false; int key = -1; int64_t V[MAXR];
+#pragma unroll
+    for (int r = 0; r < MAXR; r++) V[r] = 0;
+    if (i < total) {
+      int j, q;
+      if (queued) {
+        int lo = 0, hi = c.Q;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (d.queuedOff[mid + 1] <= i) lo = mid + 1; else hi = mid; }
+        q = lo; j = d.queuedJobs[i];
+        act = q < c.Q && !d.qCordoned[q];
+      } else {
+        j = d.ordAll[i]; q = d.jQueue[j];
+        act = d.jNode0[j] >= 0 && q >= 0 && q < c.Q;
+      }
+      if (act) { key = q * c.npc + d.jPc[j]; const int64_t* req = JREQ(d, j); for (int r = 0; r < MAXR; r++) if (r < c.R) V[r] = req[r]; }
+    }
+    unsigned long long todo = __ballot(act);
+    while (todo) {
+      int first = __ffsll((long long)todo) - 1;
+      int k0 = __shfl(key, first, 64);
+      unsigned long long sel = __ballot(act && key == k0) & todo;
+      for (int r = 0; r < c.R; r++) {
+        int64_t v = waveSumSel(V[r], sel);
+        if (lane == 0 && v) { size_t ix = (size_t)k0 * c.R + r; atomicAddI64(&d.qDemandByPc[ix], v); if (!queued) atomicAddI64(&d.qAllocByPc[ix], v); }
+      }
+      todo &= ~sel;
+    }
+  }
+}
 __global__ void k_drf(Dev d, const int64_t* alloc, double* out) { if (threadIdx.x == 0) *out = drf(d, alloc); }
 __global__ void k_fair(Dev d, const double* cds) { if (threadIdx.x == 0) updateFairShares(d, cds); }
 
@@ -1636,6 +1674,11 @@ static int plat_small(Dev& d, int what, int arg) {
   hipLaunchKernelGGL(k_round_small, dim3(1), dim3(64), 0, t_ctx->stream, d, what, arg);
   t_ctx->roundLaunches++;
   return hipOk(hipGetLastError(), "k_round_small launch") ? 0 : -1;
+}
+static int plat_agg(Dev& d, int queued, int total) {
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(k_agg, dim3(bulkGrid(total)), dim3(256), 0, t_ctx->stream, d, queued, total);
+  return hipOk(hipGetLastError(), "k_agg launch") ? 0 : -1;
 }
 static int plat_evict_apply(Dev& d, int phase3, int total) {
   if (total <= 0) return 0;

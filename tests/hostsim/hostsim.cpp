@@ -130,6 +130,7 @@ static void plat_round_end() { t_ctx->inRound = false; t_ctx->cancelWord = 0; }
 static void plat_round_times(double* out) { out[0] = 0; out[1] = 0; out[2] = t_ctx->launches; }
 static int plat_bulk(Dev& dev, int kind, int n) { Dev d = dev; for (int i = 0; i < n; i++) bulkElem(d, kind, i); t_ctx->launches++; return 0; }
 static int plat_small(Dev& dev, int what, int arg) { Dev d = dev; roundSmall(d, what, arg); t_ctx->launches++; return 0; }
+static int plat_agg(Dev& dev, int queued, int total) { Dev d = dev; if (queued) { for (int i = 0; i < total; i++) bulkElem(d, B_AGG_QUEUED, i); } else { for (int i = 0; i < total; i++) bulkElem(d, B_AGG_RUN, d.ordAll[i]); } return 0; }
 static int plat_evict_apply(Dev& dev, int phase3, int total) {
   Dev d = dev;
   for (int i = 0; i < total; i++) evictApply(d, d.ordAll[i], phase3 != 0);
