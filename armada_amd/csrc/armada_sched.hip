@@ -458,6 +458,39 @@ __device__ static inline void baseScan(KREF k, FastS& S, const JobTail& r) {
   int s = r.shape;
   int p0 = UNI32(g_fl.cand[s].pos);
   int N = k.N;
+  if (k.maskMode) {
+    // lanes as shapes: whose candidate is stale and whose cursor is not behind this walk's start (round_fast.h baseScan, serial twin)
+    const int pStart = p0;
+    int myPos = lane < k.S ? g_fl.cand[lane].pos : 0x7fffffff, myNode = lane < k.S ? g_fl.cand[lane].node : 0;
+    unsigned long long stale = __ballot(lane < k.S && (lane == s || (myNode == -2 && myPos >= pStart)));
+    bool found = false; int end = N;
+    for (;;) {
+      if (p0 >= N) break;
+      if (!(S.tP0 >= 0 && p0 >= S.tP0 && p0 < S.tP0 + 64)) baseTileLoad(k, S, p0);
+      unsigned long long clean = __ballot(S.tP0 + lane >= p0 && !S.tRem && (S.tCls & stale) != 0);
+      S.statScanSteps++;
+      while (clean) {
+        int e = __ffsll((long long)clean) - 1;
+        clean &= clean - 1;
+        int pe = S.tP0 + e;
+        unsigned long long m = slGet64(S.tCls, e);
+        unsigned long long newly = m & stale & __ballot(myPos <= pe);
+        if (!newly) continue;
+        int node = __builtin_amdgcn_readlane(S.tNode, e);
+        unsigned long long key = slGet64(S.tKey, e);
+        long long ex0 = (long long)slGet64((unsigned long long)S.tEx0, e), ex1 = (long long)slGet64((unsigned long long)S.tEx1, e);
+        if ((newly >> lane) & 1) { CandRec c; c.pos = pe; c.node = node; c.key = key; c.cls = m; c.ex0 = ex0; c.ex1 = ex1; c.pad = 0; g_fl.cand[lane] = c; }
+        stale &= ~newly;
+        if ((newly >> s) & 1) { found = true; end = pe + 1; break; }
+      }
+      if (found) break;
+      p0 = S.tP0 + 64;
+    }
+    if (!found && lane == s) { g_fl.cand[s].pos = N; g_fl.cand[s].node = -1; }
+    stale &= ~(1ull << s);
+    if ((stale >> lane) & 1) { if (myPos < end) g_fl.cand[lane].pos = end; if (!found) g_fl.cand[lane].node = -1; }
+    return;
+  }
   for (;;) {
     if (p0 >= N) { g_fl.cand[s].pos = N; g_fl.cand[s].node = -1; return; }
     if (!(S.tP0 >= 0 && p0 >= S.tP0 && p0 < S.tP0 + 64)) baseTileLoad(k, S, p0);
@@ -492,12 +525,12 @@ __device__ static inline uint64_t l0Search(KREF k, const JobTail& r, int* slot) 
   int rounds = (cnt + 63) >> 6;   // the same trip count on every lane: the cross-lane reduction below sees a converged wave
   if (k.maskMode) {   // one bit per entry says whether the job's shape fits: key + mask, nothing else
     int sh = r.shape;
-    for (int r0 = 0; r0 < rounds; r0 += 4) {
-      unsigned long long key[4], m[4];
+    for (int r0 = 0; r0 < rounds; r0 += 8) {   // up to 512 entries per group of loads: the usual list is searched with one LDS latency
+      unsigned long long key[8], m[8];
 #pragma unroll
-      for (int u = 0; u < 4; u++) { int i = ((r0 + u) << 6) + lane, j = i < cnt ? i : 0; key[u] = g_fl.l0Key[j]; m[u] = g_fl.l0Cls[j]; }
+      for (int u = 0; u < 8; u++) { int i = ((r0 + u) << 6) + lane, j = i < cnt ? i : 0; key[u] = g_fl.l0Key[j]; m[u] = g_fl.l0Cls[j]; }
 #pragma unroll
-      for (int u = 0; u < 4; u++) { int i = ((r0 + u) << 6) + lane; if (i < cnt && ((m[u] >> sh) & 1) && key[u] < best) { best = key[u]; bs = i; } }
+      for (int u = 0; u < 8; u++) { int i = ((r0 + u) << 6) + lane; if (i < cnt && ((m[u] >> sh) & 1) && key[u] < best) { best = key[u]; bs = i; } }
     }
     unsigned long long mn = waveMin64Dpp(best);
     if (mn == ~0ull) { *slot = -1; return mn; }

@@ -69,7 +69,7 @@ struct JobRec {
   int64_t req[MAXR];   // AllResourceRequirements (zero beyond R)
   uint64_t keyDelta;   // packed (req_c / resolution_c) per indexed column: what a bind subtracts from a node's order key
   uint64_t fieldMin;   // packed (req_c / resolution_c - keyLo_c): smallest key fields of a node the job fits on
-  int32_t pc, shape, gang, node0, runPrio, cls, pcPrio;
+  int32_t pc, shape, gang, node0, runPrio, cls, pcPrio;   // shape: the job's FIT shape (FastCfg.F), not its scheduling-key shape (Dev.jShape)
   uint8_t never, preemptible;
   uint8_t nlPc, nlRun; // number of priority levels a bind at pcPrio / at runPrio subtracts from (levels with priority <= cutoff, nodedb.go:1321-1334)
   int64_t ex0, ex1;    // requests on the (<= MAXE) non-indexed columns
@@ -100,7 +100,10 @@ struct FastCfg {
   int structOk, iterOk;       // host-verified exactness conditions (asched_host.inc: fastConditions)
   int relocAll;               // ASCHED_RELOC_ALL=1: stage the per-queue arrays in LDS for any Q (default: only Q <= 64, see armada_sched.hip relocateIn)
   int cascadeFuse;            // the gate + urgency sweep of one job may run as ONE multi-level plane pass (round_ctl.h selectAtPriority): planes are monotone in the level (no explicit alloc_by_prio, non-negative requests) and a level tag fits above the packed key
-  int maskMode;               // <= 64 shapes: baseCls / l0Cls / CandRec.cls hold per-shape fit masks (current capacity and requirement class folded in), not class bits
+  int F;                      // fit shapes: distinct (key fields, extras, requirement class) among the scheduling-key shapes — what node selection at priority -2 depends on;
+                              // JobRec.shape, the candidate cache, the shape table and the fit masks are indexed by fit shape (scheduling keys that differ only in the
+                              // priority class share one base cursor)
+  int maskMode;               // <= 64 fit shapes: baseCls / l0Cls / CandRec.cls hold per-shape fit masks (current capacity and requirement class folded in), not class bits
   int engine;                 // queued-job iterations run on two waves (round_fast.h "two-wave iteration"); ASCHED_ENGINE=0 turns it off
   int E; int extraCol[MAXE];  // non-indexed columns
   uint64_t fieldMask[MAXK];   // in-place mask of each packed key field

@@ -230,7 +230,7 @@ struct FastS {
 // SGPRs, batched by the compiler, no LDS traffic and no vector registers.
 HD void fastKInit(const Dev& d, FastK& k) {
   const DevCfg& c = d.cfg;
-  k.R = c.R; k.K = c.K; k.P = c.P; k.E = d.f.E; k.ex0col = d.f.extraCol[0]; k.ex1col = d.f.extraCol[1]; k.N = c.N; k.npc = c.npc; k.S = c.S;
+  k.R = c.R; k.K = c.K; k.P = c.P; k.E = d.f.E; k.ex0col = d.f.extraCol[0]; k.ex1col = d.f.extraCol[1]; k.N = c.N; k.npc = c.npc; k.S = d.f.F;   // (S: fit shapes)
   k.disableHome = c.disableHome; k.hasPcLimit = d.hasPcLimit; k.Npad = (size_t)c.Npad;
   k.anyDisallowed = 0; k.anyRoundLimit = 0;
   for (int i = 0; i < MAXR; i++) if (i < c.R && c.maxToSchedule[i] != INT64_MAX) k.anyRoundLimit = 1;  // MaximumResourceFractionToSchedule unset: +Inf x total saturates (resource_list.go:312-331)
@@ -280,7 +280,7 @@ static_assert(sizeof(ShapeReq) == 32 && 64 * sizeof(ShapeReq) <= (SMAX / 2) * si
 // fit mask of a node from scratch (per-thread loop over the shapes): class bits + level-0 key and extras -> bit s = a job of shape s fits
 HD uint64_t shapeFitMaskSerial(const Dev& d, uint64_t clsBits, uint64_t key, int64_t ex0, int64_t ex1) {
   uint64_t m = 0;
-  for (int s = 0; s < d.cfg.S && s < 64; s++) {
+  for (int s = 0; s < d.f.F && s < 64; s++) {
     const ShapeReq q = d.shapeTab[s];
     bool ok = !q.never && ((clsBits >> q.cls) & 1) && q.ex0 <= ex0 && q.ex1 <= ex1;
     if (ok) {
@@ -399,13 +399,43 @@ DEV void drf3(Dev& d, int q, int k, bool replay, double w, double* proposed, dou
 }
 DEV void fastFence(Ctl&) {}
 DEV void baseTileRemoved(KREF, FastS&, int) {}
-// advance the base cursor of shape r.shape to the next clean entry the job fits on
+// advance the base cursor of shape r.shape to the next clean entry the job fits on.  With shape-fit masks a clean entry says which shapes fit it, so the
+// walk also refreshes the candidate of every OTHER shape whose candidate is stale and whose cursor is not behind the walk's start (one bind of a base node
+// makes the candidates of all shapes that pointed at it stale: they are found again by this one walk instead of one walk each); such shapes that the
+// walk does not satisfy move their cursor to its end — every clean entry up to there has been tested against them.
 DEV void baseScan(KREF k, FastS& S, const JobTail& r) {
   int s = r.shape;
+  if (k.maskMode) {
+    int pStart = FL.cand[s].pos, end = k.N;
+    uint64_t stale = 0;
+    for (int t = 0; t < k.S && t < 64; t++) if (t == s || (FL.cand[t].node == -2 && FL.cand[t].pos >= pStart)) stale |= 1ull << t;
+    bool found = false;
+    for (int p = pStart; p < k.N && !found; p++) {
+      if (k.baseRemoved[p]) continue;
+      uint64_t m = k.baseCls[p];
+      uint64_t newly = 0;
+      for (int t = 0; t < k.S && t < 64; t++) if (((stale >> t) & 1) && ((m >> t) & 1) && FL.cand[t].pos <= p) newly |= 1ull << t;
+      if (!newly) continue;
+      for (int t = 0; t < 64; t++) if ((newly >> t) & 1) {
+        CandRec& c = FL.cand[t];
+        c.pos = p; c.node = k.baseNode[p]; c.key = k.baseKey[p]; c.cls = m; c.ex0 = k.E > 0 ? k.baseExtra[p] : 0; c.ex1 = k.E > 1 ? k.baseExtra[k.Npad + p] : 0;
+      }
+      stale &= ~newly;
+      if ((newly >> s) & 1) { found = true; end = p + 1; }
+    }
+    S.statScanSteps++;
+    if (!found) { FL.cand[s].pos = k.N; FL.cand[s].node = -1; stale &= ~(1ull << s); }
+    for (int t = 0; t < 64; t++) if (((stale >> t) & 1) && t != s) { if (FL.cand[t].pos < end) FL.cand[t].pos = end; if (!found) FL.cand[t].node = -1; }
+    return;
+  }
+  static long hsScans = 0, hsRemoved = 0, hsUnfit = 0, hsTiles = 0; static bool hsDump = getenv("HS_SCAN_STATS") != nullptr;
+  if (hsDump) { hsScans++; if ((hsScans % 20000) == 0) fprintf(stderr, "base scans %ld: removed entries walked %ld, clean unfit walked %ld, 64-entry tiles touched %ld\n", hsScans, hsRemoved, hsUnfit, hsTiles); }
+  int hsP0 = FL.cand[s].pos;
   for (int p = FL.cand[s].pos; p < k.N; p++) {
-    if (k.baseRemoved[p]) continue;
+    if (hsDump && ((p - hsP0) % 64) == 0) hsTiles++;
+    if (k.baseRemoved[p]) { if (hsDump) hsRemoved++; continue; }
     int64_t ex0 = k.E > 0 ? k.baseExtra[p] : 0, ex1 = k.E > 1 ? k.baseExtra[k.Npad + p] : 0;
-    if (!entryFits(k, r, k.baseKey[p], ex0, ex1, k.baseCls[p])) continue;
+    if (!entryFits(k, r, k.baseKey[p], ex0, ex1, k.baseCls[p])) { if (hsDump) hsUnfit++; continue; }
     CandRec& c = FL.cand[s];
     c.pos = p; c.node = k.baseNode[p]; c.key = k.baseKey[p]; c.cls = k.baseCls[p]; c.ex0 = ex0; c.ex1 = ex1;
     S.statScanSteps++;
@@ -614,8 +644,8 @@ DEV int streamBound();   // entries whose ring slot is free again (the bind wave
 DEV void wgBulk(Dev& d, int kind, int n);
 #endif
 DEV void candInvalidate(int S, int n) { FOR_LANES(s, S) if (FL.cand[s].node == n) FL.cand[s].node = -2; }
-DEV void candResetAll(Dev& d, const int32_t* pos) { FOR_LANES(s, d.cfg.S < SMAX ? d.cfg.S : SMAX) { FL.cand[s].node = -2; FL.cand[s].pos = pos ? pos[s] : 0; FL.cand[s].key = 0; } }  // key 0: no lower bound known, the first query scans
-DEV void candSaveAll(Dev& d, int32_t* pos) { FOR_LANES(s, d.cfg.S < SMAX ? d.cfg.S : SMAX) pos[s] = FL.cand[s].pos; }
+DEV void candResetAll(Dev& d, const int32_t* pos) { FOR_LANES(s, d.f.F < SMAX ? d.f.F : SMAX) { FL.cand[s].node = -2; FL.cand[s].pos = pos ? pos[s] : 0; FL.cand[s].key = 0; } }  // key 0: no lower bound known, the first query scans
+DEV void candSaveAll(Dev& d, int32_t* pos) { FOR_LANES(s, d.f.F < SMAX ? d.f.F : SMAX) pos[s] = FL.cand[s].pos; }
 
 // Before generic code runs: the LDS queue records back into the generic arrays, and the fast path's no-return atomics
 // made visible to plain loads
@@ -855,14 +885,14 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
     }
     SEG(10);
     if (generic) { ok = false; break; }  // the generic iterator continues from the same state
-    int job = UNI32(FL.winJob[q][w]), shape = UNI32(FL.winRec[q][w].shape);
+    int job = UNI32(FL.winJob[q][w]);
     if (kind == 0) f.itEi = pos + 1;
     else {
       f.itQi = pos + 1; f.itJobsSeen++;
       // JobSchedulingContextFromJob (context/job.go:149-158): a queued non-gang job still has exactly the jctx that
       // round_prepare's reset gave it (fast iterations are off once a NodeDb-level call touched per-job state): nothing to store
     }
-    if (fc.skipKnown && S.numUnfeasible > 0 && kind == 1 && k.unfeasible[shape]) {  // queue_scheduler.go:398-413
+    if (fc.skipKnown && S.numUnfeasible > 0 && kind == 1 && k.unfeasible[UNI32(d.jShape[job])]) {  // queue_scheduler.go:398-413 (the scheduling key's shape: the record carries the fit shape)
       if (FLANE == 0) {
         k.jcHasPctx[job] = 1; k.pcNode[job] = -1; k.pcMethod[job] = ASCHED_METHOD_NONE;
         k.jobFlags[job] = (uint8_t)(k.jobFlags[job] | F_UNSUCCESSFUL);  // sctx.AddJobSchedulingContext of a failed job

@@ -1,0 +1,94 @@
+"""Stream runs and gangs through the ring (armada_amd/csrc/round_fast.h): the part of the round where the control wave only merges
+precomputed per-queue cost streams while the node engine places the jobs.  The reference behaviour is the ordinary QueueScheduler loop
+(queue_scheduler.go:94-304, Less :738-798, gang_scheduler.go:46-148): every round here is compared with the oracle job by job, and the counters say that the
+rounds really went through the stream / ring code.  HS_STREAM_EAGER=1 (CPU build only) starts a stream run wherever one can start, which multiplies the number
+of run starts, ends and discarded entries per round; the production back-off is tested as is.
+"""
+import numpy as np
+import pytest
+
+from armada_amd import workloads as W
+import bench
+
+
+def workload(seed, gangs=0, occupied=0.5, n_nodes=1200, n_jobs=16000, n_queues=24, burst=None, lookback=0):
+    wl = W.config3(seed=seed, n_nodes=n_nodes, n_jobs=n_jobs, n_queues=n_queues, gangs=gangs, occupied=occupied)
+    wl.global_burst, wl.queue_burst = burst or (n_jobs // 3, max(10, n_jobs // n_queues))
+    if lookback:
+        wl.config.max_queue_lookback = lookback
+    return wl
+
+
+def both(lib, oracle, wl):
+    out = []
+    for l in (lib, oracle):
+        s = W.load(l, wl); W.prepare(s, wl)
+        r = s.schedule_round()
+        out.append((r, s.round_stats()))
+        s.close()
+    assert bench.round_diff(out[0][0], out[1][0]) == []
+    return out[0]
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_stream_rounds_equal_oracle(hostsim_lib, oracle_lib, seed):
+    r, st = both(hostsim_lib, oracle_lib, workload(900 + seed, occupied=[0.2, 0.5, 0.8, 0.5][seed], lookback=[0, 0, 0, 400][seed]))
+    assert st["stream_runs"] > 0 and st["stream_jobs"] > 0
+    if seed == 0:
+        assert st["stream_jobs"] > len(r.scheduled) // 2      # an uncrowded cluster: most of the round runs inside stream runs
+    assert st["stream_emitted"] >= st["stream_jobs"]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_stream_runs_started_everywhere_equal_oracle(hostsim_lib, oracle_lib, seed, monkeypatch):
+    monkeypatch.setenv("HS_STREAM_EAGER", "1")
+    rng = np.random.default_rng(seed)
+    wl = workload(950 + seed, gangs=int(rng.choice([0, 5, 40])), occupied=float(rng.choice([0.3, 0.8, 0.93])), n_queues=int(rng.integers(3, 30)),
+                  burst=(int(rng.choice([16000, 5000, 500])), int(rng.choice([16000, 700, 64]))))
+    r, st = both(hostsim_lib, oracle_lib, wl)
+    assert st["stream_runs"] >= 10
+
+
+def test_streams_off_is_the_same_round(hostsim_lib, oracle_lib, monkeypatch):
+    wl = workload(990)
+    a, sa = both(hostsim_lib, oracle_lib, wl)
+    monkeypatch.setenv("HS_NO_STREAM", "1")
+    b, sb = both(hostsim_lib, oracle_lib, wl)
+    assert sb["stream_runs"] == 0 and sa["stream_runs"] > 0 and bench.round_diff(a, b) == []
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_gangs_go_through_the_ring(hostsim_lib, oracle_lib, seed, monkeypatch):
+    wl = workload(970 + seed, gangs=150, occupied=0.4)
+    r, st = both(hostsim_lib, oracle_lib, wl)
+    monkeypatch.setenv("HS_NO_GANG_RING", "1")
+    r2, st2 = both(hostsim_lib, oracle_lib, wl)
+    assert st["generic_iterations"] < st2["generic_iterations"] // 2          # most gangs left the generic path (those that need preemption or do not fit stay) ...
+    assert bench.round_diff(r, r2) == []                                       # ... with the same result
+
+
+def test_gang_that_does_not_fit_is_taken_back(hostsim_lib, oracle_lib):
+    """a crowded cluster: gangs whose first members find nodes and a later member does not — nothing of the attempt may remain (held binds are dropped,
+    the nodes the placed members went to are re-read), and the generic code then fails the gang exactly as the reference does"""
+    wl = workload(985, gangs=120, occupied=0.93, n_nodes=300, n_jobs=6000, n_queues=6)
+    r, st = both(hostsim_lib, oracle_lib, wl)
+    unsched_gang = [j for j in range(wl.num_jobs) if wl.job_gang[j] >= 0 and wl.job_node[j] < 0 and j not in set(r.scheduled)]
+    assert unsched_gang, "the workload should leave some gangs unscheduled"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(3))
+def test_stream_rounds_gpu(hip_lib, oracle_lib, seed):
+    r, st = both(hip_lib, oracle_lib, workload(900 + seed, gangs=[0, 30, 0][seed], occupied=[0.3, 0.5, 0.9][seed], n_nodes=4000, n_jobs=60000, n_queues=40))
+    assert st["stream_runs"] > 0
+
+
+@pytest.mark.gpu
+def test_gangs_through_the_ring_gpu(hip_lib, oracle_lib):
+    r, st = both(hip_lib, oracle_lib, workload(971, gangs=400, occupied=0.4, n_nodes=4000, n_jobs=60000, n_queues=32))
+    assert st["generic_iterations"] < 100
+
+
+@pytest.mark.gpu
+def test_crowded_gangs_gpu(hip_lib, oracle_lib):
+    both(hip_lib, oracle_lib, workload(985, gangs=120, occupied=0.93, n_nodes=300, n_jobs=6000, n_queues=6))
