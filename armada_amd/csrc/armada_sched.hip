@@ -450,6 +450,17 @@ __device__ static inline void baseTileRemoved(KREF k, FastS& S, int pos) {
   if (S.tP0 >= 0 && pos >= S.tP0 && pos < S.tP0 + 64) { if (lane == pos - S.tP0) S.tRem = 1; }
   else baseTileLoad(k, S, pos);  // issued now, consumed by the next scan: the HBM latency overlaps the rest of the iteration
 }
+// base entry pos is stale from now on: its flag, and its bit in every fit shape's "clean and fits" bitmap (lane f clears row f; no-return atomics at L2 —
+// the scans read the bitmaps with agent-scope loads, so every wave sees them)
+__device__ static inline void baseMarkRemoved(KREF k, FastS& S, int pos) {
+  (void)S;
+  int lane = threadIdx.x & 63;
+  if (lane == 0) k.baseRemoved[pos] = 1;
+  if (k.fitBits) {
+    unsigned long long bit = 1ull << (pos & 63);
+    for (int f = lane; f < k.S; f += 64) (void)__hip_atomic_fetch_and(&k.fitBits[(size_t)f * k.fitW + (pos >> 6)], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 __device__ static inline void baseScan(KREF k, FastS& S, const JobTail& r) {
   int lane = threadIdx.x & 63;
 #ifdef ASCHED_FASTPROF
@@ -458,6 +469,31 @@ __device__ static inline void baseScan(KREF k, FastS& S, const JobTail& r) {
   int s = r.shape;
   int p0 = UNI32(g_fl.cand[s].pos);
   int N = k.N;
+  if (k.fitBits) {
+    // find-first-set over the shape's "clean and fits" bitmap: 64 lanes x 64 bits = 4096 base entries per memory round trip, whatever lies between
+    // the cursor and the next usable entry (entries used up by other shapes, clean entries this shape does not fit on)
+    S.statScanSteps++;
+    if (UNI32(g_fl.cand[s].node) == -2 && UNI64(g_fl.cand[s].key) != 0) p0++;   // a stale candidate: the entry at the cursor is the one that was used up (its bit may still be on its way to L2)
+    for (;;) {
+      if (p0 >= N) { if (lane == 0) { g_fl.cand[s].pos = N; g_fl.cand[s].node = -1; } return; }
+      int w0 = p0 >> 6, w = w0 + lane;
+      unsigned long long word = w < k.fitW ? __hip_atomic_load(&k.fitBits[(size_t)s * k.fitW + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#ifdef ASCHED_FASTPROF
+      if (lane == 0) g_rs.statSeg[4] += 1000;   // profiling: bitmap windows read
+#endif
+      if (lane == 0) word &= ~0ull << (p0 & 63);
+      unsigned long long b = __ballot(word != 0);
+      if (!b) { p0 = (w0 + 64) << 6; continue; }
+      int L = __ffsll((long long)b) - 1;
+      unsigned long long wv = slGet64(word, L);
+      int q = ((w0 + L) << 6) + (__ffsll((long long)wv) - 1);
+      // the entry itself: one more round trip, four independent loads
+      unsigned long long key = k.baseKey[q], cls = k.baseCls[q]; int node = k.baseNode[q];
+      long long ex0 = k.E > 0 ? k.baseExtra[q] : 0, ex1 = k.E > 1 ? k.baseExtra[k.Npad + q] : 0;
+      if (lane == 0) { CandRec c; c.pos = q; c.node = node; c.key = key; c.cls = cls; c.ex0 = ex0; c.ex1 = ex1; c.pad = 0; g_fl.cand[s] = c; }
+      return;
+    }
+  }
   if (k.maskMode) {
     // lanes as shapes: whose candidate is stale and whose cursor is not behind this walk's start (round_fast.h baseScan, serial twin)
     const int pStart = p0;
@@ -1536,6 +1572,12 @@ __global__ __launch_bounds__(256) void k_agg(Dev d, int queued, int total) {
     }
   }
 }
+// the fit bitmaps of a fresh base (round_fast.h fitBitsWord): one thread per (fit shape, 64 entries)
+__global__ void k_base_fitbits(Dev d) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, total = (size_t)d.f.F * d.fitW;
+  if (i >= total) return;
+  d.fitBits[i] = fitBitsWord(d, (int)(i / d.fitW), (int)(i % d.fitW));
+}
 __global__ void k_drf(Dev d, const int64_t* alloc, double* out) { if (threadIdx.x == 0) *out = drf(d, alloc); }
 __global__ void k_fair(Dev d, const double* cds) { if (threadIdx.x == 0) updateFairShares(d, cds); }
 
@@ -1813,6 +1855,7 @@ static int plat_build_base(Dev& d) {
     }
   }
   hipLaunchKernelGGL(k_base_finish, dim3((N + 255) / 256), dim3(256), 0, t_ctx->stream, d);
+  if (d.fitBits) { size_t total = (size_t)d.f.F * d.fitW; hipLaunchKernelGGL(k_base_fitbits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, t_ctx->stream, d); }
   if (!hipOk(hipGetLastError(), "base build launch")) return -1;
   if (!hipOk(hipStreamSynchronize(t_ctx->stream), "base build")) return -1;
   return 0;

@@ -250,7 +250,9 @@ struct Dev {
   int32_t* posOf;        // [N] node -> base position
   int32_t* l0Slot;       // [N] node -> L0 slot or -1
   uint64_t* nodeCls;     // [N]
-  ShapeReq* shapeTab;    // [S]
+  ShapeReq* shapeTab;    // [F] per fit shape
+  uint64_t* fitBits;     // [F][fitW] bit p of row f: base entry p is clean (unchanged since the sort) and a job of fit shape f fits on it — a base rescan is a find-first-set
+  int32_t fitW, fitPad_;  // words per row = ceil(N / 64)
   JobRec* jrec;          // [M]
   int32_t* evIdxByPos;   // [M] evicted-table Index of evList[p]
   EvKey* evKey;          // [M] per evicted-list position (queues with evCheap)

@@ -203,6 +203,7 @@ struct FastK {
   GP(int64_t) qAllocByPc; GP(int64_t) qSchedByPc; GP(int64_t) qEvictedByPc;
   GP(uint8_t) jcPreempted; GP(uint8_t) nodeFlags;
   GP(unsigned long long) qsKey;
+  GP(unsigned long long) fitBits; int fitW;
   int maskMode;
   int32_t prios[MAXP];
 };
@@ -252,6 +253,7 @@ HD void fastKInit(const Dev& d, FastK& k) {
   k.jcPreempted = GA(uint8_t, d.jcPreempted); k.nodeFlags = GA(uint8_t, d.nodeFlags);
   k.qsKey = GA(unsigned long long, (unsigned long long*)d.qsKey);
   k.maskMode = d.f.maskMode;
+  k.fitBits = GA(unsigned long long, (unsigned long long*)d.fitBits); k.fitW = d.fitW;
   for (int i = 0; i < MAXP; i++) k.prios[i] = i < c.P ? c.prios[i] : INT32_MAX;
 }
 // a register copy of the constants: one burst of scalar loads (constant address space) per call, then no memory traffic
@@ -288,6 +290,25 @@ HD uint64_t shapeFitMaskSerial(const Dev& d, uint64_t clsBits, uint64_t key, int
       else for (int i = 0; i < MAXK; i++) { uint64_t fm = d.f.fieldMask[i]; ok = ok && (key & fm) >= (q.fieldMin & fm); }
     }
     if (ok) m |= 1ull << s;
+  }
+  return m;
+}
+// one word of the fit bitmap: base entries [64 w, 64 w + 64) against fit shape f, at base build time (every entry is clean)
+HD uint64_t fitBitsWord(const Dev& d, int f, int w) {
+  const ShapeReq q = d.shapeTab[f];
+  uint64_t m = 0;
+  if (q.never) return 0;
+  for (int b = 0; b < 64; b++) {
+    int p = w * 64 + b;
+    if (p >= d.cfg.N) break;
+    uint64_t key = d.baseKey[p];
+    int64_t ex0 = d.f.E > 0 ? d.baseExtra[p] : 0, ex1 = d.f.E > 1 ? d.baseExtra[(size_t)d.cfg.Npad + p] : 0;
+    bool ok = ((d.nodeCls[d.baseNode[p]] >> q.cls) & 1) && q.ex0 <= ex0 && q.ex1 <= ex1;
+    if (ok) {
+      if (d.f.guardMask) ok = (((key | d.f.guardMask) - q.fieldMin) & d.f.guardMask) == d.f.guardMask;
+      else for (int i = 0; i < MAXK; i++) { uint64_t fm = d.f.fieldMask[i]; ok = ok && (key & fm) >= (q.fieldMin & fm); }
+    }
+    if (ok) m |= 1ull << b;
   }
   return m;
 }
@@ -399,12 +420,32 @@ DEV void drf3(Dev& d, int q, int k, bool replay, double w, double* proposed, dou
 }
 DEV void fastFence(Ctl&) {}
 DEV void baseTileRemoved(KREF, FastS&, int) {}
+DEV void baseMarkRemoved(KREF k, FastS&, int pos) {
+  k.baseRemoved[pos] = 1;
+  if (k.fitBits) for (int f = 0; f < k.S; f++) k.fitBits[(size_t)f * k.fitW + (pos >> 6)] &= ~(1ull << (pos & 63));
+}
 // advance the base cursor of shape r.shape to the next clean entry the job fits on.  With shape-fit masks a clean entry says which shapes fit it, so the
 // walk also refreshes the candidate of every OTHER shape whose candidate is stale and whose cursor is not behind the walk's start (one bind of a base node
 // makes the candidates of all shapes that pointed at it stale: they are found again by this one walk instead of one walk each); such shapes that the
 // walk does not satisfy move their cursor to its end — every clean entry up to there has been tested against them.
 DEV void baseScan(KREF k, FastS& S, const JobTail& r) {
   int s = r.shape;
+  if (k.fitBits) {   // find-first-set in the shape's "clean and fits" bitmap from the cursor on
+    S.statScanSteps++;
+    int p = FL.cand[s].pos;
+    if (FL.cand[s].node == -2 && FL.cand[s].key != 0) p++;   // a stale candidate: the entry at the cursor is the one that was used up
+    for (int w = p >> 6; w < k.fitW; w++) {
+      uint64_t word = k.fitBits[(size_t)s * k.fitW + w];
+      if (w == (p >> 6)) word &= ~0ull << (p & 63);
+      if (!word) continue;
+      int q = w * 64 + __builtin_ctzll(word);
+      CandRec& c = FL.cand[s];
+      c.pos = q; c.node = k.baseNode[q]; c.key = k.baseKey[q]; c.cls = k.baseCls[q]; c.ex0 = k.E > 0 ? k.baseExtra[q] : 0; c.ex1 = k.E > 1 ? k.baseExtra[k.Npad + q] : 0;
+      return;
+    }
+    FL.cand[s].pos = k.N; FL.cand[s].node = -1;
+    return;
+  }
   if (k.maskMode) {
     int pStart = FL.cand[s].pos, end = k.N;
     uint64_t stale = 0;
@@ -638,6 +679,7 @@ DEV unsigned long long streamStageIssue(KREF k, int base, int cnt);
 DEV void streamStageCommit(Dev& d, KREF k, int base, int cnt, unsigned long long v);
 DEV void streamEnd(int engSeq);
 DEV void streamAccount(Dev& d, KREF k, int i0, int i1);   // ring entries [i0, i1): sctx / qctx sums, FL.tmpQ[queue] counts them
+DEV void baseMarkRemoved(KREF k, FastS& S, int pos);   // base entry pos is stale from now on: flag + its bit in every fit shape's bitmap
 DEV uint64_t capMask(KREF k, uint64_t clsBits, uint64_t key, int64_t ex0, int64_t ex1);   // mask mode: bit s = shape s fits (lane s evaluates shape s)
 DEV int streamAcked(int* fail);
 DEV int streamBound();   // entries whose ring slot is free again (the bind wave has read them)
@@ -690,7 +732,7 @@ DEV void fastTouch(Dev& d, int n) {
   uint64_t key = KKEY(k, 0, n);
   int64_t ex0 = k.E > 0 ? KAL(k, 0, k.ex0col, n) : 0, ex1 = k.E > 1 ? KAL(k, 0, k.ex1col, n) : 0;
   int pos = GA(int32_t, d.posOf)[n], slot = k.l0Slot[n];
-  if (FLANE == 0) k.baseRemoved[pos] = 1;
+  { FastS TS; TS.tP0 = -1; baseMarkRemoved(k, TS, pos); }
   candInvalidate(k.S, n);
   uint64_t cls = GA(uint64_t, d.nodeCls)[n];
   bool live;
@@ -740,7 +782,7 @@ DEV bool fastAfterBind(KREF k, FastS& S, const JobTail& r, int n, const FitHandl
   if (h.src == 0) {
     uint64_t key = c.key - r.keyDelta;
     int64_t ex0 = c.ex0 - r.ex0, ex1 = c.ex1 - r.ex1;
-    if (FLANE == 0) k.baseRemoved[c.pos] = 1;
+    baseMarkRemoved(k, S, c.pos);
     baseTileRemoved(k, S, c.pos);
     candInvalidate(k.S, n);
     uint64_t cls = c.cls;
