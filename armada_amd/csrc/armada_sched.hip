@@ -494,39 +494,6 @@ __device__ static inline void baseScan(KREF k, FastS& S, const JobTail& r) {
       return;
     }
   }
-  if (k.maskMode) {
-    // lanes as shapes: whose candidate is stale and whose cursor is not behind this walk's start (round_fast.h baseScan, serial twin)
-    const int pStart = p0;
-    int myPos = lane < k.S ? g_fl.cand[lane].pos : 0x7fffffff, myNode = lane < k.S ? g_fl.cand[lane].node : 0;
-    unsigned long long stale = __ballot(lane < k.S && (lane == s || (myNode == -2 && myPos >= pStart)));
-    bool found = false; int end = N;
-    for (;;) {
-      if (p0 >= N) break;
-      if (!(S.tP0 >= 0 && p0 >= S.tP0 && p0 < S.tP0 + 64)) baseTileLoad(k, S, p0);
-      unsigned long long clean = __ballot(S.tP0 + lane >= p0 && !S.tRem && (S.tCls & stale) != 0);
-      S.statScanSteps++;
-      while (clean) {
-        int e = __ffsll((long long)clean) - 1;
-        clean &= clean - 1;
-        int pe = S.tP0 + e;
-        unsigned long long m = slGet64(S.tCls, e);
-        unsigned long long newly = m & stale & __ballot(myPos <= pe);
-        if (!newly) continue;
-        int node = __builtin_amdgcn_readlane(S.tNode, e);
-        unsigned long long key = slGet64(S.tKey, e);
-        long long ex0 = (long long)slGet64((unsigned long long)S.tEx0, e), ex1 = (long long)slGet64((unsigned long long)S.tEx1, e);
-        if ((newly >> lane) & 1) { CandRec c; c.pos = pe; c.node = node; c.key = key; c.cls = m; c.ex0 = ex0; c.ex1 = ex1; c.pad = 0; g_fl.cand[lane] = c; }
-        stale &= ~newly;
-        if ((newly >> s) & 1) { found = true; end = pe + 1; break; }
-      }
-      if (found) break;
-      p0 = S.tP0 + 64;
-    }
-    if (!found && lane == s) { g_fl.cand[s].pos = N; g_fl.cand[s].node = -1; }
-    stale &= ~(1ull << s);
-    if ((stale >> lane) & 1) { if (myPos < end) g_fl.cand[lane].pos = end; if (!found) g_fl.cand[lane].node = -1; }
-    return;
-  }
   for (;;) {
     if (p0 >= N) { g_fl.cand[s].pos = N; g_fl.cand[s].node = -1; return; }
     if (!(S.tP0 >= 0 && p0 >= S.tP0 && p0 < S.tP0 + 64)) baseTileLoad(k, S, p0);
@@ -544,15 +511,13 @@ __device__ static inline void baseScan(KREF k, FastS& S, const JobTail& r) {
   }
 }
 
-// mask mode: which shapes fit a node with these level-0 key fields / extras / class bits — lane s evaluates shape s against the table in LDS
-__device__ static inline uint64_t capMask(KREF k, uint64_t clsBits, uint64_t key, int64_t ex0, int64_t ex1) {
+// mask mode: which fit shapes fit a node with these level-0 key fields / extras / class bits — lane l evaluates shapes l and l + 64 against the table in LDS
+__device__ static inline void capMask2(KREF k, uint64_t clsBits, uint64_t key, int64_t ex0, int64_t ex1, uint64_t* m0, uint64_t* m1) {
   int lane = threadIdx.x & 63;
-  bool ok = false;
-  if (lane < k.S) {
-    const ShapeReq q = SHT(lane);
-    ok = !q.never && ((clsBits >> q.cls) & 1) && fieldsGE(k, key, q.fieldMin) && q.ex0 <= ex0 && q.ex1 <= ex1;
-  }
-  return __ballot(ok);
+  bool ok0 = false, ok1 = false;
+  if (lane < k.S) { const ShapeReq q = SHT(lane); ok0 = !q.never && ((clsBits >> q.cls) & 1) && fieldsGE(k, key, q.fieldMin) && q.ex0 <= ex0 && q.ex1 <= ex1; }
+  if (lane + 64 < k.S) { const ShapeReq q = SHT(lane + 64); ok1 = !q.never && ((clsBits >> q.cls) & 1) && fieldsGE(k, key, q.fieldMin) && q.ex0 <= ex0 && q.ex1 <= ex1; }
+  *m0 = __ballot(ok0); *m1 = __ballot(ok1);
 }
 __device__ static inline uint64_t l0Search(KREF k, const JobTail& r, int* slot) {
   int lane = threadIdx.x & 63;
@@ -560,11 +525,11 @@ __device__ static inline uint64_t l0Search(KREF k, const JobTail& r, int* slot) 
   int cnt = UNI32(g_fl.l0Count);
   int rounds = (cnt + 63) >> 6;   // the same trip count on every lane: the cross-lane reduction below sees a converged wave
   if (k.maskMode) {   // one bit per entry says whether the job's shape fits: key + mask, nothing else
-    int sh = r.shape;
+    int sh = r.shape & 63; bool hi = r.shape >= 64;   // (wave-uniform: the mask word that holds the job's fit shape)
     for (int r0 = 0; r0 < rounds; r0 += 8) {   // up to 512 entries per group of loads: the usual list is searched with one LDS latency
       unsigned long long key[8], m[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) { int i = ((r0 + u) << 6) + lane, j = i < cnt ? i : 0; key[u] = g_fl.l0Key[j]; m[u] = g_fl.l0Cls[j]; }
+      for (int u = 0; u < 8; u++) { int i = ((r0 + u) << 6) + lane, j = i < cnt ? i : 0; key[u] = g_fl.l0Key[j]; m[u] = hi ? g_fl.l0Cls2[j] : g_fl.l0Cls[j]; }
 #pragma unroll
       for (int u = 0; u < 8; u++) { int i = ((r0 + u) << 6) + lane; if (i < cnt && ((m[u] >> sh) & 1) && key[u] < best) { best = key[u]; bs = i; } }
     }
@@ -1531,7 +1496,6 @@ __global__ void k_base_finish(Dev d) {
   int node = d.nodeByRank[key & ((1ull << c.idxBits) - 1)];
   d.baseNode[i] = node; d.posOf[node] = i; d.baseRemoved[i] = 0; d.baseCls[i] = d.nodeCls[node]; d.l0Slot[node] = -1;
   for (int e = 0; e < d.f.E; e++) d.baseExtra[(size_t)e * c.Npad + i] = d.alloc[(size_t)d.f.extraCol[e] * c.Npad + node];  // level 0 planes
-  if (d.f.maskMode) d.baseCls[i] = shapeFitMaskSerial(d, d.nodeCls[node], key, d.f.E > 0 ? d.alloc[(size_t)d.f.extraCol[0] * c.Npad + node] : 0, d.f.E > 1 ? d.alloc[(size_t)d.f.extraCol[1] * c.Npad + node] : 0);
 }
 
 

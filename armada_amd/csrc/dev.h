@@ -16,7 +16,7 @@
 #define LIT_TMAX 64     // node types one requirement class may match on the literal iteration path
 #define MAXAWAY 32     // away node types over all priority classes
 #define MAXE 2        // non-indexed resource columns the level-0 fast structure carries per entry
-#define SMAX 512      // scheduling-key shapes with a cached base candidate (LDS)
+#define SMAX 256      // FIT shapes with a cached base candidate (LDS); scheduling-key shapes are unlimited (their unfeasible table lives in HBM)
 #define L0CAP 1024    // live dirty nodes held in LDS
 #define QCAPF 64      // queues the fast iteration handles (one lane per queue)
 #define WIN 4         // job records prefetched per queue and refill
@@ -103,7 +103,7 @@ struct FastCfg {
   int F;                      // fit shapes: distinct (key fields, extras, requirement class) among the scheduling-key shapes — what node selection at priority -2 depends on;
                               // JobRec.shape, the candidate cache, the shape table and the fit masks are indexed by fit shape (scheduling keys that differ only in the
                               // priority class share one base cursor)
-  int maskMode;               // <= 64 fit shapes: baseCls / l0Cls / CandRec.cls hold per-shape fit masks (current capacity and requirement class folded in), not class bits
+  int maskMode;               // <= 128 fit shapes (1: <= 64, 2: <= 128) and fit bitmaps on: the L0 list holds per-node fit masks over the fit shapes; was: baseCls / l0Cls / CandRec.cls hold per-shape fit masks (current capacity and requirement class folded in), not class bits
   int engine;                 // queued-job iterations run on two waves (round_fast.h "two-wave iteration"); ASCHED_ENGINE=0 turns it off
   int E; int extraCol[MAXE];  // non-indexed columns
   uint64_t fieldMask[MAXK];   // in-place mask of each packed key field

@@ -83,7 +83,7 @@ struct alignas(16) IterBackup {  // the job's record and request stay in the mai
 struct FastLds {
   // L0: live dirty nodes (current level-0 key / non-indexed columns / class bits)
   int l0Count;
-  uint64_t l0Key[L0CAP]; int32_t l0Node[L0CAP]; int64_t l0Ex0[L0CAP], l0Ex1[L0CAP]; uint64_t l0Cls[L0CAP];
+  uint64_t l0Key[L0CAP]; int32_t l0Node[L0CAP]; int64_t l0Ex0[L0CAP], l0Ex1[L0CAP]; uint64_t l0Cls[L0CAP], l0Cls2[L0CAP];   // class bits, or (mask mode) fit masks over fit shapes 0-63 / 64-127
   CandRec cand[SMAX];   // per-shape base cursor + validated candidate
   QHot hot[QCAPF];
   int64_t qAlloc[QCAPF][MAXR], qPenalty[QCAPF][MAXR], qReplay[QCAPF][MAXR];  // resource vectors: one lane per resource
@@ -276,23 +276,9 @@ DEV bool fieldsGE(KREF k, uint64_t key, uint64_t fmin) {  // every packed field 
   for (int i = 0; i < MAXK; i++) { uint64_t m = k.fieldMask[i]; ok = ok && (key & m) >= (fmin & m); }  // unused fields have mask 0
   return ok;
 }
-// mask mode (FastCfg.maskMode): the shape table sits in the unused upper half of the candidate array (S <= 64 <= SMAX / 2)
+// mask mode (FastCfg.maskMode): the shape table sits in the unused upper half of the candidate array (F <= 128 = SMAX / 2)
 #define SHT(s) (((ShapeReq*)&FL.cand[SMAX / 2])[s])
-static_assert(sizeof(ShapeReq) == 32 && 64 * sizeof(ShapeReq) <= (SMAX / 2) * sizeof(CandRec), "shape table fits behind the candidates");
-// fit mask of a node from scratch (per-thread loop over the shapes): class bits + level-0 key and extras -> bit s = a job of shape s fits
-HD uint64_t shapeFitMaskSerial(const Dev& d, uint64_t clsBits, uint64_t key, int64_t ex0, int64_t ex1) {
-  uint64_t m = 0;
-  for (int s = 0; s < d.f.F && s < 64; s++) {
-    const ShapeReq q = d.shapeTab[s];
-    bool ok = !q.never && ((clsBits >> q.cls) & 1) && q.ex0 <= ex0 && q.ex1 <= ex1;
-    if (ok) {
-      if (d.f.guardMask) ok = (((key | d.f.guardMask) - q.fieldMin) & d.f.guardMask) == d.f.guardMask;
-      else for (int i = 0; i < MAXK; i++) { uint64_t fm = d.f.fieldMask[i]; ok = ok && (key & fm) >= (q.fieldMin & fm); }
-    }
-    if (ok) m |= 1ull << s;
-  }
-  return m;
-}
+static_assert(sizeof(ShapeReq) == 32 && 128 * sizeof(ShapeReq) <= (SMAX / 2) * sizeof(CandRec) && SMAX / 2 >= 128, "shape table fits behind the candidates");
 // one word of the fit bitmap: base entries [64 w, 64 w + 64) against fit shape f, at base build time (every entry is clean)
 HD uint64_t fitBitsWord(const Dev& d, int f, int w) {
   const ShapeReq q = d.shapeTab[f];
@@ -313,7 +299,6 @@ HD uint64_t fitBitsWord(const Dev& d, int f, int w) {
   return m;
 }
 DEV bool entryFits(KREF k, const JobTail& r, uint64_t key, int64_t ex0, int64_t ex1, uint64_t cls) {
-  if (k.maskMode) return ((cls >> r.shape) & 1) != 0;   // cls is the entry's fit mask: capacity and requirement class already folded in
   bool ok = ((cls >> r.cls) & 1) != 0;      // StaticJobRequirementsMet via the requirement class (nodematching.go:161-183)
   ok = ok && fieldsGE(k, key, r.fieldMin);  // indexed columns: alloc/res >= req/res (both resolution-aligned)
   ok = ok && r.ex0 <= ex0 && r.ex1 <= ex1;  // non-indexed columns (nodematching.go:194-197); unused extras are 0 vs 0
@@ -446,29 +431,6 @@ DEV void baseScan(KREF k, FastS& S, const JobTail& r) {
     FL.cand[s].pos = k.N; FL.cand[s].node = -1;
     return;
   }
-  if (k.maskMode) {
-    int pStart = FL.cand[s].pos, end = k.N;
-    uint64_t stale = 0;
-    for (int t = 0; t < k.S && t < 64; t++) if (t == s || (FL.cand[t].node == -2 && FL.cand[t].pos >= pStart)) stale |= 1ull << t;
-    bool found = false;
-    for (int p = pStart; p < k.N && !found; p++) {
-      if (k.baseRemoved[p]) continue;
-      uint64_t m = k.baseCls[p];
-      uint64_t newly = 0;
-      for (int t = 0; t < k.S && t < 64; t++) if (((stale >> t) & 1) && ((m >> t) & 1) && FL.cand[t].pos <= p) newly |= 1ull << t;
-      if (!newly) continue;
-      for (int t = 0; t < 64; t++) if ((newly >> t) & 1) {
-        CandRec& c = FL.cand[t];
-        c.pos = p; c.node = k.baseNode[p]; c.key = k.baseKey[p]; c.cls = m; c.ex0 = k.E > 0 ? k.baseExtra[p] : 0; c.ex1 = k.E > 1 ? k.baseExtra[k.Npad + p] : 0;
-      }
-      stale &= ~newly;
-      if ((newly >> s) & 1) { found = true; end = p + 1; }
-    }
-    S.statScanSteps++;
-    if (!found) { FL.cand[s].pos = k.N; FL.cand[s].node = -1; stale &= ~(1ull << s); }
-    for (int t = 0; t < 64; t++) if (((stale >> t) & 1) && t != s) { if (FL.cand[t].pos < end) FL.cand[t].pos = end; if (!found) FL.cand[t].node = -1; }
-    return;
-  }
   static long hsScans = 0, hsRemoved = 0, hsUnfit = 0, hsTiles = 0; static bool hsDump = getenv("HS_SCAN_STATS") != nullptr;
   if (hsDump) { hsScans++; if ((hsScans % 20000) == 0) fprintf(stderr, "base scans %ld: removed entries walked %ld, clean unfit walked %ld, 64-entry tiles touched %ld\n", hsScans, hsRemoved, hsUnfit, hsTiles); }
   int hsP0 = FL.cand[s].pos;
@@ -487,7 +449,10 @@ DEV void baseScan(KREF k, FastS& S, const JobTail& r) {
 DEV uint64_t l0Search(KREF k, const JobTail& r, int* slot) {
   uint64_t best = ~0ull; *slot = -1;
   for (int i = 0; i < FL.l0Count; i++)
-    if (FL.l0Key[i] < best && entryFits(k, r, FL.l0Key[i], FL.l0Ex0[i], FL.l0Ex1[i], FL.l0Cls[i])) { best = FL.l0Key[i]; *slot = i; }
+  {
+    bool fits = k.maskMode ? (((r.shape < 64 ? FL.l0Cls[i] : FL.l0Cls2[i]) >> (r.shape & 63)) & 1) != 0 : entryFits(k, r, FL.l0Key[i], FL.l0Ex0[i], FL.l0Ex1[i], FL.l0Cls[i]);
+    if (FL.l0Key[i] < best && fits) { best = FL.l0Key[i]; *slot = i; }
+  }
   return best;
 }
 // load jobs [pos, pos+cnt) of a queue stream (kind 0: evicted list, 1: queued list) into the queue's window
@@ -582,10 +547,12 @@ DEV bool pinnedNodeFits(KREF k, int q, int n, int level) {
 DEV void pqHeadKey(PQState&, int t, PackedKey* key, uint32_t* nameRank) { key->A = FL.kA[t]; key->X = FL.kX[t]; key->Y = FL.kY[t]; *nameRank = (uint32_t)FL.nameRank[t]; }
 // ---- stream run, serial build.  The engine serves an entry when its record is staged, so that entries emitted but not yet staged when a job
 // does not fit are discarded exactly as on the device (there the engine runs behind the merge by up to a ring's worth of entries).
-DEV uint64_t capMask(KREF k, uint64_t clsBits, uint64_t key, int64_t ex0, int64_t ex1) {
-  uint64_t m = 0;
-  for (int s = 0; s < k.S && s < 64; s++) { const ShapeReq q = SHT(s); if (!q.never && ((clsBits >> q.cls) & 1) && fieldsGE(k, key, q.fieldMin) && q.ex0 <= ex0 && q.ex1 <= ex1) m |= 1ull << s; }
-  return m;
+DEV void capMask2(KREF k, uint64_t clsBits, uint64_t key, int64_t ex0, int64_t ex1, uint64_t* m0, uint64_t* m1) {
+  *m0 = 0; *m1 = 0;
+  for (int s = 0; s < k.S && s < 128; s++) {
+    const ShapeReq q = SHT(s);
+    if (!q.never && ((clsBits >> q.cls) & 1) && fieldsGE(k, key, q.fieldMin) && q.ex0 <= ex0 && q.ex1 <= ex1) { if (s < 64) *m0 |= 1ull << s; else *m1 |= 1ull << (s - 64); }
+  }
 }
 struct StreamLanes { int start[QCAPF], base[QCAPF], pos[QCAPF], len[QCAPF], kind[QCAPF], ws[QCAPF]; double budget[QCAPF]; uint32_t effA[QCAPF]; uint64_t effX[QCAPF], effY[QCAPF]; };
 #define SL_SET(sl, f, q, v) ((sl).f[q] = (v))
@@ -680,7 +647,7 @@ DEV void streamStageCommit(Dev& d, KREF k, int base, int cnt, unsigned long long
 DEV void streamEnd(int engSeq);
 DEV void streamAccount(Dev& d, KREF k, int i0, int i1);   // ring entries [i0, i1): sctx / qctx sums, FL.tmpQ[queue] counts them
 DEV void baseMarkRemoved(KREF k, FastS& S, int pos);   // base entry pos is stale from now on: flag + its bit in every fit shape's bitmap
-DEV uint64_t capMask(KREF k, uint64_t clsBits, uint64_t key, int64_t ex0, int64_t ex1);   // mask mode: bit s = shape s fits (lane s evaluates shape s)
+DEV void capMask2(KREF k, uint64_t clsBits, uint64_t key, int64_t ex0, int64_t ex1, uint64_t* m0, uint64_t* m1);   // mask mode: which fit shapes fit (lane l evaluates shapes l and l + 64)
 DEV int streamAcked(int* fail);
 DEV int streamBound();   // entries whose ring slot is free again (the bind wave has read them)
 DEV void wgBulk(Dev& d, int kind, int n);
@@ -704,10 +671,10 @@ DEV void fastEnterGeneric(Dev& d, Ctl& c) {
 }
 
 // ------------------------------------------------------------------------------------------------ L0 maintenance
-DEV bool l0Insert(KREF k, int n, uint64_t key, int64_t ex0, int64_t ex1, uint64_t cls) {
+DEV bool l0Insert(KREF k, int n, uint64_t key, int64_t ex0, int64_t ex1, uint64_t cls, uint64_t cls2 = 0) {
   int i = FL.l0Count;
   if (i >= L0CAP) return false;
-  FL.l0Key[i] = key; FL.l0Node[i] = n; FL.l0Cls[i] = cls; FL.l0Ex0[i] = ex0; FL.l0Ex1[i] = ex1;
+  FL.l0Key[i] = key; FL.l0Node[i] = n; FL.l0Cls[i] = cls; FL.l0Cls2[i] = cls2; FL.l0Ex0[i] = ex0; FL.l0Ex1[i] = ex1;
   FL.l0Count = i + 1;
   if (FLANE == 0) k.l0Slot[n] = i;
   return true;
@@ -717,7 +684,7 @@ DEV void l0Remove(KREF k, int slot) {
   int n = FL.l0Node[slot];
   if (FLANE == 0) k.l0Slot[n] = -1;
   if (slot != last) {
-    FL.l0Key[slot] = FL.l0Key[last]; FL.l0Node[slot] = FL.l0Node[last]; FL.l0Cls[slot] = FL.l0Cls[last];
+    FL.l0Key[slot] = FL.l0Key[last]; FL.l0Node[slot] = FL.l0Node[last]; FL.l0Cls[slot] = FL.l0Cls[last]; FL.l0Cls2[slot] = FL.l0Cls2[last];
     FL.l0Ex0[slot] = FL.l0Ex0[last]; FL.l0Ex1[slot] = FL.l0Ex1[last];
     if (FLANE == 0) k.l0Slot[FL.l0Node[slot]] = slot;
   }
@@ -734,14 +701,14 @@ DEV void fastTouch(Dev& d, int n) {
   int pos = GA(int32_t, d.posOf)[n], slot = k.l0Slot[n];
   { FastS TS; TS.tP0 = -1; baseMarkRemoved(k, TS, pos); }
   candInvalidate(k.S, n);
-  uint64_t cls = GA(uint64_t, d.nodeCls)[n];
+  uint64_t cls = GA(uint64_t, d.nodeCls)[n], cls2 = 0;
   bool live;
-  if (k.maskMode) { cls = capMask(k, cls, key, ex0, ex1); live = cls != 0; }
+  if (k.maskMode) { capMask2(k, cls, key, ex0, ex1, &cls, &cls2); live = (cls | cls2) != 0; }
   else live = entryLive(k, key, ex0, ex1);
   if (slot >= 0) {
-    if (live) { FL.l0Key[slot] = key; FL.l0Ex0[slot] = ex0; FL.l0Ex1[slot] = ex1; if (k.maskMode) FL.l0Cls[slot] = cls; }
+    if (live) { FL.l0Key[slot] = key; FL.l0Ex0[slot] = ex0; FL.l0Ex1[slot] = ex1; if (k.maskMode) { FL.l0Cls[slot] = cls; FL.l0Cls2[slot] = cls2; } }
     else l0Remove(k, slot);
-  } else if (live && !l0Insert(k, n, key, ex0, ex1, cls)) fastDrop(d);
+  } else if (live && !l0Insert(k, n, key, ex0, ex1, cls, cls2)) fastDrop(d);
 }
 
 // first fit at priority -2 for a job record; -1 none; handle says where the winner came from
@@ -785,23 +752,25 @@ DEV bool fastAfterBind(KREF k, FastS& S, const JobTail& r, int n, const FitHandl
     baseMarkRemoved(k, S, c.pos);
     baseTileRemoved(k, S, c.pos);
     candInvalidate(k.S, n);
-    uint64_t cls = c.cls;
+    uint64_t cls = c.cls, cls2 = 0;   // (the base entry's class bits)
     bool live;
-    if (k.maskMode) { cls &= capMask(k, ~0ull, key, ex0, ex1); live = cls != 0; }   // a bind only takes capacity away: the shapes that still fit are among those that did
+    if (k.maskMode) { capMask2(k, cls, key, ex0, ex1, &cls, &cls2); live = (cls | cls2) != 0; }   // which fit shapes the node can still host
     else live = entryLive(k, key, ex0, ex1);
     if (live) {
-      if (!l0Insert(k, n, key, ex0, ex1, cls)) return false;
+      if (!l0Insert(k, n, key, ex0, ex1, cls, cls2)) return false;
       if (FL.l0Count > S.statL0Max) S.statL0Max = FL.l0Count;
     }
   } else {
     int slot = h.slot;
     uint64_t key = FL.l0Key[slot] - r.keyDelta;
     int64_t ex0 = FL.l0Ex0[slot] - r.ex0, ex1 = FL.l0Ex1[slot] - r.ex1;
-    uint64_t cls = 0;
+    uint64_t cls = 0, cls2 = 0;
     bool live;
-    if (k.maskMode) { cls = UNI64(FL.l0Cls[slot]) & capMask(k, ~0ull, key, ex0, ex1); live = cls != 0; }
-    else live = entryLive(k, key, ex0, ex1);
-    if (live) { FL.l0Key[slot] = key; FL.l0Ex0[slot] = ex0; FL.l0Ex1[slot] = ex1; if (k.maskMode) FL.l0Cls[slot] = cls; }
+    if (k.maskMode) {   // a bind only takes capacity away: the shapes that still fit are among those that did
+      capMask2(k, ~0ull, key, ex0, ex1, &cls, &cls2);
+      cls &= UNI64(FL.l0Cls[slot]); cls2 &= UNI64(FL.l0Cls2[slot]); live = (cls | cls2) != 0;
+    } else live = entryLive(k, key, ex0, ex1);
+    if (live) { FL.l0Key[slot] = key; FL.l0Ex0[slot] = ex0; FL.l0Ex1[slot] = ex1; if (k.maskMode) { FL.l0Cls[slot] = cls; FL.l0Cls2[slot] = cls2; } }
     else l0Remove(k, slot);
   }
   return true;
@@ -857,9 +826,9 @@ DEV void fastLoad(Dev& d) {  // kernel start: rebuild the LDS side from HBM
   int cnt = RS.l0SaveCount;
   for (int i = 0; i < cnt; i++) {
     int n = d.l0Save[i];
-    uint64_t key = KKEY(k, 0, n), cls = d.nodeCls[n]; int64_t ex0 = k.E > 0 ? KAL(k, 0, k.ex0col, n) : 0, ex1 = k.E > 1 ? KAL(k, 0, k.ex1col, n) : 0;
-    if (k.maskMode) cls = capMask(k, cls, key, ex0, ex1);
-    l0Insert(k, n, key, ex0, ex1, cls);
+    uint64_t key = KKEY(k, 0, n), cls = d.nodeCls[n], cls2 = 0; int64_t ex0 = k.E > 0 ? KAL(k, 0, k.ex0col, n) : 0, ex1 = k.E > 1 ? KAL(k, 0, k.ex1col, n) : 0;
+    if (k.maskMode) capMask2(k, cls, key, ex0, ex1, &cls, &cls2);
+    l0Insert(k, n, key, ex0, ex1, cls, cls2);
   }
 }
 DEV void fastSave(Dev& d) {  // kernel end

@@ -158,7 +158,6 @@ static int plat_build_base(Dev& d) {
     int node = d.nodeByRank[keys[i] & mask];
     d.baseKey[i] = keys[i]; d.baseNode[i] = node; d.posOf[node] = i; d.baseRemoved[i] = 0; d.baseCls[i] = d.nodeCls[node]; d.l0Slot[node] = -1;
     for (int e = 0; e < d.f.E; e++) d.baseExtra[(size_t)e * c.Npad + i] = AL(d, 0, d.f.extraCol[e], node);
-    if (d.f.maskMode) d.baseCls[i] = shapeFitMaskSerial(d, d.nodeCls[node], keys[i], d.f.E > 0 ? AL(d, 0, d.f.extraCol[0], node) : 0, d.f.E > 1 ? AL(d, 0, d.f.extraCol[1], node) : 0);
   }
   if (d.fitBits) for (int f = 0; f < d.f.F; f++) for (int w = 0; w < d.fitW; w++) d.fitBits[(size_t)f * d.fitW + w] = fitBitsWord(d, f, w);
   return 0;
