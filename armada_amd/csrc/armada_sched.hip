@@ -859,10 +859,9 @@ __device__ static void engineLoop(Dev& d) {  // wave 1
     if (cmd == ENG_STREAM) {
       // walk the ring: entry i is ready when ringPub > i; stop at the first job that finds no node (ringFail 1), after an L0 overflow (2), or when the
       // control wave has closed the ring and everything staged is bound
-      int i = 0;
+      int i = 0, pub = 0;
       for (;;) {
-        int pub;
-        for (;;) {
+        while (pub <= i) {   // (the counter is read again only when the entries known to be staged are used up)
           pub = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringPub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
           if (pub > i) break;
           int end = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringEnd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));

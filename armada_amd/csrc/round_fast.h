@@ -832,6 +832,18 @@ DEV void fastLoad(Dev& d) {  // kernel start: rebuild the LDS side from HBM
   }
 }
 DEV void fastSave(Dev& d) {  // kernel end
+#ifdef ASCHED_HOSTSIM
+  if (getenv("HS_L0_STATS") && d.f.structOk && RS.fastActive && d.shapeTab) {
+    const FastK k = fastKRef(d);
+    int dead = 0;
+    for (int i = 0; i < FL.l0Count; i++) {
+      bool any = false;
+      for (int s = 0; s < d.f.F && !any; s++) { const ShapeReq q = d.shapeTab[s]; any = !q.never && fieldsGE(k, FL.l0Key[i], q.fieldMin) && q.ex0 <= FL.l0Ex0[i] && q.ex1 <= FL.l0Ex1[i]; }
+      if (!any) dead++;
+    }
+    fprintf(stderr, "L0 at kernel end: %d entries, %d fit no shape (max %d)\n", FL.l0Count, dead, RS.statL0Max);
+  }
+#endif
   if (!d.f.structOk || !RS.fastActive) { RS.l0SaveCount = 0; return; }
   candSaveAll(d, d.candPosSave);
   for (int i = 0; i < FL.l0Count; i++) d.l0Save[i] = FL.l0Node[i];
