@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstring>
+#include <type_traits>
 #include <string>
 #include <unistd.h>
 #include <vector>
@@ -539,20 +540,26 @@ __device__ static inline uint64_t l0Search(KREF k, const JobTail& r, int* slot) 
     *slot = __builtin_amdgcn_readlane(bs, __ffsll((long long)who) - 1);
     return mn;
   }
-  for (int r0 = 0; r0 < rounds; r0 += 4) {
-    // four rounds of loads issued together (entries past the end read slot 0 and are masked): the LDS latency is paid once per group, not per round
-    unsigned long long key[4], cls[4]; long long e0[4], e1[4];
+  // groups of 4, 2, 1 rounds: the loads of a group are issued together (the LDS latency is paid once per group) and only as many rounds as the list has are
+  // loaded and tested — late in a round the list is short (140 entries on average on configs[2], 377 over the first quarter)
+  auto group = [&](int r0, auto W) {
+    constexpr int G = decltype(W)::value;
+    unsigned long long key[G], cls[G]; long long e0[G], e1[G];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < G; u++) {
       int i = ((r0 + u) << 6) + lane, j = i < cnt ? i : 0;
       key[u] = g_fl.l0Key[j]; e0[u] = g_fl.l0Ex0[j]; e1[u] = g_fl.l0Ex1[j]; cls[u] = g_fl.l0Cls[j];
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < G; u++) {
       int i = ((r0 + u) << 6) + lane;
       if (i < cnt && key[u] < best && entryFits(k, r, key[u], e0[u], e1[u], cls[u])) { best = key[u]; bs = i; }
     }
-  }
+  };
+  int r0 = 0;
+  for (; r0 + 4 <= rounds; r0 += 4) group(r0, std::integral_constant<int, 4>{});
+  if (r0 + 2 <= rounds) { group(r0, std::integral_constant<int, 2>{}); r0 += 2; }
+  if (r0 < rounds) group(r0, std::integral_constant<int, 1>{});
   unsigned long long mn = waveMin64Dpp(best);   // keys are unique (node-index rank in the low bits): the lane that holds the minimum names the slot
   if (mn == ~0ull) { *slot = -1; return mn; }
   unsigned long long who = __ballot(best == mn);

@@ -448,6 +448,7 @@ DEV void baseScan(KREF k, FastS& S, const JobTail& r) {
 }
 DEV uint64_t l0Search(KREF k, const JobTail& r, int* slot) {
   uint64_t best = ~0ull; *slot = -1;
+  { static long calls = 0, sum = 0, hits = 0; static bool dump = getenv("HS_L0_STATS") != nullptr; if (dump) { calls++; sum += FL.l0Count; if ((calls % 50000) == 0) fprintf(stderr, "l0Search calls %ld avg entries %.1f\n", calls, (double)sum / calls); } (void)hits; }
   for (int i = 0; i < FL.l0Count; i++)
   {
     bool fits = k.maskMode ? (((r.shape < 64 ? FL.l0Cls[i] : FL.l0Cls2[i]) >> (r.shape & 63)) & 1) != 0 : entryFits(k, r, FL.l0Key[i], FL.l0Ex0[i], FL.l0Ex1[i], FL.l0Cls[i]);
