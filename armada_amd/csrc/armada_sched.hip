@@ -30,7 +30,8 @@
 
 // ------------------------------------------------------------------------------------------------ device primitives
 #define CTL_THREADS 256
-enum { OP_EXIT = 0, OP_SCAN = 1, OP_BULK = 2, OP_COMPACT = 3, OP_FAIR = 4, OP_ENGINE = 5, OP_HELPERS_EXIT = 9 };
+enum { OP_EXIT = 0, OP_SCAN = 1, OP_BULK = 2, OP_COMPACT = 3, OP_FAIR = 4, OP_ENGINE = 5, OP_BULKW = 6, OP_HELPERS_EXIT = 9 };
+struct BulkWArgs { int32_t kind, n; };   // a bulk pass whose bodies touch HBM only: shared with the helper workgroups
 
 struct Mailbox {
   int op, kind, n;
@@ -208,6 +209,18 @@ __device__ static inline int wgFairSelect(Dev& d, const FairArgs& a) {
     best = h > best ? h : best;
   }
   return best;
+}
+
+// A bulk pass over n elements on the control workgroup AND the helper workgroups (grid-stride over all of them).  Only for bodies that read and write HBM and
+// nothing the control workgroup keeps in LDS (the stream preparation, round_run.h B_QS*): the helpers see the kernel argument's Dev, i.e. the HBM homes.
+__device__ static inline void wgBulkWide(Dev& d, int kind, int n) {
+  int lane = threadIdx.x & 63;
+  if (lane == 0) { g_mb.op = OP_BULKW; g_mb.kind = kind; g_mb.n = n; if (g_H) { BulkWArgs a; a.kind = kind; a.n = n; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); helpIssue(OP_BULKW, &a); } }
+  __syncthreads();
+  { int nthreads = (g_H + 1) * (int)blockDim.x; int kd = g_mb.kind, nn = g_mb.n; for (int i = threadIdx.x; i < nn; i += nthreads) bulkElem(d, kd, i); }
+  __threadfence();
+  __syncthreads();
+  if (g_H) { (void)helpWait(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 }
 
 // Most elements of the per-job passes do nothing (queued jobs have no node, few jobs are flagged for eviction): read the one
@@ -1200,6 +1213,11 @@ __device__ static void helperMain(const Dev& d, HelpBox* b, int H) {
       FairArgs a = helpArgs<FairArgs>(b);
       int v = fairPart(d, a, tid, nthreads);
       if (lane == 0 && v >= 0) __hip_atomic_fetch_max(&g_hMax, (unsigned long long)(v + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (op == OP_BULKW) {
+      BulkWArgs a = helpArgs<BulkWArgs>(b);
+      Dev& dm = const_cast<Dev&>(d);
+      for (int i = tid; i < a.n; i += nthreads) bulkElem(dm, a.kind, i);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // this workgroup's writes before its completion count
     }
     if (lane == 0) {
       unsigned int before = __hip_atomic_fetch_add(&g_hArrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1242,6 +1260,10 @@ __global__ __launch_bounds__(CTL_THREADS) void k_control(Dev dev, int cmd, HelpB
         if ((threadIdx.x & 63) == 0) g_mb.waveCount[threadIdx.x >> 6] = v;
       } else if (op == OP_BULK) {
         bulkPart(d, g_mb.kind, g_mb.n);
+      } else if (op == OP_BULKW) {
+        int nthreads = (g_H + 1) * (int)blockDim.x; int kd = g_mb.kind, nn = g_mb.n;
+        for (int i = threadIdx.x; i < nn; i += nthreads) bulkElem(d, kd, i);
+        __threadfence();
       } else if (op == OP_COMPACT) {
         compactPart(d);
       } else if (op == OP_ENGINE) {
@@ -1928,6 +1950,10 @@ __global__ __launch_bounds__(CTL_THREADS) void k_control_aux(Dev dev, int cmd, H
         if ((threadIdx.x & 63) == 0) g_mb.waveCount[threadIdx.x >> 6] = v;
       } else if (op == OP_BULK) {
         bulkPart(d, g_mb.kind, g_mb.n);
+      } else if (op == OP_BULKW) {
+        int kd = g_mb.kind, nn = g_mb.n;
+        for (int i = threadIdx.x; i < nn; i += (int)blockDim.x) bulkElem(d, kd, i);
+        __threadfence();
       } else if (op == OP_COMPACT) {
         compactPart(d);
       } else if (op == OP_ENGINE) {

@@ -15,6 +15,7 @@ enum BulkKind {
 };
 
 DEV void wgBulk(Dev& d, int kind, int n);  // every element i in [0,n) through bulkElem(), then a workgroup barrier
+DEV void wgBulkWide(Dev& d, int kind, int n);  // the same with the helper workgroups taking their share (bodies that touch HBM only)
 DEV int wgCompactFlagged(Dev& d, const int32_t* order, const int32_t* segOff, int nseg, int n, const uint8_t* flag, int32_t* dst, int32_t* outSegOff);
 DEV int wgCompactIota(Dev& d, int n, const uint8_t* flag, int32_t* dst);
 
@@ -622,9 +623,9 @@ DEV_NOINLINE int fastStreamPrepare(Dev& d, FastCtx fc, int Q, int allowed, int a
   for (int q = 0; q < Q; q++) if (UNI32(FL.tmpQ[q]) == 2) bulk++;
   if (bulk) {
     if (!allowBulk) return 2;
-    wgBulk(d, B_QSSUM, Q * QS_CPQ);
-    wgBulk(d, B_QSSTITCH, Q);
-    wgBulk(d, B_QSKEYS, Q * QS_CPQ);
+    wgBulkWide(d, B_QSSUM, Q * QS_CPQ);
+    wgBulkWide(d, B_QSSTITCH, Q);
+    wgBulkWide(d, B_QSKEYS, Q * QS_CPQ);
     int total = 0;
     FOR_LANES(q, Q) if (FL.tmpQ[q] == 2) { int len = d.qsLen[2 * q]; FL.hot[q].sLen = len; FL.hot[q].sPos = 0; FL.sKind[q] = 0; FL.hot[q].ewCount = 0; FL.hot[q].ewStart = 0; }
     for (int q = 0; q < Q; q++) if (UNI32(FL.tmpQ[q]) == 2) total += d.qsLen[2 * q];
