@@ -444,26 +444,7 @@ __device__ static inline void fastFence(Ctl& c) {
   if (c.l1Dirty) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); c.l1Dirty = 0; }  // vmcnt(0) + L1 invalidate: the no-return atomics are now what plain loads see
 }
 
-// 64 base positions per step, coalesced (keys, removed flags, extras, class bits all stored in base order).  The tile read
-// last stays in registers (FastS::t*): the rescans that follow a bind start at the removed position, i.e. inside it.
-__device__ static inline void baseTileLoad(KREF k, FastS& S, int p0) {
-  int lane = threadIdx.x & 63;
-#ifdef ASCHED_FASTPROF
-  if (lane == 0) g_rs.statSeg[4] += 1000;   // profiling: tile loads
-#endif
-  int p = p0 + lane;
-  S.tP0 = p0; S.tKey = 0; S.tCls = 0; S.tNode = -1; S.tRem = 1; S.tEx0 = 0; S.tEx1 = 0;
-  if (p < k.N) {
-    S.tKey = k.baseKey[p]; S.tCls = k.baseCls[p]; S.tNode = k.baseNode[p]; S.tRem = k.baseRemoved[p];
-    if (k.E > 0) S.tEx0 = k.baseExtra[p];
-    if (k.E > 1) S.tEx1 = k.baseExtra[k.Npad + p];
-  }
-}
-__device__ static inline void baseTileRemoved(KREF k, FastS& S, int pos) {
-  int lane = threadIdx.x & 63;
-  if (S.tP0 >= 0 && pos >= S.tP0 && pos < S.tP0 + 64) { if (lane == pos - S.tP0) S.tRem = 1; }
-  else baseTileLoad(k, S, pos);  // issued now, consumed by the next scan: the HBM latency overlaps the rest of the iteration
-}
+__device__ static inline void baseTileRemoved(KREF, FastS&, int) {}   // (the tile walk of ASCHED_FIT_BITS=0 keeps nothing between scans)
 // base entry pos is stale from now on: its flag, and its bit in every fit shape's "clean and fits" bitmap (lane f clears row f; no-return atomics at L2 —
 // the scans read the bitmaps with agent-scope loads, so every wave sees them)
 __device__ static inline void baseMarkRemoved(KREF k, FastS& S, int pos) {
@@ -508,20 +489,29 @@ __device__ static inline void baseScan(KREF k, FastS& S, const JobTail& r) {
       return;
     }
   }
-  for (;;) {
+  for (;;) {   // ASCHED_FIT_BITS=0: walk the base 64 entries at a time (keys, removed flags, extras, class bits are stored in base order: coalesced)
     if (p0 >= N) { g_fl.cand[s].pos = N; g_fl.cand[s].node = -1; return; }
-    if (!(S.tP0 >= 0 && p0 >= S.tP0 && p0 < S.tP0 + 64)) baseTileLoad(k, S, p0);
-    bool ok = S.tP0 + lane >= p0 && !S.tRem && entryFits(k, r, S.tKey, S.tEx0, S.tEx1, S.tCls);
+#ifdef ASCHED_FASTPROF
+    if (lane == 0) g_rs.statSeg[4] += 1000;   // profiling: tile loads
+#endif
+    int p = p0 + lane;
+    unsigned long long tKey = 0, tCls = 0; int tNode = -1, tRem = 1; long long tEx0 = 0, tEx1 = 0;
+    if (p < N) {
+      tKey = k.baseKey[p]; tCls = k.baseCls[p]; tNode = k.baseNode[p]; tRem = k.baseRemoved[p];
+      if (k.E > 0) tEx0 = k.baseExtra[p];
+      if (k.E > 1) tEx1 = k.baseExtra[k.Npad + p];
+    }
+    bool ok = !tRem && entryFits(k, r, tKey, tEx0, tEx1, tCls);
     unsigned long long b = __ballot(ok);
     S.statScanSteps++;
     if (b) {
       int f = __ffsll((long long)b) - 1;
       CandRec c;
-      c.pos = S.tP0 + f; c.node = __shfl(S.tNode, f, 64); c.key = __shfl(S.tKey, f, 64); c.cls = __shfl(S.tCls, f, 64); c.ex0 = __shfl(S.tEx0, f, 64); c.ex1 = __shfl(S.tEx1, f, 64); c.pad = 0;
+      c.pos = p0 + f; c.node = __shfl(tNode, f, 64); c.key = __shfl(tKey, f, 64); c.cls = __shfl(tCls, f, 64); c.ex0 = __shfl(tEx0, f, 64); c.ex1 = __shfl(tEx1, f, 64); c.pad = 0;
       g_fl.cand[s] = c;
       return;
     }
-    p0 = S.tP0 + 64;
+    p0 += 64;
   }
 }
 
@@ -846,7 +836,7 @@ __device__ static void engineLoop(Dev& d) {  // wave 1
   const FastK k = fastKRef(d);
   int lane = threadIdx.x & 63;
   FastS ES;
-  ES.tP0 = -1; ES.engLive = 0; ES.engPend = -1;
+   ES.engLive = 0; ES.engPend = -1;
   ES.laneL = lane / (k.R > 0 ? k.R : 1); ES.laneX = lane % (k.R > 0 ? k.R : 1);
   ES.statScanSteps = 0; ES.statL0Max = __builtin_amdgcn_readfirstlane(g_fl.eng.statL0Max);
   ES.fastActive = 1; ES.engSeq = 0;
@@ -929,7 +919,7 @@ __device__ static void bindLoop(Dev& d) {
   const FastK k = fastKRef(d);
   int lane = threadIdx.x & 63;
   FastS BS;
-  BS.tP0 = -1; BS.laneL = lane / (k.R > 0 ? k.R : 1); BS.laneX = lane % (k.R > 0 ? k.R : 1);
+   BS.laneL = lane / (k.R > 0 ? k.R : 1); BS.laneX = lane % (k.R > 0 ? k.R : 1);
 #ifdef ASCHED_FASTPROF
   for (int i = 0; i < 8; i++) BS.eseg[i] = 0;
   BS.segT = 0;

@@ -214,9 +214,6 @@ struct FastS {
   int32_t numUnfeasible, numPreemptedMarks, fastActive, lvl0NonNeg, replayPending;
   int32_t statFastIters, statScanSteps, statRefills, statL0Max, statFastReplay;
   long long segT;
-  // device only: the last base tile read (64 consecutive entries, one per lane), kept in registers; a removal inside it is
-  // patched in place, a removal outside re-targets it, so the rescans that follow a bind find their entries without a load
-  int tP0; int tNode, tRem; unsigned long long tKey, tCls; long long tEx0, tEx1;
   int laneL, laneX;  // device only: this lane's (level offset, resource) in a bind: lane = laneL * R + laneX
   long long engWaitClk;  // ticks this wave spent waiting for the engine's verdict
   int engSeq;            // commands posted to the engine in this session
@@ -700,7 +697,7 @@ DEV void fastTouch(Dev& d, int n) {
   uint64_t key = KKEY(k, 0, n);
   int64_t ex0 = k.E > 0 ? KAL(k, 0, k.ex0col, n) : 0, ex1 = k.E > 1 ? KAL(k, 0, k.ex1col, n) : 0;
   int pos = GA(int32_t, d.posOf)[n], slot = k.l0Slot[n];
-  { FastS TS; TS.tP0 = -1; baseMarkRemoved(k, TS, pos); }
+  { FastS TS;  baseMarkRemoved(k, TS, pos); }
   candInvalidate(k.S, n);
   uint64_t cls = GA(uint64_t, d.nodeCls)[n], cls2 = 0;
   bool live;
@@ -736,7 +733,7 @@ DEV int fastFirstFit(KREF k, FastS& S, const JobTail& r, FitHandle* h, CandRec* 
 DEV int fastSelectLevel0(Dev& d, int job) {
   if (!d.f.structOk || !RS.fastActive) return -2;
   const FastK k = fastKRef(d);
-  FastS S; S.statScanSteps = 0; S.tP0 = -1;
+  FastS S; S.statScanSteps = 0; 
   JobRec jr = d.jrec[job];
   JobTail r; memcpy(&r, &jr.keyDelta, sizeof r);
   FitHandle h; CandRec c;
@@ -794,7 +791,7 @@ DEV bool fastGangMember(Dev& d, Ctl& c, int job) {
   uniJobTail(r);
   if (r.never) return false;
   if (k.anyDisallowed) for (int x = 0; x < k.R; x++) if (d.cfg.disallowed[x] && jr.req[x] > 0) return false;
-  FastS S; S.statScanSteps = 0; S.tP0 = -1; S.statL0Max = RS.statL0Max;
+  FastS S; S.statScanSteps = 0;  S.statL0Max = RS.statL0Max;
   S.laneL = FLANE / (k.R > 0 ? k.R : 1); S.laneX = FLANE % (k.R > 0 ? k.R : 1);
   FitHandle h; h.src = 0; h.slot = -1;
   CandRec cand; cand.pos = 0; cand.node = -1; cand.key = 0; cand.cls = 0; cand.ex0 = cand.ex1 = 0; cand.pad = 0;
@@ -1255,7 +1252,7 @@ DEV int fastReplayStep(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, int
 // current head are taken back (applyEvictedRange sign -1) and become ordinary heads again, which reproduces the exact state.
 struct SkipDelta { int evicted, iters, refills; };  // what a cold helper changed of the scheduling-context scalars the loop keeps in registers
 DEV void coldS(Dev& d, FastS& S) {
-  S.tP0 = -1; S.laneL = 0; S.laneX = 0; S.numEvictedJobs = 0; S.loopIterations = 0; S.statRefills = 0; S.statScanSteps = 0; S.statL0Max = 0;
+   S.laneL = 0; S.laneX = 0; S.numEvictedJobs = 0; S.loopIterations = 0; S.statRefills = 0; S.statScanSteps = 0; S.statL0Max = 0;
   S.numUnfeasible = RS.numUnfeasible; S.numPreemptedMarks = RS.numPreemptedMarks; S.fastActive = RS.fastActive; S.lvl0NonNeg = RS.lvl0NonNeg; S.replayPending = RS.replayPending;
   S.globalTokens = 0; S.globalBurst = 0; S.globalRateInf = 1; S.numScheduledJobs = S.numScheduledGangs = S.numNodeQueries = S.evictedTableSize = 0; S.statFastIters = S.statFastReplay = 0; S.segT = 0;
 }
@@ -1597,7 +1594,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   c.l1Dirty = 1;
   const FastK k = fastKRef(d);
   FastS S;
-  S.tP0 = -1; S.engLive = 0; S.engPend = -1; S.engWaitClk = 0; S.engSeq = 0;
+   S.engLive = 0; S.engPend = -1; S.engWaitClk = 0; S.engSeq = 0;
   S.laneL = FLANE / (d.cfg.R > 0 ? d.cfg.R : 1); S.laneX = FLANE % (d.cfg.R > 0 ? d.cfg.R : 1);
   S.globalTokens = UNID(RS.globalTokens); S.globalBurst = UNI64(RS.globalBurst); S.globalRateInf = UNI32(RS.globalRateInf);
   S.numScheduledJobs = UNI32(RS.numScheduledJobs); S.numScheduledGangs = UNI32(RS.numScheduledGangs); S.numEvictedJobs = UNI32(RS.numEvictedJobs);
@@ -1662,7 +1659,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
       GangOut go = fastGangRun(d, fc, in, t);
       S.engSeq = go.engSeq;
       if (go.dropped) { S.fastActive = 0; fastDrop(d); }
-      S.tP0 = -1;
+      
       if (!go.handled) break;
       S.numScheduledJobs += go.cnt; S.numScheduledGangs += 1; S.numNodeQueries += go.cnt; S.loopIterations++; S.statFastIters++;
       if (!S.globalRateInf && go.cnt <= S.globalBurst) S.globalTokens -= (double)go.cnt;
@@ -1691,7 +1688,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
         S.statRefills += so.refills; S.numEvictedJobs += so.evicted;
         if (FLANE == 0) { RS.statStreamRuns++; RS.statStreamJobs += E; RS.statStreamEmitted += so.emitted; }
         if (so.dropped) { S.fastActive = 0; fastDrop(d); }
-        S.tP0 = -1;
+        
         pqBuild(pq, Q);
         if (so.pend >= 0) { pend = so.pend; lastTop = so.pend; refK.A = so.lastA; refK.X = so.lastX; refK.Y = so.lastY; refN = so.lastN; }
       }
