@@ -1693,8 +1693,8 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
         if (so.pend >= 0) { pend = so.pend; lastTop = so.pend; refK.A = so.lastA; refK.X = so.lastX; refK.Y = so.lastY; refN = so.lastN; }
       }
       (void)so_max;   // (entries prepared per queue stay at QS_CMAX: the sum pass stops at a queue's first gang member, so gang-heavy queues prepare little anyway)
-      if (E >= 256) streamBackoff = 0;   // an attempt that finds every stream in place costs little (no bulk pass): back off gently, but for good when runs stay short
-      else streamBackoff = streamBackoff ? (streamBackoff < (1 << 18) ? streamBackoff * 2 : streamBackoff) : 32;
+      if (E >= 64) streamBackoff = 0;   // an attempt costs little (streams persist, the bulk passes run on the helper workgroups): back off gently, but for good when runs stay short
+      else streamBackoff = streamBackoff ? (streamBackoff < (1 << 18) ? streamBackoff * 2 : streamBackoff) : 8;
       streamNextAt = S.statFastIters + streamBackoff;
 #ifdef ASCHED_HOSTSIM
       if (getenv("HS_STREAM_EAGER")) { streamBackoff = 0; streamNextAt = S.statFastIters + (E == 0 ? 1 : 0); }   // tests: a stream run wherever one can start
