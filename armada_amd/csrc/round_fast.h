@@ -1700,6 +1700,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
       if (getenv("HS_STREAM_EAGER")) { streamBackoff = 0; streamNextAt = S.statFastIters + (E == 0 ? 1 : 0); }   // tests: a stream run wherever one can start
 #endif
       if (pend >= 0) break;
+      if (S.engLive && UNI32(FL.eng.cancel)) break;   // the engine saw the caller's cancel word: leave the loop (queueSchedule raises the timeout)
       if (code == 1) continue;
     }
     KeyOut ko; ko.valid = 0; ko.A = 0; ko.X = ko.Y = 0;
