@@ -886,9 +886,14 @@ __device__ static void engineLoop(Dev& d) {  // wave 1
           continue;
         }
         ESEG(0);
+#ifdef ASCHED_FASTPROF
         long long b0 = (long long)__builtin_readcyclecounter();
+#endif
         int st = engineServeRing(d, k, ES, i);
-        busy += (long long)__builtin_readcyclecounter() - b0; jobs++;
+#ifdef ASCHED_FASTPROF
+        busy += (long long)__builtin_readcyclecounter() - b0;   // (the clock reads sit on the engine's chain: profiling builds only)
+#endif
+        jobs++;
         if (st == 0) { if (lane == 0) __hip_atomic_store(&g_fl.eng.ringFail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
         i++;
         if (lane == 0) __hip_atomic_store(&g_fl.eng.ringAck, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

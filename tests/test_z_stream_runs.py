@@ -92,3 +92,21 @@ def test_gangs_through_the_ring_gpu(hip_lib, oracle_lib):
 @pytest.mark.gpu
 def test_crowded_gangs_gpu(hip_lib, oracle_lib):
     both(hip_lib, oracle_lib, workload(985, gangs=120, occupied=0.93, n_nodes=300, n_jobs=6000, n_queues=6))
+
+
+def test_cancel_inside_a_stream_run(hostsim_lib, oracle_lib):
+    """hard timeout (queue_scheduler.go:105-112) while the round is inside a stream run: the node engine sees the cancel word (every 256 jobs), the run ends with
+    the entries it had bound, the fast loop is left at once and the round returns ASCHED_ERR_TIMEOUT; after a fresh round_prepare the handle behaves like a new one"""
+    from armada_amd.binding import ERR_TIMEOUT, SchedError
+    wl = workload(991, occupied=0.3)
+    s = W.load(hostsim_lib, wl); W.prepare(s, wl)
+    s.set_deadline(1e-9)                       # expired when the round starts (the serial build cannot be interrupted from outside)
+    with pytest.raises(SchedError) as e:
+        s.schedule_round()
+    assert e.value.code == ERR_TIMEOUT
+    s.set_deadline(0)
+    W.prepare(s, wl)
+    r = s.schedule_round()
+    o = W.load(oracle_lib, wl); W.prepare(o, wl)
+    assert bench.round_diff(r, o.schedule_round()) == []
+    s.close(); o.close()
