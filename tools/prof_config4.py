@@ -6,11 +6,13 @@ import armada_amd
 from armada_amd import workloads as W
 kw = dict(n_nodes=20_000, n_jobs=200_000, n_queues=32, occupied=0.95)
 if len(sys.argv) > 1 and sys.argv[1] == "gangs": kw = dict(n_nodes=20_000, n_jobs=200_000, n_queues=32, gangs=2_000)
+full = len(sys.argv) > 1 and sys.argv[1] == "full"
+if full: kw = dict(n_nodes=100_000, n_jobs=1_000_000, n_queues=64, occupied=0.95)
 wl = W.config3(seed=W.SEED, **kw)
-wl.global_burst, wl.queue_burst = 40_000, 4_000
+if not full: wl.global_burst, wl.queue_burst = 40_000, 4_000
 lib = armada_amd.load_library()
 s = W.load(lib, wl)
-for i in range(2):
+for i in range(1 if full else 2):
     W.prepare(s, wl)
     t = time.perf_counter(); r = s.schedule_round(); dt = time.perf_counter() - t
     st = s.round_stats()
