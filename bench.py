@@ -302,7 +302,7 @@ def optimiser_record(hip, args):
     return rec
 
 
-def round_shape_record(hip, args, label, kwargs, steps, note):
+def round_shape_record(hip, args, label, kwargs, steps, note, warmup=1):
     """one of the other BASELINE round shapes (configs[3] gangs, configs[4] oversubscribed / preemption-heavy): GPU rounds timed like the headline,
     the oracle on the same input for the cpu_baseline and the parity verdict when its round fits the remaining budget"""
     import numpy as np
@@ -319,7 +319,7 @@ def round_shape_record(hip, args, label, kwargs, steps, note):
     if kwargs["n_jobs"] != 1_000_000:
         wl.global_burst, wl.queue_burst = max(1, int(200_000 * scale)), max(1, int(20_000 * scale))
     s = W.load(hip, wl)
-    lat, dev_ms, res = multipool.timed_rounds(s, wl, steps, 1, torch.cuda.synchronize, torch.cuda.synchronize)
+    lat, dev_ms, res = multipool.timed_rounds(s, wl, steps, warmup, torch.cuda.synchronize, torch.cuda.synchronize)
     st = s.round_stats()
     tm = s.round_timing()
     queries, iters = res.num_node_queries, res.num_loop_iterations
@@ -356,7 +356,8 @@ def other_configs(hip, args, t_start):
 
     def shape(label, full_kwargs, reduced_kwargs, note):
         def run():
-            rec, _, _, _ = round_shape_record(hip, args, label, full_kwargs, 2, note) if full_kwargs else (None, None, None, None)
+            heavy = bool(full_kwargs) and full_kwargs.get("occupied", 0.5) > 0.9   # the preemption-heavy shape at full size is ~25 s per round: ONE round, no warm-up
+            rec, _, _, _ = round_shape_record(hip, args, label, full_kwargs, 1 if heavy else 2, note + (" (one round, no warm-up round)" if heavy else ""), 0 if heavy else 1) if full_kwargs else (None, None, None, None)
             red, wl, res, iters = round_shape_record(hip, args, label + " (reduced: the size the oracle leg runs at)", reduced_kwargs, 2, note)
             if args.cpu_budget > 0:
                 base, ores = cpu_baseline(wl, 1e9, iters)   # never cut: the parity verdict needs the whole round
@@ -373,7 +374,7 @@ def other_configs(hip, args, t_start):
         return run
     guarded("BASELINE configs[3]", shape("BASELINE configs[3]", dict(n_nodes=100_000, n_jobs=1_000_000, n_queues=64, gangs=10_000),
                                          dict(n_nodes=20_000, n_jobs=200_000, n_queues=32, gangs=2_000), "gang atomic placement (ScheduleManyWithTxn + txn abort), uniform shape within a gang"))
-    guarded("BASELINE configs[4]", shape("BASELINE configs[4]", None if not args.full_other else dict(n_nodes=100_000, n_jobs=1_000_000, n_queues=64, occupied=0.95),
+    guarded("BASELINE configs[4]", shape("BASELINE configs[4]", None if args.no_full_other else dict(n_nodes=100_000, n_jobs=1_000_000, n_queues=64, occupied=0.95),
                                          dict(n_nodes=20_000, n_jobs=200_000, n_queues=32, occupied=0.95),
                                          "oversubscribed / preemption-heavy: nodes 95% occupied, fair-share + urgency preemption candidate search, oversubscribed evictor"))
 
@@ -406,8 +407,9 @@ def main():
     ap.add_argument("--submit-keys", type=int, default=2_000)
     ap.add_argument("--no-other", action="store_true", help="skip the other_configs sub-records (configs[1], [3], [4], submit check)")
     ap.add_argument("--other-budget", type=float, default=240.0, help="seconds after which no further other_configs sub-record is started")
+    ap.add_argument("--no-full-other", action="store_true", help="skip the full-size (100k x 1M) run of configs[4] (~40 s); the reduced size with its oracle leg still runs")
     ap.add_argument("--other-scale", type=float, default=1.0, help="scale the other_configs workloads (tests)")
-    ap.add_argument("--full-other", action="store_true", help="also run configs[4]'s shape at 100k x 1M on the GPU (slow: generic preemption path)")
+    ap.add_argument("--full-other", action="store_true", help="(default now; kept for older command lines)")
     args = ap.parse_args()
     if args.submit_check:
         print(json.dumps(submit_check_record(args)))

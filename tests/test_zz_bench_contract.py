@@ -52,7 +52,7 @@ def test_round_bench_line(fake_gpu, monkeypatch, capsys):
     assert line["cpu_baseline"]["rounds"] == 1 and line["cpu_baseline"]["upper_bound_extrapolation"] is False
     # every other BASELINE config + the submit check sits in the same record, each with roofline and cpu_baseline
     oc = {r["config"]: r for r in line["other_configs"]}
-    assert set(oc) == {"BASELINE configs[1]", "BASELINE configs[3]", "BASELINE configs[4] (reduced: the size the oracle leg runs at)", "submit check (SURVEY 8f-2)", "fairness optimiser node scoring (SURVEY 8f-3)"}, set(oc)
+    assert set(oc) == {"BASELINE configs[1]", "BASELINE configs[3]", "BASELINE configs[4]", "submit check (SURVEY 8f-2)", "fairness optimiser node scoring (SURVEY 8f-3)"}, set(oc)
     for name, r in oc.items():
         assert "error" not in r and "skipped" not in r, r
         assert ROOFLINE_KEYS <= set(r["roofline"]) and CPU_KEYS <= set(r["cpu_baseline"]), name
