@@ -2,6 +2,7 @@
 """Differential soaks, CPU only: the oracle against the CPU build of the device code (tests/hostsim) on many more seeds than the suite runs.
 
     python tests/soak.py rounds 3000        # workloads.small_random rounds, random sizes / occupancy / gangs / bursts / away / ragged
+    python tests/soak.py streams 1000        # medium rounds (<= 1500 nodes, <= 20000 jobs) dominated by stream runs and gangs through the ring; HS_STREAM_EAGER=1: a run wherever one can start
     python tests/soak.py features 400       # tests/test_z_feature_mix.py rounds (affinity, conditional away, extra column, limits ...)
     python tests/soak.py ops 3000           # tests/test_z_nodedb_op_sequences.py NodeDb-level operation sequences
     python tests/soak.py submitcheck 400    # batched SubmitChecker vs the literal sequential restatement (and 3-entry cache)
@@ -45,6 +46,17 @@ def main():
                 res = []
                 for lib in (orc, hs):
                     s = W.load(lib, wl); W.prepare(s, wl); res.append(s.schedule_round())
+                scenario.assert_same_round(res[0], res[1])
+            elif kind == "streams":   # medium rounds that spend most of their time in stream runs / the gang ring (HS_STREAM_EAGER=1 python tests/soak.py streams N: a run wherever one can start)
+                rng = np.random.default_rng(seed)
+                nn, nj, nq = int(rng.integers(100, 1500)), int(rng.integers(2000, 20000)), int(rng.integers(2, 40))
+                wl = W.config3(seed=seed, n_nodes=nn, n_jobs=nj, n_queues=nq, gangs=int(rng.choice([0, 0, 5, 50])), occupied=float(rng.choice([0.2, 0.5, 0.8, 0.93])))
+                wl.global_burst = int(rng.choice([nj, nj // 3, 500])); wl.queue_burst = int(rng.choice([nj, max(10, nj // nq), 64])); wl.rate_inf = bool(rng.random() < 0.2)
+                if rng.random() < 0.3:
+                    wl.config.max_queue_lookback = int(rng.choice([50, 500, 3000]))
+                res = []
+                for lib in (orc, hs):
+                    s = W.load(lib, wl); W.prepare(s, wl); res.append(s.schedule_round()); s.close()
                 scenario.assert_same_round(res[0], res[1])
             elif kind == "features":
                 import test_z_feature_mix as T
