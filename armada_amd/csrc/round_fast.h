@@ -137,7 +137,9 @@ __shared__ RoundScalars g_rs;  // d.rs points here for the whole launch (relocat
 #define UNI32(x) (x)
 #define UNI64(x) (x)
 #define UNID(x) (x)
+#define LANES_ANY(v) ((v) != 0)   // (serial build: FOR_LANES bodies share their locals)
 #else
+#define LANES_ANY(v) (__ballot((v) != 0) != 0)
 __device__ static inline int uni32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ static inline unsigned long long uni64(unsigned long long v) {
   unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
@@ -849,6 +851,53 @@ DEV void fastSave(Dev& d) {  // kernel end
 }
 
 // ------------------------------------------------------------------------------------------------ queue iterator, fast
+// QueuedGangIterator.Peek (queue_scheduler.go:376-432) for a whole gang whose members lie next to each other at the queue's cursor — the common
+// layout: a gang is submitted as one batch.  One lane per member: the jctx reset of jobItNext, the member list, the gang's total request (LDS adds),
+// then updatePQItem (:636-686) for the gang.  Anything else (members apart, a cardinality that does not match the stored members, mixed priority
+// classes, an unfeasible key among the members, the lookback limit falling inside the gang, skip mode) is left to the generic iterator, untouched.
+DEV bool fastPeekGang(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f, int pos, KeyOut* ko) {
+#ifdef ASCHED_HOSTSIM
+  if (getenv("HS_NO_GANG_PEEK")) return false;
+#endif
+  if (!fc.stream || fc.replay || f.effValid) return false;
+  int job0 = UNI32(k.queuedJobs[pos]);
+  int g = UNI32(d.jGang[job0]);
+  if (g < 0) return false;
+  int card = UNI32(d.jGangCard[job0]), off = UNI32(d.gangOff[g]);
+  if (card < 2 || card > 64 || card != UNI32(d.gangOff[g + 1]) - off || pos + card > f.qEnd || UNI32(d.gangSeen[g]) != 0) return false;
+  if (fc.maxLookback != 0 && (uint32_t)(f.itJobsSeen + card - 1) >= fc.maxLookback) return false;
+  int pc0 = UNI32(d.jPc[job0]);
+  bool skip = fc.skipKnown && S.numUnfeasible > 0;
+  int bad = 0;
+  FOR_LANES(m, card) {
+    int j = k.queuedJobs[pos + m];
+    if (d.jGang[j] != g || d.jPc[j] != pc0 || d.jNode0[j] >= 0 || d.jGangCard[j] != card || (skip && k.unfeasible[d.jShape[j]])) bad = 1;
+  }
+  if (LANES_ANY(bad)) return false;
+  FOR_LANES(x, MAXR) FL.tmpX[x] = 0;
+  FOR_LANES(m, card) {
+    int j = k.queuedJobs[pos + m];
+    resetJctxForQueued(d, j);
+    d.gangArr[off + m] = j;
+    const int64_t* rq = JREQ(d, j);
+    for (int r = 0; r < k.R; r++) if (rq[r]) LDS_ADD64(FL.tmpX[r], (uint64_t)rq[r]);
+  }
+  int64_t tot[MAXR], alloc[MAXR], with[MAXR];
+  for (int r = 0; r < k.R; r++) {
+    tot[r] = (int64_t)UNI64(FL.tmpX[r]);
+    alloc[r] = UNI64(FL.qAlloc[q][r]) + UNI64(FL.qPenalty[q][r]); with[r] = alloc[r] + tot[r];
+  }
+  if (FLANE == 0) { d.gangSeen[g] = card; d.gangAllEvicted[g] = 0; for (int r = 0; r < k.R; r++) d.gangTotal[(size_t)g * k.R + r] = tot[r]; }
+  double w = f.weight;
+  double pr = UNID(drf(d, with) / w), cu = UNID(drf(d, alloc) / w), sz = UNID(drf(d, tot) * w);
+  int32_t p = UNI32(d.cfg.pcPriority[pc0]);
+  f.itQi = pos + card; f.itJobsSeen += card;
+  f.itNext = -(g + 2); f.gctx = -(g + 2); f.headFast = 0; f.headKind = 1; f.headIdx = -1; f.headPos = -1;
+  f.proposed = pr; f.current = cu; f.size = sz; f.pcPrio = p; f.schedPrio = p;
+  *ko = packItemKeys(fc.preferLarge, q, p, pr, cu, sz, f.budget);
+  return true;
+}
+
 // costItClear(top) (queue_scheduler.go:595-606) + QueuedGangIterator.Peek (:376-432) + updatePQItem (:636-686) for the
 // next single job of queue q, from the prefetch window; gang members and rare iterator states go to the generic code.
 // `f` is the caller's register copy of FL.hot[q]; changed fields are stored back here.  Returns false when the generic
@@ -902,7 +951,10 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
         S.statRefills++;
       }
       w = pos - f.winStart;
-      if (UNI32(FL.winRec[q][w].gang) >= 0) generic = true;
+      if (UNI32(FL.winRec[q][w].gang) >= 0) {
+        if (kind == 1 && fastPeekGang(d, k, S, fc, q, f, pos, ko)) { haveHead = true; break; }
+        generic = true;
+      }
     }
     SEG(10);
     if (generic) { ok = false; break; }  // the generic iterator continues from the same state
@@ -1220,6 +1272,7 @@ DEV void fastRollback(Dev& d, KREF k, FastS& S, int q) {
   accountVectorsBk(d, k, q, UNI32(FL.bk.pc), -1);
   S.numScheduledJobs--; S.numScheduledGangs--; S.numNodeQueries--;
   S.globalTokens = UNID(FL.bk.globalTokens);
+  { int g = UNI32(FL.hot[q].gctx); if (g < -1 && FLANE == 0) d.gangSeen[-g - 2] = 0; }   // the iteration had assembled the gang behind its job (fastPeekGang): not seen yet
   engineRestore(q);
   FL.hot[q].winKind = -1; FL.hot[q].ewCount = 0;  // the windows may have moved on: refill on demand
   S.loopIterations--; S.statFastIters--;
@@ -1371,8 +1424,8 @@ DEV_NOINLINE SkipDelta fastDrain(Dev& d, int Q) {
 //     accounting had been done for them — and the entry is its queue's head again).
 // Exactness: the merge is the heap of QueueCandidateGangIteratorPQ on the very keys fastAdvance would compute (same float64 operations on the same
 // prefix sums, round_run.h B_QSKEYS), the engine executes the entries in emission order, and integer accounting is order independent.
-struct StreamIn { double globalTokens; int64_t globalBurst; int32_t globalRateInf, engSeq; };
-struct StreamOut { int executed, executedEv, pend, dropped, engSeq, emitted, refills, evicted, maxConsumed; uint32_t lastA, lastN; uint64_t lastX, lastY; };
+struct StreamIn { double globalTokens; int64_t globalBurst; int32_t globalRateInf, engSeq; int32_t skip, haveLast; uint32_t lastA, lastN; uint64_t lastX, lastY; };   // skip / last*: skip mode is on, key of the entry served last
+struct StreamOut { int executed, executedEv, pend, dropped, engSeq, emitted, refills, evicted, maxConsumed, failed, lastQ; uint32_t lastA, lastN; uint64_t lastX, lastY; };
 // streams persist between runs: head of queue q == element sPos of its stream, elements [sPos, sLen) are still to come.  A queue's stream is dropped
 // when anything but a stream run serves the queue (fastIter) or the generic code runs (fastQLoad).  prepare: 0 = the top queue has no stream,
 // 1 = ready, 2 = some queue needs the bulk passes and allowBulk was 0 (the node engine must be stopped first: they use every wave of the workgroup)
@@ -1399,6 +1452,8 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
   if (!in.globalRateInf) allowed = in.globalTokens >= 2147483000.0 ? INT32_MAX : (in.globalTokens < 1 ? 0 : (int)in.globalTokens);
   if (in.globalBurst < 1 || in.globalTokens < 1) allowed = 0;
   PackedKey lastK; lastK.A = ~0u; lastK.X = lastK.Y = ~0ull; uint32_t lastN = ~0u;
+  int skip = UNI32(in.skip), haveLast = 0, lastQ = -1;
+  if (skip && UNI32(in.haveLast)) { lastK.A = UNI32(in.lastA); lastK.X = UNI64(in.lastX); lastK.Y = UNI64(in.lastY); lastN = UNI32(in.lastN); haveLast = 1; }
   StreamLanes sl; memset(&sl, 0, sizeof sl);
   FOR_LANES(q, QCAPF) {   // (the head of a queue is element sPos of its stream = the list entry before the queue's cursor)
     const QHot& f = FL.hot[q];
@@ -1432,7 +1487,13 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
     int base = SL_GET(sl, base, t);
     EvKey e = streamKey(k, sl, t, sPos, sLen, kind, base);
     SEG(12);
-    pqHeadKey(pq, t, &lastK, &lastN);             // the key this entry is served under (fastExitSkip rebuilds the state around the last one)
+    if (skip) {                                   // skip mode (fastRun): the folded evicted streams are merged around keys served in non-decreasing order only
+      PackedKey curK; uint32_t curN;
+      pqHeadKey(pq, t, &curK, &curN);
+      if (haveLast && packedLess(curK, curN, lastK, lastN)) break;
+      lastK = curK; lastN = curN; haveLast = 1;   // the key this entry is served under (fastExitSkip rebuilds the state around the last one)
+    }
+    lastQ = t;
     if (FLANE == 0) { RJOB(emitted) = e.job; RQ(emitted) = t | ((kind & 1) ? RQ_EV : 0); }
     emitted++; if (!(kind & 1)) emittedQ++;
     if ((emitted & 3) == 0) {                     // records: gather the last four entries; the four before them have arrived by now
@@ -1473,6 +1534,7 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
   streamEnd(engSeq);
   { int a = streamAcked(&fail); if (a > acc) { streamAccount(d, k, acc, a); acc = a; } }
   if (fail == 2) out.dropped = 1;
+  out.failed = fail ? 1 : 0; out.lastQ = lastQ;
   // ---- the queues' iterator state as of the acc entries done: each queue's head becomes the first of its elements that was not done
   FOR_LANES(q, QCAPF) { FL.hot[q].winKind = -1; FL.hot[q].winCount = 0; }   // the windows served as the ring
   int doneQ = 0, doneEv = 0;
@@ -1609,7 +1671,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   fc.stream = fc.engine && d.qsKey != nullptr && !k.hasPcLimit && !k.anyRoundLimit && !k.disableHome && fc.withQueued;
   fc.stream = UNI32(fc.stream);
   int streamNextAt = UNI32(c.streamNextAt), streamBackoff = UNI32(c.streamBackoff), streamCap = UNI32(c.streamCap);
-  PackedKey refK; refK.A = ~0u; refK.X = refK.Y = ~0ull; uint32_t refN = ~0u;
+  PackedKey refK; refK.A = ~0u; refK.X = refK.Y = ~0ull; uint32_t refN = ~0u; int haveRef = 0;
   if (!mode && c.onlyEvicted && RS.terminationReason != 0 && S.lvl0NonNeg && S.numPreemptedMarks == 0 && fc.evStatic && fc.withQueued) { SkipDelta dl = fastDrain(d, Q); S.numEvictedJobs += dl.evicted; S.loopIterations += dl.iters; }
   if (c.skipEnter && !mode && S.lvl0NonNeg && S.numPreemptedMarks == 0 && fc.evStatic) { SkipDelta dl = fastEnterSkip(d, fc, Q); S.numEvictedJobs += dl.evicted; S.loopIterations += dl.iters; S.statRefills += dl.refills; c.skipActive = 1; }
   c.skipEnter = 0;
@@ -1649,13 +1711,28 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
       }
     }
 #endif
+    if (t < 0) { lastTop = t; break; }
+    if (c.skipActive) {
+      // the folded evicted streams (skip mode) are merged around the keys served so far, which must not decrease: a queue's next element may order
+      // before an entry already served (a higher priority class behind a lower one; a gang behind the queue's own evicted jobs) — rebuild the exact
+      // state around the last entry served and go on without the mode
+      PackedKey curK; uint32_t curN;
+      pqHeadKey(pq, t, &curK, &curN);
+      if (haveRef && packedLess(curK, curN, refK, refN)) {
+        SkipDelta dl = fastExitSkip(d, fc, Q, lastTop, refK, refN);
+        S.numEvictedJobs += dl.evicted; S.loopIterations += dl.iters; S.statRefills += dl.refills;
+        c.skipActive = 0;
+        pqBuild(pq, Q);
+        continue;
+      }
+      refK = curK; refN = curN; haveRef = 1;
+    }
     lastTop = t;
-    if (t >= 0) pqHeadKey(pq, t, &refK, &refN);  // lane 0 of the heap lanes
-    if (t < 0) break;
     if (UNI32(FL.hot[t].gctx) < 0) {  // a gang: through the ring when every member is an untouched queued job (fastGangRun), else generic
       if (mode || !fc.stream || !S.fastActive || UNI32(FL.hot[t].gctx) == -1) break;
       if (!S.engLive) { engineStart(d, S); S.engLive = 1; }
       StreamIn in; in.globalTokens = S.globalTokens; in.globalBurst = S.globalBurst; in.globalRateInf = S.globalRateInf; in.engSeq = S.engSeq;
+      in.skip = 0; in.haveLast = 0; in.lastA = in.lastN = 0; in.lastX = in.lastY = 0;
       GangOut go = fastGangRun(d, fc, in, t);
       S.engSeq = go.engSeq;
       if (go.dropped) { S.fastActive = 0; fastDrop(d); }
@@ -1678,6 +1755,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
       if (code == 1) {
         if (!S.engLive) { engineStart(d, S); S.engLive = 1; }
         StreamIn in; in.globalTokens = S.globalTokens; in.globalBurst = S.globalBurst; in.globalRateInf = S.globalRateInf; in.engSeq = S.engSeq;
+        in.skip = c.skipActive; in.haveLast = haveRef; in.lastA = refK.A; in.lastX = refK.X; in.lastY = refK.Y; in.lastN = refN;   // (the current top's key: it is the first entry of the run)
         StreamOut so = fastStreamRun(d, fc, Q, in);
         S.engSeq = so.engSeq;
         E = so.executed; so_max = so.maxConsumed;
@@ -1690,7 +1768,14 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
         if (so.dropped) { S.fastActive = 0; fastDrop(d); }
         
         pqBuild(pq, Q);
-        if (so.pend >= 0) { pend = so.pend; lastTop = so.pend; refK.A = so.lastA; refK.X = so.lastX; refK.Y = so.lastY; refN = so.lastN; }
+        if (so.pend >= 0) pend = so.pend;
+        if (c.skipActive && so.emitted > 0) {
+          if (!so.failed) { lastTop = so.lastQ; refK.A = so.lastA; refK.X = so.lastX; refK.Y = so.lastY; refN = so.lastN; haveRef = 1; }   // every emitted entry was served
+          else {   // served: the entries before the one that found no node, all of them ordering before it; it is the head of the heap again (nothing emitted after it was done)
+            int t2 = pqHead(pq, Q);
+            lastTop = t2; if (t2 >= 0) pqHeadKey(pq, t2, &refK, &refN);
+          }
+        }
       }
       (void)so_max;   // (entries prepared per queue stay at QS_CMAX: the sum pass stops at a queue's first gang member, so gang-heavy queues prepare little anyway)
       if (E >= 64) streamBackoff = 0;   // an attempt costs little (streams persist, the bulk passes run on the helper workgroups): back off gently, but for good when runs stay short

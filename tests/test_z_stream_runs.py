@@ -110,3 +110,37 @@ def test_cancel_inside_a_stream_run(hostsim_lib, oracle_lib):
     o = W.load(oracle_lib, wl); W.prepare(o, wl)
     assert bench.round_diff(r, o.schedule_round()) == []
     s.close(); o.close()
+
+
+def _soak_round_workload(seed):
+    """the workload tests/soak.py `rounds` builds for a seed"""
+    rng = np.random.default_rng(seed)
+    return W.small_random(n_nodes=int(rng.integers(4, 300)), n_jobs=int(rng.integers(50, 6000)), n_queues=int(rng.integers(1, 12)), seed=seed,
+                          occupied=float(rng.choice([0.0, 0.3, 0.6, 0.9, 1.0])), gangs=int(rng.integers(0, 12)),
+                          burst=None if rng.random() < 0.4 else (int(rng.integers(10, 2000)), int(rng.integers(5, 500))),
+                          away=bool(rng.random() < 0.3), ragged=bool(rng.random() < 0.2))
+
+
+@pytest.mark.parametrize("seed", [100345, 101116, 102465, 102593])
+def test_gang_assembled_behind_folded_evicted_streams(hostsim_lib, oracle_lib, seed):
+    """QueuedGangIterator.Peek in the fast loop (fastPeekGang): a queue's evicted jobs come from its evicted stream while the other queues' evicted lists
+    are folded (skip mode); the gang behind them has a higher priority class than entries already served, so it orders BEFORE them (Less,
+    queue_scheduler.go:738-798 compares the priority first).  The folded state must be rebuilt around the last entry served, not around the gang's key:
+    the gang fails on the full cluster and the generic gang scheduler's preemption attempt reads the nodes of every evicted job that has come back."""
+    both(hostsim_lib, oracle_lib, _soak_round_workload(seed))
+
+
+@pytest.mark.parametrize("gangs", [40, 400])
+def test_gang_peek_on_and_off_is_the_same_round(hostsim_lib, oracle_lib, gangs, monkeypatch):
+    wl = workload(977, gangs=gangs, occupied=0.3, n_nodes=600, n_jobs=9000, n_queues=12)
+    r1, st1 = both(hostsim_lib, oracle_lib, wl)
+    monkeypatch.setenv("HS_NO_GANG_PEEK", "1")
+    r2, st2 = both(hostsim_lib, oracle_lib, wl)
+    assert bench.round_diff(r1, r2) == []
+    assert st1["generic_iterations"] <= st2["generic_iterations"]
+
+
+@pytest.mark.gpu
+def test_gang_behind_folded_evicted_streams_gpu(hip_lib, oracle_lib):
+    for seed in (100345, 102465):
+        both(hip_lib, oracle_lib, _soak_round_workload(seed))
