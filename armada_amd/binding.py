@@ -791,11 +791,11 @@ class Scheduler:
         return dict(total_ms=out[0], control_ms=out[1], launches=int(out[2]), evict1_host_ms=out[3], evict3_host_ms=out[4], final_host_ms=out[5])
 
     def round_stats(self):
-        out = (C.c_int32 * 20)()
+        out = (C.c_int32 * 24)()
         self._check(self.lib.round_stats(self.h, out))
         names = ["fast_iterations", "generic_iterations", "base_scan_steps", "window_refills", "l0_max", "fast_replay_steps", "l0_overflows", "fast_active",
                  "kclk_evict", "kclk_replay", "kclk_pass1", "kclk_oversub_evict", "kclk_pass2", "kclk_unbind_results",
-                 "kclk_plane_scans", "kclk_fair_selects", "stream_runs", "stream_jobs", "stream_prepared", "stream_emitted"]
+                 "kclk_plane_scans", "kclk_fair_selects", "stream_runs", "stream_jobs", "stream_prepared", "stream_emitted", "preempt_fast_iterations"]
         return {k: out[i] for i, k in enumerate(names)}
 
     def job_key_unfeasible(self, job: int) -> bool:

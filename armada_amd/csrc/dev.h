@@ -137,7 +137,7 @@ struct RoundScalars {
   int32_t fastOverflow;      // L0 overflowed: structure dropped for the rest of the round
   int32_t replayPending;     // the eviction-order replay (evicted-table Index assignment) has been deferred: nothing has read it yet
   int32_t statFastIters, statGenericIters, statScanSteps, statRefills, statL0Max, statFastReplay;
-  int32_t statStreamRuns, statStreamJobs, statStreamPrepared, statStreamEmitted;   // stream runs (round_fast.h): runs, entries bound, stream entries prepared, entries emitted by the merge
+  int32_t statStreamRuns, statStreamJobs, statStreamPrepared, statStreamEmitted, statHybrid;   // stream runs (round_fast.h): runs, entries bound, stream entries prepared, entries emitted by the merge
   int32_t awayRowPlus1;      // an away attempt is in progress: static mask row (+1) that replaces the job's home shape row
   int32_t fairIndexValid;    // the per-node index of the evicted table (fairOff/fairEnt) describes the current table
   int64_t totalNewJobNs;     // sctx.TotalNewJobSchedulingTime (context/scheduling.go:212-240)

@@ -380,6 +380,7 @@ struct Ctl {
   int skipEnter;       // the next fast run may fold the gang-free evicted streams out of the loop (round_fast.h "skip mode")
   int skipActive;
   int cancelSeen;      // a fast run saw the cancel word
+  int fpLimitHit;      // queueSchedule has seen the fair-share preemption rate limit in this pass (it is acted on once: queue_scheduler.go:114-121)
   int streamNextAt, streamBackoff;   // stream runs (round_fast.h): not before this many fast iterations; doubled after a run too short to pay for its preparation
   int streamCap;                     // stream entries prepared per queue: follows what the last run consumed (a short run must not be followed by a long preparation)
 };
@@ -1044,13 +1045,14 @@ DEV void passInit(Dev& d, Ctl& c, const PassCfg& pc) {
 #endif
 DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff) {
   bool limitHit = false, resumed = false;
+  c.fpLimitHit = 0;
   const bool softClock = d.cfg.maxNewJobNs > 0 || d.cfg.maxNewJobPerQueueNs > 0;
   unsigned pollCount = 0;
   int fastSkip = 0, fastStreak = 0;
   for (;;) {
     if (d.rs->error) return;
     if ((pollCount++ & 63) == 0 && cancelRequested(d)) { raise(d, ASCHED_ERR_TIMEOUT, 900); return; }  // hard timeout: abort with an error (queue_scheduler.go:105-112)
-    if (!limitHit && d.rs->hasFpLimiter && d.rs->fpTokens < 1) { fastEnterGeneric(d, c); limitHit = true; costItOnlyEvicted(d, c, pc); }
+    if (!limitHit && d.rs->hasFpLimiter && d.rs->fpTokens < 1) { fastEnterGeneric(d, c); limitHit = true; c.fpLimitHit = 1; costItOnlyEvicted(d, c, pc); }
     // A fast run that ends without a single fast iteration (the head is a gang, a job that needs preemption, ...) costs a hand-over in and
     // out of the fast loop for nothing: after such a run the next ones are skipped, doubling up to 32 generic iterations, until one makes
     // progress again.  Skipping is always exact — the generic code handles every iteration.
@@ -1062,7 +1064,8 @@ DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff)
     if (fastOn(d, c) && !c.fqLive && fastSkip == 0 && d.rs->fastActive) {
       int t0 = pqTop(d, c);
       int r0 = t0 >= 0 ? d.pqGctx[t0] : -1;
-      if (r0 >= 0 && !d.jcEvicted[r0] && d.jcAssigned[r0] < 0 && fastSelectLevel0(d, r0) == -1) headNeedsGeneric = true;
+      // (once the deferred replay of the evicted jobs has run, the fast loop serves such a head itself: fastPreemptIter)
+      if (d.rs->replayPending && r0 >= 0 && !d.jcEvicted[r0] && d.jcAssigned[r0] < 0 && fastSelectLevel0(d, r0) == -1) headNeedsGeneric = true;
     }
     if (headNeedsGeneric) {}
     else if (fastOn(d, c) && fastSkip > 0) fastSkip--;
@@ -1076,6 +1079,7 @@ DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff)
       if (d.rs->statFastIters + d.rs->loopIterations == before && pend < 0) { if (fastStreak < 5) fastStreak++; fastSkip = (1 << fastStreak) - 1; }
       else fastStreak = 0;
       if (pend >= 0) { updateAndPush(d, c, pend, pc); continue; }
+      if (!limitHit && d.rs->hasFpLimiter && d.rs->fpTokens < 1) continue;   // the fast loop's last iteration preempted (fastPreemptIter): the rate limit check comes before the next Peek (:114-121)
     }
     int top = pqTop(d, c);
     int ref = top >= 0 ? d.pqGctx[top] : -1;

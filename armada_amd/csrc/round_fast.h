@@ -220,6 +220,7 @@ struct FastS {
   long long engWaitClk;  // ticks this wave spent waiting for the engine's verdict
   int engSeq;            // commands posted to the engine in this session
   int engLive, engPend;  // node engine started for this run; queue whose speculative iteration awaits the engine's verdict (-1 none)
+  int inlineStreak;      // queued jobs in a row that this wave placed itself (the engine starts after ENG_START_AFTER of them)
 #ifdef ASCHED_FASTPROF
   long long eseg[8];
 #endif
@@ -1089,7 +1090,11 @@ DEV void qlPutWin(int q, const QHot& f) { QHot& o = FL.hot[q]; o.winKind = f.win
 // One QueueScheduler iteration (queue_scheduler.go:94-304 body) for the head of queue `top` when it is a single job that
 // (a) is queued and fits at priority -2 or (b) is a phase-1-evicted job returning to its node.  Returns 0 WITHOUT side
 // effects when the iteration needs the generic code (any constraint failing, preemption, gangs, ...); 1 = done;
-// 2 = done, but the queue's next head must be produced by the generic updateAndPush.  Fast mode only.
+// 2 = done, but the queue's next head must be produced by the generic updateAndPush; 8 = nothing done: a queued job that passed every constraint
+// and has no node at priority -2 (fastPreemptIter takes it from there).  Fast mode only.
+#ifndef ENG_START_AFTER
+#define ENG_START_AFTER 3
+#endif
 DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* ko) {
   int q = top;
   if (k.hasPcLimit) return 0;  // per-queue per-priority-class caps: generic
@@ -1114,6 +1119,7 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
   FitHandle h; h.src = 0; h.slot = -1;
   CandRec cand; cand.pos = 0; cand.node = -1; cand.key = 0; cand.cls = 0; cand.ex0 = cand.ex1 = 0; cand.pad = 0;
   bool evInRound = true, wasPre = true; int evNl = 0; int32_t evCutoff = 0; (void)evCutoff;
+  bool useEngine = false;
   if (!ev) {
     if (!S.fastActive) return 0;
     if (k.anyRoundLimit && roundLimitExceeded(d, k)) return 0;  // CheckRoundConstraints (constraints.go:113-119)
@@ -1154,7 +1160,10 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
     if (k.disableHome) return 0;
     prio = r.pcPrio;
     SEG(8);
-    if (fc.engine) {
+    // the node engine is worth its start / stop (a workgroup-wide hand-shake and a release fence) when queued jobs keep fitting: where most of them
+    // need preemption (an oversubscribed cluster) this wave places the odd fitting one itself and the engine stays down
+    useEngine = fc.engine && (S.engLive || S.inlineStreak >= ENG_START_AFTER);
+    if (useEngine) {
       // two-wave iteration: the node engine takes first fit + bind; this wave goes on with the queue side assuming the job fits
       if (!S.engLive) { engineStart(d, S); S.engLive = 1; }
       SEG(9);
@@ -1162,12 +1171,13 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
       n = -1;
       if (fc.skipKnown && S.numUnfeasible > 0) {  // fastAdvance may record skipped jobs, which cannot be taken back: wait for the verdict
         int v = engineWait(S);
-        if (v == 0) return 0;
+        if (v == 0) return 8;
         if (v == 2) { S.fastActive = 0; fastDrop(d); }
       } else S.engPend = q;
     } else {
       n = fastFirstFit(k, S, r, &h, &cand);
-      if (n < 0) return 0;  // the generic cascade (gate, fair-share, urgency) decides
+      if (n < 0) return 8;  // every constraint holds, no node at priority -2: the cascade (gate, fair-share, urgency) decides — fastPreemptIter or the generic loop
+      S.inlineStreak++;
     }
     S.numNodeQueries++;
   } else {
@@ -1237,7 +1247,7 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
   // ---- SelectNodeForJobWithTxn result + BindJobToNode (nodedb.go:538-630, 1046-1068)
   int32_t cutoff = r.preemptible ? prio : NONPREEMPTIBLE_CUTOFF;
   int nl = ev ? evNl : r.nlPc;
-  bool nodeSideHere = ev || !fc.engine;  // a queued job's bind, result fields and L0 upkeep are the node engine's in two-wave mode
+  bool nodeSideHere = ev || !useEngine;  // a queued job's bind, result fields and L0 upkeep are the node engine's in two-wave mode
   if (nodeSideHere) bindUpdate(k, S, n, ev ? 1 : 0, nl, q, r.keyDelta);  // evicted job: level -2 gets -req (bind) and +req (un-evict): unchanged (node.go:416-442)
   if (nodeSideHere && FLANE == 0) {
     k.jcHasPctx[job] = 1; k.pcNode[job] = n; k.pcSap[job] = prio;
@@ -1645,6 +1655,66 @@ DEV_NOINLINE GangOut fastGangRun(Dev& d, FastCtx fc, StreamIn in, int t) {
   return out;
 }
 
+// ---- a queued job that needs preemption, without leaving the fast loop.  The queue side of the iteration is fastIter's (constraints already
+// checked, accounting in LDS, next head through fastAdvance); the node side is the generic one, called as is: tryScheduleGang for a one-job gang
+// (gang_scheduler.go:229-262) = SelectNodeForJobWithTxn's cascade (nodedb.go:538-838: gate, fair-share preemption, urgency preemption, away node
+// types), the victims' removal, BindJobToNode, the evicted-table upkeep, inside a transaction; it keeps the level-0 structure in line itself
+// (fastTouch).  What the generic loop would add around it — AddGangSchedulingContext / EvictGang / re-add on failure (scheduling.go:391-449), the
+// unfeasible-key registration (gang_scheduler.go:63-98), the rate limiters (:118-123), the PQS bookkeeping (pqs.go:160-166) — is applied to the fast
+// state.  Saves the hand-over of every queue's state out of and back into LDS, the generic Less over all queues and the generic peek per job.
+// The caller has stopped the node engine (the cascade's wide passes need every wave of the workgroup; it reads planes the binds must have reached)
+// and written its scalars back to RS.  Returns 0 = not handled (nothing touched), 1 = done, 2 = done + the generic code must produce the queue's
+// next head, 3 = done + leave the fast loop (the fair-share preemption rate limit ran dry: queue_scheduler.go:125-142 is the generic loop's).
+DEV_NOINLINE int fastPreemptIter(Dev& d, Ctl& c, FastCtx fc, int t) {
+#ifdef ASCHED_HOSTSIM
+  if (getenv("HS_NO_PREEMPT_FAST")) return 0;
+#endif
+  const FastK k = fastKRef(d);
+  if (RS.replayPending || !RS.fastActive || c.txn.active || RS.error) return 0;   // (the deferred replay runs fast loops of its own: the generic iteration triggers it once)
+  QHot f = FL.hot[t];
+  uniQHot(f);
+  int job = f.gctx;
+  if (job < 0 || !f.headFast || f.headKind != 1 || f.effValid) return 0;
+  JobTail r = FL.headTail[t];
+  uniJobTail(r);
+  int pcx = r.pc;
+  FastS S; coldS(d, S);
+  c.l1Dirty = 1;   // the fast iterations since the last fence bound through no-return atomics
+  fastFence(c);
+  int reason = 0;
+  bool ok = tryGang(d, c, job, &reason);
+  if (RS.error) return 1;
+  if (FLANE == 0) { RS.loopIterations++; RS.statFastIters++; RS.statHybrid++; }
+  uint8_t fl = k.jobFlags[job];
+  if (ok) {
+    accountVectors(d, k, t, pcx, false, false);
+    if (FLANE == 0) {
+      RS.numScheduledJobs++; RS.numScheduledGangs++;
+      if (!RS.globalRateInf && 1 <= RS.globalBurst) RS.globalTokens -= 1.0;
+      k.jobFlags[job] = (uint8_t)((fl & ~F_UNSUCCESSFUL) | F_SUCCESSFUL); k.inScheduled[job] = 1; k.inSchedAndEvicted[job] = 0;
+    }
+    if (!f.rateInf && 1 <= f.burst) f.tokens -= 1.0;
+  } else {
+    failJob(d, job, reason);
+    if (FLANE == 0) k.jobFlags[job] = (uint8_t)((fl & ~F_SUCCESSFUL) | F_UNSUCCESSFUL);
+    if (!c.skipKeyCheck && isPropertyOfGang(reason) && keyValid(d, job)) {
+      int sh = d.jShape[job];
+      if (!d.unfeasible[sh]) {
+        d.unfeasible[sh] = 1; d.unfeasibleReason[sh] = reason; RS.numUnfeasible++;
+        FOR_LANES(q, QCAPF) { FL.hot[q].sLen = 0; FL.hot[q].sPos = 0; }   // the queues' precomputed streams were laid out before this key was known to be unfeasible (queue_scheduler.go:398-413 skips its jobs at peek time)
+        f.sLen = 0; f.sPos = 0;
+      }
+    }
+  }
+  S.numUnfeasible = UNI32(RS.numUnfeasible); S.numPreemptedMarks = UNI32(RS.numPreemptedMarks); S.lvl0NonNeg = UNI32(RS.lvl0NonNeg); S.fastActive = UNI32(RS.fastActive);
+  KeyOut ko;
+  bool more = fastAdvance(d, k, S, fc, t, f, &ko);
+  if (FLANE == 0) { RS.numEvictedJobs += S.numEvictedJobs; RS.statRefills += S.statRefills; }
+  if (!more) return 2;
+  if (RS.hasFpLimiter && RS.fpTokens < 1 && !c.fpLimitHit) return 3;
+  return 1;
+}
+
 // Run fast iterations of the QueueScheduler loop (mode 0) or of the eviction-order replay (mode 1) until one needs the
 // generic code.  Returns the queue whose next head the generic updateAndPush must produce, or -1.  Leaves fast mode live.
 DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* counter) {
@@ -1656,13 +1726,23 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   c.l1Dirty = 1;
   const FastK k = fastKRef(d);
   FastS S;
-   S.engLive = 0; S.engPend = -1; S.engWaitClk = 0; S.engSeq = 0;
+   S.engLive = 0; S.engPend = -1; S.engWaitClk = 0; S.engSeq = 0; S.inlineStreak = 0;
   S.laneL = FLANE / (d.cfg.R > 0 ? d.cfg.R : 1); S.laneX = FLANE % (d.cfg.R > 0 ? d.cfg.R : 1);
-  S.globalTokens = UNID(RS.globalTokens); S.globalBurst = UNI64(RS.globalBurst); S.globalRateInf = UNI32(RS.globalRateInf);
-  S.numScheduledJobs = UNI32(RS.numScheduledJobs); S.numScheduledGangs = UNI32(RS.numScheduledGangs); S.numEvictedJobs = UNI32(RS.numEvictedJobs);
-  S.numNodeQueries = UNI32(RS.numNodeQueries); S.loopIterations = UNI32(RS.loopIterations); S.evictedTableSize = UNI32(RS.evictedTableSize);
-  S.numUnfeasible = UNI32(RS.numUnfeasible); S.numPreemptedMarks = UNI32(RS.numPreemptedMarks); S.fastActive = UNI32(RS.fastActive); S.lvl0NonNeg = UNI32(RS.lvl0NonNeg); S.replayPending = UNI32(RS.replayPending);
+  // the scheduling-context scalars this loop keeps in registers
+#define FAST_SCALARS_IN() \
+  S.globalTokens = UNID(RS.globalTokens); S.globalBurst = UNI64(RS.globalBurst); S.globalRateInf = UNI32(RS.globalRateInf); \
+  S.numScheduledJobs = UNI32(RS.numScheduledJobs); S.numScheduledGangs = UNI32(RS.numScheduledGangs); S.numEvictedJobs = UNI32(RS.numEvictedJobs); \
+  S.numNodeQueries = UNI32(RS.numNodeQueries); S.loopIterations = UNI32(RS.loopIterations); S.evictedTableSize = UNI32(RS.evictedTableSize); \
+  S.numUnfeasible = UNI32(RS.numUnfeasible); S.numPreemptedMarks = UNI32(RS.numPreemptedMarks); S.fastActive = UNI32(RS.fastActive); S.lvl0NonNeg = UNI32(RS.lvl0NonNeg); S.replayPending = UNI32(RS.replayPending); \
   S.statFastIters = UNI32(RS.statFastIters); S.statScanSteps = UNI32(RS.statScanSteps); S.statRefills = UNI32(RS.statRefills); S.statL0Max = UNI32(RS.statL0Max); S.statFastReplay = UNI32(RS.statFastReplay);
+#define FAST_SCALARS_OUT() \
+  RS.globalTokens = S.globalTokens; \
+  RS.numScheduledJobs = S.numScheduledJobs; RS.numScheduledGangs = S.numScheduledGangs; RS.numEvictedJobs = S.numEvictedJobs; \
+  RS.numNodeQueries = S.numNodeQueries; RS.loopIterations = S.loopIterations; \
+  if (RS.evictedTableSize != S.evictedTableSize) RS.fairIndexValid = 0;  /* the replay added table entries */ \
+  RS.evictedTableSize = S.evictedTableSize; \
+  RS.statFastIters = S.statFastIters; RS.statScanSteps = S.statScanSteps; RS.statRefills = S.statRefills; RS.statL0Max = S.statL0Max; RS.statFastReplay = S.statFastReplay;
+  FAST_SCALARS_IN()
   int Q = UNI32(d.cfg.Q);
   fc.withQueued = UNI32(fc.withQueued); fc.maxLookback = UNI32(fc.maxLookback); fc.skipKnown = UNI32(fc.skipKnown); fc.compareSchedPrio = UNI32(fc.compareSchedPrio);
   fc.preferLarge = UNI32(fc.preferLarge); fc.evStatic = UNI32(fc.evStatic); fc.engine = UNI32(fc.engine);
@@ -1694,8 +1774,12 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
       onMiss; \
     } \
   }
+  unsigned pollCount = 0;
   for (;;) {
-    ENGINE_SETTLE(break)
+    int missed = -1;
+    ENGINE_SETTLE(missed = sq)
+    // hard timeout / cancel (queue_scheduler.go:105-112): a live node engine looks at the host-mapped word itself (engineServeAt); without one this loop does
+    if (!S.engLive && (++pollCount & 63) == 0 && cancelRequested(d)) { c.cancelSeen = 1; break; }
     int t = pqHead(pq, Q);
     SEG(0);
 #ifdef ASCHED_HOSTSIM
@@ -1728,6 +1812,9 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
       refK = curK; refN = curN; haveRef = 1;
     }
     lastTop = t;
+    int st = -1;
+    if (missed >= 0) st = t == missed ? 8 : 0;   // the node engine found no node for this head (taken back above): as if fastIter had said so
+    if (st < 0) {
     if (UNI32(FL.hot[t].gctx) < 0) {  // a gang: through the ring when every member is an untouched queued job (fastGangRun), else generic
       if (mode || !fc.stream || !S.fastActive || UNI32(FL.hot[t].gctx) == -1) break;
       if (!S.engLive) { engineStart(d, S); S.engLive = 1; }
@@ -1788,8 +1875,28 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
       if (S.engLive && UNI32(FL.eng.cancel)) break;   // the engine saw the caller's cancel word: leave the loop (queueSchedule raises the timeout)
       if (code == 1) continue;
     }
+    }
     KeyOut ko; ko.valid = 0; ko.A = 0; ko.X = ko.Y = 0;
-    int st = mode ? fastReplayStep(d, k, S, fc, t, &cnt, &ko) : fastIter(d, k, S, fc, t, &ko);
+    if (st < 0) st = mode ? fastReplayStep(d, k, S, fc, t, &cnt, &ko) : fastIter(d, k, S, fc, t, &ko);
+    if (st == 8) {   // the job needs preemption: the node side through the generic cascade, the queue side stays here (fastPreemptIter)
+      if (c.skipActive) {   // it reads the nodes of evicted jobs: the folded evicted streams must be in their exact state first
+        SkipDelta dl = fastExitSkip(d, fc, Q, lastTop, refK, refN);
+        S.numEvictedJobs += dl.evicted; S.loopIterations += dl.iters; S.statRefills += dl.refills;
+        c.skipActive = 0;
+        pqBuild(pq, Q);
+        continue;
+      }
+      if (S.engLive) { engineStop(d, S); S.engLive = 0; if (UNI32(FL.eng.cancel)) { c.cancelSeen = 1; break; } }
+      S.inlineStreak = 0;
+      FAST_SCALARS_OUT()
+      int hc = fastPreemptIter(d, c, fc, t);
+      FAST_SCALARS_IN()
+      if (hc == 0) break;
+      pqBuild(pq, Q);
+      if (hc == 2) { pend = t; break; }
+      if (hc == 3 || RS.error) break;
+      continue;
+    }
     if (st == 0) break;
     pqPopPush(pq, ko, t);
     SEG(7);
@@ -1809,11 +1916,8 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   }
   c.streamNextAt = streamNextAt; c.streamBackoff = streamBackoff; c.streamCap = streamCap;
   if (counter) *counter = cnt;
-  RS.globalTokens = S.globalTokens;
-  RS.numScheduledJobs = S.numScheduledJobs; RS.numScheduledGangs = S.numScheduledGangs; RS.numEvictedJobs = S.numEvictedJobs;
-  RS.numNodeQueries = S.numNodeQueries; RS.loopIterations = S.loopIterations;
-  if (RS.evictedTableSize != S.evictedTableSize) RS.fairIndexValid = 0;  // the replay added table entries
-  RS.evictedTableSize = S.evictedTableSize;
-  RS.statFastIters = S.statFastIters; RS.statScanSteps = S.statScanSteps; RS.statRefills = S.statRefills; RS.statL0Max = S.statL0Max; RS.statFastReplay = S.statFastReplay;
+  FAST_SCALARS_OUT()
+#undef FAST_SCALARS_IN
+#undef FAST_SCALARS_OUT
   return pend;
 }

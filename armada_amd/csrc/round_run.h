@@ -878,7 +878,7 @@ DEV void controlMainAux(Dev& d, int cmd) {
   Ctl c;
   c.txn.active = d.rs->txnActive; c.fairStamp = d.rs->fairStamp; c.preList = d.preList; c.preCount = 0;
   c.skipKeyCheck = 0; c.compareSchedPrio = 0; c.preferLarge = d.cfg.preferLarge; c.useReplayAlloc = 0; c.onlyEvicted = 0;
-  c.fastEnabled = 0; c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0; c.cancelSeen = 0; c.streamNextAt = 0; c.streamBackoff = 0; c.streamCap = QS_CMAX;
+  c.fastEnabled = 0; c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0; c.cancelSeen = 0; c.fpLimitHit = 0; c.streamNextAt = 0; c.streamBackoff = 0; c.streamCap = QS_CMAX;
   fastLoad(d);
   runAuxCommand(d, c, cmd);
   fastEnterGeneric(d, c);
@@ -890,7 +890,7 @@ DEV void controlMain(Dev& d, int cmd) {
   c.txn.active = d.rs->txnActive; c.fairStamp = d.rs->fairStamp; c.preList = d.preList; c.preCount = 0;
   c.skipKeyCheck = 0; c.compareSchedPrio = 0; c.preferLarge = d.cfg.preferLarge; c.useReplayAlloc = 0; c.onlyEvicted = 0;
   c.fastEnabled = d.f.iterOk && !d.rs->apiDirty && (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY || cmd == CMD_PASS1 || cmd == CMD_PASS2);
-  c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0; c.cancelSeen = 0; c.streamNextAt = 0; c.streamBackoff = 0; c.streamCap = QS_CMAX;
+  c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0; c.cancelSeen = 0; c.fpLimitHit = 0; c.streamNextAt = 0; c.streamBackoff = 0; c.streamCap = QS_CMAX;
   fastLoad(d);
   runCommand(d, c, cmd);
   fastEnterGeneric(d, c);

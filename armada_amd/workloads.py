@@ -285,9 +285,10 @@ def load(lib, wl: Workload) -> Scheduler:
     return s
 
 
-def prepare(s: Scheduler, wl: Workload):
+def prepare(s: Scheduler, wl: Workload, fairshare_preemption_tokens=None):
     """round_prepare with the workload's queues and rate limiters (limiters start full, as a fresh rate.Limiter)"""
     q = wl.num_queues
     s.round_prepare(wl.queue_weight, wl.queued,
                     global_tokens=float(wl.global_burst), global_burst=wl.global_burst, global_rate_inf=wl.rate_inf,
-                    queue_tokens=[float(wl.queue_burst)] * q, queue_burst=[wl.queue_burst] * q, queue_rate_inf=[wl.rate_inf] * q)
+                    queue_tokens=[float(wl.queue_burst)] * q, queue_burst=[wl.queue_burst] * q, queue_rate_inf=[wl.rate_inf] * q,
+                    fairshare_preemption_tokens=fairshare_preemption_tokens)

@@ -425,8 +425,9 @@ int32_t ASCHED_FN(kernel_times)(asched_t*, double* out /*[4]*/);
 int32_t ASCHED_FN(round_timing)(asched_t*, double* out /*[8]*/);
 /* Measurement hook (no reference counterpart): how the last round ran on the device.  out = {fast iterations, generic
    iterations, base scan steps, window refills, max live dirty nodes (L0), fast replay steps, L0 overflows,
-   fast structure active at the end, 0...}.  The CPU oracle reports zeros. */
-int32_t ASCHED_FN(round_stats)(asched_t*, int32_t* out /*[20]*/);
+   fast structure active at the end, [8..15] kilo-ticks per phase, [16..19] stream runs / entries bound in them / stream entries prepared / emitted,
+   [20] iterations whose job needed preemption and stayed in the fast loop, 0...}.  The CPU oracle reports zeros. */
+int32_t ASCHED_FN(round_stats)(asched_t*, int32_t* out /*[24]*/);
 /* Hard timeout of a round (maxSchedulingDuration, config/scheduler/config.yaml:83; scheduling_algo.go:130-134 wraps the context in
    WithTimeout, queue_scheduler.go:105-112 checks ctx.Done() every loop iteration and returns ctx.Err()).  asched_set_deadline: every
    following schedule_round / schedule_queues is cancelled `seconds` after it starts (0 = none).  asched_cancel = the context's cancel

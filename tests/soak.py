@@ -3,6 +3,7 @@
 
     python tests/soak.py rounds 3000        # workloads.small_random rounds, random sizes / occupancy / gangs / bursts / away / ragged
     python tests/soak.py streams 1000        # medium rounds (<= 1500 nodes, <= 20000 jobs) dominated by stream runs and gangs through the ring; HS_STREAM_EAGER=1: a run wherever one can start
+    python tests/soak.py preempt 1500       # small crowded rounds (60-100 % occupied), most with a fair-share preemption rate limit: the jobs that need preemption stay in the fast loop (fastPreemptIter)
     python tests/soak.py features 400       # tests/test_z_feature_mix.py rounds (affinity, conditional away, extra column, limits ...)
     python tests/soak.py ops 3000           # tests/test_z_nodedb_op_sequences.py NodeDb-level operation sequences
     python tests/soak.py submitcheck 400    # batched SubmitChecker vs the literal sequential restatement (and 3-entry cache)
@@ -46,6 +47,17 @@ def main():
                 res = []
                 for lib in (orc, hs):
                     s = W.load(lib, wl); W.prepare(s, wl); res.append(s.schedule_round())
+                scenario.assert_same_round(res[0], res[1])
+            elif kind == "preempt":
+                rng = np.random.default_rng(seed)
+                wl = W.small_random(n_nodes=int(rng.integers(4, 200)), n_jobs=int(rng.integers(50, 4000)), n_queues=int(rng.integers(1, 12)), seed=seed,
+                                    occupied=float(rng.choice([0.6, 0.9, 1.0])), gangs=int(rng.integers(0, 8)),
+                                    burst=None if rng.random() < 0.5 else (int(rng.integers(10, 2000)), int(rng.integers(5, 500))),
+                                    away=bool(rng.random() < 0.3), ragged=bool(rng.random() < 0.2))
+                fp = None if rng.random() < 0.3 else float(rng.choice([0, 1, 3, 10, 40]))
+                res = []
+                for lib in (orc, hs):
+                    s = W.load(lib, wl); W.prepare(s, wl, fairshare_preemption_tokens=fp); res.append(s.schedule_round()); s.close()
                 scenario.assert_same_round(res[0], res[1])
             elif kind == "streams":   # medium rounds that spend most of their time in stream runs / the gang ring (HS_STREAM_EAGER=1 python tests/soak.py streams N: a run wherever one can start)
                 rng = np.random.default_rng(seed)
