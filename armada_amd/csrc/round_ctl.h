@@ -69,7 +69,9 @@ DEV bool fastOn(Dev& d, const Ctl& c);
 DEV void fastEnterGeneric(Dev& d, Ctl& c);
 DEV bool fastGangMember(Dev& d, Ctl& c, int job);  // select (fit at priority -2) + bind of one unpinned queued gang member through the fast structure; false = not done
 DEV void fastFence(Ctl& c);
-DEV_COLD void ensureReplay(Dev& d, Ctl& c);             // run the deferred eviction-order replay before anything reads the evicted table         // leave fast mode: LDS queue state back into the generic arrays, HBM updates visible
+DEV_COLD void ensureReplaySlow(Dev& d, Ctl& c);
+DEV void ensureReplay(Dev& d, Ctl& c) { if (d.rs->replayPending) ensureReplaySlow(d, c); }   // (the test stays with the caller: a call costs a register save / restore)
+//             // run the deferred eviction-order replay before anything reads the evicted table         // leave fast mode: LDS queue state back into the generic arrays, HBM updates visible
 
 // ------------------------------------------------------------------------------------------------
 #define AL(d, l, r, n) ((d).alloc[((size_t)(l) * (d).cfg.R + (r)) * (d).cfg.Npad + (n)])
@@ -128,7 +130,20 @@ DEV uint64_t packKey(Dev& d, int l, int n) {
   return k;
 }
 DEV void updateKeys(Dev& d, int n) { for (int l = 0; l < d.cfg.P; l++) KEY(d, l, n) = packKey(d, l, n); }
-DEV void updateKeysCtl(Dev& d, int n) { updateKeys(d, n); fastTouch(d, n); }  // control-flow call sites (not the bulk rebuild)
+// The control code runs on one full wave whose lanes all execute the same statements.  Where a statement is a loop over (level, resource) elements of one
+// node, the lanes take one element each instead: the loop's dependent HBM round trips (~0.5 us each) become one.  CTL_WAVE(): this really is a full wave.
+#if !defined(ASCHED_HOSTSIM) && defined(__HIP_DEVICE_COMPILE__)
+#define CTL_WAVE() (__builtin_popcountll(__builtin_amdgcn_read_exec()) == 64)
+#define CTL_LANE() ((int)(threadIdx.x & 63))
+#else
+#define CTL_WAVE() false
+#define CTL_LANE() 0
+#endif
+DEV void updateKeysCtl(Dev& d, int n) {  // control-flow call sites (not the bulk rebuild)
+  if (CTL_WAVE()) { int l = CTL_LANE(); if (l < d.cfg.P) KEY(d, l, n) = packKey(d, l, n); }   // one level per lane
+  else updateKeys(d, n);
+  fastTouch(d, n);
+}
 
 DEV bool fitsAlloc(Dev& d, const int64_t* req, int level, int n) {  // DynamicJobRequirementsMet (is/nodedb/nodematching.go:194-197)
   for (int r = 0; r < d.cfg.R; r++) if (req[r] > AL(d, level, r, n)) return false;
@@ -148,6 +163,13 @@ DEV void undoPush(Dev& d, int op, int a, int b, int c) {
 // markAllocatable (is/internaltypes/node.go:539-549): alloc[p] += sign*req for every level p <= cutoff
 DEV void markAllocatable(Dev& d, int n, int32_t cutoff, const int64_t* req, int sign) {
   const DevCfg& c = d.cfg;
+  if (CTL_WAVE()) {   // one (level, resource) element per lane
+    for (int i = CTL_LANE(); i < c.P * c.R; i += 64) {
+      int l = i / c.R, r = i % c.R;
+      if (c.prios[l] <= cutoff && req[r] != 0) AL(d, l, r, n) += sign * req[r];
+    }
+    return;
+  }
   for (int l = 0; l < c.P; l++)
     if (c.prios[l] <= cutoff)
       for (int r = 0; r < c.R; r++) AL(d, l, r, n) += sign * req[r];
@@ -573,12 +595,39 @@ DEV_COLD int selectWithFairPreemption(Dev& d, Ctl& c, int job) {
   int idx = wgFairSelect(d, a);
   if (d.progress) d.progress[2] = 0;
   d.rs->statClk[7] += CLK() - t0;
+  XSEG(12);
   if (idx < 0) return -1;
   if (idx >= d.rs->evictedTableSize) { raise(d, ASCHED_ERR_INTERNAL, 600); return -1; }
   int n = d.jcAssigned[d.evTabJob[idx]];
   if (n < 0) { raise(d, ASCHED_ERR_INTERNAL, 601); return -1; }
+  XSEG(13);
   // preempt every considered evicted job of node n (Index >= idx, alive, priority <= ours), in scan order (:1012-1023)
   int32_t maxPriority = ASCHED_MIN_PRIORITY;
+#if !defined(ASCHED_HOSTSIM) && defined(__HIP_DEVICE_COMPILE__)
+  if (CTL_WAVE()) {   // the node's entries one per lane (index, alive, job, priority: one round of loads), then the victims in scan order
+    int k0 = d.fairOff[n], k1 = d.fairOff[n + 1], lane = CTL_LANE();
+    for (int base = k0; base < k1; base += 64) {
+      int k = base + lane;
+      bool in = k < k1;
+      int i2 = in ? d.fairEnt[k] : -1, e2 = -1;
+      int32_t p = 0;
+      bool stop = in && i2 < idx, take = false;
+      if (in && !stop && d.evTabAlive[i2]) { e2 = d.fairEntJob[k]; p = d.schedAtPrio[e2]; take = p <= a.prio; }
+      unsigned long long stopMask = __ballot(stop), takeMask = __ballot(take);
+      if (stopMask) takeMask &= (stopMask & (0ull - stopMask)) - 1;   // (descending index order: nothing after the first entry below idx)
+      while (takeMask) {
+        int l = __builtin_ctzll(takeMask);
+        takeMask &= takeMask - 1;
+        int ti = __builtin_amdgcn_readlane(i2, l), te = __builtin_amdgcn_readlane(e2, l);
+        int32_t tp = __builtin_amdgcn_readlane(p, l);
+        evTabDelete(d, ti, true);
+        if (tp > maxPriority) maxPriority = tp;
+        c.preList[c.preCount++] = te;
+      }
+      if (stopMask) break;
+    }
+  } else
+#endif
   for (int k = d.fairOff[n]; k < d.fairOff[n + 1]; k++) {
     int i2 = d.fairEnt[k];
     if (i2 < idx) break;

@@ -1679,10 +1679,13 @@ DEV_NOINLINE int fastPreemptIter(Dev& d, Ctl& c, FastCtx fc, int t) {
   uniJobTail(r);
   int pcx = r.pc;
   FastS S; coldS(d, S);
+  XSEG_BEGIN();
   c.l1Dirty = 1;   // the fast iterations since the last fence bound through no-return atomics
   fastFence(c);
+  XSEG(35);
   int reason = 0;
   bool ok = tryGang(d, c, job, &reason);
+  XSEG(36);
   if (RS.error) return 1;
   if (FLANE == 0) { RS.loopIterations++; RS.statFastIters++; RS.statHybrid++; }
   uint8_t fl = k.jobFlags[job];
@@ -1707,8 +1710,10 @@ DEV_NOINLINE int fastPreemptIter(Dev& d, Ctl& c, FastCtx fc, int t) {
     }
   }
   S.numUnfeasible = UNI32(RS.numUnfeasible); S.numPreemptedMarks = UNI32(RS.numPreemptedMarks); S.lvl0NonNeg = UNI32(RS.lvl0NonNeg); S.fastActive = UNI32(RS.fastActive);
+  XSEG(37);
   KeyOut ko;
   bool more = fastAdvance(d, k, S, fc, t, f, &ko);
+  XSEG(38);
   if (FLANE == 0) { RS.numEvictedJobs += S.numEvictedJobs; RS.statRefills += S.statRefills; }
   if (!more) return 2;
   if (RS.hasFpLimiter && RS.fpTokens < 1 && !c.fpLimitHit) return 3;
@@ -1893,6 +1898,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
       FAST_SCALARS_IN()
       if (hc == 0) break;
       pqBuild(pq, Q);
+      XSEG(39);
       if (hc == 2) { pend = t; break; }
       if (hc == 3 || RS.error) break;
       continue;

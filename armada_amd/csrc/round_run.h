@@ -500,7 +500,7 @@ DEV void swapLoopArrays(Dev& d) {
 // The deferred addEvictedJobsToNodeDb (pqs.go:589-639): its result — the evicted-table Index of every evicted job — is a pure
 // function of the state the evictor left (qAllocSnap, the eviction lists), so it can be computed at first use.  It runs on its
 // own set of iterator / heap arrays; entries of jobs that have been rescheduled or preempted in the meantime come out dead.
-DEV_COLD void ensureReplay(Dev& d, Ctl& c) {
+DEV_COLD void ensureReplaySlow(Dev& d, Ctl& c) {
   if (!d.rs->replayPending) return;
   d.rs->replayPending = 0;
   fastEnterGeneric(d, c);
