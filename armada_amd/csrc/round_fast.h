@@ -1665,7 +1665,7 @@ DEV_NOINLINE GangOut fastGangRun(Dev& d, FastCtx fc, StreamIn in, int t) {
 // The caller has stopped the node engine (the cascade's wide passes need every wave of the workgroup; it reads planes the binds must have reached)
 // and written its scalars back to RS.  Returns 0 = not handled (nothing touched), 1 = done, 2 = done + the generic code must produce the queue's
 // next head, 3 = done + leave the fast loop (the fair-share preemption rate limit ran dry: queue_scheduler.go:125-142 is the generic loop's).
-DEV_NOINLINE int fastPreemptIter(Dev& d, Ctl& c, FastCtx fc, int t) {
+DEV __attribute__((always_inline)) int fastPreemptIter(Dev& d, Ctl& c, FastCtx fc, int t) {   // (inlined: as a call it saves and restores 109 registers per job)
 #ifdef ASCHED_HOSTSIM
   if (getenv("HS_NO_PREEMPT_FAST")) return 0;
 #endif
