@@ -30,7 +30,7 @@
 
 // ------------------------------------------------------------------------------------------------ device primitives
 #define CTL_THREADS 256
-enum { OP_EXIT = 0, OP_SCAN = 1, OP_BULK = 2, OP_COMPACT = 3, OP_FAIR = 4, OP_ENGINE = 5, OP_BULKW = 6, OP_HELPERS_EXIT = 9 };
+enum { OP_EXIT = 0, OP_SCAN = 1, OP_BULK = 2, OP_COMPACT = 3, OP_FAIR = 4, OP_ENGINE = 5, OP_BULKW = 6, OP_SCANFAIR = 7, OP_HELPERS_EXIT = 9 };
 struct BulkWArgs { int32_t kind, n; };   // a bulk pass whose bodies touch HBM only: shared with the helper workgroups
 
 struct Mailbox {
@@ -53,22 +53,29 @@ __shared__ Dev g_dev;
 struct HelpBox {
   unsigned long long cmd;      // (generation << 8) | op, published with ONE release store: a helper can never pair a new generation with an old op
   unsigned int done, pad;
-  unsigned long long result;   // OP_SCAN: min packed key; OP_FAIR: max (Index + 1)
-  unsigned long long args[16]; // ScanArgs / FairArgs image, read by the helpers with agent-scope loads
+  unsigned long long result;   // OP_SCAN / OP_SCANFAIR: min packed key; OP_FAIR: max (Index + 1)
+  unsigned long long result2;  // OP_SCANFAIR: max (Index + 1)
+  unsigned long long args[28]; // ScanArgs / FairArgs image (OP_SCANFAIR: ScanArgs at word 0, FairArgs at word HELP_ARGS2), read by the helpers with agent-scope loads
 };
-static_assert(sizeof(ScanArgs) <= 16 * 8 && sizeof(FairArgs) <= 16 * 8 && sizeof(ScanArgs) % 8 == 0 && sizeof(FairArgs) % 8 == 0, "HelpBox args image");
+#define HELP_ARGS2 14
+static_assert(sizeof(ScanArgs) <= HELP_ARGS2 * 8 && sizeof(FairArgs) <= (28 - HELP_ARGS2) * 8 && sizeof(ScanArgs) % 8 == 0 && sizeof(FairArgs) % 8 == 0, "HelpBox args image");
 __shared__ HelpBox* g_box;
 __shared__ int g_H;
 __shared__ unsigned int g_gen;
 
-template <class A> __device__ static inline void helpIssue(int op, const A* args) {  // one lane of the control wave
+template <class A, class B = A> __device__ static inline void helpIssue(int op, const A* args, const B* args2 = nullptr) {  // one lane of the control wave
   HelpBox* b = g_box;
   if (args) {
     const unsigned long long* src = (const unsigned long long*)args;
     for (int i = 0; i < (int)(sizeof(A) / 8); i++) __hip_atomic_store(&b->args[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (args2) {
+    const unsigned long long* src = (const unsigned long long*)args2;
+    for (int i = 0; i < (int)(sizeof(B) / 8); i++) __hip_atomic_store(&b->args[HELP_ARGS2 + i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&b->result2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __hip_atomic_store(&b->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(&b->result, op == OP_SCAN ? ~0ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&b->result, (op == OP_SCAN || op == OP_SCANFAIR) ? ~0ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   g_gen++;
   __hip_atomic_store(&b->cmd, ((unsigned long long)g_gen << 8) | (unsigned)op, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -209,6 +216,30 @@ __device__ static inline int wgFairSelect(Dev& d, const FairArgs& a) {
     best = h > best ? h : best;
   }
   return best;
+}
+
+// gate + fair-share evaluation in one pass (selectAtPriority, round_ctl.h): every participating thread walks its nodes once for each question; one
+// command, one completion count, two results
+__device__ static inline int wgScanFair(Dev& d, const ScanArgs& a, const FairArgs& f, uint64_t* bestKey) {
+  int lane = threadIdx.x & 63;
+  if (lane == 0) { g_mb.op = OP_SCANFAIR; g_mb.scan = a; g_mb.fair = f; if (g_H) helpIssue(OP_SCANFAIR, &a, &f); }
+  __syncthreads();
+  unsigned long long v = scanPart(d, g_mb.scan, threadIdx.x, (g_H + 1) * (int)blockDim.x);
+  int w = fairPart(d, g_mb.fair, threadIdx.x, (g_H + 1) * (int)blockDim.x);
+  if (lane == 0) { g_mb.partial[threadIdx.x >> 6] = v; g_mb.waveCount[threadIdx.x >> 6] = w; }
+  __syncthreads();
+  unsigned long long best = ~0ull; int idx = -1;
+  int nw = blockDim.x >> 6;
+  for (int k = 0; k < nw; k++) { unsigned long long p = g_mb.partial[k]; best = p < best ? p : best; int q = g_mb.waveCount[k]; idx = q > idx ? q : idx; }
+  if (g_H) {
+    unsigned long long hb = helpWait();
+    best = hb < best ? hb : best;
+    int h = (int)(unsigned int)__hip_atomic_load(&g_box->result2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;
+    idx = h > idx ? h : idx;
+  }
+  d.rs->numScans++;
+  *bestKey = best;
+  return idx;
 }
 
 // A bulk pass over n elements on the control workgroup AND the helper workgroups (grid-stride over all of them).  Only for bodies that read and write HBM and
@@ -1153,9 +1184,9 @@ __device__ static void relocateOut() {
 }
 
 // ------------------------------------------------------------------------------------------------ kernels
-template <class A> __device__ static inline A helpArgs(HelpBox* b) {
+template <class A> __device__ static inline A helpArgs(HelpBox* b, int at = 0) {
   union { A a; unsigned long long w[sizeof(A) / 8]; } u;
-  for (int i = 0; i < (int)(sizeof(A) / 8); i++) u.w[i] = __hip_atomic_load(&b->args[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = 0; i < (int)(sizeof(A) / 8); i++) u.w[i] = __hip_atomic_load(&b->args[at + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return u.a;
 }
 // Helper workgroup.  Wave 0 polls the command word in HBM (backing off to ~30 us between polls when the round has not asked
@@ -1208,6 +1239,13 @@ __device__ static void helperMain(const Dev& d, HelpBox* b, int H) {
       FairArgs a = helpArgs<FairArgs>(b);
       int v = fairPart(d, a, tid, nthreads);
       if (lane == 0 && v >= 0) __hip_atomic_fetch_max(&g_hMax, (unsigned long long)(v + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (op == OP_SCANFAIR) {
+      ScanArgs a = helpArgs<ScanArgs>(b);
+      FairArgs f = helpArgs<FairArgs>(b, HELP_ARGS2);
+      unsigned long long v = scanPart(d, a, tid, nthreads);
+      int w = fairPart(d, f, tid, nthreads);
+      if (lane == 0 && v != ~0ull) __hip_atomic_fetch_min(&g_hMin, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0 && w >= 0) __hip_atomic_fetch_max(&g_hMax, (unsigned long long)(w + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (op == OP_BULKW) {
       BulkWArgs a = helpArgs<BulkWArgs>(b);
       Dev& dm = const_cast<Dev&>(d);
@@ -1222,8 +1260,9 @@ __device__ static void helperMain(const Dev& d, HelpBox* b, int H) {
         __hip_atomic_store(&g_hMin, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_store(&g_hMax, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_store(&g_hArrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (op == OP_SCAN && mn != ~0ull) __hip_atomic_fetch_min(&b->result, mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((op == OP_SCAN || op == OP_SCANFAIR) && mn != ~0ull) __hip_atomic_fetch_min(&b->result, mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (op == OP_FAIR && mx != 0) __hip_atomic_fetch_max(&b->result, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (op == OP_SCANFAIR && mx != 0) __hip_atomic_fetch_max(&b->result2, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&b->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -1253,6 +1292,10 @@ __global__ __launch_bounds__(CTL_THREADS) void k_control(Dev dev, int cmd, HelpB
       } else if (op == OP_FAIR) {
         int v = fairPart(d, g_mb.fair, threadIdx.x, (g_H + 1) * (int)blockDim.x);
         if ((threadIdx.x & 63) == 0) g_mb.waveCount[threadIdx.x >> 6] = v;
+      } else if (op == OP_SCANFAIR) {
+        unsigned long long v = scanPart(d, g_mb.scan, threadIdx.x, (g_H + 1) * (int)blockDim.x);
+        int w = fairPart(d, g_mb.fair, threadIdx.x, (g_H + 1) * (int)blockDim.x);
+        if ((threadIdx.x & 63) == 0) { g_mb.partial[threadIdx.x >> 6] = v; g_mb.waveCount[threadIdx.x >> 6] = w; }
       } else if (op == OP_BULK) {
         bulkPart(d, g_mb.kind, g_mb.n);
       } else if (op == OP_BULKW) {
@@ -1946,6 +1989,10 @@ __global__ __launch_bounds__(CTL_THREADS) void k_control_aux(Dev dev, int cmd, H
       } else if (op == OP_FAIR) {
         int v = fairPart(d, g_mb.fair, threadIdx.x, (int)blockDim.x);
         if ((threadIdx.x & 63) == 0) g_mb.waveCount[threadIdx.x >> 6] = v;
+      } else if (op == OP_SCANFAIR) {
+        unsigned long long v = scanPart(d, g_mb.scan, threadIdx.x, (int)blockDim.x);
+        int w = fairPart(d, g_mb.fair, threadIdx.x, (int)blockDim.x);
+        if ((threadIdx.x & 63) == 0) { g_mb.partial[threadIdx.x >> 6] = v; g_mb.waveCount[threadIdx.x >> 6] = w; }
       } else if (op == OP_BULK) {
         bulkPart(d, g_mb.kind, g_mb.n);
       } else if (op == OP_BULKW) {

@@ -45,6 +45,7 @@ struct FairArgs { int64_t req[MAXR]; const uint64_t* maskA; const uint64_t* mask
 
 DEV int wgFirstFit(Dev& d, const ScanArgs& a);                       // -> node or -1
 DEV uint64_t wgFirstFitKey(Dev& d, const ScanArgs& a);               // -> the raw minimum (~0 = none): packed key, in multi-level mode tagged with the level
+DEV int wgScanFair(Dev& d, const ScanArgs& a, const FairArgs& f, uint64_t* bestKey);   // both in ONE wide pass (one hand-shake with the helper workgroups): *bestKey = wgFirstFitKey(a), returns wgFairSelect(f)
 DEV int wgFairSelect(Dev& d, const FairArgs& a);                     // -> evicted-table Index or -1 (max over nodes of fairNodeBest)
 DEV int atomicFetchAddI32(int32_t* p, int32_t v);
 template <class F> DEV void wgForEach(Dev& d, int n, F f);           // f(i) for i in [0,n), then workgroup barrier
@@ -579,6 +580,7 @@ DEV int fairNodeBest(const Dev& d, const FairArgs& a, int n, int floorIdx) {
   return -1;
 }
 DEV_COLD void ensureFairIndex(Dev& d);
+DEV_COLD int fairApply(Dev& d, Ctl& c, int job, int idx, int32_t jobPrio);
 DEV_COLD int selectWithFairPreemption(Dev& d, Ctl& c, int job) {
   ensureReplay(d, c);
   long long t0 = CLK();
@@ -596,6 +598,11 @@ DEV_COLD int selectWithFairPreemption(Dev& d, Ctl& c, int job) {
   if (d.progress) d.progress[2] = 0;
   d.rs->statClk[7] += CLK() - t0;
   XSEG(12);
+  return fairApply(d, c, job, idx, a.prio);
+}
+// the node of evicted-table entry idx wins: its considered entries are preempted (nodedb.go:1012-1023)
+DEV_COLD int fairApply(Dev& d, Ctl& c, int job, int idx, int32_t jobPrio) {
+  struct { int32_t prio; } a; a.prio = jobPrio;
   if (idx < 0) return -1;
   if (idx >= d.rs->evictedTableSize) { raise(d, ASCHED_ERR_INTERNAL, 600); return -1; }
   int n = d.jcAssigned[d.evTabJob[idx]];
@@ -657,7 +664,8 @@ DEV_COLD int selectAtPriority(Dev& d, Ctl& c, int job) {
   XSEG(32);
   if (n >= 0) { d.pcMethod[job] = ASCHED_METHOD_NO_PREEMPTION; return n; }
   int row = d.rs->awayRowPlus1 ? d.rs->awayRowPlus1 - 1 : d.jShape[job];
-  int lp = levelOf(d.cfg, d.pcSap[job]);
+  int32_t sap = d.pcSap[job];
+  int lp = levelOf(d.cfg, sap);
   if (d.f.cascadeFuse && lp >= 1 && !(d.rowLiteral && d.rowLiteral[row])) {
     ScanArgs a;
     const int64_t* req = JREQ(d, job);
@@ -666,16 +674,31 @@ DEV_COLD int selectAtPriority(Dev& d, Ctl& c, int job) {
     a.level = 1; a.levelHi = lp; a.noFit = 0; a.lowBound = 0; a.pad = 0;
     if (lp == 1) { a.level = 1; a.levelHi = 0; }   // one level: the plain pass
     long long t0 = CLK();
-    uint64_t best = wgFirstFitKey(d, a);
-    d.rs->statClk[6] += CLK() - t0;
-    d.rs->numNodeQueries++;                          // the gate
-    XSEG(33);
-    if (best == ~0ull) return -1;
-    d.pcNode[job] = -1; d.pcPap[job] = ASCHED_MIN_PRIORITY;
+    uint64_t best;
     if (!d.cfg.disableFair) {
-      n = selectWithFairPreemption(d, c, job);
+      // the gate and the per-node evaluation of fair-share preemption read the same nodes and neither depends on the other's answer: ONE wide pass,
+      // one hand-shake with the helper workgroups (the deferred replay and the per-node index of the evicted table are due before it either way —
+      // both are pure functions of state that exists already)
+      if (d.rs->replayPending | !d.rs->fairIndexValid) { ensureReplay(d, c); ensureFairIndex(d); }
+      FairArgs fa;
+      for (int r = 0; r < MAXR; r++) fa.req[r] = a.req[r];
+      fa.maskA = a.maskA; fa.maskB = a.maskB; fa.prio = sap; fa.pad = 0;
+      long long t1 = CLK();
+      int idx = wgScanFair(d, a, fa, &best);
+      d.rs->statClk[7] += CLK() - t1;   // (the pass itself; [6]: with the index check and the argument block)
+      d.rs->statClk[6] += CLK() - t0;
+      d.rs->numNodeQueries++;                        // the gate
+      XSEG(33);
+      if (best == ~0ull) return -1;
+      d.pcNode[job] = -1; d.pcPap[job] = ASCHED_MIN_PRIORITY;
+      n = fairApply(d, c, job, idx, fa.prio);
       XSEG(34);
       if (n >= 0) { d.pcMethod[job] = ASCHED_METHOD_FAIRSHARE; return n; }
+    } else {
+      best = wgFirstFitKey(d, a);
+      d.rs->statClk[6] += CLK() - t0;
+      d.rs->numNodeQueries++;                        // the gate
+      if (best == ~0ull) return -1;
     }
     d.pcNode[job] = -1; d.pcPap[job] = ASCHED_MIN_PRIORITY;
     if (d.cfg.disableUrgency) return -1;
