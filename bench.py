@@ -331,6 +331,7 @@ def round_shape_record(hip, args, label, kwargs, steps, note, warmup=1):
            "note": note, "metric": "scheduling rounds/sec", "value": 1.0 / float(np.mean(lat)), "unit": "rounds/s", "steps": steps, "ms_per_step": float(np.mean(lat)) * 1e3, "device_ms": float(np.mean(dev_ms)), "k_control_ms": kern_ms,
            "round": {"scheduled": len(res.scheduled), "preempted": len(res.preempted), "evicted_phase1": res.num_evicted_phase1, "evicted_phase3": res.num_evicted_phase3,
                      "loop_iterations": iters, "node_queries_issued": queries, "fast_iterations": st["fast_iterations"], "generic_iterations": st["generic_iterations"],
+                     "preempt_fast_iterations": st.get("preempt_fast_iterations", 0),   # jobs that needed preemption and stayed in the fast loop (node side: the generic cascade)
                      "termination_reason": res.termination_reason, "kclk_plane_scans": st["kclk_plane_scans"], "kclk_fair_selects": st["kclk_fair_selects"],
                      "kclk_pass1": st["kclk_pass1"], "kclk_pass2": st["kclk_pass2"], "l0_overflows": st["l0_overflows"]},
            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": "k_control",
