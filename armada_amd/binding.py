@@ -78,7 +78,7 @@ class CConfig(C.Structure):
         ("prefer_large_job_ordering", C.c_uint8), ("protect_uncapped_adjusted_fair_share", C.c_uint8),
         ("disable_home_scheduling", C.c_uint8), ("disable_away_scheduling", C.c_uint8),
         ("disable_gang_away_scheduling", C.c_uint8), ("disable_fairshare_scheduling", C.c_uint8),
-        ("disable_urgency_scheduling", C.c_uint8), ("pad_", C.c_uint8),
+        ("disable_urgency_scheduling", C.c_uint8), ("preempt_cross_pool_jobs_first", C.c_uint8),
         ("protected_fraction_of_fair_share", C.c_double),
         ("max_queue_lookback", C.c_uint32), ("pad2_", C.c_uint32),
         ("max_fraction_to_schedule", _f64p), ("disallowed_resource", _u8p),
@@ -117,6 +117,7 @@ class CJobs(C.Structure):
         ("m", C.c_int32), ("queue", _i32p), ("pc", _i32p), ("queue_priority", _u32p), ("submit_time", _i64p),
         ("req", _i64p), ("req_class", _i32p), ("gang_id", _i32p), ("gang_cardinality", _i32p),
         ("gang_uniformity_label", _i32p), ("node", _i32p), ("scheduled_at_priority", _i32p), ("run_timestamp", _i64p),
+        ("away", C.POINTER(C.c_uint8)),
     ]
 
 
@@ -322,6 +323,7 @@ class Config:
     disable_gang_away_scheduling: bool = False
     disable_fairshare_scheduling: bool = False
     disable_urgency_scheduling: bool = False
+    preempt_cross_pool_jobs_first: bool = False
     protected_fraction_of_fair_share: float = 0.0
     max_queue_lookback: int = 0
     max_fraction_to_schedule: Optional[Sequence[float]] = None
@@ -381,6 +383,7 @@ class Scheduler:
         c.disable_gang_away_scheduling = int(cfg.disable_gang_away_scheduling)
         c.disable_fairshare_scheduling = int(cfg.disable_fairshare_scheduling)
         c.disable_urgency_scheduling = int(cfg.disable_urgency_scheduling)
+        c.preempt_cross_pool_jobs_first = int(cfg.preempt_cross_pool_jobs_first)
         c.protected_fraction_of_fair_share = float(cfg.protected_fraction_of_fair_share)
         c.max_queue_lookback = int(cfg.max_queue_lookback)
         if cfg.max_fraction_to_schedule is not None:
@@ -486,7 +489,7 @@ class Scheduler:
 
     def jobs_set(self, req, *, queue=None, pc=None, queue_priority=None, submit_time=None, req_class=None, gang_id=None,
                  gang_cardinality=None, gang_uniformity_label=None, node=None, scheduled_at_priority=None,
-                 run_timestamp=None, class_tolerations=None, class_selectors=None, class_affinities=None):
+                 run_timestamp=None, class_tolerations=None, class_selectors=None, class_affinities=None, away=None):
         """class_affinities: per class None (no required node affinity) or a list of terms, a term = list of (key, op, [values])"""
         req = _arr(req, np.int64).reshape(-1, self.R)
         m = req.shape[0]
@@ -516,6 +519,7 @@ class Scheduler:
         put("node", node, np.int32, C.c_int32)
         put("scheduled_at_priority", scheduled_at_priority, np.int32, C.c_int32)
         put("run_timestamp", run_timestamp, np.int64, C.c_int64)
+        put("away", away, np.uint8, C.c_uint8)   # cross-pool away jobs (context.IsHomeJob false)
         cls = CReqClasses()
         tols = class_tolerations if class_tolerations is not None else [[]]
         sels = class_selectors if class_selectors is not None else [[] for _ in tols]

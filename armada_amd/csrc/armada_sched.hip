@@ -352,8 +352,9 @@ __device__ static inline int wgCompactIota(Dev& d, int n, const uint8_t* flag, i
 
 // lane-per-queue argmin under the reference's Less (a strict total order, so argmin == heap top).  Every lane reads its queue's Less inputs once; the
 // tournament moves the VALUES between lanes (no memory access per round)
-struct PqVal { int q; int32_t prio; double proposed, budget, current, size; int32_t name; };
+struct PqVal { int q; int32_t prio; double proposed, budget, current, size; int32_t name; int32_t away; };
 __device__ static inline bool pqLessV(const Ctl& c, const PqVal& a, const PqVal& b) {   // pqLess (round_ctl.h) on values
+  if (a.away != b.away) return !a.away;   // (0 everywhere unless preemptCrossPoolJobsFirst is set and cross-pool away jobs exist)
   if (a.prio != b.prio) return a.prio > b.prio;
   if (c.preferLarge) {
     if (a.proposed <= a.budget && b.proposed <= b.budget) {
@@ -371,19 +372,21 @@ __device__ static inline bool pqLessV(const Ctl& c, const PqVal& a, const PqVal&
 __device__ static inline double shflD(double v, int off) { return __shfl_xor(v, off, 64); }
 __device__ static inline int pqTop(Dev& d, const Ctl& c) {
   int lane = threadIdx.x & 63;
-  PqVal best; best.q = -1; best.prio = 0; best.proposed = best.budget = best.current = best.size = 0; best.name = 0;
+  PqVal best; best.q = -1; best.prio = 0; best.proposed = best.budget = best.current = best.size = 0; best.name = 0; best.away = 0;
   int Q = d.cfg.Q;
+  const bool homeFirst = d.cfg.preferHome && d.jAway;
   for (int base = 0; base < Q; base += 64) {  // same trip count on every lane: the wave stays converged for the shuffles below
     int q = base + lane;
     bool in = q < Q && d.pqInHeap[q < Q ? q : 0];
     if (in) {
       PqVal v; v.q = q; v.prio = c.compareSchedPrio ? d.pqSchedPrio[q] : d.pqPcPrio[q]; v.proposed = d.pqProposed[q]; v.budget = d.pqBudget[q]; v.current = d.pqCurrent[q]; v.size = d.pqSize[q]; v.name = d.qNameRank[q];
+      v.away = homeFirst ? (pqAway(d, q) ? 1 : 0) : 0;
       if (best.q < 0 || pqLessV(c, v, best)) best = v;
     }
   }
   for (int off = 32; off; off >>= 1) {
     PqVal o; o.q = __shfl_xor(best.q, off, 64); o.prio = __shfl_xor(best.prio, off, 64); o.proposed = shflD(best.proposed, off); o.budget = shflD(best.budget, off);
-    o.current = shflD(best.current, off); o.size = shflD(best.size, off); o.name = __shfl_xor(best.name, off, 64);
+    o.current = shflD(best.current, off); o.size = shflD(best.size, off); o.name = __shfl_xor(best.name, off, 64); o.away = __shfl_xor(best.away, off, 64);
     if (o.q >= 0 && (best.q < 0 || pqLessV(c, o, best))) best = o;
   }
   return best.q;

@@ -43,6 +43,7 @@ struct DevCfg {
   uint8_t pcPreemptible[MAXPC];
   double drfMult[MAXR];
   uint8_t preferLarge, protectUncapped, disableHome, disableAway, disableGangAway, disableFair, disableUrgency, hasAway;
+  uint8_t preferHome; uint8_t padHome_[7];   // preemptCrossPoolJobsFirst (queue_scheduler.go:744-746)
   double protectedFraction;
   uint32_t maxLookback;
   uint8_t disallowed[MAXR];
@@ -172,6 +173,7 @@ struct Dev {
   uint64_t* labelMask;   // [L][W] nodes carrying (uniformity label == value)
   // ---- jobs (immutable per jobs_set)
   int32_t *jQueue, *jPc, *jShape, *jGang, *jGangCard, *jGangUni, *jNode0, *jRunPrio, *jRankActive, *jRankInactive;
+  uint8_t* jAway;   // [M] cross-pool away jobs (asched_jobs.away); null = none
   int64_t* jReq;         // [M][R] row-major (control path reads one job = one 8*R byte burst)
   uint8_t* jAligned;     // [M] request is a multiple of the index resolution on every indexed column
   int32_t *gangOff, *gangJobs;  // CSR of (queue,gang) -> member jobs (jobRepo.GetGangJobsByGangId)

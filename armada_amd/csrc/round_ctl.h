@@ -175,6 +175,8 @@ DEV void markAllocatable(Dev& d, int n, int32_t cutoff, const int64_t* req, int 
     if (c.prios[l] <= cutoff)
       for (int r = 0; r < c.R; r++) AL(d, l, r, n) += sign * req[r];
 }
+// bindJobToNodeInPlace (nodedb.go:1055-1068): a cross-pool ("away") job is accounted at CrossPoolPriority whatever priority it is bound with
+DEV int32_t bindPriority(const Dev& d, int job, int32_t prio) { return (d.jAway && d.jAway[job]) ? ASCHED_CROSS_POOL_PRIORITY : prio; }
 DEV int32_t cutoffFor(Dev& d, int job, int32_t prio) {  // priorityCutoffFor (is/nodedb/nodedb.go:1329-1334)
   return d.cfg.pcPreemptible[d.jPc[job]] ? prio : NONPREEMPTIBLE_CUTOFF;
 }
@@ -369,8 +371,7 @@ DEV int checkJob(Dev& d, int ref) {
   if (d.hasPcLimit && vexceeds(d, QPV(d.qAllocByPc, q, pc), QPV(d.qPcLimit, q, pc))) return ASCHED_REASON_RESOURCE_LIMIT_EXCEEDED;
   return 0;
 }
-// sctx.IsWithinFloatingResourceLimits (context/scheduling.go:574-597) + FloatingResourceTypes.WithinLimits (floating_resource_types.go:60-72);
-// every job of a single-pool handle is a home job
+// sctx.IsWithinFloatingResourceLimits (context/scheduling.go:574-597) + FloatingResourceTypes.WithinLimits (floating_resource_types.go:60-72)
 DEV int checkFloating(Dev& d, int ref) {
   const DevCfg& c = d.cfg;
   if (!c.anyFloating) return 0;
@@ -378,6 +379,7 @@ DEV int checkFloating(Dev& d, int ref) {
   int cnt = gcCount(d, ref);
   for (int k = 0; k < cnt && !requests; k++) { const int64_t* rq = JREQ(d, gcJob(d, ref, k)); for (int r = 0; r < c.R; r++) if (c.isFloating[r] && rq[r] != 0) requests = true; }
   if (!requests) return 0;
+  if (d.jAway) for (int k = 0; k < cnt; k++) if (d.jAway[gcJob(d, ref, k)]) return 0;   // a gang from another pool passed this check there (context/scheduling.go:583-594)
   if (!c.floatingConfigured) return ASCHED_REASON_FLOATING_NOT_CONFIGURED;   // available.AllZero()
   for (int r = 0; r < c.R; r++) if (c.isFloating[r] && d.rs->allocated[r] > c.floatingLimit[r]) return ASCHED_REASON_FLOATING_EXCEEDED;
   return 0;
@@ -809,7 +811,7 @@ DEV_COLD bool scheduleMany(Dev& d, Ctl& c, int ref) {
     int pre1 = c.preCount;
     for (int i = pre0; i < pre1; i++) removeJob(d, n, c.preList[i], true);  // victims leave the returned node copy (nodedb.go:1012-1023)
     XSEG(26);
-    int32_t prio = d.pcSap[job];
+    int32_t prio = bindPriority(d, job, d.pcSap[job]);
     if (addJob(d, n, job, cutoffFor(d, job, prio), true)) return false;     // BindJobToNode :1046-1068
     XSEG(27);
     d.schedAtPrio[job] = prio;                                              // not rolled back on abort (plain Go map)
@@ -1036,8 +1038,10 @@ DEV void updateItem(Dev& d, Ctl& c, int q, const PassCfg& pc) {  // updatePQItem
 }
 DEV void updateAndPush(Dev& d, Ctl& c, int q, const PassCfg& pc) { updateItem(d, c, q, pc); d.pqInHeap[q] = d.pqGctx[q] != -1; }
 
-// QueueCandidateGangIteratorPQ.Less (queue_scheduler.go:738-798); single pool => never "away"
+// QueueCandidateGangIteratorPQ.Less (queue_scheduler.go:738-798)
+DEV bool pqAway(Dev& d, int q) { int ref = d.pqGctx[q]; return d.jAway && ref != -1 && gcCount(d, ref) > 0 && d.jAway[gcJob(d, ref, 0)] != 0; }   // item.away (:649)
 DEV bool pqLess(Dev& d, const Ctl& c, int a, int b) {
+  if (d.cfg.preferHome && d.jAway) { bool aa = pqAway(d, a), ab = pqAway(d, b); if (aa != ab) return !aa; }   // :744-746
   if (c.compareSchedPrio) { if (d.pqSchedPrio[a] != d.pqSchedPrio[b]) return d.pqSchedPrio[a] > d.pqSchedPrio[b]; }
   else { if (d.pqPcPrio[a] != d.pqPcPrio[b]) return d.pqPcPrio[a] > d.pqPcPrio[b]; }
   double pa = d.pqProposed[a], pb = d.pqProposed[b], ba = d.pqBudget[a], bb = d.pqBudget[b];

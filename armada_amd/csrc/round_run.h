@@ -287,7 +287,7 @@ DEV void bulkElem(Dev& d, int kind, int i) {
     case B_POPULATE: {  // populateNodeDb: bind every running job (nodedb.go:57-75, scheduling_algo.go:1019-1098)
       int n = d.jNode0[i];
       if (n < 0) break;
-      int32_t prio = d.jRunPrio[i];
+      int32_t prio = bindPriority(d, i, d.jRunPrio[i]);
       int32_t cutoff = cutoffFor(d, i, prio);
       atomicMarkAllocatable(d, n, cutoff, JREQ(d, i), -1);
       d.jobNode[i] = n; d.jobCutoff[i] = cutoff; d.schedAtPrio[i] = prio;
@@ -763,7 +763,7 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
     } break;
     case CMD_BIND: {
       d.rs->apiDirty = 1;
-      int job = ARG(0), n = ARG(1), prio = ARG(2);
+      int job = ARG(0), n = ARG(1), prio = bindPriority(d, ARG(0), ARG(2));
       if (addJob(d, n, job, cutoffFor(d, job, prio), c.txn.active) == 0) {
         d.schedAtPrio[job] = prio;
         updateKeysCtl(d, n);

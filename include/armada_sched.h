@@ -129,7 +129,8 @@ typedef struct asched_config {
   uint8_t protect_uncapped_adjusted_fair_share;
   uint8_t disable_home_scheduling, disable_away_scheduling, disable_gang_away_scheduling;
   uint8_t disable_fairshare_scheduling, disable_urgency_scheduling;
-  uint8_t pad_;
+  uint8_t preempt_cross_pool_jobs_first;  /* PreemptCrossPoolJobsFirst: gangs of home jobs order before gangs of cross-pool away jobs, in the scheduling loop and
+                                             in the eviction-order replay (queue_scheduler.go:744-746; pqs.go:603-606).  Away jobs: asched_jobs.away */
   double protected_fraction_of_fair_share;
   uint32_t max_queue_lookback;        /* 0 = unlimited (queue_scheduler.go:434-444) */
   uint32_t pad2_;
@@ -237,6 +238,11 @@ typedef struct asched_jobs {
   const int32_t* node;             /* [m] node (position in asched_nodes) of the active run, -1 = queued */
   const int32_t* scheduled_at_priority; /* [m] run.ScheduledAtPriority for running jobs */
   const int64_t* run_timestamp;    /* [m] activeRunTimestamp (comparison.go:83-89) */
+  const uint8_t* away;             /* [m] 1 = cross-pool away job: a running job whose latest run belongs to ANOTHER pool (context.IsHomeJob false, context/util.go:9-16);
+                                      NULL = none.  Such a job is bound at CrossPoolPriority (-1) whatever its run says (bindJobToNodeInPlace, nodedb.go:1055-1068 —
+                                      the NodeDb knows its pool), skips this pool's floating-resource limits (context/scheduling.go:585-594), orders after home jobs
+                                      when preempt_cross_pool_jobs_first is set, and belongs to the "<queue>-away" queue context: `queue` holds that context's index
+                                      (CalculateAwayQueueName; jobiteration.go:88-94, context/scheduling.go:225-226, 412-413, 646-647) */
 } asched_jobs;
 
 /* ---- per-queue round inputs (context.AddQueueSchedulingContext, scheduling/context/scheduling.go:114-166) ---- */

@@ -272,6 +272,7 @@ func NewGpuRound(cfg configuration.SchedulingConfig, rlf *internaltypes.Resource
 		return 0
 	}
 	c.prefer_large_job_ordering = b(cfg.EnablePreferLargeJobOrdering)
+	c.preempt_cross_pool_jobs_first = b(cfg.GetPreemptCrossPoolJobsFirst(pool)) // preempting_queue_scheduler.go:61-80
 	c.protected_fraction_of_fair_share = C.double(cfg.GetProtectedFractionOfFairShare(pool))
 	c.protect_uncapped_adjusted_fair_share = b(cfg.GetProtectUncappedAdjustedFairShare(pool))
 	c.max_queue_lookback = C.uint32_t(cfg.MaxQueueLookback)
@@ -403,6 +404,7 @@ func (g *GpuRound) UploadJobs(jobs []*jobdb.Job, queueIndex map[string]int32) er
 	req := make([]int64, m*R)
 	gangId, gangCard, gangUni := make([]int32, m), make([]int32, m), make([]int32, m)
 	node, runPrio := make([]int32, m), make([]int32, m)
+	away, anyAway := make([]uint8, m), false
 	gangIds := map[string]int32{}
 	var classes []reqClass
 	classKey := func(j *jobdb.Job) (string, reqClass) {
@@ -488,8 +490,16 @@ func (g *GpuRound) UploadJobs(jobs []*jobdb.Job, queueIndex map[string]int32) er
 			}
 		}
 		node[i] = -1
-		if run := j.LatestRun(); !j.Queued() && run != nil && run.Pool() == g.pool {
+		// A run in another pool on one of this NodeDb's nodes is a cross-pool away job (context.IsHomeJob false): it is accounted against the
+		// "<queue>-away" context (queueIndex holds those beside the home contexts: scheduling_algo.go:840-867) and flagged for the library, which
+		// binds it at CrossPoolPriority and orders it after home jobs (include/armada_sched.h asched_jobs.away).
+		if run := j.LatestRun(); !j.Queued() && run != nil {
 			if p, ok := g.nodePos[run.NodeId()]; ok {
+				if run.Pool() != g.pool {
+					away[i] = 1
+					anyAway = true
+					queue[i] = queueIndex[schedulercontext.CalculateAwayQueueName(j.Queue())]
+				}
 				node[i] = p
 				runTs[i] = j.ActiveRunTimestamp()
 				if sp := run.ScheduledAtPriority(); sp != nil {
@@ -561,6 +571,10 @@ func (g *GpuRound) UploadJobs(jobs []*jobdb.Job, queueIndex map[string]int32) er
 		in.submit_time, in.run_timestamp, in.req = i64p(submit), i64p(runTs), i64p(req)
 		in.gang_id, in.gang_cardinality, in.gang_uniformity_label = pin32(gangId), pin32(gangCard), pin32(gangUni)
 		in.node, in.scheduled_at_priority = pin32(node), pin32(runPrio)
+		if anyAway {
+			pins.Pin(&away[0])
+			in.away = (*C.uint8_t)(unsafe.Pointer(&away[0]))
+		}
 	}
 	return g.check(C.asched_jobs_set(g.h, &in, &cls))
 }

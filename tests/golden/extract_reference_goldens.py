@@ -242,8 +242,10 @@ def main():
     out["pqs"] = extract_table(f"{REF}/scheduling/preempting_queue_scheduler_test.go", "TestPreemptingQueueScheduler", env, skipped)
     out["queue_scheduler"] = extract_table(f"{REF}/scheduling/queue_scheduler_test.go", "TestQueueScheduler", env, skipped)
     # gang_scheduler_test.go:943-951 addFloatingResourceRequest: the floating request stays in the job's vector (AllResourceRequirements); the
-    # library keeps it away from the nodes.  createAwayJob (:821-823, a job whose run is in another pool) stays unknown: cross-pool jobs are not modelled
+    # library keeps it away from the nodes.  createAwayJob (:821-823): Test1Cpu4GiJob(TestQueue, PriorityClass2).WithNewRun(..., pool "away", priority 1) —
+    # a job whose latest run belongs to another pool (context.IsHomeJob false): the job dict carries "away": true
     genv = dict(env)
+    genv["createAwayJob"] = lambda: dict(gofixtures.Test1Cpu4GiJob(env["testfixtures.TestQueue"], env["testfixtures.PriorityClass2"]), away=True)
     genv["addFloatingResourceRequest"] = lambda req, jobs: gofixtures.WithRequestsJobs({"test-floating-resource": gofixtures.MustParse(req)}, jobs)
     gofixtures.ALLOW_FLOATING_REQUESTS = True
     try:

@@ -171,7 +171,8 @@ class Case:
             submit_time=[j["created"] for j in jobs],
             req_class=req_class, gang_id=gang_id, gang_cardinality=gang_card, gang_uniformity_label=gang_uni,
             node=node, scheduled_at_priority=sap, run_timestamp=rts,
-            class_tolerations=cls_tol, class_selectors=cls_sel, class_affinities=cls_aff)
+            class_tolerations=cls_tol, class_selectors=cls_sel, class_affinities=cls_aff,
+            away=[1 if j.get("away") else 0 for j in jobs] if any(j.get("away") for j in jobs) else None)
 
     def sort_queued(self, jobs: List[dict], idxs: List[int]) -> List[int]:
         """SchedulingOrderCompare for queued (non-active) jobs: jobdb/comparison.go:49-107"""
@@ -379,13 +380,15 @@ def run_gang_case(lib: Library, case: dict):
         return "skip: " + why
     if case.get("TotalResources") and any(case["TotalResources"].values()):
         return "skip: explicit TotalResources"
-    if case.get("AddAwayQueueContexts"):
-        return "skip: cross-pool away queues"
     c = Case(lib, cfg, case["Nodes"])
     s = c.sched
     queues = sorted({j["queue"] for j in jobs})
+    if case.get("AddAwayQueueContexts"):   # gang_scheduler_test.go:610-617: an "<queue>-away" context beside every queue (context.CalculateAwayQueueName)
+        queues = sorted(set(queues) | {q + "-away" for q in queues})
     qidx = {q: i for i, q in enumerate(queues)}
     Q = len(queues)
+    # a cross-pool away job is accounted against its queue's away context (context/scheduling.go:412-413)
+    jobs = [dict(j, queue=j["queue"] + "-away") if j.get("away") else j for j in jobs]
     c.set_jobs(jobs, qidx, {})
     glim = Tokens(cfg["maximum_scheduling_rate"], cfg["maximum_scheduling_burst"])
     qlim = Tokens(cfg["maximum_per_queue_scheduling_rate"], cfg["maximum_per_queue_scheduling_burst"])
