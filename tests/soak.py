@@ -4,6 +4,7 @@
     python tests/soak.py rounds 3000        # workloads.small_random rounds, random sizes / occupancy / gangs / bursts / away / ragged
     python tests/soak.py streams 1000        # medium rounds (<= 1500 nodes, <= 20000 jobs) dominated by stream runs and gangs through the ring; HS_STREAM_EAGER=1: a run wherever one can start
     python tests/soak.py preempt 1500       # small crowded rounds (60-100 % occupied), most with a fair-share preemption rate limit: the jobs that need preemption stay in the fast loop (fastPreemptIter)
+    python tests/soak.py away 1500          # crowded rounds with a third of the running jobs cross-pool away jobs and "<queue>-away" contexts (tests/test_z_cross_pool_away.py)
     python tests/soak.py features 400       # tests/test_z_feature_mix.py rounds (affinity, conditional away, extra column, limits ...)
     python tests/soak.py ops 3000           # tests/test_z_nodedb_op_sequences.py NodeDb-level operation sequences
     python tests/soak.py submitcheck 400    # batched SubmitChecker vs the literal sequential restatement (and 3-entry cache)
@@ -47,6 +48,13 @@ def main():
                 res = []
                 for lib in (orc, hs):
                     s = W.load(lib, wl); W.prepare(s, wl); res.append(s.schedule_round())
+                scenario.assert_same_round(res[0], res[1])
+            elif kind == "away":
+                import test_z_cross_pool_away as A
+                wl = A.with_away(seed, prefer_home=seed % 2 == 0, frac=[0.1, 0.3, 0.6][seed % 3])
+                res = []
+                for lib in (orc, hs):
+                    s = W.load(lib, wl); W.prepare(s, wl); res.append(s.schedule_round()); s.close()
                 scenario.assert_same_round(res[0], res[1])
             elif kind == "preempt":
                 rng = np.random.default_rng(seed)
