@@ -677,11 +677,12 @@ DEV_COLD int selectAtPriority(Dev& d, Ctl& c, int job) {
     if (lp == 1) { a.level = 1; a.levelHi = 0; }   // one level: the plain pass
     long long t0 = CLK();
     uint64_t best;
-    if (!d.cfg.disableFair) {
+    if (!d.cfg.disableFair && !d.rs->replayPending) {
       // the gate and the per-node evaluation of fair-share preemption read the same nodes and neither depends on the other's answer: ONE wide pass,
-      // one hand-shake with the helper workgroups (the deferred replay and the per-node index of the evicted table are due before it either way —
-      // both are pure functions of state that exists already)
-      if (d.rs->replayPending | !d.rs->fairIndexValid) { ensureReplay(d, c); ensureFairIndex(d); }
+      // one hand-shake with the helper workgroups.  The per-node index of the evicted table is due before it (a pure function of the table); while
+      // the replay of the evicted jobs is still deferred the two questions are asked one after the other as before — the replay runs loops of its
+      // own and belongs where the reference runs it: after a gate that passed.
+      ensureFairIndex(d);
       FairArgs fa;
       for (int r = 0; r < MAXR; r++) fa.req[r] = a.req[r];
       fa.maskA = a.maskA; fa.maskB = a.maskB; fa.prio = sap; fa.pad = 0;
@@ -701,6 +702,11 @@ DEV_COLD int selectAtPriority(Dev& d, Ctl& c, int job) {
       d.rs->statClk[6] += CLK() - t0;
       d.rs->numNodeQueries++;                        // the gate
       if (best == ~0ull) return -1;
+      d.pcNode[job] = -1; d.pcPap[job] = ASCHED_MIN_PRIORITY;
+      if (!d.cfg.disableFair) {
+        n = selectWithFairPreemption(d, c, job);
+        if (n >= 0) { d.pcMethod[job] = ASCHED_METHOD_FAIRSHARE; return n; }
+      }
     }
     d.pcNode[job] = -1; d.pcPap[job] = ASCHED_MIN_PRIORITY;
     if (d.cfg.disableUrgency) return -1;

@@ -1355,7 +1355,7 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
 // limiters give up cnt tokens (ReserveN), the queue's next head is produced.  A member without a node: nothing has reached HBM but "this base entry is
 // stale" flags; the nodes the placed members went to are re-read into the level-0 structure (fastTouch) and the generic code runs the gang from the state
 // it would have found (it decides about preemption, the failure reason, the unfeasible-key registration).
-struct GangOut { int handled, cnt, pend, dropped, engSeq, refills, evicted; };
+struct GangOut { int handled, cnt, pend, dropped, engSeq, refills, evicted; int koValid; uint32_t koA; uint64_t koX, koY; };   // ko*: the queue's next key (fastAdvance)
 DEV_NOINLINE GangOut fastGangRun(Dev& d, FastCtx fc, StreamIn in, int t) {
   const FastK k = fastKRef(d);
   FastS S; coldS(d, S);
@@ -1408,6 +1408,7 @@ DEV_NOINLINE GangOut fastGangRun(Dev& d, FastCtx fc, StreamIn in, int t) {
   if (!f.rateInf && cnt <= f.burst) f.tokens -= (double)cnt;   // rate.Limiter.ReserveN(cnt) (gang_scheduler.go:118-123)
   KeyOut ko;
   if (!fastAdvance(d, k, S, fc, t, f, &ko)) out.pend = t;
+  out.koValid = ko.valid; out.koA = ko.A; out.koX = ko.X; out.koY = ko.Y;
   out.handled = 1; out.cnt = cnt; out.refills = S.statRefills; out.evicted = S.numEvictedJobs;
   return out;
 }
@@ -1422,7 +1423,7 @@ DEV_NOINLINE GangOut fastGangRun(Dev& d, FastCtx fc, StreamIn in, int t) {
 // The caller has stopped the node engine (the cascade's wide passes need every wave of the workgroup; it reads planes the binds must have reached)
 // and written its scalars back to RS.  Returns 0 = not handled (nothing touched), 1 = done, 2 = done + the generic code must produce the queue's
 // next head, 3 = done + leave the fast loop (the fair-share preemption rate limit ran dry: queue_scheduler.go:125-142 is the generic loop's).
-DEV __attribute__((always_inline)) int fastPreemptIter(Dev& d, Ctl& c, FastCtx fc, int t) {   // (inlined: as a call it saves and restores 109 registers per job)
+DEV __attribute__((always_inline)) int fastPreemptIter(Dev& d, Ctl& c, FastCtx fc, int t, KeyOut* koOut) {   // (inlined: as a call it saves and restores 109 registers per job)
 #ifdef ASCHED_HOSTSIM
   if (getenv("HS_NO_PREEMPT_FAST")) return 0;
 #endif
@@ -1470,6 +1471,7 @@ DEV __attribute__((always_inline)) int fastPreemptIter(Dev& d, Ctl& c, FastCtx f
   XSEG(37);
   KeyOut ko;
   bool more = fastAdvance(d, k, S, fc, t, f, &ko);
+  *koOut = ko;
   XSEG(38);
   if (FLANE == 0) { RS.numEvictedJobs += S.numEvictedJobs; RS.statRefills += S.statRefills; }
   if (!more) return 2;
@@ -1590,8 +1592,8 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
       S.numScheduledJobs += go.cnt; S.numScheduledGangs += 1; S.numNodeQueries += go.cnt; S.loopIterations++; S.statFastIters++;
       if (!S.globalRateInf && go.cnt <= S.globalBurst) S.globalTokens -= (double)go.cnt;
       S.statRefills += go.refills; S.numEvictedJobs += go.evicted;
-      pqBuild(pq, Q);
       if (go.pend >= 0) { pend = go.pend; break; }
+      { KeyOut gk; gk.valid = go.koValid; gk.A = go.koA; gk.X = go.koX; gk.Y = go.koY; pqPopPush(pq, gk, t); }   // the gang's queue is the head: re-insert it under its next key
       continue;
     }
     if (fc.stream && S.fastActive && S.statFastIters >= streamNextAt) {
@@ -1651,10 +1653,10 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
       if (S.engLive) { engineStop(d, S); S.engLive = 0; if (UNI32(FL.eng.cancel)) { c.cancelSeen = 1; break; } }
       S.inlineStreak = 0;
       FAST_SCALARS_OUT()
-      int hc = fastPreemptIter(d, c, fc, t);
+      int hc = fastPreemptIter(d, c, fc, t, &ko);
       FAST_SCALARS_IN()
       if (hc == 0) break;
-      pqBuild(pq, Q);
+      pqPopPush(pq, ko, t);   // (only the served queue's entry changes: re-inserting it is one lane shift, sorting the heap again is 64 rounds of lane exchanges)
       XSEG(39);
       if (hc == 2) { pend = t; break; }
       if (hc == 3 || RS.error) break;

@@ -144,3 +144,23 @@ def test_gang_peek_on_and_off_is_the_same_round(hostsim_lib, oracle_lib, gangs, 
 def test_gang_behind_folded_evicted_streams_gpu(hip_lib, oracle_lib):
     for seed in (100345, 102465):
         both(hip_lib, oracle_lib, _soak_round_workload(seed))
+
+
+def _soak_stream_workload(seed):
+    """the workload tests/soak.py `streams` builds for a seed"""
+    rng = np.random.default_rng(seed)
+    nn, nj, nq = int(rng.integers(100, 1500)), int(rng.integers(2000, 20000)), int(rng.integers(2, 40))
+    wl = W.config3(seed=seed, n_nodes=nn, n_jobs=nj, n_queues=nq, gangs=int(rng.choice([0, 0, 5, 50])), occupied=float(rng.choice([0.2, 0.5, 0.8, 0.93])))
+    wl.global_burst = int(rng.choice([nj, nj // 3, 500])); wl.queue_burst = int(rng.choice([nj, max(10, nj // nq), 64])); wl.rate_inf = bool(rng.random() < 0.2)
+    if rng.random() < 0.3:
+        wl.config.max_queue_lookback = int(rng.choice([50, 500, 3000]))
+    return wl
+
+
+@pytest.mark.parametrize("seed", [100372, 100488])
+def test_deferred_replay_runs_after_a_gate_that_passed(hostsim_lib, oracle_lib, seed, monkeypatch):
+    """The eviction-order replay (addEvictedJobsToNodeDb, pqs.go:589-639) is deferred to its first use, the fair-share attempt of a job whose feasibility
+    gate passed (nodedb.go:724-789).  Running it earlier — before a gate that then FAILS, as a first version of the one-pass gate + evaluation did —
+    changes the round: found by the stream soak with a run started wherever one can start."""
+    monkeypatch.setenv("HS_STREAM_EAGER", "1")
+    both(hostsim_lib, oracle_lib, _soak_stream_workload(seed))
