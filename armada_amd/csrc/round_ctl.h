@@ -175,8 +175,9 @@ DEV void markAllocatable(Dev& d, int n, int32_t cutoff, const int64_t* req, int 
     if (c.prios[l] <= cutoff)
       for (int r = 0; r < c.R; r++) AL(d, l, r, n) += sign * req[r];
 }
-// bindJobToNodeInPlace (nodedb.go:1055-1068): a cross-pool ("away") job is accounted at CrossPoolPriority whatever priority it is bound with
-DEV int32_t bindPriority(const Dev& d, int job, int32_t prio) { return (d.jAway && d.jAway[job]) ? ASCHED_CROSS_POOL_PRIORITY : prio; }
+// bindJobToNodeInPlace (nodedb.go:1055-1068): a cross-pool ("away") job is accounted at CrossPoolPriority whatever priority it is bound with — when the
+// NodeDb knows its pool, which it does exactly when cross-pool preemption ordering is on for the pool (scheduling_algo.go:759-764)
+DEV int32_t bindPriority(const Dev& d, int job, int32_t prio) { return (d.cfg.preferHome && d.jAway && d.jAway[job]) ? ASCHED_CROSS_POOL_PRIORITY : prio; }
 DEV int32_t cutoffFor(Dev& d, int job, int32_t prio) {  // priorityCutoffFor (is/nodedb/nodedb.go:1329-1334)
   return d.cfg.pcPreemptible[d.jPc[job]] ? prio : NONPREEMPTIBLE_CUTOFF;
 }

@@ -239,9 +239,9 @@ typedef struct asched_jobs {
   const int32_t* scheduled_at_priority; /* [m] run.ScheduledAtPriority for running jobs */
   const int64_t* run_timestamp;    /* [m] activeRunTimestamp (comparison.go:83-89) */
   const uint8_t* away;             /* [m] 1 = cross-pool away job: a running job whose latest run belongs to ANOTHER pool (context.IsHomeJob false, context/util.go:9-16);
-                                      NULL = none.  Such a job is bound at CrossPoolPriority (-1) whatever its run says (bindJobToNodeInPlace, nodedb.go:1055-1068 —
-                                      the NodeDb knows its pool), skips this pool's floating-resource limits (context/scheduling.go:585-594), orders after home jobs
-                                      when preempt_cross_pool_jobs_first is set, and belongs to the "<queue>-away" queue context: `queue` holds that context's index
+                                      NULL = none.  Such a job skips this pool's floating-resource limits (context/scheduling.go:585-594) and, when
+                                      preempt_cross_pool_jobs_first is set, is bound at CrossPoolPriority (-1) whatever its run says (bindJobToNodeInPlace,
+                                      nodedb.go:1055-1068: the NodeDb is told its pool exactly then, scheduling_algo.go:759-764) and orders after home jobs; it belongs to the "<queue>-away" queue context: `queue` holds that context's index
                                       (CalculateAwayQueueName; jobiteration.go:88-94, context/scheduling.go:225-226, 412-413, 646-647) */
 } asched_jobs;
 

@@ -86,6 +86,7 @@ class Case:
             disable_home_scheduling=cfg["disable_home"], disable_away_scheduling=cfg["disable_away"],
             disable_gang_away_scheduling=cfg["disable_gang_away"], disable_fairshare_scheduling=cfg["disable_fairshare"],
             disable_urgency_scheduling=cfg["disable_urgency"],
+            preempt_cross_pool_jobs_first=bool(cfg.get("preempt_cross_pool_jobs_first", False)),   # PoolConfig.ShouldPreemptCrossPoolJobsFirst (hand-written cross-pool tests)
             protected_fraction_of_fair_share=cfg["protected_fraction_of_fair_share"],
             max_queue_lookback=cfg["max_queue_lookback"],
             max_fraction_to_schedule=[float(inf(frac.get(r, "inf"))) for r in RES],

@@ -89,3 +89,80 @@ def test_home_gangs_order_before_away_gangs(oracle_lib, hostsim_lib):
 def test_rounds_with_away_jobs_gpu(hip_lib, oracle_lib):
     for seed in range(8):
         both(hip_lib, oracle_lib, with_away(810000 + seed, prefer_home=seed % 2 == 0))
+
+
+# ------------------------------------------------------------------------------------------------ the reference's own cross-pool tests, by hand
+import os, sys  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import gofixtures as F  # noqa: E402
+import scenario  # noqa: E402
+
+
+@pytest.fixture(params=["oracle", "hostsim", pytest.param("hip", marks=pytest.mark.gpu)])
+def lib(request):
+    return request.getfixturevalue({"oracle": "oracle_lib", "hostsim": "hostsim_lib", "hip": "hip_lib"}[request.param])
+
+
+@pytest.mark.parametrize("name,pool_known,away,expected", [
+    ("away when nodeDb pool differs", True, True, CROSS_POOL_PRIORITY),
+    ("home when nodeDb pool matches run pool", True, False, None),
+    ("home when nodeDb pool unset (cross-pool detection off)", False, True, None),
+])
+def test_bind_cross_pool_job_bucketing(lib, name, pool_known, away, expected):
+    """nodedb_test.go:266-309 TestBindCrossPoolJobBucketing: BindJobToNode records CrossPoolPriority for a job whose run lives in another pool, its own
+    priority otherwise — also when the NodeDb has not been told its pool (here: preempt_cross_pool_jobs_first off, scheduling_algo.go:759-764)"""
+    cfg = F.TestSchedulingConfig()
+    cfg["preempt_cross_pool_jobs_first"] = pool_known
+    job = dict(F.Test1Cpu4GiJob("queue-a", F.PriorityClass0), away=away)
+    c = scenario.Case(lib, cfg, [F.Test32CpuNode(F.TestPriorities)])
+    c.set_jobs([job], {"queue-a": 0}, {})
+    prio = F.TEST_PRIORITY_CLASSES[F.PriorityClass0]["priority"]
+    c.sched.bind(0, 0, prio)
+    got, ok = c.sched.get_scheduled_at_priority(0)     # priority, ok := nodeDb.GetScheduledAtPriority(job.Id())
+    assert ok and got == (prio if expected is None else expected), name
+
+
+@pytest.mark.parametrize("flag_on,preemptions,scheduled", [(True, 5, 5), (False, 0, 0)])
+def test_cross_pool_preempted_first(lib, flag_on, preemptions, scheduled):
+    """preempting_queue_scheduler_test.go:3504-3634 TestPreemptingQueueScheduler_CrossPoolPreemptedFirst: five preemptible priority-2 jobs of another pool
+    fill a 5-cpu node; five queued home jobs of priority 0 preempt them when cross-pool jobs are bound at CrossPoolPriority (flag on) and cannot when the
+    NodeDb does not know its pool (flag off).  Queue contexts as in the test: "A" with the home demand, "A-away" with the cross-pool allocation."""
+    cfg = F.TestSchedulingConfig()
+    cfg["preempt_cross_pool_jobs_first"] = flag_on
+    node = F.TestNode(F.TestPriorities, {"cpu": "5", "memory": "64Gi"})
+    cross = [dict(j, away=True, queue="A-away") for j in F.N1Cpu4GiJobs("A", F.PriorityClass2, 5)]
+    home = F.N1Cpu4GiJobs("A", F.PriorityClass0, 5)
+    jobs = cross + home
+    c = scenario.Case(lib, cfg, [node])
+    p2 = F.TEST_PRIORITY_CLASSES[F.PriorityClass2]["priority"]
+    c.set_jobs(jobs, {"A": 0, "A-away": 1}, {i: (0, p2, i + 1) for i in range(5)})
+    demand = np.zeros((2, scenario.R), dtype=np.int64)
+    for j in home:
+        demand[0] += np.array(scenario.vec(j["req"]), dtype=np.int64)
+    c.sched.round_prepare([1.0, 1.0], [c.sort_queued(jobs, list(range(5, 10))), []], name_rank=[0, 1], demand=demand)
+    res = c.sched.schedule_round()
+    c.no_oversubscription()
+    assert len(res.preempted) == preemptions and len(res.scheduled) == scheduled
+    assert all(j < 5 for j in res.preempted), "only cross-pool jobs are preempted"
+    assert all(j >= 5 for j in res.scheduled), "only home jobs are scheduled"
+
+
+def test_oversubscribed_evictor_takes_the_cross_pool_jobs(lib):
+    """preempting_queue_scheduler_test.go:168-220 TestEvictOversubscribed_CrossPoolJobsEvicted: 20 cross-pool and 20 home jobs (all priority 0) on a 32-cpu
+    node.  Both debit the CrossPoolPriority bucket, which goes negative; only the home jobs debit priority 0, which does not: the oversubscribed evictor
+    evicts exactly the cross-pool jobs.  The reference calls the evictor alone; here it runs inside a round (nothing is queued, protected fraction 1 keeps
+    the balance evictor out of it): the 12 cross-pool jobs the node still has room for come back, the other 8 are the round's preemptions — no home job."""
+    cfg = F.TestSchedulingConfig()
+    cfg["preempt_cross_pool_jobs_first"] = True
+    cfg["protected_fraction_of_fair_share"] = 100.0
+    node = F.Test32CpuNode(F.TestPriorities)
+    cross = [dict(j, away=True, queue="away-queue-away") for j in F.N1Cpu4GiJobs("away-queue", F.PriorityClass0, 20)]
+    home = F.N1Cpu4GiJobs("home-queue", F.PriorityClass0, 20)
+    jobs = cross + home
+    c = scenario.Case(lib, cfg, [node])
+    p0 = F.TEST_PRIORITY_CLASSES[F.PriorityClass0]["priority"]
+    c.set_jobs(jobs, {"away-queue-away": 0, "home-queue": 1}, {i: (0, p0, i + 1) for i in range(40)})
+    c.sched.round_prepare([1.0, 1.0], [[], []], name_rank=[0, 1])
+    res = c.sched.schedule_round()
+    assert len(res.scheduled) == 0
+    assert len(res.preempted) == 8 and all(j < 20 for j in res.preempted)
