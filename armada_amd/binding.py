@@ -150,6 +150,10 @@ class CPqItem(C.Structure):
                 ("pc_priority", C.c_int32), ("scheduling_priority", C.c_int32), ("name_rank", C.c_int32), ("away", C.c_int32)]
 
 
+class CMarketJob(C.Structure):
+    _fields_ = [("price", C.c_double), ("runtime", C.c_int64), ("submit_time", C.c_int64), ("queued", C.c_int32), ("away", C.c_int32)]
+
+
 class CSubmitResult(C.Structure):
     _fields_ = [("ok", C.c_int32), ("scheduled_away", C.c_int32), ("num_schedulable", C.c_int32), ("first_node", C.c_int32)]
 
@@ -177,6 +181,7 @@ ALL_SYMBOLS = [
     "round_prepare", "schedule_round", "schedule_queues", "gang_schedule", "round_counters", "job_key_unfeasible", "kernel_times", "round_stats",
     "clear_allocated", "submit_check", "pq_order", "submit_stats", "num_nodes", "total_resources", "node_types_matching_job", "scheduling_order",
     "optimiser_schedule_job", "set_label_value_ints", "round_timing", "set_deadline", "cancel", "indexed_node_label_values", "get_node_jobs", "get_nodes_alloc", "node_upsert",
+    "market_iterate",
 ]
 
 
@@ -256,6 +261,7 @@ class Library:
         f("nodes_upsert", C.c_int32, [C.c_void_p, C.POINTER(CNodes)])
         f("jobs_set", C.c_int32, [C.c_void_p, C.POINTER(CJobs), C.POINTER(CReqClasses)])
         f("pq_order", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(CPqItem), C.c_int32, C.c_int32, _i32p, _i32p])
+        f("market_iterate", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i32p, C.POINTER(CMarketJob), C.c_int32, _i32p])
         f("submit_stats", C.c_int32, [C.c_void_p, _i32p])
         f("num_nodes", C.c_int32, [C.c_void_p])
         f("scheduling_order", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int32])
@@ -569,6 +575,26 @@ class Scheduler:
         agrees = C.c_int32(0)
         self._check(self.lib.pq_order(self.h, n, arr, int(prioritise_larger_jobs), int(bool(compare_scheduling_priority)) | (2 if preempt_cross_pool_jobs_first else 0), order, C.byref(agrees)))
         return [order[i] for i in range(n)], bool(agrees.value)
+
+    def market_iterate(self, queues: Sequence[Sequence[dict]], name_rank: Sequence[int], preempt_cross_pool_jobs_first: bool = False) -> List[int]:
+        """MarketBasedCandidateGangIterator's Peek / Clear order (oracle-only test hook); queues[q] = that queue's jobs in iterator order, a job =
+        dict(price, queued=True, runtime=0, submit_time=0, away=False) -> the queue index of every yielded job"""
+        nq = len(queues)
+        off = np.zeros(nq + 1, dtype=np.int32)
+        for q, js in enumerate(queues):
+            off[q + 1] = off[q] + len(js)
+        total = int(off[nq])
+        arr = (CMarketJob * max(total, 1))()
+        i = 0
+        for js in queues:
+            for j in js:
+                arr[i].price = float(j["price"]); arr[i].queued = int(j.get("queued", True)); arr[i].away = int(j.get("away", False))
+                arr[i].runtime = int(j.get("runtime", 0)); arr[i].submit_time = int(j.get("submit_time", 0))
+                i += 1
+        nr = _arr(name_rank, np.int32)
+        out = np.zeros(max(total, 1), dtype=np.int32)
+        self._check(self.lib.market_iterate(self.h, nq, _ptr(nr, C.c_int32), _ptr(off, C.c_int32), arr, int(preempt_cross_pool_jobs_first), _ptr(out, C.c_int32)))
+        return [int(x) for x in out[:total]]
 
     def submit_check(self, units: Sequence[Sequence[int]], strip_gang: Optional[Sequence[bool]] = None):
         """One batch of submit-check units (submitcheck.go:342-371); returns [(ok, scheduled_away, num_schedulable, first_node)]."""

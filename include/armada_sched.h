@@ -405,6 +405,19 @@ typedef struct asched_pq_item {
 int32_t ASCHED_FN(pq_order)(asched_t*, int32_t n, const asched_pq_item* items, int32_t prioritise_larger_jobs, int32_t compare_scheduling_priority,
                             int32_t* out_order /*[n]*/, int32_t* packed_agrees);
 
+/* MarketBasedCandidateGangIterator (market_iterator.go:32-295): the order in which the market-driven candidate iterator yields the queues' jobs.  Queue q
+   holds jobs[off[q] .. off[q+1]) in its iterator's order; out_queue[i] = the queue of the i-th Peek (Clear after each).  The priority queue is
+   container/heap over MarketIteratorPQ.Less (:228-273), which is NOT a strict weak order — its round-robin clause reads the queue and price of the
+   previous result — so the heap's up / down moves are restated literally.  ORACLE-ONLY test hook (market_iterator_test.go:17-122): market-driven
+   ordering is not built on the device yet and the product returns ASCHED_ERR_UNSUPPORTED. */
+typedef struct asched_market_job {
+  double price;                    /* job.GetBidPrice(pool) */
+  int64_t runtime, submit_time;    /* item.runtime as updatePQItem computes it (now - LatestRun().Created() for a job that is not queued, else 0); SubmitTime */
+  int32_t queued, away;            /* job.Queued(); !IsHomeJob(pool) */
+} asched_market_job;
+int32_t ASCHED_FN(market_iterate)(asched_t*, int32_t nq, const int32_t* name_rank /*[nq]*/, const int32_t* off /*[nq+1]*/, const asched_market_job* jobs,
+                                  int32_t preempt_cross_pool_jobs_first, int32_t* out_queue /*[off[nq]]*/);
+
 /* ------------------------------------------------------------------ round level */
 /* Builds round state: ConstructNodeDb/populateNodeDb (bind every running job, scheduling_algo.go:738-781,
    1019-1098) + constructSchedulingContext + UpdateFairShares (:783-867).  Untimed "input build". */

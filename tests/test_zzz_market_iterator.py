@@ -1,0 +1,74 @@
+"""MarketBasedCandidateGangIterator (market_iterator.go:32-295), oracle side only.
+
+The market-driven candidate iterator is the next row of SURVEY 8f; its first gate is an oracle that is pinned on the reference's own tests.  The order
+is produced by container/heap over MarketIteratorPQ.Less (:228-273), which reads the queue and price of the PREVIOUS result (round robin between queues
+that bid the same price) and therefore is not a strict weak order: the oracle restates the heap's up / down moves literally (oracle_market_iterate).
+Cases: market_iterator_test.go:17-34 (home before away), :36-50 (ordering), :52-122 (round robin, 4 tables).  The device does not build this yet: the
+product library answers ASCHED_ERR_UNSUPPORTED (checked below on the CPU build of the host code).
+"""
+import pytest
+
+from armada_amd.binding import Scheduler, SchedError
+from armada_amd import workloads as W
+
+
+def handle(lib):
+    wl = W.small_random(n_nodes=4, n_jobs=50, n_queues=2, seed=1)
+    return Scheduler(lib, wl.config)
+
+
+ROUND_ROBIN = {   # market_iterator_test.go:61-98; instantiation order = age: the first declared queue holds the oldest jobs
+    "two queues": ([("A", [600, 600, 600]), ("B", [600, 600, 400])], ["A", "B", "A", "B", "A", "B"]),
+    "two queues - reverse": ([("B", [600, 600, 400]), ("A", [600, 600, 600])], ["B", "A", "B", "A", "A", "B"]),
+    "three queues": ([("A", [600, 600, 400]), ("B", [600, 600, 600]), ("C", [600, 600, 300])], ["A", "B", "C", "A", "B", "C", "B", "A", "C"]),
+    "three queues - mixed": ([("C", [600, 600, 300]), ("A", [600, 600, 400]), ("B", [600, 600, 600])], ["C", "A", "B", "C", "A", "B", "B", "A", "C"]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(ROUND_ROBIN))
+def test_round_robin(oracle_lib, name):
+    inp, expected = ROUND_ROBIN[name]
+    names = sorted(q for q, _ in inp)
+    t = 0
+    queues = []
+    for q, prices in inp:          # createJobIterator(sctx, queue, prices...) in declaration order: submit times grow with it
+        js = []
+        for p in prices:
+            t += 1
+            js.append(dict(price=p, queued=True, submit_time=t))
+        queues.append(js)
+    s = handle(oracle_lib)
+    got = s.market_iterate(queues, [names.index(q) for q, _ in inp])
+    assert [inp[i][0] for i in got] == expected
+    s.close()
+
+
+def test_ordering(oracle_lib):
+    """:36-50 TestMarketIteratorPQ_Ordering: price desc, running before queued, runtime desc, submit time asc, queue name.  The reference sorts hand-built
+    items with sort.Sort; draining the iterator over one-job queues with the same item values visits them in the same order (the round-robin clause never
+    decides here: F and G bid 1 when the previous result bid 2)"""
+    items = {"A": dict(price=3, queued=True, runtime=10, submit_time=10), "B": dict(price=3, queued=False, runtime=10, submit_time=10),
+             "C": dict(price=2, queued=True, runtime=10, submit_time=10), "D": dict(price=2, queued=True, runtime=8, submit_time=10),
+             "E": dict(price=2, queued=True, runtime=8, submit_time=5), "F": dict(price=1, queued=True, runtime=8, submit_time=10),
+             "G": dict(price=1, queued=True, runtime=8, submit_time=10)}
+    order = ["G", "F", "E", "D", "C", "B", "A"]   # pq.items as the test builds it
+    s = handle(oracle_lib)
+    got = s.market_iterate([[items[q]] for q in order], [sorted(items).index(q) for q in order])
+    assert [order[i] for i in got] == ["B", "A", "C", "E", "D", "F", "G"]
+    s.close()
+
+
+def test_home_before_away(oracle_lib):
+    """:17-34 TestMarketIteratorPQ_HomeBeforeAway: with preemptCrossPoolJobsFirst a home item orders before an away item despite the lower price"""
+    s = handle(oracle_lib)
+    queues = [[dict(price=1)], [dict(price=1000, away=True)]]     # "q", "q-away"
+    assert s.market_iterate(queues, [0, 1], preempt_cross_pool_jobs_first=True) == [0, 1]
+    assert s.market_iterate(queues, [0, 1], preempt_cross_pool_jobs_first=False) == [1, 0]
+    s.close()
+
+
+def test_product_says_unsupported(hostsim_lib):
+    s = handle(hostsim_lib)
+    with pytest.raises(SchedError):
+        s.market_iterate([[dict(price=1)]], [0])
+    s.close()
