@@ -154,6 +154,11 @@ class CMarketJob(C.Structure):
     _fields_ = [("price", C.c_double), ("runtime", C.c_int64), ("submit_time", C.c_int64), ("queued", C.c_int32), ("away", C.c_int32)]
 
 
+class CMarketCmpJob(C.Structure):
+    _fields_ = [("bid_price", C.c_double), ("active_run_timestamp", C.c_int64), ("submit_time", C.c_int64),
+                ("pc_priority", C.c_int32), ("active", C.c_int32), ("id_rank", C.c_int32), ("pad_", C.c_int32)]
+
+
 class CSubmitResult(C.Structure):
     _fields_ = [("ok", C.c_int32), ("scheduled_away", C.c_int32), ("num_schedulable", C.c_int32), ("first_node", C.c_int32)]
 
@@ -181,7 +186,7 @@ ALL_SYMBOLS = [
     "round_prepare", "schedule_round", "schedule_queues", "gang_schedule", "round_counters", "job_key_unfeasible", "kernel_times", "round_stats",
     "clear_allocated", "submit_check", "pq_order", "submit_stats", "num_nodes", "total_resources", "node_types_matching_job", "scheduling_order",
     "optimiser_schedule_job", "set_label_value_ints", "round_timing", "set_deadline", "cancel", "indexed_node_label_values", "get_node_jobs", "get_nodes_alloc", "node_upsert",
-    "market_iterate",
+    "market_iterate", "market_compare",
 ]
 
 
@@ -261,6 +266,7 @@ class Library:
         f("nodes_upsert", C.c_int32, [C.c_void_p, C.POINTER(CNodes)])
         f("jobs_set", C.c_int32, [C.c_void_p, C.POINTER(CJobs), C.POINTER(CReqClasses)])
         f("pq_order", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(CPqItem), C.c_int32, C.c_int32, _i32p, _i32p])
+        f("market_compare", C.c_int32, [C.c_void_p, C.POINTER(CMarketCmpJob), C.POINTER(CMarketCmpJob), _i32p])
         f("market_iterate", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i32p, C.POINTER(CMarketJob), C.c_int32, _i32p])
         f("submit_stats", C.c_int32, [C.c_void_p, _i32p])
         f("num_nodes", C.c_int32, [C.c_void_p])
@@ -575,6 +581,18 @@ class Scheduler:
         agrees = C.c_int32(0)
         self._check(self.lib.pq_order(self.h, n, arr, int(prioritise_larger_jobs), int(bool(compare_scheduling_priority)) | (2 if preempt_cross_pool_jobs_first else 0), order, C.byref(agrees)))
         return [order[i] for i in range(n)], bool(agrees.value)
+
+    def market_compare(self, a: dict, b: dict) -> int:
+        """jobdb.MarketSchedulingOrderCompare (oracle-only test hook); a, b: dict(bid_price, active_run_timestamp, submit_time, pc_priority, active, id_rank)"""
+        def mk(j):
+            c = CMarketCmpJob()
+            c.bid_price = float(j.get("bid_price", 0.0)); c.active_run_timestamp = int(j.get("active_run_timestamp", 0)); c.submit_time = int(j.get("submit_time", 0))
+            c.pc_priority = int(j.get("pc_priority", 0)); c.active = int(bool(j.get("active", False))); c.id_rank = int(j.get("id_rank", 0))
+            return c
+        ca, cb = mk(a), mk(b)
+        out = C.c_int32(0)
+        self._check(self.lib.market_compare(self.h, C.byref(ca), C.byref(cb), C.byref(out)))
+        return int(out.value)
 
     def market_iterate(self, queues: Sequence[Sequence[dict]], name_rank: Sequence[int], preempt_cross_pool_jobs_first: bool = False) -> List[int]:
         """MarketBasedCandidateGangIterator's Peek / Clear order (oracle-only test hook); queues[q] = that queue's jobs in iterator order, a job =

@@ -418,6 +418,16 @@ typedef struct asched_market_job {
 int32_t ASCHED_FN(market_iterate)(asched_t*, int32_t nq, const int32_t* name_rank /*[nq]*/, const int32_t* off /*[nq+1]*/, const asched_market_job* jobs,
                                   int32_t preempt_cross_pool_jobs_first, int32_t* out_queue /*[off[nq]]*/);
 
+/* jobdb.MarketSchedulingOrderCompare (jobdb/comparison.go:113-170): the order of a queue's jobs under market-driven scheduling — priority class priority
+   (higher first), bid price for the pool (higher first), a job with an active run before one without, older run first, earlier submit time, job id.
+   *out_sign = -1 / 0 / +1.  ORACLE-ONLY test hook like market_iterate (comparison_test.go:76-178). */
+typedef struct asched_market_cmp_job {
+  double bid_price;                              /* job.GetBidPrice(currentPool) */
+  int64_t active_run_timestamp, submit_time;
+  int32_t pc_priority, active, id_rank, pad_;   /* priorityClass.Priority; activeRun != nil && !InTerminalState(); rank of the job id (equal rank = same id) */
+} asched_market_cmp_job;
+int32_t ASCHED_FN(market_compare)(asched_t*, const asched_market_cmp_job* a, const asched_market_cmp_job* b, int32_t* out_sign);
+
 /* ------------------------------------------------------------------ round level */
 /* Builds round state: ConstructNodeDb/populateNodeDb (bind every running job, scheduling_algo.go:738-781,
    1019-1098) + constructSchedulingContext + UpdateFairShares (:783-867).  Untimed "input build". */

@@ -194,11 +194,12 @@ def extract_pq_ordering(skipped):
     return out
 
 
-def extract_comparer(skipped):
+def extract_comparer(skipped, func="TestJobPriorityComparer"):
     path = f"{REF}/jobdb/comparison_test.go"
     src = open(path).read()
     rel = os.path.relpath(path, "/root/reference")
-    pos = src.index("func TestJobPriorityComparer(")
+    pos = src.index(f"func {func}(")
+    BIDS = {"bidPricesA": {"a": 1.0, "b": 2.0}, "bidPricesB": {"a": 2.0, "b": 1.0}}   # comparison_test.go:77-78 (QueuedBid == RunningBid)
     m = re.compile(r"tests\s*:=\s*map\[string\]struct\s*\{").search(src, pos)
     body_open = src.index("{", find_matching(src, m.end() - 1) + 1)
     body_close = find_matching(src, body_open)
@@ -212,9 +213,12 @@ def extract_comparer(skipped):
         if k >= 0:
             o = lit.index("(", k)
             lit = lit[:k] + lit[find_matching(lit, o, "(", ")") + 1:].lstrip(" ,")
-        v = Evaluator({"types.PriorityClass": None}).ev(Parser(tokenize(lit, 1)).parse_expr())
+        v = Evaluator({"types.PriorityClass": None, "bidPricesA": "bidPricesA", "bidPricesB": "bidPricesB"}).ev(Parser(tokenize(lit, 1)).parse_expr())
         j = {"id": v.get("id", ""), "priority": int(v.get("priority", 0)), "pcPriority": int((v.get("priorityClass") or {}).get("Priority", 0)),
              "submittedTime": int(v.get("submittedTime", 0)), "activeRunTimestamp": int(v.get("activeRunTimestamp", 0)), "active": False}
+        if func != "TestJobPriorityComparer":
+            j["bidPrices"] = BIDS.get(v.get("bidPricesPool"), {})   # pool -> bid; no map = no bid (GetBidPrice returns 0)
+            j["queued"] = bool(v.get("queued", False))
         if ".WithNewRun(" in text:
             j["active"] = True
         mm = re.search(r"\.WithUpdatedRun\(\s*&JobRun\{created:\s*(\d+)\}", text)
@@ -227,11 +231,15 @@ def extract_comparer(skipped):
         try:
             ma, mb, me = re.search(r"\ba:\s", lit), re.search(r"\n\s*b:\s", lit), re.search(r"\n\s*expected:\s*(-?\d+)", lit)
             a, b = job_of(lit[ma.end():mb.start()]), job_of(lit[mb.end():me.start()])
-            if a["id"] == b["id"]:
+            if a["id"] == b["id"] and func == "TestJobPriorityComparer":
                 continue   # "Jobs with equal id are considered equal": identity, not order
-            out.append({"name": name, "source": f"{rel}:{line}", "a": a, "b": b, "expected": int(me.group(1))})
+            case = {"name": name, "source": f"{rel}:{line}", "a": a, "b": b, "expected": int(me.group(1))}
+            mp = re.search(r'\n\s*currentPool:\s*"([^"]*)"', lit)
+            if mp:
+                case["currentPool"] = mp.group(1)
+            out.append(case)
         except (Unsupported, AttributeError, ValueError) as e:
-            skipped.append(f"{rel}:{line} TestJobPriorityComparer/{name}: {e}")
+            skipped.append(f"{rel}:{line} {func}/{name}: {e}")
     return out
 
 
@@ -366,6 +374,8 @@ def main():
     # with method chains ((&Job{...}).WithNewRun(...) / .WithUpdatedRun(&JobRun{created: t})): an active run whose timestamp is `created`
     # (job.go: activeRunTimestamp = run.created); the two cases about equal ids are about jobDb identity, not order, and are dropped.
     out["job_priority_comparer"] = extract_comparer(skipped)
+    # comparison_test.go:76-178 TestMarketJobPriorityComparer: the same kind of table for MarketSchedulingOrderCompare (bid prices per pool, currentPool)
+    out["market_job_priority_comparer"] = extract_comparer(skipped, "TestMarketJobPriorityComparer")
 
     # nodedb_test.go:1236-1291 TestConditionalAwayNodeScheduling: one node, one job of armada-preemptible-away-conditional, through
     # SelectNodeForJobWithTxn; the job built before the table (:1237-1241) is restated with the same fixtures

@@ -72,3 +72,23 @@ def test_product_says_unsupported(hostsim_lib):
     with pytest.raises(SchedError):
         s.market_iterate([[dict(price=1)]], [0])
     s.close()
+
+
+# ---- jobdb.MarketSchedulingOrderCompare (comparison.go:113-170) on the reference's own table (comparison_test.go:76-178), transcribed mechanically
+from golden_io import ids, load  # noqa: E402
+
+CMP = load("market_job_priority_comparer")
+
+
+@pytest.mark.parametrize("case", CMP, ids=ids(CMP))
+def test_market_job_priority_comparer(oracle_lib, case):
+    pool = case["currentPool"]
+    names = sorted({case["a"]["id"], case["b"]["id"]})
+
+    def job(j):
+        return dict(bid_price=j["bidPrices"].get(pool, 0.0), active_run_timestamp=j["activeRunTimestamp"], submit_time=j["submittedTime"],
+                    pc_priority=j["pcPriority"], active=j["active"], id_rank=names.index(j["id"]))
+    s = handle(oracle_lib)
+    assert s.market_compare(job(case["a"]), job(case["b"])) == case["expected"], case["name"]
+    assert s.market_compare(job(case["b"]), job(case["a"])) == -case["expected"]
+    s.close()
