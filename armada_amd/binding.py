@@ -186,7 +186,7 @@ ALL_SYMBOLS = [
     "round_prepare", "schedule_round", "schedule_queues", "gang_schedule", "round_counters", "job_key_unfeasible", "kernel_times", "round_stats",
     "clear_allocated", "submit_check", "pq_order", "submit_stats", "num_nodes", "total_resources", "node_types_matching_job", "scheduling_order",
     "optimiser_schedule_job", "set_label_value_ints", "round_timing", "set_deadline", "cancel", "indexed_node_label_values", "get_node_jobs", "get_nodes_alloc", "node_upsert",
-    "market_iterate", "market_compare",
+    "market_iterate", "market_compare", "market_multi_iterate",
 ]
 
 
@@ -266,6 +266,7 @@ class Library:
         f("nodes_upsert", C.c_int32, [C.c_void_p, C.POINTER(CNodes)])
         f("jobs_set", C.c_int32, [C.c_void_p, C.POINTER(CJobs), C.POINTER(CReqClasses)])
         f("pq_order", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(CPqItem), C.c_int32, C.c_int32, _i32p, _i32p])
+        f("market_multi_iterate", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(CMarketCmpJob), C.POINTER(C.c_uint8), C.c_int32, C.POINTER(CMarketCmpJob), C.POINTER(C.c_uint8), C.c_int32, _i32p, _i32p])
         f("market_compare", C.c_int32, [C.c_void_p, C.POINTER(CMarketCmpJob), C.POINTER(CMarketCmpJob), _i32p])
         f("market_iterate", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i32p, C.POINTER(CMarketJob), C.c_int32, _i32p])
         f("submit_stats", C.c_int32, [C.c_void_p, _i32p])
@@ -593,6 +594,23 @@ class Scheduler:
         out = C.c_int32(0)
         self._check(self.lib.market_compare(self.h, C.byref(ca), C.byref(cb), C.byref(out)))
         return int(out.value)
+
+    def market_multi_iterate(self, list1: Sequence[dict], list2: Sequence[dict], only_evicted_after: int = -1) -> List[int]:
+        """MarketDrivenMultiJobsIterator over two job lists (oracle-only test hook); a job = market_compare's dict + evicted=bool; list 2's jobs come back as len(list1) + index"""
+        def pack(js):
+            arr = (CMarketCmpJob * max(len(js), 1))()
+            ev = (C.c_uint8 * max(len(js), 1))()
+            for i, j in enumerate(js):
+                arr[i].bid_price = float(j.get("bid_price", 0.0)); arr[i].active_run_timestamp = int(j.get("active_run_timestamp", 0)); arr[i].submit_time = int(j.get("submit_time", 0))
+                arr[i].pc_priority = int(j.get("pc_priority", 0)); arr[i].active = int(bool(j.get("active", False))); arr[i].id_rank = int(j.get("id_rank", 0))
+                ev[i] = int(bool(j.get("evicted", False)))
+            return arr, ev
+        a1, e1 = pack(list1)
+        a2, e2 = pack(list2)
+        out = np.zeros(max(len(list1) + len(list2), 1), dtype=np.int32)
+        n = C.c_int32(0)
+        self._check(self.lib.market_multi_iterate(self.h, len(list1), a1, e1, len(list2), a2, e2, int(only_evicted_after), _ptr(out, C.c_int32), C.byref(n)))
+        return [int(x) for x in out[:n.value]]
 
     def market_iterate(self, queues: Sequence[Sequence[dict]], name_rank: Sequence[int], preempt_cross_pool_jobs_first: bool = False) -> List[int]:
         """MarketBasedCandidateGangIterator's Peek / Clear order (oracle-only test hook); queues[q] = that queue's jobs in iterator order, a job =

@@ -427,6 +427,11 @@ typedef struct asched_market_cmp_job {
   int32_t pc_priority, active, id_rank, pad_;   /* priorityClass.Priority; activeRun != nil && !InTerminalState(); rank of the job id (equal rank = same id) */
 } asched_market_cmp_job;
 int32_t ASCHED_FN(market_compare)(asched_t*, const asched_market_cmp_job* a, const asched_market_cmp_job* b, int32_t* out_sign);
+/* MarketDrivenMultiJobsIterator (jobiteration.go:232-321) over two InMemoryJobIterators (:22-65): the merge of a queue's two job lists by
+   MarketSchedulingOrderCompare, with OnlyYieldEvicted called before the (only_evicted_after + 1)-th Next (negative: never).  out = the yielded jobs, list 1
+   as its index, list 2 as n1 + index.  ORACLE-ONLY test hook (jobiteration_test.go:150-232). */
+int32_t ASCHED_FN(market_multi_iterate)(asched_t*, int32_t n1, const asched_market_cmp_job* list1, const uint8_t* evicted1, int32_t n2,
+                                        const asched_market_cmp_job* list2, const uint8_t* evicted2, int32_t only_evicted_after, int32_t* out, int32_t* n_out);
 
 /* ------------------------------------------------------------------ round level */
 /* Builds round state: ConstructNodeDb/populateNodeDb (bind every running job, scheduling_algo.go:738-781,

@@ -92,3 +92,43 @@ def test_market_job_priority_comparer(oracle_lib, case):
     assert s.market_compare(job(case["a"]), job(case["b"])) == case["expected"], case["name"]
     assert s.market_compare(job(case["b"]), job(case["a"])) == -case["expected"]
     s.close()
+
+
+# ---- MarketDrivenMultiJobsIterator (jobiteration.go:232-321), jobiteration_test.go:150-232 by hand.  createJctxWithPrice: a queued job of one priority class
+# whose bid is its price band's number (testfixtures.SetPricing: A = 1 ... H = 8), ids (ULIDs) and submit times grow with creation order.
+BAND = {c: i + 1 for i, c in enumerate("ABCDEFGH")}
+
+
+def _jobs(spec, counter):
+    out = []
+    for band, evicted in spec:
+        counter[0] += 1
+        out.append(dict(bid_price=BAND[band], submit_time=counter[0], id_rank=counter[0], evicted=evicted))
+    return out
+
+
+def test_market_multi_jobs_iterator(oracle_lib):
+    c = [0]
+    new = _jobs([("H", False), ("C", False)], c)
+    ev = _jobs([("F", True), ("D", True)], c)
+    s = handle(oracle_lib)
+    assert s.market_multi_iterate(new, ev) == [0, 2 + 0, 2 + 1, 1]                    # :150-171 new[0], evicted[0], evicted[1], new[1]
+    s.close()
+
+
+def test_market_multi_jobs_iterator_only_yield_evicted(oracle_lib):
+    c = [0]
+    new = _jobs([("H", False), ("H", False)], c)
+    ev = _jobs([("F", True), ("D", True)], c)
+    s = handle(oracle_lib)
+    assert s.market_multi_iterate(new, ev, only_evicted_after=0) == [2 + 0, 2 + 1]    # :173-195 OnlyYieldEvicted before the first Next
+    s.close()
+
+
+def test_market_multi_jobs_iterator_only_yield_evicted_mid_iteration(oracle_lib):
+    c = [0]
+    l1 = _jobs([("H", False), ("E", False), ("B", True)], c)
+    l2 = _jobs([("F", False), ("F", False), ("D", True)], c)
+    s = handle(oracle_lib)
+    assert s.market_multi_iterate(l1, l2, only_evicted_after=2) == [0, 3 + 0, 3 + 2, 2]   # :197-232 jctxs1[0], jctxs2[0], jctxs2[2], jctxs1[2]
+    s.close()
