@@ -78,6 +78,8 @@ type GpuRound struct {
 	nodePos  map[string]int32
 	jobs     []*jobdb.Job
 	classes  map[string]int32 // requirement class key -> index
+	// poolConfig.GetDefaultJobTolerations() (scheduling_algo.go:773): part of every requirement class (UploadJobs)
+	defaultTolerations []v1.Toleration
 }
 
 func effectOf(e v1.TaintEffect) int32 {
@@ -410,7 +412,9 @@ func (g *GpuRound) UploadJobs(jobs []*jobdb.Job, queueIndex map[string]int32) er
 	classKey := func(j *jobdb.Job) (string, reqClass) {
 		var rc reqClass
 		key := ""
-		for _, t := range j.Tolerations() {
+		// the pool's default job tolerations (SchedulingOptions.DefaultTolerations, nodedb.go:383-393) are appended to every job's tolerations for
+		// every node selection (:561-562): folded into the class here, once (g.defaultTolerations = poolConfig.GetDefaultJobTolerations())
+		for _, t := range append(append([]v1.Toleration{}, j.Tolerations()...), g.defaultTolerations...) {
 			k := int32(-1)
 			if t.Key != "" {
 				k = g.strs.id(t.Key)
