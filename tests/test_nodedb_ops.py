@@ -289,3 +289,21 @@ def test_remove_job_of_unbound_job_is_a_noop(lib):
         assert (after[l] == (before[l] - req if p <= 1 else before[l])).all()
     s.unbind(0, 0)
     assert (s.get_alloc(0) == before).all()
+
+
+def test_nodedb_includes_cross_pool_priority(lib):
+    """nodedb_test.go:33-46 TestNodeDbIncludesCrossPoolPriority: the priority axis starts EvictedPriority (-2), CrossPoolPriority (-1), then the real
+    priorities in ascending order, and there is a plane for the cross-pool bucket"""
+    c = _case(lib, F.N32CpuNodes(1, F.TestPriorities), [F.Test1Cpu4GiJob("A", F.PriorityClass0)])
+    prios = list(c.sched.priorities)
+    assert prios[0] == -2 and prios[1] == -1 and prios == sorted(prios) and len(set(prios)) == len(prios)
+    assert c.sched.get_alloc(0).shape[0] == len(prios)
+
+
+def test_select_node_for_pod_node_id_label_success(lib):
+    """nodedb_test.go:96-119 TestSelectNodeForPod_NodeIdLabel_Success: a job whose context is pinned to a node (jctx.SetAssignedNode) is given exactly that
+    node, although the first node in the order would fit as well"""
+    nodes = F.N32CpuNodes(2, F.TestPriorities)
+    c = _case(lib, nodes, F.N1Cpu4GiJobs("A", F.PriorityClass0, 1))
+    res, preempted = c.sched.select_node(0, pinned_node=1)
+    assert res.node == 1 and preempted == []
