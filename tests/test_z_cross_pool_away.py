@@ -166,3 +166,34 @@ def test_oversubscribed_evictor_takes_the_cross_pool_jobs(lib):
     res = c.sched.schedule_round()
     assert len(res.scheduled) == 0
     assert len(res.preempted) == 8 and all(j < 20 for j in res.preempted)
+
+
+@pytest.mark.parametrize("name,away,allocated,configured,expect", [
+    ("nil floating resources", False, 5, False, False),
+    ("gctx - within limits", False, 5, True, True),
+    ("gctx - not within limits", False, 15, True, False),
+    ("gctx - away - within limits", True, 5, True, True),
+    ("gctx - away - not within limits", True, 15, True, True),
+])
+def test_is_within_floating_resource_limits(lib, name, away, allocated, configured, expect):
+    """context/scheduling_test.go:529-592 TestIsWithinFloatingResourceLimits: a one-job gang that requests 1 of test-floating-resource (pool total 10) while the
+    pool already holds `allocated` of it.  A home gang must stay within the pool's total; a gang from another pool is not checked here (the check ran on
+    its own pool).  Without floating resources configured the request cannot be granted.  The reference calls the check with sctx.Allocated preset; here
+    the allocation comes in as a queue's initial allocation and the gang goes through GangScheduler.Schedule, which adds it before it checks
+    (gang_scheduler.go:100-143), so the limit is compared with allocated + 1 — same verdicts for 5 and 15 against 10."""
+    cfg = F.TestSchedulingConfig()
+    cfg["preempt_cross_pool_jobs_first"] = True
+    cfg["floating_resources"] = {"test-floating-resource": {"pool": 10000 if configured else 0}}   # factory units: 10 whole units
+    job = dict(F.Test1Cpu4GiJob("A", F.PriorityClass2), away=away)
+    job["req"] = dict(job["req"], **{"test-floating-resource": 1000})
+    if away:
+        job["queue"] = "A-away"
+    c = scenario.Case(lib, cfg, [F.Test32CpuNode(F.TestPriorities)])
+    c.set_jobs([job], {"A": 0, "A-away": 1}, {})
+    alloc = np.zeros((2, len(c.pc_names), scenario.R), dtype=np.int64)
+    alloc[0, 0, scenario.RES.index("test-floating-resource")] = allocated * 1000
+    c.sched.round_prepare([1.0, 1.0], [[], []], name_rank=[0, 1], demand=np.zeros((2, scenario.R), dtype=np.int64), allocated_by_pc=alloc)
+    ok, reason, pods = c.sched.gang_schedule([0])
+    assert ok == expect, (name, reason)
+    if not ok:
+        assert reason != 0
