@@ -117,7 +117,7 @@ class CJobs(C.Structure):
         ("m", C.c_int32), ("queue", _i32p), ("pc", _i32p), ("queue_priority", _u32p), ("submit_time", _i64p),
         ("req", _i64p), ("req_class", _i32p), ("gang_id", _i32p), ("gang_cardinality", _i32p),
         ("gang_uniformity_label", _i32p), ("node", _i32p), ("scheduled_at_priority", _i32p), ("run_timestamp", _i64p),
-        ("away", C.POINTER(C.c_uint8)),
+        ("away", C.POINTER(C.c_uint8)), ("home_queue", _i32p),
     ]
 
 
@@ -502,7 +502,7 @@ class Scheduler:
 
     def jobs_set(self, req, *, queue=None, pc=None, queue_priority=None, submit_time=None, req_class=None, gang_id=None,
                  gang_cardinality=None, gang_uniformity_label=None, node=None, scheduled_at_priority=None,
-                 run_timestamp=None, class_tolerations=None, class_selectors=None, class_affinities=None, away=None):
+                 run_timestamp=None, class_tolerations=None, class_selectors=None, class_affinities=None, away=None, home_queue=None):
         """class_affinities: per class None (no required node affinity) or a list of terms, a term = list of (key, op, [values])"""
         req = _arr(req, np.int64).reshape(-1, self.R)
         m = req.shape[0]
@@ -533,6 +533,7 @@ class Scheduler:
         put("scheduled_at_priority", scheduled_at_priority, np.int32, C.c_int32)
         put("run_timestamp", run_timestamp, np.int64, C.c_int64)
         put("away", away, np.uint8, C.c_uint8)   # cross-pool away jobs (context.IsHomeJob false)
+        put("home_queue", home_queue, np.int32, C.c_int32)   # away jobs: the home context of the job's queue in this pool (-1 none)
         cls = CReqClasses()
         tols = class_tolerations if class_tolerations is not None else [[]]
         sels = class_selectors if class_selectors is not None else [[] for _ in tols]

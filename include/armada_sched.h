@@ -243,6 +243,9 @@ typedef struct asched_jobs {
                                       preempt_cross_pool_jobs_first is set, is bound at CrossPoolPriority (-1) whatever its run says (bindJobToNodeInPlace,
                                       nodedb.go:1055-1068: the NodeDb is told its pool exactly then, scheduling_algo.go:759-764) and orders after home jobs; it belongs to the "<queue>-away" queue context: `queue` holds that context's index
                                       (CalculateAwayQueueName; jobiteration.go:88-94, context/scheduling.go:225-226, 412-413, 646-647) */
+  const int32_t* home_queue;       /* [m] for away jobs only: the index of the queue context named job.Queue() — the HOME context of the job's queue in this pool —
+                                      or -1 when the pool has none; NULL = -1 everywhere.  The node evictor's fair-share protection reads that context, not the
+                                      "-away" one (pqs.go:124: QueueSchedulingContexts[job.Queue()]); without it an away job is not protected. */
 } asched_jobs;
 
 /* ---- per-queue round inputs (context.AddQueueSchedulingContext, scheduling/context/scheduling.go:114-166) ---- */

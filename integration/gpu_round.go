@@ -407,6 +407,7 @@ func (g *GpuRound) UploadJobs(jobs []*jobdb.Job, queueIndex map[string]int32) er
 	gangId, gangCard, gangUni := make([]int32, m), make([]int32, m), make([]int32, m)
 	node, runPrio := make([]int32, m), make([]int32, m)
 	away, anyAway := make([]uint8, m), false
+	homeQueue := make([]int32, m)
 	gangIds := map[string]int32{}
 	var classes []reqClass
 	classKey := func(j *jobdb.Job) (string, reqClass) {
@@ -503,6 +504,10 @@ func (g *GpuRound) UploadJobs(jobs []*jobdb.Job, queueIndex map[string]int32) er
 					away[i] = 1
 					anyAway = true
 					queue[i] = queueIndex[schedulercontext.CalculateAwayQueueName(j.Queue())]
+					homeQueue[i] = -1 // the evictor's fair-share protection looks the job up under its plain queue name (pqs.go:124)
+					if hq, ok := queueIndex[j.Queue()]; ok {
+						homeQueue[i] = hq
+					}
 				}
 				node[i] = p
 				runTs[i] = j.ActiveRunTimestamp()
@@ -578,6 +583,7 @@ func (g *GpuRound) UploadJobs(jobs []*jobdb.Job, queueIndex map[string]int32) er
 		if anyAway {
 			pins.Pin(&away[0])
 			in.away = (*C.uint8_t)(unsafe.Pointer(&away[0]))
+			in.home_queue = pin32(homeQueue)
 		}
 	}
 	return g.check(C.asched_jobs_set(g.h, &in, &cls))

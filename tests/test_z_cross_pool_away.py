@@ -31,9 +31,14 @@ def with_away(seed, prefer_home, frac=0.3):
     pick = running[rng.random(len(running)) < frac]
     away[pick] = 1
     jq = np.asarray(wl.job_queue).copy()
+    home = np.full(wl.num_jobs, -1, dtype=np.int32)
+    home[pick] = jq[pick]                          # the home context of the same queue exists in this pool
+    if seed % 5 == 0:
+        home[pick[::2]] = -1                       # ... except where it does not: no fair-share protection for those jobs (pqs.go:124-134)
     jq[pick] += q
     wl.job_queue = jq
     wl.job_away = away
+    wl.job_home_queue = home
     wl.queue_weight = list(wl.queue_weight) + list(wl.queue_weight)
     wl.queued = [list(x) for x in wl.queued] + [[] for _ in range(q)]
     cfg = copy.copy(wl.config)
@@ -197,3 +202,24 @@ def test_is_within_floating_resource_limits(lib, name, away, allocated, configur
     assert ok == expect, (name, reason)
     if not ok:
         assert reason != 0
+
+
+@pytest.mark.parametrize("home_context_exists,evicted", [(True, 0), (False, 20)])
+def test_away_job_is_protected_by_its_home_queue_context(lib, home_context_exists, evicted):
+    """pqs.go:101-136: the node evictor's fair-share protection reads QueueSchedulingContexts[job.Queue()] — for a cross-pool away job that is the HOME
+    context of its queue (the job is accounted against "<queue>-away", but the lookup uses the plain queue name).  Queue A holds nothing of its own in this
+    pool, so it is far below its fair share and its away jobs are protected; when the pool has no context named A the `ok` of the map lookup is false and
+    nothing protects them: all 20 are evicted in phase 1 (and come straight back: nothing else wants the node)."""
+    cfg = F.TestSchedulingConfig()
+    cfg["preempt_cross_pool_jobs_first"] = True
+    node = F.Test32CpuNode(F.TestPriorities)
+    jobs = [dict(j, away=True, queue="A-away") for j in F.N1Cpu4GiJobs("A", F.PriorityClass0, 20)]
+    c = scenario.Case(lib, cfg, [node])
+    qidx = {"A": 0, "A-away": 1} if home_context_exists else {"A-away": 0}
+    p0 = F.TEST_PRIORITY_CLASSES[F.PriorityClass0]["priority"]
+    c.set_jobs(jobs, qidx, {i: (0, p0, i + 1) for i in range(20)})
+    nq = len(qidx)
+    c.sched.round_prepare([1.0] * nq, [[] for _ in range(nq)], name_rank=list(range(nq)))
+    res = c.sched.schedule_round()
+    assert res.num_evicted_phase1 == evicted
+    assert len(res.preempted) == 0 and len(res.scheduled) == 0
