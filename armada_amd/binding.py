@@ -117,7 +117,7 @@ class CJobs(C.Structure):
         ("m", C.c_int32), ("queue", _i32p), ("pc", _i32p), ("queue_priority", _u32p), ("submit_time", _i64p),
         ("req", _i64p), ("req_class", _i32p), ("gang_id", _i32p), ("gang_cardinality", _i32p),
         ("gang_uniformity_label", _i32p), ("node", _i32p), ("scheduled_at_priority", _i32p), ("run_timestamp", _i64p),
-        ("away", C.POINTER(C.c_uint8)), ("home_queue", _i32p),
+        ("away", C.POINTER(C.c_uint8)),
     ]
 
 
@@ -185,7 +185,7 @@ ALL_SYMBOLS = [
     "get_alloc", "get_scheduled_at_priority", "iterate_nodes", "fit_select_batch", "drf_cost", "fair_shares",
     "round_prepare", "schedule_round", "schedule_queues", "gang_schedule", "round_counters", "job_key_unfeasible", "kernel_times", "round_stats",
     "clear_allocated", "submit_check", "pq_order", "submit_stats", "num_nodes", "total_resources", "node_types_matching_job", "scheduling_order",
-    "optimiser_schedule_job", "set_label_value_ints", "round_timing", "set_deadline", "cancel", "indexed_node_label_values", "get_node_jobs", "get_nodes_alloc", "node_upsert",
+    "optimiser_schedule_job", "set_label_value_ints", "round_timing", "set_deadline", "cancel", "cancel_clear", "indexed_node_label_values", "get_node_jobs", "get_nodes_alloc", "node_upsert",
     "market_iterate", "market_compare", "market_multi_iterate",
 ]
 
@@ -277,6 +277,7 @@ class Library:
         f("round_timing", C.c_int32, [C.c_void_p, C.POINTER(C.c_double)])
         f("set_deadline", C.c_int32, [C.c_void_p, C.c_double])
         f("cancel", C.c_int32, [C.c_void_p])
+        f("cancel_clear", C.c_int32, [C.c_void_p])
         f("indexed_node_label_values", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int32])
         f("get_node_jobs", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _u8p, _i32p, C.c_int32])
         f("get_nodes_alloc", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i64p])
@@ -502,7 +503,7 @@ class Scheduler:
 
     def jobs_set(self, req, *, queue=None, pc=None, queue_priority=None, submit_time=None, req_class=None, gang_id=None,
                  gang_cardinality=None, gang_uniformity_label=None, node=None, scheduled_at_priority=None,
-                 run_timestamp=None, class_tolerations=None, class_selectors=None, class_affinities=None, away=None, home_queue=None):
+                 run_timestamp=None, class_tolerations=None, class_selectors=None, class_affinities=None, away=None):
         """class_affinities: per class None (no required node affinity) or a list of terms, a term = list of (key, op, [values])"""
         req = _arr(req, np.int64).reshape(-1, self.R)
         m = req.shape[0]
@@ -533,7 +534,6 @@ class Scheduler:
         put("scheduled_at_priority", scheduled_at_priority, np.int32, C.c_int32)
         put("run_timestamp", run_timestamp, np.int64, C.c_int64)
         put("away", away, np.uint8, C.c_uint8)   # cross-pool away jobs (context.IsHomeJob false)
-        put("home_queue", home_queue, np.int32, C.c_int32)   # away jobs: the home context of the job's queue in this pool (-1 none)
         cls = CReqClasses()
         tols = class_tolerations if class_tolerations is not None else [[]]
         sels = class_selectors if class_selectors is not None else [[] for _ in tols]
@@ -719,6 +719,8 @@ class Scheduler:
 
     def set_deadline(self, seconds: float): self._check(self.lib.set_deadline(self.h, float(seconds)))
     def cancel(self): self._check(self.lib.cancel(self.h))
+
+    def cancel_clear(self): self._check(self.lib.cancel_clear(self.h))
 
     def indexed_node_label_values(self, label_key: int):
         """IndexedNodeLabelValues -> sorted interned values, or None when the label is not indexed"""

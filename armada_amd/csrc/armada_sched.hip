@@ -1703,6 +1703,7 @@ static void plat_close(PlatCtx* c) {
 static int plat_wall_clock_khz() { return t_ctx ? t_ctx->wallClockKHz : 100000; }
 static void plat_set_deadline(double s) { if (t_ctx) t_ctx->deadlineS = s > 0 ? s : 0; }
 static void plat_cancel(PlatCtx* c) { if (c && c->cancelHost) __atomic_store_n(c->cancelHost, 1, __ATOMIC_RELEASE); }  // any thread: a plain store to host memory
+static void plat_cancel_clear(PlatCtx* c) { if (c && c->cancelHost) __atomic_store_n(c->cancelHost, 0, __ATOMIC_RELEASE); }
 static void* plat_malloc(size_t n) { void* p = nullptr; if (!hipOk(hipMalloc(&p, n), "hipMalloc")) return nullptr; return p; }
 static void plat_free(void* p) { if (p) (void)hipFree(p); }
 static void plat_memset(void* p, int v, size_t n) { if (!p) { hipOk(hipErrorInvalidValue, "memset of a failed allocation"); return; } hipOk(hipMemsetAsync(p, v, n, t_ctx->stream), "hipMemsetAsync"); }

@@ -174,7 +174,6 @@ struct Dev {
   // ---- jobs (immutable per jobs_set)
   int32_t *jQueue, *jPc, *jShape, *jGang, *jGangCard, *jGangUni, *jNode0, *jRunPrio, *jRankActive, *jRankInactive;
   uint8_t* jAway;   // [M] cross-pool away jobs (asched_jobs.away); null = none
-  int32_t* jHomeQueue;   // [M] with jAway: the home context of an away job's queue in this pool, -1 = none (asched_jobs.home_queue)
   int64_t* jReq;         // [M][R] row-major (control path reads one job = one 8*R byte burst)
   uint8_t* jAligned;     // [M] request is a multiple of the index resolution on every indexed column
   int32_t *gangOff, *gangJobs;  // CSR of (queue,gang) -> member jobs (jobRepo.GetGangJobsByGangId)

@@ -69,13 +69,9 @@ DEV void bulkElem(Dev& d, int kind, int i) {
     case B_RESET_GANGSEEN: d.gangSeen[i] = 0; break;
     case B_FILTER1: {  // NewNodeEvictor job filter (pqs.go:101-136)
       int n = d.jobNode[i], q = d.jQueue[i];
-      bool ok = n >= 0 && !d.jobEvictedOnNode[i] && q >= 0 && q < c.Q && c.pcPreemptible[d.jPc[i]];
-      if (ok) {
-        int qp = q;   // the fair-share protection reads QueueSchedulingContexts[job.Queue()] (:124): for a cross-pool away job the HOME context of its queue, if any
-        if (d.jAway && d.jAway[i]) qp = d.jHomeQueue[i];
-        ok = qp < 0 || qp >= c.Q ? true : (bool)d.qEvictable[qp];
-      }
-      d.evFlag[i] = ok;
+      // a cross-pool away job (job.LatestRun().Pool() != sctx.Pool, :102-104) is never evicted for balancing: urgency preemption and the oversubscribed evictor take it
+      bool ok = n >= 0 && !d.jobEvictedOnNode[i] && q >= 0 && q < c.Q && !(d.jAway && d.jAway[i]) && c.pcPreemptible[d.jPc[i]];
+      d.evFlag[i] = ok && d.qEvictable[q];
     } break;
     case B_NODE_OVER: {  // NewOversubscribedEvictor node filter (eviction.go:145-157)
       int m = 0;

@@ -52,7 +52,6 @@ class Workload:
     class_tolerations: Optional[list] = None   # per class: list of (key, op, value, effect)
     class_selectors: Optional[list] = None     # per class: list of (key, value)
     job_away: Optional[np.ndarray] = None      # [M] cross-pool away jobs (asched_jobs.away); None = none
-    job_home_queue: Optional[np.ndarray] = None  # [M] away jobs: home context of the job's queue (asched_jobs.home_queue); None = -1
 
     @property
     def num_nodes(self):
@@ -283,7 +282,7 @@ def load(lib, wl: Workload) -> Scheduler:
     s.nodes_upsert(wl.node_total, wl.node_allocatable, taints=wl.node_taints, labels=wl.node_labels, id_rank=wl.node_id_rank)
     s.jobs_set(wl.job_req, queue=wl.job_queue, pc=wl.job_pc, submit_time=wl.job_submit, node=wl.job_node,
                scheduled_at_priority=wl.job_run_prio, run_timestamp=wl.job_run_ts, gang_id=wl.job_gang, gang_cardinality=wl.job_gang_card,
-               req_class=wl.job_req_class, class_tolerations=wl.class_tolerations, class_selectors=wl.class_selectors, away=wl.job_away, home_queue=wl.job_home_queue)
+               req_class=wl.job_req_class, class_tolerations=wl.class_tolerations, class_selectors=wl.class_selectors, away=wl.job_away)
     return s
 
 

@@ -242,10 +242,9 @@ typedef struct asched_jobs {
                                       NULL = none.  Such a job skips this pool's floating-resource limits (context/scheduling.go:585-594) and, when
                                       preempt_cross_pool_jobs_first is set, is bound at CrossPoolPriority (-1) whatever its run says (bindJobToNodeInPlace,
                                       nodedb.go:1055-1068: the NodeDb is told its pool exactly then, scheduling_algo.go:759-764) and orders after home jobs; it belongs to the "<queue>-away" queue context: `queue` holds that context's index
-                                      (CalculateAwayQueueName; jobiteration.go:88-94, context/scheduling.go:225-226, 412-413, 646-647) */
-  const int32_t* home_queue;       /* [m] for away jobs only: the index of the queue context named job.Queue() — the HOME context of the job's queue in this pool —
-                                      or -1 when the pool has none; NULL = -1 everywhere.  The node evictor's fair-share protection reads that context, not the
-                                      "-away" one (pqs.go:124: QueueSchedulingContexts[job.Queue()]); without it an away job is not protected. */
+                                      (CalculateAwayQueueName; jobiteration.go:88-94, context/scheduling.go:225-226, 412-413, 646-647).  The node evictor
+                                      never evicts such a job for balancing (pqs.go:102-104: job.LatestRun().Pool() != sctx.Pool); urgency preemption and the
+                                      oversubscribed evictor may take it */
 } asched_jobs;
 
 /* ---- per-queue round inputs (context.AddQueueSchedulingContext, scheduling/context/scheduling.go:114-166) ---- */
@@ -473,6 +472,9 @@ int32_t ASCHED_FN(round_stats)(asched_t*, int32_t* out /*[24]*/);
    handle unprepared: round_prepare builds the next round from scratch. */
 int32_t ASCHED_FN(set_deadline)(asched_t*, double seconds);
 int32_t ASCHED_FN(cancel)(asched_t*);
+/* Withdraws a cancel request that no round has consumed yet — for a caller whose watcher thread fired asched_cancel a moment after the round it was
+   meant for had returned (the request would otherwise hit the NEXT round on this handle).  Same thread as the round calls; never during a round. */
+int32_t ASCHED_FN(cancel_clear)(asched_t*);
 /* IndexedNodeLabelValues (nodedb.go:340-343): values of an indexed node label present on the nodes (ascending interned id).
    Returns their number, or -1 when the label is not indexed (ok == false). */
 int32_t ASCHED_FN(indexed_node_label_values)(asched_t*, int32_t label_key, int32_t* out_values, int32_t cap);

@@ -22,9 +22,13 @@ package scheduling
 import "C"
 
 import (
+	"context"
 	"math"
 	"runtime"
 	"sort"
+	"strconv"
+	"sync"
+	"time"
 	"unsafe"
 
 	"github.com/pkg/errors"
@@ -383,6 +387,9 @@ func (g *GpuRound) UploadNodes(nodes []*internaltypes.Node) error {
 	}
 	in.taint_key, in.taint_value, in.taint_effect = i32p(tKey), i32p(tVal), i32p(tEff)
 	in.label_key, in.label_value = i32p(lKey), i32p(lVal)
+	if err := g.uploadLabelValueInts(); err != nil {
+		return err
+	}
 	return g.check(C.asched_nodes_upsert(g.h, &in))
 }
 
@@ -407,7 +414,6 @@ func (g *GpuRound) UploadJobs(jobs []*jobdb.Job, queueIndex map[string]int32) er
 	gangId, gangCard, gangUni := make([]int32, m), make([]int32, m), make([]int32, m)
 	node, runPrio := make([]int32, m), make([]int32, m)
 	away, anyAway := make([]uint8, m), false
-	homeQueue := make([]int32, m)
 	gangIds := map[string]int32{}
 	var classes []reqClass
 	classKey := func(j *jobdb.Job) (string, reqClass) {
@@ -465,7 +471,13 @@ func (g *GpuRound) UploadJobs(jobs []*jobdb.Job, queueIndex map[string]int32) er
 	}
 	classes = make([]reqClass, len(g.classes))
 	for i, j := range jobs {
-		queue[i] = queueIndex[j.Queue()]
+		// a job whose queue has no context in this pool keeps queue -1: the library treats it like sctx.QueueContextExists(job) == false
+		// ("invalid_queue": never evicted, not part of any aggregate) instead of charging it to queue 0
+		if qi, ok := queueIndex[j.Queue()]; ok {
+			queue[i] = qi
+		} else {
+			queue[i] = -1
+		}
 		pc[i] = g.pcIndex[j.PriorityClassName()]
 		qprio[i] = j.Priority()
 		submit[i] = j.SubmitTime().UnixNano()
@@ -503,10 +515,11 @@ func (g *GpuRound) UploadJobs(jobs []*jobdb.Job, queueIndex map[string]int32) er
 				if run.Pool() != g.pool {
 					away[i] = 1
 					anyAway = true
-					queue[i] = queueIndex[schedulercontext.CalculateAwayQueueName(j.Queue())]
-					homeQueue[i] = -1 // the evictor's fair-share protection looks the job up under its plain queue name (pqs.go:124)
-					if hq, ok := queueIndex[j.Queue()]; ok {
-						homeQueue[i] = hq
+					// (the node evictor never takes such a job: pqs.go:102-104; the library knows from the flag)
+					if qi, ok := queueIndex[schedulercontext.CalculateAwayQueueName(j.Queue())]; ok {
+						queue[i] = qi
+					} else {
+						queue[i] = -1
 					}
 				}
 				node[i] = p
@@ -526,7 +539,8 @@ func (g *GpuRound) UploadJobs(jobs []*jobdb.Job, queueIndex map[string]int32) er
 	exprOff, valueOff := []int32{0}, []int32{0}
 	hasAff := make([]uint8, nc)
 	anyAff := false
-	ops := map[string]int32{"In": C.ASCHED_AFFINITY_OP_IN, "NotIn": C.ASCHED_AFFINITY_OP_NOT_IN, "Exists": C.ASCHED_AFFINITY_OP_EXISTS, "DoesNotExist": C.ASCHED_AFFINITY_OP_DOES_NOT_EXIST}
+	ops := map[string]int32{"In": C.ASCHED_AFFINITY_OP_IN, "NotIn": C.ASCHED_AFFINITY_OP_NOT_IN, "Exists": C.ASCHED_AFFINITY_OP_EXISTS, "DoesNotExist": C.ASCHED_AFFINITY_OP_DOES_NOT_EXIST,
+		"Gt": C.ASCHED_AFFINITY_OP_GT, "Lt": C.ASCHED_AFFINITY_OP_LT}
 	for ci, rc := range classes {
 		for _, t := range rc.tol {
 			tolKey, tolOp, tolVal, tolEff = append(tolKey, t[0]), append(tolOp, t[1]), append(tolVal, t[2]), append(tolEff, t[3])
@@ -542,7 +556,7 @@ func (g *GpuRound) UploadJobs(jobs []*jobdb.Job, queueIndex map[string]int32) er
 				for _, e := range term {
 					op, ok := ops[e[1].(string)]
 					if !ok {
-						op = 99 // Gt / Lt: the library answers ASCHED_ERR_UNSUPPORTED and the caller keeps this round on the Go NodeDb
+						op = 99 // an operator v1.NodeSelectorOperator does not define: the library answers ASCHED_ERR_UNSUPPORTED and the caller keeps this round on the Go NodeDb
 					}
 					exprKey, exprOp = append(exprKey, e[0].(int32)), append(exprOp, op)
 					values = append(values, e[2].([]int32)...)
@@ -583,10 +597,32 @@ func (g *GpuRound) UploadJobs(jobs []*jobdb.Job, queueIndex map[string]int32) er
 		if anyAway {
 			pins.Pin(&away[0])
 			in.away = (*C.uint8_t)(unsafe.Pointer(&away[0]))
-			in.home_queue = pin32(homeQueue)
 		}
 	}
+	if err := g.uploadLabelValueInts(); err != nil { // Gt / Lt compare integers: every interned string that parses, before the masks are built
+		return err
+	}
 	return g.check(C.asched_jobs_set(g.h, &in, &cls))
+}
+
+// uploadLabelValueInts tells the library which interned strings are integers (strconv.ParseInt(v, 10, 64), what
+// labels.Requirement.Matches does for Gt / Lt) — asched_set_label_value_ints.  Called before asched_jobs_set / asched_nodes_upsert
+// evaluate affinities (the static masks are rebuilt by whichever of the two comes last).
+func (g *GpuRound) uploadLabelValueInts() error {
+	var ids []int32
+	var ints []int64
+	for s, id := range g.strs.ids {
+		if v, err := strconv.ParseInt(s, 10, 64); err == nil {
+			ids, ints = append(ids, id), append(ints, v)
+		}
+	}
+	var pins runtime.Pinner
+	defer pins.Unpin()
+	if len(ids) > 0 {
+		pins.Pin(&ids[0])
+		pins.Pin(&ints[0])
+	}
+	return g.check(C.asched_set_label_value_ints(g.h, C.int32_t(len(ids)), i32p(ids), i64p(ints)))
 }
 
 // Schedule == PreemptingQueueScheduler.Schedule (preempting_queue_scheduler.go:86-289) for one pool.  sctx supplies weights, limiters
@@ -669,27 +705,45 @@ func (g *GpuRound) Schedule(ctx *armadacontext.Context, sctx *schedulercontext.S
 		return nil, err
 	}
 	// hard timeout + cancellation: the library polls a host-mapped word from inside the round kernel
+	// (asched_set_deadline counts from the start of asched_schedule_round: what is left of the context's deadline NOW, not since sctx.Started)
 	secs := 0.0
 	if dl, ok := ctx.Deadline(); ok {
-		secs = math.Max(dl.Sub(sctx.Started).Seconds(), 1e-9)
+		secs = math.Max(time.Until(dl).Seconds(), 1e-6)
 	}
 	if err := g.check(C.asched_set_deadline(g.h, C.double(secs))); err != nil {
 		return nil, err
 	}
 	done := make(chan struct{})
+	cancelled := false
+	var wg sync.WaitGroup
+	wg.Add(1)
 	go func() { // asched_cancel may be called from any thread
+		defer wg.Done()
 		select {
 		case <-ctx.Done():
-			C.asched_cancel(g.h)
+			select {
+			case <-done: // the round is over already: a late cancel would hit the NEXT round on this handle
+			default:
+				cancelled = true
+				C.asched_cancel(g.h)
+			}
 		case <-done:
 		}
 	}()
 	var out C.asched_round_result
 	rc := C.asched_schedule_round(g.h, &out)
 	close(done)
+	wg.Wait() // the goroutine never touches g.h after Schedule returns (Close may follow)
+	if cancelled && rc != C.ASCHED_ERR_TIMEOUT {
+		C.asched_cancel_clear(g.h) // the request landed after the round had finished: it must not hit the next round on this handle
+	}
 	if rc == C.ASCHED_ERR_TIMEOUT {
-		sctx.TerminationReason = "hard timeout: " + ctx.Err().Error()
-		return nil, ctx.Err() // the caller maps this to PoolSchedulingTerminationReasonTimeout (scheduling_algo.go:262-270)
+		err := ctx.Err()
+		if err == nil { // the library's own deadline fired a moment before the context's
+			err = context.DeadlineExceeded
+		}
+		sctx.TerminationReason = "hard timeout: " + err.Error()
+		return nil, err // the caller maps this to PoolSchedulingTerminationReasonTimeout (scheduling_algo.go:262-270)
 	}
 	if err := g.check(rc); err != nil {
 		return nil, err // error => round discarded, nothing applied (scheduling_algo.go:262-285)

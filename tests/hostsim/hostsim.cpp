@@ -110,6 +110,7 @@ static bool plat_take_failure() { return false; }
 static int plat_wall_clock_khz() { return 100000; }
 static void plat_set_deadline(double s) { if (t_ctx) t_ctx->deadlineS = s; }
 static void plat_cancel(PlatCtx* c) { if (c) __atomic_store_n(&c->cancelWord, 1, __ATOMIC_RELEASE); }
+static void plat_cancel_clear(PlatCtx* c) { if (c) __atomic_store_n(&c->cancelWord, 0, __ATOMIC_RELEASE); }
 static double plat_last_control_ms() { return 0; }
 static int plat_last_control_launches() { return 0; }
 static double plat_last_fit_ms() { return 0; }

@@ -173,9 +173,7 @@ class Case:
             req_class=req_class, gang_id=gang_id, gang_cardinality=gang_card, gang_uniformity_label=gang_uni,
             node=node, scheduled_at_priority=sap, run_timestamp=rts,
             class_tolerations=cls_tol, class_selectors=cls_sel, class_affinities=cls_aff,
-            away=[1 if j.get("away") else 0 for j in jobs] if any(j.get("away") for j in jobs) else None,
-            # an away job's fair-share protection reads the HOME context of its queue (pqs.go:124): the "<queue>-away" name without its suffix, if that context exists
-            home_queue=[queue_index.get(j["queue"][:-5], -1) if j.get("away") and j["queue"].endswith("-away") else -1 for j in jobs] if any(j.get("away") for j in jobs) else None)
+            away=[1 if j.get("away") else 0 for j in jobs] if any(j.get("away") for j in jobs) else None)
 
     def sort_queued(self, jobs: List[dict], idxs: List[int]) -> List[int]:
         """SchedulingOrderCompare for queued (non-active) jobs: jobdb/comparison.go:49-107"""

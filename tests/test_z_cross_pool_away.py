@@ -31,14 +31,9 @@ def with_away(seed, prefer_home, frac=0.3):
     pick = running[rng.random(len(running)) < frac]
     away[pick] = 1
     jq = np.asarray(wl.job_queue).copy()
-    home = np.full(wl.num_jobs, -1, dtype=np.int32)
-    home[pick] = jq[pick]                          # the home context of the same queue exists in this pool
-    if seed % 5 == 0:
-        home[pick[::2]] = -1                       # ... except where it does not: no fair-share protection for those jobs (pqs.go:124-134)
     jq[pick] += q
     wl.job_queue = jq
     wl.job_away = away
-    wl.job_home_queue = home
     wl.queue_weight = list(wl.queue_weight) + list(wl.queue_weight)
     wl.queued = [list(x) for x in wl.queued] + [[] for _ in range(q)]
     cfg = copy.copy(wl.config)
@@ -204,12 +199,11 @@ def test_is_within_floating_resource_limits(lib, name, away, allocated, configur
         assert reason != 0
 
 
-@pytest.mark.parametrize("home_context_exists,evicted", [(True, 0), (False, 20)])
-def test_away_job_is_protected_by_its_home_queue_context(lib, home_context_exists, evicted):
-    """pqs.go:101-136: the node evictor's fair-share protection reads QueueSchedulingContexts[job.Queue()] — for a cross-pool away job that is the HOME
-    context of its queue (the job is accounted against "<queue>-away", but the lookup uses the plain queue name).  Queue A holds nothing of its own in this
-    pool, so it is far below its fair share and its away jobs are protected; when the pool has no context named A the `ok` of the map lookup is false and
-    nothing protects them: all 20 are evicted in phase 1 (and come straight back: nothing else wants the node)."""
+@pytest.mark.parametrize("home_context_exists,evicted", [(True, 0), (False, 0)])
+def test_away_job_is_never_evicted_for_balancing(lib, home_context_exists, evicted):
+    """pqs.go:101-104: the node evictor's job filter starts with `if job.LatestRun().Pool() != sch.schedulingContext.Pool { return false, "" }` — a cross-pool
+    away job is never evicted in phase 1, whatever its queue's share and whether or not the pool has a context named after its queue (only urgency preemption
+    and the oversubscribed evictor take it).  The 20 away jobs of queue "A-away" fill the node far above any fair share: none is evicted."""
     cfg = F.TestSchedulingConfig()
     cfg["preempt_cross_pool_jobs_first"] = True
     node = F.Test32CpuNode(F.TestPriorities)
