@@ -10,6 +10,7 @@ mirroring the Go test drivers it cites:
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List
 
 import numpy as np
@@ -117,7 +118,10 @@ class Case:
                 ts.append(UNSCHEDULABLE_TAINT)
             taints.append([(self.S(k), self.S(v), EFFECTS[e]) for k, v, e in ts])
             labels.append([(self.S(k), self.S(v)) for k, v in sorted(n["labels"].items())])
-        s.nodes_upsert(total, total, index=[n["index"] for n in self.nodes], alloc_by_prio=abp, taints=taints, labels=labels)
+        # nodes without hand-written usage are uploaded like production nodes — no explicit AllocatableByPriority — so that the golden tables run through
+        # the level-0 fast structure, the stream runs and the ring, not only through the generic path (an explicit table turns the fast structure off)
+        explicit = any(n.get("used") for n in self.nodes) or os.environ.get("ASCHED_GOLDEN_EXPLICIT_ALLOC") == "1"
+        s.nodes_upsert(total, total, index=[n["index"] for n in self.nodes], alloc_by_prio=abp if explicit else None, taints=taints, labels=labels)
 
     # ---- jobs
     def set_jobs(self, jobs: List[dict], queue_index: Dict[str, int], running: Dict[int, tuple]):
@@ -234,6 +238,19 @@ class Tokens:
             self.tokens = min(float(self.burst), self.tokens + self.rate * seconds)
 
 
+# how the golden rounds ran (asched_round_stats; the oracle reports zeros): summed over every schedule call of the drivers below, read by
+# the tests that assert the reference tables reach the fast structure / the stream runs / the preempting fast iteration
+GOLDEN_STATS: Dict[str, int] = {}
+
+
+def note_stats(s):
+    st = s.round_stats()
+    GOLDEN_STATS["rounds"] = GOLDEN_STATS.get("rounds", 0) + 1
+    GOLDEN_STATS["rounds_with_fast_iterations"] = GOLDEN_STATS.get("rounds_with_fast_iterations", 0) + (1 if st["fast_iterations"] > 0 else 0)
+    for k in ("fast_iterations", "generic_iterations", "stream_runs", "stream_jobs", "preempt_fast_iterations", "fast_replay_steps", "l0_overflows"):
+        GOLDEN_STATS[k] = GOLDEN_STATS.get(k, 0) + int(st[k])
+
+
 def run_pqs_case(lib: Library, case: dict):
     cfg = case["SchedulingConfig"]
     nodes = case["Nodes"]
@@ -284,6 +301,7 @@ def run_pqs_case(lib: Library, case: dict):
                         global_tokens=glim.tokens, global_burst=glim.burst, global_rate_inf=glim.rate_inf,
                         queue_tokens=[t.tokens for t in qlim], queue_burst=[t.burst for t in qlim], queue_rate_inf=[t.rate_inf for t in qlim])
         res = s.schedule_round()
+        note_stats(s)
         glim.tokens = res.global_tokens_after
         for t, v in zip(qlim, res.queue_tokens_after):
             t.tokens = float(v)
@@ -365,6 +383,7 @@ def run_qs_case(lib: Library, case: dict):
                     global_tokens=glim.tokens, global_burst=glim.burst, global_rate_inf=glim.rate_inf,
                     queue_tokens=[qlim.tokens] * Q, queue_burst=[qlim.burst] * Q, queue_rate_inf=[qlim.rate_inf] * Q)
     res = s.schedule_queues()
+    note_stats(s)
     exp = sorted(case.get("ExpectedScheduledIndices") or [])
     assert sorted(res.scheduled) == exp, f"expected scheduled {exp} got {sorted(res.scheduled)}"
     for i in case.get("ExpectedNeverAttemptedIndices") or []:
