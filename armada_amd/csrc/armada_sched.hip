@@ -647,6 +647,25 @@ __device__ static inline void bindUpdate(KREF k, FastS& S, int n, int lo, int nl
   }
   if (lane < nl - lo && keyDelta) __hip_atomic_fetch_add(&KKEY(k, lo + lane, n), 0ull - keyDelta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// per-field saturating subtraction on packed order keys: field 0 stands for every negative quotient, so a field that would drop below it stays there
+__device__ static inline uint64_t keyFieldsSatSub(KREF k, uint64_t key, uint64_t delta) {
+  uint64_t out = key;
+#pragma unroll
+  for (int c = 0; c < MAXK; c++) {
+    if (c >= k.K) break;
+    uint64_t m = k.fieldMask[c], f = key & m, dq = delta & m;
+    out = (out & ~m) | (f > dq ? f - dq : 0);
+  }
+  return out;
+}
+__device__ static inline void keySatSub(KREF k, int n, int lo, int nl, uint64_t keyDelta) {
+  int lane = threadIdx.x & 63;
+  if (lane < nl - lo && keyDelta) {   // one level per lane; the bind wave / node engine may be adding to the same word: compare-and-swap
+    GP(uint64_t) p = &KKEY(k, lo + lane, n);
+    uint64_t old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (!__hip_atomic_compare_exchange_strong(p, &old, keyFieldsSatSub(k, old, keyDelta), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {}
+  }
+}
 // sctx / qctx resource vectors for the head job of queue q: accumulate-only, lane x handles resource x;
 // LDS vectors through ds_add_u64, HBM by-priority-class vectors through global atomics, all without a return value
 __device__ static inline void accountVectors(Dev& d, KREF k, int q, int pc, bool ev, bool replay) {
@@ -1525,7 +1544,7 @@ __global__ __launch_bounds__(FIT_TILE) void k_fit_batch(Dev d, const int32_t* sh
 // ---- sorted base of the level-0 fast structure: the ordered index of the fresh NodeDb (nodedb.go:1164-1175), built in round_prepare
 __global__ void k_base_fill(Dev d, int nb2) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nb2) d.baseKey[i] = i < d.cfg.N ? d.keys[i] : ~0ull;  // level 0 plane of keys
+  if (i < nb2) d.baseKey[i] = i < d.cfg.N ? fastKeyOf(d, i) : ~0ull;  // level 0 plane of keys (a negative column: field 0, fits nothing)
 }
 __global__ void k_bitonic_step(unsigned long long* a, int j, int k) {
   unsigned i = blockIdx.x * blockDim.x + threadIdx.x;

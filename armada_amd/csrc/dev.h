@@ -39,6 +39,7 @@ struct DevCfg {
   int32_t keyWidth[MAXK];
   int32_t idxBits;
   int32_t keyGuard;      // 1: every key field has a spare zero bit above it (FastCfg.guardMask)
+  int32_t keyClamp;      // 1: narrow field layout — keyLo = -1 and every quotient below it shares field 0 (asched_host.inc layoutKeys); 0: every reachable quotient has its own value
   int32_t pcPriority[MAXPC];
   uint8_t pcPreemptible[MAXPC];
   double drfMult[MAXR];

@@ -388,6 +388,7 @@ DEV void winRefill(KREF k, int q, int kind, int pos, int cnt);
 DEV void loadHeadRec(KREF k, int q, int job);
 DEV void headFromWindow(int q, int w);
 DEV void bindUpdate(KREF k, FastS& S, int n, int lo, int nl, int q, uint64_t keyDelta);
+DEV void keySatSub(KREF k, int n, int lo, int nl, uint64_t keyDelta);   // keys of levels [lo, nl) of node n: every field minus keyDelta's, saturating at 0
 DEV void accountVectors(Dev& d, KREF k, int q, int pc, bool ev, bool replay);
 DEV void evWinRefill(KREF k, int q, int pos, int cnt);
 __device__ static void applyEvictedRange(Dev& d, int q, int p0, int p1, int sign = 1);  // not inlined, reads the constants itself: nothing of the hot loop has to live in memory for it
@@ -468,7 +469,7 @@ DEV void fastDrop(Dev& d) { RS.fastActive = 0; RS.fastOverflow++; FL.l0Count = 0
 DEV void fastTouch(Dev& d, int n) {
   if (!d.f.structOk || !RS.fastActive) return;
   const FastK k = fastKRef(d);
-  uint64_t key = KKEY(k, 0, n);
+  uint64_t key = fastKeyOf(d, n);
   int64_t ex0 = k.E > 0 ? KAL(k, 0, k.ex0col, n) : 0, ex1 = k.E > 1 ? KAL(k, 0, k.ex1col, n) : 0;
   int pos = GA(int32_t, d.posOf)[n], slot = k.l0Slot[n];
   { FastS TS;  baseMarkRemoved(k, TS, pos); }
@@ -943,6 +944,7 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
     // node read.  Otherwise — a preemption-based bind overdrew some priority -2 column, or the job was evicted by the oversubscribed evictor
     // (pass 2: node / priority / bookkeeping are this round's, not the original run's) — the node's current allocatable is read.
     prio = r.runPrio; n = r.node0;
+    if (r.never & 2) return 0;   // a request off the index grid: the bind below takes keyDelta off the node's keys, which is exact for multiples of the resolution only
 #ifdef ASCHED_HOSTSIM
     if (getenv("HS_NO_DYN_EV") && (!fc.evStatic || !S.lvl0NonNeg || S.numPreemptedMarks != 0)) return 0;
     if (getenv("HS_NO_DYN_EV2") && !fc.evStatic) return 0;
@@ -1005,7 +1007,12 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
   int32_t cutoff = r.preemptible ? prio : NONPREEMPTIBLE_CUTOFF;
   int nl = ev ? evNl : r.nlPc;
   bool nodeSideHere = ev || !useEngine;  // a queued job's bind, result fields and L0 upkeep are the node engine's in two-wave mode
-  if (nodeSideHere) bindUpdate(k, S, n, ev ? 1 : 0, nl, q, r.keyDelta);  // evicted job: level -2 gets -req (bind) and +req (un-evict): unchanged (node.go:416-442)
+  // evicted job: level -2 gets -req (bind) and +req (un-evict): unchanged (node.go:416-442).  The packed key subtraction cannot borrow when the job fits at
+  // priority -2 (it then fits at every level) or returns while no priority -2 column is negative; an evicted job returning onto an overdrawn node was only
+  // checked at ITS level — the levels below may go negative: per-field saturating subtraction there (field 0 = "negative", asched_host.inc layoutKeys)
+  bool evDynamic = ev && (!fc.evStatic || !S.lvl0NonNeg);
+  if (nodeSideHere) bindUpdate(k, S, n, ev ? 1 : 0, nl, q, evDynamic ? 0 : r.keyDelta);
+  if (nodeSideHere && evDynamic) keySatSub(k, n, 1, nl, r.keyDelta);
   if (nodeSideHere && FLANE == 0) {
     k.jcHasPctx[job] = 1; k.pcNode[job] = n; k.pcSap[job] = prio;
     k.jobNode[job] = n; k.jobCutoff[job] = cutoff; k.schedAtPrio[job] = prio;

@@ -132,7 +132,7 @@ DEV void bulkElem(Dev& d, int kind, int i) {
       for (int p = p0; p < p1; p++) {
         while (d.evOff[q + 1] <= p) { q++; crossed = true; for (int r = 0; r < c.R; r++) tail[r] = 0; }
         int job = d.evList[p];
-        if (d.jGang[job] >= 0) d.evCheap[q] = 0;
+        if (d.jGang[job] >= 0 || (d.jAligned && !d.jAligned[job])) d.evCheap[q] = 0;   // (a request off the index grid: its rebind recomputes the node's keys — generic)
         const int64_t* req = JREQ(d, job);
         for (int r = 0; r < c.R; r++) { tail[r] += req[r]; if (!crossed) head[r] += req[r]; }
         qLast = q;
@@ -299,7 +299,7 @@ DEV void bulkElem(Dev& d, int kind, int i) {
 
 // SchedulingContext.updateFairShares (context/scheduling.go:262-342): float64, queues in name order, this exact operation order.
 // Scratch: pqProposed = constrainedDemandShare, pqCurrent = spareShare, pqInHeap = achievedDemand, itNext = name order.
-DEV_COLD void updateFairShares(Dev& d, const double* givenCds) {
+DEV_COLD COLD_MS_8 void updateFairShares(Dev& d, const double* givenCds) {
   const DevCfg& cf = d.cfg;
   int Q = cf.Q;
   double weightSum = 0;
@@ -335,7 +335,7 @@ DEV_COLD void updateFairShares(Dev& d, const double* givenCds) {
 }
 
 // PreemptingQueueScheduler.evict (pqs.go:291-353) for an evictor whose job filter has been evaluated into evFlag
-DEV_COLD int pqsEvict(Dev& d, Ctl& c, bool phase3) {
+DEV_COLD COLD_MS_9 int pqsEvict(Dev& d, Ctl& c, bool phase3) {
   long long t0 = CLK();
   wgBulk(d, B_GANG_CLOSURE, d.cfg.G);
   wgBulk(d, phase3 ? B_EVICT_APPLY3 : B_EVICT_APPLY1, d.cfg.M);
@@ -474,7 +474,7 @@ DEV void schedulePass(Dev& d, Ctl& c, bool withQueued, bool skipKey, bool cmpPri
 
 // Per-node index of the evicted table (CSR node -> table Indexes, descending) for fair-share preemption.  Every entry below
 // evictedTableSize is indexed, dead or alive (a transaction abort can bring an entry back); rebuilt when the table has grown.
-DEV_COLD void ensureFairIndex(Dev& d) {
+DEV_COLD COLD_MS_10 void ensureFairIndex(Dev& d) {
   if (d.rs->fairIndexValid) return;
   int E = d.rs->evictedTableSize, N = d.cfg.N;
   wgBulk(d, B_FAIR_ZERO, N);
@@ -502,7 +502,7 @@ DEV void swapLoopArrays(Dev& d) {
 // The deferred addEvictedJobsToNodeDb (pqs.go:589-639): its result — the evicted-table Index of every evicted job — is a pure
 // function of the state the evictor left (qAllocSnap, the eviction lists), so it can be computed at first use.  It runs on its
 // own set of iterator / heap arrays; entries of jobs that have been rescheduled or preempted in the meantime come out dead.
-DEV_COLD void ensureReplaySlow(Dev& d, Ctl& c) {
+DEV_COLD COLD_MS_11 void ensureReplaySlow(Dev& d, Ctl& c) {
   if (!d.rs->replayPending) return;
   d.rs->replayPending = 0;
   fastEnterGeneric(d, c);
@@ -519,7 +519,7 @@ DEV_COLD void ensureReplaySlow(Dev& d, Ctl& c) {
 }
 
 // PreemptingQueueScheduler.Schedule (pqs.go:86-289)
-DEV_COLD void runRound(Dev& d, Ctl& c) {
+DEV_COLD COLD_MS_12 void runRound(Dev& d, Ctl& c) {
   const DevCfg& cf = d.cfg;
   for (int q = 0; q < cf.Q; q++) {  // balance-evictor filter inputs are the start-of-round queue allocations (pqs.go:124-134)
     double actual = drf(d, QV(d.qAlloc, q));

@@ -178,7 +178,40 @@ def config3(n_nodes=100_000, n_jobs=1_000_000, n_queues=64, seed=SEED, gangs=0, 
     return wl
 
 
-def small_random(n_nodes=64, n_jobs=600, n_queues=5, seed=1, occupied=0.6, gangs=4, burst=None, away=False, ragged=False) -> Workload:
+def default_indexed(n_nodes=20_000, n_jobs=200_000, n_queues=64, seed=SEED, occupied=0.5, aligned=True) -> Workload:
+    """config3's shape on the reference's DEFAULT indexedResources (config/scheduler/config.yaml:121-129: nvidia.com/gpu @1, cpu @100m, memory @100Mi,
+    ephemeral-storage @1Gi — four indexed columns, in that order) and current hardware: 64 cpu / 1 TiB / 4 TiB ephemeral / 8 gpu per node.  The order key needs
+    4 + 10 + 14 + 13 bits of fields + the node-index rank: 58 bits at 100 000 nodes (the round-2 layout widened every field for oversubscription and refused
+    this).  1 TiB is not a multiple of 100Mi: allocatable is off the index grid.  aligned=True: requests are multiples of the resolutions (memory in units of
+    100Mi), so node selection stays on the packed-key path; False: memory in GiB like a real job — literal iteration (exact, slow)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pcs = [(0, True), (1, True), (3, False)]
+    pc_prio = np.array([p for p, _ in pcs])
+    node_total = np.tile(np.array([1024 * Gi, 64000, 4096 * Gi, 8], dtype=np.int64), (n_nodes, 1))
+    pf = rng.integers(1, 11, size=n_queues).astype(np.float64)
+    weight = 1.0 / pf
+    mem_unit = 100 * Mi if aligned else Gi
+    mems = (40, 80, 160, 320) if aligned else (4, 8, 16, 32)
+    shapes = np.array([[m * mem_unit, c * 1000, e * Gi, 0] for c in (1, 2, 4, 8) for m in mems for e in (10, 50, 100, 200)], dtype=np.int64)
+    pc_p = np.array([0.6, 0.3, 0.1])
+    run_req, run_node, run_queue, run_pc, run_prio = _fill_nodes(rng, node_total, occupied, shapes, weight / weight.sum(), pc_p, pc_prio)
+    zipf = 1.0 / np.arange(1, n_queues + 1) ** 1.1
+    zipf /= zipf.sum()
+    q_queue = rng.choice(n_queues, size=n_jobs, p=zipf).astype(np.int32)
+    q_req = shapes[rng.integers(0, len(shapes), size=n_jobs)].copy()
+    q_req[rng.random(n_jobs) < 0.05, GPU] = 1
+    q_req[rng.random(n_jobs) < 0.2, CPU] += 500          # cpu @100m: half cores are on the grid
+    q_pc = rng.choice(3, size=n_jobs, p=pc_p).astype(np.int32)
+    cfg = _config(pcs, protected=0.5)
+    cfg.indexed_col = [GPU, CPU, MEM, EPH]
+    cfg.indexed_resolution = [1, 100, 100 * Mi, Gi]
+    cfg.drf_multiplier = [1.0, 1.0, 1.0, 1.0]
+    wl = _assemble("default_indexed", cfg, node_total, run_req, run_node, run_queue, run_pc, run_prio, q_req, q_queue, q_pc, pc_prio, weight, {"priority_factor": pf.tolist()}, rng=rng)
+    wl.global_burst, wl.queue_burst, wl.rate_inf = max(1, n_jobs // 5), max(1, n_jobs // 50), False
+    return wl
+
+
+def small_random(n_nodes=64, n_jobs=600, n_queues=5, seed=1, occupied=0.6, gangs=4, burst=None, away=False, ragged=False, offgrid=0) -> Workload:
     """a small adversarially mixed workload for HIP-vs-oracle differential tests (preemption, gangs, limits; away=True: a quarter
     of the nodes carry a well-known node type's taint and two priority classes may run there at a reduced priority)"""
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -227,6 +260,25 @@ def small_random(n_nodes=64, n_jobs=600, n_queues=5, seed=1, occupied=0.6, gangs
             mem = np.nonzero(wl.job_gang == g)[0]
             cls[mem] = cls[mem[0]]
         wl.job_req_class = cls
+    if offgrid:
+        # ONE node type (unlike `ragged`), so the level-0 fast structure stays on: bit 0 = a third of the jobs — running ones too — ask for cpu / memory off the
+        # index grid (literal iteration for those shapes next to fast iterations for the others; an evicted one returning to its node must not be rebound by
+        # key arithmetic); bit 1 = allocatable below total by odd amounts (the fast structure's key fields are floor(allocatable / resolution)); on a crowded
+        # cluster that also leaves a few columns negative
+        m = wl.num_jobs
+        if offgrid & 1:
+            odd = rng.random(m) < 0.33
+            wl.job_req[odd, CPU] += rng.integers(1, 8, size=int(odd.sum())) * 125
+            oddm = rng.random(m) < 0.2
+            wl.job_req[oddm, MEM] += rng.integers(1, 100, size=int(oddm.sum())) * 1000
+            for g in np.unique(wl.job_gang[wl.job_gang >= 0]):      # gang members share one shape
+                mem = np.nonzero(wl.job_gang == g)[0]
+                wl.job_req[mem] = wl.job_req[mem[0]]
+        if offgrid & 2:
+            alloc = wl.node_total.copy()
+            alloc[:, CPU] -= rng.integers(0, 24, size=n_nodes) * 137
+            alloc[:, MEM] -= rng.integers(0, 1000, size=n_nodes) * 1000003
+            wl.node_allocatable = np.maximum(alloc, 0)
     if away:
         tainted = rng.random(n_nodes) < 0.25
         wl.node_taints = [[(7, 1, 1)] if t else [] for t in tainted]      # (key, value, NoSchedule)

@@ -58,6 +58,25 @@ def parity_record(gpu_res, oracle_res, num_jobs, what):
             "differing_fields": bad, "against": what}
 
 
+def _pin_one_core():
+    """pin the calling thread to ONE host core for a CPU-oracle leg (core 2 when the box has it); returns (previous mask, core) or None"""
+    try:
+        old = os.sched_getaffinity(0)
+        core = 2 if 2 in old else sorted(old)[0]
+        os.sched_setaffinity(0, {core})
+        return old, core
+    except (AttributeError, OSError):
+        return None
+
+
+def _unpin(pinned):
+    if pinned:
+        try:
+            os.sched_setaffinity(0, pinned[0])
+        except OSError:
+            pass
+
+
 def cpu_baseline(wl, budget_s, full_iters):
     """The CPU oracle (C++ restatement of the reference algorithm, oracle/) timed on this box's host cores, 1 thread
     (the reference's round is single-goroutine).  Bounded sample: ONE round on the SAME nodes/jobs/queues (SURVEY 8d asks for >= 30
@@ -80,7 +99,9 @@ def cpu_baseline(wl, budget_s, full_iters):
         sample.global_burst = min(wl.global_burst, max(1, int(wl.global_burst * max(0.02, (budget_s / est)))))
         cut = sample.global_burst < wl.global_burst
     W.prepare(s, sample)
+    pinned = _pin_one_core()   # the single-threaded CPU leg pinned to one core (taskset -c 2)
     t0 = time.perf_counter(); r = s.schedule_round(); dt = time.perf_counter() - t0
+    _unpin(pinned)
     iters = max(1, r.num_loop_iterations)
     scaled = dt * (full_iters / iters) if (cut and full_iters > iters) else dt
     s.close()
@@ -88,7 +109,7 @@ def cpu_baseline(wl, budget_s, full_iters):
            "sample": f"oracle (C++ restatement of the reference algorithm, 1 thread) on the same {wl.num_nodes}-node/{wl.num_jobs}-job input, ONE round "
                      f"(not the >= 30 of SURVEY 8d: a round is {dt:.0f} s of CPU) with global burst {sample.global_burst} ({iters} of {full_iters} loop iterations, {dt:.2f} s measured"
                      + (", scaled by the iteration ratio: an upper bound of the CPU time, the evicted-job phases do not shrink with the burst)" if cut else ")"),
-           "measured_s": dt, "measured_iterations": iters, "rounds": 1, "upper_bound_extrapolation": bool(cut)}
+           "measured_s": dt, "measured_iterations": iters, "rounds": 1, "upper_bound_extrapolation": bool(cut), "pinned_core": pinned[1] if pinned else None}
     return rec, (None if cut else r)
 
 
@@ -198,6 +219,12 @@ def submit_check_record(args):
             cpu_dt = time.perf_counter() - t1
             line["cpu_baseline"] = {"value": sample / cpu_dt, "unit": "jobs/s", "cores": 1, "kind": "port",
                                     "sample": f"{sample} jobs, one Txn / ScheduleManyWithTxn / Abort each on the CPU oracle, same node set"}
+            # parity: the whole Check call once more with the oracle behind the same host flow — every job's verdict (schedulable, reason text) compared
+            fdb = ArrayPoolDb(oracle, wl, req, pc, gang, card)
+            want = SubmitChecker([PoolConfig("pool")], {"pool": fdb}).check(jobs)
+            same = set(want) == set(res) and all(want[k].is_schedulable == res[k].is_schedulable and want[k].reason == res[k].reason for k in want)
+            line["parity"] = {"checked": True, "identical": bool(same), "jobs": int(n_jobs), "schedulable": sum(r.is_schedulable for r in want.values()),
+                              "against": "the same SubmitChecker.Check call with the CPU oracle as the pool's NodeDb: per job is_schedulable and reason"}
     return line
 
 
@@ -355,8 +382,15 @@ def other_configs(hip, args, t_start):
 
     guarded("BASELINE configs[1]", lambda: fit_batch_record(hip, args))
 
-    def shape(label, full_kwargs, reduced_kwargs, note):
+    def shape(label, full_kwargs, reduced_kwargs, note, full_parity=False):
         def run():
+            if full_parity and full_kwargs and args.cpu_budget > 0:   # the oracle round of the FULL input (~1 minute, like the headline's): parity at the size the value is quoted on
+                rec, wl, res, iters = round_shape_record(hip, args, label, full_kwargs, 2, note, 1)
+                base, ores = cpu_baseline(wl, 1e9, iters)
+                rec["cpu_baseline"] = base
+                if ores is not None:
+                    rec["parity"] = parity_record(res, ores, wl.num_jobs, "oracle round on the same full-size input")
+                return rec
             heavy = bool(full_kwargs) and full_kwargs.get("occupied", 0.5) > 0.9   # the preemption-heavy shape at full size is ~25 s per round: ONE round, no warm-up
             rec, _, _, _ = round_shape_record(hip, args, label, full_kwargs, 1 if heavy else 2, note + (" (one round, no warm-up round)" if heavy else ""), 0 if heavy else 1) if full_kwargs else (None, None, None, None)
             red, wl, res, iters = round_shape_record(hip, args, label + " (reduced: the size the oracle leg runs at)", reduced_kwargs, 2, note)
@@ -374,7 +408,8 @@ def other_configs(hip, args, t_start):
             return rec
         return run
     guarded("BASELINE configs[3]", shape("BASELINE configs[3]", dict(n_nodes=100_000, n_jobs=1_000_000, n_queues=64, gangs=10_000),
-                                         dict(n_nodes=20_000, n_jobs=200_000, n_queues=32, gangs=2_000), "gang atomic placement (ScheduleManyWithTxn + txn abort), uniform shape within a gang"))
+                                         dict(n_nodes=20_000, n_jobs=200_000, n_queues=32, gangs=2_000), "gang atomic placement (ScheduleManyWithTxn + txn abort), uniform shape within a gang",
+                                         full_parity=not args.no_full_other))
     guarded("BASELINE configs[4]", shape("BASELINE configs[4]", None if args.no_full_other else dict(n_nodes=100_000, n_jobs=1_000_000, n_queues=64, occupied=0.95),
                                          dict(n_nodes=20_000, n_jobs=200_000, n_queues=32, occupied=0.95),
                                          "oversubscribed / preemption-heavy: nodes 95% occupied, fair-share + urgency preemption candidate search, oversubscribed evictor"))

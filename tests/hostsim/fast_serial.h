@@ -103,6 +103,13 @@ DEV void headFromWindow(int q, int w) { memcpy(FL.headReq[q], FL.winRec[q][w].re
 DEV void bindUpdate(KREF k, FastS&, int n, int lo, int nl, int q, uint64_t keyDelta) {
   for (int l = lo; l < nl; l++) { for (int x = 0; x < k.R; x++) KAL(k, l, x, n) -= FL.headReq[q][x]; KKEY(k, l, n) -= keyDelta; }
 }
+DEV void keySatSub(KREF k, int n, int lo, int nl, uint64_t keyDelta) {   // per-field saturating subtraction (field 0 = every negative quotient)
+  for (int l = lo; l < nl; l++) {
+    uint64_t key = KKEY(k, l, n), out = key;
+    for (int c = 0; c < k.K; c++) { uint64_t m = k.fieldMask[c], f = key & m, dq = keyDelta & m; out = (out & ~m) | (f > dq ? f - dq : 0); }
+    KKEY(k, l, n) = out;
+  }
+}
 // sctx / qctx resource vectors (context/scheduling.go:410-434, context/queue.go:231-265) for the head job of queue q:
 // accumulate-only, one lane per resource
 DEV void accountVectors(Dev& d, KREF k, int q, int pc, bool ev, bool replay) {

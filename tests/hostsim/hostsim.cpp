@@ -154,7 +154,7 @@ static int plat_build_base(Dev& d) {
   const DevCfg& c = d.cfg;
   int N = c.N;
   std::vector<uint64_t> keys(N);
-  for (int i = 0; i < N; i++) keys[i] = KEY(d, 0, i);
+  for (int i = 0; i < N; i++) keys[i] = fastKeyOf(d, i);
   std::sort(keys.begin(), keys.end());
   uint64_t mask = (1ull << c.idxBits) - 1;
   for (int i = 0; i < N; i++) {

@@ -4,6 +4,7 @@
     python tests/soak.py rounds 3000        # workloads.small_random rounds, random sizes / occupancy / gangs / bursts / away / ragged
     python tests/soak.py streams 1000        # medium rounds (<= 1500 nodes, <= 20000 jobs) dominated by stream runs and gangs through the ring; HS_STREAM_EAGER=1: a run wherever one can start
     python tests/soak.py preempt 1500       # small crowded rounds (60-100 % occupied), most with a fair-share preemption rate limit: the jobs that need preemption stay in the fast loop (fastPreemptIter)
+    python tests/soak.py offgrid 3000       # ONE node type with requests and / or allocatable off the index grid (fast structure on next to literal iteration; narrow order-key layout), crowded, some with the default indexedResources
     python tests/soak.py away 1500          # crowded rounds with a third of the running jobs cross-pool away jobs and "<queue>-away" contexts (tests/test_z_cross_pool_away.py)
     python tests/soak.py features 400       # tests/test_z_feature_mix.py rounds (affinity, conditional away, extra column, limits ...)
     python tests/soak.py ops 3000           # tests/test_z_nodedb_op_sequences.py NodeDb-level operation sequences
@@ -36,7 +37,7 @@ def main():
     kind, n = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 200
     orc, hs = libs()
     import scenario
-    bad, t0 = 0, time.time()
+    bad, refused, t0 = 0, 0, time.time()
     for seed in range(100_000, 100_000 + n):
         try:
             if kind == "rounds":
@@ -63,6 +64,23 @@ def main():
                                     burst=None if rng.random() < 0.5 else (int(rng.integers(10, 2000)), int(rng.integers(5, 500))),
                                     away=bool(rng.random() < 0.3), ragged=bool(rng.random() < 0.2))
                 fp = None if rng.random() < 0.3 else float(rng.choice([0, 1, 3, 10, 40]))
+                res = []
+                for lib in (orc, hs):
+                    s = W.load(lib, wl); W.prepare(s, wl, fairshare_preemption_tokens=fp); res.append(s.schedule_round()); s.close()
+                scenario.assert_same_round(res[0], res[1])
+            elif kind == "offgrid":
+                rng = np.random.default_rng(seed)
+                if seed % 5 == 4:
+                    wl = W.default_indexed(n_nodes=int(rng.integers(4, 120)), n_jobs=int(rng.integers(50, 3000)), n_queues=int(rng.integers(1, 12)), seed=seed,
+                                           occupied=float(rng.choice([0.3, 0.7, 0.95, 1.0])), aligned=bool(rng.random() < 0.7))
+                    if rng.random() < 0.5:
+                        wl.global_burst, wl.queue_burst = wl.num_jobs, wl.num_jobs
+                else:
+                    wl = W.small_random(n_nodes=int(rng.integers(4, 200)), n_jobs=int(rng.integers(50, 4000)), n_queues=int(rng.integers(1, 12)), seed=seed,
+                                        occupied=float(rng.choice([0.3, 0.6, 0.9, 1.0])), gangs=int(rng.integers(0, 8)),
+                                        burst=None if rng.random() < 0.5 else (int(rng.integers(10, 2000)), int(rng.integers(5, 500))),
+                                        away=bool(rng.random() < 0.2), offgrid=int(rng.integers(1, 4)))
+                fp = None if rng.random() < 0.6 else float(rng.choice([0, 1, 3, 10, 40]))
                 res = []
                 for lib in (orc, hs):
                     s = W.load(lib, wl); W.prepare(s, wl, fairshare_preemption_tokens=fp); res.append(s.schedule_round()); s.close()
@@ -105,9 +123,11 @@ def main():
         except SchedError as e:
             if e.code != -2:   # ASCHED_ERR_UNSUPPORTED: a documented refusal (e.g. fit_select_batch on literal-iteration rows)
                 bad += 1; print("seed", seed, e)
+            else:
+                refused += 1
         except AssertionError as e:
             bad += 1; print("seed", seed, str(e)[:300])
-    print(f"{kind}: {n} seeds, {bad} divergences, {time.time() - t0:.0f} s")
+    print(f"{kind}: {n} seeds, {bad} divergences, {refused} refused (ASCHED_ERR_UNSUPPORTED), {time.time() - t0:.0f} s")
     sys.exit(1 if bad else 0)
 
 

@@ -229,6 +229,17 @@ def test_preemption_heavy_round_at_scale_matches_oracle(hip_lib, oracle_lib):
     assert st["preempt_fast_iterations"] > 1000   # (round 2: the node side of these iterations is the generic cascade, the queue side stays in the fast loop)
 
 
+def test_preemption_heavy_round_at_64k_nodes_matches_oracle(hip_lib, oracle_lib):
+    """The same shape at 64 000 nodes, 95 % occupied: from 50 000 nodes on a round launch carries 127 helper workgroups (half of the CUs) and the gate + the
+    per-node fair-share evaluation of every preempting job are one OP_SCANFAIR pass over all of them — the configuration BASELINE configs[4] is benchmarked in,
+    checked against the oracle here with a burst the oracle finishes in well under a minute."""
+    wl = W.config3(n_nodes=64_000, n_jobs=120_000, n_queues=32, seed=W.SEED + 1, occupied=0.95)
+    wl.global_burst, wl.queue_burst = 10_000, 1_000
+    r, st = _differential_round(hip_lib, oracle_lib, wl)
+    assert len(r.preempted) > 2000 and any(m == 3 for m in r.scheduled_method.values()) and any(m == 4 for m in r.scheduled_method.values())
+    assert st["preempt_fast_iterations"] > 2000 and st["generic_iterations"] <= 16, st
+
+
 def test_gang_round_at_scale_matches_oracle(hip_lib, oracle_lib):
     """BASELINE configs[3]'s shape at 20k nodes x 200k queued jobs x 2000 gangs of 2-64: ScheduleManyWithTxn + txn abort at scale"""
     wl = W.config3(n_nodes=20_000, n_jobs=200_000, n_queues=32, seed=W.SEED, gangs=2_000)

@@ -59,7 +59,11 @@ def test_round_bench_line(fake_gpu, monkeypatch, capsys):
         if "parity" in r:
             assert r["parity"]["checked"] and r["parity"]["identical"], (name, r["parity"])
     assert oc["BASELINE configs[1]"]["roofline"]["kernel"] == "k_fit_batch" and oc["BASELINE configs[1]"]["parity"]["identical"]
-    assert oc["BASELINE configs[3]"]["reduced"]["parity"]["identical"] and oc["BASELINE configs[3]"]["round"]["generic_iterations"] > 0
+    # configs[3] is checked against the oracle at the size its value is quoted on (no `reduced` leg any more); configs[4] keeps the reduced leg; the submit check carries a verdict too
+    assert oc["BASELINE configs[3]"]["parity"]["identical"] and "reduced" not in oc["BASELINE configs[3]"] and oc["BASELINE configs[3]"]["round"]["generic_iterations"] > 0
+    assert oc["BASELINE configs[4]"]["reduced"]["parity"]["identical"]
+    assert oc["submit check (SURVEY 8f-2)"]["parity"]["identical"] and oc["submit check (SURVEY 8f-2)"]["parity"]["jobs"] > 0
+    assert line["cpu_baseline"]["pinned_core"] is not None
 
 
 def test_round_bench_detects_a_mismatch(fake_gpu, monkeypatch, capsys):
@@ -76,6 +80,7 @@ def test_submit_check_bench_line(fake_gpu, monkeypatch, capsys):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--submit-check", "--nodes", "500", "--submit-jobs", "1500", "--submit-keys", "120", "--steps", "1", "--cpu-budget", "5"])
     fake_gpu.main()
     line = check_line(capsys.readouterr().out, "submit checks")
+    assert line["parity"]["checked"] and line["parity"]["identical"]
     assert line["unit"] == "jobs/s" and line["how"][0]["wide_units"] == 120 and line["how"][0]["sequential_units"] == 0 and line["how"][1]["sequential_units"] > 0
 
 
