@@ -63,14 +63,18 @@ __shared__ HelpBox* g_box;
 __shared__ int g_H;
 __shared__ unsigned int g_gen;
 
+// 64-bit words of an object of another type: through a may_alias type.  (Round 2 read the argument structs through a plain unsigned long long* — undefined
+// under strict aliasing: int64_t is `long`, so the compiler was free to treat the freshly written struct as never written; `minsize` on the callers made it do
+// so and the helper workgroups received garbage requests: profiles/r03a_minsize_rootcause.txt.  The device code is also built with -fno-strict-aliasing now.)
+typedef unsigned long long __attribute__((may_alias)) ull_alias;
 template <class A, class B = A> __device__ static inline void helpIssue(int op, const A* args, const B* args2 = nullptr) {  // one lane of the control wave
   HelpBox* b = g_box;
   if (args) {
-    const unsigned long long* src = (const unsigned long long*)args;
+    const ull_alias* src = (const ull_alias*)args;
     for (int i = 0; i < (int)(sizeof(A) / 8); i++) __hip_atomic_store(&b->args[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (args2) {
-    const unsigned long long* src = (const unsigned long long*)args2;
+    const ull_alias* src = (const ull_alias*)args2;
     for (int i = 0; i < (int)(sizeof(B) / 8); i++) __hip_atomic_store(&b->args[HELP_ARGS2 + i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&b->result2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -1207,9 +1211,10 @@ __device__ static void relocateOut() {
 
 // ------------------------------------------------------------------------------------------------ kernels
 template <class A> __device__ static inline A helpArgs(HelpBox* b, int at = 0) {
-  union { A a; unsigned long long w[sizeof(A) / 8]; } u;
-  for (int i = 0; i < (int)(sizeof(A) / 8); i++) u.w[i] = __hip_atomic_load(&b->args[at + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return u.a;
+  A a;
+  ull_alias* w = (ull_alias*)&a;
+  for (int i = 0; i < (int)(sizeof(A) / 8); i++) w[i] = __hip_atomic_load(&b->args[at + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return a;
 }
 // Helper workgroup.  Wave 0 polls the command word in HBM (backing off to ~30 us between polls when the round has not asked
 // for anything for a while, so an idle helper costs no measurable fabric traffic) and republishes it in LDS; the other waves

@@ -3,7 +3,7 @@
 # -> armada_amd/csrc/libarmada_sched_prof.so ; use: ASCHED_LIB_PATH=armada_amd/csrc/libarmada_sched_prof.so ASCHED_PRINT_SEG=1 python bench.py ...
 set -e
 cd "$(dirname "$0")/../armada_amd/csrc"
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DASCHED_FASTPROF"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-strict-aliasing -DASCHED_FASTPROF"
 hipcc $F -c armada_sched.hip -o /tmp/armada_sched_prof.o &
 hipcc $F -c armada_sched_aux.hip -o /tmp/armada_sched_aux_prof.o &
 wait

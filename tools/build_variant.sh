@@ -4,7 +4,7 @@
 set -e
 NAME=$1; shift
 cd "$(dirname "$0")/../armada_amd/csrc"
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $*"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-strict-aliasing $*"
 hipcc $F -c armada_sched.hip -o /tmp/armada_sched_$NAME.o &
 hipcc $F -c armada_sched_aux.hip -o /tmp/armada_sched_aux_$NAME.o &
 wait

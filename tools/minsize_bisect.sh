@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 NAMES=(selectAtLevelLiteral selectWithFairPreemption fairApply selectAtPriority scheduleMany trySchedule gangSchedule replayEvicted updateFairShares pqsEvict ensureFairIndex ensureReplaySlow runRound)
 case ${1:-build} in
 build)
-  F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off"
+  F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-strict-aliasing"
   cd armada_amd/csrc
   one() { local tag=$1 mask=$2; hipcc $F -DCOLD_MINSIZE_MASK=$mask -c armada_sched.hip -o /tmp/ms_$tag.o && hipcc --offload-arch=gfx950 -fPIC -shared -pthread -o libarmada_sched_ms_$tag.so /tmp/ms_$tag.o armada_sched_aux.o && echo built $tag; }
   N=0
