@@ -864,7 +864,8 @@ class Scheduler:
         self._check(self.lib.round_stats(self.h, out))
         names = ["fast_iterations", "generic_iterations", "base_scan_steps", "window_refills", "l0_max", "fast_replay_steps", "l0_overflows", "fast_active",
                  "kclk_evict", "kclk_replay", "kclk_pass1", "kclk_oversub_evict", "kclk_pass2", "kclk_unbind_results",
-                 "kclk_plane_scans", "kclk_fair_selects", "stream_runs", "stream_jobs", "stream_prepared", "stream_emitted", "preempt_fast_iterations"]
+                 "kclk_plane_scans", "kclk_fair_selects", "stream_runs", "stream_jobs", "stream_prepared", "stream_emitted", "preempt_fast_iterations",
+                 "ft_queries", "ft_retries", "ft_node_updates"]
         return {k: out[i] for i, k in enumerate(names)}
 
     def job_key_unfeasible(self, job: int) -> bool:

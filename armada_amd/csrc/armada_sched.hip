@@ -30,7 +30,7 @@
 
 // ------------------------------------------------------------------------------------------------ device primitives
 #define CTL_THREADS 256
-enum { OP_EXIT = 0, OP_SCAN = 1, OP_BULK = 2, OP_COMPACT = 3, OP_FAIR = 4, OP_ENGINE = 5, OP_BULKW = 6, OP_SCANFAIR = 7, OP_HELPERS_EXIT = 9 };
+enum { OP_EXIT = 0, OP_SCAN = 1, OP_BULK = 2, OP_COMPACT = 3, OP_FAIR = 4, OP_ENGINE = 5, OP_BULKW = 6, OP_SCANFAIR = 7, OP_FTBUILD = 8, OP_HELPERS_EXIT = 9 };
 struct BulkWArgs { int32_t kind, n; };   // a bulk pass whose bodies touch HBM only: shared with the helper workgroups
 
 struct Mailbox {
@@ -257,6 +257,19 @@ __device__ static inline void wgBulkWide(Dev& d, int kind, int n) {
   __syncthreads();
   if (g_H) { (void)helpWait(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 }
+
+#ifndef ASCHED_NO_FT
+// one pass of the fair-share threshold table's build (round_ft.h): like wgBulkWide, with its own op and an out-of-line body
+__device__ static inline void wgFtBuild(Dev& d, int phase, int n) {
+  int lane = threadIdx.x & 63;
+  if (lane == 0) { g_mb.op = OP_FTBUILD; g_mb.kind = phase; g_mb.n = n; if (g_H) { BulkWArgs a; a.kind = phase; a.n = n; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); helpIssue(OP_FTBUILD, &a); } }
+  __syncthreads();
+  { int nthreads = (g_H + 1) * (int)blockDim.x; int ph = g_mb.kind, nn = g_mb.n; for (int i = threadIdx.x; i < nn; i += nthreads) ftBuildAny(d, ph, i); }
+  __threadfence();
+  __syncthreads();
+  if (g_H) { (void)helpWait(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+}
+#endif
 
 // Most elements of the per-job passes do nothing (queued jobs have no node, few jobs are flagged for eviction): read the one
 // field that decides that for BULK_U elements at once — independent loads, all in flight together — and run the body only for
@@ -1051,6 +1064,7 @@ __device__ static __attribute__((noinline)) void applyEvictedRange(Dev& d, int q
   int lane = threadIdx.x & 63;
   int R = k.R;
   int pending = g_rs.replayPending;
+  if (sign < 0 && !pending && lane == 0) g_rs.ftValid = 0;   // evicted-table entries come back: thresholds may rise (round_ft.h "Staleness") — the table is rebuilt at the next query
   int64_t accQ[MAXR], accPc[APPLY_PCS][MAXR];
 #pragma unroll
   for (int x = 0; x < MAXR; x++) { accQ[x] = 0;
@@ -1279,6 +1293,14 @@ __device__ static void helperMain(const Dev& d, HelpBox* b, int H) {
       for (int i = tid; i < a.n; i += nthreads) bulkElem(dm, a.kind, i);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // this workgroup's writes before its completion count
     }
+#ifndef ASCHED_NO_FT
+    else if (op == OP_FTBUILD) {
+      BulkWArgs a = helpArgs<BulkWArgs>(b);
+      Dev& dm = const_cast<Dev&>(d);
+      for (int i = tid; i < a.n; i += nthreads) ftBuildAny(dm, a.kind, i);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    }
+#endif
     if (lane == 0) {
       unsigned int before = __hip_atomic_fetch_add(&g_hArrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (before == (unsigned)(nw - 1)) {  // last wave of the workgroup: forward the folded result, reset the LDS words for the next command
@@ -1329,7 +1351,15 @@ __global__ __launch_bounds__(CTL_THREADS) void k_control(Dev dev, int cmd, HelpB
         int nthreads = (g_H + 1) * (int)blockDim.x; int kd = g_mb.kind, nn = g_mb.n;
         for (int i = threadIdx.x; i < nn; i += nthreads) bulkElem(d, kd, i);
         __threadfence();
-      } else if (op == OP_COMPACT) {
+      }
+#ifndef ASCHED_NO_FT
+      else if (op == OP_FTBUILD) {
+        int nthreads = (g_H + 1) * (int)blockDim.x; int ph = g_mb.kind, nn = g_mb.n;
+        for (int i = threadIdx.x; i < nn; i += nthreads) ftBuildAny(d, ph, i);
+        __threadfence();
+      }
+#endif
+      else if (op == OP_COMPACT) {
         compactPart(d);
       } else if (op == OP_ENGINE) {
         if ((threadIdx.x >> 6) == 1) engineLoop(d); else if ((threadIdx.x >> 6) == 2) bindLoop(d);
@@ -1764,7 +1794,9 @@ static int plat_run_control(Dev& dev, int cmd) {
   hipLaunchKernelGGL(k_control, dim3(1 + H), dim3(CTL_THREADS), 0, c->stream, dev, cmd, c->helpBox, H);
   (void)hipEventRecord(c->ev1, c->stream);
   if (!hipOk(hipGetLastError(), "k_control launch")) return -1;
-  if (dev.progress || (isRound && c->deadlineS > 0)) {
+  static const double safetyS = [] { const char* e = getenv("ASCHED_SAFETY_DEADLINE_S"); return e ? atof(e) : 0.0; }();   // test / measurement runs of new builds: no launch outlives this
+  double deadlineS = c->deadlineS > 0 ? c->deadlineS : safetyS;
+  if (dev.progress || (isRound && deadlineS > 0)) {
     // hard timeout (scheduling_algo.go:130-134): the kernel polls the cancel word; the host sets it when the deadline passes
     auto t0 = c->inRound ? c->roundT0 : std::chrono::steady_clock::now();
     int ticks = 0;
@@ -1772,7 +1804,7 @@ static int plat_run_control(Dev& dev, int cmd) {
     while (hipStreamQuery(c->stream) == hipErrorNotReady) {
       usleep(dev.progress ? 100000 : 100);
       double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      if (isRound && c->deadlineS > 0 && el > c->deadlineS) plat_cancel(c);
+      if (isRound && deadlineS > 0 && el > deadlineS) plat_cancel(c);
       if (dev.progress && ++ticks % 10 == 0) { fprintf(stderr, "[asched progress] t=%ds iterations=%d generic=%d phase=%d op=%d ops=%d | wait: done=%d H=%d gen=%d box.gen=%d box.op=%d | helpers:", ticks / 10, progress[0], progress[4], progress[1], progress[2], progress[3], progress[5], progress[6], progress[7], progress[8], progress[9]); for (int i = 17; i < 56; i++) fprintf(stderr, " %x", progress[i]); fprintf(stderr, "\n"); }
     }
   }

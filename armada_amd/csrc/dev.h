@@ -143,6 +143,9 @@ struct RoundScalars {
   int32_t awayRowPlus1;      // an away attempt is in progress: static mask row (+1) that replaces the job's home shape row
   int32_t fairIndexValid;    // the per-node index of the evicted table (fairOff/fairEnt) describes the current table
   int64_t totalNewJobNs;     // sctx.TotalNewJobSchedulingTime (context/scheduling.go:212-240)
+  int32_t ftWanted;          // this launch may build / use the threshold table (a scheduling pass of a round: set by the pass, cleared at kernel start)
+  int32_t ftValid;           // the fair-share threshold table (round_ft.h) describes the current planes + evicted table (an upper bound per entry); cleared with fairIndexValid and at every launch
+  int32_t statFt[3];         // threshold table: queries, validation retries, node updates
   int64_t statSeg[40];       // [24..39]: (profiling builds) segments of the generic iteration
   int64_t gsT;                     // (profiling builds) shader-clock ticks per segment of a fast iteration
   int64_t statClk[8];        // shader-clock ticks per phase of the round (device builds): evict, replay, pass 1, oversub evict, pass 2, unbind+results
@@ -229,6 +232,12 @@ struct Dev {
   int32_t* fairEnt;      // [M] evicted-table Index
   int32_t* fairEntJob;   // [M] its job
   int32_t* fairPart;     // [FAIR_CHUNKS+1] chunk sums of the offset scan
+  // fair-share threshold table (round_ft.h): T[s][n] = fairNodeBest of scheduling-key shape s on node n, its maxima per 64 / 4096 nodes; NULL = not in use
+  int32_t* ftT;          // [ftS][Npad]
+  int32_t* ftB1;         // [ftS][ftNB1]
+  int32_t* ftB2;         // [ftS][64]
+  int32_t* ftPrio;       // [ftS] priority a job of the shape asks with (its priority class's)
+  int32_t ftS, ftNB1;
   // ---- txn undo log
   int32_t* undo;         // [cap][4]
   int32_t undoCap;

@@ -62,6 +62,9 @@ DEV uint64_t wgFirstFitKey(Dev& d, const ScanArgs& a);               // -> the r
 DEV int wgScanFair(Dev& d, const ScanArgs& a, const FairArgs& f, uint64_t* bestKey);   // both in ONE wide pass (one hand-shake with the helper workgroups): *bestKey = wgFirstFitKey(a), returns wgFairSelect(f)
 DEV int wgFairSelect(Dev& d, const FairArgs& a);                     // -> evicted-table Index or -1 (max over nodes of fairNodeBest)
 DEV int atomicFetchAddI32(int32_t* p, int32_t v);
+#if !defined(ASCHED_HOSTSIM)
+DEV int waveMax32(int v);
+#endif
 template <class F> DEV void wgForEach(Dev& d, int n, F f);           // f(i) for i in [0,n), then workgroup barrier
 DEV int wgCompact(Dev& d, const int32_t* src, int n, const uint8_t* flagByValue, int32_t* dst, const int32_t* segOff, int nseg, int32_t* outSegOff);
 DEV void atomicAddI64(int64_t* p, int64_t v);
@@ -166,10 +169,26 @@ DEV void updateKeys(Dev& d, int n) { for (int l = 0; l < d.cfg.P; l++) KEY(d, l,
 #define CTL_WAVE() false
 #define CTL_LANE() 0
 #endif
+DEV_COLD void ftUpdateNode(Dev& d, int n);   // round_ft.h: the fair-share threshold table follows every change the generic code makes to a node
+DEV_COLD int ftQuery(Dev& d, int s);
+DEV_COLD void ftAfterAbort(Dev& d, int undoCount);
+// The fair-share threshold table (round_ft.h) is NOT part of the default device build.  Measured on the MI355X (profiles/r03g_*): BASELINE configs[4] at full
+// size 17.2 -> 15.1 s per round, the same shape at 20k nodes 2.55 -> 2.70 s (half of the preempting jobs need urgency preemption, which still takes a wide
+// pass), and its mere presence in k_control costs the headline 2-3 % (code placement: profiles/r03f_*).  -DASCHED_WITH_FT builds it in; the CPU build of the
+// tests always has it (its logic is soaked against the oracle like everything else).
+#if !defined(ASCHED_WITH_FT) && !defined(ASCHED_HOSTSIM)
+#define ASCHED_NO_FT 1
+#endif
+#ifdef ASCHED_NO_FT
+DEV void ftTouch(Dev&, int) {}
+#else
+DEV void ftTouch(Dev& d, int n) { if (d.ftT && d.rs->ftValid) ftUpdateNode(d, n); }
+#endif
 DEV void updateKeysCtl(Dev& d, int n) {  // control-flow call sites (not the bulk rebuild)
   if (CTL_WAVE()) { int l = CTL_LANE(); if (l < d.cfg.P) KEY(d, l, n) = packKey(d, l, n); }   // one level per lane
   else updateKeys(d, n);
   fastTouch(d, n);
+  ftTouch(d, n);
 }
 
 DEV bool fitsAlloc(Dev& d, const int64_t* req, int level, int n) {  // DynamicJobRequirementsMet (is/nodedb/nodematching.go:194-197)
@@ -253,7 +272,7 @@ DEV void evTabDelete(Dev& d, int idx, bool log) {
   if (log) undoPush(d, U_EVTAB_DEL, idx, 0, 0);
 }
 DEV void evTabInsert(Dev& d, int idx, int job) {
-  d.rs->fairIndexValid = 0;
+  d.rs->fairIndexValid = 0; d.rs->ftValid = 0;
   d.evTabJob[idx] = job; d.evTabAlive[idx] = 1; d.evIndexOfJob[job] = idx;
   if (idx + 1 > d.rs->evictedTableSize) d.rs->evictedTableSize = idx + 1;
 }
@@ -284,6 +303,9 @@ DEV void txnAbort(Dev& d, Txn& t) {
       d.evTabAlive[a] = 1; d.evIndexOfJob[d.evTabJob[a]] = a;
     }
   }
+#ifndef ASCHED_NO_FT
+  if (d.ftT && d.rs->ftValid && d.rs->undoCount > 0) ftAfterAbort(d, d.rs->undoCount);   // (round_ft.h; out of line: txnAbort is inlined into the fast loop's preempting iteration)
+#endif
   d.rs->undoCount = 0;
 }
 
@@ -710,6 +732,41 @@ DEV_COLD COLD_MS_3 int selectAtPriority(Dev& d, Ctl& c, int job) {
       // the replay of the evicted jobs is still deferred the two questions are asked one after the other as before — the replay runs loops of its
       // own and belongs where the reference runs it: after a gate that passed.
       ensureFairIndex(d);
+      // The threshold table (round_ft.h) answers the fair-share question for a home attempt of a queued job without a pass over the nodes.  A node found
+      // that way also passes the gate — its considered entries are evicted jobs, which no level above -2 counts: alloc[level] >= alloc[-2] + their requests
+      // >= the request — so the gate (counted as issued) needs no scan.  No node: the gate and the urgency sweep take the multi-level pass as before.
+#ifndef ASCHED_NO_FT
+      if (d.ftT && d.rs->ftValid && !d.rs->awayRowPlus1 && !a.maskB && d.jShape[job] < d.ftS && d.ftPrio[d.jShape[job]] == sap) {
+        long long t1 = CLK();
+        int idx = ftQuery(d, d.jShape[job]);
+        d.rs->statClk[7] += CLK() - t1;
+        XSEG(33);
+        if (idx >= 0) {
+          d.rs->statClk[6] += CLK() - t0;
+          d.rs->numNodeQueries++;                      // the gate
+          d.pcNode[job] = -1; d.pcPap[job] = ASCHED_MIN_PRIORITY;
+          n = fairApply(d, c, job, idx, sap);
+          XSEG(34);
+          if (n >= 0) { d.pcMethod[job] = ASCHED_METHOD_FAIRSHARE; return n; }
+          return -1;                                   // (fairApply raised an error)
+        }
+        if (idx == -1) {   // no node can be freed by fair-share preemption: gate + urgency sweep in one multi-level scan
+          best = wgFirstFitKey(d, a);
+          d.rs->statClk[6] += CLK() - t0;
+          XSEG(23);
+          d.rs->numNodeQueries++;                      // the gate
+          if (best == ~0ull) return -1;
+          d.pcNode[job] = -1; d.pcPap[job] = ASCHED_MIN_PRIORITY;
+          if (d.cfg.disableUrgency) return -1;
+          int l = lp == 1 ? 1 : (int)(best >> SCAN_LEVEL_SHIFT);
+          d.rs->numNodeQueries += l;                     // levels 1 .. l of the sweep
+          n = d.nodeByRank[best & ((1ull << d.cfg.idxBits) - 1)];
+          d.pcNode[job] = n; d.pcPap[job] = d.cfg.prios[l]; d.pcMethod[job] = ASCHED_METHOD_URGENCY;
+          return n;
+        }
+        // idx == -2: the table was dropped (inconsistent maxima): the wide pass below answers
+      }
+#endif
       FairArgs fa;
       for (int r = 0; r < MAXR; r++) fa.req[r] = a.req[r];
       fa.maskA = a.maskA; fa.maskB = a.maskB; fa.prio = sap; fa.pad = 0;
@@ -882,6 +939,7 @@ DEV bool tryGang(Dev& d, Ctl& c, int ref, int* reason) {
   else { txnAbort(d, c.txn); unstagePreemptions(d, c); }
   return ok;
 }
+DEV_COLD bool tryGangCold(Dev& d, Ctl& c, int ref, int* reason) { return tryGang(d, c, ref, reason); }   // (out of line for the fast loop's preempting iteration: A/B builds)
 DEV void fitOf(Dev& d, int ref, int* num, double* mean) {  // gctx.Fit (context/gang.go:94-110)
   int n = 0; int32_t tot = 0;
   int cnt = gcCount(d, ref);
@@ -1263,3 +1321,5 @@ DEV_COLD COLD_MS_7 void replayEvicted(Dev& d, Ctl& c) {
   }
   c.useReplayAlloc = 0; c.compareSchedPrio = savedCmp;
 }
+
+#include "round_ft.h"

@@ -1449,7 +1449,11 @@ DEV __attribute__((always_inline)) int fastPreemptIter(Dev& d, Ctl& c, FastCtx f
   fastFence(c);
   XSEG(35);
   int reason = 0;
+#ifdef ASCHED_TRYGANG_COLD
+  bool ok = tryGangCold(d, c, job, &reason);
+#else
   bool ok = tryGang(d, c, job, &reason);
+#endif
   XSEG(36);
   if (RS.error) return 1;
   if (FLANE == 0) { RS.loopIterations++; RS.statFastIters++; RS.statHybrid++; }
@@ -1510,7 +1514,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   RS.globalTokens = S.globalTokens; \
   RS.numScheduledJobs = S.numScheduledJobs; RS.numScheduledGangs = S.numScheduledGangs; RS.numEvictedJobs = S.numEvictedJobs; \
   RS.numNodeQueries = S.numNodeQueries; RS.loopIterations = S.loopIterations; \
-  if (RS.evictedTableSize != S.evictedTableSize) RS.fairIndexValid = 0;  /* the replay added table entries */ \
+  if (RS.evictedTableSize != S.evictedTableSize) { RS.fairIndexValid = 0; RS.ftValid = 0; }  /* the replay added table entries */ \
   RS.evictedTableSize = S.evictedTableSize; \
   RS.statFastIters = S.statFastIters; RS.statScanSteps = S.statScanSteps; RS.statRefills = S.statRefills; RS.statL0Max = S.statL0Max; RS.statFastReplay = S.statFastReplay;
   FAST_SCALARS_IN()

@@ -15,6 +15,7 @@ enum BulkKind {
 };
 
 DEV void wgBulk(Dev& d, int kind, int n);  // every element i in [0,n) through bulkElem(), then a workgroup barrier
+DEV void wgFtBuild(Dev& d, int phase, int n);  // one pass of the fair-share threshold table's build (round_ft.h ftBuildAny), helper workgroups included
 DEV void wgBulkWide(Dev& d, int kind, int n);  // the same with the helper workgroups taking their share (bodies that touch HBM only)
 DEV int wgCompactFlagged(Dev& d, const int32_t* order, const int32_t* segOff, int nseg, int n, const uint8_t* flag, int32_t* dst, int32_t* outSegOff);
 DEV int wgCompactIota(Dev& d, int n, const uint8_t* flag, int32_t* dst);
@@ -345,7 +346,7 @@ DEV_COLD COLD_MS_9 int pqsEvict(Dev& d, Ctl& c, bool phase3) {
   int n = wgCompactFlagged(d, d.ordAll, d.ordAllOff, d.cfg.Q, d.ordAllOff[d.cfg.Q], d.evFlag, d.evList, d.evOff);
   d.rs->numEvictedList = n;
   wgBulk(d, B_RESET_EVTAB, d.rs->evictedTableSize);  // nodeDb.Reset() (nodedb.go:299-313)
-  d.rs->evictedTableSize = 0; d.rs->fairIndexValid = 0;
+  d.rs->evictedTableSize = 0; d.rs->fairIndexValid = 0; d.rs->ftValid = 0;
   wgBulk(d, B_RESET_GANGSEEN, d.cfg.G);
   d.rs->replayPending = 0;
   wgBulk(d, B_SNAP, d.cfg.Q * d.cfg.R);
@@ -406,7 +407,7 @@ DEV void roundSmall(Dev& d, int what, int arg) {
       break;
     case SM_EVICT_POST:  // after the compaction of an evictor's job list: nodeDb.Reset() bookkeeping (nodedb.go:299-313)
       d.rs->numEvictedList = arg;
-      d.rs->evictedTableSize = 0; d.rs->fairIndexValid = 0; d.rs->replayPending = 0;
+      d.rs->evictedTableSize = 0; d.rs->fairIndexValid = 0; d.rs->ftValid = 0; d.rs->replayPending = 0;
       break;
     case SM_STITCH: {  // carry-in of range i = requests of the same queue summed over the ranges before it (B_EVSUM -> B_EVKEYS)
       int64_t run[MAXR]; int runQ = -1;
@@ -452,7 +453,7 @@ DEV void roundSmall(Dev& d, int what, int arg) {
       }
     } break;
     case SM_PREPARE_FIN:  // tail of CMD_PREPARE: fresh evicted table, fair shares (context/scheduling.go:262-342)
-      d.rs->fastActive = 0; d.rs->evictedTableSize = 0; d.rs->fairIndexValid = 0; d.rs->numUnfeasible = 0;
+      d.rs->fastActive = 0; d.rs->evictedTableSize = 0; d.rs->fairIndexValid = 0; d.rs->ftValid = 0; d.rs->numUnfeasible = 0;
       updateFairShares(d, (const double*)0);
       break;
     case SM_FINAL:
@@ -474,7 +475,20 @@ DEV void schedulePass(Dev& d, Ctl& c, bool withQueued, bool skipKey, bool cmpPri
 
 // Per-node index of the evicted table (CSR node -> table Indexes, descending) for fair-share preemption.  Every entry below
 // evictedTableSize is indexed, dead or alive (a transaction abort can bring an entry back); rebuilt when the table has grown.
+// The threshold table from the planes and the evicted table as they are now: three grid-wide passes shared with the helper workgroups.  They have an op of their
+// own (wgFtBuild) instead of three more kinds in bulkElem: a call inside that switch cost the stream preparation 3-5 % of the headline round (measured, profiles/r03f).
+#ifndef ASCHED_NO_FT
+DEV void ftBuild(Dev& d) {
+  wgFtBuild(d, 0, d.cfg.N * ((d.ftS + FT_CHUNK - 1) / FT_CHUNK));
+  wgFtBuild(d, 1, d.ftS * d.ftNB1);
+  wgFtBuild(d, 2, d.ftS * 64);
+  d.rs->ftValid = 1;
+}
+#endif
 DEV_COLD COLD_MS_10 void ensureFairIndex(Dev& d) {
+#ifndef ASCHED_NO_FT
+  if (d.rs->fairIndexValid) { if (d.ftT && !d.rs->ftValid && d.rs->ftWanted) ftBuild(d); return; }
+#endif
   if (d.rs->fairIndexValid) return;
   int E = d.rs->evictedTableSize, N = d.cfg.N;
   wgBulk(d, B_FAIR_ZERO, N);
@@ -487,6 +501,9 @@ DEV_COLD COLD_MS_10 void ensureFairIndex(Dev& d) {
   wgBulk(d, B_FAIR_SCATTER, E);
   wgBulk(d, B_FAIR_SORT, N);
   d.rs->fairIndexValid = 1;
+#ifndef ASCHED_NO_FT
+  if (d.ftT && d.rs->ftWanted) ftBuild(d);
+#endif
 }
 
 DEV void swapLoopArrays(Dev& d) {
@@ -667,7 +684,7 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
       break;
     case CMD_RESET_JOBS:
       wgBulk(d, B_RESET_JOBS, cf.M);
-      d.rs->evictedTableSize = 0; d.rs->fairIndexValid = 0; d.rs->txnActive = 0; d.rs->undoCount = 0;
+      d.rs->evictedTableSize = 0; d.rs->fairIndexValid = 0; d.rs->ftValid = 0; d.rs->txnActive = 0; d.rs->undoCount = 0;
       break;
     case CMD_PREPARE:
       d.rs->fastActive = 0;
@@ -675,7 +692,7 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
       wgBulk(d, B_RESET_JOBS, cf.M);
       wgBulk(d, B_POPULATE, cf.M);
       wgBulk(d, B_KEYS_ALL, cf.N);
-      d.rs->evictedTableSize = 0; d.rs->fairIndexValid = 0;
+      d.rs->evictedTableSize = 0; d.rs->fairIndexValid = 0; d.rs->ftValid = 0;
       wgBulk(d, B_CLEAR_UNFEASIBLE, cf.S);
       updateFairShares(d, (const double*)0);
       break;
@@ -791,7 +808,7 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
     case CMD_RESET_EVICTED:
       d.rs->apiDirty = 1;
       wgBulk(d, B_RESET_EVTAB, cf.M);
-      d.rs->evictedTableSize = 0; d.rs->fairIndexValid = 0;
+      d.rs->evictedTableSize = 0; d.rs->fairIndexValid = 0; d.rs->ftValid = 0;
       break;
     case CMD_TXN_BEGIN: txnBegin(d, c.txn); break;
     case CMD_TXN_COMMIT: txnCommit(d, c.txn); break;
@@ -881,6 +898,7 @@ DEV void controlMainAux(Dev& d, int cmd) {
   c.txn.active = d.rs->txnActive; c.fairStamp = d.rs->fairStamp; c.preList = d.preList; c.preCount = 0;
   c.skipKeyCheck = 0; c.compareSchedPrio = 0; c.preferLarge = d.cfg.preferLarge; c.useReplayAlloc = 0; c.onlyEvicted = 0;
   c.fastEnabled = 0; c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0; c.cancelSeen = 0; c.fpLimitHit = 0; c.streamNextAt = 0; c.streamBackoff = 0; c.streamCap = QS_CMAX;
+  d.rs->ftValid = 0; d.rs->ftWanted = 0;
   fastLoad(d);
   runAuxCommand(d, c, cmd);
   fastEnterGeneric(d, c);
@@ -893,6 +911,9 @@ DEV void controlMain(Dev& d, int cmd) {
   c.skipKeyCheck = 0; c.compareSchedPrio = 0; c.preferLarge = d.cfg.preferLarge; c.useReplayAlloc = 0; c.onlyEvicted = 0;
   c.fastEnabled = d.f.iterOk && !d.rs->apiDirty && (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY || cmd == CMD_PASS1 || cmd == CMD_PASS2);
   c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0; c.cancelSeen = 0; c.fpLimitHit = 0; c.streamNextAt = 0; c.streamBackoff = 0; c.streamCap = QS_CMAX;
+  // the fair-share threshold table (round_ft.h) lives for one launch of a scheduling pass: the grid-wide phases between launches rewrite planes wholesale
+  d.rs->ftValid = 0;
+  d.rs->ftWanted = d.ftT != nullptr && !d.rs->apiDirty && (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY || cmd == CMD_PASS1 || cmd == CMD_PASS2);
   fastLoad(d);
   runCommand(d, c, cmd);
   fastEnterGeneric(d, c);

@@ -462,7 +462,8 @@ int32_t ASCHED_FN(round_timing)(asched_t*, double* out /*[8]*/);
 /* Measurement hook (no reference counterpart): how the last round ran on the device.  out = {fast iterations, generic
    iterations, base scan steps, window refills, max live dirty nodes (L0), fast replay steps, L0 overflows,
    fast structure active at the end, [8..15] kilo-ticks per phase, [16..19] stream runs / entries bound in them / stream entries prepared / emitted,
-   [20] iterations whose job needed preemption and stayed in the fast loop, 0...}.  The CPU oracle reports zeros. */
+   [20] iterations whose job needed preemption and stayed in the fast loop, [21..23] fair-share threshold table: queries answered without a wide
+   pass, validation retries, node re-evaluations}.  The CPU oracle reports zeros. */
 int32_t ASCHED_FN(round_stats)(asched_t*, int32_t* out /*[24]*/);
 /* Hard timeout of a round (maxSchedulingDuration, config/scheduler/config.yaml:83; scheduling_algo.go:130-134 wraps the context in
    WithTimeout, queue_scheduler.go:105-112 checks ctx.Done() every loop iteration and returns ctx.Err()).  asched_set_deadline: every

@@ -68,6 +68,7 @@ DEV int wgFirstFit(Dev& d, const ScanArgs& a) {
 DEV int wgScanFair(Dev& d, const ScanArgs& a, const FairArgs& f, uint64_t* bestKey) { *bestKey = wgFirstFitKey(d, a); return wgFairSelect(d, f); }
 DEV void wgBulk(Dev& d, int kind, int n) { HsScope prof(kind); for (int i = 0; i < n; i++) bulkElem(d, kind, i); }
 DEV void wgBulkWide(Dev& d, int kind, int n) { wgBulk(d, kind, n); }
+DEV void wgFtBuild(Dev& d, int phase, int n) { for (int i = 0; i < n; i++) ftBuildAny(d, phase, i); }
 DEV int wgCompactFlagged(Dev& d, const int32_t* order, const int32_t* segOff, int nseg, int n, const uint8_t* flag, int32_t* dst, int32_t* outSegOff) {
   int cnt = 0, q = 0;
   for (int p = 0; p <= n; p++) {

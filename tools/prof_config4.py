@@ -16,4 +16,4 @@ for i in range(1 if full else 2):
     W.prepare(s, wl)
     t = time.perf_counter(); r = s.schedule_round(); dt = time.perf_counter() - t
     st = s.round_stats()
-    print("round", i, round(dt * 1e3, 1), "ms", {k: st[k] for k in ("fast_iterations", "generic_iterations", "kclk_pass1", "kclk_pass2", "kclk_plane_scans", "kclk_fair_selects", "stream_jobs")}, len(r.scheduled), len(r.preempted), flush=True)
+    print("round", i, round(dt * 1e3, 1), "ms", {k: st[k] for k in ("fast_iterations", "generic_iterations", "kclk_pass1", "kclk_pass2", "kclk_plane_scans", "kclk_fair_selects", "stream_jobs", "preempt_fast_iterations", "ft_queries", "ft_retries", "ft_node_updates")}, len(r.scheduled), len(r.preempted), flush=True)
