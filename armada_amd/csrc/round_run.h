@@ -660,6 +660,7 @@ enum Cmd {
   CMD_SUBMIT_CHECK,  // first command of the auxiliary kernel (k_control_aux, armada_sched_aux.hip)
   CMD_PQ_ORDER,
   CMD_NODE_UPSERT,
+  CMD_ITERATE_NODES,
 };
 #define CMD_AUX_FIRST CMD_SUBMIT_CHECK
 // cmdIO layout: [0..15] results, [16..] arguments
@@ -845,6 +846,36 @@ DEV void runAuxCommand(Dev& d, Ctl& c, int cmd) {
         if (packedLess(kx, (uint32_t)d.qNameRank[x], ky, (uint32_t)d.qNameRank[y]) != pqLess(d, c, x, y)) agrees = 0;
       }
       a.out[a.n] = agrees;
+    } break;
+    case CMD_ITERATE_NODES: {
+      // NodeTypesIterator (nodeiteration.go:74-149) over the given node types at one priority, materialised: the test hook behind the ordering goldens of
+      // nodeiteration_test.go.  The iterators are the literal restatement the round uses off the index grid (round_ctl.h litAdvance / litNodeLess): one
+      // NodeTypeIterator per type, the heap as an argmin under nodeTypesIteratorPQ.less, the popped iterator advanced before its node is returned (:134-149).
+      // ARG: level, number of types, output capacity, -, K x (request lo, hi), then one mask row index per type (rows of d.typeMask the host built for the call)
+      int level = ARG(0), nT = ARG(1), cap = ARG(2);
+      if (nT > LIT_TMAX) { raise(d, ASCHED_ERR_UNSUPPORTED, 511); break; }
+      int64_t ireq[MAXK];
+      for (int i = 0; i < MAXK; i++) ireq[i] = i < cf.K ? (int64_t)(((uint64_t)(uint32_t)ARG(4 + 2 * i + 1) << 32) | (uint32_t)ARG(4 + 2 * i)) : 0;
+      for (int k = 0; k < nT; k++) {
+        LitIt& it = d.lit[k];
+        it.type = ARG(4 + 2 * MAXK + k);
+        for (int i = 0; i < MAXK; i++) it.lb[i] = ireq[i];
+        it.bound = litBound(cf, it.lb);
+        litAdvance(d, level, it, ireq);
+      }
+      int n = 0;
+      for (;;) {
+        if (d.rs->error) break;
+        int best = -1;
+        for (int k = 0; k < nT; k++) if (d.lit[k].head >= 0 && (best < 0 || litNodeLess(d, level, d.lit[k].head, d.lit[best].head))) best = k;
+        if (best < 0) break;
+        int node = d.lit[best].head;
+        litAdvance(d, level, d.lit[best], ireq);
+        if (n < cap) d.nodeOver[n] = node;
+        n++;
+        if (n > cf.N) { raise(d, ASCHED_ERR_INTERNAL, 512); break; }   // "iteration loop detected" (nodeiteration.go:330-336)
+      }
+      d.cmdIO[0] = n;
     } break;
     case CMD_NODE_UPSERT: {  // UpsertWithTxn of one node (nodedb.go:1164-1175): new AllocatableByPriority, every order key rebuilt
       d.rs->apiDirty = 1;

@@ -378,8 +378,9 @@ int32_t ASCHED_FN(submit_check)(asched_t*, int32_t n_units, const int32_t* unit_
 /* Measurement hook (no reference counterpart): how the last submit_check ran.  out = {units answered by the wide fit kernel (individual
    checks on a pristine NodeDb), fit-kernel passes, units through the sequential control launch (gangs, or a NodeDb holding jobs), 0}. */
 int32_t ASCHED_FN(submit_stats)(asched_t*, int32_t* out /*[4]*/);
-/* NodeTypesIterator order (nodeiteration.go:74-149) for req at a priority over node types `types`
-   (ntypes<0: all types).  Test hook for the golden orderings of nodeiteration_test.go. */
+/* NodeTypesIterator order (nodeiteration.go:74-149) for req at a priority over node types `types` (node_type_override ids; ntypes<0: all types).
+   Test hook for the golden orderings of nodeiteration_test.go; the HIP backend materialises its literal iterator restatement (the one rounds use
+   off the index grid) in the auxiliary kernel. */
 int32_t ASCHED_FN(iterate_nodes)(asched_t*, const int64_t* type_ids, int32_t ntypes, int32_t priority,
                                  const int64_t* indexed_req /*[K]*/, int32_t* out_nodes, int32_t cap, int32_t* n_out);
 /* First feasible node per job at `priority` against the CURRENT state, no binding: n independent

@@ -46,6 +46,17 @@ def test_gang_goldens(hip_lib, case):
     _run(scenario.run_gang_case, hip_lib, case)
 
 
+NTI, NTSI = load("node_type_iterator"), load("node_types_iterator")
+
+
+@pytest.mark.parametrize("case", NTI + NTSI, ids=["one:" + n for n in ids(NTI)] + ["merged:" + n for n in ids(NTSI)])
+def test_node_iteration_order(hip_lib, case):
+    """nodeiteration_test.go:86-307, 389-635: the order NodeTypeIterator / NodeTypesIterator yield nodes in, through the device's own literal iterator
+    restatement (the code rounds use off the index grid), materialised by asched_iterate_nodes"""
+    got = scenario.run_node_iteration_case(hip_lib, case)
+    assert got == case["expected"], case["source"]
+
+
 def test_reference_tables_reach_the_fast_path(hip_lib):
     """The reference's own PQS / QueueScheduler tables must pin the code that produces the bench numbers, not only the generic path: their nodes are uploaded
     without an explicit AllocatableByPriority (scenario.Case.upsert_nodes), so the rounds go through the level-0 fast structure, the stream runs and the
