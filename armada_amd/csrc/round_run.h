@@ -4,6 +4,7 @@
 #pragma once
 #include "round_ctl.h"
 #include "round_fast.h"
+#include "round_market.h"
 
 enum BulkKind {
   B_RESET_GANGSEEN = 1, B_FILTER1, B_NODE_OVER, B_FILTER3, B_GANG_CLOSURE, B_EVICT_APPLY1, B_EVICT_APPLY3, B_KEYS_ALL,
@@ -661,6 +662,7 @@ enum Cmd {
   CMD_PQ_ORDER,
   CMD_NODE_UPSERT,
   CMD_ITERATE_NODES,
+  CMD_MARKET,
 };
 #define CMD_AUX_FIRST CMD_SUBMIT_CHECK
 // cmdIO layout: [0..15] results, [16..] arguments
@@ -846,6 +848,12 @@ DEV void runAuxCommand(Dev& d, Ctl& c, int cmd) {
         if (packedLess(kx, (uint32_t)d.qNameRank[x], ky, (uint32_t)d.qNameRank[y]) != pqLess(d, c, x, y)) agrees = 0;
       }
       a.out[a.n] = agrees;
+    } break;
+    case CMD_MARKET: {   // market-driven ordering's iterators (round_market.h)
+      MarketArgs a = *(const MarketArgs*)(d.cmdIO + 16);
+      if (a.op == 0) marketIterate(a);
+      else if (a.op == 1) a.out[0] = marketCompare(a.l1[0], a.l2[0]);
+      else marketMultiIterate(a);
     } break;
     case CMD_ITERATE_NODES: {
       // NodeTypesIterator (nodeiteration.go:74-149) over the given node types at one priority, materialised: the test hook behind the ordering goldens of

@@ -411,8 +411,9 @@ int32_t ASCHED_FN(pq_order)(asched_t*, int32_t n, const asched_pq_item* items, i
 /* MarketBasedCandidateGangIterator (market_iterator.go:32-295): the order in which the market-driven candidate iterator yields the queues' jobs.  Queue q
    holds jobs[off[q] .. off[q+1]) in its iterator's order; out_queue[i] = the queue of the i-th Peek (Clear after each).  The priority queue is
    container/heap over MarketIteratorPQ.Less (:228-273), which is NOT a strict weak order — its round-robin clause reads the queue and price of the
-   previous result — so the heap's up / down moves are restated literally.  ORACLE-ONLY test hook (market_iterator_test.go:17-122): market-driven
-   ordering is not built on the device yet and the product returns ASCHED_ERR_UNSUPPORTED. */
+   previous result — so the heap's up / down moves are restated literally (HIP backend: armada_amd/csrc/round_market.h, run by the auxiliary kernel).
+   Test hook (market_iterator_test.go:17-122).  The market-driven ROUND — evict-everything node evictor, spot price / second-price billing, indicative
+   pricer — is not built yet. */
 typedef struct asched_market_job {
   double price;                    /* job.GetBidPrice(pool) */
   int64_t runtime, submit_time;    /* item.runtime as updatePQItem computes it (now - LatestRun().Created() for a job that is not queued, else 0); SubmitTime */
@@ -423,7 +424,7 @@ int32_t ASCHED_FN(market_iterate)(asched_t*, int32_t nq, const int32_t* name_ran
 
 /* jobdb.MarketSchedulingOrderCompare (jobdb/comparison.go:113-170): the order of a queue's jobs under market-driven scheduling — priority class priority
    (higher first), bid price for the pool (higher first), a job with an active run before one without, older run first, earlier submit time, job id.
-   *out_sign = -1 / 0 / +1.  ORACLE-ONLY test hook like market_iterate (comparison_test.go:76-178). */
+   *out_sign = -1 / 0 / +1.  Test hook like market_iterate (comparison_test.go:76-178). */
 typedef struct asched_market_cmp_job {
   double bid_price;                              /* job.GetBidPrice(currentPool) */
   int64_t active_run_timestamp, submit_time;
@@ -432,7 +433,7 @@ typedef struct asched_market_cmp_job {
 int32_t ASCHED_FN(market_compare)(asched_t*, const asched_market_cmp_job* a, const asched_market_cmp_job* b, int32_t* out_sign);
 /* MarketDrivenMultiJobsIterator (jobiteration.go:232-321) over two InMemoryJobIterators (:22-65): the merge of a queue's two job lists by
    MarketSchedulingOrderCompare, with OnlyYieldEvicted called before the (only_evicted_after + 1)-th Next (negative: never).  out = the yielded jobs, list 1
-   as its index, list 2 as n1 + index.  ORACLE-ONLY test hook (jobiteration_test.go:150-232). */
+   as its index, list 2 as n1 + index.  Test hook (jobiteration_test.go:150-232). */
 int32_t ASCHED_FN(market_multi_iterate)(asched_t*, int32_t n1, const asched_market_cmp_job* list1, const uint8_t* evicted1, int32_t n2,
                                         const asched_market_cmp_job* list2, const uint8_t* evicted2, int32_t only_evicted_after, int32_t* out, int32_t* n_out);
 
