@@ -141,6 +141,12 @@ class COptResult(C.Structure):
     _fields_ = [("node", C.c_int32), ("num_preempted", C.c_int32), ("scheduling_cost", C.c_double), ("maximum_queue_impact", C.c_double)]
 
 
+class COptimiserConfig(C.Structure):
+    _fields_ = [("enabled", C.c_uint8), ("pad_", C.c_uint8 * 7), ("min_fairness_improvement_pct", C.c_double), ("max_jobs_per_round", C.c_int32), ("pad2_", C.c_int32),
+                ("max_job_size_to_preempt", C.POINTER(C.c_int64)), ("min_job_size_to_schedule", C.POINTER(C.c_int64)),
+                ("max_resource_fraction_to_schedule", C.POINTER(C.c_double)), ("now_ms", C.c_int64)]
+
+
 class COptNodeScore(C.Structure):
     _fields_ = [("scheduled", C.c_int32), ("num_preempted", C.c_int32), ("scheduling_cost", C.c_double), ("maximum_queue_impact", C.c_double)]
 
@@ -185,7 +191,7 @@ ALL_SYMBOLS = [
     "get_alloc", "get_scheduled_at_priority", "iterate_nodes", "fit_select_batch", "drf_cost", "fair_shares",
     "round_prepare", "schedule_round", "schedule_queues", "gang_schedule", "round_counters", "job_key_unfeasible", "kernel_times", "round_stats",
     "clear_allocated", "submit_check", "pq_order", "submit_stats", "num_nodes", "total_resources", "node_types_matching_job", "scheduling_order",
-    "optimiser_schedule_job", "set_label_value_ints", "round_timing", "set_deadline", "cancel", "cancel_clear", "indexed_node_label_values", "get_node_jobs", "get_nodes_alloc", "node_upsert",
+    "optimiser_schedule_job", "set_optimiser", "set_label_value_ints", "round_timing", "set_deadline", "cancel", "cancel_clear", "indexed_node_label_values", "get_node_jobs", "get_nodes_alloc", "node_upsert",
     "market_iterate", "market_compare", "market_multi_iterate",
 ]
 
@@ -273,6 +279,7 @@ class Library:
         f("num_nodes", C.c_int32, [C.c_void_p])
         f("scheduling_order", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int32])
         f("set_label_value_ints", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i64p])
+        f("set_optimiser", C.c_int32, [C.c_void_p, C.POINTER(COptimiserConfig)])
         f("optimiser_schedule_job", C.c_int32, [C.c_void_p, C.c_int32, C.c_double, _i64p, C.c_int64, C.POINTER(COptResult), _i32p, C.c_int32, C.POINTER(COptNodeScore)])
         f("round_timing", C.c_int32, [C.c_void_p, C.POINTER(C.c_double)])
         f("set_deadline", C.c_int32, [C.c_void_p, C.c_double])
@@ -699,6 +706,26 @@ class Scheduler:
         out = np.zeros((self.P, self.R), dtype=np.int64)
         self._check(self.lib.get_alloc(self.h, node, _ptr(out, C.c_int64)))
         return out
+
+    def set_optimiser(self, enabled: bool = True, min_improvement_pct: float = 0.0, max_jobs_per_round: int = 0, max_job_size_to_preempt=None,
+                      min_job_size_to_schedule=None, max_resource_fraction_to_schedule=None, now_ms: int = 0):
+        """the experimental fairness optimiser as part of the following schedule_round calls (configuration.OptimiserConfig); enabled=False: off"""
+        if not enabled:
+            self._check(self.lib.set_optimiser(self.h, None))
+            return
+        c = COptimiserConfig()
+        keep = []
+
+        def arr(v, dt, ct):
+            if v is None:
+                return None
+            a = _arr(v, dt); keep.append(a)
+            return _ptr(a, ct)
+        c.enabled = 1; c.min_fairness_improvement_pct = float(min_improvement_pct); c.max_jobs_per_round = int(max_jobs_per_round); c.now_ms = int(now_ms)
+        c.max_job_size_to_preempt = arr(max_job_size_to_preempt, np.int64, C.c_int64)
+        c.min_job_size_to_schedule = arr(min_job_size_to_schedule, np.int64, C.c_int64)
+        c.max_resource_fraction_to_schedule = arr(max_resource_fraction_to_schedule, np.float64, C.c_double)
+        self._check(self.lib.set_optimiser(self.h, C.byref(c)))
 
     def optimiser_schedule_job(self, job: int, min_improvement_pct: float = 0.0, max_job_size_to_preempt=None, now_ms: int = 0, per_node: bool = False):
         """scheduleOnNodes of the fairness optimiser for one job -> dict(node, cost, impact, preempted[, scores: [N] (scheduled, npre, cost, impact)])"""

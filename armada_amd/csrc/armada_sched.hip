@@ -1502,7 +1502,7 @@ __global__ void k_seg_off(const int32_t* segOff, int nseg, int n, const uint32_t
 
 // ---- fairness optimiser (round_opt.h): per-node job lists (count / scan / scatter), queue costs, then every node scored for one job at once
 __global__ __launch_bounds__(256) void k_opt_count(Dev d, int32_t* cnt) {
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < d.cfg.M; j += gridDim.x * blockDim.x) { int n = d.jobNode[j]; if (n >= 0) atomicAdd(&cnt[n], 1); }
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < d.cfg.M; j += gridDim.x * blockDim.x) { int n = d.jobNode[j]; if (n >= 0) atomicAdd(&cnt[n], 1); int g = d.rs->optMode ? d.optGhost[j] : -1; if (g >= 0) atomicAdd(&cnt[g], 1); }   // (ghost: dev.h optGhost)
 }
 __global__ __launch_bounds__(1024) void k_opt_scan(const int32_t* cnt, int32_t* off, int32_t* cursor, int N) {   // one block: chunk sums, serial scan of 1024 partials, chunk offsets
   __shared__ int part[1024];
@@ -1517,14 +1517,14 @@ __global__ __launch_bounds__(1024) void k_opt_scan(const int32_t* cnt, int32_t* 
   for (int n = n0; n < n1; n++) { off[n] = run; cursor[n] = run; run += cnt[n]; }
 }
 __global__ __launch_bounds__(256) void k_opt_scatter(Dev d, int32_t* cursor, int32_t* jobs) {
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < d.cfg.M; j += gridDim.x * blockDim.x) { int n = d.jobNode[j]; if (n >= 0) jobs[atomicAdd(&cursor[n], 1)] = j; }
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < d.cfg.M; j += gridDim.x * blockDim.x) { int n = d.jobNode[j]; if (n >= 0) jobs[atomicAdd(&cursor[n], 1)] = j; int g = d.rs->optMode ? d.optGhost[j] : -1; if (g >= 0) jobs[atomicAdd(&cursor[g], 1)] = j; }
 }
 __global__ void k_opt_qcost(Dev d, int job, double* qCost) {   // QueueContext.CurrentCost per queue (scheduling_context.go:19-24); [Q]: the job's own DRF cost
   int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q < d.cfg.Q) {
     int64_t a[MAXR];
     for (int r = 0; r < MAXR; r++) a[r] = r < d.cfg.R ? QV(d.qAlloc, q)[r] + QV(d.qPenalty, q)[r] : 0;
-    qCost[q] = drf(d, a);
+    qCost[q] = d.optQDelta ? d.optQDelta[q] : drf(d, a);   // (later members of a gang: CurrentCost as updateState left it, kept by the host)
   } else if (q == d.cfg.Q) qCost[q] = drf(d, JREQ(d, job));
 }
 __global__ __launch_bounds__(128) void k_opt_score(Dev d, OptArgs a, const double* qCost, const int32_t* off, const int32_t* jobs, OptNodeOut* out) {
@@ -1861,7 +1861,7 @@ static int plat_opt_score(Dev& d, const OptArgs& a, std::vector<OptNodeOut>& sco
   int N = d.cfg.N, M = d.cfg.M, Q = d.cfg.Q;
   // one allocation, carved: [scores N+1][queue costs Q+1][cnt N+1][off N+2][cursor N+1][jobs M][pre OPT_MAXJ]
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  size_t bOut = up(sizeof(OptNodeOut) * (size_t)(N + 1)), bQ = up(sizeof(double) * (size_t)(Q + 1)), bN = up(sizeof(int32_t) * (size_t)(N + 2)), bM = up(sizeof(int32_t) * (size_t)std::max(M, 1)), bP = up(sizeof(int32_t) * OPT_MAXJ);
+  size_t bOut = up(sizeof(OptNodeOut) * (size_t)(N + 1)), bQ = up(sizeof(double) * (size_t)(Q + 1)), bN = up(sizeof(int32_t) * (size_t)(N + 2)), bM = up(sizeof(int32_t) * 2 * (size_t)std::max(M, 1)), bP = up(sizeof(int32_t) * OPT_MAXJ);
   size_t need = bOut + bQ + 3 * bN + bM + bP;
   bool ok = true;
   if (c->optScratchBytes < need) {
@@ -1902,6 +1902,13 @@ static int plat_opt_score(Dev& d, const OptArgs& a, std::vector<OptNodeOut>& sco
   return ok ? 0 : -1;
 }
 static double plat_last_opt_ms() { return (double)g_lastOptMs; }
+// the queue costs the last plat_opt_score evaluated (QueueContext.CurrentCost per queue)
+static int plat_opt_qcosts(Dev& d, double* out, int Q) {
+  PlatCtx* c = t_ctx;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  size_t bOut = up(sizeof(OptNodeOut) * (size_t)(d.cfg.N + 1));
+  return hipOk(hipMemcpy(out, (char*)c->optScratch + bOut, sizeof(double) * (size_t)Q, hipMemcpyDeviceToHost), "opt queue costs") ? 0 : -1;
+}
 
 // grid-wide order-preserving compaction; *total comes back to the host (the next launches are sized by it)
 static int plat_compact(Dev& d, const int32_t* order, int n, const uint8_t* flag, int32_t* dst, uint32_t* prefix, const int32_t* segOff, int nseg, int32_t* outSegOff, int* total) {

@@ -143,6 +143,8 @@ struct RoundScalars {
   int32_t awayRowPlus1;      // an away attempt is in progress: static mask row (+1) that replaces the job's home shape row
   int32_t fairIndexValid;    // the per-node index of the evicted table (fairOff/fairEnt) describes the current table
   int64_t totalNewJobNs;     // sctx.TotalNewJobSchedulingTime (context/scheduling.go:212-240)
+  int32_t optMode;           // the fairness optimiser's candidate iteration is running: a job popped from a queue keeps the failure reason of an earlier attempt until its new
+                             // jctx is added to the scheduling context (qctx.addJobSchedulingContext drops the old one there, context/queue.go:235-237)
   int32_t ftWanted;          // this launch may build / use the threshold table (a scheduling pass of a round: set by the pass, cleared at kernel start)
   int32_t ftValid;           // the fair-share threshold table (round_ft.h) describes the current planes + evicted table (an upper bound per entry); cleared with fairIndexValid and at every launch
   int32_t statFt[3];         // threshold table: queries, validation retries, node updates
@@ -238,6 +240,11 @@ struct Dev {
   int32_t* ftB2;         // [ftS][64]
   int32_t* ftPrio;       // [ftS] priority a job of the shape asks with (its priority class's)
   int32_t ftS, ftNB1;
+  uint8_t *optSched, *optPre;   // [M] how often the fairness optimiser scheduled / preempted a job in this round: its result lists are merged into the round's at the END
+                         // of its phase (pqs.go:232-249), where a job it scheduled, preempted, scheduled again and preempted again comes out preempted
+  int32_t* optGhost;     // [M] -1, or the node on which a job the optimiser has bound elsewhere STILL holds its evicted resources: scheduled earlier in the round, evicted by the
+                         // oversubscribed evictor, not rescheduled — the reference keeps it in that node's AllocatedByJobId until the unbinding at the end of the round
+  double* optQDelta;     // [Q] or NULL: QueueContext.CurrentCost changes of the gang members placed so far in the optimiser's current gang (optimiser/gang_scheduler.go:182-188)
   // ---- txn undo log
   int32_t* undo;         // [cap][4]
   int32_t undoCap;

@@ -340,6 +340,7 @@ DEV void vadd(Dev& d, int64_t* a, const int64_t* b, int sign) { for (int r = 0; 
 DEV bool sctxAddJob(Dev& d, int job) {
   int q = d.jQueue[job], pc = d.jPc[job];
   const int64_t* req = JREQ(d, job);
+  if (d.jobFlags[job] & F_SUCCESSFUL) { raise(d, ASCHED_ERR_INTERNAL, 401); return false; }   // "failed adding job to queue: job already marked successful" (context/queue.go:232-234)
   uint8_t f = d.jobFlags[job] & ~F_UNSUCCESSFUL;
   bool evictedInRound = f & F_EVICTED;
   RoundScalars& s = *d.rs;
@@ -1033,7 +1034,8 @@ DEV_COLD COLD_MS_6 bool gangSchedule(Dev& d, Ctl& c, int ref, int* reason, const
 // ------------------------------------------------------------------------------------------------
 // job / gang iterators (is/scheduling/jobiteration.go, queue_scheduler.go:306-444)
 DEV void resetJctxForQueued(Dev& d, int job) {  // JobSchedulingContextFromJob (context/job.go:149-158)
-  d.jcEvicted[job] = 0; d.jcAssigned[job] = -1; d.jcReason[job] = 0; d.jcHasPctx[job] = 0;
+  d.jcEvicted[job] = 0; d.jcAssigned[job] = -1; d.jcHasPctx[job] = 0;
+  if (!d.rs->optMode) d.jcReason[job] = 0;   // (optimiser: jcReason is also the REPORT of an earlier failed attempt, kept until the new context is added: dev.h optMode)
   d.jcGangCard[job] = d.jGang[job] >= 0 ? d.jGangCard[job] : 1; d.jcUniValue[job] = -1; d.jcStagedBy[job] = -1;
 }
 DEV int jobItNext(Dev& d, int q, bool withQueued) {  // MultiJobsIterator(evicted, queued) :179-228

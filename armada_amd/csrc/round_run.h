@@ -663,6 +663,7 @@ enum Cmd {
   CMD_NODE_UPSERT,
   CMD_ITERATE_NODES,
   CMD_MARKET,
+  CMD_OPT_BEGIN, CMD_OPT_NEXT, CMD_OPT_APPLY, CMD_OPT_FAIL, CMD_OPT_END, CMD_OPT_TENT, CMD_OPT_TENT_UNDO,   // the fairness optimiser inside the round, gang by gang (asched_host.inc runOptimiserPhase)
 };
 #define CMD_AUX_FIRST CMD_SUBMIT_CHECK
 // cmdIO layout: [0..15] results, [16..] arguments
@@ -823,6 +824,191 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
 // armada_sched_aux.hip), so that the round kernel's code — everything above is inlined into it — stays exactly what was measured.
 struct SubmitArgs { int32_t nu, pad; int32_t* off; int32_t* jobs; int32_t* flags; int32_t* out; };  // at cmdIO + 16, written by the host
 struct PqOrderArgs { int32_t n, preferLarge, compareSchedPrio, homeFirst; int32_t* out; const int32_t* away; };  // at cmdIO + 16; out = [n] order, then 1 flag
+// ---- the experimental fairness optimiser inside the round (preempting_queue_scheduler.go:224-253, 666-710).  OptimisingQueueScheduler.Schedule
+// (optimising_queue_scheduler.go:58-180) is driven gang by gang from the host: the candidate iteration, the checks and the bookkeeping run here (the round's own
+// generic code), the node scoring of every member is the wide kernel k_opt_score launched by the host in between.
+struct OptLoopArgs { int32_t first, hasMinSize, pad0, pad1; int64_t current[MAXR], maxToSchedule[MAXR], minSize[MAXR]; };
+// createCandidateGangIterator (:200-226): queued jobs only, of the queues below their demand-capped adjusted fair share; ClearUnfeasibleSchedulingKeys (pqs.go:692)
+DEV void optBegin(Dev& d, Ctl& c) {
+  const DevCfg& cf = d.cfg;
+  wgBulk(d, B_CLEAR_UNFEASIBLE, cf.S);
+  d.rs->numUnfeasible = 0;
+  wgBulk(d, B_RESET_GANGSEEN, cf.G);
+  c.skipKeyCheck = 0; c.compareSchedPrio = 0; c.useReplayAlloc = 0; c.onlyEvicted = 0;
+  d.rs->optMode = 1;
+  { int l0 = CTL_WAVE() ? CTL_LANE() : 0, st = CTL_WAVE() ? 64 : 1; for (int j = l0; j < cf.M; j += st) { d.optSched[j] = 0; d.optPre[j] = 0; d.optGhost[j] = -1; } }
+  PassCfg pc{true, cf.maxLookback, true};
+  for (int q = 0; q < cf.Q; q++) {
+    d.itEi[q] = d.evOff[q + 1]; d.itQi[q] = d.queuedOff[q]; d.itStage[q] = 1; d.itJobsSeen[q] = 0; d.itNext[q] = -1; d.itStashed[q] = -1;
+    d.itJobOnlyEv[q] = 0; d.itGangOnlyEv[q] = 0; d.onlyEvByQueue[q] = 0; d.pqInHeap[q] = 0; d.pqGctx[q] = -1;
+    d.pqBudget[q] = d.qDc[q] / d.qWeight[q];
+  }
+  for (int q = 0; q < cf.Q; q++) {
+    int64_t a[MAXR];
+    for (int r = 0; r < cf.R; r++) a[r] = QV(d.qAlloc, q)[r] + QV(d.qPenalty, q)[r];
+    if (drf(d, a) >= d.qDc[q]) continue;           // at or above its fair share: no iterator
+    updateAndPush(d, c, q, pc);
+  }
+}
+// the loop of Schedule up to the point where a gang goes to the gang scheduler: cmdIO[0] = 1 + the gang (cmdIO[1] members in preList, [2] queue, [3] uniformity slot), or 0 = done
+DEV void optNext(Dev& d, Ctl& c, const OptLoopArgs& a) {
+  const DevCfg& cf = d.cfg;
+  PassCfg pc{true, cf.maxLookback, true};
+  bool first = a.first != 0;
+  for (;;) {
+    d.cmdIO[0] = 0;
+    if (d.rs->error) return;
+    if (!first) costItClear(d, c, pqTop(d, c), pc);   // (the cached keys have not changed since the Peek: the same top)
+    first = false;
+    int top = pqTop(d, c);
+    int ref = top >= 0 ? d.pqGctx[top] : -1;
+    if (ref == -1) return;
+    int cnt = gcCount(d, ref);
+    if (cnt == 0) continue;
+    if (gcAllEvicted(d, ref)) continue;
+    int q = gcQueue(d, ref);
+    if (d.pqProposed[top] > d.qDc[q] / d.qWeight[q]) continue;                          // :99-101
+    bool skip = false;
+    for (int k = 0; k < cnt && !skip; k++) {
+      int j = gcJob(d, ref, k);
+      if (d.jobFlags[j] & F_SUCCESSFUL) skip = true;                                      // scheduled earlier in this round (:104-108)
+      if (a.hasMinSize) for (int r = 0; r < cf.R; r++) if (a.minSize[r] > JREQ(d, j)[r]) skip = true;   // minimumJobSizeToSchedule.Exceeds(job) (:109-112)
+    }
+    if (skip) continue;
+    const int64_t* tot = gcTotal(d, ref);
+    for (int r = 0; r < cf.R; r++) if (a.current[r] + tot[r] > a.maxToSchedule[r]) skip = true;   // :115-117
+    if (skip) continue;
+    // checkIfWillBreachSchedulingLimits (:228-256): a failing constraint returns BEFORE EvictGang — the gang stays in the scheduling context (the reference's TODO)
+    int r = checkRound(d);
+    if (!r) {
+      for (int k = 0; k < cnt; k++) d.jcReason[gcJob(d, ref, k)] = 0;   // the fresh job contexts (no unschedulable reason) replace the earlier attempt's (dev.h optMode)
+      sctxAddGang(d, ref); r = checkJob(d, ref); if (!r) r = checkFloating(d, ref); if (!r) sctxEvictGang(d, ref);
+    }
+    if (r) {
+      if (isTerminal(r)) return;
+      if (isQueueTerminal(r)) costItOnlyEvictedForQueue(d, c, q, pc);
+      continue;
+    }
+    if (cancelRequested(d)) return;                                                       // hasContextExpired
+    int j0 = gcJob(d, ref, 0);
+    for (int k = 0; k < cnt; k++) d.preList[k] = gcJob(d, ref, k);
+    d.cmdIO[1] = cnt; d.cmdIO[2] = q; d.cmdIO[3] = d.jGang[j0] >= 0 ? d.jGangUni[j0] : -1;
+    d.cmdIO[0] = 1;
+    return;
+  }
+}
+// sctx.PreemptJob + qctx.preemptJob (context/scheduling.go:530-549, context/queue.go:322-349)
+DEV void sctxPreemptJob(Dev& d, int job) {
+  int q = d.jQueue[job], pc = d.jPc[job];
+  const int64_t* req = JREQ(d, job);
+  uint8_t f = d.jobFlags[job];
+  bool sched = f & F_SUCCESSFUL;
+  if (sched) { vadd(d, QPV(d.qSchedByPc, q, pc), req, -1); f &= ~F_SUCCESSFUL; }
+  f &= ~F_RESCHEDULED;
+  vadd(d, QPV(d.qAllocByPc, q, pc), req, -1);
+  vadd(d, QV(d.qAlloc, q), req, -1);
+  if (sched) { vadd(d, d.rs->scheduled, req, -1); d.rs->numScheduledJobs--; }
+  vadd(d, d.rs->allocated, req, -1);
+  d.jobFlags[job] = f;
+}
+// markJobsScheduledAndPreempted (optimiser/gang_scheduler.go:192-254) + the rate limiters (optimising_queue_scheduler.go:150-154) + the PQS result sets (pqs.go:232-249).
+// ARG: members, queue, then per member: job, node, number of victims, the victims
+DEV void optApply(Dev& d, Ctl& c) {
+  const DevCfg& cf = d.cfg;
+  (void)c;
+  int cnt = ARG(0), q = ARG(1), at = 2;
+  for (int m = 0; m < cnt; m++) {
+    int job = ARG(at), n = ARG(at + 1), npre = ARG(at + 2);
+    // A job scheduled earlier in this round, evicted by the oversubscribed evictor and not rescheduled still holds (evicted) resources on its node until the
+    // unbinding at the end of the round; the reference would now bind it on a second node as well.  This backend keeps one node per job: refused, not approximated
+    // In the reference the job is then in TWO nodes' AllocatedByJobId.  Here the old node keeps the job's evicted resources in its planes (nothing is touched) and
+    // remembers it as a ghost (dev.h optGhost): the scoring kernels list it there, a later victim selection may take it, optEnd gives the resources back.
+    if (d.jobNode[job] >= 0 && d.jobNode[job] != n) {
+      if (!d.jobEvictedOnNode[job] || d.optGhost[job] >= 0) { raise(d, ASCHED_ERR_INTERNAL, 300); return; }   // "job already has resources allocated" (node.go:416-442)
+      d.optGhost[job] = d.jobNode[job];
+      d.jobNode[job] = -1; d.jobEvictedOnNode[job] = 0;
+    }
+    for (int i = 0; i < npre; i++) {                                                  // UnbindJobsFromNode
+      int v = ARG(at + 3 + i);
+      if (d.optGhost[v] == n) { markAllocatable(d, n, ASCHED_EVICTED_PRIORITY, JREQ(d, v), +1); d.optGhost[v] = -1; }   // RemoveJob of the evicted copy on this node (node.go:480-506)
+      else removeJob(d, n, v, false);
+    }
+    int32_t prio = bindPriority(d, job, cf.pcPriority[d.jPc[job]]);
+    if (addJob(d, n, job, cutoffFor(d, job, prio), false)) return;                  // BindJobToNode
+    d.schedAtPrio[job] = prio;
+    updateKeysCtl(d, n);
+    for (int i = 0; i < npre; i++) {
+      int v = ARG(at + 3 + i);
+      sctxPreemptJob(d, v);
+      if (d.optPre[v] < 255) d.optPre[v]++;                                            // (merged into the round's sets by optEnd)
+      d.preemptedNode[v] = n;
+    }
+    d.jcHasPctx[job] = 1; d.pcNode[job] = n; d.pcSap[job] = cf.pcPriority[d.jPc[job]]; d.pcPap[job] = ASCHED_MIN_PRIORITY; d.pcMethod[job] = ASCHED_METHOD_OPTIMISER;
+    d.jcReason[job] = 0;
+    sctxAddJob(d, job);
+    if (d.optSched[job] < 255) d.optSched[job]++;
+    at += 3 + npre;
+  }
+  reserveN(&d.rs->globalTokens, d.rs->globalBurst, d.rs->globalRateInf, cnt);
+  reserveN(&d.qTokens[q], d.qBurst[q], d.qRateInf[q], cnt);
+}
+// updateState (optimiser/gang_scheduler.go:148-190) for one placed member, tentatively: the victims leave the node, the member is bound — inside the device
+// transaction the host has opened (the reference works on node copies).  What the undo log cannot express — a ghost made or consumed (dev.h optGhost) — is reported
+// to the host, which replays it backwards after the abort (optTentUndo).  ARG: job, node, number of victims, the victims.  cmdIO[0] = the member's old node if it
+// became a ghost there (else -1), cmdIO[1] = number of ghost victims, cmdIO[2..] those victims
+DEV void optTent(Dev& d, Ctl& c) {
+  int job = ARG(0), n = ARG(1), npre = ARG(2), ng = 0;
+  d.cmdIO[0] = -1;
+  if (d.jobNode[job] >= 0 && d.jobNode[job] != n) {
+    if (!d.jobEvictedOnNode[job] || d.optGhost[job] >= 0) { raise(d, ASCHED_ERR_INTERNAL, 300); return; }
+    d.cmdIO[0] = d.jobNode[job];
+    d.optGhost[job] = d.jobNode[job]; d.jobNode[job] = -1; d.jobEvictedOnNode[job] = 0;
+  }
+  for (int i = 0; i < npre; i++) {
+    int v = ARG(3 + i);
+    if (d.optGhost[v] == n) { markAllocatable(d, n, ASCHED_EVICTED_PRIORITY, JREQ(d, v), +1); d.optGhost[v] = -1; d.cmdIO[2 + ng++] = v; }
+    else removeJob(d, n, v, c.txn.active);
+  }
+  d.cmdIO[1] = ng;
+  int32_t prio = bindPriority(d, job, d.cfg.pcPriority[d.jPc[job]]);
+  if (addJob(d, n, job, cutoffFor(d, job, prio), c.txn.active)) return;
+  d.schedAtPrio[job] = prio;                         // (NodeDb.scheduledAtPriorityByJobId: one map for every node copy, not rolled back)
+  updateKeysCtl(d, n);
+}
+// ARG: job, its old node (-1: none), node, number of ghost victims, the victims — after the transaction's abort
+DEV void optTentUndo(Dev& d) {
+  int job = ARG(0), old = ARG(1), n = ARG(2), ng = ARG(3);
+  for (int i = 0; i < ng; i++) { int v = ARG(4 + i); d.optGhost[v] = n; markAllocatable(d, n, ASCHED_EVICTED_PRIORITY, JREQ(d, v), -1); }
+  if (ng) updateKeysCtl(d, n);
+  if (old >= 0) { d.optGhost[job] = -1; d.jobNode[job] = old; d.jobEvictedOnNode[job] = 1; }
+}
+// The optimiser's ScheduledJobs and PreemptedJobs lists merged into the round's sets, scheduled jobs first (pqs.go:232-249): a scheduled job leaves the preempted set or
+// enters the scheduled one; each preemption takes its job out of the scheduled set if it is there ("scheduled and preempted in the same round") and puts it into the
+// preempted set otherwise — so the second preemption of the same job does.
+DEV void optEnd(Dev& d) {
+  int l0 = CTL_WAVE() ? CTL_LANE() : 0, st = CTL_WAVE() ? 64 : 1;
+  for (int j = l0; j < d.cfg.M; j += st) {
+    if (d.optSched[j]) { if (d.inPreempted[j]) d.inPreempted[j] = 0; else d.inScheduled[j] = 1; }
+    int k = d.optPre[j];
+    if (k) {
+      if (d.inScheduled[j]) { d.inScheduled[j] = 0; if (k >= 2) d.inPreempted[j] = 1; }
+      else d.inPreempted[j] = 1;
+    }
+    int g = d.optGhost[j];   // still on its old node as an evicted job: the unbinding of the round's end (pqs.go:775-798, the job is in scheduledAndEvicted) takes it off there
+    if (g >= 0) { atomicMarkAllocatable(d, g, ASCHED_EVICTED_PRIORITY, JREQ(d, j), +1); d.optGhost[j] = -1; }
+  }
+  d.rs->optMode = 0;
+}
+// updateUnfeasibleSchedulingKeys (optimising_queue_scheduler.go:258-277).  ARG: job (a single-job gang), reason.  The registered jctx carries no unschedulable reason
+// (FairnessOptimisingGangScheduler.Schedule returns it without calling jctx.Fail): a later job skipped for this key is added as if scheduled (:398-413) — restated as it is
+DEV void optFail(Dev& d, Ctl& c) {
+  int j = ARG(0), reason = ARG(1);
+  if (!c.skipKeyCheck && isPropertyOfGang(reason) && keyValid(d, j)) {
+    int s = d.jShape[j];
+    if (!d.unfeasible[s]) { d.unfeasible[s] = 1; d.unfeasibleReason[s] = 0; d.rs->numUnfeasible++; }
+  }
+}
+
 DEV void runAuxCommand(Dev& d, Ctl& c, int cmd) {
   const DevCfg& cf = d.cfg;
   switch (cmd) {
@@ -849,6 +1035,13 @@ DEV void runAuxCommand(Dev& d, Ctl& c, int cmd) {
       }
       a.out[a.n] = agrees;
     } break;
+    case CMD_OPT_BEGIN: optBegin(d, c); break;
+    case CMD_OPT_NEXT: { OptLoopArgs a = *(const OptLoopArgs*)(d.cmdIO + 16); optNext(d, c, a); } break;
+    case CMD_OPT_APPLY: optApply(d, c); break;
+    case CMD_OPT_FAIL: optFail(d, c); break;
+    case CMD_OPT_END: optEnd(d); break;
+    case CMD_OPT_TENT: optTent(d, c); break;
+    case CMD_OPT_TENT_UNDO: optTentUndo(d); break;
     case CMD_MARKET: {   // market-driven ordering's iterators (round_market.h)
       MarketArgs a = *(const MarketArgs*)(d.cmdIO + 16);
       if (a.op == 0) marketIterate(a);

@@ -71,6 +71,7 @@ extern "C" {
 #define ASCHED_METHOD_FAIRSHARE 3
 #define ASCHED_METHOD_URGENCY 4
 #define ASCHED_METHOD_AWAY 5
+#define ASCHED_METHOD_OPTIMISER 6 /* ScheduledWithFairnessOptimiser (the experimental fairness optimiser, optimiser/gang_scheduler.go:240) */
 
 /* unschedulable / termination reasons (scheduling/constraints/constraints.go:25-58) */
 #define ASCHED_REASON_NONE 0
@@ -515,6 +516,23 @@ typedef struct asched_opt_node_score { int32_t scheduled; int32_t num_preempted;
 int32_t ASCHED_FN(optimiser_schedule_job)(asched_t*, int32_t job, double min_fairness_improvement_pct, const int64_t* max_job_size_to_preempt,
                                           int64_t now_ms, asched_opt_result* out, int32_t* preempted /*cap*/, int32_t preempted_cap,
                                           asched_opt_node_score* per_node);
+
+/* The experimental fairness optimiser as part of the round (preempting_queue_scheduler.go:224-253, 666-710): after the second pass
+   OptimisingQueueScheduler.Schedule (optimising_queue_scheduler.go:58-180) walks the queued gangs of the queues that are below their fair share in cost
+   order, and FairnessOptimisingGangScheduler.Schedule (optimiser/gang_scheduler.go:45-254) places each one by scoring EVERY node (asched_optimiser_schedule_job's
+   kernel), preempting the cheapest set of running jobs; its scheduled / preempted jobs are merged into the round's result (method ASCHED_METHOD_OPTIMISER).
+   configuration.OptimiserConfig (configuration.go:517-537); NULL or enabled == 0: off (the default).  Applies to the following schedule_round calls.
+   Node-uniformity groups are tried in ascending interned label value and remaining ties go to the earlier node id (the reference draws random ULIDs). */
+typedef struct asched_optimiser_config {
+  uint8_t enabled; uint8_t pad_[7];
+  double min_fairness_improvement_pct;             /* MinimumFairnessImprovementPercentage */
+  int32_t max_jobs_per_round; int32_t pad2_;       /* MaximumJobsPerRound */
+  const int64_t* max_job_size_to_preempt;          /* [R] or NULL; 0 = no limit on that resource (node_scheduler.go:248-268) */
+  const int64_t* min_job_size_to_schedule;         /* [R] or NULL */
+  const double* max_resource_fraction_to_schedule; /* [R] or NULL = +Inf everywhere (MaximumResourceFractionToSchedule) */
+  int64_t now_ms;                                  /* the clock job ages are taken from (asched_optimiser_schedule_job) */
+} asched_optimiser_config;
+int32_t ASCHED_FN(set_optimiser)(asched_t*, const asched_optimiser_config* cfg);
 
 /* 1 if the job's scheduling key is registered in sctx.UnfeasibleSchedulingKeys (gang_scheduler.go:80-95) */
 int32_t ASCHED_FN(job_key_unfeasible)(asched_t*, int32_t job, int32_t* out);

@@ -409,6 +409,18 @@ def Concatenate(*lists):
 def SingleQueuePriorityOne(name): return [Struct("api.Queue", {"Name": name, "PriorityFactor": 1.0})]
 
 
+def createOptimiserConfig(maximum_jobs_per_round, maximum_fraction_to_schedule, minimum_job_size_to_schedule):   # optimising_queue_scheduler_test.go:334-346 (same package as the PQS test)
+    return {"Enabled": True, "MaximumJobsPerRound": int(maximum_jobs_per_round), "MaximumResourceFractionToSchedule": dict(maximum_fraction_to_schedule or {}),
+            "MinimumJobSizeToSchedule": minimum_job_size_to_schedule, "MaximumJobSizeToPreempt": None, "MinimumFairnessImprovementPercentage": 0.0}
+
+
+def WithOptimiserConfig(pool, optimiser_config, config):   # testfixtures.go:328-336: PoolConfig.ExperimentalOptimiser of the named pool
+    config = copy.deepcopy(config)
+    if pool == "testPool":   # (TestSchedulingConfig declares that pool; the PQS driver's scheduling context is for it)
+        config["optimiser"] = optimiser_config
+    return config
+
+
 def WithRoundLimitsPoolConfig(limits, config):
     config = copy.deepcopy(config)
     config["maximum_resource_fraction_to_schedule_by_pool"] = {k: dict(v) for k, v in limits.items()}
@@ -429,6 +441,7 @@ def make_env():
     env["testfixtures.TestNodeFactory.AddTaints"] = AddTaints
     env["testfixtures.TestPool"] = "testPool"
     env["testfixtures.TestQueue"] = "testQueue"
+    env["createOptimiserConfig"] = createOptimiserConfig
     env["append"] = go_append
     c = TestSchedulingConfig()
     c["prefer_large_job_ordering"] = False

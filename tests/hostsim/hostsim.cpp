@@ -192,15 +192,20 @@ static int plat_run_fit_batch(Dev& d, const std::vector<int32_t>& shapes, int le
   return 0;
 }
 // fairness optimiser: the per-node routine of round_opt.h over all nodes, serially
+static const double* g_lastQCost = nullptr;
+static int plat_opt_qcosts(Dev&, double* out, int Q) { for (int q = 0; q < Q; q++) out[q] = g_lastQCost[q]; return 0; }
 static int plat_opt_score(Dev& dev, const OptArgs& a, std::vector<OptNodeOut>& scores, double* jobCost, int detailNode, OptNodeOut* detail, int32_t* pre, bool detailOnly = false) { (void)detailOnly;
   Dev d = dev;
   int N = d.cfg.N, M = d.cfg.M, Q = d.cfg.Q;
-  std::vector<int32_t> off(N + 2, 0), jobs(std::max(M, 1));
-  for (int j = 0; j < M; j++) if (d.jobNode[j] >= 0) off[d.jobNode[j] + 1]++;
+  std::vector<int32_t> off(N + 2, 0), jobs(2 * (size_t)std::max(M, 1));
+  auto ghost = [&](int j) { return d.rs->optMode ? d.optGhost[j] : -1; };   // (dev.h optGhost)
+  for (int j = 0; j < M; j++) { if (d.jobNode[j] >= 0) off[d.jobNode[j] + 1]++; if (ghost(j) >= 0) off[ghost(j) + 1]++; }
   for (int n = 0; n < N; n++) off[n + 1] += off[n];
-  { std::vector<int32_t> cur(off.begin(), off.end()); for (int j = 0; j < M; j++) if (d.jobNode[j] >= 0) jobs[cur[d.jobNode[j]]++] = j; }
-  std::vector<double> qCost(Q + 1);
-  for (int q = 0; q < Q; q++) { int64_t v[MAXR]; for (int r = 0; r < MAXR; r++) v[r] = r < d.cfg.R ? QV(d.qAlloc, q)[r] + QV(d.qPenalty, q)[r] : 0; qCost[q] = drf(d, v); }
+  { std::vector<int32_t> cur(off.begin(), off.end()); for (int j = 0; j < M; j++) { if (d.jobNode[j] >= 0) jobs[cur[d.jobNode[j]]++] = j; if (ghost(j) >= 0) jobs[cur[ghost(j)]++] = j; } }
+  static std::vector<double> qCost;
+  qCost.assign(Q + 1, 0.0);
+  for (int q = 0; q < Q; q++) { int64_t v[MAXR]; for (int r = 0; r < MAXR; r++) v[r] = r < d.cfg.R ? QV(d.qAlloc, q)[r] + QV(d.qPenalty, q)[r] : 0; qCost[q] = d.optQDelta ? d.optQDelta[q] : drf(d, v); }
+  g_lastQCost = qCost.data();
   *jobCost = drf(d, JREQ(d, a.job));
   scores.resize(N);
   for (int n = 0; n < N; n++) optScoreNode(d, a, qCost.data(), off.data(), jobs.data(), d.jLeaseMs, n, &scores[n], nullptr);

@@ -300,6 +300,16 @@ def run_pqs_case(lib: Library, case: dict):
                         pc_resource_limit_fraction=c.pc_limits(queues),
                         global_tokens=glim.tokens, global_burst=glim.burst, global_rate_inf=glim.rate_inf,
                         queue_tokens=[t.tokens for t in qlim], queue_burst=[t.burst for t in qlim], queue_rate_inf=[t.rate_inf for t in qlim])
+        # the experimental fairness optimiser runs in the rounds the table marks (pqs_test.go:236, 2330-2346: optimiserEnabled of NewPreemptingQueueScheduler)
+        oc = cfg.get("optimiser")
+        if oc and rnd.get("OptimiserEnabled"):
+            def rl(v):   # armadaresource.ComputeResources -> factory vector (FromJobResourceListIgnoreUnknown)
+                return None if v is None else vec(v)
+            s.set_optimiser(True, min_improvement_pct=oc.get("MinimumFairnessImprovementPercentage", 0.0), max_jobs_per_round=oc["MaximumJobsPerRound"],
+                            max_job_size_to_preempt=rl(oc.get("MaximumJobSizeToPreempt")), min_job_size_to_schedule=rl(oc.get("MinimumJobSizeToSchedule")),
+                            max_resource_fraction_to_schedule=[float(inf(oc.get("MaximumResourceFractionToSchedule", {}).get(r, "inf"))) for r in RES], now_ms=0)
+        else:
+            s.set_optimiser(False)
         res = s.schedule_round()
         note_stats(s)
         glim.tokens = res.global_tokens_after

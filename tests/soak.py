@@ -5,6 +5,7 @@
     python tests/soak.py streams 1000        # medium rounds (<= 1500 nodes, <= 20000 jobs) dominated by stream runs and gangs through the ring; HS_STREAM_EAGER=1: a run wherever one can start
     python tests/soak.py preempt 1500       # small crowded rounds (60-100 % occupied), most with a fair-share preemption rate limit: the jobs that need preemption stay in the fast loop (fastPreemptIter)
     python tests/soak.py offgrid 3000       # ONE node type with requests and / or allocatable off the index grid (fast structure on next to literal iteration; narrow order-key layout), crowded, some with the default indexedResources
+    python tests/soak.py optimiser 2000     # rounds with the experimental fairness optimiser on (asched_set_optimiser), incl. gangs only it can place
     python tests/soak.py away 1500          # crowded rounds with a third of the running jobs cross-pool away jobs and "<queue>-away" contexts (tests/test_z_cross_pool_away.py)
     python tests/soak.py features 400       # tests/test_z_feature_mix.py rounds (affinity, conditional away, extra column, limits ...)
     python tests/soak.py ops 3000           # tests/test_z_nodedb_op_sequences.py NodeDb-level operation sequences
@@ -85,6 +86,10 @@ def main():
                 for lib in (orc, hs):
                     s = W.load(lib, wl); W.prepare(s, wl, fairshare_preemption_tokens=fp); res.append(s.schedule_round()); s.close()
                 scenario.assert_same_round(res[0], res[1])
+            elif kind == "optimiser":   # rounds with the experimental fairness optimiser on (tests/test_z_optimiser_round.py): random and gang-placing shapes alternate
+                import test_z_optimiser_round as T
+                u, e_, r_ = T.compare(hs, orc, [seed], case=T._gang_case if seed % 2 else None)
+                assert r_ == 0, "refused"
             elif kind == "streams":   # medium rounds that spend most of their time in stream runs / the gang ring (HS_STREAM_EAGER=1 python tests/soak.py streams N: a run wherever one can start)
                 rng = np.random.default_rng(seed)
                 nn, nj, nq = int(rng.integers(100, 1500)), int(rng.integers(2000, 20000)), int(rng.integers(2, 40))
