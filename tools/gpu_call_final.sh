@@ -19,7 +19,7 @@ prof config2_headline
 prof config3_gangs --gangs 10000
 prof config4_reduced --nodes 20000 --jobs 200000 --queues 32 --occupied 0.95
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof_config1" -- python -c "
-import sys; sys.path.insert(0, '$PWD'); sys.argv=['bench.py']
+import sys; sys.path.insert(0, '$OLDPWD'); sys.argv=['bench.py']
 import bench, argparse, torch, armada_amd
 a = argparse.Namespace(other_scale=1.0, steps=10, cpu_budget=0)
 print(bench.fit_batch_record(armada_amd.load_library(), a)['device_ms'])" > "$OLDPWD/$OUT/prof_config1.log" 2>&1 )
