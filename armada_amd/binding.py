@@ -147,6 +147,14 @@ class COptimiserConfig(C.Structure):
                 ("max_resource_fraction_to_schedule", C.POINTER(C.c_double)), ("now_ms", C.c_int64)]
 
 
+class CGlobalKeyLayout(C.Structure):
+    _fields_ = [("n_fields", C.c_int32), ("field_bits", C.c_int32 * 6), ("rank_bits", C.c_int32), ("global_rank", C.POINTER(C.c_int32)), ("rank_offset", C.c_int64)]
+
+
+class CDeltaSummary(C.Structure):
+    _fields_ = [("conflict_nodes", C.c_int32), ("accepted", C.c_int32), ("replay", C.c_int32), ("preempted", C.c_int32)]
+
+
 class COptNodeScore(C.Structure):
     _fields_ = [("scheduled", C.c_int32), ("num_preempted", C.c_int32), ("scheduling_cost", C.c_double), ("maximum_queue_impact", C.c_double)]
 
@@ -193,6 +201,7 @@ ALL_SYMBOLS = [
     "clear_allocated", "submit_check", "pq_order", "submit_stats", "num_nodes", "total_resources", "node_types_matching_job", "scheduling_order",
     "optimiser_schedule_job", "set_optimiser", "set_label_value_ints", "round_timing", "set_deadline", "cancel", "cancel_clear", "indexed_node_label_values", "get_node_jobs", "get_nodes_alloc", "node_upsert",
     "market_iterate", "market_compare", "market_multi_iterate",
+    "fit_select_batch_global", "round_delta_words", "round_delta", "round_delta_resolve",
 ]
 
 
@@ -304,6 +313,10 @@ class Library:
         f("get_scheduled_at_priority", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _i32p])
         f("iterate_nodes", C.c_int32, [C.c_void_p, _i64p, C.c_int32, C.c_int32, _i64p, _i32p, C.c_int32, _i32p])
         f("fit_select_batch", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int32, _i32p])
+        f("fit_select_batch_global", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int32, C.POINTER(CGlobalKeyLayout), C.c_void_p])
+        f("round_delta_words", C.c_int32, [C.c_void_p, _i64p])
+        f("round_delta", C.c_int32, [C.c_void_p, C.c_void_p])
+        f("round_delta_resolve", C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(CDeltaSummary), _i32p, _i32p, _u8p])
         f("drf_cost", C.c_double, [C.c_void_p, _i64p, _i64p])
         f("fair_shares", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _f64p, _f64p, _f64p, _f64p, _f64p])
         f("round_prepare", C.c_int32, [C.c_void_p, C.POINTER(CQueues)])
@@ -798,6 +811,35 @@ class Scheduler:
         out = np.full(len(ja), -1, dtype=np.int32)
         self._check(self.lib.fit_select_batch(self.h, len(ja), _ptr(ja, C.c_int32), priority, _ptr(out, C.c_int32)))
         return out
+
+    # ---- one pool on several GPUs (include/armada_sched.h): buffers are raw addresses — a torch tensor's data_ptr() on the handle's GPU (the collective then
+    # reduces that tensor in place) or a numpy array's ctypes.data
+    def fit_select_batch_global(self, jobs: Sequence[int], priority: int, field_bits: Sequence[int], rank_bits: int, out_ptr: int, *, rank_offset: int = 0, global_rank=None):
+        ja = _arr(jobs, np.int32)
+        lay = CGlobalKeyLayout()
+        lay.n_fields = len(field_bits)
+        for i, b in enumerate(field_bits):
+            lay.field_bits[i] = int(b)
+        lay.rank_bits, lay.rank_offset = int(rank_bits), int(rank_offset)
+        gr = None if global_rank is None else _arr(global_rank, np.int32)
+        lay.global_rank = _ptr(gr, C.c_int32) if gr is not None else None
+        self._check(self.lib.fit_select_batch_global(self.h, len(ja), _ptr(ja, C.c_int32), priority, C.byref(lay), C.c_void_p(int(out_ptr))))
+
+    def round_delta_words(self) -> int:
+        n = C.c_int64(0)
+        self._check(self.lib.round_delta_words(self.h, C.byref(n)))
+        return int(n.value)
+
+    def round_delta(self, buf_ptr: int):
+        self._check(self.lib.round_delta(self.h, C.c_void_p(int(buf_ptr))))
+
+    def round_delta_resolve(self, reduced_ptr: int):
+        """-> (summary dict, job_node int32[M], job_priority int32[M], job_replay uint8[M])"""
+        m = self.num_jobs
+        node, prio, rp = np.empty(max(m, 1), dtype=np.int32), np.empty(max(m, 1), dtype=np.int32), np.empty(max(m, 1), dtype=np.uint8)
+        sm = CDeltaSummary()
+        self._check(self.lib.round_delta_resolve(self.h, C.c_void_p(int(reduced_ptr)), C.byref(sm), _ptr(node, C.c_int32), _ptr(prio, C.c_int32), _ptr(rp, C.c_uint8)))
+        return dict(conflict_nodes=sm.conflict_nodes, accepted=sm.accepted, replay=sm.replay, preempted=sm.preempted), node[:m], prio[:m], rp[:m]
 
     def drf_cost(self, alloc, total) -> float:
         a, t = _arr(alloc, np.int64), _arr(total, np.int64)

@@ -1997,6 +1997,82 @@ static int plat_run_fit_batch(Dev& d, const std::vector<int32_t>& shapes, int le
   for (int i = 0; i < ns; i++) out[i] = keys[i] == ~0ull ? -1 : nodeByRank[keys[i] & mask];
   return 0;
 }
+// ---- one pool on several GPUs: the kernels live in armada_sched_mgpu.hip (their own code object)
+#include "mgpu.h"
+extern "C" int asched_internal_mgpu_pack(const Dev* d, const GlobalKeyLayout* L, int level, const unsigned long long* keys, const int32_t* slot, int nq, long long* out, int32_t* bad, hipStream_t s);
+extern "C" int asched_internal_mgpu_delta(const Dev* d, long long* buf, int ns, int np, hipStream_t s);
+extern "C" int asched_internal_mgpu_resolve(const Dev* d, const long long* red, long long* freeC, uint8_t* ownPre, uint8_t* conflict, uint8_t* gangReplay,
+                                            int32_t* node, int32_t* prio, uint8_t* replay, int32_t* counts, int ns, int np, hipStream_t s);
+// a caller-side buffer may be memory of this handle's GPU (a tensor the collective reduces in place: used directly) or host memory (staged)
+static bool plat_is_device_ptr(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeDevice && a.device == t_ctx->device;
+}
+static int plat_run_fit_batch_global(Dev& d, const std::vector<int32_t>& shapes, const std::vector<int32_t>& slot, int level, GlobalKeyLayout L, const int32_t* globalRank, long long* out, int* badOut) {
+  int ns = (int)shapes.size(), nq = (int)slot.size();
+  bool direct = plat_is_device_ptr(out);
+  int32_t *dShapes = nullptr, *dSlot = nullptr, *dRank = nullptr, *dBad = nullptr; unsigned long long* dKeys = nullptr; long long* dWords = direct ? out : nullptr;
+  bool ok = hipOk(hipMalloc(&dShapes, ns * sizeof(int32_t)), "hipMalloc") && hipOk(hipMalloc(&dKeys, ns * sizeof(unsigned long long)), "hipMalloc") &&
+            hipOk(hipMalloc(&dSlot, nq * sizeof(int32_t)), "hipMalloc") && hipOk(hipMalloc(&dBad, sizeof(int32_t)), "hipMalloc") &&
+            (direct || hipOk(hipMalloc(&dWords, nq * sizeof(long long)), "hipMalloc")) && (!globalRank || hipOk(hipMalloc(&dRank, std::max(d.cfg.N, 1) * sizeof(int32_t)), "hipMalloc"));
+  if (ok) {
+    hipStream_t st = t_ctx->stream;
+    (void)hipMemcpyAsync(dShapes, shapes.data(), ns * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(dSlot, slot.data(), nq * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    if (globalRank) (void)hipMemcpyAsync(dRank, globalRank, d.cfg.N * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    (void)hipMemsetAsync(dKeys, 0xff, ns * sizeof(unsigned long long), st);
+    (void)hipMemsetAsync(dBad, 0, sizeof(int32_t), st);
+    L.globalRank = dRank;
+    int tiles = (d.cfg.N + FIT_TILE - 1) / FIT_TILE;
+    int ysplit = std::max(1, std::min(ns, (2048 + tiles - 1) / tiles));
+    (void)hipEventRecord(t_ctx->fitEv0, st);
+    if (d.cfg.N > 0) hipLaunchKernelGGL(k_fit_batch, dim3(tiles, ysplit), dim3(FIT_TILE), 0, st, d, dShapes, ns, level, dKeys);
+    ok = asched_internal_mgpu_pack(&d, &L, level, dKeys, dSlot, nq, dWords, dBad, st) == 0;
+    (void)hipEventRecord(t_ctx->fitEv1, st);
+    ok = ok && hipOk(hipGetLastError(), "fit_select_batch_global launch") && hipOk(hipStreamSynchronize(st), "fit_select_batch_global");
+    (void)hipEventElapsedTime(&t_ctx->lastFitMs, t_ctx->fitEv0, t_ctx->fitEv1);
+    int32_t bad = 0;
+    if (ok) ok = hipOk(hipMemcpy(&bad, dBad, sizeof bad, hipMemcpyDeviceToHost), "hipMemcpy");
+    if (ok && !direct) ok = hipOk(hipMemcpy(out, dWords, nq * sizeof(long long), hipMemcpyDeviceToHost), "hipMemcpy");
+    *badOut = bad;
+  }
+  (void)hipFree(dShapes); (void)hipFree(dKeys); (void)hipFree(dSlot); (void)hipFree(dBad); (void)hipFree(dRank); if (!direct) (void)hipFree(dWords);
+  return ok ? 0 : -1;
+}
+static int plat_round_delta(Dev& d, int ns, int np, long long* buf) {
+  size_t words = (size_t)d.cfg.N * d.cfg.R + d.cfg.M;
+  bool direct = plat_is_device_ptr(buf);
+  long long* dBuf = direct ? buf : nullptr;
+  if (!direct && !hipOk(hipMalloc(&dBuf, std::max<size_t>(words, 1) * 8), "hipMalloc")) return -1;
+  hipStream_t st = t_ctx->stream;
+  bool ok = hipOk(hipMemsetAsync(dBuf, 0, words * 8, st), "hipMemsetAsync") && asched_internal_mgpu_delta(&d, dBuf, ns, np, st) == 0 && hipOk(hipStreamSynchronize(st), "round_delta");
+  if (ok && !direct) ok = hipOk(hipMemcpy(buf, dBuf, words * 8, hipMemcpyDeviceToHost), "hipMemcpy");
+  if (!direct) (void)hipFree(dBuf);
+  return ok ? 0 : -1;
+}
+static int plat_delta_resolve(Dev& d, const long long* red, int ns, int np, int32_t* counts, int32_t* node, int32_t* prio, uint8_t* replay) {
+  int N = d.cfg.N, M = d.cfg.M, R = d.cfg.R, G = std::max(d.cfg.G, 1);
+  size_t words = (size_t)N * R + M;
+  bool direct = plat_is_device_ptr(red);
+  long long *dRed = nullptr, *freeC = nullptr; uint8_t* bytes = nullptr; int32_t* ints = nullptr;
+  size_t nb = (size_t)M + N + G + M, ni = 4 + 2 * (size_t)M;   // ownPre | conflict | gangReplay | replay ; counts | node | prio
+  bool ok = (direct || hipOk(hipMalloc(&dRed, std::max<size_t>(words, 1) * 8), "hipMalloc")) && hipOk(hipMalloc(&freeC, std::max<size_t>((size_t)N * R, 1) * 8), "hipMalloc") &&
+            hipOk(hipMalloc(&bytes, nb), "hipMalloc") && hipOk(hipMalloc(&ints, ni * 4), "hipMalloc");
+  if (ok) {
+    hipStream_t st = t_ctx->stream;
+    if (!direct) (void)hipMemcpyAsync(dRed, red, words * 8, hipMemcpyHostToDevice, st);
+    (void)hipMemsetAsync(bytes, 0, nb, st); (void)hipMemsetAsync(ints, 0, 16, st);
+    uint8_t *ownPre = bytes, *conflict = bytes + M, *gangReplay = conflict + N, *rp = gangReplay + G;
+    ok = asched_internal_mgpu_resolve(&d, direct ? red : dRed, freeC, ownPre, conflict, gangReplay, ints + 4, ints + 4 + M, rp, ints, ns, np, st) == 0 && hipOk(hipStreamSynchronize(st), "round_delta_resolve");
+    if (ok) ok = hipOk(hipMemcpy(counts, ints, 16, hipMemcpyDeviceToHost), "hipMemcpy");
+    if (ok && M) ok = hipOk(hipMemcpy(node, ints + 4, (size_t)M * 4, hipMemcpyDeviceToHost), "hipMemcpy") && hipOk(hipMemcpy(prio, ints + 4 + M, (size_t)M * 4, hipMemcpyDeviceToHost), "hipMemcpy") &&
+                     hipOk(hipMemcpy(replay, rp, M, hipMemcpyDeviceToHost), "hipMemcpy");
+  }
+  if (!direct) (void)hipFree(dRed);
+  (void)hipFree(freeC); (void)hipFree(bytes); (void)hipFree(ints);
+  return ok ? 0 : -1;
+}
 static int plat_run_drf(Dev& dev, const std::vector<int64_t>& a, const std::vector<int64_t>& t, double* out) {
   Dev d = dev;
   for (int r = 0; r < d.cfg.R; r++) d.cfg.totalResources[r] = t[r];

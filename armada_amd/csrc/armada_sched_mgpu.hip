@@ -1,0 +1,71 @@
+// armada_sched_mgpu.hip — third translation unit of libarmada_sched.so: the grid kernels that produce and consume the words of the
+// multi-GPU exchanges: one element per thread over queries / result rows / nodes / jobs, all plain coalesced streaming
+// (the per-element logic is mgpu.h, shared with the CPU build of the tests).  A separate code object so that nothing here moves the
+// round kernel's code (k_control is placement-sensitive: DESIGN.md 9).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#define MGPU_FN __device__ static inline
+#define MGPU_ADD64(p, v) atomicAdd((unsigned long long*)(p), (unsigned long long)(v))
+#define MGPU_ADD32(p, v) atomicAdd((int*)(p), (int)(v))
+#define MGPU_OR8(p) (*(volatile uint8_t*)(p) = 1)   // every writer stores the same value
+#include "mgpu.h"
+
+#define MG_THREADS 256
+static inline int mgBlocks(long long n) { return (int)((n + MG_THREADS - 1) / MG_THREADS); }
+#define MG_IDX() ((long long)blockIdx.x * MG_THREADS + threadIdx.x)
+
+__global__ __launch_bounds__(MG_THREADS) void k_mgpu_pack(Dev d, GlobalKeyLayout L, int level, const unsigned long long* keys, const int32_t* slot, int nq, long long* out, int32_t* bad) {
+  long long i = MG_IDX();
+  if (i < nq) out[i] = mgpuPackQuery(d, L, level, keys[slot[i]], bad);
+}
+__global__ __launch_bounds__(MG_THREADS) void k_mgpu_delta(Dev d, long long* buf, int ns, int np) {
+  long long i = MG_IDX();
+  if (i < ns) mgpuDeltaScheduled(d, buf, (int)i);
+  else if (i < (long long)ns + np) mgpuDeltaPreempted(d, buf, (int)(i - ns));
+}
+__global__ __launch_bounds__(MG_THREADS) void k_mgpu_free_init(Dev d, long long* freeC) {
+  long long n = MG_IDX();
+  if (n < d.cfg.N) mgpuFreeInit(d, freeC, (int)n);
+}
+__global__ __launch_bounds__(MG_THREADS) void k_mgpu_own(Dev d, long long* freeC, uint8_t* ownPre, int ns, int np) {
+  long long i = MG_IDX();
+  if (i < ns) mgpuFreeOwnScheduled(d, freeC, (int)i);
+  else if (i < (long long)ns + np) mgpuOwnPreempted(d, ownPre, (int)(i - ns));
+}
+__global__ __launch_bounds__(MG_THREADS) void k_mgpu_foreign(Dev d, const long long* red, const uint8_t* ownPre, long long* freeC) {
+  long long j = MG_IDX();
+  if (j < d.cfg.M) mgpuFreeForeignPreempted(d, red, ownPre, freeC, (int)j);
+}
+__global__ __launch_bounds__(MG_THREADS) void k_mgpu_conflict(Dev d, const long long* red, const long long* freeC, uint8_t* conflict, int32_t* counts) {
+  long long n = MG_IDX();
+  if (n < d.cfg.N) mgpuConflict(d, red, freeC, conflict, counts, (int)n);
+}
+__global__ __launch_bounds__(MG_THREADS) void k_mgpu_gang(Dev d, const long long* red, const uint8_t* conflict, uint8_t* gangReplay) {
+  long long j = MG_IDX();
+  if (j < d.cfg.M) mgpuGangConflict(d, red, conflict, gangReplay, (int)j);
+}
+__global__ __launch_bounds__(MG_THREADS) void k_mgpu_outcome(Dev d, const long long* red, const uint8_t* conflict, const uint8_t* gangReplay, int32_t* node, int32_t* prio, uint8_t* replay, int32_t* counts) {
+  long long j = MG_IDX();
+  if (j < d.cfg.M) mgpuJobOutcome(d, red, conflict, gangReplay, node, prio, replay, counts, (int)j);
+}
+
+extern "C" int asched_internal_mgpu_pack(const Dev* d, const GlobalKeyLayout* L, int level, const unsigned long long* keys, const int32_t* slot, int nq, long long* out, int32_t* bad, hipStream_t s) {
+  if (nq > 0) hipLaunchKernelGGL(k_mgpu_pack, dim3(mgBlocks(nq)), dim3(MG_THREADS), 0, s, *d, *L, level, keys, slot, nq, out, bad);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+extern "C" int asched_internal_mgpu_delta(const Dev* d, long long* buf, int ns, int np, hipStream_t s) {
+  if (ns + np > 0) hipLaunchKernelGGL(k_mgpu_delta, dim3(mgBlocks((long long)ns + np)), dim3(MG_THREADS), 0, s, *d, buf, ns, np);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+// freeC [N*R], ownPre [M], conflict [N], gangReplay [max(G,1)], counts [4]: zeroed by the caller
+extern "C" int asched_internal_mgpu_resolve(const Dev* d, const long long* red, long long* freeC, uint8_t* ownPre, uint8_t* conflict, uint8_t* gangReplay,
+                                            int32_t* node, int32_t* prio, uint8_t* replay, int32_t* counts, int ns, int np, hipStream_t s) {
+  int N = d->cfg.N, M = d->cfg.M;
+  if (N > 0) hipLaunchKernelGGL(k_mgpu_free_init, dim3(mgBlocks(N)), dim3(MG_THREADS), 0, s, *d, freeC);
+  if (ns + np > 0) hipLaunchKernelGGL(k_mgpu_own, dim3(mgBlocks((long long)ns + np)), dim3(MG_THREADS), 0, s, *d, freeC, ownPre, ns, np);
+  if (M > 0) hipLaunchKernelGGL(k_mgpu_foreign, dim3(mgBlocks(M)), dim3(MG_THREADS), 0, s, *d, red, ownPre, freeC);
+  if (N > 0) hipLaunchKernelGGL(k_mgpu_conflict, dim3(mgBlocks(N)), dim3(MG_THREADS), 0, s, *d, red, freeC, conflict, counts);
+  if (M > 0) hipLaunchKernelGGL(k_mgpu_gang, dim3(mgBlocks(M)), dim3(MG_THREADS), 0, s, *d, red, conflict, gangReplay);
+  if (M > 0) hipLaunchKernelGGL(k_mgpu_outcome, dim3(mgBlocks(M)), dim3(MG_THREADS), 0, s, *d, red, conflict, gangReplay, node, prio, replay, counts);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}

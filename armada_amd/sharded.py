@@ -10,8 +10,9 @@ bind locally; the operations served here do not bind:
   * submit check, individual units — SubmitChecker on a pristine NodeDb (submitcheck.go:272-290): the same question per scheduling key.
 
 Each rank owns an ordinary library handle over ITS rows (asched_nodes_upsert of the shard, running jobs of other shards masked out), answers the
-whole query batch against them with one k_fit_batch launch, and packs (order key, global row) per query; `torch.distributed.all_reduce(MIN)`
-(backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU tests) folds the shards.  Traffic: 8 bytes per query per rank — latency
+whole query batch against them with one k_fit_batch launch, and the library packs (order key in the layout all shards share, global rank) per query ON THE
+DEVICE into a buffer the caller owns (asched_fit_select_batch_global: armada_sched_mgpu.hip k_mgpu_pack); `torch.distributed.all_reduce(MIN)` on that
+tensor, in place (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" on host memory in the CPU tests), folds the shards.  Traffic: 8 bytes per query per rank — latency
 bound, which is why it is only used for batched passes.  The sequential round (every placement reads what all earlier placements wrote) does
 not shard this way without a collective per job; pools remain the unit of parallelism for rounds (multipool.py).
 """
@@ -25,7 +26,7 @@ import numpy as np
 from . import workloads as W
 from .binding import EVICTED_PRIORITY, Scheduler
 
-_NONE = np.int64(2 ** 62)
+NO_NODE_WORD = np.int64(2 ** 63 - 1)   # ASCHED_NO_NODE_WORD
 
 
 def shard_bounds(n_nodes: int, world: int):
@@ -72,39 +73,25 @@ class ShardedFit:
         """bind the running jobs of this shard (populateNodeDb); the queue side is not needed for read-only queries"""
         W.prepare(self.s, self.local)
 
-    def _reduce_min(self, keys: np.ndarray) -> np.ndarray:
-        if self.dist is None or self.world == 1:
-            return keys
+    def _word_buffer(self, n: int):
+        """the int64 tensor the library fills and the collective reduces IN PLACE: on the handle's GPU when there is one (RCCL), on the host otherwise (gloo)"""
         import torch
-        t = torch.from_numpy(keys.copy())
-        if self.device:
-            t = t.to(self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
-        return t.cpu().numpy()
-
-    def _pack(self, local_nodes: np.ndarray, level: int) -> np.ndarray:
-        """(rounded allocatable on the indexed columns at `level`, GLOBAL row) as one int64 per query; -1 (no node in this shard) -> +inf"""
-        keys = np.full(len(local_nodes), _NONE, dtype=np.int64)
-        hit = np.nonzero(local_nodes >= 0)[0]
-        if len(hit):
-            uniq, inv = np.unique(local_nodes[hit], return_inverse=True)
-            alloc = self.s.get_nodes_alloc(uniq.astype(np.int32))[:, level, :]          # [u][R]
-            k = np.zeros(len(uniq), dtype=np.int64)
-            for c, r, w in zip(self.idx_col, self.idx_res, self.width):
-                f = alloc[:, c] // r
-                assert (f >= 0).all() and (f < (1 << w)).all()
-                k = (k << w) | f
-            k = (k << self.row_bits) | (uniq.astype(np.int64) + self.lo)
-            keys[hit] = k[inv]
-        return keys
+        return torch.empty(max(n, 1), dtype=torch.int64, device=self.device or "cpu")
 
     def fit_select_batch(self, jobs: Sequence[int], priority: int = EVICTED_PRIORITY) -> np.ndarray:
-        """first feasible node (GLOBAL row, -1 = none) per job at `priority` against the current state — collective"""
-        level = self.s.priorities.index(priority)
-        local = self.s.fit_select_batch(np.asarray(jobs, dtype=np.int32), priority)
-        best = self._reduce_min(self._pack(local, level))
+        """first feasible node (GLOBAL row, -1 = none) per job at `priority` against the current state — collective.
+
+        The library runs k_fit_batch over this shard's rows and packs, on the device, one word per query that orders like the reference's index key with the
+        field widths all shards share (asched_fit_select_batch_global); ONE all_reduce(MIN) over that buffer folds the shards; the low bits of the winning
+        word are the node's global rank (= its row: shards are contiguous row ranges in index order)."""
+        n = len(jobs)
+        t = self._word_buffer(n)
+        self.s.fit_select_batch_global(np.asarray(jobs, dtype=np.int32), priority, self.width, self.row_bits, t.data_ptr(), rank_offset=self.lo)
+        if self.dist is not None and self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        best = t[:n].cpu().numpy()
         out = (best & ((1 << self.row_bits) - 1)).astype(np.int32)
-        out[best == _NONE] = -1
+        out[best == NO_NODE_WORD] = -1
         return out
 
     def close(self):

@@ -427,6 +427,86 @@ def other_configs(hip, args, t_start):
     return recs
 
 
+def single_pool_mode_record(hip, args, rank, local_rank, world, dist, torch):
+    """--mode node-sharded-fit / queue-hash: ONE pool on `world` GPUs.  Same timing contract as the pools line: W untimed steps, then exactly K steps
+    between barrier + synchronize, MAX over ranks.  Total work is fixed as N grows (strong scaling).  No scaling curve has been measured by this repository: the
+    8-GPU runs are the driver's, and it runs the default (pools) mode."""
+    import numpy as np
+    from armada_amd import workloads as W
+    device = "cuda"   # the exchange buffers live on the GPU: the library writes / reads them in place (also at N = 1, where the collective is skipped)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def tmax(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64",
+            "data": "synthetic", "mode": args.mode,
+            "scaling_note": "one pool on N GPUs; no scaling curve has been measured by this repository (the driver's SCALE runs use the default pools mode)"}
+    if args.mode == "node-sharded-fit":
+        from armada_amd.sharded import ShardedFit
+        n_nodes, n_jobs = (10_000, 100_000) if args.nodes == 100_000 and args.jobs == 1_000_000 else (args.nodes, args.jobs)   # BASELINE configs[1] unless sizes are given
+        wl = W.config2(n_nodes=n_nodes, n_jobs=n_jobs)
+        wl.config.device = local_rank
+        sf = ShardedFit(hip, wl, rank, world, dist=dist, device=device)
+        sf.prepare()
+        jobs = np.nonzero(wl.job_node < 0)[0].astype(np.int32)
+        prio = sf.s.priorities[0]
+        for _ in range(args.warmup):
+            got = sf.fit_select_batch(jobs, prio)
+        barrier(); t0 = time.perf_counter()
+        for _ in range(args.steps):
+            got = sf.fit_select_batch(jobs, prio)
+        barrier(); dt = tmax(time.perf_counter() - t0)
+        sf.close()
+        parity = None
+        if rank == 0:   # the unsharded library on one GPU answers the same batch: identical node per query
+            s1 = W.load(hip, wl); W.prepare(s1, wl); want = s1.fit_select_batch(jobs, prio); s1.close()
+            parity = {"checked": True, "identical": bool((want == got).all()), "jobs": int(len(jobs)), "against": "the unsharded library on one GPU, node per query"}
+        return dict(base, metric="first-fit queries/s, one pool's nodes partitioned over the GPUs (asched_fit_select_batch_global + one all-reduce MIN per batch)",
+                    value=len(jobs) * args.steps / dt, unit="queries/s", ms_per_step=dt / args.steps * 1e3, parity=parity,
+                    config={"workload": f"BASELINE configs[1] shape: {wl.num_nodes} nodes x {len(jobs)} first-fit queries per step at priority {prio}", "nodes": wl.num_nodes,
+                            "parallelism": f"nodes of one pool in {world} contiguous row shards", "exchange_bytes_per_step_per_rank": int(len(jobs)) * 8})
+    from armada_amd.queuehash import QueueHashRound
+    wl = W.config3(n_nodes=args.nodes, n_jobs=args.jobs, n_queues=args.queues, seed=W.SEED, gangs=args.gangs, occupied=args.occupied)
+    scale = args.jobs / 1_000_000.0
+    if args.jobs != 1_000_000:
+        wl.global_burst, wl.queue_burst = max(1, int(200_000 * scale)), max(1, int(20_000 * scale))
+    wl.config.device = local_rank
+    qh = QueueHashRound(hip, wl, rank, world, dist=dist, device=device)
+    for _ in range(args.warmup):
+        r = qh.run()
+    barrier(); t0 = time.perf_counter()
+    parts = []
+    for _ in range(args.steps):
+        r = qh.run(); parts.append(dict(qh.timing))
+    barrier(); dt = tmax(time.perf_counter() - t0)
+    qh.close()
+    cmp_, exact_ms = None, None
+    if rank == 0:   # the exact round of the same pool on one GPU: what this mode's assignment is measured against
+        s1 = W.load(hip, wl); W.prepare(s1, wl)
+        torch.cuda.synchronize(); t1 = time.perf_counter(); exact = s1.schedule_round(); torch.cuda.synchronize(); exact_ms = (time.perf_counter() - t1) * 1e3
+        s1.close()
+        cmp_ = QueueHashRound.compare(r, exact.scheduled, wl)
+    words = wl.num_nodes * wl.job_req.shape[1] + wl.num_jobs
+    return dict(base, metric="scheduling rounds/sec, ONE pool's queues hashed over the GPUs (approximate: see mismatch_vs_exact_round)", value=args.steps / dt, unit="rounds/s",
+                ms_per_step=dt / args.steps * 1e3, exact_single_gpu_round_ms=exact_ms,
+                phases_ms={k: float(np.mean([p[k] for p in parts])) * 1e3 for k in parts[0]},
+                round={k: (len(r[k]) if isinstance(r[k], (list, dict)) else int(r[k])) for k in ("scheduled", "dropped", "conflicts", "accepted", "replay_set", "replayed", "preempted")},
+                mismatch_vs_exact_round=cmp_, exchange_bytes_per_round_per_rank=words * 8,
+                config={"workload": f"{wl.num_nodes} nodes x {wl.num_queues} queues x {args.jobs} queued jobs (+{wl.num_jobs - args.jobs} running), global burst {wl.global_burst}, queue burst {wl.queue_burst}",
+                        "nodes": wl.num_nodes, "queued_jobs": args.jobs, "queues": wl.num_queues,
+                        "parallelism": f"queue q on rank q mod {world}; one all-reduce SUM of N*R + M int64 words; ordered replay of the conflict set on every rank"})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -446,6 +526,11 @@ def main():
     ap.add_argument("--no-full-other", action="store_true", help="skip the full-size (100k x 1M) run of configs[4] (~40 s); the reduced size with its oracle leg still runs")
     ap.add_argument("--other-scale", type=float, default=1.0, help="scale the other_configs workloads (tests)")
     ap.add_argument("--full-other", action="store_true", help="(default now; kept for older command lines)")
+    ap.add_argument("--mode", choices=["pools", "node-sharded-fit", "queue-hash"], default="pools",
+                    help="what --gpus N > 1 does (DESIGN.md 7): pools = one pool per GPU, exact, no data-path collective (the default and the line the driver records); "
+                         "node-sharded-fit = ONE pool's nodes partitioned over the GPUs for the wide first-fit queries, one all-reduce MIN per batch, exact; "
+                         "queue-hash = the north_star's split of ONE pool's queues over the GPUs with one all-reduce SUM and an ordered replay, approximate: the line "
+                         "reports the mismatch against the exact round")
     args = ap.parse_args()
     if args.submit_check:
         print(json.dumps(submit_check_record(args)))
@@ -467,6 +552,14 @@ def main():
     import armada_amd
     from armada_amd import workloads as W
     hip = armada_amd.load_library()
+
+    if args.mode != "pools":
+        rec = single_pool_mode_record(hip, args, rank, local_rank, world, dist, torch)
+        if rank == 0:
+            print(json.dumps(rec))
+        if dist is not None:
+            dist.destroy_process_group()
+        return 0
 
     # one pool per rank; seeds differ per pool
     from armada_amd.multipool import pool_seed

@@ -388,6 +388,42 @@ int32_t ASCHED_FN(iterate_nodes)(asched_t*, const int64_t* type_ids, int32_t nty
    selectNodeForPodAtPriority calls (nodedb.go:840-879) — BASELINE config 2 ("nodedb fit kernel"). */
 int32_t ASCHED_FN(fit_select_batch)(asched_t*, int32_t n, const int32_t* jobs, int32_t priority, int32_t* out_node);
 
+/* ------------------------------------------------------------------ one pool on several GPUs (no reference counterpart: SURVEY 8e)
+ * The words the collectives reduce are produced and consumed ON THE DEVICE.  A pointer marked "device-accessible" may be memory of the
+ * handle's GPU — e.g. a torch tensor's data_ptr(): the caller runs ncclAllReduce / torch.distributed.all_reduce on that tensor in place
+ * (RCCL over xGMI) — or ordinary host memory (the CPU tests, gloo). */
+#define ASCHED_NO_NODE_WORD INT64_MAX
+/* Node-partitioned exact first fit: rows [lo, hi) of the pool's nodes live in this handle.  fit_select_batch_global answers
+   fit_select_batch and packs, per query, the winning node's ORDER KEY in a layout every shard shares — (floor(allocatable / resolution) on
+   the indexed resources ..., rank of the node's index among ALL nodes of the pool): RoundedNodeIndexKeyFromResourceList (encoding.go:37-54)
+   as one integer — so that all-reduce MIN over the shards IS the reference's "first node in index order that fits"
+   (nodeiteration.go:318-382 across the shards).  No node in this shard: ASCHED_NO_NODE_WORD.  The library's own packed key is sized per
+   handle; the field widths here come from the caller (the GLOBAL maxima), n_fields must equal the number of indexed resources and
+   sum(field_bits) + rank_bits <= 62. */
+typedef struct asched_global_key_layout {
+  int32_t n_fields;
+  int32_t field_bits[6];
+  int32_t rank_bits;
+  const int32_t* global_rank;   /* [N] rank of each local node's index among all nodes of the pool; NULL: rank_offset + the local rank */
+  int64_t rank_offset;
+} asched_global_key_layout;
+int32_t ASCHED_FN(fit_select_batch_global)(asched_t*, int32_t n, const int32_t* jobs, int32_t priority, const asched_global_key_layout* layout,
+                                           int64_t* out_words /* device-accessible [n] */);
+/* The north_star's queue-hash round: queues are split over the ranks, every rank runs schedule_round on a full replica with the queued
+   jobs of ITS queues, then ONE all-reduce SUM of the buffer round_delta fills:
+     buf[node * R + r]   resources this rank's NEWLY scheduled jobs (not running before the round) committed on the node
+     buf[N * R + job]    (node + 1) | (priority level << 28) if this rank newly scheduled the job (at most one rank does: it owns the job's
+                         queue), plus 1 << 32 if this rank preempted the job
+   round_delta_resolve reads the reduced buffer: a node whose summed commitments exceed what is free there once every rank's preemptions are
+   applied is a CONFLICT; new jobs on conflict nodes (and every member of a gang that has one) are not accepted — the caller replays them in
+   global order through the ordinary queue scheduler (schedule_queues) on the accepted state.  Outputs, per job: the node it runs on after
+   the accepted placements and all preemptions (-1: none), the priority it is bound at there, replay flag. */
+typedef struct asched_delta_summary { int32_t conflict_nodes, accepted, replay, preempted; } asched_delta_summary;
+int32_t ASCHED_FN(round_delta_words)(asched_t*, int64_t* n_words);
+int32_t ASCHED_FN(round_delta)(asched_t*, int64_t* buf /* device-accessible [N*R + M] */);
+int32_t ASCHED_FN(round_delta_resolve)(asched_t*, const int64_t* reduced /* device-accessible */, asched_delta_summary* summary,
+                                       int32_t* job_node /*[M]*/, int32_t* job_priority /*[M]*/, uint8_t* job_replay /*[M]*/);
+
 /* ------------------------------------------------------------------ float helpers (goldens) */
 /* DominantResourceFairness.UnweightedCostFromAllocation (fairness/fairness.go:103-105) */
 double ASCHED_FN(drf_cost)(asched_t*, const int64_t* alloc /*[R]*/, const int64_t* total /*[R]*/);

@@ -191,6 +191,35 @@ static int plat_run_fit_batch(Dev& d, const std::vector<int32_t>& shapes, int le
   }
   return 0;
 }
+// one pool on several GPUs (armada_amd/csrc/mgpu.h): the per-element functions of the grid kernels in serial loops
+#include "../../armada_amd/csrc/mgpu.h"
+static int plat_run_fit_batch_global(Dev& d, const std::vector<int32_t>& shapes, const std::vector<int32_t>& slot, int level, GlobalKeyLayout L, const int32_t* globalRank, long long* out, int* badOut) {
+  std::vector<int32_t> node(shapes.size(), -1);
+  if (d.cfg.N > 0) plat_run_fit_batch(d, shapes, level, node);
+  L.globalRank = globalRank;
+  int32_t bad = 0;
+  for (size_t i = 0; i < slot.size(); i++) { int n = node[slot[i]]; out[i] = mgpuPackQuery(d, L, level, n < 0 ? ~0ull : (unsigned long long)d.idxRank[n], &bad); }
+  *badOut = bad;
+  return 0;
+}
+static int plat_round_delta(Dev& d, int ns, int np, long long* buf) {
+  memset(buf, 0, ((size_t)d.cfg.N * d.cfg.R + d.cfg.M) * 8);
+  for (int i = 0; i < ns; i++) mgpuDeltaScheduled(d, buf, i);
+  for (int i = 0; i < np; i++) mgpuDeltaPreempted(d, buf, i);
+  return 0;
+}
+static int plat_delta_resolve(Dev& d, const long long* red, int ns, int np, int32_t* counts, int32_t* node, int32_t* prio, uint8_t* replay) {
+  int N = d.cfg.N, M = d.cfg.M, R = d.cfg.R;
+  std::vector<long long> freeC((size_t)N * R + 1, 0); std::vector<uint8_t> ownPre(M + 1, 0), conflict(N + 1, 0), gangReplay(std::max(d.cfg.G, 1), 0);
+  for (int n = 0; n < N; n++) mgpuFreeInit(d, freeC.data(), n);
+  for (int i = 0; i < ns; i++) mgpuFreeOwnScheduled(d, freeC.data(), i);
+  for (int i = 0; i < np; i++) mgpuOwnPreempted(d, ownPre.data(), i);
+  for (int j = 0; j < M; j++) mgpuFreeForeignPreempted(d, red, ownPre.data(), freeC.data(), j);
+  for (int n = 0; n < N; n++) mgpuConflict(d, red, freeC.data(), conflict.data(), counts, n);
+  for (int j = 0; j < M; j++) mgpuGangConflict(d, red, conflict.data(), gangReplay.data(), j);
+  for (int j = 0; j < M; j++) mgpuJobOutcome(d, red, conflict.data(), gangReplay.data(), node, prio, replay, counts, j);
+  return 0;
+}
 // fairness optimiser: the per-node routine of round_opt.h over all nodes, serially
 static const double* g_lastQCost = nullptr;
 static int plat_opt_qcosts(Dev&, double* out, int Q) { for (int q = 0; q < Q; q++) out[q] = g_lastQCost[q]; return 0; }

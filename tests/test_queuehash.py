@@ -26,11 +26,22 @@ out = {}
 for name, kw in (("uncrowded", dict(occupied=0.3)), ("crowded", dict(occupied=0.85))):
     wl = W.config3(n_nodes=600, n_jobs=8000, n_queues=12, seed=11, **kw)
     wl.global_burst, wl.queue_burst = 3000, 600
+    o = W.load(oracle, wl); W.prepare(o, wl); exact = o.schedule_round(); o.close()
+    qh0 = QueueHashRound(lib, wl, rank, world, dist=dist, replay=False)
+    r0 = qh0.run(); qh0.close()
     qh = QueueHashRound(lib, wl, rank, world, dist=dist)
     r = qh.run()
     qh.close()
-    o = W.load(oracle, wl); W.prepare(o, wl); exact = o.schedule_round(); o.close()
     r["compare"] = QueueHashRound.compare(r, exact.scheduled, wl)
+    r["compare_without_replay"] = QueueHashRound.compare(r0, exact.scheduled, wl)
+    # feasible: running jobs that were not preempted + everything scheduled fits every node
+    cap = wl.node_total if wl.node_allocatable is None else wl.node_allocatable
+    base = np.zeros_like(cap)
+    keep = np.nonzero(wl.job_node >= 0)[0]
+    keep = keep[~np.isin(keep, np.asarray(r["preempted"], dtype=np.int64))]
+    np.add.at(base, wl.job_node[keep], wl.job_req[keep])
+    r["feasible"] = bool(((base + r.pop("committed")) <= cap).all())
+    r0.pop("committed")
     digest = sorted(r["scheduled"].items())
     t = torch.tensor([hash(json.dumps(digest)) %% (1 << 40)], dtype=torch.int64)
     lo, hi = t.clone(), t.clone()
@@ -59,7 +70,7 @@ def test_one_rank_is_the_exact_round(tmp_path, hostsim_lib, oracle_lib):
     res = _run(tmp_path, 1, 29741)
     for name, r in res.items():
         c = r["compare"]
-        assert r["conflicts"] == 0 and r["dropped"] == 0
+        assert r["conflicts"] == 0 and r["dropped"] == 0 and r["feasible"]
         assert c["only_exact"] == 0 and c["only_approx"] == 0 and c["other_node"] == 0, (name, c)
 
 
@@ -68,9 +79,11 @@ def test_queue_hash_round_is_feasible_and_its_distance_is_reported(tmp_path, hos
     res = _run(tmp_path, world, port)
     for name, r in res.items():
         c = r["compare"]
-        assert r["same_on_all_ranks"]
+        assert r["same_on_all_ranks"] and r["feasible"]
+        c0 = r["compare_without_replay"]
+        assert c["only_exact"] <= c0["only_exact"], "the ordered replay must not lose jobs the plain re-admission keeps"
         assert r["scheduled"] + r["dropped"] >= c["approx_new"] and c["approx_new"] == r["scheduled"]
         assert c["same_node"] + c["other_node"] + c["only_approx"] == c["approx_new"]
-        print(f"queue-hash world={world} {name}: {json.dumps({k: r[k] for k in ('scheduled', 'dropped', 'conflicts', 'preempted')})} vs exact {json.dumps(c)}")
+        print(f"queue-hash world={world} {name}: {json.dumps({k: r[k] for k in ('scheduled', 'dropped', 'conflicts', 'accepted', 'replay_set', 'replayed', 'preempted')})} vs exact {json.dumps(c)}; without the replay {json.dumps(c0)}")
     # the point of the measurement: side-by-side queues do not see each other's binds, so the assignment differs from the reference's
     assert any(r["compare"]["other_node"] + r["compare"]["only_exact"] + r["compare"]["only_approx"] > 0 for r in res.values())
