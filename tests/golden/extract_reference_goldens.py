@@ -399,6 +399,10 @@ def main():
     menv["types.AwayNodeTypeConditionOpEqual"] = "=="
     out["matches_conditions"] = extract_table(f"{REF}/nodedb/nodedb_test.go", "TestMatchesConditions", menv, skipped)
 
+    # market-driven rounds: the same driver as TestPreemptingQueueScheduler over jobs with price bands, plus the expected spot price / billing
+    # (extracted last: the fixtures number every job they create, and the other tables keep their numbering)
+    out["market_pqs"] = extract_table(f"{REF}/scheduling/market_driven_preempting_queue_scheduler_test.go", "TestMarketDrivenPreemptingQueueScheduler", env, skipped)
+
     for k, v in out.items():
         path = os.path.join(HERE, f"{k}_cases.json")
         with open(path, "w") as f:

@@ -421,6 +421,23 @@ def WithOptimiserConfig(pool, optimiser_config, config):   # testfixtures.go:328
     return config
 
 
+def WithMarketBasedSchedulingEnabled(config):   # testfixtures.go:297-306: PoolConfig.ExperimentalMarketScheduling of every pool
+    config = copy.deepcopy(config)
+    config["market"] = {"Enabled": True, "SpotPriceCutoff": 0.9}
+    return config
+
+
+def N1Cpu4GiJobsWithPriceBandAndPriorityClass(queue, band, pc, n):   # testfixtures.go:601-610 + SetPricing :573-585: QueuedBid = the band's number, RunningBid the same
+    return [dict(Test1Cpu4GiJob(queue, pc), price_band=int(band)) for _ in range(int(n))]     # (pricing.NonPreemptibleRunningPrice for a non-preemptible class: the driver resolves it)
+
+
+def N1Cpu4GiJobsWithPriceBand(queue, band, n): return N1Cpu4GiJobsWithPriceBandAndPriorityClass(queue, band, "priority-0", n)   # :597-599
+
+
+def N1GpuJobsWithPriceBandAndPriorityClass(queue, band, pc, n):   # :612-621
+    return [dict(Test1GpuJob(queue, pc), price_band=int(band)) for _ in range(int(n))]
+
+
 def WithRoundLimitsPoolConfig(limits, config):
     config = copy.deepcopy(config)
     config["maximum_resource_fraction_to_schedule_by_pool"] = {k: dict(v) for k, v in limits.items()}
@@ -457,6 +474,11 @@ def make_env():
     env["v1.TaintEffectNoSchedule"] = "NoSchedule"
     env["v1.TaintEffectNoExecute"] = "NoExecute"
     env["v1.TaintEffectPreferNoSchedule"] = "PreferNoSchedule"
+    for i, b in enumerate("ABCDEFGH"):
+        env["bidstore.PriceBand_PRICE_BAND_" + b] = i + 1   # pkg/bidstore/bids.pb.go:72-81
+    env["testfixtures.TestResourceListFactory.MakeAllZero"] = lambda: rl({})   # an all-zero list of the factory's resources
+    env["floatPtr"] = float                                  # market_driven_preempting_queue_scheduler_test.go:964-966
+    env["makeIntArray"] = lambda n: list(range(int(n)))      # :956-962
     env["math.MaxInt"] = 2**62
     env["math.Inf"] = lambda s: math.inf if s >= 0 else -math.inf
     return env
