@@ -14,6 +14,11 @@
 static inline int mgBlocks(long long n) { return (int)((n + MG_THREADS - 1) / MG_THREADS); }
 #define MG_IDX() ((long long)blockIdx.x * MG_THREADS + threadIdx.x)
 
+// one atomic per wave: ballot + popcount (a counter every thread bumps serialises the whole grid on one address)
+__device__ static inline void waveCount(int32_t* counter, bool pred) {
+  unsigned long long m = __ballot(pred);
+  if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(counter, (int)__builtin_popcountll(m));
+}
 __global__ __launch_bounds__(MG_THREADS) void k_mgpu_pack(Dev d, GlobalKeyLayout L, int level, const unsigned long long* keys, const int32_t* slot, int nq, long long* out, int32_t* bad) {
   long long i = MG_IDX();
   if (i < nq) out[i] = mgpuPackQuery(d, L, level, keys[slot[i]], bad);
@@ -38,7 +43,8 @@ __global__ __launch_bounds__(MG_THREADS) void k_mgpu_foreign(Dev d, const long l
 }
 __global__ __launch_bounds__(MG_THREADS) void k_mgpu_conflict(Dev d, const long long* red, const long long* freeC, uint8_t* conflict, int32_t* counts) {
   long long n = MG_IDX();
-  if (n < d.cfg.N) mgpuConflict(d, red, freeC, conflict, counts, (int)n);
+  bool over = n < d.cfg.N && mgpuConflict(d, red, freeC, conflict, (int)n);
+  waveCount(counts + 0, over);
 }
 __global__ __launch_bounds__(MG_THREADS) void k_mgpu_gang(Dev d, const long long* red, const uint8_t* conflict, uint8_t* gangReplay) {
   long long j = MG_IDX();
@@ -46,7 +52,8 @@ __global__ __launch_bounds__(MG_THREADS) void k_mgpu_gang(Dev d, const long long
 }
 __global__ __launch_bounds__(MG_THREADS) void k_mgpu_outcome(Dev d, const long long* red, const uint8_t* conflict, const uint8_t* gangReplay, int32_t* node, int32_t* prio, uint8_t* replay, int32_t* counts) {
   long long j = MG_IDX();
-  if (j < d.cfg.M) mgpuJobOutcome(d, red, conflict, gangReplay, node, prio, replay, counts, (int)j);
+  int k = j < d.cfg.M ? mgpuJobOutcome(d, red, conflict, gangReplay, node, prio, replay, (int)j) : 0;
+  waveCount(counts + 1, k == 1); waveCount(counts + 2, k == 2); waveCount(counts + 3, k == 3);
 }
 
 extern "C" int asched_internal_mgpu_pack(const Dev* d, const GlobalKeyLayout* L, int level, const unsigned long long* keys, const int32_t* slot, int nq, long long* out, int32_t* bad, hipStream_t s) {

@@ -86,11 +86,11 @@ MGPU_FN void mgpuFreeForeignPreempted(const Dev& d, const long long* red, const 
   for (int r = 0; r < c.R; r++) MGPU_ADD64(freeC + (size_t)n * c.R + r, (long long)d.jReq[(size_t)j * c.R + r]);
 }
 // step 4 (per node)
-MGPU_FN void mgpuConflict(const Dev& d, const long long* red, const long long* freeC, uint8_t* conflict, int32_t* counts, int n) {
+MGPU_FN bool mgpuConflict(const Dev& d, const long long* red, const long long* freeC, uint8_t* conflict, int n) {
   bool over = false;
   for (int r = 0; r < d.cfg.R; r++) over = over || red[(size_t)n * d.cfg.R + r] > freeC[(size_t)n * d.cfg.R + r];
   conflict[n] = over;
-  if (over) MGPU_ADD32(counts + 0, 1);
+  return over;
 }
 // step 5 (per job): a gang with a member on a conflict node is replayed as a whole (gang placement is atomic: gang_scheduler.go:100-148)
 MGPU_FN void mgpuGangConflict(const Dev& d, const long long* red, const uint8_t* conflict, uint8_t* gangReplay, int j) {
@@ -99,17 +99,17 @@ MGPU_FN void mgpuGangConflict(const Dev& d, const long long* red, const uint8_t*
   if (place && conflict[place - 1] && d.jGang[j] >= 0) MGPU_OR8(gangReplay + d.jGang[j]);
 }
 // step 6 (per job): the job's node / priority on the accepted state, replay flag
-MGPU_FN void mgpuJobOutcome(const Dev& d, const long long* red, const uint8_t* conflict, const uint8_t* gangReplay, int32_t* node, int32_t* prio, uint8_t* replay,
-                            int32_t* counts, int j) {
+// returns which summary counter the job belongs to (0: none, 1: accepted, 2: replay, 3: preempted) — the caller counts (per wave on the device: one atomic per wave, not per job)
+MGPU_FN int mgpuJobOutcome(const Dev& d, const long long* red, const uint8_t* conflict, const uint8_t* gangReplay, int32_t* node, int32_t* prio, uint8_t* replay, int j) {
   const DevCfg& c = d.cfg;
   long long w = red[(size_t)c.N * c.R + j];
   int place = (int)(w & MGPU_NODE_MASK), level = (int)((w >> MGPU_LEVEL_SHIFT) & 15);
   node[j] = d.jNode0[j]; prio[j] = d.jRunPrio[j]; replay[j] = 0;
   if (place) {
     bool rp = conflict[place - 1] || (d.jGang[j] >= 0 && gangReplay[d.jGang[j]]);
-    if (rp) { node[j] = -1; replay[j] = 1; MGPU_ADD32(counts + 2, 1); }
-    else { node[j] = place - 1; prio[j] = c.prios[level]; MGPU_ADD32(counts + 1, 1); }
-  } else if ((w >> MGPU_PRE_SHIFT) != 0) {
-    node[j] = -1; MGPU_ADD32(counts + 3, 1);
+    if (rp) { node[j] = -1; replay[j] = 1; return 2; }
+    node[j] = place - 1; prio[j] = c.prios[level]; return 1;
   }
+  if ((w >> MGPU_PRE_SHIFT) != 0) { node[j] = -1; return 3; }
+  return 0;
 }

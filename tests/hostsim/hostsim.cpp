@@ -215,9 +215,9 @@ static int plat_delta_resolve(Dev& d, const long long* red, int ns, int np, int3
   for (int i = 0; i < ns; i++) mgpuFreeOwnScheduled(d, freeC.data(), i);
   for (int i = 0; i < np; i++) mgpuOwnPreempted(d, ownPre.data(), i);
   for (int j = 0; j < M; j++) mgpuFreeForeignPreempted(d, red, ownPre.data(), freeC.data(), j);
-  for (int n = 0; n < N; n++) mgpuConflict(d, red, freeC.data(), conflict.data(), counts, n);
+  for (int n = 0; n < N; n++) counts[0] += mgpuConflict(d, red, freeC.data(), conflict.data(), n);
   for (int j = 0; j < M; j++) mgpuGangConflict(d, red, conflict.data(), gangReplay.data(), j);
-  for (int j = 0; j < M; j++) mgpuJobOutcome(d, red, conflict.data(), gangReplay.data(), node, prio, replay, counts, j);
+  for (int j = 0; j < M; j++) { int k = mgpuJobOutcome(d, red, conflict.data(), gangReplay.data(), node, prio, replay, j); if (k) counts[k]++; }
   return 0;
 }
 // fairness optimiser: the per-node routine of round_opt.h over all nodes, serially
