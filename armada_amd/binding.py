@@ -117,7 +117,7 @@ class CJobs(C.Structure):
         ("m", C.c_int32), ("queue", _i32p), ("pc", _i32p), ("queue_priority", _u32p), ("submit_time", _i64p),
         ("req", _i64p), ("req_class", _i32p), ("gang_id", _i32p), ("gang_cardinality", _i32p),
         ("gang_uniformity_label", _i32p), ("node", _i32p), ("scheduled_at_priority", _i32p), ("run_timestamp", _i64p),
-        ("away", C.POINTER(C.c_uint8)),
+        ("away", C.POINTER(C.c_uint8)), ("bid_price", _f64p),
     ]
 
 
@@ -145,6 +145,15 @@ class COptimiserConfig(C.Structure):
     _fields_ = [("enabled", C.c_uint8), ("pad_", C.c_uint8 * 7), ("min_fairness_improvement_pct", C.c_double), ("max_jobs_per_round", C.c_int32), ("pad2_", C.c_int32),
                 ("max_job_size_to_preempt", C.POINTER(C.c_int64)), ("min_job_size_to_schedule", C.POINTER(C.c_int64)),
                 ("max_resource_fraction_to_schedule", C.POINTER(C.c_double)), ("now_ms", C.c_int64)]
+
+
+class CMarketConfig(C.Structure):
+    _fields_ = [("enabled", C.c_uint8), ("pad_", C.c_uint8 * 7), ("spot_price_cutoff", C.c_double)]
+
+
+class CMarketResult(C.Structure):
+    _fields_ = [("has_spot_price", C.c_int32), ("pad_", C.c_int32), ("spot_price", C.c_double), ("queue_billable_resource", _i64p),
+                ("queue_billable_price_override", _f64p), ("queue_has_price_override", _u8p)]
 
 
 class CGlobalKeyLayout(C.Structure):
@@ -202,6 +211,7 @@ ALL_SYMBOLS = [
     "optimiser_schedule_job", "set_optimiser", "set_label_value_ints", "round_timing", "set_deadline", "cancel", "cancel_clear", "indexed_node_label_values", "get_node_jobs", "get_nodes_alloc", "node_upsert",
     "market_iterate", "market_compare", "market_multi_iterate",
     "fit_select_batch_global", "round_delta_words", "round_delta", "round_delta_resolve",
+    "set_market", "market_result",
 ]
 
 
@@ -314,6 +324,8 @@ class Library:
         f("iterate_nodes", C.c_int32, [C.c_void_p, _i64p, C.c_int32, C.c_int32, _i64p, _i32p, C.c_int32, _i32p])
         f("fit_select_batch", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int32, _i32p])
         f("fit_select_batch_global", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int32, C.POINTER(CGlobalKeyLayout), C.c_void_p])
+        f("set_market", C.c_int32, [C.c_void_p, C.POINTER(CMarketConfig)])
+        f("market_result", C.c_int32, [C.c_void_p, C.POINTER(CMarketResult)])
         f("round_delta_words", C.c_int32, [C.c_void_p, _i64p])
         f("round_delta", C.c_int32, [C.c_void_p, C.c_void_p])
         f("round_delta_resolve", C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(CDeltaSummary), _i32p, _i32p, _u8p])
@@ -523,7 +535,7 @@ class Scheduler:
 
     def jobs_set(self, req, *, queue=None, pc=None, queue_priority=None, submit_time=None, req_class=None, gang_id=None,
                  gang_cardinality=None, gang_uniformity_label=None, node=None, scheduled_at_priority=None,
-                 run_timestamp=None, class_tolerations=None, class_selectors=None, class_affinities=None, away=None):
+                 run_timestamp=None, class_tolerations=None, class_selectors=None, class_affinities=None, away=None, bid_price=None):
         """class_affinities: per class None (no required node affinity) or a list of terms, a term = list of (key, op, [values])"""
         req = _arr(req, np.int64).reshape(-1, self.R)
         m = req.shape[0]
@@ -542,6 +554,7 @@ class Scheduler:
             keep.append(a)
             setattr(s, name, _ptr(a, ctype))
 
+        put("bid_price", bid_price, np.float64, C.c_double)
         put("queue", queue, np.int32, C.c_int32, 0)
         put("pc", pc, np.int32, C.c_int32, 0)
         put("queue_priority", queue_priority, np.uint32, C.c_uint32)
@@ -824,6 +837,19 @@ class Scheduler:
         gr = None if global_rank is None else _arr(global_rank, np.int32)
         lay.global_rank = _ptr(gr, C.c_int32) if gr is not None else None
         self._check(self.lib.fit_select_batch_global(self.h, len(ja), _ptr(ja, C.c_int32), priority, C.byref(lay), C.c_void_p(int(out_ptr))))
+
+    def set_market(self, enabled: bool = True, spot_price_cutoff: float = 0.0):
+        c = CMarketConfig(); c.enabled = 1 if enabled else 0; c.spot_price_cutoff = float(spot_price_cutoff)
+        self._check(self.lib.set_market(self.h, C.byref(c)))
+
+    def market_result(self):
+        """-> dict(spot_price (None: unset), billable [Q][R] int64, price_override [Q] (None: unset))"""
+        r = CMarketResult()
+        self._check(self.lib.market_result(self.h, C.byref(r)))
+        q = self.num_queues
+        bill = np.ctypeslib.as_array(r.queue_billable_resource, shape=(q * self.R,)).astype(np.int64).reshape(q, self.R) if q else np.zeros((0, self.R), dtype=np.int64)
+        ov = [float(r.queue_billable_price_override[i]) if r.queue_has_price_override[i] else None for i in range(q)]
+        return dict(spot_price=float(r.spot_price) if r.has_spot_price else None, billable=bill, price_override=ov)
 
     def round_delta_words(self) -> int:
         n = C.c_int64(0)

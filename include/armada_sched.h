@@ -246,6 +246,9 @@ typedef struct asched_jobs {
                                       (CalculateAwayQueueName; jobiteration.go:88-94, context/scheduling.go:225-226, 412-413, 646-647).  The node evictor
                                       never evicts such a job for balancing (pqs.go:102-104: job.LatestRun().Pool() != sctx.Pool); urgency preemption and the
                                       oversubscribed evictor may take it */
+  const double* bid_price;         /* [m] job.GetBidPrice(pool) as the job stands at the start of the round (jobdb/job.go:459-481: QueuedBid of a queued job, RunningBid of a
+                                      running one, pricing.NonPreemptibleRunningPrice = 1e6 for a running non-preemptible job); NULL = 0 everywhere.  Read by market-driven
+                                      rounds only (asched_set_market) */
 } asched_jobs;
 
 /* ---- per-queue round inputs (context.AddQueueSchedulingContext, scheduling/context/scheduling.go:114-166) ---- */
@@ -569,6 +572,30 @@ typedef struct asched_optimiser_config {
   int64_t now_ms;                                  /* the clock job ages are taken from (asched_optimiser_schedule_job) */
 } asched_optimiser_config;
 int32_t ASCHED_FN(set_optimiser)(asched_t*, const asched_optimiser_config* cfg);
+
+/* Market-driven scheduling of a pool (configuration.MarketSchedulingConfig; preempting_queue_scheduler.go:61-62): the following schedule_round calls
+     - let the node evictor take EVERY job of the pool (pqs.go:117-119; cross-pool away jobs excepted, :102-104) — the prices decide who comes back;
+     - order each queue's evicted jobs with jobdb.MarketSchedulingOrderCompare (pqs.go:292-295, jobdb/comparison.go:113-170) and merge them with the queued jobs by the
+       same comparer (MarketDrivenMultiJobsIterator, jobiteration.go:232-321; the caller passes asched_queues.queued_jobs in that order: jobdb.PriceOrder);
+     - pick the next queue with MarketBasedCandidateGangIterator (market_iterator.go: bid price, running before queued, round robin between queues at the same price ...),
+       a literal container/heap because its Less reads the previous result; the queues are pushed in name order (the reference ranges over a Go map);
+     - set the spot price to the lowest bid of the gang that takes the DRF cost of what this pass has scheduled beyond spot_price_cutoff, mark what is in the queue
+       contexts at that moment billable, and bill the price-setting queue the highest competing bid (queue_scheduler.go:177-203);
+     - do not run the fairness optimiser (pqs.go:224).
+   A fair-share preemption rate limiter together with market-driven scheduling is ASCHED_ERR_INVALID (the reference rejects it at config validation).  The runtime the
+   reference compares between two running jobs (time.Now() - run.Created) orders like -run_timestamp: no clock is read.  NULL or enabled == 0: off (the default). */
+typedef struct asched_market_config { uint8_t enabled; uint8_t pad_[7]; double spot_price_cutoff; } asched_market_config;
+int32_t ASCHED_FN(set_market)(asched_t*, const asched_market_config* cfg);
+/* What the last market-driven round left in the scheduling context: sctx.SpotPrice (has_spot_price 0: nil), per queue qctx.GetBillableResource() (floored at zero) and
+   qctx.BillablePriceOverride (context/queue.go:39-44, 108-127).  Buffers are owned by the handle until the next round. */
+typedef struct asched_market_result {
+  int32_t has_spot_price; int32_t pad_;
+  double spot_price;
+  const int64_t* queue_billable_resource;      /* [q][R] */
+  const double* queue_billable_price_override; /* [q] */
+  const uint8_t* queue_has_price_override;     /* [q] */
+} asched_market_result;
+int32_t ASCHED_FN(market_result)(asched_t*, asched_market_result* out);
 
 /* 1 if the job's scheduling key is registered in sctx.UnfeasibleSchedulingKeys (gang_scheduler.go:80-95) */
 int32_t ASCHED_FN(job_key_unfeasible)(asched_t*, int32_t job, int32_t* out);

@@ -100,9 +100,15 @@ class Case:
         self.nodes = nodes
         self.upsert_nodes(set())
 
-    def upsert_nodes(self, cordoned):
+    def upsert_nodes(self, cordoned, excluded=()):
+        """cordoned: nodes that carry the unschedulable taint; excluded: nodes that are not in this round's NodeDb at all (the market table's nodes on cordoned clusters)"""
         s = self.sched
         P = s.P
+        self.all_nodes = getattr(self, "all_nodes", None) or self.nodes
+        self.global_of_local = [i for i in range(len(self.all_nodes)) if i not in set(excluded)]
+        self.local_of_global = {g: l for l, g in enumerate(self.global_of_local)}
+        cordoned = {self.local_of_global[g] for g in cordoned if g in self.local_of_global}
+        self.nodes = [self.all_nodes[g] for g in self.global_of_local]
         total = np.array([vec(n["total"]) for n in self.nodes], dtype=np.int64).reshape(len(self.nodes), R)
         abp = np.repeat(total[:, None, :], P, axis=1)
         for i, n in enumerate(self.nodes):
@@ -177,12 +183,21 @@ class Case:
             req_class=req_class, gang_id=gang_id, gang_cardinality=gang_card, gang_uniformity_label=gang_uni,
             node=node, scheduled_at_priority=sap, run_timestamp=rts,
             class_tolerations=cls_tol, class_selectors=cls_sel, class_affinities=cls_aff,
-            away=[1 if j.get("away") else 0 for j in jobs] if any(j.get("away") for j in jobs) else None)
+            away=[1 if j.get("away") else 0 for j in jobs] if any(j.get("away") for j in jobs) else None,
+            bid_price=self.bid_prices(jobs, running) if (self.cfgj.get("market") or {}).get("Enabled") else None)
 
     def sort_queued(self, jobs: List[dict], idxs: List[int]) -> List[int]:
-        """SchedulingOrderCompare for queued (non-active) jobs: jobdb/comparison.go:49-107"""
+        """SchedulingOrderCompare for queued (non-active) jobs: jobdb/comparison.go:49-107; on a market-driven pool jobdb.PriceOrder = MarketSchedulingOrderCompare (:113-170)"""
         pcs = self.cfgj["priority_classes"]
+        if (self.cfgj.get("market") or {}).get("Enabled"):
+            return sorted(idxs, key=lambda i: (-pcs[jobs[i]["pc"]]["priority"], -float(jobs[i].get("price_band", 0)), jobs[i]["created"], i))
         return sorted(idxs, key=lambda i: (-pcs[jobs[i]["pc"]]["priority"], jobs[i]["priority"], jobs[i]["created"], i))
+
+    def bid_prices(self, jobs: List[dict], running: Dict[int, tuple]):
+        """job.GetBidPrice(pool) (jobdb/job.go:459-481) with testfixtures.SetPricing (:573-585): QueuedBid = RunningBid = the price band's number, a running
+        non-preemptible job bids pricing.NonPreemptibleRunningPrice"""
+        pcs = self.cfgj["priority_classes"]
+        return [1_000_000.0 if (i in running and not pcs[j["pc"]]["preemptible"]) else float(j.get("price_band", 0)) for i, j in enumerate(jobs)]
 
     def pc_limits(self, queues: List[str], queue_cfgs=None, pool="pool"):
         """calculatePerQueueLimits (constraints.go:218-256): PC defaults, overridden per queue and per (queue, pool)."""
@@ -285,7 +300,9 @@ def run_pqs_case(lib: Library, case: dict):
         assert not rnd.get("IndicesToUnbind"), "IndicesToUnbind not supported by the driver"
         for idx in rnd.get("NodeIndicesToCordon") or []:
             cordoned.add(int(idx))
-        c.upsert_nodes(cordoned)
+        # market_driven_preempting_queue_scheduler_test.go:697-705: nodes on cordoned clusters are not added to this round's NodeDb (and the jobs running there are not bound)
+        excluded = set(int(i) for i in rnd.get("IndiciesOfNodesOnCordonedCluster") or [])
+        c.upsert_nodes(cordoned, excluded)
         queued_now = []
         for q, js in (rnd.get("JobsByQueue") or {}).items():
             for k, j in enumerate(js):
@@ -293,7 +310,7 @@ def run_pqs_case(lib: Library, case: dict):
                 queued_now.append(j)
                 demand[qidx[q]] += np.array(vec(j["req"]), dtype=np.int64)
         jobs = live + queued_now
-        running = {i: j["run"] for i, j in enumerate(jobs) if "run" in j}
+        running = {i: (c.local_of_global[j["run"][0]], j["run"][1], j["run"][2]) for i, j in enumerate(jobs) if "run" in j and j["run"][0] in c.local_of_global}
         c.set_jobs(jobs, qidx, running)
         queued = [c.sort_queued(jobs, [i for i, j in enumerate(jobs) if "run" not in j and j["queue"] == q]) for q in queues]
         s.round_prepare(weight, queued, name_rank=list(range(Q)), allocated_by_pc=allocated, demand=demand,
@@ -310,7 +327,11 @@ def run_pqs_case(lib: Library, case: dict):
                             max_resource_fraction_to_schedule=[float(inf(oc.get("MaximumResourceFractionToSchedule", {}).get(r, "inf"))) for r in RES], now_ms=0)
         else:
             s.set_optimiser(False)
+        market = cfg.get("market") or {}
+        s.set_market(bool(market.get("Enabled")), float(market.get("SpotPriceCutoff", 0.0)))
         res = s.schedule_round()
+        res.scheduled = {j: c.global_of_local[n] for j, n in res.scheduled.items()}
+        res.preempted = {j: c.global_of_local[n] for j, n in res.preempted.items()}
         note_stats(s)
         glim.tokens = res.global_tokens_after
         for t, v in zip(qlim, res.queue_tokens_after):
@@ -352,6 +373,19 @@ def run_pqs_case(lib: Library, case: dict):
             e = {int(k): sorted(v) for k, v in (exp_p.get(q) or {}).items()}
             g = {k: sorted(v) for k, v in got_p.get(q, {}).items()}
             assert e == g, f"round {ri}: preempting from queue {q}: expected {e} got {g}"
+        # expected market data (market_driven_preempting_queue_scheduler_test.go:855-887)
+        emd = rnd.get("ExpectedMarketData")
+        if emd:
+            mr = s.market_result()
+            assert (mr["spot_price"] or 0.0) == float(emd.get("ExpectedSpotPrice") or 0.0), f"round {ri}: spot price {mr['spot_price']} expected {emd.get('ExpectedSpotPrice')}"
+            for q, exp in (emd.get("ExpectedBillableResource") or {}).items():
+                assert mr["billable"][qidx[q]].tolist() == vec(exp), f"round {ri}: billable resource of {q}: {mr['billable'][qidx[q]].tolist()} expected {vec(exp)}"
+            for q, exp in (emd.get("ExpectedBillablePriceOverride") or {}).items():
+                assert mr["price_override"][qidx[q]] == (None if exp is None else float(exp)), f"round {ri}: billable price override of {q}: {mr['price_override'][qidx[q]]} expected {exp}"
+            one = emd.get("ExpectedExactlyOneOverrideWithValue")
+            if one is not None:
+                have = [v for v in mr["price_override"] if v is not None]
+                assert have == [float(one)], f"round {ri}: expected exactly one billable price override of {one}, got {mr['price_override']}"
         c.no_oversubscription()
         # jobDb update (:2499-2547): queued jobs deleted, preempted failed, scheduled get runs in submit order
         new_live = [j for i, j in enumerate(jobs) if "run" in j and i not in res.preempted]

@@ -36,6 +36,15 @@ def test_pqs_goldens(hip_lib, case):
     _run(scenario.run_pqs_case, hip_lib, case)
 
 
+MARKET = load("market_pqs")
+
+
+@pytest.mark.parametrize("case", MARKET, ids=ids(MARKET))
+def test_market_pqs_goldens(hip_lib, case):
+    """TestMarketDrivenPreemptingQueueScheduler: whole market-driven rounds (evict-everything node evictor, price-ordered iterators, spot price, second-price billing)"""
+    _run(scenario.run_pqs_case, hip_lib, case)
+
+
 @pytest.mark.parametrize("case", QS, ids=ids(QS))
 def test_qs_goldens(hip_lib, case):
     _run(scenario.run_qs_case, hip_lib, case)

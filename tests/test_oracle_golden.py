@@ -14,6 +14,15 @@ QS = load("queue_scheduler")
 GANG = load("gang_scheduler")
 
 
+MARKET = load("market_pqs")
+
+
+@pytest.mark.parametrize("case", MARKET, ids=ids(MARKET))
+def test_market_pqs_goldens(oracle_lib, case):
+    """TestMarketDrivenPreemptingQueueScheduler (market_driven_preempting_queue_scheduler_test.go): whole market-driven rounds incl. spot price and billing"""
+    assert scenario.run_pqs_case(oracle_lib, case) == "ok"
+
+
 @pytest.mark.parametrize("case", PQS, ids=ids(PQS))
 def test_preempting_queue_scheduler(oracle_lib, case):
     r = scenario.run_pqs_case(oracle_lib, case)
