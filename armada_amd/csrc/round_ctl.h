@@ -337,6 +337,11 @@ DEV double drf(Dev& d, const int64_t* a) {  // fairness.go:103-105 (float64, thi
 DEV void vadd(Dev& d, int64_t* a, const int64_t* b, int sign) { for (int r = 0; r < d.cfg.R; r++) a[r] += sign * b[r]; }
 
 // qctx.addJobSchedulingContext + sctx.AddJobSchedulingContext (context/queue.go:231-265, scheduling.go:410-434)
+// The market-driven round exists in the auxiliary kernel and the CPU build only (round_mkt.h): the round kernel's own translation unit compiles none of it.
+#if (defined(ASCHED_AUX_TU) || defined(ASCHED_HOSTSIM)) && !defined(ASCHED_MARKET_ROUND)
+#define ASCHED_MARKET_ROUND 1
+#endif
+#include "round_mkt.h"
 DEV bool sctxAddJob(Dev& d, int job) {
   int q = d.jQueue[job], pc = d.jPc[job];
   const int64_t* req = JREQ(d, job);
@@ -380,6 +385,8 @@ DEV bool sctxEvictJob(Dev& d, int job) {
   if (sched || resched) {
     if (sched) { vadd(d, QPV(d.qSchedByPc, q, pc), req, -1); f &= ~F_SUCCESSFUL; }
     if (resched) f &= ~F_RESCHEDULED;
+    // context/queue.go:368-376: a billable jctx that leaves the queue context takes its AllResourceRequirements out of the bill
+    MK(if (mkOn(d) && d.mk.jobBillable[job]) { vadd(d, QV(d.mk.qBillable, q), req, -1); d.mk.jobBillable[job] = 0; })
   } else {
     vadd(d, QPV(d.qEvictedByPc, q, pc), req, +1);
     f |= F_EVICTED;
@@ -1039,6 +1046,20 @@ DEV void resetJctxForQueued(Dev& d, int job) {  // JobSchedulingContextFromJob (
   d.jcGangCard[job] = d.jGang[job] >= 0 ? d.jGangCard[job] : 1; d.jcUniValue[job] = -1; d.jcStagedBy[job] = -1;
 }
 DEV int jobItNext(Dev& d, int q, bool withQueued) {  // MultiJobsIterator(evicted, queued) :179-228
+#ifdef ASCHED_MARKET_ROUND
+  if (mkOn(d) && withQueued) {   // MarketDrivenMultiJobsIterator.Next (jobiteration.go:250-294; pqs.go:730-731: only when there is a jobRepo)
+    if (d.mk.itV1[q] < 0 && d.itEi[q] < d.evOff[q + 1]) d.mk.itV1[q] = d.evList[d.itEi[q]++];                       // InMemoryJobIterator.Next: every entry is an evicted job
+    if (d.mk.itV2[q] < 0 && !d.itJobOnlyEv[q] && d.itQi[q] < d.queuedOff[q + 1]) { int job = d.queuedJobs[d.itQi[q]++]; resetJctxForQueued(d, job); d.mk.itV2[q] = job; }   // QueuedJobsIterator.Next :152-161
+    int j1 = d.mk.itV1[q], j2 = d.mk.itV2[q];
+    if (j1 >= 0 && j2 >= 0) {
+      if (d.mk.jRank[j1] < d.mk.jRank[j2]) { d.mk.itV1[q] = -1; return j1; }   // MarketSchedulingOrderCompare(j1, j2) < 0: the pool-wide rank under that order (asched_host.inc)
+      d.mk.itV2[q] = -1; return j2;
+    }
+    if (j1 >= 0) { d.mk.itV1[q] = -1; return j1; }
+    if (j2 >= 0) { d.mk.itV2[q] = -1; return j2; }
+    return -1;
+  }
+#endif
   if (d.itStage[q] == 0) {
     if (d.itEi[q] < d.evOff[q + 1]) return d.evList[d.itEi[q]++];
     d.itStage[q] = 1;
@@ -1050,6 +1071,7 @@ DEV int jobItNext(Dev& d, int q, bool withQueued) {  // MultiJobsIterator(evicte
 DEV void gangItOnlyEvicted(Dev& d, int q) {  // :338-350
   if (d.itGangOnlyEv[q]) return;
   d.itGangOnlyEv[q] = 1; d.itJobOnlyEv[q] = 1;
+  MK(if (mkOn(d) && d.mk.itV2[q] >= 0 && !d.jcEvicted[d.mk.itV2[q]]) d.mk.itV2[q] = -1;)   // MarketDrivenMultiJobsIterator.OnlyYieldEvicted :296-309 (it1Value is always an evicted job)
   int nx = d.itNext[q];
   if (nx != -1 && !gcAllEvicted(d, nx)) { d.itStashed[q] = nx; d.itNext[q] = -1; }
 }
@@ -1106,6 +1128,7 @@ DEV void updateItem(Dev& d, Ctl& c, int q, const PassCfg& pc) {  // updatePQItem
   int ref = gangItPeek(d, c, q, pc.withQueued, pc.maxLookback, pc.skipKnown);
   if (ref == -1) return;
   d.pqGctx[q] = ref;
+  MK(if (mkOn(d)) { mkItemOf(d, q, ref, gcJob(d, ref, 0)); return; })
   const DevCfg& cf = d.cfg;
   int64_t alloc[MAXR], withGang[MAXR];
   const int64_t* base = c.useReplayAlloc ? QV(d.replayAlloc, q) : QV(d.qAlloc, q);
@@ -1129,7 +1152,11 @@ DEV void updateItem(Dev& d, Ctl& c, int q, const PassCfg& pc) {  // updatePQItem
   d.pqPcPrio[q] = pcp; d.pqSchedPrio[q] = sp;
   fastItemKeys(d, c, q);
 }
-DEV void updateAndPush(Dev& d, Ctl& c, int q, const PassCfg& pc) { updateItem(d, c, q, pc); d.pqInHeap[q] = d.pqGctx[q] != -1; }
+DEV void updateAndPush(Dev& d, Ctl& c, int q, const PassCfg& pc) {
+  updateItem(d, c, q, pc);
+  MK(if (mkOn(d)) { if (d.pqGctx[q] != -1) mkPush(d, q); else d.pqInHeap[q] = 0; return; })   // updateAndPushPQItem market_iterator.go:103-111
+  d.pqInHeap[q] = d.pqGctx[q] != -1;
+}
 
 // QueueCandidateGangIteratorPQ.Less (queue_scheduler.go:738-798)
 DEV bool pqAway(Dev& d, int q) { int ref = d.pqGctx[q]; return d.jAway && ref != -1 && gcCount(d, ref) > 0 && d.jAway[gcJob(d, ref, 0)] != 0; }   // item.away (:649)
@@ -1153,8 +1180,30 @@ DEV bool pqLess(Dev& d, const Ctl& c, int a, int b) {
   return d.qNameRank[a] < d.qNameRank[b];
 }
 DEV int pqTop(Dev& d, const Ctl& c);  // argmin over items with pqInHeap (Less is a strict total order => heap top)
+#ifdef ASCHED_MARKET_ROUND
+DEV int pqTopAny(Dev& d, const Ctl& c) { return mkOn(d) ? mkTop(d) : pqTop(d, c); }   // MarketBasedCandidateGangIterator.Peek: pq.items[0]
+#else
+#define pqTopAny pqTop
+#endif
 
 DEV void costItOnlyEvicted(Dev& d, Ctl& c, const PassCfg& pc) {  // :521-544
+#ifdef ASCHED_MARKET_ROUND
+  if (mkOn(d)) {   // MarketBasedCandidateGangIterator.OnlyYieldEvicted (market_iterator.go:153-176): the items in array order, then heap.Init
+    if (!c.onlyEvicted) {
+      int n = d.rs->mkHeapN, m = 0;
+      for (int i = 0; i < n; i++) {
+        int q = d.mk.heap[i];
+        gangItOnlyEvicted(d, q);
+        updateItem(d, c, q, pc);
+        if (d.pqGctx[q] != -1) d.mk.heap[m++] = q; else d.pqInHeap[q] = 0;
+      }
+      d.rs->mkHeapN = m;
+      mkInit(d);
+    }
+    c.onlyEvicted = 1;
+    return;
+  }
+#endif
   if (!c.onlyEvicted) {
     for (int q = 0; q < d.cfg.Q; q++) {
       if (!d.pqInHeap[q]) continue;
@@ -1166,6 +1215,20 @@ DEV void costItOnlyEvicted(Dev& d, Ctl& c, const PassCfg& pc) {  // :521-544
   c.onlyEvicted = 1;
 }
 DEV void costItOnlyEvictedForQueue(Dev& d, Ctl& c, int q, const PassCfg& pc) {  // :546-566
+#ifdef ASCHED_MARKET_ROUND
+  if (mkOn(d)) {   // OnlyYieldEvictedForQueue (market_iterator.go:185-201): heap.Remove / heap.Fix at the item's index
+    if (!c.onlyEvicted && !d.onlyEvByQueue[q]) {
+      for (int i = 0; i < d.rs->mkHeapN; i++) if (d.mk.heap[i] == q) {
+        gangItOnlyEvicted(d, q);
+        updateItem(d, c, q, pc);
+        if (d.pqGctx[q] == -1) mkRemove(d, i); else mkFix(d, i);
+        break;
+      }
+    }
+    d.onlyEvByQueue[q] = 1;
+    return;
+  }
+#endif
   if (!c.onlyEvicted && !d.onlyEvByQueue[q] && d.pqInHeap[q]) {
     gangItOnlyEvicted(d, q);
     updateItem(d, c, q, pc);
@@ -1185,6 +1248,15 @@ DEV void costItResume(Dev& d, Ctl& c, const PassCfg& pc) {  // :572-591
 }
 DEV void costItClear(Dev& d, Ctl& c, int top, const PassCfg& pc) {  // :595-606
   if (top < 0) return;
+#ifdef ASCHED_MARKET_ROUND
+  if (mkOn(d)) {   // MarketBasedCandidateGangIterator.Clear (market_iterator.go:74-89): Pop, item.it.Clear(), remember the result, update and push
+    int q = mkPop(d);
+    d.itNext[q] = -1;
+    d.rs->mkPrevRank = d.qNameRank[q]; d.rs->mkPrevCost = d.mk.pqPrice[q];
+    updateAndPush(d, c, q, pc);
+    return;
+  }
+#endif
   d.pqInHeap[top] = 0;
   d.itNext[top] = -1;
   updateAndPush(d, c, top, pc);
@@ -1199,7 +1271,9 @@ DEV void passInit(Dev& d, Ctl& c, const PassCfg& pc) {
     d.itJobOnlyEv[q] = 0; d.itGangOnlyEv[q] = 0; d.onlyEvByQueue[q] = 0; d.pqInHeap[q] = 0;
     d.pqBudget[q] = d.qDc[q] / d.qWeight[q];  // pushQueue :509-519
     if (d.qsSave && q < QCAPF) d.qsSave[q].valid = 0;   // a new pass: no stream carries over
+    MK(if (mkOn(d)) { d.mk.itV1[q] = -1; d.mk.itV2[q] = -1; })
   }
+  MK(if (mkOn(d)) { d.rs->mkHeapN = 0; d.rs->mkPrevCost = 0.0; d.rs->mkPrevRank = -1; })   // a fresh MarketIteratorPQ (NewMarketCandidateGangIterator :38-60; previousResultQueue "" orders before every name)
   c.onlyEvicted = 0;
   for (int q = 0; q < Q; q++) updateAndPush(d, c, q, pc);
 }
@@ -1212,8 +1286,33 @@ DEV void passInit(Dev& d, Ctl& c, const PassCfg& pc) {
 #define GSEG_BEGIN() do {} while (0)
 #define GSEG(i) do {} while (0)
 #endif
+#ifdef ASCHED_MARKET_ROUND
+// queue_scheduler.go:176-203 after a gang has been scheduled on a market-driven pool: the spot price is the lowest bid of the gang that takes the DRF cost of what this
+// pass has scheduled beyond the cutoff; what the queue contexts hold at that moment is billable; the price-setting queue pays the highest competing bid
+DEV_COLD void mkAfterScheduled(Dev& d, int ref, int gangQueue) {
+  const DevCfg& cf = d.cfg;
+  const int64_t* tot = gcTotal(d, ref);
+  for (int r = 0; r < cf.R; r++) d.rs->mkSchedRes[r] += tot[r];
+  if (d.rs->hasSpotPrice) return;
+  if (!(drf(d, d.rs->mkSchedRes) > d.rs->spotCutoff)) return;
+  int cnt = gcCount(d, ref);
+  double price = d.mk.jBid ? d.mk.jBid[gcJob(d, ref, 0)] : 0.0;
+  for (int k = 0; k < cnt; k++) { double b = d.mk.jBid ? d.mk.jBid[gcJob(d, ref, k)] : 0.0; if (b < price) price = b; }
+  d.rs->hasSpotPrice = 1; d.rs->spotPrice = price;
+  for (int i = 0; i < cf.Q * cf.R; i++) d.mk.qBillable[i] = 0;
+  for (int j = 0; j < cf.M; j++) {                                      // qctx.SetBillableResource (context/queue.go:108-119)
+    if (!(d.jobFlags[j] & (F_SUCCESSFUL | F_RESCHEDULED))) continue;
+    int q = d.jQueue[j];
+    if (q < 0 || q >= cf.Q) continue;
+    d.mk.jobBillable[j] = 1;
+    for (int r = 0; r < cf.R; r++) if (!d.cfg.isFloating[r]) QV(d.mk.qBillable, q)[r] += JREQ(d, j)[r];   // jctx.KubernetesResourceRequirements
+  }
+  d.mk.qOverride[gangQueue] = mkSecondPrice(d, gangQueue); d.mk.qHasOverride[gangQueue] = 1;
+}
+#endif
 DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff) {
   bool limitHit = false, resumed = false;
+  MK(if (mkOn(d)) { for (int r = 0; r < MAXR; r++) d.rs->mkSchedRes[r] = 0; if (d.rs->hasFpLimiter) { raise(d, ASCHED_ERR_INVALID, 950); return; } })
   c.fpLimitHit = 0;
   const bool softClock = d.cfg.maxNewJobNs > 0 || d.cfg.maxNewJobPerQueueNs > 0;
   unsigned pollCount = 0;
@@ -1250,7 +1349,7 @@ DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff)
       if (pend >= 0) { updateAndPush(d, c, pend, pc); continue; }
       if (!limitHit && d.rs->hasFpLimiter && d.rs->fpTokens < 1) continue;   // the fast loop's last iteration preempted (fastPreemptIter): the rate limit check comes before the next Peek (:114-121)
     }
-    int top = pqTop(d, c);
+    int top = pqTopAny(d, c);
     int ref = top >= 0 ? d.pqGctx[top] : -1;
     d.rs->statGenericIters++;
     if (d.progress) { d.progress[0] = d.rs->loopIterations; d.progress[4] = d.rs->statGenericIters; }
@@ -1281,6 +1380,7 @@ DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff)
           d.inSchedAndEvicted[j] = 0;
         }
       }
+      MK(if (mkOn(d)) mkAfterScheduled(d, ref, gangQueue);)
     } else if (isTerminal(reason)) {
       d.rs->terminationReason = reason;
       costItOnlyEvicted(d, c, pc);
@@ -1313,7 +1413,7 @@ DEV_COLD COLD_MS_7 void replayEvicted(Dev& d, Ctl& c) {
       fastEnterGeneric(d, c);
       if (pend >= 0) { updateAndPush(d, c, pend, pc); continue; }
     }
-    int top = pqTop(d, c);
+    int top = pqTopAny(d, c);
     int ref = top >= 0 ? d.pqGctx[top] : -1;
     if (ref == -1) break;
     int cnt = gcCount(d, ref);

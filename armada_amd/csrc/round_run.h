@@ -50,6 +50,7 @@ DEV void evictApply(Dev& d, int j, bool phase3) {
   if (sched || resched) {
     if (sched) { atomicVadd(d, QPV(d.qSchedByPc, q, pc), req, -1); f &= ~F_SUCCESSFUL; }
     if (resched) f &= ~F_RESCHEDULED;
+    MK(if (mkOn(d) && d.mk.jobBillable[j]) { atomicVadd(d, QV(d.mk.qBillable, q), req, -1); d.mk.jobBillable[j] = 0; })   // context/queue.go:368-376
   } else {
     atomicVadd(d, QPV(d.qEvictedByPc, q, pc), req, +1);
     f |= F_EVICTED;
@@ -72,6 +73,9 @@ DEV void bulkElem(Dev& d, int kind, int i) {
     case B_FILTER1: {  // NewNodeEvictor job filter (pqs.go:101-136)
       int n = d.jobNode[i], q = d.jQueue[i];
       // a cross-pool away job (job.LatestRun().Pool() != sctx.Pool, :102-104) is never evicted for balancing: urgency preemption and the oversubscribed evictor take it
+#ifdef ASCHED_MARKET_ROUND
+      if (mkOn(d)) { d.evFlag[i] = n >= 0 && !d.jobEvictedOnNode[i] && q >= 0 && q < c.Q && !(d.jAway && d.jAway[i]); break; }   // pqs.go:117-119: a market-driven pool evicts every job
+#endif
       bool ok = n >= 0 && !d.jobEvictedOnNode[i] && q >= 0 && q < c.Q && !(d.jAway && d.jAway[i]) && c.pcPreemptible[d.jPc[i]];
       d.evFlag[i] = ok && d.qEvictable[q];
     } break;
@@ -344,7 +348,10 @@ DEV_COLD COLD_MS_9 int pqsEvict(Dev& d, Ctl& c, bool phase3) {
   wgBulk(d, B_KEYS_ALL, d.cfg.N);
   // InMemoryJobRepository.EnqueueMany (jobiteration.go:85-108): per-queue lists in SchedulingOrderCompare order ==
   // order-preserving compaction of the pre-sorted job order
-  int n = wgCompactFlagged(d, d.ordAll, d.ordAllOff, d.cfg.Q, d.ordAllOff[d.cfg.Q], d.evFlag, d.evList, d.evOff);
+  // (a market-driven pool orders them with MarketSchedulingOrderCompare, pqs.go:292-295: the same compaction of the job order sorted by that comparer)
+  const int32_t* order = d.ordAll;
+  MK(if (mkOn(d)) order = d.mk.ord;)
+  int n = wgCompactFlagged(d, order, d.ordAllOff, d.cfg.Q, d.ordAllOff[d.cfg.Q], d.evFlag, d.evList, d.evOff);
   d.rs->numEvictedList = n;
   wgBulk(d, B_RESET_EVTAB, d.rs->evictedTableSize);  // nodeDb.Reset() (nodedb.go:299-313)
   d.rs->evictedTableSize = 0; d.rs->fairIndexValid = 0; d.rs->ftValid = 0;
@@ -664,6 +671,7 @@ enum Cmd {
   CMD_ITERATE_NODES,
   CMD_MARKET,
   CMD_OPT_BEGIN, CMD_OPT_NEXT, CMD_OPT_APPLY, CMD_OPT_FAIL, CMD_OPT_END, CMD_OPT_TENT, CMD_OPT_TENT_UNDO,   // the fairness optimiser inside the round, gang by gang (asched_host.inc runOptimiserPhase)
+  CMD_MARKET_ROUND,   // a whole market-driven round (asched_set_market; round_mkt.h): PreemptingQueueScheduler.Schedule in one launch of the auxiliary kernel
 };
 #define CMD_AUX_FIRST CMD_SUBMIT_CHECK
 // cmdIO layout: [0..15] results, [16..] arguments
@@ -1012,6 +1020,9 @@ DEV void optFail(Dev& d, Ctl& c) {
 DEV void runAuxCommand(Dev& d, Ctl& c, int cmd) {
   const DevCfg& cf = d.cfg;
   switch (cmd) {
+#ifdef ASCHED_MARKET_ROUND
+    case CMD_MARKET_ROUND: runRound(d, c); break;   // d.rs->market is set: every market-specific step is behind mkOn(d) (round_mkt.h)
+#endif
     case CMD_PQ_ORDER: {
       // sort.Sort over QueueCandidateGangIteratorPQ.Less (queue_scheduler.go:738-798) — the float goldens of queue_scheduler_test.go:995-1164.
       // The items sit in the per-queue arrays the round uses (the host points d.pq* / d.qNameRank at a scratch copy for this launch),

@@ -336,11 +336,11 @@ def load(lib, wl: Workload) -> Scheduler:
     return s
 
 
-def set_jobs(s: Scheduler, wl: Workload, job_node=None, job_run_prio=None):
+def set_jobs(s: Scheduler, wl: Workload, job_node=None, job_run_prio=None, bid_price=None):
     """jobs_set with the workload's job table (optionally with other run placements: the queue-hash round re-uploads the accepted state)"""
     s.jobs_set(wl.job_req, queue=wl.job_queue, pc=wl.job_pc, submit_time=wl.job_submit, node=wl.job_node if job_node is None else job_node,
                scheduled_at_priority=wl.job_run_prio if job_run_prio is None else job_run_prio, run_timestamp=wl.job_run_ts, gang_id=wl.job_gang,
-               gang_cardinality=wl.job_gang_card, req_class=wl.job_req_class, class_tolerations=wl.class_tolerations, class_selectors=wl.class_selectors, away=wl.job_away)
+               gang_cardinality=wl.job_gang_card, req_class=wl.job_req_class, class_tolerations=wl.class_tolerations, class_selectors=wl.class_selectors, away=wl.job_away, bid_price=bid_price)
 
 
 def prepare(s: Scheduler, wl: Workload, fairshare_preemption_tokens=None):

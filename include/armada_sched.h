@@ -588,14 +588,14 @@ typedef struct asched_market_config { uint8_t enabled; uint8_t pad_[7]; double s
 int32_t ASCHED_FN(set_market)(asched_t*, const asched_market_config* cfg);
 /* What the last market-driven round left in the scheduling context: sctx.SpotPrice (has_spot_price 0: nil), per queue qctx.GetBillableResource() (floored at zero) and
    qctx.BillablePriceOverride (context/queue.go:39-44, 108-127).  Buffers are owned by the handle until the next round. */
-typedef struct asched_market_result {
+typedef struct asched_market_outcome {
   int32_t has_spot_price; int32_t pad_;
   double spot_price;
   const int64_t* queue_billable_resource;      /* [q][R] */
   const double* queue_billable_price_override; /* [q] */
   const uint8_t* queue_has_price_override;     /* [q] */
-} asched_market_result;
-int32_t ASCHED_FN(market_result)(asched_t*, asched_market_result* out);
+} asched_market_outcome;
+int32_t ASCHED_FN(market_result)(asched_t*, asched_market_outcome* out);
 
 /* 1 if the job's scheduling key is registered in sctx.UnfeasibleSchedulingKeys (gang_scheduler.go:80-95) */
 int32_t ASCHED_FN(job_key_unfeasible)(asched_t*, int32_t job, int32_t* out);

@@ -104,21 +104,20 @@ class Case:
         """cordoned: nodes that carry the unschedulable taint; excluded: nodes that are not in this round's NodeDb at all (the market table's nodes on cordoned clusters)"""
         s = self.sched
         P = s.P
-        self.all_nodes = getattr(self, "all_nodes", None) or self.nodes
-        self.global_of_local = [i for i in range(len(self.all_nodes)) if i not in set(excluded)]
+        self.global_of_local = [i for i in range(len(self.nodes)) if i not in set(excluded)]
         self.local_of_global = {g: l for l, g in enumerate(self.global_of_local)}
         cordoned = {self.local_of_global[g] for g in cordoned if g in self.local_of_global}
-        self.nodes = [self.all_nodes[g] for g in self.global_of_local]
-        total = np.array([vec(n["total"]) for n in self.nodes], dtype=np.int64).reshape(len(self.nodes), R)
+        nodes = self.nodes_now = [self.nodes[g] for g in self.global_of_local]
+        total = np.array([vec(n["total"]) for n in nodes], dtype=np.int64).reshape(len(nodes), R)
         abp = np.repeat(total[:, None, :], P, axis=1)
-        for i, n in enumerate(self.nodes):
+        for i, n in enumerate(nodes):
             for p_str, used in (n.get("used") or {}).items():
                 p = int(p_str)
                 for l, prio in enumerate(s.priorities):
                     if prio <= p:  # MarkAllocated(allocatableByPriority, p, rl): internaltypes/node.go:535-549
                         abp[i, l, :] -= np.array(vec(used), dtype=np.int64)
         taints, labels = [], []
-        for i, n in enumerate(self.nodes):
+        for i, n in enumerate(nodes):
             ts = [list(t) for t in n["taints"]]
             if i in cordoned:
                 ts.append(UNSCHEDULABLE_TAINT)
@@ -126,8 +125,8 @@ class Case:
             labels.append([(self.S(k), self.S(v)) for k, v in sorted(n["labels"].items())])
         # nodes without hand-written usage are uploaded like production nodes — no explicit AllocatableByPriority — so that the golden tables run through
         # the level-0 fast structure, the stream runs and the ring, not only through the generic path (an explicit table turns the fast structure off)
-        explicit = any(n.get("used") for n in self.nodes) or os.environ.get("ASCHED_GOLDEN_EXPLICIT_ALLOC") == "1"
-        s.nodes_upsert(total, total, index=[n["index"] for n in self.nodes], alloc_by_prio=abp if explicit else None, taints=taints, labels=labels)
+        explicit = any(n.get("used") for n in nodes) or os.environ.get("ASCHED_GOLDEN_EXPLICIT_ALLOC") == "1"
+        s.nodes_upsert(total, total, index=[n["index"] for n in nodes], alloc_by_prio=abp if explicit else None, taints=taints, labels=labels)
 
     # ---- jobs
     def set_jobs(self, jobs: List[dict], queue_index: Dict[str, int], running: Dict[int, tuple]):
@@ -220,7 +219,7 @@ class Case:
 
     def no_oversubscription(self):
         s = self.sched
-        for n in range(len(self.nodes)):
+        for n in range(len(self.nodes_now)):
             a = s.get_alloc(n)
             for l, p in enumerate(s.priorities):
                 if p >= 0:

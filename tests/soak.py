@@ -6,6 +6,7 @@
     python tests/soak.py preempt 1500       # small crowded rounds (60-100 % occupied), most with a fair-share preemption rate limit: the jobs that need preemption stay in the fast loop (fastPreemptIter)
     python tests/soak.py offgrid 3000       # ONE node type with requests and / or allocatable off the index grid (fast structure on next to literal iteration; narrow order-key layout), crowded, some with the default indexedResources
     python tests/soak.py optimiser 2000     # rounds with the experimental fairness optimiser on (asched_set_optimiser), incl. gangs only it can place
+    python tests/soak.py market 2000        # market-driven rounds (asched_set_market): tied and distinct bids, gangs, away types, rate limits
     python tests/soak.py away 1500          # crowded rounds with a third of the running jobs cross-pool away jobs and "<queue>-away" contexts (tests/test_z_cross_pool_away.py)
     python tests/soak.py features 400       # tests/test_z_feature_mix.py rounds (affinity, conditional away, extra column, limits ...)
     python tests/soak.py ops 3000           # tests/test_z_nodedb_op_sequences.py NodeDb-level operation sequences
@@ -90,6 +91,9 @@ def main():
                 import test_z_optimiser_round as T
                 u, e_, r_ = T.compare(hs, orc, [seed], case=T._gang_case if seed % 2 else None)
                 assert r_ == 0, "refused"
+            elif kind == "market":   # market-driven rounds (tests/test_z_market_round.py): spot price, billing and overrides compared as well
+                import test_z_market_round as T
+                T.compare(hs, orc, [seed])
             elif kind == "streams":   # medium rounds that spend most of their time in stream runs / the gang ring (HS_STREAM_EAGER=1 python tests/soak.py streams N: a run wherever one can start)
                 rng = np.random.default_rng(seed)
                 nn, nj, nq = int(rng.integers(100, 1500)), int(rng.integers(2000, 20000)), int(rng.integers(2, 40))
