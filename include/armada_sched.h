@@ -578,7 +578,7 @@ int32_t ASCHED_FN(set_optimiser)(asched_t*, const asched_optimiser_config* cfg);
      - order each queue's evicted jobs with jobdb.MarketSchedulingOrderCompare (pqs.go:292-295, jobdb/comparison.go:113-170) and merge them with the queued jobs by the
        same comparer (MarketDrivenMultiJobsIterator, jobiteration.go:232-321; the caller passes asched_queues.queued_jobs in that order: jobdb.PriceOrder);
      - pick the next queue with MarketBasedCandidateGangIterator (market_iterator.go: bid price, running before queued, round robin between queues at the same price ...),
-       a literal container/heap because its Less reads the previous result; the queues are pushed in name order (the reference ranges over a Go map);
+       a literal container/heap because its Less reads the previous result; the queues are pushed in queue-index order (the reference ranges over a Go map);
      - set the spot price to the lowest bid of the gang that takes the DRF cost of what this pass has scheduled beyond spot_price_cutoff, mark what is in the queue
        contexts at that moment billable, and bill the price-setting queue the highest competing bid (queue_scheduler.go:177-203);
      - do not run the fairness optimiser (pqs.go:224).
