@@ -756,11 +756,12 @@ class Scheduler:
     def optimiser_schedule_job(self, job: int, min_improvement_pct: float = 0.0, max_job_size_to_preempt=None, now_ms: int = 0, per_node: bool = False):
         """scheduleOnNodes of the fairness optimiser for one job -> dict(node, cost, impact, preempted[, scores: [N] (scheduled, npre, cost, impact)])"""
         out = COptResult()
-        pre = (C.c_int32 * 256)()
+        cap = max(256, self.num_jobs)
+        pre = (C.c_int32 * cap)()
         ms = None if max_job_size_to_preempt is None else _arr(max_job_size_to_preempt, np.int64)
         scores = (COptNodeScore * max(self.num_nodes, 1))() if per_node else None
-        self._check(self.lib.optimiser_schedule_job(self.h, job, float(min_improvement_pct), _ptr(ms, C.c_int64), int(now_ms), C.byref(out), pre, 256, scores))
-        r = dict(node=out.node, cost=out.scheduling_cost, impact=out.maximum_queue_impact, preempted=[pre[i] for i in range(min(out.num_preempted, 256))])
+        self._check(self.lib.optimiser_schedule_job(self.h, job, float(min_improvement_pct), _ptr(ms, C.c_int64), int(now_ms), C.byref(out), pre, cap, scores))
+        r = dict(node=out.node, cost=out.scheduling_cost, impact=out.maximum_queue_impact, preempted=[pre[i] for i in range(min(out.num_preempted, cap))])
         if per_node:
             r["scores"] = [(bool(s.scheduled), s.num_preempted, s.scheduling_cost, s.maximum_queue_impact) for s in scores[: self.num_nodes]]
         return r

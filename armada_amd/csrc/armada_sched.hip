@@ -44,6 +44,10 @@ struct Mailbox {
 };
 __shared__ Mailbox g_mb;
 __shared__ Dev g_dev;
+#ifdef ASCHED_AUX_TU
+__shared__ MktDev g_mk;   // market-driven rounds (round_mkt.h): this launch's market state, a kernel argument of k_control_aux
+__device__ static inline MktDev* mktDev() { return &g_mk; }
+#endif
 
 // Helper workgroups.  A round launch carries H extra workgroups (one per CU) that spin on a mailbox in HBM and take a share of
 // the two read-only full-width queries of the generic path: the first-fit plane scan (OP_SCAN) and the per-node evaluation of
@@ -1534,6 +1538,14 @@ __global__ __launch_bounds__(128) void k_opt_score(Dev d, OptArgs a, const doubl
 __global__ void k_opt_detail(Dev d, OptArgs a, const double* qCost, const int32_t* off, const int32_t* jobs, int n, OptNodeOut* out, int32_t* pre) {
   if (blockIdx.x == 0 && threadIdx.x == 0) optScoreNode(d, a, qCost, off, jobs, d.jLeaseMs, n, out, pre);
 }
+// nodes with more than OPT_MAXJ candidates (k_opt_score reported overflow): the same routine with the entry list in an HBM scratch sized by the node's job count
+__global__ void k_opt_score_big(Dev d, OptArgs a, const double* qCost, const int32_t* off, const int32_t* jobs, const int32_t* nodes, const long long* eOff, int nb, OptEntry* scratch, OptNodeOut* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nb) { int n = nodes[i]; optScoreNodeE(d, a, qCost, off, jobs, d.jLeaseMs, n, &out[n], nullptr, scratch + eOff[i], off[n + 1] - off[n]); }
+}
+__global__ void k_opt_detail_big(Dev d, OptArgs a, const double* qCost, const int32_t* off, const int32_t* jobs, int n, OptNodeOut* out, int32_t* pre, OptEntry* scratch) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) optScoreNodeE(d, a, qCost, off, jobs, d.jLeaseMs, n, out, pre, scratch, off[n + 1] - off[n]);
+}
 
 __global__ void k_shape_mask(Dev d, const uint64_t* classMask, const int32_t* shapeClass) {
   const DevCfg& c = d.cfg;
@@ -1774,7 +1786,10 @@ static void plat_d2h(void* d, const void* s, size_t n) {
 static double plat_last_control_ms() { return t_ctx ? (double)t_ctx->lastControlMs : 0.0; }
 static int plat_last_control_launches() { return t_ctx ? t_ctx->lastControlLaunches : 0; }
 
-extern "C" int asched_internal_aux_launch(const Dev* dev, int cmd, hipStream_t stream, void* helpBox);  // armada_sched_aux.hip
+extern "C" int asched_internal_aux_launch(const Dev* dev, int cmd, hipStream_t stream, void* helpBox, const MktDev* mk);  // armada_sched_aux.hip
+// market-driven rounds: the market state the next auxiliary launch of this thread's handle runs with (asched_host.inc sets it around CMD_MARKET_ROUND)
+static thread_local const MktDev* t_mkt = nullptr;
+static void plat_set_market_dev(const MktDev* m) { t_mkt = m; }
 static int plat_run_control(Dev& dev, int cmd) {
   PlatCtx* c = t_ctx;
   if (c->failed) return -1;  // an earlier upload failed: the kernel would read unset pointers
@@ -1789,7 +1804,7 @@ static int plat_run_control(Dev& dev, int cmd) {
   if (!hipOk(hipMemsetAsync(c->helpBox, 0, sizeof(HelpBox), c->stream), "help box reset")) return -1;
   (void)hipEventRecord(c->ev0, c->stream);
   if (cmd >= CMD_AUX_FIRST) {  // submit-check commands: their kernel lives in its own code object (armada_sched_aux.hip)
-    if (asched_internal_aux_launch(&dev, cmd, c->stream, c->helpBox)) { c->err = "k_control_aux launch failed"; return -1; }
+    if (asched_internal_aux_launch(&dev, cmd, c->stream, c->helpBox, t_mkt)) { c->err = "k_control_aux launch failed"; return -1; }
   } else
   hipLaunchKernelGGL(k_control, dim3(1 + H), dim3(CTL_THREADS), 0, c->stream, dev, cmd, c->helpBox, H);
   (void)hipEventRecord(c->ev1, c->stream);
@@ -1856,7 +1871,7 @@ static int plat_evict_apply(Dev& d, int phase3, int total) {
 }
 // fairness optimiser: every node scored for one job (k_opt_score), scores downloaded; detailNode >= 0: that node's preemption list as well
 static float g_lastOptMs = 0.f;
-static int plat_opt_score(Dev& d, const OptArgs& a, std::vector<OptNodeOut>& scores, double* jobCost, int detailNode, OptNodeOut* detail, int32_t* pre, bool detailOnly = false) {   // detailOnly: the index and scores of the previous call are still in the scratch
+static int plat_opt_score(Dev& d, const OptArgs& a, std::vector<OptNodeOut>& scores, double* jobCost, int detailNode, OptNodeOut* detail, std::vector<int32_t>* pre, bool detailOnly = false) {   // detailOnly: the index and scores of the previous call are still in the scratch
   PlatCtx* c = t_ctx;
   int N = d.cfg.N, M = d.cfg.M, Q = d.cfg.Q;
   // one allocation, carved: [scores N+1][queue costs Q+1][cnt N+1][off N+2][cursor N+1][jobs M][pre OPT_MAXJ]
@@ -1874,12 +1889,29 @@ static int plat_opt_score(Dev& d, const OptArgs& a, std::vector<OptNodeOut>& sco
   OptNodeOut* out = (OptNodeOut*)base; double* qCost = (double*)(base + bOut);
   int32_t* cnt = (int32_t*)(base + bOut + bQ); int32_t* off = (int32_t*)(base + bOut + bQ + bN); int32_t* cursor = (int32_t*)(base + bOut + bQ + 2 * bN);
   int32_t* jobs = (int32_t*)(base + bOut + bQ + 3 * bN); int32_t* dPre = (int32_t*)(base + bOut + bQ + 3 * bN + bM);
-  if (ok && detailOnly) {
-    hipLaunchKernelGGL(k_opt_detail, dim3(1), dim3(64), 0, c->stream, d, a, (const double*)qCost, (const int32_t*)off, (const int32_t*)jobs, detailNode, out + N, dPre);
-    ok = hipOk(hipGetLastError(), "optimiser launch") && hipOk(hipMemcpyAsync(detail, out + N, sizeof(OptNodeOut), hipMemcpyDeviceToHost, c->stream), "opt detail") &&
-         hipOk(hipMemcpyAsync(pre, dPre, sizeof(int32_t) * OPT_MAXJ, hipMemcpyDeviceToHost, c->stream), "opt detail") && hipOk(hipStreamSynchronize(c->stream), "optimiser kernels");
-    return ok ? 0 : -1;
-  }
+  // the preemption list of one node: the private entry list when its job count fits, an HBM list otherwise
+  auto runDetail = [&]() -> bool {
+    int32_t o2[2] = {0, 0};
+    if (!hipOk(hipMemcpy(o2, off + detailNode, sizeof o2, hipMemcpyDeviceToHost), "opt detail")) return false;
+    int cnt = o2[1] - o2[0];
+    if (cnt <= OPT_MAXJ) {
+      pre->assign(OPT_MAXJ, -1);
+      hipLaunchKernelGGL(k_opt_detail, dim3(1), dim3(64), 0, c->stream, d, a, (const double*)qCost, (const int32_t*)off, (const int32_t*)jobs, detailNode, out + N, dPre);
+      return hipOk(hipGetLastError(), "optimiser launch") && hipOk(hipMemcpyAsync(detail, out + N, sizeof(OptNodeOut), hipMemcpyDeviceToHost, c->stream), "opt detail") &&
+             hipOk(hipMemcpyAsync(pre->data(), dPre, sizeof(int32_t) * OPT_MAXJ, hipMemcpyDeviceToHost, c->stream), "opt detail") && hipOk(hipStreamSynchronize(c->stream), "optimiser kernels");
+    }
+    pre->assign((size_t)cnt, -1);
+    OptEntry* es = nullptr; int32_t* dp = nullptr;
+    bool k = hipOk(hipMalloc(&es, sizeof(OptEntry) * (size_t)cnt), "optimiser scratch") && hipOk(hipMalloc(&dp, sizeof(int32_t) * (size_t)cnt), "optimiser scratch");
+    if (k) {
+      hipLaunchKernelGGL(k_opt_detail_big, dim3(1), dim3(64), 0, c->stream, d, a, (const double*)qCost, (const int32_t*)off, (const int32_t*)jobs, detailNode, out + N, dp, es);
+      k = hipOk(hipGetLastError(), "optimiser launch") && hipOk(hipMemcpyAsync(detail, out + N, sizeof(OptNodeOut), hipMemcpyDeviceToHost, c->stream), "opt detail") &&
+          hipOk(hipMemcpyAsync(pre->data(), dp, sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToHost, c->stream), "opt detail") && hipOk(hipStreamSynchronize(c->stream), "optimiser kernels");
+    }
+    (void)hipFree(es); (void)hipFree(dp);
+    return k;
+  };
+  if (ok && detailOnly) return runDetail() ? 0 : -1;
   if (ok) {
     (void)hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(N + 1), c->stream);
     hipLaunchKernelGGL(k_opt_count, dim3(bulkGrid(M)), dim3(256), 0, c->stream, d, cnt);
@@ -1889,7 +1921,6 @@ static int plat_opt_score(Dev& d, const OptArgs& a, std::vector<OptNodeOut>& sco
     (void)hipEventRecord(c->fitEv0, c->stream);
     hipLaunchKernelGGL(k_opt_score, dim3((N + 127) / 128), dim3(128), 0, c->stream, d, a, (const double*)qCost, (const int32_t*)off, (const int32_t*)jobs, out);
     (void)hipEventRecord(c->fitEv1, c->stream);
-    if (detailNode >= 0) hipLaunchKernelGGL(k_opt_detail, dim3(1), dim3(64), 0, c->stream, d, a, (const double*)qCost, (const int32_t*)off, (const int32_t*)jobs, detailNode, out + N, dPre);
     ok = hipOk(hipGetLastError(), "optimiser launch") && hipOk(hipStreamSynchronize(c->stream), "optimiser kernels");
     (void)hipEventElapsedTime(&g_lastOptMs, c->fitEv0, c->fitEv1);
   }
@@ -1897,8 +1928,31 @@ static int plat_opt_score(Dev& d, const OptArgs& a, std::vector<OptNodeOut>& sco
     scores.resize(N);
     if (N) ok = hipOk(hipMemcpy(scores.data(), out, sizeof(OptNodeOut) * (size_t)N, hipMemcpyDeviceToHost), "opt scores");
     if (ok) ok = hipOk(hipMemcpy(jobCost, qCost + Q, sizeof(double), hipMemcpyDeviceToHost), "opt job cost");
-    if (ok && detailNode >= 0) ok = hipOk(hipMemcpy(detail, out + N, sizeof(OptNodeOut), hipMemcpyDeviceToHost), "opt detail") && hipOk(hipMemcpy(pre, dPre, sizeof(int32_t) * OPT_MAXJ, hipMemcpyDeviceToHost), "opt detail");
   }
+  if (ok) {   // nodes whose candidates did not fit the private list: scored again with a list in HBM (one thread per such node; they are few)
+    std::vector<int32_t> big;
+    for (int n = 0; n < N; n++) if (scores[n].scheduled < 0) big.push_back(n);
+    if (!big.empty()) {
+      std::vector<int32_t> hOff((size_t)N + 2);
+      ok = hipOk(hipMemcpy(hOff.data(), off, sizeof(int32_t) * (size_t)(N + 1), hipMemcpyDeviceToHost), "opt index");
+      std::vector<long long> eOff(big.size());
+      long long total = 0;
+      for (size_t i = 0; i < big.size(); i++) { eOff[i] = total; total += hOff[big[i] + 1] - hOff[big[i]]; }
+      OptEntry* es = nullptr; int32_t* dn = nullptr; long long* de = nullptr;
+      ok = ok && hipOk(hipMalloc(&es, sizeof(OptEntry) * (size_t)std::max<long long>(total, 1)), "optimiser scratch") && hipOk(hipMalloc(&dn, sizeof(int32_t) * big.size()), "optimiser scratch") &&
+           hipOk(hipMalloc(&de, sizeof(long long) * big.size()), "optimiser scratch");
+      if (ok) {
+        (void)hipMemcpyAsync(dn, big.data(), sizeof(int32_t) * big.size(), hipMemcpyHostToDevice, c->stream);
+        (void)hipMemcpyAsync(de, eOff.data(), sizeof(long long) * big.size(), hipMemcpyHostToDevice, c->stream);
+        hipLaunchKernelGGL(k_opt_score_big, dim3(((int)big.size() + 63) / 64), dim3(64), 0, c->stream, d, a, (const double*)qCost, (const int32_t*)off, (const int32_t*)jobs, (const int32_t*)dn, (const long long*)de,
+                           (int)big.size(), es, out);
+        ok = hipOk(hipGetLastError(), "optimiser launch") && hipOk(hipStreamSynchronize(c->stream), "optimiser kernels");
+        for (size_t i = 0; ok && i < big.size(); i++) ok = hipOk(hipMemcpy(&scores[big[i]], out + big[i], sizeof(OptNodeOut), hipMemcpyDeviceToHost), "opt scores");
+      }
+      (void)hipFree(es); (void)hipFree(dn); (void)hipFree(de);
+    }
+  }
+  if (ok && detailNode >= 0) ok = runDetail();
   return ok ? 0 : -1;
 }
 static double plat_last_opt_ms() { return (double)g_lastOptMs; }
@@ -2111,9 +2165,9 @@ static int plat_run_fair_shares(Dev& dev, int q, const int32_t* nameRank, const 
 // (k_control_aux: the submit-check commands, round_run.h runAuxCommand) and no host ABI.  A separate translation unit = a
 // separate code object: whatever is added to the auxiliary commands can never move a register, an LDS offset or an inlining
 // decision in the round kernel, whose code is the measured one.
-__global__ __launch_bounds__(CTL_THREADS) void k_control_aux(Dev dev, int cmd, HelpBox* box) {
+__global__ __launch_bounds__(CTL_THREADS) void k_control_aux(Dev dev, int cmd, HelpBox* box, MktDev mk) {
   // workgroup 0 of k_control without helper workgroups: wave 0 runs the command, the other waves serve its mailbox
-  if (threadIdx.x == 0) { g_box = box; g_H = 0; g_gen = 0; }
+  if (threadIdx.x == 0) { g_box = box; g_H = 0; g_gen = 0; g_mk = mk; }
   {
     const int* src = (const int*)&dev; int* dst = (int*)&g_dev;
     for (int i = threadIdx.x; i < (int)(sizeof(Dev) / sizeof(int)); i += blockDim.x) dst[i] = src[i];
@@ -2158,8 +2212,9 @@ __global__ __launch_bounds__(CTL_THREADS) void k_control_aux(Dev dev, int cmd, H
   __syncthreads();
   relocateOut();
 }
-extern "C" __attribute__((visibility("hidden"))) int asched_internal_aux_launch(const Dev* dev, int cmd, hipStream_t stream, void* helpBox) {
-  hipLaunchKernelGGL(k_control_aux, dim3(1), dim3(CTL_THREADS), 0, stream, *dev, cmd, (HelpBox*)helpBox);
+extern "C" __attribute__((visibility("hidden"))) int asched_internal_aux_launch(const Dev* dev, int cmd, hipStream_t stream, void* helpBox, const MktDev* mk) {
+  MktDev none; memset(&none, 0, sizeof none);
+  hipLaunchKernelGGL(k_control_aux, dim3(1), dim3(CTL_THREADS), 0, stream, *dev, cmd, (HelpBox*)helpBox, mk ? *mk : none);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 #endif  // ASCHED_AUX_TU

@@ -151,11 +151,6 @@ struct RoundScalars {
   int64_t statSeg[40];       // [24..39]: (profiling builds) segments of the generic iteration
   int64_t gsT;                     // (profiling builds) shader-clock ticks per segment of a fast iteration
   int64_t statClk[8];        // shader-clock ticks per phase of the round (device builds): evict, replay, pass 1, oversub evict, pass 2, unbind+results
-  // (kept at the END of the struct: the round kernel's code addresses the fields above by offset and must not move — tools/kcontrol_isa_hash.sh)
-  // market-driven round (round_mkt.h; runs in the auxiliary kernel): MarketIteratorPQ's previous result, sctx.SpotPrice, QueueScheduler's scheduledResource
-  int32_t market, mkHeapN, mkPrevRank, hasSpotPrice;
-  double mkPrevCost, spotCutoff, spotPrice;
-  int64_t mkSchedRes[MAXR];
 };
 
 // the per-queue iterator / heap arrays a QueueScheduler-style loop owns; a second set lets the eviction-order replay run
@@ -299,12 +294,23 @@ struct Dev {
   int64_t* qNewJobNs;     // [Q] qctx.TotalNewJobSchedulingTime
   volatile int32_t* cancel;    // host-mapped word: != 0 = the caller's context is done (hard timeout / cancel, queue_scheduler.go:105-112); NULL = never
   volatile int32_t* progress;  // optional host-visible heartbeat (ASCHED_PROGRESS=1): [0] loop iterations, [1] phase, [2] current wide op, [3] wide ops issued
-  // market-driven rounds (asched_set_market): bid per job, the pool-wide rank of every job under jobdb.MarketSchedulingOrderCompare and the per-queue job order sorted by
-  // it, MarketIteratorPQ (items = queues; heap[] is pq.items), MarketDrivenMultiJobsIterator's two held values per queue, billing
-  struct MktDev {
-    double* jBid; int64_t* jSubmit; int64_t* jRunTs; int32_t* jRank; int32_t* ord;
-    int32_t* heap; double* pqPrice; int64_t* pqRuntime; int64_t* pqSubmit; uint8_t* pqQueued;
-    int32_t* itV1; int32_t* itV2;
-    int64_t* qBillable; double* qOverride; uint8_t* qHasOverride; uint8_t* jobBillable;
-  } mk;
+};
+
+// Market-driven rounds (asched_set_market; round_mkt.h).  Deliberately NOT part of Dev / RoundScalars: those two are copied into the round kernel's LDS, and the round
+// kernel's code object must not change with a feature it does not run (placement-sensitive; tools/kcontrol_isa_hash.sh).  The auxiliary kernel receives this
+// struct as a kernel argument of its own.
+struct MktScalars {   // MarketIteratorPQ's previous result, sctx.SpotPrice, QueueScheduler's scheduledResource
+  int32_t market, heapN, prevRank, hasSpotPrice;
+  double prevCost, spotCutoff, spotPrice;
+  int64_t schedRes[MAXR];
+};
+struct MktDev {
+  MktScalars* s;
+  // bid per job, the pool-wide rank of every job under jobdb.MarketSchedulingOrderCompare and the per-queue job order sorted by it
+  double* jBid; int64_t* jSubmit; int64_t* jRunTs; int32_t* jRank; int32_t* ord;
+  // MarketIteratorPQ (items = queues; heap[] is pq.items), MarketDrivenMultiJobsIterator's two held values per queue
+  int32_t* heap; double* pqPrice; int64_t* pqRuntime; int64_t* pqSubmit; uint8_t* pqQueued;
+  int32_t* itV1; int32_t* itV2;
+  // billing
+  int64_t* qBillable; double* qOverride; uint8_t* qHasOverride; uint8_t* jobBillable;
 };

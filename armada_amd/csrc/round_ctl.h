@@ -386,7 +386,7 @@ DEV bool sctxEvictJob(Dev& d, int job) {
     if (sched) { vadd(d, QPV(d.qSchedByPc, q, pc), req, -1); f &= ~F_SUCCESSFUL; }
     if (resched) f &= ~F_RESCHEDULED;
     // context/queue.go:368-376: a billable jctx that leaves the queue context takes its AllResourceRequirements out of the bill
-    MK(if (mkOn(d) && d.mk.jobBillable[job]) { vadd(d, QV(d.mk.qBillable, q), req, -1); d.mk.jobBillable[job] = 0; })
+    MK(if (mkOn(d) && MKD.jobBillable[job]) { vadd(d, QV(MKD.qBillable, q), req, -1); MKD.jobBillable[job] = 0; })
   } else {
     vadd(d, QPV(d.qEvictedByPc, q, pc), req, +1);
     f |= F_EVICTED;
@@ -1048,15 +1048,15 @@ DEV void resetJctxForQueued(Dev& d, int job) {  // JobSchedulingContextFromJob (
 DEV int jobItNext(Dev& d, int q, bool withQueued) {  // MultiJobsIterator(evicted, queued) :179-228
 #ifdef ASCHED_MARKET_ROUND
   if (mkOn(d) && withQueued) {   // MarketDrivenMultiJobsIterator.Next (jobiteration.go:250-294; pqs.go:730-731: only when there is a jobRepo)
-    if (d.mk.itV1[q] < 0 && d.itEi[q] < d.evOff[q + 1]) d.mk.itV1[q] = d.evList[d.itEi[q]++];                       // InMemoryJobIterator.Next: every entry is an evicted job
-    if (d.mk.itV2[q] < 0 && !d.itJobOnlyEv[q] && d.itQi[q] < d.queuedOff[q + 1]) { int job = d.queuedJobs[d.itQi[q]++]; resetJctxForQueued(d, job); d.mk.itV2[q] = job; }   // QueuedJobsIterator.Next :152-161
-    int j1 = d.mk.itV1[q], j2 = d.mk.itV2[q];
+    if (MKD.itV1[q] < 0 && d.itEi[q] < d.evOff[q + 1]) MKD.itV1[q] = d.evList[d.itEi[q]++];                       // InMemoryJobIterator.Next: every entry is an evicted job
+    if (MKD.itV2[q] < 0 && !d.itJobOnlyEv[q] && d.itQi[q] < d.queuedOff[q + 1]) { int job = d.queuedJobs[d.itQi[q]++]; resetJctxForQueued(d, job); MKD.itV2[q] = job; }   // QueuedJobsIterator.Next :152-161
+    int j1 = MKD.itV1[q], j2 = MKD.itV2[q];
     if (j1 >= 0 && j2 >= 0) {
-      if (d.mk.jRank[j1] < d.mk.jRank[j2]) { d.mk.itV1[q] = -1; return j1; }   // MarketSchedulingOrderCompare(j1, j2) < 0: the pool-wide rank under that order (asched_host.inc)
-      d.mk.itV2[q] = -1; return j2;
+      if (MKD.jRank[j1] < MKD.jRank[j2]) { MKD.itV1[q] = -1; return j1; }   // MarketSchedulingOrderCompare(j1, j2) < 0: the pool-wide rank under that order (asched_host.inc)
+      MKD.itV2[q] = -1; return j2;
     }
-    if (j1 >= 0) { d.mk.itV1[q] = -1; return j1; }
-    if (j2 >= 0) { d.mk.itV2[q] = -1; return j2; }
+    if (j1 >= 0) { MKD.itV1[q] = -1; return j1; }
+    if (j2 >= 0) { MKD.itV2[q] = -1; return j2; }
     return -1;
   }
 #endif
@@ -1071,7 +1071,7 @@ DEV int jobItNext(Dev& d, int q, bool withQueued) {  // MultiJobsIterator(evicte
 DEV void gangItOnlyEvicted(Dev& d, int q) {  // :338-350
   if (d.itGangOnlyEv[q]) return;
   d.itGangOnlyEv[q] = 1; d.itJobOnlyEv[q] = 1;
-  MK(if (mkOn(d) && d.mk.itV2[q] >= 0 && !d.jcEvicted[d.mk.itV2[q]]) d.mk.itV2[q] = -1;)   // MarketDrivenMultiJobsIterator.OnlyYieldEvicted :296-309 (it1Value is always an evicted job)
+  MK(if (mkOn(d) && MKD.itV2[q] >= 0 && !d.jcEvicted[MKD.itV2[q]]) MKD.itV2[q] = -1;)   // MarketDrivenMultiJobsIterator.OnlyYieldEvicted :296-309 (it1Value is always an evicted job)
   int nx = d.itNext[q];
   if (nx != -1 && !gcAllEvicted(d, nx)) { d.itStashed[q] = nx; d.itNext[q] = -1; }
 }
@@ -1190,14 +1190,14 @@ DEV void costItOnlyEvicted(Dev& d, Ctl& c, const PassCfg& pc) {  // :521-544
 #ifdef ASCHED_MARKET_ROUND
   if (mkOn(d)) {   // MarketBasedCandidateGangIterator.OnlyYieldEvicted (market_iterator.go:153-176): the items in array order, then heap.Init
     if (!c.onlyEvicted) {
-      int n = d.rs->mkHeapN, m = 0;
+      int n = MKS.heapN, m = 0;
       for (int i = 0; i < n; i++) {
-        int q = d.mk.heap[i];
+        int q = MKD.heap[i];
         gangItOnlyEvicted(d, q);
         updateItem(d, c, q, pc);
-        if (d.pqGctx[q] != -1) d.mk.heap[m++] = q; else d.pqInHeap[q] = 0;
+        if (d.pqGctx[q] != -1) MKD.heap[m++] = q; else d.pqInHeap[q] = 0;
       }
-      d.rs->mkHeapN = m;
+      MKS.heapN = m;
       mkInit(d);
     }
     c.onlyEvicted = 1;
@@ -1218,7 +1218,7 @@ DEV void costItOnlyEvictedForQueue(Dev& d, Ctl& c, int q, const PassCfg& pc) {  
 #ifdef ASCHED_MARKET_ROUND
   if (mkOn(d)) {   // OnlyYieldEvictedForQueue (market_iterator.go:185-201): heap.Remove / heap.Fix at the item's index
     if (!c.onlyEvicted && !d.onlyEvByQueue[q]) {
-      for (int i = 0; i < d.rs->mkHeapN; i++) if (d.mk.heap[i] == q) {
+      for (int i = 0; i < MKS.heapN; i++) if (MKD.heap[i] == q) {
         gangItOnlyEvicted(d, q);
         updateItem(d, c, q, pc);
         if (d.pqGctx[q] == -1) mkRemove(d, i); else mkFix(d, i);
@@ -1252,7 +1252,7 @@ DEV void costItClear(Dev& d, Ctl& c, int top, const PassCfg& pc) {  // :595-606
   if (mkOn(d)) {   // MarketBasedCandidateGangIterator.Clear (market_iterator.go:74-89): Pop, item.it.Clear(), remember the result, update and push
     int q = mkPop(d);
     d.itNext[q] = -1;
-    d.rs->mkPrevRank = d.qNameRank[q]; d.rs->mkPrevCost = d.mk.pqPrice[q];
+    MKS.prevRank = d.qNameRank[q]; MKS.prevCost = MKD.pqPrice[q];
     updateAndPush(d, c, q, pc);
     return;
   }
@@ -1271,9 +1271,9 @@ DEV void passInit(Dev& d, Ctl& c, const PassCfg& pc) {
     d.itJobOnlyEv[q] = 0; d.itGangOnlyEv[q] = 0; d.onlyEvByQueue[q] = 0; d.pqInHeap[q] = 0;
     d.pqBudget[q] = d.qDc[q] / d.qWeight[q];  // pushQueue :509-519
     if (d.qsSave && q < QCAPF) d.qsSave[q].valid = 0;   // a new pass: no stream carries over
-    MK(if (mkOn(d)) { d.mk.itV1[q] = -1; d.mk.itV2[q] = -1; })
+    MK(if (mkOn(d)) { MKD.itV1[q] = -1; MKD.itV2[q] = -1; })
   }
-  MK(if (mkOn(d)) { d.rs->mkHeapN = 0; d.rs->mkPrevCost = 0.0; d.rs->mkPrevRank = -1; })   // a fresh MarketIteratorPQ (NewMarketCandidateGangIterator :38-60; previousResultQueue "" orders before every name)
+  MK(if (mkOn(d)) { MKS.heapN = 0; MKS.prevCost = 0.0; MKS.prevRank = -1; })   // a fresh MarketIteratorPQ (NewMarketCandidateGangIterator :38-60; previousResultQueue "" orders before every name)
   c.onlyEvicted = 0;
   for (int q = 0; q < Q; q++) updateAndPush(d, c, q, pc);
 }
@@ -1292,27 +1292,27 @@ DEV void passInit(Dev& d, Ctl& c, const PassCfg& pc) {
 DEV_COLD void mkAfterScheduled(Dev& d, int ref, int gangQueue) {
   const DevCfg& cf = d.cfg;
   const int64_t* tot = gcTotal(d, ref);
-  for (int r = 0; r < cf.R; r++) d.rs->mkSchedRes[r] += tot[r];
-  if (d.rs->hasSpotPrice) return;
-  if (!(drf(d, d.rs->mkSchedRes) > d.rs->spotCutoff)) return;
+  for (int r = 0; r < cf.R; r++) MKS.schedRes[r] += tot[r];
+  if (MKS.hasSpotPrice) return;
+  if (!(drf(d, MKS.schedRes) > MKS.spotCutoff)) return;
   int cnt = gcCount(d, ref);
-  double price = d.mk.jBid ? d.mk.jBid[gcJob(d, ref, 0)] : 0.0;
-  for (int k = 0; k < cnt; k++) { double b = d.mk.jBid ? d.mk.jBid[gcJob(d, ref, k)] : 0.0; if (b < price) price = b; }
-  d.rs->hasSpotPrice = 1; d.rs->spotPrice = price;
-  for (int i = 0; i < cf.Q * cf.R; i++) d.mk.qBillable[i] = 0;
+  double price = MKD.jBid ? MKD.jBid[gcJob(d, ref, 0)] : 0.0;
+  for (int k = 0; k < cnt; k++) { double b = MKD.jBid ? MKD.jBid[gcJob(d, ref, k)] : 0.0; if (b < price) price = b; }
+  MKS.hasSpotPrice = 1; MKS.spotPrice = price;
+  for (int i = 0; i < cf.Q * cf.R; i++) MKD.qBillable[i] = 0;
   for (int j = 0; j < cf.M; j++) {                                      // qctx.SetBillableResource (context/queue.go:108-119)
     if (!(d.jobFlags[j] & (F_SUCCESSFUL | F_RESCHEDULED))) continue;
     int q = d.jQueue[j];
     if (q < 0 || q >= cf.Q) continue;
-    d.mk.jobBillable[j] = 1;
-    for (int r = 0; r < cf.R; r++) if (!d.cfg.isFloating[r]) QV(d.mk.qBillable, q)[r] += JREQ(d, j)[r];   // jctx.KubernetesResourceRequirements
+    MKD.jobBillable[j] = 1;
+    for (int r = 0; r < cf.R; r++) if (!d.cfg.isFloating[r]) QV(MKD.qBillable, q)[r] += JREQ(d, j)[r];   // jctx.KubernetesResourceRequirements
   }
-  d.mk.qOverride[gangQueue] = mkSecondPrice(d, gangQueue); d.mk.qHasOverride[gangQueue] = 1;
+  MKD.qOverride[gangQueue] = mkSecondPrice(d, gangQueue); MKD.qHasOverride[gangQueue] = 1;
 }
 #endif
 DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff) {
   bool limitHit = false, resumed = false;
-  MK(if (mkOn(d)) { for (int r = 0; r < MAXR; r++) d.rs->mkSchedRes[r] = 0; if (d.rs->hasFpLimiter) { raise(d, ASCHED_ERR_INVALID, 950); return; } })
+  MK(if (mkOn(d)) { for (int r = 0; r < MAXR; r++) MKS.schedRes[r] = 0; if (d.rs->hasFpLimiter) { raise(d, ASCHED_ERR_INVALID, 950); return; } })
   c.fpLimitHit = 0;
   const bool softClock = d.cfg.maxNewJobNs > 0 || d.cfg.maxNewJobPerQueueNs > 0;
   unsigned pollCount = 0;

@@ -10,7 +10,8 @@
 #pragma once
 #include "round_ctl.h"
 
-#define OPT_MAXJ 48   // preemptible candidates one node may hold for the per-thread walk (more: the node reports overflow and the call is refused)
+#define OPT_MAXJ 48   // preemptible candidates the per-thread walk of k_opt_score keeps in private memory; a node with more reports overflow (scheduled = -1) and is scored
+                      // again with its entries in an HBM scratch list sized by its job count (k_opt_score_big: rare, one thread per such node)
 
 struct OptArgs {
   int32_t job, hasMaxSize;
@@ -47,7 +48,8 @@ DEV bool optGlobalLess(const OptEntry& a, const OptEntry& b) {
 
 // PreemptingNodeScheduler.Schedule for (a.job, node n).  qCost[q] = QueueContext.CurrentCost (scheduling_context.go:19-24), fair share =
 // demand-capped adjusted fair share, weight: the round's queue state.  preOut (optional): the jobs to preempt, in order.
-DEV void optScoreNode(const Dev& d, const OptArgs& a, const double* qCost, const int32_t* nodeOff, const int32_t* nodeJobs, const int64_t* leaseMs, int n, OptNodeOut* out, int32_t* preOut) {
+DEV void optScoreNodeE(const Dev& d, const OptArgs& a, const double* qCost, const int32_t* nodeOff, const int32_t* nodeJobs, const int64_t* leaseMs, int n, OptNodeOut* out, int32_t* preOut,
+                       OptEntry* e, int cap) {
   const DevCfg& c = d.cfg;
   out->scheduled = 0; out->npre = 0; out->cost = 0; out->impact = 0;
   int job = a.job;
@@ -59,7 +61,6 @@ DEV void optScoreNode(const Dev& d, const OptArgs& a, const double* qCost, const
   for (int r = 0; r < MAXR; r++) { avail[r] = r < c.R ? AL(d, c.evLevel, r, n) : 0; if (r < c.R && req[r] > avail[r]) fits = false; }
   if (fits) { out->scheduled = 1; return; }                                   // :57-64: fits without preemption
   int32_t jobPrio = c.pcPriority[d.jPc[job]];
-  OptEntry e[OPT_MAXJ];
   int m = 0;
   for (int k = nodeOff[n]; k < nodeOff[n + 1]; k++) {                         // node.AllocatedByJobId (:137-200)
     int j = nodeJobs[k];
@@ -74,7 +75,7 @@ DEV void optScoreNode(const Dev& d, const OptArgs& a, const double* qCost, const
     int32_t sap = d.schedAtPrio[j];
     if (sap == NO_PRIORITY) continue;
     if (sap > jobPrio) continue;
-    if (m >= OPT_MAXJ) { out->scheduled = -1; return; }                      // overflow: reported to the host
+    if (m >= cap) { out->scheduled = -1; return; }                           // more candidates than this call's entry list holds: scored again with a list in HBM
     OptEntry& x = e[m++];
     x.job = j; x.queue = d.jQueue[j]; x.sap = sap; x.ordinal = 0;
     x.age = d.jNode0[j] < 0 ? 0 : a.nowMs - leaseMs[j];                      // job.Queued() (scheduled in this round): age 0
@@ -122,4 +123,8 @@ DEV void optScoreNode(const Dev& d, const OptArgs& a, const double* qCost, const
     if (imp > impact) impact = imp;
   }
   out->scheduled = 1; out->npre = used; out->cost = total; out->impact = impact;
+}
+DEV void optScoreNode(const Dev& d, const OptArgs& a, const double* qCost, const int32_t* nodeOff, const int32_t* nodeJobs, const int64_t* leaseMs, int n, OptNodeOut* out, int32_t* preOut) {
+  OptEntry e[OPT_MAXJ];
+  optScoreNodeE(d, a, qCost, nodeOff, nodeJobs, leaseMs, n, out, preOut, e, OPT_MAXJ);
 }

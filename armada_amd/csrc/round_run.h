@@ -50,7 +50,7 @@ DEV void evictApply(Dev& d, int j, bool phase3) {
   if (sched || resched) {
     if (sched) { atomicVadd(d, QPV(d.qSchedByPc, q, pc), req, -1); f &= ~F_SUCCESSFUL; }
     if (resched) f &= ~F_RESCHEDULED;
-    MK(if (mkOn(d) && d.mk.jobBillable[j]) { atomicVadd(d, QV(d.mk.qBillable, q), req, -1); d.mk.jobBillable[j] = 0; })   // context/queue.go:368-376
+    MK(if (mkOn(d) && MKD.jobBillable[j]) { atomicVadd(d, QV(MKD.qBillable, q), req, -1); MKD.jobBillable[j] = 0; })   // context/queue.go:368-376
   } else {
     atomicVadd(d, QPV(d.qEvictedByPc, q, pc), req, +1);
     f |= F_EVICTED;
@@ -350,7 +350,7 @@ DEV_COLD COLD_MS_9 int pqsEvict(Dev& d, Ctl& c, bool phase3) {
   // order-preserving compaction of the pre-sorted job order
   // (a market-driven pool orders them with MarketSchedulingOrderCompare, pqs.go:292-295: the same compaction of the job order sorted by that comparer)
   const int32_t* order = d.ordAll;
-  MK(if (mkOn(d)) order = d.mk.ord;)
+  MK(if (mkOn(d)) order = MKD.ord;)
   int n = wgCompactFlagged(d, order, d.ordAllOff, d.cfg.Q, d.ordAllOff[d.cfg.Q], d.evFlag, d.evList, d.evOff);
   d.rs->numEvictedList = n;
   wgBulk(d, B_RESET_EVTAB, d.rs->evictedTableSize);  // nodeDb.Reset() (nodedb.go:299-313)
@@ -1021,7 +1021,7 @@ DEV void runAuxCommand(Dev& d, Ctl& c, int cmd) {
   const DevCfg& cf = d.cfg;
   switch (cmd) {
 #ifdef ASCHED_MARKET_ROUND
-    case CMD_MARKET_ROUND: runRound(d, c); break;   // d.rs->market is set: every market-specific step is behind mkOn(d) (round_mkt.h)
+    case CMD_MARKET_ROUND: runRound(d, c); break;   // MKS.market is set: every market-specific step is behind mkOn(d) (round_mkt.h)
 #endif
     case CMD_PQ_ORDER: {
       // sort.Sort over QueueCandidateGangIteratorPQ.Less (queue_scheduler.go:738-798) — the float goldens of queue_scheduler_test.go:995-1164.

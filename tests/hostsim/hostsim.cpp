@@ -15,6 +15,8 @@
 #include <time.h>
 #include "../../armada_amd/csrc/round_run.h"
 #include "../../armada_amd/csrc/round_opt.h"
+static thread_local MktDev g_mk;   // market-driven rounds (round_mkt.h): the market state of the launch in progress (a kernel argument on the device)
+DEV MktDev* mktDev() { return &g_mk; }
 // optional per-primitive wall-clock profile of the serial build (HOSTSIM_PROF=1): where would a wide device primitive matter?
 struct HsProf { double t[40]; long n[40]; bool on; HsProf() : on(getenv("HOSTSIM_PROF") != nullptr) { for (int i = 0; i < 40; i++) { t[i] = 0; n[i] = 0; } }
   ~HsProf() { if (on) for (int i = 0; i < 40; i++) if (n[i]) fprintf(stderr, "hsprof[%d] calls=%ld total=%.3fs\n", i, n[i], t[i]); } };
@@ -116,6 +118,7 @@ static double plat_last_control_ms() { return 0; }
 static int plat_last_control_launches() { return 0; }
 static double plat_last_fit_ms() { return 0; }
 static const char* plat_last_error() { return g_err.c_str(); }
+static void plat_set_market_dev(const MktDev* m) { if (m) g_mk = *m; else memset(&g_mk, 0, sizeof g_mk); }
 static int plat_run_control(Dev& dev, int cmd) {
   Dev d = dev;
   d.cancel = &t_ctx->cancelWord;
@@ -223,7 +226,7 @@ static int plat_delta_resolve(Dev& d, const long long* red, int ns, int np, int3
 // fairness optimiser: the per-node routine of round_opt.h over all nodes, serially
 static const double* g_lastQCost = nullptr;
 static int plat_opt_qcosts(Dev&, double* out, int Q) { for (int q = 0; q < Q; q++) out[q] = g_lastQCost[q]; return 0; }
-static int plat_opt_score(Dev& dev, const OptArgs& a, std::vector<OptNodeOut>& scores, double* jobCost, int detailNode, OptNodeOut* detail, int32_t* pre, bool detailOnly = false) { (void)detailOnly;
+static int plat_opt_score(Dev& dev, const OptArgs& a, std::vector<OptNodeOut>& scores, double* jobCost, int detailNode, OptNodeOut* detail, std::vector<int32_t>* pre, bool detailOnly = false) { (void)detailOnly;
   Dev d = dev;
   int N = d.cfg.N, M = d.cfg.M, Q = d.cfg.Q;
   std::vector<int32_t> off(N + 2, 0), jobs(2 * (size_t)std::max(M, 1));
@@ -237,8 +240,14 @@ static int plat_opt_score(Dev& dev, const OptArgs& a, std::vector<OptNodeOut>& s
   g_lastQCost = qCost.data();
   *jobCost = drf(d, JREQ(d, a.job));
   scores.resize(N);
-  for (int n = 0; n < N; n++) optScoreNode(d, a, qCost.data(), off.data(), jobs.data(), d.jLeaseMs, n, &scores[n], nullptr);
-  if (detailNode >= 0) optScoreNode(d, a, qCost.data(), off.data(), jobs.data(), d.jLeaseMs, detailNode, detail, pre);
+  // the device keeps OPT_MAXJ entries per thread and re-scores fuller nodes with a list in HBM (armada_sched.hip plat_opt_score); here: the private list first, the big list on overflow — the same two steps
+  std::vector<OptEntry> big;
+  auto score = [&](int n, OptNodeOut* o, int32_t* p) {
+    optScoreNode(d, a, qCost.data(), off.data(), jobs.data(), d.jLeaseMs, n, o, p && off[n + 1] - off[n] <= OPT_MAXJ ? p : nullptr);
+    if (o->scheduled < 0 || (p && off[n + 1] - off[n] > OPT_MAXJ)) { big.resize((size_t)(off[n + 1] - off[n]) + 1); optScoreNodeE(d, a, qCost.data(), off.data(), jobs.data(), d.jLeaseMs, n, o, p, big.data(), off[n + 1] - off[n]); }
+  };
+  for (int n = 0; n < N; n++) score(n, &scores[n], nullptr);
+  if (detailNode >= 0) { pre->assign((size_t)std::max(off[detailNode + 1] - off[detailNode], OPT_MAXJ), -1); score(detailNode, detail, pre->data()); }
   return 0;
 }
 static double plat_last_opt_ms() { return 0; }

@@ -220,3 +220,31 @@ def test_scores_gpu_equal_oracle_at_scale(hip_lib, oracle_lib):
     """20k nodes, 95% occupied: the wide kernel with every CU busy"""
     res = _differential(hip_lib, oracle_lib, 42, n_nodes=20_000, n_jobs=60_000)
     assert any(r["preempted"] for r in res)
+
+
+# ---- nodes holding more preemptible candidates than the per-thread list of k_opt_score keeps (OPT_MAXJ = 48): scored again with the entry list in HBM
+def _crowded_node_case(lib, per_node=(130, 20, 120)):
+    """three 64-cpu nodes filled with 0.25-cpu jobs of four queues (130 / 20 / 120 of them: the first and third overflow the private list; the second node's jobs
+    are not preemptible), one queued 60-cpu job: it needs more than a hundred victims wherever it goes"""
+    nodes = [(64, 0, False)] * 3
+    jobs = []
+    for n, cnt in enumerate(per_node):
+        for i in range(cnt):
+            jobs.append(("ABCD"[(i * 7 + n) % 4], 0.25, 0, "pc3" if n == 1 else ("pc2" if i % 5 else "pc1"), n, 1000 + (i * 37 + n * 11) % 997))
+    jobs.append(("A", 60, 0, "pc2", -1, 0))
+    s = build(lib, nodes, jobs, [QA, QB, QC, QD])
+    out = s.optimiser_schedule_job(len(jobs) - 1, min_improvement_pct=-1e9, now_ms=5000, per_node=True)
+    s.close()
+    return out
+
+
+def test_more_candidates_than_the_private_list_cpu_build(hostsim_lib, oracle_lib):
+    want, got = _crowded_node_case(oracle_lib), _crowded_node_case(hostsim_lib)
+    assert got == want
+    assert want["node"] >= 0 and len(want["preempted"]) > 48                  # the chosen node really needs more victims than OPT_MAXJ
+    assert sum(1 for sc in want["scores"] if sc[1] > 48) >= 2
+
+
+@pytest.mark.gpu
+def test_more_candidates_than_the_private_list_gpu(hip_lib, oracle_lib):
+    assert _crowded_node_case(hip_lib) == _crowded_node_case(oracle_lib)
