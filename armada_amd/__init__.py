@@ -7,6 +7,7 @@ synthetic workload generators of BASELINE.json.  There is no CPU fallback: loadi
 the HIP library has not been built.
 """
 import os
+import sys
 
 from .binding import Config, Library, Scheduler, SchedError  # noqa: F401
 
@@ -20,6 +21,15 @@ def load_library() -> Library:
     """Load the HIP implementation (prefix ``asched_``). Raises if it has not been built."""
     global _lib
     if _lib is None:
+        # PyTorch bundles its own HIP / HSA runtime; the library links /opt/rocm's.  In one process the runtime that initialises second finds no GPU, so when the
+        # caller uses torch at all (device buffers for the collectives: sharded.py, queuehash.py, bench.py) torch's has to come up first.
+        if "torch" in sys.modules:
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    torch.cuda.init()
+            except Exception:
+                pass
         # ASCHED_LIB_PATH: another build of the SAME HIP sources (e.g. -DASCHED_FASTPROF, the per-segment clock profile); never a different backend
         _lib = Library(os.environ.get("ASCHED_LIB_PATH") or LIB_PATH, "asched_")
     return _lib

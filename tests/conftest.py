@@ -33,11 +33,23 @@ def oracle_lib():
     return Library(_oracle_path(), "oracle_")
 
 
+def _torch_cuda_first():
+    """PyTorch ships its own HIP / HSA runtime next to /opt/rocm's, which the library links: in one process the runtime that initialises SECOND finds no GPU.  The
+    tests that hand the library a torch tensor on the GPU need torch's to be the first (bench.py does the same by calling torch.cuda.set_device before loading the library)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 @pytest.fixture(scope="session")
 def hip_lib():
     """The product: the HIP implementation.  No fallback — missing library is a hard failure.
     ASCHED_GPU_TESTS_DRY_RUN=1 (build container only) substitutes the CPU build of the device code so that the *test code* of the
     `-m gpu` tests can be exercised without a GPU; it proves nothing about the HIP library and is never set by the driver."""
+    _torch_cuda_first()
     if os.environ.get("ASCHED_GPU_TESTS_DRY_RUN") == "1":
         from armada_amd.binding import Library
         here = os.path.join(ROOT, "tests", "hostsim")
