@@ -597,6 +597,26 @@ typedef struct asched_market_outcome {
 } asched_market_outcome;
 int32_t ASCHED_FN(market_result)(asched_t*, asched_market_outcome* out);
 
+/* The indicative gang pricer of a market-driven pool (scheduling/pricer/gang_pricer.go:48-161, node_scheduler.go:41-146; called after the round by
+   MarketDrivenIndicativePricer.Price, preempting_queue_scheduler.go:248-252, 641-664): the lowest price at which a gang could be scheduled on the NodeDb as it stands.
+   Per member, in order, MinPriceNodeScheduler.Schedule scores EVERY node of the uniformity group (one wide pass, k_price_score): static requirements, fit at the
+   evicted priority (price 0), else ALL jobs on the node except the gang's own members — whatever their priority class or preemptibility — ordered by (bid price,
+   age, id) and preempted one at a time until the member fits: price = the last victim's bid.  The node with the lowest price takes the member (the first price-0
+   node in id order wins outright; the reference breaks other ties by a random ULID, here the earlier node id), its victims are unbound and the member is bound
+   (on a transaction that is aborted at the end: no side effects), and the gang's price is the highest member price; over the uniformity groups (label values in
+   ascending interned order) the cheapest schedulable group wins.  `jobs` are rows of the job set (the synthetic jobs of a configuration.GangDefinition are uploaded
+   like any other job, queued nowhere); bids are asched_jobs.bid_price; ages are now_ms minus the lease time.
+   reason: 0, ASCHED_REASON_JOB_DOES_NOT_FIT / ASCHED_REASON_GANG_DOES_NOT_FIT, or one of the two below. */
+#define ASCHED_PRICE_REASON_LABEL_NOT_INDEXED 101   /* "uniformity label is not indexed" (gang_pricer.go:18) */
+#define ASCHED_PRICE_REASON_NO_NODES_WITH_LABEL 102 /* "no nodes with uniformity label" (:19) */
+typedef struct asched_gang_price { int32_t evaluated, schedulable; double price; int32_t reason, pad_; } asched_gang_price;
+int32_t ASCHED_FN(price_gang)(asched_t*, int32_t n, const int32_t* jobs, int64_t now_ms, asched_gang_price* out);
+/* MinPriceNodeScheduler.Schedule (node_scheduler.go:41-107) for one job against every node (test hook for node_scheduler_test.go and the differential tests):
+   per node scheduled / price / number of victims; for `detail_node` >= 0 also its victims in preemption order. */
+typedef struct asched_price_node_score { int32_t scheduled, num_preempted; double price; } asched_price_node_score;
+int32_t ASCHED_FN(price_job_on_nodes)(asched_t*, int32_t job, int64_t now_ms, asched_price_node_score* per_node /*[N]*/, int32_t detail_node,
+                                      int32_t* preempted /*[cap]*/, int32_t cap);
+
 /* 1 if the job's scheduling key is registered in sctx.UnfeasibleSchedulingKeys (gang_scheduler.go:80-95) */
 int32_t ASCHED_FN(job_key_unfeasible)(asched_t*, int32_t job, int32_t* out);
 
