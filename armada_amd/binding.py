@@ -147,6 +147,14 @@ class COptimiserConfig(C.Structure):
                 ("max_resource_fraction_to_schedule", C.POINTER(C.c_double)), ("now_ms", C.c_int64)]
 
 
+class CGangPrice(C.Structure):
+    _fields_ = [("evaluated", C.c_int32), ("schedulable", C.c_int32), ("price", C.c_double), ("reason", C.c_int32), ("pad_", C.c_int32)]
+
+
+class CPriceNodeScore(C.Structure):
+    _fields_ = [("scheduled", C.c_int32), ("num_preempted", C.c_int32), ("price", C.c_double)]
+
+
 class CMarketConfig(C.Structure):
     _fields_ = [("enabled", C.c_uint8), ("pad_", C.c_uint8 * 7), ("spot_price_cutoff", C.c_double)]
 
@@ -211,7 +219,7 @@ ALL_SYMBOLS = [
     "optimiser_schedule_job", "set_optimiser", "set_label_value_ints", "round_timing", "set_deadline", "cancel", "cancel_clear", "indexed_node_label_values", "get_node_jobs", "get_nodes_alloc", "node_upsert",
     "market_iterate", "market_compare", "market_multi_iterate",
     "fit_select_batch_global", "round_delta_words", "round_delta", "round_delta_resolve",
-    "set_market", "market_result",
+    "set_market", "market_result", "price_gang", "price_job_on_nodes",
 ]
 
 
@@ -324,6 +332,8 @@ class Library:
         f("iterate_nodes", C.c_int32, [C.c_void_p, _i64p, C.c_int32, C.c_int32, _i64p, _i32p, C.c_int32, _i32p])
         f("fit_select_batch", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int32, _i32p])
         f("fit_select_batch_global", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int32, C.POINTER(CGlobalKeyLayout), C.c_void_p])
+        f("price_gang", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int64, C.POINTER(CGangPrice)])
+        f("price_job_on_nodes", C.c_int32, [C.c_void_p, C.c_int32, C.c_int64, C.POINTER(CPriceNodeScore), C.c_int32, _i32p, C.c_int32])
         f("set_market", C.c_int32, [C.c_void_p, C.POINTER(CMarketConfig)])
         f("market_result", C.c_int32, [C.c_void_p, C.POINTER(CMarketResult)])
         f("round_delta_words", C.c_int32, [C.c_void_p, _i64p])
@@ -838,6 +848,23 @@ class Scheduler:
         gr = None if global_rank is None else _arr(global_rank, np.int32)
         lay.global_rank = _ptr(gr, C.c_int32) if gr is not None else None
         self._check(self.lib.fit_select_batch_global(self.h, len(ja), _ptr(ja, C.c_int32), priority, C.byref(lay), C.c_void_p(int(out_ptr))))
+
+    def price_gang(self, jobs: Sequence[int], now_ms: int = 0):
+        """GangPricer.Price -> dict(evaluated, schedulable, price, reason)"""
+        ja = _arr(jobs, np.int32)
+        o = CGangPrice()
+        self._check(self.lib.price_gang(self.h, len(ja), _ptr(ja, C.c_int32), int(now_ms), C.byref(o)))
+        return dict(evaluated=bool(o.evaluated), schedulable=bool(o.schedulable), price=float(o.price), reason=int(o.reason))
+
+    def price_job_on_nodes(self, job: int, now_ms: int = 0, detail_node: int = -1):
+        """MinPriceNodeScheduler.Schedule against every node -> ([(scheduled, num_preempted, price)] per node, victims of detail_node in order)"""
+        sc = (CPriceNodeScore * max(self.num_nodes, 1))()
+        cap = max(self.num_jobs, 1)
+        pre = (C.c_int32 * cap)()
+        self._check(self.lib.price_job_on_nodes(self.h, int(job), int(now_ms), sc, int(detail_node), pre, cap))
+        scores = [(bool(x.scheduled), int(x.num_preempted), float(x.price)) for x in sc[: self.num_nodes]]
+        victims = [int(pre[i]) for i in range(scores[detail_node][1])] if detail_node >= 0 else []
+        return scores, victims
 
     def set_market(self, enabled: bool = True, spot_price_cutoff: float = 0.0):
         c = CMarketConfig(); c.enabled = 1 if enabled else 0; c.spot_price_cutoff = float(spot_price_cutoff)

@@ -27,6 +27,7 @@
 #define ASCHED_PREFIX asched_
 #include "round_run.h"
 #include "round_opt.h"
+#include "round_price.h"
 
 // ------------------------------------------------------------------------------------------------ device primitives
 #define CTL_THREADS 256
@@ -1547,6 +1548,15 @@ __global__ void k_opt_detail_big(Dev d, OptArgs a, const double* qCost, const in
   if (blockIdx.x == 0 && threadIdx.x == 0) optScoreNodeE(d, a, qCost, off, jobs, d.jLeaseMs, n, out, pre, scratch, off[n + 1] - off[n]);
 }
 
+// the indicative gang pricer (round_price.h): every node priced for one gang member; the entry list shares the layout of the node -> jobs index
+__global__ __launch_bounds__(128) void k_price_score(Dev d, PriceArgs a, const int32_t* off, const int32_t* jobs, PriceEntry* entries, PriceNodeOut* out) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < d.cfg.N) priceScoreNode(d, a, off, jobs, d.jLeaseMs, n, &out[n], nullptr, entries + off[n]);
+}
+__global__ void k_price_detail(Dev d, PriceArgs a, const int32_t* off, const int32_t* jobs, PriceEntry* entries, int n, PriceNodeOut* out, int32_t* pre) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) priceScoreNode(d, a, off, jobs, d.jLeaseMs, n, out, pre, entries + off[n]);
+}
+
 __global__ void k_shape_mask(Dev d, const uint64_t* classMask, const int32_t* shapeClass) {
   const DevCfg& c = d.cfg;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1956,6 +1966,40 @@ static int plat_opt_score(Dev& d, const OptArgs& a, std::vector<OptNodeOut>& sco
   return ok ? 0 : -1;
 }
 static double plat_last_opt_ms() { return (double)g_lastOptMs; }
+// indicative pricer: every node priced for one job (k_price_score over the node -> jobs index of the current binding state); detailNode >= 0: that node's victims in order
+static int plat_price_score(Dev& d, const PriceArgs& a, std::vector<PriceNodeOut>& scores, int detailNode, std::vector<int32_t>* pre) {
+  PlatCtx* c = t_ctx;
+  int N = d.cfg.N, M = d.cfg.M;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  size_t bOut = up(sizeof(PriceNodeOut) * (size_t)(N + 1)), bN = up(sizeof(int32_t) * (size_t)(N + 2)), bM = up(sizeof(int32_t) * 2 * (size_t)std::max(M, 1)),
+         bE = up(sizeof(PriceEntry) * 2 * (size_t)std::max(M, 1));
+  char* base = nullptr;
+  if (!hipOk(hipMalloc(&base, bOut + 3 * bN + 2 * bM + bE), "pricer scratch")) return -1;
+  PriceNodeOut* out = (PriceNodeOut*)base;
+  int32_t* cnt = (int32_t*)(base + bOut); int32_t* off = (int32_t*)(base + bOut + bN); int32_t* cursor = (int32_t*)(base + bOut + 2 * bN);
+  int32_t* jobs = (int32_t*)(base + bOut + 3 * bN); int32_t* dPre = (int32_t*)(base + bOut + 3 * bN + bM); PriceEntry* entries = (PriceEntry*)(base + bOut + 3 * bN + 2 * bM);
+  (void)hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(N + 1), c->stream);
+  hipLaunchKernelGGL(k_opt_count, dim3(bulkGrid(M)), dim3(256), 0, c->stream, d, cnt);
+  hipLaunchKernelGGL(k_opt_scan, dim3(1), dim3(1024), 0, c->stream, (const int32_t*)cnt, off, cursor, N);
+  hipLaunchKernelGGL(k_opt_scatter, dim3(bulkGrid(M)), dim3(256), 0, c->stream, d, cursor, jobs);
+  (void)hipEventRecord(c->fitEv0, c->stream);
+  hipLaunchKernelGGL(k_price_score, dim3((N + 127) / 128), dim3(128), 0, c->stream, d, a, (const int32_t*)off, (const int32_t*)jobs, entries, out);
+  (void)hipEventRecord(c->fitEv1, c->stream);
+  if (detailNode >= 0) hipLaunchKernelGGL(k_price_detail, dim3(1), dim3(64), 0, c->stream, d, a, (const int32_t*)off, (const int32_t*)jobs, entries, detailNode, out + N, dPre);
+  bool ok = hipOk(hipGetLastError(), "pricer launch") && hipOk(hipStreamSynchronize(c->stream), "pricer kernels");
+  (void)hipEventElapsedTime(&g_lastOptMs, c->fitEv0, c->fitEv1);
+  if (ok) {
+    scores.resize(N);
+    if (N) ok = hipOk(hipMemcpy(scores.data(), out, sizeof(PriceNodeOut) * (size_t)N, hipMemcpyDeviceToHost), "pricer scores");
+    if (ok && detailNode >= 0) {
+      int npre = scores[detailNode].npre;
+      pre->assign((size_t)std::max(npre, 1), -1);
+      if (npre > 0) ok = hipOk(hipMemcpy(pre->data(), dPre, sizeof(int32_t) * (size_t)npre, hipMemcpyDeviceToHost), "pricer victims");
+    }
+  }
+  (void)hipFree(base);
+  return ok ? 0 : -1;
+}
 // the queue costs the last plat_opt_score evaluated (QueueContext.CurrentCost per queue)
 static int plat_opt_qcosts(Dev& d, double* out, int Q) {
   PlatCtx* c = t_ctx;

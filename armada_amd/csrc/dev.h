@@ -151,6 +151,9 @@ struct RoundScalars {
   int64_t statSeg[40];       // [24..39]: (profiling builds) segments of the generic iteration
   int64_t gsT;                     // (profiling builds) shader-clock ticks per segment of a fast iteration
   int64_t statClk[8];        // shader-clock ticks per phase of the round (device builds): evict, replay, pass 1, oversub evict, pass 2, unbind+results
+#ifdef ASCHED_RS_PAD
+  char rsPad_[ASCHED_RS_PAD];   // layout experiments only (tools/lds_layout_sweep.sh): this struct is copied into the round kernel's LDS
+#endif
 };
 
 // the per-queue iterator / heap arrays a QueueScheduler-style loop owns; a second set lets the eviction-order replay run
@@ -294,6 +297,9 @@ struct Dev {
   int64_t* qNewJobNs;     // [Q] qctx.TotalNewJobSchedulingTime
   volatile int32_t* cancel;    // host-mapped word: != 0 = the caller's context is done (hard timeout / cancel, queue_scheduler.go:105-112); NULL = never
   volatile int32_t* progress;  // optional host-visible heartbeat (ASCHED_PROGRESS=1): [0] loop iterations, [1] phase, [2] current wide op, [3] wide ops issued
+#ifdef ASCHED_DEV_PAD
+  char devPad_[ASCHED_DEV_PAD];   // layout experiments only (tools/lds_layout_sweep.sh): this struct is copied into the round kernel's LDS
+#endif
 };
 
 // Market-driven rounds (asched_set_market; round_mkt.h).  Deliberately NOT part of Dev / RoundScalars: those two are copied into the round kernel's LDS, and the round

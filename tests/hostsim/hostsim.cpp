@@ -15,6 +15,7 @@
 #include <time.h>
 #include "../../armada_amd/csrc/round_run.h"
 #include "../../armada_amd/csrc/round_opt.h"
+#include "../../armada_amd/csrc/round_price.h"
 static thread_local MktDev g_mk;   // market-driven rounds (round_mkt.h): the market state of the launch in progress (a kernel argument on the device)
 DEV MktDev* mktDev() { return &g_mk; }
 // optional per-primitive wall-clock profile of the serial build (HOSTSIM_PROF=1): where would a wide device primitive matter?
@@ -251,6 +252,20 @@ static int plat_opt_score(Dev& dev, const OptArgs& a, std::vector<OptNodeOut>& s
   return 0;
 }
 static double plat_last_opt_ms() { return 0; }
+// indicative pricer: round_price.h's per-node routine over all nodes, serially
+static int plat_price_score(Dev& dev, const PriceArgs& a, std::vector<PriceNodeOut>& scores, int detailNode, std::vector<int32_t>* pre) {
+  Dev d = dev;
+  int N = d.cfg.N, M = d.cfg.M;
+  std::vector<int32_t> off(N + 2, 0), jobs((size_t)std::max(M, 1));
+  for (int j = 0; j < M; j++) if (d.jobNode[j] >= 0) off[d.jobNode[j] + 1]++;
+  for (int n = 0; n < N; n++) off[n + 1] += off[n];
+  { std::vector<int32_t> cur(off.begin(), off.end()); for (int j = 0; j < M; j++) if (d.jobNode[j] >= 0) jobs[cur[d.jobNode[j]]++] = j; }
+  std::vector<PriceEntry> entries((size_t)std::max(M, 1) + 1);
+  scores.resize(N);
+  for (int n = 0; n < N; n++) priceScoreNode(d, a, off.data(), jobs.data(), d.jLeaseMs, n, &scores[n], nullptr, entries.data() + off[n]);
+  if (detailNode >= 0) { PriceNodeOut o; pre->assign((size_t)std::max(off[detailNode + 1] - off[detailNode], 1), -1); priceScoreNode(d, a, off.data(), jobs.data(), d.jLeaseMs, detailNode, &o, pre->data(), entries.data() + off[detailNode]); }
+  return 0;
+}
 static int plat_run_drf(Dev& dev, const std::vector<int64_t>& a, const std::vector<int64_t>& t, double* out) {
   Dev d = dev;
   for (int r = 0; r < d.cfg.R; r++) d.cfg.totalResources[r] = t[r];
