@@ -38,7 +38,9 @@ import (
 	"github.com/armadaproject/armada/internal/scheduler/configuration"
 	"github.com/armadaproject/armada/internal/scheduler/internaltypes"
 	"github.com/armadaproject/armada/internal/scheduler/jobdb"
+	schedulerconstraints "github.com/armadaproject/armada/internal/scheduler/scheduling/constraints"
 	schedulercontext "github.com/armadaproject/armada/internal/scheduler/scheduling/context"
+	"github.com/armadaproject/armada/internal/scheduler/scheduling/pricer"
 )
 
 // interner: strings -> dense ids (label / taint keys and values).
@@ -84,6 +86,9 @@ type GpuRound struct {
 	classes  map[string]int32 // requirement class key -> index
 	// poolConfig.GetDefaultJobTolerations() (scheduling_algo.go:773): part of every requirement class (UploadJobs)
 	defaultTolerations []v1.Toleration
+	rlf                *internaltypes.ResourceListFactory
+	// config.GetMarketConfig(pool) (preempting_queue_scheduler.go:61-62): nil or !Enabled = fair-share scheduling
+	market *configuration.MarketSchedulingConfig
 }
 
 func effectOf(e v1.TaintEffect) int32 {
@@ -135,7 +140,7 @@ func f64p(x []float64) *C.double {
 // configuration.SchedulingConfig.  resNames is the factory's column order; floating[i] >= 0 marks a floating resource and
 // carries the pool's total (floatingresources.GetTotalAvailableForPool), -1 an ordinary one.
 func NewGpuRound(cfg configuration.SchedulingConfig, rlf *internaltypes.ResourceListFactory, resNames []string, floating []int64, pool string, device int) (*GpuRound, error) {
-	g := &GpuRound{pool: pool, resNames: resNames, strs: newInterner(), pcIndex: map[string]int32{}, classes: map[string]int32{}}
+	g := &GpuRound{pool: pool, resNames: resNames, strs: newInterner(), pcIndex: map[string]int32{}, classes: map[string]int32{}, rlf: rlf, market: cfg.GetMarketConfig(pool)}
 	var pins runtime.Pinner // the config struct points at Go memory for the duration of asched_create
 	defer pins.Unpin()
 	R := len(resNames)
@@ -598,6 +603,14 @@ func (g *GpuRound) UploadJobs(jobs []*jobdb.Job, queueIndex map[string]int32) er
 			pins.Pin(&away[0])
 			in.away = (*C.uint8_t)(unsafe.Pointer(&away[0]))
 		}
+		if g.market != nil && g.market.Enabled { // job.GetBidPrice(pool) as the job stands now (jobdb/job.go:459-481): queued / running / non-preemptible-running bid
+			bid := make([]float64, m)
+			for i, job := range jobs {
+				bid[i] = job.GetBidPrice(g.pool)
+			}
+			pins.Pin(&bid[0])
+			in.bid_price = f64p(bid)
+		}
 	}
 	if err := g.uploadLabelValueInts(); err != nil { // Gt / Lt compare integers: every interned string that parses, before the masks are built
 		return err
@@ -701,6 +714,16 @@ func (g *GpuRound) Schedule(ctx *armadacontext.Context, sctx *schedulercontext.S
 		in.has_fairshare_preemption_limiter = 1
 		in.fairshare_preemption_tokens = C.double(sctx.FairsharePreemptionLimiter.TokensAt(sctx.Started))
 	}
+	{ // market-driven pool (pqs.go:61-62): evict-everything evictor, price-ordered iterators, spot price (asched_set_market); queuedJobs then come in jobdb.PriceOrder
+		var mc C.asched_market_config
+		if g.market != nil && g.market.Enabled {
+			mc.enabled = 1
+			mc.spot_price_cutoff = C.double(g.market.SpotPriceCutoff)
+		}
+		if err := g.check(C.asched_set_market(g.h, &mc)); err != nil {
+			return nil, err
+		}
+	}
 	if err := g.check(C.asched_round_prepare(g.h, &in)); err != nil {
 		return nil, err
 	}
@@ -748,7 +771,52 @@ func (g *GpuRound) Schedule(ctx *armadacontext.Context, sctx *schedulercontext.S
 	if err := g.check(rc); err != nil {
 		return nil, err // error => round discarded, nothing applied (scheduling_algo.go:262-285)
 	}
+	if g.market != nil && g.market.Enabled { // sctx.SpotPrice, qctx.BillableResource, qctx.BillablePriceOverride (queue_scheduler.go:177-203)
+		var mr C.asched_market_outcome
+		if err := g.check(C.asched_market_result(g.h, &mr)); err != nil {
+			return nil, err
+		}
+		if mr.has_spot_price != 0 {
+			p := float64(mr.spot_price)
+			sctx.SpotPrice = &p
+		}
+		bill := unsafe.Slice((*int64)(unsafe.Pointer(mr.queue_billable_resource)), Q*R)
+		over := unsafe.Slice((*float64)(unsafe.Pointer(mr.queue_billable_price_override)), Q)
+		has := unsafe.Slice((*uint8)(unsafe.Pointer(mr.queue_has_price_override)), Q)
+		for q, name := range names {
+			qctx := sctx.QueueSchedulingContexts[name]
+			if mr.has_spot_price != 0 {
+				qctx.BillableResource = g.rlf.FromInt64Slice(bill[q*R : (q+1)*R]) // (a factory constructor over the vector: internaltypes.ResourceListFactory)
+			}
+			if has[q] != 0 {
+				v := over[q]
+				qctx.BillablePriceOverride = &v
+			}
+		}
+	}
 	return g.buildResult(sctx, &out), nil
+}
+
+// PriceGang == pricer.GangPricer.Price (pricer/gang_pricer.go:48-117) on the NodeDb as the round left it; jobs are rows of the uploaded job set (the synthetic
+// jobs MarketDrivenIndicativePricer builds from a configuration.GangDefinition are uploaded with the others, queued nowhere).  The limit and deadline checks of
+// market_driven_indicative_pricer.go:64-118 stay with the caller.
+func (g *GpuRound) PriceGang(jobs []int32, now time.Time) (pricer.GangPricingResult, error) {
+	var out C.asched_gang_price
+	if err := g.check(C.asched_price_gang(g.h, C.int32_t(len(jobs)), i32p(jobs), C.int64_t(now.UnixMilli()), &out)); err != nil {
+		return pricer.GangPricingResult{}, err
+	}
+	reason := ""
+	switch int(out.reason) {
+	case C.ASCHED_REASON_JOB_DOES_NOT_FIT:
+		reason = schedulerconstraints.JobDoesNotFitUnschedulableReason
+	case C.ASCHED_REASON_GANG_DOES_NOT_FIT:
+		reason = schedulerconstraints.GangDoesNotFitUnschedulableReason
+	case C.ASCHED_PRICE_REASON_LABEL_NOT_INDEXED:
+		reason = pricer.GangUniformityLabelIsNotIndexedUnschedulableReason
+	case C.ASCHED_PRICE_REASON_NO_NODES_WITH_LABEL:
+		reason = pricer.GangNoNodesWithUniformityLabelUnschedulableReason
+	}
+	return pricer.GangPricingResult{Evaluated: out.evaluated != 0, Schedulable: out.schedulable != 0, Price: float64(out.price), UnschedulableReason: reason}, nil
 }
 
 // buildResult turns the flat result into the jctx lists SchedulingResult carries (result.go:96-107).  Result buffers are owned by the
