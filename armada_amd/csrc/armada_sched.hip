@@ -1536,6 +1536,165 @@ __global__ __launch_bounds__(128) void k_opt_score(Dev d, OptArgs a, const doubl
   int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n < d.cfg.N) optScoreNode(d, a, qCost, off, jobs, d.jLeaseMs, n, &out[n], nullptr);
 }
+// ---- k_opt_score_wave: PreemptingNodeScheduler.Schedule (round_opt.h optScoreNodeE) with ONE WAVE per node, one lane per job on the node.
+// The one-node-per-thread kernel walks its node's job list serially — a chain of dependent gathers per job and two insertion sorts in private memory (2.4 KB of
+// scratch per thread) — and leaves most of the chip idle (20 000 nodes = 313 waves).  Here the gathers of a node are one round trip (lane k loads job k's row), the two
+// orderings are rank sorts (lane k counts the entries that order before its own; entries are broadcast with v_readlane, so the loop is wave-uniform and as long as the
+// node's job count), the fit prefix is a wave scan of the request vectors and "first prefix that fits" a ballot.  What the reference computes with SEQUENTIAL float
+// arithmetic keeps its order: the running queue cost (rounded after every subtraction), the sum of the preemption costs and the per-queue cost changes are serial
+// loops over broadcast values — every lane performs the same operations in the same order, so the doubles are the ones the serial routine produces.
+// Nodes with more than 64 jobs report overflow (-1) like the private-list kernel and go through k_opt_score_big.
+template <class T> __device__ static inline T wvRead(T v, int lane) {   // lane: wave-uniform
+  static_assert(sizeof(T) % 4 == 0, "dword multiples");
+  int w[sizeof(T) / 4]; T r;
+  __builtin_memcpy(w, &v, sizeof(T));
+  for (int k = 0; k < (int)(sizeof(T) / 4); k++) w[k] = __builtin_amdgcn_readlane(w[k], lane);
+  __builtin_memcpy(&r, w, sizeof(T));
+  return r;
+}
+template <class T> __device__ static inline T wvPush(T v, int dstLane) {   // lane dstLane receives this lane's v (ds_permute: dstLane must be a permutation of the lanes)
+  int w[sizeof(T) / 4]; T r;
+  __builtin_memcpy(w, &v, sizeof(T));
+  for (int k = 0; k < (int)(sizeof(T) / 4); k++) w[k] = __builtin_amdgcn_ds_permute(dstLane << 2, w[k]);
+  __builtin_memcpy(&r, w, sizeof(T));
+  return r;
+}
+template <class T> __device__ static inline T wvPull(T v, int srcLane) {   // this lane receives lane srcLane's v
+  int w[sizeof(T) / 4]; T r;
+  __builtin_memcpy(w, &v, sizeof(T));
+  for (int k = 0; k < (int)(sizeof(T) / 4); k++) w[k] = __builtin_amdgcn_ds_bpermute(srcLane << 2, w[k]);
+  __builtin_memcpy(&r, w, sizeof(T));
+  return r;
+}
+struct OptLane { int32_t job, queue, sap, ordinal, prioPre, ctpZero; int64_t age; double cost, wcap; };
+__device__ static inline bool optInQueueLessL(const OptLane& a, const OptLane& b) {   // round_opt.h optInQueueLess
+  if (a.queue != b.queue) return a.queue < b.queue;
+  if (a.sap != b.sap) return a.sap < b.sap;
+  if (a.cost != b.cost) return a.cost < b.cost;
+  if (a.age != b.age) return a.age < b.age;
+  return a.job < b.job;
+}
+__device__ static inline bool optGlobalLessL(const OptLane& a, const OptLane& b) {    // round_opt.h optGlobalLess
+  if (a.queue == b.queue) return a.ordinal < b.ordinal;
+  if (a.prioPre != b.prioPre) return a.prioPre != 0;
+  if (a.wcap > b.wcap) return true;
+  if (a.wcap == b.wcap) {
+    if (a.sap != b.sap) return a.sap < b.sap;
+    if (a.cost != b.cost) return a.cost < b.cost;
+    if (a.age != b.age) return a.age < b.age;
+    return a.job < b.job;
+  }
+  return false;
+}
+// entries to their ranks: valid lanes go to lane `rank` (0 .. m-1), the others fill m .. 63 in lane order, so the move is a permutation
+__device__ static inline int optDest(bool valid, int rank, unsigned long long validMask, int lane) {
+  int m = __builtin_popcountll(validMask);
+  int invalidBefore = __builtin_popcountll(~validMask & ((1ull << lane) - 1));
+  return valid ? rank : m + invalidBefore;
+}
+__global__ __launch_bounds__(256) void k_opt_score_wave(Dev d, OptArgs a, const double* qCost, const int32_t* off, const int32_t* jobs, OptNodeOut* out) {
+  const DevCfg& c = d.cfg;
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= c.N) return;                                                        // (whole waves leave together: one node per wave)
+  OptNodeOut res; res.scheduled = 0; res.npre = 0; res.cost = 0; res.impact = 0;
+  const int job = a.job;
+  const uint64_t* mask = d.shapeMask + (size_t)d.jShape[job] * c.W;
+  if (!((mask[n >> 6] >> (n & 63)) & 1)) { if (lane == 0) out[n] = res; return; }
+  const int64_t* req = JREQ(d, job);
+  int64_t avail[MAXR];
+  bool fits0 = true;
+  for (int r = 0; r < MAXR; r++) { avail[r] = r < c.R ? AL(d, c.evLevel, r, n) : 0; if (r < c.R && req[r] > avail[r]) fits0 = false; }
+  if (fits0) { res.scheduled = 1; if (lane == 0) out[n] = res; return; }
+  const int k0 = off[n], cnt = off[n + 1] - k0;
+  if (cnt > 64) { res.scheduled = -1; if (lane == 0) out[n] = res; return; }   // more jobs than lanes: scored by k_opt_score_big
+  const int32_t jobPrio = c.pcPriority[d.jPc[job]];
+  // ---- one lane per job on the node (node.AllocatedByJobId, node_scheduler.go:137-200)
+  OptLane e; e.job = 0x7fffffff; e.queue = 0; e.sap = 0; e.ordinal = 0; e.prioPre = 0; e.ctpZero = 1; e.age = 0; e.cost = 0; e.wcap = 0;
+  int64_t jr[MAXR];
+  for (int r = 0; r < MAXR; r++) jr[r] = 0;
+  bool valid = false;
+  if (lane < cnt) {
+    int j = jobs[k0 + lane];
+    bool ok = c.pcPreemptible[d.jPc[j]] != 0 && d.jGang[j] < 0;
+    const int64_t* q = JREQ(d, j);
+    if (ok && a.hasMaxSize) for (int r = 0; r < c.R; r++) if (a.maxSize[r] != 0 && q[r] > a.maxSize[r]) ok = false;
+    int32_t sap = d.schedAtPrio[j];
+    ok = ok && sap != NO_PRIORITY && sap <= jobPrio;
+    if (ok) {
+      valid = true;
+      e.job = j; e.queue = d.jQueue[j]; e.sap = sap;
+      e.age = d.jNode0[j] < 0 ? 0 : a.nowMs - d.jLeaseMs[j];
+      e.cost = drf(d, q);
+      for (int r = 0; r < c.R; r++) jr[r] = q[r];
+    }
+  }
+  unsigned long long vm = __ballot(valid);
+  const int m = __builtin_popcountll(vm);
+  if (m == 0) { if (lane == 0) out[n] = res; return; }
+  // ---- per queue order (optInQueueLess): rank = how many entries order before mine
+  {
+    int rank = 0;
+    for (int i = 0; i < cnt; i++) {
+      if (!((vm >> i) & 1)) continue;
+      OptLane o = wvRead(e, i);
+      if (valid && optInQueueLessL(o, e)) rank++;
+    }
+    int dst = optDest(valid, rank, vm, lane);
+    e = wvPush(e, dst);
+    for (int r = 0; r < c.R; r++) jr[r] = wvPush(jr[r], dst);
+  }
+  valid = lane < m;
+  // the queue's cost, weight and capped fair share, one gather per lane (broadcast below)
+  double qc = valid ? qCost[e.queue] : 0.0, qw = valid ? d.qWeight[e.queue] : 1.0, qd = valid ? d.qDc[e.queue] : 0.0;
+  // ---- populateQueueImpactFields (:203-232): the running queue cost is rounded after every subtraction — in order, on broadcast values
+  {
+    double updated = 0; int prevQ = -1, ord = 0;
+    for (int i = 0; i < m; i++) {
+      int qi = wvRead(e.queue, i);
+      if (qi != prevQ) { updated = wvRead(qc, i); ord = 0; prevQ = qi; }
+      updated = optRound8(updated - wvRead(e.cost, i));
+      double w = updated / wvRead(qw, i);
+      int sapi = wvRead(e.sap, i);
+      int prioPre = sapi < jobPrio, ctpZero = (sapi < jobPrio) || (updated > wvRead(qd, i));
+      if (lane == i) { e.wcap = w; e.prioPre = prioPre; e.ctpZero = ctpZero; e.ordinal = ord; }
+      ord++;
+    }
+  }
+  // ---- global preemption order (optGlobalLess)
+  {
+    int rank = 0;
+    for (int i = 0; i < m; i++) {
+      OptLane o = wvRead(e, i);
+      if (valid && optGlobalLessL(o, e)) rank++;
+    }
+    unsigned long long m2 = m >= 64 ? ~0ull : ((1ull << m) - 1);
+    int dst = optDest(valid, rank, m2, lane);
+    e = wvPush(e, dst); qc = wvPush(qc, dst);
+    for (int r = 0; r < c.R; r++) jr[r] = wvPush(jr[r], dst);
+  }
+  // ---- preempt one job at a time until the job fits (:84-99): inclusive prefix sums of the victims' requests, first prefix that fits
+  for (int r = 0; r < c.R; r++) {
+    int64_t v = valid ? jr[r] : 0;
+    for (int s = 1; s < 64; s <<= 1) { int64_t o = wvPull(v, lane >= s ? lane - s : lane); if (lane >= s) v += o; }
+    jr[r] = v;
+  }
+  bool f = valid;
+  for (int r = 0; r < c.R; r++) if (req[r] > avail[r] + jr[r]) f = false;
+  unsigned long long fm = __ballot(f);
+  if (fm == 0) { if (lane == 0) out[n] = res; return; }
+  const int used = __builtin_ctzll(fm) + 1;
+  double total = 0;
+  for (int i = 0; i < used; i++) total += wvRead(e.ctpZero, i) ? 0.0 : wvRead(e.cost, i);
+  // maximumQueueImpact (:101-113): per queue |sum of the preempted jobs' costs, in preemption order| / CurrentCost
+  double change = 0;
+  for (int i = 0; i < used; i++) { int qi = wvRead(e.queue, i); double ci = wvRead(e.cost, i); if (qi == e.queue) change -= ci; }
+  double imp = lane < used ? fabs(change) / qc : 0.0;
+  if (!(imp > 0.0)) imp = 0.0;   // (the serial routine keeps a value only if it compares greater than the running maximum: a NaN never does)
+  for (int s = 32; s; s >>= 1) { double o = __shfl_xor(imp, s, 64); imp = o > imp ? o : imp; }
+  res.scheduled = 1; res.npre = used; res.cost = total; res.impact = imp;
+  if (lane == 0) out[n] = res;
+}
 __global__ void k_opt_detail(Dev d, OptArgs a, const double* qCost, const int32_t* off, const int32_t* jobs, int n, OptNodeOut* out, int32_t* pre) {
   if (blockIdx.x == 0 && threadIdx.x == 0) optScoreNode(d, a, qCost, off, jobs, d.jLeaseMs, n, out, pre);
 }
@@ -1929,7 +2088,9 @@ static int plat_opt_score(Dev& d, const OptArgs& a, std::vector<OptNodeOut>& sco
     hipLaunchKernelGGL(k_opt_scatter, dim3(bulkGrid(M)), dim3(256), 0, c->stream, d, cursor, jobs);
     hipLaunchKernelGGL(k_opt_qcost, dim3((Q + 1 + 63) / 64), dim3(64), 0, c->stream, d, a.job, qCost);
     (void)hipEventRecord(c->fitEv0, c->stream);
-    hipLaunchKernelGGL(k_opt_score, dim3((N + 127) / 128), dim3(128), 0, c->stream, d, a, (const double*)qCost, (const int32_t*)off, (const int32_t*)jobs, out);
+    static const bool perThread = [] { const char* e = getenv("ASCHED_OPT_PER_THREAD"); return e && e[0] == '1'; }();   // A/B: the one-node-per-thread kernel of rounds 2-3
+    if (perThread) hipLaunchKernelGGL(k_opt_score, dim3((N + 127) / 128), dim3(128), 0, c->stream, d, a, (const double*)qCost, (const int32_t*)off, (const int32_t*)jobs, out);
+    else hipLaunchKernelGGL(k_opt_score_wave, dim3((N + 3) / 4), dim3(256), 0, c->stream, d, a, (const double*)qCost, (const int32_t*)off, (const int32_t*)jobs, out);
     (void)hipEventRecord(c->fitEv1, c->stream);
     ok = hipOk(hipGetLastError(), "optimiser launch") && hipOk(hipStreamSynchronize(c->stream), "optimiser kernels");
     (void)hipEventElapsedTime(&g_lastOptMs, c->fitEv0, c->fitEv1);
