@@ -1592,11 +1592,11 @@ __device__ static inline int optDest(bool valid, int rank, unsigned long long va
   int invalidBefore = __builtin_popcountll(~validMask & ((1ull << lane) - 1));
   return valid ? rank : m + invalidBefore;
 }
-__global__ __launch_bounds__(256) void k_opt_score_wave(Dev d, OptArgs a, const double* qCost, const int32_t* off, const int32_t* jobs, OptNodeOut* out) {
+// one wave, node n: *outp = the node's score (written by lane 0), preOut (optional) = the victims in preemption order
+__device__ static void optScoreNodeWave(Dev& d, const OptArgs& a, const double* qCost, const int32_t* off, const int32_t* jobs, int n, OptNodeOut* outp, int32_t* preOut) {
   const DevCfg& c = d.cfg;
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= c.N) return;                                                        // (whole waves leave together: one node per wave)
+  OptNodeOut* out = outp - n;                                                  // (the body below writes out[n])
   OptNodeOut res; res.scheduled = 0; res.npre = 0; res.cost = 0; res.impact = 0;
   const int job = a.job;
   const uint64_t* mask = d.shapeMask + (size_t)d.jShape[job] * c.W;
@@ -1693,7 +1693,16 @@ __global__ __launch_bounds__(256) void k_opt_score_wave(Dev d, OptArgs a, const 
   if (!(imp > 0.0)) imp = 0.0;   // (the serial routine keeps a value only if it compares greater than the running maximum: a NaN never does)
   for (int s = 32; s; s >>= 1) { double o = __shfl_xor(imp, s, 64); imp = o > imp ? o : imp; }
   res.scheduled = 1; res.npre = used; res.cost = total; res.impact = imp;
+  if (preOut && lane < used) preOut[lane] = e.job;
   if (lane == 0) out[n] = res;
+}
+__global__ __launch_bounds__(256) void k_opt_score_wave(Dev d, OptArgs a, const double* qCost, const int32_t* off, const int32_t* jobs, OptNodeOut* out) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= d.cfg.N) return;                                                    // (whole waves leave together: one node per wave)
+  optScoreNodeWave(d, a, qCost, off, jobs, n, &out[n], nullptr);
+}
+__global__ __launch_bounds__(64) void k_opt_detail_wave(Dev d, OptArgs a, const double* qCost, const int32_t* off, const int32_t* jobs, int n, OptNodeOut* out, int32_t* pre) {
+  optScoreNodeWave(d, a, qCost, off, jobs, n, out, pre);
 }
 __global__ void k_opt_detail(Dev d, OptArgs a, const double* qCost, const int32_t* off, const int32_t* jobs, int n, OptNodeOut* out, int32_t* pre) {
   if (blockIdx.x == 0 && threadIdx.x == 0) optScoreNode(d, a, qCost, off, jobs, d.jLeaseMs, n, out, pre);
@@ -1872,6 +1881,7 @@ struct PlatCtx {
   hipEvent_t rEv0 = nullptr, rEv1 = nullptr;
   float roundTotalMs = 0.f, roundControlMs = 0.f; int roundLaunches = 0;
   int32_t* cmpScratch = nullptr; size_t cmpScratchInts = 0;   // block counts + total of the grid-wide compaction
+  int optIndexN = -1, optIndexM = -1;   // sizes the optimiser's node -> jobs index in the scratch was built for (asched_host.inc decides when it may be reused)
   void* optScratch = nullptr; size_t optScratchBytes = 0;     // node -> jobs index, queue costs and per-node scores of the fairness optimiser, kept across calls
   std::string err;
   bool failed = false;              // sticky: an allocation / copy / memset failed since the last plat_take_failure()
@@ -2040,17 +2050,18 @@ static int plat_evict_apply(Dev& d, int phase3, int total) {
 }
 // fairness optimiser: every node scored for one job (k_opt_score), scores downloaded; detailNode >= 0: that node's preemption list as well
 static float g_lastOptMs = 0.f;
-static int plat_opt_score(Dev& d, const OptArgs& a, std::vector<OptNodeOut>& scores, double* jobCost, int detailNode, OptNodeOut* detail, std::vector<int32_t>* pre, bool detailOnly = false) {   // detailOnly: the index and scores of the previous call are still in the scratch
+static int plat_opt_score(Dev& d, const OptArgs& a, std::vector<OptNodeOut>& scores, double* jobCost, int detailNode, OptNodeOut* detail, std::vector<int32_t>* pre, bool detailOnly = false,
+                          bool reuseIndex = false) {   // detailOnly: the index and scores of the previous call are still in the scratch; reuseIndex: so is the node -> jobs index (nothing was bound since)
   PlatCtx* c = t_ctx;
   int N = d.cfg.N, M = d.cfg.M, Q = d.cfg.Q;
   // one allocation, carved: [scores N+1][queue costs Q+1][cnt N+1][off N+2][cursor N+1][jobs M][pre OPT_MAXJ]
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  size_t bOut = up(sizeof(OptNodeOut) * (size_t)(N + 1)), bQ = up(sizeof(double) * (size_t)(Q + 1)), bN = up(sizeof(int32_t) * (size_t)(N + 2)), bM = up(sizeof(int32_t) * 2 * (size_t)std::max(M, 1)), bP = up(sizeof(int32_t) * OPT_MAXJ);
+  size_t bOut = up(sizeof(OptNodeOut) * (size_t)(N + 1)), bQ = up(sizeof(double) * (size_t)(Q + 1)), bN = up(sizeof(int32_t) * (size_t)(N + 2)), bM = up(sizeof(int32_t) * 2 * (size_t)std::max(M, 1)), bP = up(sizeof(int32_t) * 64);
   size_t need = bOut + bQ + 3 * bN + bM + bP;
   bool ok = true;
   if (c->optScratchBytes < need) {
     if (c->optScratch) (void)hipFree(c->optScratch);
-    c->optScratch = nullptr; c->optScratchBytes = 0;
+    c->optScratch = nullptr; c->optScratchBytes = 0; c->optIndexN = c->optIndexM = -1;
     ok = hipOk(hipMalloc(&c->optScratch, need), "optimiser scratch");
     if (ok) c->optScratchBytes = need;
   }
@@ -2063,11 +2074,13 @@ static int plat_opt_score(Dev& d, const OptArgs& a, std::vector<OptNodeOut>& sco
     int32_t o2[2] = {0, 0};
     if (!hipOk(hipMemcpy(o2, off + detailNode, sizeof o2, hipMemcpyDeviceToHost), "opt detail")) return false;
     int cnt = o2[1] - o2[0];
-    if (cnt <= OPT_MAXJ) {
-      pre->assign(OPT_MAXJ, -1);
-      hipLaunchKernelGGL(k_opt_detail, dim3(1), dim3(64), 0, c->stream, d, a, (const double*)qCost, (const int32_t*)off, (const int32_t*)jobs, detailNode, out + N, dPre);
+    static const bool perThread = [] { const char* e = getenv("ASCHED_OPT_PER_THREAD"); return e && e[0] == '1'; }();
+    if (cnt <= (perThread ? OPT_MAXJ : 64)) {
+      pre->assign(64, -1);
+      if (perThread) hipLaunchKernelGGL(k_opt_detail, dim3(1), dim3(64), 0, c->stream, d, a, (const double*)qCost, (const int32_t*)off, (const int32_t*)jobs, detailNode, out + N, dPre);
+      else hipLaunchKernelGGL(k_opt_detail_wave, dim3(1), dim3(64), 0, c->stream, d, a, (const double*)qCost, (const int32_t*)off, (const int32_t*)jobs, detailNode, out + N, dPre);
       return hipOk(hipGetLastError(), "optimiser launch") && hipOk(hipMemcpyAsync(detail, out + N, sizeof(OptNodeOut), hipMemcpyDeviceToHost, c->stream), "opt detail") &&
-             hipOk(hipMemcpyAsync(pre->data(), dPre, sizeof(int32_t) * OPT_MAXJ, hipMemcpyDeviceToHost, c->stream), "opt detail") && hipOk(hipStreamSynchronize(c->stream), "optimiser kernels");
+             hipOk(hipMemcpyAsync(pre->data(), dPre, sizeof(int32_t) * 64, hipMemcpyDeviceToHost, c->stream), "opt detail") && hipOk(hipStreamSynchronize(c->stream), "optimiser kernels");
     }
     pre->assign((size_t)cnt, -1);
     OptEntry* es = nullptr; int32_t* dp = nullptr;
@@ -2082,10 +2095,13 @@ static int plat_opt_score(Dev& d, const OptArgs& a, std::vector<OptNodeOut>& sco
   };
   if (ok && detailOnly) return runDetail() ? 0 : -1;
   if (ok) {
-    (void)hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(N + 1), c->stream);
-    hipLaunchKernelGGL(k_opt_count, dim3(bulkGrid(M)), dim3(256), 0, c->stream, d, cnt);
-    hipLaunchKernelGGL(k_opt_scan, dim3(1), dim3(1024), 0, c->stream, (const int32_t*)cnt, off, cursor, N);
-    hipLaunchKernelGGL(k_opt_scatter, dim3(bulkGrid(M)), dim3(256), 0, c->stream, d, cursor, jobs);
+    if (!(reuseIndex && c->optIndexN == N && c->optIndexM == M)) {
+      (void)hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(N + 1), c->stream);
+      hipLaunchKernelGGL(k_opt_count, dim3(bulkGrid(M)), dim3(256), 0, c->stream, d, cnt);
+      hipLaunchKernelGGL(k_opt_scan, dim3(1), dim3(1024), 0, c->stream, (const int32_t*)cnt, off, cursor, N);
+      hipLaunchKernelGGL(k_opt_scatter, dim3(bulkGrid(M)), dim3(256), 0, c->stream, d, cursor, jobs);
+      c->optIndexN = N; c->optIndexM = M;
+    }
     hipLaunchKernelGGL(k_opt_qcost, dim3((Q + 1 + 63) / 64), dim3(64), 0, c->stream, d, a.job, qCost);
     (void)hipEventRecord(c->fitEv0, c->stream);
     static const bool perThread = [] { const char* e = getenv("ASCHED_OPT_PER_THREAD"); return e && e[0] == '1'; }();   // A/B: the one-node-per-thread kernel of rounds 2-3

@@ -227,7 +227,7 @@ static int plat_delta_resolve(Dev& d, const long long* red, int ns, int np, int3
 // fairness optimiser: the per-node routine of round_opt.h over all nodes, serially
 static const double* g_lastQCost = nullptr;
 static int plat_opt_qcosts(Dev&, double* out, int Q) { for (int q = 0; q < Q; q++) out[q] = g_lastQCost[q]; return 0; }
-static int plat_opt_score(Dev& dev, const OptArgs& a, std::vector<OptNodeOut>& scores, double* jobCost, int detailNode, OptNodeOut* detail, std::vector<int32_t>* pre, bool detailOnly = false) { (void)detailOnly;
+static int plat_opt_score(Dev& dev, const OptArgs& a, std::vector<OptNodeOut>& scores, double* jobCost, int detailNode, OptNodeOut* detail, std::vector<int32_t>* pre, bool detailOnly = false, bool reuseIndex = false) { (void)detailOnly; (void)reuseIndex;
   Dev d = dev;
   int N = d.cfg.N, M = d.cfg.M, Q = d.cfg.Q;
   std::vector<int32_t> off(N + 2, 0), jobs(2 * (size_t)std::max(M, 1));

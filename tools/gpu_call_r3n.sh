@@ -8,6 +8,7 @@ for mode in 0 1; do
   ASCHED_OPT_PER_THREAD=$mode python - <<'PY' 2>&1 | tee -a $OUT/summary.txt
 import sys, argparse, os
 sys.argv=['bench.py']
+import torch; torch.cuda.init()   # torch's HIP runtime first (see tests/conftest.py)
 import bench, armada_amd
 a = argparse.Namespace(other_scale=1.0, steps=10, cpu_budget=30)
 r = bench.optimiser_record(armada_amd.load_library(), a)
@@ -16,6 +17,7 @@ PY
 done
 ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof_opt" -- python -c "
 import sys; sys.path.insert(0, '$OLDPWD'); sys.argv=['bench.py']
+import torch; torch.cuda.init()
 import bench, argparse, armada_amd
 a = argparse.Namespace(other_scale=1.0, steps=10, cpu_budget=0)
 print(bench.optimiser_record(armada_amd.load_library(), a)['k_opt_score_ms'])" > "$OLDPWD/$OUT/prof_opt.log" 2>&1 )
