@@ -329,6 +329,58 @@ def optimiser_record(hip, args):
     return rec
 
 
+def market_record(hip, args):
+    """one market-driven round (asched_set_market: evict-everything node evictor, price-ordered iterators, MarketIteratorPQ as a literal heap, spot price /
+    billing) and the indicative gang pricer behind it (asched_price_gang) on a mid-size pool; the oracle on the same input for the baseline and the parity verdict.  The
+    market round is the generic path in ONE launch of the auxiliary kernel: this line is its price, not a tuned number."""
+    import numpy as np
+    import torch
+    from armada_amd import workloads as W
+    from armada_amd.binding import Library
+    sc = args.other_scale
+    wl = W.config3(seed=W.SEED, n_nodes=max(16, int(4_000 * sc)), n_jobs=max(200, int(40_000 * sc)), n_queues=16 if sc == 1.0 else 4, occupied=0.8)
+    wl.global_burst, wl.queue_burst = max(1, int(8_000 * sc)), max(1, int(2_000 * sc))
+    rng = np.random.default_rng(W.SEED)
+    bids = rng.integers(1, 9, size=wl.num_jobs).astype(np.float64)                     # eight price bands (pkg/bidstore)
+    nonpre = np.array([not wl.config.pc_preemptible[p] for p in wl.job_pc])
+    bids[(wl.job_node >= 0) & nonpre] = 1_000_000.0                                     # pricing.NonPreemptibleRunningPrice
+    pcp = np.asarray(wl.config.pc_priority)
+    queued = [sorted(q, key=lambda j: (-int(pcp[wl.job_pc[j]]), -float(bids[j]), int(j))) for q in wl.queued]   # jobdb.PriceOrder
+    nq = wl.num_queues
+
+    def run(lib, timed):
+        s = W.load(lib, wl); W.set_jobs(s, wl, bid_price=bids)
+        s.round_prepare(wl.queue_weight, queued, global_tokens=float(wl.global_burst), global_burst=wl.global_burst, global_rate_inf=wl.rate_inf,
+                        queue_tokens=[float(wl.queue_burst)] * nq, queue_burst=[wl.queue_burst] * nq, queue_rate_inf=[wl.rate_inf] * nq)
+        s.set_market(True, 0.9)
+        if timed: torch.cuda.synchronize()
+        t0 = time.perf_counter(); res = s.schedule_round(); dt = time.perf_counter() - t0
+        mr = s.market_result()
+        left = [int(j) for j in np.nonzero((wl.job_node < 0) & (wl.job_gang < 0))[0] if int(j) not in res.scheduled][:16]
+        t1 = time.perf_counter(); prices = [s.price_gang([j], now_ms=300_000) for j in left]; dp = time.perf_counter() - t1
+        kms = s.kernel_times()["fit_batch_ms"] if timed else 0.0
+        s.close()
+        return res, mr, prices, dt, dp, kms
+
+    res, mr, prices, dt, dp, kms = run(hip, True)
+    rec = {"config": "market-driven round + indicative gang pricer (SURVEY 8f-4)",
+           "workload": f"{wl.num_nodes} nodes x {wl.num_queues} queues x {sum(len(q) for q in queued)} queued jobs (+{int((wl.job_node >= 0).sum())} running, 80% occupied), 8 price bands, spot price cutoff 0.9, global burst {wl.global_burst}",
+           "metric": "market-driven scheduling rounds/sec (one launch of the auxiliary kernel, generic path)", "value": 1.0 / dt, "unit": "rounds/s", "ms_per_step": dt * 1e3, "steps": 1,
+           "round": {"scheduled": len(res.scheduled), "preempted": len(res.preempted), "evicted_phase1": res.num_evicted_phase1, "loop_iterations": res.num_loop_iterations,
+                     "spot_price": mr["spot_price"], "queues_with_price_override": sum(v is not None for v in mr["price_override"])},
+           "pricer": {"gangs_priced": len(prices), "schedulable": sum(p["schedulable"] for p in prices), "ms_per_gang": dp / max(len(prices), 1) * 1e3, "k_price_score_ms": kms},
+           "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": "k_control_aux (CMD_MARKET_ROUND)",
+                        "note": "a sequential heap-ordered round on one workgroup: latency bound by construction, no bandwidth figure is claimed"}}
+    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if args.cpu_budget > 0 and os.path.exists(path):
+        ores, omr, oprices, odt, odp, _ = run(Library(path, "oracle_"), False)
+        rec["cpu_baseline"] = {"value": 1.0 / odt, "unit": "rounds/s", "cores": 1, "kind": "port", "sample": f"the same round on the CPU oracle, {odt:.2f} s; pricer {odp / max(len(oprices), 1) * 1e3:.1f} ms per gang"}
+        same = (res.scheduled == ores.scheduled and res.preempted == ores.preempted and (res.queue_allocated_by_pc == ores.queue_allocated_by_pc).all() and mr["spot_price"] == omr["spot_price"]
+                and (mr["billable"] == omr["billable"]).all() and mr["price_override"] == omr["price_override"] and prices == oprices)
+        rec["parity"] = {"checked": True, "identical": bool(same), "jobs": wl.num_jobs, "against": "oracle: scheduled / preempted jobs and nodes, queue accounting, spot price, billable resources, price overrides, gang prices"}
+    return rec
+
+
 def round_shape_record(hip, args, label, kwargs, steps, note, warmup=1):
     """one of the other BASELINE round shapes (configs[3] gangs, configs[4] oversubscribed / preemption-heavy): GPU rounds timed like the headline,
     the oracle on the same input for the cpu_baseline and the parity verdict when its round fits the remaining budget"""
@@ -424,6 +476,7 @@ def other_configs(hip, args, t_start):
         return rec
     guarded("submit check", submit)
     guarded("fairness optimiser node scoring", lambda: optimiser_record(hip, args))
+    guarded("market-driven round + pricer", lambda: market_record(hip, args))
     return recs
 
 

@@ -52,7 +52,8 @@ def test_round_bench_line(fake_gpu, monkeypatch, capsys):
     assert line["cpu_baseline"]["rounds"] == 1 and line["cpu_baseline"]["upper_bound_extrapolation"] is False
     # every other BASELINE config + the submit check sits in the same record, each with roofline and cpu_baseline
     oc = {r["config"]: r for r in line["other_configs"]}
-    assert set(oc) == {"BASELINE configs[1]", "BASELINE configs[3]", "BASELINE configs[4]", "submit check (SURVEY 8f-2)", "fairness optimiser node scoring (SURVEY 8f-3)"}, set(oc)
+    assert set(oc) == {"BASELINE configs[1]", "BASELINE configs[3]", "BASELINE configs[4]", "submit check (SURVEY 8f-2)", "fairness optimiser node scoring (SURVEY 8f-3)",
+                       "market-driven round + indicative gang pricer (SURVEY 8f-4)"}, set(oc)
     for name, r in oc.items():
         assert "error" not in r and "skipped" not in r, r
         assert ROOFLINE_KEYS <= set(r["roofline"]) and CPU_KEYS <= set(r["cpu_baseline"]), name
@@ -64,6 +65,8 @@ def test_round_bench_line(fake_gpu, monkeypatch, capsys):
     assert oc["BASELINE configs[4]"]["reduced"]["parity"]["identical"]
     assert oc["submit check (SURVEY 8f-2)"]["parity"]["identical"] and oc["submit check (SURVEY 8f-2)"]["parity"]["jobs"] > 0
     assert line["cpu_baseline"]["pinned_core"] is not None
+    mk = oc["market-driven round + indicative gang pricer (SURVEY 8f-4)"]
+    assert mk["parity"]["identical"] and mk["round"]["scheduled"] > 0 and mk["pricer"]["gangs_priced"] >= 0
 
 
 def test_round_bench_detects_a_mismatch(fake_gpu, monkeypatch, capsys):
