@@ -278,7 +278,7 @@ def fit_batch_record(hip, args):
 def optimiser_record(hip, args):
     """SURVEY 8f-3, the experimental fairness optimiser's node scoring: after a round on the preemption-heavy shape (20k nodes 95% occupied), every
     remaining queued job of a sample is scored against EVERY node (PreemptingNodeScheduler.Schedule per node, optimiser/gang_scheduler.go:100-141)
-    by one k_opt_score launch; selections, preemption lists and all per-node scores compared with the oracle's serial loop."""
+    by one k_opt_score_wave launch; selections, preemption lists and all per-node scores compared with the oracle's serial loop."""
     import numpy as np
     import torch
     from armada_amd import workloads as W
@@ -318,8 +318,9 @@ def optimiser_record(hip, args):
            "metric": "jobs scored against all nodes per second (asched_optimiser_schedule_job: node -> jobs index, k_opt_score, selection, preemption list)",
            "value": len(got) / max(sum(host), 1e-12), "unit": "jobs/s", "host_ms_per_job": float(np.mean(host)) * 1e3 if host else None, "k_opt_score_ms": dev_ms,
            "nodes_needing_preemption_walk": walked_frac, "selected_with_preemption": sum(1 for g in got if g["preempted"]), "selected_without": sum(1 for g in got if g["node"] >= 0 and not g["preempted"]),
-           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": "k_opt_score", "algorithmic_bytes_per_launch": alg,
-                        "note": "one node per thread; the per-node job walk is data dependent (gathered rows of the job tables), so this kernel is latency rather than bandwidth bound at this size"}}
+           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": "k_opt_score_wave", "algorithmic_bytes_per_launch": alg,
+                        "note": "one wave per node, one lane per job on the node (rank sorts on broadcast entries, wave scan of the request vectors); the rows are gathered through the node -> jobs index, "
+                                "so the kernel is bound by a few dependent gather round trips per wave, not by bandwidth, at this size"}}
     path = os.path.join(ROOT, "oracle", "liboracle.so")
     if args.cpu_budget > 0 and os.path.exists(path):
         want, chost, _, _ = run(Library(path, "oracle_"), False)
