@@ -766,11 +766,15 @@ class Scheduler:
     def optimiser_schedule_job(self, job: int, min_improvement_pct: float = 0.0, max_job_size_to_preempt=None, now_ms: int = 0, per_node: bool = False):
         """scheduleOnNodes of the fairness optimiser for one job -> dict(node, cost, impact, preempted[, scores: [N] (scheduled, npre, cost, impact)])"""
         out = COptResult()
-        cap = max(256, self.num_jobs)
+        cap = 256
         pre = (C.c_int32 * cap)()
         ms = None if max_job_size_to_preempt is None else _arr(max_job_size_to_preempt, np.int64)
         scores = (COptNodeScore * max(self.num_nodes, 1))() if per_node else None
         self._check(self.lib.optimiser_schedule_job(self.h, job, float(min_improvement_pct), _ptr(ms, C.c_int64), int(now_ms), C.byref(out), pre, cap, scores))
+        if out.num_preempted > cap:   # a node that needs more victims than the usual buffer holds (nothing was applied: the call is repeated with room for all of them)
+            cap = out.num_preempted
+            pre = (C.c_int32 * cap)()
+            self._check(self.lib.optimiser_schedule_job(self.h, job, float(min_improvement_pct), _ptr(ms, C.c_int64), int(now_ms), C.byref(out), pre, cap, scores))
         r = dict(node=out.node, cost=out.scheduling_cost, impact=out.maximum_queue_impact, preempted=[pre[i] for i in range(min(out.num_preempted, cap))])
         if per_node:
             r["scores"] = [(bool(s.scheduled), s.num_preempted, s.scheduling_cost, s.maximum_queue_impact) for s in scores[: self.num_nodes]]
@@ -859,9 +863,13 @@ class Scheduler:
     def price_job_on_nodes(self, job: int, now_ms: int = 0, detail_node: int = -1):
         """MinPriceNodeScheduler.Schedule against every node -> ([(scheduled, num_preempted, price)] per node, victims of detail_node in order)"""
         sc = (CPriceNodeScore * max(self.num_nodes, 1))()
-        cap = max(self.num_jobs, 1)
+        cap = 256
         pre = (C.c_int32 * cap)()
         self._check(self.lib.price_job_on_nodes(self.h, int(job), int(now_ms), sc, int(detail_node), pre, cap))
+        if detail_node >= 0 and sc[detail_node].num_preempted > cap:
+            cap = sc[detail_node].num_preempted
+            pre = (C.c_int32 * cap)()
+            self._check(self.lib.price_job_on_nodes(self.h, int(job), int(now_ms), sc, int(detail_node), pre, cap))
         scores = [(bool(x.scheduled), int(x.num_preempted), float(x.price)) for x in sc[: self.num_nodes]]
         victims = [int(pre[i]) for i in range(scores[detail_node][1])] if detail_node >= 0 else []
         return scores, victims
