@@ -252,6 +252,7 @@ static int plat_opt_score(Dev& dev, const OptArgs& a, std::vector<OptNodeOut>& s
   return 0;
 }
 static double plat_last_opt_ms() { return 0; }
+static int plat_opt_select(Dev&, const OptArgs&, double, bool, int32_t*, int32_t*, double*, double*, std::vector<int32_t>*) { return 1; }   // device-side selection: the CPU build always takes the host loop
 // indicative pricer: round_price.h's per-node routine over all nodes, serially
 static int plat_price_score(Dev& dev, const PriceArgs& a, std::vector<PriceNodeOut>& scores, int detailNode, std::vector<int32_t>* pre) {
   Dev d = dev;

@@ -197,6 +197,8 @@ def _differential(lib, oracle, seed, n_nodes=60, n_jobs=900):
         for j in left:
             for pct, ms in ((-1e9, None), (5.0, None), (-1e9, [8 * GI, 2000, 0, 0])):
                 res.append(s.optimiser_schedule_job(j, min_improvement_pct=pct, max_job_size_to_preempt=ms, now_ms=200_000, per_node=True))
+                short = s.optimiser_schedule_job(j, min_improvement_pct=pct, max_job_size_to_preempt=ms, now_ms=200_000)   # without per-node scores the HIP library selects on the device
+                assert short == {k: res[-1][k] for k in short}, (j, short, {k: res[-1][k] for k in short})
         out.append(res)
         s.close()
     assert out[0] == out[1]
