@@ -2207,6 +2207,8 @@ static double plat_last_opt_ms() { return (double)g_lastOptMs; }
 // asched_optimiser_schedule_job without per-node scores: index (when stale), queue costs, scores, selection and the selected node's victims as ONE stream-ordered sequence.
 // Returns 1 when a node overflowed the wave kernel (the caller takes plat_opt_score's path), 0 on success, -1 on a device error.
 static int plat_opt_select(Dev& d, const OptArgs& a, double minPct, bool reuseIndex, int32_t* node, int32_t* npre, double* cost, double* impact, std::vector<int32_t>* pre) {
+  static const bool perThread = [] { const char* e = getenv("ASCHED_OPT_PER_THREAD"); return e && e[0] == '1'; }();
+  if (perThread) return 1;   // A/B runs of the round-2 kernel take the host-side selection as well
   PlatCtx* c = t_ctx;
   int N = d.cfg.N, M = d.cfg.M, Q = d.cfg.Q;
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
