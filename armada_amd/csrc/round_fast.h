@@ -1362,6 +1362,12 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
 // limiters give up cnt tokens (ReserveN), the queue's next head is produced.  A member without a node: nothing has reached HBM but "this base entry is
 // stale" flags; the nodes the placed members went to are re-read into the level-0 structure (fastTouch) and the generic code runs the gang from the state
 // it would have found (it decides about preemption, the failure reason, the unfeasible-key registration).
+#ifndef ASCHED_STREAM_BACKOFF_MAX
+#define ASCHED_STREAM_BACKOFF_MAX (1 << 18)   // fast iterations between two attempts to start a stream run after short runs (doubling from _MIN): A/B-measured, profiles/r03r_*
+#endif
+#ifndef ASCHED_STREAM_BACKOFF_MIN
+#define ASCHED_STREAM_BACKOFF_MIN 8
+#endif
 struct GangOut { int handled, cnt, pend, dropped, engSeq, refills, evicted; int koValid; uint32_t koA; uint64_t koX, koY; };   // ko*: the queue's next key (fastAdvance)
 DEV_NOINLINE GangOut fastGangRun(Dev& d, FastCtx fc, StreamIn in, int t) {
   const FastK k = fastKRef(d);
@@ -1641,7 +1647,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
       }
       (void)so_max;   // (entries prepared per queue stay at QS_CMAX: the sum pass stops at a queue's first gang member, so gang-heavy queues prepare little anyway)
       if (E >= 64) streamBackoff = 0;   // an attempt costs little (streams persist, the bulk passes run on the helper workgroups): back off gently, but for good when runs stay short
-      else streamBackoff = streamBackoff ? (streamBackoff < (1 << 18) ? streamBackoff * 2 : streamBackoff) : 8;
+      else streamBackoff = streamBackoff ? (streamBackoff < ASCHED_STREAM_BACKOFF_MAX ? streamBackoff * 2 : streamBackoff) : ASCHED_STREAM_BACKOFF_MIN;
       streamNextAt = S.statFastIters + streamBackoff;
 #ifdef ASCHED_HOSTSIM
       if (getenv("HS_STREAM_EAGER")) { streamBackoff = 0; streamNextAt = S.statFastIters + (E == 0 ? 1 : 0); }   // tests: a stream run wherever one can start
