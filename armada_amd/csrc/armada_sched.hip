@@ -1941,6 +1941,7 @@ struct PlatCtx {
   float roundTotalMs = 0.f, roundControlMs = 0.f; int roundLaunches = 0;
   int32_t* cmpScratch = nullptr; size_t cmpScratchInts = 0;   // block counts + total of the grid-wide compaction
   int optIndexN = -1, optIndexM = -1;   // sizes the optimiser's node -> jobs index in the scratch was built for (asched_host.inc decides when it may be reused)
+  void* fitScratch = nullptr; size_t fitScratchBytes = 0;   // keys + shape list of a fit batch
   void* optSel = nullptr; size_t optSelBytes = 0;   // block partials + result of the device-side candidate selection
   void* optScratch = nullptr; size_t optScratchBytes = 0;     // node -> jobs index, queue costs and per-node scores of the fairness optimiser, kept across calls
   std::string err;
@@ -2001,6 +2002,7 @@ static void plat_close(PlatCtx* c) {
   if (c->cmpScratch) (void)hipFree(c->cmpScratch);
   if (c->optScratch) (void)hipFree(c->optScratch);
   if (c->optSel) (void)hipFree(c->optSel);
+  if (c->fitScratch) (void)hipFree(c->fitScratch);
   if (c->cancelHost) (void)hipHostFree(c->cancelHost);
   if (c->progress) (void)hipHostFree(c->progress);
   if (t_ctx == c) t_ctx = nullptr;
@@ -2362,11 +2364,19 @@ static int plat_run_shape_mask(Dev& d, const uint64_t* classMask, const int32_t*
 // kernel duration of the last fit batch, measured with HIP events on the launch stream
 static double plat_last_fit_ms() { return t_ctx ? (double)t_ctx->lastFitMs : 0.0; }
 
-static int plat_run_fit_batch(Dev& d, const std::vector<int32_t>& shapes, int level, std::vector<int32_t>& out) {
+// (the scratch of a fit batch is kept across calls and the rank -> node table is the host's own copy: the call is launch + one small download, nothing else)
+static int plat_run_fit_batch(Dev& d, const std::vector<int32_t>& shapes, int level, std::vector<int32_t>& out, const int32_t* nodeByRankHost = nullptr) {
   int ns = (int)shapes.size();
   if (ns == 0) return 0;
-  int32_t* dShapes = nullptr; unsigned long long* dOut = nullptr;
-  if (!hipOk(hipMalloc(&dShapes, ns * sizeof(int32_t)), "hipMalloc") || !hipOk(hipMalloc(&dOut, ns * sizeof(unsigned long long)), "hipMalloc")) return -1;
+  PlatCtx* c = t_ctx;
+  size_t need = (size_t)ns * (sizeof(int32_t) + sizeof(unsigned long long)) + 16;
+  if (c->fitScratchBytes < need) {
+    if (c->fitScratch) (void)hipFree(c->fitScratch);
+    c->fitScratch = nullptr; c->fitScratchBytes = 0;
+    if (!hipOk(hipMalloc(&c->fitScratch, need * 2), "hipMalloc")) return -1;
+    c->fitScratchBytes = need * 2;
+  }
+  unsigned long long* dOut = (unsigned long long*)c->fitScratch; int32_t* dShapes = (int32_t*)(dOut + ns);
   (void)hipMemcpyAsync(dShapes, shapes.data(), ns * sizeof(int32_t), hipMemcpyHostToDevice, t_ctx->stream);
   (void)hipMemsetAsync(dOut, 0xff, ns * sizeof(unsigned long long), t_ctx->stream);
   int tiles = (d.cfg.N + FIT_TILE - 1) / FIT_TILE;
@@ -2375,16 +2385,15 @@ static int plat_run_fit_batch(Dev& d, const std::vector<int32_t>& shapes, int le
   (void)hipEventRecord(e0, t_ctx->stream);
   hipLaunchKernelGGL(k_fit_batch, dim3(tiles, ysplit), dim3(FIT_TILE), 0, t_ctx->stream, d, dShapes, ns, level, dOut);
   (void)hipEventRecord(e1, t_ctx->stream);
-  bool ok = hipOk(hipGetLastError(), "k_fit_batch launch") && hipOk(hipStreamSynchronize(t_ctx->stream), "k_fit_batch");
-  (void)hipEventElapsedTime(&t_ctx->lastFitMs, e0, e1);
   std::vector<unsigned long long> keys(ns);
-  if (ok) ok = hipOk(hipMemcpy(keys.data(), dOut, ns * sizeof(unsigned long long), hipMemcpyDeviceToHost), "hipMemcpy");
-  (void)hipFree(dShapes); (void)hipFree(dOut);
+  bool ok = hipOk(hipGetLastError(), "k_fit_batch launch") && hipOk(hipMemcpyAsync(keys.data(), dOut, ns * sizeof(unsigned long long), hipMemcpyDeviceToHost, t_ctx->stream), "hipMemcpy") &&
+            hipOk(hipStreamSynchronize(t_ctx->stream), "k_fit_batch");
+  (void)hipEventElapsedTime(&t_ctx->lastFitMs, e0, e1);
   if (!ok) return -1;
-  std::vector<int32_t> nodeByRank(d.cfg.N);
-  if (d.cfg.N) (void)hipMemcpy(nodeByRank.data(), d.nodeByRank, d.cfg.N * sizeof(int32_t), hipMemcpyDeviceToHost);
+  std::vector<int32_t> nodeByRank;
+  if (!nodeByRankHost) { nodeByRank.resize(d.cfg.N); if (d.cfg.N) (void)hipMemcpy(nodeByRank.data(), d.nodeByRank, d.cfg.N * sizeof(int32_t), hipMemcpyDeviceToHost); nodeByRankHost = nodeByRank.data(); }
   unsigned long long mask = (1ull << d.cfg.idxBits) - 1;
-  for (int i = 0; i < ns; i++) out[i] = keys[i] == ~0ull ? -1 : nodeByRank[keys[i] & mask];
+  for (int i = 0; i < ns; i++) out[i] = keys[i] == ~0ull ? -1 : nodeByRankHost[keys[i] & mask];
   return 0;
 }
 // ---- one pool on several GPUs: the kernels live in armada_sched_mgpu.hip (their own code object)

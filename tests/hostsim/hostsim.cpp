@@ -186,7 +186,7 @@ static int plat_run_shape_mask(Dev& d, const uint64_t* classMask, const int32_t*
   }
   return 0;
 }
-static int plat_run_fit_batch(Dev& d, const std::vector<int32_t>& shapes, int level, std::vector<int32_t>& out) {
+static int plat_run_fit_batch(Dev& d, const std::vector<int32_t>& shapes, int level, std::vector<int32_t>& out, const int32_t* = nullptr) {
   for (size_t i = 0; i < shapes.size(); i++) {
     ScanArgs a; memset(&a, 0, sizeof a);
     for (int r = 0; r < d.cfg.R; r++) a.req[r] = d.shapeReq[(size_t)shapes[i] * d.cfg.R + r];
