@@ -138,8 +138,10 @@ __shared__ RoundScalars g_rs;  // d.rs points here for the whole launch (relocat
 #define UNI64(x) (x)
 #define UNID(x) (x)
 #define LANES_ANY(v) ((v) != 0)   // (serial build: FOR_LANES bodies share their locals)
+#define FAST_GLOBAL_FENCE() do {} while (0)
 #else
 #define LANES_ANY(v) (__ballot((v) != 0) != 0)
+#define FAST_GLOBAL_FENCE() __threadfence()
 __device__ static inline int uni32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ static inline unsigned long long uni64(unsigned long long v) {
   unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
@@ -1204,6 +1206,7 @@ struct StreamOut { int executed, executedEv, pend, dropped, engSeq, emitted, ref
 // when anything but a stream run serves the queue (fastIter) or the generic code runs (fastQLoad).  prepare: 0 = the top queue has no stream,
 // 1 = ready, 2 = some queue needs the bulk passes and allowBulk was 0 (the node engine must be stopped first: they use every wave of the workgroup)
 DEV_NOINLINE int fastStreamPrepare(Dev& d, FastCtx fc, int Q, int allowed, int allowBulk, int top, int capHint);   // round_run.h
+DEV_NOINLINE int fastStreamPrepareOne(Dev& d, FastCtx fc, int q, int allowed, int capHint);                          // round_run.h
 DEV EvKey streamKey(KREF k, StreamLanes& sl, int q, int pos, int sLen, int kind, int base) {
   int ws = SL_GET(sl, ws, q);
   if (!(pos >= ws && pos < ws + WIN)) {
@@ -1530,8 +1533,9 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   mode = UNI32(mode);
   int cnt = counter ? UNI32(*counter) : 0, pend = -1, lastTop = -1;
   fc.stream = fc.engine && d.qsKey != nullptr && !k.hasPcLimit && !k.anyRoundLimit && !k.disableHome && fc.withQueued;
+  if (fc.stream && (d.fitPad_ & 1)) fc.stream |= 2;   // bit 1: after a gang its queue's next stretch of single jobs is prepared as a stream at once (round_run.h fastStreamPrepareOne; host flag)
   fc.stream = UNI32(fc.stream);
-  int streamNextAt = UNI32(c.streamNextAt), streamBackoff = UNI32(c.streamBackoff), streamCap = UNI32(c.streamCap);
+  int streamNextAt = UNI32(c.streamNextAt), streamBackoff = UNI32(c.streamBackoff), streamCap = UNI32(c.streamCap), cheapTry = 0;
   PackedKey refK; refK.A = ~0u; refK.X = refK.Y = ~0ull; uint32_t refN = ~0u; int haveRef = 0;
   if (!mode && c.onlyEvicted && RS.terminationReason != 0 && S.lvl0NonNeg && S.numPreemptedMarks == 0 && fc.evStatic && fc.withQueued) { SkipDelta dl = fastDrain(d, Q); S.numEvictedJobs += dl.evicted; S.loopIterations += dl.iters; }
   if (c.skipEnter && !mode && S.lvl0NonNeg && S.numPreemptedMarks == 0 && fc.evStatic) { SkipDelta dl = fastEnterSkip(d, fc, Q); S.numEvictedJobs += dl.evicted; S.loopIterations += dl.iters; S.statRefills += dl.refills; c.skipActive = 1; }
@@ -1611,14 +1615,24 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
       S.statRefills += go.refills; S.numEvictedJobs += go.evicted;
       if (go.pend >= 0) { pend = go.pend; break; }
       { KeyOut gk; gk.valid = go.koValid; gk.A = go.koA; gk.X = go.koX; gk.Y = go.koY; pqPopPush(pq, gk, t); }   // the gang's queue is the head: re-insert it under its next key
+      if ((fc.stream & 2) && go.koValid) {   // the single jobs behind the gang as a stream, prepared right here (the queue's old stream ended at the gang)
+        int want = INT32_MAX;
+        if (!S.globalRateInf) want = S.globalTokens >= 2147483000.0 ? INT32_MAX : (S.globalTokens < 1 ? 0 : (int)S.globalTokens);
+        if (fastStreamPrepareOne(d, fc, t, want, streamCap) > 0) cheapTry = 1;   // a run may start again at once — with the streams there are, no bulk preparation
+      }
       continue;
     }
-    if (fc.stream && S.fastActive && S.statFastIters >= streamNextAt) {
+    if (fc.stream && S.fastActive && (S.statFastIters >= streamNextAt || cheapTry)) {
       // stream run: the queues' next costs come precomputed (bulk passes where a queue has none left), this wave merges + stages, the node engine binds
       int want = INT32_MAX;
       if (!S.globalRateInf) want = S.globalTokens >= 2147483000.0 ? INT32_MAX : (S.globalTokens < 1 ? 0 : (int)S.globalTokens);
-      int code = fastStreamPrepare(d, fc, Q, want, !S.engLive, t, streamCap);
+      // (fc.stream & 2, fastStreamPrepareOne) the node engine is never stopped for the bulk passes: queues that would need them go without a stream, and when the
+      // queue at the top is one of them the control wave prepares its stream alone.  The bulk passes still run where no engine is live (the start of a pass).
+      const int cheap = (fc.stream & 2) && (S.engLive || S.statFastIters < streamNextAt);
+      cheapTry = 0;
+      int code = fastStreamPrepare(d, fc, Q, want, cheap ? -1 : !S.engLive, t, streamCap);
       if (code == 2) { engineStop(d, S); S.engLive = 0; code = fastStreamPrepare(d, fc, Q, want, 1, t, streamCap); }   // the bulk passes need every wave of the workgroup at the mailbox
+      if (code == 0 && (fc.stream & 2) && fastStreamPrepareOne(d, fc, t, want, streamCap) > 0) code = 1;
       int E = 0, so_max = 0;
       if (code == 1) {
         if (!S.engLive) { engineStart(d, S); S.engLive = 1; }
@@ -1646,12 +1660,18 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
         }
       }
       (void)so_max;   // (entries prepared per queue stay at QS_CMAX: the sum pass stops at a queue's first gang member, so gang-heavy queues prepare little anyway)
+      if (fc.stream & 2) {   // attempts are cheap: try again at once after a run that got somewhere, after a few iterations otherwise
+        streamBackoff = (code == 1 && E >= 1) ? 0 : (streamBackoff ? (streamBackoff < 64 ? streamBackoff * 2 : streamBackoff) : 4);
+        streamNextAt = S.statFastIters + streamBackoff;
+      } else
+      if (!cheap) {   // (the back-off belongs to the attempts that may run the bulk passes)
       if (E >= 64) streamBackoff = 0;   // an attempt costs little (streams persist, the bulk passes run on the helper workgroups): back off gently, but for good when runs stay short
       else streamBackoff = streamBackoff ? (streamBackoff < ASCHED_STREAM_BACKOFF_MAX ? streamBackoff * 2 : streamBackoff) : ASCHED_STREAM_BACKOFF_MIN;
       streamNextAt = S.statFastIters + streamBackoff;
 #ifdef ASCHED_HOSTSIM
       if (getenv("HS_STREAM_EAGER")) { streamBackoff = 0; streamNextAt = S.statFastIters + (E == 0 ? 1 : 0); }   // tests: a stream run wherever one can start
 #endif
+      }
       if (pend >= 0) break;
       if (S.engLive && UNI32(FL.eng.cancel)) break;   // the engine saw the caller's cancel word: leave the loop (queueSchedule raises the timeout)
       if (code == 1) continue;

@@ -648,6 +648,7 @@ DEV_NOINLINE int fastStreamPrepare(Dev& d, FastCtx fc, int Q, int allowed, int a
   }
   int bulk = 0;
   for (int q = 0; q < Q; q++) if (UNI32(FL.tmpQ[q]) == 2) bulk++;
+  if (bulk && allowBulk < 0) bulk = 0;   // a cheap attempt: the queues that would need the bulk passes stay without a stream
   if (bulk) {
     if (!allowBulk) return 2;
     wgBulkWide(d, B_QSSUM, Q * QS_CPQ);
@@ -659,6 +660,87 @@ DEV_NOINLINE int fastStreamPrepare(Dev& d, FastCtx fc, int Q, int allowed, int a
     if (FLANE == 0) RS.statStreamPrepared += total;
   }
   return UNI32(FL.hot[top].sLen) > UNI32(FL.hot[top].sPos) ? 1 : 0;
+}
+
+// A queue's stream ends at its next gang member, and preparing streams again is a bulk job (three passes over all queues, the node engine stopped): on gang-heavy
+// rounds most single jobs therefore went through the per-job iteration (profiles/r03r_*).  After a gang has been placed its queue's next stretch of single jobs —
+// up to the next gang member, at most QS_ONE_MAX entries — is prepared by the CONTROL WAVE ALONE, one lane per entry, while the engine stays live: the same
+// barrier rules and the same float64 operations per entry as B_QSSUM / B_QSSTITCH / B_QSKEYS (entry e's allocation = the queue's allocation + the requests of entries
+// 0 .. e-1, which every lane sums for itself: integer adds, so the order is free).  Returns the prepared length (0: the queue's head is not a streamable single job).
+#define QS_ONE_MAX 1024
+DEV_NOINLINE int fastStreamPrepareOne(Dev& d, FastCtx fc, int q, int allowed, int capHint) {
+  const FastK k = fastKRef(d);
+  const DevCfg& c = d.cfg;
+  QHot f = FL.hot[q];
+  uniQHot(f);
+  if (f.sLen > f.sPos) return 0;
+  bool head = UNI32(FL.inHeap[q]) && f.gctx >= 0;
+  int cap = allowed < QS_ONE_MAX ? allowed : QS_ONE_MAX;
+  if (cap > capHint) cap = capHint;
+  if (!(head && cap >= 1 && f.headFast && f.headKind == 1 && f.itStage == 1 && !f.itJobOnlyEv && !f.cordoned && f.burst >= 1 && f.tokens >= 1 && f.evApplied == f.evDone &&
+        f.itQi >= 1 && f.itQi <= f.qEnd && UNI32(k.queuedJobs[f.itQi - 1]) == f.gctx)) return 0;
+  int want = f.qEnd - (f.itQi - 1);
+  if (want > cap) want = cap;
+  if (!f.rateInf && f.tokens < (double)want) want = (int)f.tokens;
+  if (fc.maxLookback != 0 && !f.itGangOnlyEv) {   // (fastStreamPrepare: element e >= 1 is peeked when itJobsSeen = seen + e - 1 < maxLookback)
+    int64_t lim = (int64_t)fc.maxLookback - f.itJobsSeen + 1;
+    if (lim < 1) lim = 1;
+    if (want > lim) want = (int)lim;
+  }
+  if (want < 1) return 0;
+  const int base = f.itQi - 1;
+  const int skipUnf = fc.skipKnown && RS.numUnfeasible > 0;
+  int64_t carry[MAXR];   // the queue's allocation (+ penalty) before the batch in hand
+  for (int r = 0; r < MAXR; r++) carry[r] = r < c.R ? (int64_t)(UNI64(FL.qAlloc[q][r]) + UNI64(FL.qPenalty[q][r])) : 0;
+  const double w = f.weight;
+  EvKey* out = d.qsKey + (size_t)q * QS_CMAX;
+  int len = 0; bool cut = false;
+  for (int b = 0; b * 64 < want && !cut; b++) {
+    // the first entry of this batch the stream cannot contain (B_QSSUM's barrier)
+    int nb = want - b * 64 < 64 ? want - b * 64 : 64;
+    FOR_LANES(x, 64) {
+      int e = b * 64 + x, stop = 0;
+      if (x < nb) {
+        int job = k.queuedJobs[base + e];
+        const int64_t* req = JREQ(d, job);
+        stop = d.jGang[job] >= 0 || (e > 0 && skipUnf && k.unfeasible[d.jShape[job]]);
+        for (int r = 0; r < c.R; r++) if (c.disallowed[r] && req[r] > 0) stop = 1;
+      }
+      FL.tmpQ[x] = stop;
+    }
+    for (int x = 0; x < nb; x++) if (UNI32(FL.tmpQ[x])) { nb = x; cut = true; break; }
+    // entry e's allocation = carry + the requests of the batch's entries before it (integer adds: every lane sums for itself), its costs with B_QSKEYS' operations
+    FOR_LANES(x, MAXR) FL.tmpX[x] = 0;
+    FOR_LANES(x, 64) {
+      if (x < nb) {
+        int e = b * 64 + x;
+        int64_t a[MAXR], with[MAXR];
+        for (int r = 0; r < MAXR; r++) a[r] = carry[r];
+        for (int m = b * 64; m < e; m++) { const int64_t* rq = JREQ(d, k.queuedJobs[base + m]); for (int r = 0; r < c.R; r++) a[r] += rq[r]; }
+        int job = k.queuedJobs[base + e];
+        const int64_t* req = JREQ(d, job);
+        for (int r = 0; r < c.R; r++) { with[r] = a[r] + req[r]; if (req[r]) LDS_ADD64(FL.tmpX[r], (uint64_t)req[r]); }
+        EvKey key;
+        key.proposed = drf(d, with) / w; key.current = drf(d, a) / w; key.size = drf(d, req) * w;   // updatePQItem (queue_scheduler.go:636-686)
+        key.pcPrio = c.pcPriority[d.jPc[job]]; key.job = job;
+        out[e] = key;
+      }
+    }
+    for (int r = 0; r < c.R; r++) carry[r] += (int64_t)UNI64(FL.tmpX[r]);
+    len += nb;
+  }
+  FOR_LANES(x, QCAPF) FL.tmpQ[x] = 0;
+  FOR_LANES(x, MAXR) FL.tmpX[x] = 0;
+  if (len < 1) return 0;
+  FAST_GLOBAL_FENCE();   // the keys are read back through global loads by this wave (streamKey)
+  if (FLANE == 0) {
+    FL.hot[q].sLen = len; FL.hot[q].sPos = 0; FL.hot[q].ewCount = 0; FL.hot[q].ewStart = 0; FL.sKind[q] = 0;
+    d.qsLen[2 * q] = len;
+    d.qsLen[2 * q + 1] = (!cut && base + want == d.queuedOff[q + 1]) ? 1 : 0;   // the queue's list ends where the stream ends (B_QSSTITCH)
+    RS.statStreamPrepared += len;
+  }
+  FAST_GLOBAL_FENCE();
+  return len;
 }
 
 enum Cmd {
