@@ -1386,6 +1386,7 @@ DEV_NOINLINE GangOut fastGangRun(Dev& d, FastCtx fc, StreamIn in, int t) {
   int g = -ref - 2;
   int cnt = UNI32(d.gangSeen[g]), off = UNI32(d.gangOff[g]);
   if (cnt < 2 || cnt > RING_N - 16) return out;
+  SEG_BEGIN();   // (profiling builds: statSeg[26..31] = member checks, staging, waiting for the engine's verdict, release of the held binds, accounting, the queue's next head)
   // CheckJobConstraints for the gang (constraints.go:121-157): anything that fails is the generic code's to report
   if (f.cordoned || in.globalTokens < (double)cnt || in.globalBurst < cnt || f.tokens < (double)cnt || f.burst < cnt) return out;
   if (UNI32((int)d.gangAllEvicted[g])) return out;
@@ -1403,6 +1404,7 @@ DEV_NOINLINE GangOut fastGangRun(Dev& d, FastCtx fc, StreamIn in, int t) {
   FOR_LANES(q, QCAPF) if (q * WIN < cnt + 4) { FL.hot[q].winKind = -1; FL.hot[q].winCount = 0; }
   if (f.sLen) { if (FLANE == 0) { FL.hot[t].sLen = 0; FL.hot[t].sPos = 0; } f.sLen = 0; f.sPos = 0; }
   int engSeq = in.engSeq;
+  SEG(26);
   streamBegin(&engSeq, 1);
   for (int b = 0; b < cnt; b += 4) {
     int n4 = cnt - b < 4 ? cnt - b : 4;
@@ -1410,8 +1412,10 @@ DEV_NOINLINE GangOut fastGangRun(Dev& d, FastCtx fc, StreamIn in, int t) {
     streamStageCommit(d, k, b, n4, v);
   }
   streamEnd(engSeq);
+  SEG(27);
   int fail = 0;
   int placed = streamAcked(&fail);
+  SEG(28);
   out.engSeq = engSeq;
   if (fail == 2) out.dropped = 1;
   if (placed < cnt || fail) {
@@ -1420,10 +1424,13 @@ DEV_NOINLINE GangOut fastGangRun(Dev& d, FastCtx fc, StreamIn in, int t) {
     return out;
   }
   streamRelease(d, k, 1);
+  SEG(29);
   streamAccount(d, k, 0, cnt);
+  SEG(30);
   if (!f.rateInf && cnt <= f.burst) f.tokens -= (double)cnt;   // rate.Limiter.ReserveN(cnt) (gang_scheduler.go:118-123)
   KeyOut ko;
   if (!fastAdvance(d, k, S, fc, t, f, &ko)) out.pend = t;
+  SEG(31);
   out.koValid = ko.valid; out.koA = ko.A; out.koX = ko.X; out.koY = ko.Y;
   out.handled = 1; out.cnt = cnt; out.refills = S.statRefills; out.evicted = S.numEvictedJobs;
   return out;
