@@ -20,7 +20,8 @@ prof config3_gangs --gangs 10000
 prof config4_reduced --nodes 20000 --jobs 200000 --queues 32 --occupied 0.95
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof_config1" -- python -c "
 import sys; sys.path.insert(0, '$OLDPWD'); sys.argv=['bench.py']
-import bench, argparse, torch, armada_amd
+import torch; torch.cuda.init()   # torch's bundled HIP runtime before the library's (tests/conftest.py)
+import bench, argparse, armada_amd
 a = argparse.Namespace(other_scale=1.0, steps=10, cpu_budget=0)
 print(bench.fit_batch_record(armada_amd.load_library(), a)['device_ms'])" > "$OLDPWD/$OUT/prof_config1.log" 2>&1 )
 DB=$(find "$OUT/prof_config1" -name "*.db" | head -1); [ -n "$DB" ] && python tools/rocprof_summary.py "$DB" "$OUT/kernel_stats_config1_fit_batch.csv" > /dev/null
@@ -32,3 +33,5 @@ F=$(find "$OUT/pmc_FETCH_SIZE" -name "*.db" | head -1); W=$(find "$OUT/pmc_WRITE
 find "$OUT" -name "*.db" -size +8M -delete
 ASCHED_HOSTPROF=1 timeout 300 python bench.py --steps 1 --warmup 0 --cpu-budget 0 --no-other > "$OUT/bench_hostprof.json" 2> "$OUT/bench_hostprof.err"; grep hostprof "$OUT/bench_hostprof.err" | tail -20 > "$OUT/hostprof.txt"
 head -c 900 "$OUT/bench_full.json" | tee -a "$OUT/summary.txt"; echo; ls "$OUT" | tee -a "$OUT/summary.txt"
+timeout 1500 python -m pytest tests -q -m gpu > "$OUT/pytest_gpu.log" 2>&1; echo "pytest(all gpu) rc=$?" | tee -a "$OUT/summary.txt"
+tail -4 "$OUT/pytest_gpu.log" | tee -a "$OUT/summary.txt"
