@@ -753,6 +753,7 @@ enum Cmd {
   CMD_ITERATE_NODES,
   CMD_MARKET,
   CMD_OPT_BEGIN, CMD_OPT_NEXT, CMD_OPT_APPLY, CMD_OPT_FAIL, CMD_OPT_END, CMD_OPT_TENT, CMD_OPT_TENT_UNDO,   // the fairness optimiser inside the round, gang by gang (asched_host.inc runOptimiserPhase)
+  CMD_MARKET_QUEUES,  // QueueScheduler.Schedule of a market-driven pool (asched_schedule_queues after asched_set_market)
   CMD_MARKET_ROUND,   // a whole market-driven round (asched_set_market; round_mkt.h): PreemptingQueueScheduler.Schedule in one launch of the auxiliary kernel
 };
 #define CMD_AUX_FIRST CMD_SUBMIT_CHECK
@@ -1104,6 +1105,18 @@ DEV void runAuxCommand(Dev& d, Ctl& c, int cmd) {
   switch (cmd) {
 #ifdef ASCHED_MARKET_ROUND
     case CMD_MARKET_ROUND: runRound(d, c); break;   // MKS.market is set: every market-specific step is behind mkOn(d) (round_mkt.h)
+    case CMD_MARKET_QUEUES: {   // QueueScheduler.Schedule on a market-driven pool (queue_scheduler.go:73-74, 176-203): CMD_QUEUES_ONLY's steps, here because the market code lives in this kernel
+      for (int q = 0; q <= cf.Q; q++) d.evOff[q] = 0;
+      if (d.evCheap) wgBulk(d, B_EVKEYS_OFF, cf.Q);
+      c.fastEvStatic = 1;
+      d.rs->lvl0NonNeg = 1;
+      wgBulk(d, B_LVL0, cf.N);
+      schedulePass(d, c, true, false, false);
+      d.cmdIO[2] = wgCompactIota(d, cf.M, d.inScheduled, d.resJob);
+      d.cmdIO[3] = wgCompactIota(d, cf.M, d.jcPreempted, d.resPreJob);
+      wgBulk(d, B_GATHER_SCHED, d.cmdIO[2]);
+      wgBulk(d, B_GATHER_PRE, d.cmdIO[3]);
+    } break;
 #endif
     case CMD_PQ_ORDER: {
       // sort.Sort over QueueCandidateGangIteratorPQ.Less (queue_scheduler.go:738-798) — the float goldens of queue_scheduler_test.go:995-1164.

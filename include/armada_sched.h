@@ -486,7 +486,9 @@ int32_t ASCHED_FN(round_prepare)(asched_t*, const asched_queues* queues);
 int32_t ASCHED_FN(schedule_round)(asched_t*, asched_round_result* out);
 
 /* QueueScheduler.Schedule (queue_scheduler.go:94-304) over the queued jobs only — no eviction phases; the entry the
-   reference's queue_scheduler_test.go drives.  `preempted_*` lists the fair-share victims (sctx.PreemptedJobIds). */
+   reference's queue_scheduler_test.go drives.  `preempted_*` lists the fair-share victims (sctx.PreemptedJobIds).
+   On a market-driven pool (set_market) the queue is picked by the market iterator and the spot price is set, as NewQueueScheduler
+   does when marketDriven is true (queue_scheduler.go:73-74, 176-203). */
 int32_t ASCHED_FN(schedule_queues)(asched_t*, asched_round_result* out);
 /* GangScheduler.Schedule (gang_scheduler.go:100-148) for one gang of queued jobs against the current round state. */
 int32_t ASCHED_FN(gang_schedule)(asched_t*, int32_t n, const int32_t* jobs, int32_t* ok, int32_t* reason, asched_pod_result* out /*[n]*/);

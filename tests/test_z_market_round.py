@@ -29,7 +29,7 @@ def market_case(seed):
     return wl, bids, cutoff
 
 
-def market_round(lib, wl, bids, cutoff):
+def market_round(lib, wl, bids, cutoff, queues_only=False):
     s = W.load(lib, wl)
     W.set_jobs(s, wl, bid_price=bids)
     pcp = np.asarray(wl.config.pc_priority)
@@ -38,7 +38,7 @@ def market_round(lib, wl, bids, cutoff):
     s.round_prepare(wl.queue_weight, queued, global_tokens=float(wl.global_burst), global_burst=wl.global_burst, global_rate_inf=wl.rate_inf,
                     queue_tokens=[float(wl.queue_burst)] * nq, queue_burst=[wl.queue_burst] * nq, queue_rate_inf=[wl.rate_inf] * nq)
     s.set_market(True, cutoff)
-    res = s.schedule_round()
+    res = s.schedule_queues() if queues_only else s.schedule_round()
     mr = s.market_result()
     s.close()
     return res, mr
@@ -61,6 +61,23 @@ def compare(lib, oracle_lib, seeds):
 def test_market_rounds_hostsim_equal_oracle(hostsim_lib, oracle_lib):
     spot, sched, over = compare(hostsim_lib, oracle_lib, range(7000, 7060))
     assert spot >= 20 and sched > 2000 and over >= 20   # the rounds do set spot prices and overrides
+
+
+def queues_only(lib, oracle_lib, seeds):
+    n = 0
+    for seed in seeds:
+        wl, bids, cutoff = market_case(seed)
+        a, ma = market_round(oracle_lib, wl, bids, cutoff, queues_only=True)
+        b, mb = market_round(lib, wl, bids, cutoff, queues_only=True)
+        scenario.assert_same_round(a, b)
+        assert ma["spot_price"] == mb["spot_price"] and (ma["billable"] == mb["billable"]).all() and ma["price_override"] == mb["price_override"], seed
+        n += len(a.scheduled)
+    return n
+
+
+def test_market_queue_scheduler_alone(hostsim_lib, oracle_lib):
+    """asched_schedule_queues on a market-driven pool: QueueScheduler.Schedule with the market iterator and the spot price, no eviction phases"""
+    assert queues_only(hostsim_lib, oracle_lib, range(7100, 7130)) > 500
 
 
 def test_market_mode_changes_the_round(oracle_lib):
@@ -98,3 +115,4 @@ def test_market_with_fairshare_preemption_limiter_is_refused(hostsim_lib, oracle
 def test_market_rounds_gpu_equal_oracle(hip_lib, oracle_lib):
     spot, sched, over = compare(hip_lib, oracle_lib, range(7000, 7030))
     assert spot >= 10 and sched > 1000
+    assert queues_only(hip_lib, oracle_lib, range(7100, 7115)) > 200
