@@ -1170,7 +1170,12 @@ __device__ static void relocateIn(Dev& d, int cmd) {
     g_nreloc = 0;
     g_rsGlobal = d.rs;
     int Q = d.cfg.Q, R = d.cfg.R, npc = d.cfg.npc;
-    bool want = (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY || cmd == CMD_PASS1 || cmd == CMD_PASS2) && Q > 0 && d.qWeight != nullptr && (Q <= QCAPF || d.f.relocAll);
+#ifdef ASCHED_AUX_TU
+    const bool marketCmd = cmd == CMD_MARKET_ROUND || cmd == CMD_MARKET_QUEUES;   // (the auxiliary kernel's rounds; the round kernel's code does not see this)
+#else
+    const bool marketCmd = false;
+#endif
+    bool want = (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY || cmd == CMD_PASS1 || cmd == CMD_PASS2 || marketCmd) && Q > 0 && d.qWeight != nullptr && (Q <= QCAPF || d.f.relocAll);
     if (want) {
       int off = 0, n = 0; bool fits = true;
       auto add = [&](void** pp, int bytes) {
@@ -1190,6 +1195,14 @@ __device__ static void relocateIn(Dev& d, int cmd) {
       add((void**)&d.pqProposed, q1 * 8); add((void**)&d.pqCurrent, q1 * 8); add((void**)&d.pqBudget, q1 * 8); add((void**)&d.pqSize, q1 * 8);
       add((void**)&d.pqPcPrio, q1 * 4); add((void**)&d.pqSchedPrio, q1 * 4); add((void**)&d.pqGctx, q1 * 4); add((void**)&d.pqInHeap, q1);
       add((void**)&d.replayAlloc, q1 * R * 8);
+#ifdef ASCHED_AUX_TU
+      if (marketCmd && g_mk.s) {   // MarketIteratorPQ's items and heap, the merge iterators' held values, the round's market scalars (round_mkt.h)
+        add((void**)&g_mk.s, (int)sizeof(MktScalars));
+        add((void**)&g_mk.heap, q1 * 4); add((void**)&g_mk.pqPrice, q1 * 8); add((void**)&g_mk.pqRuntime, q1 * 8); add((void**)&g_mk.pqSubmit, q1 * 8); add((void**)&g_mk.pqQueued, q1);
+        add((void**)&g_mk.itV1, q1 * 4); add((void**)&g_mk.itV2, q1 * 4);
+        add((void**)&g_mk.qBillable, Q * R * 8); add((void**)&g_mk.qOverride, Q * 8); add((void**)&g_mk.qHasOverride, Q);
+      }
+#endif
       g_nreloc = fits ? n : 0;
     }
   }

@@ -1154,7 +1154,7 @@ DEV void updateItem(Dev& d, Ctl& c, int q, const PassCfg& pc) {  // updatePQItem
 }
 DEV void updateAndPush(Dev& d, Ctl& c, int q, const PassCfg& pc) {
   updateItem(d, c, q, pc);
-  MK(if (mkOn(d)) { if (d.pqGctx[q] != -1) mkPush(d, q); else d.pqInHeap[q] = 0; return; })   // updateAndPushPQItem market_iterator.go:103-111
+  MK(if (mkOn(d)) { XSEG(17); if (d.pqGctx[q] != -1) mkPush(d, q); else d.pqInHeap[q] = 0; XSEG(18); return; })   // updateAndPushPQItem market_iterator.go:103-111
   d.pqInHeap[q] = d.pqGctx[q] != -1;
 }
 
@@ -1250,7 +1250,9 @@ DEV void costItClear(Dev& d, Ctl& c, int top, const PassCfg& pc) {  // :595-606
   if (top < 0) return;
 #ifdef ASCHED_MARKET_ROUND
   if (mkOn(d)) {   // MarketBasedCandidateGangIterator.Clear (market_iterator.go:74-89): Pop, item.it.Clear(), remember the result, update and push
+    XSEG_BEGIN();
     int q = mkPop(d);
+    XSEG(16);
     d.itNext[q] = -1;
     MKS.prevRank = d.qNameRank[q]; MKS.prevCost = MKD.pqPrice[q];
     updateAndPush(d, c, q, pc);

@@ -435,7 +435,7 @@ def other_configs(hip, args, t_start):
 
     guarded("BASELINE configs[1]", lambda: fit_batch_record(hip, args))
 
-    def shape(label, full_kwargs, reduced_kwargs, note, full_parity=False):
+    def shape(label, full_kwargs, reduced_kwargs, note, full_parity=False, only_size=False):
         def run():
             if full_parity and full_kwargs and args.cpu_budget > 0:   # the oracle round of the FULL input (~1 minute, like the headline's): parity at the size the value is quoted on
                 rec, wl, res, iters = round_shape_record(hip, args, label, full_kwargs, 2, note, 1)
@@ -453,6 +453,7 @@ def other_configs(hip, args, t_start):
                 if ores is not None:
                     red["parity"] = parity_record(res, ores, wl.num_jobs, "oracle round on the same input")
             if rec is None:
+                if only_size: red["config"] = label   # (a record that has no full-size leg by design)
                 return red
             rec["reduced"] = red
             rec["cpu_baseline"] = dict(red.get("cpu_baseline") or {}, note="measured at the reduced size (see `reduced`); the GPU value of this record is the full size")
@@ -478,6 +479,9 @@ def other_configs(hip, args, t_start):
     guarded("submit check", submit)
     guarded("fairness optimiser node scoring", lambda: optimiser_record(hip, args))
     guarded("market-driven round + pricer", lambda: market_record(hip, args))
+    # the queue-count cliff (round-2 review): more than 64 queues leave the fast iteration (one lane per queue) for the generic one; measured, not hidden
+    guarded("256 queues", shape("256 queues (beyond the 64-lane fast iteration)", None, dict(n_nodes=20_000, n_jobs=200_000, n_queues=256),
+                                "more than 64 queues: the whole round on the generic iteration (DESIGN.md 9); the same nodes and jobs as the reduced configs[3] / [4] inputs, 256 queues", only_size=True))
     return recs
 
 

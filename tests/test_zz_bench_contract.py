@@ -53,7 +53,7 @@ def test_round_bench_line(fake_gpu, monkeypatch, capsys):
     # every other BASELINE config + the submit check sits in the same record, each with roofline and cpu_baseline
     oc = {r["config"]: r for r in line["other_configs"]}
     assert set(oc) == {"BASELINE configs[1]", "BASELINE configs[3]", "BASELINE configs[4]", "submit check (SURVEY 8f-2)", "fairness optimiser node scoring (SURVEY 8f-3)",
-                       "market-driven round + indicative gang pricer (SURVEY 8f-4)"}, set(oc)
+                       "market-driven round + indicative gang pricer (SURVEY 8f-4)", "256 queues (beyond the 64-lane fast iteration)"}, set(oc)
     for name, r in oc.items():
         assert "error" not in r and "skipped" not in r, r
         assert ROOFLINE_KEYS <= set(r["roofline"]) and CPU_KEYS <= set(r["cpu_baseline"]), name
