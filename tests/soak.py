@@ -13,6 +13,7 @@
     python tests/soak.py submitcheck 400    # batched SubmitChecker vs the literal sequential restatement (and 3-entry cache)
     python tests/soak.py fit 600            # fit_select_batch at every priority on occupied NodeDbs
 
+SOAK_LIB=hip (on a GPU box): the same seeds through the product library instead of the CPU build.
 Prints one line per divergence and a summary; exit code 1 if anything diverged.  (Round 1: all clean after the submit-check fix.)
 """
 import os
@@ -31,6 +32,11 @@ from armada_amd.binding import Library, SchedError  # noqa: E402
 def libs():
     import subprocess
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    if os.environ.get("SOAK_LIB") == "hip":   # on a GPU box: the product library itself against the oracle (torch's HIP runtime first: tests/conftest.py)
+        import torch
+        torch.cuda.init()
+        import armada_amd
+        return Library(os.path.join(ROOT, "oracle", "liboracle.so"), "oracle_"), armada_amd.load_library()
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hostsim")])
     return Library(os.path.join(ROOT, "oracle", "liboracle.so"), "oracle_"), Library(os.path.join(ROOT, "tests", "hostsim", "libhostsim.so"), "asched_")
 
