@@ -72,3 +72,45 @@ def test_preempting_a_gang_member_takes_the_whole_gang(lib):
     new = ident[id(incoming)]
     assert res.scheduled == {new: 0}, res.scheduled       # g1 has the highest index: it is preempted directly, on node 1
     assert set(res.preempted) == {ident[id(g1)], ident[id(g2)]}, "exactly the two gang members, no filler job"   # :905-922
+
+
+@pytest.mark.parametrize("already_preempted", [False, True])
+def test_preempted_job_is_not_rescheduled(lib, already_preempted):
+    """nodedb_test.go:1103-1148 TestPreemptedJobIsNotRescheduled: SelectNodeForJobWithTxn refuses a job that carries PreemptionDetails (the failsafe of
+    nodedb.go:538-544) although a node has room for it; a job that was never preempted schedules there.  The ABI has no setter for PreemptionDetails: the state
+    is reached the way the scheduler reaches it — the job is the victim of a fair-share preemption applied by the gang scheduler (gang_scheduler.go:268-273) —
+    and a second, empty node then has room for it."""
+    nodes = [F.Test32CpuNode(F.TestPriorities), F.Test32CpuNode(F.TestPriorities)]
+    incumbents = F.N1Cpu4GiJobs("A", F.PriorityClass0, 32)
+    incoming = F.Test1Cpu4GiJob("B", F.PriorityClass1)
+    fresh = F.Test1Cpu4GiJob("A", F.PriorityClass0)
+    cfg = F.TestSchedulingConfig()
+    # node 1 is held by one big non-preemptible-by-anyone job (non-preemptible priority class) while B is scheduled, so B has to preempt on node 0; it is unbound afterwards
+    big = F.Test32Cpu256GiJob("A", F.PriorityClass3)
+    jobs = incumbents + [incoming, fresh, big]
+    ident = {id(j): i for i, j in enumerate(jobs)}
+    c = scenario.Case(lib, cfg, nodes)
+    c.set_jobs(jobs, {"A": 0, "B": 1}, {})
+    s = c.sched
+    npc = len(c.pc_names)
+    s.round_prepare([1.0, 1.0], [[], [ident[id(incoming)]]], name_rank=[0, 1], demand=np.zeros((2, scenario.R), dtype=np.int64),
+                    allocated_by_pc=np.zeros((2, npc, scenario.R), dtype=np.int64), fairshare_preemption_tokens=100.0)
+    for j in incumbents:
+        s.bind(ident[id(j)], 0, cfg["priority_classes"][j["pc"]]["priority"])
+    s.bind(ident[id(big)], 1, cfg["priority_classes"][big["pc"]]["priority"])
+    for idx, j in enumerate(incumbents):
+        s.evict(ident[id(j)], 0)
+        s.add_evicted(idx, ident[id(j)], 0)
+    res = s.schedule_queues()
+    assert res.scheduled == {ident[id(incoming)]: 0} and len(res.preempted) == 1
+    victim = next(iter(res.preempted))
+    s.unbind(ident[id(big)], 1)                                # node 1 is empty now
+    job = victim if already_preempted else ident[id(fresh)]
+    s.txn_begin()
+    ok, pods, pre = s.schedule_many([job])
+    s.txn_abort()
+    assert len(pre) == 0                                       # :1135
+    if already_preempted:
+        assert not ok and pods[0].node < 0                     # :1143-1144 (no PodSchedulingContext is created)
+    else:
+        assert ok and pods[0].node == 1                        # :1138-1141
