@@ -2,6 +2,7 @@
 profiling build (tools/build_prof.sh) the segment clocks of the generic iteration are printed by round_stats()"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch; torch.cuda.init()   # torch's bundled HIP runtime before the library's (tests/conftest.py)
 import armada_amd
 from armada_amd import workloads as W
 kw = dict(n_nodes=20_000, n_jobs=200_000, n_queues=32, occupied=0.95)
