@@ -1104,7 +1104,7 @@ __device__ static __attribute__((noinline)) void applyEvictedRange(Dev& d, int q
     if (sign < 0) {  // taken back: the job is evicted again, exactly as the evictor left it (eviction.go:245-260, evictApply)
       k.jcHasPctx[job] = 0; k.pcNode[job] = -1; k.pcSap[job] = 0; k.pcPap[job] = ASCHED_MIN_PRIORITY; k.pcMethod[job] = ASCHED_METHOD_NONE;
       k.jobEvictedOnNode[job] = 1; k.jobFlags[job] = F_EVICTED; k.inPreempted[job] = 1;
-      if (!pending) { int idx = k.evIdxByPos[p]; k.evTabAlive[idx] = 1; k.evIndexOfJob[job] = idx; }
+      if (!pending) { int idx = k.evIdxByPos[p]; k.evTabAlive[idx] = 1; k.evIndexOfJob[job] = idx; g_rs.fairIndexValid = 0; }   // (an entry comes back: ensureFairIndex)
       continue;
     }
     k.jcReason[job] = 0; k.jcHasPctx[job] = 1; k.pcNode[job] = n; k.pcSap[job] = prio;

@@ -301,6 +301,7 @@ DEV void txnAbort(Dev& d, Txn& t) {
       updateKeysCtl(d, n);
     } else if (kind == U_EVTAB_DEL) {
       d.evTabAlive[a] = 1; d.evIndexOfJob[d.evTabJob[a]] = a;
+      d.rs->fairIndexValid = 0; d.rs->ftValid = 0;   // an entry comes back: the per-node index may have been built without it (ensureFairIndex)
     }
   }
 #ifndef ASCHED_NO_FT

@@ -258,7 +258,7 @@ DEV void bulkElem(Dev& d, int kind, int i) {
     } break;
     // per-node index of the evicted table (ensureFairIndex): count -> offsets -> scatter -> per-node sort by descending Index
     case B_FAIR_ZERO: d.accStamp[i] = 0; break;
-    case B_FAIR_COUNT: { int n = d.jcAssigned[d.evTabJob[i]]; if (n >= 0) atomicAddI32(&d.accStamp[n], 1); } break;
+    case B_FAIR_COUNT: { int n = d.evTabAlive[i] ? d.jcAssigned[d.evTabJob[i]] : -1; if (n >= 0) atomicAddI32(&d.accStamp[n], 1); } break;   // (dead entries are left out: ensureFairIndex)
     case B_FAIR_PSUM: {
       int C = (c.N + FAIR_CHUNKS - 1) / FAIR_CHUNKS, n0 = i * C, n1 = n0 + C < c.N ? n0 + C : c.N;
       int sum = 0;
@@ -270,7 +270,7 @@ DEV void bulkElem(Dev& d, int kind, int i) {
       int run = d.fairPart[i];
       for (int n = n0; n < n1; n++) { int cnt = d.accStamp[n]; d.fairOff[n] = run; d.accStamp[n] = run; run += cnt; }
     } break;
-    case B_FAIR_SCATTER: { int n = d.jcAssigned[d.evTabJob[i]]; if (n >= 0) d.fairEnt[atomicFetchAddI32(&d.accStamp[n], 1)] = i; } break;
+    case B_FAIR_SCATTER: { int n = d.evTabAlive[i] ? d.jcAssigned[d.evTabJob[i]] : -1; if (n >= 0) d.fairEnt[atomicFetchAddI32(&d.accStamp[n], 1)] = i; } break;
     case B_FAIR_SORT: {
       int k0 = d.fairOff[i], k1 = d.fairOff[i + 1];
       for (int a = k0 + 1; a < k1; a++) {
@@ -481,8 +481,19 @@ DEV void schedulePass(Dev& d, Ctl& c, bool withQueued, bool skipKey, bool cmpPri
   queueSchedule(d, c, pc, d.uniOff);
 }
 
-// Per-node index of the evicted table (CSR node -> table Indexes, descending) for fair-share preemption.  Every entry below
-// evictedTableSize is indexed, dead or alive (a transaction abort can bring an entry back); rebuilt when the table has grown.
+// Per-node index of the evicted table (CSR node -> table Indexes, descending) for fair-share preemption.  It holds the entries that were ALIVE when it was
+// built: late in a pass most of the table is dead (rescheduled or preempted jobs), and the per-node evaluation of the wide pass walks a node's slice entry by
+// entry — two dependent gathers per dead entry, nine entries per node at 100 000 nodes x 900 000 evicted jobs.  Rebuilt when the table has grown, when an entry
+// has come back (a transaction abort, a taken-back commit of the fast path: both clear fairIndexValid) and every FAIR_REBUILD_EVERY queries, which
+// drops the entries that have died since (entries that die after a build stay in it and are skipped by their alive flag, as before).
+#ifndef FAIR_REBUILD_EVERY
+#ifdef ASCHED_HOSTSIM
+#define FAIR_REBUILD_EVERY 5      // (the CPU build of the tests rebuilds all the time: every seeded round exercises an index built in the middle of a pass)
+#else
+#define FAIR_REBUILD_EVERY 8192   // (measured on configs[4], profiles/r03z: what pays is leaving out the entries that are dead when the index is first built in a pass — 128 / 512 / 2 048 / 8 192 queries between
+                                  //  rebuilds give the same time inside the passes, and a rebuild costs 4.5 ms at 900 000 table entries: 17.3 / 14.7 / 14.1 / 13.7 s per round)
+#endif
+#endif
 // The threshold table from the planes and the evicted table as they are now: three grid-wide passes shared with the helper workgroups.  They have an op of their
 // own (wgFtBuild) instead of three more kinds in bulkElem: a call inside that switch cost the stream preparation 3-5 % of the headline round (measured, profiles/r03f).
 #ifndef ASCHED_NO_FT
@@ -494,10 +505,12 @@ DEV void ftBuild(Dev& d) {
 }
 #endif
 DEV_COLD COLD_MS_10 void ensureFairIndex(Dev& d) {
+  const bool periodic = d.rs->fairIndexValid && ++d.accEpoch_unused >= FAIR_REBUILD_EVERY;   // (queries since the last build: a counter of this launch, in the descriptor's LDS copy)
 #ifndef ASCHED_NO_FT
-  if (d.rs->fairIndexValid) { if (d.ftT && !d.rs->ftValid && d.rs->ftWanted) ftBuild(d); return; }
+  if (d.rs->fairIndexValid && !periodic) { if (d.ftT && !d.rs->ftValid && d.rs->ftWanted) ftBuild(d); return; }
 #endif
-  if (d.rs->fairIndexValid) return;
+  if (d.rs->fairIndexValid && !periodic) return;
+  d.accEpoch_unused = 0;
   int E = d.rs->evictedTableSize, N = d.cfg.N;
   wgBulk(d, B_FAIR_ZERO, N);
   wgBulk(d, B_FAIR_COUNT, E);
@@ -537,6 +550,7 @@ DEV_COLD COLD_MS_11 void ensureReplaySlow(Dev& d, Ctl& c) {
   fastEnterGeneric(d, c);
   wgBulk(d, B_EVIDX, d.rs->numEvictedList);
   wgBulk(d, B_EVALIVE, d.rs->evictedTableSize);
+  d.rs->fairIndexValid = 0;   // the alive flags were rewritten: entries may have come back
   swapLoopArrays(d);
   c.onlyEvicted = sOnly; c.compareSchedPrio = sCmp; c.useReplayAlloc = sUse; c.skipKeyCheck = sSkip; c.fastEvStatic = sEv;
   fastPassReset();

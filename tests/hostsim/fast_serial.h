@@ -145,7 +145,7 @@ DEV void applyEvictedRange(Dev& d, int q, int p0, int p1, int sign = 1) {
     if (sign < 0) {  // state of a job the evictor has just evicted (eviction.go:245-260, evictApply)
       k.jcHasPctx[job] = 0; k.pcNode[job] = -1; k.pcSap[job] = 0; k.pcPap[job] = ASCHED_MIN_PRIORITY; k.pcMethod[job] = ASCHED_METHOD_NONE;
       k.jobEvictedOnNode[job] = 1; k.jobFlags[job] = F_EVICTED; k.inPreempted[job] = 1;
-      if (!RS.replayPending) { int idx = k.evIdxByPos[p]; k.evTabAlive[idx] = 1; k.evIndexOfJob[job] = idx; RS.ftValid = 0; }   // (an entry comes back: round_ft.h "Staleness")
+      if (!RS.replayPending) { int idx = k.evIdxByPos[p]; k.evTabAlive[idx] = 1; k.evIndexOfJob[job] = idx; RS.ftValid = 0; RS.fairIndexValid = 0; }   // (an entry comes back: round_ft.h "Staleness", ensureFairIndex)
       continue;
     }
     k.jcReason[job] = 0; k.jcHasPctx[job] = 1; k.pcNode[job] = n; k.pcSap[job] = prio;

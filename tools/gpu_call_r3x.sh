@@ -2,7 +2,7 @@
 # after r03v (k_control unchanged: tools/kcontrol_isa_hash.sh): the driver-shaped bench line with the new sub-records, the GPU suite, and the differential soaks
 # through the PRODUCT library (SOAK_LIB=hip).   /usr/local/graft/bin/gpurun --timeout 2000 -- 'bash tools/gpu_call_r3x.sh'
 set -u
-OUT=gpurun_out/r03x; mkdir -p "$OUT"
+OUT=gpurun_out/${TAG:-r03z}; mkdir -p "$OUT"
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; echo "smoke rc=$?" | tee -a "$OUT/summary.txt"
 timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench_full.json" 2> "$OUT/bench_full.err"; echo "bench rc=$?" | tee -a "$OUT/summary.txt"
