@@ -229,3 +229,14 @@ def test_two_handles_run_rounds_concurrently(hip_lib, oracle_lib):
     assert not any(t.is_alive() for t in th), "a round hung"
     for i in (0, 1):
         scenario.assert_same_round(want[i], got[i])
+
+
+def test_null_handle_is_refused(hostsim_lib):
+    """every int32-returning entry point answers ASCHED_ERR_INVALID to a NULL handle instead of dereferencing it (round-2 advice)"""
+    import ctypes as C
+    lib = C.CDLL(hostsim_lib.path)
+    for name in ("asched_schedule_round", "asched_schedule_queues", "asched_round_prepare", "asched_jobs_set", "asched_nodes_upsert", "asched_set_market", "asched_round_stats"):
+        fn = getattr(lib, name)
+        fn.restype = C.c_int32
+        fn.argtypes = [C.c_void_p, C.c_void_p] + ([C.c_void_p] if name == "asched_jobs_set" else [])
+        assert fn(None, None, *([None] if name == "asched_jobs_set" else [])) != 0, name
