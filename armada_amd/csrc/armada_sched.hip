@@ -55,12 +55,16 @@ __device__ static inline MktDev* mktDev() { return &g_mk; }
 // fair-share preemption (OP_FAIR).  They read only HBM state (never the control workgroup's LDS); the hand-shake is a
 // generation counter (release store by the control wave, relaxed polls + acquire fence by the helpers) and a completion
 // counter (release increments, acquire poll) at agent scope, so it is correct across XCDs (separate L2s).
+struct HelpSlot { unsigned long long gen, mn, mx, pad; };   // one per helper workgroup: written by that workgroup alone (plain stores, the generation last with release)
+#define HELP_MAX 255
 struct HelpBox {
   unsigned long long cmd;      // (generation << 8) | op, published with ONE release store: a helper can never pair a new generation with an old op
-  unsigned int done, pad;
-  unsigned long long result;   // OP_SCAN / OP_SCANFAIR: min packed key; OP_FAIR: max (Index + 1)
-  unsigned long long result2;  // OP_SCANFAIR: max (Index + 1)
+  unsigned long long pad[3];
   unsigned long long args[28]; // ScanArgs / FairArgs image (OP_SCANFAIR: ScanArgs at word 0, FairArgs at word HELP_ARGS2), read by the helpers with agent-scope loads
+  // Results and completion (round 4): helper h folds its workgroup's minimum / maximum into slot[h] and stores the command's generation there LAST (release); the
+  // control wave polls the generations one slot per lane and folds the values across its lanes.  No read-modify-write on a shared word: round 3 counted ~180 clocks
+  // of serialised atomics per helper on result / result2 / done (23 k of a pass with 127 helpers, profiles/r03z_fair_index_alive_only.txt).
+  HelpSlot slot[HELP_MAX];
 };
 #define HELP_ARGS2 14
 static_assert(sizeof(ScanArgs) <= HELP_ARGS2 * 8 && sizeof(FairArgs) <= (28 - HELP_ARGS2) * 8 && sizeof(ScanArgs) % 8 == 0 && sizeof(FairArgs) % 8 == 0, "HelpBox args image");
@@ -81,27 +85,45 @@ template <class A, class B = A> __device__ static inline void helpIssue(int op, 
   if (args2) {
     const ull_alias* src = (const ull_alias*)args2;
     for (int i = 0; i < (int)(sizeof(B) / 8); i++) __hip_atomic_store(&b->args[HELP_ARGS2 + i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&b->result2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __hip_atomic_store(&b->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(&b->result, (op == OP_SCAN || op == OP_SCANFAIR) ? ~0ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   g_gen++;
   __hip_atomic_store(&b->cmd, ((unsigned long long)g_gen << 8) | (unsigned)op, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ static inline unsigned long long helpWait() {  // whole control wave, uniformly (no lane-divergent spin)
+__device__ static inline unsigned long long waveMin64Dpp(unsigned long long v);
+// Completion of the command issued last: every helper's slot carries its generation.  Whole control wave, uniformly (no lane-divergent spin): lane l watches
+// slots l, l + 64, ...  Returns the folded minimum; the folded maximum goes back through *mxOut — both in REGISTERS, wave-uniform (round 3's slot variants handed
+// the maximum back through a new __shared__ word written by lane 0 and read by the wave with nothing in between: profiles/r04a_lds_handback_rootcause.txt).
+__device__ static inline unsigned long long helpWait(unsigned long long* mxOut = nullptr) {
   HelpBox* b = g_box;
-  unsigned int want = (unsigned)g_H, spins = 0;
-  for (;;) {
-    unsigned int dn = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&b->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
-    if (dn == want) break;
-    __builtin_amdgcn_s_sleep(1);
-    if ((++spins & 0xffff) == 0 && cancelRequested(g_dev)) {  // the caller gave up (hard timeout): do not wait for a helper that may never answer
-      raise(g_dev, ASCHED_ERR_TIMEOUT, 902);
-      break;
+  int lane = threadIdx.x & 63;
+  int H = __builtin_amdgcn_readfirstlane(g_H);
+  unsigned long long gen = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)g_gen);   // (written by lane 0 in helpIssue; a workgroup barrier lies between)
+  unsigned long long mn = ~0ull, mxInv = ~0ull;
+  unsigned int spins = 0;
+  bool gaveUp = false;
+  for (int base = 0; base < H && !gaveUp; base += 64) {
+    int i = base + lane;
+    bool mine = i < H;
+    for (;;) {
+      unsigned long long g = mine ? __hip_atomic_load(&b->slot[mine ? i : 0].gen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : gen;
+      if (__ballot(g != gen) == 0) break;
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 0xffff) == 0 && cancelRequested(g_dev)) {  // the caller gave up (hard timeout): do not wait for a helper that may never answer
+        raise(g_dev, ASCHED_ERR_TIMEOUT, 902);
+        gaveUp = true;
+        break;
+      }
+      if ((spins & 0xffff) == 0 && g_dev.progress) { g_dev.progress[5] = __popcll(__ballot(g == gen)); g_dev.progress[6] = H; g_dev.progress[7] = (int)gen; g_dev.progress[8] = (int)(b->cmd >> 8); g_dev.progress[9] = (int)(b->cmd & 255); }
     }
-    if ((spins & 0xffff) == 0 && g_dev.progress) { g_dev.progress[5] = (int)dn; g_dev.progress[6] = g_H; g_dev.progress[7] = (int)g_gen; g_dev.progress[8] = (int)(b->cmd >> 8); g_dev.progress[9] = (int)(b->cmd & 255); }
+    if (mine && !gaveUp) {
+      unsigned long long a = __hip_atomic_load(&b->slot[i].mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long m = ~__hip_atomic_load(&b->slot[i].mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      mn = a < mn ? a : mn; mxInv = m < mxInv ? m : mxInv;
+    }
   }
-  return __hip_atomic_load(&b->result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  mn = waveMin64Dpp(mn);
+  if (mxOut) *mxOut = ~waveMin64Dpp(mxInv);   // max(x) = ~min(~x)
+  return mn;
 }
 
 __device__ static inline void atomicAddI64(int64_t* p, int64_t v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
@@ -220,8 +242,9 @@ __device__ static inline int wgFairSelect(Dev& d, const FairArgs& a) {
   int nw = blockDim.x >> 6;
   for (int w = 0; w < nw; w++) { int p = g_mb.waveCount[w]; best = p > best ? p : best; }
   if (g_H) {
-    unsigned long long hb = helpWait();
-    int h = (int)(unsigned int)hb - 1;
+    unsigned long long hmx;
+    (void)helpWait(&hmx);
+    int h = (int)(unsigned int)hmx - 1;
     best = h > best ? h : best;
   }
   return best;
@@ -241,9 +264,10 @@ __device__ static inline int wgScanFair(Dev& d, const ScanArgs& a, const FairArg
   int nw = blockDim.x >> 6;
   for (int k = 0; k < nw; k++) { unsigned long long p = g_mb.partial[k]; best = p < best ? p : best; int q = g_mb.waveCount[k]; idx = q > idx ? q : idx; }
   if (g_H) {
-    unsigned long long hb = helpWait();
+    unsigned long long hmx;
+    unsigned long long hb = helpWait(&hmx);
     best = hb < best ? hb : best;
-    int h = (int)(unsigned int)__hip_atomic_load(&g_box->result2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;
+    int h = (int)(unsigned int)hmx - 1;
     idx = h > idx ? h : idx;
   }
   d.rs->numScans++;
@@ -526,7 +550,7 @@ __device__ static inline void baseScan(KREF k, FastS& S, const JobTail& r) {
     S.statScanSteps++;
     if (UNI32(g_fl.cand[s].node) == -2 && UNI64(g_fl.cand[s].key) != 0) p0++;   // a stale candidate: the entry at the cursor is the one that was used up (its bit may still be on its way to L2)
     for (;;) {
-      if (p0 >= N) { if (lane == 0) { g_fl.cand[s].pos = N; g_fl.cand[s].node = -1; } return; }
+      if (p0 >= N) { if (lane == 0) { g_fl.cand[s].pos = N; g_fl.cand[s].node = -1; } LANE0_PUBLISHED(); return; }
       int w0 = p0 >> 6, w = w0 + lane;
       unsigned long long word = w < k.fitW ? __hip_atomic_load(&k.fitBits[(size_t)s * k.fitW + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
 #ifdef ASCHED_FASTPROF
@@ -542,6 +566,7 @@ __device__ static inline void baseScan(KREF k, FastS& S, const JobTail& r) {
       unsigned long long key = k.baseKey[q], cls = k.baseCls[q]; int node = k.baseNode[q];
       long long ex0 = k.E > 0 ? k.baseExtra[q] : 0, ex1 = k.E > 1 ? k.baseExtra[k.Npad + q] : 0;
       if (lane == 0) { CandRec c; c.pos = q; c.node = node; c.key = key; c.cls = cls; c.ex0 = ex0; c.ex1 = ex1; c.pad = 0; g_fl.cand[s] = c; }
+      LANE0_PUBLISHED();
       return;
     }
   }
@@ -767,6 +792,7 @@ __device__ static inline void engineRestore(int q) {
   else if (lane < B) g_fl.headReq[q][lane - HW - TW] = g_fl.eng.req[lane - HW - TW];
   else if (lane == B) { g_fl.kA[q] = g_fl.bk.kA; g_fl.kX[q] = g_fl.bk.kX; g_fl.kY[q] = g_fl.bk.kY; }
   else if (lane == B + 1) { g_fl.effA[q] = g_fl.bk.effA; g_fl.effX[q] = g_fl.bk.effX; g_fl.effY[q] = g_fl.bk.effY; g_fl.inHeap[q] = g_fl.bk.inHeap; }
+  LANE0_PUBLISHED();   // lanes B, B + 1 wrote fixed words the whole wave reads next (fastRollback's caller rebuilds the heap from them)
 }
 __device__ static inline int engineWait(const FastS& S) {
   int want = S.engSeq;
@@ -904,6 +930,7 @@ __device__ static inline void engineStop(Dev& d, FastS& S) {
   if (m > S.statL0Max) S.statL0Max = m;
 #ifndef ASCHED_FASTPROF
   if (lane == 0) { g_rs.statSeg[1] += g_fl.eng.busyClk; g_rs.statSeg[2] += g_fl.eng.jobs; }
+  LANE0_PUBLISHED();
 #endif
   __syncthreads();  // end barrier of the OP_ENGINE op
 }
@@ -1069,7 +1096,8 @@ __device__ static __attribute__((noinline)) void applyEvictedRange(Dev& d, int q
   int lane = threadIdx.x & 63;
   int R = k.R;
   int pending = g_rs.replayPending;
-  if (sign < 0 && !pending && lane == 0) g_rs.ftValid = 0;   // evicted-table entries come back: thresholds may rise (round_ft.h "Staleness") — the table is rebuilt at the next query
+  if (sign < 0 && !pending && lane == 0) g_rs.ftValid = 0;
+  LANE0_PUBLISHED();   // evicted-table entries come back: thresholds may rise (round_ft.h "Staleness") — the table is rebuilt at the next query
   int64_t accQ[MAXR], accPc[APPLY_PCS][MAXR];
 #pragma unroll
   for (int x = 0; x < MAXR; x++) { accQ[x] = 0;
@@ -1116,6 +1144,7 @@ __device__ static __attribute__((noinline)) void applyEvictedRange(Dev& d, int q
   for (int x = 0; x < MAXR; x++) {
     if (x >= R) break;
     int64_t v = waveSum64(accQ[x]);
+    if (x == 0) LANE0_PUBLISHED();   // (the loop above: g_rs.fairIndexValid = 0 under a lane-divergent condition)
     if (lane == 0 && v) { LDS_ADD64(g_fl.qAlloc[q][x], v); LDS_ADD64(g_rs.allocated[x], v); LDS_ADD64(g_rs.evicted[x], -v); }
 #pragma unroll
     for (int c = 0; c < APPLY_PCS; c++) {
@@ -1327,10 +1356,10 @@ __device__ static void helperMain(const Dev& d, HelpBox* b, int H) {
         __hip_atomic_store(&g_hMin, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_store(&g_hMax, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_store(&g_hArrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if ((op == OP_SCAN || op == OP_SCANFAIR) && mn != ~0ull) __hip_atomic_fetch_min(&b->result, mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (op == OP_FAIR && mx != 0) __hip_atomic_fetch_max(&b->result, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (op == OP_SCANFAIR && mx != 0) __hip_atomic_fetch_max(&b->result2, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&b->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        HelpSlot* sl = &b->slot[blockIdx.x - 1];
+        __hip_atomic_store(&sl->mn, mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sl->mx, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sl->gen, seen >> 8, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // completion: this workgroup's results (and, for the bulk ops, its writes) are visible before it
       }
     }
   }
@@ -1990,7 +2019,7 @@ static PlatCtx* plat_open(std::string& err, int device) {
   bool ok = hipStreamCreate(&c->stream) == hipSuccess && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
             hipEventCreate(&c->fitEv0) == hipSuccess && hipEventCreate(&c->fitEv1) == hipSuccess && hipEventCreate(&c->rEv0) == hipSuccess && hipEventCreate(&c->rEv1) == hipSuccess;
   // the mailbox is written from both sides across XCDs: it must not live in an XCD-private L2 -> fine-grained (uncached, device-coherent) memory
-  ok = ok && hipExtMallocWithFlags((void**)&c->helpBox, 256, hipDeviceMallocFinegrained) == hipSuccess;
+  ok = ok && hipExtMallocWithFlags((void**)&c->helpBox, sizeof(HelpBox), hipDeviceMallocFinegrained) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->cancelHost, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
   if (ok) { *c->cancelHost = 0; ok = hipHostGetDevicePointer((void**)&c->cancelDev, c->cancelHost, 0) == hipSuccess; }
   if (!ok) { err = "HIP resource creation failed (stream / events / mailbox / cancel word)"; delete c; return nullptr; }
@@ -2048,7 +2077,7 @@ static void plat_set_market_dev(const MktDev* m) { t_mkt = m; }
 static int plat_run_control(Dev& dev, int cmd) {
   PlatCtx* c = t_ctx;
   if (c->failed) return -1;  // an earlier upload failed: the kernel would read unset pointers
-  static_assert(sizeof(HelpBox) <= 256, "mailbox allocation");
+  static_assert(sizeof(HelpBox) == 256 + HELP_MAX * 32, "mailbox allocation");
   bool isRound = cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY || cmd == CMD_PASS1 || cmd == CMD_PASS2;
   int H = isRound ? c->helpers : 0;
   // the wide queries of the generic path (plane scan, fair-share evaluation) are one node per thread: from ~50k nodes on half of the CUs pay off (measured at 100k

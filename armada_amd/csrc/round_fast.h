@@ -139,9 +139,16 @@ __shared__ RoundScalars g_rs;  // d.rs points here for the whole launch (relocat
 #define UNID(x) (x)
 #define LANES_ANY(v) ((v) != 0)   // (serial build: FOR_LANES bodies share their locals)
 #define FAST_GLOBAL_FENCE() do {} while (0)
+#define LANE0_PUBLISHED() do {} while (0)
 #else
 #define LANES_ANY(v) (__ballot((v) != 0) != 0)
 #define FAST_GLOBAL_FENCE() __threadfence()
+// After a store to an LDS word that only SOME lanes execute (if (lane == 0) word = v;) and before the wave reads that word again: a wavefront-scope fence.
+// It emits no instruction (LDS executes one wave's accesses in issue order) but it is what makes the read legal for the compiler: in the single-thread view
+// of a lane that did not store, nothing wrote the word, so without the fence LLVM may reuse a value loaded BEFORE the store (GVN / load PRE / LICM) and the
+// lanes disagree.  profiles/r04a_lds_handback_rootcause.txt has the ISA of the failing idiom; tests/lds_idiom pins it.  (Reads through UNI32 / readfirstlane
+// take lane 0's value, which is the stored one either way: that is why the sites below were right before the fence was spelled out.)
+#define LANE0_PUBLISHED() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 __device__ static inline int uni32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ static inline unsigned long long uni64(unsigned long long v) {
   unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
@@ -800,7 +807,7 @@ DEV int engineServeAt(Dev& d, KREF k, FastS& ES, const JobTail& tailSrc, const i
   // hard timeout / cancel (queue_scheduler.go:105-112): the node engine has the slack of the two waves, so IT reads the host-mapped word (every
   // 256 jobs; a read crosses PCIe) and answers "no node" without touching anything: the control wave takes the iteration back, leaves the fast
   // loop, finds the flag and raises ASCHED_ERR_TIMEOUT.  The control wave's loop carries no extra instruction for this.
-  if ((++ES.engSeq & 255) == 0 && cancelRequested(d)) { if (FLANE == 0) FL.eng.cancel = 1; return 0; }
+  if ((++ES.engSeq & 255) == 0 && cancelRequested(d)) { if (FLANE == 0) FL.eng.cancel = 1; LANE0_PUBLISHED(); return 0; }
   JobTail r = tailSrc;
   uniJobTail(r);
   FitHandle h; h.src = 0; h.slot = -1;
@@ -810,7 +817,7 @@ DEV int engineServeAt(Dev& d, KREF k, FastS& ES, const JobTail& tailSrc, const i
   ESEG(2);
   if (n < 0) return 0;
 #if !defined(ASCHED_HOSTSIM)
-  if (ringIdx >= 0) { if (FLANE == 0) RREC(ringIdx).node0 = n; }   // stream run: the bind wave issues the HBM side (bindJob) from the ring entry
+  if (ringIdx >= 0) { if (FLANE == 0) RREC(ringIdx).node0 = n; LANE0_PUBLISHED(); }   // stream run: the bind wave issues the HBM side (bindJob) from the ring entry
   else
 #else
   if (ringIdx >= 0 && FL.eng.bindHold) RREC(ringIdx).node0 = n;     // (serial build: binds at once unless they are held for a gang's verdict)
@@ -860,7 +867,7 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
   if (k.hasPcLimit) return 0;  // per-queue per-priority-class caps: generic
   QHot f = FL.hot[q];
   uniQHot(f);
-  if (f.sLen) { if (FLANE == 0) { FL.hot[q].sLen = 0; FL.hot[q].sPos = 0; } f.sLen = 0; f.sPos = 0; }   // the queue is served outside a stream run: its stream no longer describes it
+  if (f.sLen) { if (FLANE == 0) { FL.hot[q].sLen = 0; FL.hot[q].sPos = 0; } LANE0_PUBLISHED(); f.sLen = 0; f.sPos = 0; }   // the queue is served outside a stream run: its stream no longer describes it
   int job = f.gctx;
   if (f.headFast && f.headKind == 2) {  // evicted job with precomputed costs
     SEG(1);
@@ -1139,7 +1146,7 @@ DEV_NOINLINE SkipDelta fastExitSkip(Dev& d, FastCtx fc, int Q, int top, PackedKe
     applyEvictedRange(d, q, lo, b1, -1);
     S.numEvictedJobs += b1 - lo;
     if (f.gctx >= 0) { f.itQi -= 1; f.itJobsSeen -= 1; }  // the queued head goes back into its stream
-    if (f.sLen) { f.sLen = 0; f.sPos = 0; if (FLANE == 0) { FL.hot[q].sLen = 0; FL.hot[q].sPos = 0; } }   // its precomputed stream started at that head
+    if (f.sLen) { f.sLen = 0; f.sPos = 0; if (FLANE == 0) { FL.hot[q].sLen = 0; FL.hot[q].sPos = 0; } LANE0_PUBLISHED(); }   // its precomputed stream started at that head
     f.itStage = 0; f.itEi = lo; f.evApplied = f.evDone = lo;
     KeyOut ko;
     fastAdvance(d, k, S, fc, q, f, &ko);  // head = evicted entry `lo` (cheap path)
@@ -1272,6 +1279,7 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
     }
     lastQ = t;
     if (FLANE == 0) { RJOB(emitted) = e.job; RQ(emitted) = t | ((kind & 1) ? RQ_EV : 0); }
+    LANE0_PUBLISHED();
     emitted++; if (!(kind & 1)) emittedQ++;
     if ((emitted & 3) == 0) {                     // records: gather the last four entries; the four before them have arrived by now
       if (stageBase >= 0) streamStageCommit(d, k, stageBase, stageCnt, stageV);
@@ -1326,6 +1334,7 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
     if (getenv("HS_NO_STREAM_KEEP")) more = false;
 #endif
     if (FLANE == 0) { FL.hot[q].sPos = more ? pos : 0; FL.hot[q].sLen = more ? f.sLen : 0; FL.hot[q].ewCount = 0; FL.hot[q].ewStart = 0; }
+    LANE0_PUBLISHED();
     f.sPos = more ? pos : 0; f.sLen = more ? f.sLen : 0; f.ewCount = 0; f.ewStart = 0; f.winKind = -1; f.winCount = 0;
     if (moved == 0) continue;                     // never reached the top of the heap: nothing of the queue changed
     if (kind) doneEv += cq; else { doneQ += cq; if (cq > out.maxConsumed) out.maxConsumed = cq; }
@@ -1402,7 +1411,7 @@ DEV_NOINLINE GangOut fastGangRun(Dev& d, FastCtx fc, StreamIn in, int t) {
   FOR_LANES(q, QCAPF) FL.tmpQ[q] = 0;
   // the ring overwrites the prefetch windows of the first queues: they refill on demand
   FOR_LANES(q, QCAPF) if (q * WIN < cnt + 4) { FL.hot[q].winKind = -1; FL.hot[q].winCount = 0; }
-  if (f.sLen) { if (FLANE == 0) { FL.hot[t].sLen = 0; FL.hot[t].sPos = 0; } f.sLen = 0; f.sPos = 0; }
+  if (f.sLen) { if (FLANE == 0) { FL.hot[t].sLen = 0; FL.hot[t].sPos = 0; } LANE0_PUBLISHED(); f.sLen = 0; f.sPos = 0; }
   int engSeq = in.engSeq;
   SEG(26);
   streamBegin(&engSeq, 1);
@@ -1473,6 +1482,7 @@ DEV __attribute__((always_inline)) int fastPreemptIter(Dev& d, Ctl& c, FastCtx f
   XSEG(36);
   if (RS.error) return 1;
   if (FLANE == 0) { RS.loopIterations++; RS.statFastIters++; RS.statHybrid++; }
+  LANE0_PUBLISHED();
   uint8_t fl = k.jobFlags[job];
   if (ok) {
     accountVectors(d, k, t, pcx, false, false);
@@ -1481,6 +1491,7 @@ DEV __attribute__((always_inline)) int fastPreemptIter(Dev& d, Ctl& c, FastCtx f
       if (!RS.globalRateInf && 1 <= RS.globalBurst) RS.globalTokens -= 1.0;
       k.jobFlags[job] = (uint8_t)((fl & ~F_UNSUCCESSFUL) | F_SUCCESSFUL); k.inScheduled[job] = 1; k.inSchedAndEvicted[job] = 0;
     }
+    LANE0_PUBLISHED();
     if (!f.rateInf && 1 <= f.burst) f.tokens -= 1.0;
   } else {
     failJob(d, job, reason);
@@ -1501,6 +1512,7 @@ DEV __attribute__((always_inline)) int fastPreemptIter(Dev& d, Ctl& c, FastCtx f
   *koOut = ko;
   XSEG(38);
   if (FLANE == 0) { RS.numEvictedJobs += S.numEvictedJobs; RS.statRefills += S.statRefills; }
+  LANE0_PUBLISHED();
   if (!more) return 2;
   if (RS.hasFpLimiter && RS.fpTokens < 1 && !c.fpLimitHit) return 3;
   return 1;
@@ -1654,6 +1666,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
         S.loopIterations += E; S.statFastIters += E;
         S.statRefills += so.refills; S.numEvictedJobs += so.evicted;
         if (FLANE == 0) { RS.statStreamRuns++; RS.statStreamJobs += E; RS.statStreamEmitted += so.emitted; }
+        LANE0_PUBLISHED();
         if (so.dropped) { S.fastActive = 0; fastDrop(d); }
         
         pqBuild(pq, Q);
@@ -1717,6 +1730,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   if (S.engLive) { engineStop(d, S); S.engLive = 0; if (UNI32(FL.eng.cancel)) c.cancelSeen = 1; }
 #ifndef ASCHED_FASTPROF
   if (FLANE == 0 && S.engWaitClk) RS.statSeg[0] += S.engWaitClk;
+  LANE0_PUBLISHED();
 #endif
   if (c.skipActive) {  // generic code comes next: rebuild the exact interleaved state
     SkipDelta dl = fastExitSkip(d, fc, Q, lastTop, refK, refN);

@@ -672,6 +672,7 @@ DEV_NOINLINE int fastStreamPrepare(Dev& d, FastCtx fc, int Q, int allowed, int a
     FOR_LANES(q, Q) if (FL.tmpQ[q] == 2) { int len = d.qsLen[2 * q]; FL.hot[q].sLen = len; FL.hot[q].sPos = 0; FL.sKind[q] = 0; FL.hot[q].ewCount = 0; FL.hot[q].ewStart = 0; }
     for (int q = 0; q < Q; q++) if (UNI32(FL.tmpQ[q]) == 2) total += d.qsLen[2 * q];
     if (FLANE == 0) RS.statStreamPrepared += total;
+    LANE0_PUBLISHED();
   }
   return UNI32(FL.hot[top].sLen) > UNI32(FL.hot[top].sPos) ? 1 : 0;
 }
@@ -753,6 +754,7 @@ DEV_NOINLINE int fastStreamPrepareOne(Dev& d, FastCtx fc, int q, int allowed, in
     d.qsLen[2 * q + 1] = (!cut && base + want == d.queuedOff[q + 1]) ? 1 : 0;   // the queue's list ends where the stream ends (B_QSSTITCH)
     RS.statStreamPrepared += len;
   }
+  LANE0_PUBLISHED();
   FAST_GLOBAL_FENCE();
   return len;
 }
