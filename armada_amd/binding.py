@@ -220,7 +220,11 @@ ALL_SYMBOLS = [
     "market_iterate", "market_compare", "market_multi_iterate",
     "fit_select_batch_global", "round_delta_words", "round_delta", "round_delta_resolve",
     "set_market", "market_result", "price_gang", "price_job_on_nodes",
+    "comm_unique_id", "comm_init", "comm_init_external", "comm_destroy", "comm_rank", "fit_select_batch_sharded", "round_exchange",
 ]
+# entry points the CPU oracle does not implement (it is the single-process checker): the communicator and the collectives that run on it
+OPTIONAL_SYMBOLS = {"comm_unique_id", "comm_init", "comm_init_external", "comm_destroy", "comm_rank", "fit_select_batch_sharded", "round_exchange"}
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
 
 
 class SchedError(RuntimeError):
@@ -339,6 +343,13 @@ class Library:
         f("round_delta_words", C.c_int32, [C.c_void_p, _i64p])
         f("round_delta", C.c_int32, [C.c_void_p, C.c_void_p])
         f("round_delta_resolve", C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(CDeltaSummary), _i32p, _i32p, _u8p])
+        f("comm_unique_id", C.c_int32, [C.c_void_p])
+        f("comm_init", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32])
+        f("comm_init_external", C.c_int32, [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int32, C.c_int32])
+        f("comm_destroy", C.c_int32, [C.c_void_p])
+        f("comm_rank", C.c_int32, [C.c_void_p, _i32p, _i32p])
+        f("fit_select_batch_sharded", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int32, C.POINTER(CGlobalKeyLayout), _i32p])
+        f("round_exchange", C.c_int32, [C.c_void_p, C.POINTER(CDeltaSummary), _i32p, _i32p, _u8p])
         f("drf_cost", C.c_double, [C.c_void_p, _i64p, _i64p])
         f("fair_shares", C.c_int32, [C.c_void_p, C.c_int32, _i32p, _f64p, _f64p, _f64p, _f64p, _f64p])
         f("round_prepare", C.c_int32, [C.c_void_p, C.POINTER(CQueues)])
@@ -351,6 +362,8 @@ class Library:
         f("round_stats", C.c_int32, [C.c_void_p, _i32p])
 
     def _fn(self, name, restype, argtypes):
+        if name in OPTIONAL_SYMBOLS and not hasattr(self.lib, self.prefix + name):
+            return
         fn = getattr(self.lib, self.prefix + name)
         fn.restype, fn.argtypes = restype, argtypes
         setattr(self, name, fn)
@@ -901,6 +914,63 @@ class Scheduler:
         node, prio, rp = np.empty(max(m, 1), dtype=np.int32), np.empty(max(m, 1), dtype=np.int32), np.empty(max(m, 1), dtype=np.uint8)
         sm = CDeltaSummary()
         self._check(self.lib.round_delta_resolve(self.h, C.c_void_p(int(reduced_ptr)), C.byref(sm), _ptr(node, C.c_int32), _ptr(prio, C.c_int32), _ptr(rp, C.c_uint8)))
+        return dict(conflict_nodes=sm.conflict_nodes, accepted=sm.accepted, replay=sm.replay, preempted=sm.preempted), node[:m], prio[:m], rp[:m]
+
+    # ---- the handle's communicator (include/armada_sched.h "The communicator"): the collectives run INSIDE the library, on the handle's stream
+    def comm_unique_id(self) -> bytes:
+        """ncclGetUniqueId (rank 0 creates it; hand the 128 bytes to every rank)"""
+        buf = C.create_string_buffer(128)
+        rc = self.lib.comm_unique_id(C.cast(buf, C.c_void_p))
+        if rc != 0:
+            raise SchedError(rc, "comm_unique_id: RCCL is not available in this library")
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        """ncclCommInitRank on the handle's GPU (blocks until every rank has called it)"""
+        assert len(unique_id) == 128
+        buf = C.create_string_buffer(unique_id, 128)
+        self._check(self.lib.comm_init(self.h, C.cast(buf, C.c_void_p), int(rank), int(world)))
+
+    def comm_init_external(self, allreduce, rank: int, world: int):
+        """any other transport: allreduce(ptr, count, op) -> 0 reduces `count` int64 words at address `ptr` in place over all ranks (op 0 SUM, 1 MIN, 2 MAX)"""
+        def tramp(_ctx, ptr, count, op):
+            try:
+                return int(allreduce(int(ptr), int(count), int(op)) or 0)
+            except Exception:   # an exception must not cross the C boundary
+                import traceback; traceback.print_exc()
+                return 1
+        self._allreduce_cb = ALLREDUCE_FN(tramp)   # keep the trampoline alive as long as the handle
+        self._check(self.lib.comm_init_external(self.h, self._allreduce_cb, None, int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._check(self.lib.comm_destroy(self.h))
+        self._allreduce_cb = None
+
+    def comm_rank(self):
+        r, w = C.c_int32(0), C.c_int32(1)
+        self._check(self.lib.comm_rank(self.h, C.byref(r), C.byref(w)))
+        return int(r.value), int(w.value)
+
+    def fit_select_batch_sharded(self, jobs: Sequence[int], priority: int, field_bits: Sequence[int], rank_bits: int, *, rank_offset: int = 0, global_rank=None) -> np.ndarray:
+        """exact node-partitioned first fit over the communicator's ranks: global rank of the chosen node per job, -1 none (collective: every rank calls it)"""
+        ja = _arr(jobs, np.int32)
+        lay = CGlobalKeyLayout()
+        lay.n_fields = len(field_bits)
+        for i, b in enumerate(field_bits):
+            lay.field_bits[i] = int(b)
+        lay.rank_bits, lay.rank_offset = int(rank_bits), int(rank_offset)
+        gr = None if global_rank is None else _arr(global_rank, np.int32)
+        lay.global_rank = _ptr(gr, C.c_int32) if gr is not None else None
+        out = np.full(max(len(ja), 1), -1, dtype=np.int32)
+        self._check(self.lib.fit_select_batch_sharded(self.h, len(ja), _ptr(ja, C.c_int32), priority, C.byref(lay), _ptr(out, C.c_int32)))
+        return out[:len(ja)]
+
+    def round_exchange(self):
+        """queue-hash round (approximate): round_delta + ONE all-reduce SUM + round_delta_resolve on the handle's stream -> like round_delta_resolve"""
+        m = self.num_jobs
+        node, prio, rp = np.empty(max(m, 1), dtype=np.int32), np.empty(max(m, 1), dtype=np.int32), np.empty(max(m, 1), dtype=np.uint8)
+        sm = CDeltaSummary()
+        self._check(self.lib.round_exchange(self.h, C.byref(sm), _ptr(node, C.c_int32), _ptr(prio, C.c_int32), _ptr(rp, C.c_uint8)))
         return dict(conflict_nodes=sm.conflict_nodes, accepted=sm.accepted, replay=sm.replay, preempted=sm.preempted), node[:m], prio[:m], rp[:m]
 
     def drf_cost(self, alloc, total) -> float:

@@ -23,6 +23,8 @@
 #include <string>
 #include <unistd.h>
 #include <vector>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the functions are bound with dlsym at asched_comm_init (no link-time dependency on librccl)
 
 #define ASCHED_PREFIX asched_
 #include "round_run.h"
@@ -1988,6 +1990,9 @@ struct PlatCtx {
   void* optScratch = nullptr; size_t optScratchBytes = 0;     // node -> jobs index, queue costs and per-node scores of the fairness optimiser, kept across calls
   std::string err;
   bool failed = false;              // sticky: an allocation / copy / memset failed since the last plat_take_failure()
+  // the handle's communicator (asched_comm_init: RCCL over xGMI; asched_comm_init_external: the caller's transport)
+  ncclComm_t comm = nullptr; int commRank = 0, commWorld = 1;
+  asched_allreduce_fn extFn = nullptr; void* extCtx = nullptr;
 };
 static thread_local PlatCtx* t_ctx = nullptr;
 static std::string g_noCtxErr;
@@ -2035,10 +2040,94 @@ static PlatCtx* plat_open(std::string& err, int device) {
   t_ctx = c;
   return c;
 }
+// ---- RCCL, bound at run time.  dlopen by soname: when the process already holds an RCCL (torch bundles one and loads it before this library in the Python
+// harness) the loader hands back THAT copy — one RCCL per process, on the HIP runtime the process already uses; a Go scheduler gets /opt/rocm/lib's.
+struct RcclApi {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) getUniqueId = nullptr;
+  decltype(&ncclCommInitRank) commInitRank = nullptr;
+  decltype(&ncclCommDestroy) commDestroy = nullptr;
+  decltype(&ncclAllReduce) allReduce = nullptr;
+  decltype(&ncclGetErrorString) errorString = nullptr;
+};
+static RcclApi* rcclApi(std::string& err) {
+  static RcclApi api; static bool tried = false; static std::string why;
+  if (!tried) {
+    tried = true;
+    const char* names[] = {getenv("ASCHED_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) { if (!n || !*n) continue; api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (api.lib) break; why = dlerror(); }
+    if (api.lib) {
+      api.getUniqueId = (decltype(api.getUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+      api.commInitRank = (decltype(api.commInitRank))dlsym(api.lib, "ncclCommInitRank");
+      api.commDestroy = (decltype(api.commDestroy))dlsym(api.lib, "ncclCommDestroy");
+      api.allReduce = (decltype(api.allReduce))dlsym(api.lib, "ncclAllReduce");
+      api.errorString = (decltype(api.errorString))dlsym(api.lib, "ncclGetErrorString");
+      if (!api.getUniqueId || !api.commInitRank || !api.commDestroy || !api.allReduce) { why = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce"; dlclose(api.lib); api.lib = nullptr; }
+    }
+  }
+  if (!api.lib) { err = "RCCL is not available: " + why; return nullptr; }
+  return &api;
+}
+static bool rcclOk(RcclApi* a, ncclResult_t r, const char* what) {
+  if (r == ncclSuccess) return true;
+  std::string m = std::string(what) + ": " + (a->errorString ? a->errorString(r) : "RCCL error");
+  if (t_ctx) { t_ctx->err = m; t_ctx->failed = true; } else g_noCtxErr = m;
+  return false;
+}
+static int plat_comm_unique_id(char* out128) {
+  std::string err; RcclApi* a = rcclApi(err);
+  if (!a) { g_noCtxErr = err; if (t_ctx) t_ctx->err = err; return -1; }
+  ncclUniqueId id;
+  static_assert(sizeof(id) == 128, "asched_unique_id carries an ncclUniqueId");
+  if (!rcclOk(a, a->getUniqueId(&id), "ncclGetUniqueId")) return -1;
+  memcpy(out128, &id, sizeof id);
+  return 0;
+}
+static void plat_comm_destroy_ctx(PlatCtx* c) {
+  if (c->comm) { std::string err; if (RcclApi* a = rcclApi(err)) (void)a->commDestroy(c->comm); c->comm = nullptr; }
+  c->extFn = nullptr; c->extCtx = nullptr; c->commRank = 0; c->commWorld = 1;
+}
+static int plat_comm_init(const char* id128, int rank, int world) {
+  PlatCtx* c = t_ctx;
+  std::string err; RcclApi* a = rcclApi(err);
+  if (!a) { c->err = err; return -1; }
+  plat_comm_destroy_ctx(c);
+  ncclUniqueId id; memcpy(&id, id128, sizeof id);
+  if (!rcclOk(a, a->commInitRank(&c->comm, world, id, rank), "ncclCommInitRank")) { c->comm = nullptr; return -1; }
+  c->commRank = rank; c->commWorld = world;
+  return 0;
+}
+static int plat_comm_init_external(asched_allreduce_fn fn, void* ctx, int rank, int world) {
+  PlatCtx* c = t_ctx;
+  plat_comm_destroy_ctx(c);
+  c->extFn = fn; c->extCtx = ctx; c->commRank = rank; c->commWorld = world;
+  return 0;
+}
+static void plat_comm_destroy() { if (t_ctx) { (void)hipStreamSynchronize(t_ctx->stream); plat_comm_destroy_ctx(t_ctx); } }
+static void plat_comm_info(int* rank, int* world) { *rank = t_ctx ? t_ctx->commRank : 0; *world = t_ctx ? t_ctx->commWorld : 1; }
+static bool plat_comm_live() { return t_ctx && (t_ctx->comm || t_ctx->extFn); }
+// in-place all-reduce of `count` int64 words in memory of this handle's GPU, on the handle's stream: behind whatever produced the words there, in front of
+// whatever the caller enqueues next.  op: 0 SUM, 1 MIN, 2 MAX.
+static int plat_allreduce(long long* dbuf, size_t count, int op) {
+  PlatCtx* c = t_ctx;
+  if (c->commWorld <= 1 && !c->comm && !c->extFn) return 0;
+  if (c->comm) {
+    std::string err; RcclApi* a = rcclApi(err);
+    if (!a) { c->err = err; return -1; }
+    ncclRedOp_t o = op == 0 ? ncclSum : op == 1 ? ncclMin : ncclMax;
+    if (!rcclOk(a, a->allReduce(dbuf, dbuf, count, ncclInt64, o, c->comm, c->stream), "ncclAllReduce")) return -1;
+    return 0;
+  }
+  if (!hipOk(hipStreamSynchronize(c->stream), "all-reduce (external transport): stream sync")) return -1;   // the transport sees finished words and an idle stream
+  if (c->extFn(c->extCtx, dbuf, (int64_t)count, op) != 0) { c->err = "the external all-reduce transport failed"; return -1; }
+  return 0;
+}
 static void plat_close(PlatCtx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  plat_comm_destroy_ctx(c);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   for (hipEvent_t e : {c->ev0, c->ev1, c->fitEv0, c->fitEv1, c->rEv0, c->rEv1}) if (e) (void)hipEventDestroy(e);
   if (c->helpBox) (void)hipFree(c->helpBox);
   if (c->cmpScratch) (void)hipFree(c->cmpScratch);

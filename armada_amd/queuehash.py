@@ -46,7 +46,22 @@ class QueueHashRound:
             local.global_burst = wl.global_burst // world + (1 if rank < wl.global_burst % world else 0)
         self.local = local
         self.s: Scheduler = W.load(lib, local)
+        self.in_library = False
         self.timing: Dict[str, float] = {}
+
+    def comm_init(self, transport: str = "rccl"):
+        """the handle's own communicator ("rccl": ncclCommInitRank inside the library; "external": the library calls back into torch.distributed)"""
+        from . import comm
+        if transport == "rccl":
+            comm.init_rccl(self.s, self.dist, device=self.device)
+        else:
+            comm.init_external(self.s, self.dist, device_memory=self.device is not None)
+        self.in_library = True
+
+    def _sync_device(self):
+        if self.device is not None:
+            import torch
+            torch.cuda.synchronize()
 
     def run(self) -> Dict:
         import time
@@ -57,11 +72,17 @@ class QueueHashRound:
         res = s.schedule_round()
         t1 = time.perf_counter()
         # THE exchange of the round: the buffer is filled on the device and reduced in place
-        buf = torch.zeros(max(s.round_delta_words(), 1), dtype=torch.int64, device=self.device or "cpu")
-        s.round_delta(buf.data_ptr())
-        if self.dist is not None and self.world > 1:
-            self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM)
-        summary, node, prio, rp = s.round_delta_resolve(buf.data_ptr())
+        if self.in_library:
+            # delta -> ncclAllReduce(SUM) -> resolve as one stream-ordered sequence on the handle's stream (asched_round_exchange)
+            summary, node, prio, rp = s.round_exchange()
+        else:
+            buf = torch.zeros(max(s.round_delta_words(), 1), dtype=torch.int64, device=self.device or "cpu")
+            self._sync_device()      # torch's fill on its stream before the library's kernels on the handle's stream
+            s.round_delta(buf.data_ptr())
+            if self.dist is not None and self.world > 1:
+                self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM)
+                self._sync_device()  # ... and the collective before the library reads the reduced words (round-3 ADVICE: the ordering was implicit)
+            summary, node, prio, rp = s.round_delta_resolve(buf.data_ptr())
         t2 = time.perf_counter()
         was_running = wl.job_node >= 0
         final = {int(j): int(node[j]) for j in np.nonzero(~was_running & (node >= 0))[0]}

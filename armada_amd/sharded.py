@@ -58,6 +58,7 @@ class ShardedFit:
         self.wl, self.rank, self.world, self.dist, self.device = wl, rank, world, dist, device
         self.lo, self.hi = shard_bounds(wl.num_nodes, world)[rank:rank + 2]
         self.local = shard_workload(wl, rank, world)
+        self.in_library = False
         self.s: Scheduler = W.load(lib, self.local)
         cfg = wl.config
         self.idx_col = list(cfg.indexed_col)
@@ -68,6 +69,21 @@ class ShardedFit:
         self.row_bits = max(1, int(wl.num_nodes - 1).bit_length())
         if sum(self.width) + self.row_bits > 62:
             raise ValueError("order key does not fit 62 bits: use two reductions (fields, then row)")
+
+    def comm_init(self, transport: str = "rccl"):
+        """give the handle its own communicator: "rccl" (ncclCommInitRank inside the library; the process group only carries the unique id) or "external"
+        (the library calls back into torch.distributed: gloo in the CPU tests).  fit_select_batch then runs the collective inside the library."""
+        from . import comm
+        if transport == "rccl":
+            comm.init_rccl(self.s, self.dist, device=self.device)
+        else:
+            comm.init_external(self.s, self.dist, device_memory=self.device is not None)
+        self.in_library = True
+
+    def _sync_device(self):
+        if self.device is not None:
+            import torch
+            torch.cuda.synchronize()
 
     def prepare(self):
         """bind the running jobs of this shard (populateNodeDb); the queue side is not needed for read-only queries"""
@@ -85,10 +101,15 @@ class ShardedFit:
         field widths all shards share (asched_fit_select_batch_global); ONE all_reduce(MIN) over that buffer folds the shards; the low bits of the winning
         word are the node's global rank (= its row: shards are contiguous row ranges in index order)."""
         n = len(jobs)
+        if self.in_library:
+            # the product path: k_fit_batch + pack + ncclAllReduce(MIN) + unpack as ONE stream-ordered sequence inside the library (asched_fit_select_batch_sharded)
+            return self.s.fit_select_batch_sharded(np.asarray(jobs, dtype=np.int32), priority, self.width, self.row_bits, rank_offset=self.lo)
         t = self._word_buffer(n)
         self.s.fit_select_batch_global(np.asarray(jobs, dtype=np.int32), priority, self.width, self.row_bits, t.data_ptr(), rank_offset=self.lo)
         if self.dist is not None and self.world > 1:
+            self._sync_device()   # the library wrote the words on ITS stream (synchronised on return); the collective runs on torch's: order them explicitly
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+            self._sync_device()
         best = t[:n].cpu().numpy()
         out = (best & ((1 << self.row_bits) - 1)).astype(np.int32)
         out[best == NO_NODE_WORD] = -1

@@ -223,8 +223,10 @@ typedef struct asched_req_classes {
 #define ASCHED_AFFINITY_OP_LT 5   /* needs asched_set_label_value_ints for both; anything that does not parse matches nothing */
 
 /* ---- jobs: the jobdb view the round needs (jobdb/job.go accessors used on the path).
- *      Job ids are their index in this table; index order is the id-string order used as the
- *      final tie-break of SchedulingOrderCompare (jobdb/comparison.go:99-105). ---- */
+ *      Job ids are their index in this table; ROWS MUST BE IN ASCENDING JOB-ID (string) ORDER: the row is the
+ *      final tie-break of SchedulingOrderCompare (jobdb/comparison.go:99-105), of MarketSchedulingOrderCompare
+ *      (:160-168) and of the pricer's victim order (pricer/node_scheduler.go priceOrder.Less) — the library never
+ *      sees the strings, so it cannot check this; integration/gpu_round.go sorts before it uploads. ---- */
 typedef struct asched_jobs {
   int32_t m;
   const int32_t* queue;            /* [m] queue index */
@@ -426,6 +428,36 @@ int32_t ASCHED_FN(round_delta_words)(asched_t*, int64_t* n_words);
 int32_t ASCHED_FN(round_delta)(asched_t*, int64_t* buf /* device-accessible [N*R + M] */);
 int32_t ASCHED_FN(round_delta_resolve)(asched_t*, const int64_t* reduced /* device-accessible */, asched_delta_summary* summary,
                                        int32_t* job_node /*[M]*/, int32_t* job_priority /*[M]*/, uint8_t* job_replay /*[M]*/);
+
+/* ---- The communicator: RCCL over xGMI inside the library (round 4).  One communicator per handle; every collective below is enqueued on the
+   HANDLE'S OWN STREAM, behind the kernels that produce the words and in front of the kernels that consume them, so there is nothing for the
+   caller to order (the pointer-taking entry points above leave the collective, and the stream ordering around it, to the caller).
+   No reference counterpart: FairSchedulingAlgo schedules one pool on one goroutine (scheduling_algo.go:165); this is BASELINE north_star's
+   "single RCCL all-reduce over xGMI".
+     asched_comm_unique_id     ncclGetUniqueId: one rank creates it, the caller's control plane (the Go scheduler's leader election / gRPC, an MPI
+                               broadcast, a file) hands the 128 bytes to every rank
+     asched_comm_init          ncclCommInitRank on the handle's GPU; blocks until all `world` ranks have called it
+     asched_comm_init_external any other transport (MPI, gloo in the CPU tests of this repository): the library calls `fn` with its stream idle;
+                               `buf` is memory of the handle's GPU in the HIP library (host memory in the CPU build of the tests), count int64 words
+     asched_comm_destroy       also done by asched_destroy
+   op: 0 SUM, 1 MIN, 2 MAX (int64). */
+typedef struct asched_unique_id { char bytes[128]; } asched_unique_id;
+typedef int32_t (*asched_allreduce_fn)(void* ctx, void* buf, int64_t count, int32_t op);
+int32_t ASCHED_FN(comm_unique_id)(asched_unique_id* out);
+int32_t ASCHED_FN(comm_init)(asched_t*, const asched_unique_id* id, int32_t rank, int32_t world);
+int32_t ASCHED_FN(comm_init_external)(asched_t*, asched_allreduce_fn fn, void* ctx, int32_t rank, int32_t world);
+int32_t ASCHED_FN(comm_destroy)(asched_t*);
+int32_t ASCHED_FN(comm_rank)(asched_t*, int32_t* rank, int32_t* world);   /* world = 1 without a communicator */
+/* EXACT, node-partitioned: fit_select_batch over a pool whose node rows are split across the ranks of the communicator — k_fit_batch over this
+   rank's rows, the order-key words packed on the device (fit_select_batch_global), ONE all-reduce MIN on the handle's stream, the winners unpacked:
+   out_rank[i] = rank of the chosen node's index among ALL nodes of the pool (layout->rank_offset + local rank, or layout->global_rank), -1 none.
+   Every rank must call it with the same jobs / priority / layout widths.  MIN over the shards IS the reference's first node in index order
+   that fits (nodedb.go:840-879, nodeiteration.go:318-382). */
+int32_t ASCHED_FN(fit_select_batch_sharded)(asched_t*, int32_t n, const int32_t* jobs, int32_t priority, const asched_global_key_layout* layout,
+                                            int32_t* out_rank /*[n]*/);
+/* APPROXIMATE (labelled so everywhere), queue-hash round: round_delta + ONE all-reduce SUM + round_delta_resolve as one stream-ordered sequence
+   on the handle's stream; outputs as round_delta_resolve. */
+int32_t ASCHED_FN(round_exchange)(asched_t*, asched_delta_summary* summary, int32_t* job_node /*[M]*/, int32_t* job_priority /*[M]*/, uint8_t* job_replay /*[M]*/);
 
 /* ------------------------------------------------------------------ float helpers (goldens) */
 /* DominantResourceFairness.UnweightedCostFromAllocation (fairness/fairness.go:103-105) */

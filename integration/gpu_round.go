@@ -33,6 +33,7 @@ import (
 
 	"github.com/pkg/errors"
 	v1 "k8s.io/api/core/v1"
+	k8sResource "k8s.io/apimachinery/pkg/api/resource"
 
 	"github.com/armadaproject/armada/internal/common/armadacontext"
 	"github.com/armadaproject/armada/internal/scheduler/configuration"
@@ -109,6 +110,24 @@ func (g *GpuRound) vec(rl internaltypes.ResourceList) []int64 {
 		out[i] = rl.GetRawByNameZeroIfMissing(n)
 	}
 	return out
+}
+
+// listFromRaw builds a ResourceList from the library's raw int64 vector with the factory's OWN public constructors (round-3 ADVICE: there is no
+// FromInt64Slice upstream and ResourceList.resources is unexported): raw value r of column i is r * 10^scale_i (resource_list_factory.go:41-52, GetScale :151),
+// which NewScaledQuantity represents exactly, so the round-up of FromJobResourceListIgnoreUnknown (:99-109) returns r again.
+func (g *GpuRound) listFromRaw(raw []int64) internaltypes.ResourceList {
+	m := make(map[string]k8sResource.Quantity, len(raw))
+	for i, n := range g.resNames {
+		if raw[i] == 0 {
+			continue
+		}
+		scale, err := g.rlf.GetScale(n)
+		if err != nil {
+			continue // a column the factory does not know (cannot happen: resNames is the factory's own column order)
+		}
+		m[n] = *k8sResource.NewScaledQuantity(raw[i], scale)
+	}
+	return g.rlf.FromJobResourceListIgnoreUnknown(m)
 }
 
 func i32p(x []int32) *C.int32_t {
@@ -411,6 +430,11 @@ type reqClass struct {
 // calculateJobSchedulingInfo reads, scheduling_algo.go:591-698).  queueIndex maps queue names to dense indices (name order).
 func (g *GpuRound) UploadJobs(jobs []*jobdb.Job, queueIndex map[string]int32) error {
 	m, R := len(jobs), len(g.resNames)
+	// The ABI's contract (include/armada_sched.h, asched_jobs): a job's row IS its rank in job-id order — the final tie-break of SchedulingOrderCompare
+	// (jobdb/comparison.go:99-105), of MarketSchedulingOrderCompare (:160-168) and of the pricer's priceOrder (pricer/node_scheduler.go).  Callers hand jobs over
+	// in whatever order they hold them, so the shim sorts (a copy) by id before anything is indexed by row (round-3 ADVICE).
+	jobs = append([]*jobdb.Job(nil), jobs...)
+	sort.SliceStable(jobs, func(a, b int) bool { return jobs[a].Id() < jobs[b].Id() })
 	g.jobs = jobs
 	queue, pc, reqClassIdx := make([]int32, m), make([]int32, m), make([]int32, m)
 	qprio := make([]uint32, m)
@@ -757,8 +781,11 @@ func (g *GpuRound) Schedule(ctx *armadacontext.Context, sctx *schedulercontext.S
 	rc := C.asched_schedule_round(g.h, &out)
 	close(done)
 	wg.Wait() // the goroutine never touches g.h after Schedule returns (Close may follow)
-	if cancelled && rc != C.ASCHED_ERR_TIMEOUT {
-		C.asched_cancel_clear(g.h) // the request landed after the round had finished: it must not hit the next round on this handle
+	if cancelled {
+		// Whatever rc is: the round has returned, so a request that is still pending belongs to THIS context.  (The library's own deadline is the same instant as
+		// the context's; it can end the round and clear the word a moment before the watcher goroutine stores its request — round-3 ADVICE — which would make the
+		// next round on this handle fail at once.)
+		C.asched_cancel_clear(g.h)
 	}
 	if rc == C.ASCHED_ERR_TIMEOUT {
 		err := ctx.Err()
@@ -786,7 +813,7 @@ func (g *GpuRound) Schedule(ctx *armadacontext.Context, sctx *schedulercontext.S
 		for q, name := range names {
 			qctx := sctx.QueueSchedulingContexts[name]
 			if mr.has_spot_price != 0 {
-				qctx.BillableResource = g.rlf.FromInt64Slice(bill[q*R : (q+1)*R]) // (a factory constructor over the vector: internaltypes.ResourceListFactory)
+				qctx.BillableResource = g.listFromRaw(bill[q*R : (q+1)*R])
 			}
 			if has[q] != 0 {
 				v := over[q]
@@ -946,4 +973,57 @@ func (g *GpuRound) SubmitCheck(off, jobs, flags []int32) ([]C.asched_submit_resu
 	}
 	rc := C.asched_submit_check(g.h, C.int32_t(len(res)), i32p(off), i32p(jobs), i32p(flags), &res[0])
 	return res, g.check(rc)
+}
+
+// ---- one pool on several GPUs: the handle's communicator (include/armada_sched.h "The communicator"; no reference counterpart — FairSchedulingAlgo runs a pool on
+// one goroutine, scheduling_algo.go:165).  The library enqueues ncclAllReduce itself on the handle's stream; the Go side only moves the 128-byte unique id between
+// the scheduler replicas (one process — or one locked OS thread — per GPU) through whatever it already has: the leader's gRPC, a Pulsar message, a shared file.
+
+// CommUniqueId is called by ONE rank (ncclGetUniqueId); every rank then passes the same bytes to CommInit.
+func CommUniqueId() ([128]byte, error) {
+	var id C.asched_unique_id
+	var out [128]byte
+	if rc := C.asched_comm_unique_id(&id); rc != 0 {
+		return out, errors.Errorf("asched_comm_unique_id: RCCL is not available (rc %d)", int(rc))
+	}
+	copy(out[:], C.GoBytes(unsafe.Pointer(&id.bytes[0]), 128))
+	return out, nil
+}
+
+// CommInit == ncclCommInitRank on this handle's GPU; blocks until all `world` ranks have called it.
+func (g *GpuRound) CommInit(id [128]byte, rank, world int) error {
+	var cid C.asched_unique_id
+	for i := range id {
+		cid.bytes[i] = C.char(id[i])
+	}
+	return g.check(C.asched_comm_init(g.h, &cid, C.int32_t(rank), C.int32_t(world)))
+}
+
+func (g *GpuRound) CommDestroy() error { return g.check(C.asched_comm_destroy(g.h)) }
+
+// FitSelectBatchSharded: this handle holds rows [rankOffset, rankOffset+len(nodes)) of the pool's nodes in index order; every rank calls it with the same jobs.
+// EXACT: out[i] = position of the chosen node among ALL nodes of the pool in index order (-1: none) == nodeDb.SelectNodeForJobWithTxn's first fit at `priority`
+// on a NodeDb holding all shards (nodedb.go:840-879).  fieldBits[k] = bits of floor(max allocatable / resolution) of indexed resource k over ALL shards.
+func (g *GpuRound) FitSelectBatchSharded(jobs []int32, priority int32, fieldBits []int32, rankBits int32, rankOffset int64) ([]int32, error) {
+	var lay C.asched_global_key_layout
+	lay.n_fields = C.int32_t(len(fieldBits))
+	for i, b := range fieldBits {
+		lay.field_bits[i] = C.int32_t(b)
+	}
+	lay.rank_bits = C.int32_t(rankBits)
+	lay.rank_offset = C.int64_t(rankOffset)
+	out := make([]int32, len(jobs))
+	if err := g.check(C.asched_fit_select_batch_sharded(g.h, C.int32_t(len(jobs)), i32p(jobs), C.int32_t(priority), &lay, i32p(out))); err != nil {
+		return nil, err
+	}
+	return out, nil
+}
+
+// RoundExchange is the queue-hash mode of BASELINE's north_star after Schedule on every rank's replica: APPROXIMATE (DESIGN.md 7 — a conflict set is replayed, the
+// result is feasible but not the reference's); per job: node after the accepted placements and all preemptions, priority there, replay flag.
+func (g *GpuRound) RoundExchange(numJobs int) (C.asched_delta_summary, []int32, []int32, []uint8, error) {
+	var sum C.asched_delta_summary
+	node, prio, replay := make([]int32, numJobs), make([]int32, numJobs), make([]uint8, numJobs)
+	err := g.check(C.asched_round_exchange(g.h, &sum, i32p(node), i32p(prio), u8p(replay)))
+	return sum, node, prio, replay, err
 }

@@ -100,7 +100,7 @@ DEV int pqTop(Dev& d, const Ctl& c) {
 
 // ---- platform layer
 static std::string g_err;
-struct PlatCtx { int32_t cancelWord = 0; double deadlineS = 0; bool inRound = false; int launches = 0; };   // per handle, like the device build's (stream / events / mailbox there)
+struct PlatCtx { int32_t cancelWord = 0; double deadlineS = 0; bool inRound = false; int launches = 0; asched_allreduce_fn extFn = nullptr; void* extCtx = nullptr; int commRank = 0, commWorld = 1; };   // per handle, like the device build's (stream / events / mailbox there)
 static thread_local PlatCtx* t_ctx = nullptr;
 static void* plat_malloc(size_t n) { return malloc(n); }
 static void plat_free(void* p) { free(p); }
@@ -193,6 +193,17 @@ static int plat_run_fit_batch(Dev& d, const std::vector<int32_t>& shapes, int le
     a.maskA = d.shapeMask + (size_t)shapes[i] * d.cfg.W; a.maskB = nullptr; a.level = level; a.levelHi = 0;
     out[i] = wgFirstFit(d, a);
   }
+  return 0;
+}
+// the handle's communicator: the CPU build has no RCCL — only the caller's transport (asched_comm_init_external; gloo in the world-size-2 tests)
+static int plat_comm_unique_id(char*) { g_err = "the CPU build of the tests has no RCCL: asched_comm_init_external only"; return -1; }
+static int plat_comm_init(const char*, int, int) { g_err = "the CPU build of the tests has no RCCL: asched_comm_init_external only"; return -1; }
+static int plat_comm_init_external(asched_allreduce_fn fn, void* ctx, int rank, int world) { t_ctx->extFn = fn; t_ctx->extCtx = ctx; t_ctx->commRank = rank; t_ctx->commWorld = world; return 0; }
+static void plat_comm_destroy() { if (t_ctx) { t_ctx->extFn = nullptr; t_ctx->extCtx = nullptr; t_ctx->commRank = 0; t_ctx->commWorld = 1; } }
+static void plat_comm_info(int* rank, int* world) { *rank = t_ctx ? t_ctx->commRank : 0; *world = t_ctx ? t_ctx->commWorld : 1; }
+static int plat_allreduce(long long* buf, size_t count, int op) {
+  if (!t_ctx->extFn) return 0;
+  if (t_ctx->extFn(t_ctx->extCtx, buf, (int64_t)count, op) != 0) { g_err = "the external all-reduce transport failed"; return -1; }
   return 0;
 }
 // one pool on several GPUs (armada_amd/csrc/mgpu.h): the per-element functions of the grid kernels in serial loops

@@ -5,7 +5,7 @@ import os
 import pytest
 
 import armada_amd
-from armada_amd.binding import ALL_SYMBOLS, Config, SchedError, Scheduler
+from armada_amd.binding import ALL_SYMBOLS, OPTIONAL_SYMBOLS, Config, SchedError, Scheduler
 
 
 def _has_gpu():
@@ -26,7 +26,8 @@ def test_library_exports_every_symbol(hip_lib):
 
 
 def test_oracle_exports_every_symbol(oracle_lib):
-    assert sorted(oracle_lib.exported()) == sorted(ALL_SYMBOLS)
+    # the single-process checker has no communicator: the collectives that run on one are the product's (and the CPU build's, over an external transport)
+    assert sorted(oracle_lib.exported()) == sorted(set(ALL_SYMBOLS) - OPTIONAL_SYMBOLS)
 
 
 @pytest.mark.skipif(_has_gpu(), reason="only meaningful on a machine without a GPU")
