@@ -64,6 +64,9 @@ def hostsim_lib():
     """The device control code compiled for the CPU (tests/hostsim): logic checks without a GPU, never shipped."""
     from armada_amd.binding import Library
     here = os.path.join(ROOT, "tests", "hostsim")
-    subprocess.check_call(["make", "-C", here])
+    import fcntl
+    with open(os.path.join(here, ".build.lock"), "w") as lock:   # pytest-xdist workers reach this at the same time: one rebuilds, the others wait (a half-written .so is "file too short")
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-s", "-C", here])
     return Library(os.path.join(here, "libhostsim.so"), "asched_")
 
