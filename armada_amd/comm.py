@@ -15,6 +15,17 @@ import ctypes
 import numpy as np
 
 _OPS = None
+_HIP = None
+
+
+def hip_memcpy(dst: int, src: int, nbytes: int, kind: int) -> int:
+    """hipMemcpy of the HIP runtime this process already holds (torch's, which the library binds to as well); kind: 1 H2D, 2 D2H, 3 D2D"""
+    global _HIP
+    if _HIP is None:
+        _HIP = ctypes.CDLL("libamdhip64.so")
+        _HIP.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        _HIP.hipMemcpy.restype = ctypes.c_int
+    return int(_HIP.hipMemcpy(ctypes.c_void_p(dst), ctypes.c_void_p(src), nbytes, kind))
 
 
 def _ops(dist):
@@ -48,11 +59,9 @@ def init_external(s, dist, device_memory: bool = False):
             return 0
         host = torch.empty(count, dtype=torch.int64).pin_memory()
         torch.cuda.synchronize()
-        rc = torch.cuda.cudart().cudaMemcpy(host.data_ptr(), ptr, count * 8, 2)   # device -> host
-        if int(rc) != 0:
+        if hip_memcpy(host.data_ptr(), ptr, count * 8, 2) != 0:   # device -> host
             return 1
         dist.all_reduce(host, op=_ops(dist)[op])
-        rc = torch.cuda.cudart().cudaMemcpy(ptr, host.data_ptr(), count * 8, 1)   # host -> device
-        return 0 if int(rc) == 0 else 1
+        return 0 if hip_memcpy(ptr, host.data_ptr(), count * 8, 1) == 0 else 1   # host -> device
 
     s.comm_init_external(allreduce, rank, world)

@@ -99,7 +99,7 @@ struct ShapeReq { uint64_t fieldMin; int64_t ex0, ex1; int32_t cls, never; };
 
 // Level-0 ("fit without preemption", priority -2) fast structure, DESIGN.md "Sorted base + LDS delta".
 struct FastCfg {
-  int structOk, iterOk;       // host-verified exactness conditions (asched_host.inc: fastConditions)
+  int structOk, iterOk;       // host-verified exactness conditions (asched_host.inc: fastConditions); iterOk: 1 = fast iterations (Q <= QCAPF, round_fast.h), 2 = wide runs (Q > QCAPF, round_wide.h)
   int relocAll;               // ASCHED_RELOC_ALL=1: stage the per-queue arrays in LDS for any Q (default: only Q <= 64, see armada_sched.hip relocateIn)
   int cascadeFuse;            // the gate + urgency sweep of one job may run as ONE multi-level plane pass (round_ctl.h selectAtPriority): planes are monotone in the level (no explicit alloc_by_prio, non-negative requests) and a level tag fits above the packed key
   int F;                      // fit shapes: distinct (key fields, extras, requirement class) among the scheduling-key shapes — what node selection at priority -2 depends on;
@@ -165,6 +165,25 @@ struct QueueLoopArrays {
 
 // NodeTypeIterator state (nodeiteration.go:211-251): current lower bound (raw quantities), its packed form, the node it yielded last
 struct LitIt { int64_t lb[MAXK]; uint64_t bound; int32_t head; int32_t type; };
+
+// ---- wide runs (round_wide.h): stream runs for pools of more than QCAPF queues.  Per queue a stream of at most WIDE_L entries — its remaining cheap evicted jobs, then
+// its next single queued jobs — with precomputed queue-order keys; the k-way merge of QueueCandidateGangIteratorPQ over them is a BULK RANK (every entry counts, by binary
+// search in every other queue's monotone key sequence, the entries that order before it) instead of a lane per queue.
+#define WIDE_L 256
+struct WideSeg { int32_t evStart, evCnt, qBase, qLen, flags, total, qWant, pad; };   // flags: 1 stream, 2 barrier (a head the wide run cannot serve: its key stops the merge), 4 open (the queue goes on behind its last entry under a key not known here), 8 element 0 of the queued part is the peeked head
+struct WideKey { uint64_t a, x, y; };               // running maximum of the packed queue-order keys up to an entry (an entry is never served before its predecessor)
+struct WideEnt { int32_t job, qk; };                // qk = queue | 1 << 30 for an evicted job returning to its node
+struct WideParams { int32_t evOk, queuedOk, skipUnf, preferLarge, cap, numEvictedList, replayPending, executed; uint32_t maxLookback; int32_t pad[3]; };
+struct WideDev {
+  WideSeg* seg;        // [Q]
+  WideKey* key;        // [Q][WIDE_L]
+  int32_t* rank;       // [Q][WIDE_L] position of every entry in the merged order
+  WideEnt* merged;     // [Q * WIDE_L + Q]
+  int32_t* cnt;        // [2Q] entries executed per queue: evicted, queued
+  int64_t* tot;        // [3 * MAXR]: requests of the executed queued entries, of the executed evicted entries; [2 * MAXR + 0 / 1] their counts
+  uint32_t* stop;      // [2] first position the merged order is NOT valid at (atomic min); number of stream entries
+  WideParams* par;
+};
 
 struct Dev {
   DevCfg cfg;
@@ -285,7 +304,11 @@ struct Dev {
   int32_t evChunks;
   EvKey* qsKey;          // [QCAPF][QS_CMAX] precomputed costs of the queued-job streams
   QsIn* qsIn;            // [QCAPF]
-  QsSave* qsSave;        // [QCAPF]
+  union {
+    QsSave* qsSave;      // [QCAPF]  (pools of at most QCAPF queues: stream runs of the lane heap, round_fast.h)
+    struct WideDev* wide;  // pools of MORE than QCAPF queues (f.iterOk == 2): the arrays of the wide runs (round_wide.h) — the same slot, so that sizeof(Dev), which the
+                           // round kernel copies into its LDS, does not change with the feature (placement-sensitive)
+  };
   int64_t* qsPart;       // [QCAPF * QS_CPQ][MAXR + 2] chunk sums -> carries, first barrier of the chunk
   int32_t* qsLen;        // [QCAPF][2] usable stream length, 1 = the queue's list ends with the stream
   int32_t* l0Save;       // [L0CAP]

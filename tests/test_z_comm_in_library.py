@@ -147,7 +147,8 @@ def test_external_transport_sees_device_memory(hip_lib, oracle_lib):
     def allreduce(ptr, count, op):
         t = torch.empty(count, dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()
-        assert int(torch.cuda.cudart().cudaMemcpy(t.data_ptr(), ptr, count * 8, 3)) == 0   # device -> device: the words ARE device memory, complete, stream idle
+        from armada_amd.comm import hip_memcpy
+        assert hip_memcpy(t.data_ptr(), ptr, count * 8, 3) == 0   # device -> device: the words ARE device memory, complete, stream idle
         seen.append((count, op, int((t != 2 ** 63 - 1).sum())))
         return 0
     s.comm_init_external(allreduce, 0, 1)
