@@ -33,7 +33,7 @@
 
 // ------------------------------------------------------------------------------------------------ device primitives
 #define CTL_THREADS 256
-enum { OP_EXIT = 0, OP_SCAN = 1, OP_BULK = 2, OP_COMPACT = 3, OP_FAIR = 4, OP_ENGINE = 5, OP_BULKW = 6, OP_SCANFAIR = 7, OP_FTBUILD = 8, OP_HELPERS_EXIT = 9 };
+enum { OP_EXIT = 0, OP_SCAN = 1, OP_BULK = 2, OP_COMPACT = 3, OP_FAIR = 4, OP_ENGINE = 5, OP_BULKW = 6, OP_SCANFAIR = 7, OP_FTBUILD = 8, OP_HELPERS_EXIT = 9, OP_WIDE = 10 };
 struct BulkWArgs { int32_t kind, n; };   // a bulk pass whose bodies touch HBM only: shared with the helper workgroups
 
 struct Mailbox {
@@ -131,6 +131,7 @@ __device__ static inline unsigned long long helpWait(unsigned long long* mxOut =
 __device__ static inline void atomicAddI64(int64_t* p, int64_t v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
 __device__ static inline void atomicAddI32(int32_t* p, int32_t v) { atomicAdd(p, v); }
 __device__ static inline void atomicOrI32(int32_t* p, int32_t v) { atomicOr(p, v); }
+__device__ static inline void atomicMinU32(uint32_t* p, uint32_t v) { atomicMin(p, v); }
 __device__ static inline int atomicFetchAddI32(int32_t* p, int32_t v) { return atomicAdd(p, v); }
 __device__ static inline int waveMax32(int v) {
   for (int off = 32; off; off >>= 1) { int o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
@@ -287,6 +288,19 @@ __device__ static inline void wgBulkWide(Dev& d, int kind, int n) {
   __threadfence();
   __syncthreads();
   if (g_H) { (void)helpWait(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+}
+
+// one pass of a wide run's preparation / commit (round_wide.h): like wgBulkWide, with its own op and an out-of-line body — a call inside bulkElem's switch moves the
+// hot loops of the headline round
+__device__ static inline void wgWide(Dev& d, int kind, int n) {
+  int lane = threadIdx.x & 63;
+  if (lane == 0) { g_mb.op = OP_WIDE; g_mb.kind = kind; g_mb.n = n; if (g_H) { BulkWArgs a; a.kind = kind; a.n = n; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); helpIssue(OP_WIDE, &a); } }
+  __syncthreads();
+  { int nthreads = (g_H + 1) * (int)blockDim.x; int kd = g_mb.kind, nn = g_mb.n; for (int i = threadIdx.x; i < nn; i += nthreads) wideBulkAny(d, kd, i); }
+  __threadfence();
+  __syncthreads();
+  if (g_H) { (void)helpWait(); }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 #ifndef ASCHED_NO_FT
@@ -1342,6 +1356,12 @@ __device__ static void helperMain(const Dev& d, HelpBox* b, int H) {
       for (int i = tid; i < a.n; i += nthreads) bulkElem(dm, a.kind, i);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // this workgroup's writes before its completion count
     }
+    else if (op == OP_WIDE) {
+      BulkWArgs a = helpArgs<BulkWArgs>(b);
+      Dev& dm = const_cast<Dev&>(d);
+      for (int i = tid; i < a.n; i += nthreads) wideBulkAny(dm, a.kind, i);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    }
 #ifndef ASCHED_NO_FT
     else if (op == OP_FTBUILD) {
       BulkWArgs a = helpArgs<BulkWArgs>(b);
@@ -1399,6 +1419,11 @@ __global__ __launch_bounds__(CTL_THREADS) void k_control(Dev dev, int cmd, HelpB
       } else if (op == OP_BULKW) {
         int nthreads = (g_H + 1) * (int)blockDim.x; int kd = g_mb.kind, nn = g_mb.n;
         for (int i = threadIdx.x; i < nn; i += nthreads) bulkElem(d, kd, i);
+        __threadfence();
+      }
+      else if (op == OP_WIDE) {
+        int nthreads = (g_H + 1) * (int)blockDim.x; int kd = g_mb.kind, nn = g_mb.n;
+        for (int i = threadIdx.x; i < nn; i += nthreads) wideBulkAny(d, kd, i);
         __threadfence();
       }
 #ifndef ASCHED_NO_FT

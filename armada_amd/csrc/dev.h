@@ -169,17 +169,18 @@ struct LitIt { int64_t lb[MAXK]; uint64_t bound; int32_t head; int32_t type; };
 // ---- wide runs (round_wide.h): stream runs for pools of more than QCAPF queues.  Per queue a stream of at most WIDE_L entries — its remaining cheap evicted jobs, then
 // its next single queued jobs — with precomputed queue-order keys; the k-way merge of QueueCandidateGangIteratorPQ over them is a BULK RANK (every entry counts, by binary
 // search in every other queue's monotone key sequence, the entries that order before it) instead of a lane per queue.
-#define WIDE_L 256
+#define WIDE_L 1024
 struct WideSeg { int32_t evStart, evCnt, qBase, qLen, flags, total, qWant, pad; };   // flags: 1 stream, 2 barrier (a head the wide run cannot serve: its key stops the merge), 4 open (the queue goes on behind its last entry under a key not known here), 8 element 0 of the queued part is the peeked head
 struct WideKey { uint64_t a, x, y; };               // running maximum of the packed queue-order keys up to an entry (an entry is never served before its predecessor)
 struct WideEnt { int32_t job, qk; };                // qk = queue | 1 << 30 for an evicted job returning to its node
-struct WideParams { int32_t evOk, queuedOk, skipUnf, preferLarge, cap, numEvictedList, replayPending, executed; uint32_t maxLookback; int32_t pad[3]; };
+struct WideParams { int32_t evOk, queuedOk, skipUnf, preferLarge, cap, numEvictedList, replayPending, executed; uint32_t maxLookback; int32_t noNew, pad[2]; };
 struct WideDev {
   WideSeg* seg;        // [Q]
   WideKey* key;        // [Q][WIDE_L]
   int32_t* rank;       // [Q][WIDE_L] position of every entry in the merged order
   WideEnt* merged;     // [Q * WIDE_L + Q]
   int32_t* cnt;        // [2Q] entries executed per queue: evicted, queued
+  int32_t* cap;        // [Q] entries to prepare for the queue in the next run: follows what the queue consumes (queues advance at very different rates under DRF)
   int64_t* tot;        // [3 * MAXR]: requests of the executed queued entries, of the executed evicted entries; [2 * MAXR + 0 / 1] their counts
   uint32_t* stop;      // [2] first position the merged order is NOT valid at (atomic min); number of stream entries
   WideParams* par;

@@ -70,6 +70,7 @@ DEV int wgCompact(Dev& d, const int32_t* src, int n, const uint8_t* flagByValue,
 DEV void atomicAddI64(int64_t* p, int64_t v);
 DEV void atomicAddI32(int32_t* p, int32_t v);
 DEV void atomicOrI32(int32_t* p, int32_t v);
+DEV void atomicMinU32(uint32_t* p, uint32_t v);
 
 // fast path (round_fast.h): level-0 sorted base + LDS delta, LDS-resident heads, key-based queue argmin
 struct Ctl; struct PassCfg;
@@ -88,6 +89,9 @@ DEV void fastEnterGeneric(Dev& d, Ctl& c);
 DEV bool fastGangMember(Dev& d, Ctl& c, int job);  // select (fit at priority -2) + bind of one unpinned queued gang member through the fast structure; false = not done
 DEV void fastFence(Ctl& c);
 DEV_COLD void ensureReplaySlow(Dev& d, Ctl& c);
+// pools of more than QCAPF queues (round_wide.h): stream runs whose k-way merge is a bulk rank over all queues' precomputed key sequences
+DEV_COLD int wideRun(Dev& d, Ctl& c, const PassCfg& pc);
+DEV bool wideHeadOk(Dev& d, const Ctl& c, const PassCfg& pc, int t);
 DEV void ensureReplay(Dev& d, Ctl& c) { if (d.rs->replayPending) ensureReplaySlow(d, c); }   // (the test stays with the caller: a call costs a register save / restore)
 //             // run the deferred eviction-order replay before anything reads the evicted table         // leave fast mode: LDS queue state back into the generic arrays, HBM updates visible
 
@@ -1273,7 +1277,7 @@ DEV void passInit(Dev& d, Ctl& c, const PassCfg& pc) {
     d.itEi[q] = d.evOff[q]; d.itQi[q] = d.queuedOff[q]; d.itStage[q] = 0; d.itJobsSeen[q] = 0; d.itNext[q] = -1; d.itStashed[q] = -1;
     d.itJobOnlyEv[q] = 0; d.itGangOnlyEv[q] = 0; d.onlyEvByQueue[q] = 0; d.pqInHeap[q] = 0;
     d.pqBudget[q] = d.qDc[q] / d.qWeight[q];  // pushQueue :509-519
-    if (d.qsSave && q < QCAPF) d.qsSave[q].valid = 0;   // a new pass: no stream carries over
+    if (d.f.iterOk == 1 && d.qsSave && q < QCAPF) d.qsSave[q].valid = 0;   // a new pass: no stream carries over (iterOk == 2: the slot holds the wide runs' arrays)
     MK(if (mkOn(d)) { MKD.itV1[q] = -1; MKD.itV2[q] = -1; })
   }
   MK(if (mkOn(d)) { MKS.heapN = 0; MKS.prevCost = 0.0; MKS.prevRank = -1; })   // a fresh MarketIteratorPQ (NewMarketCandidateGangIterator :38-60; previousResultQueue "" orders before every name)
@@ -1338,7 +1342,21 @@ DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff)
       // (once the deferred replay of the evicted jobs has run, the fast loop serves such a head itself: fastPreemptIter)
       if (d.rs->replayPending && r0 >= 0 && !d.jcEvicted[r0] && d.jcAssigned[r0] < 0 && fastSelectLevel0(d, r0) == -1) headNeedsGeneric = true;
     }
-    if (headNeedsGeneric) {}
+    if (c.fastEnabled && d.f.iterOk == 2 && d.rs->fastActive) {
+      // more than QCAPF queues: a wide run (round_wide.h) serves every head it can in one go; the generic iteration below takes the first one it cannot.  After a
+      // run that got nowhere the next attempts wait (doubling, up to 64 generic iterations): an attempt costs the bulk preparation.
+      if (fastSkip > 0) fastSkip--;
+      else {
+        int t0 = pqTop(d, c);
+        int E = (t0 >= 0 && wideHeadOk(d, c, pc, t0)) ? wideRun(d, c, pc) : -1;
+        if (c.cancelSeen) { raise(d, ASCHED_ERR_TIMEOUT, 901); return; }
+        if (d.rs->error) return;
+        if (E >= 16) fastStreak = 0;
+        else if (E >= 0) { if (fastStreak < 6) fastStreak++; fastSkip = (1 << fastStreak) - 1; }
+        if (E > 0) continue;
+      }
+    }
+    else if (headNeedsGeneric) {}
     else if (fastOn(d, c) && fastSkip > 0) fastSkip--;
     else if (fastOn(d, c)) {
       int before = d.rs->statFastIters + d.rs->loopIterations;

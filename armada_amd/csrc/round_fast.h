@@ -316,7 +316,7 @@ DEV bool entryFits(KREF k, const JobTail& r, uint64_t key, int64_t ex0, int64_t 
 DEV bool entryLive(KREF k, uint64_t key, int64_t ex0, int64_t ex1) {  // could still host the smallest request of some shape
   return fieldsGE(k, key, k.minFieldMin) && k.minEx0 <= ex0 && k.minEx1 <= ex1;
 }
-DEV bool fastOn(Dev& d, const Ctl& c) { return c.fastEnabled && d.f.iterOk; }
+DEV bool fastOn(Dev& d, const Ctl& c) { return c.fastEnabled && d.f.iterOk == 1; }   // (iterOk == 2: more than QCAPF queues, round_wide.h)
 DEV void fastHeadInvalidate(int q) { if (q < QCAPF) FL.hot[q].headFast = 0; }
 DEV void fastPassReset() { for (int q = 0; q < QCAPF; q++) { FL.hot[q].headFast = 0; FL.hot[q].winCount = 0; FL.hot[q].winKind = -1; FL.hot[q].ewCount = 0; FL.hot[q].ewStart = 0; } }
 
@@ -329,7 +329,7 @@ DEV KeyOut packItemKeys(int preferLarge, int q, int32_t prio, double proposed, d
   return o;
 }
 DEV void fastItemKeys(Dev& d, const Ctl& c, int q) {  // from the generic arrays (generic updatePQItem)
-  if (!d.f.iterOk || q >= QCAPF) return;
+  if (d.f.iterOk != 1 || q >= QCAPF) return;
   packItemKeys(c.preferLarge, q, c.compareSchedPrio ? d.pqSchedPrio[q] : d.pqPcPrio[q], d.pqProposed[q], d.pqCurrent[q], d.pqSize[q], d.pqBudget[q]);
 }
 

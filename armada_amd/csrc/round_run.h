@@ -18,6 +18,7 @@ enum BulkKind {
 DEV void wgBulk(Dev& d, int kind, int n);  // every element i in [0,n) through bulkElem(), then a workgroup barrier
 DEV void wgFtBuild(Dev& d, int phase, int n);  // one pass of the fair-share threshold table's build (round_ft.h ftBuildAny), helper workgroups included
 DEV void wgBulkWide(Dev& d, int kind, int n);  // the same with the helper workgroups taking their share (bodies that touch HBM only)
+#include "round_wide.h"
 DEV int wgCompactFlagged(Dev& d, const int32_t* order, const int32_t* segOff, int nseg, int n, const uint8_t* flag, int32_t* dst, int32_t* outSegOff);
 DEV int wgCompactIota(Dev& d, int n, const uint8_t* flag, int32_t* dst);
 

@@ -1,0 +1,420 @@
+// round_wide.h — wide runs: the stream run (round_fast.h) for pools of MORE than QCAPF queues.
+//
+// Why.  The fast iteration keeps one queue per lane of the control wave and 1.1 KB of per-queue state in LDS: beyond 64 queues a round used to run on the generic
+// code alone, one iteration per job at ~86 k clocks with every queue's state behind HBM pointers — slower than one host core (256 queues 0.59x).
+// CostBasedCandidateGangIterator itself has no queue limit (queue_scheduler.go:449-699), and production pools hold hundreds of queues.
+//
+// What.  While the heads of the queues are single jobs that need no preemption — phase-1-evicted jobs returning to their nodes (nodedb.go:897-906) and queued
+// jobs that fit at priority -2 — the order in which QueueCandidateGangIteratorPQ serves them is a function of every queue's OWN allocation prefix (the Less
+// inputs of queue_scheduler.go:636-686, 738-798), not of anything the node side produces.  So per queue the next <= WIDE_L entries are laid out ahead — the rest
+// of its gang-free eviction list with the costs B_EVKEYS computed (round_run.h), then its next single queued jobs with the costs of the chunked prefix passes
+// B_QSSUM / B_QSSTITCH / B_QSKEYS (the same float64 operations as updatePQItem on the same sums) — and the k-way heap merge over those sequences is computed as a
+// BULK RANK on the helper workgroups: an entry's position = the number of entries that order before it = its index in its own queue + for every other queue a
+// binary search in that queue's sequence.  A heap merge serves a queue's entries in list order whatever their keys, so the sequences are compared by their
+// running-maximum keys (the argument of round_fast.h "skip mode": an entry is never served before its predecessor), ties broken like Less by the queue's name
+// rank.  The control wave then only STAGES the merged order into the ring; the node engine and the bind wave place the queued jobs exactly as in a stream run
+// (first fit at priority -2 through the sorted base + L0; evicted entries need no node work: DESIGN.md 3.1 item 2); when the run ends the entries that were
+// executed are committed per queue (one thread per queue: accounting, the evicted jobs' return, iterator cursors, tokens) and the generic updatePQItem
+// produces every touched queue's next head from the state the reference would have at that point.
+//
+// Where a run must stop — BEFORE any side effect that would have to be taken back:
+//   * a queue in the heap whose head the run cannot serve (a gang, a job that is pinned / preempted-marked, an evicted job of a list with gangs ...): its
+//     current key is an entry of the merge ("barrier"); nothing that orders after it is executed;
+//   * a queue that goes on behind its last prepared entry under a key that is not known here (the cap, a gang member, a known-unfeasible scheduling key, a
+//     disallowed request, the queue's rate-limit tokens, the lookback limit): the run ends with that entry ("open");
+//   * the global rate limiter has no token for another new job; the engine finds no node for an entry (that entry and everything after it are forgotten: no
+//     accounting had been done for them; the generic cascade decides about the job); the caller's cancel word.
+// Everything else (per-class resource caps, round resource limits, floating resources, soft time budgets, cross-pool away jobs, market mode, the pass over
+// evicted jobs only ordered by scheduled-at priority) keeps the pool on the generic path: asched_host.inc decides (FastCfg.iterOk == 2).
+//
+// Exactness rests on the same three facts as the stream run: the keys are the ones updatePQItem would compute (same operations, same order); the packed key
+// orders like Less for finite non-negative costs; integer accounting is order independent.  tests/test_z_wide_runs.py and `tests/soak.py wide` compare whole
+// rounds with the oracle for 65 ... 1 024 queues (CPU build and -m gpu).
+#pragma once
+
+enum { W_SEG = 0, W_EVSUM, W_KEYS, W_RANK, W_COMMIT };
+
+DEV bool wideKeyLess(const WideKey& a, const WideKey& b) { return a.a != b.a ? a.a < b.a : a.x != b.x ? a.x < b.x : a.y < b.y; }
+DEV bool wideKeyEq(const WideKey& a, const WideKey& b) { return a.a == b.a && a.x == b.x && a.y == b.y; }
+DEV WideKey widePack(int preferLarge, const EvKey& e, double budget) {
+  PackedKey p = packKey3(preferLarge, e.pcPrio, e.proposed, e.current, e.size, budget);
+  WideKey k; k.a = p.A; k.x = p.X; k.y = p.Y;
+  return k;
+}
+
+// ---- the bulk bodies (one element per call: every workgroup of the launch takes a share; they read and write HBM only and never the scheduling-context
+// scalars, which live in the control workgroup's LDS for the launch — what they need of those comes through WideParams)
+DEV_COLD void wideBulkAny(Dev& d, int kind, int i) {
+  const DevCfg& c = d.cfg;
+  WideDev& w = *d.wide;
+  const WideParams& P = *w.par;
+  switch (kind) {
+    case W_SEG: {   // queue i: what its stream consists of, the inputs of the queued part's prefix passes (QsIn)
+      int q = i;
+      WideSeg s; s.evStart = 0; s.evCnt = 0; s.qBase = 0; s.qLen = 0; s.flags = 0; s.total = 0; s.qWant = 0; s.pad = 0;
+      QsIn in; in.base = 0; in.len = 0; in.skipUnf = P.skipUnf; in.pad = 0; in.weight = d.qWeight[q];
+      for (int r = 0; r < MAXR; r++) in.a0[r] = r < c.R ? QV(d.qAlloc, q)[r] + QV(d.qPenalty, q)[r] : 0;
+      w.cnt[2 * q] = 0; w.cnt[2 * q + 1] = 0;
+      int cap = w.cap[q] > 0 ? w.cap[q] : P.cap;
+      if (cap > WIDE_L) cap = WIDE_L;
+      if (d.pqInHeap[q]) {
+        int ref = d.pqGctx[q];
+        bool stream = false, queuedPart = false, headQueued = false;
+        int qBase = 0;
+        const bool queuedOk = P.queuedOk && !d.onlyEvByQueue[q] && !d.itJobOnlyEv[q] && !d.itGangOnlyEv[q];
+        if (ref >= 0 && d.itNext[q] == ref && !d.jcPreempted[ref] && d.jGang[ref] < 0) {
+          if (d.jcEvicted[ref]) {   // an evicted job on its way back (fastStreamPrepare's evicted stream: the costs exist, B_EVKEYS)
+            int p = d.itEi[q] - 1, end = d.evOff[q + 1];
+            if (P.evOk && d.evCheap[q] && d.itStage[q] == 0 && p >= d.evOff[q] && p < end && d.evList[p] == ref) {
+              stream = true;
+              s.evStart = p; s.evCnt = end - p;
+              if (s.evCnt > cap) { s.evCnt = cap; s.flags |= 4; }   // more evicted jobs behind the cap
+              else if (queuedOk) { queuedPart = true; qBase = d.itQi[q]; }
+              // (not queuedOk: the queue yields nothing behind its evicted jobs — it leaves the heap, the merge goes on without it)
+            }
+          } else {                  // a queued job: element 0 of the queued part is the peeked head (fastStreamPrepare's queued stream)
+            int b = d.itQi[q] - 1;
+            if (d.itStage[q] == 1 && queuedOk && b >= d.queuedOff[q] && b < d.queuedOff[q + 1] && d.queuedJobs[b] == ref && d.jcAssigned[ref] < 0) {
+              stream = true; queuedPart = true; headQueued = true; qBase = b; s.flags |= 8;
+            }
+          }
+        }
+        if (stream && queuedPart) {
+          int avail = d.queuedOff[q + 1] - qBase;
+          int len = avail, room = cap - s.evCnt;
+          bool open = false;
+          // CheckJobConstraints (constraints.go:121-157) on the queue side: a queue that may not schedule new jobs answers with a queue-terminal reason — the generic code's
+          if (avail > 0 && (P.noNew || d.qCordoned[q] || d.qBurst[q] < 1 || d.qTokens[q] < 1)) { len = 0; open = true; }   // (noNew: the global limiter is empty — the first new job to reach the top gets the terminal reason)
+          if (len > room) { len = room; open = true; }
+          if (len > 0 && !d.qRateInf[q] && d.qTokens[q] < (double)len) { len = (int)d.qTokens[q]; open = true; }
+          if (len > 0 && P.maxLookback != 0) {   // element e is peeked while itJobsSeen < maxLookback (queue_scheduler.go:434-444); the head was counted when it was peeked
+            int64_t lim = (int64_t)P.maxLookback - d.itJobsSeen[q] + (headQueued ? 1 : 0);
+            if (lim < (headQueued ? 1 : 0)) lim = headQueued ? 1 : 0;
+            if (len > lim) { len = (int)lim; open = true; }   // (behind the limit the queue yields evicted jobs only: the generic iterator makes that switch)
+          }
+          // element 0 of a queued part that has not been peeked yet goes through Peek's unfeasible-key skip like every later one (B_QSSUM exempts element 0: there it is the head)
+          if (len > 0 && !headQueued && P.skipUnf && d.unfeasible[d.jShape[d.queuedJobs[qBase]]]) { len = 0; open = true; }
+          if (open) s.flags |= 4;
+          s.qBase = qBase; s.qWant = len;
+          in.base = qBase; in.len = len;
+        }
+        if (stream) s.flags |= 1;
+        else { s.flags = 2 | 4; s.total = 1; }
+      }
+      d.qsIn[q] = in;
+      if (in.len == 0) { d.qsLen[2 * q] = 0; d.qsLen[2 * q + 1] = 0; }
+      w.seg[q] = s;
+    } break;
+    case W_EVSUM: {   // eviction-list position i: the queued part of its queue starts from the allocation the queue has once these evicted jobs are back
+      int p = i;
+      if (p >= P.numEvictedList) break;
+      int job = d.evList[p];
+      int q = d.jQueue[job];
+      if (q < 0 || q >= c.Q) break;
+      const WideSeg& s = w.seg[q];
+      if (!(s.flags & 1) || s.qWant <= 0 || p < s.evStart || p >= s.evStart + s.evCnt) break;
+      const int64_t* req = JREQ(d, job);
+      for (int r = 0; r < c.R; r++) if (req[r]) atomicAddI64(&d.qsIn[q].a0[r], req[r]);
+    } break;
+    case W_KEYS: {    // queue i: the running maximum of its entries' packed keys, its final length, whether it goes on behind its last entry
+      int q = i;
+      WideSeg s = w.seg[q];
+      if (!(s.flags & 3)) break;
+      double budget = d.pqBudget[q];
+      WideKey* out = w.key + (size_t)q * WIDE_L;
+      if (s.flags & 2) {   // a head the run cannot serve: its key as the generic Less sees it
+        EvKey e; e.proposed = d.pqProposed[q]; e.current = d.pqCurrent[q]; e.size = d.pqSize[q]; e.pcPrio = d.pqPcPrio[q]; e.job = -1;
+        out[0] = widePack(P.preferLarge, e, budget);
+        break;
+      }
+      int qLen = 0;
+      if (s.qWant > 0) {
+        qLen = d.qsLen[2 * q];
+        if (qLen < s.qWant) s.flags |= 4;                 // cut at a gang member / unfeasible key / disallowed request (B_QSSUM's barrier)
+        else if (!d.qsLen[2 * q + 1]) s.flags |= 4;       // the queue's list goes on behind the prepared entries
+      }
+      s.qLen = qLen; s.total = s.evCnt + qLen;
+      if (s.total == 0) {   // nothing of this queue can be laid out (no token, cordoned, a barrier at its head): its head stops the merge like any other head the run cannot serve
+        EvKey e; e.proposed = d.pqProposed[q]; e.current = d.pqCurrent[q]; e.size = d.pqSize[q]; e.pcPrio = d.pqPcPrio[q]; e.job = -1;
+        out[0] = widePack(P.preferLarge, e, budget);
+        s.flags = 2 | 4; s.total = 1;
+        w.seg[q] = s;
+        break;
+      }
+      WideKey eff; eff.a = 0; eff.x = 0; eff.y = 0;
+      for (int e = 0; e < s.total; e++) {
+        const EvKey& k = e < s.evCnt ? d.evKey[s.evStart + e] : d.qsKey[(size_t)q * QS_CMAX + (e - s.evCnt)];
+        WideKey pk = widePack(P.preferLarge, k, budget);
+        if (wideKeyLess(eff, pk)) eff = pk;
+        out[e] = eff;
+      }
+      w.seg[q] = s;
+      if (s.total > 0) atomicAddI32((int32_t*)&w.stop[1], s.total);
+    } break;
+    case W_RANK: {    // entry i = (queue, index): its position in the merged order
+      int q = i / WIDE_L, e = i % WIDE_L;
+      const WideSeg s = w.seg[q];
+      if (e >= s.total) break;
+      const WideKey key = w.key[(size_t)q * WIDE_L + e];
+      const int myName = d.qNameRank[q];
+      int rank = e;
+      for (int q2 = 0; q2 < c.Q; q2++) {
+        if (q2 == q) continue;
+        int n2 = w.seg[q2].total;
+        if (n2 == 0) continue;
+        const WideKey* k2 = w.key + (size_t)q2 * WIDE_L;
+        const bool nameBefore = d.qNameRank[q2] < myName;   // equal keys: Less ends with the queue name (queue_scheduler.go:796-797)
+        int lo = 0, hi = n2;
+        while (lo < hi) {
+          int mid = (lo + hi) >> 1;
+          const WideKey m = k2[mid];
+          bool before = wideKeyLess(m, key) || (nameBefore && wideKeyEq(m, key));
+          if (before) lo = mid + 1; else hi = mid;
+        }
+        rank += lo;
+      }
+      w.rank[(size_t)q * WIDE_L + e] = rank;
+      if (s.flags & 2) { atomicMinU32(&w.stop[0], (uint32_t)rank); break; }
+      WideEnt en;
+      if (e < s.evCnt) { en.job = d.evList[s.evStart + e]; en.qk = q | (1 << 30); }
+      else { en.job = d.queuedJobs[s.qBase + (e - s.evCnt)]; en.qk = q; }
+      w.merged[rank] = en;
+      if (e == s.total - 1 && (s.flags & 4)) atomicMinU32(&w.stop[0], (uint32_t)(rank + 1));
+    } break;
+    case W_COMMIT: {  // queue i: its entries among the first P.executed of the merged order have been executed — accounting, the evicted jobs' return, cursors, tokens
+      int q = i;
+      const WideSeg s = w.seg[q];
+      if (!(s.flags & 1) || s.total == 0) break;
+      const int E = P.executed;
+      int cEv = 0, cQ = 0;
+      int64_t sumEv[MAXR], sumQ[MAXR];
+      for (int r = 0; r < MAXR; r++) sumEv[r] = sumQ[r] = 0;
+      for (int e = 0; e < s.total; e++) {
+        if (w.rank[(size_t)q * WIDE_L + e] >= E) break;   // (positions grow with e)
+        if (e < s.evCnt) {
+          // an evicted job is back on its node: the evicted branch of fastIter's commit == applyEvictedRange (node.go:416-442 arithmetic on the levels above the
+          // evicted priority; level 0 is unchanged: +req un-evicts, -req binds), sctx.AddJobSchedulingContext of a rescheduled job (context/queue.go:231-265)
+          int p = s.evStart + e, job = d.evList[p];
+          const JobRec& jr = d.jrec[job];
+          int n = jr.node0, pcx = jr.pc; int32_t prio = jr.runPrio;
+          int32_t cutoff = jr.preemptible ? prio : NONPREEMPTIBLE_CUTOFF;
+          for (int x = 0; x < c.R; x++) {
+            int64_t v = jr.req[x];
+            if (!v) continue;
+            sumEv[x] += v;
+            size_t ix = ((size_t)q * c.npc + pcx) * c.R + x;
+            d.qAllocByPc[ix] += v; d.qEvictedByPc[ix] -= v;
+            for (int l = 1; l < jr.nlRun; l++) atomicAddI64(&d.alloc[((size_t)l * c.R + x) * c.Npad + n], -v);
+          }
+          if (jr.keyDelta) for (int l = 1; l < jr.nlRun; l++) atomicAddI64((int64_t*)&d.keys[(size_t)l * c.Npad + n], -(int64_t)jr.keyDelta);
+          d.jcReason[job] = 0; d.jcHasPctx[job] = 1; d.pcNode[job] = n; d.pcSap[job] = prio;
+          d.jobNode[job] = n; d.jobCutoff[job] = cutoff; d.jobEvictedOnNode[job] = 0; d.schedAtPrio[job] = prio; d.inSchedAndEvicted[job] = 0;
+          d.pcPap[job] = prio; d.pcMethod[job] = ASCHED_METHOD_RESCHEDULED; d.jobFlags[job] = F_RESCHEDULED; d.inPreempted[job] = 0;
+          if (!P.replayPending) { d.evTabAlive[d.evIdxByPos[p]] = 0; d.evIndexOfJob[job] = -1; }
+          cEv++;
+        } else {
+          // a new job: the bind wave has issued BindJobToNode and the job's result fields (round_fast.h bindJob); the queue side of sctx.AddGangSchedulingContext here
+          int job = d.queuedJobs[s.qBase + (e - s.evCnt)];
+          const int64_t* req = JREQ(d, job);
+          int pcx = d.jPc[job];
+          for (int x = 0; x < c.R; x++) {
+            int64_t v = req[x];
+            if (!v) continue;
+            sumQ[x] += v;
+            size_t ix = ((size_t)q * c.npc + pcx) * c.R + x;
+            d.qAllocByPc[ix] += v; d.qSchedByPc[ix] += v;
+          }
+          cQ++;
+        }
+      }
+      if (cEv + cQ >= s.total && (s.flags & 4)) {   // the queue used up what it had been given and goes on: IT ended the run — twice as many entries next time.  (Queues advance
+        int have = w.cap[q] > 0 ? w.cap[q] : P.cap;   //  at very different rates under DRF; the caps only grow: the rank pass is cheap next to a run cut short)
+        w.cap[q] = 2 * have > WIDE_L ? WIDE_L : 2 * have;
+      }
+      if (cEv + cQ == 0) break;
+      for (int x = 0; x < c.R; x++) {
+        QV(d.qAlloc, q)[x] += sumEv[x] + sumQ[x];
+        if (sumQ[x]) atomicAddI64(&w.tot[x], sumQ[x]);
+        if (sumEv[x]) atomicAddI64(&w.tot[MAXR + x], sumEv[x]);
+      }
+      if (cQ) atomicAddI64(&w.tot[2 * MAXR], cQ);
+      if (cEv) atomicAddI64(&w.tot[2 * MAXR + 1], cEv);
+      w.cnt[2 * q] = cEv; w.cnt[2 * q + 1] = cQ;
+      // the iterators as Clear + the Peeks of the entries served leave them (queue_scheduler.go:595-606, 376-444; jobiteration.go:179-228): the next Peek yields
+      // the first entry that was not served.  The head had been peeked (and, a queued one, counted) before the run.
+      if (cEv) d.itEi[q] = s.evStart + cEv;
+      if (cQ) {
+        d.itQi[q] = s.qBase + cQ;
+        d.itJobsSeen[q] += (s.flags & 8) ? cQ - 1 : cQ;
+        if (!d.qRateInf[q] && 1 <= d.qBurst[q]) d.qTokens[q] -= (double)cQ;   // rate.Limiter.ReserveN per scheduled job (gang_scheduler.go:118-123)
+      }
+      d.itNext[q] = -1; d.pqInHeap[q] = 0;
+    } break;
+  }
+}
+
+#ifdef ASCHED_HOSTSIM
+DEV void wgWide(Dev& d, int kind, int n) { for (int i = 0; i < n; i++) wideBulkAny(d, kind, i); }
+#else
+DEV void wgWide(Dev& d, int kind, int n);   // armada_sched.hip: the pass on the control workgroup and the helper workgroups (OP_WIDE)
+#endif
+
+
+// Is the head of queue t something a wide run can start with?  (The bulk preparation costs a few hundred microseconds: not worth it for a head the run stops at.)
+DEV bool wideHeadOk(Dev& d, const Ctl& c, const PassCfg& pc, int t) {
+  int ref = d.pqGctx[t];
+  if (ref < 0 || d.itNext[t] != ref || d.jcPreempted[ref] || d.jGang[ref] >= 0) return false;
+  if (d.jcEvicted[ref]) {
+    int p = d.itEi[t] - 1;
+    return c.fastEvStatic && d.rs->lvl0NonNeg && d.rs->numPreemptedMarks == 0 && d.evCheap[t] && d.itStage[t] == 0 && p >= d.evOff[t] && p < d.evOff[t + 1] && d.evList[p] == ref;
+  }
+  int b = d.itQi[t] - 1;
+  return d.itStage[t] == 1 && pc.withQueued && !c.onlyEvicted && !d.onlyEvByQueue[t] && !d.itJobOnlyEv[t] && !d.itGangOnlyEv[t] && !d.qCordoned[t] && d.qBurst[t] >= 1 &&
+         d.qTokens[t] >= 1 && d.rs->globalTokens >= 1 && d.rs->globalBurst >= 1 && b >= d.queuedOff[t] && d.queuedJobs[b] == ref && d.jcAssigned[ref] < 0;
+}
+
+// One wide run.  Called by queueSchedule with the generic state live (every queue's iterator, heap item and allocation in the generic arrays) and the queue at
+// the top of the heap known to be servable; returns the number of entries executed (0: nothing changed).  On return the generic state is the live one again.
+// coarse segment clocks of a run (always on: a dozen clock reads per run of thousands of entries) in statSeg[24..35]: [24] W_SEG + W_EVSUM, [25] queued-part prefix passes,
+// [26] W_KEYS, [27] W_RANK, [28] engine start, [29] staging (the engine's pace), [30] engine stop, [31] W_COMMIT, [32] the touched queues' next heads, [33] runs, [34] entries ranked
+#define WSEG(i) do { long long n_ = CLK(); rs.statSeg[i] += n_ - wT_; wT_ = n_; } while (0)
+DEV_COLD int wideRun(Dev& d, Ctl& c, const PassCfg& pc) {
+  const FastK k = fastKRef(d);
+  const int Q = d.cfg.Q, R = d.cfg.R;
+  WideDev& w = *d.wide;
+  RoundScalars& rs = *d.rs;
+  if (!rs.fastActive || c.compareSchedPrio || c.useReplayAlloc || c.txn.active || k.hasPcLimit || k.anyRoundLimit || k.disableHome || !d.qsKey) return 0;
+  int allowed = INT32_MAX;
+  if (!rs.globalRateInf) allowed = rs.globalTokens >= 2147483000.0 ? INT32_MAX : (rs.globalTokens < 1 ? 0 : (int)rs.globalTokens);
+  if (rs.globalBurst < 1 || rs.globalTokens < 1) allowed = 0;
+  // ---- preparation: every body below reads HBM only; the helper workgroups take their share
+  fastFence(c);
+  {
+    WideParams P; memset(&P, 0, sizeof P);
+    P.evOk = c.fastEvStatic && rs.lvl0NonNeg && rs.numPreemptedMarks == 0;
+    P.queuedOk = pc.withQueued && !c.onlyEvicted; P.noNew = allowed <= 0;
+    P.skipUnf = pc.skipKnown && rs.numUnfeasible > 0;
+    P.preferLarge = c.preferLarge; P.cap = 32;   // (a queue's first run; WideDev.cap[q] follows its consumption from then on)
+    P.numEvictedList = rs.numEvictedList; P.replayPending = rs.replayPending; P.executed = 0; P.maxLookback = pc.maxLookback;
+    *w.par = P;
+    w.stop[0] = 0xffffffffu; w.stop[1] = 0;
+    FOR_LANES(x, 3 * MAXR) w.tot[x] = 0;
+  }
+  FAST_GLOBAL_FENCE();
+  long long wT_ = CLK();
+  wgWide(d, W_SEG, Q);
+  if (c.fastEvStatic && rs.numEvictedList > 0) wgWide(d, W_EVSUM, rs.numEvictedList);
+  WSEG(24);
+  wgBulkWide(d, B_QSSUM, Q * QS_CPQ);
+  wgBulkWide(d, B_QSSTITCH, Q);
+  wgBulkWide(d, B_QSKEYS, Q * QS_CPQ);
+  WSEG(25);
+  wgWide(d, W_KEYS, Q);
+  WSEG(26);
+  wgWide(d, W_RANK, Q * WIDE_L);
+  WSEG(27);
+  uint32_t stop = UNI32(w.stop[0]), total = UNI32(w.stop[1]);
+  int V = stop < total ? (int)stop : (int)total;
+#ifdef ASCHED_HOSTSIM
+  if (V > 0) {   // the merged order starts with the queue the generic Less serves next
+    int t = pqTop(d, c);
+    if ((w.merged[0].qk & 0xffffff) != t) { fprintf(stderr, "hostsim: wide merge disagrees with Less (merged %d, generic %d)\n", w.merged[0].qk & 0xffffff, t); abort(); }
+  }
+  if (getenv("HS_WIDE_TRACE")) {
+    fprintf(stderr, "wide run: V %d stop %u total %u allowed %d", V, stop, total, allowed);
+    for (int q = 0; q < Q; q++) { const WideSeg& s = w.seg[q]; for (int e = 0; e < s.total; e++) { int r = w.rank[(size_t)q * WIDE_L + e];
+      if ((s.flags & 2) && r == (int)stop) fprintf(stderr, "  | barrier q%d gctx %d ev %d stage %d evCheap %d itNext %d", q, d.pqGctx[q], d.pqGctx[q] >= 0 ? d.jcEvicted[d.pqGctx[q]] : -1, d.itStage[q], d.evCheap[q], d.itNext[q]);
+      if (!(s.flags & 2) && (s.flags & 4) && e == s.total - 1 && r + 1 == (int)stop) fprintf(stderr, "  | open q%d evCnt %d qLen %d qWant %d cap %d avail %d tokens %.0f", q, s.evCnt, s.qLen, s.qWant, w.cap[q], d.queuedOff[q + 1] - s.qBase, d.qTokens[q]); } }
+    fprintf(stderr, "\n");
+  }
+#endif
+  if (V <= 0) return 0;
+  // ---- execution: stage the merged order into the ring; the node engine places the queued jobs, the bind wave issues the HBM side behind it
+  FastS S;
+  S.engLive = 0; S.engPend = -1; S.engWaitClk = 0; S.engSeq = 0; S.inlineStreak = 0;
+  S.laneL = FLANE / (R > 0 ? R : 1); S.laneX = FLANE % (R > 0 ? R : 1);
+  S.statScanSteps = 0; S.statL0Max = UNI32(rs.statL0Max); S.fastActive = 1; S.numUnfeasible = UNI32(rs.numUnfeasible); S.statRefills = 0;
+  S.lvl0NonNeg = UNI32(rs.lvl0NonNeg); S.numPreemptedMarks = UNI32(rs.numPreemptedMarks); S.replayPending = UNI32(rs.replayPending);
+  rs.statSeg[33] += 1; rs.statSeg[34] += total;
+  wT_ = CLK();
+  engineStart(d, S);
+  int engSeq = S.engSeq;
+  streamBegin(&engSeq);
+  WSEG(28);
+  int emitted = 0, emittedQ = 0, stageBase = -1, stageCnt = 0, fail = 0;
+  unsigned long long stageV = 0;
+  for (int base = 0; base < V && !fail; base += 64) {
+    int nb = V - base < 64 ? V - base : 64;
+    FOR_LANES(x, 64) if (x < nb) { WideEnt en = w.merged[base + x]; FL.tmpX[x] = ((uint64_t)(uint32_t)en.qk << 32) | (uint32_t)en.job; }
+    LANE0_PUBLISHED();
+    bool over = false;
+    for (int x = 0; x < nb; x++) {
+      for (;;) {   // the ring is the engine's pace
+        int a = streamAcked(&fail);
+        if (fail || (emitted - a < RING_N - 8 && emitted - streamBound() < RING_N - 8)) break;
+        STREAM_IDLE();
+      }
+      if (fail) break;
+      uint64_t v = UNI64(FL.tmpX[x]);
+      int job = (int)(uint32_t)v, qk = (int)(uint32_t)(v >> 32);
+      int ev = (qk >> 30) & 1;
+      if (!ev && emittedQ >= allowed) { over = true; break; }   // no global token left for another new job (constraints.go:129-141)
+      if (FLANE == 0) { RJOB(emitted) = job; RQ(emitted) = ev ? RQ_EV : 0; }
+      LANE0_PUBLISHED();
+      emitted++; if (!ev) emittedQ++;
+      if ((emitted & 3) == 0) {
+        if (stageBase >= 0) streamStageCommit(d, k, stageBase, stageCnt, stageV);
+        stageBase = emitted - 4; stageCnt = 4;
+        stageV = streamStageIssue(k, stageBase, 4);
+      }
+    }
+    if (over) break;
+  }
+  if (!fail) {
+    if (stageBase >= 0) streamStageCommit(d, k, stageBase, stageCnt, stageV);
+    int done = stageBase >= 0 ? stageBase + stageCnt : 0;
+    if (emitted > done) { stageV = streamStageIssue(k, done, emitted - done); streamStageCommit(d, k, done, emitted - done, stageV); }
+  }
+  streamEnd(engSeq);
+  int E = streamAcked(&fail);
+  S.engSeq = engSeq;
+  WSEG(29);
+  engineStop(d, S);
+  WSEG(30);
+  if (UNI32(FL.eng.cancel)) c.cancelSeen = 1;
+  c.l1Dirty = 1;
+  fastFence(c);
+  if (fail == 2) { rs.fastActive = 0; fastDrop(d); }   // placed, but the L0 list overflowed: the full plane scan takes over (counted in round_stats)
+  rs.statScanSteps += S.statScanSteps;
+  if (S.statL0Max > rs.statL0Max) rs.statL0Max = S.statL0Max;
+  // ---- commit: per queue on all workgroups, then the scheduling context's scalars here
+  int EQ = 0, EEv = 0;
+  if (E > 0) {
+    w.par->executed = E;
+    FAST_GLOBAL_FENCE();
+    wT_ = CLK();
+    wgWide(d, W_COMMIT, Q);
+    WSEG(31);
+    EQ = (int)UNI64(w.tot[2 * MAXR]); EEv = (int)UNI64(w.tot[2 * MAXR + 1]);
+    for (int x = 0; x < R; x++) {
+      int64_t sq = (int64_t)UNI64(w.tot[x]), se = (int64_t)UNI64(w.tot[MAXR + x]);
+      rs.allocated[x] += sq + se; rs.scheduled[x] += sq; rs.evicted[x] -= se;
+    }
+    rs.numScheduledJobs += EQ; rs.numScheduledGangs += EQ; rs.numNodeQueries += EQ; rs.numEvictedJobs -= EEv;
+    if (!rs.globalRateInf && 1 <= rs.globalBurst) rs.globalTokens -= (double)EQ;
+    rs.loopIterations += E; rs.statFastIters += E;
+    rs.statStreamRuns++; rs.statStreamJobs += E; rs.statStreamEmitted += emitted; rs.statStreamPrepared += (int)total;
+    // the touched queues' next heads, from the state the reference has at this point: updatePQItem through the generic iterator
+    for (int q0 = 0; q0 < Q; q0 += 64) {
+      FOR_LANES(x, 64) FL.tmpQ[x] = q0 + x < Q ? w.cnt[2 * (q0 + x)] + w.cnt[2 * (q0 + x) + 1] : 0;
+      LANE0_PUBLISHED();
+      for (int x = 0; x < 64 && q0 + x < Q; x++) {
+        int n = UNI32(FL.tmpQ[x]);
+        if (n > 0) updateAndPush(d, c, q0 + x, pc);
+      }
+    }
+    FOR_LANES(x, 64) FL.tmpQ[x] = 0;
+    WSEG(32);
+  }
+  return E;
+}

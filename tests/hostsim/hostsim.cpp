@@ -29,6 +29,7 @@ struct HsScope { int k; std::chrono::steady_clock::time_point t0; HsScope(int k_
 DEV void atomicAddI64(int64_t* p, int64_t v) { *p += v; }
 DEV void atomicAddI32(int32_t* p, int32_t v) { *p += v; }
 DEV void atomicOrI32(int32_t* p, int32_t v) { *p |= v; }
+DEV void atomicMinU32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
 DEV int atomicFetchAddI32(int32_t* p, int32_t v) { int o = *p; *p += v; return o; }
 DEV int wgFairSelect(Dev& d, const FairArgs& a) {
   HsScope prof(39);

@@ -8,6 +8,7 @@
     python tests/soak.py optimiser 2000     # rounds with the experimental fairness optimiser on (asched_set_optimiser), incl. gangs only it can place
     python tests/soak.py market 2000        # market-driven rounds (asched_set_market): tied and distinct bids, gangs, away types, rate limits
     python tests/soak.py away 1500          # crowded rounds with a third of the running jobs cross-pool away jobs and "<queue>-away" contexts (tests/test_z_cross_pool_away.py)
+    python tests/soak.py wide 500           # more than 64 queues: wide runs (round_wide.h) — 65 ... 400 queues, evicted jobs returning, gangs, bursts, lookback limits
     python tests/soak.py features 400       # tests/test_z_feature_mix.py rounds (affinity, conditional away, extra column, limits ...)
     python tests/soak.py ops 3000           # tests/test_z_nodedb_op_sequences.py NodeDb-level operation sequences
     python tests/soak.py submitcheck 400    # batched SubmitChecker vs the literal sequential restatement (and 3-entry cache)
@@ -110,6 +111,20 @@ def main():
                 res = []
                 for lib in (orc, hs):
                     s = W.load(lib, wl); W.prepare(s, wl); res.append(s.schedule_round()); s.close()
+                scenario.assert_same_round(res[0], res[1])
+            elif kind == "wide":   # more than 64 queues (round_wide.h): medium rounds, 65 ... 400 queues, evicted jobs returning, gangs, bursts, lookback limits
+                rng = np.random.default_rng(seed)
+                nn, nj, nq = int(rng.integers(60, 1200)), int(rng.integers(1500, 16000)), int(rng.choice([65, 70, 100, 130, 200, 257, 400]))
+                wl = W.config3(seed=seed, n_nodes=nn, n_jobs=nj, n_queues=nq, gangs=int(rng.choice([0, 0, 0, 5, 40])), occupied=float(rng.choice([0.2, 0.5, 0.8, 0.93])))
+                wl.global_burst = int(rng.choice([nj, nj // 3, 500])); wl.queue_burst = int(rng.choice([nj, max(10, 4 * nj // nq), 16])); wl.rate_inf = bool(rng.random() < 0.2)
+                if rng.random() < 0.3:
+                    wl.config.max_queue_lookback = int(rng.choice([20, 200, 3000]))
+                res = []
+                for lib in (orc, hs):
+                    s = W.load(lib, wl); W.prepare(s, wl); res.append(s.schedule_round())
+                    if lib is hs and os.environ.get("SOAK_STATS"):
+                        st = s.round_stats(); print(seed, nq, {k: st[k] for k in ("fast_iterations", "generic_iterations", "stream_runs", "stream_jobs")}, len(res[-1].scheduled), len(res[-1].preempted))
+                    s.close()
                 scenario.assert_same_round(res[0], res[1])
             elif kind == "features":
                 import test_z_feature_mix as T

@@ -7,6 +7,7 @@ import armada_amd
 from armada_amd import workloads as W
 kw = dict(n_nodes=20_000, n_jobs=200_000, n_queues=32, occupied=0.95)
 if len(sys.argv) > 1 and sys.argv[1] == "gangs": kw = dict(n_nodes=20_000, n_jobs=200_000, n_queues=32, gangs=2_000)
+if len(sys.argv) > 1 and sys.argv[1].startswith("q") and sys.argv[1][1:].isdigit(): kw = dict(n_nodes=20_000, n_jobs=200_000, n_queues=int(sys.argv[1][1:]))   # bench.py's "256 queues" sub-record shape (q256), or any queue count
 full = len(sys.argv) > 1 and sys.argv[1] in ("full", "gangsfull", "headline")
 if full: kw = dict(n_nodes=100_000, n_jobs=1_000_000, n_queues=64, occupied=0.95)
 if len(sys.argv) > 1 and sys.argv[1] == "gangsfull": kw = dict(n_nodes=100_000, n_jobs=1_000_000, n_queues=64, gangs=10_000)   # BASELINE configs[3]
