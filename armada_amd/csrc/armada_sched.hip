@@ -2197,6 +2197,8 @@ static int plat_run_control(Dev& dev, int cmd) {
   // the wide queries of the generic path (plane scan, fair-share evaluation) are one node per thread: from ~50k nodes on half of the CUs pay off (measured at 100k
   // nodes x 1M jobs 95% occupied: 29.5 -> 23.0 s per round with 127 helpers, 24.6 s with 255; flat between 15 and 63 at 20k nodes)
   if (isRound && !getenv("ASCHED_HELPERS") && dev.cfg.N >= 50000 && c->cus >= 128) H = c->cus / 2 - 1;
+  // more than QCAPF queues (round_wide.h): the merge of a wide run is a bulk rank over all queues' entries — work for every workgroup the launch can bring
+  if (isRound && !getenv("ASCHED_HELPERS") && dev.f.iterOk == 2 && c->cus >= 128) H = c->cus / 2 - 1;
   dev.progress = ((cmd == CMD_ROUND || cmd == CMD_PASS1 || cmd == CMD_PASS2) && c->progress) ? c->progress : nullptr;
   dev.cancel = c->cancelDev;
   if (!hipOk(hipMemsetAsync(c->helpBox, 0, sizeof(HelpBox), c->stream), "help box reset")) return -1;

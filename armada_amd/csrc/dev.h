@@ -173,10 +173,12 @@ struct LitIt { int64_t lb[MAXK]; uint64_t bound; int32_t head; int32_t type; };
 struct WideSeg { int32_t evStart, evCnt, qBase, qLen, flags, total, qWant, pad; };   // flags: 1 stream, 2 barrier (a head the wide run cannot serve: its key stops the merge), 4 open (the queue goes on behind its last entry under a key not known here), 8 element 0 of the queued part is the peeked head
 struct WideKey { uint64_t a, x, y; };               // running maximum of the packed queue-order keys up to an entry (an entry is never served before its predecessor)
 struct WideEnt { int32_t job, qk; };                // qk = queue | 1 << 30 for an evicted job returning to its node
-struct WideParams { int32_t evOk, queuedOk, skipUnf, preferLarge, cap, numEvictedList, replayPending, executed; uint32_t maxLookback; int32_t noNew, pad[2]; };
+struct WideParams { int32_t evOk, queuedOk, skipUnf, preferLarge, cap, numEvictedList, replayPending, executed; uint32_t maxLookback; int32_t noNew, withQueued, pad; };
 struct WideDev {
   WideSeg* seg;        // [Q]
   WideKey* key;        // [Q][WIDE_L]
+  WideKey* cmax;       // [Q][WIDE_L / 8] maximum of each chunk of a queue's keys (the running maximum is stitched across the chunks)
+  int64_t* part;       // [Q * WIDE_L / 8][MAXR + 2] chunk sums -> carries of the queued part's requests, first barrier of the chunk
   int32_t* rank;       // [Q][WIDE_L] position of every entry in the merged order
   WideEnt* merged;     // [Q * WIDE_L + Q]
   int32_t* cnt;        // [2Q] entries executed per queue: evicted, queued

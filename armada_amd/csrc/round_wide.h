@@ -32,7 +32,10 @@
 // rounds with the oracle for 65 ... 1 024 queues (CPU build and -m gpu).
 #pragma once
 
-enum { W_SEG = 0, W_EVSUM, W_KEYS, W_RANK, W_COMMIT };
+enum { W_SEG = 0, W_EVSUM, W_QSUM, W_STITCH, W_PACK, W_FIX, W_RANK, W_SCATTER, W_COMMIT_E, W_COMMIT_Q };
+#define W_RB 8                          // queues one item of the rank pass merges against
+#define WQ_CHUNK 8                      // entries one item of the chunked passes covers (streams here are tens of entries long, not thousands: round_run.h uses 64)
+#define WQ_CPQ (WIDE_L / WQ_CHUNK)
 
 DEV bool wideKeyLess(const WideKey& a, const WideKey& b) { return a.a != b.a ? a.a < b.a : a.x != b.x ? a.x < b.x : a.y < b.y; }
 DEV bool wideKeyEq(const WideKey& a, const WideKey& b) { return a.a == b.a && a.x == b.x && a.y == b.y; }
@@ -102,7 +105,6 @@ DEV_COLD void wideBulkAny(Dev& d, int kind, int i) {
         else { s.flags = 2 | 4; s.total = 1; }
       }
       d.qsIn[q] = in;
-      if (in.len == 0) { d.qsLen[2 * q] = 0; d.qsLen[2 * q + 1] = 0; }
       w.seg[q] = s;
     } break;
     case W_EVSUM: {   // eviction-list position i: the queued part of its queue starts from the allocation the queue has once these evicted jobs are back
@@ -116,64 +118,146 @@ DEV_COLD void wideBulkAny(Dev& d, int kind, int i) {
       const int64_t* req = JREQ(d, job);
       for (int r = 0; r < c.R; r++) if (req[r]) atomicAddI64(&d.qsIn[q].a0[r], req[r]);
     } break;
-    case W_KEYS: {    // queue i: the running maximum of its entries' packed keys, its final length, whether it goes on behind its last entry
+    // ---- the queued part's costs: B_QSSUM / B_QSSTITCH / B_QSKEYS of round_run.h with chunks of WQ_CHUNK entries (a chunk is one thread's serial walk: dependent loads per job)
+    case W_QSUM: {    // item i = (queue, chunk): sums of the requests, the first element the stream cannot contain (B_QSSUM's barrier rules)
+      int q = i / WQ_CPQ, ch = i % WQ_CPQ;
+      const QsIn& in = d.qsIn[q];
+      int e0 = ch * WQ_CHUNK, e1 = e0 + WQ_CHUNK < in.len ? e0 + WQ_CHUNK : in.len;
+      if (e0 >= in.len) break;
+      int64_t* part = w.part + (size_t)i * (MAXR + 2);
+      int64_t sum[MAXR]; for (int r = 0; r < MAXR; r++) sum[r] = 0;
+      int barrier = INT32_MAX;
+      const bool headPeeked = (w.seg[q].flags & 8) != 0;
+      for (int e = e0; e < e1; e++) {
+        int job = d.queuedJobs[in.base + e];
+        const int64_t* req = JREQ(d, job);
+        bool stop = d.jGang[job] >= 0 || ((e > 0 || !headPeeked) && in.skipUnf && d.unfeasible[d.jShape[job]]);   // (element 0 is exempt only where it is the peeked head: Peek's skip ran for it)
+        for (int r = 0; r < c.R; r++) if (c.disallowed[r] && req[r] > 0) stop = true;
+        if (stop) { barrier = e; break; }
+        for (int r = 0; r < c.R; r++) sum[r] += req[r];
+      }
+      for (int r = 0; r < MAXR; r++) part[r] = sum[r];
+      part[MAXR] = barrier;
+    } break;
+    case W_STITCH: {  // queue i: chunk sums -> carries, the stream's final length, whether the queue goes on behind it
       int q = i;
       WideSeg s = w.seg[q];
       if (!(s.flags & 3)) break;
-      double budget = d.pqBudget[q];
-      WideKey* out = w.key + (size_t)q * WIDE_L;
-      if (s.flags & 2) {   // a head the run cannot serve: its key as the generic Less sees it
+      if (s.flags & 1) {
+        const QsIn& in = d.qsIn[q];
+        int len = in.len; bool cut = false;
+        int64_t run[MAXR]; for (int r = 0; r < MAXR; r++) run[r] = 0;
+        for (int ch = 0; ch < WQ_CPQ && ch * WQ_CHUNK < in.len; ch++) {
+          int64_t* part = w.part + ((size_t)q * WQ_CPQ + ch) * (MAXR + 2);
+          int barrier = (int)part[MAXR];
+          for (int r = 0; r < MAXR; r++) { int64_t v = part[r]; part[r] = run[r]; run[r] += v; }
+          if (barrier != INT32_MAX) { len = barrier; cut = true; break; }
+        }
+        if (s.qWant > 0) {
+          if (cut) s.flags |= 4;                                                        // a gang member / unfeasible key / disallowed request: the generic iterator's
+          else if (in.base + in.len != d.queuedOff[q + 1]) s.flags |= 4;               // the queue's list goes on behind the prepared entries
+        }
+        s.qLen = s.qWant > 0 ? len : 0; s.total = s.evCnt + s.qLen;
+        if (s.total == 0) { s.flags = 2 | 4; }   // nothing of this queue can be laid out (no token, cordoned, a barrier at its head): its head stops the merge like any other the run cannot serve
+      }
+      if (s.flags & 2) {   // a head the run cannot serve: its key as the generic Less sees it — ONE entry of the merge
         EvKey e; e.proposed = d.pqProposed[q]; e.current = d.pqCurrent[q]; e.size = d.pqSize[q]; e.pcPrio = d.pqPcPrio[q]; e.job = -1;
-        out[0] = widePack(P.preferLarge, e, budget);
-        break;
-      }
-      int qLen = 0;
-      if (s.qWant > 0) {
-        qLen = d.qsLen[2 * q];
-        if (qLen < s.qWant) s.flags |= 4;                 // cut at a gang member / unfeasible key / disallowed request (B_QSSUM's barrier)
-        else if (!d.qsLen[2 * q + 1]) s.flags |= 4;       // the queue's list goes on behind the prepared entries
-      }
-      s.qLen = qLen; s.total = s.evCnt + qLen;
-      if (s.total == 0) {   // nothing of this queue can be laid out (no token, cordoned, a barrier at its head): its head stops the merge like any other head the run cannot serve
-        EvKey e; e.proposed = d.pqProposed[q]; e.current = d.pqCurrent[q]; e.size = d.pqSize[q]; e.pcPrio = d.pqPcPrio[q]; e.job = -1;
-        out[0] = widePack(P.preferLarge, e, budget);
-        s.flags = 2 | 4; s.total = 1;
-        w.seg[q] = s;
-        break;
-      }
-      WideKey eff; eff.a = 0; eff.x = 0; eff.y = 0;
-      for (int e = 0; e < s.total; e++) {
-        const EvKey& k = e < s.evCnt ? d.evKey[s.evStart + e] : d.qsKey[(size_t)q * QS_CMAX + (e - s.evCnt)];
-        WideKey pk = widePack(P.preferLarge, k, budget);
-        if (wideKeyLess(eff, pk)) eff = pk;
-        out[e] = eff;
+        w.key[(size_t)q * WIDE_L] = widePack(P.preferLarge, e, d.pqBudget[q]);
+        w.rank[(size_t)q * WIDE_L] = 0;
+        s.total = 1;
       }
       w.seg[q] = s;
-      if (s.total > 0) atomicAddI32((int32_t*)&w.stop[1], s.total);
+      atomicAddI32((int32_t*)&w.stop[1], s.total);
     } break;
-    case W_RANK: {    // entry i = (queue, index): its position in the merged order
-      int q = i / WIDE_L, e = i % WIDE_L;
+    case W_PACK: {    // item i = (queue, chunk of the whole stream): packed keys of its entries, running maximum within the chunk, the chunk's maximum
+      int q = i / WQ_CPQ, ch = i % WQ_CPQ;
+      const WideSeg s = w.seg[q];
+      if (!(s.flags & 1)) break;
+      int e0 = ch * WQ_CHUNK, e1 = e0 + WQ_CHUNK < s.total ? e0 + WQ_CHUNK : s.total;
+      if (e0 >= e1) break;
+      const QsIn& in = d.qsIn[q];
+      const double budget = d.pqBudget[q], wgt = in.weight;
+      WideKey* out = w.key + (size_t)q * WIDE_L;
+      WideKey eff; eff.a = 0; eff.x = 0; eff.y = 0;
+      int64_t a[MAXR], with[MAXR]; bool haveA = false;
+      for (int e = e0; e < e1; e++) {
+        WideKey pk;
+        if (e < s.evCnt) pk = widePack(P.preferLarge, d.evKey[s.evStart + e], budget);   // B_EVKEYS' costs of the whole eviction list
+        else {
+          int e2 = e - s.evCnt;   // position in the queued part: allocation before it = a0 + carry of its chunk + the requests of the chunk's entries before it
+          if (!haveA || e2 % WQ_CHUNK == 0) {
+            const int64_t* carry = w.part + ((size_t)q * WQ_CPQ + e2 / WQ_CHUNK) * (MAXR + 2);
+            for (int r = 0; r < c.R; r++) a[r] = in.a0[r] + carry[r];
+            for (int m = (e2 / WQ_CHUNK) * WQ_CHUNK; m < e2; m++) { const int64_t* rq = JREQ(d, d.queuedJobs[in.base + m]); for (int r = 0; r < c.R; r++) a[r] += rq[r]; }
+            haveA = true;
+          }
+          int job = d.queuedJobs[in.base + e2];
+          const int64_t* req = JREQ(d, job);
+          for (int r = 0; r < c.R; r++) with[r] = a[r] + req[r];
+          EvKey k;   // updatePQItem (queue_scheduler.go:636-686): the same float64 operations in the same order as B_QSKEYS
+          k.proposed = drf(d, with) / wgt; k.current = drf(d, a) / wgt; k.size = drf(d, req) * wgt;
+          k.pcPrio = c.pcPriority[d.jPc[job]]; k.job = job;
+          pk = widePack(P.preferLarge, k, budget);
+          for (int r = 0; r < c.R; r++) a[r] = with[r];
+        }
+        if (wideKeyLess(eff, pk)) eff = pk;
+        out[e] = eff;
+        w.rank[(size_t)q * WIDE_L + e] = e;   // (the entries of its own queue that order before it; W_RANK adds the other queues')
+      }
+      w.cmax[(size_t)q * WQ_CPQ + ch] = eff;
+    } break;
+    case W_FIX: {     // queue i: running maximum across the chunks (almost always a no-op: DRF costs grow along a queue)
+      int q = i;
+      const WideSeg s = w.seg[q];
+      if (!(s.flags & 1)) break;
+      WideKey* out = w.key + (size_t)q * WIDE_L;
+      WideKey run; run.a = 0; run.x = 0; run.y = 0;
+      int nch = (s.total + WQ_CHUNK - 1) / WQ_CHUNK;
+      for (int ch = 0; ch < nch; ch++) {
+        int e0 = ch * WQ_CHUNK, e1 = e0 + WQ_CHUNK < s.total ? e0 + WQ_CHUNK : s.total;
+        if (ch > 0 && wideKeyLess(out[e0], run)) { for (int e = e0; e < e1; e++) { if (wideKeyLess(out[e], run)) out[e] = run; else break; } }
+        const WideKey m = w.cmax[(size_t)q * WQ_CPQ + ch];
+        if (wideKeyLess(run, m)) run = m;
+      }
+    } break;
+    case W_RANK: {    // item i = (queue q, block of W_RB other queues): for every entry of q the number of the block's entries that order before it.  Both sequences are
+      // sorted (running-maximum keys), so one forward pointer per other queue does it: entries(q) x W_RB + entries(block) steps over sequential memory — the merge
+      // path of the k-way merge, not a binary search per pair (round 4's first version: 57 % of a 256-queue round).
+      const int q = i % c.Q, b0 = (i / c.Q) * W_RB;
+      const WideSeg s = w.seg[q];
+      if (s.total == 0) break;
+      const int myName = d.qNameRank[q];
+      int n2[W_RB], ptr[W_RB]; bool nameBefore[W_RB]; WideKey cur[W_RB];
+      int any = 0;
+#pragma unroll
+      for (int j = 0; j < W_RB; j++) {
+        int q2 = b0 + j;
+        bool valid = q2 < c.Q && q2 != q;
+        n2[j] = valid ? w.seg[valid ? q2 : 0].total : 0; ptr[j] = 0;
+        nameBefore[j] = valid && d.qNameRank[valid ? q2 : 0] < myName;   // equal keys: Less ends with the queue name (queue_scheduler.go:796-797)
+        if (n2[j] > 0) { cur[j] = w.key[(size_t)q2 * WIDE_L]; any = 1; } else { cur[j].a = 0; cur[j].x = 0; cur[j].y = 0; }
+      }
+      if (!any) break;
+      const WideKey* mine = w.key + (size_t)q * WIDE_L;
+      for (int e = 0; e < s.total; e++) {
+        const WideKey key = mine[e];
+        int sum = 0;
+#pragma unroll
+        for (int j = 0; j < W_RB; j++) {
+          while (ptr[j] < n2[j] && (wideKeyLess(cur[j], key) || (nameBefore[j] && wideKeyEq(cur[j], key)))) {
+            ptr[j]++;
+            if (ptr[j] < n2[j]) cur[j] = w.key[(size_t)(b0 + j) * WIDE_L + ptr[j]];
+          }
+          sum += ptr[j];
+        }
+        if (sum) atomicAddI32(&w.rank[(size_t)q * WIDE_L + e], sum);
+      }
+    } break;
+    case W_SCATTER: { // entry i = (queue, index): into its position of the merged order; where the order stops being valid
+      int q = i % c.Q, e = i / c.Q;   // (neighbouring threads take the same index of DIFFERENT queues: the entries that exist — e < total — are spread over all threads)
       const WideSeg s = w.seg[q];
       if (e >= s.total) break;
-      const WideKey key = w.key[(size_t)q * WIDE_L + e];
-      const int myName = d.qNameRank[q];
-      int rank = e;
-      for (int q2 = 0; q2 < c.Q; q2++) {
-        if (q2 == q) continue;
-        int n2 = w.seg[q2].total;
-        if (n2 == 0) continue;
-        const WideKey* k2 = w.key + (size_t)q2 * WIDE_L;
-        const bool nameBefore = d.qNameRank[q2] < myName;   // equal keys: Less ends with the queue name (queue_scheduler.go:796-797)
-        int lo = 0, hi = n2;
-        while (lo < hi) {
-          int mid = (lo + hi) >> 1;
-          const WideKey m = k2[mid];
-          bool before = wideKeyLess(m, key) || (nameBefore && wideKeyEq(m, key));
-          if (before) lo = mid + 1; else hi = mid;
-        }
-        rank += lo;
-      }
-      w.rank[(size_t)q * WIDE_L + e] = rank;
+      const int rank = w.rank[(size_t)q * WIDE_L + e];
       if (s.flags & 2) { atomicMinU32(&w.stop[0], (uint32_t)rank); break; }
       WideEnt en;
       if (e < s.evCnt) { en.job = d.evList[s.evStart + e]; en.qk = q | (1 << 30); }
@@ -181,67 +265,59 @@ DEV_COLD void wideBulkAny(Dev& d, int kind, int i) {
       w.merged[rank] = en;
       if (e == s.total - 1 && (s.flags & 4)) atomicMinU32(&w.stop[0], (uint32_t)(rank + 1));
     } break;
-    case W_COMMIT: {  // queue i: its entries among the first P.executed of the merged order have been executed — accounting, the evicted jobs' return, cursors, tokens
-      int q = i;
-      const WideSeg s = w.seg[q];
-      if (!(s.flags & 1) || s.total == 0) break;
-      const int E = P.executed;
-      int cEv = 0, cQ = 0;
-      int64_t sumEv[MAXR], sumQ[MAXR];
-      for (int r = 0; r < MAXR; r++) sumEv[r] = sumQ[r] = 0;
-      for (int e = 0; e < s.total; e++) {
-        if (w.rank[(size_t)q * WIDE_L + e] >= E) break;   // (positions grow with e)
-        if (e < s.evCnt) {
-          // an evicted job is back on its node: the evicted branch of fastIter's commit == applyEvictedRange (node.go:416-442 arithmetic on the levels above the
-          // evicted priority; level 0 is unchanged: +req un-evicts, -req binds), sctx.AddJobSchedulingContext of a rescheduled job (context/queue.go:231-265)
-          int p = s.evStart + e, job = d.evList[p];
-          const JobRec& jr = d.jrec[job];
-          int n = jr.node0, pcx = jr.pc; int32_t prio = jr.runPrio;
-          int32_t cutoff = jr.preemptible ? prio : NONPREEMPTIBLE_CUTOFF;
-          for (int x = 0; x < c.R; x++) {
-            int64_t v = jr.req[x];
-            if (!v) continue;
-            sumEv[x] += v;
-            size_t ix = ((size_t)q * c.npc + pcx) * c.R + x;
-            d.qAllocByPc[ix] += v; d.qEvictedByPc[ix] -= v;
-            for (int l = 1; l < jr.nlRun; l++) atomicAddI64(&d.alloc[((size_t)l * c.R + x) * c.Npad + n], -v);
-          }
-          if (jr.keyDelta) for (int l = 1; l < jr.nlRun; l++) atomicAddI64((int64_t*)&d.keys[(size_t)l * c.Npad + n], -(int64_t)jr.keyDelta);
-          d.jcReason[job] = 0; d.jcHasPctx[job] = 1; d.pcNode[job] = n; d.pcSap[job] = prio;
-          d.jobNode[job] = n; d.jobCutoff[job] = cutoff; d.jobEvictedOnNode[job] = 0; d.schedAtPrio[job] = prio; d.inSchedAndEvicted[job] = 0;
-          d.pcPap[job] = prio; d.pcMethod[job] = ASCHED_METHOD_RESCHEDULED; d.jobFlags[job] = F_RESCHEDULED; d.inPreempted[job] = 0;
-          if (!P.replayPending) { d.evTabAlive[d.evIdxByPos[p]] = 0; d.evIndexOfJob[job] = -1; }
-          cEv++;
-        } else {
-          // a new job: the bind wave has issued BindJobToNode and the job's result fields (round_fast.h bindJob); the queue side of sctx.AddGangSchedulingContext here
-          int job = d.queuedJobs[s.qBase + (e - s.evCnt)];
-          const int64_t* req = JREQ(d, job);
-          int pcx = d.jPc[job];
-          for (int x = 0; x < c.R; x++) {
-            int64_t v = req[x];
-            if (!v) continue;
-            sumQ[x] += v;
-            size_t ix = ((size_t)q * c.npc + pcx) * c.R + x;
-            d.qAllocByPc[ix] += v; d.qSchedByPc[ix] += v;
-          }
-          cQ++;
+    case W_COMMIT_E: {   // merged position i < P.executed has been executed: the job's side and the per-(queue, class) sums
+      if (i >= P.executed) break;
+      const WideEnt en = w.merged[i];
+      const int q = en.qk & 0xffffff, job = en.job;
+      if ((en.qk >> 30) & 1) {
+        // an evicted job is back on its node: the evicted branch of fastIter's commit == applyEvictedRange (node.go:416-442 arithmetic on the levels above the
+        // evicted priority; level 0 is unchanged: +req un-evicts, -req binds), sctx.AddJobSchedulingContext of a rescheduled job (context/queue.go:231-265)
+        const JobRec& jr = d.jrec[job];
+        int n = jr.node0, pcx = jr.pc; int32_t prio = jr.runPrio;
+        int32_t cutoff = jr.preemptible ? prio : NONPREEMPTIBLE_CUTOFF;
+        for (int x = 0; x < c.R; x++) {
+          int64_t v = jr.req[x];
+          if (!v) continue;
+          size_t ix = ((size_t)q * c.npc + pcx) * c.R + x;
+          atomicAddI64(&d.qAllocByPc[ix], v); atomicAddI64(&d.qEvictedByPc[ix], -v);
+          atomicAddI64(&QV(d.qAlloc, q)[x], v); atomicAddI64(&w.tot[MAXR + x], v);
+          for (int l = 1; l < jr.nlRun; l++) atomicAddI64(&d.alloc[((size_t)l * c.R + x) * c.Npad + n], -v);
         }
+        if (jr.keyDelta) for (int l = 1; l < jr.nlRun; l++) atomicAddI64((int64_t*)&d.keys[(size_t)l * c.Npad + n], -(int64_t)jr.keyDelta);
+        d.jcReason[job] = 0; d.jcHasPctx[job] = 1; d.pcNode[job] = n; d.pcSap[job] = prio;
+        d.jobNode[job] = n; d.jobCutoff[job] = cutoff; d.jobEvictedOnNode[job] = 0; d.schedAtPrio[job] = prio; d.inSchedAndEvicted[job] = 0;
+        d.pcPap[job] = prio; d.pcMethod[job] = ASCHED_METHOD_RESCHEDULED; d.jobFlags[job] = F_RESCHEDULED; d.inPreempted[job] = 0;
+        if (!P.replayPending) { int idx = d.evIndexOfJob[job]; if (idx >= 0) d.evTabAlive[idx] = 0; d.evIndexOfJob[job] = -1; }
+        atomicAddI32(&w.cnt[2 * q], 1);
+        atomicAddI64(&w.tot[2 * MAXR + 1], 1);
+      } else {
+        // a new job: the bind wave has issued BindJobToNode and the job's result fields (round_fast.h bindJob); the queue side of sctx.AddGangSchedulingContext here
+        const int64_t* req = JREQ(d, job);
+        int pcx = d.jPc[job];
+        for (int x = 0; x < c.R; x++) {
+          int64_t v = req[x];
+          if (!v) continue;
+          size_t ix = ((size_t)q * c.npc + pcx) * c.R + x;
+          atomicAddI64(&d.qAllocByPc[ix], v); atomicAddI64(&d.qSchedByPc[ix], v);
+          atomicAddI64(&QV(d.qAlloc, q)[x], v); atomicAddI64(&w.tot[x], v);
+        }
+        atomicAddI32(&w.cnt[2 * q + 1], 1);
+        atomicAddI64(&w.tot[2 * MAXR], 1);
       }
-      if (cEv + cQ >= s.total && (s.flags & 4)) {   // the queue used up what it had been given and goes on: IT ended the run — twice as many entries next time.  (Queues advance
+    } break;
+    case W_COMMIT_Q: {   // queue i after W_COMMIT_E: cursors and tokens as Clear + the Peeks of the entries served leave them, the next cap, and — where it is the plain case — the next head
+      int q = i;
+      WideSeg s = w.seg[q];
+      s.pad = 0;
+      if (!(s.flags & 1) || s.total == 0) { w.seg[q] = s; break; }
+      const int cEv = w.cnt[2 * q], cQ = w.cnt[2 * q + 1];
+      if (cEv + cQ >= s.total && (s.flags & 4)) {   // the queue used up what it had been given and goes on: IT ended the run — four times as many entries next time.  (Queues advance
         int have = w.cap[q] > 0 ? w.cap[q] : P.cap;   //  at very different rates under DRF; the caps only grow: the rank pass is cheap next to a run cut short)
-        w.cap[q] = 2 * have > WIDE_L ? WIDE_L : 2 * have;
+        w.cap[q] = 4 * have > WIDE_L ? WIDE_L : 4 * have;
       }
-      if (cEv + cQ == 0) break;
-      for (int x = 0; x < c.R; x++) {
-        QV(d.qAlloc, q)[x] += sumEv[x] + sumQ[x];
-        if (sumQ[x]) atomicAddI64(&w.tot[x], sumQ[x]);
-        if (sumEv[x]) atomicAddI64(&w.tot[MAXR + x], sumEv[x]);
-      }
-      if (cQ) atomicAddI64(&w.tot[2 * MAXR], cQ);
-      if (cEv) atomicAddI64(&w.tot[2 * MAXR + 1], cEv);
-      w.cnt[2 * q] = cEv; w.cnt[2 * q + 1] = cQ;
-      // the iterators as Clear + the Peeks of the entries served leave them (queue_scheduler.go:595-606, 376-444; jobiteration.go:179-228): the next Peek yields
-      // the first entry that was not served.  The head had been peeked (and, a queued one, counted) before the run.
+      if (cEv + cQ == 0) { w.seg[q] = s; break; }
+      // the iterators (queue_scheduler.go:595-606, 376-444; jobiteration.go:179-228): the next Peek yields the first entry that was not served.  The head had been
+      // peeked (and, a queued one, counted) before the run.
       if (cEv) d.itEi[q] = s.evStart + cEv;
       if (cQ) {
         d.itQi[q] = s.qBase + cQ;
@@ -249,6 +325,37 @@ DEV_COLD void wideBulkAny(Dev& d, int kind, int i) {
         if (!d.qRateInf[q] && 1 <= d.qBurst[q]) d.qTokens[q] -= (double)cQ;   // rate.Limiter.ReserveN per scheduled job (gang_scheduler.go:118-123)
       }
       d.itNext[q] = -1; d.pqInHeap[q] = 0;
+      s.pad = 2;   // the control wave produces the next head through the generic updateAndPush ...
+      // ... unless it is the plain case, done right here: Clear (:595-606) + Peek (:376-432) + updatePQItem (:636-686) for a next job that is a single job with
+      // nothing special about it.  Anything else (the lookback switch, a gang member, a known-unfeasible key: records and counters of the scheduling context) is left
+      // untouched for the generic code.
+      do {
+        if (P.maxLookback != 0 && !d.itGangOnlyEv[q] && (uint32_t)d.itJobsSeen[q] >= P.maxLookback) break;
+        int job = -1; bool fromEv = false;
+        if (d.itStage[q] == 0 && d.itEi[q] < d.evOff[q + 1]) { job = d.evList[d.itEi[q]]; fromEv = true; }
+        else if (!(d.itJobOnlyEv[q] || !P.withQueued) && d.itQi[q] < d.queuedOff[q + 1]) job = d.queuedJobs[d.itQi[q]];
+        d.pqGctx[q] = -1; d.pqProposed[q] = d.pqCurrent[q] = d.pqSize[q] = 0;
+        if (job < 0) { if (d.itStage[q] == 0) d.itStage[q] = 1; s.pad = 1; break; }   // the queue has nothing more to yield: it stays out of the heap
+        if (d.jGang[job] >= 0) break;
+        if (!fromEv && P.skipUnf && d.unfeasible[d.jShape[job]]) break;   // (an evicted job has a node assigned: its key is not valid, keyValid)
+        if (fromEv) d.itEi[q]++; else { if (d.itStage[q] == 0) d.itStage[q] = 1; d.itQi[q]++; }
+        if (!fromEv) {   // JobSchedulingContextFromJob (context/job.go:149-158)
+          d.jcEvicted[job] = 0; d.jcAssigned[job] = -1; d.jcHasPctx[job] = 0; d.jcReason[job] = 0; d.jcGangCard[job] = 1; d.jcUniValue[job] = -1; d.jcStagedBy[job] = -1;
+        }
+        if (!d.jcEvicted[job]) d.itJobsSeen[q]++;
+        d.itNext[q] = job; d.pqGctx[q] = job;
+        int64_t al[MAXR], with[MAXR];
+        const int64_t* req = JREQ(d, job);
+        for (int r = 0; r < c.R; r++) { al[r] = QV(d.qAlloc, q)[r] + QV(d.qPenalty, q)[r]; with[r] = al[r] + req[r]; }
+        double wq = d.qWeight[q];
+        d.pqProposed[q] = drf(d, with) / wq; d.pqCurrent[q] = drf(d, al) / wq; d.pqSize[q] = drf(d, req) * wq;
+        int32_t pp = c.pcPriority[d.jPc[job]], sp = pp;
+        if (d.jcHasPctx[job]) sp = d.pcSap[job]; else if (d.jNode0[job] >= 0) sp = d.jRunPrio[job];
+        d.pqPcPrio[q] = pp; d.pqSchedPrio[q] = sp;
+        d.pqInHeap[q] = 1;
+        s.pad = 1;
+      } while (0);
+      w.seg[q] = s;
     } break;
   }
 }
@@ -283,7 +390,7 @@ DEV_COLD int wideRun(Dev& d, Ctl& c, const PassCfg& pc) {
   const int Q = d.cfg.Q, R = d.cfg.R;
   WideDev& w = *d.wide;
   RoundScalars& rs = *d.rs;
-  if (!rs.fastActive || c.compareSchedPrio || c.useReplayAlloc || c.txn.active || k.hasPcLimit || k.anyRoundLimit || k.disableHome || !d.qsKey) return 0;
+  if (!rs.fastActive || c.compareSchedPrio || c.useReplayAlloc || c.txn.active || k.hasPcLimit || k.anyRoundLimit || k.disableHome || !d.qsIn) return 0;
   int allowed = INT32_MAX;
   if (!rs.globalRateInf) allowed = rs.globalTokens >= 2147483000.0 ? INT32_MAX : (rs.globalTokens < 1 ? 0 : (int)rs.globalTokens);
   if (rs.globalBurst < 1 || rs.globalTokens < 1) allowed = 0;
@@ -295,7 +402,7 @@ DEV_COLD int wideRun(Dev& d, Ctl& c, const PassCfg& pc) {
     P.queuedOk = pc.withQueued && !c.onlyEvicted; P.noNew = allowed <= 0;
     P.skipUnf = pc.skipKnown && rs.numUnfeasible > 0;
     P.preferLarge = c.preferLarge; P.cap = 32;   // (a queue's first run; WideDev.cap[q] follows its consumption from then on)
-    P.numEvictedList = rs.numEvictedList; P.replayPending = rs.replayPending; P.executed = 0; P.maxLookback = pc.maxLookback;
+    P.numEvictedList = rs.numEvictedList; P.replayPending = rs.replayPending; P.executed = 0; P.maxLookback = pc.maxLookback; P.withQueued = pc.withQueued;
     *w.par = P;
     w.stop[0] = 0xffffffffu; w.stop[1] = 0;
     FOR_LANES(x, 3 * MAXR) w.tot[x] = 0;
@@ -305,13 +412,14 @@ DEV_COLD int wideRun(Dev& d, Ctl& c, const PassCfg& pc) {
   wgWide(d, W_SEG, Q);
   if (c.fastEvStatic && rs.numEvictedList > 0) wgWide(d, W_EVSUM, rs.numEvictedList);
   WSEG(24);
-  wgBulkWide(d, B_QSSUM, Q * QS_CPQ);
-  wgBulkWide(d, B_QSSTITCH, Q);
-  wgBulkWide(d, B_QSKEYS, Q * QS_CPQ);
+  wgWide(d, W_QSUM, Q * WQ_CPQ);
+  wgWide(d, W_STITCH, Q);
   WSEG(25);
-  wgWide(d, W_KEYS, Q);
+  wgWide(d, W_PACK, Q * WQ_CPQ);
+  wgWide(d, W_FIX, Q);
   WSEG(26);
-  wgWide(d, W_RANK, Q * WIDE_L);
+  wgWide(d, W_RANK, Q * ((Q + W_RB - 1) / W_RB));
+  wgWide(d, W_SCATTER, Q * WIDE_L);
   WSEG(27);
   uint32_t stop = UNI32(w.stop[0]), total = UNI32(w.stop[1]);
   int V = stop < total ? (int)stop : (int)total;
@@ -393,7 +501,8 @@ DEV_COLD int wideRun(Dev& d, Ctl& c, const PassCfg& pc) {
     w.par->executed = E;
     FAST_GLOBAL_FENCE();
     wT_ = CLK();
-    wgWide(d, W_COMMIT, Q);
+    wgWide(d, W_COMMIT_E, E);
+    wgWide(d, W_COMMIT_Q, Q);
     WSEG(31);
     EQ = (int)UNI64(w.tot[2 * MAXR]); EEv = (int)UNI64(w.tot[2 * MAXR + 1]);
     for (int x = 0; x < R; x++) {
@@ -404,14 +513,11 @@ DEV_COLD int wideRun(Dev& d, Ctl& c, const PassCfg& pc) {
     if (!rs.globalRateInf && 1 <= rs.globalBurst) rs.globalTokens -= (double)EQ;
     rs.loopIterations += E; rs.statFastIters += E;
     rs.statStreamRuns++; rs.statStreamJobs += E; rs.statStreamEmitted += emitted; rs.statStreamPrepared += (int)total;
-    // the touched queues' next heads, from the state the reference has at this point: updatePQItem through the generic iterator
+    // the next heads of the queues W_COMMIT_Q left to the generic iterator (a gang member, a known-unfeasible key, the lookback switch)
     for (int q0 = 0; q0 < Q; q0 += 64) {
-      FOR_LANES(x, 64) FL.tmpQ[x] = q0 + x < Q ? w.cnt[2 * (q0 + x)] + w.cnt[2 * (q0 + x) + 1] : 0;
+      FOR_LANES(x, 64) FL.tmpQ[x] = q0 + x < Q ? w.seg[q0 + x].pad : 0;
       LANE0_PUBLISHED();
-      for (int x = 0; x < 64 && q0 + x < Q; x++) {
-        int n = UNI32(FL.tmpQ[x]);
-        if (n > 0) updateAndPush(d, c, q0 + x, pc);
-      }
+      for (int x = 0; x < 64 && q0 + x < Q; x++) if (UNI32(FL.tmpQ[x]) == 2) updateAndPush(d, c, q0 + x, pc);
     }
     FOR_LANES(x, 64) FL.tmpQ[x] = 0;
     WSEG(32);

@@ -178,6 +178,20 @@ def config3(n_nodes=100_000, n_jobs=1_000_000, n_queues=64, seed=SEED, gangs=0, 
     return wl
 
 
+def reference_benchmark(n_nodes: int, n_queues: int, jobs_per_queue: int) -> Workload:
+    """BenchmarkPreemptingQueueScheduler's input (preempting_queue_scheduler_test.go:2561-2700): testfixtures.N32CpuNodes (32 cpu / 256 Gi), N1Cpu4GiJobs of PriorityClass0 in
+    `n_queues` queues of weight 1, TestSchedulingConfig (unlimited rate limiters, protectedFractionOfFairShare 1.0, prefer-large ordering on), every job queued."""
+    pcs = [(0, True)]
+    node_total = np.tile(np.array([256 * Gi, 32000, 1024 * Gi, 0], dtype=np.int64), (n_nodes, 1))
+    n_jobs = n_queues * jobs_per_queue
+    q_req = np.tile(np.array([4 * Gi, 1000, 0, 0], dtype=np.int64), (n_jobs, 1))
+    q_queue = np.repeat(np.arange(n_queues, dtype=np.int32), jobs_per_queue)
+    none = np.zeros(0, np.int32)
+    wl = _assemble("reference_benchmark", _config(pcs, protected=1.0), node_total, np.zeros((0, R), np.int64), none, none, none, none,
+                   q_req, q_queue, np.zeros(n_jobs, np.int32), np.array([0]), np.ones(n_queues), {})
+    return wl
+
+
 def default_indexed(n_nodes=20_000, n_jobs=200_000, n_queues=64, seed=SEED, occupied=0.5, aligned=True) -> Workload:
     """config3's shape on the reference's DEFAULT indexedResources (config/scheduler/config.yaml:121-129: nvidia.com/gpu @1, cpu @100m, memory @100Mi,
     ephemeral-storage @1Gi — four indexed columns, in that order) and current hardware: 64 cpu / 1 TiB / 4 TiB ephemeral / 8 gpu per node.  The order key needs
