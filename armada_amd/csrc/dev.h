@@ -176,10 +176,13 @@ struct WideEnt { int32_t job, qk; };                // qk = queue | 1 << 30 for 
 struct WideParams { int32_t evOk, queuedOk, skipUnf, preferLarge, cap, numEvictedList, replayPending, executed; uint32_t maxLookback; int32_t noNew, withQueued, pad; };
 struct WideDev {
   WideSeg* seg;        // [Q]
-  WideKey* key;        // [Q][WIDE_L]
+  WideKey* key;        // [Q * WIDE_L] COMPACT: queue q's entries at off[2q] .. + off[2q + 1] (the rank pass walks every queue's keys for every entry: 256 arrays 24 KB apart cost a TLB / cache
+                       // line walk per step — measured 2.4x slower than a 3 KB stride; compact, a run's keys are a few hundred KB in one piece)
+  int32_t* off;        // [Q][2] start and number of the queue's entries in the compact arrays
+  int32_t* own;        // [Q * WIDE_L] queue of a compact entry
   WideKey* cmax;       // [Q][WIDE_L / 8] maximum of each chunk of a queue's keys (the running maximum is stitched across the chunks)
   int64_t* part;       // [Q * WIDE_L / 8][MAXR + 2] chunk sums -> carries of the queued part's requests, first barrier of the chunk
-  int32_t* rank;       // [Q][WIDE_L] position of every entry in the merged order
+  int32_t* rank;       // [Q * WIDE_L] position of every (compact) entry in the merged order
   WideEnt* merged;     // [Q * WIDE_L + Q]
   int32_t* cnt;        // [2Q] entries executed per queue: evicted, queued
   int32_t* cap;        // [Q] entries to prepare for the queue in the next run: follows what the queue consumes (queues advance at very different rates under DRF)

@@ -33,9 +33,11 @@
 #pragma once
 
 enum { W_SEG = 0, W_EVSUM, W_QSUM, W_STITCH, W_PACK, W_FIX, W_RANK, W_SCATTER, W_COMMIT_E, W_COMMIT_Q };
-#define W_RB 8                          // queues one item of the rank pass merges against
+#define W_PER 16                        // queues one item of the rank pass walks for its entry: an entry's walk over the other queues is cut into Q / W_PER items (the entries of a run
+                                        // alone fill a third of the lanes once)
 #define WQ_CHUNK 8                      // entries one item of the chunked passes covers (streams here are tens of entries long, not thousands: round_run.h uses 64)
 #define WQ_CPQ (WIDE_L / WQ_CHUNK)
+#define W_RG 8                          // binary searches of the rank pass that run side by side (independent loads in flight together)
 
 DEV bool wideKeyLess(const WideKey& a, const WideKey& b) { return a.a != b.a ? a.a < b.a : a.x != b.x ? a.x < b.x : a.y < b.y; }
 DEV bool wideKeyEq(const WideKey& a, const WideKey& b) { return a.a == b.a && a.x == b.x && a.y == b.y; }
@@ -142,7 +144,7 @@ DEV_COLD void wideBulkAny(Dev& d, int kind, int i) {
     case W_STITCH: {  // queue i: chunk sums -> carries, the stream's final length, whether the queue goes on behind it
       int q = i;
       WideSeg s = w.seg[q];
-      if (!(s.flags & 3)) break;
+      if (!(s.flags & 3)) { w.off[2 * q] = 0; w.off[2 * q + 1] = 0; break; }
       if (s.flags & 1) {
         const QsIn& in = d.qsIn[q];
         int len = in.len; bool cut = false;
@@ -160,24 +162,26 @@ DEV_COLD void wideBulkAny(Dev& d, int kind, int i) {
         s.qLen = s.qWant > 0 ? len : 0; s.total = s.evCnt + s.qLen;
         if (s.total == 0) { s.flags = 2 | 4; }   // nothing of this queue can be laid out (no token, cordoned, a barrier at its head): its head stops the merge like any other the run cannot serve
       }
-      if (s.flags & 2) {   // a head the run cannot serve: its key as the generic Less sees it — ONE entry of the merge
-        EvKey e; e.proposed = d.pqProposed[q]; e.current = d.pqCurrent[q]; e.size = d.pqSize[q]; e.pcPrio = d.pqPcPrio[q]; e.job = -1;
-        w.key[(size_t)q * WIDE_L] = widePack(P.preferLarge, e, d.pqBudget[q]);
-        w.rank[(size_t)q * WIDE_L] = 0;
-        s.total = 1;
-      }
+      if (s.flags & 2) s.total = 1;   // a head the run cannot serve: its key as the generic Less sees it is ONE entry of the merge (W_PACK writes it)
       w.seg[q] = s;
-      atomicAddI32((int32_t*)&w.stop[1], s.total);
+      // where the queue's entries live in the compact arrays: any order will do (positions in the merged order do not depend on it), so a fetch-add hands out the space
+      w.off[2 * q] = s.total > 0 ? atomicFetchAddI32((int32_t*)&w.stop[1], s.total) : 0;
+      w.off[2 * q + 1] = s.total;
     } break;
     case W_PACK: {    // item i = (queue, chunk of the whole stream): packed keys of its entries, running maximum within the chunk, the chunk's maximum
       int q = i / WQ_CPQ, ch = i % WQ_CPQ;
       const WideSeg s = w.seg[q];
+      if ((s.flags & 2) && ch == 0) {
+        EvKey e; e.proposed = d.pqProposed[q]; e.current = d.pqCurrent[q]; e.size = d.pqSize[q]; e.pcPrio = d.pqPcPrio[q]; e.job = -1;
+        w.key[w.off[2 * q]] = widePack(P.preferLarge, e, d.pqBudget[q]); w.own[w.off[2 * q]] = q; w.rank[w.off[2 * q]] = 0;
+      }
       if (!(s.flags & 1)) break;
       int e0 = ch * WQ_CHUNK, e1 = e0 + WQ_CHUNK < s.total ? e0 + WQ_CHUNK : s.total;
       if (e0 >= e1) break;
       const QsIn& in = d.qsIn[q];
       const double budget = d.pqBudget[q], wgt = in.weight;
-      WideKey* out = w.key + (size_t)q * WIDE_L;
+      const int base = w.off[2 * q];
+      WideKey* out = w.key + base;
       WideKey eff; eff.a = 0; eff.x = 0; eff.y = 0;
       int64_t a[MAXR], with[MAXR]; bool haveA = false;
       for (int e = e0; e < e1; e++) {
@@ -202,7 +206,7 @@ DEV_COLD void wideBulkAny(Dev& d, int kind, int i) {
         }
         if (wideKeyLess(eff, pk)) eff = pk;
         out[e] = eff;
-        w.rank[(size_t)q * WIDE_L + e] = e;   // (the entries of its own queue that order before it; W_RANK adds the other queues')
+        w.own[base + e] = q; w.rank[base + e] = e;   // (the entries of its own queue that order before it; W_RANK adds the other queues')
       }
       w.cmax[(size_t)q * WQ_CPQ + ch] = eff;
     } break;
@@ -210,7 +214,7 @@ DEV_COLD void wideBulkAny(Dev& d, int kind, int i) {
       int q = i;
       const WideSeg s = w.seg[q];
       if (!(s.flags & 1)) break;
-      WideKey* out = w.key + (size_t)q * WIDE_L;
+      WideKey* out = w.key + w.off[2 * q];
       WideKey run; run.a = 0; run.x = 0; run.y = 0;
       int nch = (s.total + WQ_CHUNK - 1) / WQ_CHUNK;
       for (int ch = 0; ch < nch; ch++) {
@@ -220,44 +224,54 @@ DEV_COLD void wideBulkAny(Dev& d, int kind, int i) {
         if (wideKeyLess(run, m)) run = m;
       }
     } break;
-    case W_RANK: {    // item i = (queue q, block of W_RB other queues): for every entry of q the number of the block's entries that order before it.  Both sequences are
-      // sorted (running-maximum keys), so one forward pointer per other queue does it: entries(q) x W_RB + entries(block) steps over sequential memory — the merge
-      // path of the k-way merge, not a binary search per pair (round 4's first version: 57 % of a 256-queue round).
-      const int q = i % c.Q, b0 = (i / c.Q) * W_RB;
-      const WideSeg s = w.seg[q];
-      if (s.total == 0) break;
+    case W_RANK: {    // entry i: its position in the merged order = its index in its own queue + for every other queue the number of that queue's entries that order before it
+      // (a binary search: all sequences are sorted by their running-maximum keys).  The mapping of items to threads is the point: the 64 lanes of a wave take 64
+      // CONSECUTIVE entries of ONE queue, so every search step of the wave reads the same other queue's (small) key array — a broadcast or a handful of cache lines, not
+      // 64 lines of 64 different arrays (measured on the MI355X: a wave-wide gather over 64 arrays costs ~2 k clocks per step: 57 % of a 256-queue round) — and
+      // consecutive waves take DIFFERENT queues, so the entries that exist (index < total) are spread over all workgroups.
+      const int total = (int)w.stop[1];
+      const int ent = i % total, slice = i / total;   // (the lanes of a wave: consecutive compact entries — almost always of one queue — and ONE slice of the other queues)
+      const int q = w.own[ent];
+      const WideKey key = w.key[ent];
       const int myName = d.qNameRank[q];
-      int n2[W_RB], ptr[W_RB]; bool nameBefore[W_RB]; WideKey cur[W_RB];
-      int any = 0;
+      const int per = W_PER;
+      const int g0 = slice * per, g1 = g0 + per < c.Q ? g0 + per : c.Q;
+      int rank = 0;
+      // W_RG searches side by side: their loads are independent, so a step of the group is ONE memory round trip (a lone wave per SIMD hides nothing: every
+      // dependent load is a full trip to L2 / HBM — measured ~2 k clocks per step with one search at a time)
+      for (int g = g0; g < g1; g += W_RG) {
+        int lo[W_RG], hi[W_RG]; bool nb[W_RG]; const WideKey* kk[W_RG];
 #pragma unroll
-      for (int j = 0; j < W_RB; j++) {
-        int q2 = b0 + j;
-        bool valid = q2 < c.Q && q2 != q;
-        n2[j] = valid ? w.seg[valid ? q2 : 0].total : 0; ptr[j] = 0;
-        nameBefore[j] = valid && d.qNameRank[valid ? q2 : 0] < myName;   // equal keys: Less ends with the queue name (queue_scheduler.go:796-797)
-        if (n2[j] > 0) { cur[j] = w.key[(size_t)q2 * WIDE_L]; any = 1; } else { cur[j].a = 0; cur[j].x = 0; cur[j].y = 0; }
-      }
-      if (!any) break;
-      const WideKey* mine = w.key + (size_t)q * WIDE_L;
-      for (int e = 0; e < s.total; e++) {
-        const WideKey key = mine[e];
-        int sum = 0;
-#pragma unroll
-        for (int j = 0; j < W_RB; j++) {
-          while (ptr[j] < n2[j] && (wideKeyLess(cur[j], key) || (nameBefore[j] && wideKeyEq(cur[j], key)))) {
-            ptr[j]++;
-            if (ptr[j] < n2[j]) cur[j] = w.key[(size_t)(b0 + j) * WIDE_L + ptr[j]];
-          }
-          sum += ptr[j];
+        for (int j = 0; j < W_RG; j++) {
+          int q2 = g + j;
+          bool valid = q2 < g1 && q2 != q;
+          int q2c = valid ? q2 : q;
+          const int o2 = w.off[2 * q2c];
+          lo[j] = 0; hi[j] = valid ? w.off[2 * q2c + 1] : 0;
+          nb[j] = valid && d.qNameRank[q2c] < myName;   // equal keys: Less ends with the queue name (queue_scheduler.go:796-797)
+          kk[j] = w.key + o2;
         }
-        if (sum) atomicAddI32(&w.rank[(size_t)q * WIDE_L + e], sum);
+        for (;;) {
+          WideKey m[W_RG]; bool live[W_RG]; bool any = false;
+#pragma unroll
+          for (int j = 0; j < W_RG; j++) { live[j] = lo[j] < hi[j]; any = any || live[j]; if (live[j]) m[j] = kk[j][(lo[j] + hi[j]) >> 1]; else { m[j].a = 0; m[j].x = 0; m[j].y = 0; } }
+          if (!any) break;
+#pragma unroll
+          for (int j = 0; j < W_RG; j++) if (live[j]) {
+            int mid = (lo[j] + hi[j]) >> 1;
+            bool before = wideKeyLess(m[j], key) || (nb[j] && wideKeyEq(m[j], key));
+            if (before) lo[j] = mid + 1; else hi[j] = mid;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < W_RG; j++) rank += lo[j];
       }
+      if (rank) atomicAddI32(&w.rank[ent], rank);
     } break;
-    case W_SCATTER: { // entry i = (queue, index): into its position of the merged order; where the order stops being valid
-      int q = i % c.Q, e = i / c.Q;   // (neighbouring threads take the same index of DIFFERENT queues: the entries that exist — e < total — are spread over all threads)
+    case W_SCATTER: { // compact entry i into its position of the merged order; where the order stops being valid
+      const int q = w.own[i], e = i - w.off[2 * q];
       const WideSeg s = w.seg[q];
-      if (e >= s.total) break;
-      const int rank = w.rank[(size_t)q * WIDE_L + e];
+      const int rank = w.rank[i];
       if (s.flags & 2) { atomicMinU32(&w.stop[0], (uint32_t)rank); break; }
       WideEnt en;
       if (e < s.evCnt) { en.job = d.evList[s.evStart + e]; en.qk = q | (1 << 30); }
@@ -418,10 +432,11 @@ DEV_COLD int wideRun(Dev& d, Ctl& c, const PassCfg& pc) {
   wgWide(d, W_PACK, Q * WQ_CPQ);
   wgWide(d, W_FIX, Q);
   WSEG(26);
-  wgWide(d, W_RANK, Q * ((Q + W_RB - 1) / W_RB));
-  wgWide(d, W_SCATTER, Q * WIDE_L);
+  uint32_t total = UNI32(w.stop[1]);
+  wgWide(d, W_RANK, (int)total * ((Q + W_PER - 1) / W_PER));
+  wgWide(d, W_SCATTER, (int)total);
   WSEG(27);
-  uint32_t stop = UNI32(w.stop[0]), total = UNI32(w.stop[1]);
+  uint32_t stop = UNI32(w.stop[0]);
   int V = stop < total ? (int)stop : (int)total;
 #ifdef ASCHED_HOSTSIM
   if (V > 0) {   // the merged order starts with the queue the generic Less serves next
@@ -430,7 +445,7 @@ DEV_COLD int wideRun(Dev& d, Ctl& c, const PassCfg& pc) {
   }
   if (getenv("HS_WIDE_TRACE")) {
     fprintf(stderr, "wide run: V %d stop %u total %u allowed %d", V, stop, total, allowed);
-    for (int q = 0; q < Q; q++) { const WideSeg& s = w.seg[q]; for (int e = 0; e < s.total; e++) { int r = w.rank[(size_t)q * WIDE_L + e];
+    for (int q = 0; q < Q; q++) { const WideSeg& s = w.seg[q]; for (int e = 0; e < s.total; e++) { int r = w.rank[w.off[2 * q] + e];
       if ((s.flags & 2) && r == (int)stop) fprintf(stderr, "  | barrier q%d gctx %d ev %d stage %d evCheap %d itNext %d", q, d.pqGctx[q], d.pqGctx[q] >= 0 ? d.jcEvicted[d.pqGctx[q]] : -1, d.itStage[q], d.evCheap[q], d.itNext[q]);
       if (!(s.flags & 2) && (s.flags & 4) && e == s.total - 1 && r + 1 == (int)stop) fprintf(stderr, "  | open q%d evCnt %d qLen %d qWant %d cap %d avail %d tokens %.0f", q, s.evCnt, s.qLen, s.qWant, w.cap[q], d.queuedOff[q + 1] - s.qBase, d.qTokens[q]); } }
     fprintf(stderr, "\n");

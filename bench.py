@@ -352,7 +352,7 @@ def market_record(hip, args):
     from armada_amd.binding import Library
     sc = args.other_scale
     wl = W.config3(seed=W.SEED, n_nodes=max(16, int(4_000 * sc)), n_jobs=max(200, int(40_000 * sc)), n_queues=16 if sc == 1.0 else 4, occupied=0.8)
-    wl.global_burst, wl.queue_burst = max(1, int(8_000 * sc)), max(1, int(2_000 * sc))
+    wl.global_burst, wl.queue_burst = max(1, int(3_000 * sc)), max(1, int(750 * sc))   # (the oracle: ~17 s for the 827 000 evicted jobs + ~7 s per 1 000 new jobs at this size)
     rng = np.random.default_rng(W.SEED)
     bids = rng.integers(1, 9, size=wl.num_jobs).astype(np.float64)                     # eight price bands (pkg/bidstore)
     nonpre = np.array([not wl.config.pc_preemptible[p] for p in wl.job_pc])
@@ -511,7 +511,7 @@ def config4_checker_record(hip, args):
     from armada_amd import workloads as W, multipool
     sc = args.other_scale
     wl = W.config3(seed=W.SEED, n_nodes=max(64, int(100_000 * sc)), n_jobs=max(640, int(300_000 * sc)), n_queues=64, occupied=0.95)
-    wl.global_burst, wl.queue_burst = max(1, int(8_000 * sc)), max(1, int(2_000 * sc))
+    wl.global_burst, wl.queue_burst = max(1, int(3_000 * sc)), max(1, int(750 * sc))   # (the oracle: ~17 s for the 827 000 evicted jobs + ~7 s per 1 000 new jobs at this size)
     s = W.load(hip, wl)
     lat, dev_ms, res = multipool.timed_rounds(s, wl, 3, 1, torch.cuda.synchronize, torch.cuda.synchronize)
     st = s.round_stats(); tm = s.round_timing()
@@ -679,7 +679,7 @@ def main():
     ap.add_argument("--submit-jobs", type=int, default=50_000)
     ap.add_argument("--submit-keys", type=int, default=2_000)
     ap.add_argument("--no-other", action="store_true", help="skip the other_configs sub-records (configs[1], [3], [4], submit check)")
-    ap.add_argument("--other-budget", type=float, default=240.0, help="seconds after which no further other_configs sub-record is started")
+    ap.add_argument("--other-budget", type=float, default=480.0, help="seconds after which no further other_configs sub-record is started")
     ap.add_argument("--no-full-other", action="store_true", help="skip the full-size (100k x 1M) run of configs[4] (~40 s); the reduced size with its oracle leg still runs")
     ap.add_argument("--other-scale", type=float, default=1.0, help="scale the other_configs workloads (tests)")
     ap.add_argument("--full-other", action="store_true", help="(default now; kept for older command lines)")
