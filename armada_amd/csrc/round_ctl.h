@@ -90,6 +90,7 @@ DEV bool fastGangMember(Dev& d, Ctl& c, int job);  // select (fit at priority -2
 DEV void fastFence(Ctl& c);
 DEV_COLD void ensureReplaySlow(Dev& d, Ctl& c);
 // pools of more than QCAPF queues (round_wide.h): stream runs whose k-way merge is a bulk rank over all queues' precomputed key sequences
+DEV int skipUnfeasibleRun(Dev& d, int pos, int max);   // round_fast.h: Peek's skip of known-unfeasible scheduling keys (queue_scheduler.go:398-413) for a stretch of queued jobs, 64 at a time
 DEV_COLD int wideRun(Dev& d, Ctl& c, const PassCfg& pc);
 DEV bool wideHeadOk(Dev& d, const Ctl& c, const PassCfg& pc, int t);
 DEV void ensureReplay(Dev& d, Ctl& c) { if (d.rs->replayPending) ensureReplaySlow(d, c); }   // (the test stays with the caller: a call costs a register save / restore)
@@ -1099,6 +1100,13 @@ DEV int gangItPeek(Dev& d, Ctl& c, int q, bool withQueued, uint32_t maxLookback,
         d.jcHasPctx[job] = 1; d.pcNode[job] = -1; d.pcMethod[job] = ASCHED_METHOD_NONE;
         sctxAddJob(d, job);
         d.jcReason[job] = ASCHED_REASON_SKIPPED_UNFEASIBLE_KEY;
+        // A queue of thousands of identical jobs that do not fit (the steady state BenchmarkPreemptingQueueScheduler times, preempting_queue_scheduler_test.go:2561-2799) is
+        // skipped job by job here; the jobs behind this one that Peek would skip as well are independent of each other: one lane each (round 4).
+        if (d.itStage[q] == 1 && !d.itJobOnlyEv[q] && withQueued && !d.rs->optMode) {
+          int max = d.queuedOff[q + 1] - d.itQi[q];
+          if (maxLookback != 0 && !d.itGangOnlyEv[q]) { int64_t lim = (int64_t)maxLookback - d.itJobsSeen[q]; if (lim < max) max = lim < 0 ? 0 : (int)lim; }   // (the switch to evicted-only happens at the top of this loop)
+          if (max >= 4) { int n = skipUnfeasibleRun(d, d.itQi[q], max); d.itQi[q] += n; d.itJobsSeen[q] += n; }
+        }
         continue;
       }
     }

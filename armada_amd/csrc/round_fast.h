@@ -438,6 +438,36 @@ DEV void candInvalidate(int S, int n) { FOR_LANES(s, S) if (FL.cand[s].node == n
 DEV void candResetAll(Dev& d, const int32_t* pos) { FOR_LANES(s, d.f.F < SMAX ? d.f.F : SMAX) { FL.cand[s].node = -2; FL.cand[s].pos = pos ? pos[s] : 0; FL.cand[s].key = 0; } }  // key 0: no lower bound known, the first query scans
 DEV void candSaveAll(Dev& d, int32_t* pos) { FOR_LANES(s, d.f.F < SMAX ? d.f.F : SMAX) pos[s] = FL.cand[s].pos; }
 
+// Peek's skip of known-unfeasible scheduling keys (queue_scheduler.go:398-413) for the queued jobs at queuedJobs[pos .. pos + max): how many of them, from the first on, are
+// single jobs whose scheduling key is registered as unfeasible — each gets the record the generic loop gives it (JobSchedulingContextFromJob, the key's reason replaced by
+// "skipped", sctx.AddJobSchedulingContext of a failed job: flags only).  The jobs are independent of each other: 64 per step, one lane each.  The caller advances the queue's
+// cursor and jobs-seen count and has bounded `max` by the lookback limit.
+DEV int skipUnfeasibleRun(Dev& d, int pos, int max) {
+  int done = 0;
+  while (done < max) {
+    int nb = max - done < 64 ? max - done : 64, n = 0;
+#if defined(ASCHED_HOSTSIM) || !defined(__HIP_DEVICE_COMPILE__)
+    while (n < nb) { int job = d.queuedJobs[pos + done + n]; if (!(d.jGang[job] < 0 && d.unfeasible[d.jShape[job]] && !(d.jobFlags[job] & F_SUCCESSFUL))) break; n++; }
+#else
+    { int x = FLANE; bool ok = false;
+      if (x < nb) { int job = d.queuedJobs[pos + done + x]; ok = d.jGang[job] < 0 && d.unfeasible[d.jShape[job]] && !(d.jobFlags[job] & F_SUCCESSFUL); }
+      unsigned long long bad = ~__ballot(ok);
+      n = bad ? __ffsll((long long)bad) - 1 : 64;
+      if (n > nb) n = nb; }
+#endif
+    FOR_LANES(x, 64) if (x < n) {
+      int job = d.queuedJobs[pos + done + x];
+      d.jcEvicted[job] = 0; d.jcAssigned[job] = -1; d.jcGangCard[job] = 1; d.jcUniValue[job] = -1; d.jcStagedBy[job] = -1;   // JobSchedulingContextFromJob (context/job.go:149-158)
+      d.jcHasPctx[job] = 1; d.pcNode[job] = -1; d.pcMethod[job] = ASCHED_METHOD_NONE;
+      d.jobFlags[job] = (uint8_t)(d.jobFlags[job] | F_UNSUCCESSFUL);
+      d.jcReason[job] = ASCHED_REASON_SKIPPED_UNFEASIBLE_KEY;
+    }
+    done += n;
+    if (n < nb) break;
+  }
+  return done;
+}
+
 // Before generic code runs: the LDS queue records back into the generic arrays, and the fast path's no-return atomics
 // made visible to plain loads
 DEV void fastFlushEvicted(Dev& d) {  // apply every queue's deferred evicted-job commits
@@ -752,6 +782,11 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
         k.jcHasPctx[job] = 1; k.pcNode[job] = -1; k.pcMethod[job] = ASCHED_METHOD_NONE;
         k.jobFlags[job] = (uint8_t)(k.jobFlags[job] | F_UNSUCCESSFUL);  // sctx.AddJobSchedulingContext of a failed job
         k.jcReason[job] = ASCHED_REASON_SKIPPED_UNFEASIBLE_KEY;
+      }
+      {   // the jobs behind it that Peek skips as well, one lane each (round_ctl.h gangItPeek has the same step)
+        int max = end - (pos + 1);
+        if (fc.maxLookback != 0 && !f.itGangOnlyEv) { int64_t lim = (int64_t)fc.maxLookback - f.itJobsSeen; if (lim < max) max = lim < 0 ? 0 : (int)lim; }
+        if (max >= 4) { int n = skipUnfeasibleRun(d, pos + 1, max); f.itQi += n; f.itJobsSeen += n; }
       }
       continue;
     }

@@ -592,7 +592,9 @@ DEV_COLD COLD_MS_12 void runRound(Dev& d, Ctl& c) {
   int n3 = pqsEvict(d, c, true);
   long long td = CLK();
   if (d.progress) d.progress[1] = 4;
-  if (n3 > 0) schedulePass(d, c, false, true, true);
+  { int fe = c.fastEnabled; if (d.jAway) c.fastEnabled = 0;   // (cross-pool away jobs may be among the jobs the oversubscribed evictor took: the generic code knows their rules)
+    if (n3 > 0) schedulePass(d, c, false, true, true);
+    c.fastEnabled = fe; }
   if (d.rs->error) return;
   long long te = CLK();
   d.rs->statClk[4] += te - td;
@@ -1265,6 +1267,7 @@ DEV void controlMain(Dev& d, int cmd) {
   c.txn.active = d.rs->txnActive; c.fairStamp = d.rs->fairStamp; c.preList = d.preList; c.preCount = 0;
   c.skipKeyCheck = 0; c.compareSchedPrio = 0; c.preferLarge = d.cfg.preferLarge; c.useReplayAlloc = 0; c.onlyEvicted = 0;
   c.fastEnabled = d.f.iterOk && !d.rs->apiDirty && (cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY || cmd == CMD_PASS1 || cmd == CMD_PASS2);
+  if (d.jAway && (cmd == CMD_PASS2 || cmd == CMD_QUEUES_ONLY)) c.fastEnabled = 0;   // cross-pool away jobs can sit in the queues of these passes (the oversubscribed evictor takes them; a caller's queue-only pass): generic
   c.fastEvStatic = 0; c.l1Dirty = 0; c.fqLive = 0; c.skipEnter = 0; c.skipActive = 0; c.cancelSeen = 0; c.fpLimitHit = 0; c.streamNextAt = 0; c.streamBackoff = 0; c.streamCap = QS_CMAX;
   // the fair-share threshold table (round_ft.h) lives for one launch of a scheduling pass: the grid-wide phases between launches rewrite planes wholesale
   d.rs->ftValid = 0;
