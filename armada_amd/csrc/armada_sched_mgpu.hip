@@ -21,7 +21,7 @@ __device__ static inline void waveCount(int32_t* counter, bool pred) {
 }
 __global__ __launch_bounds__(MG_THREADS) void k_mgpu_pack(Dev d, GlobalKeyLayout L, int level, const unsigned long long* keys, const int32_t* slot, int nq, long long* out, int32_t* bad) {
   long long i = MG_IDX();
-  if (i < nq) out[i] = mgpuPackQuery(d, L, level, keys[slot[i]], bad);
+  if (i < nq) out[i] = mgpuPackQuery(d, L, level, keys[(size_t)slot[i] * FIT_OSTR], bad);   // (k_fit_batch's result words are FIT_OSTR apart)
 }
 __global__ __launch_bounds__(MG_THREADS) void k_mgpu_delta(Dev d, long long* buf, int ns, int np) {
   long long i = MG_IDX();
