@@ -26,6 +26,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and prototypes only: the functions are bound with dlsym at asched_comm_init (no link-time dependency on librccl)
 
+#if defined(ASCHED_AUX_TU) && defined(HELP_TRACE)
+#undef HELP_TRACE   // (the trace variant instruments the round kernel only)
+#endif
 #define ASCHED_PREFIX asched_
 #include "round_run.h"
 #include "round_opt.h"
@@ -74,6 +77,13 @@ __shared__ HelpBox* g_box;
 __shared__ int g_H;
 __shared__ unsigned int g_gen;
 
+#ifdef HELP_TRACE
+// Timeline of the fused wide pass (tools/build_variant.sh trace -DHELP_TRACE; never in the product): the control wave stamps the wall clock (s_memrealtime, 100 MHz, one time base for
+// the whole chip) when it issues an OP_SCANFAIR; helper workgroups 1, H/2 and H add (their stamp - the issue stamp) at five points, the control workgroup at two.
+__device__ unsigned long long g_traceT0[1024];
+__device__ unsigned long long g_traceSum[64];   // [cls * 8 + point]: cls 0 control (0 own share done, 1 wait done), 1..3 helpers (0 seen, 1 args + acquire, 2 scan done, 3 fair done, 4 slot written); [56 + cls] counts
+#define TRACE_ADD(cls, pt, gen) atomicAdd(&g_traceSum[(cls) * 8 + (pt)], (unsigned long long)(wall_clock64() - g_traceT0[(gen) & 1023]))
+#endif
 // 64-bit words of an object of another type: through a may_alias type.  (Round 2 read the argument structs through a plain unsigned long long* — undefined
 // under strict aliasing: int64_t is `long`, so the compiler was free to treat the freshly written struct as never written; `minsize` on the callers made it do
 // so and the helper workgroups received garbage requests: profiles/r03a_minsize_rootcause.txt.  The device code is also built with -fno-strict-aliasing now.)
@@ -257,18 +267,27 @@ __device__ static inline int wgFairSelect(Dev& d, const FairArgs& a) {
 // command, one completion count, two results
 __device__ static inline int wgScanFair(Dev& d, const ScanArgs& a, const FairArgs& f, uint64_t* bestKey) {
   int lane = threadIdx.x & 63;
+#ifdef HELP_TRACE
+  if (lane == 0 && g_H) { g_traceT0[(g_gen + 1) & 1023] = wall_clock64(); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+#endif
   if (lane == 0) { g_mb.op = OP_SCANFAIR; g_mb.scan = a; g_mb.fair = f; if (g_H) helpIssue(OP_SCANFAIR, &a, &f); }
   __syncthreads();
   unsigned long long v = scanPart(d, g_mb.scan, threadIdx.x, (g_H + 1) * (int)blockDim.x);
   int w = fairPart(d, g_mb.fair, threadIdx.x, (g_H + 1) * (int)blockDim.x);
   if (lane == 0) { g_mb.partial[threadIdx.x >> 6] = v; g_mb.waveCount[threadIdx.x >> 6] = w; }
   __syncthreads();
+#ifdef HELP_TRACE
+  if (lane == 0 && g_H) { TRACE_ADD(0, 0, g_gen); atomicAdd(&g_traceSum[56], 1ull); }
+#endif
   unsigned long long best = ~0ull; int idx = -1;
   int nw = blockDim.x >> 6;
   for (int k = 0; k < nw; k++) { unsigned long long p = g_mb.partial[k]; best = p < best ? p : best; int q = g_mb.waveCount[k]; idx = q > idx ? q : idx; }
   if (g_H) {
     unsigned long long hmx;
     unsigned long long hb = helpWait(&hmx);
+#ifdef HELP_TRACE
+    if (lane == 0) TRACE_ADD(0, 1, g_gen);
+#endif
     best = hb < best ? hb : best;
     int h = (int)(unsigned int)hmx - 1;
     idx = h > idx ? h : idx;
@@ -1344,10 +1363,24 @@ __device__ static void helperMain(const Dev& d, HelpBox* b, int H) {
       int v = fairPart(d, a, tid, nthreads);
       if (lane == 0 && v >= 0) __hip_atomic_fetch_max(&g_hMax, (unsigned long long)(v + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (op == OP_SCANFAIR) {
+#ifdef HELP_TRACE
+      const int tcls = (int)blockIdx.x == 1 ? 1 : ((int)blockIdx.x == (H + 1) / 2 ? 2 : ((int)blockIdx.x == H ? 3 : 0));
+      const int tgen = (int)(seen >> 8);
+      if (tcls && threadIdx.x == 0) { TRACE_ADD(tcls, 0, tgen); atomicAdd(&g_traceSum[56 + tcls], 1ull); }
+#endif
       ScanArgs a = helpArgs<ScanArgs>(b);
       FairArgs f = helpArgs<FairArgs>(b, HELP_ARGS2);
+#ifdef HELP_TRACE
+      if (tcls && threadIdx.x == 0) TRACE_ADD(tcls, 1, tgen);
+#endif
       unsigned long long v = scanPart(d, a, tid, nthreads);
+#ifdef HELP_TRACE
+      if (tcls && threadIdx.x == 0) TRACE_ADD(tcls, 2, tgen);
+#endif
       int w = fairPart(d, f, tid, nthreads);
+#ifdef HELP_TRACE
+      if (tcls && threadIdx.x == 0) TRACE_ADD(tcls, 3, tgen);
+#endif
       if (lane == 0 && v != ~0ull) __hip_atomic_fetch_min(&g_hMin, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (lane == 0 && w >= 0) __hip_atomic_fetch_max(&g_hMax, (unsigned long long)(w + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (op == OP_BULKW) {
@@ -1382,6 +1415,9 @@ __device__ static void helperMain(const Dev& d, HelpBox* b, int H) {
         __hip_atomic_store(&sl->mn, mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&sl->mx, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&sl->gen, seen >> 8, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // completion: this workgroup's results (and, for the bulk ops, its writes) are visible before it
+#ifdef HELP_TRACE
+        if (op == OP_SCANFAIR) { const int tc2 = (int)blockIdx.x == 1 ? 1 : ((int)blockIdx.x == (H + 1) / 2 ? 2 : ((int)blockIdx.x == H ? 3 : 0)); if (tc2) TRACE_ADD(tc2, 4, (int)(seen >> 8)); }
+#endif
       }
     }
   }
@@ -2733,3 +2769,7 @@ extern "C" __attribute__((visibility("hidden"))) int asched_internal_aux_launch(
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 #endif  // ASCHED_AUX_TU
+
+#ifdef HELP_TRACE
+extern "C" int asched_debug_help_trace(unsigned long long* out64) { return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_traceSum), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1; }
+#endif

@@ -21,3 +21,11 @@ for i in range(1 if full else 2):
     t = time.perf_counter(); r = s.schedule_round(); dt = time.perf_counter() - t
     st = s.round_stats()
     print("round", i, round(dt * 1e3, 1), "ms", {k: st[k] for k in ("fast_iterations", "generic_iterations", "kclk_pass1", "kclk_pass2", "kclk_plane_scans", "kclk_fair_selects", "stream_runs", "stream_jobs", "window_refills", "preempt_fast_iterations", "ft_queries", "ft_retries", "ft_node_updates")}, len(r.scheduled), len(r.preempted), flush=True)
+
+import ctypes
+if hasattr(lib.lib, "asched_debug_help_trace"):   # tools/build_variant.sh trace -DHELP_TRACE: the timeline of the fused wide pass (wall clock, 10 ns units)
+    buf = (ctypes.c_uint64 * 64)(); lib.lib.asched_debug_help_trace(buf)
+    names = {0: ["own share done", "wait done"], 1: ["seen", "args+acquire", "scan done", "fair done", "slot written"]}
+    for cls, label in ((0, "control workgroup"), (1, "helper 1"), (2, "helper H/2"), (3, "helper H")):
+        n = buf[56 + cls]
+        if n: print(label, n, "passes:", ", ".join(f"{nm} {buf[cls * 8 + i] / n / 100:.2f} us" for i, nm in enumerate(names[0 if cls == 0 else 1])))
