@@ -1217,6 +1217,20 @@ __device__ static inline bool pinnedNodeFits(KREF k, int q, int n, int level) {
   return __ballot(bad) == 0;
 }
 
+__device__ static inline EvDyn evDynLoad(KREF k, int q, int job, int n, int level, bool wantMark, bool wantPin) {
+  int lane = threadIdx.x & 63;
+  // three independent loads, issued back to back; the first use below waits for all of them once
+  int mark = wantMark ? (int)k.jcPreempted[job] : 0;
+  int nf = wantPin ? (int)k.nodeFlags[n] : 0;
+  int64_t have = 0;
+  if (wantPin && lane < k.R) have = __hip_atomic_load(&KAL(k, level, lane, n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  EvDyn r;
+  r.preempted = UNI32(mark);
+  bool bad = wantPin && lane < k.R && g_fl.headReq[q][lane] > have;
+  r.fits = (!wantPin || (UNI32(nf) & 1) || __ballot(bad) == 0) ? 1 : 0;
+  return r;
+}
+
 // ------------------------------------------------------------------------------------------------ LDS residency of the round's small state
 // Every per-queue array and the scheduling-context scalars are moved into LDS for the duration of the launch by
 // re-pointing the Dev descriptor (which itself lives in LDS): generic and fast code alike then pay LDS latency for them.

@@ -381,6 +381,7 @@ DEV void fastEnsureLive(Dev& d, Ctl& c) { if (!c.fqLive) { fastQLoad(d); c.fqLiv
 // ------------------------------------------------------------------------------------------------ lane-parallel primitives
 // The queue heap of CostBasedCandidateGangIterator as the fast loop sees it.  Device: the queues sorted by key across the
 // lanes of the control wave (registers); serving the head re-inserts it with one lane shift.  Host: argmin over the keys.
+struct EvDyn { int preempted; int fits; };
 #ifdef ASCHED_HOSTSIM
 #include "fast_serial.h"          // tests/hostsim/: serial stand-ins of the primitives below for the CPU build of the control code (test infrastructure)
 #else  // device versions: armada_sched.hip
@@ -412,6 +413,7 @@ DEV void engineStart(Dev& d, FastS& S);
 DEV void engineStop(Dev& d, FastS& S);
 DEV bool headRequestsDisallowed(Dev& d, KREF k, int q);
 DEV bool pinnedNodeFits(KREF k, int q, int n, int level);
+DEV EvDyn evDynLoad(KREF k, int q, int job, int n, int level, bool wantMark, bool wantPin);   // a returning evicted job's preempted mark and its pinned-node check, their loads in flight together
 // per-queue state of a stream run, held in the lanes of the control wave (lane q: queue q): position at the start of the run, list position of element 0,
 // merge cursor, length, kind (bit 0: evicted stream, bit 1: the queue's evicted list was folded (running-maximum key)), first element of the key window in
 // LDS, the queue's budget, the running-maximum key.  Reading queue t's values is a v_readlane (scalar result), no LDS round trip.
@@ -999,7 +1001,13 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
       evInRound = (UNI32((int)k.jobFlags[job]) & F_EVICTED) != 0; wasPre = UNI32((int)k.inPreempted[job]) != 0;
       if (n < 0 || prio == NO_PRIORITY) return 0;
     }
-    if (S.numPreemptedMarks != 0 && UNI32((int)k.jcPreempted[job]) != 0) {
+    // After a preemption-based bind a returning evicted job needs its preempted mark and its node's current row: three HBM reads that used to be three round trips of the control
+    // wave, one after the other (mark, node flags, planes) — 340 000 such iterations in a configs[4] round (profiles/r04h_wide_pass_timeline.txt).  One round trip now.
+    int dynLevel = -1;
+    const bool dynPin = fc.evStatic && !S.lvl0NonNeg;
+    if (dynPin) for (int l = 0; l < MAXP; l++) if (l < k.P && k.prios[l] == prio) dynLevel = l;
+    const EvDyn dyn = evDynLoad(k, q, job, n, dynLevel, S.numPreemptedMarks != 0, dynPin && dynLevel >= 0);
+    if (S.numPreemptedMarks != 0 && dyn.preempted != 0) {
       // a job preempted earlier in this round is skipped: Clear() + continue, no scheduling attempt, not a counted iteration
       // (queue_scheduler.go:150-156); a queued job never carries the mark
       if (f.evApplied < f.evDone) { applyEvictedRange(d, q, f.evApplied, f.evDone); S.numEvictedJobs -= f.evDone - f.evApplied; }
@@ -1010,7 +1018,7 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
       int level = -1;
       for (int l = 0; l < MAXP; l++) if (l < k.P && k.prios[l] == prio) level = l;
       if (level < 0) return 0;
-      if (!pinnedNodeFits(k, q, n, level)) {
+      if (!(dynPin ? dyn.fits != 0 : pinnedNodeFits(k, q, n, level))) {
         // The job does not fit on its node any more (urgency preemption took the space): SelectNodeForJobWithTxn returns no node,
         // the gang fails with "job does not fit on any node" (gang_scheduler.go:229-262, 63-98).  Net effect of AddGangSchedulingContext /
         // EvictGang / re-add-as-failed on the scheduling context (scheduling.go:391-449, 551-572; queue.go:231-265, 351-386): the job's

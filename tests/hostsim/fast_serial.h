@@ -180,6 +180,10 @@ DEV bool pinnedNodeFits(KREF k, int q, int n, int level) {
   for (int x = 0; x < k.R; x++) if (FL.headReq[q][x] > KAL(k, level, x, n)) return false;
   return true;
 }
+DEV EvDyn evDynLoad(KREF k, int q, int job, int n, int level, bool wantMark, bool wantPin) {
+  EvDyn r; r.preempted = wantMark ? (int)k.jcPreempted[job] : 0; r.fits = (!wantPin || pinnedNodeFits(k, q, n, level)) ? 1 : 0;
+  return r;
+}
 DEV void pqHeadKey(PQState&, int t, PackedKey* key, uint32_t* nameRank) { key->A = FL.kA[t]; key->X = FL.kX[t]; key->Y = FL.kY[t]; *nameRank = (uint32_t)FL.nameRank[t]; }
 // ---- stream run, serial build.  The engine serves an entry when its record is staged, so that entries emitted but not yet staged when a job
 // does not fit are discarded exactly as on the device (there the engine runs behind the merge by up to a ring's worth of entries).
