@@ -210,6 +210,13 @@ class CRoundResult(C.Structure):
     ]
 
 
+class CExcludedReason(C.Structure):  # asched_excluded_reason
+    _fields_ = [("kind", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_int32), ("required", C.c_int64), ("available", C.c_int64),
+                ("count", C.c_int32), ("pad_", C.c_int32)]
+
+
+EXCL_KINDS = ("implicit", "untolerated_taint", "missing_label", "unmatched_label", "unmatched_affinity", "insufficient_resources", "disallowed_resource")
+
 ALL_SYMBOLS = [
     "create", "destroy", "last_error", "priorities", "nodes_upsert", "jobs_set", "txn_begin", "txn_commit",
     "txn_abort", "select_node", "schedule_many", "bind", "evict", "unbind", "add_evicted", "reset_evicted",
@@ -221,6 +228,7 @@ ALL_SYMBOLS = [
     "fit_select_batch_global", "round_delta_words", "round_delta", "round_delta_resolve",
     "set_market", "market_result", "price_gang", "price_job_on_nodes",
     "comm_unique_id", "comm_init", "comm_init_external", "comm_destroy", "comm_rank", "fit_select_batch_sharded", "round_exchange",
+    "excluded_nodes", "set_excluded_nodes",
 ]
 # entry points the CPU oracle does not implement (it is the single-process checker): the communicator and the collectives that run on it
 OPTIONAL_SYMBOLS = {"comm_unique_id", "comm_init", "comm_init_external", "comm_destroy", "comm_rank", "fit_select_batch_sharded", "round_exchange"}
@@ -360,6 +368,8 @@ class Library:
         f("job_key_unfeasible", C.c_int32, [C.c_void_p, C.c_int32, _i32p])
         f("kernel_times", C.c_int32, [C.c_void_p, _f64p])
         f("round_stats", C.c_int32, [C.c_void_p, _i32p])
+        f("excluded_nodes", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(CExcludedReason), C.c_int32])
+        f("set_excluded_nodes", C.c_int32, [C.c_void_p, C.c_int32])
 
     def _fn(self, name, restype, argtypes):
         if name in OPTIONAL_SYMBOLS and not hasattr(self.lib, self.prefix + name):
@@ -1068,6 +1078,22 @@ class Scheduler:
                  "kclk_plane_scans", "kclk_fair_selects", "stream_runs", "stream_jobs", "stream_prepared", "stream_emitted", "preempt_fast_iterations",
                  "ft_queries", "ft_retries", "ft_node_updates"]
         return {k: out[i] for i, k in enumerate(names)}
+
+    def excluded_nodes(self, job: int):
+        """PodSchedulingContext.NumExcludedNodesByReason of the job's last node selection, which ended without a node (include/armada_sched.h
+        asched_excluded_reason): [(kind, a, b, c, required, available, count)] ascending, kind as in EXCL_KINDS.  [] = nothing on record."""
+        cap = 64
+        while True:
+            buf = (CExcludedReason * cap)()
+            n = self.lib.excluded_nodes(self.h, job, buf, cap)
+            if n < 0:
+                self._check(n)
+            if n <= cap:
+                return [(EXCL_KINDS[buf[i].kind], buf[i].a, buf[i].b, buf[i].c, buf[i].required, buf[i].available, buf[i].count) for i in range(n)]
+            cap = n
+
+    def set_excluded_nodes(self, max_failed_selections: int):
+        self._check(self.lib.set_excluded_nodes(self.h, max_failed_selections))
 
     def job_key_unfeasible(self, job: int) -> bool:
         o = C.c_int32(0)

@@ -163,6 +163,21 @@ struct QueueLoopArrays {
   double *pqProposed, *pqCurrent, *pqBudget, *pqSize; int32_t *pqPcPrio, *pqSchedPrio, *pqGctx; uint8_t* pqInHeap;
 };
 
+// ---- NumExcludedNodesByReason (asched_excluded_nodes): what the device keeps of a node selection that ended without a node.  The reasons that do not depend on the
+// round's state (taints, selectors, affinity, total resources) are worked out by the host when somebody asks; the device records what only it knows — which nodes the
+// iterator yielded at the job's priority (a bit per node) and, for the yielded nodes that pass the static checks, the first resource that did not fit and what was there.
+struct ExclRec { int32_t job, kind, level, row, uni, node, res, flags; int64_t avail; };   // kind: EXCL_K_*; flags bit 0: more dynamic reasons than the arena holds
+struct ExclDyn { int32_t slot, node, res, pad; int64_t avail; };
+struct ExclDev {
+  int32_t* jobSlot;      // [M] -1 = nothing on record, -2 = dropped (more failed selections than `cap`), else the job's record
+  ExclRec* rec;          // [cap]
+  uint64_t* bits;        // [cap][W] nodes the iterator yielded
+  ExclDyn* dyn;          // [dynCap] arena, tagged with the record
+  int32_t cap, dynCap, W, cur;   // cur: the record the pass in flight fills
+  int32_t count, dynCount;
+};
+enum { EXCL_K_WIDE = 0, EXCL_K_PINNED = 1, EXCL_K_DISALLOWED = 2, EXCL_K_NONE = 3, EXCL_K_UNSUPPORTED = 4 };
+
 // NodeTypeIterator state (nodeiteration.go:211-251): current lower bound (raw quantities), its packed form, the node it yielded last
 struct LitIt { int64_t lb[MAXK]; uint64_t bound; int32_t head; int32_t type; };
 
@@ -257,7 +272,8 @@ struct Dev {
   int64_t* accAvail;     // [N][R]
   int32_t* accStamp;     // [N]
   uint8_t* accStaticFailed;  // [N]
-  int32_t accEpoch_unused;
+  struct ExclDev* excl;  // failed node selections on record (asched_excluded_nodes; round_wide.h "excluded nodes"), or NULL: recording is off.  (In the slot of a retired
+                         // 4-byte field + its padding: sizeof(Dev) — the struct is copied into the round kernel's LDS — is unchanged.)
   // per-node index of the evicted table for fair-share preemption (round_run.h ensureFairIndex): CSR node -> table Indexes, descending
   int32_t* fairOff;      // [Npad+2]
   int32_t* fairEnt;      // [M] evicted-table Index
@@ -277,6 +293,7 @@ struct Dev {
   // ---- txn undo log
   int32_t* undo;         // [cap][4]
   int32_t undoCap;
+  int32_t accEpoch_unused;   // fair-share index: queries since the last build (round_run.h ensureFairIndex).  (Moved into undoCap's padding in round 4: its old slot + padding hold `excl`.)
   // ---- misc
   RoundScalars* rs;
   uint64_t* scanResult;  // [8] scratch for wide scans

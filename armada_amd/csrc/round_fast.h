@@ -1026,6 +1026,7 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
         // other sum is back where it was.  No unfeasible-key registration: an evicted job's key is not valid (context/job.go:104-109).
         if (f.evApplied < f.evDone) { applyEvictedRange(d, q, f.evApplied, f.evDone); S.numEvictedJobs -= f.evDone - f.evApplied; }
         f.evApplied = f.evDone = f.headPos + 1;
+        if (d.excl) exclRecord(d, job, EXCL_K_PINNED, n, level);   // (asched_excluded_nodes: the dynamic reason on its node)
         if (evInRound) FOR_LANES(x, k.R) {
           int64_t v = FL.headReq[q][x];
           if (v) {

@@ -32,7 +32,7 @@
 // rounds with the oracle for 65 ... 1 024 queues (CPU build and -m gpu).
 #pragma once
 
-enum { W_SEG = 0, W_EVSUM, W_QSUM, W_STITCH, W_PACK, W_FIX, W_RANK, W_SCATTER, W_COMMIT_E, W_COMMIT_Q };
+enum { W_SEG = 0, W_EVSUM, W_QSUM, W_STITCH, W_PACK, W_FIX, W_RANK, W_SCATTER, W_COMMIT_E, W_COMMIT_Q, W_EXCL };   // (W_EXCL: not a pass of a wide run — the pass behind asched_excluded_nodes shares the op)
 #define W_PER 16                        // queues one item of the rank pass walks for its entry: an entry's walk over the other queues is cut into Q / W_PER items (the entries of a run
                                         // alone fill a third of the lanes once)
 #define WQ_CHUNK 8                      // entries one item of the chunked passes covers (streams here are tens of entries long, not thousands: round_run.h uses 64)
@@ -49,7 +49,45 @@ DEV WideKey widePack(int preferLarge, const EvKey& e, double budget) {
 
 // ---- the bulk bodies (one element per call: every workgroup of the launch takes a share; they read and write HBM only and never the scheduling-context
 // scalars, which live in the control workgroup's LDS for the launch — what they need of those comes through WideParams)
+// ---- excluded nodes (asched_excluded_nodes; NumExcludedNodesByReason, nodedb.go:566-580,881-928).  One pass over the nodes for a selection that found no node at the job's
+// priority: element i = node i.  The iterator of the attempt yields exactly the nodes whose INDEXED columns cover the request at that level (nodeiteration.go:318-382, for
+// requests on the index grid; rows on the literal path walk the iterators instead, exclLiteral below) — a bit per node; the host intersects it with the node types the job
+// matches.  A yielded node that passes the static checks (the row's mask) fails the dynamic one, since the attempt found nothing: its reason is the first column, in factory
+// order, that the allocatable at that level does not cover (resource_list.go:167-191) — an arena entry.  Every other reason is a function of the inputs alone: the host's.
+DEV void exclPutBits(uint64_t* words, int n, bool bit) {
+#ifdef ASCHED_HOSTSIM
+  if ((n & 63) == 0) words[n >> 6] = 0;            // (the serial build visits the nodes in ascending order)
+  if (bit) words[n >> 6] |= 1ull << (n & 63);
+#else
+  unsigned long long m = __ballot(bit);            // (the 64 nodes of a word are the 64 lanes of one wave: the pass runs over W * 64 elements)
+  if ((threadIdx.x & 63) == 0) words[n >> 6] = m;
+#endif
+}
+DEV void exclDynPut(Dev& d, ExclDev& x, int slot, int n, int level, const int64_t* req) {
+  int res = -1; int64_t avail = 0;
+  for (int r = 0; r < d.cfg.R; r++) if (res < 0 && req[r] > AL(d, level, r, n)) { res = r; avail = AL(d, level, r, n); }
+  int at = atomicFetchAddI32(&x.dynCount, 1);
+  if (res < 0 || at >= x.dynCap) { atomicOrI32(&x.rec[slot].flags, res < 0 ? 2 : 1); return; }   // (bit 1: a yielded, statically matching node that fits — the attempt would have taken it)
+  ExclDyn e; e.slot = slot; e.node = n; e.res = res; e.pad = 0; e.avail = avail;
+  x.dyn[at] = e;
+}
+DEV void exclBulk(Dev& d, int n) {
+  const DevCfg& c = d.cfg;
+  ExclDev& x = *d.excl;
+  const int slot = x.cur;
+  const ExclRec& r = x.rec[slot];
+  const int64_t* req = JREQ(d, r.job);
+  bool fit = n < c.N;
+  if (fit) for (int k = 0; k < c.K; k++) fit = fit && AL(d, r.level, c.indexedCol[k], n) >= req[c.indexedCol[k]];
+  exclPutBits(x.bits + (size_t)slot * x.W, n, fit);
+  if (!fit) return;
+  bool st = (d.shapeMask[(size_t)r.row * c.W + (n >> 6)] >> (n & 63)) & 1;
+  if (st && r.uni >= 0) st = (d.labelMask[(size_t)r.uni * c.W + (n >> 6)] >> (n & 63)) & 1;
+  if (st) exclDynPut(d, x, slot, n, r.level, req);
+}
+
 DEV_COLD void wideBulkAny(Dev& d, int kind, int i) {
+  if (kind == W_EXCL) { exclBulk(d, i); return; }
   const DevCfg& c = d.cfg;
   WideDev& w = *d.wide;
   const WideParams& P = *w.par;
@@ -379,6 +417,62 @@ DEV void wgWide(Dev& d, int kind, int n) { for (int i = 0; i < n; i++) wideBulkA
 #else
 DEV void wgWide(Dev& d, int kind, int n);   // armada_sched.hip: the pass on the control workgroup and the helper workgroups (OP_WIDE)
 #endif
+
+// rows on the literal iteration path: the nodes the iterators yield, one after the other (selectAtLevelLiteral's walk without the early exit)
+DEV_COLD void exclLiteral(Dev& d, ExclDev& x, int slot) {
+  const DevCfg& c = d.cfg;
+  const ExclRec r = x.rec[slot];
+  const int64_t* req = JREQ(d, r.job);
+  uint64_t* bits = x.bits + (size_t)slot * x.W;
+  FOR_LANES(w, x.W) bits[w] = 0;
+  int64_t ireq[MAXK];
+  for (int i = 0; i < c.K; i++) ireq[i] = req[c.indexedCol[i]];
+  int t0 = d.rowTypeOff[r.row], nT = d.rowTypeOff[r.row + 1] - t0;
+  if (nT > LIT_TMAX) { x.rec[slot].kind = EXCL_K_UNSUPPORTED; return; }
+  for (int k = 0; k < nT; k++) {
+    LitIt& it = d.lit[k];
+    it.type = d.rowTypes[t0 + k];
+    for (int i = 0; i < MAXK; i++) it.lb[i] = i < c.K ? ireq[i] : 0;
+    it.bound = litBound(c, it.lb);
+    litAdvance(d, r.level, it, ireq);
+  }
+  for (;;) {
+    int best = -1;
+    for (int k = 0; k < nT; k++) if (d.lit[k].head >= 0 && (best < 0 || litNodeLess(d, r.level, d.lit[k].head, d.lit[best].head))) best = k;
+    if (best < 0) return;
+    int n = d.lit[best].head;
+    litAdvance(d, r.level, d.lit[best], ireq);
+    if (FLANE == 0) {
+      bits[n >> 6] |= 1ull << (n & 63);
+      bool st = (d.shapeMask[(size_t)r.row * c.W + (n >> 6)] >> (n & 63)) & 1;
+      if (st && r.uni >= 0) st = (d.labelMask[(size_t)r.uni * c.W + (n >> 6)] >> (n & 63)) & 1;
+      if (st) exclDynPut(d, x, slot, n, r.level, req);
+    }
+  }
+}
+// the record of a selection that ended without a node (round_ctl.h selectNodeForJob; round_fast.h: an evicted job that no longer fits on its node)
+DEV_COLD void exclRecord(Dev& d, int job, int kind, int node, int level) {
+  ExclDev& x = *d.excl;
+  if (x.cap <= 0) return;
+  int slot = x.jobSlot[job];
+  if (slot == -2) return;
+  if (slot < 0) {
+    int cnt = x.count;
+    if (cnt >= x.cap) { x.jobSlot[job] = -2; return; }
+    slot = cnt; x.count = cnt + 1; x.jobSlot[job] = slot;
+  }
+  ExclRec r;
+  r.job = job; r.kind = kind; r.level = level; r.row = d.rs->awayRowPlus1 ? d.rs->awayRowPlus1 - 1 : d.jShape[job]; r.uni = d.jcUniValue[job]; r.node = node; r.res = -1; r.flags = 0; r.avail = 0;
+  if (kind == EXCL_K_PINNED) {   // DynamicJobRequirementsMet's reason on the one node (nodedb.go:897-920)
+    const int64_t* req = JREQ(d, job);
+    for (int q = 0; q < d.cfg.R; q++) if (r.res < 0 && req[q] > AL(d, level, q, node)) { r.res = q; r.avail = AL(d, level, q, node); }
+  }
+  x.rec[slot] = r;
+  if (kind != EXCL_K_WIDE) return;
+  if (d.rowLiteral && d.rowLiteral[r.row]) { exclLiteral(d, x, slot); return; }
+  x.cur = slot;
+  wgWide(d, W_EXCL, x.W * 64);
+}
 
 
 // Is the head of queue t something a wide run can start with?  (The bulk preparation costs a few hundred microseconds: not worth it for a head the run stops at.)

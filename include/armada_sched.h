@@ -284,6 +284,40 @@ typedef struct asched_pod_result {
   int32_t method;               /* ASCHED_METHOD_* */
 } asched_pod_result;
 
+/* ---- PodSchedulingContext.NumExcludedNodesByReason (scheduling/context/pod.go:51) of a job whose last node selection ended WITHOUT a node: how many
+ *      nodes each reason excluded.  The reference keys the histogram by the reason's string (nodematching.go:14-125); strings never cross this
+ *      boundary, so an entry carries what the string is made of and the caller formats it:
+ *        IMPLICIT                "insufficient resources available": nodes the iterator never yielded (nodedb.go:566-580)
+ *        UNTOLERATED_TAINT       a = key, b = value, c = effect          "taint %s=%s:%s not tolerated"
+ *        MISSING_LABEL           a = label key                            "node does not match pod NodeSelector: label %s not set"
+ *        UNMATCHED_LABEL         a = key, b = pod value, c = node value   "... required label %s = %s, but node has %s"
+ *        UNMATCHED_AFFINITY      (the job's own node affinity)            "node does not match pod NodeAffinity %s"
+ *        INSUFFICIENT_RESOURCES  a = resource column, required, available "pod requires %s %s, but only %s is available" (static: the node's total; dynamic:
+ *                                                                         allocatable at the priority of the attempt, nodematching.go:161-197,257-267)
+ *        DISALLOWED_RESOURCE     count = NumNodes (nodedb.go:596-601)
+ *      Semantics (nodedb.go:538-630,724-789,881-928): the histogram of the LAST attempt — NodeTypesMatchingJob's per-type exclusions (:1118-1133), one reason per
+ *      node the iterator yielded at the job's priority (every one of them failed), the rest as IMPLICIT; the counts add up to NumNodes (the reference's own
+ *      check, queue_scheduler_test.go:676-690).  A pinned (evicted) job: its node's dynamic reason, the rest IMPLICIT.
+ *      Where the reference itself is order-dependent the smallest id is reported: a node selector is a Go map (nodematching.go:216-243: the first failing label
+ *      in map order), node-type taints are sorted by key STRING (node_type.go:87-97) — intern taint keys in lexicographic order for the same first taint.
+ *      Not produced: for jobs that got a node (the nodes rejected before the match depend on the iterator's order: nothing is on record, 0 entries), and — as
+ *      ASCHED_ERR_UNSUPPORTED — for attempts that passed the feasibility gate and still ended without a node (urgency preemption disabled: the gate's early exit
+ *      makes the histogram order-dependent). ---- */
+typedef struct asched_excluded_reason {
+  int32_t kind;       /* ASCHED_EXCL_* */
+  int32_t a, b, c;
+  int64_t required, available;
+  int32_t count;
+  int32_t pad_;
+} asched_excluded_reason;
+#define ASCHED_EXCL_IMPLICIT 0
+#define ASCHED_EXCL_UNTOLERATED_TAINT 1
+#define ASCHED_EXCL_MISSING_LABEL 2
+#define ASCHED_EXCL_UNMATCHED_LABEL 3
+#define ASCHED_EXCL_UNMATCHED_AFFINITY 4
+#define ASCHED_EXCL_INSUFFICIENT_RESOURCES 5
+#define ASCHED_EXCL_DISALLOWED_RESOURCE 6
+
 /* ---- one unit of a submit check: SubmitChecker.getSchedulingResult's per-pool core (internal/scheduler/submitcheck.go:345-349):
  *      txn := nodeDb.Txn(true); ok, _, err := nodeDb.ScheduleManyWithTxn(txn, gctx); txn.Abort() ---- */
 typedef struct asched_submit_result {
@@ -347,6 +381,14 @@ int32_t ASCHED_FN(select_node)(asched_t*, int32_t job, int32_t pinned_node, asch
 int32_t ASCHED_FN(schedule_many)(asched_t*, int32_t n, const int32_t* jobs, const int32_t* pinned_nodes /*NULL*/,
                                  asched_pod_result* out /*[n]*/, int32_t* ok,
                                  int32_t* preempted, int32_t preempted_cap, int32_t* num_preempted);
+/* NumExcludedNodesByReason of `job`'s last node selection (select_node, schedule_many, gang_schedule, submit_check or a round), see asched_excluded_reason.
+   Entries ascending by (kind, a, b, c, required, available).  Returns the number of entries (the first `cap` are written; 0 = the job has no failed
+   selection on record: never attempted, skipped by scheduling key, or failed a constraint before any node was looked at), ASCHED_ERR_UNSUPPORTED as documented
+   above or when the record was dropped (more than the configured number of failed selections since the job table / round was set up, or more dynamic reasons
+   than the arena holds).  asched_set_excluded_nodes: how many failed selections are kept per round / job table (default 1024; 0 = none are recorded, and the one
+   wide pass per failed selection is not run). */
+int32_t ASCHED_FN(excluded_nodes)(asched_t*, int32_t job, asched_excluded_reason* out, int32_t cap);
+int32_t ASCHED_FN(set_excluded_nodes)(asched_t*, int32_t max_failed_selections);
 /* BindJobToNode+Upsert (nodedb.go:1046-1068), EvictJobsFromNode (:1079), UnbindJobFromNode (:1108) */
 int32_t ASCHED_FN(bind)(asched_t*, int32_t job, int32_t node, int32_t priority);
 int32_t ASCHED_FN(evict)(asched_t*, int32_t job, int32_t node);

@@ -431,7 +431,24 @@ def run_qs_case(lib: Library, case: dict):
     assert sorted(res.scheduled) == exp, f"expected scheduled {exp} got {sorted(res.scheduled)}"
     for i in case.get("ExpectedNeverAttemptedIndices") or []:
         assert i not in res.scheduled and res.job_unschedulable_reason[i] == 0, f"job {i} was attempted"
+    check_excluded_nodes(s, jobs, res.job_unschedulable_reason, len(case["Nodes"]))
     return "ok"
+
+
+def check_excluded_nodes(s, jobs, reasons, num_nodes):
+    """queue_scheduler_test.go:676-690: for every job that could not be scheduled and has a PodSchedulingContext, the counts of NumExcludedNodesByReason
+    add up to the number of nodes (gang members are exempt there too).  asched_excluded_nodes: [] = no failed node selection on record (never attempted, skipped
+    by key, failed a constraint first); ASCHED_ERR_UNSUPPORTED = documented as not produced."""
+    from armada_amd.binding import SchedError
+    for i, j in enumerate(jobs):
+        if reasons[i] == 0 or j.get("gang"):
+            continue
+        try:
+            h = s.excluded_nodes(i)
+        except SchedError:
+            continue
+        if h:
+            assert sum(x[-1] for x in h) == num_nodes, f"job {i}: NumExcludedNodesByReason {h} does not add up to {num_nodes} nodes"
 
 
 def run_gang_case(lib: Library, case: dict):
@@ -519,6 +536,9 @@ def run_nodedb_schedule_case(lib: Library, case: dict):
         ok, pods, _ = s.schedule_many(ids)
         assert ok == case["ExpectSuccess"][gi], f"group {gi}: success {ok}, expected {case['ExpectSuccess'][gi]}"
         if not ok:
+            if len(g) == 1:   # (the same property at NodeDb level: a single job that found no node accounts for every node)
+                h = s.excluded_nodes(ids[0])
+                assert h and sum(x[-1] for x in h) == len(case["Nodes"]), f"group {gi}: NumExcludedNodesByReason {h}"
             s.txn_abort()
             for n in before:  # the aborted transaction leaves the NodeDb exactly as it was
                 assert (s.get_alloc(n) == before[n]).all(), f"group {gi}: abort did not restore node {n}"

@@ -13,6 +13,7 @@
     python tests/soak.py ops 3000           # tests/test_z_nodedb_op_sequences.py NodeDb-level operation sequences
     python tests/soak.py submitcheck 400    # batched SubmitChecker vs the literal sequential restatement (and 3-entry cache)
     python tests/soak.py fit 600            # fit_select_batch at every priority on occupied NodeDbs
+    python tests/soak.py excluded 1000      # NumExcludedNodesByReason (asched_excluded_nodes) of every failed selection of a round, incl. literal rows / away types / off-grid requests
 
 SOAK_LIB=hip (on a GPU box): the same seeds through the product library instead of the CPU build.
 Prints one line per divergence and a summary; exit code 1 if anything diverged.  (Round 1: all clean after the submit-check fix.)
@@ -138,6 +139,14 @@ def main():
                 c = T.random_case(seed)
                 H.same_results(H.literal_check(orc, c), H.batched_check(hs, c))
                 H.same_results(H.literal_check(orc, c, cache_size=3), H.batched_check(hs, c, cache_size=3))
+            elif kind == "excluded":   # NumExcludedNodesByReason of every job whose node selection failed (tests/test_z_excluded_nodes.py): random rounds incl. literal rows, away types, off-grid requests
+                import test_z_excluded_nodes as X
+                rng = np.random.default_rng(seed)
+                wl = W.small_random(n_nodes=int(rng.integers(4, 200)), n_jobs=int(rng.integers(50, 1500)), n_queues=int(rng.integers(1, 10)), seed=seed,
+                                    occupied=float(rng.choice([0.0, 0.3, 0.6, 0.9, 1.0])), gangs=int(rng.integers(0, 8)),
+                                    burst=None if rng.random() < 0.7 else (int(rng.integers(10, 500)), int(rng.integers(5, 100))),
+                                    away=bool(rng.random() < 0.3), ragged=bool(rng.random() < 0.3), offgrid=int(rng.choice([0, 0, 1, 3])))
+                X.check_against_oracle(hs, orc, wl)
             elif kind == "fit":
                 rng = np.random.default_rng(seed)
                 wl = W.small_random(n_nodes=int(rng.integers(4, 200)), n_jobs=int(rng.integers(50, 2000)), n_queues=int(rng.integers(1, 8)), seed=seed,
