@@ -374,6 +374,8 @@ class Library:
     def _fn(self, name, restype, argtypes):
         if name in OPTIONAL_SYMBOLS and not hasattr(self.lib, self.prefix + name):
             return
+        if os.environ.get("ASCHED_AB_OLD_LIB") and not hasattr(self.lib, self.prefix + name):
+            return   # tools/ab_call.sh only: an older build of the library (A/B inside one GPU call) lacks the entry points added since
         fn = getattr(self.lib, self.prefix + name)
         fn.restype, fn.argtypes = restype, argtypes
         setattr(self, name, fn)

@@ -1217,6 +1217,16 @@ __device__ static inline bool pinnedNodeFits(KREF k, int q, int n, int level) {
   return __ballot(bad) == 0;
 }
 
+__device__ static inline void exclPinnedFast(Dev& d, KREF k, int q, int job, int n, int level) {
+  int lane = threadIdx.x & 63;
+  int64_t have = 0;
+  if (lane < k.R) have = __hip_atomic_load(&KAL(k, level, lane, n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool bad = lane < k.R && g_fl.headReq[q][lane] > have;
+  unsigned long long m = __ballot(bad);
+  if (!m) { if (lane == 0) d.excl[job] = EXCL_S_UNSUPPORTED; return; }
+  int res = __builtin_ctzll(m);
+  if (lane == res) { EXCL(d)->pinAvail[job] = have; d.excl[job] = EXCL_S_PINNED0 - res; }
+}
 __device__ static inline EvDyn evDynLoad(KREF k, int q, int job, int n, int level, bool wantMark, bool wantPin) {
   int lane = threadIdx.x & 63;
   // three independent loads, issued back to back; the first use below waits for all of them once

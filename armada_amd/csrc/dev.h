@@ -166,17 +166,25 @@ struct QueueLoopArrays {
 // ---- NumExcludedNodesByReason (asched_excluded_nodes): what the device keeps of a node selection that ended without a node.  The reasons that do not depend on the
 // round's state (taints, selectors, affinity, total resources) are worked out by the host when somebody asks; the device records what only it knows — which nodes the
 // iterator yielded at the job's priority (a bit per node) and, for the yielded nodes that pass the static checks, the first resource that did not fit and what was there.
-struct ExclRec { int32_t job, kind, level, row, uni, node, res, flags; int64_t avail; };   // kind: EXCL_K_*; flags bit 0: more dynamic reasons than the arena holds
+struct ExclRec { int32_t job, level, row, uni, flags, pad[3]; };   // flags bit 0: more dynamic reasons than the arena holds; bit 1: inconsistent (a yielded node that fits)
 struct ExclDyn { int32_t slot, node, res, pad; int64_t avail; };
 struct ExclDev {
-  int32_t* jobSlot;      // [M] -1 = nothing on record, -2 = dropped (more failed selections than `cap`), else the job's record
+  int32_t* jobSlot;      // [M] == Dev::excl: >= 0 the job's record of a failed attempt over the iterators; < 0 an EXCL_S_* code (the outcomes that need no record)
   ExclRec* rec;          // [cap]
   uint64_t* bits;        // [cap][W] nodes the iterator yielded
   ExclDyn* dyn;          // [dynCap] arena, tagged with the record
+  int64_t* pinAvail;     // [M] what the pinned node had of the resource that did not fit (EXCL_S_PINNED0 - resource)
   int32_t cap, dynCap, W, cur;   // cur: the record the pass in flight fills
   int32_t count, dynCount;
 };
-enum { EXCL_K_WIDE = 0, EXCL_K_PINNED = 1, EXCL_K_DISALLOWED = 2, EXCL_K_NONE = 3, EXCL_K_UNSUPPORTED = 4 };
+#define EXCL_S_NONE (-1)          // nothing on record
+#define EXCL_S_DROPPED (-2)       // more failed attempts than `cap` records
+#define EXCL_S_DISALLOWED (-3)    // a disallowed resource was requested: every node, one reason (nodedb.go:596-601)
+#define EXCL_S_NO_ATTEMPT (-4)    // no attempt was made (home scheduling disabled, no usable away type): every node implicit
+#define EXCL_S_UNSUPPORTED (-5)   // order-dependent in the reference: not produced
+#define EXCL_S_PINNED0 (-8)       // - resource column: a pinned (evicted) job whose node no longer covers that column (nodedb.go:583-594, 897-920)
+#define EXCL_HDR 256
+#define EXCL(d) ((ExclDev*)((char*)(d).excl - EXCL_HDR))
 
 // NodeTypeIterator state (nodeiteration.go:211-251): current lower bound (raw quantities), its packed form, the node it yielded last
 struct LitIt { int64_t lb[MAXK]; uint64_t bound; int32_t head; int32_t type; };
@@ -272,8 +280,10 @@ struct Dev {
   int64_t* accAvail;     // [N][R]
   int32_t* accStamp;     // [N]
   uint8_t* accStaticFailed;  // [N]
-  struct ExclDev* excl;  // failed node selections on record (asched_excluded_nodes; round_wide.h "excluded nodes"), or NULL: recording is off.  (In the slot of a retired
-                         // 4-byte field + its padding: sizeof(Dev) — the struct is copied into the round kernel's LDS — is unchanged.)
+  int32_t* excl;         // [M] failed node selections on record (asched_excluded_nodes; round_wide.h "excluded nodes"): -1 = none, -2 = dropped, else the job's record; NULL =
+                         // recording is off.  The store's header (ExclDev) sits EXCL_HDR bytes in front of it — one pointer here, and the hot path (a job that gets a node
+                         // forgets its record) is one store with no load in front of it.  (In the slot of a 4-byte field + its padding: sizeof(Dev), which the round
+                         // kernel copies into its LDS, is unchanged.)
   // per-node index of the evicted table for fair-share preemption (round_run.h ensureFairIndex): CSR node -> table Indexes, descending
   int32_t* fairOff;      // [Npad+2]
   int32_t* fairEnt;      // [M] evicted-table Index

@@ -93,8 +93,9 @@ DEV_COLD void ensureReplaySlow(Dev& d, Ctl& c);
 DEV int skipUnfeasibleRun(Dev& d, int pos, int max);   // round_fast.h: Peek's skip of known-unfeasible scheduling keys (queue_scheduler.go:398-413) for a stretch of queued jobs, 64 at a time
 DEV_COLD int wideRun(Dev& d, Ctl& c, const PassCfg& pc);
 DEV bool wideHeadOk(Dev& d, const Ctl& c, const PassCfg& pc, int t);
-DEV_COLD void exclRecord(Dev& d, int job, int kind, int node, int level);   // round_wide.h "excluded nodes": what asched_excluded_nodes needs of a selection that ended without a node
-DEV void exclForget(Dev& d, int job) { if (d.excl && d.excl->jobSlot[job] != -1) d.excl->jobSlot[job] = -1; }   // the job got a node: its PodSchedulingContext is a new one
+DEV_COLD void exclRecordWide(Dev& d, int job, int level);   // round_wide.h "excluded nodes": what asched_excluded_nodes needs of an attempt that found no node at the job's priority
+DEV_COLD void exclPinned(Dev& d, int job, int node, int level);
+DEV void exclForget(Dev& d, int job) { if (d.excl) d.excl[job] = -1; }   // the job got a node: its PodSchedulingContext is a new one
 DEV void ensureReplay(Dev& d, Ctl& c) { if (d.rs->replayPending) ensureReplaySlow(d, c); }   // (the test stays with the caller: a call costs a register save / restore)
 //             // run the deferred eviction-order replay before anything reads the evicted table         // leave fast mode: LDS queue state back into the generic arrays, HBM updates visible
 
@@ -850,16 +851,16 @@ DEV int selectNodeForJob(Dev& d, Ctl& c, int job) {
     bool ok = (d.nodeFlags[pinned] & 1) || fitsAlloc(d, JREQ(d, job), level, pinned);
     d.pcMethod[job] = ASCHED_METHOD_RESCHEDULED;
     if (ok) { d.pcNode[job] = pinned; d.pcPap[job] = prio; exclForget(d, job); return pinned; }
-    if (d.excl) exclRecord(d, job, EXCL_K_PINNED, pinned, level);
+    if (d.excl) exclPinned(d, job, pinned, level);
     return -1;
   }
   const int64_t* req = JREQ(d, job);
-  for (int r = 0; r < d.cfg.R; r++) if (d.cfg.disallowed[r] && req[r] > 0) { if (d.excl) exclRecord(d, job, EXCL_K_DISALLOWED, -1, 0); return -1; }  // :596-601
+  for (int r = 0; r < d.cfg.R; r++) if (d.cfg.disallowed[r] && req[r] > 0) { if (d.excl) d.excl[job] = EXCL_S_DISALLOWED; return -1; }  // :596-601
   bool recorded = false;
   if (!d.cfg.disableHome) {
     int n = selectAtPriority(d, c, job);
     if (n >= 0) { exclForget(d, job); return n; }
-    if (d.excl && !d.rs->error) { exclRecord(d, job, n == -2 ? EXCL_K_UNSUPPORTED : EXCL_K_WIDE, -1, levelOf(d.cfg, d.pcSap[job])); recorded = true; }
+    if (d.excl && !d.rs->error) { if (n == -2) d.excl[job] = EXCL_S_UNSUPPORTED; else exclRecordWide(d, job, levelOf(d.cfg, d.pcSap[job])); recorded = true; }
   }
   if (d.cfg.hasAway) {
     bool awayDisabled = d.cfg.disableAway || (d.jGang[job] >= 0 && d.cfg.disableGangAway);
@@ -870,14 +871,14 @@ DEV int selectNodeForJob(Dev& d, Ctl& c, int job) {
         d.rs->awayRowPlus1 = d.cfg.S + d.awayRowOff[s] + (k - d.cfg.pcAwayOff[pc]) + 1;
         d.pcSap[job] = d.cfg.awayPrio[k];      // :719 (stays at the last away priority when every attempt fails)
         int n = selectAtPriority(d, c, job);
-        if (n < 0 && d.excl && !d.rs->error) { exclRecord(d, job, n == -2 ? EXCL_K_UNSUPPORTED : EXCL_K_WIDE, -1, levelOf(d.cfg, d.pcSap[job])); recorded = true; }   // (this attempt's row: the last one stays, nodedb.go:736,748)
+        if (n < 0 && d.excl && !d.rs->error) { if (n == -2) d.excl[job] = EXCL_S_UNSUPPORTED; else exclRecordWide(d, job, levelOf(d.cfg, d.pcSap[job])); recorded = true; }   // (this attempt's row: the last one stays, nodedb.go:736,748)
         d.rs->awayRowPlus1 = 0;
         if (d.rs->error) return -1;
         if (n >= 0) { d.pcMethod[job] = ASCHED_METHOD_AWAY; exclForget(d, job); return n; }
       }
     }
   }
-  if (d.excl && !recorded) exclRecord(d, job, EXCL_K_NONE, -1, 0);   // (no attempt at all — home scheduling disabled, no usable away type — leaves every node implicit, nodedb.go:566-580)
+  if (d.excl && !recorded) d.excl[job] = EXCL_S_NO_ATTEMPT;   // (no attempt at all — home scheduling disabled, no usable away type — leaves every node implicit, nodedb.go:566-580)
   return -1;
 }
 

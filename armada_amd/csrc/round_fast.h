@@ -413,6 +413,7 @@ DEV void engineStart(Dev& d, FastS& S);
 DEV void engineStop(Dev& d, FastS& S);
 DEV bool headRequestsDisallowed(Dev& d, KREF k, int q);
 DEV bool pinnedNodeFits(KREF k, int q, int n, int level);
+DEV void exclPinnedFast(Dev& d, KREF k, int q, int job, int n, int level);   // the lane-parallel form of round_wide.h exclPinned (lane r: resource column r)
 DEV EvDyn evDynLoad(KREF k, int q, int job, int n, int level, bool wantMark, bool wantPin);   // a returning evicted job's preempted mark and its pinned-node check, their loads in flight together
 // per-queue state of a stream run, held in the lanes of the control wave (lane q: queue q): position at the start of the run, list position of element 0,
 // merge cursor, length, kind (bit 0: evicted stream, bit 1: the queue's evicted list was folded (running-maximum key)), first element of the key window in
@@ -1026,7 +1027,7 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
         // other sum is back where it was.  No unfeasible-key registration: an evicted job's key is not valid (context/job.go:104-109).
         if (f.evApplied < f.evDone) { applyEvictedRange(d, q, f.evApplied, f.evDone); S.numEvictedJobs -= f.evDone - f.evApplied; }
         f.evApplied = f.evDone = f.headPos + 1;
-        if (d.excl) exclRecord(d, job, EXCL_K_PINNED, n, level);   // (asched_excluded_nodes: the dynamic reason on its node)
+        if (d.excl) exclPinnedFast(d, k, q, job, n, level);   // (asched_excluded_nodes: the dynamic reason on its node; inline — a call here costs the whole loop registers)
         if (evInRound) FOR_LANES(x, k.R) {
           int64_t v = FL.headReq[q][x];
           if (v) {

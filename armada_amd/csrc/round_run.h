@@ -292,7 +292,7 @@ DEV void bulkElem(Dev& d, int kind, int i) {
       d.pcMethod[i] = 0; d.jcGangCard[i] = d.jGang[i] >= 0 ? d.jGangCard[i] : 1; d.jcPreempted[i] = 0; d.jcUniValue[i] = -1; d.jcStagedBy[i] = -1;
       d.inPreempted[i] = d.inScheduled[i] = d.inSchedAndEvicted[i] = 0; d.preemptedNode[i] = -1; d.evFlag[i] = 0;
       d.evTabAlive[i] = 0; d.evIndexOfJob[i] = -1;
-      if (d.excl) { d.excl->jobSlot[i] = -1; if (i == 0) { d.excl->count = 0; d.excl->dynCount = 0; } }   // (asched_excluded_nodes: a round starts with nothing on record)
+      if (d.excl) { d.excl[i] = -1; if (i == 0) { EXCL(d)->count = 0; EXCL(d)->dynCount = 0; } }   // (asched_excluded_nodes: a round starts with nothing on record)
     } break;
     case B_POPULATE: {  // populateNodeDb: bind every running job (nodedb.go:57-75, scheduling_algo.go:1019-1098)
       int n = d.jNode0[i];

@@ -73,7 +73,7 @@ DEV void exclDynPut(Dev& d, ExclDev& x, int slot, int n, int level, const int64_
 }
 DEV void exclBulk(Dev& d, int n) {
   const DevCfg& c = d.cfg;
-  ExclDev& x = *d.excl;
+  ExclDev& x = *EXCL(d);
   const int slot = x.cur;
   const ExclRec& r = x.rec[slot];
   const int64_t* req = JREQ(d, r.job);
@@ -428,7 +428,7 @@ DEV_COLD void exclLiteral(Dev& d, ExclDev& x, int slot) {
   int64_t ireq[MAXK];
   for (int i = 0; i < c.K; i++) ireq[i] = req[c.indexedCol[i]];
   int t0 = d.rowTypeOff[r.row], nT = d.rowTypeOff[r.row + 1] - t0;
-  if (nT > LIT_TMAX) { x.rec[slot].kind = EXCL_K_UNSUPPORTED; return; }
+  if (nT > LIT_TMAX) { d.excl[r.job] = EXCL_S_UNSUPPORTED; return; }
   for (int k = 0; k < nT; k++) {
     LitIt& it = d.lit[k];
     it.type = d.rowTypes[t0 + k];
@@ -450,28 +450,31 @@ DEV_COLD void exclLiteral(Dev& d, ExclDev& x, int slot) {
     }
   }
 }
-// the record of a selection that ended without a node (round_ctl.h selectNodeForJob; round_fast.h: an evicted job that no longer fits on its node)
-DEV_COLD void exclRecord(Dev& d, int job, int kind, int node, int level) {
-  ExclDev& x = *d.excl;
-  if (x.cap <= 0) return;
-  int slot = x.jobSlot[job];
-  if (slot == -2) return;
+// the record of an attempt that found no node at the job's priority (round_ctl.h selectNodeForJob)
+DEV_COLD void exclRecordWide(Dev& d, int job, int level) {
+  ExclDev& x = *EXCL(d);
+  int slot = d.excl[job];
+  if (slot == EXCL_S_DROPPED) return;
   if (slot < 0) {
     int cnt = x.count;
-    if (cnt >= x.cap) { x.jobSlot[job] = -2; return; }
-    slot = cnt; x.count = cnt + 1; x.jobSlot[job] = slot;
+    if (cnt >= x.cap) { d.excl[job] = EXCL_S_DROPPED; return; }
+    slot = cnt; x.count = cnt + 1; d.excl[job] = slot;
   }
   ExclRec r;
-  r.job = job; r.kind = kind; r.level = level; r.row = d.rs->awayRowPlus1 ? d.rs->awayRowPlus1 - 1 : d.jShape[job]; r.uni = d.jcUniValue[job]; r.node = node; r.res = -1; r.flags = 0; r.avail = 0;
-  if (kind == EXCL_K_PINNED) {   // DynamicJobRequirementsMet's reason on the one node (nodedb.go:897-920)
-    const int64_t* req = JREQ(d, job);
-    for (int q = 0; q < d.cfg.R; q++) if (r.res < 0 && req[q] > AL(d, level, q, node)) { r.res = q; r.avail = AL(d, level, q, node); }
-  }
+  r.job = job; r.level = level; r.row = d.rs->awayRowPlus1 ? d.rs->awayRowPlus1 - 1 : d.jShape[job]; r.uni = d.jcUniValue[job]; r.flags = 0; r.pad[0] = r.pad[1] = r.pad[2] = 0;
   x.rec[slot] = r;
-  if (kind != EXCL_K_WIDE) return;
   if (d.rowLiteral && d.rowLiteral[r.row]) { exclLiteral(d, x, slot); return; }
   x.cur = slot;
   wgWide(d, W_EXCL, x.W * 64);
+}
+// a pinned (evicted) job that no longer fits on its node: DynamicJobRequirementsMet's reason on that one node (nodedb.go:897-920) — the first column in factory order
+DEV_COLD void exclPinned(Dev& d, int job, int node, int level) {
+  const int64_t* req = JREQ(d, job);
+  int res = -1; int64_t av = 0;
+  for (int q = 0; q < d.cfg.R; q++) if (res < 0 && req[q] > AL(d, level, q, node)) { res = q; av = AL(d, level, q, node); }
+  if (res < 0) { d.excl[job] = EXCL_S_UNSUPPORTED; return; }
+  EXCL(d)->pinAvail[job] = av;
+  d.excl[job] = EXCL_S_PINNED0 - res;
 }
 
 

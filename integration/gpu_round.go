@@ -39,13 +39,17 @@ import (
 	"github.com/armadaproject/armada/internal/scheduler/configuration"
 	"github.com/armadaproject/armada/internal/scheduler/internaltypes"
 	"github.com/armadaproject/armada/internal/scheduler/jobdb"
+	"github.com/armadaproject/armada/internal/scheduler/nodedb"
 	schedulerconstraints "github.com/armadaproject/armada/internal/scheduler/scheduling/constraints"
 	schedulercontext "github.com/armadaproject/armada/internal/scheduler/scheduling/context"
 	"github.com/armadaproject/armada/internal/scheduler/scheduling/pricer"
 )
 
 // interner: strings -> dense ids (label / taint keys and values).
-type interner struct{ ids map[string]int32 }
+type interner struct {
+	ids  map[string]int32
+	strs []string // id -> string (ExcludedNodes formats the reference's reason strings from ids)
+}
 
 func newInterner() *interner { return &interner{ids: map[string]int32{}} }
 func (in *interner) id(s string) int32 {
@@ -54,7 +58,14 @@ func (in *interner) id(s string) int32 {
 	}
 	v := int32(len(in.ids))
 	in.ids[s] = v
+	in.strs = append(in.strs, s)
 	return v
+}
+func (in *interner) str(id int32) string {
+	if id < 0 || int(id) >= len(in.strs) {
+		return ""
+	}
+	return in.strs[id]
 }
 
 // rank of every string of xs in lexicographic order (ties cannot occur: names are unique).
@@ -361,6 +372,22 @@ func (g *GpuRound) UploadNodes(nodes []*internaltypes.Node) error {
 	unsched, over := make([]uint8, n), make([]uint8, n)
 	tOff, tKey, tVal, tEff := make([]int32, 1, n+1), []int32{}, []int32{}, []int32{}
 	lOff, lKey, lVal := make([]int32, 1, n+1), []int32{}, []int32{}
+	{ // taint keys first, in lexicographic order: the library reports the FIRST untolerated taint of a node type in ascending key id, the reference in ascending key string (node_type.go:87-97)
+		keys := map[string]bool{}
+		for _, node := range nodes {
+			for _, t := range node.GetTaints() {
+				keys[t.Key] = true
+			}
+		}
+		sorted := make([]string, 0, len(keys))
+		for k := range keys {
+			sorted = append(sorted, k)
+		}
+		sort.Strings(sorted)
+		for _, k := range sorted {
+			g.strs.id(k)
+		}
+	}
 	for i, node := range nodes {
 		ids[i], index[i] = node.GetId(), node.GetIndex()
 		g.nodePos[node.GetId()] = int32(i)
@@ -978,6 +1005,68 @@ func (g *GpuRound) SubmitCheck(off, jobs, flags []int32) ([]C.asched_submit_resu
 // ---- one pool on several GPUs: the handle's communicator (include/armada_sched.h "The communicator"; no reference counterpart — FairSchedulingAlgo runs a pool on
 // one goroutine, scheduling_algo.go:165).  The library enqueues ncclAllReduce itself on the handle's stream; the Go side only moves the 128-byte unique id between
 // the scheduler replicas (one process — or one locked OS thread — per GPU) through whatever it already has: the leader's gRPC, a Pulsar message, a shared file.
+
+// ExcludedNodes is PodSchedulingContext.NumExcludedNodesByReason (scheduling/context/pod.go:51) for a job whose last node selection ended without a node:
+// asched_excluded_nodes returns what the reference's reason strings are made of (interned ids, a resource column and two raw quantities) and the strings are
+// built here with the reference's OWN reason types (nodedb/nodematching.go:14-125), so a report prints what the CPU scheduler would print.  nil, nil = nothing on
+// record (the job got a node, was never attempted, or failed a constraint before any node was looked at).  For the first untolerated taint of a node type to be
+// the reference's (node_type.go:87-97 sorts taints by key STRING) UploadNodes interns the taint keys in lexicographic order before anything else.
+func (g *GpuRound) ExcludedNodes(job int32) (map[string]int, error) {
+	buf := make([]C.asched_excluded_reason, 64)
+	n := C.asched_excluded_nodes(g.h, C.int32_t(job), &buf[0], C.int32_t(len(buf)))
+	if int(n) > len(buf) {
+		buf = make([]C.asched_excluded_reason, int(n))
+		n = C.asched_excluded_nodes(g.h, C.int32_t(job), &buf[0], C.int32_t(len(buf)))
+	}
+	if n < 0 {
+		return nil, g.check(n)
+	}
+	if n == 0 {
+		return nil, nil
+	}
+	quantity := func(col C.int32_t, raw C.int64_t) k8sResource.Quantity { // ResourceList.asQuantity (resource_list.go:292-301): raw * 10^scale of the column
+		scale, _ := g.rlf.GetScale(g.resNames[col])
+		return *k8sResource.NewScaledQuantity(int64(raw), scale)
+	}
+	out := make(map[string]int, int(n))
+	for _, r := range buf[:n] {
+		var s string
+		switch r.kind {
+		case C.ASCHED_EXCL_IMPLICIT:
+			s = nodedb.PodRequirementsNotMetReasonInsufficientResources
+		case C.ASCHED_EXCL_UNTOLERATED_TAINT:
+			t := v1.Taint{Key: g.strs.str(int32(r.a)), Value: g.strs.str(int32(r.b)), Effect: effectName(int32(r.c))}
+			if r.a == -2 { // the taint an unschedulable node carries (internaltypes/unschedulable.go:12-18, node.go:127-129)
+				t = internaltypes.UnschedulableTaint()
+			}
+			s = (&nodedb.UntoleratedTaint{Taint: t}).String()
+		case C.ASCHED_EXCL_MISSING_LABEL:
+			s = (&nodedb.MissingLabel{Label: g.strs.str(int32(r.a))}).String()
+		case C.ASCHED_EXCL_UNMATCHED_LABEL:
+			s = (&nodedb.UnmatchedLabel{Label: g.strs.str(int32(r.a)), PodValue: g.strs.str(int32(r.b)), NodeValue: g.strs.str(int32(r.c))}).String()
+		case C.ASCHED_EXCL_UNMATCHED_AFFINITY:
+			s = (&nodedb.UnmatchedNodeSelector{NodeSelector: g.jobs[job].PodRequirements().GetAffinityNodeSelector()}).String()
+		case C.ASCHED_EXCL_INSUFFICIENT_RESOURCES:
+			s = (&nodedb.InsufficientResources{ResourceName: g.resNames[r.a], Required: quantity(r.a, r.required), Available: quantity(r.a, r.available)}).String()
+		case C.ASCHED_EXCL_DISALLOWED_RESOURCE:
+			s = "job requests disallowed resource and therefore cannot be scheduled" // nodedb.disallowedResourceRequested (nodedb.go:27, unexported)
+		}
+		out[s] += int(r.count)
+	}
+	return out, nil
+}
+
+func effectName(e int32) v1.TaintEffect {
+	switch e {
+	case C.ASCHED_EFFECT_NO_SCHEDULE:
+		return v1.TaintEffectNoSchedule
+	case C.ASCHED_EFFECT_PREFER_NO_SCHEDULE:
+		return v1.TaintEffectPreferNoSchedule
+	case C.ASCHED_EFFECT_NO_EXECUTE:
+		return v1.TaintEffectNoExecute
+	}
+	return ""
+}
 
 // CommUniqueId is called by ONE rank (ncclGetUniqueId); every rank then passes the same bytes to CommInit.
 func CommUniqueId() ([128]byte, error) {

@@ -180,6 +180,7 @@ DEV bool pinnedNodeFits(KREF k, int q, int n, int level) {
   for (int x = 0; x < k.R; x++) if (FL.headReq[q][x] > KAL(k, level, x, n)) return false;
   return true;
 }
+DEV void exclPinnedFast(Dev& d, KREF, int, int job, int n, int level) { exclPinned(d, job, n, level); }
 DEV EvDyn evDynLoad(KREF k, int q, int job, int n, int level, bool wantMark, bool wantPin) {
   EvDyn r; r.preempted = wantMark ? (int)k.jcPreempted[job] : 0; r.fits = (!wantPin || pinnedNodeFits(k, q, n, level)) ? 1 : 0;
   return r;

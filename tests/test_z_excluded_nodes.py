@@ -247,7 +247,9 @@ def test_record_limit_and_switch(lib, oracle_lib):
     _, two = histograms(lib, wl, lambda s: s.set_excluded_nodes(2))
     kept = [j for j in with_record if two[j] and two[j][0] != "error"]
     dropped = [j for j in with_record if two[j] and two[j][0] == "error"]
-    assert len(kept) == 2 and len(dropped) == len(with_record) - 2          # the rest fail loudly: ASCHED_ERR_UNSUPPORTED, not a wrong histogram
+    # two records of attempts over the iterators are kept (the fixed-size outcomes — a pinned job's node, a disallowed resource — need none); the rest fail loudly
+    # (ASCHED_ERR_UNSUPPORTED), not with a wrong histogram
+    assert len(dropped) > 5 and len(kept) + len(dropped) == len(with_record)   # (which ones: compared with the oracle below — pinned outcomes need no record and are never dropped)
     assert all(two[j] == full[j] for j in kept)
     _, otwo = histograms(oracle_lib, wl, lambda s: s.set_excluded_nodes(2))
     assert {j: (h if not h or h[0] != "error" else "error") for j, h in two.items()} == {j: (h if not h or h[0] != "error" else "error") for j, h in otwo.items()}

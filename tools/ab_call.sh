@@ -4,11 +4,13 @@
 # workloads: headline | gangs | preempt | preempt_full | q256 | q1024 (tools/prof_config4.py); the optional pytest -k expression runs on the working tree's build afterwards.
 # (round 4's one-off call scripts gpu_call_r4a … r4j were each an instance of this; their outputs are under profiles/r04*.)
 set -u
+export ASCHED_AB_OLD_LIB=1   # (armada_amd/binding.py: tolerate entry points an older build lacks)
 TAG=${1:-ab}; LIBS=${2:-"base new"}; WHAT=${3:-"headline gangs preempt"}; KEXPR=${4:-}
 OUT=gpurun_out/$TAG; mkdir -p "$OUT"
 for rep in 1 2; do
   for L in $LIBS; do
     P=$PWD/armada_amd/csrc/libarmada_sched_$L.so; [ $L = new ] && P=$PWD/armada_amd/csrc/libarmada_sched.so
+    unset ASCHED_EXCLUDED_NODES; [ $L = new_norec ] && { P=$PWD/armada_amd/csrc/libarmada_sched.so; export ASCHED_EXCLUDED_NODES=0; }   # the tree's build without the failed-selection records
     for W in $WHAT; do
       echo "== $L $W (rep $rep)" >> "$OUT/ab.txt"
       case $W in
@@ -21,5 +23,6 @@ for rep in 1 2; do
     done
   done
 done
+unset ASCHED_EXCLUDED_NODES ASCHED_AB_OLD_LIB
 if [ -n "$KEXPR" ]; then timeout 900 python -m pytest tests -q -m gpu -k "$KEXPR" -p no:cacheprovider > "$OUT/pytest_ab.log" 2>&1; echo "pytest rc=$?" >> "$OUT/ab.txt"; tail -n 5 "$OUT/pytest_ab.log" >> "$OUT/ab.txt"; fi
 cat "$OUT/ab.txt"
