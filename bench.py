@@ -110,6 +110,16 @@ def cpu_baseline(wl, budget_s, full_iters):
     dt = float(np.mean(times))
     iters = max(1, r.num_loop_iterations)
     scaled = dt * (full_iters / iters) if (cut and full_iters > iters) else dt
+    excluded = {}
+    if not cut:   # NumExcludedNodesByReason of a sample of the jobs whose node selection failed (asched_excluded_nodes): compared with the GPU round's by the caller
+        from armada_amd.binding import SchedError
+        reasons = np.asarray(r.job_unschedulable_reason)
+        fit = np.nonzero((reasons == 10) | (reasons == 11))[0]   # ASCHED_REASON_GANG_DOES_NOT_FIT / JOB_DOES_NOT_FIT: the ones a node selection failed for
+        for j in list(fit[:EXCLUDED_SAMPLE]) + list(np.nonzero(reasons)[0][:EXCLUDED_SAMPLE // 8]):
+            try:
+                excluded[int(j)] = s.excluded_nodes(int(j))
+            except SchedError:
+                excluded[int(j)] = "not produced"
     s.close()
     rec = {"value": 1.0 / scaled, "unit": "rounds/s", "cores": 1, "kind": "port",
            "sample": f"oracle (C++ restatement of the reference algorithm, 1 thread) on the same {wl.num_nodes}-node/{wl.num_jobs}-job input, {len(times)} round(s) "
@@ -117,7 +127,31 @@ def cpu_baseline(wl, budget_s, full_iters):
                      + (", scaled by the iteration ratio: an upper bound of the CPU time, the evicted-job phases do not shrink with the burst)" if cut else ")"),
            "measured_s": dt, "measured_rounds_s": [round(t, 4) for t in times], "measured_iterations": iters, "rounds": len(times), "upper_bound_extrapolation": bool(cut),
            "pinned_core": pinned[1] if pinned else None}
+    if not cut:
+        r.excluded_sample = excluded
     return rec, (None if cut else r)
+
+
+EXCLUDED_SAMPLE = 128
+
+
+def excluded_parity(s, oracle_res):
+    """the exclusion histograms (why a job found no node) of the oracle round's sample against the GPU handle's records of the same round"""
+    from armada_amd.binding import SchedError
+    exp = getattr(oracle_res, "excluded_sample", None)
+    if not exp:
+        return {"checked": False}
+    bad, with_record = [], 0
+    for j, h in exp.items():
+        try:
+            g = s.excluded_nodes(j)
+        except SchedError:
+            g = "not produced"
+        with_record += bool(h) and h != "not produced"
+        if g != h:
+            bad.append(j)
+    return {"checked": True, "identical": not bad, "jobs": len(exp), "with_a_failed_selection_on_record": int(with_record), "differing_jobs": bad[:8],
+            "what": "NumExcludedNodesByReason (asched_excluded_nodes) of the first jobs with an unschedulable reason: GPU records vs the oracle's walk"}
 
 
 # ------------------------------------------------------------------------------------------------ --submit-check
@@ -803,7 +837,8 @@ def main():
             out["cpu_baseline"], ores = cpu_baseline(wl, args.cpu_budget, iters)
             if ores is not None:  # the headline number is self-verifying: the timed GPU round against the oracle round on the same input
                 out["parity"] = parity_record(res, ores, wl.num_jobs, "oracle round of the cpu_baseline leg, same input")
-                if not out["parity"]["identical"]:
+                out["parity"]["excluded_nodes"] = excluded_parity(s, ores)
+                if not out["parity"]["identical"] or out["parity"]["excluded_nodes"].get("identical") is False:
                     rc = 3
             else:
                 out["parity"] = {"checked": False, "reason": "cpu_baseline ran with a cut burst (--cpu-budget)"}

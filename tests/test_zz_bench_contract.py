@@ -49,6 +49,8 @@ def test_round_bench_line(fake_gpu, monkeypatch, capsys):
     assert line["steps"] == 2 and line["warmup"] == 1 and line["unit"] == "rounds/s" and line["round"]["scheduled"] > 0
     # the headline is self-verifying: the timed round is compared with the oracle round of the cpu_baseline leg
     assert line["parity"] == dict(line["parity"], checked=True, identical=True) and line["parity"]["jobs"] > 5000
+    ex = line["parity"]["excluded_nodes"]   # why a job found no node: the records of the timed round against the oracle's walk, for a sample of the failed jobs
+    assert ex["checked"] and ex["identical"] and ex["jobs"] > 0 and ex["with_a_failed_selection_on_record"] >= 0, ex   # (the toy round's failures are rate limits: none may have a record)
     assert 1 <= line["cpu_baseline"]["rounds"] <= 3 and line["cpu_baseline"]["upper_bound_extrapolation"] is False   # (up to three oracle rounds when a round is short)
     # every other BASELINE config + the submit check sits in the same record, each with roofline and cpu_baseline
     oc = {r["config"]: r for r in line["other_configs"]}
