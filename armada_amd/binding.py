@@ -737,7 +737,7 @@ class Scheduler:
     def submit_stats(self):
         out = (C.c_int32 * 4)()
         self._check(self.lib.submit_stats(self.h, out))
-        return dict(wide_units=out[0], wide_passes=out[1], sequential_units=out[2])
+        return dict(wide_units=out[0], wide_passes=out[1], sequential_units=out[2], gang_units=out[3])
 
     def select_node(self, job: int, pinned_node: int = -1):
         out = CPodResult()

@@ -2632,6 +2632,28 @@ extern "C" int asched_internal_mgpu_pack(const Dev* d, const GlobalKeyLayout* L,
 extern "C" int asched_internal_mgpu_delta(const Dev* d, long long* buf, int ns, int np, hipStream_t s);
 extern "C" int asched_internal_mgpu_resolve(const Dev* d, const long long* red, long long* freeC, uint8_t* ownPre, uint8_t* conflict, uint8_t* gangReplay,
                                             int32_t* node, int32_t* prio, uint8_t* replay, int32_t* counts, int ns, int np, hipStream_t s);
+// the submit check's gang units, one workgroup per unit (submit_gang.h; the kernel lives in armada_sched_mgpu.hip).  out: 4 words per unit; the kernel time goes to lastFitMs
+extern "C" int asched_internal_submit_gangs(const Dev* d, const int32_t* off, const int32_t* jobs, int nu, int32_t* out, hipStream_t s);
+#define SG_MAX_NODES 262144   // the workgroup's node bitmap lives in LDS (32 KB at this size)
+static int plat_run_submit_gangs(Dev& d, const std::vector<int32_t>& off, const std::vector<int32_t>& jobs, std::vector<int32_t>& out) {
+  int nu = (int)off.size() - 1;
+  out.assign((size_t)std::max(nu, 0) * 4, 0);
+  if (nu <= 0) return 0;
+  hipStream_t st = t_ctx->stream;
+  int32_t *dOff = nullptr, *dJobs = nullptr, *dOut = nullptr;
+  bool ok = hipOk(hipMalloc(&dOff, off.size() * 4), "hipMalloc") && hipOk(hipMalloc(&dJobs, std::max<size_t>(jobs.size(), 1) * 4), "hipMalloc") && hipOk(hipMalloc(&dOut, out.size() * 4), "hipMalloc");
+  if (ok) {
+    (void)hipMemcpyAsync(dOff, off.data(), off.size() * 4, hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(dJobs, jobs.data(), jobs.size() * 4, hipMemcpyHostToDevice, st);
+    (void)hipEventRecord(t_ctx->fitEv0, st);
+    ok = asched_internal_submit_gangs(&d, dOff, dJobs, nu, dOut, st) == 0;
+    (void)hipEventRecord(t_ctx->fitEv1, st);
+    ok = ok && hipOk(hipMemcpyAsync(out.data(), dOut, out.size() * 4, hipMemcpyDeviceToHost, st), "hipMemcpy") && hipOk(hipStreamSynchronize(st), "k_submit_gangs");
+    (void)hipEventElapsedTime(&t_ctx->lastFitMs, t_ctx->fitEv0, t_ctx->fitEv1);
+  }
+  if (dOff) (void)hipFree(dOff); if (dJobs) (void)hipFree(dJobs); if (dOut) (void)hipFree(dOut);
+  return ok ? 0 : -1;
+}
 // a caller-side buffer may be memory of this handle's GPU (a tensor the collective reduces in place: used directly) or host memory (staged)
 static bool plat_is_device_ptr(const void* p) {
   hipPointerAttribute_t a;

@@ -1,5 +1,5 @@
-// armada_sched_mgpu.hip — third translation unit of libarmada_sched.so: the grid kernels that produce and consume the words of the
-// multi-GPU exchanges: one element per thread over queries / result rows / nodes / jobs, all plain coalesced streaming
+// armada_sched_mgpu.hip — third translation unit of libarmada_sched.so: grid kernels outside the round kernel's code object — the ones that produce and consume the words of the
+// multi-GPU exchanges, and since round 4 the submit check's gang units, one workgroup per unit (submit_gang.h): one element per thread over queries / result rows / nodes / jobs, all plain coalesced streaming
 // (the per-element logic is mgpu.h, shared with the CPU build of the tests).  A separate code object so that nothing here moves the
 // round kernel's code (k_control is placement-sensitive: DESIGN.md 9).
 #include <hip/hip_runtime.h>
@@ -74,5 +74,38 @@ extern "C" int asched_internal_mgpu_resolve(const Dev* d, const long long* red, 
   if (N > 0) hipLaunchKernelGGL(k_mgpu_conflict, dim3(mgBlocks(N)), dim3(MG_THREADS), 0, s, *d, red, freeC, conflict, counts);
   if (M > 0) hipLaunchKernelGGL(k_mgpu_gang, dim3(mgBlocks(M)), dim3(MG_THREADS), 0, s, *d, red, conflict, gangReplay);
   if (M > 0) hipLaunchKernelGGL(k_mgpu_outcome, dim3(mgBlocks(M)), dim3(MG_THREADS), 0, s, *d, red, conflict, gangReplay, node, prio, replay, counts);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ------------------------------------------------------------------------------------------------ submit check: gang units, one workgroup each (submit_gang.h)
+#define SG_FN __device__ static inline
+#define SG_TID ((int)threadIdx.x)
+#define SG_NT ((int)blockDim.x)
+#define SG_SYNC() __syncthreads()
+struct SgShared;
+__device__ static inline unsigned long long sgWgMin(SgShared& s, unsigned long long v);
+#define SG_WGMIN(s, v) sgWgMin(s, v)
+#include "submit_gang.h"
+__device__ static inline unsigned long long sgWgMin(SgShared& s, unsigned long long v) {
+  for (int off = 32; off; off >>= 1) { unsigned long long o = __shfl_xor(v, off, 64); v = o < v ? o : v; }
+  __syncthreads();                                   // (the previous reduction's readers are done with wmin)
+  if ((threadIdx.x & 63) == 0) s.wmin[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned long long r = s.wmin[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); w++) r = s.wmin[w] < r ? s.wmin[w] : r;
+  return r;
+}
+#define SG_THREADS 256
+__global__ __launch_bounds__(SG_THREADS) void k_submit_gangs(Dev d, const int32_t* off, const int32_t* jobs, int nu, int32_t* out) {
+  extern __shared__ uint32_t sgBits[];               // a bit per node: an earlier member of the unit in flight sits there
+  __shared__ SgShared s;
+  for (int i = threadIdx.x; i < (d.cfg.N + 31) / 32; i += SG_THREADS) sgBits[i] = 0;
+  __syncthreads();
+  for (int u = blockIdx.x; u < nu; u += gridDim.x) submitGangUnit(d, jobs + off[u], off[u + 1] - off[u], s, sgBits, out + 4 * (size_t)u);
+}
+extern "C" int asched_internal_submit_gangs(const Dev* d, const int32_t* off, const int32_t* jobs, int nu, int32_t* out, hipStream_t st) {
+  if (nu <= 0) return 0;
+  size_t lds = (size_t)((d->cfg.N + 31) / 32) * 4;
+  hipLaunchKernelGGL(k_submit_gangs, dim3(nu < 4096 ? nu : 4096), dim3(SG_THREADS), lds, st, *d, off, jobs, nu, out);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

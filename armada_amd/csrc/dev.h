@@ -192,6 +192,7 @@ struct LitIt { int64_t lb[MAXK]; uint64_t bound; int32_t head; int32_t type; };
 // ---- wide runs (round_wide.h): stream runs for pools of more than QCAPF queues.  Per queue a stream of at most WIDE_L entries — its remaining cheap evicted jobs, then
 // its next single queued jobs — with precomputed queue-order keys; the k-way merge of QueueCandidateGangIteratorPQ over them is a BULK RANK (every entry counts, by binary
 // search in every other queue's monotone key sequence, the entries that order before it) instead of a lane per queue.
+#define SG_TMAX 256           // submit check, gang units one workgroup each (submit_gang.h): members per unit (nodes the unit's scratch can hold)
 #define FIT_OSTR 16          // k_fit_batch's result words are 128 bytes apart (one cache line per shape: the words of neighbouring shapes shared lines, and every wave's look at its word queued up behind the others in ONE L2 channel)
 #define WIDE_L 1024
 struct WideSeg { int32_t evStart, evCnt, qBase, qLen, flags, total, qWant, pad; };   // flags: 1 stream, 2 barrier (a head the wide run cannot serve: its key stops the merge), 4 open (the queue goes on behind its last entry under a key not known here), 8 element 0 of the queued part is the peeked head

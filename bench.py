@@ -245,7 +245,7 @@ def submit_check_record(args):
         "schedulable": sum(r.is_schedulable for r in res.values()), "native_calls": chk.launches, "how": db.stats, "device_s": dev_s,
         "roofline": {"bound": "hbm", "achieved": queries * algorithmic_bytes(args.nodes, W.R, 1, 0) / max(dev_s, 1e-9) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": queries * algorithmic_bytes(args.nodes, W.R, 1, 0) / max(dev_s, 1e-9) / 1e9 / HBM_PEAK_GBS, "traffic": None, "node_queries": queries,
-                     "kernel": "k_fit_batch (individual checks) + k_control_aux (gangs)"},
+                     "kernel": "k_fit_batch (individual checks) + k_submit_gangs (gang units, one workgroup each; k_control_aux for what is left)"},
     }
     if args.cpu_budget > 0:   # cpu_baseline leg: the reference's sequential flow on the oracle, distinct keys so that its cache cannot help
         path = os.path.join(ROOT, "oracle", "liboracle.so")

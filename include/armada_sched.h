@@ -424,7 +424,8 @@ int32_t ASCHED_FN(clear_allocated)(asched_t*);
 int32_t ASCHED_FN(submit_check)(asched_t*, int32_t n_units, const int32_t* unit_off /*[n_units+1]*/, const int32_t* unit_jobs,
                                 const int32_t* unit_flags /*[n_units] or NULL*/, asched_submit_result* out /*[n_units]*/);
 /* Measurement hook (no reference counterpart): how the last submit_check ran.  out = {units answered by the wide fit kernel (individual
-   checks on a pristine NodeDb), fit-kernel passes, units through the sequential control launch (gangs, or a NodeDb holding jobs), 0}. */
+   checks on a pristine NodeDb), fit-kernel passes, units through the sequential control launch (a NodeDb holding jobs, away types, literal rows), gang units answered
+   one workgroup per unit on a pristine NodeDb (csrc/submit_gang.h)}. */
 int32_t ASCHED_FN(submit_stats)(asched_t*, int32_t* out /*[4]*/);
 /* NodeTypesIterator order (nodeiteration.go:74-149) for req at a priority over node types `types` (node_type_override ids; ntypes<0: all types).
    Test hook for the golden orderings of nodeiteration_test.go; the HIP backend materialises its literal iterator restatement (the one rounds use

@@ -207,6 +207,17 @@ static int plat_allreduce(long long* buf, size_t count, int op) {
   if (t_ctx->extFn(t_ctx->extCtx, buf, (int64_t)count, op) != 0) { g_err = "the external all-reduce transport failed"; return -1; }
   return 0;
 }
+// the submit check's gang units (armada_amd/csrc/submit_gang.h): the same per-unit function, one unit after the other on one thread
+#include "../../armada_amd/csrc/submit_gang.h"
+#define SG_MAX_NODES 262144
+static int plat_run_submit_gangs(Dev& d, const std::vector<int32_t>& off, const std::vector<int32_t>& jobs, std::vector<int32_t>& out) {
+  int nu = (int)off.size() - 1;
+  out.assign((size_t)std::max(nu, 0) * 4, 0);
+  std::vector<uint32_t> bits((d.cfg.N + 31) / 32 + 1, 0);
+  static SgShared s;
+  for (int u = 0; u < nu; u++) submitGangUnit(d, jobs.data() + off[u], off[u + 1] - off[u], s, bits.data(), out.data() + 4 * (size_t)u);
+  return 0;
+}
 // one pool on several GPUs (armada_amd/csrc/mgpu.h): the per-element functions of the grid kernels in serial loops
 #include "../../armada_amd/csrc/mgpu.h"
 static int plat_run_fit_batch_global(Dev& d, const std::vector<int32_t>& shapes, const std::vector<int32_t>& slot, int level, GlobalKeyLayout L, const int32_t* globalRank, long long* out, int* badOut) {

@@ -93,7 +93,7 @@ def test_submit_check_bench_line(fake_gpu, monkeypatch, capsys):
     fake_gpu.main()
     line = check_line(capsys.readouterr().out, "submit checks")
     assert line["parity"]["checked"] and line["parity"]["identical"]
-    assert line["unit"] == "jobs/s" and line["how"][0]["wide_units"] == 120 and line["how"][0]["sequential_units"] == 0 and line["how"][1]["sequential_units"] > 0
+    assert line["unit"] == "jobs/s" and line["how"][0]["wide_units"] == 120 and line["how"][0]["sequential_units"] == 0 and line["how"][1]["gang_units"] > 0 and line["how"][1]["sequential_units"] == 0   # gang units: one workgroup each (csrc/submit_gang.h)
 
 
 def test_smoke_entry_point(fake_gpu, capsys):

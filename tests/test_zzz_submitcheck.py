@@ -323,3 +323,64 @@ def test_empty_nodedb_oracle_and_hostsim(oracle_lib, hostsim_lib):
 @pytest.mark.gpu
 def test_empty_nodedb_gpu(hip_lib):
     _empty_nodedb(hip_lib)
+
+
+# ---- gang units, one workgroup per unit on a pristine NodeDb (csrc/submit_gang.h) -------------------------------------------------------------------------------
+def _gang_units_equal_sequential(lib, oracle, seed, monkeypatch):
+    """ScheduleManyWithTxn on units of several members (submitcheck.go:345-349): the gang path (members one after the other inside ONE workgroup, binds in the workgroup's
+    scratch, units side by side) against the sequential control launch (ASCHED_SUBMIT_GANGS=0) and against the oracle — gangs that fit, gangs whose k-th member finds no
+    node (num_schedulable = k), members that share nodes, members bigger than any node, selectors / tolerations / off-grid requests (those units keep the sequential path)."""
+    from armada_amd import workloads as W
+    rng = np.random.default_rng(1000 + seed)
+    wl = W.small_random(n_nodes=int(rng.integers(6, 120)), n_jobs=int(rng.integers(200, 900)), n_queues=3, seed=500 + seed, occupied=0.0, gangs=0,
+                        ragged=bool(seed % 4 == 3), away=bool(seed % 5 == 4))
+    m = wl.num_jobs
+    if seed % 3 == 0:
+        wl.job_req[:, W.CPU] *= 4   # big members: gangs run out of nodes half way
+    units, strip = [], []
+    perm = rng.permutation(m)
+    i = 0
+    while i < m:
+        n = int(rng.choice([1, 2, 3, 5, 8, 17, 40]))
+        u = [int(x) for x in perm[i:i + n]]
+        i += n
+        if len(u) > 1 and rng.random() < 0.7:   # a gang shares one priority class (and here one shape, as a gang's members usually do)
+            wl.job_pc[u] = wl.job_pc[u[0]]
+            if rng.random() < 0.6:
+                wl.job_req[u] = wl.job_req[u[0]]
+                if wl.job_req_class is not None:
+                    wl.job_req_class[u] = wl.job_req_class[u[0]]
+        units.append(u); strip.append(len(u) == 1)
+    out, stats = [], []
+    for l in (lib, oracle):
+        s = W.load(l, wl)
+        s.clear_allocated()
+        monkeypatch.delenv("ASCHED_SUBMIT_GANGS", raising=False)
+        out.append(s.submit_check(units, strip)); stats.append(s.submit_stats())
+        if l is lib:
+            monkeypatch.setenv("ASCHED_SUBMIT_GANGS", "0")
+            out.append(s.submit_check(units, strip)); stats.append(s.submit_stats())
+            monkeypatch.delenv("ASCHED_SUBMIT_GANGS", raising=False)
+        s.close()
+    assert out[0] == out[1], [(u, a, b) for u, a, b in zip(units, out[0], out[1]) if a != b][:3]
+    assert out[0] == out[2], [(u, a, b) for u, a, b in zip(units, out[0], out[2]) if a != b][:3]
+    assert stats[1]["gang_units"] == 0 and stats[1]["sequential_units"] >= stats[0]["sequential_units"] + stats[0]["gang_units"]
+    multi = [o for u, o in zip(units, out[0]) if len(u) > 1]
+    return stats[0]["gang_units"], sum(1 for o in multi if o[0]), sum(1 for o in multi if not o[0] and o[2] > 0)
+
+
+def test_gang_units_equal_sequential_hostsim(hostsim_lib, oracle_lib, monkeypatch):
+    g = ok = partial = 0
+    for seed in range(12):
+        a, b, c = _gang_units_equal_sequential(hostsim_lib, oracle_lib, seed, monkeypatch)
+        g += a; ok += b; partial += c
+    assert g > 100 and ok > 100 and partial > 10, (g, ok, partial)   # the path is taken, gangs fit, and gangs fail half way (num_schedulable of the failed unit is compared too)
+
+
+@pytest.mark.gpu
+def test_gang_units_equal_sequential_gpu(hip_lib, oracle_lib, monkeypatch):
+    g = ok = partial = 0
+    for seed in range(12):
+        a, b, c = _gang_units_equal_sequential(hip_lib, oracle_lib, seed, monkeypatch)
+        g += a; ok += b; partial += c
+    assert g > 100 and ok > 100 and partial > 10, (g, ok, partial)
