@@ -530,6 +530,9 @@ def other_configs(hip, args, t_start):
                                 "more than 64 queues: wide runs since round 4 (round_wide.h: per-queue streams merged by a bulk rank on the helper workgroups; the generic iteration in "
                                 "rounds 1-3, 3.3 s); the same nodes and jobs as the reduced configs[3] / [4] inputs, 256 queues", only_size=True))
     guarded("1024 queues", shape("1024 queues", None, dict(n_nodes=20_000, n_jobs=200_000, n_queues=1024), "as above with 1 024 queues", only_size=True))
+    guarded("256 queues, crowded", shape("256 queues on a crowded pool (95 % occupied: most new jobs need preemption)", None, dict(n_nodes=20_000, n_jobs=200_000, n_queues=256, occupied=0.95),
+                                         "where wide runs help least: a queue whose head needs preemption is a barrier of a run, and evicted heads leave the runs once a preemption has marked jobs — "
+                                         "more than half of the iterations are the generic one (one workgroup)", only_size=True))
     guarded("nodedb fit kernel at 100k nodes x 1M queries", lambda: fit_batch_record(hip, args, big=True))
     guarded("configs[4] checker at 100k nodes", lambda: config4_checker_record(hip, args))
     guarded("reference benchmark shapes", lambda: reference_benchmark_record(hip, args))

@@ -55,7 +55,7 @@ def test_round_bench_line(fake_gpu, monkeypatch, capsys):
     # every other BASELINE config + the submit check sits in the same record, each with roofline and cpu_baseline
     oc = {r["config"]: r for r in line["other_configs"]}
     assert set(oc) == {"BASELINE configs[1]", "BASELINE configs[3]", "BASELINE configs[4]", "submit check (SURVEY 8f-2)", "fairness optimiser node scoring (SURVEY 8f-3)",
-                       "market-driven round + indicative gang pricer (SURVEY 8f-4)", "256 queues (beyond the 64-lane fast iteration)", "1024 queues",
+                       "market-driven round + indicative gang pricer (SURVEY 8f-4)", "256 queues (beyond the 64-lane fast iteration)", "1024 queues", "256 queues on a crowded pool (95 % occupied: most new jobs need preemption)",
                        "nodedb fit kernel at 100 000 nodes x 1 000 000 queries", "configs[4] shape at 100 000 nodes with an oracle-sized burst (checker)",
                        "BenchmarkPreemptingQueueScheduler shapes (preempting_queue_scheduler_test.go:2561-2799)"}, set(oc)
     ref = oc.pop("BenchmarkPreemptingQueueScheduler shapes (preempting_queue_scheduler_test.go:2561-2799)")   # a table of eight small shapes: rows instead of one roofline
