@@ -100,6 +100,28 @@ class SubmitChecker:
 
     # ---- which jobs a Check call reaches before its deadlines (the clock is read exactly where the reference reads it)
     def _select(self, jobs: Sequence[SubmitJob]):
+        if self.max_duration <= 0 and self.max_duration_per_queue <= 0:
+            # no deadline can fire: the clock reads below are unobservable (a zero deadline never exceeds, submitcheck.go:34-45) — the same grouping without them
+            gids = [j.gang_id for j in jobs]
+            by_queue: Dict[str, List[int]] = {}
+            for i, j in enumerate(jobs):
+                by_queue.setdefault(j.queue, []).append(i)
+            events: List[List[int]] = []
+            for idxs in by_queue.values():
+                by_gang: Dict[str, List[int]] = {}
+                for i in idxs:
+                    g = gids[i]
+                    if g is not None:
+                        by_gang.setdefault(g, []).append(i)
+                processed = set()
+                for i in idxs:
+                    g = gids[i]
+                    if g is None:
+                        events.append([i])
+                    elif g not in processed:
+                        events.append(by_gang[g])
+                        processed.add(g)
+            return events
         start = self.now()
         global_deadline = _Deadline(self.max_duration, start)
         by_queue: Dict[str, List[int]] = {}
