@@ -273,24 +273,61 @@ class PodResult:
     method: int
 
 
-@dataclass
 class RoundResult:
-    scheduled: Dict[int, int]            # job -> node
-    scheduled_priority: Dict[int, int]   # job -> nodeDb.GetScheduledAtPriority
-    scheduled_method: Dict[int, int]
-    preempted: Dict[int, int]            # job -> node it was preempted from
-    termination_reason: int
-    num_evicted_phase1: int
-    num_evicted_phase3: int
-    num_node_queries: int
-    num_loop_iterations: int
-    queue_allocated_by_pc: np.ndarray
-    fair_share: np.ndarray
-    demand_capped_adjusted_fair_share: np.ndarray
-    uncapped_adjusted_fair_share: np.ndarray
-    job_unschedulable_reason: np.ndarray
-    global_tokens_after: float
-    queue_tokens_after: np.ndarray
+    """scheduling.SchedulingResult as asched_schedule_round hands it over.  The result ARRAYS (ascending job ids with their nodes / priorities / methods, the preempted
+    jobs with the nodes they leave, per-job reasons, per-queue accounting) are copied out of the library's buffers when the call returns; the job -> value dict views
+    below are a convenience of this binding and are built on first use (three 200 000-entry Python dicts are tens of milliseconds — more than the library's own
+    host time per round — and a caller that consumes arrays, like the cgo shim, never builds them)."""
+
+    def __init__(self, *, scheduled_job, scheduled_node, scheduled_priority_arr, scheduled_method_arr, preempted_job, preempted_node, termination_reason, num_evicted_phase1,
+                 num_evicted_phase3, num_node_queries, num_loop_iterations, queue_allocated_by_pc, fair_share, demand_capped_adjusted_fair_share,
+                 uncapped_adjusted_fair_share, job_unschedulable_reason, global_tokens_after, queue_tokens_after):
+        self.scheduled_job, self.scheduled_node = scheduled_job, scheduled_node                     # [num_scheduled] ascending job ids, jctx.PodSchedulingContext.NodeId
+        self.scheduled_priority_arr, self.scheduled_method_arr = scheduled_priority_arr, scheduled_method_arr
+        self.preempted_job, self.preempted_node = preempted_job, preempted_node                     # [num_preempted] ascending job ids, jctx.AssignedNode
+        self.termination_reason = termination_reason
+        self.num_evicted_phase1, self.num_evicted_phase3 = num_evicted_phase1, num_evicted_phase3
+        self.num_node_queries, self.num_loop_iterations = num_node_queries, num_loop_iterations
+        self.queue_allocated_by_pc = queue_allocated_by_pc
+        self.fair_share, self.demand_capped_adjusted_fair_share, self.uncapped_adjusted_fair_share = fair_share, demand_capped_adjusted_fair_share, uncapped_adjusted_fair_share
+        self.job_unschedulable_reason = job_unschedulable_reason
+        self.global_tokens_after, self.queue_tokens_after = global_tokens_after, queue_tokens_after
+        self._views: Dict[str, Dict[int, int]] = {}
+
+    def _view(self, name, keys, vals) -> Dict[int, int]:
+        v = self._views.get(name)
+        if v is None:
+            v = self._views[name] = dict(zip(keys.tolist(), vals.tolist()))
+        return v
+
+    @property
+    def scheduled(self) -> Dict[int, int]:            # job -> node
+        return self._view("scheduled", self.scheduled_job, self.scheduled_node)
+
+    @property
+    def scheduled_priority(self) -> Dict[int, int]:   # job -> nodeDb.GetScheduledAtPriority
+        return self._view("scheduled_priority", self.scheduled_job, self.scheduled_priority_arr)
+
+    @property
+    def scheduled_method(self) -> Dict[int, int]:
+        return self._view("scheduled_method", self.scheduled_job, self.scheduled_method_arr)
+
+    @property
+    def preempted(self) -> Dict[int, int]:            # job -> node it was preempted from
+        return self._view("preempted", self.preempted_job, self.preempted_node)
+
+    # (a caller may replace a view, e.g. the golden runner re-labels node ids: tests/scenario.py)
+    @scheduled.setter
+    def scheduled(self, v): self._views["scheduled"] = v
+
+    @scheduled_priority.setter
+    def scheduled_priority(self, v): self._views["scheduled_priority"] = v
+
+    @scheduled_method.setter
+    def scheduled_method(self, v): self._views["scheduled_method"] = v
+
+    @preempted.setter
+    def preempted(self, v): self._views["preempted"] = v
 
 
 class Library:
@@ -1121,10 +1158,7 @@ class Scheduler:
         pj, pn = arr(r.preempted_job, npre, np.int32), arr(r.preempted_node, npre, np.int32)
         q = self.num_queues
         return RoundResult(
-            scheduled=dict(zip(sj.tolist(), sn.tolist())),
-            scheduled_priority=dict(zip(sj.tolist(), sp.tolist())),
-            scheduled_method=dict(zip(sj.tolist(), sm.tolist())),
-            preempted=dict(zip(pj.tolist(), pn.tolist())),
+            scheduled_job=sj, scheduled_node=sn, scheduled_priority_arr=sp, scheduled_method_arr=sm, preempted_job=pj, preempted_node=pn,
             termination_reason=r.termination_reason,
             num_evicted_phase1=r.num_evicted_phase1, num_evicted_phase3=r.num_evicted_phase3,
             num_node_queries=r.num_node_queries, num_loop_iterations=r.num_loop_iterations,

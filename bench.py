@@ -774,6 +774,8 @@ def main():
 
     from armada_amd import multipool
     tp = time.perf_counter()
+    # (timed: asched_schedule_round through the C ABI + the copy of every result array out of the library's buffers; the binding's job -> node DICT views are built lazily, outside —
+    #  three 200 000-entry Python dicts cost more than the library's whole host side of a round and no array consumer builds them)
     lat, dev_ms, res = multipool.timed_rounds(s, wl, args.steps, args.warmup, barrier, torch.cuda.synchronize)
     prep_s = multipool.timed_rounds.prepare_s  # untimed input build (fresh NodeDb + bind running jobs + fair shares + sorted base)
 
