@@ -2654,6 +2654,37 @@ static int plat_run_submit_gangs(Dev& d, const std::vector<int32_t>& off, const 
   if (dOff) (void)hipFree(dOff); if (dJobs) (void)hipFree(dJobs); if (dOut) (void)hipFree(dOut);
   return ok ? 0 : -1;
 }
+// uniform submit-check units (submit_gang.h): per shape {first node or -1, members all nodes take together}
+extern "C" int asched_internal_fit_capacity(const Dev* d, const int32_t* shapes, int ns, unsigned long long* out, hipStream_t s);
+static int plat_run_fit_capacity(Dev& d, const std::vector<int32_t>& shapes, std::vector<int32_t>& firstNode, std::vector<long long>& capacity, const int32_t* nodeByRankHost) {
+  int ns = (int)shapes.size();
+  firstNode.assign(ns, -1); capacity.assign(ns, 0);
+  if (ns == 0 || d.cfg.N == 0) return 0;
+  hipStream_t st = t_ctx->stream;
+  unsigned long long* dOut = nullptr; int32_t* dShapes = nullptr;
+  size_t words = (size_t)ns * FIT_OSTR;
+  bool ok = hipOk(hipMalloc(&dOut, words * 8), "hipMalloc") && hipOk(hipMalloc(&dShapes, (size_t)ns * 4), "hipMalloc");
+  std::vector<unsigned long long> init(words, 0), got(words);
+  for (int i = 0; i < ns; i++) init[(size_t)i * FIT_OSTR] = ~0ull;
+  if (ok) {
+    (void)hipMemcpyAsync(dOut, init.data(), words * 8, hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(dShapes, shapes.data(), (size_t)ns * 4, hipMemcpyHostToDevice, st);
+    (void)hipEventRecord(t_ctx->fitEv0, st);
+    ok = asched_internal_fit_capacity(&d, dShapes, ns, dOut, st) == 0;
+    (void)hipEventRecord(t_ctx->fitEv1, st);
+    ok = ok && hipOk(hipMemcpyAsync(got.data(), dOut, words * 8, hipMemcpyDeviceToHost, st), "hipMemcpy") && hipOk(hipStreamSynchronize(st), "k_fit_capacity");
+    (void)hipEventElapsedTime(&t_ctx->lastFitMs, t_ctx->fitEv0, t_ctx->fitEv1);
+  }
+  if (dOut) (void)hipFree(dOut); if (dShapes) (void)hipFree(dShapes);
+  if (!ok) return -1;
+  unsigned long long mask = (1ull << d.cfg.idxBits) - 1;
+  for (int i = 0; i < ns; i++) {
+    unsigned long long k = got[(size_t)i * FIT_OSTR];
+    firstNode[i] = k == ~0ull ? -1 : nodeByRankHost[k & mask];
+    capacity[i] = (long long)got[(size_t)i * FIT_OSTR + 1];
+  }
+  return 0;
+}
 // a caller-side buffer may be memory of this handle's GPU (a tensor the collective reduces in place: used directly) or host memory (staged)
 static bool plat_is_device_ptr(const void* p) {
   hipPointerAttribute_t a;

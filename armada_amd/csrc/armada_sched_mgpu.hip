@@ -109,3 +109,30 @@ extern "C" int asched_internal_submit_gangs(const Dev* d, const int32_t* off, co
   hipLaunchKernelGGL(k_submit_gangs, dim3(nu < 4096 ? nu : 4096), dim3(SG_THREADS), lds, st, *d, off, jobs, nu, out);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// uniform units: per shape the smallest key among the nodes that take at least one member, and the number of members all nodes take together (submit_gang.h)
+__global__ __launch_bounds__(256) void k_fit_capacity(Dev d, const int32_t* shapes, int ns, unsigned long long* out /*[ns][FIT_OSTR]: [0] min key, [1] capacity sum*/) {
+  __shared__ unsigned long long wmin[4], wsum[4];
+  int n = blockIdx.x * 256 + threadIdx.x;
+  for (int i = blockIdx.y; i < ns; i += gridDim.y) {
+    long long cap = n < d.cfg.N ? sgNodeCapacity(d, shapes[i], n) : 0;
+    unsigned long long key = cap > 0 ? d.keys[n] : ~0ull, sum = (unsigned long long)cap;
+    for (int off = 32; off; off >>= 1) { unsigned long long o = __shfl_xor(key, off, 64); key = o < key ? o : key; sum += __shfl_xor(sum, off, 64); }
+    if ((threadIdx.x & 63) == 0) { wmin[threadIdx.x >> 6] = key; wsum[threadIdx.x >> 6] = sum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long m = wmin[0], t = wsum[0];
+      for (int w = 1; w < 4; w++) { m = wmin[w] < m ? wmin[w] : m; t += wsum[w]; }
+      if (m != ~0ull) atomicMin(&out[(size_t)i * FIT_OSTR], m);
+      if (t) atomicAdd(&out[(size_t)i * FIT_OSTR + 1], t);
+    }
+    __syncthreads();
+  }
+}
+extern "C" int asched_internal_fit_capacity(const Dev* d, const int32_t* shapes, int ns, unsigned long long* out, hipStream_t st) {
+  if (ns <= 0 || d->cfg.N <= 0) return 0;
+  int tiles = (d->cfg.N + 255) / 256;
+  int ysplit = ns < 1 ? 1 : (ns < (2048 + tiles - 1) / tiles ? ns : (2048 + tiles - 1) / tiles);
+  hipLaunchKernelGGL(k_fit_capacity, dim3(tiles, ysplit < 1 ? 1 : ysplit), dim3(256), 0, st, *d, shapes, ns, out);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -86,3 +86,23 @@ SG_FN void submitGangUnit(const Dev& d, const int32_t* jobs, int n, SgShared& s,
   }
   SG_SYNC();
 }
+
+// ---- uniform units: every member has the same scheduling-key shape (the usual gang: identical replicas; the reference's own BenchmarkScheduleMany*, nodedb_test.go:1590-1712, is
+// ONE such unit of up to 64 000 members).  On a pristine NodeDb the members fill the nodes in ascending key order: the node a member was bound to keeps the smallest key among the
+// nodes that fit (a bind only lowers it; nobody else moves) until it no longer fits, and never fits again.  So the unit's outcome is a sum, not a sequence: node n takes
+// cap_n = min over requested columns of floor(allocatable / request) members, num_schedulable = min(members, sum of cap_n over the row's nodes), ok = that sum covers the unit,
+// first_node = the smallest key with cap_n >= 1 — per SHAPE, whatever the number of units or members: one pass over the nodes (k_fit_capacity), no per-member work at all.
+#define SG_CAP_CLAMP (1ll << 31)   // a node's capacity as it enters the sum (N * 2^31 < 2^63)
+SG_FN long long sgNodeCapacity(const Dev& d, int shape, int node) {
+  const DevCfg& c = d.cfg;
+  const uint64_t* mask = d.shapeMask + (size_t)shape * c.W;
+  if (!((mask[node >> 6] >> (node & 63)) & 1)) return 0;
+  const int64_t* req = d.shapeReq + (size_t)shape * c.R;
+  long long cap = SG_CAP_CLAMP;
+  for (int r = 0; r < c.R; r++) {
+    long long a = d.alloc[(size_t)r * c.Npad + node];
+    if (a < req[r]) return 0;                       // (also a negative column under a zero request: DynamicJobRequirementsMet fails, nodematching.go:194-197)
+    if (req[r] > 0) { long long q = a / req[r]; if (q < cap) cap = q; }
+  }
+  return cap;
+}

@@ -536,6 +536,7 @@ def other_configs(hip, args, t_start):
     guarded("nodedb fit kernel at 100k nodes x 1M queries", lambda: fit_batch_record(hip, args, big=True))
     guarded("configs[4] checker at 100k nodes", lambda: config4_checker_record(hip, args))
     guarded("reference benchmark shapes", lambda: reference_benchmark_record(hip, args))
+    guarded("BenchmarkScheduleMany shapes", lambda: schedule_many_benchmark_record(hip, args))
     return recs
 
 
@@ -569,6 +570,59 @@ def config4_checker_record(hip, args):
         rec["cpu_baseline"] = base
         if ores is not None:
             rec["parity"] = parity_record(res, ores, wl.num_jobs, "oracle round on the same 100 000-node input")
+    return rec
+
+
+def schedule_many_benchmark_record(hip, args):
+    """BenchmarkScheduleMany* (nodedb_test.go:1590-1712): ONE gang context of J identical 1-cpu / 4-Gi jobs through `txn := nodeDb.Txn(true); nodeDb.ScheduleManyWithTxn(txn, gctx);
+    txn.Abort()` on a fresh NodeDb of N 32-cpu nodes — the loop body of the benchmark is exactly one unit of asched_submit_check.  Such a unit is UNIFORM (every member of one shape):
+    on a NodeDb in its initial state its outcome is a sum over the nodes, one pass (csrc/submit_gang.h k_fit_capacity), whatever J.  The shapes whose nodes carry used resources at
+    priority 0 (`WithUsedResourcesNodes`, :1666-1700) qualify too: that lowers the planes of every level up to the jobs' own alike.  No Go toolchain here: both legs are timed on this box."""
+    import numpy as np
+    import torch
+    from armada_amd import workloads as W
+    from armada_amd.binding import Library
+    shapes = [(1, 320, 0), (1, 640, 0), (100, 3200, 0), (100, 6400, 0), (1000, 32000, 0), (1000, 64000, 0), (100, 100, 31), (1000, 1000, 31), (10000, 10000, 31)]   # (nodes, jobs, cpus used per node at priority 0)
+    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    oracle = Library(path, "oracle_") if (args.cpu_budget > 0 and os.path.exists(path)) else None
+    rows, all_same = [], True
+    for nn, nj, used in shapes:
+        nj = max(4, int(nj * args.other_scale)); nn = max(1, int(nn * min(1.0, args.other_scale * 10)))
+        wl = W.reference_benchmark(nn, 1, nj)
+        legs = {}
+        for name, lib in (("gpu", hip), ("oracle", oracle)):
+            if lib is None:
+                continue
+            s = W.Scheduler(lib, wl.config)
+            abp = None
+            if used:   # testfixtures.WithUsedResourcesNodes(0, Cpu("31"), nodes): AllocatableByPriority[p] -= 31 cpu for p <= 0 (node.go:535-549)
+                abp = np.repeat(wl.node_total[:, None, :], s.P, axis=1).copy()
+                for l, pr in enumerate(s.priorities):
+                    if pr <= 0:
+                        abp[:, l, W.CPU] -= used * 1000
+            s.nodes_upsert(wl.node_total, wl.node_allocatable, alloc_by_prio=abp)
+            W.set_jobs(s, wl)
+            unit = [list(range(nj))]
+            s.submit_check(unit, [False])   # warm-up
+            times, r = [], None
+            for _ in range(3):
+                if name == "gpu": torch.cuda.synchronize()
+                t0 = time.perf_counter(); r = s.submit_check(unit, [False])
+                if name == "gpu": torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            legs[name] = (float(np.mean(times)), r[0], s.submit_stats() if name == "gpu" else None)
+            s.close()
+        row = {"shape": f"{nn} nodes {nj} jobs" + (f" ({used} of 32 cpus used per node)" if used else ""), "gpu_ms": legs["gpu"][0] * 1e3, "ok": bool(legs["gpu"][1][0]), "num_schedulable": int(legs["gpu"][1][2]),
+               "how": "capacity pass" if legs["gpu"][2]["gang_units"] else "sequential control launch"}
+        if "oracle" in legs:
+            same = legs["oracle"][1] == legs["gpu"][1]
+            all_same = all_same and same
+            row.update({"oracle_ms": legs["oracle"][0] * 1e3, "x_oracle": legs["oracle"][0] / max(legs["gpu"][0], 1e-12), "identical": bool(same)})
+        rows.append(row)
+    rec = {"config": "BenchmarkScheduleMany shapes (nodedb_test.go:1590-1712)", "metric": "ms per Txn / ScheduleManyWithTxn / Abort of one gang context", "unit": "ms", "rows": rows,
+           "note": "a NodeDb in its initial state + identical members: one pass over the nodes per call, whatever the number of members (the time that is left is marshalling J job ids through ctypes)"}
+    if oracle is not None:
+        rec["parity"] = {"checked": True, "identical": bool(all_same), "against": "oracle: ok, num_schedulable, first node per shape", "jobs": int(sum(int(r["shape"].split()[2]) for r in rows))}
     return rec
 
 

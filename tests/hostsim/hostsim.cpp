@@ -218,6 +218,14 @@ static int plat_run_submit_gangs(Dev& d, const std::vector<int32_t>& off, const 
   for (int u = 0; u < nu; u++) submitGangUnit(d, jobs.data() + off[u], off[u + 1] - off[u], s, bits.data(), out.data() + 4 * (size_t)u);
   return 0;
 }
+static int plat_run_fit_capacity(Dev& d, const std::vector<int32_t>& shapes, std::vector<int32_t>& firstNode, std::vector<long long>& capacity, const int32_t*) {
+  firstNode.assign(shapes.size(), -1); capacity.assign(shapes.size(), 0);
+  for (size_t i = 0; i < shapes.size(); i++) {
+    unsigned long long best = ~0ull;
+    for (int n = 0; n < d.cfg.N; n++) { long long c = sgNodeCapacity(d, shapes[i], n); capacity[i] += c; if (c > 0 && d.keys[n] < best) { best = d.keys[n]; firstNode[i] = n; } }
+  }
+  return 0;
+}
 // one pool on several GPUs (armada_amd/csrc/mgpu.h): the per-element functions of the grid kernels in serial loops
 #include "../../armada_amd/csrc/mgpu.h"
 static int plat_run_fit_batch_global(Dev& d, const std::vector<int32_t>& shapes, const std::vector<int32_t>& slot, int level, GlobalKeyLayout L, const int32_t* globalRank, long long* out, int* badOut) {
