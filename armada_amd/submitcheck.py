@@ -237,6 +237,20 @@ class SubmitChecker:
 
         results: Dict[str, SchedulingResult] = {}
         todo: List[List[int]] = []
+        if len(self._cache) + len(keys) <= self.cache_size:
+            # No entry can be evicted during this call (the cache holds at most cache_size - len(keys) other keys), so every access of a key returns what its FIRST access
+            # returned and the LRU order only matters afterwards: the replay is a dict lookup per job, and the order is restored from the access sequence at the end.
+            local: Dict[Hashable, SchedulingResult] = {}
+            touched: List[Hashable] = []
+            slow = individual
+
+            def individual(i: int) -> SchedulingResult:   # noqa: F811 (the same function, memoised per call)
+                key = jobs[i].scheduling_key
+                r = local.get(key)
+                if r is None:
+                    r = local[key] = slow(i)
+                touched.append(key)
+                return r
         for ev in events:
             if jobs[ev[0]].gang_id is None:
                 results[jobs[ev[0]].id] = individual(ev[0])
@@ -261,4 +275,9 @@ class SubmitChecker:
                 r = self._pool_loop(jobs[g[0]], [jobs[i] for i in g], {p.name: raw_gang[p.name][u] for p in self.pools})
                 for i in g:
                     results[jobs[i].id] = r
+        if len(self._cache) <= self.cache_size and "touched" in locals():   # the LRU order the per-access move_to_end would have left: keys by their LAST access
+            seen = set()
+            order = [k for k in reversed(touched) if not (k in seen or seen.add(k))]
+            for k in reversed(order):
+                self._cache.move_to_end(k)
         return results
