@@ -192,6 +192,7 @@ struct LitIt { int64_t lb[MAXK]; uint64_t bound; int32_t head; int32_t type; };
 // ---- wide runs (round_wide.h): stream runs for pools of more than QCAPF queues.  Per queue a stream of at most WIDE_L entries — its remaining cheap evicted jobs, then
 // its next single queued jobs — with precomputed queue-order keys; the k-way merge of QueueCandidateGangIteratorPQ over them is a BULK RANK (every entry counts, by binary
 // search in every other queue's monotone key sequence, the entries that order before it) instead of a lane per queue.
+#define SKIP_BULK_MIN 2048    // Peek's skip of known-unfeasible keys: from this many jobs on as two bulk passes on every workgroup (round_wide.h) instead of 64 per step on the control wave
 #define SG_TMAX 256           // submit check, gang units one workgroup each (submit_gang.h): members per unit (nodes the unit's scratch can hold)
 #define FIT_OSTR 16          // k_fit_batch's result words are 128 bytes apart (one cache line per shape: the words of neighbouring shapes shared lines, and every wave's look at its word queued up behind the others in ONE L2 channel)
 #define WIDE_L 1024
@@ -307,7 +308,7 @@ struct Dev {
   int32_t accEpoch_unused;   // fair-share index: queries since the last build (round_run.h ensureFairIndex).  (Moved into undoCap's padding in round 4: its old slot + padding hold `excl`.)
   // ---- misc
   RoundScalars* rs;
-  uint64_t* scanResult;  // [8] scratch for wide scans
+  uint64_t* scanResult;  // [8] HBM scratch words of bulk passes that need one ([0]: the first job of a skip stretch that is NOT skipped, round_wide.h W_SKIP_FIND)
   int32_t* nodeOver;     // [N] bitmask of oversubscribed levels (phase 3)
   uint8_t* evFlag;       // [M] job selected by the current evictor
   uint8_t* qEvictable;   // [Q] queue is above protectedFractionOfFairShare (pqs.go:124-134)

@@ -90,6 +90,7 @@ DEV bool fastGangMember(Dev& d, Ctl& c, int job);  // select (fit at priority -2
 DEV void fastFence(Ctl& c);
 DEV_COLD void ensureReplaySlow(Dev& d, Ctl& c);
 // pools of more than QCAPF queues (round_wide.h): stream runs whose k-way merge is a bulk rank over all queues' precomputed key sequences
+DEV int skipUnfeasibleBulk(Dev& d, int pos, int max);   // round_wide.h: the same on every workgroup of the launch (two passes), for long stretches; the caller's other waves must be parked (no live node engine)
 DEV int skipUnfeasibleRun(Dev& d, int pos, int max);   // round_fast.h: Peek's skip of known-unfeasible scheduling keys (queue_scheduler.go:398-413) for a stretch of queued jobs, 64 at a time
 DEV_COLD int wideRun(Dev& d, Ctl& c, const PassCfg& pc);
 DEV bool wideHeadOk(Dev& d, const Ctl& c, const PassCfg& pc, int t);
@@ -1113,7 +1114,7 @@ DEV int gangItPeek(Dev& d, Ctl& c, int q, bool withQueued, uint32_t maxLookback,
         if (d.itStage[q] == 1 && !d.itJobOnlyEv[q] && withQueued && !d.rs->optMode) {
           int max = d.queuedOff[q + 1] - d.itQi[q];
           if (maxLookback != 0 && !d.itGangOnlyEv[q]) { int64_t lim = (int64_t)maxLookback - d.itJobsSeen[q]; if (lim < max) max = lim < 0 ? 0 : (int)lim; }   // (the switch to evicted-only happens at the top of this loop)
-          if (max >= 4) { int n = skipUnfeasibleRun(d, d.itQi[q], max); d.itQi[q] += n; d.itJobsSeen[q] += n; }
+          if (max >= 4) { int n = max >= SKIP_BULK_MIN ? skipUnfeasibleBulk(d, d.itQi[q], max) : skipUnfeasibleRun(d, d.itQi[q], max); d.itQi[q] += n; d.itJobsSeen[q] += n; }
         }
         continue;
       }

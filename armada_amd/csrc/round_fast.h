@@ -789,7 +789,7 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
       {   // the jobs behind it that Peek skips as well, one lane each (round_ctl.h gangItPeek has the same step)
         int max = end - (pos + 1);
         if (fc.maxLookback != 0 && !f.itGangOnlyEv) { int64_t lim = (int64_t)fc.maxLookback - f.itJobsSeen; if (lim < max) max = lim < 0 ? 0 : (int)lim; }
-        if (max >= 4) { int n = skipUnfeasibleRun(d, pos + 1, max); f.itQi += n; f.itJobsSeen += n; }
+        if (max >= 4) { int n = (max >= SKIP_BULK_MIN && !S.engLive) ? skipUnfeasibleBulk(d, pos + 1, max) : skipUnfeasibleRun(d, pos + 1, max); f.itQi += n; f.itJobsSeen += n; }
       }
       continue;
     }

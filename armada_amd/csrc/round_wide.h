@@ -32,7 +32,7 @@
 // rounds with the oracle for 65 ... 1 024 queues (CPU build and -m gpu).
 #pragma once
 
-enum { W_SEG = 0, W_EVSUM, W_QSUM, W_STITCH, W_PACK, W_FIX, W_RANK, W_SCATTER, W_COMMIT_E, W_COMMIT_Q, W_EXCL };   // (W_EXCL: not a pass of a wide run — the pass behind asched_excluded_nodes shares the op)
+enum { W_SEG = 0, W_EVSUM, W_QSUM, W_STITCH, W_PACK, W_FIX, W_RANK, W_SCATTER, W_COMMIT_E, W_COMMIT_Q, W_EXCL, W_SKIP_FIND, W_SKIP_MARK };   // (W_EXCL: not a pass of a wide run — the pass behind asched_excluded_nodes shares the op)
 #define W_PER 16                        // queues one item of the rank pass walks for its entry: an entry's walk over the other queues is cut into Q / W_PER items (the entries of a run
                                         // alone fill a third of the lanes once)
 #define WQ_CHUNK 8                      // entries one item of the chunked passes covers (streams here are tens of entries long, not thousands: round_run.h uses 64)
@@ -86,8 +86,23 @@ DEV void exclBulk(Dev& d, int n) {
   if (st) exclDynPut(d, x, slot, n, r.level, req);
 }
 
+// ---- Peek's skip of known-unfeasible scheduling keys (queue_scheduler.go:398-413) for a LONG stretch of queued jobs: the steady state the reference's own benchmark times
+// (BenchmarkPreemptingQueueScheduler: full nodes, a queue of 320 000 identical jobs that no longer fit — each one gets a failed job context and is skipped).  The jobs are
+// independent, the stretch ends at the first job that is not skippable: pass 1 finds that job (atomic minimum), pass 2 writes the records of the jobs in front of it.
+// The stretch's start travels in the high bits of the pass's kind (the two words of a bulk command are all the helpers read).
+DEV bool skipOk(Dev& d, int job) { return d.jGang[job] < 0 && d.unfeasible[d.jShape[job]] && !(d.jobFlags[job] & F_SUCCESSFUL); }
+DEV void skipBulk(Dev& d, int kind, int pos, int i) {
+  int job = d.queuedJobs[pos + i];
+  if (kind == W_SKIP_FIND) { if (!skipOk(d, job)) atomicMinU32((uint32_t*)d.scanResult, (uint32_t)i); return; }
+  d.jcEvicted[job] = 0; d.jcAssigned[job] = -1; d.jcGangCard[job] = 1; d.jcUniValue[job] = -1; d.jcStagedBy[job] = -1;   // JobSchedulingContextFromJob (context/job.go:149-158)
+  d.jcHasPctx[job] = 1; d.pcNode[job] = -1; d.pcMethod[job] = ASCHED_METHOD_NONE;
+  d.jobFlags[job] = (uint8_t)(d.jobFlags[job] | F_UNSUCCESSFUL);
+  d.jcReason[job] = ASCHED_REASON_SKIPPED_UNFEASIBLE_KEY;
+}
+
 DEV_COLD void wideBulkAny(Dev& d, int kind, int i) {
   if (kind == W_EXCL) { exclBulk(d, i); return; }
+  if ((kind & 255) >= W_SKIP_FIND) { skipBulk(d, kind & 255, kind >> 8, i); return; }
   const DevCfg& c = d.cfg;
   WideDev& w = *d.wide;
   const WideParams& P = *w.par;
@@ -417,6 +432,19 @@ DEV void wgWide(Dev& d, int kind, int n) { for (int i = 0; i < n; i++) wideBulkA
 #else
 DEV void wgWide(Dev& d, int kind, int n);   // armada_sched.hip: the pass on the control workgroup and the helper workgroups (OP_WIDE)
 #endif
+
+DEV_COLD int skipUnfeasibleBulk(Dev& d, int pos, int max) {
+  if (pos >= (1 << 22)) return skipUnfeasibleRun(d, pos, max);   // (the start has 23 bits of the kind word)
+  if (FLANE == 0) *(volatile uint32_t*)d.scanResult = (uint32_t)max;
+  wgWide(d, W_SKIP_FIND | (pos << 8), max);
+  int n = (int)UNI32(*(volatile uint32_t*)d.scanResult);
+  if (n > max) n = max;
+  if (n > 0) wgWide(d, W_SKIP_MARK | (pos << 8), n);
+#ifdef ASCHED_HOSTSIM
+  if (getenv("HS_TRACE_SKIP")) fprintf(stderr, "bulk skip: %d of %d jobs from position %d\n", n, max, pos);
+#endif
+  return n;
+}
 
 // rows on the literal iteration path: the nodes the iterators yield, one after the other (selectAtLevelLiteral's walk without the early exit)
 DEV_COLD void exclLiteral(Dev& d, ExclDev& x, int slot) {

@@ -85,3 +85,40 @@ def test_preemptions_stay_in_the_fast_loop_gpu(hip_lib, oracle_lib):
     assert len(r.preempted) > 500 and st["preempt_fast_iterations"] > 500
     for tokens in (0.0, 7.0):
         both(hip_lib, oracle_lib, wl, tokens)
+
+
+def _long_skip_workload(variant):
+    """BenchmarkPreemptingQueueScheduler's steady state (preempting_queue_scheduler_test.go:2561-2799): full nodes, queues of thousands of identical jobs that no longer fit — the
+    first one registers its scheduling key as unfeasible, the rest are skipped at peek time (queue_scheduler.go:398-413).  Stretches of >= SKIP_BULK_MIN jobs are skipped as two
+    bulk passes (round_wide.h skipUnfeasibleBulk); the variants put what ENDS a stretch in the middle of one: a job of another shape, a gang, the lookback limit."""
+    wl = W.reference_benchmark(6, 3, 9000)
+    first = 6 * 32                                  # the first round's jobs fill the 6 nodes (32 x 1 cpu each)
+    node = wl.job_node.copy(); prio = wl.job_run_prio.copy()
+    filled = 0
+    for q in wl.queued:
+        for j in q[:first // 3]:
+            node[int(j)] = filled // 32; prio[int(j)] = 0; filled += 1
+    wl.job_node, wl.job_run_prio = node.astype(np.int32), prio.astype(np.int32)
+    wl.queued = [np.array([int(j) for j in q if node[int(j)] < 0], dtype=np.int32) for q in wl.queued]
+    if variant == "other_shape":                    # a 2-cpu job 5 000 jobs into queue 1: its key is not registered — the stretch stops there, it is attempted (and fails), the rest goes on
+        wl.job_req[int(wl.queued[1][5000]), W.CPU] = 2000
+    elif variant == "lookback":
+        wl.config.max_queue_lookback = 3000         # every queue stops looking after 3 000 jobs: the stretch is cut by the limit
+    return wl
+
+
+@pytest.mark.parametrize("variant", ["plain", "other_shape", "lookback"])
+def test_long_stretches_of_known_unfeasible_jobs(hostsim_lib, oracle_lib, variant):
+    wl = _long_skip_workload(variant)
+    r, st = both(hostsim_lib, oracle_lib, wl)
+    reasons = np.asarray(r.job_unschedulable_reason)
+    skipped = int((reasons == 17).sum())            # ASCHED_REASON_SKIPPED_UNFEASIBLE_KEY
+    assert len(r.scheduled) == 0 and skipped > (8000 if variant == "lookback" else 26000), (len(r.scheduled), skipped)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["plain", "other_shape", "lookback"])
+def test_long_stretches_of_known_unfeasible_jobs_gpu(hip_lib, oracle_lib, variant):
+    wl = _long_skip_workload(variant)
+    r, st = both(hip_lib, oracle_lib, wl)
+    assert len(r.scheduled) == 0
