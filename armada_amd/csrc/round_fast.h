@@ -1136,6 +1136,7 @@ DEV void coldS(Dev& d, FastS& S) {
    S.laneL = 0; S.laneX = 0; S.numEvictedJobs = 0; S.loopIterations = 0; S.statRefills = 0; S.statScanSteps = 0; S.statL0Max = 0;
   S.numUnfeasible = RS.numUnfeasible; S.numPreemptedMarks = RS.numPreemptedMarks; S.fastActive = RS.fastActive; S.lvl0NonNeg = RS.lvl0NonNeg; S.replayPending = RS.replayPending;
   S.globalTokens = 0; S.globalBurst = 0; S.globalRateInf = 1; S.numScheduledJobs = S.numScheduledGangs = S.numNodeQueries = S.evictedTableSize = 0; S.statFastIters = S.statFastReplay = 0; S.segT = 0;
+  S.engLive = 0; S.engPend = -1;   // (every caller of a cold helper has the node engine stopped: fastAdvance's bulk skip asks)
 }
 DEV_NOINLINE SkipDelta fastEnterSkip(Dev& d, FastCtx fc, int Q) {
   const FastK k = fastKRef(d);
