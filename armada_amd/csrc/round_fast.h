@@ -1133,6 +1133,10 @@ DEV int fastReplayStep(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, int
 // current head are taken back (applyEvictedRange sign -1) and become ordinary heads again, which reproduces the exact state.
 struct SkipDelta { int evicted, iters, refills; };  // what a cold helper changed of the scheduling-context scalars the loop keeps in registers
 DEV void coldS(Dev& d, FastS& S) {
+#ifdef ASCHED_HOSTSIM
+  memset((void*)&S, 0xA5, sizeof S);   // the CPU build poisons what is not set below: a cold helper that reads such a field fails the differential tests here instead of reading a
+                                       // register's leftovers on the device (round 4: engLive — the bulk skip never ran on the GPU while the CPU build happened to read 0)
+#endif
    S.laneL = 0; S.laneX = 0; S.numEvictedJobs = 0; S.loopIterations = 0; S.statRefills = 0; S.statScanSteps = 0; S.statL0Max = 0;
   S.numUnfeasible = RS.numUnfeasible; S.numPreemptedMarks = RS.numPreemptedMarks; S.fastActive = RS.fastActive; S.lvl0NonNeg = RS.lvl0NonNeg; S.replayPending = RS.replayPending;
   S.globalTokens = 0; S.globalBurst = 0; S.globalRateInf = 1; S.numScheduledJobs = S.numScheduledGangs = S.numNodeQueries = S.evictedTableSize = 0; S.statFastIters = S.statFastReplay = 0; S.segT = 0;
