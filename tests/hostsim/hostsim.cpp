@@ -128,6 +128,8 @@ static int plat_run_control(Dev& dev, int cmd) {
   // another thread works as on the device
   bool isRound = cmd == CMD_ROUND || cmd == CMD_QUEUES_ONLY || cmd == CMD_PASS1 || cmd == CMD_PASS2;
   if (isRound && t_ctx->deadlineS > 0 && t_ctx->deadlineS <= 1e-6) t_ctx->cancelWord = 1;
+  if (!getenv("HS_NO_LDS_POISON")) memset((void*)&g_fl, 0xA5, sizeof g_fl);   // on the device this is LDS: whatever the previous kernel left there.  A launch that reads a field before writing it
+                                                                              // must not pass here on a zeroed (or a still valid) one.
   if (cmd >= CMD_AUX_FIRST) controlMainAux(d, cmd); else controlMain(d, cmd);
   if (isRound && !t_ctx->inRound) t_ctx->cancelWord = 0;
   if (t_ctx->inRound) t_ctx->launches++;
