@@ -130,6 +130,11 @@ __shared__ RoundScalars g_rs;  // d.rs points here for the whole launch (relocat
 #define DEV_NOINLINE __device__ static __attribute__((noinline))
 #endif
 #define FL g_fl
+#ifdef ASCHED_HOSTSIM
+#define HS_POISON(x) memset((void*)&(x), 0xA5, sizeof(x))   // the CPU build: a local the device keeps in registers starts as garbage there, not as whatever the host stack holds
+#else
+#define HS_POISON(x) do {} while (0)
+#endif
 
 // A value every lane of the control wave holds identically, moved to scalar registers: branches on it become scalar
 // branches (no exec-mask bookkeeping) and arithmetic on it runs on the scalar unit.
@@ -514,7 +519,7 @@ DEV void fastTouch(Dev& d, int n) {
   uint64_t key = fastKeyOf(d, n);
   int64_t ex0 = k.E > 0 ? KAL(k, 0, k.ex0col, n) : 0, ex1 = k.E > 1 ? KAL(k, 0, k.ex1col, n) : 0;
   int pos = GA(int32_t, d.posOf)[n], slot = k.l0Slot[n];
-  { FastS TS;  baseMarkRemoved(k, TS, pos); }
+  { FastS TS; HS_POISON(TS); baseMarkRemoved(k, TS, pos); }
   candInvalidate(k.S, n);
   uint64_t cls = GA(uint64_t, d.nodeCls)[n], cls2 = 0;
   bool live;
@@ -550,7 +555,7 @@ DEV int fastFirstFit(KREF k, FastS& S, const JobTail& r, FitHandle* h, CandRec* 
 DEV int fastSelectLevel0(Dev& d, int job) {
   if (!d.f.structOk || !RS.fastActive) return -2;
   const FastK k = fastKRef(d);
-  FastS S; S.statScanSteps = 0; 
+  FastS S; HS_POISON(S); S.statScanSteps = 0; 
   JobRec jr = d.jrec[job];
   JobTail r; memcpy(&r, &jr.keyDelta, sizeof r);
   FitHandle h; CandRec c;
@@ -608,7 +613,7 @@ DEV bool fastGangMember(Dev& d, Ctl& c, int job) {
   uniJobTail(r);
   if (r.never) return false;
   if (k.anyDisallowed) for (int x = 0; x < k.R; x++) if (d.cfg.disallowed[x] && jr.req[x] > 0) return false;
-  FastS S; S.statScanSteps = 0;  S.statL0Max = RS.statL0Max;
+  FastS S; HS_POISON(S); S.statScanSteps = 0;  S.statL0Max = RS.statL0Max;
   S.laneL = FLANE / (k.R > 0 ? k.R : 1); S.laneX = FLANE % (k.R > 0 ? k.R : 1);
   FitHandle h; h.src = 0; h.slot = -1;
   CandRec cand; cand.pos = 0; cand.node = -1; cand.key = 0; cand.cls = 0; cand.ex0 = cand.ex1 = 0; cand.pad = 0;
@@ -1134,7 +1139,7 @@ DEV int fastReplayStep(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, int
 struct SkipDelta { int evicted, iters, refills; };  // what a cold helper changed of the scheduling-context scalars the loop keeps in registers
 DEV void coldS(Dev& d, FastS& S) {
 #ifdef ASCHED_HOSTSIM
-  memset((void*)&S, 0xA5, sizeof S);   // the CPU build poisons what is not set below: a cold helper that reads such a field fails the differential tests here instead of reading a
+  HS_POISON(S);                        // the CPU build poisons what is not set below: a cold helper that reads such a field fails the differential tests here instead of reading a
                                        // register's leftovers on the device (round 4: engLive — the bulk skip never ran on the GPU while the CPU build happened to read 0)
 #endif
    S.laneL = 0; S.laneX = 0; S.numEvictedJobs = 0; S.loopIterations = 0; S.statRefills = 0; S.statScanSteps = 0; S.statL0Max = 0;
@@ -1578,7 +1583,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   fastEnsureLive(d, c);
   c.l1Dirty = 1;
   const FastK k = fastKRef(d);
-  FastS S;
+  FastS S; HS_POISON(S);
    S.engLive = 0; S.engPend = -1; S.engWaitClk = 0; S.engSeq = 0; S.inlineStreak = 0;
   S.laneL = FLANE / (d.cfg.R > 0 ? d.cfg.R : 1); S.laneX = FLANE % (d.cfg.R > 0 ? d.cfg.R : 1);
   // the scheduling-context scalars this loop keeps in registers

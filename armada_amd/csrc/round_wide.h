@@ -578,7 +578,7 @@ DEV_COLD int wideRun(Dev& d, Ctl& c, const PassCfg& pc) {
 #endif
   if (V <= 0) return 0;
   // ---- execution: stage the merged order into the ring; the node engine places the queued jobs, the bind wave issues the HBM side behind it
-  FastS S;
+  FastS S; HS_POISON(S);
   S.engLive = 0; S.engPend = -1; S.engWaitClk = 0; S.engSeq = 0; S.inlineStreak = 0;
   S.laneL = FLANE / (R > 0 ? R : 1); S.laneX = FLANE % (R > 0 ? R : 1);
   S.statScanSteps = 0; S.statL0Max = UNI32(rs.statL0Max); S.fastActive = 1; S.numUnfeasible = UNI32(rs.numUnfeasible); S.statRefills = 0;
