@@ -1056,6 +1056,11 @@ func (g *GpuRound) ExcludedNodes(job int32) (map[string]int, error) {
 	return out, nil
 }
 
+// SetExcludedNodes bounds how many failed node selections a round keeps a record of (default 1 024; 0 turns the records — and their one wide pass per failed attempt — off).
+func (g *GpuRound) SetExcludedNodes(maxFailedSelections int) error {
+	return g.check(C.asched_set_excluded_nodes(g.h, C.int32_t(maxFailedSelections)))
+}
+
 func effectName(e int32) v1.TaintEffect {
 	switch e {
 	case C.ASCHED_EFFECT_NO_SCHEDULE:
