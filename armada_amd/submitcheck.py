@@ -73,6 +73,69 @@ class PoolNodeDb:
         """floatingResourceTypes.GetTotalAvailableForPool"""
         return {}
 
+    def explain(self, job_index: int) -> Optional[str]:
+        """pctx.String() (scheduling/context/pod.go:62-83) of job `job_index` of the loaded table after a failed individual check in this pool — node, number of nodes,
+        NumExcludedNodesByReason — or None when the backend does not produce it (asched_select_node + asched_excluded_nodes + pod_context_string below).  Only asked for
+        with SubmitChecker(explain=True): one selection + one histogram per failing scheduling key and pool."""
+        return None
+
+
+def quantity_string(raw: int, scale: int) -> str:
+    """resource.Quantity.String() of NewScaledQuantity(raw, scale) (DecimalSI; k8s.io/apimachinery/pkg/api/resource: int64Amount.AsCanonicalBytes + the decimal suffixes):
+    trailing zeros go into the exponent, the exponent is brought down to a multiple of three, the suffix names it"""
+    if raw == 0:
+        return "0"
+    amount, exp = int(raw), int(scale)
+    while amount % 10 == 0:
+        amount //= 10
+        exp += 1
+    r = exp % 3            # Python's % is non-negative: 1 == Go's {1, -2}, 2 == Go's {2, -1}
+    if r == 1:
+        amount *= 10; exp -= 1
+    elif r == 2:
+        amount *= 100; exp -= 2
+    suffix = {-9: "n", -6: "u", -3: "m", 0: "", 3: "k", 6: "M", 9: "G", 12: "T", 15: "P", 18: "E"}.get(exp)
+    return f"{amount}{suffix}" if suffix is not None else f"{amount}e{exp}"
+
+
+def excluded_reason_string(entry, names) -> str:
+    """the reference's reason strings (nodedb/nodematching.go:14-125, nodedb.go:27) for one asched_excluded_nodes entry; `names`: .string(id) for interned label / taint strings,
+    .effect(code), .resource(col) -> (name, scale), .affinity() -> the job's NodeSelector as Go prints it"""
+    kind, a, b, c, required, available, _ = entry
+    if kind == "implicit":
+        return "insufficient resources available"
+    if kind == "untolerated_taint":
+        return f"taint {names.string(a)}={names.string(b)}:{names.effect(c)} not tolerated"
+    if kind == "missing_label":
+        return f"node does not match pod NodeSelector: label {names.string(a)} not set"
+    if kind == "unmatched_label":
+        return f"node does not match pod NodeSelector: required label {names.string(a)} = {names.string(b)}, but node has {names.string(c)}"
+    if kind == "unmatched_affinity":
+        return f"node does not match pod NodeAffinity {names.affinity()}"
+    if kind == "insufficient_resources":
+        name, scale = names.resource(a)
+        return f"pod requires {quantity_string(required, scale)} {name}, but only {quantity_string(available, scale)} is available"
+    if kind == "disallowed_resource":
+        return "job requests disallowed resource and therefore cannot be scheduled"
+    return kind
+
+
+def pod_context_string(num_nodes: int, excluded: Sequence[Tuple[str, int]]) -> str:
+    """PodSchedulingContext.String() for a pod without a node (pod.go:62-83), laid out like text/tabwriter.NewWriter(&sb, 1, 1, 1, ' ', 0): a cell is text terminated by a tab,
+    a column of consecutive lines is as wide as its widest cell + 1, text behind a line's last tab is not part of a column, a line without a tab ends the column block.
+    `excluded`: (reason string, count); the reference ranges over a Go map — here sorted by reason."""
+    head = [("Node:", "none"), ("Number of nodes in cluster:", str(num_nodes))]
+    if not excluded:
+        head.append(("Excluded nodes:", "none"))
+    w0 = max(len(k) for k, _ in head) + 1
+    out = [k.ljust(w0) + v for k, v in head]
+    if excluded:
+        out.append("Excluded nodes:")
+        rows = sorted(excluded)
+        w1 = max(len(f"{n}:") for _, n in rows) + 1
+        out += [" " + f"{n}:".ljust(w1) + reason for reason, n in rows]   # "\t%d:\t%s": an empty first cell (width 0 + padding 1), then the count column
+    return "\n".join(out) + "\n"
+
 
 class _Deadline:                               # submitcheck.go:34-45
     def __init__(self, limit: float, now: float):
@@ -86,7 +149,8 @@ class SubmitChecker:
     """SubmitChecker.Check (submitcheck.go:225-269) with the NodeDb work batched per pool."""
 
     def __init__(self, pools: Sequence[PoolConfig], node_db_by_pool: Dict[str, PoolNodeDb], *, max_duration: float = 0.0,
-                 max_duration_per_queue: float = 0.0, now: Optional[Callable[[], float]] = None):
+                 max_duration_per_queue: float = 0.0, now: Optional[Callable[[], float]] = None, explain: bool = False):
+        self.explain = explain   # a failing individual check carries pctx.String() with NumExcludedNodesByReason, like the reference's (:372-381), instead of a fixed sentence
         self.pools = list(pools)
         self.node_db_by_pool = node_db_by_pool
         self.max_duration, self.max_duration_per_queue = max_duration, max_duration_per_queue
@@ -148,7 +212,7 @@ class SubmitChecker:
         return events
 
     # ---- getSchedulingResult's pool loop (:309-394) over per-pool answers that are already known
-    def _pool_loop(self, rep: SubmitJob, members: Sequence[SubmitJob], raw: Dict[str, Tuple[bool, bool, int, int]]) -> SchedulingResult:
+    def _pool_loop(self, rep: SubmitJob, members: Sequence[SubmitJob], raw: Dict[str, Tuple[bool, bool, int, int]], rep_index: int = -1) -> SchedulingResult:
         successful: Dict[str, bool] = {}
         reason: List[str] = []
         total = [sum(m.request[r] for m in members) for r in range(len(rep.request))]        # gctx.TotalResourceRequests
@@ -178,7 +242,11 @@ class SubmitChecker:
                     for p in self.pools_by_submission_group[pool.get_submission_group()]:
                         successful[p] = True
                 continue
-            reason.append("job does not fit on any node\n---\n" if len(members) == 1 else f": {nsched} out of {len(members)} pods schedulable\n")
+            if len(members) == 1:
+                txt = db.explain(rep_index) if (self.explain and rep_index >= 0) else None
+                reason.append((txt + "\n" if txt is not None else "job does not fit on any node\n") + "---\n")   # pctx.String() + "\n" + "---" + "\n" (:377-381; String() ends its last line itself: a blank line follows)
+            else:
+                reason.append(f": {nsched} out of {len(members)} pods schedulable\n")
         if successful:
             return SchedulingResult(True, list(successful.keys()))
         return SchedulingResult(False, [], "".join(reason))
@@ -231,7 +299,7 @@ class SubmitChecker:
             if hit is not None:
                 return hit
             u = unit_of_key[key]
-            r = self._pool_loop(jobs[i], [jobs[i]], {p.name: raw_ind[p.name][u] for p in self.pools})
+            r = self._pool_loop(jobs[i], [jobs[i]], {p.name: raw_ind[p.name][u] for p in self.pools}, rep_index=reps[u])
             self._cache_add(key, r)
             return r
 

@@ -79,6 +79,29 @@ class CasePoolDb(PoolNodeDb):
             return [(False, False, 0, -1) for _ in units]
         return self.case.sched.submit_check(units, strip_gang)
 
+    def explain(self, job_index):
+        """pctx.String() of the job's failed selection in this pool (scheduling/context/pod.go:62-83)"""
+        from armada_amd.submitcheck import excluded_reason_string, pod_context_string
+        if not self.case:
+            return pod_context_string(0, [])
+        s = self.case.sched
+        pod, _ = s.select_node(job_index)
+        if pod.node >= 0:
+            return None
+        inv = {v: k for k, v in self.case.S.d.items()}
+        job = self.loaded[job_index]
+
+        class Names:
+            string = staticmethod(lambda i: "armadaproject.io/unschedulable" if i == -2 else inv.get(i, f"#{i}"))
+            effect = staticmethod(lambda e: {1: "NoSchedule", 2: "PreferNoSchedule", 3: "NoExecute"}.get(e, ""))
+            resource = staticmethod(lambda col: (RES[col], -3 if RES[col] == "cpu" else 0))
+            affinity = staticmethod(lambda: repr(job.get("affinity")))
+        merged = {}
+        for e in s.excluded_nodes(job_index):
+            r = excluded_reason_string(e, Names)
+            merged[r] = merged.get(r, 0) + e[-1]
+        return pod_context_string(len(self.nodes), list(merged.items()))
+
     def queue_resource_limit(self, queue, pc):
         """calculatePerQueueLimits (constraints.go:218-256) -> GetQueueResourceLimit (:180-185)"""
         if not any(self.total):              # totalResources.IsEmpty(): no limits at all (:226-228)
@@ -140,12 +163,12 @@ def make_clock(case: dict):
     return SteppingClock(case.get("clockStep") or 0)
 
 
-def batched_check(lib: Library, case: dict, cache_size: int = 10000) -> Dict[str, SchedulingResult]:
+def batched_check(lib: Library, case: dict, cache_size: int = 10000, explain: bool = False) -> Dict[str, SchedulingResult]:
     """the product flow: armada_amd.submitcheck.SubmitChecker over asched_submit_check"""
     pools, dbs = build_state(lib, case)
     cfg = case.get("submitCheckConfig") or {}
     chk = SubmitChecker(pools, dbs, max_duration=cfg.get("MaxDuration", 0), max_duration_per_queue=cfg.get("MaxDurationPerQueue", 0),
-                        now=make_clock(case))
+                        now=make_clock(case), explain=explain)
     chk.cache_size = cache_size
     return chk.check([to_submit_job(j) for j in case["jobs"]])
 

@@ -386,3 +386,54 @@ def test_gang_units_equal_sequential_gpu(hip_lib, oracle_lib, monkeypatch):
         a, b, c = _gang_units_equal_sequential(hip_lib, oracle_lib, seed, monkeypatch)
         g += a; ok += b; partial += c
     assert g > 100 and ok > 100 and partial > 10, (g, ok, partial)
+
+
+# ---- the rejection message of an individual check: pctx.String() with NumExcludedNodesByReason (submitcheck.go:372-381, scheduling/context/pod.go:62-83) ------------------
+def test_quantity_and_pod_context_strings():
+    """resource.Quantity.String() of NewScaledQuantity (int64Amount.AsCanonicalBytes: trailing zeros into the exponent, exponent down to a multiple of three) and the
+    text/tabwriter layout of PodSchedulingContext.String() (minwidth 1, tabwidth 1, padding 1, ' '), worked out by hand from the two sources"""
+    from armada_amd.submitcheck import pod_context_string, quantity_string
+    assert [quantity_string(*x) for x in [(1000, -3), (1500, -3), (32000, -3), (5, -3), (4294967296, 0), (100, 0), (1000000, 0), (0, 0), (12000000, -3)]] == \
+        ["1", "1500m", "32", "5m", "4294967296", "100", "1M", "0", "12k"]
+    assert pod_context_string(3, [("taint foo=bar:NoSchedule not tolerated", 2), ("insufficient resources available", 1)]) == (
+        "Node:                       none\n"
+        "Number of nodes in cluster: 3\n"
+        "Excluded nodes:\n"
+        " 1: insufficient resources available\n"
+        " 2: taint foo=bar:NoSchedule not tolerated\n")
+    assert pod_context_string(12, [("insufficient resources available", 12)]).splitlines()[-1] == " 12: insufficient resources available"
+    assert pod_context_string(1, []) == "Node:                       none\nNumber of nodes in cluster: 1\nExcluded nodes:             none\n"
+
+
+def _explained(lib, case):
+    return H.batched_check(lib, case, explain=True)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_rejection_messages_carry_the_excluded_nodes_hostsim(oracle_lib, hostsim_lib, seed):
+    """with explain=True a failing individual check reports why, per pool, like the reference's: the product's text (device records + host-derived static reasons) against the
+    oracle's (its iterator walk), and the counts of every message add up to the pool's nodes"""
+    case = random_case(seed)
+    a, b = _explained(oracle_lib, case), _explained(hostsim_lib, case)
+    H.same_results(a, b)
+    seen = 0
+    for k in a:
+        assert a[k].reason == b[k].reason, (k, a[k].reason, b[k].reason)
+        for block in a[k].reason.split("---\n"):
+            if "Excluded nodes:" in block and "Excluded nodes:             none" not in block:
+                n = int(block.split("Number of nodes in cluster:")[1].split()[0])
+                counts = [int(line.split(":")[0]) for line in block.split("Excluded nodes:\n")[1].splitlines() if line.startswith(" ")]
+                assert sum(counts) == n, block
+                seen += 1
+    assert seen > 0
+    plain = H.batched_check(hostsim_lib, case)                       # the default stays the fixed sentence (and the fast batch: no extra selections)
+    assert all(("Excluded nodes" not in r.reason) for r in plain.values())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(4))
+def test_rejection_messages_carry_the_excluded_nodes_gpu(oracle_lib, hip_lib, seed):
+    case = random_case(seed)
+    a, b = _explained(oracle_lib, case), _explained(hip_lib, case)
+    for k in a:
+        assert a[k].reason == b[k].reason, (k, a[k].reason, b[k].reason)
