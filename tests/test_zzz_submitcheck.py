@@ -285,6 +285,16 @@ def _pristine_tracking(lib, oracle):
         assert (s.get_alloc(0) == np.array(H.vec(nodes[0]["total"]))[None, :]).all()
         cleared = s.submit_check([[0], [1], [2]], [True] * 3)
         st_cleared = s.submit_stats()
+        pod, _ = s.select_node(1)                                     # a selection that finds a node does not bind it, but may have preempted: not pristine any more ...
+        assert pod.node == 0
+        s.clear_allocated(); c.set_jobs(jobs, {"q": 0}, {})
+        big = dict(jobs[1], req={"cpu": 64000, "memory": GI}); c.set_jobs(jobs + [big], {"q": 0}, {})
+        pod, _ = s.select_node(4)                                     # ... a selection that finds NONE touched nothing (nil, nil, nil): the batch paths stay on
+        assert pod.node < 0 and s.excluded_nodes(4)
+        again = s.submit_check([[0], [1], [2]], [True] * 3)
+        if l is lib:
+            assert s.submit_stats()["wide_units"] == 3 and again == cleared
+        c.set_jobs(jobs, {"q": 0}, {})
         s.bind(3, 0, 0)                                               # 2 cpus taken: the 4-cpu job no longer fits, and the NodeDb is not pristine
         occupied = s.submit_check([[0], [1], [2]], [True] * 3)
         st_occ = s.submit_stats()
