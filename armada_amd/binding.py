@@ -740,12 +740,18 @@ class Scheduler:
 
     def submit_check(self, units: Sequence[Sequence[int]], strip_gang: Optional[Sequence[bool]] = None):
         """One batch of submit-check units (submitcheck.go:342-371); returns [(ok, scheduled_away, num_schedulable, first_node)]."""
-        nu = len(units)
-        if nu == 0:
-            return []
-        off = np.zeros(nu + 1, dtype=np.int32)
-        off[1:] = np.cumsum([len(u) for u in units])
-        jobs = _arr([j for u in units for j in u], np.int32)
+        if isinstance(units, tuple) and len(units) == 2 and isinstance(units[0], np.ndarray):   # (unit_off, unit_jobs) as the ABI takes them: no per-member Python work (a unit of 64 000 members)
+            off, jobs = np.ascontiguousarray(units[0], dtype=np.int32), np.ascontiguousarray(units[1], dtype=np.int32)
+            nu = len(off) - 1
+            if nu <= 0:
+                return []
+        else:
+            nu = len(units)
+            if nu == 0:
+                return []
+            off = np.zeros(nu + 1, dtype=np.int32)
+            off[1:] = np.cumsum([len(u) for u in units])
+            jobs = _arr([j for u in units for j in u], np.int32)
         flags = _arr([SUBMIT_STRIP_GANG if (strip_gang is not None and strip_gang[i]) else 0 for i in range(nu)], np.int32)
         out = (CSubmitResult * nu)()
         self._check(self.lib.submit_check(self.h, nu, _ptr(off, C.c_int32), _ptr(jobs, C.c_int32), _ptr(flags, C.c_int32), out))

@@ -602,7 +602,7 @@ def schedule_many_benchmark_record(hip, args):
                         abp[:, l, W.CPU] -= used * 1000
             s.nodes_upsert(wl.node_total, wl.node_allocatable, alloc_by_prio=abp)
             W.set_jobs(s, wl)
-            unit = [list(range(nj))]
+            unit = (np.array([0, nj], dtype=np.int32), np.arange(nj, dtype=np.int32))   # the unit in the ABI's CSR form (the job ids of a gang context: built once, like the benchmark's `jobs`)
             s.submit_check(unit, [False])   # warm-up
             times, r = [], None
             for _ in range(3):
