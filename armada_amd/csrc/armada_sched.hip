@@ -2632,6 +2632,17 @@ extern "C" int asched_internal_mgpu_pack(const Dev* d, const GlobalKeyLayout* L,
 extern "C" int asched_internal_mgpu_delta(const Dev* d, long long* buf, int ns, int np, hipStream_t s);
 extern "C" int asched_internal_mgpu_resolve(const Dev* d, const long long* red, long long* freeC, uint8_t* ownPre, uint8_t* conflict, uint8_t* gangReplay,
                                             int32_t* node, int32_t* prio, uint8_t* replay, int32_t* counts, int ns, int np, hipStream_t s);
+// the handle's scratch buffer of the fit / capacity / gang-unit launches (kept across calls: an allocation per call showed up as a 13 ms outlier among 0.06 ms calls)
+static void* plat_fit_scratch(size_t need) {
+  PlatCtx* c = t_ctx;
+  if (c->fitScratchBytes < need) {
+    if (c->fitScratch) (void)hipFree(c->fitScratch);
+    c->fitScratch = nullptr; c->fitScratchBytes = 0;
+    if (!hipOk(hipMalloc(&c->fitScratch, need * 2), "hipMalloc")) return nullptr;
+    c->fitScratchBytes = need * 2;
+  }
+  return c->fitScratch;
+}
 // the submit check's gang units, one workgroup per unit (submit_gang.h; the kernel lives in armada_sched_mgpu.hip).  out: 4 words per unit; the kernel time goes to lastFitMs
 extern "C" int asched_internal_submit_gangs(const Dev* d, const int32_t* off, const int32_t* jobs, int nu, int32_t* out, hipStream_t s);
 #define SG_MAX_NODES 262144   // the workgroup's node bitmap lives in LDS (32 KB at this size)
@@ -2640,8 +2651,10 @@ static int plat_run_submit_gangs(Dev& d, const std::vector<int32_t>& off, const 
   out.assign((size_t)std::max(nu, 0) * 4, 0);
   if (nu <= 0) return 0;
   hipStream_t st = t_ctx->stream;
-  int32_t *dOff = nullptr, *dJobs = nullptr, *dOut = nullptr;
-  bool ok = hipOk(hipMalloc(&dOff, off.size() * 4), "hipMalloc") && hipOk(hipMalloc(&dJobs, std::max<size_t>(jobs.size(), 1) * 4), "hipMalloc") && hipOk(hipMalloc(&dOut, out.size() * 4), "hipMalloc");
+  size_t nOff = (off.size() + 3) & ~(size_t)3, nJobs = (std::max<size_t>(jobs.size(), 1) + 3) & ~(size_t)3;
+  int32_t* base = (int32_t*)plat_fit_scratch((nOff + nJobs + out.size()) * 4);
+  bool ok = base != nullptr;
+  int32_t *dOff = base, *dJobs = base + nOff, *dOut = base + nOff + nJobs;
   if (ok) {
     (void)hipMemcpyAsync(dOff, off.data(), off.size() * 4, hipMemcpyHostToDevice, st);
     (void)hipMemcpyAsync(dJobs, jobs.data(), jobs.size() * 4, hipMemcpyHostToDevice, st);
@@ -2651,7 +2664,6 @@ static int plat_run_submit_gangs(Dev& d, const std::vector<int32_t>& off, const 
     ok = ok && hipOk(hipMemcpyAsync(out.data(), dOut, out.size() * 4, hipMemcpyDeviceToHost, st), "hipMemcpy") && hipOk(hipStreamSynchronize(st), "k_submit_gangs");
     (void)hipEventElapsedTime(&t_ctx->lastFitMs, t_ctx->fitEv0, t_ctx->fitEv1);
   }
-  if (dOff) (void)hipFree(dOff); if (dJobs) (void)hipFree(dJobs); if (dOut) (void)hipFree(dOut);
   return ok ? 0 : -1;
 }
 // uniform submit-check units (submit_gang.h): per shape {first node or -1, members all nodes take together}
@@ -2661,9 +2673,10 @@ static int plat_run_fit_capacity(Dev& d, const std::vector<int32_t>& shapes, std
   firstNode.assign(ns, -1); capacity.assign(ns, 0);
   if (ns == 0 || d.cfg.N == 0) return 0;
   hipStream_t st = t_ctx->stream;
-  unsigned long long* dOut = nullptr; int32_t* dShapes = nullptr;
   size_t words = (size_t)ns * FIT_OSTR;
-  bool ok = hipOk(hipMalloc(&dOut, words * 8), "hipMalloc") && hipOk(hipMalloc(&dShapes, (size_t)ns * 4), "hipMalloc");
+  unsigned long long* dOut = (unsigned long long*)plat_fit_scratch(words * 8 + (size_t)ns * 4 + 16);
+  int32_t* dShapes = (int32_t*)(dOut + words);
+  bool ok = dOut != nullptr;
   std::vector<unsigned long long> init(words, 0), got(words);
   for (int i = 0; i < ns; i++) init[(size_t)i * FIT_OSTR] = ~0ull;
   if (ok) {
@@ -2675,7 +2688,6 @@ static int plat_run_fit_capacity(Dev& d, const std::vector<int32_t>& shapes, std
     ok = ok && hipOk(hipMemcpyAsync(got.data(), dOut, words * 8, hipMemcpyDeviceToHost, st), "hipMemcpy") && hipOk(hipStreamSynchronize(st), "k_fit_capacity");
     (void)hipEventElapsedTime(&t_ctx->lastFitMs, t_ctx->fitEv0, t_ctx->fitEv1);
   }
-  if (dOut) (void)hipFree(dOut); if (dShapes) (void)hipFree(dShapes);
   if (!ok) return -1;
   unsigned long long mask = (1ull << d.cfg.idxBits) - 1;
   for (int i = 0; i < ns; i++) {
