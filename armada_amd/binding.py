@@ -23,7 +23,7 @@ EVICTED_PRIORITY = -2
 CROSS_POOL_PRIORITY = -1
 
 OK = 0
-ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_INTERNAL, ERR_TIMEOUT = -1, -2, -3, -4, -5
+ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_INTERNAL, ERR_TIMEOUT, ERR_PEER = -1, -2, -3, -4, -5, -6
 
 EFFECT_NONE, EFFECT_NO_SCHEDULE, EFFECT_PREFER_NO_SCHEDULE, EFFECT_NO_EXECUTE = 0, 1, 2, 3
 TOL_EQUAL, TOL_EXISTS = 0, 1
@@ -738,10 +738,13 @@ class Scheduler:
         self._check(self.lib.market_iterate(self.h, nq, _ptr(nr, C.c_int32), _ptr(off, C.c_int32), arr, int(preempt_cross_pool_jobs_first), _ptr(out, C.c_int32)))
         return [int(x) for x in out[:total]]
 
-    def submit_check(self, units: Sequence[Sequence[int]], strip_gang: Optional[Sequence[bool]] = None):
-        """One batch of submit-check units (submitcheck.go:342-371); returns [(ok, scheduled_away, num_schedulable, first_node)]."""
-        if isinstance(units, tuple) and len(units) == 2 and isinstance(units[0], np.ndarray):   # (unit_off, unit_jobs) as the ABI takes them: no per-member Python work (a unit of 64 000 members)
-            off, jobs = np.ascontiguousarray(units[0], dtype=np.int32), np.ascontiguousarray(units[1], dtype=np.int32)
+    def submit_check(self, units: Optional[Sequence[Sequence[int]]] = None, strip_gang: Optional[Sequence[bool]] = None, *, csr=None):
+        """One batch of submit-check units (submitcheck.go:342-371); returns [(ok, scheduled_away, num_schedulable, first_node)].
+        `units`: a list of job-id lists; or `csr=(unit_off, unit_jobs)`, the ABI's own form (explicit keyword: never guessed from the shape of `units`)."""
+        if csr is not None:   # no per-member Python work (a unit of 64 000 members)
+            if units is not None:
+                raise ValueError("submit_check: give `units` or `csr`, not both")
+            off, jobs = np.ascontiguousarray(csr[0], dtype=np.int32), np.ascontiguousarray(csr[1], dtype=np.int32)
             nu = len(off) - 1
             if nu <= 0:
                 return []
@@ -778,9 +781,9 @@ class Scheduler:
         return a.value, b.value
 
     def submit_stats(self):
-        out = (C.c_int32 * 4)()
+        out = (C.c_int32 * 6)()
         self._check(self.lib.submit_stats(self.h, out))
-        return dict(wide_units=out[0], wide_passes=out[1], sequential_units=out[2], gang_units=out[3])
+        return dict(wide_units=out[0], wide_passes=out[1], sequential_units=out[2], gang_units=out[3], node_passes=out[4])
 
     def select_node(self, job: int, pinned_node: int = -1):
         out = CPodResult()

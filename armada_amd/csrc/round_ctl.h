@@ -21,26 +21,12 @@
 #include <cstring>
 #define DEV static inline
 #define DEV_COLD static
-#define COLD_MS_0
-#define COLD_MS_1
-#define COLD_MS_2
-#define COLD_MS_3
-#define COLD_MS_4
-#define COLD_MS_5
-#define COLD_MS_6
-#define COLD_MS_7
-#define COLD_MS_8
-#define COLD_MS_9
-#define COLD_MS_10
-#define COLD_MS_11
-#define COLD_MS_12
 #define WG_THREADS 1
 #else
 #define DEV __device__ static inline
 // the big generic-path functions: out of line.  Inlined into every call site they made the round kernel's code several times larger (the
 // whole cascade sits in selectNodeForJob twice — home and away), which costs compile time and instruction-cache room next to the hot loop
 #define DEV_COLD __device__ static __attribute__((noinline))
-#include "cold_attr.h"
 #define WG_THREADS 1024
 #define CLK() ((long long)__builtin_readcyclecounter())
 #endif
@@ -565,7 +551,7 @@ DEV bool litNodeLess(Dev& d, int level, int a, int b) {  // nodeTypesIteratorPQ.
   return d.nodeIdRank[a] < d.nodeIdRank[b];
 }
 // selectNodeForPodAtPriority + selectNodeForPodWithItAtPriority (nodedb.go:840-928) over the literal iterators
-DEV_COLD COLD_MS_0 int selectAtLevelLiteral(Dev& d, int job, int32_t prio, int level, int row) {
+DEV_COLD int selectAtLevelLiteral(Dev& d, int job, int32_t prio, int level, int row) {
   const DevCfg& c = d.cfg;
   const int64_t* req = JREQ(d, job);
   int64_t ireq[MAXK];
@@ -650,7 +636,7 @@ DEV int fairNodeBest(const Dev& d, const FairArgs& a, int n, int floorIdx) {
 }
 DEV_COLD void ensureFairIndex(Dev& d);
 DEV_COLD int fairApply(Dev& d, Ctl& c, int job, int idx, int32_t jobPrio);
-DEV_COLD COLD_MS_1 int selectWithFairPreemption(Dev& d, Ctl& c, int job) {
+DEV_COLD int selectWithFairPreemption(Dev& d, Ctl& c, int job) {
   ensureReplay(d, c);
   long long t0 = CLK();
   if (d.progress) { d.progress[2] = 2; d.progress[3]++; }
@@ -670,7 +656,7 @@ DEV_COLD COLD_MS_1 int selectWithFairPreemption(Dev& d, Ctl& c, int job) {
   return fairApply(d, c, job, idx, a.prio);
 }
 // the node of evicted-table entry idx wins: its considered entries are preempted (nodedb.go:1012-1023)
-DEV_COLD COLD_MS_2 int fairApply(Dev& d, Ctl& c, int job, int idx, int32_t jobPrio) {
+DEV_COLD int fairApply(Dev& d, Ctl& c, int job, int idx, int32_t jobPrio) {
   struct { int32_t prio; } a; a.prio = jobPrio;
   if (idx < 0) return -1;
   if (idx >= d.rs->evictedTableSize) { raise(d, ASCHED_ERR_INTERNAL, 600); return -1; }
@@ -727,7 +713,7 @@ DEV_COLD COLD_MS_2 int fairApply(Dev& d, Ctl& c, int job, int idx, int32_t jobPr
 // above.  Hence "first level with any fitting node, then the minimum key at that level" == the minimum over nodes of (lowest level the node
 // fits at, its key at that level), and the gate is "is there any such node".  ONE multi-level pass (ScanArgs.levelHi) answers both; the
 // fair-share attempt in between changes nothing when it fails.  Query counts are kept as the level-by-level loop would have issued them.
-DEV_COLD COLD_MS_3 int selectAtPriority(Dev& d, Ctl& c, int job) {
+DEV_COLD int selectAtPriority(Dev& d, Ctl& c, int job) {
   XSEG(31);
   int n = selectAtLevel(d, job, ASCHED_EVICTED_PRIORITY);
   XSEG(32);
@@ -905,7 +891,7 @@ DEV void preemptSiblings(Dev& d, Ctl& c, int firstPre, int lastPre) {
 }
 
 // ScheduleManyWithTxn (nodedb.go:417-462)
-DEV_COLD COLD_MS_4 bool scheduleMany(Dev& d, Ctl& c, int ref) {
+DEV_COLD bool scheduleMany(Dev& d, Ctl& c, int ref) {
   int cnt = gcCount(d, ref);
   for (int k = 0; k < cnt; k++) {
     int job = gcJob(d, ref, k);
@@ -972,7 +958,7 @@ DEV void fitOf(Dev& d, int ref, int* num, double* mean) {  // gctx.Fit (context/
 // host-built table of uniformity label values: uniOff[label slot], uniVals[] = labelMask ids in ascending value order
 struct UniTable { const int32_t* slotOfLabel; const int32_t* off; int nLabels; };
 // trySchedule (gang_scheduler.go:150-227).  jGangUni[job] holds the label *slot* (-1 none, -2 label not indexed).
-DEV_COLD COLD_MS_5 bool trySchedule(Dev& d, Ctl& c, int ref, int* reason, const int32_t* uniOff) {
+DEV_COLD bool trySchedule(Dev& d, Ctl& c, int ref, int* reason, const int32_t* uniOff) {
   int j0 = gcJob(d, ref, 0);
   int slot = d.jGang[j0] >= 0 ? d.jGangUni[j0] : -1;
   if (slot == -1) return tryGang(d, c, ref, reason);
@@ -1013,7 +999,7 @@ DEV void failJob(Dev& d, int job, int reason) {  // jctx.Fail (context/job.go:11
 }
 
 // GangScheduler.Schedule incl. deferred bookkeeping (gang_scheduler.go:46-148)
-DEV_COLD COLD_MS_6 bool gangSchedule(Dev& d, Ctl& c, int ref, int* reason, const int32_t* uniOff) {
+DEV_COLD bool gangSchedule(Dev& d, Ctl& c, int ref, int* reason, const int32_t* uniOff) {
   *reason = 0;
   bool allEv = gcAllEvicted(d, ref);
   if (!allEv) {
@@ -1437,7 +1423,7 @@ DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff)
 }
 
 // addEvictedJobsToNodeDb (preempting_queue_scheduler.go:589-639): replay the DRF order over the evicted gangs
-DEV_COLD COLD_MS_7 void replayEvicted(Dev& d, Ctl& c) {
+DEV_COLD void replayEvicted(Dev& d, Ctl& c) {
   int Q = d.cfg.Q;
   for (int q = 0; q < Q; q++) for (int r = 0; r < d.cfg.R; r++) QV(d.replayAlloc, q)[r] = QV(d.qAllocSnap, q)[r];  // allocations as the evictor left them
   int savedCmp = c.compareSchedPrio;

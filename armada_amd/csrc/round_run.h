@@ -307,7 +307,7 @@ DEV void bulkElem(Dev& d, int kind, int i) {
 
 // SchedulingContext.updateFairShares (context/scheduling.go:262-342): float64, queues in name order, this exact operation order.
 // Scratch: pqProposed = constrainedDemandShare, pqCurrent = spareShare, pqInHeap = achievedDemand, itNext = name order.
-DEV_COLD COLD_MS_8 void updateFairShares(Dev& d, const double* givenCds) {
+DEV_COLD void updateFairShares(Dev& d, const double* givenCds) {
   const DevCfg& cf = d.cfg;
   int Q = cf.Q;
   double weightSum = 0;
@@ -343,7 +343,7 @@ DEV_COLD COLD_MS_8 void updateFairShares(Dev& d, const double* givenCds) {
 }
 
 // PreemptingQueueScheduler.evict (pqs.go:291-353) for an evictor whose job filter has been evaluated into evFlag
-DEV_COLD COLD_MS_9 int pqsEvict(Dev& d, Ctl& c, bool phase3) {
+DEV_COLD int pqsEvict(Dev& d, Ctl& c, bool phase3) {
   long long t0 = CLK();
   wgBulk(d, B_GANG_CLOSURE, d.cfg.G);
   wgBulk(d, phase3 ? B_EVICT_APPLY3 : B_EVICT_APPLY1, d.cfg.M);
@@ -506,7 +506,7 @@ DEV void ftBuild(Dev& d) {
   d.rs->ftValid = 1;
 }
 #endif
-DEV_COLD COLD_MS_10 void ensureFairIndex(Dev& d) {
+DEV_COLD void ensureFairIndex(Dev& d) {
   const bool periodic = d.rs->fairIndexValid && ++d.accEpoch_unused >= FAIR_REBUILD_EVERY;   // (queries since the last build: a counter of this launch, in the descriptor's LDS copy)
 #ifndef ASCHED_NO_FT
   if (d.rs->fairIndexValid && !periodic) { if (d.ftT && !d.rs->ftValid && d.rs->ftWanted) ftBuild(d); return; }
@@ -542,7 +542,7 @@ DEV void swapLoopArrays(Dev& d) {
 // The deferred addEvictedJobsToNodeDb (pqs.go:589-639): its result — the evicted-table Index of every evicted job — is a pure
 // function of the state the evictor left (qAllocSnap, the eviction lists), so it can be computed at first use.  It runs on its
 // own set of iterator / heap arrays; entries of jobs that have been rescheduled or preempted in the meantime come out dead.
-DEV_COLD COLD_MS_11 void ensureReplaySlow(Dev& d, Ctl& c) {
+DEV_COLD void ensureReplaySlow(Dev& d, Ctl& c) {
   if (!d.rs->replayPending) return;
   d.rs->replayPending = 0;
   fastEnterGeneric(d, c);
@@ -560,7 +560,7 @@ DEV_COLD COLD_MS_11 void ensureReplaySlow(Dev& d, Ctl& c) {
 }
 
 // PreemptingQueueScheduler.Schedule (pqs.go:86-289)
-DEV_COLD COLD_MS_12 void runRound(Dev& d, Ctl& c) {
+DEV_COLD void runRound(Dev& d, Ctl& c) {
   const DevCfg& cf = d.cfg;
   for (int q = 0; q < cf.Q; q++) {  // balance-evictor filter inputs are the start-of-round queue allocations (pqs.go:124-134)
     double actual = drf(d, QV(d.qAlloc, q));

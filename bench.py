@@ -35,6 +35,20 @@ def algorithmic_bytes(n_nodes, R, queries, binds, fair_scan_rows=0):
     return queries * n_nodes * (R * 8 + 8) + binds * 256 + fair_scan_rows * (R * 8 + 16)
 
 
+def kernel_isa_hash():
+    """sha256 (16 hex digits) of the disassembled round-kernel code object of the library under test (tools/kcontrol_isa_hash.sh): ties the line to the rocprof / PMC files
+    under profiles/, which carry the same hash when they were taken from the same code"""
+    import re
+    import subprocess
+    try:
+        lib = os.environ.get("ASCHED_LIB_PATH") or os.path.join(ROOT, "armada_amd", "csrc", "libarmada_sched.so")
+        txt = subprocess.run(["bash", os.path.join(ROOT, "tools", "kcontrol_isa_hash.sh"), lib], capture_output=True, text=True, timeout=120).stdout
+        m = re.search(r"sha256 ([0-9a-f]{16})", txt)
+        return m.group(1) if m else None
+    except Exception:
+        return None
+
+
 def round_diff(a, b):
     """fields of two RoundResults that differ (tests/scenario.assert_same_round semantics: job->node, priorities, methods, preempted,
     per-queue allocation by priority class, per-job reasons, fair shares and token counts with tolerance zero)"""
@@ -236,15 +250,19 @@ def submit_check_record(args):
         res = chk.check(jobs)
         torch.cuda.synchronize(); lat.append(time.perf_counter() - t0)
     dt = float(np.mean(lat))
-    queries = len({j.scheduling_key for j in jobs}) + int((gang >= 0).sum())
+    queries = len({j.scheduling_key for j in jobs}) + int((gang >= 0).sum())   # what the reference would ask one by one
+    passes = sum(int(st.get("node_passes", 0)) for st in db.stats)              # walks over the node set the launches actually made (submit_stats)
     dev_s = sum(db.launch_ms) / 1e3
+    priced = algorithmic_bytes(args.nodes, W.R, max(passes, 1), 0)
     line = {
         "metric": "submit checks/s (jobs of one SubmitChecker.Check call, one pool)", "value": n_jobs / dt, "unit": "jobs/s", "n_gpus": 1, "steps": args.steps,
         "warmup": 1, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": {"workload": f"{args.nodes} nodes (32 cpu / 256 Gi), {n_jobs} submitted jobs, {n_shapes} scheduling keys, {int((gang >= 0).sum())} gang members, one pool"},
         "schedulable": sum(r.is_schedulable for r in res.values()), "native_calls": chk.launches, "how": db.stats, "device_s": dev_s,
-        "roofline": {"bound": "hbm", "achieved": queries * algorithmic_bytes(args.nodes, W.R, 1, 0) / max(dev_s, 1e-9) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": queries * algorithmic_bytes(args.nodes, W.R, 1, 0) / max(dev_s, 1e-9) / 1e9 / HBM_PEAK_GBS, "traffic": None, "node_queries": queries,
+        # identical queries batched into one pass count ONCE — the figure is priced on the passes the launches executed, not on the queries they answer
+        "roofline": {"bound": "hbm", "achieved": priced / max(dev_s, 1e-9) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": priced / max(dev_s, 1e-9) / 1e9 / HBM_PEAK_GBS, "traffic": None, "node_queries": queries, "passes_executed": passes, "algorithmic_bytes_per_launch": priced,
+                     "unbatched_equivalent_GBs": queries * algorithmic_bytes(args.nodes, W.R, 1, 0) / max(dev_s, 1e-9) / 1e9,
                      "kernel": "k_fit_batch (individual checks) + k_submit_gangs (gang units, one workgroup each; k_control_aux for what is left)"},
     }
     if args.cpu_budget > 0:   # cpu_baseline leg: the reference's sequential flow on the oracle, distinct keys so that its cache cannot help
@@ -295,16 +313,18 @@ def fit_batch_record(hip, args, big=False):
         got = s.fit_select_batch(jobs, -2)
         torch.cuda.synchronize(); host.append(time.perf_counter() - t0)
         dev.append(s.kernel_times()["fit_batch_ms"])
-    passes = len(np.unique(wl.job_req[jobs], axis=0))
+    shapes = len(np.unique(wl.job_req[jobs], axis=0))
+    passes = 1   # ONE launch walks the node tile for every shape (a batched pass counts once; round 4 priced one pass per distinct shape and the review called it)
     dev_ms, host_ms = float(np.mean(dev)), float(np.mean(host)) * 1e3
     alg = algorithmic_bytes(wl.num_nodes, W.R, passes, 0)
     ach = alg / max(dev_ms * 1e-3, 1e-12) / 1e9
     rec = {"config": "nodedb fit kernel at 100 000 nodes x 1 000 000 queries" if big else "BASELINE configs[1]", "workload": f"{wl.num_nodes} nodes x {wl.num_queues} queues x {len(jobs)} queued jobs, R=4, K=3, nodedb fit kernel at priority -2",
            "metric": "first-fit queries/s (asched_fit_select_batch, host call incl. result download)", "value": len(jobs) / (host_ms * 1e-3), "unit": "queries/s",
-           "host_ms": host_ms, "device_ms": dev_ms, "queries_issued": int(len(jobs)), "passes_executed": int(passes), "fitting": int((got >= 0).sum()),
+           "host_ms": host_ms, "device_ms": dev_ms, "queries_issued": int(len(jobs)), "passes_executed": int(passes), "distinct_shapes": int(shapes), "fitting": int((got >= 0).sum()),
            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": "k_fit_batch",
                         "algorithmic_bytes_per_launch": alg, "unbatched_equivalent_GBs": algorithmic_bytes(wl.num_nodes, W.R, len(jobs), 0) / max(dev_ms * 1e-3, 1e-12) / 1e9,
-                        "note": "one launch answers every query; bytes = passes_executed x N x 40 B (the node tile is read once and held in registers for all shapes)"}}
+                        "per_shape_equivalent_GBs": algorithmic_bytes(wl.num_nodes, W.R, shapes, 0) / max(dev_ms * 1e-3, 1e-12) / 1e9,
+                        "note": "one launch answers every query; bytes = 1 pass x N x 40 B (the node tile is held in registers for all shapes): at this size the launch is latency-bound, not bandwidth-bound"}}
     path = os.path.join(ROOT, "oracle", "liboracle.so")
     if args.cpu_budget > 0 and os.path.exists(path):
         oracle = Library(path, "oracle_")
@@ -603,11 +623,11 @@ def schedule_many_benchmark_record(hip, args):
             s.nodes_upsert(wl.node_total, wl.node_allocatable, alloc_by_prio=abp)
             W.set_jobs(s, wl)
             unit = (np.array([0, nj], dtype=np.int32), np.arange(nj, dtype=np.int32))   # the unit in the ABI's CSR form (the job ids of a gang context: built once, like the benchmark's `jobs`)
-            s.submit_check(unit, [False])   # warm-up
+            s.submit_check(None, [False], csr=unit)   # warm-up
             times, r = [], None
             for _ in range(7):
                 if name == "gpu": torch.cuda.synchronize()
-                t0 = time.perf_counter(); r = s.submit_check(unit, [False])
+                t0 = time.perf_counter(); r = s.submit_check(None, [False], csr=unit)
                 if name == "gpu": torch.cuda.synchronize()
                 times.append(time.perf_counter() - t0)
             legs[name] = (float(np.median(times)), r[0], s.submit_stats() if name == "gpu" else None)   # median of 7 (a 0.1 ms call: one host hiccup must not be the row)
@@ -755,6 +775,83 @@ def single_pool_mode_record(hip, args, rank, local_rank, world, dist, torch):
                         "parallelism": f"queue q on rank q mod {world}; one all-reduce SUM of N*R + M int64 words; ordered replay of the conflict set on every rank"})
 
 
+COMPACT_LIMIT = 4000   # characters: the driver keeps the last 8 kB of stdout and parses the last line (round 4's 28 kB line came back `parsed: null`)
+
+
+def compact_line(out):
+    """The LAST stdout line: the headline with `roofline`, `cpu_baseline`, `parity` and one short row per other config — at most COMPACT_LIMIT characters.
+    Everything else of the record goes to bench_full.json (and to the stdout line before this one)."""
+    def pick(d, keys):
+        return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+    def num(x):
+        return round(x, 6 - len(str(int(abs(x))))) if isinstance(x, float) and abs(x) >= 1 else (float(f"{x:.4g}") if isinstance(x, float) else x)
+
+    def short(d):
+        return {k: num(v) for k, v in d.items()}
+    line = short(pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "p50_ms", "p99_ms", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "mode")))
+    cfg = out.get("config") or {}
+    line["config"] = {k: (v[:300] if isinstance(v, str) else v) for k, v in cfg.items()} if isinstance(cfg, dict) else cfg
+    if "roofline" in out:
+        line["roofline"] = short(pick(out["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "algorithmic_bytes_per_launch", "kernel_isa_hash", "kernel_avg_ms", "node_queries")))
+    if "cpu_baseline" in out:
+        cb = out["cpu_baseline"]
+        line["cpu_baseline"] = short(pick(cb, ("value", "unit", "cores", "kind", "rounds", "measured_s", "error")))
+        if "sample" in cb:
+            line["cpu_baseline"]["sample"] = cb["sample"][:160]
+    if "parity" in out:
+        line["parity"] = pick(out["parity"], ("checked", "identical", "jobs", "scheduled", "preempted", "reason"))
+    if "round" in out:
+        line["round"] = short(pick(out["round"], ("scheduled", "preempted", "evicted_phase1", "loop_iterations", "node_queries_issued", "device_ms", "k_control_ms", "kernel_launches", "host_ms")))
+    rows = []
+    for r in out.get("other_configs", []):
+        name = str(r.get("config", "?"))
+        if "error" in r or "skipped" in r:
+            rows.append([name[:40], None, "error" if "error" in r else "skipped", None, None, None]); continue
+        cb, par, rf = r.get("cpu_baseline") or {}, r.get("parity") or {}, r.get("roofline") or {}
+        val, unit = r.get("value"), r.get("unit")
+        x = None
+        if isinstance(val, (int, float)) and isinstance(cb.get("value"), (int, float)) and cb["value"] > 0 and not (r.get("reduced")):
+            x = val / cb["value"]
+        elif r.get("reduced"):   # the oracle leg ran at the reduced size: the ratio is the reduced leg's
+            red = r["reduced"]; rcb = red.get("cpu_baseline") or {}
+            if isinstance(rcb.get("value"), (int, float)) and rcb["value"] > 0:
+                x = red["value"] / rcb["value"]
+        elif "rows" in r:   # a table of shapes: the worst row's ratio
+            xs = [q["x_oracle"] for q in r["rows"] if "x_oracle" in q]
+            x = min(xs) if xs else None
+        rows.append([name[:40], num(val) if isinstance(val, float) else val, unit, num(x) if x is not None else None,
+                     num(rf["frac"]) if isinstance(rf.get("frac"), float) else None, par.get("identical")])
+    if rows:
+        line["other_configs"] = rows
+        line["other_configs_columns"] = ["config", "value", "unit", "x_oracle (reduced leg's where the oracle ran reduced; worst row of a table)", "roofline.frac", "parity.identical"]
+    for k in ("scaling_note", "full_record"):
+        if k in out:
+            line[k] = out[k]
+    txt = json.dumps(line)
+    while len(txt) > COMPACT_LIMIT and line.get("other_configs"):   # never over the limit: drop rows from the end, say so
+        line["other_configs"].pop(); line["other_configs_truncated"] = True
+        txt = json.dumps(line)
+    return txt
+
+
+def emit(out):
+    """full record -> bench_full.json (+ gpurun_out/ when that exists) and one stdout line; then the compact line LAST"""
+    full = json.dumps(out)
+    wrote = []
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_full.json"), "w") as f:
+                    f.write(full + "\n")
+                wrote.append(os.path.relpath(os.path.join(d, "bench_full.json"), ROOT))
+            except OSError:
+                pass
+    out = dict(out, full_record=(wrote[0] if wrote else "the stdout line before this one"))
+    print(full)
+    print(compact_line(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -781,7 +878,7 @@ def main():
                          "reports the mismatch against the exact round")
     args = ap.parse_args()
     if args.submit_check:
-        print(json.dumps(submit_check_record(args)))
+        emit(submit_check_record(args))
         return 0
 
     rank = int(os.environ.get("RANK", "0"))
@@ -804,7 +901,7 @@ def main():
     if args.mode != "pools":
         rec = single_pool_mode_record(hip, args, rank, local_rank, world, dist, torch)
         if rank == 0:
-            print(json.dumps(rec))
+            emit(rec)
         if dist is not None:
             dist.destroy_process_group()
         return 0
@@ -886,10 +983,13 @@ def main():
             fetch = max(x["max_kb"] for x in c["FETCH_SIZE"] if x["kernel"].startswith("k_control"))
             write = max(x["max_kb"] for x in c["WRITE_SIZE"] if x["kernel"].startswith("k_control"))
             out["roofline"]["traffic"] = (2 * fetch + write) * 1024
+            out["roofline"]["traffic_kernel_isa_hash"] = json.load(open(pmcs[-1])).get("kernel_isa_hash")   # equal to kernel_isa_hash below <=> the counters were taken from this round kernel
             out["roofline"]["traffic_source"] = (f"profiles/{os.path.basename(pmcs[-1])} (2*FETCH_SIZE + WRITE_SIZE of the round launch) — NOT measured in this run: rocprofv3 PMC passes cannot run "
                                                  f"inside bench.py; the file is the newest committed PMC collection on this exact workload (tools/gpu_call.sh) and may predate the library under test")
         except Exception:
             pass
+    out["roofline"]["kernel_isa_hash"] = kernel_isa_hash()
+    out["roofline"]["kernel_avg_ms"] = kern_ms
     rc = 0
     if args.cpu_budget > 0 and world == 1:  # rank 0 at N=1 only
         try:
@@ -914,7 +1014,7 @@ def main():
                     rc = 3
     if world > 1:
         out["scaling_note"] = "pool-per-GPU replicas (weak scaling, no data-path collective); no single-pool multi-GPU scaling curve is claimed by this line"
-    print(json.dumps(out))
+    emit(out)
     if dist is not None:
         dist.destroy_process_group()
     return rc

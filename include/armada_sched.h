@@ -54,6 +54,7 @@ extern "C" {
 #define ASCHED_ERR_UNSUPPORTED (-2)  /* feature of the reference not implemented by this backend */
 #define ASCHED_ERR_DEVICE (-3)       /* HIP runtime failure or no gfx950 device */
 #define ASCHED_ERR_INTERNAL (-4)     /* reference would return an error here (e.g. iteration loop) */
+#define ASCHED_ERR_PEER (-6)         /* a collective entry point: another rank of the communicator failed in front of the exchange (its own call returns the cause); nothing was exchanged */
 #define ASCHED_ERR_TIMEOUT (-5)      /* the round's context was done: hard timeout or cancel (queue_scheduler.go:105-112 returns ctx.Err()); no result */
 
 /* taint effects / toleration operators (k8s core/v1), interned */
@@ -425,8 +426,9 @@ int32_t ASCHED_FN(submit_check)(asched_t*, int32_t n_units, const int32_t* unit_
                                 const int32_t* unit_flags /*[n_units] or NULL*/, asched_submit_result* out /*[n_units]*/);
 /* Measurement hook (no reference counterpart): how the last submit_check ran.  out = {units answered by the wide fit kernel (individual
    checks on a pristine NodeDb), fit-kernel passes, units through the sequential control launch (a NodeDb holding jobs, away types, literal rows), gang units answered
-   one workgroup per unit on a pristine NodeDb (csrc/submit_gang.h)}. */
-int32_t ASCHED_FN(submit_stats)(asched_t*, int32_t* out /*[4]*/);
+   one workgroup per unit on a pristine NodeDb (csrc/submit_gang.h), walks over the node set the wide / capacity / gang-unit launches made (one per launch of the fit or
+   capacity kernel, one per member of a gang unit: what a roofline prices), 0 (reserved)}. */
+int32_t ASCHED_FN(submit_stats)(asched_t*, int32_t* out /*[6]*/);
 /* NodeTypesIterator order (nodeiteration.go:74-149) for req at a priority over node types `types` (node_type_override ids; ntypes<0: all types).
    Test hook for the golden orderings of nodeiteration_test.go; the HIP backend materialises its literal iterator restatement (the one rounds use
    off the index grid) in the auxiliary kernel. */

@@ -159,3 +159,65 @@ def test_external_transport_sees_device_memory(hip_lib, oracle_lib):
     assert got.tolist() == o.fit_select_batch(jobs, s.priorities[0]).tolist()
     assert seen and seen[0][0] == len(jobs) and seen[0][1] == 1 and seen[0][2] == int((got >= 0).sum())
     s.close(); o.close()
+
+
+FAIL_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from armada_amd import workloads as W
+from armada_amd.binding import Library, SchedError
+from armada_amd.sharded import ShardedFit
+from armada_amd.queuehash import QueueHashRound
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+lib = Library(os.path.join(%(root)r, "tests", "hostsim", "libhostsim.so"), "asched_")
+dist.init_process_group("gloo")
+codes = {}
+wl = W.config3(n_nodes=600, n_jobs=4000, n_queues=6, seed=3, occupied=0.8)
+sf = ShardedFit(lib, wl, rank, world, dist=dist)
+sf.comm_init("external")
+sf.prepare()
+jobs = np.nonzero(wl.job_node < 0)[0].astype(np.int32)
+good = sf.fit_select_batch(jobs, sf.s.priorities[0])            # a healthy collective first
+# (1) a layout whose fields are too narrow on ONE rank only: that rank's words do not fit, the other rank's do
+bits = list(sf.width) if rank != world - 1 else [1] * len(sf.width)
+try:
+    sf.s.fit_select_batch_sharded(jobs, sf.s.priorities[0], bits, sf.row_bits, rank_offset=sf.lo)
+    codes["sharded"] = 0
+except SchedError as e:
+    codes["sharded"] = e.code
+codes["still_works"] = bool((sf.fit_select_batch(jobs, sf.s.priorities[0]) == good).all())   # the communicator is still usable: the same healthy collective again
+# (2) the queue-hash exchange with no round result on ONE rank
+if rank != world - 1:
+    sf.s.schedule_round()
+try:
+    sf.s.round_exchange()
+    codes["exchange"] = 0
+except SchedError as e:
+    codes["exchange"] = e.code
+again = sf.fit_select_batch(jobs, sf.s.priorities[0])   # (node state differs between the ranks now: only that the collective completes and every rank holds the same words)
+codes["after_exchange"] = int(np.asarray(again, dtype=np.int64).sum())
+sf.close()
+allc = [None] * world
+dist.all_gather_object(allc, codes)
+if rank == 0:
+    print("RESULT " + json.dumps(allc))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_a_rank_local_failure_fails_every_rank_instead_of_hanging(tmp_path, hostsim_lib, world):
+    """round-4 advisor, medium: a precondition that fails on one rank only used to return before the all-reduce while the peers were already inside it (a hang under RCCL).
+    Now one status word is all-reduced first: the failing rank returns its own error, every other rank ASCHED_ERR_PEER, and the communicator stays usable."""
+    script = tmp_path / "fail_worker.py"
+    script.write_text(FAIL_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                          "--master-port", str(29660 + world), str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    codes = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
+    from armada_amd.binding import ERR_INVALID, ERR_PEER
+    for r, c in enumerate(codes):
+        want = ERR_INVALID if r == world - 1 else ERR_PEER
+        assert c["sharded"] == want and c["exchange"] == want and c["still_works"] and c["after_exchange"] == codes[0]["after_exchange"], (r, c)

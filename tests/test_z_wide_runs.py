@@ -110,3 +110,41 @@ def test_wide_round_at_scale_on_the_device(hip_lib, oracle_lib):
     b, _ = _round(oracle_lib, wl)
     scenario.assert_same_round(b, a)
     assert st["fast_iterations"] >= 0.9 * a.num_loop_iterations
+
+
+def _reuse_rounds(lib, wls):
+    """ONE handle through several rounds, nodes and jobs uploaded again before each (the lifecycle of integration/gpu_round.go: one handle per pool, UploadJobs every cycle)"""
+    s = W.load(lib, wls[0])
+    out = []
+    for i, wl in enumerate(wls):
+        if i:
+            s.nodes_upsert(wl.node_total, wl.node_allocatable, taints=wl.node_taints, labels=wl.node_labels, id_rank=wl.node_id_rank)
+            W.set_jobs(s, wl)
+        W.prepare(s, wl)
+        out.append(s.schedule_round())
+    s.close()
+    return out
+
+
+REUSE = [(100, 8), (100, 8, 100, 8), (8, 100, 8), (300, 64, 65, 3)]
+
+
+def _reuse_wls(qs):
+    return [_wl(40 + i, nq, nn=300, nj=4000) for i, nq in enumerate(qs)]
+
+
+@pytest.mark.parametrize("qs", REUSE)
+def test_a_reused_handle_drops_from_many_to_few_queues(hostsim_lib, oracle_lib, qs):
+    """round-4 advisor, high: a wide round parked the 64-queue stream buffers in the handle; the next jobs_set freed and reallocated them, and the following round_prepare put
+    the FREED pointers back over the fresh ones — a round with <= 64 queues then wrote through dangling pointers (segfault in the CPU build)."""
+    wls = _reuse_wls(qs)
+    for b, a in zip(_reuse_rounds(oracle_lib, wls), _reuse_rounds(hostsim_lib, wls)):
+        scenario.assert_same_round(b, a)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qs", REUSE)
+def test_a_reused_handle_drops_from_many_to_few_queues_on_the_device(hip_lib, oracle_lib, qs):
+    wls = _reuse_wls(qs)
+    for b, a in zip(_reuse_rounds(oracle_lib, wls), _reuse_rounds(hip_lib, wls)):
+        scenario.assert_same_round(b, a)

@@ -32,7 +32,29 @@ def fake_gpu(monkeypatch, hostsim_lib):
 
 
 def check_line(out, metric_word):
-    line = json.loads(out.strip().splitlines()[-1])
+    """the LAST stdout line is the compact record the driver parses (round 4's 28 kB line did not fit its 8 kB capture: `parsed: null`); the line before it — and
+    bench_full.json — is the full record.  Returns the full record after checking that both carry the contract's keys and agree."""
+    lines = out.strip().splitlines()
+    last = lines[-1]
+    assert len(last) <= 4000, len(last)
+    assert json.loads(out[-8000:].strip().splitlines()[-1]) == json.loads(last)   # what a capture of the final 8 000 characters yields
+    compact, line = json.loads(last), json.loads(lines[-2])
+    assert ROUND_KEYS <= set(compact), ROUND_KEYS - set(compact)
+    assert ROOFLINE_KEYS <= set(compact["roofline"]) and CPU_KEYS <= set(compact["cpu_baseline"])
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert compact[k] == line[k], k
+    assert abs(compact["value"] - line["value"]) <= 1e-3 * abs(line["value"]) and abs(compact["roofline"]["frac"] - line["roofline"]["frac"]) <= 1e-3 * abs(line["roofline"]["frac"]) + 1e-12
+    timed0 = line.get("device_s", 0) > 0 or (line.get("round") or {}).get("device_ms", 0) > 0   # (the CPU build has no HIP events: no launch duration to price)
+    assert not timed0 or compact["roofline"]["frac"] <= 1.0, compact["roofline"]   # a fraction above 1 says the kernel did not do the work it is priced on
+    assert compact["parity"]["identical"] == line["parity"]["identical"]
+    if "other_configs" in line:
+        assert [r[0] for r in compact["other_configs"]] == [r["config"][:40] for r in line["other_configs"]] and "other_configs_truncated" not in compact
+        for row, full in zip(compact["other_configs"], line["other_configs"]):
+            assert row[5] == (full.get("parity") or {}).get("identical"), row
+            timed = full.get("device_ms", 0) > 0 or full.get("device_s", 0) > 0   # (the CPU build has no HIP events: no launch duration to price)
+            assert row[4] is None or not timed or row[4] <= 1.0, row
+    with open(os.path.join(ROOT, "bench_full.json")) as f:
+        assert json.loads(f.read()) == line
     assert ROUND_KEYS <= set(line), ROUND_KEYS - set(line)
     assert metric_word in line["metric"] and line["n_gpus"] == 1 and line["higher_is_better"] is True and line["scaling"] == "weak"
     assert line["vs_baseline"] is None and line["dtype"] == "int64" and line["data"] == "synthetic" and "workload" in line["config"]
@@ -86,8 +108,10 @@ def test_round_bench_detects_a_mismatch(fake_gpu, monkeypatch, capsys):
     monkeypatch.setattr(fake_gpu, "round_diff", lambda a, b: real(a, b) + ["scheduled (injected)"])
     monkeypatch.setattr(sys, "argv", ["bench.py", "--nodes", "300", "--jobs", "3000", "--queues", "4", "--steps", "1", "--warmup", "0", "--cpu-budget", "5", "--no-other"])
     rc = fake_gpu.main()
-    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    lines = capsys.readouterr().out.strip().splitlines()
+    line, compact = json.loads(lines[-2]), json.loads(lines[-1])
     assert rc == 3 and line["parity"]["checked"] and not line["parity"]["identical"] and "other_configs" not in line
+    assert compact["parity"]["checked"] and compact["parity"]["identical"] is False
 
 
 def test_submit_check_bench_line(fake_gpu, monkeypatch, capsys):

@@ -327,6 +327,21 @@ def _empty_nodedb(lib):
     assert list(s.fit_select_batch([0, 1], -2)) == [-1, -1]
 
 
+def test_units_given_as_numpy_arrays_are_units_not_csr(hostsim_lib):
+    """round-4 advisor: a tuple of two numpy index arrays used to be re-read as (unit_off, unit_jobs); the CSR form is an explicit keyword now"""
+    from armada_amd.binding import Config, Scheduler
+    s = Scheduler(hostsim_lib, Config(num_resources=2, indexed_col=[0], indexed_resolution=[1], pc_priority=[0], pc_preemptible=[1], drf_multiplier=[1.0, 1.0]))
+    s.nodes_upsert(np.array([[4, 4], [4, 4]], dtype=np.int64))
+    s.clear_allocated()
+    s.jobs_set(np.array([[1, 1], [3, 3], [3, 3]], dtype=np.int64), gang_id=[-1, 0, 0], gang_cardinality=[1, 2, 2])
+    want = s.submit_check([[0], [1, 2]], [True, False])
+    assert s.submit_check((np.array([0]), np.array([1, 2])), [True, False]) == want
+    assert s.submit_check(None, [True, False], csr=(np.array([0, 1, 3]), np.array([0, 1, 2]))) == want
+    with pytest.raises(ValueError):
+        s.submit_check([[0]], [True], csr=(np.array([0, 1]), np.array([0])))
+    s.close()
+
+
 def test_empty_nodedb_oracle_and_hostsim(oracle_lib, hostsim_lib):
     _empty_nodedb(oracle_lib)
     _empty_nodedb(hostsim_lib)

@@ -18,7 +18,13 @@ def main(fetch_db, write_db, out_path):
         out[name] = [dict(kernel=r[0][:60], counter=r[1], dispatches=r[2], sum_kb=r[3], max_kb=r[4]) for r in rows[:6]]
     note = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 1 --warmup 0 --cpu-budget 0` at BASELINE "
             "configs[2]; values in KB as reported; FETCH_SIZE on gfx950 under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md HBM section)")
-    json.dump({"note": note, "counters": out}, open(out_path, "w"), indent=1)
+    import os, re, subprocess
+    try:   # the round kernel these counters were taken from (bench.py prints the same hash of the library it times)
+        txt = subprocess.run(["bash", os.path.join(os.path.dirname(os.path.abspath(__file__)), "kcontrol_isa_hash.sh")], capture_output=True, text=True, timeout=120).stdout
+        isa = (re.search(r"sha256 ([0-9a-f]{16})", txt) or [None, None])[1]
+    except Exception:
+        isa = None
+    json.dump({"note": note, "kernel_isa_hash": isa, "counters": out}, open(out_path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 

@@ -1,5 +1,5 @@
 """one preemption-heavy round (BASELINE configs[4] shape at 20k x 200k, tools/prof_config4.py's input) on the library named by ASCHED_LIB_PATH: prints the
-counts and a fingerprint of the whole result, so that builds of the same sources can be compared without an oracle round each (tools/minsize_bisect.sh)"""
+counts and a fingerprint of the whole result, so that builds of the same sources can be compared without an oracle round each"""
 import hashlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
