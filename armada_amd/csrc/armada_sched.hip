@@ -1241,6 +1241,21 @@ __device__ static inline EvDyn evDynLoad(KREF k, int q, int job, int n, int leve
   return r;
 }
 
+__device__ static inline EvDyn evCleanLoad(KREF k, int job, int n, bool wantMark, bool wantClean) {
+  int lane = threadIdx.x & 63;
+  int mark = wantMark ? (int)k.jcPreempted[job] : 0;   // independent loads, issued back to back
+  int64_t have = 0;
+  if (wantClean && lane < k.R) have = __hip_atomic_load(&KAL(k, 0, lane, n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  EvDyn r;
+  r.preempted = UNI32(mark);
+  r.fits = __ballot(wantClean && lane < k.R && have < 0) == 0 ? 1 : 0;
+  return r;
+}
+__device__ static inline unsigned long long evPendingMask(int Q) {
+  int q = threadIdx.x & 63;
+  return __ballot(q < Q && g_fl.hot[q].evApplied < g_fl.hot[q].evDone);
+}
+
 // ------------------------------------------------------------------------------------------------ LDS residency of the round's small state
 // Every per-queue array and the scheduling-context scalars are moved into LDS for the duration of the launch by
 // re-pointing the Dev descriptor (which itself lives in LDS): generic and fast code alike then pay LDS latency for them.
@@ -2665,6 +2680,13 @@ static int plat_run_submit_gangs(Dev& d, const std::vector<int32_t>& off, const 
     (void)hipEventElapsedTime(&t_ctx->lastFitMs, t_ctx->fitEv0, t_ctx->fitEv1);
   }
   return ok ? 0 : -1;
+}
+// the evicted table by rank (replay_rank.h; kernels in armada_sched_mgpu.hip): three launches on the handle's stream, no read-back
+extern "C" int asched_internal_replay_rank(const Dev* d, int n, int keepPending, hipStream_t s);
+static int plat_replay_rank(Dev& d, int n, int keepPending) {
+  if (n <= 0) return 0;
+  t_ctx->roundLaunches += 3;
+  return asched_internal_replay_rank(&d, n, keepPending, t_ctx->stream) == 0 && hipOk(hipGetLastError(), "k_replay_rank launch") ? 0 : -1;
 }
 // uniform submit-check units (submit_gang.h): per shape {first node or -1, members all nodes take together}
 extern "C" int asched_internal_fit_capacity(const Dev* d, const int32_t* shapes, int ns, unsigned long long* out, hipStream_t s);

@@ -110,6 +110,28 @@ extern "C" int asched_internal_submit_gangs(const Dev* d, const int32_t* off, co
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// ---- the evicted table by rank (replay_rank.h): check (one thread) -> rank (one thread per evicted-list position) -> finish (one thread).  replayPending == 2 between the
+// check and the finish says "by rank"; the round kernel never sees it (the three launches sit back to back on the handle's stream, in front of CMD_PASS1 / CMD_PASS2).
+#include "replay_rank.h"
+__global__ void k_replay_check(Dev d, int n) { if (threadIdx.x == 0 && blockIdx.x == 0 && rrOk(d, n)) d.rs->replayPending = 2; }
+__global__ __launch_bounds__(MG_THREADS) void k_replay_rank(Dev d, int n) {
+  if (d.rs->replayPending != 2) return;
+  long long i = MG_IDX();
+  if (i < n) rrElem(d, (int)i);
+}
+__global__ void k_replay_fin(Dev d, int n, int keepPending) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (d.rs->replayPending == 2) rrFinish(d, n);
+  else if (!keepPending) d.rs->replayPending = 0;   // (pass 2 has no lazy replay: CMD_PASS2 walks when the table was not built here)
+}
+extern "C" int asched_internal_replay_rank(const Dev* d, int n, int keepPending, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_replay_check, dim3(1), dim3(64), 0, st, *d, n);
+  hipLaunchKernelGGL(k_replay_rank, dim3(mgBlocks(n)), dim3(MG_THREADS), 0, st, *d, n);
+  hipLaunchKernelGGL(k_replay_fin, dim3(1), dim3(64), 0, st, *d, n, keepPending);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // uniform units: per shape the smallest key among the nodes that take at least one member, and the number of members all nodes take together (submit_gang.h)
 __global__ __launch_bounds__(256) void k_fit_capacity(Dev d, const int32_t* shapes, int ns, unsigned long long* out /*[ns][FIT_OSTR]: [0] min key, [1] capacity sum*/) {
   __shared__ unsigned long long wmin[4], wsum[4];

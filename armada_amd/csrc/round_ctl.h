@@ -1385,7 +1385,9 @@ DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff)
     if (cnt == 0) { costItClear(d, c, top, pc); continue; }
     bool hasPre = false;
     for (int k = 0; k < cnt; k++) if (d.jcPreempted[gcJob(d, ref, k)]) hasPre = true;
-    if (hasPre) { costItClear(d, c, top, pc); continue; }
+    // (a queue's precomputed evicted-stream costs, round_fast.h evCheapOff: they count every earlier evicted job of the queue as returned — one that is skipped as preempted
+    //  or, below, finds no room on its node ends that for the rest of the queue's stream)
+    if (hasPre) { if (d.evCheap && top < d.cfg.Q) d.evCheap[top] = 0; costItClear(d, c, top, pc); continue; }
     int reason;
     bool gangAllEv = gcAllEvicted(d, ref); int gangQueue = gcQueue(d, ref);
     int64_t tStart = (softClock && d.cfg.clockStepNs <= 0) ? clockNowNs(d) : 0;   // start := sch.clock.Now() (:157)
@@ -1393,6 +1395,7 @@ DEV void queueSchedule(Dev& d, Ctl& c, const PassCfg& pc, const int32_t* uniOff)
     bool ok = gangSchedule(d, c, ref, &reason, uniOff);
     GSEG(14);
     if (d.rs->error) return;
+    if (!ok && gangAllEv && d.evCheap && gangQueue >= 0 && gangQueue < d.cfg.Q) d.evCheap[gangQueue] = 0;
     costItClear(d, c, top, pc);
     GSEG(15);
     if (ok) {

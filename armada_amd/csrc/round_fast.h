@@ -97,7 +97,11 @@ struct FastLds {
   uint32_t effA[QCAPF]; uint64_t effX[QCAPF], effY[QCAPF];  // skip mode: running maximum of the queue's keys
   EngineBox eng; IterBackup bk;
   uint8_t sKind[QCAPF];   // stream of queue q: 0 queued jobs (d.qsKey), 1 its evicted jobs (d.evKey)
+  // evicted-stream repair (evRepair): the requests of up to 64 consecutive evicted jobs of one queue (0 for a job that carries a preempted mark), and per queue the
+  // stream position below which the queue's precomputed costs are valid for its CURRENT allocation prefix
+  int64_t evStage[64][MAXR]; int32_t evValidEnd[QCAPF];
 };
+#define EV_EXCL(d) ((d).evCheap + 4104)   // [M] per evicted-list position: the repair that produced its costs found the job marked preempted and left it out of the prefix
 
 #ifdef ASCHED_HOSTSIM
 static FastLds g_fl;
@@ -353,6 +357,7 @@ DEV void fastQLoad(Dev& d) {
     f.rateInf = d.qRateInf[q]; f.cordoned = d.qCordoned[q]; f.itJobOnlyEv = d.itJobOnlyEv[q]; f.itGangOnlyEv = d.itGangOnlyEv[q];
     { int g = f.gctx; bool headEv = g >= 0 && d.jcEvicted[g];  // an evicted head was yielded from evList[itEi-1] and is not served yet
       f.evCheap = d.evCheap ? d.evCheap[q] : 0; f.evDone = f.evApplied = headEv ? f.itEi - 1 : f.itEi; f.headPos = headEv ? f.itEi - 1 : -1;
+      FL.evValidEnd[q] = f.evCheap == 2 ? 0 : INT32_MAX;   // (2: the stream was repaired in this pass — how far is not kept across a generic excursion: the next cheap head repairs again)
       f.effValid = 0; f.skipStart = 0; f.sPos = 0; f.sLen = 0;
       if (d.qsSave && d.qsSave[q].valid) {   // the queue's stream from before the generic excursion still describes it: same head, same cursor, same allocation, same tokens
         const QsSave& sv = d.qsSave[q];
@@ -419,7 +424,9 @@ DEV void engineStop(Dev& d, FastS& S);
 DEV bool headRequestsDisallowed(Dev& d, KREF k, int q);
 DEV bool pinnedNodeFits(KREF k, int q, int n, int level);
 DEV void exclPinnedFast(Dev& d, KREF k, int q, int job, int n, int level);   // the lane-parallel form of round_wide.h exclPinned (lane r: resource column r)
-DEV EvDyn evDynLoad(KREF k, int q, int job, int n, int level, bool wantMark, bool wantPin);   // a returning evicted job's preempted mark and its pinned-node check, their loads in flight together
+DEV EvDyn evDynLoad(KREF k, int q, int job, int n, int level, bool wantMark, bool wantPin);
+DEV EvDyn evCleanLoad(KREF k, int job, int n, bool wantMark, bool wantClean);   // a returning evicted job's preempted mark and "no priority -2 column of ITS node is negative" (fits = clean), the loads in flight together
+DEV unsigned long long evPendingMask(int Q);   // queues with deferred evicted-job commits (evApplied < evDone)   // a returning evicted job's preempted mark and its pinned-node check, their loads in flight together
 // per-queue state of a stream run, held in the lanes of the control wave (lane q: queue q): position at the start of the run, list position of element 0,
 // merge cursor, length, kind (bit 0: evicted stream, bit 1: the queue's evicted list was folded (running-maximum key)), first element of the key window in
 // LDS, the queue's budget, the running-maximum key.  Reading queue t's values is a v_readlane (scalar result), no LDS round trip.
@@ -484,6 +491,65 @@ DEV void fastFlushEvicted(Dev& d) {  // apply every queue's deferred evicted-job
     int p0 = UNI32(FL.hot[q].evApplied), p1 = UNI32(FL.hot[q].evDone);
     if (p0 < p1) { applyEvictedRange(d, q, p0, p1); FL.hot[q].evApplied = p1; RS.numEvictedJobs -= p1 - p0; }
   }
+}
+// the same in front of a cascade that stays in the fast loop (fastPreemptIter): the queues with something pending are found lane-parallel (usually none or a few)
+DEV void fastFlushEvictedPending(Dev& d) {
+  unsigned long long m = evPendingMask(d.cfg.Q < QCAPF ? d.cfg.Q : QCAPF);
+  while (m) {
+    int q = __builtin_ctzll(m); m &= m - 1;
+    int p0 = UNI32(FL.hot[q].evApplied), p1 = UNI32(FL.hot[q].evDone);
+    applyEvictedRange(d, q, p0, p1);
+    if (FLANE == 0) { FL.hot[q].evApplied = p1; RS.numEvictedJobs -= p1 - p0; }
+    LANE0_PUBLISHED();
+  }
+}
+// queue q's precomputed evicted-stream costs (B_EVKEYS) assume that every earlier evicted job of the queue came back: once one was skipped as preempted or found
+// no room on its node the rest of the stream is costed from the queue's actual allocation (fastAdvance's window path)
+DEV void evCheapOff(Dev& d, int q, QHot& f) {
+  f.evCheap = 0;
+  if (FLANE == 0) { FL.hot[q].evCheap = 0; if (d.evCheap) d.evCheap[q] = 0; }
+  LANE0_PUBLISHED();
+}
+// May a queue's evicted stream be repaired in place?  Not while the deferred replay of the evicted jobs is still to come (it merges the very same costs, as the
+// evictor left them) and not inside the replay itself.
+DEV bool evRepairOk(Dev& d, const FastCtx& fc) { return fc.evStatic && !fc.replay && !RS.replayPending; }
+// Queue q's precomputed costs from stream position p on no longer describe it (the job before p was skipped as preempted or found no room: the prefix the bulk pass
+// counted on is not the queue's allocation): the next cheap head of the queue recomputes them (fastAdvance -> evRepair).
+DEV void evInvalidateFrom(Dev& d, int q, QHot& f, int p) {
+  f.evCheap = 2; f.ewCount = 0;
+  if (FLANE == 0) { FL.evValidEnd[q] = p; FL.hot[q].evCheap = 2; FL.hot[q].ewCount = 0; d.evCheap[q] = 2; }
+  LANE0_PUBLISHED();
+}
+// The costs of queue q's evicted jobs [p0, p1), p1 - p0 <= 64, recomputed in place (d.evKey) from the queue's allocation as it is NOW — every deferred commit of the queue
+// applied by the caller — one lane per job: the float64 operations of B_EVKEYS (round_run.h) on the same prefix sums, with one difference that is the point: a job that
+// carries a preempted mark stays out of the prefix of the jobs behind it (it will be skipped, queue_scheduler.go:150-156; its own key is the one the iterator would
+// compute for it).  Such positions are flagged (EV_EXCL): reaching them later does not invalidate the stream again.
+DEV void evRepair(Dev& d, KREF k, int q, int p0, int p1) {
+  const int cnt = p1 - p0, R = k.R;
+  FOR_LANES(i, cnt) {
+    int job = k.evList[p0 + i];
+    bool marked = k.jcPreempted[job] != 0;
+    const int64_t* rq = JREQ(d, job);
+    for (int r = 0; r < R; r++) FL.evStage[i][r] = marked ? 0 : rq[r];
+    EV_EXCL(d)[p0 + i] = marked ? 1 : 0;
+  }
+  LANE0_PUBLISHED();
+  const double w = UNID(FL.hot[q].weight);
+  FOR_LANES(i, cnt) {
+    int job = k.evList[p0 + i];
+    int64_t a[MAXR], with[MAXR];
+    for (int r = 0; r < R; r++) a[r] = FL.qAlloc[q][r] + FL.qPenalty[q][r];
+    for (int j = 0; j < i; j++) for (int r = 0; r < R; r++) a[r] += FL.evStage[j][r];
+    const int64_t* req = JREQ(d, job);
+    for (int r = 0; r < R; r++) with[r] = a[r] + req[r];
+    EvKey e;
+    e.proposed = drf(d, with) / w; e.current = drf(d, a) / w; e.size = drf(d, req) * w;
+    e.pcPrio = d.cfg.pcPriority[d.jPc[job]]; e.job = job;
+    d.evKey[p0 + i] = e;
+  }
+  FAST_GLOBAL_FENCE();   // the window refills read these from HBM
+  if (FLANE == 0) { FL.evValidEnd[q] = p1; FL.hot[q].ewCount = 0; FL.hot[q].evCheap = 2; d.evCheap[q] = 2; }
+  LANE0_PUBLISHED();
 }
 DEV void fastEnterGeneric(Dev& d, Ctl& c) {
   if (c.fqLive) { fastFlushEvicted(d); fastQFlush(d); c.fqLive = 0; }
@@ -744,7 +810,14 @@ DEV bool fastAdvance(Dev& d, KREF k, FastS& S, const FastCtx& fc, int q, QHot& f
     // costs precomputed for the whole evicted stream (B_EVKEYS): no job record, no DRF evaluation.  They assume that every earlier evicted job of
     // the queue came back — true while evicted jobs always return; after a preemption-based bind an evicted job may fail or be skipped as
     // preempted, and the costs are evaluated from the queue's actual allocation again (window path below)
-    if (!generic && kind == 0 && f.evCheap && (fc.replay || (S.lvl0NonNeg && S.numPreemptedMarks == 0 && fc.evStatic))) {  // (the replay places every evicted job by definition)
+    // (round 5) After a preemption-based bind the costs stay valid PER QUEUE until one of the queue's own evicted jobs fails to come back: fastIter validates such a head
+    // job by job (its preempted mark, its node's priority -2 columns) and switches the queue off (evCheapOff) at the first one that is skipped or does not fit.
+    if (!generic && kind == 0 && f.evCheap && (fc.replay || fc.evStatic)) {  // (the replay places every evicted job by definition)
+      if (pos >= UNI32(FL.evValidEnd[q])) {   // the queue's stream was invalidated at or before this position: recompute the next stretch from the queue's allocation as it is
+        if (f.evApplied < f.evDone) { applyEvictedRange(d, q, f.evApplied, f.evDone); S.numEvictedJobs -= f.evDone - f.evApplied; f.evApplied = f.evDone; }
+        evRepair(d, k, q, pos, end - pos > 64 ? pos + 64 : end);
+        f.evCheap = 2; f.ewCount = 0;
+      }
       if (!(pos >= f.ewStart && pos < f.ewStart + f.ewCount)) {
         int cnt = end - pos; if (cnt > WIN) cnt = WIN;
         evWinRefill(k, q, pos, cnt);
@@ -914,9 +987,33 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
   int job = f.gctx;
   if (f.headFast && f.headKind == 2) {  // evicted job with precomputed costs
     SEG(1);
-    if (!(fc.evStatic && S.lvl0NonNeg) || S.numPreemptedMarks != 0) return 0;  // generic (it re-reads everything from HBM; pending commits are flushed on the way); preempted jobs are skipped there (queue_scheduler.go:150-156)
-    f.evDone = f.headPos + 1;  // served; its commit is deferred (applyEvictedRange)
-    return fastAdvance(d, k, S, fc, q, f, ko) ? 1 : 2;
+    if (!fc.evStatic) return 0;  // generic (it re-reads everything from HBM; pending commits are flushed on the way)
+    bool cheapOk = S.lvl0NonNeg && S.numPreemptedMarks == 0;
+    if (!cheapOk) {
+      // Jobs have been preempted in this round (marks), or some node's priority -2 column is negative (an urgency preemption overdrew it).  "Evicted jobs always
+      // return" still holds for THIS job when it carries no preempted mark (it is still on its node) and no priority -2 column of ITS node is negative:
+      // alloc[level] - alloc[-2] >= req is bucket arithmetic of one node.  Then the precomputed costs are the right ones and the commit can wait
+      // (applyEvictedRange; fastPreemptIter and fastEnterGeneric apply what is pending before any cascade reads the planes).  Otherwise the head becomes an ordinary
+      // evicted head and the dynamic code below decides (skip, "does not fit", or a rebind with the node's row read).
+      loadHeadRec(k, q, job);
+      LANE0_PUBLISHED();
+      JobTail hr = FL.headTail[q];
+      uniJobTail(hr);
+      const EvDyn cl = evCleanLoad(k, job, hr.node0, S.numPreemptedMarks != 0, !S.lvl0NonNeg);
+      cheapOk = !cl.preempted && cl.fits && !(hr.never & 2);
+#ifdef ASCHED_HOSTSIM
+      { static long okN = 0, badN = 0; static const bool st = getenv("HS_EV_STATS") != nullptr; if (st) { (cheapOk ? okN : badN)++; if (((okN + badN) % 100) == 0) fprintf(stderr, "validated evicted heads: %ld cheap, %ld to the dynamic path\n", okN, badN); } }
+#endif
+      if (!cheapOk) {
+        f.headKind = 0; f.headIdx = UNI32(k.evIdxByPos[f.headPos]); f.headFast = 1;
+        if (FLANE == 0) { FL.hot[q].headKind = 0; FL.hot[q].headIdx = f.headIdx; FL.hot[q].headFast = 1; }
+        LANE0_PUBLISHED();
+      }
+    }
+    if (cheapOk) {
+      f.evDone = f.headPos + 1;  // served; its commit is deferred (applyEvictedRange)
+      return fastAdvance(d, k, S, fc, q, f, ko) ? 1 : 2;
+    }
   }
   if (!f.headFast) { fastLoadHead(k, q, job, f); FL.hot[q].headFast = 1; FL.hot[q].headKind = f.headKind; FL.hot[q].headIdx = f.headIdx; FL.hot[q].headPos = f.headPos; }
   JobTail r = FL.headTail[q];
@@ -996,6 +1093,9 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
     // node read.  Otherwise — a preemption-based bind overdrew some priority -2 column, or the job was evicted by the oversubscribed evictor
     // (pass 2: node / priority / bookkeeping are this round's, not the original run's) — the node's current allocatable is read.
     prio = r.runPrio; n = r.node0;
+#ifdef ASCHED_HOSTSIM
+    { static long slowN = 0, cheapQ = 0; static const bool st = getenv("HS_EV_STATS") != nullptr; if (st) { slowN++; if (f.evCheap) cheapQ++; if ((slowN % 500) == 0) fprintf(stderr, "dynamic evicted heads: %ld (queue still cheap: %ld) marks %d lvl0NonNeg %d\n", slowN, cheapQ, S.numPreemptedMarks, S.lvl0NonNeg); } }
+#endif
     if (r.never & 2) return 0;   // a request off the index grid: the bind below takes keyDelta off the node's keys, which is exact for multiples of the resolution only
 #ifdef ASCHED_HOSTSIM
     if (getenv("HS_NO_DYN_EV") && (!fc.evStatic || !S.lvl0NonNeg || S.numPreemptedMarks != 0)) return 0;
@@ -1018,6 +1118,9 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
       // (queue_scheduler.go:150-156); a queued job never carries the mark
       if (f.evApplied < f.evDone) { applyEvictedRange(d, q, f.evApplied, f.evDone); S.numEvictedJobs -= f.evDone - f.evApplied; }
       f.evApplied = f.evDone = f.headPos + 1;
+      if (f.evCheap && !(f.evCheap == 2 && f.headPos < UNI32(FL.evValidEnd[q]) && UNI32((int)EV_EXCL(d)[f.headPos]))) {   // the queue's later precomputed costs counted this job in (unless the repair that made them knew the mark)
+        if (evRepairOk(d, fc)) evInvalidateFrom(d, q, f, f.headPos + 1); else evCheapOff(d, q, f);
+      }
       return (fastAdvance(d, k, S, fc, q, f, ko) ? 1 : 2) | 4;
     }
     if (!fc.evStatic || !S.lvl0NonNeg) {
@@ -1032,6 +1135,7 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
         // other sum is back where it was.  No unfeasible-key registration: an evicted job's key is not valid (context/job.go:104-109).
         if (f.evApplied < f.evDone) { applyEvictedRange(d, q, f.evApplied, f.evDone); S.numEvictedJobs -= f.evDone - f.evApplied; }
         f.evApplied = f.evDone = f.headPos + 1;
+        if (f.evCheap) { if (evRepairOk(d, fc)) evInvalidateFrom(d, q, f, f.headPos + 1); else evCheapOff(d, q, f); }   // the queue's later precomputed costs counted this job in
         if (d.excl) exclPinnedFast(d, k, q, job, n, level);   // (asched_excluded_nodes: the dynamic reason on its node; inline — a call here costs the whole loop registers)
         if (evInRound) FOR_LANES(x, k.R) {
           int64_t v = FL.headReq[q][x];
@@ -1516,6 +1620,7 @@ DEV __attribute__((always_inline)) int fastPreemptIter(Dev& d, Ctl& c, FastCtx f
 #endif
   const FastK k = fastKRef(d);
   if (RS.replayPending || !RS.fastActive || c.txn.active || RS.error) return 0;   // (the deferred replay runs fast loops of its own: the generic iteration triggers it once)
+  fastFlushEvictedPending(d);   // the cascade reads planes above priority -2 and the evicted table: returned evicted jobs whose commits were deferred go in first
   QHot f = FL.hot[t];
   uniQHot(f);
   int job = f.gctx;
@@ -1561,6 +1666,10 @@ DEV __attribute__((always_inline)) int fastPreemptIter(Dev& d, Ctl& c, FastCtx f
     }
   }
   S.numUnfeasible = UNI32(RS.numUnfeasible); S.numPreemptedMarks = UNI32(RS.numPreemptedMarks); S.lvl0NonNeg = UNI32(RS.lvl0NonNeg); S.fastActive = UNI32(RS.fastActive);
+  // A queue's evicted jobs as a stream (FL.sKind 1) rest on "evicted jobs always return": once this cascade has preempted — marks, or a priority -2 column overdrawn —
+  // the streams that were prepared before it must not outlive it (a new preparation asks evOk itself).  Never met while the replay was deferred: the first preempting
+  // job went through the generic loop, which drops every stream; with the evicted table built up front (replay_rank.h) the first one comes through here.
+  if (S.numPreemptedMarks != 0 || !S.lvl0NonNeg) { FOR_LANES(q, QCAPF) if (FL.sKind[q] && FL.hot[q].sLen) { FL.hot[q].sLen = 0; FL.hot[q].sPos = 0; } LANE0_PUBLISHED(); }
   XSEG(37);
   KeyOut ko;
   bool more = fastAdvance(d, k, S, fc, t, f, &ko);

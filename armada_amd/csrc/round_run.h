@@ -445,6 +445,9 @@ DEV void roundSmall(Dev& d, int what, int arg) {
       }
       bool lazy = true;
       for (int q = 0; q < cf.Q; q++) if (!d.evCheap[q]) lazy = false;
+#ifdef ASCHED_HOSTSIM
+      if (getenv("HS_NO_LAZY")) lazy = false;   // tests: the walk at the start of the pass even when it could wait
+#endif
       if (lazy) d.rs->replayPending = 1;
     } break;
     case SM_LVL0_BEGIN: d.rs->lvl0NonNeg = 1; break;
@@ -545,6 +548,7 @@ DEV void swapLoopArrays(Dev& d) {
 DEV_COLD void ensureReplaySlow(Dev& d, Ctl& c) {
   if (!d.rs->replayPending) return;
   d.rs->replayPending = 0;
+  const long long tReplay0 = CLK();
   fastEnterGeneric(d, c);
   int sOnly = c.onlyEvicted, sCmp = c.compareSchedPrio, sUse = c.useReplayAlloc, sSkip = c.skipKeyCheck, sEv = c.fastEvStatic;
   swapLoopArrays(d);
@@ -557,6 +561,13 @@ DEV_COLD void ensureReplaySlow(Dev& d, Ctl& c) {
   c.onlyEvicted = sOnly; c.compareSchedPrio = sCmp; c.useReplayAlloc = sUse; c.skipKeyCheck = sSkip; c.fastEvStatic = sEv;
   fastPassReset();
   for (int q = 0; q < d.cfg.Q; q++) if (d.pqGctx[q] != -1) fastItemKeys(d, c, q);  // the pass's own heads again
+  d.rs->statClk[1] += CLK() - tReplay0;   // (round_stats kclk_replay: the deferred replay sits inside the pass that needed it)
+#ifdef ASCHED_HOSTSIM
+  if (getenv("HS_RANK_CHECK")) {   // the walk's table against replay_rank.h's closed form
+    extern int hsRankCheck(Dev& d);
+    hsRankCheck(d);
+  }
+#endif
 }
 
 // PreemptingQueueScheduler.Schedule (pqs.go:86-289)
@@ -819,7 +830,7 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
       long long t0 = CLK();
       int n1 = ARG(0);
       c.fastEvStatic = 1;
-      if (!d.rs->replayPending) { replayEvicted(d, c); wgBulk(d, B_EVIDX, n1); }
+      if (!d.rs->replayPending && !(n1 > 0 && d.rs->evictedTableSize == n1)) { replayEvicted(d, c); wgBulk(d, B_EVIDX, n1); }   // (evictedTableSize == n1: the table was built by rank in front of this launch, replay_rank.h)
       long long t1 = CLK();
       c.skipEnter = fastOn(d, c) && d.evMono != nullptr && d.rs->lvl0NonNeg && n1 > 0;
       schedulePass(d, c, true, false, false);

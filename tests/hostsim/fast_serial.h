@@ -185,6 +185,12 @@ DEV EvDyn evDynLoad(KREF k, int q, int job, int n, int level, bool wantMark, boo
   EvDyn r; r.preempted = wantMark ? (int)k.jcPreempted[job] : 0; r.fits = (!wantPin || pinnedNodeFits(k, q, n, level)) ? 1 : 0;
   return r;
 }
+DEV EvDyn evCleanLoad(KREF k, int job, int n, bool wantMark, bool wantClean) {
+  EvDyn r; r.preempted = wantMark ? (int)k.jcPreempted[job] : 0; r.fits = 1;
+  if (wantClean) for (int x = 0; x < k.R; x++) if (KAL(k, 0, x, n) < 0) r.fits = 0;
+  return r;
+}
+DEV unsigned long long evPendingMask(int Q) { unsigned long long m = 0; for (int q = 0; q < Q && q < 64; q++) if (FL.hot[q].evApplied < FL.hot[q].evDone) m |= 1ull << q; return m; }
 DEV void pqHeadKey(PQState&, int t, PackedKey* key, uint32_t* nameRank) { key->A = FL.kA[t]; key->X = FL.kX[t]; key->Y = FL.kY[t]; *nameRank = (uint32_t)FL.nameRank[t]; }
 // ---- stream run, serial build.  The engine serves an entry when its record is staged, so that entries emitted but not yet staged when a job
 // does not fit are discarded exactly as on the device (there the engine runs behind the merge by up to a ring's worth of entries).

@@ -230,6 +230,31 @@ static int plat_run_fit_capacity(Dev& d, const std::vector<int32_t>& shapes, std
 }
 // one pool on several GPUs (armada_amd/csrc/mgpu.h): the per-element functions of the grid kernels in serial loops
 #include "../../armada_amd/csrc/mgpu.h"
+#include "../../armada_amd/csrc/replay_rank.h"
+int hsRankCheck(Dev& d) {
+  int n = d.rs->numEvictedList, bad = 0;
+  bool mono = true;
+  for (int q = 0; q < d.cfg.Q; q++) if (d.evOff[q + 1] > d.evOff[q] && (!d.evMono[q] || !d.evCheap[q])) mono = false;
+  if (!mono) { fprintf(stderr, "rank check: not every stream monotone / cheap — skipped\n"); return 0; }
+  std::vector<int> idxOf(d.cfg.M, -1);
+  for (int i = 0; i < d.rs->evictedTableSize; i++) idxOf[d.evTabJob[i]] = i;   // (dead entries have lost their evIndexOfJob)
+  for (int p = 0; p < n; p++) {
+    int want = idxOf[d.evList[p]], got = rrRank(d, p);
+    if (want != got && bad++ < 10) {
+      int q = 0; while (d.evOff[q + 1] <= p) q++;
+      const EvKey e = d.evKey[p];
+      fprintf(stderr, "rank check: position %d (queue %d, job %d) walk %d rank %d  key prop %.17g cur %.17g size %.17g pc %d budget %.17g\n", p, q, d.evList[p], want, got, e.proposed, e.current, e.size, e.pcPrio, d.qDc[q] / d.qWeight[q]);
+    }
+  }
+  fprintf(stderr, "rank check: %d positions, %d differ\n", n, bad);
+  return bad;
+}
+static int plat_replay_rank(Dev& d, int n, int keepPending) {   // armada_sched_mgpu.hip k_replay_check / k_replay_rank / k_replay_fin, serially
+  if (n <= 0) return 0;
+  if (rrOk(d, n)) { for (int p = 0; p < n; p++) rrElem(d, p); rrFinish(d, n); }
+  else if (!keepPending) d.rs->replayPending = 0;
+  return 0;
+}
 static int plat_run_fit_batch_global(Dev& d, const std::vector<int32_t>& shapes, const std::vector<int32_t>& slot, int level, GlobalKeyLayout L, const int32_t* globalRank, long long* out, int* badOut) {
   std::vector<int32_t> node(shapes.size(), -1);
   if (d.cfg.N > 0) plat_run_fit_batch(d, shapes, level, node);

@@ -18,6 +18,7 @@ for rep in 1 2; do
         gangs) ASCHED_LIB_PATH=$P timeout 300 python tools/prof_config4.py gangs 2>&1 | tail -n 1 >> "$OUT/ab.txt" ;;
         preempt) [ $rep = 1 ] && ASCHED_LIB_PATH=$P timeout 300 python tools/prof_config4.py 2>&1 | grep "^round" | tail -n 1 | cut -c1-330 >> "$OUT/ab.txt" ;;
         preempt_full) [ $rep = 1 ] && ASCHED_LIB_PATH=$P timeout 400 python tools/prof_config4.py full 2>&1 | grep "^round" | tail -n 1 | cut -c1-330 >> "$OUT/ab.txt" ;;
+        checker) ASCHED_LIB_PATH=$P timeout 300 python tools/prof_config4.py checker 2>&1 | grep "^round" | tail -n 1 | cut -c1-330 >> "$OUT/ab.txt" ;;
         q*) ASCHED_LIB_PATH=$P timeout 300 python tools/prof_config4.py $W 2>&1 | grep "^round" | tail -n 1 | cut -c1-330 >> "$OUT/ab.txt" ;;   # q256, q1024: wide runs
       esac
     done

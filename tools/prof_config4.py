@@ -12,15 +12,18 @@ full = len(sys.argv) > 1 and sys.argv[1] in ("full", "gangsfull", "headline")
 if full: kw = dict(n_nodes=100_000, n_jobs=1_000_000, n_queues=64, occupied=0.95)
 if len(sys.argv) > 1 and sys.argv[1] == "gangsfull": kw = dict(n_nodes=100_000, n_jobs=1_000_000, n_queues=64, gangs=10_000)   # BASELINE configs[3]
 if len(sys.argv) > 1 and sys.argv[1] == "headline": kw = dict(n_nodes=100_000, n_jobs=1_000_000, n_queues=64)                  # BASELINE configs[2]
+checker = len(sys.argv) > 1 and sys.argv[1] == "checker"   # bench.py's configs[4] checker: 100 000 nodes 95 % occupied, a burst of 3 000 (the production-shaped round: evicted jobs returning, few new ones)
+if checker: kw = dict(n_nodes=100_000, n_jobs=300_000, n_queues=64, occupied=0.95)
 wl = W.config3(seed=W.SEED, **kw)
-if not full: wl.global_burst, wl.queue_burst = 40_000, 4_000
+if checker: wl.global_burst, wl.queue_burst = 3_000, 750
+elif not full: wl.global_burst, wl.queue_burst = 40_000, 4_000
 lib = armada_amd.load_library()
 s = W.load(lib, wl)
 for i in range(1 if full else 2):
     W.prepare(s, wl)
     t = time.perf_counter(); r = s.schedule_round(); dt = time.perf_counter() - t
     st = s.round_stats()
-    print("round", i, round(dt * 1e3, 1), "ms", {k: st[k] for k in ("fast_iterations", "generic_iterations", "kclk_pass1", "kclk_pass2", "kclk_plane_scans", "kclk_fair_selects", "stream_runs", "stream_jobs", "window_refills", "preempt_fast_iterations", "ft_queries", "ft_retries", "ft_node_updates")}, len(r.scheduled), len(r.preempted), flush=True)
+    print("round", i, round(dt * 1e3, 1), "ms", {k: st[k] for k in ("fast_iterations", "generic_iterations", "kclk_pass1", "kclk_pass2", "kclk_plane_scans", "kclk_fair_selects", "stream_runs", "stream_jobs", "window_refills", "preempt_fast_iterations", "kclk_replay", "fast_replay_steps")}, len(r.scheduled), len(r.preempted), flush=True)
 
 import ctypes
 if hasattr(lib.lib, "asched_debug_help_trace"):   # tools/build_variant.sh trace -DHELP_TRACE: the timeline of the fused wide pass (wall clock, 10 ns units)
