@@ -841,7 +841,7 @@ DEV void runCommand(Dev& d, Ctl& c, int cmd) {
     case CMD_PASS2: {  // pqs.go:199-221: schedule(evicted only; skipKeyCheck; compareSchedulingPriority)
       long long t0 = CLK();
       int n3 = ARG(0);
-      replayEvicted(d, c); wgBulk(d, B_EVIDX, n3);
+      if (!(n3 > 0 && d.rs->evictedTableSize == n3)) { replayEvicted(d, c); wgBulk(d, B_EVIDX, n3); }   // (== n3: built by rank in front of this launch, replay_rank.h)
       schedulePass(d, c, false, true, true);
       d.rs->statClk[4] += CLK() - t0;
     } break;
