@@ -2261,6 +2261,14 @@ static void plat_h2d(void* d, const void* s, size_t n) {
   if (!d) { hipOk(hipErrorInvalidValue, "upload into a failed allocation"); return; }
   if (hipOk(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, t_ctx->stream), "hipMemcpyAsync (h2d)")) hipOk(hipStreamSynchronize(t_ctx->stream), "h2d sync");
 }
+// pinned host memory + asynchronous downloads on the handle's stream (the round's result arrays: one wait for all of them)
+static void* plat_pinned(size_t n) { void* p = nullptr; if (!hipOk(hipHostMalloc(&p, n, hipHostMallocDefault), "hipHostMalloc")) return nullptr; return p; }
+static void plat_pinned_free(void* p) { if (p) (void)hipHostFree(p); }
+static void plat_d2h_async(void* d, const void* s, size_t n) {
+  if (!s) { hipOk(hipErrorInvalidValue, "download from a failed allocation"); std::memset(d, 0, n); return; }
+  hipOk(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, t_ctx->stream), "hipMemcpyAsync (d2h)");
+}
+static void plat_sync() { hipOk(hipStreamSynchronize(t_ctx->stream), "stream sync"); }
 static void plat_d2h(void* d, const void* s, size_t n) {
   if (!s) { hipOk(hipErrorInvalidValue, "download from a failed allocation"); std::memset(d, 0, n); return; }
   if (hipOk(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, t_ctx->stream), "hipMemcpyAsync (d2h)")) hipOk(hipStreamSynchronize(t_ctx->stream), "d2h sync");

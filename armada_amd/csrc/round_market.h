@@ -6,7 +6,7 @@
 // (jobdb/comparison.go:113-170) and merges a queue's evicted and queued jobs with MarketDrivenMultiJobsIterator (jobiteration.go:232-321).  These three are
 // what follows, as wave-uniform control code run by the auxiliary kernel (CMD_MARKET), pinned by the reference's own tests through the same hooks the oracle
 // is pinned by (tests/test_zzz_market_iterator.py).  The round around them — the evict-everything node evictor (pqs.go:117-119), spot price and second-price
-// billing (queue_scheduler.go:177-203), the indicative pricer — is not built.
+// billing (queue_scheduler.go:177-203), the indicative pricer — is not built (HISTORY.md §9).
 #pragma once
 
 struct MarketArgs {

@@ -108,6 +108,10 @@ static void plat_free(void* p) { free(p); }
 static void plat_memset(void* p, int v, size_t n) { memset(p, v, n); }
 static void plat_h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
 static void plat_d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+static void* plat_pinned(size_t n) { return malloc(n); }
+static void plat_pinned_free(void* p) { free(p); }
+static void plat_d2h_async(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+static void plat_sync() {}
 static PlatCtx* plat_open(std::string&, int) { t_ctx = new PlatCtx(); return t_ctx; }
 static void plat_close(PlatCtx* c) { if (t_ctx == c) t_ctx = nullptr; delete c; }
 static void plat_enter(PlatCtx* c) { t_ctx = c; }

@@ -1,6 +1,6 @@
 """Fair-share threshold table (armada_amd/csrc/round_ft.h): T[shape][node] = the evicted-table Index at which the node's own entries first cover the shape's
 request (fairNodeBest), a two-level maximum over it, lazy validation of a query's winner.  It replaces the wide pass of selectNodeForJobWithFairPreemption
-(nodedb.go:935-1043) for home attempts of queued jobs.  Not in the default device build (measured: DESIGN.md §9, profiles/r03g_*); the CPU build of the device
+(nodedb.go:935-1043) for home attempts of queued jobs.  Not in the default device build (measured: HISTORY.md §9, profiles/r03g_*); the CPU build of the device
 code carries it, so its logic is checked against the oracle here (and by every crowded round of the suite and the soaks)."""
 import pytest
 

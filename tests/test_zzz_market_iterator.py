@@ -6,7 +6,7 @@ robin between queues that bid the same price) and therefore is not a strict weak
 (oracle_market_iterate) and by the device (armada_amd/csrc/round_market.h, run by the auxiliary kernel).  Every case below runs on the oracle, on the CPU
 build of the device code and (-m gpu) on the HIP library.
 Cases: market_iterator_test.go:17-34 (home before away), :36-50 (ordering), :52-122 (round robin, 4 tables), comparison_test.go:76-178 (11 cases,
-transcribed mechanically), jobiteration_test.go:150-232 (3 tests).  The market ROUND (evictor, spot price, pricer) is not built: DESIGN.md §9.
+transcribed mechanically), jobiteration_test.go:150-232 (3 tests).  The market ROUND (evictor, spot price, pricer) is not built: HISTORY.md §9.
 """
 import pytest
 
