@@ -1076,7 +1076,15 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
       SEG(9);
       enginePost(d, k, S, job, q, pcx, prio, r.preemptible ? prio : NONPREEMPTIBLE_CUTOFF, r.nlPc);  // also saves queue q's state: FL.hot[q] is still as of the start of this iteration
       n = -1;
-      if (fc.skipKnown && S.numUnfeasible > 0) {  // fastAdvance may record skipped jobs, which cannot be taken back: wait for the verdict
+      // (round 5) fastAdvance may record jobs it skips as "known-unfeasible key" (queue_scheduler.go:398-413).  Rounds 2-4 waited for the engine's verdict before the queue
+      // side whenever such keys existed — which made every two-wave iteration of a round with ONE failed gang synchronous (configs[3]: 16 k instead of 9 k ticks per job,
+      // profiles/r05j_gangs_segments.txt).  The records are taken back with the rest of the iteration now (fastRollback: the skipped jobs lie between the backup's cursor and
+      // the current one and held their round_prepare defaults).  The optimiser's candidate iteration keeps the wait (jcReason doubles as its report there).
+#ifdef ASCHED_SYNC_UNFEASIBLE
+      if (fc.skipKnown && S.numUnfeasible > 0) {
+#else
+      if (fc.skipKnown && S.numUnfeasible > 0 && UNI32(RS.optMode)) {
+#endif
         int v = engineWait(S);
         if (v == 0) return 8;
         if (v == 2) { S.fastActive = 0; fastDrop(d); }
@@ -1210,6 +1218,24 @@ DEV void fastRollback(Dev& d, KREF k, FastS& S, int q) {
   S.numScheduledJobs--; S.numScheduledGangs--; S.numNodeQueries--;
   S.globalTokens = UNID(FL.bk.globalTokens);
   { int g = UNI32(FL.hot[q].gctx); if (g < -1 && FLANE == 0) d.gangSeen[-g - 2] = 0; }   // the iteration had assembled the gang behind its job (fastPeekGang): not seen yet
+  {   // the jobs fastAdvance skipped behind the iteration's job as "known-unfeasible key": list positions [the backup's cursor, the current one); nothing had looked at them
+      // before (the cursor only moves forward), so their records go back to round_prepare's (B_RESET_JOBS); the generic code peeks — and skips — them again if it gets that far
+    int p0 = UNI32(FL.bk.hot.itQi), p1 = UNI32(FL.hot[q].itQi);
+    if (S.numUnfeasible > 0 && p1 > p0) {
+      for (int b = p0; b < p1; b += 64) {
+        FOR_LANES(x, 64) if (b + x < p1) {
+          int job = k.queuedJobs[b + x];
+          if (d.jcReason[job] == ASCHED_REASON_SKIPPED_UNFEASIBLE_KEY) {
+            d.jcReason[job] = 0; d.jcHasPctx[job] = 0; d.pcMethod[job] = ASCHED_METHOD_NONE;
+            d.jobFlags[job] = (uint8_t)(d.jobFlags[job] & ~F_UNSUCCESSFUL);
+#ifdef ASCHED_HOSTSIM
+            { static long undone = 0; static const bool st = getenv("HS_EV_STATS") != nullptr; if (st && (++undone % 50) == 1) fprintf(stderr, "rollback took back %ld skip records\n", undone); }
+#endif
+          }
+        }
+      }
+    }
+  }
   engineRestore(q);
   FL.hot[q].winKind = -1; FL.hot[q].ewCount = 0;  // the windows may have moved on: refill on demand
   S.loopIterations--; S.statFastIters--;
@@ -1367,7 +1393,8 @@ DEV_NOINLINE SkipDelta fastDrain(Dev& d, int Q) {
 // Exactness: the merge is the heap of QueueCandidateGangIteratorPQ on the very keys fastAdvance would compute (same float64 operations on the same
 // prefix sums, round_run.h B_QSKEYS), the engine executes the entries in emission order, and integer accounting is order independent.
 struct StreamIn { double globalTokens; int64_t globalBurst; int32_t globalRateInf, engSeq; int32_t skip, haveLast; uint32_t lastA, lastN; uint64_t lastX, lastY; };   // skip / last*: skip mode is on, key of the entry served last
-struct StreamOut { int executed, executedEv, pend, dropped, engSeq, emitted, refills, evicted, maxConsumed, failed, lastQ; uint32_t lastA, lastN; uint64_t lastX, lastY; };
+struct StreamOut { int executed, executedEv, pend, dropped, engSeq, emitted, refills, evicted, maxConsumed, failed, lastQ; uint32_t lastA, lastN; uint64_t lastX, lastY;
+                   int gangJobs, gangs; };   // gangs placed INSIDE the run (round 5) and their members: the caller accounts them like fastGangRun's (ReserveN, one scheduled gang each)
 // streams persist between runs: head of queue q == element sPos of its stream, elements [sPos, sLen) are still to come.  A queue's stream is dropped
 // when anything but a stream run serves the queue (fastIter) or the generic code runs (fastQLoad).  prepare: 0 = the top queue has no stream,
 // 1 = ready, 2 = some queue needs the bulk passes and allowBulk was 0 (the node engine must be stopped first: they use every wave of the workgroup)
@@ -1385,10 +1412,46 @@ DEV EvKey streamKey(KREF k, StreamLanes& sl, int q, int pos, int sLen, int kind,
   e.proposed = UNID(e.proposed); e.current = UNID(e.current); e.size = UNID(e.size); e.pcPrio = UNI32(e.pcPrio); e.job = UNI32(e.job);
   return e;
 }
+struct GangOut { int handled, cnt, pend, dropped, engSeq, refills, evicted, koValid; uint32_t koA; uint64_t koX, koY; };
+DEV_NOINLINE GangOut fastGangRun(Dev& d, FastCtx fc, StreamIn in, int t);
+struct RunState {   // the state of a run, handed by value between its three out-of-line parts (fastStreamRun: set-up and settling; streamMerge: the merge loop; streamNest: the two rare events)
+  PQState pq; StreamLanes sl;
+  PackedKey lastK; uint32_t lastN; int haveLast, lastQ;
+  int emitted, emittedQ, acc, stageBase, stageCnt, issuedTo, fail, allowed, engSeq, sessLive, emittedPrev, doneQmid, maxMid, gangJobs, gangs, refills, evicted, pend, dropped, go;
+  int ev, evT, evSLen;   // why the merge loop returned: 0 the run ends, 1 queue evT's queued stream (evSLen elements) is used up in front of a gang member, 2 the head of the heap, queue evT, is an assembled gang
+  unsigned long long stageV;
+};
+// what the rare events of a run (streamNest) read and change: wave-uniform scalars only.  (A first version handed the whole RunState — lane-private heap and stream lanes
+// included — by value through the noinline call: on the device the run then behaved differently (52 000 evicted entries emitted that HEAD folds), profiles/r05l…; the CPU
+// build did not.  Lane-private state stays in the inlined caller, which applies the heap / lane updates the event asks for.)
+struct NestIO {
+  int emitted, emittedQ, acc, fail, allowed, engSeq, sessLive, emittedPrev, doneQmid, maxMid, gangJobs, gangs, refills, evicted, pend, dropped, go;
+  int replace, relane, koValid; uint32_t koA; uint64_t koX, koY;   // replace: queue t's heap entry becomes (koValid, koA, koX, koY); relane: the queue was settled — its stream lanes (and its count of done entries) start again from its record
+};
+DEV_NOINLINE NestIO streamNest(Dev& d, FastCtx fc, StreamIn in, NestIO st, int ev, int t);
+DEV RunState streamMerge(Dev& d, FastCtx fc, int Q, int skip, int nest, RunState m);
+// ---- (round 5) a run does not end where a queue's stream ends at a gang.  A queue's stream is cut at its next gang member (B_QSSUM), and until round 4 the run ended
+// the moment any queue used its stream up — on gang-heavy pools (BASELINE configs[3]) most single jobs therefore took the per-job iteration, whose queue side costs the
+// control wave 8.5 k ticks against ~4 k for a merged entry, while the node engine idled 58 % (profiles/r05j_gangs_segments.txt).  Now, when the element behind a used-up
+// QUEUED stream is a gang that fastPeekGang can assemble, the run (a) drains — every emitted entry placed, accounted and its ring slot read by the bind wave —, (b) settles
+// that ONE queue exactly as the end of a run would (cursor, tokens, fastAdvance -> the gang is the head, its key enters the heap), and goes on merging; when the gang reaches
+// the top it (c) drains again, closes the ring session, places the gang through a session of its own (fastGangRun: binds held until every member is placed), gives the queue
+// its next stretch of single jobs as a stream (fastStreamPrepareOne) and opens a new session.  Anything else — a single job behind the stream, a gang the fast path does not
+// take, a member without a node, skip mode — ends the run as before.  Exactness: every step is one the loop outside would have taken in the same order on the same state
+// (a drained run is a finished run); soaks: tests/soak.py streams / rounds with gangs.
 DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
   const FastK k = fastKRef(d);
   FastS S; coldS(d, S);
   StreamOut out; memset(&out, 0, sizeof out); out.pend = -1; out.engSeq = in.engSeq;
+  int doneQmid = 0, maxMid = 0, sessLive = 1, emittedPrev = 0;
+#ifdef ASCHED_HOSTSIM
+  static const bool nestOff = getenv("HS_NO_GANG_NEST") != nullptr;
+#elif defined(ASCHED_NO_NEST)
+  const bool nestOff = true;
+#else
+  const bool nestOff = false;
+#endif
+  const bool nest = !nestOff && !fc.replay;
   PQState pq;
   pqBuild(pq, Q);
   int allowed = INT32_MAX;
@@ -1411,72 +1474,57 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
   }
   int engSeq = in.engSeq;
   streamBegin(&engSeq);
-  int emitted = 0, emittedQ = 0, acc = 0, stageBase = -1, stageCnt = 0;
-  unsigned long long stageV = 0;
-  int fail = 0;
-  SEG_BEGIN();
+  // The merge loop and the two rare events live in functions of their own, the run's state going in and out BY VALUE: with the event code inline the loop's registers had their
+  // addresses taken / its allocation changed and the headline lost 14-20 % (profiles/r05l_nested_gang_runs.txt); as a separate function the loop compiles as it did in round 4.
+  RunState m; memset(&m, 0, sizeof m);
+  m.pq = pq; m.sl = sl; m.lastK = lastK; m.lastN = lastN; m.haveLast = haveLast; m.lastQ = lastQ;
+  m.stageBase = -1; m.allowed = allowed; m.engSeq = engSeq; m.sessLive = 1; m.pend = -1;
   for (;;) {
-    int a = streamAcked(&fail);
-    if (a > acc) { streamAccount(d, k, acc, a); acc = a; }
-    if (fail) break;
-    if (emitted - acc >= RING_N - 8 || emitted - streamBound() >= RING_N - 8) { STREAM_IDLE(); SEG(15); continue; }   // the ring is full: the engine is the pace
-    SEG(11);
-    int t = pqHead(pq, Q);
-    if (t < 0) break;
-    int sPos = SL_GET(sl, pos, t), sLen = SL_GET(sl, len, t);
-    if (sPos >= sLen) break;                      // the head of the heap is not a stream element
-    int kind = SL_GET(sl, kind, t);
-    if (!(kind & 1) && emittedQ >= allowed) break;   // no global token left for another new job
-    int base = SL_GET(sl, base, t);
-    EvKey e = streamKey(k, sl, t, sPos, sLen, kind, base);
-    SEG(12);
-    if (skip) {                                   // skip mode (fastRun): the folded evicted streams are merged around keys served in non-decreasing order only
-      PackedKey curK; uint32_t curN;
-      pqHeadKey(pq, t, &curK, &curN);
-      if (haveLast && packedLess(curK, curN, lastK, lastN)) break;
-      lastK = curK; lastN = curN; haveLast = 1;   // the key this entry is served under (fastExitSkip rebuilds the state around the last one)
+    m = streamMerge(d, fc, Q, skip, nest ? 1 : 0, m);
+    if (m.ev == 0) break;
+    // an event: everything emitted so far is staged here (the gathered records in flight are lane-private), the rest happens out of line on scalars
+    const int t = m.evT;
+    if (m.stageBase >= 0) { streamStageCommit(d, k, m.stageBase, m.stageCnt, m.stageV); m.stageBase = -1; }
+    if (m.emitted > m.issuedTo) { unsigned long long v = streamStageIssue(k, m.issuedTo, m.emitted - m.issuedTo); streamStageCommit(d, k, m.issuedTo, m.emitted - m.issuedTo, v); m.issuedTo = m.emitted; }   // (never twice: the serial build serves an entry when it is staged)
+    NestIO io; memset(&io, 0, sizeof io);
+    io.emitted = m.emitted; io.emittedQ = m.emittedQ; io.acc = m.acc; io.fail = m.fail; io.allowed = m.allowed; io.engSeq = m.engSeq; io.sessLive = m.sessLive; io.emittedPrev = m.emittedPrev;
+    io.doneQmid = m.doneQmid; io.maxMid = m.maxMid; io.gangJobs = m.gangJobs; io.gangs = m.gangs; io.pend = m.pend; io.dropped = m.dropped;
+    io = streamNest(d, fc, in, io, m.ev, t);
+    m.emitted = io.emitted; m.acc = io.acc; m.fail = io.fail; m.allowed = io.allowed; m.engSeq = io.engSeq; m.sessLive = io.sessLive; m.emittedPrev = io.emittedPrev;
+    m.doneQmid = io.doneQmid; m.maxMid = io.maxMid; m.gangJobs = io.gangJobs; m.gangs = io.gangs; m.refills += io.refills; m.evicted += io.evicted; m.pend = io.pend; m.dropped = io.dropped;
+    if (io.emitted == 0) m.issuedTo = 0;   // (a new ring session)
+    if (io.replace) {
+      KeyOut nk; nk.valid = io.koValid; nk.A = io.koA; nk.X = io.koX; nk.Y = io.koY;
+      pqPopPush(m.pq, nk, t);
     }
-    lastQ = t;
-    if (FLANE == 0) { RJOB(emitted) = e.job; RQ(emitted) = t | ((kind & 1) ? RQ_EV : 0); }
-    LANE0_PUBLISHED();
-    emitted++; if (!(kind & 1)) emittedQ++;
-    if ((emitted & 3) == 0) {                     // records: gather the last four entries; the four before them have arrived by now
-      if (stageBase >= 0) streamStageCommit(d, k, stageBase, stageCnt, stageV);
-      stageBase = emitted - 4; stageCnt = 4;
-      stageV = streamStageIssue(k, stageBase, 4);
+    if (io.relane) {
+      const QHot& f = FL.hot[t];   // queue t's lane state of the run from its (just materialised) record
+      int kd = UNI32((int)FL.sKind[t]) ? 1 : 0, sp = UNI32(f.sPos), sn = UNI32(f.sLen);
+      SL_SET(m.sl, start, t, sp); SL_SET(m.sl, pos, t, sp); SL_SET(m.sl, len, t, sn);
+      SL_SET(m.sl, base, t, (kd ? UNI32(f.itEi) : UNI32(f.itQi)) - 1 - sp);
+      SL_SET(m.sl, kind, t, kd | (UNI32(f.effValid) ? 2 : 0));
+      SL_SET(m.sl, ws, t, -2 * WIN);
+      SL_SET(m.sl, budget, t, UNID(f.budget));
+      if (FLANE == 0) FL.tmpQ[t] = 0;
+      LANE0_PUBLISHED();
     }
-    sPos++;
-    SL_SET(sl, pos, t, sPos);
-    SEG(13);
-    KeyOut ko; ko.valid = 0; ko.A = 0; ko.X = ko.Y = 0;
-    if (sPos < sLen) {
-      EvKey n = streamKey(k, sl, t, sPos, sLen, kind, base);
-      PackedKey own = packKey3(fc.preferLarge, n.pcPrio, n.proposed, n.current, n.size, SL_GETD(sl, budget, t));
-      if (kind & 2) {   // skip mode: as fastAdvance — a head is not served before what precedes it in its queue
-        PackedKey eff; eff.A = (uint32_t)SL_GET(sl, effA, t); eff.X = SL_GET64(sl, effX, t); eff.Y = SL_GET64(sl, effY, t);
-        if (packedLess(own, 0, eff, 0)) own = eff;
-        else { SL_SET(sl, effA, t, own.A); SL_SET(sl, effX, t, own.X); SL_SET(sl, effY, t, own.Y); }
-      }
-      ko.valid = 1; ko.A = own.A; ko.X = own.X; ko.Y = own.Y;
-      SEG(14);
-      pqPopPush(pq, ko, t);
-      SEG(10);
-    } else {
-      pqPopPush(pq, ko, t);
-      if ((kind & 1) || !UNI32(d.qsLen[2 * t + 1])) break;   // the queue goes on beyond its stream (its queued jobs after the evicted ones / more of its list): the next key is not known here
-    }
+    if (!io.go) break;
   }
-#ifdef ASCHED_HOSTSIM
-  if (getenv("HS_STREAM_TRACE")) { int t = pqHead(pq, Q); fprintf(stderr, "stream run end: emitted %d (new %d) acc %d fail %d allowed %d top %d", emitted, emittedQ, acc, fail, allowed, t); if (t >= 0) fprintf(stderr, " sPos %d sLen %d skind %d kind %d gctx %d stage %d inHeap %d", SL_GET(sl, pos, t), SL_GET(sl, len, t), SL_GET(sl, kind, t), FL.hot[t].headKind, FL.hot[t].gctx, FL.hot[t].itStage, FL.inHeap[t]); fprintf(stderr, "\n"); }
-#endif
+  pq = m.pq; sl = m.sl; lastK = m.lastK; lastN = m.lastN; lastQ = m.lastQ;
+  int emitted = m.emitted, acc = m.acc, stageBase = m.stageBase, stageCnt = m.stageCnt, issuedTo = m.issuedTo, fail = m.fail;
+  unsigned long long stageV = m.stageV;
+  engSeq = m.engSeq; sessLive = m.sessLive; emittedPrev = m.emittedPrev; doneQmid = m.doneQmid; maxMid = m.maxMid;
+  out.gangJobs = m.gangJobs; out.gangs = m.gangs; out.pend = m.pend; out.dropped = m.dropped;
+  S.statRefills += m.refills; S.numEvictedJobs += m.evicted;
   // drain: what is still in flight, then the tail group
-  if (!fail) {
-    if (stageBase >= 0) streamStageCommit(d, k, stageBase, stageCnt, stageV);
-    int done = stageBase >= 0 ? stageBase + stageCnt : 0;
-    if (emitted > done) { stageV = streamStageIssue(k, done, emitted - done); streamStageCommit(d, k, done, emitted - done, stageV); }
+  if (sessLive) {
+    if (!fail) {
+      if (stageBase >= 0) streamStageCommit(d, k, stageBase, stageCnt, stageV);
+      if (emitted > issuedTo) { stageV = streamStageIssue(k, issuedTo, emitted - issuedTo); streamStageCommit(d, k, issuedTo, emitted - issuedTo, stageV); issuedTo = emitted; }
+    }
+    streamEnd(engSeq);
+    { int a = streamAcked(&fail); if (a > acc) { streamAccount(d, k, acc, a); acc = a; } }
   }
-  streamEnd(engSeq);
-  { int a = streamAcked(&fail); if (a > acc) { streamAccount(d, k, acc, a); acc = a; } }
   if (fail == 2) out.dropped = 1;
   out.failed = fail ? 1 : 0; out.lastQ = lastQ;
   // ---- the queues' iterator state as of the acc entries done: each queue's head becomes the first of its elements that was not done
@@ -1521,9 +1569,174 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
     KeyOut ko;
     if (!fastAdvance(d, k, S, fc, q, f, &ko)) out.pend = q;
   }
-  out.executed = doneQ; out.executedEv = doneEv; out.engSeq = engSeq; out.emitted = emitted; out.refills = S.statRefills; out.evicted = S.numEvictedJobs;
+  doneQ += doneQmid; if (maxMid > out.maxConsumed) out.maxConsumed = maxMid;
+  out.executed = doneQ; out.executedEv = doneEv; out.engSeq = engSeq; out.emitted = emittedPrev + emitted; out.refills = S.statRefills; out.evicted = S.numEvictedJobs;
   out.lastA = lastK.A; out.lastX = lastK.X; out.lastY = lastK.Y; out.lastN = lastN;
   return out;
+}
+
+// the merge loop of a run (fastStreamRun): pop the head of the lane heap, emit (job, queue) into the ring, take the queue's next precomputed costs, re-insert
+DEV RunState streamMerge(Dev& d, FastCtx fc, int Q, int skip, int nest, RunState m) {
+  const FastK k = fastKRef(d);
+  FastS S; coldS(d, S);
+  PQState pq = m.pq; StreamLanes sl = m.sl;
+  PackedKey lastK = m.lastK; uint32_t lastN = m.lastN; int haveLast = m.haveLast, lastQ = m.lastQ;
+  int emitted = m.emitted, emittedQ = m.emittedQ, acc = m.acc, stageBase = m.stageBase, stageCnt = m.stageCnt, issuedTo = m.issuedTo, fail = m.fail;
+  const int allowed = m.allowed;
+  unsigned long long stageV = m.stageV;
+  int ev = 0, evT = -1, evSLen = 0;
+  SEG_BEGIN();
+  for (;;) {
+    int a = streamAcked(&fail);
+    if (a > acc) { streamAccount(d, k, acc, a); acc = a; }
+    if (fail) break;
+    if (emitted - acc >= RING_N - 8 || emitted - streamBound() >= RING_N - 8) { STREAM_IDLE(); SEG(15); continue; }   // the ring is full: the engine is the pace
+    SEG(11);
+    int t = pqHead(pq, Q);
+    if (t < 0) break;
+    int sPos = SL_GET(sl, pos, t), sLen = SL_GET(sl, len, t);
+    if (sPos >= sLen) {                           // the head of the heap is not a stream element
+      if (!(nest && UNI32(FL.hot[t].gctx) < -1 && UNI32(FL.hot[t].sLen) == 0)) break;
+      // an assembled gang (fastPeekGang): through a ring session of its own, inside the run (streamNest)
+      if (skip) {   // skip mode: entries are served in non-decreasing key order only (as for a stream element below; fastRun makes the same test in front of a gang)
+        PackedKey curK; uint32_t curN;
+        pqHeadKey(pq, t, &curK, &curN);
+        if (haveLast && packedLess(curK, curN, lastK, lastN)) break;
+        lastK = curK; lastN = curN; haveLast = 1;
+      }
+      lastQ = t;
+      ev = 2; evT = t;
+      break;
+    }
+    int kind = SL_GET(sl, kind, t);
+    if (!(kind & 1) && emittedQ >= allowed) break;   // no global token left for another new job
+    int base = SL_GET(sl, base, t);
+    EvKey e = streamKey(k, sl, t, sPos, sLen, kind, base);
+    SEG(12);
+    if (skip) {                                   // skip mode (fastRun): the folded evicted streams are merged around keys served in non-decreasing order only
+      PackedKey curK; uint32_t curN;
+      pqHeadKey(pq, t, &curK, &curN);
+      if (haveLast && packedLess(curK, curN, lastK, lastN)) break;
+      lastK = curK; lastN = curN; haveLast = 1;   // the key this entry is served under (fastExitSkip rebuilds the state around the last one)
+    }
+    lastQ = t;
+    if (FLANE == 0) { RJOB(emitted) = e.job; RQ(emitted) = t | ((kind & 1) ? RQ_EV : 0); }
+    LANE0_PUBLISHED();
+    emitted++; if (!(kind & 1)) emittedQ++;
+    if (emitted - issuedTo == 4) {                // records: gather the last four entries; the four before them have arrived by now
+      if (stageBase >= 0) streamStageCommit(d, k, stageBase, stageCnt, stageV);
+      stageBase = issuedTo; stageCnt = 4; issuedTo += 4;
+      stageV = streamStageIssue(k, stageBase, 4);
+    }
+    sPos++;
+    SL_SET(sl, pos, t, sPos);
+    SEG(13);
+    KeyOut ko; ko.valid = 0; ko.A = 0; ko.X = ko.Y = 0;
+    if (sPos < sLen) {
+      EvKey n = streamKey(k, sl, t, sPos, sLen, kind, base);
+      PackedKey own = packKey3(fc.preferLarge, n.pcPrio, n.proposed, n.current, n.size, SL_GETD(sl, budget, t));
+      if (kind & 2) {   // skip mode: as fastAdvance — a head is not served before what precedes it in its queue
+        PackedKey eff; eff.A = (uint32_t)SL_GET(sl, effA, t); eff.X = SL_GET64(sl, effX, t); eff.Y = SL_GET64(sl, effY, t);
+        if (packedLess(own, 0, eff, 0)) own = eff;
+        else { SL_SET(sl, effA, t, own.A); SL_SET(sl, effX, t, own.X); SL_SET(sl, effY, t, own.Y); }
+      }
+      ko.valid = 1; ko.A = own.A; ko.X = own.X; ko.Y = own.Y;
+      SEG(14);
+      pqPopPush(pq, ko, t);
+      SEG(10);
+    } else {
+      bool listEnds = !(kind & 1) && UNI32(d.qsLen[2 * t + 1]);
+      if (listEnds) { pqPopPush(pq, ko, t); continue; }     // the queue's list ends where its stream ends: it leaves the heap
+      // the queue goes on beyond its stream (its queued jobs after the evicted ones / more of its list): the next key is not known here ...
+      bool gangNext = false;
+      if (nest && !(kind & 1) && !UNI32(FL.hot[t].effValid)) {   // ... unless the element behind a queued stream is a gang member (where B_QSSUM cuts): settle the queue, peek the gang (streamNest)
+        int nx = base + sLen;                                     // list position of the element behind the stream
+        if (nx < UNI32(FL.hot[t].qEnd)) gangNext = UNI32(d.jGang[UNI32(k.queuedJobs[nx])]) >= 0;
+      }
+      if (!gangNext) { pqPopPush(pq, ko, t); break; }
+      ev = 1; evT = t; evSLen = sLen;
+      break;
+    }
+  }
+#ifdef ASCHED_HOSTSIM
+  if (getenv("HS_STREAM_TRACE")) { int t = pqHead(pq, Q); fprintf(stderr, "merge loop returns %d: emitted %d (new %d) acc %d fail %d allowed %d top %d", ev, emitted, emittedQ, acc, fail, allowed, t); if (t >= 0) fprintf(stderr, " sPos %d sLen %d skind %d kind %d gctx %d stage %d inHeap %d", SL_GET(sl, pos, t), SL_GET(sl, len, t), SL_GET(sl, kind, t), FL.hot[t].headKind, FL.hot[t].gctx, FL.hot[t].itStage, FL.inHeap[t]); fprintf(stderr, "\n"); }
+#endif
+  m.pq = pq; m.sl = sl; m.lastK = lastK; m.lastN = lastN; m.haveLast = haveLast; m.lastQ = lastQ;
+  m.emitted = emitted; m.emittedQ = emittedQ; m.acc = acc; m.stageBase = stageBase; m.stageCnt = stageCnt; m.issuedTo = issuedTo; m.fail = fail; m.stageV = stageV;
+  m.ev = ev; m.evT = evT; m.evSLen = evSLen;
+  return m;
+}
+// the two events of fastStreamRun (see there), on wave-uniform state.  ev 1: queue t's queued stream is used up and the element behind it is a gang member; ev 2: the head of
+// the heap, queue t, is an assembled gang.  The caller has staged everything emitted.  st.go = 1: the run goes on; 0: it ends (st.pend / st.dropped / st.fail say why).
+DEV_NOINLINE NestIO streamNest(Dev& d, FastCtx fc, StreamIn in, NestIO st, int ev, int t) {
+  const FastK k = fastKRef(d);
+  FastS S; coldS(d, S);
+  st.go = 0; st.replace = 0; st.relane = 0; st.koValid = 0; st.koA = 0; st.koX = st.koY = 0;
+  // drain: everything emitted placed, accounted, and its ring slot read by the bind wave (the job-record windows ARE the ring: fastAdvance refills them)
+  bool drained = false;
+  for (;;) {
+    int a = streamAcked(&st.fail);
+    if (a > st.acc) { streamAccount(d, k, st.acc, a); st.acc = a; }
+    if (st.fail) break;
+    if (st.acc >= st.emitted && streamBound() >= st.emitted) { drained = true; break; }
+    STREAM_IDLE();
+  }
+  if (ev == 1) {
+    st.replace = 1;                       // (not drained — an entry found no node —: the queue leaves the heap, as at the end of its stream before round 5)
+    if (!drained) return st;
+    // every element of queue t's stream is done: its iterator state as the end of a run leaves it, then the next head through the ordinary fastAdvance
+    QHot f = FL.hot[t];
+    uniQHot(f);
+    int cq = UNI32(FL.tmpQ[t]);
+    if (FLANE == 0) { FL.hot[t].sPos = 0; FL.hot[t].sLen = 0; FL.hot[t].ewCount = 0; FL.hot[t].ewStart = 0; FL.hot[t].winKind = -1; FL.hot[t].winCount = 0; }
+    LANE0_PUBLISHED();
+    f.sPos = 0; f.sLen = 0; f.ewCount = 0; f.ewStart = 0; f.winKind = -1; f.winCount = 0;
+    st.doneQmid += cq; if (cq > st.maxMid) st.maxMid = cq;
+    f.itQi = f.itQi - 1 + cq; f.itJobsSeen = f.itJobsSeen - 1 + cq;
+    if (!f.rateInf && 1 <= f.burst) f.tokens -= (double)cq;
+    KeyOut nk;
+    bool more = fastAdvance(d, k, S, fc, t, f, &nk);
+    if (FLANE == 0) { FL.hot[t].winKind = -1; FL.hot[t].winCount = 0; }   // (its window lies in the ring)
+    LANE0_PUBLISHED();
+    st.koValid = nk.valid; st.koA = nk.A; st.koX = nk.X; st.koY = nk.Y; st.relane = 1;
+    st.refills += S.statRefills; st.evicted += S.numEvictedJobs;
+    if (!more) { st.pend = t; return st; }
+    st.go = 1;
+    return st;
+  }
+  // ev == 2: the gang
+  if (!drained) return st;
+  streamEnd(st.engSeq); st.sessLive = 0;
+  FOR_LANES(q, QCAPF) FL.tmpN[q] = (uint32_t)FL.tmpQ[q];   // (fastGangRun and fastStreamPrepareOne use tmpQ as scratch: the run's per-queue counts wait in the heap's scatter space)
+  LANE0_PUBLISHED();
+  StreamIn gi = in;
+  gi.globalTokens = in.globalTokens - (double)st.emittedQ - (double)st.gangJobs; gi.engSeq = st.engSeq; gi.skip = 0; gi.haveLast = 0;
+  GangOut go = fastGangRun(d, fc, gi, t);
+  st.engSeq = go.engSeq;
+  if (go.dropped) st.dropped = 1;
+  bool goOn = false;
+  if (go.handled) {
+    st.gangJobs += go.cnt; st.gangs++;
+    if (st.allowed != INT32_MAX) st.allowed -= go.cnt;
+    st.refills += go.refills; st.evicted += go.evicted;
+    st.replace = 1; st.relane = 1; st.koValid = go.koValid; st.koA = go.koA; st.koX = go.koX; st.koY = go.koY;
+    if (go.pend >= 0 || st.dropped) st.pend = go.pend;
+    else {
+      if (go.koValid && UNI32(FL.hot[t].gctx) >= 0) {   // the single jobs behind the gang as the queue's next stream, prepared right here
+        int want = st.allowed == INT32_MAX ? INT32_MAX : (st.allowed - st.emittedQ > 0 ? st.allowed - st.emittedQ : 0);
+        (void)fastStreamPrepareOne(d, fc, t, want, QS_CMAX);
+      }
+      goOn = true;
+    }
+  }   // (not handled: nothing of the gang was done — the loop outside meets it as the head)
+  FOR_LANES(q, QCAPF) FL.tmpQ[q] = (int32_t)FL.tmpN[q];
+  LANE0_PUBLISHED();
+  if (!goOn) return st;
+  FOR_LANES(q, QCAPF) { FL.hot[q].winKind = -1; FL.hot[q].winCount = 0; }   // the windows serve as the ring again
+  streamBegin(&st.engSeq); st.sessLive = 1;
+  st.emittedPrev += st.emitted; st.emitted = 0; st.acc = 0;
+  st.go = 1;
+  return st;
 }
 
 // ---- a gang through the ring.  GangScheduler.Schedule for the common gang (gang_scheduler.go:46-148, 229-262): every member a queued job, no
@@ -1539,7 +1752,6 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
 #ifndef ASCHED_STREAM_BACKOFF_MIN
 #define ASCHED_STREAM_BACKOFF_MIN 8
 #endif
-struct GangOut { int handled, cnt, pend, dropped, engSeq, refills, evicted; int koValid; uint32_t koA; uint64_t koX, koY; };   // ko*: the queue's next key (fastAdvance)
 DEV_NOINLINE GangOut fastGangRun(Dev& d, FastCtx fc, StreamIn in, int t) {
   const FastK k = fastKRef(d);
   FastS S; coldS(d, S);
@@ -1826,6 +2038,11 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
         E = so.executed; so_max = so.maxConsumed;
         S.numScheduledJobs += E; S.numScheduledGangs += E; S.numNodeQueries += E;
         if (!S.globalRateInf && 1 <= S.globalBurst) S.globalTokens -= (double)E;
+        if (so.gangs) {   // gangs placed inside the run: accounted like fastGangRun's (cnt new jobs, ONE scheduled gang, ReserveN(cnt) on the global limiter, one loop iteration)
+          S.numScheduledJobs += so.gangJobs; S.numScheduledGangs += so.gangs; S.numNodeQueries += so.gangJobs;
+          if (!S.globalRateInf) S.globalTokens -= (double)so.gangJobs;
+          S.loopIterations += so.gangs; S.statFastIters += so.gangs;
+        }
         E += so.executedEv;
         S.loopIterations += E; S.statFastIters += E;
         S.statRefills += so.refills; S.numEvictedJobs += so.evicted;

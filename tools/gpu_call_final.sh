@@ -18,6 +18,7 @@ prof() {   # name, bench flags
 prof config2_headline
 prof config3_gangs --gangs 10000
 prof config4_reduced --nodes 20000 --jobs 200000 --queues 32 --occupied 0.95
+prof config4_full --occupied 0.95 --steps 1 --warmup 0
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof_config1" -- python -c "
 import sys; sys.path.insert(0, '$OLDPWD'); sys.argv=['bench.py']
 import torch; torch.cuda.init()   # torch's bundled HIP runtime before the library's (tests/conftest.py)
@@ -30,6 +31,12 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 F=$(find "$OUT/pmc_FETCH_SIZE" -name "*.db" | head -1); W=$(find "$OUT/pmc_WRITE_SIZE" -name "*.db" | head -1)
 [ -n "$F" ] && [ -n "$W" ] && python tools/pmc_summary.py "$F" "$W" "$OUT/pmc_hbm_traffic.json" > /dev/null
+# the same two counters on the production-shaped configs[4] round (bench.py's checker record reads this file for its roofline.traffic)
+for C in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace -d "$OLDPWD/$OUT/pmc4_$C" -- python "$OLDPWD/tools/prof_config4.py" checker > "$OLDPWD/$OUT/pmc4_$C.log" 2>&1 )
+done
+F=$(find "$OUT/pmc4_FETCH_SIZE" -name "*.db" | head -1); W=$(find "$OUT/pmc4_WRITE_SIZE" -name "*.db" | head -1)
+[ -n "$F" ] && [ -n "$W" ] && python tools/pmc_summary.py "$F" "$W" "$OUT/pmc_hbm_traffic_config4_checker.json" > /dev/null
 find "$OUT" -name "*.db" -size +8M -delete
 ASCHED_HOSTPROF=1 timeout 300 python bench.py --steps 1 --warmup 0 --cpu-budget 0 --no-other > "$OUT/bench_hostprof.json" 2> "$OUT/bench_hostprof.err"; grep hostprof "$OUT/bench_hostprof.err" | tail -20 > "$OUT/hostprof.txt"
 head -c 900 "$OUT/bench_full.json" | tee -a "$OUT/summary.txt"; echo; ls "$OUT" | tee -a "$OUT/summary.txt"

@@ -12,10 +12,10 @@ full = len(sys.argv) > 1 and sys.argv[1] in ("full", "gangsfull", "headline")
 if full: kw = dict(n_nodes=100_000, n_jobs=1_000_000, n_queues=64, occupied=0.95)
 if len(sys.argv) > 1 and sys.argv[1] == "gangsfull": kw = dict(n_nodes=100_000, n_jobs=1_000_000, n_queues=64, gangs=10_000)   # BASELINE configs[3]
 if len(sys.argv) > 1 and sys.argv[1] == "headline": kw = dict(n_nodes=100_000, n_jobs=1_000_000, n_queues=64)                  # BASELINE configs[2]
-checker = len(sys.argv) > 1 and sys.argv[1] == "checker"   # bench.py's configs[4] checker: 100 000 nodes 95 % occupied, a burst of 3 000 (the production-shaped round: evicted jobs returning, few new ones)
+checker = len(sys.argv) > 1 and sys.argv[1] == "checker"   # bench.py's configs[4] checker: 100 000 nodes 95 % occupied, the reference's default burst of 1 000 (the production-shaped round: evicted jobs returning, few new ones)
 if checker: kw = dict(n_nodes=100_000, n_jobs=300_000, n_queues=64, occupied=0.95)
 wl = W.config3(seed=W.SEED, **kw)
-if checker: wl.global_burst, wl.queue_burst = 3_000, 750
+if checker: wl.global_burst, wl.queue_burst = 1_000, 1_000; wl.config.max_queue_lookback = 100_000   # (bench.py config4_checker_record: the reference's shipped limits)
 elif not full: wl.global_burst, wl.queue_burst = 40_000, 4_000
 lib = armada_amd.load_library()
 s = W.load(lib, wl)
