@@ -1463,7 +1463,15 @@ __device__ static void helperMain(const Dev& d, HelpBox* b, int H) {
 }
 
 #ifndef ASCHED_AUX_TU
-__global__ __launch_bounds__(CTL_THREADS) void k_control(Dev dev, int cmd, HelpBox* box, int H) {
+// armada_sched_ft.hip compiles this file once more with ASCHED_FT_TU + ASCHED_WITH_FT: the same round kernel WITH the fair-share threshold table (round_ft.h) under the name
+// k_control_ft, in a code object of its own — the table's call sites cost the default round kernel 2-3 % by code placement alone (profiles/r03f_*), so it is not in k_control;
+// the host launches k_control_ft for rounds whose handle carries a table (asched_host.inc ensureFt: crowded pools of >= 50 000 nodes, from the second round on).
+#ifdef ASCHED_FT_TU
+#define K_CONTROL_NAME k_control_ft
+#else
+#define K_CONTROL_NAME k_control
+#endif
+__global__ __launch_bounds__(CTL_THREADS) void K_CONTROL_NAME(Dev dev, int cmd, HelpBox* box, int H) {
   if (blockIdx.x != 0) { helperMain(dev, box, H); return; }
   if (threadIdx.x == 0) { g_box = box; g_H = H; g_gen = 0; }
   // the Dev descriptor (pointers + config) is staged in LDS once; every wave reads it from there
@@ -1525,6 +1533,12 @@ __global__ __launch_bounds__(CTL_THREADS) void k_control(Dev dev, int cmd, HelpB
   relocateOut();
 }
 
+#ifdef ASCHED_FT_TU
+extern "C" __attribute__((visibility("hidden"))) int asched_internal_ft_launch(const Dev* dev, int cmd, hipStream_t stream, void* helpBox, int H) {
+  hipLaunchKernelGGL(k_control_ft, dim3(1 + H), dim3(CTL_THREADS), 0, stream, *dev, cmd, (HelpBox*)helpBox, H);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+#else   // !ASCHED_FT_TU: the grid-wide kernels and the host side exist once, in the main translation unit
 // ---- grid-wide kernels of the split round (asched_host.inc runRoundSplit): the data-parallel phases of PreemptingQueueScheduler.Schedule over
 // all CUs.  Between launches the authoritative state is in HBM (relocateOut), so the per-element bodies of round_run.h run unchanged.
 __global__ __launch_bounds__(256) void k_bulk(Dev d, int kind, int n) {
@@ -2279,6 +2293,7 @@ static double plat_last_control_ms() { return t_ctx ? (double)t_ctx->lastControl
 static int plat_last_control_launches() { return t_ctx ? t_ctx->lastControlLaunches : 0; }
 
 extern "C" int asched_internal_aux_launch(const Dev* dev, int cmd, hipStream_t stream, void* helpBox, const MktDev* mk);  // armada_sched_aux.hip
+extern "C" int asched_internal_ft_launch(const Dev* dev, int cmd, hipStream_t stream, void* helpBox, int H);               // armada_sched_ft.hip
 // market-driven rounds: the market state the next auxiliary launch of this thread's handle runs with (asched_host.inc sets it around CMD_MARKET_ROUND)
 static thread_local const MktDev* t_mkt = nullptr;
 static void plat_set_market_dev(const MktDev* m) { t_mkt = m; }
@@ -2299,6 +2314,8 @@ static int plat_run_control(Dev& dev, int cmd) {
   (void)hipEventRecord(c->ev0, c->stream);
   if (cmd >= CMD_AUX_FIRST) {  // submit-check commands: their kernel lives in its own code object (armada_sched_aux.hip)
     if (asched_internal_aux_launch(&dev, cmd, c->stream, c->helpBox, t_mkt)) { c->err = "k_control_aux launch failed"; return -1; }
+  } else if (isRound && dev.ftT != nullptr) {   // this handle carries a fair-share threshold table: the round kernel that uses it (armada_sched_ft.hip)
+    if (asched_internal_ft_launch(&dev, cmd, c->stream, c->helpBox, H)) { c->err = "k_control_ft launch failed"; return -1; }
   } else
   hipLaunchKernelGGL(k_control, dim3(1 + H), dim3(CTL_THREADS), 0, c->stream, dev, cmd, c->helpBox, H);
   (void)hipEventRecord(c->ev1, c->stream);
@@ -2830,6 +2847,7 @@ static int plat_run_fair_shares(Dev& dev, int q, const int32_t* nameRank, const 
 
 #include "asched_host.inc"
 
+#endif  // !ASCHED_FT_TU
 #else  // ASCHED_AUX_TU ----------------------------------------------------------------------------------------------------
 // armada_sched_aux.hip compiles this file a second time with ASCHED_AUX_TU defined: the device code above, ONE kernel
 // (k_control_aux: the submit-check commands, round_run.h runAuxCommand) and no host ABI.  A separate translation unit = a

@@ -87,6 +87,7 @@ func ranks(xs []string) []int32 {
 // handles of different pools are independent and may sit on different GPUs.
 type GpuRound struct {
 	h        *C.asched_t
+	lastCode C.int32_t // return code of the last library call (ErrPeer)
 	pool     string
 	resNames []string // ResourceListFactory column order (resource_list_factory.go:41-52)
 	pcNames  []string // sorted priority-class names == the library's priority-class indices
@@ -356,6 +357,7 @@ func (g *GpuRound) Close() {
 }
 
 func (g *GpuRound) check(rc C.int32_t) error {
+	g.lastCode = rc
 	if rc == 0 {
 		return nil
 	}
@@ -1094,6 +1096,12 @@ func (g *GpuRound) CommInit(id [128]byte, rank, world int) error {
 }
 
 func (g *GpuRound) CommDestroy() error { return g.check(C.asched_comm_destroy(g.h)) }
+
+// ErrPeer: a collective entry point returned ASCHED_ERR_PEER — another rank of the communicator failed in front of the exchange (its own call returns the cause); nothing
+// was exchanged and the communicator stays usable.  (Every rank all-reduces one status word before the data: a rank-local failure can no longer leave the others in RCCL.)
+func (g *GpuRound) ErrPeer(err error) bool {
+	return err != nil && g.lastCode == C.ASCHED_ERR_PEER
+}
 
 // FitSelectBatchSharded: this handle holds rows [rankOffset, rankOffset+len(nodes)) of the pool's nodes in index order; every rank calls it with the same jobs.
 // EXACT: out[i] = position of the chosen node among ALL nodes of the pool in index order (-1: none) == nodeDb.SelectNodeForJobWithTxn's first fit at `priority`

@@ -7,6 +7,7 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-strict-alia
 hipcc $F -c armada_sched.hip -o /tmp/armada_sched_prof.o &
 hipcc $F -c armada_sched_aux.hip -o /tmp/armada_sched_aux_prof.o &
 hipcc $F -c armada_sched_mgpu.hip -o /tmp/armada_sched_mgpu_prof.o &
+hipcc $F -c armada_sched_ft.hip -o /tmp/armada_sched_ft_prof.o &
 wait
-hipcc --offload-arch=gfx950 -fPIC -shared -pthread -o libarmada_sched_prof.so /tmp/armada_sched_prof.o /tmp/armada_sched_aux_prof.o /tmp/armada_sched_mgpu_prof.o
+hipcc --offload-arch=gfx950 -fPIC -shared -pthread -o libarmada_sched_prof.so /tmp/armada_sched_prof.o /tmp/armada_sched_aux_prof.o /tmp/armada_sched_mgpu_prof.o /tmp/armada_sched_ft_prof.o
 ls -la libarmada_sched_prof.so
