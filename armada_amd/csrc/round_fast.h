@@ -1205,6 +1205,21 @@ DEV int fastIter(Dev& d, KREF k, FastS& S, const FastCtx& fc, int top, KeyOut* k
   return fastAdvance(d, k, S, fc, q, f, ko) ? 1 : 2;
 }
 
+// the jobs fastAdvance skipped behind a speculative iteration's job as "known-unfeasible key" (queue_scheduler.go:398-413): list positions [p0, p1) — the backup's cursor to the
+// current one; nothing had looked at them before (the cursor only moves forward), so their records go back to round_prepare's (B_RESET_JOBS); the generic code peeks — and
+// skips — them again if it gets that far.  (Out of line: rare, and nothing of the main loop's registers has to live across it.)
+DEV_NOINLINE void fastUndoSkipRecords(Dev& d, int p0, int p1) {
+  const FastK k = fastKRef(d);
+  for (int b = p0; b < p1; b += 64) {
+    FOR_LANES(x, 64) if (b + x < p1) {
+      int job = k.queuedJobs[b + x];
+      if (d.jcReason[job] == ASCHED_REASON_SKIPPED_UNFEASIBLE_KEY) {
+        d.jcReason[job] = 0; d.jcHasPctx[job] = 0; d.pcMethod[job] = ASCHED_METHOD_NONE;
+        d.jobFlags[job] = (uint8_t)(d.jobFlags[job] & ~F_UNSUCCESSFUL);
+      }
+    }
+  }
+}
 // The node engine found no node for the job of queue q's last (speculative) iteration: take the queue side of that iteration
 // back — accounting, counters, tokens, the queue's head / iterator / key — so that the generic code meets the state fastIter
 // would have left by returning 0.  The heap lanes are rebuilt by the caller.
@@ -1218,24 +1233,7 @@ DEV void fastRollback(Dev& d, KREF k, FastS& S, int q) {
   S.numScheduledJobs--; S.numScheduledGangs--; S.numNodeQueries--;
   S.globalTokens = UNID(FL.bk.globalTokens);
   { int g = UNI32(FL.hot[q].gctx); if (g < -1 && FLANE == 0) d.gangSeen[-g - 2] = 0; }   // the iteration had assembled the gang behind its job (fastPeekGang): not seen yet
-  {   // the jobs fastAdvance skipped behind the iteration's job as "known-unfeasible key": list positions [the backup's cursor, the current one); nothing had looked at them
-      // before (the cursor only moves forward), so their records go back to round_prepare's (B_RESET_JOBS); the generic code peeks — and skips — them again if it gets that far
-    int p0 = UNI32(FL.bk.hot.itQi), p1 = UNI32(FL.hot[q].itQi);
-    if (S.numUnfeasible > 0 && p1 > p0) {
-      for (int b = p0; b < p1; b += 64) {
-        FOR_LANES(x, 64) if (b + x < p1) {
-          int job = k.queuedJobs[b + x];
-          if (d.jcReason[job] == ASCHED_REASON_SKIPPED_UNFEASIBLE_KEY) {
-            d.jcReason[job] = 0; d.jcHasPctx[job] = 0; d.pcMethod[job] = ASCHED_METHOD_NONE;
-            d.jobFlags[job] = (uint8_t)(d.jobFlags[job] & ~F_UNSUCCESSFUL);
-#ifdef ASCHED_HOSTSIM
-            { static long undone = 0; static const bool st = getenv("HS_EV_STATS") != nullptr; if (st && (++undone % 50) == 1) fprintf(stderr, "rollback took back %ld skip records\n", undone); }
-#endif
-          }
-        }
-      }
-    }
-  }
+  { int p0 = UNI32(FL.bk.hot.itQi), p1 = UNI32(FL.hot[q].itQi); if (S.numUnfeasible > 0 && p1 > p0) fastUndoSkipRecords(d, p0, p1); }
   engineRestore(q);
   FL.hot[q].winKind = -1; FL.hot[q].ewCount = 0;  // the windows may have moved on: refill on demand
   S.loopIterations--; S.statFastIters--;
@@ -1392,9 +1390,10 @@ DEV_NOINLINE SkipDelta fastDrain(Dev& d, int Q) {
 //     accounting had been done for them — and the entry is its queue's head again).
 // Exactness: the merge is the heap of QueueCandidateGangIteratorPQ on the very keys fastAdvance would compute (same float64 operations on the same
 // prefix sums, round_run.h B_QSKEYS), the engine executes the entries in emission order, and integer accounting is order independent.
-struct StreamIn { double globalTokens; int64_t globalBurst; int32_t globalRateInf, engSeq; int32_t skip, haveLast; uint32_t lastA, lastN; uint64_t lastX, lastY; };   // skip / last*: skip mode is on, key of the entry served last
+struct StreamIn { double globalTokens; int64_t globalBurst; int32_t globalRateInf, engSeq; int32_t skip, haveLast; uint32_t lastA, lastN; uint64_t lastX, lastY; int32_t resume; };   // skip / last*: skip mode is on, key of the entry served last
 struct StreamOut { int executed, executedEv, pend, dropped, engSeq, emitted, refills, evicted, maxConsumed, failed, lastQ; uint32_t lastA, lastN; uint64_t lastX, lastY;
-                   int gangJobs, gangs; };   // gangs placed INSIDE the run (round 5) and their members: the caller accounts them like fastGangRun's (ReserveN, one scheduled gang each)
+                   int gangJobs, gangs;    // gangs placed INSIDE the run (round 5) and their members: the caller accounts them like fastGangRun's (ReserveN, one scheduled gang each)
+                   int event, evT; };      // event != 0: the run is PARKED at one of its two rare events (streamNestSettle / streamNestGang on queue evT) — the caller runs it and calls again with in.resume
 // streams persist between runs: head of queue q == element sPos of its stream, elements [sPos, sLen) are still to come.  A queue's stream is dropped
 // when anything but a stream run serves the queue (fastIter) or the generic code runs (fastQLoad).  prepare: 0 = the top queue has no stream,
 // 1 = ready, 2 = some queue needs the bulk passes and allowBulk was 0 (the node engine must be stopped first: they use every wave of the workgroup)
@@ -1428,7 +1427,82 @@ struct NestIO {
   int emitted, emittedQ, acc, fail, allowed, engSeq, sessLive, emittedPrev, doneQmid, maxMid, gangJobs, gangs, refills, evicted, pend, dropped, go;
   int replace, relane, koValid; uint32_t koA; uint64_t koX, koY;   // replace: queue t's heap entry becomes (koValid, koA, koX, koY); relane: the queue was settled — its stream lanes (and its count of done entries) start again from its record
 };
-DEV_NOINLINE NestIO streamNest(Dev& d, FastCtx fc, StreamIn in, NestIO st, int ev, int t);
+// A run parks at an event and RETURNS to the round's main loop, which calls the event's function and then the run again (in.resume).  The events' functions (and what they
+// call: fastGangRun, fastAdvance, fastStreamPrepareOne) clobber every VGPR and ~80 AGPRs; called from inside the run, everything the run holds had to live above that, the
+// run's own footprint grew from 56 to 206 AGPRs, and the main loop — whose register allocation must keep clear of what its callees clobber — spilled more in EVERY round,
+// stream run or not (configs[4] +15 %, profiles/r05z_nest_register_footprint.txt).  Parked state: lane-private words per lane + the uniform scalars, in d.qsPart (the
+// carries of the preparation passes: idle during a run).
+enum { PK_haveLast, PK_lastQ, PK_emitted, PK_emittedQ, PK_acc, PK_stageBase, PK_stageCnt, PK_issuedTo, PK_fail, PK_allowed, PK_engSeq, PK_sessLive, PK_emittedPrev, PK_doneQmid,
+       PK_maxMid, PK_gangJobs, PK_gangs, PK_refills, PK_evicted, PK_pend, PK_dropped, PK_go, PK_ev, PK_evT, PK_evSLen, PK_lastA, PK_lastN, PK_lastX, PK_lastY,
+       PK_replace, PK_relane, PK_koValid, PK_koA, PK_koX, PK_koY, PK_COUNT };
+#define PK_LANE_WORDS 12
+#define PK_BASE(d) ((d).qsPart)
+#define PKW(d) ((volatile unsigned long long*)PK_BASE(d) + 64 * PK_LANE_WORDS)
+#define PK_INTS(X) X(haveLast) X(lastQ) X(emitted) X(emittedQ) X(acc) X(stageBase) X(stageCnt) X(issuedTo) X(fail) X(allowed) X(engSeq) X(sessLive) X(emittedPrev) X(doneQmid) \
+                   X(maxMid) X(gangJobs) X(gangs) X(refills) X(evicted) X(pend) X(dropped) X(go) X(ev) X(evT) X(evSLen)
+#define NEST_INTS(X) X(emitted) X(emittedQ) X(acc) X(fail) X(allowed) X(engSeq) X(sessLive) X(emittedPrev) X(doneQmid) X(maxMid) X(gangJobs) X(gangs) X(refills) X(evicted) X(pend) X(dropped) X(go)
+#ifdef ASCHED_HOSTSIM
+static thread_local RunState hsParkedRun;   // (the serial build's lane state is arrays inside the struct)
+#endif
+DEV void runPark(Dev& d, const RunState& m) {
+  volatile unsigned long long* u = PKW(d);
+  if (FLANE == 0) {
+#define X(f) u[PK_##f] = (unsigned long long)(unsigned)m.f;
+    PK_INTS(X)
+#undef X
+    u[PK_lastA] = m.lastK.A; u[PK_lastX] = m.lastK.X; u[PK_lastY] = m.lastK.Y; u[PK_lastN] = m.lastN;
+  }
+#ifdef ASCHED_HOSTSIM
+  hsParkedRun = m;
+#else
+  volatile unsigned long long* sv = (volatile unsigned long long*)PK_BASE(d) + (size_t)FLANE * PK_LANE_WORDS;
+  sv[0] = m.pq.X; sv[1] = m.pq.Y; sv[2] = ((unsigned long long)m.pq.A << 32) | m.pq.N; sv[3] = ((unsigned long long)(unsigned)m.pq.q << 32) | (unsigned)m.pq.count;
+  sv[4] = ((unsigned long long)(unsigned)m.sl.start << 32) | (unsigned)m.sl.base; sv[5] = ((unsigned long long)(unsigned)m.sl.pos << 32) | (unsigned)m.sl.len;
+  sv[6] = ((unsigned long long)(unsigned)m.sl.kind << 32) | (unsigned)m.sl.ws; sv[7] = __builtin_bit_cast(unsigned long long, m.sl.budget);
+  sv[8] = m.sl.effX; sv[9] = m.sl.effY; sv[10] = m.sl.effA; sv[11] = m.stageV;
+#endif
+  LANE0_PUBLISHED();
+}
+DEV void runUnpark(Dev& d, RunState& m) {
+#ifdef ASCHED_HOSTSIM
+  m = hsParkedRun;
+#else
+  volatile unsigned long long* sv = (volatile unsigned long long*)PK_BASE(d) + (size_t)FLANE * PK_LANE_WORDS;
+  unsigned long long w2 = sv[2], w3 = sv[3], w4 = sv[4], w5 = sv[5], w6 = sv[6];
+  m.pq.X = sv[0]; m.pq.Y = sv[1]; m.pq.A = (uint32_t)(w2 >> 32); m.pq.N = (uint32_t)w2; m.pq.q = (int)(w3 >> 32); m.pq.count = (int)(uint32_t)w3;
+  m.sl.start = (int)(w4 >> 32); m.sl.base = (int)(uint32_t)w4; m.sl.pos = (int)(w5 >> 32); m.sl.len = (int)(uint32_t)w5;
+  m.sl.kind = (int)(w6 >> 32); m.sl.ws = (int)(uint32_t)w6; m.sl.budget = __builtin_bit_cast(double, (unsigned long long)sv[7]);
+  m.sl.effX = sv[8]; m.sl.effY = sv[9]; m.sl.effA = (uint32_t)sv[10]; m.stageV = sv[11];
+#endif
+  volatile unsigned long long* u = PKW(d);
+#define X(f) m.f = UNI32((int)(unsigned)u[PK_##f]);
+  PK_INTS(X)
+#undef X
+  m.lastK.A = UNI32((uint32_t)u[PK_lastA]); m.lastK.X = UNI64(u[PK_lastX]); m.lastK.Y = UNI64(u[PK_lastY]); m.lastN = UNI32((uint32_t)u[PK_lastN]);
+}
+DEV NestIO nestLoad(Dev& d) {
+  volatile unsigned long long* u = PKW(d);
+  NestIO st;
+#define X(f) st.f = UNI32((int)(unsigned)u[PK_##f]);
+  NEST_INTS(X)
+#undef X
+  st.replace = st.relane = st.koValid = 0; st.koA = 0; st.koX = st.koY = 0;
+  return st;
+}
+DEV void nestStore(Dev& d, const NestIO& st) {
+  volatile unsigned long long* u = PKW(d);
+  if (FLANE == 0) {
+#define X(f) u[PK_##f] = (unsigned long long)(unsigned)st.f;
+    NEST_INTS(X)
+#undef X
+    u[PK_replace] = (unsigned)st.replace; u[PK_relane] = (unsigned)st.relane; u[PK_koValid] = (unsigned)st.koValid; u[PK_koA] = st.koA; u[PK_koX] = st.koX; u[PK_koY] = st.koY;
+  }
+  LANE0_PUBLISHED();
+}
+DEV_NOINLINE void streamNestSettle(Dev& d, FastCtx fc, int t);
+DEV NestIO streamNestSettleBody(Dev& d, FastCtx fc, NestIO st, int t);
+DEV NestIO streamNestGangBody(Dev& d, FastCtx fc, StreamIn in, NestIO st, int t);
+DEV_NOINLINE void streamNestGang(Dev& d, FastCtx fc, StreamIn in, int t);
 DEV RunState streamMerge(Dev& d, FastCtx fc, int Q, int skip, int nest, RunState m);
 // ---- (round 5) a run does not end where a queue's stream ends at a gang.  A queue's stream is cut at its next gang member (B_QSSUM), and until round 4 the run ended
 // the moment any queue used its stream up — on gang-heavy pools (BASELINE configs[3]) most single jobs therefore took the per-job iteration, whose queue side costs the
@@ -1452,52 +1526,51 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
   const bool nestOff = false;
 #endif
   const bool nest = !nestOff && !fc.replay;
-  PQState pq;
-  pqBuild(pq, Q);
-  int allowed = INT32_MAX;
-  if (!in.globalRateInf) allowed = in.globalTokens >= 2147483000.0 ? INT32_MAX : (in.globalTokens < 1 ? 0 : (int)in.globalTokens);
-  if (in.globalBurst < 1 || in.globalTokens < 1) allowed = 0;
-  PackedKey lastK; lastK.A = ~0u; lastK.X = lastK.Y = ~0ull; uint32_t lastN = ~0u;
-  int skip = UNI32(in.skip), haveLast = 0, lastQ = -1;
-  if (skip && UNI32(in.haveLast)) { lastK.A = UNI32(in.lastA); lastK.X = UNI64(in.lastX); lastK.Y = UNI64(in.lastY); lastN = UNI32(in.lastN); haveLast = 1; }
+  const int skip = UNI32(in.skip);
+  PQState pq; memset(&pq, 0, sizeof pq);
   StreamLanes sl; memset(&sl, 0, sizeof sl);
-  FOR_LANES(q, QCAPF) {   // (the head of a queue is element sPos of its stream = the list entry before the queue's cursor)
-    const QHot& f = FL.hot[q];
-    int kind = FL.sKind[q] ? 1 : 0;
-    SL_SET(sl, start, q, f.sPos); SL_SET(sl, pos, q, f.sPos); SL_SET(sl, len, q, q < Q ? f.sLen : 0);
-    SL_SET(sl, base, q, (kind ? f.itEi : f.itQi) - 1 - f.sPos);
-    SL_SET(sl, kind, q, kind | (f.effValid ? 2 : 0));
-    SL_SET(sl, ws, q, -2 * WIN);
-    SL_SET(sl, budget, q, f.budget);
-    SL_SET(sl, effA, q, FL.effA[q]); SL_SET(sl, effX, q, FL.effX[q]); SL_SET(sl, effY, q, FL.effY[q]);
-    FL.tmpQ[q] = 0;
-  }
+  PackedKey lastK; lastK.A = ~0u; lastK.X = lastK.Y = ~0ull; uint32_t lastN = ~0u; int lastQ = -1;
   int engSeq = in.engSeq;
-  streamBegin(&engSeq);
-  // The merge loop and the two rare events live in functions of their own, the run's state going in and out BY VALUE: with the event code inline the loop's registers had their
-  // addresses taken / its allocation changed and the headline lost 14-20 % (profiles/r05l_nested_gang_runs.txt); as a separate function the loop compiles as it did in round 4.
+  // The merge loop lives in a function of its own (streamMerge), the run's state going in and out by value.  (The first version of the nested runs had the event code inline in
+  // the loop and the headline lost 14-20 %, profiles/r05l_nested_gang_runs.txt — put down to register allocation then; in hindsight more likely the miscompiled key test
+  // described at streamMerge, which makes skip mode rebuild its state around a stale key.)
   RunState m; memset(&m, 0, sizeof m);
-  m.pq = pq; m.sl = sl; m.lastK = lastK; m.lastN = lastN; m.haveLast = haveLast; m.lastQ = lastQ;
-  m.stageBase = -1; m.allowed = allowed; m.engSeq = engSeq; m.sessLive = 1; m.pend = -1;
-  for (;;) {
-    m = streamMerge(d, fc, Q, skip, nest ? 1 : 0, m);
-    if (m.ev == 0) break;
-    // an event: everything emitted so far is staged here (the gathered records in flight are lane-private), the rest happens out of line on scalars
-    const int t = m.evT;
-    if (m.stageBase >= 0) { streamStageCommit(d, k, m.stageBase, m.stageCnt, m.stageV); m.stageBase = -1; }
-    if (m.emitted > m.issuedTo) { unsigned long long v = streamStageIssue(k, m.issuedTo, m.emitted - m.issuedTo); streamStageCommit(d, k, m.issuedTo, m.emitted - m.issuedTo, v); m.issuedTo = m.emitted; }   // (never twice: the serial build serves an entry when it is staged)
-    NestIO io; memset(&io, 0, sizeof io);
-    io.emitted = m.emitted; io.emittedQ = m.emittedQ; io.acc = m.acc; io.fail = m.fail; io.allowed = m.allowed; io.engSeq = m.engSeq; io.sessLive = m.sessLive; io.emittedPrev = m.emittedPrev;
-    io.doneQmid = m.doneQmid; io.maxMid = m.maxMid; io.gangJobs = m.gangJobs; io.gangs = m.gangs; io.pend = m.pend; io.dropped = m.dropped;
-    io = streamNest(d, fc, in, io, m.ev, t);
-    m.emitted = io.emitted; m.acc = io.acc; m.fail = io.fail; m.allowed = io.allowed; m.engSeq = io.engSeq; m.sessLive = io.sessLive; m.emittedPrev = io.emittedPrev;
-    m.doneQmid = io.doneQmid; m.maxMid = io.maxMid; m.gangJobs = io.gangJobs; m.gangs = io.gangs; m.refills += io.refills; m.evicted += io.evicted; m.pend = io.pend; m.dropped = io.dropped;
-    if (io.emitted == 0) m.issuedTo = 0;   // (a new ring session)
-    if (io.replace) {
-      KeyOut nk; nk.valid = io.koValid; nk.A = io.koA; nk.X = io.koX; nk.Y = io.koY;
+  bool go = true;
+  if (!UNI32(in.resume)) {
+    pqBuild(pq, Q);
+    int allowed = INT32_MAX;
+    if (!in.globalRateInf) allowed = in.globalTokens >= 2147483000.0 ? INT32_MAX : (in.globalTokens < 1 ? 0 : (int)in.globalTokens);
+    if (in.globalBurst < 1 || in.globalTokens < 1) allowed = 0;
+    lastK.A = ~0u; lastK.X = lastK.Y = ~0ull; lastN = ~0u;
+    int haveLast = 0;
+    if (skip && UNI32(in.haveLast)) { lastK.A = UNI32(in.lastA); lastK.X = UNI64(in.lastX); lastK.Y = UNI64(in.lastY); lastN = UNI32(in.lastN); haveLast = 1; }
+    memset(&sl, 0, sizeof sl);
+    FOR_LANES(q, QCAPF) {   // (the head of a queue is element sPos of its stream = the list entry before the queue's cursor)
+      const QHot& f = FL.hot[q];
+      int kind = FL.sKind[q] ? 1 : 0;
+      SL_SET(sl, start, q, f.sPos); SL_SET(sl, pos, q, f.sPos); SL_SET(sl, len, q, q < Q ? f.sLen : 0);
+      SL_SET(sl, base, q, (kind ? f.itEi : f.itQi) - 1 - f.sPos);
+      SL_SET(sl, kind, q, kind | (f.effValid ? 2 : 0));
+      SL_SET(sl, ws, q, -2 * WIN);
+      SL_SET(sl, budget, q, f.budget);
+      SL_SET(sl, effA, q, FL.effA[q]); SL_SET(sl, effX, q, FL.effX[q]); SL_SET(sl, effY, q, FL.effY[q]);
+      FL.tmpQ[q] = 0;
+    }
+    engSeq = in.engSeq;
+    streamBegin(&engSeq);
+    m.pq = pq; m.sl = sl; m.lastK = lastK; m.lastN = lastN; m.haveLast = haveLast; m.lastQ = -1;
+    m.stageBase = -1; m.allowed = allowed; m.engSeq = engSeq; m.sessLive = 1; m.pend = -1;
+  } else {
+    // the event the run was parked at has run (streamNestSettle / streamNestGang, called by the main loop): the heap / lane updates it asks for, then on with the merge
+    runUnpark(d, m);
+    volatile unsigned long long* u = PKW(d);
+    const int t = m.evT, replace = UNI32((int)(unsigned)u[PK_replace]), relane = UNI32((int)(unsigned)u[PK_relane]);
+    if (m.emitted == 0) m.issuedTo = 0;   // (a new ring session)
+    if (replace) {
+      KeyOut nk; nk.valid = UNI32((int)(unsigned)u[PK_koValid]); nk.A = UNI32((uint32_t)u[PK_koA]); nk.X = UNI64(u[PK_koX]); nk.Y = UNI64(u[PK_koY]);
       pqPopPush(m.pq, nk, t);
     }
-    if (io.relane) {
+    if (relane) {
       const QHot& f = FL.hot[t];   // queue t's lane state of the run from its (just materialised) record
       int kd = UNI32((int)FL.sKind[t]) ? 1 : 0, sp = UNI32(f.sPos), sn = UNI32(f.sLen);
       SL_SET(m.sl, start, t, sp); SL_SET(m.sl, pos, t, sp); SL_SET(m.sl, len, t, sn);
@@ -1508,13 +1581,25 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
       if (FLANE == 0) FL.tmpQ[t] = 0;
       LANE0_PUBLISHED();
     }
-    if (!io.go) break;
+    go = m.go != 0;
+  }
+  if (go) {
+    m = streamMerge(d, fc, Q, skip, nest ? 1 : 0, m);
+    if (m.ev != 0) {
+      // an event: everything emitted so far is staged here (the gathered records in flight are lane-private), the run parks and the main loop runs the event
+      if (m.stageBase >= 0) { streamStageCommit(d, k, m.stageBase, m.stageCnt, m.stageV); m.stageBase = -1; }
+      if (m.emitted > m.issuedTo) { unsigned long long v = streamStageIssue(k, m.issuedTo, m.emitted - m.issuedTo); streamStageCommit(d, k, m.issuedTo, m.emitted - m.issuedTo, v); m.issuedTo = m.emitted; }   // (never twice: the serial build serves an entry when it is staged)
+      runPark(d, m);
+      out.event = m.ev; out.evT = m.evT;
+      return out;
+    }
   }
   pq = m.pq; sl = m.sl; lastK = m.lastK; lastN = m.lastN; lastQ = m.lastQ;
   int emitted = m.emitted, acc = m.acc, stageBase = m.stageBase, stageCnt = m.stageCnt, issuedTo = m.issuedTo, fail = m.fail;
   unsigned long long stageV = m.stageV;
   engSeq = m.engSeq; sessLive = m.sessLive; emittedPrev = m.emittedPrev; doneQmid = m.doneQmid; maxMid = m.maxMid;
-  out.gangJobs = m.gangJobs; out.gangs = m.gangs; out.pend = m.pend; out.dropped = m.dropped;
+  out.gangJobs = m.gangJobs; out.gangs = m.gangs;
+  out.pend = m.pend; out.dropped = m.dropped;
   S.statRefills += m.refills; S.numEvictedJobs += m.evicted;
   // drain: what is still in flight, then the tail group
   if (sessLive) {
@@ -1576,6 +1661,11 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
 }
 
 // the merge loop of a run (fastStreamRun): pop the head of the lane heap, emit (job, queue) into the ring, take the queue's next precomputed costs, re-insert
+// NOTE (round 5, profiles/r05y_lastkey_miscompile.txt): the two "served in non-decreasing key order" tests below branch on a condition made wave-uniform by hand (UNI32).  Written
+// as a plain `if (haveLast && packedLess(...)) break;` — haveLast arrives in a VGPR, so the branch is compiled as a divergent one — hipcc 7.2 emitted, in some builds of this
+// function, a masked update that refreshes lastK.X / lastK.Y after the test but leaves lastK.A, lastN and haveLast at their old values on the "not less" path (the (A, N) pair
+// is reset to the old pair after the compare and never set again): fastExitSkip then rebuilt the state around a key with a stale priority field and the round diverged (test
+// test_gang_behind_folded_evicted_streams_gpu, seeds 100345 / 102465).  Whether a build had it depended on unrelated code around the loop; the CPU build never had it.
 DEV RunState streamMerge(Dev& d, FastCtx fc, int Q, int skip, int nest, RunState m) {
   const FastK k = fastKRef(d);
   FastS S; coldS(d, S);
@@ -1601,7 +1691,7 @@ DEV RunState streamMerge(Dev& d, FastCtx fc, int Q, int skip, int nest, RunState
       if (skip) {   // skip mode: entries are served in non-decreasing key order only (as for a stream element below; fastRun makes the same test in front of a gang)
         PackedKey curK; uint32_t curN;
         pqHeadKey(pq, t, &curK, &curN);
-        if (haveLast && packedLess(curK, curN, lastK, lastN)) break;
+        if (UNI32((int)(haveLast && packedLess(curK, curN, lastK, lastN)))) break;   // (a scalar branch: see the note above the loop)
         lastK = curK; lastN = curN; haveLast = 1;
       }
       lastQ = t;
@@ -1616,7 +1706,7 @@ DEV RunState streamMerge(Dev& d, FastCtx fc, int Q, int skip, int nest, RunState
     if (skip) {                                   // skip mode (fastRun): the folded evicted streams are merged around keys served in non-decreasing order only
       PackedKey curK; uint32_t curN;
       pqHeadKey(pq, t, &curK, &curN);
-      if (haveLast && packedLess(curK, curN, lastK, lastN)) break;
+      if (UNI32((int)(haveLast && packedLess(curK, curN, lastK, lastN)))) break;   // (a scalar branch: see the note above the loop)
       lastK = curK; lastN = curN; haveLast = 1;   // the key this entry is served under (fastExitSkip rebuilds the state around the last one)
     }
     lastQ = t;
@@ -1666,46 +1756,49 @@ DEV RunState streamMerge(Dev& d, FastCtx fc, int Q, int skip, int nest, RunState
   m.ev = ev; m.evT = evT; m.evSLen = evSLen;
   return m;
 }
-// the two events of fastStreamRun (see there), on wave-uniform state.  ev 1: queue t's queued stream is used up and the element behind it is a gang member; ev 2: the head of
-// the heap, queue t, is an assembled gang.  The caller has staged everything emitted.  st.go = 1: the run goes on; 0: it ends (st.pend / st.dropped / st.fail say why).
-DEV_NOINLINE NestIO streamNest(Dev& d, FastCtx fc, StreamIn in, NestIO st, int ev, int t) {
-  const FastK k = fastKRef(d);
-  FastS S; coldS(d, S);
-  st.go = 0; st.replace = 0; st.relane = 0; st.koValid = 0; st.koA = 0; st.koX = st.koY = 0;
-  // drain: everything emitted placed, accounted, and its ring slot read by the bind wave (the job-record windows ARE the ring: fastAdvance refills them)
-  bool drained = false;
+// the two rare events of fastStreamRun (see there), on wave-uniform state; the caller has staged everything emitted.  st.go = 1: the run goes on; 0: it ends (st.pend /
+// st.dropped / st.fail say why).  Two functions, each as small as it can be: what they (and their callees) clobber is what the run's caller must keep clear of.
+DEV bool streamDrain(Dev& d, KREF k, NestIO& st) {   // everything emitted placed, accounted, and its ring slot read by the bind wave (the job-record windows ARE the ring: fastAdvance refills them)
   for (;;) {
     int a = streamAcked(&st.fail);
     if (a > st.acc) { streamAccount(d, k, st.acc, a); st.acc = a; }
-    if (st.fail) break;
-    if (st.acc >= st.emitted && streamBound() >= st.emitted) { drained = true; break; }
+    if (st.fail) return false;
+    if (st.acc >= st.emitted && streamBound() >= st.emitted) return true;
     STREAM_IDLE();
   }
-  if (ev == 1) {
-    st.replace = 1;                       // (not drained — an entry found no node —: the queue leaves the heap, as at the end of its stream before round 5)
-    if (!drained) return st;
-    // every element of queue t's stream is done: its iterator state as the end of a run leaves it, then the next head through the ordinary fastAdvance
-    QHot f = FL.hot[t];
-    uniQHot(f);
-    int cq = UNI32(FL.tmpQ[t]);
-    if (FLANE == 0) { FL.hot[t].sPos = 0; FL.hot[t].sLen = 0; FL.hot[t].ewCount = 0; FL.hot[t].ewStart = 0; FL.hot[t].winKind = -1; FL.hot[t].winCount = 0; }
-    LANE0_PUBLISHED();
-    f.sPos = 0; f.sLen = 0; f.ewCount = 0; f.ewStart = 0; f.winKind = -1; f.winCount = 0;
-    st.doneQmid += cq; if (cq > st.maxMid) st.maxMid = cq;
-    f.itQi = f.itQi - 1 + cq; f.itJobsSeen = f.itJobsSeen - 1 + cq;
-    if (!f.rateInf && 1 <= f.burst) f.tokens -= (double)cq;
-    KeyOut nk;
-    bool more = fastAdvance(d, k, S, fc, t, f, &nk);
-    if (FLANE == 0) { FL.hot[t].winKind = -1; FL.hot[t].winCount = 0; }   // (its window lies in the ring)
-    LANE0_PUBLISHED();
-    st.koValid = nk.valid; st.koA = nk.A; st.koX = nk.X; st.koY = nk.Y; st.relane = 1;
-    st.refills += S.statRefills; st.evicted += S.numEvictedJobs;
-    if (!more) { st.pend = t; return st; }
-    st.go = 1;
-    return st;
-  }
-  // ev == 2: the gang
-  if (!drained) return st;
+}
+// queue t's queued stream is used up and the element behind it is a gang member
+DEV NestIO streamNestSettleBody(Dev& d, FastCtx fc, NestIO st, int t) {
+  const FastK k = fastKRef(d);
+  FastS S; coldS(d, S);
+  st.go = 0; st.replace = 1; st.relane = 0; st.koValid = 0; st.koA = 0; st.koX = st.koY = 0;
+  if (!streamDrain(d, k, st)) return st;   // (an entry found no node: the queue leaves the heap, as at the end of its stream before round 5)
+  // every element of queue t's stream is done: its iterator state as the end of a run leaves it, then the next head through the ordinary fastAdvance
+  QHot f = FL.hot[t];
+  uniQHot(f);
+  int cq = UNI32(FL.tmpQ[t]);
+  if (FLANE == 0) { FL.hot[t].sPos = 0; FL.hot[t].sLen = 0; FL.hot[t].ewCount = 0; FL.hot[t].ewStart = 0; FL.hot[t].winKind = -1; FL.hot[t].winCount = 0; }
+  LANE0_PUBLISHED();
+  f.sPos = 0; f.sLen = 0; f.ewCount = 0; f.ewStart = 0; f.winKind = -1; f.winCount = 0;
+  st.doneQmid += cq; if (cq > st.maxMid) st.maxMid = cq;
+  f.itQi = f.itQi - 1 + cq; f.itJobsSeen = f.itJobsSeen - 1 + cq;
+  if (!f.rateInf && 1 <= f.burst) f.tokens -= (double)cq;
+  KeyOut nk;
+  bool more = fastAdvance(d, k, S, fc, t, f, &nk);
+  if (FLANE == 0) { FL.hot[t].winKind = -1; FL.hot[t].winCount = 0; }   // (its window lies in the ring)
+  LANE0_PUBLISHED();
+  st.koValid = nk.valid; st.koA = nk.A; st.koX = nk.X; st.koY = nk.Y; st.relane = 1;
+  st.refills += S.statRefills; st.evicted += S.numEvictedJobs;
+  if (!more) { st.pend = t; return st; }
+  st.go = 1;
+  return st;
+}
+// the head of the heap, queue t, is an assembled gang
+DEV_NOINLINE void streamNestSettle(Dev& d, FastCtx fc, int t) { NestIO st = nestLoad(d); st = streamNestSettleBody(d, fc, st, t); nestStore(d, st); }
+DEV NestIO streamNestGangBody(Dev& d, FastCtx fc, StreamIn in, NestIO st, int t) {
+  const FastK k = fastKRef(d);
+  st.go = 0; st.replace = 0; st.relane = 0; st.koValid = 0; st.koA = 0; st.koX = st.koY = 0;
+  if (!streamDrain(d, k, st)) return st;
   streamEnd(st.engSeq); st.sessLive = 0;
   FOR_LANES(q, QCAPF) FL.tmpN[q] = (uint32_t)FL.tmpQ[q];   // (fastGangRun and fastStreamPrepareOne use tmpQ as scratch: the run's per-queue counts wait in the heap's scatter space)
   LANE0_PUBLISHED();
@@ -1738,6 +1831,8 @@ DEV_NOINLINE NestIO streamNest(Dev& d, FastCtx fc, StreamIn in, NestIO st, int e
   st.go = 1;
   return st;
 }
+
+DEV_NOINLINE void streamNestGang(Dev& d, FastCtx fc, StreamIn in, int t) { NestIO st = nestLoad(d); st = streamNestGangBody(d, fc, in, st, t); nestStore(d, st); }
 
 // ---- a gang through the ring.  GangScheduler.Schedule for the common gang (gang_scheduler.go:46-148, 229-262): every member a queued job, no
 // uniformity label, every member fits without preemption.  The members go through the ring like a stream run's entries — the node engine places them one
@@ -1982,7 +2077,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
       // state around the last entry served and go on without the mode
       PackedKey curK; uint32_t curN;
       pqHeadKey(pq, t, &curK, &curN);
-      if (haveRef && packedLess(curK, curN, refK, refN)) {
+      if (UNI32((int)(haveRef && packedLess(curK, curN, refK, refN)))) {   // (a scalar branch: see the note at streamMerge)
         SkipDelta dl = fastExitSkip(d, fc, Q, lastTop, refK, refN);
         S.numEvictedJobs += dl.evicted; S.loopIterations += dl.iters; S.statRefills += dl.refills;
         c.skipActive = 0;
@@ -1998,7 +2093,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
     if (UNI32(FL.hot[t].gctx) < 0) {  // a gang: through the ring when every member is an untouched queued job (fastGangRun), else generic
       if (mode || !fc.stream || !S.fastActive || UNI32(FL.hot[t].gctx) == -1) break;
       if (!S.engLive) { engineStart(d, S); S.engLive = 1; }
-      StreamIn in; in.globalTokens = S.globalTokens; in.globalBurst = S.globalBurst; in.globalRateInf = S.globalRateInf; in.engSeq = S.engSeq;
+      StreamIn in; in.globalTokens = S.globalTokens; in.globalBurst = S.globalBurst; in.globalRateInf = S.globalRateInf; in.engSeq = S.engSeq; in.resume = 0;
       in.skip = 0; in.haveLast = 0; in.lastA = in.lastN = 0; in.lastX = in.lastY = 0;
       GangOut go = fastGangRun(d, fc, in, t);
       S.engSeq = go.engSeq;
@@ -2033,7 +2128,13 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
         if (!S.engLive) { engineStart(d, S); S.engLive = 1; }
         StreamIn in; in.globalTokens = S.globalTokens; in.globalBurst = S.globalBurst; in.globalRateInf = S.globalRateInf; in.engSeq = S.engSeq;
         in.skip = c.skipActive; in.haveLast = haveRef; in.lastA = refK.A; in.lastX = refK.X; in.lastY = refK.Y; in.lastN = refN;   // (the current top's key: it is the first entry of the run)
+        in.resume = 0;
         StreamOut so = fastStreamRun(d, fc, Q, in);
+        while (so.event) {   // the run is parked at one of its rare events (see runPark): run it from here, then the run again
+          if (so.event == 1) streamNestSettle(d, fc, so.evT); else streamNestGang(d, fc, in, so.evT);
+          in.resume = 1;
+          so = fastStreamRun(d, fc, Q, in);
+        }
         S.engSeq = so.engSeq;
         E = so.executed; so_max = so.maxConsumed;
         S.numScheduledJobs += E; S.numScheduledGangs += E; S.numNodeQueries += E;
