@@ -1420,9 +1420,9 @@ struct RunState {   // the state of a run, handed by value between its three out
   int ev, evT, evSLen;   // why the merge loop returned: 0 the run ends, 1 queue evT's queued stream (evSLen elements) is used up in front of a gang member, 2 the head of the heap, queue evT, is an assembled gang
   unsigned long long stageV;
 };
-// what the rare events of a run (streamNest) read and change: wave-uniform scalars only.  (A first version handed the whole RunState — lane-private heap and stream lanes
-// included — by value through the noinline call: on the device the run then behaved differently (52 000 evicted entries emitted that HEAD folds), profiles/r05l…; the CPU
-// build did not.  Lane-private state stays in the inlined caller, which applies the heap / lane updates the event asks for.)
+// what the rare events of a run (streamNestSettle / streamNestGang) read and change: wave-uniform scalars only.  (A first version handed the whole RunState by value
+// through a noinline call and the device then emitted 52 000 evicted entries that HEAD folds — put down to lane-private values not surviving the call boundary at the
+// time, profiles/r05l; it was the miscompiled key test described at streamMerge.  The split stands on its own merits: the events are rare, large, and out of line.)
 struct NestIO {
   int emitted, emittedQ, acc, fail, allowed, engSeq, sessLive, emittedPrev, doneQmid, maxMid, gangJobs, gangs, refills, evicted, pend, dropped, go;
   int replace, relane, koValid; uint32_t koA; uint64_t koX, koY;   // replace: queue t's heap entry becomes (koValid, koA, koX, koY); relane: the queue was settled — its stream lanes (and its count of done entries) start again from its record

@@ -503,10 +503,16 @@ DEV void schedulePass(Dev& d, Ctl& c, bool withQueued, bool skipKey, bool cmpPri
 // own (wgFtBuild) instead of three more kinds in bulkElem: a call inside that switch cost the stream preparation 3-5 % of the headline round (measured, profiles/r03f).
 #ifndef ASCHED_NO_FT
 DEV void ftBuild(Dev& d) {
+#ifdef ASCHED_HOSTSIM
+  { static long builds = 0; static const bool st = getenv("HS_FT_STATS") != nullptr; if (st && (++builds % 100) == 1) fprintf(stderr, "ftBuild %ld (queries %d retries %d node updates %d)\n", builds, d.rs->statFt[0], d.rs->statFt[1], d.rs->statFt[2]); }
+#endif
   wgFtBuild(d, 0, d.cfg.N * ((d.ftS + FT_CHUNK - 1) / FT_CHUNK));
   wgFtBuild(d, 1, d.ftS * d.ftNB1);
   wgFtBuild(d, 2, d.ftS * 64);
   d.rs->ftValid = 1;
+#ifdef ASCHED_FT_COUNT_BUILDS
+  d.rs->statFt[1] += 1000;   // (experiment builds: table builds show in ft_retries as thousands)
+#endif
 }
 #endif
 DEV_COLD void ensureFairIndex(Dev& d) {

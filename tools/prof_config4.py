@@ -23,7 +23,7 @@ for i in range(1 if full else 2):
     W.prepare(s, wl)
     t = time.perf_counter(); r = s.schedule_round(); dt = time.perf_counter() - t
     st = s.round_stats()
-    print("round", i, round(dt * 1e3, 1), "ms", {k: st[k] for k in ("fast_iterations", "generic_iterations", "kclk_pass1", "kclk_pass2", "kclk_plane_scans", "kclk_fair_selects", "stream_runs", "stream_jobs", "window_refills", "preempt_fast_iterations", "kclk_replay", "fast_replay_steps")}, len(r.scheduled), len(r.preempted), flush=True)
+    print("round", i, round(dt * 1e3, 1), "ms", {k: st[k] for k in ("fast_iterations", "generic_iterations", "kclk_pass1", "kclk_pass2", "kclk_plane_scans", "kclk_fair_selects", "ft_queries", "ft_retries", "ft_node_updates", "stream_runs", "stream_jobs", "window_refills", "preempt_fast_iterations", "kclk_replay", "fast_replay_steps")}, len(r.scheduled), len(r.preempted), flush=True)
 
 import ctypes
 if hasattr(lib.lib, "asched_debug_help_trace"):   # tools/build_variant.sh trace -DHELP_TRACE: the timeline of the fused wide pass (wall clock, 10 ns units)
