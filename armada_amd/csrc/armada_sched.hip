@@ -949,7 +949,7 @@ __device__ static inline void pqHeadKey(PQState& s, int t, PackedKey* key, uint3
 __device__ static inline void engineStart(Dev& d, FastS& S) {
   (void)d;
   S.engSeq = 0;
-  if ((threadIdx.x & 63) == 0) { g_fl.eng.seq = 0; g_fl.eng.ack = 0; g_fl.eng.statScan = 0; g_fl.eng.statL0Max = S.statL0Max; g_fl.eng.busyClk = 0; g_fl.eng.jobs = 0; g_fl.eng.cancel = 0; g_fl.eng.bindQuit = 0; g_fl.eng.bindGen = 0; g_fl.eng.bindFin = 0; g_mb.op = OP_ENGINE; }
+  if ((threadIdx.x & 63) == 0) { g_fl.eng.seq = 0; g_fl.eng.ack = 0; g_fl.eng.statScan = 0; g_fl.eng.statL0Max = S.statL0Max; g_fl.eng.busyClk = 0; g_fl.eng.jobs = 0; g_fl.eng.cancel = 0; g_fl.eng.bindQuit = 0; g_fl.eng.bindGen = 0; g_fl.eng.bindFin = 0; g_fl.eng.live = 1; g_mb.op = OP_ENGINE; }
   __syncthreads();
 }
 __device__ static inline void engineStop(Dev& d, FastS& S) {
@@ -960,6 +960,8 @@ __device__ static inline void engineStop(Dev& d, FastS& S) {
   S.engSeq++;
   if (lane == 0) __hip_atomic_store(&g_fl.eng.seq, S.engSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   (void)engineWait(S);
+  if (lane == 0) g_fl.eng.live = 0;
+  LANE0_PUBLISHED();
   S.statScanSteps += __builtin_amdgcn_readfirstlane(g_fl.eng.statScan);
   int m = __builtin_amdgcn_readfirstlane(g_fl.eng.statL0Max);
   if (m > S.statL0Max) S.statL0Max = m;

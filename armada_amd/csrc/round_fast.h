@@ -65,7 +65,8 @@ struct alignas(16) EngineBox {
   int64_t busyClk; int32_t jobs, cancel;     // shader-clock ticks the engine spent serving jobs, and how many; cancel: the engine saw the caller's cancel word
   int32_t ringPub, ringAck, ringEnd, ringFail;   // stream run: entries staged in the ring / placed by the engine; no more entries will come; 1 = entry ringAck found no node, 2 = placed but L0 overflowed
   int32_t bindHold;   // 1: the bind wave waits for the verdict on the whole ring (a gang: all members or none), 2: go, 3: discard
-  int32_t ringClosed, bindGen, bindDone, bindFin, bindQuit;   // the engine has left the ring; stream generation / entries whose bind + result fields the bind wave has issued / generation it has finished
+  int32_t ringClosed, bindGen, bindDone, bindFin, bindQuit, live;   // live: the node engine runs (engineStart .. engineStop) — what coldS tells the out-of-line helpers
+  //   // the engine has left the ring; stream generation / entries whose bind + result fields the bind wave has issued / generation it has finished
 };
 // stream run: the job-record windows are idle and serve as the ring between the control wave and the node engine
 #define RING_N (QCAPF * WIN)
@@ -1273,7 +1274,11 @@ DEV void coldS(Dev& d, FastS& S) {
    S.laneL = 0; S.laneX = 0; S.numEvictedJobs = 0; S.loopIterations = 0; S.statRefills = 0; S.statScanSteps = 0; S.statL0Max = 0;
   S.numUnfeasible = RS.numUnfeasible; S.numPreemptedMarks = RS.numPreemptedMarks; S.fastActive = RS.fastActive; S.lvl0NonNeg = RS.lvl0NonNeg; S.replayPending = RS.replayPending;
   S.globalTokens = 0; S.globalBurst = 0; S.globalRateInf = 1; S.numScheduledJobs = S.numScheduledGangs = S.numNodeQueries = S.evictedTableSize = 0; S.statFastIters = S.statFastReplay = 0; S.segT = 0;
-  S.engLive = 0; S.engPend = -1;   // (every caller of a cold helper has the node engine stopped: fastAdvance's bulk skip asks)
+  // fastAdvance asks before it skips a long stretch of known-unfeasible keys with the bulk passes: they need every wave of the workgroup at the mailbox, and a live
+  // engine wave never gets there.  Until round 5 this said 0 — "every caller of a cold helper has the engine stopped" — which is not true of the end of a stream run, of a
+  // gang through the ring or of the run's events: a queue with >= SKIP_BULK_MIN (2 048) such jobs behind its stream hung the round kernel on the device (tests/soak.py
+  // rounds, seed 100036: one queue, 4 489 jobs, 97 empty nodes; the CPU build runs the passes serially and cannot hang).  profiles/r05y_bulk_skip_hang.txt
+  S.engLive = UNI32(FL.eng.live); S.engPend = -1;
 }
 DEV_NOINLINE SkipDelta fastEnterSkip(Dev& d, FastCtx fc, int Q) {
   const FastK k = fastKRef(d);
@@ -2001,6 +2006,8 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
   const FastK k = fastKRef(d);
   FastS S; HS_POISON(S);
    S.engLive = 0; S.engPend = -1; S.engWaitClk = 0; S.engSeq = 0; S.inlineStreak = 0;
+  if (FLANE == 0) FL.eng.live = 0;
+  LANE0_PUBLISHED();
   S.laneL = FLANE / (d.cfg.R > 0 ? d.cfg.R : 1); S.laneX = FLANE % (d.cfg.R > 0 ? d.cfg.R : 1);
   // the scheduling-context scalars this loop keeps in registers
 #define FAST_SCALARS_IN() \

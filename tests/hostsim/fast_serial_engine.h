@@ -1,8 +1,8 @@
 // The node engine of the serial build (tests/hostsim; see fast_serial.h): TEST INFRASTRUCTURE, included by round_fast.h only under ASCHED_HOSTSIM.
 // serial build: the engine runs at post time; the control code still proceeds on the assumption that the job fits and takes the
 // iteration back at the next settle point when it did not — the same control flow as on the device
-DEV void engineStart(Dev&, FastS& S) { g_engS = S; g_engS.statScanSteps = 0; g_engS.engSeq = 0; FL.eng.cancel = 0; }
-DEV void engineStop(Dev&, FastS& S) { S.statScanSteps += g_engS.statScanSteps; if (g_engS.statL0Max > S.statL0Max) S.statL0Max = g_engS.statL0Max; }
+DEV void engineStart(Dev&, FastS& S) { g_engS = S; g_engS.statScanSteps = 0; g_engS.engSeq = 0; FL.eng.cancel = 0; FL.eng.live = 1; }
+DEV void engineStop(Dev&, FastS& S) { FL.eng.live = 0; S.statScanSteps += g_engS.statScanSteps; if (g_engS.statL0Max > S.statL0Max) S.statL0Max = g_engS.statL0Max; }
 DEV void enginePost(Dev& d, KREF k, FastS& S, int job, int q, int pc, int32_t prio, int32_t cutoff, int nl) {
   IterBackup& b = FL.bk;
   b.hot = FL.hot[q];

@@ -48,7 +48,9 @@ def main():
     orc, hs = libs()
     import scenario
     bad, refused, t0 = 0, 0, time.time()
-    for seed in range(100_000, 100_000 + n):
+    first = int(os.environ.get("SOAK_FIRST", "0"))   # SOAK_FIRST=k: start at seed 100000 + k; SOAK_PROGRESS=1: print every seed before it runs (a hang names its seed)
+    for seed in range(100_000 + first, 100_000 + n):
+        if os.environ.get("SOAK_PROGRESS"): print("seed", seed, flush=True)
         try:
             if kind == "rounds":
                 rng = np.random.default_rng(seed)

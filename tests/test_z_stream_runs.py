@@ -164,3 +164,23 @@ def test_deferred_replay_runs_after_a_gate_that_passed(hostsim_lib, oracle_lib, 
     changes the round: found by the stream soak with a run started wherever one can start."""
     monkeypatch.setenv("HS_STREAM_EAGER", "1")
     both(hostsim_lib, oracle_lib, _soak_stream_workload(seed))
+
+
+def _long_unfeasible_tail_workload():
+    """tests/soak.py `rounds` seed 100036: ONE queue of 4 489 jobs on 97 empty nodes.  The nodes fill after ~345 jobs, the failing scheduling keys are registered as
+    unfeasible, and a stream run then ends in front of more than SKIP_BULK_MIN (2 048) jobs that Peek skips with a record each (queue_scheduler.go:398-413)."""
+    return _soak_round_workload(100036)
+
+
+def test_long_unfeasible_tail_behind_a_stream_run(hostsim_lib, oracle_lib):
+    r, st = both(hostsim_lib, oracle_lib, _long_unfeasible_tail_workload())
+    assert st["stream_runs"] > 0 and len(r.scheduled) > 300
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(120)
+def test_long_unfeasible_tail_behind_a_stream_run_gpu(hip_lib, oracle_lib):
+    """On the device the skip of that many jobs is two bulk passes that need every wave of the control workgroup — the engine wave must not be live (round 5: coldS said
+    it never was, and this round hung the kernel; profiles/r05y_bulk_skip_hang.txt)."""
+    r, st = both(hip_lib, oracle_lib, _long_unfeasible_tail_workload())
+    assert st["stream_runs"] > 0 and len(r.scheduled) > 300
