@@ -1442,67 +1442,95 @@ enum { PK_haveLast, PK_lastQ, PK_emitted, PK_emittedQ, PK_acc, PK_stageBase, PK_
        PK_replace, PK_relane, PK_koValid, PK_koA, PK_koX, PK_koY, PK_COUNT };
 #define PK_LANE_WORDS 12
 #define PK_BASE(d) ((d).qsPart)
-#define PKW(d) ((volatile unsigned long long*)PK_BASE(d) + 64 * PK_LANE_WORDS)
 #define PK_INTS(X) X(haveLast) X(lastQ) X(emitted) X(emittedQ) X(acc) X(stageBase) X(stageCnt) X(issuedTo) X(fail) X(allowed) X(engSeq) X(sessLive) X(emittedPrev) X(doneQmid) \
                    X(maxMid) X(gangJobs) X(gangs) X(refills) X(evicted) X(pend) X(dropped) X(go) X(ev) X(evT) X(evSLen)
 #define NEST_INTS(X) X(emitted) X(emittedQ) X(acc) X(fail) X(allowed) X(engSeq) X(sessLive) X(emittedPrev) X(doneQmid) X(maxMid) X(gangJobs) X(gangs) X(refills) X(evicted) X(pend) X(dropped) X(go)
+// The uniform scalars are word i of one 64-word vector (lane i owns word i: one coalesced store / load, fields read back with v_readlane); the lane-private words are stored
+// word-major (word w of lane l at [w * 64 + l]).  Plain loads and stores, ordered for the compiler by workgroup-scope fences: the wave reads back its own stores through its
+// own CU's L1.  (The first version used volatile accesses — system-scope on gfx950, each batch a round trip to memory: configs[3], 20 000 events per round, lost 9 %.)
 #ifdef ASCHED_HOSTSIM
 static thread_local RunState hsParkedRun;   // (the serial build's lane state is arrays inside the struct)
+static thread_local unsigned long long hsParkedWords[64];
+#define PK_WORDS_LOAD(d) 0ull
+#define PK_I(w, i) ((int)(unsigned)hsParkedWords[i])
+#define PK_L(w, i) (hsParkedWords[i])
+#define PK_PUT(w, i, v) (hsParkedWords[i] = (unsigned long long)(v))
+#define PK_WORDS_STORE(d, w, mask) do { (void)(w); } while (0)
+#else
+#define PK_WORDS_LOAD(d) pkWordsLoad(d)
+#define PK_I(w, i) ((int)__builtin_amdgcn_readlane((int)(unsigned)(w), (i)))
+#define PK_L(w, i) slGet64((w), (i))
+#define PK_PUT(w, i, v) ((w) = (int)(threadIdx.x & 63) == (i) ? (unsigned long long)(v) : (w))
+#define PK_WORDS_STORE(d, w, mask) pkWordsStore(d, w, mask)
+__device__ static inline unsigned long long pkWordsLoad(Dev& d) {
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return ((const unsigned long long*)PK_BASE(d))[64 * PK_LANE_WORDS + (threadIdx.x & 63)];
+}
+__device__ static inline void pkWordsStore(Dev& d, unsigned long long w, unsigned long long mask) {   // lanes in `mask` store their word
+  if ((mask >> (threadIdx.x & 63)) & 1) ((unsigned long long*)PK_BASE(d))[64 * PK_LANE_WORDS + (threadIdx.x & 63)] = w;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
 #endif
+#define PK_BIT(f) (1ull << PK_##f)
 DEV void runPark(Dev& d, const RunState& m) {
-  volatile unsigned long long* u = PKW(d);
-  if (FLANE == 0) {
-#define X(f) u[PK_##f] = (unsigned long long)(unsigned)m.f;
-    PK_INTS(X)
+  unsigned long long w = 0, mask = 0;
+#define X(f) PK_PUT(w, PK_##f, (unsigned)m.f); mask |= PK_BIT(f);
+  PK_INTS(X)
 #undef X
-    u[PK_lastA] = m.lastK.A; u[PK_lastX] = m.lastK.X; u[PK_lastY] = m.lastK.Y; u[PK_lastN] = m.lastN;
-  }
+  PK_PUT(w, PK_lastA, m.lastK.A); PK_PUT(w, PK_lastX, m.lastK.X); PK_PUT(w, PK_lastY, m.lastK.Y); PK_PUT(w, PK_lastN, m.lastN);
+  mask |= PK_BIT(lastA) | PK_BIT(lastX) | PK_BIT(lastY) | PK_BIT(lastN);
 #ifdef ASCHED_HOSTSIM
   hsParkedRun = m;
 #else
-  volatile unsigned long long* sv = (volatile unsigned long long*)PK_BASE(d) + (size_t)FLANE * PK_LANE_WORDS;
-  sv[0] = m.pq.X; sv[1] = m.pq.Y; sv[2] = ((unsigned long long)m.pq.A << 32) | m.pq.N; sv[3] = ((unsigned long long)(unsigned)m.pq.q << 32) | (unsigned)m.pq.count;
-  sv[4] = ((unsigned long long)(unsigned)m.sl.start << 32) | (unsigned)m.sl.base; sv[5] = ((unsigned long long)(unsigned)m.sl.pos << 32) | (unsigned)m.sl.len;
-  sv[6] = ((unsigned long long)(unsigned)m.sl.kind << 32) | (unsigned)m.sl.ws; sv[7] = __builtin_bit_cast(unsigned long long, m.sl.budget);
-  sv[8] = m.sl.effX; sv[9] = m.sl.effY; sv[10] = m.sl.effA; sv[11] = m.stageV;
+  unsigned long long* sv = (unsigned long long*)PK_BASE(d) + (threadIdx.x & 63);
+  sv[0 * 64] = m.pq.X; sv[1 * 64] = m.pq.Y; sv[2 * 64] = ((unsigned long long)m.pq.A << 32) | m.pq.N; sv[3 * 64] = ((unsigned long long)(unsigned)m.pq.q << 32) | (unsigned)m.pq.count;
+  sv[4 * 64] = ((unsigned long long)(unsigned)m.sl.start << 32) | (unsigned)m.sl.base; sv[5 * 64] = ((unsigned long long)(unsigned)m.sl.pos << 32) | (unsigned)m.sl.len;
+  sv[6 * 64] = ((unsigned long long)(unsigned)m.sl.kind << 32) | (unsigned)m.sl.ws; sv[7 * 64] = __builtin_bit_cast(unsigned long long, m.sl.budget);
+  sv[8 * 64] = m.sl.effX; sv[9 * 64] = m.sl.effY; sv[10 * 64] = m.sl.effA; sv[11 * 64] = m.stageV;
 #endif
-  LANE0_PUBLISHED();
+  PK_WORDS_STORE(d, w, mask);
 }
 DEV void runUnpark(Dev& d, RunState& m) {
+  const unsigned long long w = PK_WORDS_LOAD(d);
 #ifdef ASCHED_HOSTSIM
   m = hsParkedRun;
 #else
-  volatile unsigned long long* sv = (volatile unsigned long long*)PK_BASE(d) + (size_t)FLANE * PK_LANE_WORDS;
-  unsigned long long w2 = sv[2], w3 = sv[3], w4 = sv[4], w5 = sv[5], w6 = sv[6];
-  m.pq.X = sv[0]; m.pq.Y = sv[1]; m.pq.A = (uint32_t)(w2 >> 32); m.pq.N = (uint32_t)w2; m.pq.q = (int)(w3 >> 32); m.pq.count = (int)(uint32_t)w3;
+  const unsigned long long* sv = (const unsigned long long*)PK_BASE(d) + (threadIdx.x & 63);
+  unsigned long long w2 = sv[2 * 64], w3 = sv[3 * 64], w4 = sv[4 * 64], w5 = sv[5 * 64], w6 = sv[6 * 64];
+  m.pq.X = sv[0 * 64]; m.pq.Y = sv[1 * 64]; m.pq.A = (uint32_t)(w2 >> 32); m.pq.N = (uint32_t)w2; m.pq.q = (int)(w3 >> 32); m.pq.count = (int)(uint32_t)w3;
   m.sl.start = (int)(w4 >> 32); m.sl.base = (int)(uint32_t)w4; m.sl.pos = (int)(w5 >> 32); m.sl.len = (int)(uint32_t)w5;
-  m.sl.kind = (int)(w6 >> 32); m.sl.ws = (int)(uint32_t)w6; m.sl.budget = __builtin_bit_cast(double, (unsigned long long)sv[7]);
-  m.sl.effX = sv[8]; m.sl.effY = sv[9]; m.sl.effA = (uint32_t)sv[10]; m.stageV = sv[11];
+  m.sl.kind = (int)(w6 >> 32); m.sl.ws = (int)(uint32_t)w6; m.sl.budget = __builtin_bit_cast(double, sv[7 * 64]);
+  m.sl.effX = sv[8 * 64]; m.sl.effY = sv[9 * 64]; m.sl.effA = (uint32_t)sv[10 * 64]; m.stageV = sv[11 * 64];
 #endif
-  volatile unsigned long long* u = PKW(d);
-#define X(f) m.f = UNI32((int)(unsigned)u[PK_##f]);
+#define X(f) m.f = PK_I(w, PK_##f);
   PK_INTS(X)
 #undef X
-  m.lastK.A = UNI32((uint32_t)u[PK_lastA]); m.lastK.X = UNI64(u[PK_lastX]); m.lastK.Y = UNI64(u[PK_lastY]); m.lastN = UNI32((uint32_t)u[PK_lastN]);
+  m.lastK.A = (uint32_t)PK_I(w, PK_lastA); m.lastK.X = PK_L(w, PK_lastX); m.lastK.Y = PK_L(w, PK_lastY); m.lastN = (uint32_t)PK_I(w, PK_lastN);
+}
+// what the event asked for (read by the resumed run)
+struct NestAsk { int replace, relane, koValid; uint32_t koA; uint64_t koX, koY; };
+DEV NestAsk nestAsked(Dev& d) {
+  const unsigned long long w = PK_WORDS_LOAD(d);
+  NestAsk a; a.replace = PK_I(w, PK_replace); a.relane = PK_I(w, PK_relane); a.koValid = PK_I(w, PK_koValid); a.koA = (uint32_t)PK_I(w, PK_koA); a.koX = PK_L(w, PK_koX); a.koY = PK_L(w, PK_koY);
+  return a;
 }
 DEV NestIO nestLoad(Dev& d) {
-  volatile unsigned long long* u = PKW(d);
+  const unsigned long long w = PK_WORDS_LOAD(d);
   NestIO st;
-#define X(f) st.f = UNI32((int)(unsigned)u[PK_##f]);
+#define X(f) st.f = PK_I(w, PK_##f);
   NEST_INTS(X)
 #undef X
   st.replace = st.relane = st.koValid = 0; st.koA = 0; st.koX = st.koY = 0;
   return st;
 }
 DEV void nestStore(Dev& d, const NestIO& st) {
-  volatile unsigned long long* u = PKW(d);
-  if (FLANE == 0) {
-#define X(f) u[PK_##f] = (unsigned long long)(unsigned)st.f;
-    NEST_INTS(X)
+  unsigned long long w = 0, mask = 0;
+#define X(f) PK_PUT(w, PK_##f, (unsigned)st.f); mask |= PK_BIT(f);
+  NEST_INTS(X)
 #undef X
-    u[PK_replace] = (unsigned)st.replace; u[PK_relane] = (unsigned)st.relane; u[PK_koValid] = (unsigned)st.koValid; u[PK_koA] = st.koA; u[PK_koX] = st.koX; u[PK_koY] = st.koY;
-  }
-  LANE0_PUBLISHED();
+  PK_PUT(w, PK_replace, (unsigned)st.replace); PK_PUT(w, PK_relane, (unsigned)st.relane); PK_PUT(w, PK_koValid, (unsigned)st.koValid); PK_PUT(w, PK_koA, st.koA); PK_PUT(w, PK_koX, st.koX); PK_PUT(w, PK_koY, st.koY);
+  mask |= PK_BIT(replace) | PK_BIT(relane) | PK_BIT(koValid) | PK_BIT(koA) | PK_BIT(koX) | PK_BIT(koY);
+  PK_WORDS_STORE(d, w, mask);
 }
 DEV_NOINLINE void streamNestSettle(Dev& d, FastCtx fc, int t);
 DEV NestIO streamNestSettleBody(Dev& d, FastCtx fc, NestIO st, int t);
@@ -1568,11 +1596,11 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
   } else {
     // the event the run was parked at has run (streamNestSettle / streamNestGang, called by the main loop): the heap / lane updates it asks for, then on with the merge
     runUnpark(d, m);
-    volatile unsigned long long* u = PKW(d);
-    const int t = m.evT, replace = UNI32((int)(unsigned)u[PK_replace]), relane = UNI32((int)(unsigned)u[PK_relane]);
+    const NestAsk ask = nestAsked(d);
+    const int t = m.evT, replace = ask.replace, relane = ask.relane;
     if (m.emitted == 0) m.issuedTo = 0;   // (a new ring session)
     if (replace) {
-      KeyOut nk; nk.valid = UNI32((int)(unsigned)u[PK_koValid]); nk.A = UNI32((uint32_t)u[PK_koA]); nk.X = UNI64(u[PK_koX]); nk.Y = UNI64(u[PK_koY]);
+      KeyOut nk; nk.valid = ask.koValid; nk.A = ask.koA; nk.X = ask.koX; nk.Y = ask.koY;
       pqPopPush(m.pq, nk, t);
     }
     if (relane) {

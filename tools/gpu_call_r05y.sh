@@ -1,4 +1,7 @@
-OUT=gpurun_out/r05y29; mkdir -p $OUT
-timeout 400 python -m pytest tests -q -m gpu -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -n 3 $OUT/pytest_gpu.log
-SOAK_LIB=hip SOAK_PROGRESS=1 timeout 100 python tests/soak.py rounds 2000 > $OUT/rounds_progress.txt 2>&1; echo "rounds rc=$? (124 = the time limit, not a hang, when the last seed is far beyond 100036)"; grep -v "^seed [0-9]*$" $OUT/rounds_progress.txt | grep -v amdgpu | tail -n 3; tail -n 1 $OUT/rounds_progress.txt
-SOAK_LIB=hip timeout 80 python tests/soak.py streams 400 2>&1 | tail -n 1 | tee $OUT/streams.txt
+OUT=gpurun_out/r05z5; mkdir -p $OUT
+timeout 100 python -m pytest tests -q -m gpu -k "stream or gang or nest or unfeasible" -p no:cacheprovider 2>&1 | tail -n 2 | tee $OUT/pytest_subset.txt
+for L in prev new; do
+  P=$PWD/armada_amd/csrc/libarmada_sched_$L.so; [ $L = new ] && P=$PWD/armada_amd/csrc/libarmada_sched.so
+  echo "== $L gangsfull" | tee -a $OUT/ab.txt
+  ASCHED_LIB_PATH=$P timeout 60 python tools/prof_config4.py gangsfull 2>&1 | grep "^round" | tail -n 1 | cut -c1-120 | tee -a $OUT/ab.txt
+done
