@@ -428,7 +428,8 @@ DEV_COLD void wideBulkAny(Dev& d, int kind, int i) {
 }
 
 #ifdef ASCHED_HOSTSIM
-DEV void wgWide(Dev& d, int kind, int n) { for (int i = 0; i < n; i++) wideBulkAny(d, kind, i); }
+void hsEngineMustBeStopped(const char* what);   // tests/hostsim/hostsim.cpp: a wide op posted with the node engine live would hang the device
+DEV void wgWide(Dev& d, int kind, int n) { hsEngineMustBeStopped("wgWide"); for (int i = 0; i < n; i++) wideBulkAny(d, kind, i); }
 #else
 DEV void wgWide(Dev& d, int kind, int n);   // armada_sched.hip: the pass on the control workgroup and the helper workgroups (OP_WIDE)
 #endif

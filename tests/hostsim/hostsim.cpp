@@ -31,7 +31,9 @@ DEV void atomicAddI32(int32_t* p, int32_t v) { *p += v; }
 DEV void atomicOrI32(int32_t* p, int32_t v) { *p |= v; }
 DEV void atomicMinU32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
 DEV int atomicFetchAddI32(int32_t* p, int32_t v) { int o = *p; *p += v; return o; }
+void hsEngineMustBeStopped(const char* what);
 DEV int wgFairSelect(Dev& d, const FairArgs& a) {
+  hsEngineMustBeStopped("wgFairSelect");
   HsScope prof(39);
   int best = -1;
   static long calls = 0, maxSeg = 0, sumMax = 0;
@@ -41,7 +43,13 @@ DEV int wgFairSelect(Dev& d, const FairArgs& a) {
   return best;
 }
 
+// On the device every wide op needs all waves of the control workgroup at the mailbox: one posted while the node engine wave sits in its serve loop never completes
+// (round 5: the bulk skip of unfeasible keys at the end of a stream run, profiles/r05y_bulk_skip_hang.txt).  The serial build cannot hang — it can say so.
+void hsEngineMustBeStopped(const char* what) {
+  if (g_fl.eng.live == 1) { fprintf(stderr, "hostsim: %s posted while the node engine is live: the device would hang here\n", what); abort(); }
+}
 DEV uint64_t wgFirstFitKey(Dev& d, const ScanArgs& a) {
+  hsEngineMustBeStopped("wgFirstFitKey");
   HsScope prof(38);
   const DevCfg& c = d.cfg;
   uint64_t best = ~0ull;
@@ -70,9 +78,9 @@ DEV int wgFirstFit(Dev& d, const ScanArgs& a) {
   return d.nodeByRank[best & ((1ull << d.cfg.idxBits) - 1)];
 }
 DEV int wgScanFair(Dev& d, const ScanArgs& a, const FairArgs& f, uint64_t* bestKey) { *bestKey = wgFirstFitKey(d, a); return wgFairSelect(d, f); }
-DEV void wgBulk(Dev& d, int kind, int n) { HsScope prof(kind); for (int i = 0; i < n; i++) bulkElem(d, kind, i); }
+DEV void wgBulk(Dev& d, int kind, int n) { hsEngineMustBeStopped("wgBulk"); HsScope prof(kind); for (int i = 0; i < n; i++) bulkElem(d, kind, i); }
 DEV void wgBulkWide(Dev& d, int kind, int n) { wgBulk(d, kind, n); }
-DEV void wgFtBuild(Dev& d, int phase, int n) { for (int i = 0; i < n; i++) ftBuildAny(d, phase, i); }
+DEV void wgFtBuild(Dev& d, int phase, int n) { hsEngineMustBeStopped("wgFtBuild"); for (int i = 0; i < n; i++) ftBuildAny(d, phase, i); }
 DEV int wgCompactFlagged(Dev& d, const int32_t* order, const int32_t* segOff, int nseg, int n, const uint8_t* flag, int32_t* dst, int32_t* outSegOff) {
   int cnt = 0, q = 0;
   for (int p = 0; p <= n; p++) {
