@@ -182,7 +182,10 @@ template <class T> __device__ static inline T uniT64(T v) { return (T)uni64((uns
 #define ESEG(i) do {} while (0)
 #define FSEG(i) do {} while (0)
 #endif
-#if defined(ASCHED_HOSTSIM) || !defined(__HIP_DEVICE_COMPILE__)
+#if defined(ASCHED_HOSTSIM)
+void hsRingIdle();   // tests/hostsim/fast_serial.h: the serial engine makes progress while the control code waits (HS_RING_LAG)
+#define STREAM_IDLE() hsRingIdle()
+#elif !defined(__HIP_DEVICE_COMPILE__)
 #define STREAM_IDLE() do {} while (0)
 #else
 #define STREAM_IDLE() __builtin_amdgcn_s_sleep(2)

@@ -209,7 +209,8 @@ struct StreamLanes { int start[QCAPF], base[QCAPF], pos[QCAPF], len[QCAPF], kind
 DEV void qsWinRefill(KREF k, int q, int pos, int cnt) { for (int i = 0; i < cnt; i++) memcpy(&FL.evWin[q][i], (const char*)k.qsKey + ((size_t)q * QS_CMAX + pos + i) * sizeof(EvKey), sizeof(EvKey)); }
 DEV int engineServe(Dev& d, KREF k, FastS& ES);
 static FastS g_engS;
-DEV void streamBegin(int* engSeq, int hold = 0) { FL.eng.ringPub = FL.eng.ringAck = FL.eng.ringEnd = FL.eng.ringFail = 0; FL.eng.bindHold = hold; FL.eng.cmd = ENG_STREAM; (*engSeq)++; }
+static void hsLagRead();
+DEV void streamBegin(int* engSeq, int hold = 0) { hsLagRead(); FL.eng.ringPub = FL.eng.ringAck = FL.eng.ringEnd = FL.eng.ringFail = 0; FL.eng.bindHold = hold; FL.eng.cmd = ENG_STREAM; (*engSeq)++; }
 DEV void bindJob(KREF k, FastS& ES, int n, int nl, uint64_t keyDelta, const int64_t* req, int job, int32_t prio, int32_t cutoff);
 DEV void streamRelease(Dev& d, KREF k, int go) {
   (void)d;
@@ -226,13 +227,32 @@ DEV void streamServeOne(Dev& d, KREF k, int i) {
   FL.eng.ringAck = i + 1;
   if (st == 2) FL.eng.ringFail = 2;
 }
+// HS_RING_LAG=<seed>: the serial engine does NOT serve an entry when it is staged but falls behind by a pseudo-random number of entries, as the device's engine wave does
+// (there the merge runs ahead by up to a ring's worth): entries are served a few at a time whenever the control code looks at the ring or idles, and all that are left when the
+// session ends.  Everything the control code does with entries that were emitted but not yet placed — accounting, the end of a run, a run's nested events, a member
+// without a node — then sees the interleavings the device produces, in the CPU soaks (tests/soak.py with HS_RING_LAG set).  Unset: every entry is served at once, as before.
+static Dev* g_hsRingDev = nullptr;
+static uint32_t g_hsLagState = 0;
+static int g_hsLagSeed = 0;   // read at every streamBegin: tests switch it per round (monkeypatch.setenv)
+static int hsLagSeed() { return g_hsLagSeed; }
+static void hsLagRead() { const char* e = getenv("HS_RING_LAG"); int v = e && *e ? atoi(e) + 1 : 0; if (v != g_hsLagSeed) { g_hsLagSeed = v; g_hsLagState = 0; } }
+static uint32_t hsLagRand() { if (!g_hsLagState) g_hsLagState = 0x9E3779B9u * (uint32_t)hsLagSeed() + 12345u; g_hsLagState = g_hsLagState * 1664525u + 1013904223u; return g_hsLagState >> 16; }
+DEV void hsRingServe(int count) {
+  if (!g_hsRingDev || !(FL.eng.ringAck < FL.eng.ringPub) || FL.eng.ringFail) return;   // (nothing pending: the pointer may be a previous launch's)
+  Dev& d = *g_hsRingDev;
+  const FastK k = fastKRef(d);
+  while (count-- > 0 && FL.eng.ringAck < FL.eng.ringPub && !FL.eng.ringFail) streamServeOne(d, k, FL.eng.ringAck);
+}
+void hsRingIdle() { if (hsLagSeed()) hsRingServe(1 + (int)(hsLagRand() % 3)); }   // STREAM_IDLE of the serial build: the engine makes progress while the control code waits
 DEV void streamStageCommit(Dev& d, KREF k, int base, int cnt, unsigned long long) {
   for (int i = 0; i < cnt; i++) if (!(RQ(base + i) & RQ_EV)) RREC(base + i) = g_hsStage[i];
   FL.eng.ringPub = base + cnt;
+  g_hsRingDev = &d;
+  if (hsLagSeed()) { uint32_t r = hsLagRand(); hsRingServe((r & 7) < 3 ? 0 : (int)((r >> 3) % 6)); return; }   // (often nothing: the backlog grows towards the ring's size)
   for (int i = base; i < base + cnt; i++) if (!FL.eng.ringFail) streamServeOne(d, k, i);
 }
-DEV void streamEnd(int) { FL.eng.ringEnd = 1; }
-DEV int streamAcked(int* fail) { *fail = FL.eng.ringFail; return FL.eng.ringAck; }
+DEV void streamEnd(int) { FL.eng.ringEnd = 1; if (hsLagSeed()) hsRingServe(1 << 30); }
+DEV int streamAcked(int* fail) { if (hsLagSeed() && (hsLagRand() & 3) == 0) hsRingServe(1); *fail = FL.eng.ringFail; return FL.eng.ringAck; }
 DEV int streamBound() { return FL.eng.ringAck; }
 DEV void streamAccount(Dev& d, KREF k, int i0, int i1) {
   for (int i = i0; i < i1; i++) {

@@ -15,6 +15,7 @@
     python tests/soak.py fit 600            # fit_select_batch at every priority on occupied NodeDbs
     python tests/soak.py excluded 1000      # NumExcludedNodesByReason (asched_excluded_nodes) of every failed selection of a round, incl. literal rows / away types / off-grid requests
 
+HS_RING_LAG=<seed> (CPU build): the serial node engine lags behind the merge by a pseudo-random number of ring entries, as on the device (tests/hostsim/fast_serial.h).
 SOAK_LIB=hip (on a GPU box): the same seeds through the product library instead of the CPU build.
 Prints one line per divergence and a summary; exit code 1 if anything diverged.  (Round 1: all clean after the submit-check fix.)
 """

@@ -184,3 +184,18 @@ def test_long_unfeasible_tail_behind_a_stream_run_gpu(hip_lib, oracle_lib):
     it never was, and this round hung the kernel; profiles/r05y_bulk_skip_hang.txt)."""
     r, st = both(hip_lib, oracle_lib, _long_unfeasible_tail_workload())
     assert st["stream_runs"] > 0 and len(r.scheduled) > 300
+
+
+@pytest.mark.parametrize("lag", [1, 2, 3])
+def test_stream_rounds_with_a_lagging_engine(hostsim_lib, oracle_lib, lag, monkeypatch):
+    """HS_RING_LAG (tests/hostsim/fast_serial.h): the serial node engine falls behind the merge by a pseudo-random number of ring entries, as the engine wave does on the
+    device, instead of serving every entry the moment it is staged — the end of a run, the nested events around gangs, a member without a node and the accounting then
+    meet entries that were emitted but not yet placed.  Same rounds as the oracle's, whatever the lag."""
+    monkeypatch.setenv("HS_RING_LAG", str(lag))
+    emitted = jobs = 0
+    for wl in (workload(900, occupied=0.2), workload(903, occupied=0.5, lookback=400),
+               workload(977, gangs=400, occupied=0.3, n_nodes=600, n_jobs=9000, n_queues=12),
+               _soak_round_workload(100345), _soak_round_workload(102465), _long_unfeasible_tail_workload()):
+        r, st = both(hostsim_lib, oracle_lib, wl)
+        emitted += st["stream_emitted"]; jobs += st["stream_jobs"]
+    assert jobs > 0 and emitted > jobs      # entries were emitted ahead of the engine and taken back
