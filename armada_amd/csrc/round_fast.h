@@ -184,6 +184,7 @@ template <class T> __device__ static inline T uniT64(T v) { return (T)uni64((uns
 #endif
 #if defined(ASCHED_HOSTSIM)
 void hsRingIdle();   // tests/hostsim/fast_serial.h: the serial engine makes progress while the control code waits (HS_RING_LAG)
+int hsBindLag();
 #define STREAM_IDLE() hsRingIdle()
 #elif !defined(__HIP_DEVICE_COMPILE__)
 #define STREAM_IDLE() do {} while (0)
@@ -940,7 +941,7 @@ DEV int engineServeAt(Dev& d, KREF k, FastS& ES, const JobTail& tailSrc, const i
   if (ringIdx >= 0) { if (FLANE == 0) RREC(ringIdx).node0 = n; LANE0_PUBLISHED(); }   // stream run: the bind wave issues the HBM side (bindJob) from the ring entry
   else
 #else
-  if (ringIdx >= 0 && FL.eng.bindHold) RREC(ringIdx).node0 = n;     // (serial build: binds at once unless they are held for a gang's verdict)
+  if (ringIdx >= 0 && (FL.eng.bindHold || hsBindLag())) RREC(ringIdx).node0 = n;     // (serial build: binds at once unless they are held for a gang's verdict — or HS_RING_LAG makes the bind side lag, fast_serial.h)
   else
 #endif
   bindJob(k, ES, n, nl, r.keyDelta, reqSrc, job, prio, cutoff);

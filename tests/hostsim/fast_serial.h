@@ -210,7 +210,7 @@ DEV void qsWinRefill(KREF k, int q, int pos, int cnt) { for (int i = 0; i < cnt;
 DEV int engineServe(Dev& d, KREF k, FastS& ES);
 static FastS g_engS;
 static void hsLagRead();
-DEV void streamBegin(int* engSeq, int hold = 0) { hsLagRead(); FL.eng.ringPub = FL.eng.ringAck = FL.eng.ringEnd = FL.eng.ringFail = 0; FL.eng.bindHold = hold; FL.eng.cmd = ENG_STREAM; (*engSeq)++; }
+DEV void streamBegin(int* engSeq, int hold = 0) { hsLagRead(); FL.eng.ringPub = FL.eng.ringAck = FL.eng.ringEnd = FL.eng.ringFail = 0; FL.eng.bindDone = 0; FL.eng.bindHold = hold; FL.eng.cmd = ENG_STREAM; (*engSeq)++; }
 DEV void bindJob(KREF k, FastS& ES, int n, int nl, uint64_t keyDelta, const int64_t* req, int job, int32_t prio, int32_t cutoff);
 DEV void streamRelease(Dev& d, KREF k, int go) {
   (void)d;
@@ -237,23 +237,37 @@ static int g_hsLagSeed = 0;   // read at every streamBegin: tests switch it per 
 static int hsLagSeed() { return g_hsLagSeed; }
 static void hsLagRead() { const char* e = getenv("HS_RING_LAG"); int v = e && *e ? atoi(e) + 1 : 0; if (v != g_hsLagSeed) { g_hsLagSeed = v; g_hsLagState = 0; } }
 static uint32_t hsLagRand() { if (!g_hsLagState) g_hsLagState = 0x9E3779B9u * (uint32_t)hsLagSeed() + 12345u; g_hsLagState = g_hsLagState * 1664525u + 1013904223u; return g_hsLagState >> 16; }
+// ... and the BIND side lags too (the device's bind wave issues the HBM side of a placed entry from its ring slot, later): in lag mode engineServeAt only records the node in
+// the ring entry (as on the device) and the binds are issued from the slots in order, a few at a time; streamBound() is what the bind side has read.  A ring slot overwritten too
+// early, or HBM state read before its bind, shows up as a wrong round.
+int hsBindLag() { return hsLagSeed() != 0; }
+DEV void hsBindSome(int count) {
+  if (!g_hsRingDev || FL.eng.bindHold || !(FL.eng.bindDone < FL.eng.ringAck)) return;
+  Dev& d = *g_hsRingDev;
+  const FastK k = fastKRef(d);
+  while (count-- > 0 && FL.eng.bindDone < FL.eng.ringAck) {
+    int i = FL.eng.bindDone;
+    if (!(RQ(i) & RQ_EV)) { const JobRec& r = RREC(i); bindJob(k, g_engS, r.node0, r.nlPc, r.keyDelta, r.req, RJOB(i), r.pcPrio, r.preemptible ? r.pcPrio : NONPREEMPTIBLE_CUTOFF); }
+    FL.eng.bindDone = i + 1;
+  }
+}
 DEV void hsRingServe(int count) {
   if (!g_hsRingDev || !(FL.eng.ringAck < FL.eng.ringPub) || FL.eng.ringFail) return;   // (nothing pending: the pointer may be a previous launch's)
   Dev& d = *g_hsRingDev;
   const FastK k = fastKRef(d);
   while (count-- > 0 && FL.eng.ringAck < FL.eng.ringPub && !FL.eng.ringFail) streamServeOne(d, k, FL.eng.ringAck);
 }
-void hsRingIdle() { if (hsLagSeed()) hsRingServe(1 + (int)(hsLagRand() % 3)); }   // STREAM_IDLE of the serial build: the engine makes progress while the control code waits
+void hsRingIdle() { if (hsLagSeed()) { hsRingServe(1 + (int)(hsLagRand() % 3)); hsBindSome(1 + (int)(hsLagRand() % 3)); } }   // STREAM_IDLE of the serial build: engine and bind side make progress while the control code waits
 DEV void streamStageCommit(Dev& d, KREF k, int base, int cnt, unsigned long long) {
   for (int i = 0; i < cnt; i++) if (!(RQ(base + i) & RQ_EV)) RREC(base + i) = g_hsStage[i];
   FL.eng.ringPub = base + cnt;
   g_hsRingDev = &d;
-  if (hsLagSeed()) { uint32_t r = hsLagRand(); hsRingServe((r & 7) < 3 ? 0 : (int)((r >> 3) % 6)); return; }   // (often nothing: the backlog grows towards the ring's size)
+  if (hsLagSeed()) { uint32_t r = hsLagRand(); hsRingServe((r & 7) < 3 ? 0 : (int)((r >> 3) % 6)); hsBindSome((int)((r >> 8) % 4)); return; }   // (often nothing: the backlog grows towards the ring's size)
   for (int i = base; i < base + cnt; i++) if (!FL.eng.ringFail) streamServeOne(d, k, i);
 }
-DEV void streamEnd(int) { FL.eng.ringEnd = 1; if (hsLagSeed()) hsRingServe(1 << 30); }
-DEV int streamAcked(int* fail) { if (hsLagSeed() && (hsLagRand() & 3) == 0) hsRingServe(1); *fail = FL.eng.ringFail; return FL.eng.ringAck; }
-DEV int streamBound() { return FL.eng.ringAck; }
+DEV void streamEnd(int) { FL.eng.ringEnd = 1; if (hsLagSeed()) { hsRingServe(1 << 30); hsBindSome(1 << 30); } }   // (the device waits for the engine's acknowledgement and for the bind wave's last bind)
+DEV int streamAcked(int* fail) { if (hsLagSeed() && (hsLagRand() & 3) == 0) { hsRingServe(1); hsBindSome((int)(hsLagRand() & 1)); } *fail = FL.eng.ringFail; return FL.eng.ringAck; }
+DEV int streamBound() { return hsLagSeed() && !FL.eng.bindHold ? FL.eng.bindDone : FL.eng.ringAck; }
 DEV void streamAccount(Dev& d, KREF k, int i0, int i1) {
   for (int i = i0; i < i1; i++) {
     int rq = RQ(i), q = rq & 0xff;
