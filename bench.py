@@ -486,10 +486,11 @@ def round_shape_record(hip, args, label, kwargs, steps, note, warmup=1):
     return rec, wl, res, iters
 
 
-def other_configs(hip, args, t_start):
+def other_configs(hip, args, t_start, sink=None):
     """BASELINE configs[1], [3], [4] and the submit check as sub-records of the driver-run line (each with roofline + cpu_baseline).  configs[3] runs at
-    the full 100k x 1M size on the GPU; the oracle legs (cpu_baseline + parity) run at the largest size whose oracle round fits the budget."""
-    recs = []
+    the full 100k x 1M size on the GPU; the oracle legs (cpu_baseline + parity) run at the largest size whose oracle round fits the budget.
+    `sink`: the list the records are appended to as they finish (the watchdog prints what is there if a later one never comes back)."""
+    recs = sink if sink is not None else []
 
     def guarded(name, fn):
         if time.perf_counter() - t_start > args.other_budget:
@@ -841,7 +842,7 @@ def compact_line(out):
     if rows:
         line["other_configs"] = rows
         line["other_configs_columns"] = ["config", "value", "unit", "x_oracle (reduced leg's where the oracle ran reduced; worst row of a table)", "roofline.frac", "parity.identical"]
-    for k in ("scaling_note", "full_record"):
+    for k in ("scaling_note", "full_record", "watchdog"):
         if k in out:
             line[k] = out[k]
     txt = json.dumps(line)
@@ -868,8 +869,36 @@ def emit(out):
     print(compact_line(out))
 
 
+_WATCHDOG = {"timer": None}
+
+
+def watchdog_arm(out, seconds):
+    """After `seconds` print the record as it stands (the headline + the sub-records finished so far, `watchdog` saying so) as the last stdout line and leave with exit code 5.
+    The host thread of a hung round kernel sits inside the C ABI call and cannot be interrupted; the process can still end."""
+    import threading
+    if seconds <= 0:
+        return
+
+    def fire():
+        snap = dict(out, other_configs=list(out.get("other_configs", [])), watchdog=f"a sub-record did not return within {seconds:.0f} s of the headline; the record was cut there")
+        emit(snap)
+        sys.stdout.flush()
+        os._exit(5)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    _WATCHDOG["timer"] = t
+
+
+def watchdog_disarm():
+    if _WATCHDOG["timer"] is not None:
+        _WATCHDOG["timer"].cancel()
+        _WATCHDOG["timer"] = None
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--watchdog", type=float, default=900.0, help="seconds after the headline within which the other_configs sub-records must have finished; then the record is printed as it stands (0 = off)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
@@ -1023,7 +1052,10 @@ def main():
         out["parity"] = {"checked": False, "reason": "no oracle leg at --cpu-budget 0 / N>1"}
     if world == 1 and not args.no_other:
         s.close()
-        out["other_configs"] = other_configs(hip, args, time.perf_counter())
+        out["other_configs"] = []
+        watchdog_arm(out, args.watchdog)   # from here on the headline exists: a sub-record that never returns (a hung kernel: profiles/r05y_bulk_skip_hang.txt) must not take it down
+        other_configs(hip, args, time.perf_counter(), sink=out["other_configs"])
+        watchdog_disarm()
         for r in out["other_configs"]:
             for p in (r.get("parity"), (r.get("reduced") or {}).get("parity")):
                 if p and p.get("checked") and not p.get("identical"):

@@ -127,3 +127,23 @@ def test_smoke_entry_point(fake_gpu, capsys):
     import __graft_entry__ as g
     g.smoke()
     assert "smoke ok" in capsys.readouterr().out
+
+
+def test_watchdog_prints_the_record_as_it_stands(fake_gpu, monkeypatch, capsys):
+    """a sub-record that never returns (a hung kernel) must not take the headline down: after --watchdog seconds the record is printed with what has finished"""
+    import time
+    bench = fake_gpu
+    exits = []
+    monkeypatch.setattr(os, "_exit", lambda code: exits.append(code))
+    out = {"metric": "scheduling rounds/sec", "value": 2.0, "unit": "rounds/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 500.0, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic", "config": {"workload": "toy"},
+           "roofline": {"bound": "hbm", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.000125, "traffic": None}, "cpu_baseline": {"value": 0.01, "unit": "rounds/s", "cores": 1, "kind": "port", "sample": "x"},
+           "other_configs": [{"config": "BASELINE configs[1]", "value": 1.0, "unit": "ms"}]}
+    bench.watchdog_arm(out, 0.05)
+    time.sleep(0.5)
+    bench.watchdog_disarm()
+    assert exits == [5]
+    lines = capsys.readouterr().out.strip().splitlines()
+    compact, full = json.loads(lines[-1]), json.loads(lines[-2])
+    assert "did not return" in compact["watchdog"] and compact["value"] == 2.0 and compact["other_configs"][0][0] == "BASELINE configs[1]"
+    assert full["other_configs"] == out["other_configs"] and "watchdog" in full
