@@ -1,5 +1,3 @@
-# round 5: the LAST of ~30 one-off GPU calls made while bisecting the nested-run issues (profiles/r05y_*.txt describe what each found); kept as the template of a short call
-OUT=gpurun_out/r05z6; mkdir -p $OUT
-timeout 30 python tools/dbg_nest.py 100345 102465 100036 2>&1 | grep "^10" | cut -c1-60 | tee $OUT/seeds.txt
-timeout 60 python bench.py --steps 5 --warmup 1 --cpu-budget 0 --no-other 2>/dev/null | tail -n 1 > $OUT/headline.json; python -c "
-import json; o = json.load(open('$OUT/headline.json')); print('headline', o['ms_per_step'], o['roofline']['kernel_avg_ms'], o['roofline']['kernel_isa_hash'])"
+# round 5: the LAST of ~35 short GPU calls made while bisecting the nested-run issues (profiles/r05y_*.txt describe what each found); kept as the template of a short call
+OUT=gpurun_out/r05z7; mkdir -p $OUT
+timeout 25 python -m pytest tests -q -m gpu -x -k "stream or gang or reused or handle" -p no:cacheprovider 2>&1 | tail -n 2 | tee $OUT/pytest_subset.txt
