@@ -85,7 +85,9 @@ struct EvKey { double proposed, current, size; int32_t pcPrio; int32_t job; };
 // nothing but the queue's own allocation prefix: the same costs, for the next QS_CMAX queued jobs of every queue, are computed ahead by a
 // chunked prefix pass (round_run.h B_QSSUM -> B_QSSTITCH -> B_QSKEYS) into EvKey records; the control wave then merely merges the
 // precomputed streams through its lane heap and stages job records for the node engine.
-#define QS_CMAX 4096          // stream entries per queue and preparation
+#ifndef QS_CMAX
+#define QS_CMAX 32768         // stream entries per queue and preparation (round 6: one preparation covers a queue's rate-limit burst, so that a bulk-merged run — round_merge.h — seldom ends because a stream ran out)
+#endif
 #define QS_CHUNK 64           // entries one bulk item covers
 #define QS_CPQ (QS_CMAX / QS_CHUNK)
 // a queue's stream as of the last hand-over to the generic code (fastQFlush): taken up again at the next fastQLoad if the generic code left the queue alone
@@ -216,6 +218,28 @@ struct WideDev {
   uint32_t* stop;      // [2] first position the merged order is NOT valid at (atomic min); number of stream entries
   WideParams* par;
 };
+
+// ---- bulk-merged stream runs (round_merge.h): the k-way heap merge of the <= QCAPF queues' precomputed streams computed as a BULK RANK on every workgroup (the wide runs' idea,
+// round_wide.h W_RANK, on the stream representation of round_fast.h); the control wave then only stages the merged order for the node engine.
+struct MgQ {   // one queue of the heap as the merge sees it, written by the control wave before the passes (HBM: the helper workgroups read it)
+  int32_t start, len, kind, base;      // stream elements [start, len) are still to come; kind bit 0: evicted stream (d.evKey[base + e]), else queued (d.qsKey[q][e]); bit 1: folded (skip mode)
+  int32_t flags, off, total, nameRank; // flags 1: stream, 2: barrier (a head the run cannot serve: ONE entry under its heap key), 4: open (the queue goes on behind its last element under a key not known here), 8: skip mode (keys must not decrease)
+  double budget; int64_t pad_;
+  WideKey eff, head;                   // skip mode: the running maximum the queue's keys start from; the heap key of a barrier head
+};
+struct MgEnt { int32_t job, qk, e, ci; };   // merged position -> job, queue | 1 << 30 for an evicted job, stream position, compact index (its key: MgDev.key[ci])
+struct MgDev {
+  MgQ* q;            // [QCAPF]
+  WideKey* key;      // [cap] running-maximum packed keys, compact: queue q's entries at q.off .. + q.total
+  int32_t* own;      // [cap] queue of a compact entry | 1 << 30 when its own key orders before the running maximum in front of it
+  int32_t* rank;     // [cap] position in the merged order
+  MgEnt* merged;     // [cap]
+  WideKey* cmax;     // [QCAPF * MG_CPQ] maximum of each chunk of a queue's keys
+  uint32_t* stop;    // [4] first merged position that is NOT valid (atomic min); total entries; scratch
+  int32_t cap, pad;
+};
+#define MG_CHUNK 64
+#define MG_CPQ (QS_CMAX / MG_CHUNK)
 
 struct Dev {
   DevCfg cfg;
@@ -354,6 +378,7 @@ struct Dev {
   int64_t* qAllocSnap;    // [Q][R] queue allocations right after an evictor ran: what addEvictedJobsToNodeDb starts from
   int64_t* jLeaseMs;      // [M] lease time of the active run in ms (run_timestamp / 1e6): job ages of the fairness optimiser
   int64_t* qNewJobNs;     // [Q] qctx.TotalNewJobSchedulingTime
+  MgDev* mg;              // bulk-merged stream runs (round_merge.h); NULL = off (ASCHED_MERGE=0, more than QCAPF queues)
   volatile int32_t* cancel;    // host-mapped word: != 0 = the caller's context is done (hard timeout / cancel, queue_scheduler.go:105-112); NULL = never
   volatile int32_t* progress;  // optional host-visible heartbeat (ASCHED_PROGRESS=1): [0] loop iterations, [1] phase, [2] current wide op, [3] wide ops issued
 #ifdef ASCHED_DEV_PAD

@@ -74,6 +74,9 @@ struct alignas(16) EngineBox {
 #define RJOB(i) (((int32_t*)FL.winJob)[(i) & (RING_N - 1)])
 #define RQ(i) (((int32_t*)FL.winIdx)[(i) & (RING_N - 1)])
 #define RQ_EV 0x100   // ring entry of an evicted stream: nothing for the engine to do
+#ifndef MG_MIN_ENTRIES_DEFAULT
+#define MG_MIN_ENTRIES_DEFAULT 2048   // (round_merge.h MG_MIN_ENTRIES)
+#endif
 static_assert((RING_N & (RING_N - 1)) == 0, "ring size");
 struct alignas(16) IterBackup {  // the job's record and request stay in the mailbox (the engine only reads them)
   QHot hot;
@@ -1399,7 +1402,7 @@ DEV_NOINLINE SkipDelta fastDrain(Dev& d, int Q) {
 //     accounting had been done for them — and the entry is its queue's head again).
 // Exactness: the merge is the heap of QueueCandidateGangIteratorPQ on the very keys fastAdvance would compute (same float64 operations on the same
 // prefix sums, round_run.h B_QSKEYS), the engine executes the entries in emission order, and integer accounting is order independent.
-struct StreamIn { double globalTokens; int64_t globalBurst; int32_t globalRateInf, engSeq; int32_t skip, haveLast; uint32_t lastA, lastN; uint64_t lastX, lastY; int32_t resume; };   // skip / last*: skip mode is on, key of the entry served last
+struct StreamIn { double globalTokens; int64_t globalBurst; int32_t globalRateInf, engSeq; int32_t skip, haveLast; uint32_t lastA, lastN; uint64_t lastX, lastY; int32_t resume; int32_t bulkV; };   // skip / last*: skip mode is on, key of the entry served last; bulkV > 0: the run's merged order has been computed by the bulk passes (round_merge.h), that many entries of it are valid
 struct StreamOut { int executed, executedEv, pend, dropped, engSeq, emitted, refills, evicted, maxConsumed, failed, lastQ; uint32_t lastA, lastN; uint64_t lastX, lastY;
                    int gangJobs, gangs;    // gangs placed INSIDE the run (round 5) and their members: the caller accounts them like fastGangRun's (ReserveN, one scheduled gang each)
                    int event, evT; };      // event != 0: the run is PARKED at one of its two rare events (streamNestSettle / streamNestGang on queue evT) — the caller runs it and calls again with in.resume
@@ -1541,6 +1544,8 @@ DEV NestIO streamNestSettleBody(Dev& d, FastCtx fc, NestIO st, int t);
 DEV NestIO streamNestGangBody(Dev& d, FastCtx fc, StreamIn in, NestIO st, int t);
 DEV_NOINLINE void streamNestGang(Dev& d, FastCtx fc, StreamIn in, int t);
 DEV RunState streamMerge(Dev& d, FastCtx fc, int Q, int skip, int nest, RunState m);
+DEV RunState streamStaged(Dev& d, FastCtx fc, int Q, int skip, int V, RunState m);   // the same for a run whose merged order exists already (round_merge.h)
+DEV_NOINLINE int mgPrepare(Dev& d, FastCtx fc, int Q, int skip);                    // round_merge.h
 // ---- (round 5) a run does not end where a queue's stream ends at a gang.  A queue's stream is cut at its next gang member (B_QSSUM), and until round 4 the run ended
 // the moment any queue used its stream up — on gang-heavy pools (BASELINE configs[3]) most single jobs therefore took the per-job iteration, whose queue side costs the
 // control wave 8.5 k ticks against ~4 k for a merged entry, while the node engine idled 58 % (profiles/r05j_gangs_segments.txt).  Now, when the element behind a used-up
@@ -1591,7 +1596,7 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
       SL_SET(sl, ws, q, -2 * WIN);
       SL_SET(sl, budget, q, f.budget);
       SL_SET(sl, effA, q, FL.effA[q]); SL_SET(sl, effX, q, FL.effX[q]); SL_SET(sl, effY, q, FL.effY[q]);
-      FL.tmpQ[q] = 0;
+      FL.tmpQ[q] = 0; FL.tmpA[q] = (uint32_t)f.sPos;   // (tmpA: a staged run's merge cursor per queue, streamStaged)
     }
     engSeq = in.engSeq;
     streamBegin(&engSeq);
@@ -1621,7 +1626,8 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
     go = m.go != 0;
   }
   if (go) {
-    m = streamMerge(d, fc, Q, skip, nest ? 1 : 0, m);
+    if (!UNI32(in.resume) && UNI32(in.bulkV) > 0) m = streamStaged(d, fc, Q, skip, UNI32(in.bulkV), m);
+    else m = streamMerge(d, fc, Q, skip, nest ? 1 : 0, m);
     if (m.ev != 0) {
       // an event: everything emitted so far is staged here (the gathered records in flight are lane-private), the run parks and the main loop runs the event
       if (m.stageBase >= 0) { streamStageCommit(d, k, m.stageBase, m.stageCnt, m.stageV); m.stageBase = -1; }
@@ -1791,6 +1797,61 @@ DEV RunState streamMerge(Dev& d, FastCtx fc, int Q, int skip, int nest, RunState
   m.pq = pq; m.sl = sl; m.lastK = lastK; m.lastN = lastN; m.haveLast = haveLast; m.lastQ = lastQ;
   m.emitted = emitted; m.emittedQ = emittedQ; m.acc = acc; m.stageBase = stageBase; m.stageCnt = stageCnt; m.issuedTo = issuedTo; m.fail = fail; m.stageV = stageV;
   m.ev = ev; m.evT = evT; m.evSLen = evSLen;
+  return m;
+}
+// A run whose merged order was computed ahead (round_merge.h mgPrepare: d.mg->merged[0 .. V)): this wave only STAGES — four entries per step: ring space, the (job, queue)
+// words, the job records' gather — and accounts what the engine has placed; the state it hands back is what streamMerge would have left after emitting the same entries.
+DEV RunState streamStaged(Dev& d, FastCtx fc, int Q, int skip, int V, RunState m) {
+  (void)fc; (void)Q;
+  const FastK k = fastKRef(d);
+  StreamLanes sl = m.sl;
+  int emitted = 0, emittedQ = 0, acc = m.acc, stageBase = -1, stageCnt = 0, issuedTo = 0, fail = 0, lastQ = -1, lastCi = -1;
+  const int allowed = m.allowed;
+  unsigned long long stageV = 0;
+  const MgEnt* mer = d.mg->merged;
+  bool over = false;
+  for (int base = 0; base < V && !fail && !over; base += 64) {
+    const int nb = V - base < 64 ? V - base : 64;
+    FOR_LANES(x, 64) if (x < nb) { const MgEnt en = mer[base + x]; FL.tmpX[x] = ((uint64_t)(uint32_t)en.qk << 32) | (uint32_t)en.job; FL.tmpY[x] = ((uint64_t)(uint32_t)en.ci << 32) | (uint32_t)en.e; }
+    LANE0_PUBLISHED();
+    for (int g = 0; g < nb && !over; g += 4) {
+      const int n4 = nb - g < 4 ? nb - g : 4;
+      for (;;) {   // the ring is the engine's pace
+        int a = streamAcked(&fail);
+        if (a > acc) { streamAccount(d, k, acc, a); acc = a; }
+        if (fail || (emitted + 4 - a <= RING_N - 8 && emitted + 4 - streamBound() <= RING_N - 8)) break;
+        STREAM_IDLE();
+      }
+      if (fail) break;
+      int put = 0;
+      for (int x = 0; x < n4; x++) {
+        const uint64_t v = UNI64(FL.tmpX[g + x]), w = UNI64(FL.tmpY[g + x]);
+        const int job = (int)(uint32_t)v, qk = (int)(uint32_t)(v >> 32), e = (int)(uint32_t)w;
+        const int ev = (qk >> 30) & 1, q = qk & 0xffffff;
+        if (!ev && emittedQ >= allowed) { over = true; break; }   // no global token left for another new job (constraints.go:129-141)
+        if (FLANE == 0) { RJOB(emitted + put) = job; RQ(emitted + put) = q | (ev ? RQ_EV : 0); FL.tmpA[q] = (uint32_t)(e + 1); }
+        LANE0_PUBLISHED();
+        put++; if (!ev) emittedQ++;
+        lastQ = q; lastCi = (int)(uint32_t)(w >> 32);
+      }
+      if (put > 0) {
+        if (stageBase >= 0) streamStageCommit(d, k, stageBase, stageCnt, stageV);
+        stageBase = emitted; stageCnt = put; emitted += put; issuedTo = emitted;
+        stageV = streamStageIssue(k, stageBase, put);
+      }
+    }
+  }
+  // every queue's merge cursor: behind its last emitted element
+  FOR_LANES(q, QCAPF) SL_SET(sl, pos, q, (int)FL.tmpA[q]);
+  m.sl = sl;
+  if (lastCi >= 0) {   // the key the last entry was served under (its running maximum: in skip mode every emitted entry's own key IS that — the passes stop in front of a decrease)
+    const WideKey lk = d.mg->key[lastCi];
+    m.lastK.A = (uint32_t)UNI64(lk.a); m.lastK.X = UNI64(lk.x); m.lastK.Y = UNI64(lk.y); m.lastN = (uint32_t)UNI32(FL.nameRank[lastQ]); m.haveLast = 1;
+  }
+  (void)skip;
+  m.lastQ = lastQ;
+  m.emitted = emitted; m.emittedQ = emittedQ; m.acc = acc; m.stageBase = stageBase; m.stageCnt = stageCnt; m.issuedTo = issuedTo; m.fail = fail; m.stageV = stageV;
+  m.ev = 0; m.evT = -1; m.evSLen = 0;
   return m;
 }
 // the two rare events of fastStreamRun (see there), on wave-uniform state; the caller has staged everything emitted.  st.go = 1: the run goes on; 0: it ends (st.pend /
@@ -2026,6 +2087,26 @@ DEV __attribute__((always_inline)) int fastPreemptIter(Dev& d, Ctl& c, FastCtx f
   return 1;
 }
 
+// Is the run about to start long enough for the bulk merge (round_merge.h)?  The sum of the streams' remaining lengths, lane-parallel — asked BEFORE the node engine
+// is stopped for the passes (mgPrepare asks again, exactly).
+DEV bool mgWorth(Dev& d, int Q) {
+#ifdef ASCHED_HOSTSIM
+  static const int minEntries = getenv("HS_MG_MIN") ? atoi(getenv("HS_MG_MIN")) : MG_MIN_ENTRIES_DEFAULT;
+  if (getenv("HS_NO_MERGE")) return false;
+#else
+  const int minEntries = MG_MIN_ENTRIES_DEFAULT;
+#endif
+  (void)d;
+  int total = 0;
+  for (int q0 = 0; q0 < Q; q0 += 64) {
+    FOR_LANES(x, 64) FL.tmpQ[x] = (q0 + x < Q && FL.inHeap[q0 + x] && FL.hot[q0 + x].sLen > FL.hot[q0 + x].sPos) ? FL.hot[q0 + x].sLen - FL.hot[q0 + x].sPos : 0;
+    LANE0_PUBLISHED();
+    for (int x = 0; x < 64 && q0 + x < Q; x++) total += UNI32(FL.tmpQ[x]);
+  }
+  FOR_LANES(x, 64) FL.tmpQ[x] = 0;
+  LANE0_PUBLISHED();
+  return total >= minEntries;
+}
 // Run fast iterations of the QueueScheduler loop (mode 0) or of the eviction-order replay (mode 1) until one needs the
 // generic code.  Returns the queue whose next head the generic updateAndPush must produce, or -1.  Leaves fast mode live.
 DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* counter) {
@@ -2133,7 +2214,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
       if (mode || !fc.stream || !S.fastActive || UNI32(FL.hot[t].gctx) == -1) break;
       if (!S.engLive) { engineStart(d, S); S.engLive = 1; }
       StreamIn in; in.globalTokens = S.globalTokens; in.globalBurst = S.globalBurst; in.globalRateInf = S.globalRateInf; in.engSeq = S.engSeq; in.resume = 0;
-      in.skip = 0; in.haveLast = 0; in.lastA = in.lastN = 0; in.lastX = in.lastY = 0;
+      in.skip = 0; in.haveLast = 0; in.lastA = in.lastN = 0; in.lastX = in.lastY = 0; in.bulkV = 0;
       GangOut go = fastGangRun(d, fc, in, t);
       S.engSeq = go.engSeq;
       if (go.dropped) { S.fastActive = 0; fastDrop(d); }
@@ -2164,8 +2245,14 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
       if (code == 0 && (fc.stream & 2) && fastStreamPrepareOne(d, fc, t, want, streamCap) > 0) code = 1;
       int E = 0, so_max = 0;
       if (code == 1) {
+        // (round 6) the run's merged order on every workgroup (round_merge.h) when the streams are long enough to pay for it: the node engine stops for the passes
+        int bulkV = 0;
+        if (d.mg && mgWorth(d, Q)) {
+          if (S.engLive) { engineStop(d, S); S.engLive = 0; if (UNI32(FL.eng.cancel)) { c.cancelSeen = 1; break; } }
+          bulkV = mgPrepare(d, fc, Q, c.skipActive);
+        }
         if (!S.engLive) { engineStart(d, S); S.engLive = 1; }
-        StreamIn in; in.globalTokens = S.globalTokens; in.globalBurst = S.globalBurst; in.globalRateInf = S.globalRateInf; in.engSeq = S.engSeq;
+        StreamIn in; in.globalTokens = S.globalTokens; in.globalBurst = S.globalBurst; in.globalRateInf = S.globalRateInf; in.engSeq = S.engSeq; in.bulkV = bulkV;
         in.skip = c.skipActive; in.haveLast = haveRef; in.lastA = refK.A; in.lastX = refK.X; in.lastY = refK.Y; in.lastN = refN;   // (the current top's key: it is the first entry of the run)
         in.resume = 0;
         StreamOut so = fastStreamRun(d, fc, Q, in);

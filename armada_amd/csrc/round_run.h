@@ -19,6 +19,7 @@ DEV void wgBulk(Dev& d, int kind, int n);  // every element i in [0,n) through b
 DEV void wgFtBuild(Dev& d, int phase, int n);  // one pass of the fair-share threshold table's build (round_ft.h ftBuildAny), helper workgroups included
 DEV void wgBulkWide(Dev& d, int kind, int n);  // the same with the helper workgroups taking their share (bodies that touch HBM only)
 #include "round_wide.h"
+#include "round_merge.h"
 DEV int wgCompactFlagged(Dev& d, const int32_t* order, const int32_t* segOff, int nseg, int n, const uint8_t* flag, int32_t* dst, int32_t* outSegOff);
 DEV int wgCompactIota(Dev& d, int n, const uint8_t* flag, int32_t* dst);
 
@@ -650,6 +651,18 @@ DEV_NOINLINE int fastStreamPrepare(Dev& d, FastCtx fc, int Q, int allowed, int a
 #ifdef ASCHED_HOSTSIM
   if (getenv("HS_NO_EV_STREAM")) evOk = false;
 #endif
+  // (round 6) a head the generic code peeked and no fast iteration has looked at yet has no cached record (headFast 0), and such a queue used to get its first stream only
+  // after a fast iteration had served it once: a pass started with 64 short runs, each ending at the next such queue.  Their records are fetched here.
+  if (allowBulk > 0) for (int q = 0; q < Q; q++) {
+    if (!UNI32(FL.inHeap[q]) || UNI32(FL.hot[q].headFast) || UNI32(FL.hot[q].sLen) > UNI32(FL.hot[q].sPos)) continue;
+    const int job = UNI32(FL.hot[q].gctx);
+    if (job < 0) continue;
+    QHot f = FL.hot[q];
+    uniQHot(f);
+    fastLoadHead(k, q, job, f);
+    if (FLANE == 0) { FL.hot[q].headFast = 1; FL.hot[q].headKind = f.headKind; FL.hot[q].headIdx = f.headIdx; FL.hot[q].headPos = f.headPos; }
+    LANE0_PUBLISHED();
+  }
   FOR_LANES(q, QCAPF) FL.tmpQ[q] = 0;
   FOR_LANES(q, Q) {
     QHot& f = FL.hot[q];

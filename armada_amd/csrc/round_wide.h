@@ -100,7 +100,9 @@ DEV void skipBulk(Dev& d, int kind, int pos, int i) {
   d.jcReason[job] = ASCHED_REASON_SKIPPED_UNFEASIBLE_KEY;
 }
 
+DEV_COLD void mergeBulkAny(Dev& d, int kind, int i);   // round_merge.h: the passes of a bulk-merged stream run share the op
 DEV_COLD void wideBulkAny(Dev& d, int kind, int i) {
+  if (kind >= 32 && kind < 40) { mergeBulkAny(d, kind, i); return; }   // (W_MG_*)
   if (kind == W_EXCL) { exclBulk(d, i); return; }
   if ((kind & 255) >= W_SKIP_FIND) { skipBulk(d, kind & 255, kind >> 8, i); return; }
   const DevCfg& c = d.cfg;

@@ -46,7 +46,7 @@ def test_stream_runs_started_everywhere_equal_oracle(hostsim_lib, oracle_lib, se
     wl = workload(950 + seed, gangs=int(rng.choice([0, 5, 40])), occupied=float(rng.choice([0.3, 0.8, 0.93])), n_queues=int(rng.integers(3, 30)),
                   burst=(int(rng.choice([16000, 5000, 500])), int(rng.choice([16000, 700, 64]))))
     r, st = both(hostsim_lib, oracle_lib, wl)
-    assert st["stream_runs"] >= 10
+    assert st["stream_runs"] >= 5   # (round 6: streams cover a queue's whole burst and every head gets one from the first preparation on — fewer, longer runs)
 
 
 def test_streams_off_is_the_same_round(hostsim_lib, oracle_lib, monkeypatch):
