@@ -845,9 +845,9 @@ __device__ static inline void qsWinRefill(KREF k, int q, int pos, int cnt) {
   int lane = threadIdx.x & 63;
   if (lane < cnt * 4) ((unsigned long long*)&g_fl.evWin[q][0])[lane] = k.qsKey[((size_t)q * QS_CMAX + pos) * 4 + lane];
 }
-__device__ static inline void streamBegin(int* engSeq, int hold) {
+__device__ static inline void streamBegin(int* engSeq, int hold, int hc) {
   int lane = threadIdx.x & 63;
-  if (lane == 0) { g_fl.eng.bindHold = hold; g_fl.eng.ringPub = 0; g_fl.eng.ringAck = 0; g_fl.eng.ringEnd = 0; g_fl.eng.ringFail = 0; g_fl.eng.ringClosed = 0; g_fl.eng.bindDone = 0; g_fl.eng.cmd = ENG_STREAM; }
+  if (lane == 0) { g_fl.eng.bindHold = hold; g_fl.eng.ringPub = 0; g_fl.eng.ringAck = 0; g_fl.eng.ringEnd = 0; g_fl.eng.ringFail = 0; g_fl.eng.ringClosed = 0; g_fl.eng.bindDone = 0; g_fl.eng.cmd = hc ? ENG_STREAM_HC : ENG_STREAM; }
   (*engSeq)++;
   LDS_ORDER();
   if (lane == 0) __hip_atomic_store(&g_fl.eng.bindGen, g_fl.eng.bindGen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -949,7 +949,7 @@ __device__ static inline void pqHeadKey(PQState& s, int t, PackedKey* key, uint3
 __device__ static inline void engineStart(Dev& d, FastS& S) {
   (void)d;
   S.engSeq = 0;
-  if ((threadIdx.x & 63) == 0) { g_fl.eng.seq = 0; g_fl.eng.ack = 0; g_fl.eng.statScan = 0; g_fl.eng.statL0Max = S.statL0Max; g_fl.eng.busyClk = 0; g_fl.eng.jobs = 0; g_fl.eng.cancel = 0; g_fl.eng.bindQuit = 0; g_fl.eng.bindGen = 0; g_fl.eng.bindFin = 0; g_fl.eng.live = 1; g_mb.op = OP_ENGINE; }
+  if ((threadIdx.x & 63) == 0) { g_fl.eng.seq = 0; g_fl.eng.ack = 0; g_fl.eng.statScan = 0; g_fl.eng.statL0Max = S.statL0Max; g_fl.eng.busyClk = 0; g_fl.eng.jobs = 0; g_fl.eng.cancel = 0; g_fl.eng.bindQuit = 0; g_fl.eng.bindGen = 0; g_fl.eng.bindFin = 0; g_fl.eng.hcGen = 0; g_fl.eng.live = 1; g_mb.op = OP_ENGINE; }
   __syncthreads();
 }
 __device__ static inline void engineStop(Dev& d, FastS& S) {
@@ -971,6 +971,7 @@ __device__ static inline void engineStop(Dev& d, FastS& S) {
 #endif
   __syncthreads();  // end barrier of the OP_ENGINE op
 }
+#include "engine_hc.h"
 __device__ static void engineLoop(Dev& d) {  // wave 1
   const FastK k = fastKRef(d);
   int lane = threadIdx.x & 63;
@@ -1004,6 +1005,15 @@ __device__ static void engineLoop(Dev& d) {  // wave 1
       LDS_ORDER();
       if (lane == 0) __hip_atomic_store(&g_fl.eng.ack, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       return;
+    }
+    if (cmd == ENG_STREAM_HC) {   // a bulk-merged run's ring session on the split level-0 structure (engine_hc.h); same ring contract as below
+      long long b0 = (long long)__builtin_readcyclecounter();
+      engineStreamHc(d, k, ES);
+      busy += (long long)__builtin_readcyclecounter() - b0; jobs += __builtin_amdgcn_readfirstlane(g_fl.eng.ringAck);
+      LDS_ORDER();
+      if (lane == 0) __hip_atomic_store(&g_fl.eng.ringClosed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) __hip_atomic_store(&g_fl.eng.ack, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      continue;
     }
     if (cmd == ENG_STREAM) {
       // walk the ring: entry i is ready when ringPub > i; stop at the first job that finds no node (ringFail 1), after an L0 overflow (2), or when the
@@ -1521,7 +1531,7 @@ __global__ __launch_bounds__(CTL_THREADS) void K_CONTROL_NAME(Dev dev, int cmd, 
       else if (op == OP_COMPACT) {
         compactPart(d);
       } else if (op == OP_ENGINE) {
-        if ((threadIdx.x >> 6) == 1) engineLoop(d); else if ((threadIdx.x >> 6) == 2) bindLoop(d);
+        if ((threadIdx.x >> 6) == 1) engineLoop(d); else if ((threadIdx.x >> 6) == 2) bindLoop(d); else if ((threadIdx.x >> 6) == 3) coldLoop(d);
       }
       __syncthreads();
     }
@@ -2889,7 +2899,7 @@ __global__ __launch_bounds__(CTL_THREADS) void k_control_aux(Dev dev, int cmd, H
       } else if (op == OP_COMPACT) {
         compactPart(d);
       } else if (op == OP_ENGINE) {
-        if ((threadIdx.x >> 6) == 1) engineLoop(d); else if ((threadIdx.x >> 6) == 2) bindLoop(d);
+        if ((threadIdx.x >> 6) == 1) engineLoop(d); else if ((threadIdx.x >> 6) == 2) bindLoop(d); else if ((threadIdx.x >> 6) == 3) coldLoop(d);
       }
       __syncthreads();
     }

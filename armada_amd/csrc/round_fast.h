@@ -56,7 +56,7 @@ struct alignas(16) CandRec { int32_t pos, node; uint64_t key, cls; int64_t ex0, 
 // control wave posts the job to a second wave (the node engine) and carries on with the queue side assuming it fits; the verdict
 // is collected before the next iteration starts.  On a miss the queue side of that one iteration is taken back (IterBackup) and
 // the generic code runs it from exactly the state it would have found.
-enum { ENG_JOB = 1, ENG_QUIT = 2, ENG_STREAM = 3 };
+enum { ENG_JOB = 1, ENG_QUIT = 2, ENG_STREAM = 3, ENG_STREAM_HC = 4 };   // ENG_STREAM_HC: a ring session on the split level-0 structure (engine_hc.h)
 struct alignas(16) EngineBox {
   JobTail tail; int64_t req[MAXR];          // the job: its record as fastIter read it
   int32_t job, prio, cutoff, nl, cmd, status;
@@ -65,6 +65,7 @@ struct alignas(16) EngineBox {
   int64_t busyClk; int32_t jobs, cancel;     // shader-clock ticks the engine spent serving jobs, and how many; cancel: the engine saw the caller's cancel word
   int32_t ringPub, ringAck, ringEnd, ringFail;   // stream run: entries staged in the ring / placed by the engine; no more entries will come; 1 = entry ringAck found no node, 2 = placed but L0 overflowed
   int32_t bindHold;   // 1: the bind wave waits for the verdict on the whole ring (a gang: all members or none), 2: go, 3: discard
+  int32_t hcGen, cleanFrom;   // engine_hc.h: generation of the cold wave's sessions; no clean base entry lies before this position (kept for the launch)
   int32_t ringClosed, bindGen, bindDone, bindFin, bindQuit, live;   // live: the node engine runs (engineStart .. engineStop) — what coldS tells the out-of-line helpers
   //   // the engine has left the ring; stream generation / entries whose bind + result fields the bind wave has issued / generation it has finished
 };
@@ -445,7 +446,7 @@ __device__ static inline unsigned long long slGet64(unsigned long long v, int q)
 #define SL_GET64(sl, f, q) slGet64((sl).f, (q))
 #define SL_GETD(sl, f, q) __builtin_bit_cast(double, slGet64(__builtin_bit_cast(unsigned long long, (sl).f), (q)))
 DEV void qsWinRefill(KREF k, int q, int pos, int cnt);
-DEV void streamBegin(int* engSeq, int hold = 0);
+DEV void streamBegin(int* engSeq, int hold = 0, int hc = 0);   // hc: the ring session runs on the split level-0 structure (engine_hc.h; device only)
 DEV void streamRelease(Dev& d, KREF k, int go);   // gang: the held binds of every placed member are issued (go) or dropped
 DEV unsigned long long streamStageIssue(KREF k, int base, int cnt);
 DEV void streamStageCommit(Dev& d, KREF k, int base, int cnt, unsigned long long v);
@@ -711,7 +712,7 @@ DEV bool fastGangMember(Dev& d, Ctl& c, int job) {
 }
 // ------------------------------------------------------------------------------------------------ launch persistence
 DEV void fastLoad(Dev& d) {  // kernel start: rebuild the LDS side from HBM
-  FL.l0Count = 0;
+  FL.l0Count = 0; FL.eng.cleanFrom = 0;
   fastPassReset();
   if (!d.f.structOk || !RS.fastActive) return;
   const FastK k = fastKRef(d);
@@ -1599,7 +1600,12 @@ DEV_NOINLINE StreamOut fastStreamRun(Dev& d, FastCtx fc, int Q, StreamIn in) {
       FL.tmpQ[q] = 0; FL.tmpA[q] = (uint32_t)f.sPos;   // (tmpA: a staged run's merge cursor per queue, streamStaged)
     }
     engSeq = in.engSeq;
-    streamBegin(&engSeq);
+    const int hc = UNI32(in.bulkV) > 0 && d.f.engineHc;
+    if (hc) {   // the session's mailbox lives in the queues' key windows (FL.evWin, engine_hc.h): no queue's window survives it
+      FOR_LANES(q, QCAPF) { FL.hot[q].ewCount = 0; FL.hot[q].ewStart = 0; }
+      LANE0_PUBLISHED();
+    }
+    streamBegin(&engSeq, 0, hc);
     m.pq = pq; m.sl = sl; m.lastK = lastK; m.lastN = lastN; m.haveLast = haveLast; m.lastQ = -1;
     m.stageBase = -1; m.allowed = allowed; m.engSeq = engSeq; m.sessLive = 1; m.pend = -1;
   } else {

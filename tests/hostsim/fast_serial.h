@@ -210,7 +210,7 @@ DEV void qsWinRefill(KREF k, int q, int pos, int cnt) { for (int i = 0; i < cnt;
 DEV int engineServe(Dev& d, KREF k, FastS& ES);
 static FastS g_engS;
 static void hsLagRead();
-DEV void streamBegin(int* engSeq, int hold = 0) { hsLagRead(); FL.eng.ringPub = FL.eng.ringAck = FL.eng.ringEnd = FL.eng.ringFail = 0; FL.eng.bindDone = 0; FL.eng.bindHold = hold; FL.eng.cmd = ENG_STREAM; (*engSeq)++; }
+DEV void streamBegin(int* engSeq, int hold = 0, int hc = 0) { (void)hc; hsLagRead(); FL.eng.ringPub = FL.eng.ringAck = FL.eng.ringEnd = FL.eng.ringFail = 0; FL.eng.bindDone = 0; FL.eng.bindHold = hold; FL.eng.cmd = ENG_STREAM; (*engSeq)++; }
 DEV void bindJob(KREF k, FastS& ES, int n, int nl, uint64_t keyDelta, const int64_t* req, int job, int32_t prio, int32_t cutoff);
 DEV void streamRelease(Dev& d, KREF k, int go) {
   (void)d;
