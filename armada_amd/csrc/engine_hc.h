@@ -104,7 +104,7 @@ template <int E> __device__ static void coldSession(Dev& d, KREF k) {
   const unsigned long long G = UNI64(k.guardMask);
   HcRows rows;
   int hi = __builtin_amdgcn_readfirstlane(g_fl.l0Count);   // slots [0, hi) are entries or holes
-  int nfree = 0, insDone = 0;
+  int nfree = 0, insDone = 0, overflow = 0;
 #pragma unroll
   for (int r = 0; r < HC_ROWS; r++) {
     const int s = r * 64 + lane;
@@ -116,21 +116,23 @@ template <int E> __device__ static void coldSession(Dev& d, KREF k) {
   long long cBusy = 0, cT0 = 0; int cQ = 0, cI = 0;
 #endif
   for (;;) {
-    int pub;
-    for (;;) { pub = hcLoadI32(&HCB.cmdPub); if (pub != done) break; __builtin_amdgcn_s_sleep(1); }
+    // the publication counter and the next command's words in ONE batch of LDS reads (the counter first: a command it covers is complete)
+    const HcCmd& c = HCB.cmd[done & (HC_CMDS - 1)];
+    const int pubV = __hip_atomic_load(&HCB.cmdPub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     LDS_ORDER();
+    const int typeV = c.type, aV = c.a, seqV = c.seq;
+    HcNeed q; q.fmin = c.fieldMin; q.ex0 = c.ex0; q.ex1 = c.ex1; q.cls = c.cls;   // (every lane reads the same words)
+    if (__builtin_amdgcn_readfirstlane(pubV) == done) { __builtin_amdgcn_s_sleep(1); continue; }
 #ifdef ASCHED_FASTPROF
     cT0 = CLK();
 #endif
-    for (; done < pub; done++) {
-      const HcCmd& c = HCB.cmd[done & (HC_CMDS - 1)];
-      const int type = __builtin_amdgcn_readfirstlane(c.type), a = __builtin_amdgcn_readfirstlane(c.a);
+    {
+      const int type = __builtin_amdgcn_readfirstlane(typeV), a = __builtin_amdgcn_readfirstlane(aV);
       if (type == HC_Q) {
 #ifdef ASCHED_FASTPROF
         cQ++;
 #endif
-        HcNeed q; q.fmin = c.fieldMin; q.ex0 = c.ex0; q.ex1 = c.ex1; q.cls = c.cls;   // (every lane reads the same words)
-        const int seq = __builtin_amdgcn_readfirstlane(c.seq);
+        const int seq = __builtin_amdgcn_readfirstlane(seqV);
         unsigned long long best = ~0ull; int bs = -1;
         const int nrows = (hi + 63) >> 6;
 #pragma unroll
@@ -144,7 +146,7 @@ template <int E> __device__ static void coldSession(Dev& d, KREF k) {
         const unsigned long long mn = hcMinKey(best, &bl);
         const int slot = bl >= 0 ? __builtin_amdgcn_readlane(bs, bl) : -1;
         HcRep& o = HCB.rep[seq & 3];
-        if (lane == 0) { o.slot = slot; o.key = mn; o.insDone = insDone; }
+        if (lane == 0) { o.slot = slot; o.key = mn; o.insDone = overflow ? -1 : insDone; }
         LDS_ORDER();
         hcStoreI32(&o.seq, seq);
       } else if (type == HC_I) {
@@ -158,7 +160,7 @@ template <int E> __device__ static void coldSession(Dev& d, KREF k) {
         if (nfree > 0) { nfree--; slot = __builtin_amdgcn_readfirstlane((int)HCB.freeStack[nfree]); }
         else if (hi < L0CAP) slot = hi++;
         else slot = -1;
-        if (slot < 0) { hcStoreI32(&HCB.overflow, 1); }   // the list is full: the engine ends the session and reports it (the generic full scan takes over, counted in round_stats)
+        if (slot < 0) overflow = 1;   // the list is full: every later answer says so (insDone < 0); the engine ends the session and reports it (the generic full scan takes over, counted in round_stats)
         else {
           if (lane == 0) { g_fl.l0Key[slot] = key; g_fl.l0Node[slot] = node; g_fl.l0Ex0[slot] = ex0; g_fl.l0Ex1[slot] = ex1; g_fl.l0Cls[slot] = cls; g_fl.l0Cls2[slot] = 0; HCB.insSlot[a & (HC_CMDS - 1)] = slot; }
           LANE0_PUBLISHED();
@@ -203,7 +205,7 @@ template <int E> __device__ static void coldSession(Dev& d, KREF k) {
         return;
       }
       LDS_ORDER();
-      hcStoreI32(&HCB.cmdDone, done + 1);
+      done++;   // (cmdDone is published with HC_E only: the engine never looks at it before)
     }
 #ifdef ASCHED_FASTPROF
     cBusy += CLK() - cT0;
@@ -230,16 +232,6 @@ __device__ static void coldLoop(Dev& d) {
 struct HcHot { unsigned long long key, cls; long long ex0, ex1; int node, state, seq; };   // state 0 empty, 1 entry, 2 entry handed to C (insert `seq` in flight)
 struct HcFront { unsigned long long key, cls; long long ex0, ex1; int node, pos; };           // node -1: no entry in this lane
 
-// one command for wave 3; the job's needs travel as the lanes hold them (lane 0 writes)
-__device__ static inline void hcPost(int& cmdPub, int type, int a, const HcNeed* q, int seq) {
-  const int lane = threadIdx.x & 63;
-  for (;;) { if (cmdPub - hcLoadI32(&HCB.cmdDone) < HC_CMDS - 1) break; __builtin_amdgcn_s_sleep(1); }
-  HcCmd& c = HCB.cmd[cmdPub & (HC_CMDS - 1)];
-  if (lane == 0) { c.type = type; c.a = a; c.seq = seq; if (q) { c.fieldMin = q->fmin; c.ex0 = q->ex0; c.ex1 = q->ex1; c.cls = q->cls; } }
-  LDS_ORDER();
-  cmdPub++;
-  hcStoreI32(&HCB.cmdPub, cmdPub);
-}
 // the clean front from base position `from` on: the next <= 64 clean entries in base order.  Returns G: every clean entry in [from, G) is in a lane.
 __device__ static inline int hcFrontFill(KREF k, FastS& ES, HcFront& cf, int from) {   // (inlined at its ONE call site: a call would put the front and the loop constants in memory)
   const int lane = threadIdx.x & 63;
@@ -299,8 +291,37 @@ __device__ static inline int hcBehindFront(KREF k, FastS& ES, const JobTail& r, 
   return c.node >= 0 ? 1 : -1;
 }
 
+// a ring entry as the engine's lanes hold it (every lane the same words: vector operands; nothing is moved to scalar registers unless a branch needs it)
+struct HcJobV { unsigned long long keyDelta, fmin; long long ex0, ex1; int cls, never, rq, pub; };
+// ring entry idx and the publication counter in ONE batch of LDS reads (the counter first: LDS executes a wave's reads in order, so an entry the counter covers is complete)
+__device__ static inline void hcLoadEntry(int idx, HcJobV& o) {
+  o.pub = __hip_atomic_load(&g_fl.eng.ringPub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  LDS_ORDER();   // (no instruction: it keeps the compiler from moving the entry's reads in front of the counter's)
+  o.rq = RQ(idx);
+  const JobTail& t = *(const JobTail*)&RREC(idx).keyDelta;
+  o.keyDelta = t.keyDelta; o.fmin = t.fieldMin; o.cls = t.cls; o.never = (int)t.never; o.ex0 = t.ex0; o.ex1 = t.ex1;
+}
+// a command for wave 3 (no look at the ring's space: once the answer to a job's question is in, everything posted before that question is done, and a job posts at most
+// four commands — the ring holds sixteen)
+__device__ static inline void hcPostQ(int& cmdPub, const HcJobV& j, int seq) {
+  HcCmd& c = HCB.cmd[cmdPub & (HC_CMDS - 1)];
+  if ((threadIdx.x & 63) == 0) { c.type = HC_Q; c.a = 0; c.seq = seq; c.fieldMin = j.fmin; c.ex0 = j.ex0; c.ex1 = j.ex1; c.cls = j.cls; }
+  LDS_ORDER();
+  cmdPub++;
+  hcStoreI32(&HCB.cmdPub, cmdPub);
+}
+__device__ static inline void hcPostA(int& cmdPub, int type, int a) {
+  HcCmd& c = HCB.cmd[cmdPub & (HC_CMDS - 1)];
+  if ((threadIdx.x & 63) == 0) { c.type = type; c.a = a; }
+  LDS_ORDER();
+  cmdPub++;
+  hcStoreI32(&HCB.cmdPub, cmdPub);
+}
+
 // One ring session with the split structure.  Same contract as the ENG_STREAM walk of engineLoop: entry i is ready when ringPub > i; the chosen node goes into the
 // ring entry (the bind wave issues the HBM side); ringAck counts the entries placed; ringFail 1 = entry ringAck found no node, 2 = the list overflowed.
+// The loop is written around two costs measured on the MI355X (profiles/r06f_hc_segments.txt): ~8 shader clocks per instruction of a lone wave, ~140 per dependent LDS
+// round trip.  Per job: ONE batch of LDS reads for the next entry (issued before the tests, used after the decision) and one for the cold set's answer.
 template <int E> __device__ static void engineStreamHcT(Dev& d, KREF k, FastS& ES) {
   const int lane = threadIdx.x & 63;
   const unsigned long long G = UNI64(k.guardMask), MFM = UNI64(k.minFieldMin);
@@ -329,38 +350,52 @@ template <int E> __device__ static void engineStreamHcT(Dev& d, KREF k, FastS& E
   int cfFill = -1;
 #else
   int cfFill = cfG;   // >= 0: gather the front from this base position before the next job
-  int total = __builtin_amdgcn_readfirstlane(g_fl.l0Count);   // dirty nodes alive (H + C): the list's high-water mark for round_stats
 #endif
-  int i = 0, pub = 0, qUpTo = 0, fail = 0;
+  int total = __builtin_amdgcn_readfirstlane(g_fl.l0Count);   // dirty nodes alive (H + C): the list's high-water mark for round_stats
+  int i = 0, qUpTo = 0, fail = 0;
+  HcJobV cur; bool haveCur = false;
+#ifdef ASCHED_FASTPROF
+  int pSrc[4] = {0, 0, 0, 0}, pBehind = 0, pFill = 0, pDry = 0, pRepWait = 0;
+#endif
   for (;;) {
-    if (cfFill >= 0) { cfG = hcFrontFill(k, ES, cf, cfFill); cfFill = -1; }
-    if (pub <= i) {
+    if (cfFill >= 0) { cfG = hcFrontFill(k, ES, cf, cfFill); cfFill = -1;
+#ifdef ASCHED_FASTPROF
+      pFill++;
+#endif
+    }
+    if (!haveCur) {
+#ifdef ASCHED_FASTPROF
+      pDry++;
+#endif   // the ring ran dry (or the session starts): wait for entry i
       for (;;) {
-        pub = hcLoadI32(&g_fl.eng.ringPub);
-        if (pub > i) break;
-        if (hcLoadI32(&g_fl.eng.ringEnd)) { pub = hcLoadI32(&g_fl.eng.ringPub); break; }
+        hcLoadEntry(i, cur);
+        if (__builtin_amdgcn_readfirstlane(cur.pub) > i) break;
+        if (hcLoadI32(&g_fl.eng.ringEnd)) { hcLoadEntry(i, cur); break; }
         __builtin_amdgcn_s_sleep(1);
       }
-      if (pub <= i) break;
-      LDS_ORDER();
+      if (__builtin_amdgcn_readfirstlane(cur.pub) <= i) break;
+      haveCur = true;
     }
     ESEG(0);   // [16] waiting for a ring entry
-    if (__builtin_amdgcn_readfirstlane(RQ(i)) & RQ_EV) {   // an evicted job returning to its node: nothing to select or bind here
-      i++;
+    if (__builtin_amdgcn_readfirstlane(cur.rq) & RQ_EV) {   // an evicted job returning to its node: nothing to select or bind here
+      i++; haveCur = false;
       hcStoreI32(&g_fl.eng.ringAck, i);
       continue;
     }
     if ((++ES.engSeq & 255) == 0 && cancelRequested(d)) { if (lane == 0) g_fl.eng.cancel = 1; LANE0_PUBLISHED(); fail = 1; break; }
-    // the job as every lane reads it from the ring entry (the same words in all lanes: vector operands of the tests below)
-    const JobTail& jt = *(const JobTail*)&RREC(i).keyDelta;
-    HcNeed q; q.fmin = jt.fieldMin; q.ex0 = jt.ex0; q.ex1 = jt.ex1; q.cls = jt.cls;
-    const unsigned long long keyDelta = jt.keyDelta;
-    if (__builtin_amdgcn_readfirstlane((int)jt.never)) { fail = 1; break; }
-    if (qUpTo <= i) { hcPost(cmdPub, HC_Q, 0, &q, i); qUpTo = i + 1; }
+    if (__builtin_amdgcn_readfirstlane(cur.never)) { fail = 1; break; }
+    if (qUpTo <= i) { hcPostQ(cmdPub, cur, i); qUpTo = i + 1; }
 #ifndef HC_NO_CF
     if (cfG < N && __ballot(cf.node >= 0) == 0) { cfFill = cfG; continue; }   // the front is used up (or its stretch of the base held nothing clean): the next stretch first
 #endif
+    // ---- the next entry and the cold set's answer: their LDS reads are in flight during the tests
+    HcJobV nxt; hcLoadEntry(i + 1, nxt);
+    HcRep& rp = HCB.rep[i & 3];
+    int rSeq = __hip_atomic_load(&rp.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    LDS_ORDER();
+    int rSlot = rp.slot, rIns = rp.insDone; unsigned long long rKey = rp.key;
     // ---- H and the clean front: one test per lane each
+    HcNeed q; q.fmin = cur.fmin; q.ex0 = cur.ex0; q.ex1 = cur.ex1; q.cls = cur.cls;
     const bool fitH = (h.state != 0) & hcFits<E>(G, q, h.key, h.cls, h.ex0, h.ex1);
     int hLane;
     unsigned long long hk = hcMinKey(fitH ? h.key : ~0ull, &hLane);
@@ -370,15 +405,21 @@ template <int E> __device__ static void engineStreamHcT(Dev& d, KREF k, FastS& E
     const unsigned long long bCf = __ballot((cf.node >= 0) & hcFits<E>(G, q, cf.key, cf.cls, cf.ex0, cf.ex1));
 #endif
     const int cfLane = bCf ? (int)__builtin_ctzll(bCf) : -1;
-    ESEG(1);   // [17] record, H and front tests
+    ESEG(1);   // [17] H and front tests
     // ---- the cold set's answer for this job
-    HcRep& rp = HCB.rep[i & 3];
-    for (;;) { if (hcLoadI32(&rp.seq) == i) break; __builtin_amdgcn_s_sleep(1); }
-    LDS_ORDER();
+    while (__builtin_amdgcn_readfirstlane(rSeq) != i) {
+#ifdef ASCHED_FASTPROF
+      pRepWait++;
+#endif
+      __builtin_amdgcn_s_sleep(1);
+      rSeq = __hip_atomic_load(&rp.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      LDS_ORDER();
+      rSlot = rp.slot; rIns = rp.insDone; rKey = rp.key;
+    }
     ESEG(2);   // [18] waiting for the cold set's answer
-    const int cSlot = __builtin_amdgcn_readfirstlane(rp.slot), insDone = __builtin_amdgcn_readfirstlane(rp.insDone);
-    const unsigned long long ck = UNI64(rp.key);   // (~0 when no entry fits)
-    if (hcLoadI32(&HCB.overflow)) { fail = 2; break; }
+    const int cSlot = __builtin_amdgcn_readfirstlane(rSlot), insDone = __builtin_amdgcn_readfirstlane(rIns);
+    const unsigned long long ck = UNI64(rKey);   // (~0 when no entry fits)
+    if (insDone < 0) { fail = 2; break; }   // the cold list overflowed
     {   // entries whose hand-over to C this answer already counts leave H; the best lane among them: the answer is at least as good (it saw that very entry)
       const bool rel = (h.state == 2) & (h.seq < insDone);
       const unsigned long long rb = __ballot(rel);
@@ -395,7 +436,10 @@ template <int E> __device__ static void engineStreamHcT(Dev& d, KREF k, FastS& E
       const unsigned long long fk = hcRead64(cf.key, cfLane);
       src = lk < fk ? (hk < ck ? 0 : 1) : 2;
     } else {
-      JobTail r = jt; uniJobTail(r);
+#ifdef ASCHED_FASTPROF
+      pBehind++;
+#endif
+      JobTail r = *(const JobTail*)&RREC(i).keyDelta; uniJobTail(r);
       const int v = hcBehindFront(k, ES, r, lk, cfG, &c);
       if (v < 0) { fail = 1; break; }
       src = v ? 3 : (hk < ck ? 0 : 1);
@@ -406,6 +450,9 @@ template <int E> __device__ static void engineStreamHcT(Dev& d, KREF k, FastS& E
     else if (src == 1) n = __builtin_amdgcn_readfirstlane(g_fl.l0Node[cSlot]);
     else if (src == 2) n = __builtin_amdgcn_readlane(cf.node, cfLane);
     else n = c.node;
+#ifdef ASCHED_FASTPROF
+    pSrc[src & 3]++;
+#endif
     ESEG(3);   // [19] the three-way minimum (incl. a base rescan behind the front)
     if (lane == 0) RREC(i).node0 = n;
     LANE0_PUBLISHED();
@@ -413,20 +460,14 @@ template <int E> __device__ static void engineStreamHcT(Dev& d, KREF k, FastS& E
     i++;
     hcStoreI32(&g_fl.eng.ringAck, i);
     // ---- what C must know before it answers for the next job, then the next job's question
-    if (src == 1) hcPost(cmdPub, HC_D, cSlot, nullptr, 0);
-    if (src == 0 && __builtin_amdgcn_readlane(h.state, hLane) == 2) hcPost(cmdPub, HC_C, __builtin_amdgcn_readlane(h.seq, hLane), nullptr, 0);
-    if (pub <= i) { pub = hcLoadI32(&g_fl.eng.ringPub); LDS_ORDER(); }
-    if (pub > i && !(__builtin_amdgcn_readfirstlane(RQ(i)) & RQ_EV)) {
-      const JobTail& jn = *(const JobTail*)&RREC(i).keyDelta;
-      if (!__builtin_amdgcn_readfirstlane((int)jn.never)) {
-        HcNeed qn; qn.fmin = jn.fieldMin; qn.ex0 = jn.ex0; qn.ex1 = jn.ex1; qn.cls = jn.cls;
-        hcPost(cmdPub, HC_Q, 0, &qn, i); qUpTo = i + 1;
-      }
-    }
+    if (src == 1) hcPostA(cmdPub, HC_D, cSlot);
+    if (src == 0 && __builtin_amdgcn_readlane(h.state, hLane) == 2) hcPostA(cmdPub, HC_C, __builtin_amdgcn_readlane(h.seq, hLane));
+    const bool haveNext = __builtin_amdgcn_readfirstlane(nxt.pub) > i;
+    if (haveNext && !(__builtin_amdgcn_readfirstlane(nxt.rq) & RQ_EV) && !__builtin_amdgcn_readfirstlane(nxt.never)) { hcPostQ(cmdPub, nxt, i); qUpTo = i + 1; }
     ESEG(4);   // [20] verdict, commands, the next job's question
     // ---- the bind's effect on the node's level-0 entry: key and extras go down; an entry that can no longer host anything is dropped
     if (src == 0) {   // in place, in its lane
-      const unsigned long long nk = h.key - keyDelta; const long long n0 = h.ex0 - q.ex0, n1 = h.ex1 - q.ex1;
+      const unsigned long long nk = h.key - cur.keyDelta; const long long n0 = h.ex0 - cur.ex0, n1 = h.ex1 - cur.ex1;
       const bool alive = ((((nk | G) - MFM) & G) == G) & (ME0 <= n0) & (ME1 <= n1);
       if (lane == hLane) { if (alive) { h.key = nk; h.ex0 = n0; h.ex1 = n1; h.state = 1; } else { h.state = 0; h.node = -1; h.key = ~0ull; } }
       if (__ballot((lane == hLane) & !alive)) total--;
@@ -439,7 +480,7 @@ template <int E> __device__ static void engineStreamHcT(Dev& d, KREF k, FastS& E
         if (lane == cfLane) cf.node = -1;
       } else { okey = c.key; ocls = c.cls; oex0 = c.ex0; oex1 = c.ex1; usedPos = c.pos; }
       if (src >= 2) hcCleanUsed(k, ES, usedPos, n);
-      const unsigned long long nk = okey - UNI64(keyDelta); const long long n0 = oex0 - (long long)UNI64(q.ex0), n1 = oex1 - (long long)UNI64(q.ex1);
+      const unsigned long long nk = okey - UNI64(cur.keyDelta); const long long n0 = oex0 - (long long)UNI64(cur.ex0), n1 = oex1 - (long long)UNI64(cur.ex1);
       const bool alive = ((((nk | G) - MFM) & G) == G) && ME0 <= n0 && ME1 <= n1;
       if (alive) {
         // a free lane (there is always one: at most HC_H_MAX entries + the few in flight)
@@ -455,11 +496,10 @@ template <int E> __device__ static void engineStreamHcT(Dev& d, KREF k, FastS& E
           const unsigned long long hiPart = cand & (~0ull << rrNext);
           const int v = hiPart ? (int)__builtin_ctzll(hiPart) : (int)__builtin_ctzll(cand);
           rrNext = (v + 1) & 63;
-          for (;;) { if (cmdPub - hcLoadI32(&HCB.cmdDone) < HC_CMDS - 1) break; __builtin_amdgcn_s_sleep(1); }   // (the payload slot of an insert that old has been read)
-          HcIns& in = HCB.ins[insSeq & (HC_CMDS - 1)];
+          HcIns& in = HCB.ins[insSeq & (HC_CMDS - 1)];   // (free: an insert sixteen inserts old has been read)
           if (lane == v) { in.key = h.key; in.node = h.node; in.ex0 = h.ex0; in.ex1 = h.ex1; in.cls = h.cls; h.state = 2; h.seq = insSeq; }
           LDS_ORDER();
-          hcPost(cmdPub, HC_I, insSeq, nullptr, 0);
+          hcPostA(cmdPub, HC_I, insSeq);
           insSeq++;
         }
       } else if (src == 1) total--;
@@ -468,14 +508,16 @@ template <int E> __device__ static void engineStreamHcT(Dev& d, KREF k, FastS& E
     // ---- the front runs low: gather it again from its first remaining entry
     if (src == 2) {
       const unsigned long long left = __ballot(cf.node >= 0);
-      if (__popcll(left) <= HC_CF_LOW && cfG < N) {
-        cfFill = left ? __builtin_amdgcn_readlane(cf.pos, (int)__builtin_ctzll(left)) : cfG;
-      }
+      if (__popcll(left) <= HC_CF_LOW && cfG < N) cfFill = left ? __builtin_amdgcn_readlane(cf.pos, (int)__builtin_ctzll(left)) : cfG;
     }
+    cur = nxt; haveCur = haveNext;
     ESEG(6);   // [22] gathering the front
   }
+#ifdef ASCHED_FASTPROF
+  if (lane == 0) { g_rs.statSeg[29] += pSrc[0] * 1000ll; g_rs.statSeg[30] += pSrc[1] * 1000ll; g_rs.statSeg[31] += pSrc[2] * 1000ll; g_rs.statSeg[32] += pSrc[3] * 1000ll; g_rs.statSeg[33] += pBehind * 1000ll; g_rs.statSeg[34] += pFill * 1000ll; g_rs.statSeg[35] += pDry * 1000ll; g_rs.statSeg[36] += pRepWait * 1000ll; }   // picks from H / C / front / behind the front; jobs no front lane fitted; front gathers; ring-dry waits; polls of the answer
+#endif
   // ---- session end: C compacts the LDS list; H's entries are appended; a pending failure is reported after the structure is whole again
-  hcPost(cmdPub, HC_E, 0, nullptr, 0);
+  hcPostA(cmdPub, HC_E, 0);
   for (;;) { if (hcLoadI32(&HCB.cmdDone) == cmdPub) break; __builtin_amdgcn_s_sleep(1); }
   LDS_ORDER();
   {
