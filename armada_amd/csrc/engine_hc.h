@@ -25,17 +25,19 @@
 //   HC_E  the session ends: compact the LDS list, publish its length
 #pragma once
 
-#define HC_CMDS 16
+#define HC_CMDS 32
+#define HC_INS 16      // payload slots of entries H hands over (at most HC_INS / 2 are in flight)
 enum { HC_Q = 1, HC_I, HC_D, HC_C, HC_E };
 struct alignas(16) HcCmd { int32_t type, a; uint64_t fieldMin; int64_t ex0, ex1; int32_t cls, seq; uint64_t pad[2]; };
 struct alignas(16) HcRep { int32_t seq, slot; uint64_t key; int32_t node, insDone; int64_t ex0, ex1; uint64_t cls; uint64_t pad; };
 struct alignas(16) HcIns { uint64_t key; int32_t node, pad; int64_t ex0, ex1; uint64_t cls; uint64_t pad2[2]; };
 struct HcBox {
-  int32_t cmdPub, cmdDone, overflow, pad0;
+  int32_t cmdPub, cmdDone, overflow, insDone;   // insDone: hand-overs wave 3 has taken in (-1: its list overflowed)
+  unsigned long long clb[128];                  // per fit shape: a LOWER bound of the smallest key in C the shape fits on (0: not known yet); written by wave 3 only
   int32_t scratch[64];
   int16_t freeStack[512];
   int32_t insSlot[HC_CMDS];
-  HcCmd cmd[HC_CMDS]; HcRep rep[4]; HcIns ins[HC_CMDS];
+  HcCmd cmd[HC_CMDS]; HcRep rep[4]; HcIns ins[HC_INS];
 };
 static_assert(sizeof(HcCmd) == 64 && sizeof(HcRep) == 64 && sizeof(HcIns) == 64, "HC mailbox records are 64 bytes");
 static_assert(sizeof(HcBox) <= sizeof(g_fl.evWin), "the HC mailbox lives in the idle key windows");
@@ -105,6 +107,9 @@ template <int E> __device__ static void coldSession(Dev& d, KREF k) {
   HcRows rows;
   int hi = __builtin_amdgcn_readfirstlane(g_fl.l0Count);   // slots [0, hi) are entries or holes
   int nfree = 0, insDone = 0, overflow = 0;
+  ShapeReq sq[2];   // what fit shapes (lane, lane + 64) need: an entry handed over lowers the bound of every shape it fits
+#pragma unroll
+  for (int x = 0; x < 2; x++) { const int t = lane + 64 * x; if (t < k.S) sq[x] = d.shapeTab[t]; else { sq[x].fieldMin = 0; sq[x].ex0 = sq[x].ex1 = 0; sq[x].cls = 0; sq[x].never = 1; } }
 #pragma unroll
   for (int r = 0; r < HC_ROWS; r++) {
     const int s = r * 64 + lane;
@@ -146,14 +151,14 @@ template <int E> __device__ static void coldSession(Dev& d, KREF k) {
         const unsigned long long mn = hcMinKey(best, &bl);
         const int slot = bl >= 0 ? __builtin_amdgcn_readlane(bs, bl) : -1;
         HcRep& o = HCB.rep[seq & 3];
-        if (lane == 0) { o.slot = slot; o.key = mn; o.insDone = overflow ? -1 : insDone; }
+        if (lane == 0) { o.slot = slot; o.key = mn; o.insDone = overflow ? -1 : insDone; HCB.clb[a & 127] = mn; }   // (the exact minimum is the best bound there is; ~0: no entry fits)
         LDS_ORDER();
         hcStoreI32(&o.seq, seq);
       } else if (type == HC_I) {
 #ifdef ASCHED_FASTPROF
         cI++;
 #endif
-        const HcIns& in = HCB.ins[a & (HC_CMDS - 1)];
+        const HcIns& in = HCB.ins[a & (HC_INS - 1)];
         const unsigned long long key = UNI64(in.key), cls = UNI64(in.cls); const long long ex0 = (long long)UNI64(in.ex0), ex1 = (long long)UNI64(in.ex1);
         const int node = __builtin_amdgcn_readfirstlane(in.node);
         int slot;
@@ -165,8 +170,15 @@ template <int E> __device__ static void coldSession(Dev& d, KREF k) {
           if (lane == 0) { g_fl.l0Key[slot] = key; g_fl.l0Node[slot] = node; g_fl.l0Ex0[slot] = ex0; g_fl.l0Ex1[slot] = ex1; g_fl.l0Cls[slot] = cls; g_fl.l0Cls2[slot] = 0; HCB.insSlot[a & (HC_CMDS - 1)] = slot; }
           LANE0_PUBLISHED();
           hcRowSetAt(rows, slot, key, ex0, ex1, cls);
+#pragma unroll
+          for (int x = 0; x < 2; x++) {   // every fit shape the entry fits: its bound may not stay above the entry's key
+            HcNeed nq; nq.fmin = sq[x].fieldMin; nq.ex0 = sq[x].ex0; nq.ex1 = sq[x].ex1; nq.cls = sq[x].cls;
+            if (!sq[x].never && hcFits<E>(G, nq, key, cls, ex0, ex1)) (void)__hip_atomic_fetch_min(&HCB.clb[lane + 64 * x], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
         }
         insDone = a + 1;
+        LDS_ORDER();
+        hcStoreI32(&HCB.insDone, overflow ? -1 : insDone);
       } else if (type == HC_D || type == HC_C) {
         const int slot = type == HC_D ? a : __builtin_amdgcn_readfirstlane(HCB.insSlot[a & (HC_CMDS - 1)]);
         if (slot >= 0) {
@@ -228,84 +240,111 @@ __device__ static void coldLoop(Dev& d) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------ wave 1: hot set + clean front
+// ------------------------------------------------------------------------------------------------ wave 1: hot set + per-shape clean candidates
 struct HcHot { unsigned long long key, cls; long long ex0, ex1; int node, state, seq; };   // state 0 empty, 1 entry, 2 entry handed to C (insert `seq` in flight)
-struct HcFront { unsigned long long key, cls; long long ex0, ex1; int node, pos; };           // node -1: no entry in this lane
-
-// the clean front from base position `from` on: the next <= 64 clean entries in base order.  Returns G: every clean entry in [from, G) is in a lane.
-__device__ static inline int hcFrontFill(KREF k, FastS& ES, HcFront& cf, int from) {   // (inlined at its ONE call site: a call would put the front and the loop constants in memory)
+// The clean side: fastFirstFit's per-shape base cursor (FL.cand, round_fast.h) held in registers for the session, two fit shapes per lane (lane, lane + 64), plus the
+// bitmap word ("clean and fits", d.fitBits) the cursor stands in.  A consumed candidate's successor is then known without a memory access (the next set bit); its
+// fields cost ONE HBM round trip, fetched on demand for every shape that lacks them at once (hcShapesFetch).  st: 0 nothing left, 1 scanning from pos (inclusive), 2 the
+// head candidate at pos has its fields here.  lb: key of the candidate consumed last = a lower bound for what the base can still offer the shape (the base is sorted).
+enum { SC_NONE = 0, SC_SCAN = 1, SC_HEAD = 2 };
+struct HcShapes { int pos[2], st[2], node[2], wIdx[2]; unsigned long long w[2], key[2], cls[2], lb[2]; long long ex0[2], ex1[2]; };
+__device__ static inline void hcShapesLoad(KREF k, HcShapes& sc) {   // from the LDS cursors, as the serial engine left them
   const int lane = threadIdx.x & 63;
-  const int N = k.N;
-  int have = 0, pos0 = from, G = from;
-  cf.node = -1; cf.pos = -1;
-  bool seenClean = false;
-  for (int w = 0; w < 32 && have < 64 && pos0 < N; w++, pos0 += 64) {
-    const int p = pos0 + lane;
-    const int rem = p < N ? (int)__hip_atomic_load(&k.baseRemoved[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1;
+#pragma unroll
+  for (int x = 0; x < 2; x++) {
+    const int s = lane + 64 * x;
+    sc.st[x] = SC_NONE; sc.pos[x] = 0; sc.node[x] = -1; sc.wIdx[x] = -1; sc.w[x] = 0; sc.key[x] = 0; sc.cls[x] = 0; sc.lb[x] = 0; sc.ex0[x] = 0; sc.ex1[x] = 0;
+    if (s < k.S) {
+      const CandRec c = g_fl.cand[s];
+      if (c.node >= 0) { sc.st[x] = SC_HEAD; sc.pos[x] = c.pos; sc.node[x] = c.node; sc.key[x] = c.key; sc.cls[x] = c.cls; sc.ex0[x] = c.ex0; sc.ex1[x] = c.ex1; }
+      else if (c.node == -2) { sc.st[x] = SC_SCAN; sc.pos[x] = c.pos + (c.key != 0 ? 1 : 0); sc.lb[x] = c.key; }   // (a stale candidate: the entry at the cursor is the one that was used up)
+    }
+  }
+}
+__device__ static inline void hcShapesStore(KREF k, const HcShapes& sc) {   // back into the LDS cursors, in the serial engine's terms
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int x = 0; x < 2; x++) {
+    const int s = lane + 64 * x;
+    if (s < k.S) {
+      CandRec c; c.pad = 0;
+      if (sc.st[x] == SC_HEAD) { c.pos = sc.pos[x]; c.node = sc.node[x]; c.key = sc.key[x]; c.cls = sc.cls[x]; c.ex0 = sc.ex0[x]; c.ex1 = sc.ex1[x]; }
+      else if (sc.st[x] == SC_SCAN) { c.node = -2; c.key = sc.lb[x]; c.pos = sc.lb[x] != 0 ? sc.pos[x] - 1 : sc.pos[x]; c.cls = 0; c.ex0 = c.ex1 = 0; }   // (baseScan starts behind a stale candidate's position, at a fresh cursor's)
+      else { c.node = -1; c.pos = k.N; c.key = 0; c.cls = 0; c.ex0 = c.ex1 = 0; }
+      g_fl.cand[s] = c;
+    }
+  }
+}
+// base position P was used up: its bit leaves every cached word; a shape whose head it was scans on from behind it
+__device__ static inline void hcShapesUsed(HcShapes& sc, int P) {
+  const int wi = P >> 6; const unsigned long long bit = 1ull << (P & 63);
+#pragma unroll
+  for (int x = 0; x < 2; x++) {
+    sc.w[x] = sc.wIdx[x] == wi ? sc.w[x] & ~bit : sc.w[x];
+    const bool was = (sc.st[x] == SC_HEAD) & (sc.pos[x] == P);
+    sc.lb[x] = was ? sc.key[x] : sc.lb[x]; sc.pos[x] = was ? P + 1 : sc.pos[x]; sc.st[x] = was ? SC_SCAN : sc.st[x];
+  }
+}
+// every scanning shape advances to its next candidate (bitmap word where the cached one does not cover the cursor: one HBM round trip; then the candidate's fields and
+// its removed flag: one more) until fit shape `target` has a head or nothing left.  The removed flag guards against a bit whose clearing is still on its way to L2.
+__device__ static inline void hcShapesFetch(KREF k, FastS& ES, HcShapes& sc, int target) {
+  const int lane = threadIdx.x & 63;
+  const int tx = target >> 6, tl = target & 63;
+  for (;;) {
+    unsigned long long nw[2]; bool needW[2];
+#pragma unroll
+    for (int x = 0; x < 2; x++) {
+      const int s = lane + 64 * x, wi = sc.pos[x] >> 6;
+      if (sc.st[x] == SC_SCAN && wi >= k.fitW) sc.st[x] = SC_NONE;
+      needW[x] = sc.st[x] == SC_SCAN && sc.wIdx[x] != wi;
+      nw[x] = 0;
+      if (needW[x]) nw[x] = __hip_atomic_load(&k.fitBits[(size_t)s * k.fitW + wi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     ES.statScanSteps++;
-    const unsigned long long b = __ballot(rem == 0);
-    if (!seenClean) {   // nothing clean before this position: where the next session's front may start (this launch)
-      if (b) { seenClean = true; hcStoreI32(&g_fl.eng.cleanFrom, pos0 + (__ffsll((long long)b) - 1)); } else hcStoreI32(&g_fl.eng.cleanFrom, pos0 + 64 < N ? pos0 + 64 : N);
+    unsigned long long fKey[2], fCls[2]; long long fEx0[2], fEx1[2]; int fNode[2], fRem[2], hp[2]; bool needF[2];
+#pragma unroll
+    for (int x = 0; x < 2; x++) {
+      const int wi = sc.pos[x] >> 6;
+      if (needW[x]) { sc.w[x] = nw[x]; sc.wIdx[x] = wi; }
+      const unsigned long long m = sc.st[x] == SC_SCAN ? sc.w[x] & (~0ull << (sc.pos[x] & 63)) : 0ull;
+      needF[x] = m != 0;
+      hp[x] = wi * 64 + (int)__builtin_ctzll(m | (1ull << 63));
+      if (sc.st[x] == SC_SCAN && m == 0) sc.pos[x] = (wi + 1) << 6;   // nothing left in this word: the next one in the next round
+      fKey[x] = 0; fCls[x] = 0; fEx0[x] = 0; fEx1[x] = 0; fNode[x] = -1; fRem[x] = 1;
+      if (needF[x]) {
+        const int q = hp[x];
+        fRem[x] = (int)__hip_atomic_load(&k.baseRemoved[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fKey[x] = k.baseKey[q]; fCls[x] = k.baseCls[q]; fNode[x] = k.baseNode[q];
+        fEx0[x] = k.E > 0 ? k.baseExtra[q] : 0; fEx1[x] = k.E > 1 ? k.baseExtra[k.Npad + q] : 0;
+      }
     }
-    const int dst = have + __popcll(b & ((1ull << lane) - 1));
-    if (rem == 0 && dst < 64) HCB.scratch[dst] = p;
-    const int cnt = __popcll(b);
-    if (have + cnt >= 64) {   // the lane that received slot 63 ends the front
-      const unsigned long long last = __ballot(rem == 0 && dst == 63);
-      G = pos0 + (__ffsll((long long)last) - 1) + 1;
-      have = 64;
-      break;
+#pragma unroll
+    for (int x = 0; x < 2; x++) {
+      if (needF[x]) {
+        if (fRem[x]) { sc.w[x] &= ~(1ull << (hp[x] & 63)); sc.pos[x] = hp[x] + 1; }
+        else { sc.st[x] = SC_HEAD; sc.pos[x] = hp[x]; sc.key[x] = fKey[x]; sc.cls[x] = fCls[x]; sc.node[x] = fNode[x]; sc.ex0[x] = fEx0[x]; sc.ex1[x] = fEx1[x]; }
+      }
     }
-    have += cnt;
-    G = pos0 + 64 < N ? pos0 + 64 : N;
+    const int ts = tx ? __builtin_amdgcn_readlane(sc.st[1], tl) : __builtin_amdgcn_readlane(sc.st[0], tl);
+    if (ts != SC_SCAN) return;
   }
-  LDS_ORDER();
-  const int q = lane < have ? HCB.scratch[lane] : -1;
-  LDS_ORDER();
-  if (q >= 0) {
-    cf.pos = q; cf.key = k.baseKey[q]; cf.cls = k.baseCls[q]; cf.node = k.baseNode[q];
-    cf.ex0 = k.E > 0 ? k.baseExtra[q] : 0; cf.ex1 = k.E > 1 ? k.baseExtra[k.Npad + q] : 0;
-  }
-  return G;
-}
-// a clean entry is used up (fastAfterBind's base branch): its flag and bitmap bits, every shape's candidate that named it
-__device__ static inline void hcCleanUsed(KREF k, FastS& ES, int pos, int n) {
-  baseMarkRemoved(k, ES, pos);
-  candInvalidate(k.S, n);
-}
-// no lane of the front fits: the shape's own cursor behind the front (fastFirstFit's rule).  Returns 1 when the candidate c is the pick, 0 when the dirty candidate (key lk) is, -1: no node.
-__device__ static inline int hcBehindFront(KREF k, FastS& ES, const JobTail& r, unsigned long long lk, int cfG, CandRec* cOut) {
-  const int lane = threadIdx.x & 63;
-  const int s = r.shape;
-  CandRec c = g_fl.cand[s]; uniCand(c);
-  if (c.node != -1 && c.pos < cfG) {   // every clean entry in front of cfG is in a lane and none fits: the cursor moves up to the front's end
-    c.node = -2;
-    if (c.key != 0) c.pos = cfG - 1; else c.pos = cfG;   // baseScan starts behind a stale candidate's position, at a fresh cursor's
-    if (lane == 0) { g_fl.cand[s].pos = c.pos; g_fl.cand[s].node = -2; }
-    LANE0_PUBLISHED();
-  }
-  if (c.node == -2 && !(lk < c.key)) { baseScan(k, ES, r); c = g_fl.cand[s]; uniCand(c); }
-  const unsigned long long bk = c.node >= 0 ? c.key : (c.node == -2 ? c.key : ~0ull);
-  *cOut = c;
-  if (lk < bk) return 0;
-  return c.node >= 0 ? 1 : -1;
 }
 
 // a ring entry as the engine's lanes hold it (every lane the same words: vector operands; nothing is moved to scalar registers unless a branch needs it)
-struct HcJobV { unsigned long long keyDelta, fmin; long long ex0, ex1; int cls, never, rq, pub; };
+struct HcJobV { unsigned long long keyDelta, fmin; long long ex0, ex1; int cls, never, rq, pub, shape; };
 // ring entry idx and the publication counter in ONE batch of LDS reads (the counter first: LDS executes a wave's reads in order, so an entry the counter covers is complete)
 __device__ static inline void hcLoadEntry(int idx, HcJobV& o) {
   o.pub = __hip_atomic_load(&g_fl.eng.ringPub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   LDS_ORDER();   // (no instruction: it keeps the compiler from moving the entry's reads in front of the counter's)
   o.rq = RQ(idx);
   const JobTail& t = *(const JobTail*)&RREC(idx).keyDelta;
-  o.keyDelta = t.keyDelta; o.fmin = t.fieldMin; o.cls = t.cls; o.never = (int)t.never; o.ex0 = t.ex0; o.ex1 = t.ex1;
+  o.keyDelta = t.keyDelta; o.fmin = t.fieldMin; o.cls = t.cls; o.never = (int)t.never; o.ex0 = t.ex0; o.ex1 = t.ex1; o.shape = t.shape;
 }
 // a command for wave 3 (no look at the ring's space: once the answer to a job's question is in, everything posted before that question is done, and a job posts at most
-// four commands — the ring holds sixteen)
+// three commands — the ring holds sixteen)
 __device__ static inline void hcPostQ(int& cmdPub, const HcJobV& j, int seq) {
   HcCmd& c = HCB.cmd[cmdPub & (HC_CMDS - 1)];
-  if ((threadIdx.x & 63) == 0) { c.type = HC_Q; c.a = 0; c.seq = seq; c.fieldMin = j.fmin; c.ex0 = j.ex0; c.ex1 = j.ex1; c.cls = j.cls; }
+  if ((threadIdx.x & 63) == 0) { c.type = HC_Q; c.a = j.shape; c.seq = seq; c.fieldMin = j.fmin; c.ex0 = j.ex0; c.ex1 = j.ex1; c.cls = j.cls; }
   LDS_ORDER();
   cmdPub++;
   hcStoreI32(&HCB.cmdPub, cmdPub);
@@ -320,53 +359,35 @@ __device__ static inline void hcPostA(int& cmdPub, int type, int a) {
 
 // One ring session with the split structure.  Same contract as the ENG_STREAM walk of engineLoop: entry i is ready when ringPub > i; the chosen node goes into the
 // ring entry (the bind wave issues the HBM side); ringAck counts the entries placed; ringFail 1 = entry ringAck found no node, 2 = the list overflowed.
-// The loop is written around two costs measured on the MI355X (profiles/r06f_hc_segments.txt): ~8 shader clocks per instruction of a lone wave, ~140 per dependent LDS
-// round trip.  Per job: ONE batch of LDS reads for the next entry (issued before the tests, used after the decision) and one for the cold set's answer.
-template <int E> __device__ static void engineStreamHcT(Dev& d, KREF k, FastS& ES) {
+// The loop is written around two costs measured on the MI355X (profiles/r06g_hc_engine_segments.txt): ~8 shader clocks per instruction of a lone wave, ~140 per
+// dependent LDS round trip.  Per job: ONE batch of LDS reads for the next entry and the cold set's answer (issued before the tests, used after them).
+// (A function of its own, not inlined: inside engineLoop its loop shared the register allocation of the serial engine's paths and lived partly in AGPRs.  Its constants
+// and counters are copied in and out: nothing in the loop goes through the references.)
+template <int E> __device__ static __attribute__((noinline)) void engineStreamHcT(Dev& d, const FastK& kRef, FastS& ESRef) {
+  const FastK k = kRef;
+  FastS ES = ESRef;
   const int lane = threadIdx.x & 63;
   const unsigned long long G = UNI64(k.guardMask), MFM = UNI64(k.minFieldMin);
   const long long ME0 = (long long)UNI64(k.minEx0), ME1 = (long long)UNI64(k.minEx1);
-  const int N = UNI32(k.N);
-  // ---- session start: the mailbox, wave 3, the clean front
-  if (lane == 0) { HCB.cmdPub = 0; HCB.cmdDone = 0; HCB.overflow = 0; for (int x = 0; x < 4; x++) HCB.rep[x].seq = -1; }
+  // ---- session start: the mailbox, wave 3, the shapes' cursors
+  if (lane == 0) { HCB.cmdPub = 0; HCB.cmdDone = 0; HCB.overflow = 0; HCB.insDone = 0; for (int x = 0; x < 4; x++) HCB.rep[x].seq = -1; }
+  HCB.clb[lane] = 0; HCB.clb[lane + 64] = 0;   // no shape's bound is known yet: its first job asks
   LDS_ORDER();
   hcStoreI32(&g_fl.eng.hcGen, __builtin_amdgcn_readfirstlane(g_fl.eng.hcGen) + 1);
-  int cmdPub = 0, insSeq = 0, rrNext = 0;
+  int cmdPub = 0, insSeq = 0, rrNext = 0, qSeq = 0;
   HcHot h; h.key = ~0ull; h.cls = 0; h.ex0 = h.ex1 = 0; h.node = -1; h.state = 0; h.seq = 0;
-  HcFront cf;
-  int cfG;
-  {   // no clean entry a job could fit on lies before the smallest shape cursor
-    unsigned mp = 0xffffffffu;
-    for (int s = lane; s < k.S; s += 64) { unsigned p = (unsigned)g_fl.cand[s].pos; mp = p < mp ? p : mp; }
-    unsigned m = hcMin32(mp);
-    const unsigned cfrom = (unsigned)__builtin_amdgcn_readfirstlane(g_fl.eng.cleanFrom);
-    if (m == 0xffffffffu) m = (unsigned)N;
-    if (cfrom > m) m = cfrom;
-    cf.node = -1; cf.pos = -1; cf.key = 0; cf.cls = 0; cf.ex0 = cf.ex1 = 0;
-    cfG = (int)m < N ? (int)m : N;   // (the front is gathered at the top of the loop: cfFill)
-  }
-#ifdef HC_NO_CF
-  cfG = 0;   // (debugging: no clean front — every clean candidate through the shape cursors)
-  int cfFill = -1;
-#else
-  int cfFill = cfG;   // >= 0: gather the front from this base position before the next job
-#endif
+  HcShapes sc; hcShapesLoad(k, sc);
   int total = __builtin_amdgcn_readfirstlane(g_fl.l0Count);   // dirty nodes alive (H + C): the list's high-water mark for round_stats
-  int i = 0, qUpTo = 0, fail = 0;
+  int i = 0, fail = 0;
   HcJobV cur; bool haveCur = false;
 #ifdef ASCHED_FASTPROF
-  int pSrc[4] = {0, 0, 0, 0}, pBehind = 0, pFill = 0, pDry = 0, pRepWait = 0;
+  int pSrc[4] = {0, 0, 0, 0}, pFetch = 0, pDry = 0, pAsk = 0;
 #endif
   for (;;) {
-    if (cfFill >= 0) { cfG = hcFrontFill(k, ES, cf, cfFill); cfFill = -1;
-#ifdef ASCHED_FASTPROF
-      pFill++;
-#endif
-    }
-    if (!haveCur) {
+    if (!haveCur) {   // the ring ran dry (or the session starts): wait for entry i
 #ifdef ASCHED_FASTPROF
       pDry++;
-#endif   // the ring ran dry (or the session starts): wait for entry i
+#endif
       for (;;) {
         hcLoadEntry(i, cur);
         if (__builtin_amdgcn_readfirstlane(cur.pub) > i) break;
@@ -384,139 +405,148 @@ template <int E> __device__ static void engineStreamHcT(Dev& d, KREF k, FastS& E
     }
     if ((++ES.engSeq & 255) == 0 && cancelRequested(d)) { if (lane == 0) g_fl.eng.cancel = 1; LANE0_PUBLISHED(); fail = 1; break; }
     if (__builtin_amdgcn_readfirstlane(cur.never)) { fail = 1; break; }
-    if (qUpTo <= i) { hcPostQ(cmdPub, cur, i); qUpTo = i + 1; }
-#ifndef HC_NO_CF
-    if (cfG < N && __ballot(cf.node >= 0) == 0) { cfFill = cfG; continue; }   // the front is used up (or its stretch of the base held nothing clean): the next stretch first
-#endif
-    // ---- the next entry and the cold set's answer: their LDS reads are in flight during the tests
+    // ---- ONE batch of LDS reads, in flight during the tests: the next entry, wave 3's hand-over counter, then the shape's lower bound for the cold set
     HcJobV nxt; hcLoadEntry(i + 1, nxt);
-    HcRep& rp = HCB.rep[i & 3];
-    int rSeq = __hip_atomic_load(&rp.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    LDS_ORDER();
-    int rSlot = rp.slot, rIns = rp.insDone; unsigned long long rKey = rp.key;
-    // ---- H and the clean front: one test per lane each
+    const int rIns = __hip_atomic_load(&HCB.insDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    LDS_ORDER();   // (the bound is read behind the counter: a hand-over the counter covers has lowered it already)
+    const unsigned long long rLb = HCB.clb[cur.shape & 127];
+    // ---- H: one test per lane, the 64-lane minimum
     HcNeed q; q.fmin = cur.fmin; q.ex0 = cur.ex0; q.ex1 = cur.ex1; q.cls = cur.cls;
     const bool fitH = (h.state != 0) & hcFits<E>(G, q, h.key, h.cls, h.ex0, h.ex1);
     int hLane;
     unsigned long long hk = hcMinKey(fitH ? h.key : ~0ull, &hLane);
-#ifdef HC_NO_CF
-    const unsigned long long bCf = 0;
-#else
-    const unsigned long long bCf = __ballot((cf.node >= 0) & hcFits<E>(G, q, cf.key, cf.cls, cf.ex0, cf.ex1));
-#endif
-    const int cfLane = bCf ? (int)__builtin_ctzll(bCf) : -1;
-    ESEG(1);   // [17] H and front tests
-    // ---- the cold set's answer for this job
-    while (__builtin_amdgcn_readfirstlane(rSeq) != i) {
-#ifdef ASCHED_FASTPROF
-      pRepWait++;
-#endif
-      __builtin_amdgcn_s_sleep(1);
-      rSeq = __hip_atomic_load(&rp.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      LDS_ORDER();
-      rSlot = rp.slot; rIns = rp.insDone; rKey = rp.key;
-    }
-    ESEG(2);   // [18] waiting for the cold set's answer
-    const int cSlot = __builtin_amdgcn_readfirstlane(rSlot), insDone = __builtin_amdgcn_readfirstlane(rIns);
-    const unsigned long long ck = UNI64(rKey);   // (~0 when no entry fits)
+    // ---- the shape's clean candidate as it stands
+    const int shape = __builtin_amdgcn_readfirstlane(cur.shape), sx = shape >> 6, sl = shape & 63;
+    int cst = sx ? __builtin_amdgcn_readlane(sc.st[1], sl) : __builtin_amdgcn_readlane(sc.st[0], sl);
+    unsigned long long cKey = sx ? hcRead64(sc.key[1], sl) : hcRead64(sc.key[0], sl);        // (SC_HEAD: the candidate's key)
+    const unsigned long long cLb = sx ? hcRead64(sc.lb[1], sl) : hcRead64(sc.lb[0], sl);     // (SC_SCAN: a lower bound)
+    ESEG(1);   // [17] H test, clean candidate
+    int insDone = __builtin_amdgcn_readfirstlane(rIns);
     if (insDone < 0) { fail = 2; break; }   // the cold list overflowed
-    {   // entries whose hand-over to C this answer already counts leave H; the best lane among them: the answer is at least as good (it saw that very entry)
+    {   // entries whose hand-over wave 3 has taken in leave H: the bound read behind the counter covers them.  The best lane among them: ask C (it has that very entry)
       const bool rel = (h.state == 2) & (h.seq < insDone);
       const unsigned long long rb = __ballot(rel);
-      if (rb) {
-        if (rel) { h.state = 0; h.node = -1; h.key = ~0ull; }
-        if (hLane >= 0 && ((rb >> hLane) & 1)) { hLane = -1; hk = ~0ull; }
-      }
+      h.state = rel ? 0 : h.state; h.node = rel ? -1 : h.node; h.key = rel ? ~0ull : h.key;
+      const bool drop = hLane >= 0 && ((rb >> hLane) & 1);
+      hLane = drop ? -1 : hLane; hk = drop ? ~0ull : hk;
     }
-    // ---- first fit = min(H, C, clean): fastFirstFit's rule with the front in place of the shape's cursor
-    const unsigned long long lk = hk < ck ? hk : ck;
-    int src;   // 0 H, 1 C, 2 front, 3 the shape's cursor behind the front
-    CandRec c; c.node = -1; c.pos = 0; c.key = 0; c.cls = 0; c.ex0 = c.ex1 = 0; c.pad = 0;
-    if (cfLane >= 0) {
-      const unsigned long long fk = hcRead64(cf.key, cfLane);
-      src = lk < fk ? (hk < ck ? 0 : 1) : 2;
-    } else {
+    // ---- does the cold set matter?  Only when its bound lies below both the hot candidate and the clean candidate at hand: then the exact answer, synchronously (rare)
+    const unsigned long long ckLb = UNI64(rLb);
+    const unsigned long long known = cst == SC_HEAD && cKey < hk ? cKey : hk;
+    unsigned long long ck = ~0ull; int cSlot = -1;
+    if (ckLb < known) {
 #ifdef ASCHED_FASTPROF
-      pBehind++;
+      pAsk++;
 #endif
-      JobTail r = *(const JobTail*)&RREC(i).keyDelta; uniJobTail(r);
-      const int v = hcBehindFront(k, ES, r, lk, cfG, &c);
-      if (v < 0) { fail = 1; break; }
-      src = v ? 3 : (hk < ck ? 0 : 1);
+      hcPostQ(cmdPub, cur, qSeq);
+      HcRep& rp = HCB.rep[qSeq & 3];
+      for (;;) { if (hcLoadI32(&rp.seq) == qSeq) break; __builtin_amdgcn_s_sleep(1); }
+      LDS_ORDER();
+      qSeq++;
+      cSlot = __builtin_amdgcn_readfirstlane(rp.slot); ck = UNI64(rp.key);
+      insDone = __builtin_amdgcn_readfirstlane(rp.insDone);
+      if (insDone < 0) { fail = 2; break; }
+      const bool rel = (h.state == 2) & (h.seq < insDone);   // the answer counts these hand-overs: the entries are C's now
+      const unsigned long long rb = __ballot(rel);
+      h.state = rel ? 0 : h.state; h.node = rel ? -1 : h.node; h.key = rel ? ~0ull : h.key;
+      const bool drop = hLane >= 0 && ((rb >> hLane) & 1);
+      hLane = drop ? -1 : hLane; hk = drop ? ~0ull : hk;
     }
+    ESEG(2);   // [18] the cold set: bound, or question and answer
+    // ---- first fit = min(H, C, clean): fastFirstFit's rule
+    const unsigned long long lk = hk < ck ? hk : ck;
+    if (cst == SC_SCAN && !(lk < cLb)) {   // the base may hold something better than the dirty candidate: the shape's next clean candidate (and every other scanning shape's)
+#ifdef ASCHED_FASTPROF
+      pFetch++;
+#endif
+      hcShapesFetch(k, ES, sc, shape);
+      cst = sx ? __builtin_amdgcn_readlane(sc.st[1], sl) : __builtin_amdgcn_readlane(sc.st[0], sl);
+      cKey = sx ? hcRead64(sc.key[1], sl) : hcRead64(sc.key[0], sl);
+      // (the cold set needs no second look: it was asked above unless its bound lies at or above the hot candidate, and then it cannot win whatever the base offers)
+    }
+    const unsigned long long lk2 = hk < ck ? hk : ck;
+    const unsigned long long bk = cst == SC_HEAD ? cKey : (cst == SC_SCAN ? cLb : ~0ull);
+    int src;   // 0 H, 1 C, 2 the shape's clean candidate
+    if (lk2 < bk) src = hk < ck ? 0 : 1;
+    else if (cst == SC_HEAD) src = 2;
+    else { fail = 1; break; }
     // ---- the pick: its node goes to the bind wave at once; its level-0 entry after the bind (fastAfterBind) is worked out where it lives
     int n;
     if (src == 0) n = __builtin_amdgcn_readlane(h.node, hLane);
     else if (src == 1) n = __builtin_amdgcn_readfirstlane(g_fl.l0Node[cSlot]);
-    else if (src == 2) n = __builtin_amdgcn_readlane(cf.node, cfLane);
-    else n = c.node;
+    else n = sx ? __builtin_amdgcn_readlane(sc.node[1], sl) : __builtin_amdgcn_readlane(sc.node[0], sl);
 #ifdef ASCHED_FASTPROF
     pSrc[src & 3]++;
 #endif
-    ESEG(3);   // [19] the three-way minimum (incl. a base rescan behind the front)
-    if (lane == 0) RREC(i).node0 = n;
-    LANE0_PUBLISHED();
+    ESEG(3);   // [19] the three-way minimum (incl. fetching clean candidates)
+    RREC(i).node0 = n;   // (every lane stores the same word)
     LDS_ORDER();
     i++;
     hcStoreI32(&g_fl.eng.ringAck, i);
-    // ---- what C must know before it answers for the next job, then the next job's question
+    // ---- what C must know: an entry it gives up, a hand-over taken back
     if (src == 1) hcPostA(cmdPub, HC_D, cSlot);
     if (src == 0 && __builtin_amdgcn_readlane(h.state, hLane) == 2) hcPostA(cmdPub, HC_C, __builtin_amdgcn_readlane(h.seq, hLane));
     const bool haveNext = __builtin_amdgcn_readfirstlane(nxt.pub) > i;
-    if (haveNext && !(__builtin_amdgcn_readfirstlane(nxt.rq) & RQ_EV) && !__builtin_amdgcn_readfirstlane(nxt.never)) { hcPostQ(cmdPub, nxt, i); qUpTo = i + 1; }
-    ESEG(4);   // [20] verdict, commands, the next job's question
+    ESEG(4);   // [20] verdict, commands
     // ---- the bind's effect on the node's level-0 entry: key and extras go down; an entry that can no longer host anything is dropped
     if (src == 0) {   // in place, in its lane
       const unsigned long long nk = h.key - cur.keyDelta; const long long n0 = h.ex0 - cur.ex0, n1 = h.ex1 - cur.ex1;
       const bool alive = ((((nk | G) - MFM) & G) == G) & (ME0 <= n0) & (ME1 <= n1);
-      if (lane == hLane) { if (alive) { h.key = nk; h.ex0 = n0; h.ex1 = n1; h.state = 1; } else { h.state = 0; h.node = -1; h.key = ~0ull; } }
-      if (__ballot((lane == hLane) & !alive)) total--;
+      const bool me = lane == hLane;
+      h.key = me ? (alive ? nk : ~0ull) : h.key; h.ex0 = me ? n0 : h.ex0; h.ex1 = me ? n1 : h.ex1; h.state = me ? (alive ? 1 : 0) : h.state; h.node = (me & !alive) ? -1 : h.node;
+      if (__ballot(me & !alive)) total--;
     } else {
-      unsigned long long okey, ocls; long long oex0, oex1; int usedPos = 0;
+      unsigned long long okey, ocls; long long oex0, oex1;
       if (src == 1) { okey = ck; ocls = UNI64(g_fl.l0Cls[cSlot]); oex0 = (long long)UNI64(g_fl.l0Ex0[cSlot]); oex1 = (long long)UNI64(g_fl.l0Ex1[cSlot]); }
-      else if (src == 2) {
-        okey = hcRead64(cf.key, cfLane); ocls = hcRead64(cf.cls, cfLane); oex0 = (long long)hcRead64((unsigned long long)cf.ex0, cfLane); oex1 = (long long)hcRead64((unsigned long long)cf.ex1, cfLane);
-        usedPos = __builtin_amdgcn_readlane(cf.pos, cfLane);
-        if (lane == cfLane) cf.node = -1;
-      } else { okey = c.key; ocls = c.cls; oex0 = c.ex0; oex1 = c.ex1; usedPos = c.pos; }
-      if (src >= 2) hcCleanUsed(k, ES, usedPos, n);
+      else {
+        okey = cKey;
+        ocls = sx ? hcRead64(sc.cls[1], sl) : hcRead64(sc.cls[0], sl);
+        oex0 = (long long)(sx ? hcRead64((unsigned long long)sc.ex0[1], sl) : hcRead64((unsigned long long)sc.ex0[0], sl));
+        oex1 = (long long)(sx ? hcRead64((unsigned long long)sc.ex1[1], sl) : hcRead64((unsigned long long)sc.ex1[0], sl));
+        const int usedPos = sx ? __builtin_amdgcn_readlane(sc.pos[1], sl) : __builtin_amdgcn_readlane(sc.pos[0], sl);
+        baseMarkRemoved(k, ES, usedPos);   // a clean entry is used up (fastAfterBind's base branch): its flag and bitmap bits; the shapes' cursors are in registers here
+        hcShapesUsed(sc, usedPos);
+      }
       const unsigned long long nk = okey - UNI64(cur.keyDelta); const long long n0 = oex0 - (long long)UNI64(cur.ex0), n1 = oex1 - (long long)UNI64(cur.ex1);
       const bool alive = ((((nk | G) - MFM) & G) == G) && ME0 <= n0 && ME1 <= n1;
       if (alive) {
         // a free lane (there is always one: at most HC_H_MAX entries + the few in flight)
         const unsigned long long occ = __ballot(h.state != 0);
-        if (occ == ~0ull) { fail = 2; break; }   // (cannot happen: HC_H_MAX entries + the inserts in flight are fewer than the lanes; reported as an overflow if it ever does)
+        if (occ == ~0ull) { fail = 2; break; }   // (cannot happen: HC_H_MAX entries + the hand-overs in flight are fewer than the lanes; reported as an overflow if it ever does)
         const int fl = (int)__builtin_ctzll(~occ);
-        if (lane == fl) { h.key = nk; h.cls = ocls; h.ex0 = n0; h.ex1 = n1; h.node = n; h.state = 1; h.seq = 0; }
+        const bool me = lane == fl;
+        h.key = me ? nk : h.key; h.cls = me ? ocls : h.cls; h.ex0 = me ? n0 : h.ex0; h.ex1 = me ? n1 : h.ex1; h.node = me ? n : h.node; h.state = me ? 1 : h.state;
         if (src != 1) { total++; if (total > ES.statL0Max) ES.statL0Max = total; }
         // H over its size: the next entry in lane order (round robin) goes to C
         const unsigned long long normal = __ballot(h.state == 1);
         if (__popcll(normal) > HC_H_MAX) {
+          while (insSeq - insDone >= HC_INS / 2) {   // (wave 3 is far behind with the hand-overs: never seen; the payload slots and the command ring are bounded by this)
+            __builtin_amdgcn_s_sleep(1);
+            insDone = hcLoadI32(&HCB.insDone);
+            if (insDone < 0) break;
+          }
+          if (insDone < 0) { fail = 2; break; }
           const unsigned long long cand = normal & ~(1ull << fl);
           const unsigned long long hiPart = cand & (~0ull << rrNext);
           const int v = hiPart ? (int)__builtin_ctzll(hiPart) : (int)__builtin_ctzll(cand);
           rrNext = (v + 1) & 63;
-          HcIns& in = HCB.ins[insSeq & (HC_CMDS - 1)];   // (free: an insert sixteen inserts old has been read)
-          if (lane == v) { in.key = h.key; in.node = h.node; in.ex0 = h.ex0; in.ex1 = h.ex1; in.cls = h.cls; h.state = 2; h.seq = insSeq; }
+          HcIns& in = HCB.ins[insSeq & (HC_INS - 1)];
+          if (lane == v) { in.key = h.key; in.node = h.node; in.ex0 = h.ex0; in.ex1 = h.ex1; in.cls = h.cls; }
+          h.state = lane == v ? 2 : h.state; h.seq = lane == v ? insSeq : h.seq;
           LDS_ORDER();
           hcPostA(cmdPub, HC_I, insSeq);
           insSeq++;
         }
       } else if (src == 1) total--;
     }
-    ESEG(5);   // [21] hot-set / base upkeep
-    // ---- the front runs low: gather it again from its first remaining entry
-    if (src == 2) {
-      const unsigned long long left = __ballot(cf.node >= 0);
-      if (__popcll(left) <= HC_CF_LOW && cfG < N) cfFill = left ? __builtin_amdgcn_readlane(cf.pos, (int)__builtin_ctzll(left)) : cfG;
-    }
     cur = nxt; haveCur = haveNext;
-    ESEG(6);   // [22] gathering the front
+    ESEG(5);   // [21] hot-set / base upkeep
   }
 #ifdef ASCHED_FASTPROF
-  if (lane == 0) { g_rs.statSeg[29] += pSrc[0] * 1000ll; g_rs.statSeg[30] += pSrc[1] * 1000ll; g_rs.statSeg[31] += pSrc[2] * 1000ll; g_rs.statSeg[32] += pSrc[3] * 1000ll; g_rs.statSeg[33] += pBehind * 1000ll; g_rs.statSeg[34] += pFill * 1000ll; g_rs.statSeg[35] += pDry * 1000ll; g_rs.statSeg[36] += pRepWait * 1000ll; }   // picks from H / C / front / behind the front; jobs no front lane fitted; front gathers; ring-dry waits; polls of the answer
+  if (lane == 0) { g_rs.statSeg[29] += pSrc[0] * 1000ll; g_rs.statSeg[30] += pSrc[1] * 1000ll; g_rs.statSeg[31] += pSrc[2] * 1000ll; g_rs.statSeg[33] += pFetch * 1000ll; g_rs.statSeg[35] += pDry * 1000ll; g_rs.statSeg[36] += pAsk * 1000ll; }   // picks from H / C / the base; clean-candidate fetches; ring-dry waits; questions put to the cold set
 #endif
-  // ---- session end: C compacts the LDS list; H's entries are appended; a pending failure is reported after the structure is whole again
+  // ---- session end: the shapes' cursors go back to LDS; C compacts the LDS list; H's entries are appended; a pending failure is reported after the structure is whole again
+  hcShapesStore(k, sc);
   hcPostA(cmdPub, HC_E, 0);
   for (;;) { if (hcLoadI32(&HCB.cmdDone) == cmdPub) break; __builtin_amdgcn_s_sleep(1); }
   LDS_ORDER();
@@ -536,6 +566,11 @@ template <int E> __device__ static void engineStreamHcT(Dev& d, KREF k, FastS& E
   }
   if (fail == 3) fail = 2;
   if (fail) { LDS_ORDER(); hcStoreI32(&g_fl.eng.ringFail, fail); }
+  ESRef.engSeq = ES.engSeq; ESRef.statScanSteps = ES.statScanSteps; ESRef.statL0Max = ES.statL0Max;
+#ifdef ASCHED_FASTPROF
+  for (int x = 0; x < 8; x++) ESRef.eseg[x] = ES.eseg[x];
+  ESRef.segT = ES.segT;
+#endif
 }
 __device__ static void engineStreamHc(Dev& d, KREF k, FastS& ES) {
   if (k.E == 0) engineStreamHcT<0>(d, k, ES); else if (k.E == 1) engineStreamHcT<1>(d, k, ES); else engineStreamHcT<2>(d, k, ES);
