@@ -72,7 +72,7 @@ __device__ static inline unsigned long long hcMinKey(unsigned long long key, int
 }
 __device__ static inline unsigned long long hcRead64(unsigned long long v, int lane) { return slGet64(v, lane); }
 __device__ static inline int hcLoadI32(const int32_t* p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
-__device__ static inline void hcStoreI32(int32_t* p, int v) { if ((threadIdx.x & 63) == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ static inline void hcStoreI32(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // (every lane stores the same word: no exec-mask bookkeeping)
 // what a job needs of a level-0 entry, as the lanes hold it (every lane the same values: plain vector operands, nothing is moved to scalar registers for it)
 struct HcNeed { unsigned long long fmin; long long ex0, ex1; int cls; };
 // entryFits (round_fast.h) for key layouts with guard bits (the only ones this engine runs on: asched_host.inc), branch-free: requirement class, every key field >= the
@@ -416,10 +416,11 @@ template <int E> __device__ static __attribute__((noinline)) void engineStreamHc
     int hLane;
     unsigned long long hk = hcMinKey(fitH ? h.key : ~0ull, &hLane);
     // ---- the shape's clean candidate as it stands
-    const int shape = __builtin_amdgcn_readfirstlane(cur.shape), sx = shape >> 6, sl = shape & 63;
-    int cst = sx ? __builtin_amdgcn_readlane(sc.st[1], sl) : __builtin_amdgcn_readlane(sc.st[0], sl);
-    unsigned long long cKey = sx ? hcRead64(sc.key[1], sl) : hcRead64(sc.key[0], sl);        // (SC_HEAD: the candidate's key)
-    const unsigned long long cLb = sx ? hcRead64(sc.lb[1], sl) : hcRead64(sc.lb[0], sl);     // (SC_SCAN: a lower bound)
+    const int shape = __builtin_amdgcn_readfirstlane(cur.shape), sl = shape & 63;
+    const bool hiSet = cur.shape >= 64;   // (the same in every lane: a select per word, then ONE v_readlane — no branch on the set)
+    int cst = __builtin_amdgcn_readlane(hiSet ? sc.st[1] : sc.st[0], sl);
+    unsigned long long cKey = hcRead64(hiSet ? sc.key[1] : sc.key[0], sl);        // (SC_HEAD: the candidate's key)
+    const unsigned long long cLb = hcRead64(hiSet ? sc.lb[1] : sc.lb[0], sl);     // (SC_SCAN: a lower bound)
     ESEG(1);   // [17] H test, clean candidate
     int insDone = __builtin_amdgcn_readfirstlane(rIns);
     if (insDone < 0) { fail = 2; break; }   // the cold list overflowed
@@ -460,8 +461,8 @@ template <int E> __device__ static __attribute__((noinline)) void engineStreamHc
       pFetch++;
 #endif
       hcShapesFetch(k, ES, sc, shape);
-      cst = sx ? __builtin_amdgcn_readlane(sc.st[1], sl) : __builtin_amdgcn_readlane(sc.st[0], sl);
-      cKey = sx ? hcRead64(sc.key[1], sl) : hcRead64(sc.key[0], sl);
+      cst = __builtin_amdgcn_readlane(hiSet ? sc.st[1] : sc.st[0], sl);
+      cKey = hcRead64(hiSet ? sc.key[1] : sc.key[0], sl);
       // (the cold set needs no second look: it was asked above unless its bound lies at or above the hot candidate, and then it cannot win whatever the base offers)
     }
     const unsigned long long lk2 = hk < ck ? hk : ck;
@@ -474,7 +475,7 @@ template <int E> __device__ static __attribute__((noinline)) void engineStreamHc
     int n;
     if (src == 0) n = __builtin_amdgcn_readlane(h.node, hLane);
     else if (src == 1) n = __builtin_amdgcn_readfirstlane(g_fl.l0Node[cSlot]);
-    else n = sx ? __builtin_amdgcn_readlane(sc.node[1], sl) : __builtin_amdgcn_readlane(sc.node[0], sl);
+    else n = __builtin_amdgcn_readlane(hiSet ? sc.node[1] : sc.node[0], sl);
 #ifdef ASCHED_FASTPROF
     pSrc[src & 3]++;
 #endif
@@ -500,10 +501,10 @@ template <int E> __device__ static __attribute__((noinline)) void engineStreamHc
       if (src == 1) { okey = ck; ocls = UNI64(g_fl.l0Cls[cSlot]); oex0 = (long long)UNI64(g_fl.l0Ex0[cSlot]); oex1 = (long long)UNI64(g_fl.l0Ex1[cSlot]); }
       else {
         okey = cKey;
-        ocls = sx ? hcRead64(sc.cls[1], sl) : hcRead64(sc.cls[0], sl);
-        oex0 = (long long)(sx ? hcRead64((unsigned long long)sc.ex0[1], sl) : hcRead64((unsigned long long)sc.ex0[0], sl));
-        oex1 = (long long)(sx ? hcRead64((unsigned long long)sc.ex1[1], sl) : hcRead64((unsigned long long)sc.ex1[0], sl));
-        const int usedPos = sx ? __builtin_amdgcn_readlane(sc.pos[1], sl) : __builtin_amdgcn_readlane(sc.pos[0], sl);
+        ocls = hcRead64(hiSet ? sc.cls[1] : sc.cls[0], sl);
+        oex0 = (long long)hcRead64((unsigned long long)(hiSet ? sc.ex0[1] : sc.ex0[0]), sl);
+        oex1 = (long long)hcRead64((unsigned long long)(hiSet ? sc.ex1[1] : sc.ex1[0]), sl);
+        const int usedPos = __builtin_amdgcn_readlane(hiSet ? sc.pos[1] : sc.pos[0], sl);
         baseMarkRemoved(k, ES, usedPos);   // a clean entry is used up (fastAfterBind's base branch): its flag and bitmap bits; the shapes' cursors are in registers here
         hcShapesUsed(sc, usedPos);
       }

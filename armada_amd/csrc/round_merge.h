@@ -234,10 +234,15 @@ DEV_NOINLINE int mgPrepare(Dev& d, FastCtx fc, int Q, int skip) {
   if (FLANE == 0) { mg.stop[0] = 0xffffffffu; mg.stop[1] = (uint32_t)total; }
   LANE0_PUBLISHED();
   FAST_GLOBAL_FENCE();
+  const long long t0_ = CLK();
   wgWide(d, W_MG_PACK, Q * MG_CPQ);
   wgWide(d, W_MG_FIX, Q);
+  const long long t1_ = CLK();
   wgWide(d, W_MG_RANK, total * ((Q + MG_PER - 1) / MG_PER));
+  const long long t2_ = CLK();
   wgWide(d, W_MG_SCATTER, total);
+  if (FLANE == 0) { RS.statSeg[37] += t1_ - t0_; RS.statSeg[38] += t2_ - t1_; RS.statSeg[39] += CLK() - t2_; }   // (always on: three clock reads per run) ticks of the key passes, the rank pass, the scatter
+  LANE0_PUBLISHED();
   const uint32_t stop = UNI32(*(volatile uint32_t*)&mg.stop[0]);
   const int V = stop < (uint32_t)total ? (int)stop : total;
 #ifdef ASCHED_HOSTSIM
