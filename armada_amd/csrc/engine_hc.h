@@ -374,7 +374,7 @@ template <int E> __device__ static __attribute__((noinline)) void engineStreamHc
   HCB.clb[lane] = 0; HCB.clb[lane + 64] = 0;   // no shape's bound is known yet: its first job asks
   LDS_ORDER();
   hcStoreI32(&g_fl.eng.hcGen, __builtin_amdgcn_readfirstlane(g_fl.eng.hcGen) + 1);
-  int cmdPub = 0, insSeq = 0, rrNext = 0, qSeq = 0;
+  int cmdPub = 0, insSeq = 0, rrNext = 0, qSeq = 0, inFlight = 0;   // inFlight: lanes of H whose entry has been handed to C and not yet been taken in
   HcHot h; h.key = ~0ull; h.cls = 0; h.ex0 = h.ex1 = 0; h.node = -1; h.state = 0; h.seq = 0;
   HcShapes sc; hcShapesLoad(k, sc);
   int total = __builtin_amdgcn_readfirstlane(g_fl.l0Count);   // dirty nodes alive (H + C): the list's high-water mark for round_stats
@@ -398,13 +398,14 @@ template <int E> __device__ static __attribute__((noinline)) void engineStreamHc
       haveCur = true;
     }
     ESEG(0);   // [16] waiting for a ring entry
-    if (__builtin_amdgcn_readfirstlane(cur.rq) & RQ_EV) {   // an evicted job returning to its node: nothing to select or bind here
-      i++; haveCur = false;
+    const int flags = __builtin_amdgcn_readfirstlane((cur.rq & RQ_EV) | (cur.never << 16));   // (ONE scalar look at what makes an entry special)
+    if (flags) {
+      if (flags >> 16) { fail = 1; break; }
+      i++; haveCur = false;   // an evicted job returning to its node: nothing to select or bind here
       hcStoreI32(&g_fl.eng.ringAck, i);
       continue;
     }
     if ((++ES.engSeq & 255) == 0 && cancelRequested(d)) { if (lane == 0) g_fl.eng.cancel = 1; LANE0_PUBLISHED(); fail = 1; break; }
-    if (__builtin_amdgcn_readfirstlane(cur.never)) { fail = 1; break; }
     // ---- ONE batch of LDS reads, in flight during the tests: the next entry, wave 3's hand-over counter, then the shape's lower bound for the cold set
     HcJobV nxt; hcLoadEntry(i + 1, nxt);
     const int rIns = __hip_atomic_load(&HCB.insDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -412,7 +413,7 @@ template <int E> __device__ static __attribute__((noinline)) void engineStreamHc
     const unsigned long long rLb = HCB.clb[cur.shape & 127];
     // ---- H: one test per lane, the 64-lane minimum
     HcNeed q; q.fmin = cur.fmin; q.ex0 = cur.ex0; q.ex1 = cur.ex1; q.cls = cur.cls;
-    const bool fitH = (h.state != 0) & hcFits<E>(G, q, h.key, h.cls, h.ex0, h.ex1);
+    const bool fitH = hcFits<E>(G, q, h.key, h.cls, h.ex0, h.ex1);   // (an empty lane has class bits 0: it fits nothing)
     int hLane;
     unsigned long long hk = hcMinKey(fitH ? h.key : ~0ull, &hLane);
     // ---- the shape's clean candidate as it stands
@@ -424,10 +425,11 @@ template <int E> __device__ static __attribute__((noinline)) void engineStreamHc
     ESEG(1);   // [17] H test, clean candidate
     int insDone = __builtin_amdgcn_readfirstlane(rIns);
     if (insDone < 0) { fail = 2; break; }   // the cold list overflowed
-    {   // entries whose hand-over wave 3 has taken in leave H: the bound read behind the counter covers them.  The best lane among them: ask C (it has that very entry)
+    if (inFlight > 0) {   // entries whose hand-over wave 3 has taken in leave H: the bound read behind the counter covers them.  The best lane among them: ask C (it has that very entry)
       const bool rel = (h.state == 2) & (h.seq < insDone);
       const unsigned long long rb = __ballot(rel);
-      h.state = rel ? 0 : h.state; h.node = rel ? -1 : h.node; h.key = rel ? ~0ull : h.key;
+      h.state = rel ? 0 : h.state; h.cls = rel ? 0ull : h.cls; h.key = rel ? ~0ull : h.key;
+      inFlight -= __popcll(rb);
       const bool drop = hLane >= 0 && ((rb >> hLane) & 1);
       hLane = drop ? -1 : hLane; hk = drop ? ~0ull : hk;
     }
@@ -449,7 +451,8 @@ template <int E> __device__ static __attribute__((noinline)) void engineStreamHc
       if (insDone < 0) { fail = 2; break; }
       const bool rel = (h.state == 2) & (h.seq < insDone);   // the answer counts these hand-overs: the entries are C's now
       const unsigned long long rb = __ballot(rel);
-      h.state = rel ? 0 : h.state; h.node = rel ? -1 : h.node; h.key = rel ? ~0ull : h.key;
+      h.state = rel ? 0 : h.state; h.cls = rel ? 0ull : h.cls; h.key = rel ? ~0ull : h.key;
+      inFlight -= __popcll(rb);
       const bool drop = hLane >= 0 && ((rb >> hLane) & 1);
       hLane = drop ? -1 : hLane; hk = drop ? ~0ull : hk;
     }
@@ -486,7 +489,7 @@ template <int E> __device__ static __attribute__((noinline)) void engineStreamHc
     hcStoreI32(&g_fl.eng.ringAck, i);
     // ---- what C must know: an entry it gives up, a hand-over taken back
     if (src == 1) hcPostA(cmdPub, HC_D, cSlot);
-    if (src == 0 && __builtin_amdgcn_readlane(h.state, hLane) == 2) hcPostA(cmdPub, HC_C, __builtin_amdgcn_readlane(h.seq, hLane));
+    if (inFlight > 0 && src == 0 && __builtin_amdgcn_readlane(h.state, hLane) == 2) { hcPostA(cmdPub, HC_C, __builtin_amdgcn_readlane(h.seq, hLane)); inFlight--; }
     const bool haveNext = __builtin_amdgcn_readfirstlane(nxt.pub) > i;
     ESEG(4);   // [20] verdict, commands
     // ---- the bind's effect on the node's level-0 entry: key and extras go down; an entry that can no longer host anything is dropped
@@ -494,7 +497,7 @@ template <int E> __device__ static __attribute__((noinline)) void engineStreamHc
       const unsigned long long nk = h.key - cur.keyDelta; const long long n0 = h.ex0 - cur.ex0, n1 = h.ex1 - cur.ex1;
       const bool alive = ((((nk | G) - MFM) & G) == G) & (ME0 <= n0) & (ME1 <= n1);
       const bool me = lane == hLane;
-      h.key = me ? (alive ? nk : ~0ull) : h.key; h.ex0 = me ? n0 : h.ex0; h.ex1 = me ? n1 : h.ex1; h.state = me ? (alive ? 1 : 0) : h.state; h.node = (me & !alive) ? -1 : h.node;
+      h.key = me ? (alive ? nk : ~0ull) : h.key; h.ex0 = me ? n0 : h.ex0; h.ex1 = me ? n1 : h.ex1; h.state = me ? (alive ? 1 : 0) : h.state; h.cls = (me & !alive) ? 0ull : h.cls;
       if (__ballot(me & !alive)) total--;
     } else {
       unsigned long long okey, ocls; long long oex0, oex1;
@@ -536,7 +539,7 @@ template <int E> __device__ static __attribute__((noinline)) void engineStreamHc
           h.state = lane == v ? 2 : h.state; h.seq = lane == v ? insSeq : h.seq;
           LDS_ORDER();
           hcPostA(cmdPub, HC_I, insSeq);
-          insSeq++;
+          insSeq++; inFlight++;
         }
       } else if (src == 1) total--;
     }
