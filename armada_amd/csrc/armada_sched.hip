@@ -1531,7 +1531,7 @@ __global__ __launch_bounds__(CTL_THREADS) void K_CONTROL_NAME(Dev dev, int cmd, 
       else if (op == OP_COMPACT) {
         compactPart(d);
       } else if (op == OP_ENGINE) {
-        if ((threadIdx.x >> 6) == 1) engineLoop(d); else if ((threadIdx.x >> 6) == 2) bindLoop(d); else if ((threadIdx.x >> 6) == 3) coldLoop(d);
+        if ((threadIdx.x >> 6) == 1) engineLoop(d); else if ((threadIdx.x >> 6) == 2) bindLoop(d); else if ((threadIdx.x >> 6) == 3 && d.f.engineHc) coldLoop(d);
       }
       __syncthreads();
     }
@@ -2899,7 +2899,7 @@ __global__ __launch_bounds__(CTL_THREADS) void k_control_aux(Dev dev, int cmd, H
       } else if (op == OP_COMPACT) {
         compactPart(d);
       } else if (op == OP_ENGINE) {
-        if ((threadIdx.x >> 6) == 1) engineLoop(d); else if ((threadIdx.x >> 6) == 2) bindLoop(d); else if ((threadIdx.x >> 6) == 3) coldLoop(d);
+        if ((threadIdx.x >> 6) == 1) engineLoop(d); else if ((threadIdx.x >> 6) == 2) bindLoop(d); else if ((threadIdx.x >> 6) == 3 && d.f.engineHc) coldLoop(d);
       }
       __syncthreads();
     }

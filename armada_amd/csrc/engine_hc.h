@@ -363,9 +363,14 @@ __device__ static inline void hcPostA(int& cmdPub, int type, int a) {
 // dependent LDS round trip.  Per job: ONE batch of LDS reads for the next entry and the cold set's answer (issued before the tests, used after them).
 // (A function of its own, not inlined: inside engineLoop its loop shared the register allocation of the serial engine's paths and lived partly in AGPRs.  Its constants
 // and counters are copied in and out: nothing in the loop goes through the references.)
-template <int E> __device__ static __attribute__((noinline)) void engineStreamHcT(Dev& d, const FastK& kRef, FastS& ESRef) {
-  const FastK k = kRef;
-  FastS ES = ESRef;
+struct HcOut { int engSeq, statScanSteps, statL0Max; long long segT, eseg[8]; };
+template <int E> __device__ static __attribute__((noinline)) HcOut engineStreamHcT(Dev& d, const FastK k, const int engSeq0, const int statScan0, const int statL0Max0, const long long segT0) {
+  // (every argument BY VALUE: a reference to the caller's constants or counters would put them in memory over there — the serial engine's loops read them too;
+  //  measured: 20 % on gang-heavy rounds, profiles/r06v)
+  FastS ES; ES.engSeq = engSeq0; ES.statScanSteps = statScan0; ES.statL0Max = statL0Max0; ES.segT = segT0; ES.laneL = 0; ES.laneX = 0;
+#ifdef ASCHED_FASTPROF
+  for (int x = 0; x < 8; x++) ES.eseg[x] = 0;
+#endif
   const int lane = threadIdx.x & 63;
   const unsigned long long G = UNI64(k.guardMask), MFM = UNI64(k.minFieldMin);
   const long long ME0 = (long long)UNI64(k.minEx0), ME1 = (long long)UNI64(k.minEx1);
@@ -570,12 +575,18 @@ template <int E> __device__ static __attribute__((noinline)) void engineStreamHc
   }
   if (fail == 3) fail = 2;
   if (fail) { LDS_ORDER(); hcStoreI32(&g_fl.eng.ringFail, fail); }
-  ESRef.engSeq = ES.engSeq; ESRef.statScanSteps = ES.statScanSteps; ESRef.statL0Max = ES.statL0Max;
+  HcOut o; o.engSeq = ES.engSeq; o.statScanSteps = ES.statScanSteps; o.statL0Max = ES.statL0Max; o.segT = ES.segT;
+  for (int x = 0; x < 8; x++) o.eseg[x] = 0;
 #ifdef ASCHED_FASTPROF
-  for (int x = 0; x < 8; x++) ESRef.eseg[x] = ES.eseg[x];
-  ESRef.segT = ES.segT;
+  for (int x = 0; x < 8; x++) o.eseg[x] = ES.eseg[x];
 #endif
+  return o;
 }
-__device__ static void engineStreamHc(Dev& d, KREF k, FastS& ES) {
-  if (k.E == 0) engineStreamHcT<0>(d, k, ES); else if (k.E == 1) engineStreamHcT<1>(d, k, ES); else engineStreamHcT<2>(d, k, ES);
+__device__ static inline void engineStreamHc(Dev& d, KREF k, FastS& ES) {
+  HcOut o;
+  if (k.E == 0) o = engineStreamHcT<0>(d, k, ES.engSeq, ES.statScanSteps, ES.statL0Max, ES.segT); else if (k.E == 1) o = engineStreamHcT<1>(d, k, ES.engSeq, ES.statScanSteps, ES.statL0Max, ES.segT); else o = engineStreamHcT<2>(d, k, ES.engSeq, ES.statScanSteps, ES.statL0Max, ES.segT);
+  ES.engSeq = o.engSeq; ES.statScanSteps = o.statScanSteps; ES.statL0Max = o.statL0Max;
+#ifdef ASCHED_FASTPROF
+  ES.segT = o.segT; for (int x = 0; x < 8; x++) ES.eseg[x] += o.eseg[x];
+#endif
 }

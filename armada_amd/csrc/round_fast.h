@@ -2102,17 +2102,49 @@ DEV bool mgWorth(Dev& d, int Q) {
 #else
   const int minEntries = MG_MIN_ENTRIES_DEFAULT;
 #endif
-  (void)d;
-  int total = 0;
-  for (int q0 = 0; q0 < Q; q0 += 64) {
-    FOR_LANES(x, 64) FL.tmpQ[x] = (q0 + x < Q && FL.inHeap[q0 + x] && FL.hot[q0 + x].sLen > FL.hot[q0 + x].sPos) ? FL.hot[q0 + x].sLen - FL.hot[q0 + x].sPos : 0;
-    LANE0_PUBLISHED();
-    for (int x = 0; x < 64 && q0 + x < Q; x++) total += UNI32(FL.tmpQ[x]);
+  const FastK k = fastKRef(d);
+  // one lane per queue, the verdict through ballots (a serial walk over the queues' LDS records costs ~13 k ticks per call, and gang-heavy rounds ask twenty thousand times:
+  // BASELINE configs[3] 692 -> 843 ms, profiles/r06r).  Worth it: one long stream, or many of some length — mgPrepare counts exactly.
+  int big = 0, some = 0, bad = 0;
+  FOR_LANES(q, QCAPF) {
+    int t = 0;
+    if (q < Q && FL.inHeap[q] && FL.hot[q].sLen > FL.hot[q].sPos) t = FL.hot[q].sLen - FL.hot[q].sPos;
+#if defined(ASCHED_HOSTSIM) || !defined(__HIP_DEVICE_COMPILE__)
+    if (t >= minEntries) big = 1;
+    if (t >= minEntries / 16) some++;
+#else
+    big = t >= minEntries; some = t >= minEntries / 16;
+#endif
   }
-  FOR_LANES(x, 64) FL.tmpQ[x] = 0;
-  LANE0_PUBLISHED();
-  return total >= minEntries;
+#if !defined(ASCHED_HOSTSIM) && defined(__HIP_DEVICE_COMPILE__)
+  big = __ballot(big != 0) != 0; some = __popcll(__ballot(some != 0));
+#endif
+  if (!(big || some >= 16)) return false;
+  // (mgPrepare's rules, asked here BEFORE the node engine is stopped for nothing: a run that would nest a gang stays with the control wave's merge; these look at HBM,
+  // so only once the lengths say the run is worth it)
+  FOR_LANES(q, QCAPF) {
+    int b2 = 0;
+    if (q < Q && FL.inHeap[q]) {
+      const QHot& f = FL.hot[q];
+      if (f.sLen > f.sPos) {
+        const bool kd = FL.sKind[q] != 0;
+        if (!kd && !d.qsLen[2 * q + 1] && !f.effValid) { const int nx = f.itQi - 1 - f.sPos + f.sLen; if (nx < f.qEnd && d.jGang[k.queuedJobs[nx]] >= 0) b2 = 1; }
+        if (!kd && f.sLen > QS_CMAX) b2 = 1;
+      } else if (f.gctx < -1) b2 = 1;
+    }
+#if defined(ASCHED_HOSTSIM) || !defined(__HIP_DEVICE_COMPILE__)
+    if (b2) bad = 1;
+#else
+    bad = b2;
+#endif
+  }
+#if !defined(ASCHED_HOSTSIM) && defined(__HIP_DEVICE_COMPILE__)
+  bad = __ballot(bad != 0) != 0;
+#endif
+  return !bad;
 }
+
+
 // Run fast iterations of the QueueScheduler loop (mode 0) or of the eviction-order replay (mode 1) until one needs the
 // generic code.  Returns the queue whose next head the generic updateAndPush must produce, or -1.  Leaves fast mode live.
 DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* counter) {

@@ -647,16 +647,24 @@ DEV_NOINLINE int fastStreamPrepare(Dev& d, FastCtx fc, int Q, int allowed, int a
   int skipUnf = fc.skipKnown && RS.numUnfeasible > 0;
   int cap = allowed < QS_CMAX ? allowed : QS_CMAX;
   if (cap > capHint) cap = capHint;
+  if (d.cfg.G > 0 && cap > 4096) cap = 4096;   // a pool with gangs: a stream is cut at the queue's next gang member, and the chunks behind the cut are scanned for nothing (BASELINE configs[3]: 686 -> 838 ms with 32 768)
   bool evOk = fc.evStatic && RS.lvl0NonNeg && RS.numPreemptedMarks == 0;
 #ifdef ASCHED_HOSTSIM
   if (getenv("HS_NO_EV_STREAM")) evOk = false;
 #endif
   // (round 6) a head the generic code peeked and no fast iteration has looked at yet has no cached record (headFast 0), and such a queue used to get its first stream only
   // after a fast iteration had served it once: a pass started with 64 short runs, each ending at the next such queue.  Their records are fetched here.
-  if (allowBulk > 0) for (int q = 0; q < Q; q++) {
-    if (!UNI32(FL.inHeap[q]) || UNI32(FL.hot[q].headFast) || UNI32(FL.hot[q].sLen) > UNI32(FL.hot[q].sPos)) continue;
+  unsigned long long needHead = 0;   // (found one lane per queue: a serial look at 64 LDS records costs ~20 k ticks per call, and crowded rounds prepare streams thousands of times)
+  if (allowBulk > 0) {
+#if defined(ASCHED_HOSTSIM) || !defined(__HIP_DEVICE_COMPILE__)
+    for (int q = 0; q < Q && q < 64; q++) if (FL.inHeap[q] && !FL.hot[q].headFast && !(FL.hot[q].sLen > FL.hot[q].sPos) && FL.hot[q].gctx >= 0) needHead |= 1ull << q;
+#else
+    { const int q = FLANE; needHead = __ballot(q < Q && FL.inHeap[q] && !FL.hot[q].headFast && !(FL.hot[q].sLen > FL.hot[q].sPos) && FL.hot[q].gctx >= 0); }
+#endif
+  }
+  while (needHead) {
+    const int q = __builtin_ctzll(needHead); needHead &= needHead - 1;
     const int job = UNI32(FL.hot[q].gctx);
-    if (job < 0) continue;
     QHot f = FL.hot[q];
     uniQHot(f);
     fastLoadHead(k, q, job, f);

@@ -22,6 +22,7 @@ def timed_rounds(s, wl, steps: int, warmup: int, barrier: Callable[[], None], sy
     """`warmup` untimed + `steps` timed rounds of one pool.  round_prepare (input build) is outside the timed region."""
     lat, dev_ms, res = [], [], None
     timed_rounds.prepare_s = 0.0
+    timed_rounds.control_ms = []   # per timed round: ms inside the persistent k_control launches (HIP events on the launch stream)
     for i in range(warmup + steps):
         tp = time.perf_counter()
         W.prepare(s, wl)
@@ -34,6 +35,7 @@ def timed_rounds(s, wl, steps: int, warmup: int, barrier: Callable[[], None], sy
         if i >= warmup:
             lat.append(dt)
             dev_ms.append(s.kernel_times()["round_ms"])
+            timed_rounds.control_ms.append(s.round_timing()["control_ms"])
     barrier()
     return lat, dev_ms, res
 

@@ -91,7 +91,13 @@ def _unpin(pinned):
             pass
 
 
-def cpu_baseline(wl, budget_s, full_iters):
+def cut_possible(wl, budget_s, full_iters):
+    """would cpu_baseline cut the burst for this budget?  (then its sample is an extrapolation and one round of it is enough)"""
+    est = full_iters * 170e-6 * (wl.num_nodes / 100_000.0) ** 0.5
+    return est > budget_s and not wl.rate_inf
+
+
+def cpu_baseline(wl, budget_s, full_iters, min_rounds=1):
     """The CPU oracle (C++ restatement of the reference algorithm, oracle/) timed on this box's host cores, 1 thread
     (the reference's round is single-goroutine).  Bounded sample: ONE round on the SAME nodes/jobs/queues (SURVEY 8d asks for >= 30
     rounds; one oracle round of BASELINE configs[2] is ~1 minute, so the sample is one round and says so).  When the estimate exceeds
@@ -118,7 +124,7 @@ def cpu_baseline(wl, budget_s, full_iters):
     for _ in range(3):         # THREE rounds when a round is at most ~13 s (the reduced legs, the production-defaults record), ONE when a round is a minute (round-4 review, weak #8: mean of 3 where it is affordable)
         W.prepare(s, sample)
         t0 = time.perf_counter(); r = s.schedule_round(); times.append(time.perf_counter() - t0)
-        if sum(times) + times[-1] > min(40.0, max(budget_s, 0.0)) or times[-1] > 13.5:
+        if len(times) >= min_rounds and (sum(times) + times[-1] > min(40.0, max(budget_s, 0.0)) or times[-1] > 13.5):   # (min_rounds: the headline takes three rounds whatever a round costs — round-5 review: a one-sample baseline has no variance)
             break
     _unpin(pinned)
     dt = float(np.mean(times))
@@ -139,7 +145,7 @@ def cpu_baseline(wl, budget_s, full_iters):
            "sample": f"oracle (C++ restatement of the reference algorithm, 1 thread) on the same {wl.num_nodes}-node/{wl.num_jobs}-job input, {len(times)} round(s) "
                      f"(not the >= 30 of SURVEY 8d: a round is {dt:.1f} s of CPU) with global burst {sample.global_burst} ({iters} of {full_iters} loop iterations, mean {dt:.2f} s measured"
                      + (", scaled by the iteration ratio: an upper bound of the CPU time, the evicted-job phases do not shrink with the burst)" if cut else ")"),
-           "measured_s": dt, "measured_rounds_s": [round(t, 4) for t in times], "measured_iterations": iters, "rounds": len(times), "upper_bound_extrapolation": bool(cut),
+           "measured_s": dt, "measured_min_s": float(min(times)), "measured_max_s": float(max(times)), "measured_rounds_s": [round(t, 4) for t in times], "measured_iterations": iters, "rounds": len(times), "upper_bound_extrapolation": bool(cut),
            "pinned_core": pinned[1] if pinned else None}
     if not cut:
         r.excluded_sample = excluded
@@ -810,10 +816,12 @@ def compact_line(out):
     cfg = out.get("config") or {}
     line["config"] = {k: (v[:300] if isinstance(v, str) else v) for k, v in cfg.items()} if isinstance(cfg, dict) else cfg
     if "roofline" in out:
-        line["roofline"] = short(pick(out["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "algorithmic_bytes_per_launch", "kernel_isa_hash", "kernel_avg_ms", "node_queries")))
+        line["roofline"] = short(pick(out["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "traffic_kernel_isa_hash", "kernel", "algorithmic_bytes_per_launch", "kernel_isa_hash", "kernel_avg_ms", "ticks_per_placement", "passes_executed", "node_queries")))
+        if "frac_kind" in out["roofline"]:
+            line["roofline"]["frac_kind"] = "unbatched-equivalent (queries issued x N x 40 B; no plane is scanned: see ticks_per_placement)"
     if "cpu_baseline" in out:
         cb = out["cpu_baseline"]
-        line["cpu_baseline"] = short(pick(cb, ("value", "unit", "cores", "kind", "rounds", "measured_s", "error")))
+        line["cpu_baseline"] = short(pick(cb, ("value", "unit", "cores", "kind", "rounds", "measured_s", "measured_min_s", "measured_max_s", "error")))
         if "sample" in cb:
             line["cpu_baseline"]["sample"] = cb["sample"][:160]
     if "parity" in out:
@@ -991,7 +999,8 @@ def main():
     alg = algorithmic_bytes(wl.num_nodes, W.R, queries, binds)
     seq_ms = float(np.mean(dev_ms))                  # the whole launch sequence of a round (HIP events on the stream)
     timing = s.round_timing()                        # last round: ms inside the persistent k_control launches, launches, bulk phases
-    kern_ms = timing["control_ms"] if timing["control_ms"] > 0 else seq_ms
+    ctl = [x for x in getattr(multipool.timed_rounds, "control_ms", []) if x > 0]
+    kern_ms = float(np.mean(ctl)) if ctl else (timing["control_ms"] if timing["control_ms"] > 0 else seq_ms)   # MEAN over the timed rounds (round-5 review: it was the last round's)
     achieved = alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     out = {
         "metric": "scheduling rounds/sec (p99 round latency in p99_ms), 100k nodes x 1M jobs",
@@ -1014,6 +1023,8 @@ def main():
         "input_build_s": build_s, "round_prepare_s": prep_s / (args.warmup + args.steps),
         "prepare_inclusive_rounds_per_s": 1.0 / (total / args.steps + prep_s / (args.warmup + args.steps)),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "frac_kind": "unbatched-equivalent: SURVEY 8d's per-query bytes x the queries the ALGORITHM issues; no node plane is scanned (passes_executed), the kernel is a serial "
+                                  "chain of placements, not an HBM stream — ticks_per_placement is its real figure of merit",
                      "traffic": None, "kernel": "k_control", "algorithmic_bytes_per_launch": alg,
                      "note": "algorithmic bytes = node_queries_issued x N x (R*8+8) + binds x 256 (SURVEY 8d); duration = the persistent k_control launch(es) of one round "
                              "(HIP events on the launch stream; the grid-wide bulk kernels around them are in round.device_ms)"},
@@ -1035,10 +1046,19 @@ def main():
             pass
     out["roofline"]["kernel_isa_hash"] = kernel_isa_hash()
     out["roofline"]["kernel_avg_ms"] = kern_ms
+    out["roofline"]["kernel_ms_per_round"] = [round(x, 3) for x in ctl]
+    if out["roofline"].get("traffic") is not None and out["roofline"].get("traffic_kernel_isa_hash") != out["roofline"]["kernel_isa_hash"]:
+        out["roofline"]["traffic_of_another_build"] = out["roofline"]["traffic"]   # kept in the full record for reference only
+        out["roofline"]["traffic"] = None
+        out["roofline"]["traffic_stale"] = True   # the committed PMC passes were taken from a different round kernel: no byte count is claimed for this one
+    st_ = s.round_stats()
+    placed = max(1, len(res.scheduled))
+    out["roofline"]["ticks_per_placement"] = (st_["kclk_pass1"] + st_["kclk_pass2"]) * 1000.0 / placed   # shader clocks of the two sequential passes per job placed (last round)
+    out["roofline"]["passes_executed"] = {"base_window_reads": st_["base_scan_steps"], "plane_scan_kclk": st_["kclk_plane_scans"], "stream_runs": st_["stream_runs"]}
     rc = 0
     if args.cpu_budget > 0 and world == 1:  # rank 0 at N=1 only
         try:
-            out["cpu_baseline"], ores = cpu_baseline(wl, args.cpu_budget, iters)
+            out["cpu_baseline"], ores = cpu_baseline(wl, args.cpu_budget, iters, min_rounds=3 if not cut_possible(wl, args.cpu_budget, iters) else 1)
             if ores is not None:  # the headline number is self-verifying: the timed GPU round against the oracle round on the same input
                 out["parity"] = parity_record(res, ores, wl.num_jobs, "oracle round of the cpu_baseline leg, same input")
                 out["parity"]["excluded_nodes"] = excluded_parity(s, ores)
