@@ -771,6 +771,58 @@ __device__ static inline void accountVectors(Dev& d, KREF k, int q, int pc, bool
 // compiler must keep the order (wavefront-scope fences emit nothing).  No s_waitcnt vmcnt anywhere on this path: neither wave
 // ever waits for its own outstanding HBM atomics.
 #define LDS_ORDER() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+// ---- bounded waits (round 6).  Every spin of the control workgroup's protocols (mailbox words, ring counters, the engine's acknowledgements) counts its turns; every
+// 16 384 turns (~1 ms) it looks at the caller's cancel word (hard timeout / asched_cancel: a read across PCIe) and at the launch's `abandon` flag, and gives up when either is
+// set — or when the wait has lasted ~2^26 turns (seconds: no wait of a healthy launch is that long), which raises ASCHED_ERR_DEVICE.  Giving up sets `abandon`, so the
+// waves waiting on the other side give up as well and everybody meets at the end barrier of the engine session; the round then returns its error (the handle wants a
+// fresh round_prepare, as after any failed round).  What this cannot bound is a workgroup BARRIER that a wave never reaches (profiles/r05y_bulk_skip_hang.txt): those
+// are ruled out by construction (eng.live; the CPU build aborts on a wide op posted with the engine live).
+#define SPIN_CHECK 0x3fffu
+#define SPIN_LIMIT (1u << 26)
+__device__ static inline bool waitExpired(unsigned& spins) {
+  if ((++spins & SPIN_CHECK) != 0) return false;
+  bool ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.abandon, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0;
+  if (!ab && (spins >= SPIN_LIMIT || cancelRequested(g_dev))) {
+    if (spins >= SPIN_LIMIT) raise(g_dev, ASCHED_ERR_DEVICE, 950);
+    __hip_atomic_store(&g_fl.eng.abandon, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&g_fl.eng.cancel, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    ab = true;
+  }
+  return ab;
+}
+// The node engine's waits (engine_hc.h) sit inside the per-job loop, whose instruction schedule is the headline (its region holds lane-divergent branches, so every branch
+// in it costs exec-mask code: a counter with a test per wait cost 4-20 % of the round, profiles/r06z_bounded_waits.txt).  They carry no counter: a turn reads `abandon`
+// in LDS, nothing else.  Setting it is the other waves' business: whenever the engine (or the cold wave, or the bind wave behind it) is stuck the control wave ends up in
+// streamIdle (the ring is full, or drains) — which looks at the cancel word and keeps the tick budget for all of them — or in one of its own counted waits.
+__device__ static inline bool waitAbandoned() { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.abandon, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0; }
+__device__ static inline bool waitGaveUp(unsigned& spins) {   // the cold wave's polls: `abandon` every 1 024 turns
+  if ((++spins & 0x3ffu) != 0) return false;
+  return waitAbandoned();
+}
+#define IDLE_BUDGET (1u << 22)   // in units of 1 024 shader-clock ticks: ~2 s without one entry placed or bound while the control wave does nothing but wait
+__device__ static inline void streamIdle() {   // the control wave while the ring is full / drains: its waits look at ringFail every turn, so giving up = a failure posted there
+  __builtin_amdgcn_s_sleep(2);
+  // No counter in LDS or registers (the macro has no state; a 64-lane LDS add per turn took the LDS from the node engine): the shader clock says when to look — one window
+  // of 2 048 ticks in every 2^21 (~1 ms); a turn of any of these waits is shorter than the window, so every period is seen at least once.
+  const unsigned long long clk = __builtin_readcyclecounter();
+  if ((((unsigned)clk) & 0x1fffffu) < 0x800u) {
+    const int abV = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.abandon, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    // the tick budget: entries placed + entries bound stand still over a stretch of CONTINUOUS waiting (a visit more than three periods after the last one starts a new stretch)
+    const unsigned now = (unsigned)(clk >> 10) | 1u;
+    const int prog = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringAck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) + __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.bindDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    const unsigned since = (unsigned)__builtin_amdgcn_readfirstlane(g_fl.eng.idleSince), last = (unsigned)__builtin_amdgcn_readfirstlane(g_fl.eng.idleLast);
+    const bool fresh = since == 0 || prog != __builtin_amdgcn_readfirstlane(g_fl.eng.idleProg) || now - last > (3u << 11);
+    bool expired = !fresh && now - since > IDLE_BUDGET;
+    if (fresh) { __hip_atomic_store(&g_fl.eng.idleProg, prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_store(&g_fl.eng.idleSince, (int)now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __hip_atomic_store(&g_fl.eng.idleLast, (int)now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (expired && abV == 0) raise(g_dev, ASCHED_ERR_DEVICE, 950);
+    if (abV != 0 || expired || cancelRequested(g_dev)) {
+      if (abV == 0) __hip_atomic_store(&g_fl.eng.abandon, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(&g_fl.eng.cancel, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringFail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) __hip_atomic_store(&g_fl.eng.ringFail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+}
 __device__ static inline void bindUpdateEng(KREF k, FastS& S, int n, int nl, uint64_t keyDelta, const int64_t* req) {
   int lane = threadIdx.x & 63;
   int l = S.laneL;
@@ -831,10 +883,12 @@ __device__ static inline void engineRestore(int q) {
 }
 __device__ static inline int engineWait(const FastS& S) {
   int want = S.engSeq;
+  unsigned spins = 0;
   for (;;) {
     int a = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     if (a == want) break;
     __builtin_amdgcn_s_sleep(1);
+    if (waitExpired(spins)) return 0;   // (as if the job had found no node: the caller takes the iteration back and meets the cancel flag)
   }
   LDS_ORDER();
   return __builtin_amdgcn_readfirstlane(g_fl.eng.status);
@@ -847,7 +901,7 @@ __device__ static inline void qsWinRefill(KREF k, int q, int pos, int cnt) {
 }
 __device__ static inline void streamBegin(int* engSeq, int hold, int hc) {
   int lane = threadIdx.x & 63;
-  if (lane == 0) { g_fl.eng.bindHold = hold; g_fl.eng.ringPub = 0; g_fl.eng.ringAck = 0; g_fl.eng.ringEnd = 0; g_fl.eng.ringFail = 0; g_fl.eng.ringClosed = 0; g_fl.eng.bindDone = 0; g_fl.eng.cmd = hc ? ENG_STREAM_HC : ENG_STREAM; }
+  if (lane == 0) { g_fl.eng.bindHold = hold; g_fl.eng.ringPub = 0; g_fl.eng.ringAck = 0; g_fl.eng.ringEnd = 0; g_fl.eng.ringFail = 0; g_fl.eng.ringClosed = 0; g_fl.eng.bindDone = 0; g_fl.eng.idleSince = 0; g_fl.eng.cmd = hc ? ENG_STREAM_HC : ENG_STREAM; }
   (*engSeq)++;
   LDS_ORDER();
   if (lane == 0) __hip_atomic_store(&g_fl.eng.bindGen, g_fl.eng.bindGen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -875,10 +929,12 @@ __device__ static inline void streamEnd(int engSeq) {
   int lane = threadIdx.x & 63;
   LDS_ORDER();
   if (lane == 0) __hip_atomic_store(&g_fl.eng.ringEnd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  unsigned spins = 0;
   for (;;) {   // the engine acknowledges the ENG_STREAM command when it has left the ring
     int a = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     if (a == engSeq) break;
     __builtin_amdgcn_s_sleep(1);
+    if (waitExpired(spins)) { LDS_ORDER(); return; }
   }
   if (__builtin_amdgcn_readfirstlane(g_fl.eng.bindHold)) { LDS_ORDER(); return; }   // a gang: the verdict comes first (streamRelease)
   int gen = __builtin_amdgcn_readfirstlane(g_fl.eng.bindGen);
@@ -886,6 +942,7 @@ __device__ static inline void streamEnd(int engSeq) {
     int f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.bindFin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     if (f == gen) break;
     __builtin_amdgcn_s_sleep(1);
+    if (waitExpired(spins)) break;
   }
   LDS_ORDER();
 }
@@ -894,10 +951,12 @@ __device__ static inline void streamRelease(Dev& d, KREF k, int go) {
   int lane = threadIdx.x & 63;
   if (lane == 0) __hip_atomic_store(&g_fl.eng.bindHold, go ? 2 : 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   int gen = __builtin_amdgcn_readfirstlane(g_fl.eng.bindGen);
+  unsigned spins = 0;
   for (;;) {
     int f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.bindFin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     if (f == gen) break;
     __builtin_amdgcn_s_sleep(1);
+    if (waitExpired(spins)) break;
   }
   LDS_ORDER();
 }
@@ -949,7 +1008,7 @@ __device__ static inline void pqHeadKey(PQState& s, int t, PackedKey* key, uint3
 __device__ static inline void engineStart(Dev& d, FastS& S) {
   (void)d;
   S.engSeq = 0;
-  if ((threadIdx.x & 63) == 0) { g_fl.eng.seq = 0; g_fl.eng.ack = 0; g_fl.eng.statScan = 0; g_fl.eng.statL0Max = S.statL0Max; g_fl.eng.busyClk = 0; g_fl.eng.jobs = 0; g_fl.eng.cancel = 0; g_fl.eng.bindQuit = 0; g_fl.eng.bindGen = 0; g_fl.eng.bindFin = 0; g_fl.eng.hcGen = 0; g_fl.eng.live = 1; g_mb.op = OP_ENGINE; }
+  if ((threadIdx.x & 63) == 0) { g_fl.eng.seq = 0; g_fl.eng.ack = 0; g_fl.eng.statScan = 0; g_fl.eng.statL0Max = S.statL0Max; g_fl.eng.busyClk = 0; g_fl.eng.jobs = 0; g_fl.eng.cancel = 0; g_fl.eng.bindQuit = 0; g_fl.eng.bindGen = 0; g_fl.eng.bindFin = 0; g_fl.eng.hcGen = 0; g_fl.eng.idleSince = 0; g_fl.eng.live = 1; g_mb.op = OP_ENGINE; }
   __syncthreads();
 }
 __device__ static inline void engineStop(Dev& d, FastS& S) {
@@ -986,13 +1045,16 @@ __device__ static void engineLoop(Dev& d) {  // wave 1
   for (int i = 0; i < 8; i++) ES.eseg[i] = 0;
   ES.segT = CLK();
 #endif
+  unsigned spins = 0;
   for (;;) {
     int sq;
     for (;;) {
       sq = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
       if (sq != seen) break;
       __builtin_amdgcn_s_sleep(1);
+      if (waitExpired(spins)) return;   // (to the end barrier of the engine session: the control wave, whose waits give up too, comes there through engineStop)
     }
+    spins = 0;
     seen = sq;
     LDS_ORDER();
     int cmd = __builtin_amdgcn_readfirstlane(g_fl.eng.cmd);
@@ -1026,6 +1088,7 @@ __device__ static void engineLoop(Dev& d) {  // wave 1
           int end = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringEnd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
           if (end) { pub = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringPub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); break; }
           __builtin_amdgcn_s_sleep(1);
+          if (waitExpired(spins)) return;
         }
         if (pub <= i) break;
         LDS_ORDER();
@@ -1079,13 +1142,16 @@ __device__ static void bindLoop(Dev& d) {
   BS.segT = 0;
 #endif
   int gen = 0;
+  unsigned spins = 0;
   for (;;) {
     for (;;) {
       int g = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.bindGen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
       if (g != gen) { gen = g; break; }
       if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.bindQuit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) return;
       __builtin_amdgcn_s_sleep(2);
+      if (waitExpired(spins)) return;
     }
+    spins = 0;
     int i = 0;
     bool discard = false;
     if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.bindHold, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {   // a gang: all members or none
@@ -1094,6 +1160,7 @@ __device__ static void bindLoop(Dev& d) {
         hmode = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.bindHold, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (hmode != 1) break;
         __builtin_amdgcn_s_sleep(1);
+        if (waitExpired(spins)) return;
       }
       discard = hmode == 3;
     }
@@ -1103,7 +1170,7 @@ __device__ static void bindLoop(Dev& d) {
         if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringClosed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
           ack = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringAck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
           if (i >= ack) break;
-        } else { __builtin_amdgcn_s_sleep(1); continue; }
+        } else { __builtin_amdgcn_s_sleep(1); if (waitExpired(spins)) return; continue; }
       }
       LDS_ORDER();
       for (; i < ack; i++) {
@@ -1485,7 +1552,7 @@ __device__ static void helperMain(const Dev& d, HelpBox* b, int H) {
 #endif
 __global__ __launch_bounds__(CTL_THREADS) void K_CONTROL_NAME(Dev dev, int cmd, HelpBox* box, int H) {
   if (blockIdx.x != 0) { helperMain(dev, box, H); return; }
-  if (threadIdx.x == 0) { g_box = box; g_H = H; g_gen = 0; }
+  if (threadIdx.x == 0) { g_box = box; g_H = H; g_gen = 0; g_fl.eng.abandon = 0; g_fl.eng.idleSince = 0; g_fl.eng.idleLast = 0; g_fl.eng.idleProg = 0; }
   // the Dev descriptor (pointers + config) is staged in LDS once; every wave reads it from there
   {
     const int* src = (const int*)&dev; int* dst = (int*)&g_dev;
@@ -2867,7 +2934,7 @@ static int plat_run_fair_shares(Dev& dev, int q, const int32_t* nameRank, const 
 // decision in the round kernel, whose code is the measured one.
 __global__ __launch_bounds__(CTL_THREADS) void k_control_aux(Dev dev, int cmd, HelpBox* box, MktDev mk) {
   // workgroup 0 of k_control without helper workgroups: wave 0 runs the command, the other waves serve its mailbox
-  if (threadIdx.x == 0) { g_box = box; g_H = 0; g_gen = 0; g_mk = mk; }
+  if (threadIdx.x == 0) { g_box = box; g_H = 0; g_gen = 0; g_mk = mk; g_fl.eng.abandon = 0; g_fl.eng.idleSince = 0; g_fl.eng.idleLast = 0; g_fl.eng.idleProg = 0; }
   {
     const int* src = (const int*)&dev; int* dst = (int*)&g_dev;
     for (int i = threadIdx.x; i < (int)(sizeof(Dev) / sizeof(int)); i += blockDim.x) dst[i] = src[i];

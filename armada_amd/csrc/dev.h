@@ -108,6 +108,7 @@ struct FastCfg {
                               // JobRec.shape, the candidate cache, the shape table and the fit masks are indexed by fit shape (scheduling keys that differ only in the
                               // priority class share one base cursor)
   int maskMode;               // <= 128 fit shapes (1: <= 64, 2: <= 128) and fit bitmaps on: the L0 list holds per-node fit masks over the fit shapes; was: baseCls / l0Cls / CandRec.cls hold per-shape fit masks (current capacity and requirement class folded in), not class bits
+  int debugHang;              // tests only (ASCHED_DEBUG_HANG=<n>): the node engine stops answering at its n-th job of a ring session, as a protocol defect would make it — every wait must still end
   int engineHc;               // the ring session of a bulk-merged stream run uses the split level-0 structure (engine_hc.h): hot set / cold set / clean front; ASCHED_ENGINE_HC=1 turns it on
   int engine;                 // queued-job iterations run on two waves (round_fast.h "two-wave iteration"); ASCHED_ENGINE=0 turns it off
   int E; int extraCol[MAXE];  // non-indexed columns

@@ -117,6 +117,8 @@ template <int E> __device__ static void coldSession(Dev& d, KREF k) {
     rows.key[r] = in ? g_fl.l0Key[s] : ~0ull; rows.ex0[r] = in ? g_fl.l0Ex0[s] : 0; rows.ex1[r] = in ? g_fl.l0Ex1[s] : 0; rows.cls[r] = in ? g_fl.l0Cls[s] : 0ull;
   }
   int done = 0;
+  unsigned spins = 0;
+  const int debugHang = d.f.debugHang;
 #ifdef ASCHED_FASTPROF
   long long cBusy = 0, cT0 = 0; int cQ = 0, cI = 0;
 #endif
@@ -127,7 +129,9 @@ template <int E> __device__ static void coldSession(Dev& d, KREF k) {
     LDS_ORDER();
     const int typeV = c.type, aV = c.a, seqV = c.seq;
     HcNeed q; q.fmin = c.fieldMin; q.ex0 = c.ex0; q.ex1 = c.ex1; q.cls = c.cls;   // (every lane reads the same words)
-    if (__builtin_amdgcn_readfirstlane(pubV) == done) { __builtin_amdgcn_s_sleep(1); continue; }
+    if (__builtin_amdgcn_readfirstlane(pubV) == done) { __builtin_amdgcn_s_sleep(1); if (waitGaveUp(spins)) return; continue; }   // (a wait given up: armada_sched.hip "bounded waits")
+    spins = 0;
+    if (debugHang > 0 && done == debugHang) { for (;;) { __builtin_amdgcn_s_sleep(1); if (waitGaveUp(spins)) return; } }   // (tests: a cold-set wave that stops answering; only the bounded waits end this)
 #ifdef ASCHED_FASTPROF
     cT0 = CLK();
 #endif
@@ -228,13 +232,16 @@ template <int E> __device__ static void coldSession(Dev& d, KREF k) {
 __device__ static void coldLoop(Dev& d) {
   const FastK k = fastKRef(d);
   int gen = 0;
+  unsigned spins = 0;
   for (;;) {
     for (;;) {
       int g = hcLoadI32(&g_fl.eng.hcGen);
       if (g != gen) { gen = g; break; }
       if (hcLoadI32(&g_fl.eng.bindQuit)) return;
       __builtin_amdgcn_s_sleep(2);
+      if (waitGaveUp(spins)) return;
     }
+    spins = 0;
     LDS_ORDER();
     if (k.E == 0) coldSession<0>(d, k); else if (k.E == 1) coldSession<1>(d, k); else coldSession<2>(d, k);
   }
@@ -384,6 +391,8 @@ template <int E> __device__ static __attribute__((noinline)) HcOut engineStreamH
   HcShapes sc; hcShapesLoad(k, sc);
   int total = __builtin_amdgcn_readfirstlane(g_fl.l0Count);   // dirty nodes alive (H + C): the list's high-water mark for round_stats
   int i = 0, fail = 0;
+  // (bounded waits, armada_sched.hip: a turn of a wait here reads the launch's `abandon` word — 0 or 1 — and leaves through an exit the loop has anyway; NO flag is carried
+  //  around the per-job loop: a bool live across this loop is a lane mask merged with three scalar instructions at every join, +5 % on the headline round)
   HcJobV cur; bool haveCur = false;
 #ifdef ASCHED_FASTPROF
   int pSrc[4] = {0, 0, 0, 0}, pFetch = 0, pDry = 0, pAsk = 0;
@@ -396,7 +405,7 @@ template <int E> __device__ static __attribute__((noinline)) HcOut engineStreamH
       for (;;) {
         hcLoadEntry(i, cur);
         if (__builtin_amdgcn_readfirstlane(cur.pub) > i) break;
-        if (hcLoadI32(&g_fl.eng.ringEnd)) { hcLoadEntry(i, cur); break; }
+        if (hcLoadI32(&g_fl.eng.ringEnd) | hcLoadI32(&g_fl.eng.abandon)) { hcLoadEntry(i, cur); break; }   // (a wait given up leaves through the exits the loop has, and nothing about it is carried around the loop: see `gaveUp` below)
         __builtin_amdgcn_s_sleep(1);
       }
       if (__builtin_amdgcn_readfirstlane(cur.pub) <= i) break;
@@ -448,11 +457,11 @@ template <int E> __device__ static __attribute__((noinline)) HcOut engineStreamH
 #endif
       hcPostQ(cmdPub, cur, qSeq);
       HcRep& rp = HCB.rep[qSeq & 3];
-      for (;;) { if (hcLoadI32(&rp.seq) == qSeq) break; __builtin_amdgcn_s_sleep(1); }
+      for (;;) { if ((int)(hcLoadI32(&rp.seq) == qSeq) | hcLoadI32(&g_fl.eng.abandon)) break; __builtin_amdgcn_s_sleep(1); }
       LDS_ORDER();
       qSeq++;
       cSlot = __builtin_amdgcn_readfirstlane(rp.slot); ck = UNI64(rp.key);
-      insDone = __builtin_amdgcn_readfirstlane(rp.insDone);
+      insDone = __builtin_amdgcn_readfirstlane(rp.insDone) | -hcLoadI32(&g_fl.eng.abandon);   // (given up: -1, the overflow's exit)
       if (insDone < 0) { fail = 2; break; }
       const bool rel = (h.state == 2) & (h.seq < insDone);   // the answer counts these hand-overs: the entries are C's now
       const unsigned long long rb = __ballot(rel);
@@ -531,7 +540,7 @@ template <int E> __device__ static __attribute__((noinline)) HcOut engineStreamH
         if (__popcll(normal) > HC_H_MAX) {
           while (insSeq - insDone >= HC_INS / 2) {   // (wave 3 is far behind with the hand-overs: never seen; the payload slots and the command ring are bounded by this)
             __builtin_amdgcn_s_sleep(1);
-            insDone = hcLoadI32(&HCB.insDone);
+            insDone = hcLoadI32(&HCB.insDone) | -hcLoadI32(&g_fl.eng.abandon);
             if (insDone < 0) break;
           }
           if (insDone < 0) { fail = 2; break; }
@@ -551,15 +560,19 @@ template <int E> __device__ static __attribute__((noinline)) HcOut engineStreamH
     cur = nxt; haveCur = haveNext;
     ESEG(5);   // [21] hot-set / base upkeep
   }
+  bool gaveUp = waitAbandoned();   // the session ends without its hand-shakes
+  if (gaveUp) fail = 1;
 #ifdef ASCHED_FASTPROF
   if (lane == 0) { g_rs.statSeg[29] += pSrc[0] * 1000ll; g_rs.statSeg[30] += pSrc[1] * 1000ll; g_rs.statSeg[31] += pSrc[2] * 1000ll; g_rs.statSeg[33] += pFetch * 1000ll; g_rs.statSeg[35] += pDry * 1000ll; g_rs.statSeg[36] += pAsk * 1000ll; }   // picks from H / C / the base; clean-candidate fetches; ring-dry waits; questions put to the cold set
 #endif
   // ---- session end: the shapes' cursors go back to LDS; C compacts the LDS list; H's entries are appended; a pending failure is reported after the structure is whole again
   hcShapesStore(k, sc);
-  hcPostA(cmdPub, HC_E, 0);
-  for (;;) { if (hcLoadI32(&HCB.cmdDone) == cmdPub) break; __builtin_amdgcn_s_sleep(1); }
+  if (!gaveUp) {
+    hcPostA(cmdPub, HC_E, 0);
+    for (;;) { if (hcLoadI32(&HCB.cmdDone) == cmdPub) break; __builtin_amdgcn_s_sleep(1); if (waitAbandoned()) { gaveUp = true; break; } }
+  }
   LDS_ORDER();
-  {
+  if (!gaveUp) {
     int cnt = __builtin_amdgcn_readfirstlane(g_fl.l0Count);
     const bool mine = h.state == 1;   // (state 2: C has it — every insert is done once HC_E is)
     const unsigned long long b = __ballot(mine);

@@ -65,6 +65,7 @@ struct alignas(16) EngineBox {
   int64_t busyClk; int32_t jobs, cancel;     // shader-clock ticks the engine spent serving jobs, and how many; cancel: the engine saw the caller's cancel word
   int32_t ringPub, ringAck, ringEnd, ringFail;   // stream run: entries staged in the ring / placed by the engine; no more entries will come; 1 = entry ringAck found no node, 2 = placed but L0 overflowed
   int32_t bindHold;   // 1: the bind wave waits for the verdict on the whole ring (a gang: all members or none), 2: go, 3: discard
+  int32_t abandon, idleProg, idleSince, idleLast;   // a bounded wait gave up (the caller's cancel word, or the tick budget): every other wait of the launch gives up too; streamIdle's stretch of waiting without progress (armada_sched.hip)
   int32_t hcGen, cleanFrom;   // engine_hc.h: generation of the cold wave's sessions; no clean base entry lies before this position (kept for the launch)
   int32_t ringClosed, bindGen, bindDone, bindFin, bindQuit, live;   // live: the node engine runs (engineStart .. engineStop) — what coldS tells the out-of-line helpers
   //   // the engine has left the ring; stream generation / entries whose bind + result fields the bind wave has issued / generation it has finished
@@ -193,7 +194,8 @@ int hsBindLag();
 #elif !defined(__HIP_DEVICE_COMPILE__)
 #define STREAM_IDLE() do {} while (0)
 #else
-#define STREAM_IDLE() __builtin_amdgcn_s_sleep(2)
+DEV void streamIdle();   // armada_sched.hip: a short sleep + the bounded-wait bookkeeping
+#define STREAM_IDLE() streamIdle()
 #endif
 DEV void uniQHot(QHot& f) {
   f.weight = UNID(f.weight); f.tokens = UNID(f.tokens); f.budget = UNID(f.budget); f.proposed = UNID(f.proposed); f.current = UNID(f.current); f.size = UNID(f.size);

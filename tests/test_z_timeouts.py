@@ -191,3 +191,31 @@ def test_deadline_cancels_a_fast_path_round_in_flight(hip_lib, oracle_lib):
     s.set_deadline(0)
     W.prepare(s, wl)
     scenario.assert_same_round(full, s.schedule_round())
+
+
+@pytest.mark.gpu
+def test_deadline_ends_a_round_whose_node_engine_is_stuck(hip_lib, monkeypatch):
+    """Round 6 ("bounded waits", armada_sched.hip): ASCHED_DEBUG_HANG=<n> makes the cold-set wave of a bulk-merged stream run stop answering at its n-th command (the node engine then waits for it) — what a protocol
+    defect between the waves of the control workgroup looks like from outside (profiles/r05y_bulk_skip_hang.txt was one).  Every spin on the other side (the control wave's
+    ring waits, the bind wave, the cold-set wave, the engine's own waits) counts its turns and looks at the caller's cancel word: with a deadline set the call returns
+    ASCHED_ERR_TIMEOUT instead of hanging, and after a fresh round_prepare the handle computes the round a healthy launch computes."""
+    import time
+    wl = W.config3(n_nodes=50_000, n_jobs=500_000, n_queues=64, seed=W.SEED)
+    wl.global_burst, wl.queue_burst = 100_000, 10_000
+    s = W.load(hip_lib, wl)
+    W.prepare(s, wl)
+    full = s.schedule_round()
+    assert s.round_stats()["stream_jobs"] > 50_000
+    monkeypatch.setenv("ASCHED_DEBUG_HANG", "500")
+    W.prepare(s, wl)
+    s.set_deadline(0.3)
+    t0 = time.perf_counter()
+    with pytest.raises(SchedError) as e:
+        s.schedule_round()
+    dt = time.perf_counter() - t0
+    assert e.value.code == ERR_TIMEOUT and dt < 5.0, (e.value.code, dt)
+    monkeypatch.delenv("ASCHED_DEBUG_HANG")
+    s.set_deadline(0)
+    W.prepare(s, wl)
+    scenario.assert_same_round(full, s.schedule_round())
+    s.close()
