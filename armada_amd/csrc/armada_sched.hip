@@ -779,7 +779,7 @@ __device__ static inline void accountVectors(Dev& d, KREF k, int q, int pc, bool
 // are ruled out by construction (eng.live; the CPU build aborts on a wide op posted with the engine live).
 #define SPIN_CHECK 0x3fffu
 #define SPIN_LIMIT (1u << 26)
-__device__ static inline bool waitExpired(unsigned& spins) {
+__device__ static inline bool waitExpired(unsigned& spins) {   // (inline, and streamIdle's watch too: out of line — tried for the gang rounds, which pay ~2.5 % for these waits — the callers stop being leaf functions and the headline round loses 7 ms)
   if ((++spins & SPIN_CHECK) != 0) return false;
   bool ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.abandon, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0;
   if (!ab && (spins >= SPIN_LIMIT || cancelRequested(g_dev))) {
@@ -800,28 +800,29 @@ __device__ static inline bool waitGaveUp(unsigned& spins) {   // the cold wave's
   return waitAbandoned();
 }
 #define IDLE_BUDGET (1u << 22)   // in units of 1 024 shader-clock ticks: ~2 s without one entry placed or bound while the control wave does nothing but wait
+__device__ static inline void streamIdleWatch(unsigned long long clk) {
+  const int abV = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.abandon, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+  // the tick budget: entries placed + entries bound stand still over a stretch of CONTINUOUS waiting (a visit more than three periods after the last one starts a new stretch)
+  const unsigned now = (unsigned)(clk >> 10) | 1u;
+  const int prog = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringAck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) + __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.bindDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+  const unsigned since = (unsigned)__builtin_amdgcn_readfirstlane(g_fl.eng.idleSince), last = (unsigned)__builtin_amdgcn_readfirstlane(g_fl.eng.idleLast);
+  const bool fresh = since == 0 || prog != __builtin_amdgcn_readfirstlane(g_fl.eng.idleProg) || now - last > (3u << 11);
+  bool expired = !fresh && now - since > IDLE_BUDGET;
+  if (fresh) { __hip_atomic_store(&g_fl.eng.idleProg, prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_store(&g_fl.eng.idleSince, (int)now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  __hip_atomic_store(&g_fl.eng.idleLast, (int)now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (expired && abV == 0) raise(g_dev, ASCHED_ERR_DEVICE, 950);
+  if (abV != 0 || expired || cancelRequested(g_dev)) {
+    if (abV == 0) __hip_atomic_store(&g_fl.eng.abandon, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&g_fl.eng.cancel, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringFail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) __hip_atomic_store(&g_fl.eng.ringFail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
 __device__ static inline void streamIdle() {   // the control wave while the ring is full / drains: its waits look at ringFail every turn, so giving up = a failure posted there
+  const unsigned long long clk = __builtin_readcyclecounter();   // (issued BEFORE the sleep: its ~80 clocks pass while the wave sleeps; behind the sleep they delayed every wake-up — gang rounds +3.5 %)
   __builtin_amdgcn_s_sleep(2);
   // No counter in LDS or registers (the macro has no state; a 64-lane LDS add per turn took the LDS from the node engine): the shader clock says when to look — one window
   // of 2 048 ticks in every 2^21 (~1 ms); a turn of any of these waits is shorter than the window, so every period is seen at least once.
-  const unsigned long long clk = __builtin_readcyclecounter();
-  if ((((unsigned)clk) & 0x1fffffu) < 0x800u) {
-    const int abV = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.abandon, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-    // the tick budget: entries placed + entries bound stand still over a stretch of CONTINUOUS waiting (a visit more than three periods after the last one starts a new stretch)
-    const unsigned now = (unsigned)(clk >> 10) | 1u;
-    const int prog = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringAck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) + __builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.bindDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-    const unsigned since = (unsigned)__builtin_amdgcn_readfirstlane(g_fl.eng.idleSince), last = (unsigned)__builtin_amdgcn_readfirstlane(g_fl.eng.idleLast);
-    const bool fresh = since == 0 || prog != __builtin_amdgcn_readfirstlane(g_fl.eng.idleProg) || now - last > (3u << 11);
-    bool expired = !fresh && now - since > IDLE_BUDGET;
-    if (fresh) { __hip_atomic_store(&g_fl.eng.idleProg, prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_store(&g_fl.eng.idleSince, (int)now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-    __hip_atomic_store(&g_fl.eng.idleLast, (int)now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (expired && abV == 0) raise(g_dev, ASCHED_ERR_DEVICE, 950);
-    if (abV != 0 || expired || cancelRequested(g_dev)) {
-      if (abV == 0) __hip_atomic_store(&g_fl.eng.abandon, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_store(&g_fl.eng.cancel, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&g_fl.eng.ringFail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) __hip_atomic_store(&g_fl.eng.ringFail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-  }
+  if ((((unsigned)clk) & 0x1fffffu) < 0x800u) streamIdleWatch(clk);
 }
 __device__ static inline void bindUpdateEng(KREF k, FastS& S, int n, int nl, uint64_t keyDelta, const int64_t* req) {
   int lane = threadIdx.x & 63;

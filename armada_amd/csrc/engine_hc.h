@@ -254,13 +254,17 @@ struct HcHot { unsigned long long key, cls; long long ex0, ex1; int node, state,
 // fields cost ONE HBM round trip, fetched on demand for every shape that lacks them at once (hcShapesFetch).  st: 0 nothing left, 1 scanning from pos (inclusive), 2 the
 // head candidate at pos has its fields here.  lb: key of the candidate consumed last = a lower bound for what the base can still offer the shape (the base is sorted).
 enum { SC_NONE = 0, SC_SCAN = 1, SC_HEAD = 2 };
-struct HcShapes { int pos[2], st[2], node[2], wIdx[2]; unsigned long long w[2], key[2], cls[2], lb[2]; long long ex0[2], ex1[2]; };
+// The SPARE (pos2 >= 0): the candidate behind the head — the next set bit of the same bitmap word, fetched in the head's round trip.  A consumed head is replaced by it
+// without a memory access (half of the fetches of a headline round, profiles/r06z_spare_candidates.txt); a spare whose node another shape takes is dropped.
+struct HcShapes { int pos[2], st[2], node[2], wIdx[2]; unsigned long long w[2], key[2], cls[2], lb[2]; long long ex0[2], ex1[2];
+                  int pos2[2], node2[2]; unsigned long long key2[2], cls2[2]; long long ex02[2], ex12[2]; };
 __device__ static inline void hcShapesLoad(KREF k, HcShapes& sc) {   // from the LDS cursors, as the serial engine left them
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int x = 0; x < 2; x++) {
     const int s = lane + 64 * x;
     sc.st[x] = SC_NONE; sc.pos[x] = 0; sc.node[x] = -1; sc.wIdx[x] = -1; sc.w[x] = 0; sc.key[x] = 0; sc.cls[x] = 0; sc.lb[x] = 0; sc.ex0[x] = 0; sc.ex1[x] = 0;
+    sc.pos2[x] = -1; sc.node2[x] = -1; sc.key2[x] = 0; sc.cls2[x] = 0; sc.ex02[x] = 0; sc.ex12[x] = 0;
     if (s < k.S) {
       const CandRec c = g_fl.cand[s];
       if (c.node >= 0) { sc.st[x] = SC_HEAD; sc.pos[x] = c.pos; sc.node[x] = c.node; sc.key[x] = c.key; sc.cls[x] = c.cls; sc.ex0[x] = c.ex0; sc.ex1[x] = c.ex1; }
@@ -289,7 +293,13 @@ __device__ static inline void hcShapesUsed(HcShapes& sc, int P) {
   for (int x = 0; x < 2; x++) {
     sc.w[x] = sc.wIdx[x] == wi ? sc.w[x] & ~bit : sc.w[x];
     const bool was = (sc.st[x] == SC_HEAD) & (sc.pos[x] == P);
-    sc.lb[x] = was ? sc.key[x] : sc.lb[x]; sc.pos[x] = was ? P + 1 : sc.pos[x]; sc.st[x] = was ? SC_SCAN : sc.st[x];
+    const bool promote = was & (sc.pos2[x] >= 0);   // (the spare lies behind the head: P is not its position)
+    const bool scan = was & !promote;
+    sc.lb[x] = was ? sc.key[x] : sc.lb[x];
+    sc.key[x] = promote ? sc.key2[x] : sc.key[x]; sc.cls[x] = promote ? sc.cls2[x] : sc.cls[x]; sc.node[x] = promote ? sc.node2[x] : sc.node[x];
+    sc.ex0[x] = promote ? sc.ex02[x] : sc.ex0[x]; sc.ex1[x] = promote ? sc.ex12[x] : sc.ex1[x];
+    sc.pos[x] = promote ? sc.pos2[x] : (scan ? P + 1 : sc.pos[x]); sc.st[x] = scan ? SC_SCAN : sc.st[x];
+    sc.pos2[x] = (promote | (sc.pos2[x] == P)) ? -1 : sc.pos2[x];
   }
 }
 // every scanning shape advances to its next candidate (bitmap word where the cached one does not cover the cursor: one HBM round trip; then the candidate's fields and
@@ -309,6 +319,7 @@ __device__ static inline void hcShapesFetch(KREF k, FastS& ES, HcShapes& sc, int
     }
     ES.statScanSteps++;
     unsigned long long fKey[2], fCls[2]; long long fEx0[2], fEx1[2]; int fNode[2], fRem[2], hp[2]; bool needF[2];
+    unsigned long long gKey[2], gCls[2]; long long gEx0[2], gEx1[2]; int gNode[2], gRem[2], hp2[2]; bool needG[2];   // the spare: the set bit behind the first
 #pragma unroll
     for (int x = 0; x < 2; x++) {
       const int wi = sc.pos[x] >> 6;
@@ -324,12 +335,26 @@ __device__ static inline void hcShapesFetch(KREF k, FastS& ES, HcShapes& sc, int
         fKey[x] = k.baseKey[q]; fCls[x] = k.baseCls[q]; fNode[x] = k.baseNode[q];
         fEx0[x] = k.E > 0 ? k.baseExtra[q] : 0; fEx1[x] = k.E > 1 ? k.baseExtra[k.Npad + q] : 0;
       }
+      const unsigned long long m2 = m & (m - 1);
+      needG[x] = needF[x] & (m2 != 0);
+      hp2[x] = wi * 64 + (int)__builtin_ctzll(m2 | (1ull << 63));
+      gKey[x] = 0; gCls[x] = 0; gEx0[x] = 0; gEx1[x] = 0; gNode[x] = -1; gRem[x] = 1;
+      if (needG[x]) {
+        const int q = hp2[x];
+        gRem[x] = (int)__hip_atomic_load(&k.baseRemoved[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gKey[x] = k.baseKey[q]; gCls[x] = k.baseCls[q]; gNode[x] = k.baseNode[q];
+        gEx0[x] = k.E > 0 ? k.baseExtra[q] : 0; gEx1[x] = k.E > 1 ? k.baseExtra[k.Npad + q] : 0;
+      }
     }
 #pragma unroll
     for (int x = 0; x < 2; x++) {
       if (needF[x]) {
         if (fRem[x]) { sc.w[x] &= ~(1ull << (hp[x] & 63)); sc.pos[x] = hp[x] + 1; }
-        else { sc.st[x] = SC_HEAD; sc.pos[x] = hp[x]; sc.key[x] = fKey[x]; sc.cls[x] = fCls[x]; sc.node[x] = fNode[x]; sc.ex0[x] = fEx0[x]; sc.ex1[x] = fEx1[x]; }
+        else {
+          sc.st[x] = SC_HEAD; sc.pos[x] = hp[x]; sc.key[x] = fKey[x]; sc.cls[x] = fCls[x]; sc.node[x] = fNode[x]; sc.ex0[x] = fEx0[x]; sc.ex1[x] = fEx1[x];
+          const bool sp = needG[x] & (gRem[x] == 0);   // (a removed entry behind the head: no spare; the scan meets its bit later)
+          sc.pos2[x] = sp ? hp2[x] : -1; sc.key2[x] = gKey[x]; sc.cls2[x] = gCls[x]; sc.node2[x] = gNode[x]; sc.ex02[x] = gEx0[x]; sc.ex12[x] = gEx1[x];
+        }
       }
     }
     const int ts = tx ? __builtin_amdgcn_readlane(sc.st[1], tl) : __builtin_amdgcn_readlane(sc.st[0], tl);
@@ -374,6 +399,10 @@ struct HcOut { int engSeq, statScanSteps, statL0Max; long long segT, eseg[8]; };
 template <int E> __device__ static __attribute__((noinline)) HcOut engineStreamHcT(Dev& d, const FastK k, const int engSeq0, const int statScan0, const int statL0Max0, const long long segT0) {
   // (every argument BY VALUE: a reference to the caller's constants or counters would put them in memory over there — the serial engine's loops read them too;
   //  measured: 20 % on gang-heavy rounds, profiles/r06v)
+  // (The arguments of a function that is not inlined count as lane-DIVERGENT for the compiler, and so does everything loaded through the flat `Dev&`: with the cancel word
+  //  on the way to a `break` the per-job loop has a divergent exit, its carried values live in vector registers and 65 of its 82 branches are exec-masked ones
+  //  (opt -passes='print<uniformity>').  Making the inputs uniform — g_dev, v_readfirstlane on the counters and the cancel word: 33 divergent branches left — was
+  //  measured SLOWER, 262 -> 291 ms on the headline round: the scalar file is what this kernel is short of.  profiles/r06z_uniform_arguments.txt)
   FastS ES; ES.engSeq = engSeq0; ES.statScanSteps = statScan0; ES.statL0Max = statL0Max0; ES.segT = segT0; ES.laneL = 0; ES.laneX = 0;
 #ifdef ASCHED_FASTPROF
   for (int x = 0; x < 8; x++) ES.eseg[x] = 0;

@@ -287,6 +287,9 @@ HD void fastKInit(const Dev& d, FastK& k) {
 }
 // a register copy of the constants: one burst of scalar loads (constant address space) per call, then no memory traffic
 #if defined(__HIP_DEVICE_COMPILE__)
+// (NOT scalar loads, whatever the cast says: the struct copy goes through the copy constructor's generic reference and comes out as flat loads into vector registers.
+//  Measured the other way round — a word-by-word copy through the constant address space, the constants in SGPRs — the kernel spills 130 more SGPRs and every round
+//  is 4-10 % SLOWER: the vector file has room for them, the scalar file has not; profiles/r06z_uniform_arguments.txt)
 __device__ static inline FastK fastKRef(const Dev& d) { return *(const __attribute__((address_space(4))) FastK*)d.fk; }
 #else
 HD FastK fastKRef(const Dev& d) { return *d.fk; }
