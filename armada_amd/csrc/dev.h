@@ -108,7 +108,8 @@ struct FastCfg {
                               // JobRec.shape, the candidate cache, the shape table and the fit masks are indexed by fit shape (scheduling keys that differ only in the
                               // priority class share one base cursor)
   int maskMode;               // <= 128 fit shapes (1: <= 64, 2: <= 128) and fit bitmaps on: the L0 list holds per-node fit masks over the fit shapes; was: baseCls / l0Cls / CandRec.cls hold per-shape fit masks (current capacity and requirement class folded in), not class bits
-  int debugHang;              // tests only (ASCHED_DEBUG_HANG=<n>): the node engine stops answering at its n-th job of a ring session, as a protocol defect would make it — every wait must still end
+  int debugHang;              // tests only (ASCHED_DEBUG_HANG=<n>): the cold-set wave stops answering at its n-th command of a ring session, as a protocol defect would make it — every wait must still end
+  int mgMin;                  // round_merge.h: a run of at least this many entries is merged by the bulk passes (MG_MIN_ENTRIES_DEFAULT; ASCHED_MERGE_MIN=<n> for soaks: small rounds through the bulk merge and the split node engine)
   int engineHc;               // the ring session of a bulk-merged stream run uses the split level-0 structure (engine_hc.h): hot set / cold set / clean front; ASCHED_ENGINE_HC=1 turns it on
   int engine;                 // queued-job iterations run on two waves (round_fast.h "two-wave iteration"); ASCHED_ENGINE=0 turns it off
   int E; int extraCol[MAXE];  // non-indexed columns
@@ -237,7 +238,9 @@ struct MgDev {
   int32_t* rank;     // [cap] position in the merged order
   MgEnt* merged;     // [cap]
   WideKey* cmax;     // [QCAPF * MG_CPQ] maximum of each chunk of a queue's keys
-  uint32_t* stop;    // [4] first merged position that is NOT valid (atomic min); total entries; scratch
+  uint32_t* stop;    // [4] first merged position that is NOT valid (atomic min); total entries; W_MG_CUT: entries the run can serve at most; 1 = the cut is on
+  WideKey* cut;      // [1] W_MG_CUT: K* — entries above it are left out of this run's merged order
+  uint32_t* cutPick; // [1] W_MG_CUT: (samples at or below the key) << 16 | sample, atomic min over the samples that cover the need
   int32_t cap, pad;
 };
 #define MG_CHUNK 64

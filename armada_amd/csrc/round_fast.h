@@ -1551,7 +1551,7 @@ DEV NestIO streamNestGangBody(Dev& d, FastCtx fc, StreamIn in, NestIO st, int t)
 DEV_NOINLINE void streamNestGang(Dev& d, FastCtx fc, StreamIn in, int t);
 DEV RunState streamMerge(Dev& d, FastCtx fc, int Q, int skip, int nest, RunState m);
 DEV RunState streamStaged(Dev& d, FastCtx fc, int Q, int skip, int V, RunState m);   // the same for a run whose merged order exists already (round_merge.h)
-DEV_NOINLINE int mgPrepare(Dev& d, FastCtx fc, int Q, int skip);                    // round_merge.h
+DEV_NOINLINE int mgPrepare(Dev& d, FastCtx fc, int Q, int skip, int need);                    // round_merge.h
 // ---- (round 5) a run does not end where a queue's stream ends at a gang.  A queue's stream is cut at its next gang member (B_QSSUM), and until round 4 the run ended
 // the moment any queue used its stream up — on gang-heavy pools (BASELINE configs[3]) most single jobs therefore took the per-job iteration, whose queue side costs the
 // control wave 8.5 k ticks against ~4 k for a merged entry, while the node engine idled 58 % (profiles/r05j_gangs_segments.txt).  Now, when the element behind a used-up
@@ -2105,7 +2105,7 @@ DEV bool mgWorth(Dev& d, int Q) {
   static const int minEntries = getenv("HS_MG_MIN") ? atoi(getenv("HS_MG_MIN")) : MG_MIN_ENTRIES_DEFAULT;
   if (getenv("HS_NO_MERGE")) return false;
 #else
-  const int minEntries = MG_MIN_ENTRIES_DEFAULT;
+  const int minEntries = d.f.mgMin;
 #endif
   const FastK k = fastKRef(d);
   // one lane per queue, the verdict through ballots (a serial walk over the queues' LDS records costs ~13 k ticks per call, and gang-heavy rounds ask twenty thousand times:
@@ -2292,7 +2292,7 @@ DEV_NOINLINE int fastRun(Dev& d, Ctl& c, const PassCfg& pc, int mode, int* count
         int bulkV = 0;
         if (d.mg && mgWorth(d, Q)) {
           if (S.engLive) { engineStop(d, S); S.engLive = 0; if (UNI32(FL.eng.cancel)) { c.cancelSeen = 1; break; } }
-          bulkV = mgPrepare(d, fc, Q, c.skipActive);
+          bulkV = mgPrepare(d, fc, Q, c.skipActive, want);
         }
         if (!S.engLive) { engineStart(d, S); S.engLive = 1; }
         StreamIn in; in.globalTokens = S.globalTokens; in.globalBurst = S.globalBurst; in.globalRateInf = S.globalRateInf; in.engSeq = S.engSeq; in.bulkV = bulkV;

@@ -12,6 +12,10 @@
 // Passes (bodies below, run through wgWide on the control workgroup and the helper workgroups; they read and write HBM only):
 //   W_MG_PACK     (queue, chunk of 64): packed keys (packKey3 on the precomputed costs: d.qsKey / d.evKey), running maximum within the chunk, the chunk's maximum
 //   W_MG_FIX      queue: the running maximum across the chunks
+//   W_MG_CUT      (round 6) a run can serve at most `need` entries (the global tokens left + the evicted entries there are): a key K* with at least that many entries at or
+//                 below it is found from every 256th key of each queue (a sample at or below K* stands for 256 entries of its queue at or below K*), and only
+//                 entries with key <= K* are ranked and scattered — plus each queue's first entry above it, whose rank is where the merged order ends.  On the
+//                 headline round: 1 M entries, 200 k tokens -> the rank pass works on ~215 k (profiles/r06z_merge_cut.txt)
 //   W_MG_RANK     (element, slice of the other queues): the binary searches
 //   W_MG_SCATTER  element: merged[rank] = (job, queue, stream position); where the merged order stops being valid
 // The run stops — before any side effect — at the first of: a queue in the heap whose head is not a stream element (ONE entry under its heap key: nothing that orders
@@ -23,7 +27,9 @@
 // The CPU build replays the heap merge literally after the passes and aborts on the first difference (mgCheck).
 #pragma once
 
-enum { W_MG_PACK = 32, W_MG_FIX, W_MG_RANK, W_MG_SCATTER };
+enum { W_MG_PACK = 32, W_MG_FIX, W_MG_RANK, W_MG_SCATTER, W_MG_CUT };
+#define MG_SAMPLE 256   // W_MG_CUT: every 256th key of a queue is a sample
+#define MG_SPQ (QS_CMAX / MG_SAMPLE)
 #define MG_PER 16      // other queues one item of the rank pass walks for its element
 #define MG_RG 16       // binary searches that run side by side (independent loads in flight together: a step of the group is one memory round trip)
 #define MG_F_STREAM 1
@@ -87,6 +93,10 @@ DEV_COLD void mergeBulkAny(Dev& d, int kind, int i) {
       const int ent = i % total, slice = i / total;
       const int q = mg.own[ent] & 0xffffff;
       const WideKey key = mg.key[ent];
+      if (mg.stop[3]) {   // the cut: entries above K* are not ranked — but for the first such entry of a queue (its rank ends the merged order)
+        const WideKey ks = mg.cut[0];
+        if (wideKeyLess(ks, key) && ent != mg.q[q].off && wideKeyLess(ks, mg.key[ent - 1])) break;
+      }
       const int myName = mg.q[q].nameRank;
       const int Q = d.cfg.Q;
       const int g0 = slice * MG_PER, g1 = g0 + MG_PER < Q ? g0 + MG_PER : Q;
@@ -127,11 +137,31 @@ DEV_COLD void mergeBulkAny(Dev& d, int kind, int i) {
       const int e = i - s.off;
       const int rank = mg.rank[i];
       if (s.flags & MG_F_BARRIER) { atomicMinU32(&mg.stop[0], (uint32_t)rank); break; }
+      if (mg.stop[3] && wideKeyLess(mg.cut[0], mg.key[i])) {   // above the cut: not part of this run's merged order, which ends in front of the first of them
+        if (e == 0 || !wideKeyLess(mg.cut[0], mg.key[i - 1])) atomicMinU32(&mg.stop[0], (uint32_t)rank);
+        break;
+      }
       const int pos = s.start + e;
       MgEnt en; en.job = mgCost(d, s, q, pos).job; en.qk = q | ((s.kind & 1) ? (1 << 30) : 0); en.e = pos; en.ci = i;
       mg.merged[rank] = en;
       if (e == s.total - 1 && (s.flags & MG_F_OPEN)) atomicMinU32(&mg.stop[0], (uint32_t)(rank + 1));
       if (dec && (s.flags & MG_F_SKIP)) atomicMinU32(&mg.stop[0], (uint32_t)rank);
+    } break;
+    case W_MG_CUT: {   // item = (queue, sample): how many entries are AT LEAST at or below this sample's key — 256 per sample at or below it, over all queues
+      const int q = i / MG_SPQ, j = i % MG_SPQ;
+      const MgQ s = mg.q[q];
+      if (!(s.flags & MG_F_STREAM) || (j + 1) * MG_SAMPLE > s.total) break;
+      const WideKey ks = mg.key[s.off + j * MG_SAMPLE + MG_SAMPLE - 1];
+      const int Q = d.cfg.Q;
+      uint32_t cnt = 0;
+      for (int q2 = 0; q2 < Q; q2++) {
+        const MgQ o = mg.q[q2];
+        if (!(o.flags & MG_F_STREAM)) continue;
+        int lo = 0, hi = o.total / MG_SAMPLE;   // samples of q2 at or below ks: a prefix (the keys are running maxima)
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (!wideKeyLess(ks, mg.key[o.off + mid * MG_SAMPLE + MG_SAMPLE - 1])) lo = mid + 1; else hi = mid; }
+        cnt += (uint32_t)lo;
+      }
+      if ((uint64_t)cnt * MG_SAMPLE >= (uint64_t)mg.stop[2]) atomicMinU32(&mg.cutPick[0], (cnt << 16) | (uint32_t)i);   // the smallest such key (count and key grow together; equal keys, equal counts)
     } break;
   }
 }
@@ -181,12 +211,12 @@ static void mgCheck(Dev& d, const FastCtx& fc, int Q, int skip, int V) {
 // The merged order of the run that is about to start, for the queues' streams as fastStreamRun will see them.  Control wave, node engine STOPPED (the passes use every
 // wave of the workgroup).  Returns the number of valid merged entries; 0 = this run is merged by the control wave as before (too few entries; a gang the run would nest;
 // a stream longer than the key arrays).
-DEV_NOINLINE int mgPrepare(Dev& d, FastCtx fc, int Q, int skip) {
+DEV_NOINLINE int mgPrepare(Dev& d, FastCtx fc, int Q, int skip, int need) {   // need: queued jobs the run can serve at most (the global tokens), INT32_MAX = no such bound
 #ifdef ASCHED_HOSTSIM
   { static const bool off = getenv("HS_NO_MERGE") != nullptr; if (off) return 0; }
   static const int minEntries = getenv("HS_MG_MIN") ? atoi(getenv("HS_MG_MIN")) : MG_MIN_ENTRIES;
 #else
-  const int minEntries = MG_MIN_ENTRIES;
+  const int minEntries = d.f.mgMin;
 #endif
   if (!d.mg || fc.replay || Q > QCAPF) return 0;
   const FastK k = fastKRef(d);
@@ -225,18 +255,33 @@ DEV_NOINLINE int mgPrepare(Dev& d, FastCtx fc, int Q, int skip) {
   FOR_LANES(q, Q) { const MgQ s = describe(q, 0); FL.tmpQ[q] = s.total; FL.tmpN[q] = (uint32_t)s.pad_; }
   LANE0_PUBLISHED();
   int total = 0, bad = 0, streams = 0;
-  for (int q = 0; q < Q; q++) { const int t = UNI32(FL.tmpQ[q]); bad |= (int)UNI32(FL.tmpN[q]); if (FLANE == 0) FL.tmpA[q] = (uint32_t)total; total += t; if (t > 1) streams++; }
+  long long needAll = need;   // the cut (W_MG_CUT): evicted entries cost no token — all of them count on top of `need`
+  for (int q = 0; q < Q; q++) {
+    const int t = UNI32(FL.tmpQ[q]); bad |= (int)UNI32(FL.tmpN[q]); if (FLANE == 0) FL.tmpA[q] = (uint32_t)total; total += t; if (t > 1) streams++;
+    if (UNI32(FL.sKind[q]) && UNI32(FL.inHeap[q]) && UNI32(FL.hot[q].sLen) > UNI32(FL.hot[q].sPos)) needAll += t;
+  }
   LANE0_PUBLISHED();
   if (!(bad || total < minEntries || total > mg.cap || streams < 1)) FOR_LANES(q, Q) mg.q[q] = describe(q, (int)FL.tmpA[q]);
   FOR_LANES(q, QCAPF) { FL.tmpQ[q] = 0; FL.tmpN[q] = 0; }
   LANE0_PUBLISHED();
   if (bad || total < minEntries || total > mg.cap || streams < 1) return 0;
-  if (FLANE == 0) { mg.stop[0] = 0xffffffffu; mg.stop[1] = (uint32_t)total; }
+  const bool cut = need < INT32_MAX && needAll + 2 * MG_SAMPLE < total && total < (1 << 16) * MG_SAMPLE && Q * MG_SPQ <= (1 << 16);
+  if (FLANE == 0) { mg.stop[0] = 0xffffffffu; mg.stop[1] = (uint32_t)total; mg.stop[2] = cut ? (uint32_t)needAll : 0u; mg.stop[3] = 0; mg.cutPick[0] = 0xffffffffu; }
   LANE0_PUBLISHED();
   FAST_GLOBAL_FENCE();
   const long long t0_ = CLK();
   wgWide(d, W_MG_PACK, Q * MG_CPQ);
   wgWide(d, W_MG_FIX, Q);
+  if (cut) {
+    wgWide(d, W_MG_CUT, Q * MG_SPQ);
+    const uint32_t pick = UNI32(*(volatile uint32_t*)&mg.cutPick[0]);
+    if (pick != 0xffffffffu) {   // (none: fewer complete samples than entries needed — everything is ranked)
+      const int si = (int)(pick & 0xffffu), sq = si / MG_SPQ, sj = si % MG_SPQ;
+      if (FLANE == 0) { mg.cut[0] = mg.key[mg.q[sq].off + sj * MG_SAMPLE + MG_SAMPLE - 1]; mg.stop[3] = 1; }
+      LANE0_PUBLISHED();
+      FAST_GLOBAL_FENCE();
+    }
+  }
   const long long t1_ = CLK();
   wgWide(d, W_MG_RANK, total * ((Q + MG_PER - 1) / MG_PER));
   const long long t2_ = CLK();
@@ -248,7 +293,7 @@ DEV_NOINLINE int mgPrepare(Dev& d, FastCtx fc, int Q, int skip) {
 #ifdef ASCHED_HOSTSIM
   mgCheck(d, fc, Q, skip, V);
   if (getenv("HS_MG_TRACE")) {
-    fprintf(stderr, "bulk merge: %d entries of %d queues, valid %d, skip %d", total, streams, V, skip);
+    fprintf(stderr, "bulk merge: %d entries of %d queues, valid %d, skip %d, cut %d (need %lld)", total, streams, V, skip, (int)mg.stop[3], needAll);
     for (int q = 0; q < Q; q++) { const MgQ& s = mg.q[q]; if (!s.total) continue;
       if ((s.flags & MG_F_BARRIER) && mg.rank[s.off] == (int)stop) fprintf(stderr, " | barrier q%d gctx %d headKind %d headFast %d stage %d itEi %d evEnd %d itQi %d qEnd %d tokens %.0f eff %d sLen %d", q, FL.hot[q].gctx, FL.hot[q].headKind, FL.hot[q].headFast, FL.hot[q].itStage, FL.hot[q].itEi, FL.hot[q].evEnd, FL.hot[q].itQi, FL.hot[q].qEnd, FL.hot[q].tokens, FL.hot[q].effValid, FL.hot[q].sLen);
       if ((s.flags & MG_F_STREAM)) { int last = mg.rank[s.off + s.total - 1]; if ((s.flags & MG_F_OPEN) && last + 1 == (int)stop) fprintf(stderr, " | open q%d total %d kind %d", q, s.total, s.kind);
