@@ -99,3 +99,26 @@ def cap_resources(limit_by_pc: Optional[Mapping[str, Sequence[int]]], resources_
         lim = limit_by_pc.get(pc)
         out[pc] = [int(v) for v in r] if lim is None else [min(int(v), int(c)) for v, c in zip(r, lim)]
     return out
+
+
+# ---- report figures of the scheduling context that hosts compute from the round's fair shares (context/scheduling.go); the float work is the library's
+def theoretical_share(sched, name_rank: Sequence[int], weight: Sequence[float], constrained_demand_share: Sequence[float], priority: float, total: Sequence[int]) -> float:
+    """SchedulingContext.CalculateTheoreticalShare (context/scheduling.go:240-256; scheduling_algo.go:984 fills ExperimentalIndicativeShares with it): the
+    demand-capped adjusted fair share a NEW queue of weight 1/priority with infinite demand would get — updateFairShares (asched_fair_shares) over the round's
+    queues plus that one.  Its name is a fresh ULID: digits first, it sorts in front of the queues' names (the order only fixes the float summation order)."""
+    q = len(weight)
+    all_max = sched.drf_cost([INT64_MAX] * len(total), list(total))   # UnweightedCostFromAllocation(MakeAllMax())
+    ranks = [0] + [int(r) + 1 for r in name_rank]
+    _, dc, _ = sched.fair_shares(ranks, [1.0 / float(priority)] + [float(w) for w in weight], [all_max] + [float(c) for c in constrained_demand_share])
+    return float(dc[0]) if q + 1 == len(dc) else float("nan")
+
+
+def fairness_error(sched, allocated: Sequence[Sequence[int]], total: Sequence[int], demand_capped_adjusted_fair_share: Sequence[float]) -> float:
+    """SchedulingContext.FairnessError (context/scheduling.go:632-642; the cycle metric of metrics/cycle_metrics.go:609): the sum over the queues of how far
+    the actual share (UnweightedCostFromAllocation of the queue's allocation) lies BELOW its demand-capped adjusted fair share."""
+    err = 0.0
+    for a, share in zip(allocated, demand_capped_adjusted_fair_share):
+        delta = float(share) - sched.drf_cost(list(a), list(total))
+        if delta > 0:
+            err += delta
+    return err

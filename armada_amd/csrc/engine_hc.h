@@ -513,15 +513,15 @@ template <int E> __device__ static __attribute__((noinline)) HcOut engineStreamH
     }
     const unsigned long long lk2 = hk < ck ? hk : ck;
     const unsigned long long bk = cst == SC_HEAD ? cKey : (cst == SC_SCAN ? cLb : ~0ull);
-    int src;   // 0 H, 1 C, 2 the shape's clean candidate
-    if (lk2 < bk) src = hk < ck ? 0 : 1;
-    else if (cst == SC_HEAD) src = 2;
-    else { fail = 1; break; }
+    // 0 H, 1 C, 2 the shape's clean candidate — selects, not branches (every branch in this loop is an exec-masked one: profiles/r06z_uniform_arguments.txt); only the
+    // cold set's node, which is rare and in LDS, is fetched under one
+    const bool dirtyWins = lk2 < bk;
+    if (!dirtyWins & (cst != SC_HEAD)) { fail = 1; break; }
+    const int src = dirtyWins ? (hk < ck ? 0 : 1) : 2;
     // ---- the pick: its node goes to the bind wave at once; its level-0 entry after the bind (fastAfterBind) is worked out where it lives
-    int n;
-    if (src == 0) n = __builtin_amdgcn_readlane(h.node, hLane);
-    else if (src == 1) n = __builtin_amdgcn_readfirstlane(g_fl.l0Node[cSlot]);
-    else n = __builtin_amdgcn_readlane(hiSet ? sc.node[1] : sc.node[0], sl);
+    const int nH = __builtin_amdgcn_readlane(h.node, hLane & 63), nB = __builtin_amdgcn_readlane(hiSet ? sc.node[1] : sc.node[0], sl);
+    int n = dirtyWins ? nH : nB;
+    if (src == 1) n = __builtin_amdgcn_readfirstlane(g_fl.l0Node[cSlot]);
 #ifdef ASCHED_FASTPROF
     pSrc[src & 3]++;
 #endif
