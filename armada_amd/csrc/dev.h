@@ -171,12 +171,17 @@ struct QueueLoopArrays {
 // ---- NumExcludedNodesByReason (asched_excluded_nodes): what the device keeps of a node selection that ended without a node.  The reasons that do not depend on the
 // round's state (taints, selectors, affinity, total resources) are worked out by the host when somebody asks; the device records what only it knows — which nodes the
 // iterator yielded at the job's priority (a bit per node) and, for the yielded nodes that pass the static checks, the first resource that did not fit and what was there.
-struct ExclRec { int32_t job, level, row, uni, flags, pad[3]; };   // flags bit 0: more dynamic reasons than the arena holds; bit 1: inconsistent (a yielded node that fits)
+struct ExclRec { int32_t job, level, row, uni, flags, gate, fair, pad; };   // flags bit 0: more dynamic reasons than the arena holds; bit 1: inconsistent (a yielded node that fits)
+// gate > 0: the attempt FOUND node gate - 1 at the job's priority and still ended without a node (nodedb.go:747-789 with urgency preemption disabled): the walk that stays
+// on record is the gate's, which stopped at that node — `bits` holds the yielded nodes that order BEFORE it; fair != 0: fair-share preemption ran in between, and `fbits`
+// holds the nodes its walk over the evicted table found room on (the evicted jobs it may take, added in table order, cover the request): the ones among them that fail
+// the static requirements were counted once more (:996-1006) — the host knows which
 struct ExclDyn { int32_t slot, node, res, pad; int64_t avail; };
 struct ExclDev {
   int32_t* jobSlot;      // [M] == Dev::excl: >= 0 the job's record of a failed attempt over the iterators; < 0 an EXCL_S_* code (the outcomes that need no record)
   ExclRec* rec;          // [cap]
   uint64_t* bits;        // [cap][W] nodes the iterator yielded
+  uint64_t* fbits;       // [cap][W] gate-passed records: nodes the failed fair-preemption walk found room on
   ExclDyn* dyn;          // [dynCap] arena, tagged with the record
   int64_t* pinAvail;     // [M] what the pinned node had of the resource that did not fit (EXCL_S_PINNED0 - resource)
   int32_t cap, dynCap, W, cur;   // cur: the record the pass in flight fills
@@ -186,7 +191,7 @@ struct ExclDev {
 #define EXCL_S_DROPPED (-2)       // more failed attempts than `cap` records
 #define EXCL_S_DISALLOWED (-3)    // a disallowed resource was requested: every node, one reason (nodedb.go:596-601)
 #define EXCL_S_NO_ATTEMPT (-4)    // no attempt was made (home scheduling disabled, no usable away type): every node implicit
-#define EXCL_S_UNSUPPORTED (-5)   // order-dependent in the reference: not produced
+#define EXCL_S_UNSUPPORTED (-5)   // not produced (more node types than the literal walk holds; an inconsistent record)
 #define EXCL_S_PINNED0 (-8)       // - resource column: a pinned (evicted) job whose node no longer covers that column (nodedb.go:583-594, 897-920)
 #define EXCL_HDR 256
 #define EXCL(d) ((ExclDev*)((char*)(d).excl - EXCL_HDR))

@@ -80,7 +80,7 @@ DEV int skipUnfeasibleBulk(Dev& d, int pos, int max);   // round_wide.h: the sam
 DEV int skipUnfeasibleRun(Dev& d, int pos, int max);   // round_fast.h: Peek's skip of known-unfeasible scheduling keys (queue_scheduler.go:398-413) for a stretch of queued jobs, 64 at a time
 DEV_COLD int wideRun(Dev& d, Ctl& c, const PassCfg& pc);
 DEV bool wideHeadOk(Dev& d, const Ctl& c, const PassCfg& pc, int t);
-DEV_COLD void exclRecordWide(Dev& d, int job, int level);   // round_wide.h "excluded nodes": what asched_excluded_nodes needs of an attempt that found no node at the job's priority
+DEV_COLD void exclRecordWide(Dev& d, int job, int level, int gate = -1);   // round_wide.h "excluded nodes": what asched_excluded_nodes needs of an attempt that found no node at the job's priority
 DEV_COLD void exclPinned(Dev& d, int job, int node, int level);
 DEV void exclForget(Dev& d, int job) { if (d.excl) d.excl[job] = -1; }   // the job got a node: its PodSchedulingContext is a new one
 DEV void ensureReplay(Dev& d, Ctl& c) { if (d.rs->replayPending) ensureReplaySlow(d, c); }   // (the test stays with the caller: a call costs a register save / restore)
@@ -728,6 +728,7 @@ DEV_COLD int selectAtPriority(Dev& d, Ctl& c, int job) {
     a.maskA = shapeMaskOf(d, job); a.maskB = uniMask(d, job);
     a.level = 1; a.levelHi = lp; a.noFit = 0; a.lowBound = 0; a.pad = 0;
     if (lp == 1) { a.level = 1; a.levelHi = 0; }   // one level: the plain pass
+    if (d.cfg.disableUrgency) { a.level = lp; a.levelHi = 0; }   // no sweep to fuse with: the gate alone, at the job's level — its node is what a failed attempt's record needs (exclRecordWide)
     long long t0 = CLK();
     uint64_t best;
     if (!d.cfg.disableFair && !d.rs->replayPending) {
@@ -761,7 +762,7 @@ DEV_COLD int selectAtPriority(Dev& d, Ctl& c, int job) {
           d.rs->numNodeQueries++;                      // the gate
           if (best == ~0ull) return -1;
           d.pcNode[job] = -1; d.pcPap[job] = ASCHED_MIN_PRIORITY;
-          if (d.cfg.disableUrgency) return -2;
+          if (d.cfg.disableUrgency) return -2 - d.nodeByRank[best & ((1ull << d.cfg.idxBits) - 1)];
           int l = lp == 1 ? 1 : (int)(best >> SCAN_LEVEL_SHIFT);
           d.rs->numNodeQueries += l;                     // levels 1 .. l of the sweep
           n = d.nodeByRank[best & ((1ull << d.cfg.idxBits) - 1)];
@@ -797,7 +798,7 @@ DEV_COLD int selectAtPriority(Dev& d, Ctl& c, int job) {
       }
     }
     d.pcNode[job] = -1; d.pcPap[job] = ASCHED_MIN_PRIORITY;
-    if (d.cfg.disableUrgency) return -2;               // (-2: the gate had found a node — selectNodeForJob's record of the failure says so)
+    if (d.cfg.disableUrgency) return -2 - d.nodeByRank[best & ((1ull << d.cfg.idxBits) - 1)];   // (<= -2: the gate had found node -2 - n — selectNodeForJob's record of the failure needs it)
     int l = lp == 1 ? 1 : (int)(best >> SCAN_LEVEL_SHIFT);
     d.rs->numNodeQueries += l;                       // levels 1 .. l of the sweep
     n = d.nodeByRank[best & ((1ull << d.cfg.idxBits) - 1)];
@@ -806,6 +807,7 @@ DEV_COLD int selectAtPriority(Dev& d, Ctl& c, int job) {
   }
   n = selectAtLevel(d, job, d.pcSap[job]);  // feasibility gate
   if (n < 0) return -1;
+  const int gateNode = n;
   d.pcNode[job] = -1; d.pcPap[job] = ASCHED_MIN_PRIORITY;
   if (!d.cfg.disableFair) {
     n = selectWithFairPreemption(d, c, job);
@@ -821,7 +823,7 @@ DEV_COLD int selectAtPriority(Dev& d, Ctl& c, int job) {
       if (n >= 0) { d.pcMethod[job] = ASCHED_METHOD_URGENCY; return n; }
     }
   }
-  return -2;
+  return -2 - gateNode;
 }
 
 // SelectNodeForJobWithTxn (nodedb.go:538-630)
@@ -847,7 +849,7 @@ DEV int selectNodeForJob(Dev& d, Ctl& c, int job) {
   if (!d.cfg.disableHome) {
     int n = selectAtPriority(d, c, job);
     if (n >= 0) { exclForget(d, job); return n; }
-    if (d.excl && !d.rs->error) { if (n == -2) d.excl[job] = EXCL_S_UNSUPPORTED; else exclRecordWide(d, job, levelOf(d.cfg, d.pcSap[job])); recorded = true; }
+    if (d.excl && !d.rs->error) { exclRecordWide(d, job, levelOf(d.cfg, d.pcSap[job]), n <= -2 ? -2 - n : -1); recorded = true; }
   }
   if (d.cfg.hasAway) {
     bool awayDisabled = d.cfg.disableAway || (d.jGang[job] >= 0 && d.cfg.disableGangAway);
@@ -858,7 +860,7 @@ DEV int selectNodeForJob(Dev& d, Ctl& c, int job) {
         d.rs->awayRowPlus1 = d.cfg.S + d.awayRowOff[s] + (k - d.cfg.pcAwayOff[pc]) + 1;
         d.pcSap[job] = d.cfg.awayPrio[k];      // :719 (stays at the last away priority when every attempt fails)
         int n = selectAtPriority(d, c, job);
-        if (n < 0 && d.excl && !d.rs->error) { if (n == -2) d.excl[job] = EXCL_S_UNSUPPORTED; else exclRecordWide(d, job, levelOf(d.cfg, d.pcSap[job])); recorded = true; }   // (this attempt's row: the last one stays, nodedb.go:736,748)
+        if (n < 0 && d.excl && !d.rs->error) { exclRecordWide(d, job, levelOf(d.cfg, d.pcSap[job]), n <= -2 ? -2 - n : -1); recorded = true; }   // (this attempt's row: the last one stays, nodedb.go:736,748)
         d.rs->awayRowPlus1 = 0;
         if (d.rs->error) return -1;
         if (n >= 0) { d.pcMethod[job] = ASCHED_METHOD_AWAY; exclForget(d, job); return n; }

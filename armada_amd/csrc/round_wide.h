@@ -32,7 +32,7 @@
 // rounds with the oracle for 65 ... 1 024 queues (CPU build and -m gpu).
 #pragma once
 
-enum { W_SEG = 0, W_EVSUM, W_QSUM, W_STITCH, W_PACK, W_FIX, W_RANK, W_SCATTER, W_COMMIT_E, W_COMMIT_Q, W_EXCL, W_SKIP_FIND, W_SKIP_MARK };   // (W_EXCL: not a pass of a wide run — the pass behind asched_excluded_nodes shares the op)
+enum { W_SEG = 0, W_EVSUM, W_QSUM, W_STITCH, W_PACK, W_FIX, W_RANK, W_SCATTER, W_COMMIT_E, W_COMMIT_Q, W_EXCL, W_SKIP_FIND, W_SKIP_MARK, W_EXCLF };   // (W_EXCL: not a pass of a wide run — the pass behind asched_excluded_nodes shares the op)
 #define W_PER 16                        // queues one item of the rank pass walks for its entry: an entry's walk over the other queues is cut into Q / W_PER items (the entries of a run
                                         // alone fill a third of the lanes once)
 #define WQ_CHUNK 8                      // entries one item of the chunked passes covers (streams here are tens of entries long, not thousands: round_run.h uses 64)
@@ -79,11 +79,39 @@ DEV void exclBulk(Dev& d, int n) {
   const int64_t* req = JREQ(d, r.job);
   bool fit = n < c.N;
   if (fit) for (int k = 0; k < c.K; k++) fit = fit && AL(d, r.level, c.indexedCol[k], n) >= req[c.indexedCol[k]];
+  if (fit && r.gate > 0) fit = d.keys[(size_t)r.level * c.Npad + n] < d.keys[(size_t)r.level * c.Npad + (r.gate - 1)];   // the gate's walk stopped at its node: what orders before it was yielded
   exclPutBits(x.bits + (size_t)slot * x.W, n, fit);
   if (!fit) return;
   bool st = (d.shapeMask[(size_t)r.row * c.W + (n >> 6)] >> (n & 63)) & 1;
   if (st && r.uni >= 0) st = (d.labelMask[(size_t)r.uni * c.W + (n >> 6)] >> (n & 63)) & 1;
   if (st) exclDynPut(d, x, slot, n, r.level, req);
+}
+
+// gate-passed records: the failed fair-preemption walk (nodedb.go:935-1043 without a node at its end: every entry of the evicted table is visited).  Per node, its entries in
+// walk order (the per-node index: descending table Index): the ones the job may take (scheduled at or below its priority, :963) are added to what priority -2 leaves
+// on the node; the bit says the request was covered at some point — where the reference then looks at the static requirements (:996-1006).
+DEV void exclFairBulk(Dev& d, int n) {
+  const DevCfg& c = d.cfg;
+  ExclDev& x = *EXCL(d);
+  const int slot = x.cur;
+  const ExclRec& r = x.rec[slot];
+  const int64_t* req = JREQ(d, r.job);
+  bool bit = false;
+  if (n < c.N) {
+    const int32_t sap = c.prios[r.level];
+    int64_t av[MAXR];
+    for (int q = 0; q < c.R; q++) av[q] = AL(d, 0, q, n);
+    for (int k = d.fairOff[n]; k < d.fairOff[n + 1] && !bit; k++) {
+      if (!d.evTabAlive[d.fairEnt[k]]) continue;
+      const int ej = d.fairEntJob[k];
+      if (d.schedAtPrio[ej] > sap) continue;
+      const int64_t* er = JREQ(d, ej);
+      bool met = true;
+      for (int q = 0; q < c.R; q++) { av[q] += er[q]; met = met && av[q] >= req[q]; }
+      bit = met;
+    }
+  }
+  exclPutBits(x.fbits + (size_t)slot * x.W, n, bit);
 }
 
 // ---- Peek's skip of known-unfeasible scheduling keys (queue_scheduler.go:398-413) for a LONG stretch of queued jobs: the steady state the reference's own benchmark times
@@ -104,6 +132,7 @@ DEV_COLD void mergeBulkAny(Dev& d, int kind, int i);   // round_merge.h: the pas
 DEV_COLD void wideBulkAny(Dev& d, int kind, int i) {
   if (kind >= 32 && kind < 40) { mergeBulkAny(d, kind, i); return; }   // (W_MG_*)
   if (kind == W_EXCL) { exclBulk(d, i); return; }
+  if (kind == W_EXCLF) { exclFairBulk(d, i); return; }
   if ((kind & 255) >= W_SKIP_FIND) { skipBulk(d, kind & 255, kind >> 8, i); return; }
   const DevCfg& c = d.cfg;
   WideDev& w = *d.wide;
@@ -472,6 +501,7 @@ DEV_COLD void exclLiteral(Dev& d, ExclDev& x, int slot) {
     for (int k = 0; k < nT; k++) if (d.lit[k].head >= 0 && (best < 0 || litNodeLess(d, r.level, d.lit[k].head, d.lit[best].head))) best = k;
     if (best < 0) return;
     int n = d.lit[best].head;
+    if (r.gate > 0 && n == r.gate - 1) return;   // the node the gate found: its walk stopped here
     litAdvance(d, r.level, d.lit[best], ireq);
     if (FLANE == 0) {
       bits[n >> 6] |= 1ull << (n & 63);
@@ -482,7 +512,7 @@ DEV_COLD void exclLiteral(Dev& d, ExclDev& x, int slot) {
   }
 }
 // the record of an attempt that found no node at the job's priority (round_ctl.h selectNodeForJob)
-DEV_COLD void exclRecordWide(Dev& d, int job, int level) {
+DEV_COLD void exclRecordWide(Dev& d, int job, int level, int gate) {   // gate >= 0: the node the attempt found at the job's priority before it ended without one (ExclRec)
   ExclDev& x = *EXCL(d);
   int slot = d.excl[job];
   if (slot == EXCL_S_DROPPED) return;
@@ -492,10 +522,12 @@ DEV_COLD void exclRecordWide(Dev& d, int job, int level) {
     slot = cnt; x.count = cnt + 1; d.excl[job] = slot;
   }
   ExclRec r;
-  r.job = job; r.level = level; r.row = d.rs->awayRowPlus1 ? d.rs->awayRowPlus1 - 1 : d.jShape[job]; r.uni = d.jcUniValue[job]; r.flags = 0; r.pad[0] = r.pad[1] = r.pad[2] = 0;
+  r.job = job; r.level = level; r.row = d.rs->awayRowPlus1 ? d.rs->awayRowPlus1 - 1 : d.jShape[job]; r.uni = d.jcUniValue[job]; r.flags = 0;
+  r.gate = gate >= 0 ? gate + 1 : 0; r.fair = gate >= 0 && !d.cfg.disableFair; r.pad = 0;
   x.rec[slot] = r;
-  if (d.rowLiteral && d.rowLiteral[r.row]) { exclLiteral(d, x, slot); return; }
   x.cur = slot;
+  if (r.fair) { ensureFairIndex(d); wgWide(d, W_EXCLF, x.W * 64); }
+  if (d.rowLiteral && d.rowLiteral[r.row]) { exclLiteral(d, x, slot); return; }
   wgWide(d, W_EXCL, x.W * 64);
 }
 // a pinned (evicted) job that no longer fits on its node: DynamicJobRequirementsMet's reason on that one node (nodedb.go:897-920) — the first column in factory order

@@ -301,9 +301,10 @@ typedef struct asched_pod_result {
  *      check, queue_scheduler_test.go:676-690).  A pinned (evicted) job: its node's dynamic reason, the rest IMPLICIT.
  *      Where the reference itself is order-dependent the smallest id is reported: a node selector is a Go map (nodematching.go:216-243: the first failing label
  *      in map order), node-type taints are sorted by key STRING (node_type.go:87-97) — intern taint keys in lexicographic order for the same first taint.
- *      Not produced: for jobs that got a node (the nodes rejected before the match depend on the iterator's order: nothing is on record, 0 entries), and — as
- *      ASCHED_ERR_UNSUPPORTED — for attempts that passed the feasibility gate and still ended without a node (urgency preemption disabled: the gate's early exit
- *      makes the histogram order-dependent). ---- */
+ *      Not produced: for jobs that got a node (the nodes rejected before the match depend on the iterator's order: nothing is on record, 0 entries).
+ *      An attempt that passed the feasibility gate and still ended without a node (nodedb.go:747-789: urgency preemption disabled) reports what the reference's map
+ *      holds then: the gate's walk up to the node it stopped at, plus — fair-share preemption on — the static reason of every node the failed walk over the evicted
+ *      table found room on (:996-1006; such a node may be counted twice, as in the reference). ---- */
 typedef struct asched_excluded_reason {
   int32_t kind;       /* ASCHED_EXCL_* */
   int32_t a, b, c;

@@ -149,6 +149,9 @@ def main():
                                     occupied=float(rng.choice([0.0, 0.3, 0.6, 0.9, 1.0])), gangs=int(rng.integers(0, 8)),
                                     burst=None if rng.random() < 0.7 else (int(rng.integers(10, 500)), int(rng.integers(5, 100))),
                                     away=bool(rng.random() < 0.3), ragged=bool(rng.random() < 0.3), offgrid=int(rng.choice([0, 0, 1, 3])))
+                if seed % 4 == 3:   # (round 6) urgency preemption off, fair-share preemption on or off: selections that pass the gate and still end without a node
+                    wl.config.disable_urgency_scheduling = True
+                    wl.config.disable_fairshare_scheduling = bool(seed % 8 == 7)
                 X.check_against_oracle(hs, orc, wl)
             elif kind == "fit":
                 rng = np.random.default_rng(seed)

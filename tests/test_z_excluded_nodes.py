@@ -229,6 +229,48 @@ def test_rounds_match_the_oracle_gpu(hip_lib, oracle_lib, kw):
     assert n > (0 if "burst" in kw else 20)
 
 
+# ---- a selection that FOUND a node at the job's priority and still ended without one (nodedb.go:747-789): only with urgency preemption disabled — with it on, the sweep
+# reaches the gate's node at the latest.  The map then holds the gate's walk up to the node it stopped at, plus (fair-share preemption on) the static reasons of the
+# nodes the failed walk over the evicted table found room on (:996-1006).  Until round 6 both implementations answered ASCHED_ERR_UNSUPPORTED here.
+GATE_SEEDS = [dict(seed=31, occupied=0.9), dict(seed=32, occupied=1.0, away=True), dict(seed=33, occupied=0.9, ragged=True), dict(seed=34, occupied=1.0, offgrid=3),
+              dict(seed=35, occupied=0.9, away=True, ragged=True)]
+METHOD_URGENCY = 4
+
+
+def gate_workload(kw, fair):
+    wl = W.small_random(**kw)
+    wl.config.disable_urgency_scheduling = True
+    wl.config.disable_fairshare_scheduling = not fair
+    return wl
+
+
+def check_gate_passed(lib, oracle_lib, kw, fair):
+    with_urgency = W.small_random(**kw)
+    with_urgency.config.disable_fairshare_scheduling = not fair
+    s = W.load(oracle_lib, with_urgency); W.prepare(s, with_urgency); r = s.schedule_round(); s.close()
+    urgent = [j for j, m in r.scheduled_method.items() if m == METHOD_URGENCY]   # jobs that need the sweep: with it disabled their selection passes the gate and fails
+    n, exp = check_against_oracle(lib, oracle_lib, gate_workload(kw, fair))
+    assert not any(h and h[0] == "error" and h[1] == ERR_UNSUPPORTED for h in exp.values()), "a gate-passed record is produced, not refused"
+    return len(urgent), n
+
+
+@pytest.mark.parametrize("fair", [True, False], ids=["fair-preemption-on", "fair-preemption-off"])
+@pytest.mark.parametrize("kw", GATE_SEEDS, ids=[str(k) for k in GATE_SEEDS])
+def test_gate_passed_records_match_the_oracle_cpu_build(hostsim_lib, oracle_lib, kw, fair):
+    check_gate_passed(hostsim_lib, oracle_lib, kw, fair)
+
+
+def test_gate_passed_selections_occur_in_those_rounds(oracle_lib):
+    assert sum(check_gate_passed(oracle_lib, oracle_lib, kw, False)[0] for kw in GATE_SEEDS) > 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fair", [True, False], ids=["fair-preemption-on", "fair-preemption-off"])
+@pytest.mark.parametrize("kw", GATE_SEEDS + [dict(seed=36, n_nodes=2000, n_jobs=8000, n_queues=10, occupied=0.95)], ids=lambda k: str(k))
+def test_gate_passed_records_match_the_oracle_gpu(hip_lib, oracle_lib, kw, fair):
+    check_gate_passed(hip_lib, oracle_lib, kw, fair)
+
+
 def test_every_kind_of_reason_occurs_in_the_random_rounds(oracle_lib):
     seen = set()
     for kw in SEEDS:
