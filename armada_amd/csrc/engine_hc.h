@@ -7,22 +7,26 @@
 // (measured on the CPU build: DESIGN.md).
 //
 // What.  The level-0 structure of round_fast.h (sorted base + list of dirty nodes, "L0") split three ways for the length of one ring session:
-//   H   the HOT set: the <= 64 dirty nodes modified most recently, one per lane of the engine wave, in registers.  A query is one entryFits per lane, a ballot and
-//       a 64-lane minimum (two 32-bit DPP reductions); a bind rewrites one lane.
+//   H   the HOT set: the <= 48 (HC_H_MAX) dirty nodes modified most recently, one per lane of the engine wave, in registers.  A query is one branch-free fit test per
+//       lane (hcFits: requirement class, every key field through the guard bits, the extras) and a 64-lane minimum (two 32-bit DPP reductions); a bind rewrites one lane.
 //   C   the COLD set: every other dirty node = the LDS list itself (FL.l0*), mirrored in the registers of wave 3 (16 rows x 64 lanes).  Wave 3 answers "minimum-key
-//       entry a job fits on" for the NEXT job while the engine wave finishes the current one, takes the entries H evicts, and gives up the ones that are picked.
-//   CF  the CLEAN FRONT: the next <= 64 clean base entries in base (= key) order, one per lane of the engine wave, gathered from HBM in one go (removed flags, then
-//       the entries' fields).  Base order is key order, so the first lane that fits is the first feasible clean entry; a consumed entry is struck in its lane.
-//       A job no lane fits falls back on its shape's cursor behind the front (baseScan, as before).
+//       entry a job fits on", takes the entries H evicts, gives up the ones that are picked — and keeps, per fit shape, a LOWER BOUND of the keys of its entries the
+//       shape fits on (HCB.clb[128]: lowered by every hand-over, refreshed by every answer).  The engine asks only when that bound lies below both the hot and the clean
+//       candidate it has at hand: 2 246 of 200 000 jobs on the headline round; every other job costs wave 3 nothing and the engine one LDS word in its read batch.
+//   S   the CLEAN side per fit shape (HcShapes): fastFirstFit's base cursor, the bitmap word it stands in, the head candidate's fields and a SPARE (the next set bit,
+//       fetched in the head's round trip), two shapes per lane of the engine wave, in registers.  A consumed head is replaced by the spare without a memory access, else
+//       the shape scans on: ONE fetch serves every scanning shape at once (hcShapesFetch; 20 750 fetches for 51 533 clean picks on the headline round).
+//       (Round 6 tried a "clean front" of the next 64 base entries first: shapes that fit few of them made 175 k of 200 k jobs fall through it — profiles/r06g.)
 // First fit = min(H, C, clean candidate): the same three-way minimum as fastFirstFit — clean entries are unchanged since the sort, H and C hold current values, keys
 // are unique.  When the ring closes the three are folded back into the LDS list / candidate cursors exactly as the serial engine would have left them (same set of
 // dirty nodes, same removed flags and bitmaps; slot numbers differ, which nothing depends on).
 //
-// Protocol engine wave -> wave 3: a ring of 64-byte commands in LDS (the idle key windows FL.evWin), processed strictly in order:
+// Protocol engine wave -> wave 3: a ring of 64-byte commands in LDS (the idle key windows FL.evWin: the queues' windows are invalidated for the session), in order:
 //   HC_Q  what a job needs (key fields, extras, class)              -> reply slot [seq & 3]: best entry (slot, key, node, extras, class bits), inserts done so far
-//   HC_I  an entry H evicts (payload ring)                             it stays in H ("evicting") until a reply says the insert is done: no query can miss it
+//   HC_I  an entry H evicts (payload ring)                             it stays in H ("evicting") until wave 3's counter (HCB.insDone) covers it: no query can miss it
 //   HC_D  slot picked by the engine: the entry leaves C                HC_C  an evicting entry was picked while in flight: its insert is taken back
 //   HC_E  the session ends: compact the LDS list, publish its length
+// Every wait of this protocol reads the launch's `abandon` word (armada_sched.hip "bounded waits") and leaves through an exit its loop has anyway.
 #pragma once
 
 #define HC_CMDS 32
@@ -44,7 +48,6 @@ static_assert(sizeof(HcBox) <= sizeof(g_fl.evWin), "the HC mailbox lives in the 
 #define HCB (*(HcBox*)&g_fl.evWin[0][0])
 #define HC_ROWS (L0CAP / 64)
 #define HC_H_MAX 48     // normal entries H keeps; beyond that the oldest is handed to C
-#define HC_CF_LOW 6     // clean-front entries left when it is gathered again
 
 // minimum over the 64 lanes, wave-uniform.  One v_min_u32 with a DPP source per step (a lane without a source keeps its value); the DPP read of a freshly written
 // register needs two wait states, which the assembler does not insert inside an asm statement.
