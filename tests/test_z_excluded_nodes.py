@@ -209,7 +209,10 @@ def check_against_oracle(lib, oracle_lib, wl, prepare=None):
             n += 1
             assert reasons[j] != 0 or wl.job_gang[j] >= 0 or wl.job_node[j] >= 0, (j, h)
             if wl.job_gang[j] < 0:   # queue_scheduler_test.go:676-690 (gang members are exempt there too)
-                assert sum(x[-1] for x in h) == wl.num_nodes, (j, h)
+                total = sum(x[-1] for x in h)
+                # (urgency preemption disabled: a gate-passed record counts a node the failed fair-preemption walk gave up for its static requirements ON TOP of its
+                #  type's or the gate walk's count, nodedb.go:996-1006 — the sum may exceed NumNodes, and then there is no implicit rest; soak seed 101099)
+                assert total == wl.num_nodes or (wl.config.disable_urgency_scheduling and total > wl.num_nodes), (j, h)
     return n, exp
 
 
