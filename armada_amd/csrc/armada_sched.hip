@@ -50,7 +50,7 @@ struct Mailbox {
 };
 __shared__ Mailbox g_mb;
 __shared__ Dev g_dev;
-#ifdef ASCHED_AUX_TU
+#if defined(ASCHED_AUX_TU) || defined(ASCHED_WK_TU)
 __shared__ MktDev g_mk;   // market-driven rounds (round_mkt.h): this launch's market state, a kernel argument of k_control_aux
 __device__ static inline MktDev* mktDev() { return &g_mk; }
 #endif
@@ -202,6 +202,24 @@ __device__ static unsigned long long scanPart(const Dev& d, const ScanArgs& a, i
   }
   const uint64_t* keys = d.keys + (size_t)a.level * c.Npad;
   const int64_t* plane = d.alloc + (size_t)a.level * c.R * c.Npad;
+#ifdef ASCHED_TWO_WORD_KEYS
+  if (WIDE_KEYS(c)) {   // two-word keys (dev.h keyWords): pass 1 (a.pad == 0) the minimum HIGH word among the fitting nodes, pass 2 (a.pad == 1, a.lowBound = that word) the minimum LOW word among those that carry it
+    const uint64_t* lows = d.keys + ((size_t)c.P + a.level) * c.Npad;
+    for (int n = tid; n < c.N; n += nthreads) {
+      uint64_t w = a.maskA[n >> 6];
+      if (a.maskB) w &= a.maskB[n >> 6];
+      if (!((w >> (n & 63)) & 1)) continue;
+      unsigned long long k = keys[n];
+      if (a.pad) { if (k != a.lowBound) continue; k = lows[n]; if (k < a.lowBoundLo) continue; }
+      else if (k < a.lowBound || (k == a.lowBound && a.lowBoundLo && lows[n] < a.lowBoundLo)) continue;
+      if (k >= best) continue;
+      bool fits = true;
+      if (!a.noFit) for (int r = 0; r < c.R; r++) fits = fits && (a.req[r] <= plane[(size_t)r * c.Npad + n]);
+      if (fits) best = k;
+    }
+    return waveMin64(best);
+  }
+#endif
   for (int n = tid; n < c.N; n += nthreads) {
     uint64_t w = a.maskA[n >> 6];
     if (a.maskB) w &= a.maskB[n >> 6];
@@ -215,7 +233,11 @@ __device__ static unsigned long long scanPart(const Dev& d, const ScanArgs& a, i
   return waveMin64(best);
 }
 
+#ifdef ASCHED_TWO_WORD_KEYS
+__device__ static inline uint64_t wgFirstFitKeyPass(Dev& d, const ScanArgs& a) {
+#else
 __device__ static inline uint64_t wgFirstFitKey(Dev& d, const ScanArgs& a) {
+#endif
   int lane = threadIdx.x & 63;
   if (lane == 0) { g_mb.op = OP_SCAN; g_mb.scan = a; if (g_H) helpIssue(OP_SCAN, &a); }
   __syncthreads();
@@ -232,6 +254,20 @@ __device__ static inline uint64_t wgFirstFitKey(Dev& d, const ScanArgs& a) {
   d.rs->numScans++;
   return best;
 }
+#ifdef ASCHED_TWO_WORD_KEYS
+// -> the minimum order key among the fitting nodes, ~0 = none.  Two-word keys: the LOW word of the minimum (it carries the node-index rank the callers look at), found in two
+// passes — the order is (high word, low word), so the second pass only looks at the nodes that carry the first pass's high word.
+__device__ static inline uint64_t wgFirstFitKey(Dev& d, const ScanArgs& a) {
+  uint64_t best = wgFirstFitKeyPass(d, a);
+  if (WIDE_KEYS(d.cfg)) {
+    if (a.levelHi > a.level) { raise(d, ASCHED_ERR_UNSUPPORTED, 520); return ~0ull; }   // (the fused multi-level pass is one-word only: the host never selects it)
+    if (best == ~0ull) return best;
+    ScanArgs b = a; b.pad = 1; b.lowBound = best; b.lowBoundLo = best == a.lowBound ? a.lowBoundLo : 0;
+    best = wgFirstFitKeyPass(d, b);
+  }
+  return best;
+}
+#endif
 __device__ static inline int wgFirstFit(Dev& d, const ScanArgs& a) {
   unsigned long long best = wgFirstFitKey(d, a);
   if (best == ~0ull) return -1;
@@ -1353,7 +1389,7 @@ __device__ static void relocateIn(Dev& d, int cmd) {
     g_nreloc = 0;
     g_rsGlobal = d.rs;
     int Q = d.cfg.Q, R = d.cfg.R, npc = d.cfg.npc;
-#ifdef ASCHED_AUX_TU
+#if defined(ASCHED_AUX_TU) || defined(ASCHED_WK_TU)
     const bool marketCmd = cmd == CMD_MARKET_ROUND || cmd == CMD_MARKET_QUEUES;   // (the auxiliary kernel's rounds; the round kernel's code does not see this)
 #else
     const bool marketCmd = false;
@@ -1378,7 +1414,7 @@ __device__ static void relocateIn(Dev& d, int cmd) {
       add((void**)&d.pqProposed, q1 * 8); add((void**)&d.pqCurrent, q1 * 8); add((void**)&d.pqBudget, q1 * 8); add((void**)&d.pqSize, q1 * 8);
       add((void**)&d.pqPcPrio, q1 * 4); add((void**)&d.pqSchedPrio, q1 * 4); add((void**)&d.pqGctx, q1 * 4); add((void**)&d.pqInHeap, q1);
       add((void**)&d.replayAlloc, q1 * R * 8);
-#ifdef ASCHED_AUX_TU
+#if defined(ASCHED_AUX_TU) || defined(ASCHED_WK_TU)
       if (marketCmd && g_mk.s) {   // MarketIteratorPQ's items and heap, the merge iterators' held values, the round's market scalars (round_mkt.h)
         add((void**)&g_mk.s, (int)sizeof(MktScalars));
         add((void**)&g_mk.heap, q1 * 4); add((void**)&g_mk.pqPrice, q1 * 8); add((void**)&g_mk.pqRuntime, q1 * 8); add((void**)&g_mk.pqSubmit, q1 * 8); add((void**)&g_mk.pqQueued, q1);
@@ -1546,12 +1582,21 @@ __device__ static void helperMain(const Dev& d, HelpBox* b, int H) {
 // armada_sched_ft.hip compiles this file once more with ASCHED_FT_TU + ASCHED_WITH_FT: the same round kernel WITH the fair-share threshold table (round_ft.h) under the name
 // k_control_ft, in a code object of its own — the table's call sites cost the default round kernel 2-3 % by code placement alone (profiles/r03f_*), so it is not in k_control;
 // the host launches k_control_ft for rounds whose handle carries a table (asched_host.inc ensureFt: crowded pools of >= 50 000 nodes, from the second round on).
-#ifdef ASCHED_FT_TU
+// armada_sched_wk.hip compiles it a third time with ASCHED_WK_TU: the round kernel for handles whose order key takes TWO words (dev.h keyWords, WIDE_KEYS), as k_control_wk —
+// every control command of such a handle runs there (the auxiliary ones too), and its key rebuild as k_bulk_wk.
+#if defined(ASCHED_FT_TU)
 #define K_CONTROL_NAME k_control_ft
+#elif defined(ASCHED_WK_TU)
+#define K_CONTROL_NAME k_control_wk
 #else
 #define K_CONTROL_NAME k_control
 #endif
+#ifdef ASCHED_WK_TU
+__global__ __launch_bounds__(CTL_THREADS) void K_CONTROL_NAME(Dev dev, int cmd, HelpBox* box, int H, MktDev mk) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) g_mk = mk;   // (market-driven rounds of such a handle run here too: round_mkt.h)
+#else
 __global__ __launch_bounds__(CTL_THREADS) void K_CONTROL_NAME(Dev dev, int cmd, HelpBox* box, int H) {
+#endif
   if (blockIdx.x != 0) { helperMain(dev, box, H); return; }
   if (threadIdx.x == 0) { g_box = box; g_H = H; g_gen = 0; g_fl.eng.abandon = 0; g_fl.eng.idleSince = 0; g_fl.eng.idleLast = 0; g_fl.eng.idleProg = 0; }
   // the Dev descriptor (pointers + config) is staged in LDS once; every wave reads it from there
@@ -1606,6 +1651,9 @@ __global__ __launch_bounds__(CTL_THREADS) void K_CONTROL_NAME(Dev dev, int cmd, 
     relocateOut();
     return;
   }
+#ifdef ASCHED_WK_TU
+  if (cmd >= CMD_AUX_FIRST) controlMainAux(d, cmd); else
+#endif
   controlMain(d, cmd);
   __threadfence();
   if ((threadIdx.x & 63) == 0) { g_mb.op = OP_EXIT; if (g_H) helpIssue(OP_HELPERS_EXIT, (const ScanArgs*)nullptr); }
@@ -1618,7 +1666,62 @@ extern "C" __attribute__((visibility("hidden"))) int asched_internal_ft_launch(c
   hipLaunchKernelGGL(k_control_ft, dim3(1 + H), dim3(CTL_THREADS), 0, stream, *dev, cmd, (HelpBox*)helpBox, H);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-#else   // !ASCHED_FT_TU: the grid-wide kernels and the host side exist once, in the main translation unit
+#elif defined(ASCHED_WK_TU)
+__global__ __launch_bounds__(256) void k_bulk_wk(Dev d, int kind, int n) {
+  // (the element bodies ask mkOn(): this code object carries the market-driven round, whose state is an LDS copy of a kernel argument of k_control_wk.  A market round is ONE
+  //  launch of that kernel — the grid-wide phases never belong to one: no market state here)
+  if (threadIdx.x == 0) memset(&g_mk, 0, sizeof g_mk);
+  __syncthreads();
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) bulkElem(d, kind, i);
+}
+// k_fit_batch (below, main translation unit) for a two-word key, one launch per word: pass 0 leaves the minimum HIGH word among a shape's fitting nodes in out[i][0],
+// pass 1 the minimum LOW word among the fitting nodes that carry it in out[i][1] (the node-index rank is in its low bits).
+#define FIT_TILE_WK 256
+__global__ __launch_bounds__(FIT_TILE_WK) void k_fit_batch_wk(Dev d, const int32_t* shapes, int nshapes, int level, unsigned long long* out, int pass) {
+  const DevCfg& c = d.cfg;
+  int n = blockIdx.x * FIT_TILE_WK + threadIdx.x;
+  bool valid = n < c.N;
+  unsigned long long hi = valid ? d.keys[(size_t)level * c.Npad + n] : ~0ull;
+  unsigned long long lo = (valid && pass) ? d.keys[((size_t)c.P + level) * c.Npad + n] : ~0ull;
+  int64_t al[MAXR];
+  for (int r = 0; r < MAXR; r++) al[r] = (valid && r < c.R) ? d.alloc[((size_t)level * c.R + r) * c.Npad + n] : 0;
+  int per = (nshapes + gridDim.y - 1) / gridDim.y;
+  int s0 = blockIdx.y * per, s1 = min(nshapes, s0 + per);
+  int word = n >> 6, bit = n & 63;
+  __shared__ unsigned long long wmin[FIT_TILE_WK / 64];
+  for (int i = s0; i < s1; i++) {
+    int s = shapes[i];
+    bool f = valid && ((d.shapeMask[(size_t)s * c.W + word] >> bit) & 1);
+    const int64_t* req = d.shapeReq + (size_t)s * c.R;
+    for (int r = 0; r < c.R; r++) f = f && req[r] <= al[r];
+    unsigned long long key = hi;
+    if (pass) { f = f && hi == out[(size_t)i * FIT_OSTR]; key = lo; }   // (word 0 is final: pass 0 completed on this stream)
+    unsigned long long v = __ballot(f) ? waveMin64Dpp(f ? key : ~0ull) : ~0ull;
+    if ((threadIdx.x & 63) == 0) wmin[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long m = wmin[0];
+      for (int w = 1; w < FIT_TILE_WK / 64; w++) m = wmin[w] < m ? wmin[w] : m;
+      unsigned long long* o = &out[(size_t)i * FIT_OSTR + pass];
+      if (m != ~0ull && m < __hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(o, m);
+    }
+    __syncthreads();
+  }
+}
+extern "C" __attribute__((visibility("hidden"))) int asched_internal_wk_fit_batch(const Dev* dev, const int32_t* shapes, int ns, int level, unsigned long long* out, int tiles, int ysplit, hipStream_t stream) {
+  for (int pass = 0; pass < 2; pass++) hipLaunchKernelGGL(k_fit_batch_wk, dim3(tiles, ysplit), dim3(FIT_TILE_WK), 0, stream, *dev, shapes, ns, level, out, pass);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+extern "C" __attribute__((visibility("hidden"))) int asched_internal_wk_launch(const Dev* dev, int cmd, hipStream_t stream, void* helpBox, int H, const MktDev* mk) {
+  MktDev none; memset(&none, 0, sizeof none);
+  hipLaunchKernelGGL(k_control_wk, dim3(1 + H), dim3(CTL_THREADS), 0, stream, *dev, cmd, (HelpBox*)helpBox, H, mk ? *mk : none);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+extern "C" __attribute__((visibility("hidden"))) int asched_internal_wk_bulk(const Dev* dev, int kind, int n, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(k_bulk_wk, dim3(grid), dim3(256), 0, stream, *dev, kind, n);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+#else   // the grid-wide kernels and the host side exist once, in the main translation unit
 // ---- grid-wide kernels of the split round (asched_host.inc runRoundSplit): the data-parallel phases of PreemptingQueueScheduler.Schedule over
 // all CUs.  Between launches the authoritative state is in HBM (relocateOut), so the per-element bodies of round_run.h run unchanged.
 __global__ __launch_bounds__(256) void k_bulk(Dev d, int kind, int n) {
@@ -2374,6 +2477,9 @@ static int plat_last_control_launches() { return t_ctx ? t_ctx->lastControlLaunc
 
 extern "C" int asched_internal_aux_launch(const Dev* dev, int cmd, hipStream_t stream, void* helpBox, const MktDev* mk);  // armada_sched_aux.hip
 extern "C" int asched_internal_ft_launch(const Dev* dev, int cmd, hipStream_t stream, void* helpBox, int H);               // armada_sched_ft.hip
+extern "C" int asched_internal_wk_launch(const Dev* dev, int cmd, hipStream_t stream, void* helpBox, int H, const MktDev* mk);               // armada_sched_wk.hip: handles with a two-word order key
+extern "C" int asched_internal_wk_bulk(const Dev* dev, int kind, int n, int grid, hipStream_t stream);
+extern "C" int asched_internal_wk_fit_batch(const Dev* dev, const int32_t* shapes, int ns, int level, unsigned long long* out, int tiles, int ysplit, hipStream_t stream);
 // market-driven rounds: the market state the next auxiliary launch of this thread's handle runs with (asched_host.inc sets it around CMD_MARKET_ROUND)
 static thread_local const MktDev* t_mkt = nullptr;
 static void plat_set_market_dev(const MktDev* m) { t_mkt = m; }
@@ -2392,7 +2498,9 @@ static int plat_run_control(Dev& dev, int cmd) {
   dev.cancel = c->cancelDev;
   if (!hipOk(hipMemsetAsync(c->helpBox, 0, sizeof(HelpBox), c->stream), "help box reset")) return -1;
   (void)hipEventRecord(c->ev0, c->stream);
-  if (cmd >= CMD_AUX_FIRST) {  // submit-check commands: their kernel lives in its own code object (armada_sched_aux.hip)
+  if (dev.cfg.keyWords == 2) {   // a two-word order key: every control command on the kernel built for it (armada_sched_wk.hip)
+    if (asched_internal_wk_launch(&dev, cmd, c->stream, c->helpBox, H, t_mkt)) { c->err = "k_control_wk launch failed"; return -1; }
+  } else if (cmd >= CMD_AUX_FIRST) {  // submit-check commands: their kernel lives in its own code object (armada_sched_aux.hip)
     if (asched_internal_aux_launch(&dev, cmd, c->stream, c->helpBox, t_mkt)) { c->err = "k_control_aux launch failed"; return -1; }
   } else if (isRound && dev.ftT != nullptr) {   // this handle carries a fair-share threshold table: the round kernel that uses it (armada_sched_ft.hip)
     if (asched_internal_ft_launch(&dev, cmd, c->stream, c->helpBox, H)) { c->err = "k_control_ft launch failed"; return -1; }
@@ -2440,6 +2548,8 @@ static void plat_round_times(double* out) { PlatCtx* c = t_ctx; out[0] = c->roun
 static int bulkGrid(int n) { int b = (n + 255) / 256; int cap = (t_ctx->cus > 0 ? t_ctx->cus : 256) * 8; return b < 1 ? 1 : (b > cap ? cap : b); }
 static int plat_bulk(Dev& d, int kind, int n) {
   if (n <= 0) return 0;
+  if (d.cfg.keyWords == 2) { if (asched_internal_wk_bulk(&d, kind, n, bulkGrid(n), t_ctx->stream)) { t_ctx->err = "k_bulk_wk launch failed"; return -1; } }
+  else
   hipLaunchKernelGGL(k_bulk, dim3(bulkGrid(n)), dim3(256), 0, t_ctx->stream, d, kind, n);
   t_ctx->roundLaunches++;
   return hipOk(hipGetLastError(), "k_bulk launch") ? 0 : -1;
@@ -2732,6 +2842,9 @@ static int plat_run_fit_batch(Dev& d, const std::vector<int32_t>& shapes, int le
   int ysplit = std::max(1, std::min(ns, (2048 + tiles - 1) / tiles));  // >= ~2048 workgroups when the node count alone cannot fill 256 CUs
   hipEvent_t e0 = t_ctx->fitEv0, e1 = t_ctx->fitEv1;
   (void)hipEventRecord(e0, t_ctx->stream);
+  const bool two = d.cfg.keyWords == 2;   // a two-word order key: one launch per word (armada_sched_wk.hip k_fit_batch_wk), the low word of the minimum in word 1
+  if (two) { if (asched_internal_wk_fit_batch(&d, dShapes, ns, level, dOut, tiles, ysplit, t_ctx->stream)) { c->err = "k_fit_batch_wk launch failed"; return -1; } }
+  else
   hipLaunchKernelGGL(k_fit_batch, dim3(tiles, ysplit), dim3(FIT_TILE), 0, t_ctx->stream, d, dShapes, ns, level, dOut);
   (void)hipEventRecord(e1, t_ctx->stream);
   std::vector<unsigned long long> wide((size_t)ns * FIT_OSTR), keys(ns);
@@ -2739,7 +2852,7 @@ static int plat_run_fit_batch(Dev& d, const std::vector<int32_t>& shapes, int le
             hipOk(hipStreamSynchronize(t_ctx->stream), "k_fit_batch");
   (void)hipEventElapsedTime(&t_ctx->lastFitMs, e0, e1);
   if (!ok) return -1;
-  for (int i = 0; i < ns; i++) keys[i] = wide[(size_t)i * FIT_OSTR];
+  for (int i = 0; i < ns; i++) keys[i] = (two && wide[(size_t)i * FIT_OSTR] != ~0ull) ? wide[(size_t)i * FIT_OSTR + 1] : wide[(size_t)i * FIT_OSTR];
   std::vector<int32_t> nodeByRank;
   if (!nodeByRankHost) { nodeByRank.resize(d.cfg.N); if (d.cfg.N) (void)hipMemcpy(nodeByRank.data(), d.nodeByRank, d.cfg.N * sizeof(int32_t), hipMemcpyDeviceToHost); nodeByRankHost = nodeByRank.data(); }
   unsigned long long mask = (1ull << d.cfg.idxBits) - 1;
@@ -2927,7 +3040,7 @@ static int plat_run_fair_shares(Dev& dev, int q, const int32_t* nameRank, const 
 
 #include "asched_host.inc"
 
-#endif  // !ASCHED_FT_TU
+#endif  // main translation unit
 #else  // ASCHED_AUX_TU ----------------------------------------------------------------------------------------------------
 // armada_sched_aux.hip compiles this file a second time with ASCHED_AUX_TU defined: the device code above, ONE kernel
 // (k_control_aux: the submit-check commands, round_run.h runAuxCommand) and no host ABI.  A separate translation unit = a

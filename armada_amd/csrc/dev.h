@@ -62,8 +62,21 @@ struct DevCfg {
   int64_t floatingLimit[MAXR];
   // soft time budgets (constraints.go:159-169): 0 = off; clockStepNs > 0 = a stepping clock (testfixtures.SteppingClock), else the device's wall clock
   int64_t maxNewJobNs, maxNewJobPerQueueNs, clockStepNs;
-  int32_t wallClockKHz, pad2_;
+  int32_t wallClockKHz;
+  int32_t keyWords;      // 2: the order key is TWO words (asched_host.inc layoutKeys: more than 64 bits of fields).  `keys` then holds [2][P][Npad]: the high words of every level,
+                         // then the low words (node-index rank in the low idxBits of the LOW word); keyShift[c] >= 64 names a field of the high word.  (In the slot of a pad word.)
 };
+// Two-word order keys are served by the generic path of a round kernel of their own (armada_sched_wk.hip: k_control_wk, k_bulk_wk): in every other device code object the
+// test below is a compile-time `false`, so the one-word kernels carry none of it (their ISA is what it was); the CPU build of the tests decides per handle.
+#if defined(ASCHED_HOSTSIM)
+#define WIDE_KEYS(cfg) ((cfg).keyWords == 2)
+#define ASCHED_TWO_WORD_KEYS 1
+#elif defined(ASCHED_WK_TU)
+#define WIDE_KEYS(cfg) true
+#define ASCHED_TWO_WORD_KEYS 1
+#else
+#define WIDE_KEYS(cfg) false
+#endif
 #define FLOATING_NODE_CAPACITY ((int64_t)1 << 60)
 
 // One job as the fast path reads it: a single 128-byte burst (16 lanes x 8 B) instead of 12 dependent array reads.
@@ -197,7 +210,12 @@ struct ExclDev {
 #define EXCL(d) ((ExclDev*)((char*)(d).excl - EXCL_HDR))
 
 // NodeTypeIterator state (nodeiteration.go:211-251): current lower bound (raw quantities), its packed form, the node it yielded last
+#ifdef ASCHED_TWO_WORD_KEYS
+struct LitIt { int64_t lb[MAXK]; uint64_t bound; int32_t head; int32_t type; uint64_t boundLo; };   // (two-word keys: `bound` is the high word; the host allocates LITIT_BYTES per iterator)
+#else
 struct LitIt { int64_t lb[MAXK]; uint64_t bound; int32_t head; int32_t type; };
+#endif
+#define LITIT_BYTES (sizeof(int64_t) * MAXK + 8 + 4 + 4 + 8)
 
 // ---- wide runs (round_wide.h): stream runs for pools of more than QCAPF queues.  Per queue a stream of at most WIDE_L entries — its remaining cheap evicted jobs, then
 // its next single queued jobs — with precomputed queue-order keys; the k-way merge of QueueCandidateGangIteratorPQ over them is a BULK RANK (every entry counts, by binary

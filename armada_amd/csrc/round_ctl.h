@@ -36,7 +36,17 @@
 // min key >= lowBound among masked nodes (that fit req at level, unless noFit).  levelHi > level: multi-level mode — per node the LOWEST level in
 // [level, levelHi] at which it fits, result = min over nodes of (that level << 60 | key at that level): the urgency sweep and the feasibility gate
 // of one job in one pass over the planes (selectAtPriority)
+#ifdef ASCHED_TWO_WORD_KEYS
+#define SCAN_NO_LOW_WORD(a) ((a).lowBoundLo = 0)
+#else
+#define SCAN_NO_LOW_WORD(a) ((void)0)
+#endif
+#ifdef ASCHED_TWO_WORD_KEYS
+// (two-word keys: lowBound / lowBoundLo = the bound's two words; pad = 1: the second pass of a selection — lowBound is the high word to match, lowBoundLo the least low word)
+struct ScanArgs { int64_t req[MAXR]; const uint64_t* maskA; const uint64_t* maskB; int level; int noFit; uint64_t lowBound; int32_t levelHi, pad; uint64_t lowBoundLo; };
+#else
 struct ScanArgs { int64_t req[MAXR]; const uint64_t* maskA; const uint64_t* maskB; int level; int noFit; uint64_t lowBound; int32_t levelHi, pad; };
+#endif
 #define SCAN_LEVEL_SHIFT 60
 
 struct FairArgs { int64_t req[MAXR]; const uint64_t* maskA; const uint64_t* maskB; int32_t prio; int32_t pad; };
@@ -89,6 +99,7 @@ DEV void ensureReplay(Dev& d, Ctl& c) { if (d.rs->replayPending) ensureReplaySlo
 // ------------------------------------------------------------------------------------------------
 #define AL(d, l, r, n) ((d).alloc[((size_t)(l) * (d).cfg.R + (r)) * (d).cfg.Npad + (n)])
 #define KEY(d, l, n) ((d).keys[(size_t)(l) * (d).cfg.Npad + (n)])
+#define KEYLO(d, l, n) ((d).keys[((size_t)(d).cfg.P + (l)) * (d).cfg.Npad + (n)])   // two-word keys (dev.h keyWords): KEY is the high word, this the low one
 #define JREQ(d, j) ((d).jReq + (size_t)(j) * (d).cfg.R)
 
 #if defined(ASCHED_FASTPROF) && defined(__HIP_DEVICE_COMPILE__)
@@ -154,7 +165,38 @@ DEV uint64_t fastKeyOf(const Dev& d, int n) {
   for (int i = 0; i < d.cfg.K; i++) if (AL(d, 0, d.cfg.indexedCol[i], n) < 0) key &= ~d.f.fieldMask[i];
   return key;
 }
+// the same key as two words (dev.h keyWords == 2): ONE 128-bit integer — field i at bit keyShift[i] (< 128; a field may lie across the word boundary), the node-index
+// rank in the low idxBits — stored as its high and its low 64 bits
+typedef unsigned __int128 Key2;
+#define KEY2_NONE (~(Key2)0)
+DEV Key2 key2Of(uint64_t hi, uint64_t lo) { return ((Key2)hi << 64) | lo; }
+DEV Key2 packKey2(Dev& d, int l, int n) {
+  const DevCfg& c = d.cfg;
+  Key2 k = (Key2)(uint64_t)d.idxRank[n];
+  for (int i = 0; i < c.K; i++) {
+    int64_t q = AL(d, l, c.indexedCol[i], n) / c.indexedRes[i];
+    int64_t f = q - c.keyLo[i];
+    if (f < 0 && c.keyClamp) f = 0;
+    if (f < 0 || (c.keyWidth[i] < 63 && f >= ((int64_t)1 << c.keyWidth[i]))) { raise(d, ASCHED_ERR_UNSUPPORTED, 100 + i); f = 0; }
+    k |= (Key2)(uint64_t)f << c.keyShift[i];
+  }
+  return k;
+}
+DEV void storeKey(Dev& d, int l, int n) {
+  if (WIDE_KEYS(d.cfg)) { Key2 k = packKey2(d, l, n); KEY(d, l, n) = (uint64_t)(k >> 64); KEYLO(d, l, n) = (uint64_t)k; }
+  else KEY(d, l, n) = packKey(d, l, n);
+}
+// node a orders before node b at this level (both words of a two-word key)
+DEV bool keyBefore(Dev& d, int l, int a, int b) {
+  uint64_t ka = KEY(d, l, a), kb = KEY(d, l, b);
+  if (WIDE_KEYS(d.cfg) && ka == kb) return KEYLO(d, l, a) < KEYLO(d, l, b);
+  return ka < kb;
+}
+#ifdef ASCHED_TWO_WORD_KEYS
+DEV void updateKeys(Dev& d, int n) { for (int l = 0; l < d.cfg.P; l++) storeKey(d, l, n); }
+#else   // (the one-word kernels: the statements as they were — their instruction text is pinned, tools/kcontrol_isa_hash.sh)
 DEV void updateKeys(Dev& d, int n) { for (int l = 0; l < d.cfg.P; l++) KEY(d, l, n) = packKey(d, l, n); }
+#endif
 // The control code runs on one full wave whose lanes all execute the same statements.  Where a statement is a loop over (level, resource) elements of one
 // node, the lanes take one element each instead: the loop's dependent HBM round trips (~0.5 us each) become one.  CTL_WAVE(): this really is a full wave.
 #if !defined(ASCHED_HOSTSIM) && defined(__HIP_DEVICE_COMPILE__)
@@ -180,7 +222,11 @@ DEV void ftTouch(Dev&, int) {}
 DEV void ftTouch(Dev& d, int n) { if (d.ftT && d.rs->ftValid) ftUpdateNode(d, n); }
 #endif
 DEV void updateKeysCtl(Dev& d, int n) {  // control-flow call sites (not the bulk rebuild)
+#ifdef ASCHED_TWO_WORD_KEYS
+  if (CTL_WAVE()) { int l = CTL_LANE(); if (l < d.cfg.P) storeKey(d, l, n); }   // one level per lane
+#else
   if (CTL_WAVE()) { int l = CTL_LANE(); if (l < d.cfg.P) KEY(d, l, n) = packKey(d, l, n); }   // one level per lane
+#endif
   else updateKeys(d, n);
   fastTouch(d, n);
   ftTouch(d, n);
@@ -334,7 +380,7 @@ DEV void vadd(Dev& d, int64_t* a, const int64_t* b, int sign) { for (int r = 0; 
 
 // qctx.addJobSchedulingContext + sctx.AddJobSchedulingContext (context/queue.go:231-265, scheduling.go:410-434)
 // The market-driven round exists in the auxiliary kernel and the CPU build only (round_mkt.h): the round kernel's own translation unit compiles none of it.
-#if (defined(ASCHED_AUX_TU) || defined(ASCHED_HOSTSIM)) && !defined(ASCHED_MARKET_ROUND)
+#if (defined(ASCHED_AUX_TU) || defined(ASCHED_WK_TU) || defined(ASCHED_HOSTSIM)) && !defined(ASCHED_MARKET_ROUND)
 #define ASCHED_MARKET_ROUND 1
 #endif
 #include "round_mkt.h"
@@ -512,13 +558,72 @@ DEV uint64_t litBound(const DevCfg& c, const int64_t* b) {
   }
   return acc << c.idxBits;
 }
+#ifdef ASCHED_TWO_WORD_KEYS
+// litBound for a two-word key (packKey2's layout: the fields from bit keyShift[K - 1] up, no guard bits)
+DEV Key2 litBound2(const DevCfg& c, const int64_t* b) {
+  Key2 acc = 0; int bits = 0; bool stop = false;
+  for (int i = 0; i < c.K; i++) {
+    int w = c.keyWidth[i];
+    if (stop) { acc <<= w; bits += w; continue; }
+    int64_t res = c.indexedRes[i];
+    bool aligned = b[i] % res == 0;
+    int64_t f = (aligned ? b[i] / res : litCeilDiv(b[i], res)) - c.keyLo[i];
+    if (f < 0) { f = 0; stop = true; }
+    else if (w < 63 && f >= ((int64_t)1 << w)) {
+      if (bits == 0) return KEY2_NONE;
+      acc += 1;
+      if (acc >= ((Key2)1 << bits)) return KEY2_NONE;
+      f = 0; stop = true;
+    } else if (!aligned) stop = true;
+    acc = (acc << w) | (Key2)(uint64_t)f; bits += w;
+  }
+  return acc << c.keyShift[c.K - 1];
+}
+DEV void litSetBound(const DevCfg& c, LitIt& it) {
+  if (WIDE_KEYS(c)) { Key2 b = litBound2(c, it.lb); it.bound = (uint64_t)(b >> 64); it.boundLo = (uint64_t)b; }
+  else it.bound = litBound(c, it.lb);
+}
+#define LIT_SET_BOUND(c, it) litSetBound(c, it)
+#else
+#define LIT_SET_BOUND(c, it) ((it).bound = litBound(c, (it).lb))
+#endif
 DEV bool litLbLess(const DevCfg& c, const int64_t* a, const int64_t* b) {  // bytes.Compare(it.key, it.newKey) == -1 (:364)
   for (int i = 0; i < c.K; i++) { if (a[i] < b[i]) return true; if (a[i] > b[i]) return false; }
   return false;
 }
 // NodeTypeIterator.NextNode (:318-382)
+#ifdef ASCHED_TWO_WORD_KEYS
+DEV void litAdvance2(Dev& d, int level, LitIt& it, const int64_t* ireq) {   // litAdvance below, on a two-word key
+  const DevCfg& c = d.cfg;
+  for (;;) {
+    if (it.bound == ~0ull && it.boundLo == ~0ull) { it.head = -1; return; }
+    ScanArgs a;
+    for (int r = 0; r < MAXR; r++) a.req[r] = 0;
+    a.maskA = d.typeMask + (size_t)it.type * c.W; a.maskB = nullptr; a.level = level; a.noFit = 1; a.lowBound = it.bound; a.lowBoundLo = it.boundLo; a.levelHi = 0; a.pad = 0;
+    int n = wgFirstFit(d, a);
+    if (n < 0) { it.head = -1; return; }
+    Key2 key = key2Of(KEY(d, level, n), KEYLO(d, level, n));
+    int64_t nlb[MAXK];
+    bool yielded = false, sought = false;
+    for (int i = 0; i < c.K; i++) {
+      int64_t nodeQ = AL(d, level, c.indexedCol[i], n);
+      nlb[i] = (nodeQ / c.indexedRes[i]) * c.indexedRes[i];
+      if (nodeQ < ireq[i]) {
+        for (int j = i; j < c.K; j++) nlb[j] = ireq[j];
+        if (litLbLess(c, it.lb, nlb)) { for (int j = 0; j < c.K; j++) it.lb[j] = nlb[j]; litSetBound(c, it); sought = true; }
+        break;
+      } else if (i == c.K - 1) yielded = true;
+    }
+    if (!sought) { Key2 nx = key == KEY2_NONE ? KEY2_NONE : key + 1; it.bound = (uint64_t)(nx >> 64); it.boundLo = (uint64_t)nx; }
+    if (yielded) { it.head = n; return; }
+  }
+}
+#endif
 DEV void litAdvance(Dev& d, int level, LitIt& it, const int64_t* ireq) {
   const DevCfg& c = d.cfg;
+#ifdef ASCHED_TWO_WORD_KEYS
+  if (WIDE_KEYS(c)) { litAdvance2(d, level, it, ireq); return; }
+#endif
   for (;;) {
     if (it.bound == ~0ull) { it.head = -1; return; }
     ScanArgs a;
@@ -562,7 +667,7 @@ DEV_COLD int selectAtLevelLiteral(Dev& d, int job, int32_t prio, int level, int 
     LitIt& it = d.lit[k];
     it.type = d.rowTypes[t0 + k];
     for (int i = 0; i < MAXK; i++) it.lb[i] = i < c.K ? ireq[i] : 0;
-    it.bound = litBound(c, it.lb);
+    LIT_SET_BOUND(c, it);
     litAdvance(d, level, it, ireq);
   }
   const uint64_t* mA = shapeMaskOf(d, job);
@@ -594,7 +699,7 @@ DEV int selectAtLevel(Dev& d, int job, int32_t prio) {
   for (int r = 0; r < MAXR; r++) a.req[r] = r < d.cfg.R ? req[r] : 0;
   a.maskA = shapeMaskOf(d, job);
   a.maskB = uniMask(d, job);
-  a.level = level; a.noFit = 0; a.lowBound = 0; a.levelHi = 0; a.pad = 0;
+  a.level = level; a.noFit = 0; a.lowBound = 0; a.levelHi = 0; a.pad = 0; SCAN_NO_LOW_WORD(a);
   long long t0 = CLK();
   if (d.progress) { d.progress[2] = 1; d.progress[3]++; }
   int n = wgFirstFit(d, a);
@@ -726,7 +831,7 @@ DEV_COLD int selectAtPriority(Dev& d, Ctl& c, int job) {
     const int64_t* req = JREQ(d, job);
     for (int r = 0; r < MAXR; r++) a.req[r] = r < d.cfg.R ? req[r] : 0;
     a.maskA = shapeMaskOf(d, job); a.maskB = uniMask(d, job);
-    a.level = 1; a.levelHi = lp; a.noFit = 0; a.lowBound = 0; a.pad = 0;
+    a.level = 1; a.levelHi = lp; a.noFit = 0; a.lowBound = 0; a.pad = 0; SCAN_NO_LOW_WORD(a);
     if (lp == 1) { a.level = 1; a.levelHi = 0; }   // one level: the plain pass
     if (d.cfg.disableUrgency) { a.level = lp; a.levelHi = 0; }   // no sweep to fuse with: the gate alone, at the job's level — its node is what a failed attempt's record needs (exclRecordWide)
     long long t0 = CLK();

@@ -1225,7 +1225,7 @@ DEV void runAuxCommand(Dev& d, Ctl& c, int cmd) {
         LitIt& it = d.lit[k];
         it.type = ARG(4 + 2 * MAXK + k);
         for (int i = 0; i < MAXK; i++) it.lb[i] = ireq[i];
-        it.bound = litBound(cf, it.lb);
+        LIT_SET_BOUND(cf, it);
         litAdvance(d, level, it, ireq);
       }
       int n = 0;

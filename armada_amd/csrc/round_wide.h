@@ -79,7 +79,7 @@ DEV void exclBulk(Dev& d, int n) {
   const int64_t* req = JREQ(d, r.job);
   bool fit = n < c.N;
   if (fit) for (int k = 0; k < c.K; k++) fit = fit && AL(d, r.level, c.indexedCol[k], n) >= req[c.indexedCol[k]];
-  if (fit && r.gate > 0) fit = d.keys[(size_t)r.level * c.Npad + n] < d.keys[(size_t)r.level * c.Npad + (r.gate - 1)];   // the gate's walk stopped at its node: what orders before it was yielded
+  if (fit && r.gate > 0) fit = WIDE_KEYS(c) ? keyBefore(d, r.level, n, r.gate - 1) : d.keys[(size_t)r.level * c.Npad + n] < d.keys[(size_t)r.level * c.Npad + (r.gate - 1)];   // the gate's walk stopped at its node: what orders before it was yielded
   exclPutBits(x.bits + (size_t)slot * x.W, n, fit);
   if (!fit) return;
   bool st = (d.shapeMask[(size_t)r.row * c.W + (n >> 6)] >> (n & 63)) & 1;
@@ -493,7 +493,7 @@ DEV_COLD void exclLiteral(Dev& d, ExclDev& x, int slot) {
     LitIt& it = d.lit[k];
     it.type = d.rowTypes[t0 + k];
     for (int i = 0; i < MAXK; i++) it.lb[i] = i < c.K ? ireq[i] : 0;
-    it.bound = litBound(c, it.lb);
+    LIT_SET_BOUND(c, it);
     litAdvance(d, r.level, it, ireq);
   }
   for (;;) {

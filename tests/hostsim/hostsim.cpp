@@ -52,8 +52,9 @@ DEV uint64_t wgFirstFitKey(Dev& d, const ScanArgs& a) {
   hsEngineMustBeStopped("wgFirstFitKey");
   HsScope prof(38);
   const DevCfg& c = d.cfg;
-  uint64_t best = ~0ull;
+  uint64_t best = ~0ull, bestHi = ~0ull;
   d.rs->numScans++;
+  if (WIDE_KEYS(c) && a.levelHi > a.level) { fprintf(stderr, "hostsim: the fused multi-level pass on a two-word key\n"); abort(); }
   for (int n = 0; n < c.N; n++) {
     if (!((a.maskA[n >> 6] >> (n & 63)) & 1)) continue;
     if (a.maskB && !((a.maskB[n >> 6] >> (n & 63)) & 1)) continue;
@@ -66,6 +67,15 @@ DEV uint64_t wgFirstFitKey(Dev& d, const ScanArgs& a) {
       continue;
     }
     uint64_t k = KEY(d, a.level, n);
+    if (WIDE_KEYS(c)) {   // two-word keys: (high word, low word); the LOW word of the minimum is returned (armada_sched.hip wgFirstFitKey does it in two passes)
+      uint64_t lo = KEYLO(d, a.level, n);
+      if (k < a.lowBound || (k == a.lowBound && lo < a.lowBoundLo)) continue;
+      if (getenv("HOSTSIM_IGNORE_HIGH_WORD")) k = 0;   // negative control for the tests: a selection that compares low words only
+      if (k > bestHi || (k == bestHi && lo >= best)) continue;
+      if (!a.noFit && !fitsAlloc(d, a.req, a.level, n)) continue;
+      bestHi = k; best = lo;
+      continue;
+    }
     if (k >= best || k < a.lowBound) continue;
     if (!a.noFit && !fitsAlloc(d, a.req, a.level, n)) continue;
     best = k;

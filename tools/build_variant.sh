@@ -9,6 +9,7 @@ hipcc $F -c armada_sched.hip -o /tmp/armada_sched_$NAME.o &
 hipcc $F -c armada_sched_aux.hip -o /tmp/armada_sched_aux_$NAME.o &
 hipcc $F -c armada_sched_mgpu.hip -o /tmp/armada_sched_mgpu_$NAME.o &
 hipcc $F -c armada_sched_ft.hip -o /tmp/armada_sched_ft_$NAME.o &
+hipcc $F -c armada_sched_wk.hip -o /tmp/armada_sched_wk_$NAME.o &
 wait
-hipcc --offload-arch=gfx950 -fPIC -shared -pthread -o libarmada_sched_$NAME.so /tmp/armada_sched_$NAME.o /tmp/armada_sched_aux_$NAME.o /tmp/armada_sched_mgpu_$NAME.o /tmp/armada_sched_ft_$NAME.o
+hipcc --offload-arch=gfx950 -fPIC -shared -pthread -o libarmada_sched_$NAME.so /tmp/armada_sched_$NAME.o /tmp/armada_sched_aux_$NAME.o /tmp/armada_sched_mgpu_$NAME.o /tmp/armada_sched_ft_$NAME.o /tmp/armada_sched_wk_$NAME.o
 ls -la libarmada_sched_$NAME.so
