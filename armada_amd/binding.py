@@ -228,10 +228,11 @@ ALL_SYMBOLS = [
     "fit_select_batch_global", "round_delta_words", "round_delta", "round_delta_resolve",
     "set_market", "market_result", "price_gang", "price_job_on_nodes",
     "comm_unique_id", "comm_init", "comm_init_external", "comm_destroy", "comm_rank", "fit_select_batch_sharded", "round_exchange",
+    "shard_round", "shard_exchanges",
     "excluded_nodes", "set_excluded_nodes",
 ]
 # entry points the CPU oracle does not implement (it is the single-process checker): the communicator and the collectives that run on it
-OPTIONAL_SYMBOLS = {"comm_unique_id", "comm_init", "comm_init_external", "comm_destroy", "comm_rank", "fit_select_batch_sharded", "round_exchange"}
+OPTIONAL_SYMBOLS = {"comm_unique_id", "comm_init", "comm_init_external", "comm_destroy", "comm_rank", "fit_select_batch_sharded", "round_exchange", "shard_round", "shard_exchanges"}
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
 
 
@@ -393,6 +394,8 @@ class Library:
         f("comm_init_external", C.c_int32, [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int32, C.c_int32])
         f("comm_destroy", C.c_int32, [C.c_void_p])
         f("comm_rank", C.c_int32, [C.c_void_p, _i32p, _i32p])
+        f("shard_round", C.c_int32, [C.c_void_p, C.c_int32])
+        f("shard_exchanges", C.c_int64, [C.c_void_p])
         f("fit_select_batch_sharded", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int32, C.POINTER(CGlobalKeyLayout), _i32p])
         f("round_exchange", C.c_int32, [C.c_void_p, C.POINTER(CDeltaSummary), _i32p, _i32p, _u8p])
         f("drf_cost", C.c_double, [C.c_void_p, _i64p, _i64p])
@@ -1008,6 +1011,13 @@ class Scheduler:
         r, w = C.c_int32(0), C.c_int32(1)
         self._check(self.lib.comm_rank(self.h, C.byref(r), C.byref(w)))
         return int(r.value), int(w.value)
+
+    def shard_round(self, on: bool = True):
+        """ONE pool's round on the communicator's ranks, exact: every rank holds the whole pool, the wide passes over the nodes are split and all-reduced (include/armada_sched.h)"""
+        self._check(self.lib.shard_round(self.h, 1 if on else 0))
+
+    def shard_exchanges(self) -> int:
+        return int(self.lib.shard_exchanges(self.h))
 
     def fit_select_batch_sharded(self, jobs: Sequence[int], priority: int, field_bits: Sequence[int], rank_bits: int, *, rank_offset: int = 0, global_rank=None) -> np.ndarray:
         """exact node-partitioned first fit over the communicator's ranks: global rank of the chosen node per job, -1 none (collective: every rank calls it)"""

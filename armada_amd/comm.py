@@ -52,7 +52,9 @@ def init_external(s, dist, device_memory: bool = False):
     def allreduce(ptr: int, count: int, op: int) -> int:
         if count <= 0:
             return 0
-        if not device_memory:
+        host_words = bool(op & 16)   # ASCHED_ALLREDUCE_HOST_WORDS: the exchange words of a sharded round's wide pass — host memory, and the round kernel is RUNNING (no device sync)
+        op &= 15
+        if not device_memory or host_words:
             arr = np.ctypeslib.as_array((ctypes.c_int64 * count).from_address(ptr))
             t = torch.from_numpy(arr)            # shares the library's words: reduced in place
             dist.all_reduce(t, op=_ops(dist)[op])

@@ -185,7 +185,7 @@ __device__ static unsigned long long scanPart(const Dev& d, const ScanArgs& a, i
   const DevCfg& c = d.cfg;
   unsigned long long best = ~0ull;
   if (a.levelHi > a.level) {  // multi-level mode: per node the lowest level in [level, levelHi] it fits at, tagged key
-    for (int n = tid; n < c.N; n += nthreads) {
+    for (int n = SHARD_LO(c) + tid; n < SHARD_HI(c); n += nthreads) {
       uint64_t w = a.maskA[n >> 6];
       if (a.maskB) w &= a.maskB[n >> 6];
       if (!((w >> (n & 63)) & 1)) continue;
@@ -205,7 +205,7 @@ __device__ static unsigned long long scanPart(const Dev& d, const ScanArgs& a, i
 #ifdef ASCHED_TWO_WORD_KEYS
   if (WIDE_KEYS(c)) {   // two-word keys (dev.h keyWords): pass 1 (a.pad == 0) the minimum HIGH word among the fitting nodes, pass 2 (a.pad == 1, a.lowBound = that word) the minimum LOW word among those that carry it
     const uint64_t* lows = d.keys + ((size_t)c.P + a.level) * c.Npad;
-    for (int n = tid; n < c.N; n += nthreads) {
+    for (int n = SHARD_LO(c) + tid; n < SHARD_HI(c); n += nthreads) {
       uint64_t w = a.maskA[n >> 6];
       if (a.maskB) w &= a.maskB[n >> 6];
       if (!((w >> (n & 63)) & 1)) continue;
@@ -220,7 +220,7 @@ __device__ static unsigned long long scanPart(const Dev& d, const ScanArgs& a, i
     return waveMin64(best);
   }
 #endif
-  for (int n = tid; n < c.N; n += nthreads) {
+  for (int n = SHARD_LO(c) + tid; n < SHARD_HI(c); n += nthreads) {
     uint64_t w = a.maskA[n >> 6];
     if (a.maskB) w &= a.maskB[n >> 6];
     if (!((w >> (n & 63)) & 1)) continue;
@@ -233,6 +233,43 @@ __device__ static unsigned long long scanPart(const Dev& d, const ScanArgs& a, i
   return waveMin64(best);
 }
 
+#ifdef ASCHED_SHARDED_PASSES
+// A sharded wide pass (dev.h shardWorld): the minimum of the word and the maximum of the index over the replicas' shares.  The control wave posts its two words (the
+// index as its complement: one MIN all-reduce serves both) in the handle's host-mapped block and waits for the answer of the host thread that drives the launch
+// (plat_run_control: the all-reduce runs on the handle's communicator).  A PCIe round trip + the collective per pass: worth it where a pass is long (100 000 nodes and
+// up) — measured numbers for one GPU only.  Bounded like every wait of this kernel: the caller's cancel word ends it.
+__shared__ unsigned int g_xgen;
+__device__ static inline void shardReduce(Dev& d, unsigned long long* mn, int* mxIdx) {
+  unsigned long long* X = (unsigned long long*)d.cancel;
+  if (!X) { raise(d, ASCHED_ERR_INTERNAL, 530); return; }
+  int lane = threadIdx.x & 63;
+  unsigned int gen = (unsigned int)__builtin_amdgcn_readfirstlane((int)g_xgen) + 1;
+  unsigned long long w0 = *mn, w1 = ~(unsigned long long)(unsigned int)(*mxIdx + 1);
+  if (lane == 0) {
+    g_xgen = gen;
+    __hip_atomic_store(&X[XCHG_WORD0 + 1], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&X[XCHG_WORD0 + 2], w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&X[XCHG_WORD0], (unsigned long long)gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  unsigned int spins = 0;
+  for (;;) {
+    unsigned long long g = __hip_atomic_load(&X[XCHG_WORD0 + 3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (g == gen) break;
+    __builtin_amdgcn_s_sleep(4);
+    if ((++spins & 0x3ff) == 0 && cancelRequested(d)) { raise(d, ASCHED_ERR_TIMEOUT, 903); return; }
+  }
+  w0 = __hip_atomic_load(&X[XCHG_WORD0 + 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  w1 = __hip_atomic_load(&X[XCHG_WORD0 + 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  *mn = w0; *mxIdx = (int)(unsigned int)~w1 - 1;
+}
+#define SHARD_REDUCE(d, mn, idx) do { if (SHARD_ON((d).cfg)) shardReduce(d, &(mn), &(idx)); } while (0)
+#define SHARD_REDUCE_MIN(d, mn) do { if (SHARD_ON((d).cfg)) { int none_ = -1; shardReduce(d, &(mn), &none_); } } while (0)
+#define SHARD_REDUCE_MAX(d, idx) do { if (SHARD_ON((d).cfg)) { unsigned long long none_ = ~0ull; shardReduce(d, &none_, &(idx)); } } while (0)
+#else
+#define SHARD_REDUCE(d, mn, idx) do {} while (0)
+#define SHARD_REDUCE_MIN(d, mn) do {} while (0)
+#define SHARD_REDUCE_MAX(d, idx) do {} while (0)
+#endif
 #ifdef ASCHED_TWO_WORD_KEYS
 __device__ static inline uint64_t wgFirstFitKeyPass(Dev& d, const ScanArgs& a) {
 #else
@@ -251,6 +288,7 @@ __device__ static inline uint64_t wgFirstFitKey(Dev& d, const ScanArgs& a) {
     unsigned long long hb = helpWait();
     best = hb < best ? hb : best;
   }
+  SHARD_REDUCE_MIN(d, best);
   d.rs->numScans++;
   return best;
 }
@@ -277,7 +315,7 @@ __device__ static inline int wgFirstFit(Dev& d, const ScanArgs& a) {
 // one thread per node (grid-stride over the participating workgroups): highest evicted-table Index at which a node covers the request
 __device__ static int fairPart(const Dev& d, const FairArgs& a, int tid, int nthreads) {
   int best = -1;
-  for (int n = tid; n < d.cfg.N; n += nthreads) { int v = fairNodeBest(d, a, n, best); best = v > best ? v : best; }
+  for (int n = SHARD_LO(d.cfg) + tid; n < SHARD_HI(d.cfg); n += nthreads) { int v = fairNodeBest(d, a, n, best); best = v > best ? v : best; }
   return waveMax32(best);
 }
 __device__ static inline int wgFairSelect(Dev& d, const FairArgs& a) {
@@ -296,6 +334,7 @@ __device__ static inline int wgFairSelect(Dev& d, const FairArgs& a) {
     int h = (int)(unsigned int)hmx - 1;
     best = h > best ? h : best;
   }
+  SHARD_REDUCE_MAX(d, best);
   return best;
 }
 
@@ -328,6 +367,7 @@ __device__ static inline int wgScanFair(Dev& d, const ScanArgs& a, const FairArg
     int h = (int)(unsigned int)hmx - 1;
     idx = h > idx ? h : idx;
   }
+  SHARD_REDUCE(d, best, idx);
   d.rs->numScans++;
   *bestKey = best;
   return idx;
@@ -1593,7 +1633,7 @@ __device__ static void helperMain(const Dev& d, HelpBox* b, int H) {
 #endif
 #ifdef ASCHED_WK_TU
 __global__ __launch_bounds__(CTL_THREADS) void K_CONTROL_NAME(Dev dev, int cmd, HelpBox* box, int H, MktDev mk) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) g_mk = mk;   // (market-driven rounds of such a handle run here too: round_mkt.h)
+  if (threadIdx.x == 0 && blockIdx.x == 0) { g_mk = mk; g_xgen = 0; }   // (market-driven rounds of such a handle run here too: round_mkt.h; the exchange generation of sharded passes restarts with every launch)
 #else
 __global__ __launch_bounds__(CTL_THREADS) void K_CONTROL_NAME(Dev dev, int cmd, HelpBox* box, int H) {
 #endif
@@ -2300,6 +2340,8 @@ struct PlatCtx {
   bool failed = false;              // sticky: an allocation / copy / memset failed since the last plat_take_failure()
   // the handle's communicator (asched_comm_init: RCCL over xGMI; asched_comm_init_external: the caller's transport)
   ncclComm_t comm = nullptr; int commRank = 0, commWorld = 1;
+  hipStream_t xStream = nullptr; long long* xBuf = nullptr;   // sharded wide passes (dev.h shardWorld) over RCCL: the exchanged words' all-reduce runs here, beside the persistent kernel
+  long lastShardExchanges = 0;
   asched_allreduce_fn extFn = nullptr; void* extCtx = nullptr;
 };
 static thread_local PlatCtx* t_ctx = nullptr;
@@ -2333,8 +2375,8 @@ static PlatCtx* plat_open(std::string& err, int device) {
             hipEventCreate(&c->fitEv0) == hipSuccess && hipEventCreate(&c->fitEv1) == hipSuccess && hipEventCreate(&c->rEv0) == hipSuccess && hipEventCreate(&c->rEv1) == hipSuccess;
   // the mailbox is written from both sides across XCDs: it must not live in an XCD-private L2 -> fine-grained (uncached, device-coherent) memory
   ok = ok && hipExtMallocWithFlags((void**)&c->helpBox, sizeof(HelpBox), hipDeviceMallocFinegrained) == hipSuccess;
-  ok = ok && hipHostMalloc((void**)&c->cancelHost, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
-  if (ok) { *c->cancelHost = 0; ok = hipHostGetDevicePointer((void**)&c->cancelDev, c->cancelHost, 0) == hipSuccess; }
+  ok = ok && hipHostMalloc((void**)&c->cancelHost, 256, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;   // [0] the cancel word; from byte 64: the exchange words of sharded passes (dev.h XCHG_WORD0)
+  if (ok) { memset(c->cancelHost, 0, 256); ok = hipHostGetDevicePointer((void**)&c->cancelDev, c->cancelHost, 0) == hipSuccess; }
   if (!ok) { err = "HIP resource creation failed (stream / events / mailbox / cancel word)"; delete c; return nullptr; }
   // helper workgroups of a round launch: one per CU, an eighth of the device by default — measured flat between 15 and 63 (ASCHED_HELPERS overrides; 0 = none)
   c->helpers = c->cus >= 16 ? c->cus / 8 - 1 : 0;
@@ -2430,10 +2472,35 @@ static int plat_allreduce(long long* dbuf, size_t count, int op) {
   if (c->extFn(c->extCtx, dbuf, (int64_t)count, op) != 0) { c->err = "the external all-reduce transport failed"; return -1; }
   return 0;
 }
+// all-reduce MIN of a few UNSIGNED 64-bit words that live in HOST memory, while the handle's stream is busy with the persistent kernel that waits for the answer
+// (shardReduce): RCCL on a side stream through a device staging buffer, or the caller's transport with ASCHED_ALLREDUCE_HOST_WORDS in `op` (the words are host memory: reduce
+// them where they are, do not synchronise the device).  The collectives compare int64: the sign bit is flipped around them.
+static int plat_allreduce_host_min(unsigned long long* w, int count) {
+  PlatCtx* c = t_ctx;
+  long long v[8];
+  if (count > 8) return -1;
+  for (int i = 0; i < count; i++) v[i] = (long long)(w[i] ^ 0x8000000000000000ull);
+  if (c->comm) {
+    std::string err; RcclApi* a = rcclApi(err);
+    if (!a) { c->err = err; return -1; }
+    if (!c->xStream && !hipOk(hipStreamCreateWithFlags(&c->xStream, hipStreamNonBlocking), "hipStreamCreate (exchange)")) return -1;
+    if (!c->xBuf && !hipOk(hipMalloc((void**)&c->xBuf, 8 * sizeof(long long)), "hipMalloc (exchange)")) return -1;
+    if (!hipOk(hipMemcpyAsync(c->xBuf, v, count * sizeof(long long), hipMemcpyHostToDevice, c->xStream), "exchange h2d")) return -1;
+    if (!rcclOk(a, a->allReduce(c->xBuf, c->xBuf, count, ncclInt64, ncclMin, c->comm, c->xStream), "ncclAllReduce (exchange)")) return -1;
+    if (!hipOk(hipMemcpyAsync(v, c->xBuf, count * sizeof(long long), hipMemcpyDeviceToHost, c->xStream), "exchange d2h") || !hipOk(hipStreamSynchronize(c->xStream), "exchange sync")) return -1;
+  } else if (c->extFn) {
+    if (c->extFn(c->extCtx, v, (int64_t)count, 1 | ASCHED_ALLREDUCE_HOST_WORDS) != 0) { c->err = "the external all-reduce transport failed"; return -1; }
+  }
+  for (int i = 0; i < count; i++) w[i] = (unsigned long long)v[i] ^ 0x8000000000000000ull;
+  return 0;
+}
+static long plat_last_shard_exchanges() { return t_ctx ? t_ctx->lastShardExchanges : 0; }
 static void plat_close(PlatCtx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->xStream) (void)hipStreamDestroy(c->xStream);
+  if (c->xBuf) (void)hipFree(c->xBuf);
   plat_comm_destroy_ctx(c);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   for (hipEvent_t e : {c->ev0, c->ev1, c->fitEv0, c->fitEv1, c->rEv0, c->rEv1}) if (e) (void)hipEventDestroy(e);
@@ -2498,7 +2565,10 @@ static int plat_run_control(Dev& dev, int cmd) {
   dev.cancel = c->cancelDev;
   if (!hipOk(hipMemsetAsync(c->helpBox, 0, sizeof(HelpBox), c->stream), "help box reset")) return -1;
   (void)hipEventRecord(c->ev0, c->stream);
-  if (dev.cfg.keyWords == 2) {   // a two-word order key: every control command on the kernel built for it (armada_sched_wk.hip)
+  const bool shard = dev.cfg.shardWorld > 1;
+  volatile unsigned long long* X = (volatile unsigned long long*)c->cancelHost;
+  if (shard) { for (int i = 0; i < 6; i++) X[XCHG_WORD0 + i] = 0; __atomic_thread_fence(__ATOMIC_SEQ_CST); c->lastShardExchanges = 0; }
+  if (dev.cfg.keyWords == 2 || shard) {   // a two-word order key, or wide passes sharded across GPUs: every control command on the kernel built for them (armada_sched_wk.hip)
     if (asched_internal_wk_launch(&dev, cmd, c->stream, c->helpBox, H, t_mkt)) { c->err = "k_control_wk launch failed"; return -1; }
   } else if (cmd >= CMD_AUX_FIRST) {  // submit-check commands: their kernel lives in its own code object (armada_sched_aux.hip)
     if (asched_internal_aux_launch(&dev, cmd, c->stream, c->helpBox, t_mkt)) { c->err = "k_control_aux launch failed"; return -1; }
@@ -2510,6 +2580,24 @@ static int plat_run_control(Dev& dev, int cmd) {
   if (!hipOk(hipGetLastError(), "k_control launch")) return -1;
   static const double safetyS = [] { const char* e = getenv("ASCHED_SAFETY_DEADLINE_S"); return e ? atof(e) : 0.0; }();   // test / measurement runs of new builds: no launch outlives this
   double deadlineS = c->deadlineS > 0 ? c->deadlineS : safetyS;
+  if (shard) {
+    // the exchange proxy of sharded passes: the kernel posts (generation, two words), this thread runs the all-reduce on the handle's communicator and answers (dev.h XCHG_WORD0)
+    auto t0 = c->inRound ? c->roundT0 : std::chrono::steady_clock::now();
+    unsigned long long served = 0; unsigned int idle = 0; bool failed = false;
+    while (hipStreamQuery(c->stream) == hipErrorNotReady) {
+      unsigned long long g = __atomic_load_n(&X[XCHG_WORD0], __ATOMIC_ACQUIRE);
+      if (g != served && !failed) {
+        unsigned long long w[2] = {X[XCHG_WORD0 + 1], X[XCHG_WORD0 + 2]};
+        if (plat_allreduce_host_min(w, 2)) { failed = true; plat_cancel(c); continue; }   // (the kernel's wait ends on the cancel word: ASCHED_ERR_TIMEOUT 903, reported as a device error below)
+        X[XCHG_WORD0 + 4] = w[0]; X[XCHG_WORD0 + 5] = w[1];
+        __atomic_store_n(&X[XCHG_WORD0 + 3], g, __ATOMIC_RELEASE);
+        served = g; c->lastShardExchanges++; idle = 0;
+        continue;
+      }
+      if ((++idle & 0xfff) == 0 && isRound && deadlineS > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > deadlineS) plat_cancel(c);
+    }
+    if (failed) { (void)hipStreamSynchronize(c->stream); return -1; }
+  } else
   if (dev.progress || (isRound && deadlineS > 0)) {
     // hard timeout (scheduling_algo.go:130-134): the kernel polls the cancel word; the host sets it when the deadline passes
     auto t0 = c->inRound ? c->roundT0 : std::chrono::steady_clock::now();

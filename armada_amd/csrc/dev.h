@@ -44,7 +44,11 @@ struct DevCfg {
   uint8_t pcPreemptible[MAXPC];
   double drfMult[MAXR];
   uint8_t preferLarge, protectUncapped, disableHome, disableAway, disableGangAway, disableFair, disableUrgency, hasAway;
-  uint8_t preferHome; uint8_t padHome_[7];   // preemptCrossPoolJobsFirst (queue_scheduler.go:744-746)
+  uint8_t preferHome;    // preemptCrossPoolJobsFirst (queue_scheduler.go:744-746)
+  uint8_t shardRank, shardWorld;   // shardWorld > 1 (asched_shard_round): this handle is one of shardWorld replicas of ONE pool on as many GPUs — every replica holds the whole state
+                                   // and runs the whole round, but the round's wide passes over the nodes (plane scan, fair-share evaluation) look at this rank's share of the node
+                                   // words only and their results are all-reduced (MIN / MAX) across the replicas.  (In pad bytes; served by armada_sched_wk.hip.)
+  uint8_t padHome_[5];
   double protectedFraction;
   uint32_t maxLookback;
   uint8_t disallowed[MAXR];
@@ -66,13 +70,28 @@ struct DevCfg {
   int32_t keyWords;      // 2: the order key is TWO words (asched_host.inc layoutKeys: more than 64 bits of fields).  `keys` then holds [2][P][Npad]: the high words of every level,
                          // then the low words (node-index rank in the low idxBits of the LOW word); keyShift[c] >= 64 names a field of the high word.  (In the slot of a pad word.)
 };
+// Node-sharded wide passes (shardWorld above): compiled into the CPU build and k_control_wk only.
+#if defined(ASCHED_HOSTSIM) || defined(ASCHED_WK_TU)
+#define ASCHED_SHARDED_PASSES 1
+#define SHARD_ON(cfg) ((cfg).shardWorld > 1)
+#define SHARD_LO(cfg) (SHARD_ON(cfg) ? (int)((long long)(((cfg).N + 63) >> 6) * (cfg).shardRank / (cfg).shardWorld) * 64 : 0)
+#define SHARD_HI(cfg) (SHARD_ON(cfg) ? ((cfg).shardRank + 1 == (cfg).shardWorld ? (cfg).N : (int)((long long)(((cfg).N + 63) >> 6) * ((cfg).shardRank + 1) / (cfg).shardWorld) * 64) : (cfg).N)
+#else
+#define SHARD_ON(cfg) false
+#define SHARD_LO(cfg) 0
+#define SHARD_HI(cfg) ((cfg).N)
+#endif
+// the exchange words of a sharded pass live behind the cancel word in the handle's host-mapped block (armada_sched.hip PlatCtx.cancelHost, 256 bytes): 64-bit words
+// [8] request generation, [9..10] this rank's two words, [11] answer generation, [12..13] the reduced words.  The kernel posts, the host thread that waits for the launch
+// runs the all-reduce on the handle's communicator (RCCL over xGMI on a side stream, or the caller's transport) and answers.
+#define XCHG_WORD0 8
 // Two-word order keys are served by the generic path of a round kernel of their own (armada_sched_wk.hip: k_control_wk, k_bulk_wk): in every other device code object the
 // test below is a compile-time `false`, so the one-word kernels carry none of it (their ISA is what it was); the CPU build of the tests decides per handle.
 #if defined(ASCHED_HOSTSIM)
 #define WIDE_KEYS(cfg) ((cfg).keyWords == 2)
 #define ASCHED_TWO_WORD_KEYS 1
 #elif defined(ASCHED_WK_TU)
-#define WIDE_KEYS(cfg) true
+#define WIDE_KEYS(cfg) ((cfg).keyWords == 2)   // (k_control_wk also serves one-word handles whose wide passes are sharded across GPUs: SHARD_ON)
 #define ASCHED_TWO_WORD_KEYS 1
 #else
 #define WIDE_KEYS(cfg) false

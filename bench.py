@@ -766,6 +766,43 @@ def single_pool_mode_record(hip, args, rank, local_rank, world, dist, torch):
                     value=len(jobs) * args.steps / dt, unit="queries/s", ms_per_step=dt / args.steps * 1e3, parity=parity,
                     config={"workload": f"BASELINE configs[1] shape: {wl.num_nodes} nodes x {len(jobs)} first-fit queries per step at priority {prio}", "nodes": wl.num_nodes,
                             "parallelism": f"nodes of one pool in {world} contiguous row shards", "exchange_bytes_per_step_per_rank": int(len(jobs)) * 8})
+    if args.mode == "node-sharded-round":
+        # ONE pool's round, exact, on N GPUs: every rank holds the pool and runs the round; the wide passes over the nodes are split N ways and end with one all-reduce MIN of
+        # two words over RCCL (asched_shard_round).  What it can buy is the wide passes' share of a round (crowded pools: --occupied 0.95); the headline round issues none.
+        from armada_amd import comm
+        wl = W.config3(n_nodes=args.nodes, n_jobs=args.jobs, n_queues=args.queues, seed=W.SEED, gangs=args.gangs, occupied=args.occupied)
+        scale = args.jobs / 1_000_000.0
+        if args.jobs != 1_000_000:
+            wl.global_burst, wl.queue_burst = max(1, int(200_000 * scale)), max(1, int(20_000 * scale))
+        wl.config.device = local_rank
+        s = W.load(hip, wl)
+        if world > 1:
+            comm.init_rccl(s, dist, device="cuda")
+            s.shard_round(True)
+        times, ex = [], 0
+        for i in range(args.warmup + args.steps):
+            W.prepare(s, wl)
+            barrier(); t0 = time.perf_counter()
+            r = s.schedule_round()
+            barrier(); dt = tmax(time.perf_counter() - t0)
+            if i >= args.warmup:
+                times.append(dt)
+            ex = s.shard_exchanges()
+        st = s.round_stats()
+        s.close()
+        parity = None
+        if rank == 0 and world > 1:   # the unsharded library on one GPU runs the same round
+            s1 = W.load(hip, wl); W.prepare(s1, wl); want = s1.schedule_round(); s1.close()
+            parity = {"checked": True, "identical": bool(np.array_equal(want.scheduled_job, r.scheduled_job) and np.array_equal(want.scheduled_node, r.scheduled_node) and
+                                                        np.array_equal(want.preempted_job, r.preempted_job)),
+                      "against": "the unsharded library on one GPU", "jobs": int(len(want.scheduled_job))}
+        return dict(base, metric="scheduling rounds/sec, ONE pool on N GPUs: whole state on every GPU, wide node passes split N ways + one all-reduce MIN each (exact)",
+                    value=len(times) / sum(times), unit="rounds/s", ms_per_step=sum(times) / len(times) * 1e3, parity=parity, exchanges_last_launch=int(ex),
+                    kclk_plane_scans=int(st.get("kclk_plane_scans", 0)), kclk_fair_selects=int(st.get("kclk_fair_selects", 0)),
+                    scaling_note="unmeasured on more than one GPU: this repository's GPU boxes have one; world 2 / 3 parity runs over gloo in tests/test_z_sharded_round.py",
+                    config={"workload": f"{wl.num_nodes} nodes x {wl.num_queues} queues x {args.jobs} queued jobs (+{wl.num_jobs - args.jobs} running), occupied {args.occupied}",
+                            "nodes": wl.num_nodes, "queued_jobs": args.jobs, "queues": wl.num_queues,
+                            "parallelism": f"replicated pool, node words split {world} ways for the plane scan and the fair-share evaluation; 16 bytes all-reduced per pass"})
     from armada_amd.queuehash import QueueHashRound
     wl = W.config3(n_nodes=args.nodes, n_jobs=args.jobs, n_queues=args.queues, seed=W.SEED, gangs=args.gangs, occupied=args.occupied)
     scale = args.jobs / 1_000_000.0
@@ -924,9 +961,10 @@ def main():
     ap.add_argument("--no-full-other", action="store_true", help="skip the full-size (100k x 1M) run of configs[4] (~40 s); the reduced size with its oracle leg still runs")
     ap.add_argument("--other-scale", type=float, default=1.0, help="scale the other_configs workloads (tests)")
     ap.add_argument("--full-other", action="store_true", help="(default now; kept for older command lines)")
-    ap.add_argument("--mode", choices=["pools", "node-sharded-fit", "queue-hash"], default="pools",
+    ap.add_argument("--mode", choices=["pools", "node-sharded-fit", "node-sharded-round", "queue-hash"], default="pools",
                     help="what --gpus N > 1 does (DESIGN.md 7): pools = one pool per GPU, exact, no data-path collective (the default and the line the driver records); "
                          "node-sharded-fit = ONE pool's nodes partitioned over the GPUs for the wide first-fit queries, one all-reduce MIN per batch, exact; "
+                         "node-sharded-round = ONE pool's whole round on every GPU with the wide node passes split N ways and all-reduced (asched_shard_round), exact; "
                          "queue-hash = the north_star's split of ONE pool's queues over the GPUs with one all-reduce SUM and an ordered replay, approximate: the line "
                          "reports the mismatch against the exact round")
     args = ap.parse_args()

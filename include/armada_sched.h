@@ -501,6 +501,17 @@ int32_t ASCHED_FN(comm_rank)(asched_t*, int32_t* rank, int32_t* world);   /* wor
    that fits (nodedb.go:840-879, nodeiteration.go:318-382). */
 int32_t ASCHED_FN(fit_select_batch_sharded)(asched_t*, int32_t n, const int32_t* jobs, int32_t priority, const asched_global_key_layout* layout,
                                             int32_t* out_rank /*[n]*/);
+/* EXACT, ONE pool's round on several GPUs (SURVEY 8e "Nodes (exact)"): every rank of the communicator holds the WHOLE pool (same nodes, jobs, queues: the state of a
+   round is tens of megabytes) and runs the whole round, but after shard_round(h, 1) the round's wide passes over the nodes — the first-fit plane scan and the per-node
+   evaluation of fair-share preemption (selectNodeForPodAtPriority nodedb.go:840-928, selectNodeForJobWithFairPreemption :935-1043) — look at this rank's 1/world of the
+   node words only, and every pass ends with ONE all-reduce MIN of two 64-bit words (the minimum order key; the complement of the maximum evicted-table index) on the
+   handle's communicator: RCCL on a side stream while the round kernel waits, or the external transport, which is then called with ASCHED_ALLREDUCE_HOST_WORDS or-ed into
+   `op` (buf is host memory: reduce it in place, do not synchronise the device — the round kernel is running).  The minimum over the shares IS the unsharded pass's answer,
+   so every rank computes the reference's round, bit for bit the same one.  Every rank must run the same calls on the same inputs.  shard_exchanges: all-reduces of the
+   handle's last control launch.  Not measured on more than one GPU. */
+#define ASCHED_ALLREDUCE_HOST_WORDS 16
+int32_t ASCHED_FN(shard_round)(asched_t*, int32_t on);
+int64_t ASCHED_FN(shard_exchanges)(asched_t*);
 /* APPROXIMATE (labelled so everywhere), queue-hash round: round_delta + ONE all-reduce SUM + round_delta_resolve as one stream-ordered sequence
    on the handle's stream; outputs as round_delta_resolve. */
 int32_t ASCHED_FN(round_exchange)(asched_t*, asched_delta_summary* summary, int32_t* job_node /*[M]*/, int32_t* job_priority /*[M]*/, uint8_t* job_replay /*[M]*/);

@@ -1097,6 +1097,17 @@ func (g *GpuRound) CommInit(id [128]byte, rank, world int) error {
 
 func (g *GpuRound) CommDestroy() error { return g.check(C.asched_comm_destroy(g.h)) }
 
+// ShardRound: this handle is one of the communicator's replicas of ONE pool (same nodes, jobs and queues on every replica).  From now on its rounds split their wide passes
+// over the nodes across the replicas and all-reduce each pass's two result words (asched_shard_round; INTEGRATION.md 3a): every replica's Schedule returns the same round,
+// the reference's.  Call after CommInit; ShardRound(false) goes back to whole passes.
+func (g *GpuRound) ShardRound(on bool) error {
+	v := C.int32_t(0)
+	if on {
+		v = 1
+	}
+	return g.check(C.asched_shard_round(g.h, v))
+}
+
 // ErrPeer: a collective entry point returned ASCHED_ERR_PEER — another rank of the communicator failed in front of the exchange (its own call returns the cause); nothing
 // was exchanged and the communicator stays usable.  (Every rank all-reduces one status word before the data: a rank-local failure can no longer leave the others in RCCL.)
 func (g *GpuRound) ErrPeer(err error) bool {

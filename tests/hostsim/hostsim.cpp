@@ -32,12 +32,26 @@ DEV void atomicOrI32(int32_t* p, int32_t v) { *p |= v; }
 DEV void atomicMinU32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
 DEV int atomicFetchAddI32(int32_t* p, int32_t v) { int o = *p; *p += v; return o; }
 void hsEngineMustBeStopped(const char* what);
+// sharded wide passes (dev.h shardWorld; asched_shard_round): this rank's share of the node words, then the all-reduce on the handle's communicator — here synchronously
+// through the caller's transport (the device posts the words to the host thread that drives the launch: armada_sched.hip shardReduce / plat_run_control)
+static int plat_allreduce(long long* buf, size_t count, int op);
+static long g_shardExchanges = 0;
+static uint64_t hsShardMin(uint64_t v) {
+  long long w = (long long)(v ^ 0x8000000000000000ull);
+  if (plat_allreduce(&w, 1, 1)) { fprintf(stderr, "hostsim: the all-reduce of a sharded pass failed\n"); abort(); }
+  g_shardExchanges++;
+  return (uint64_t)w ^ 0x8000000000000000ull;
+}
 DEV int wgFairSelect(Dev& d, const FairArgs& a) {
   hsEngineMustBeStopped("wgFairSelect");
   HsScope prof(39);
   int best = -1;
   static long calls = 0, maxSeg = 0, sumMax = 0;
   long callMax = 0;
+  if (SHARD_ON(d.cfg)) {
+    for (int n = SHARD_LO(d.cfg); n < SHARD_HI(d.cfg); n++) { int v = fairNodeBest(d, a, n, -1); if (v > best) best = v; }
+    return (int)(uint32_t)~hsShardMin(~(uint64_t)(uint32_t)(best + 1)) - 1;
+  }
   for (int n = 0; n < d.cfg.N; n++) { int v = fairNodeBest(d, a, n, -1); if (v > best) best = v; long L = d.fairOff[n + 1] - d.fairOff[n]; if (L > callMax) callMax = L; }
   if (g_prof.on) { calls++; sumMax += callMax; if (callMax > maxSeg) maxSeg = callMax; if ((calls & 4095) == 0) fprintf(stderr, "fair calls=%ld max segment=%ld avg max=%.1f E=%d\n", calls, maxSeg, (double)sumMax / calls, d.rs->evictedTableSize); }
   return best;
@@ -55,7 +69,7 @@ DEV uint64_t wgFirstFitKey(Dev& d, const ScanArgs& a) {
   uint64_t best = ~0ull, bestHi = ~0ull;
   d.rs->numScans++;
   if (WIDE_KEYS(c) && a.levelHi > a.level) { fprintf(stderr, "hostsim: the fused multi-level pass on a two-word key\n"); abort(); }
-  for (int n = 0; n < c.N; n++) {
+  for (int n = SHARD_LO(c); n < SHARD_HI(c); n++) {
     if (!((a.maskA[n >> 6] >> (n & 63)) & 1)) continue;
     if (a.maskB && !((a.maskB[n >> 6] >> (n & 63)) & 1)) continue;
     if (a.levelHi > a.level) {   // multi-level mode
@@ -79,6 +93,13 @@ DEV uint64_t wgFirstFitKey(Dev& d, const ScanArgs& a) {
     if (k >= best || k < a.lowBound) continue;
     if (!a.noFit && !fitsAlloc(d, a.req, a.level, n)) continue;
     best = k;
+  }
+  if (SHARD_ON(c)) {
+    if (WIDE_KEYS(c) && !(a.levelHi > a.level)) {   // (high word, low word): the minimum high word first, then the low words of the ranks that hold it
+      uint64_t hi = hsShardMin(bestHi);
+      if (hi == ~0ull) return ~0ull;   // (no rank has a candidate: every rank leaves here)
+      best = hsShardMin(bestHi == hi ? best : ~0ull);
+    } else best = hsShardMin(best);
   }
   return best;
 }
@@ -225,6 +246,8 @@ static int plat_comm_unique_id(char*) { g_err = "the CPU build of the tests has 
 static int plat_comm_init(const char*, int, int) { g_err = "the CPU build of the tests has no RCCL: asched_comm_init_external only"; return -1; }
 static int plat_comm_init_external(asched_allreduce_fn fn, void* ctx, int rank, int world) { t_ctx->extFn = fn; t_ctx->extCtx = ctx; t_ctx->commRank = rank; t_ctx->commWorld = world; return 0; }
 static void plat_comm_destroy() { if (t_ctx) { t_ctx->extFn = nullptr; t_ctx->extCtx = nullptr; t_ctx->commRank = 0; t_ctx->commWorld = 1; } }
+static bool plat_comm_live() { return t_ctx && t_ctx->extFn; }
+static long plat_last_shard_exchanges() { return g_shardExchanges; }
 static void plat_comm_info(int* rank, int* world) { *rank = t_ctx ? t_ctx->commRank : 0; *world = t_ctx ? t_ctx->commWorld : 1; }
 static int plat_allreduce(long long* buf, size_t count, int op) {
   if (!t_ctx->extFn) return 0;
