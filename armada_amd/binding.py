@@ -197,6 +197,10 @@ class CSubmitResult(C.Structure):
 SUBMIT_STRIP_GANG = 1
 
 
+class CShardArea(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("ipc", C.c_char * 64)]
+
+
 class CRoundResult(C.Structure):
     _fields_ = [
         ("num_scheduled", C.c_int32), ("num_preempted", C.c_int32), ("termination_reason", C.c_int32),
@@ -228,11 +232,11 @@ ALL_SYMBOLS = [
     "fit_select_batch_global", "round_delta_words", "round_delta", "round_delta_resolve",
     "set_market", "market_result", "price_gang", "price_job_on_nodes",
     "comm_unique_id", "comm_init", "comm_init_external", "comm_destroy", "comm_rank", "fit_select_batch_sharded", "round_exchange",
-    "shard_round", "shard_exchanges",
+    "shard_round", "shard_exchanges", "shard_area", "shard_open", "shard_peers",
     "excluded_nodes", "set_excluded_nodes",
 ]
 # entry points the CPU oracle does not implement (it is the single-process checker): the communicator and the collectives that run on it
-OPTIONAL_SYMBOLS = {"comm_unique_id", "comm_init", "comm_init_external", "comm_destroy", "comm_rank", "fit_select_batch_sharded", "round_exchange", "shard_round", "shard_exchanges"}
+OPTIONAL_SYMBOLS = {"comm_unique_id", "comm_init", "comm_init_external", "comm_destroy", "comm_rank", "fit_select_batch_sharded", "round_exchange", "shard_round", "shard_exchanges", "shard_area", "shard_open", "shard_peers"}
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
 
 
@@ -396,6 +400,9 @@ class Library:
         f("comm_rank", C.c_int32, [C.c_void_p, _i32p, _i32p])
         f("shard_round", C.c_int32, [C.c_void_p, C.c_int32])
         f("shard_exchanges", C.c_int64, [C.c_void_p])
+        f("shard_area", C.c_int32, [C.c_void_p, C.POINTER(CShardArea)])
+        f("shard_open", C.c_int32, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)])
+        f("shard_peers", C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32])
         f("fit_select_batch_sharded", C.c_int32, [C.c_void_p, C.c_int32, _i32p, C.c_int32, C.POINTER(CGlobalKeyLayout), _i32p])
         f("round_exchange", C.c_int32, [C.c_void_p, C.POINTER(CDeltaSummary), _i32p, _i32p, _u8p])
         f("drf_cost", C.c_double, [C.c_void_p, _i64p, _i64p])
@@ -1018,6 +1025,24 @@ class Scheduler:
 
     def shard_exchanges(self) -> int:
         return int(self.lib.shard_exchanges(self.h))
+
+    def shard_area(self):
+        """this handle's exchange area of the GPU-to-GPU variant: (device pointer, 64 IPC-handle bytes for replicas in other processes)"""
+        a = CShardArea()
+        self._check(self.lib.shard_area(self.h, C.byref(a)))
+        return int(a.ptr), C.string_at(C.addressof(a) + CShardArea.ipc.offset, 64)
+
+    def shard_open(self, ipc: bytes) -> int:
+        out = C.c_void_p(0)
+        self._check(self.lib.shard_open(self.h, C.create_string_buffer(ipc, 64).raw, C.byref(out)))
+        return int(out.value)
+
+    def shard_peers(self, areas: Optional[Sequence[int]], rank: int = 0):
+        """areas[r] = replica r's exchange area as this process addresses it; None: back to whole passes"""
+        if areas is None:
+            self._check(self.lib.shard_peers(self.h, None, 0, 0)); return
+        arr = (C.c_void_p * len(areas))(*[C.c_void_p(a) for a in areas])
+        self._check(self.lib.shard_peers(self.h, arr, len(areas), int(rank)))
 
     def fit_select_batch_sharded(self, jobs: Sequence[int], priority: int, field_bits: Sequence[int], rank_bits: int, *, rank_offset: int = 0, global_rank=None) -> np.ndarray:
         """exact node-partitioned first fit over the communicator's ranks: global rank of the chosen node per job, -1 none (collective: every rank calls it)"""

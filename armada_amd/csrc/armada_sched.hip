@@ -239,7 +239,41 @@ __device__ static unsigned long long scanPart(const Dev& d, const ScanArgs& a, i
 // (plat_run_control: the all-reduce runs on the handle's communicator).  A PCIe round trip + the collective per pass: worth it where a pass is long (100 000 nodes and
 // up) — measured numbers for one GPU only.  Bounded like every wait of this kernel: the caller's cancel word ends it.
 __shared__ unsigned int g_xgen;
+__shared__ unsigned long long g_xpeers;   // 0: the exchange goes through the host proxy; else the device address of the peer table (asched_shard_peers): GPU-to-GPU
+// The same exchange GPU-to-GPU (asched_shard_peers): every replica owns an exchange area in its HBM (fine-grained; the peers map it: peer access inside a process, hipIpc across
+// processes) — word 0 the owner's generation counter (it outlives a launch), from word 8 two banks (generation parity) of one 4-word slot per rank: {generation, word 0, word 1, -}.
+// Lane r of the control wave stores this rank's two words and then the generation (release, system scope) into ITS slot of rank r's area — over xGMI for a remote r —, then
+// watches slot r of the own area; when every rank's generation is there the words are folded across the lanes.  No host, no PCIe: an exchange is a round of posted stores
+// and one polling read of local HBM.  A rank can run at most one exchange ahead of another (it needs the other's words to finish its own), hence two banks.
+__device__ static inline void shardReduceDirect(Dev& d, unsigned long long* mn, int* mxIdx) {
+  unsigned long long* const* peers = (unsigned long long* const*)g_xpeers;
+  const int lane = threadIdx.x & 63, W = d.cfg.shardWorld, me = d.cfg.shardRank;
+  unsigned int gen = (unsigned int)__builtin_amdgcn_readfirstlane((int)g_xgen) + 1;
+  const size_t bank = (size_t)(gen & 1) * 256;
+  unsigned long long w0 = *mn, w1 = ~(unsigned long long)(unsigned int)(*mxIdx + 1);
+  unsigned long long* own = peers[me];
+  if (lane == 0) { g_xgen = gen; __hip_atomic_store(own, (unsigned long long)gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+  if (lane < W) {
+    unsigned long long* slot = peers[lane] + 8 + (bank + me) * 4;
+    __hip_atomic_store(slot + 1, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(slot + 2, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(slot, (unsigned long long)gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  unsigned long long* mine = own + 8 + (bank + (lane < W ? lane : 0)) * 4;
+  unsigned int spins = 0;
+  for (;;) {
+    bool there = lane >= W || __hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == gen;
+    if (__ballot(!there) == 0) break;
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 0xfff) == 0 && cancelRequested(d)) { raise(d, ASCHED_ERR_TIMEOUT, 904); return; }
+  }
+  unsigned long long v0 = lane < W ? __hip_atomic_load(mine + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : ~0ull;
+  unsigned long long v1 = lane < W ? __hip_atomic_load(mine + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : ~0ull;
+  v0 = waveMin64Dpp(v0); v1 = waveMin64Dpp(v1);
+  *mn = v0; *mxIdx = (int)(unsigned int)~v1 - 1;
+}
 __device__ static inline void shardReduce(Dev& d, unsigned long long* mn, int* mxIdx) {
+  if (__builtin_amdgcn_readfirstlane((int)(g_xpeers != 0))) { shardReduceDirect(d, mn, mxIdx); return; }
   unsigned long long* X = (unsigned long long*)d.cancel;
   if (!X) { raise(d, ASCHED_ERR_INTERNAL, 530); return; }
   int lane = threadIdx.x & 63;
@@ -1633,7 +1667,17 @@ __device__ static void helperMain(const Dev& d, HelpBox* b, int H) {
 #endif
 #ifdef ASCHED_WK_TU
 __global__ __launch_bounds__(CTL_THREADS) void K_CONTROL_NAME(Dev dev, int cmd, HelpBox* box, int H, MktDev mk) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) { g_mk = mk; g_xgen = 0; }   // (market-driven rounds of such a handle run here too: round_mkt.h; the exchange generation of sharded passes restarts with every launch)
+  if (threadIdx.x == 0 && blockIdx.x == 0) {   // (market-driven rounds of such a handle run here too: round_mkt.h)
+    g_mk = mk; g_xgen = 0; g_xpeers = 0;       // the exchange generation of sharded passes restarts with every launch through the host proxy ...
+    if (dev.cfg.shardWorld > 1 && dev.cancel) {
+      const unsigned long long* X = (const unsigned long long*)dev.cancel;
+      unsigned long long pt = __hip_atomic_load(&X[XCHG_WORD0 + 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (pt) {                                // ... and goes on where the last launch left it GPU-to-GPU (the peers' counters do not restart either)
+        g_xpeers = pt;
+        g_xgen = (unsigned int)__hip_atomic_load(((unsigned long long* const*)pt)[dev.cfg.shardRank], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 #else
 __global__ __launch_bounds__(CTL_THREADS) void K_CONTROL_NAME(Dev dev, int cmd, HelpBox* box, int H) {
 #endif
@@ -2340,6 +2384,7 @@ struct PlatCtx {
   bool failed = false;              // sticky: an allocation / copy / memset failed since the last plat_take_failure()
   // the handle's communicator (asched_comm_init: RCCL over xGMI; asched_comm_init_external: the caller's transport)
   ncclComm_t comm = nullptr; int commRank = 0, commWorld = 1;
+  unsigned long long* xArea = nullptr; unsigned long long** xPeerTable = nullptr; bool xDirect = false;   // GPU-to-GPU exchange of sharded passes (asched_shard_area / asched_shard_peers)
   hipStream_t xStream = nullptr; long long* xBuf = nullptr;   // sharded wide passes (dev.h shardWorld) over RCCL: the exchanged words' all-reduce runs here, beside the persistent kernel
   long lastShardExchanges = 0;
   asched_allreduce_fn extFn = nullptr; void* extCtx = nullptr;
@@ -2495,12 +2540,51 @@ static int plat_allreduce_host_min(unsigned long long* w, int count) {
   return 0;
 }
 static long plat_last_shard_exchanges() { return t_ctx ? t_ctx->lastShardExchanges : 0; }
+#define XCHG_AREA_BYTES (64 + 2 * 256 * 32)
+// this handle's exchange area (device memory, fine-grained where the runtime offers it: remote GPUs store into it) and its IPC handle for replicas in other processes
+static int plat_shard_area(void** ptr, char* ipc64) {
+  PlatCtx* c = t_ctx;
+  if (!c->xArea) {
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, XCHG_AREA_BYTES, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); if (!hipOk(hipMalloc(&p, XCHG_AREA_BYTES), "hipMalloc (exchange area)")) return -1; }
+    if (!hipOk(hipMemset(p, 0, XCHG_AREA_BYTES), "exchange area reset")) { (void)hipFree(p); return -1; }
+    c->xArea = (unsigned long long*)p;
+  }
+  *ptr = c->xArea;
+  if (ipc64) {
+    hipIpcMemHandle_t h; memset(&h, 0, sizeof h);
+    static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle");
+    memset(ipc64, 0, 64);
+    if (hipIpcGetMemHandle(&h, c->xArea) == hipSuccess) memcpy(ipc64, &h, sizeof h); else (void)hipGetLastError();   // (all zero: not exportable here; in-process peers still work)
+  }
+  return 0;
+}
+static int plat_shard_open(const char* ipc64, void** out) {
+  hipIpcMemHandle_t h; memcpy(&h, ipc64, sizeof h);
+  return hipOk(hipIpcOpenMemHandle(out, h, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle (exchange area)") ? 0 : -1;
+}
+static int plat_shard_peers(void* const* areas, int world, int rank) {
+  PlatCtx* c = t_ctx;
+  if (!areas) { c->xDirect = false; return 0; }
+  if (!c->xArea || areas[rank] != (void*)c->xArea) { c->err = "shard_peers: areas[rank] must be this handle's own area (asched_shard_area)"; return -1; }
+  for (int r = 0; r < world; r++) {   // a peer area on another GPU of this process: let this GPU store into it
+    hipPointerAttribute_t at; memset(&at, 0, sizeof at);
+    if (hipPointerGetAttributes(&at, areas[r]) == hipSuccess && at.device != c->device) { hipError_t e = hipDeviceEnablePeerAccess(at.device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { hipOk(e, "hipDeviceEnablePeerAccess"); return -1; } (void)hipGetLastError(); }
+    else (void)hipGetLastError();
+  }
+  if (!c->xPeerTable && !hipOk(hipMalloc((void**)&c->xPeerTable, 256 * sizeof(void*)), "hipMalloc (peer table)")) return -1;
+  if (!hipOk(hipMemcpy(c->xPeerTable, areas, world * sizeof(void*), hipMemcpyHostToDevice), "peer table upload")) return -1;
+  c->xDirect = true;
+  return 0;
+}
 static void plat_close(PlatCtx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->xStream) (void)hipStreamDestroy(c->xStream);
   if (c->xBuf) (void)hipFree(c->xBuf);
+  if (c->xArea) (void)hipFree(c->xArea);
+  if (c->xPeerTable) (void)hipFree(c->xPeerTable);
   plat_comm_destroy_ctx(c);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   for (hipEvent_t e : {c->ev0, c->ev1, c->fitEv0, c->fitEv1, c->rEv0, c->rEv1}) if (e) (void)hipEventDestroy(e);
@@ -2567,7 +2651,8 @@ static int plat_run_control(Dev& dev, int cmd) {
   (void)hipEventRecord(c->ev0, c->stream);
   const bool shard = dev.cfg.shardWorld > 1;
   volatile unsigned long long* X = (volatile unsigned long long*)c->cancelHost;
-  if (shard) { for (int i = 0; i < 6; i++) X[XCHG_WORD0 + i] = 0; __atomic_thread_fence(__ATOMIC_SEQ_CST); c->lastShardExchanges = 0; }
+  const bool direct = shard && c->xDirect;   // GPU-to-GPU exchange (asched_shard_peers): the kernel finds the peer table's address in the block; no proxy
+  if (shard) { for (int i = 0; i < 6; i++) X[XCHG_WORD0 + i] = 0; X[XCHG_WORD0 + 6] = direct ? (unsigned long long)c->xPeerTable : 0; __atomic_thread_fence(__ATOMIC_SEQ_CST); if (!c->inRound) c->lastShardExchanges = 0; }
   if (dev.cfg.keyWords == 2 || shard) {   // a two-word order key, or wide passes sharded across GPUs: every control command on the kernel built for them (armada_sched_wk.hip)
     if (asched_internal_wk_launch(&dev, cmd, c->stream, c->helpBox, H, t_mkt)) { c->err = "k_control_wk launch failed"; return -1; }
   } else if (cmd >= CMD_AUX_FIRST) {  // submit-check commands: their kernel lives in its own code object (armada_sched_aux.hip)
@@ -2580,7 +2665,7 @@ static int plat_run_control(Dev& dev, int cmd) {
   if (!hipOk(hipGetLastError(), "k_control launch")) return -1;
   static const double safetyS = [] { const char* e = getenv("ASCHED_SAFETY_DEADLINE_S"); return e ? atof(e) : 0.0; }();   // test / measurement runs of new builds: no launch outlives this
   double deadlineS = c->deadlineS > 0 ? c->deadlineS : safetyS;
-  if (shard) {
+  if (shard && !direct) {
     // the exchange proxy of sharded passes: the kernel posts (generation, two words), this thread runs the all-reduce on the handle's communicator and answers (dev.h XCHG_WORD0)
     auto t0 = c->inRound ? c->roundT0 : std::chrono::steady_clock::now();
     unsigned long long served = 0; unsigned int idle = 0; bool failed = false;
@@ -2621,7 +2706,7 @@ static int plat_run_control(Dev& dev, int cmd) {
 // ---- the split round: grid-wide kernels between the persistent passes, all on the handle's stream (no host sync except where a count is needed)
 static void plat_round_begin() {
   PlatCtx* c = t_ctx;
-  c->inRound = true; c->roundT0 = std::chrono::steady_clock::now(); c->roundControlMs = 0.f; c->roundLaunches = 0;
+  c->inRound = true; c->roundT0 = std::chrono::steady_clock::now(); c->roundControlMs = 0.f; c->roundLaunches = 0; c->lastShardExchanges = 0;
   (void)hipEventRecord(c->rEv0, c->stream);
 }
 static void plat_round_end() {

@@ -508,10 +508,21 @@ int32_t ASCHED_FN(fit_select_batch_sharded)(asched_t*, int32_t n, const int32_t*
    handle's communicator: RCCL on a side stream while the round kernel waits, or the external transport, which is then called with ASCHED_ALLREDUCE_HOST_WORDS or-ed into
    `op` (buf is host memory: reduce it in place, do not synchronise the device — the round kernel is running).  The minimum over the shares IS the unsharded pass's answer,
    so every rank computes the reference's round, bit for bit the same one.  Every rank must run the same calls on the same inputs.  shard_exchanges: all-reduces of the
-   handle's last control launch.  Not measured on more than one GPU. */
+   handle's last round (of its last control launch outside a round).  Not measured on more than one GPU. */
 #define ASCHED_ALLREDUCE_HOST_WORDS 16
 int32_t ASCHED_FN(shard_round)(asched_t*, int32_t on);
 int64_t ASCHED_FN(shard_exchanges)(asched_t*);
+/* The same exchange GPU-to-GPU, without the host (and without a communicator): every replica owns an exchange area in its HBM; the control wave of its round kernel stores
+   its two words into its slot of EVERY replica's area (over xGMI for a remote one) and watches its own area fill.  shard_area: this handle's area — its device pointer and
+   the hipIpcMemHandle_t bytes (all zero where the runtime cannot export it) for replicas in other processes, who map it with shard_open.  shard_peers(areas[world], world,
+   rank): areas[r] = replica r's area as THIS process addresses it (areas[rank] = the own one); switches the handle's rounds to sharded passes with the direct exchange;
+   world <= 64.  shard_peers(NULL, ..) switches back to whole passes.  Order: every replica calls shard_area (allocates + zeroes), the caller distributes the pointers /
+   handles (that is also the barrier the zeroing needs), every replica calls shard_peers, then the replicas run the same rounds.  A replica that leaves a round early
+   (deadline) leaves the counters out of step: start over with fresh handles.  Exercised with two replicas on ONE GPU (two round kernels side by side); never over xGMI. */
+typedef struct asched_shard_area_t { void* ptr; char ipc[64]; } asched_shard_area_t;
+int32_t ASCHED_FN(shard_area)(asched_t*, asched_shard_area_t* out);
+int32_t ASCHED_FN(shard_open)(asched_t*, const char* ipc /*[64]*/, void** out);
+int32_t ASCHED_FN(shard_peers)(asched_t*, void* const* areas /*[world]*/, int32_t world, int32_t rank);
 /* APPROXIMATE (labelled so everywhere), queue-hash round: round_delta + ONE all-reduce SUM + round_delta_resolve as one stream-ordered sequence
    on the handle's stream; outputs as round_delta_resolve. */
 int32_t ASCHED_FN(round_exchange)(asched_t*, asched_delta_summary* summary, int32_t* job_node /*[M]*/, int32_t* job_priority /*[M]*/, uint8_t* job_replay /*[M]*/);

@@ -179,7 +179,7 @@ static int plat_run_control(Dev& dev, int cmd) {
   return 0;
 }
 // the grid-wide kernels of the split round, serially
-static void plat_round_begin() { t_ctx->inRound = true; t_ctx->launches = 0; }
+static void plat_round_begin() { t_ctx->inRound = true; t_ctx->launches = 0; g_shardExchanges = 0; }
 static void plat_round_end() { t_ctx->inRound = false; t_ctx->cancelWord = 0; }
 static void plat_round_times(double* out) { out[0] = 0; out[1] = 0; out[2] = t_ctx->launches; }
 static int plat_bulk(Dev& dev, int kind, int n) { Dev d = dev; for (int i = 0; i < n; i++) bulkElem(d, kind, i); t_ctx->launches++; return 0; }
@@ -248,6 +248,10 @@ static int plat_comm_init_external(asched_allreduce_fn fn, void* ctx, int rank, 
 static void plat_comm_destroy() { if (t_ctx) { t_ctx->extFn = nullptr; t_ctx->extCtx = nullptr; t_ctx->commRank = 0; t_ctx->commWorld = 1; } }
 static bool plat_comm_live() { return t_ctx && t_ctx->extFn; }
 static long plat_last_shard_exchanges() { return g_shardExchanges; }
+// the GPU-to-GPU exchange (asched_shard_area / shard_open / shard_peers) is stores of one round kernel into another GPU's memory: the CPU build has the communicator path only
+static int plat_shard_area(void**, char*) { g_err = "the CPU build of the tests has no exchange areas: asched_shard_round over asched_comm_init_external only"; return -1; }
+static int plat_shard_open(const char*, void**) { g_err = "the CPU build of the tests has no exchange areas"; return -1; }
+static int plat_shard_peers(void* const* areas, int, int) { if (!areas) return 0; g_err = "the CPU build of the tests has no exchange areas"; return -1; }
 static void plat_comm_info(int* rank, int* world) { *rank = t_ctx ? t_ctx->commRank : 0; *world = t_ctx ? t_ctx->commWorld : 1; }
 static int plat_allreduce(long long* buf, size_t count, int op) {
   if (!t_ctx->extFn) return 0;

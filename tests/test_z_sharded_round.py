@@ -102,3 +102,53 @@ def test_sharded_round_equals_the_oracle_on_every_rank(tmp_path, hostsim_lib, or
 def test_sharded_round_equals_the_oracle_on_every_rank_gpu(tmp_path, hip_lib, oracle_lib):
     """two persistent round kernels on ONE GPU, each waiting for the other's words: the device protocol + the host proxy (gloo between the two processes)"""
     _check(_run(tmp_path, 2, True, 29741, scale=2), 2)
+
+
+def _direct_pair(hip_lib, wl, fp=None, rounds=2):
+    """two replicas of one pool as two handles of this process on device 0, their round kernels exchanging GPU-to-GPU (asched_shard_peers); one thread per handle"""
+    import threading
+    from armada_amd import workloads as W
+    hs = [W.load(hip_lib, wl) for _ in range(2)]
+    areas = [h.shard_area()[0] for h in hs]
+    for r, h in enumerate(hs):
+        h.shard_peers(areas, r)
+        h.set_deadline(120.0)
+    got, err = [None, None], [None, None]
+
+    def run(i):
+        try:
+            for _ in range(rounds):
+                W.prepare(hs[i], wl, fairshare_preemption_tokens=fp)
+                got[i] = hs[i].schedule_round()
+        except Exception as e:   # noqa: BLE001
+            err[i] = e
+    th = [threading.Thread(target=run, args=(i,)) for i in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=400)
+    assert not any(t.is_alive() for t in th), "a sharded round hung"
+    assert err == [None, None], err
+    for h in hs:
+        h.close()
+    return got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["preempt", "gangs", "small", "small-two-word"])
+def test_sharded_round_gpu_to_gpu_exchange(hip_lib, oracle_lib, monkeypatch, case):
+    """the exchange without the host: each round kernel stores its words into the other replica's area and watches its own (here both areas are on the one GPU)"""
+    import scenario
+    from armada_amd import workloads as W
+    if case == "small-two-word":
+        monkeypatch.setenv("ASCHED_KEY_WORDS", "2")
+    wl, fp = {"preempt": (W.config3(n_nodes=3000, n_jobs=24000, n_queues=8, seed=11, occupied=0.95), None),
+              "gangs": (W.config3(n_nodes=1800, n_jobs=12000, n_queues=6, seed=12, occupied=0.6, gangs=40), None),
+              "small": (W.small_random(n_nodes=70, n_jobs=700, n_queues=5, seed=13, occupied=0.95, gangs=3, away=True, ragged=True), 5.0),
+              "small-two-word": (W.small_random(n_nodes=70, n_jobs=700, n_queues=5, seed=13, occupied=0.95, gangs=3, away=True, ragged=True), 5.0)}[case]
+    o = W.load(oracle_lib, wl); W.prepare(o, wl, fairshare_preemption_tokens=fp); want = o.schedule_round(); o.close()
+    got = _direct_pair(hip_lib, wl, fp)
+    for g in got:
+        scenario.assert_same_round(want, g)
+    if case == "preempt":
+        assert len(want.preempted) > 100
