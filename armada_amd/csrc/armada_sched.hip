@@ -1667,6 +1667,7 @@ __device__ static void helperMain(const Dev& d, HelpBox* b, int H) {
 #endif
 #ifdef ASCHED_WK_TU
 __global__ __launch_bounds__(CTL_THREADS) void K_CONTROL_NAME(Dev dev, int cmd, HelpBox* box, int H, MktDev mk) {
+  if (threadIdx.x == 0 && blockIdx.x != 0) g_mk = mk;   // (helper workgroups: the market state's HBM homes — none of the bodies they serve looks at it; never garbage)
   if (threadIdx.x == 0 && blockIdx.x == 0) {   // (market-driven rounds of such a handle run here too: round_mkt.h)
     g_mk = mk; g_xgen = 0; g_xpeers = 0;       // the exchange generation of sharded passes restarts with every launch through the host proxy ...
     if (dev.cfg.shardWorld > 1 && dev.cancel) {

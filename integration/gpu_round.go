@@ -1108,6 +1108,33 @@ func (g *GpuRound) ShardRound(on bool) error {
 	return g.check(C.asched_shard_round(g.h, v))
 }
 
+// ShardArea / ShardOpen / ShardPeers: the GPU-to-GPU exchange of sharded passes (INTEGRATION.md 3a): this replica's exchange area and its IPC handle bytes; another
+// process' area mapped into this one; the list of every replica's area (areas[rank] = the own one) — from then on the handle's rounds split their wide passes.
+func (g *GpuRound) ShardArea() (unsafe.Pointer, [64]byte, error) {
+	var a C.asched_shard_area_t
+	var ipc [64]byte
+	if err := g.check(C.asched_shard_area(g.h, &a)); err != nil {
+		return nil, ipc, err
+	}
+	for i := range ipc {
+		ipc[i] = byte(a.ipc[i])
+	}
+	return a.ptr, ipc, nil
+}
+
+func (g *GpuRound) ShardOpen(ipc [64]byte) (unsafe.Pointer, error) {
+	var out unsafe.Pointer
+	err := g.check(C.asched_shard_open(g.h, (*C.char)(unsafe.Pointer(&ipc[0])), &out))
+	return out, err
+}
+
+func (g *GpuRound) ShardPeers(areas []unsafe.Pointer, rank int) error {
+	if len(areas) == 0 {
+		return g.check(C.asched_shard_peers(g.h, nil, 0, 0))
+	}
+	return g.check(C.asched_shard_peers(g.h, (*unsafe.Pointer)(unsafe.Pointer(&areas[0])), C.int32_t(len(areas)), C.int32_t(rank)))
+}
+
 // ErrPeer: a collective entry point returned ASCHED_ERR_PEER — another rank of the communicator failed in front of the exchange (its own call returns the cause); nothing
 // was exchanged and the communicator stays usable.  (Every rank all-reduces one status word before the data: a rank-local failure can no longer leave the others in RCCL.)
 func (g *GpuRound) ErrPeer(err error) bool {
