@@ -152,3 +152,56 @@ def test_sharded_round_gpu_to_gpu_exchange(hip_lib, oracle_lib, monkeypatch, cas
         scenario.assert_same_round(want, g)
     if case == "preempt":
         assert len(want.preempted) > 100
+
+
+IPC_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import scenario, armada_amd
+from armada_amd import workloads as W
+from armada_amd.binding import Library
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+lib = armada_amd.load_library()
+orc = Library(os.path.join(%(root)r, "oracle", "liboracle.so"), "oracle_")
+dist.init_process_group("gloo")
+wl = W.config3(n_nodes=3000, n_jobs=24000, n_queues=8, seed=11, occupied=0.95)
+s = W.load(lib, wl)
+ptr, ipc = s.shard_area()
+handles = [None] * world
+dist.all_gather_object(handles, ipc)          # (also the barrier the freshly zeroed areas need)
+assert any(handles[rank]), "the runtime could not export the exchange area"
+areas = [ptr if r == rank else s.shard_open(handles[r]) for r in range(world)]
+s.shard_peers(areas, rank)
+s.set_deadline(120.0)
+dist.barrier()
+for _ in range(2):
+    W.prepare(s, wl); r = s.schedule_round()
+o = W.load(orc, wl); W.prepare(o, wl); ro = o.schedule_round(); o.close()
+try:
+    scenario.assert_same_round(ro, r); same = True
+except AssertionError as e:
+    same = False; print("DIFF", rank, str(e)[:300], file=sys.stderr)
+res = [None] * world
+dist.all_gather_object(res, [same, len(r.scheduled), len(r.preempted)])
+dist.barrier()
+s.close()
+if rank == 0:
+    print("RESULT " + json.dumps(res))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+def test_sharded_round_gpu_to_gpu_exchange_across_processes(tmp_path, hip_lib, oracle_lib):
+    """the replicas as two PROCESSES (the deployment shape: one process per GPU): each maps the other's exchange area through its hipIpc handle (asched_shard_open)"""
+    script = tmp_path / "ipc_worker.py"
+    script.write_text(IPC_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("ASCHED_KEY_WORDS", None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29751", str(script)],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
+    assert all(x[0] for x in res) and res[0][2] > 100 and res[0] == res[1], res
