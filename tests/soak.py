@@ -13,6 +13,7 @@
     python tests/soak.py ops 3000           # tests/test_z_nodedb_op_sequences.py NodeDb-level operation sequences
     python tests/soak.py submitcheck 400    # batched SubmitChecker vs the literal sequential restatement (and 3-entry cache)
     python tests/soak.py fit 600            # fit_select_batch at every priority on occupied NodeDbs
+    python tests/soak.py sharded 1000       # ONE pool's round on 2-3 replicas with its wide passes split and all-reduced (asched_shard_round; SOAK_SHARD=direct on a GPU box: asched_shard_peers)
     python tests/soak.py excluded 1000      # NumExcludedNodesByReason (asched_excluded_nodes) of every failed selection of a round, incl. literal rows / away types / off-grid requests
 
 HS_RING_LAG=<seed> (CPU build): the serial node engine lags behind the merge by a pseudo-random number of ring entries, as on the device (tests/hostsim/fast_serial.h).
@@ -42,6 +43,54 @@ def libs():
         return Library(os.path.join(ROOT, "oracle", "liboracle.so"), "oracle_"), armada_amd.load_library()
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hostsim")])
     return Library(os.path.join(ROOT, "oracle", "liboracle.so"), "oracle_"), Library(os.path.join(ROOT, "tests", "hostsim", "libhostsim.so"), "asched_")
+
+
+def sharded_rounds(lib, wl, fp, world):
+    """`world` replicas of one pool as threads of this process; the all-reduce of a sharded pass is a barrier + a fold over the replicas' words (host memory in both builds:
+    the CPU build calls synchronously, the HIP library's proxy passes ASCHED_ALLREDUCE_HOST_WORDS); SOAK_SHARD=direct: the GPU-to-GPU exchange instead"""
+    import ctypes, threading
+    direct = os.environ.get("SOAK_SHARD") == "direct"
+    hs = [W.load(lib, wl) for _ in range(world)]
+    bar = threading.Barrier(world, timeout=120)
+    slots = [None] * world
+
+    def make(rank):
+        def allreduce(ptr, count, op):
+            arr = np.ctypeslib.as_array((ctypes.c_int64 * count).from_address(ptr))
+            slots[rank] = arr.copy()
+            bar.wait()
+            stack = np.stack(slots)
+            red = stack.sum(axis=0) if (op & 15) == 0 else stack.min(axis=0) if (op & 15) == 1 else stack.max(axis=0)
+            bar.wait()
+            arr[:] = red
+            return 0
+        return allreduce
+    if direct:
+        areas = [h.shard_area()[0] for h in hs]
+        for r, h in enumerate(hs):
+            h.shard_peers(areas, r)
+    else:
+        for r, h in enumerate(hs):
+            h.comm_init_external(make(r), r, world); h.shard_round(True)
+    got, err = [None] * world, [None] * world
+
+    def run(i):
+        try:
+            hs[i].set_deadline(100.0)
+            W.prepare(hs[i], wl, fairshare_preemption_tokens=fp)
+            got[i] = hs[i].schedule_round()
+        except Exception as e:   # noqa: BLE001
+            err[i] = e; print('replica', i, 'failed:', repr(e)[:300], flush=True); bar.abort()
+    th = [threading.Thread(target=run, args=(i,)) for i in range(world)]
+    for t in th: t.start()
+    for t in th: t.join(timeout=300)
+    alive = any(t.is_alive() for t in th)
+    for h in hs:
+        if not alive: h.close()
+    assert not alive, "a sharded round hung"
+    for e in err:
+        if e is not None: raise e
+    return got
 
 
 def main():
@@ -163,6 +212,18 @@ def main():
                     queued = [int(j) for q in wl.queued for j in q][:400]
                     out.append({p: s.fit_select_batch(queued, p).tolist() for p in s.priorities})
                 assert out[0] == out[1], "fit_select_batch differs"
+            elif kind == "sharded":   # ONE pool's round on 2-3 replicas (threads of this process), wide passes split + all-reduced (asched_shard_round; SOAK_SHARD=direct on a GPU box: asched_shard_peers)
+                if os.environ.get("SOAK_LIB") != "hip":
+                    raise SystemExit("soak.py sharded runs the replicas as threads: the product library only (SOAK_LIB=hip on a GPU box); CPU build: tests/soak_sharded_worker.py under torch.distributed.run")
+                rng = np.random.default_rng(seed)
+                wl = W.small_random(n_nodes=int(rng.integers(4, 300)), n_jobs=int(rng.integers(50, 4000)), n_queues=int(rng.integers(1, 12)), seed=seed,
+                                    occupied=float(rng.choice([0.3, 0.6, 0.9, 1.0])), gangs=int(rng.integers(0, 8)),
+                                    burst=None if rng.random() < 0.5 else (int(rng.integers(10, 2000)), int(rng.integers(5, 500))),
+                                    away=bool(rng.random() < 0.3), ragged=bool(rng.random() < 0.2), offgrid=int(rng.choice([0, 0, 0, 3])))
+                fp = None if rng.random() < 0.4 else float(rng.choice([0, 1, 3, 10, 40]))
+                s = W.load(orc, wl); W.prepare(s, wl, fairshare_preemption_tokens=fp); want = s.schedule_round(); s.close()
+                for got in sharded_rounds(hs, wl, fp, 2 + seed % 2):
+                    scenario.assert_same_round(want, got)
             else:
                 raise SystemExit(__doc__)
         except SchedError as e:
