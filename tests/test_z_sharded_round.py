@@ -36,15 +36,15 @@ else:
 orc = Library(os.path.join(%(root)r, "oracle", "liboracle.so"), "oracle_")
 dist.init_process_group("gloo")
 scale = %(scale)r
-cases = [("preempt", W.config3(n_nodes=1500 * scale, n_jobs=12000 * scale, n_queues=8, seed=11, occupied=0.95), None),
-         ("gangs", W.config3(n_nodes=900 * scale, n_jobs=6000 * scale, n_queues=6, seed=12, occupied=0.6, gangs=40), None),
+cases = [("preempt", W.config3(n_nodes=int(1500 * scale), n_jobs=int(12000 * scale), n_queues=8, seed=11, occupied=0.95), None),
+         ("gangs", W.config3(n_nodes=int(900 * scale), n_jobs=int(6000 * scale), n_queues=6, seed=12, occupied=0.6, gangs=int(40 * min(scale, 1))), None),
          ("small", W.small_random(n_nodes=70, n_jobs=700, n_queues=5, seed=13, occupied=0.95, gangs=3, away=True, ragged=True), 5.0)]
 out = {}
 for name, wl, fp in cases:
     for two in (0, 1):
         if two: os.environ["ASCHED_KEY_WORDS"] = "2"
         else: os.environ.pop("ASCHED_KEY_WORDS", None)
-        if two and use_gpu and name != "small": continue
+        if two and name != "small": continue   # (the two-word key on the small mixed case: twice the exchanges per selection)
         s = W.load(lib, wl)
         comm.init_external(s, dist, device_memory=use_gpu)
         s.shard_round(True)
@@ -95,7 +95,7 @@ def _check(res, world):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_round_equals_the_oracle_on_every_rank(tmp_path, hostsim_lib, oracle_lib, world):
-    _check(_run(tmp_path, world, False, 29731 + world), world)
+    _check(_run(tmp_path, world, False, 29731 + world, scale=0.4), world)
 
 
 @pytest.mark.gpu
