@@ -2682,7 +2682,7 @@ static int plat_run_control(Dev& dev, int cmd) {
       }
       if ((++idle & 0xfff) == 0 && isRound && deadlineS > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > deadlineS) plat_cancel(c);
     }
-    if (failed) { (void)hipStreamSynchronize(c->stream); return -1; }
+    if (failed) { (void)hipStreamSynchronize(c->stream); if (!c->inRound) __atomic_store_n(c->cancelHost, 0, __ATOMIC_RELEASE); return -1; }
   } else
   if (dev.progress || (isRound && deadlineS > 0)) {
     // hard timeout (scheduling_algo.go:130-134): the kernel polls the cancel word; the host sets it when the deadline passes

@@ -454,6 +454,81 @@ def market_record(hip, args):
     return rec
 
 
+def two_word_record(hip, args):
+    """a pool whose order key needs more than 64 bits (five indexed resources at fine resolutions: 80 bits of fields + the node-index rank) — served since round 6 by the
+    generic path of k_control_wk with a two-word key.  The price of exactness where rounds 1-5 answered ASCHED_ERR_UNSUPPORTED, not a tuned number."""
+    import torch
+    from armada_amd import workloads as W
+    from armada_amd.binding import Library
+    sc = args.other_scale
+    wl = W.fine_indexed(n_nodes=max(64, int(20_000 * sc)), n_jobs=max(400, int(100_000 * sc)), n_queues=32 if sc == 1.0 else 4, occupied=0.5)
+    s = W.load(hip, wl)
+    times = []
+    for _ in range(2):
+        W.prepare(s, wl); torch.cuda.synchronize()
+        t0 = time.perf_counter(); res = s.schedule_round(); times.append(time.perf_counter() - t0)
+    st = s.round_stats(); s.close()
+    dt = times[-1]
+    rec = {"config": "two-word order keys (SURVEY a4)", "workload": f"{wl.num_nodes} nodes x {wl.num_queues} queues x {sum(len(q) for q in wl.queued)} queued jobs, indexed gpu @1, cpu @1m, memory @1Mi, "
+                     "ephemeral-storage @1Mi, nvme @1Gi: the key needs 80 bits of fields + the node-index rank",
+           "metric": "scheduling rounds/sec on a pool with a 128-bit order key (generic path of k_control_wk)", "value": 1.0 / dt, "unit": "rounds/s", "ms_per_step": dt * 1e3, "steps": 1,
+           "round": {"scheduled": len(res.scheduled), "preempted": len(res.preempted), "loop_iterations": res.num_loop_iterations, "generic_iterations": int(st.get("generic_iterations", 0)),
+                     "fast_iterations": int(st.get("fast_iterations", 0)), "kclk_plane_scans": int(st.get("kclk_plane_scans", 0)), "kclk_pass1": int(st.get("kclk_pass1", 0))},
+           "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": "k_control_wk",
+                        "note": "the generic path: two plane passes per selection (high word, low word), latency bound; no bandwidth figure is claimed"}}
+    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if args.cpu_budget > 0 and os.path.exists(path):
+        o = W.load(Library(path, "oracle_"), wl); W.prepare(o, wl)
+        t0 = time.perf_counter(); ores = o.schedule_round(); odt = time.perf_counter() - t0; o.close()
+        rec["cpu_baseline"] = {"value": 1.0 / odt, "unit": "rounds/s", "cores": 1, "kind": "port", "sample": f"the same round on the CPU oracle, {odt:.2f} s"}
+        rec["parity"] = parity_record(res, ores, wl.num_jobs, "oracle round on the same input")
+    return rec
+
+
+def sharded_record(hip, args):
+    """ONE pool's round on two replicas with its wide node passes split and exchanged GPU-to-GPU (asched_shard_peers) — here both replicas are handles of this process on
+    the ONE GPU, their round kernels side by side (never run on two GPUs).  Compared with two whole rounds side by side on the same GPU."""
+    import threading
+    import numpy as np
+    from armada_amd import workloads as W
+    if str(getattr(hip, "path", "")).endswith("libhostsim.so"):   # (the contract test's CPU stand-in keeps its LDS stand-ins in process-wide variables: no two rounds at a time)
+        return {"config": "one pool on two replicas, wide passes split (SURVEY 8e)", "skipped": "needs the HIP library (two round kernels side by side)"}
+    sc = args.other_scale
+    wl = W.config3(n_nodes=max(64, int(20_000 * sc)), n_jobs=max(400, int(200_000 * sc)), n_queues=32 if sc == 1.0 else 4, seed=W.SEED, occupied=0.95)
+    wl.global_burst, wl.queue_burst = max(1, wl.num_jobs // 8), max(1, wl.num_jobs // 80)
+
+    def pair(shard):
+        hs = [W.load(hip, wl) for _ in range(2)]
+        if shard:
+            areas = [h.shard_area()[0] for h in hs]
+            for r, h in enumerate(hs):
+                h.shard_peers(areas, r)
+        for h in hs:
+            h.set_deadline(240.0)
+        times, res = [[], []], [None, None]
+
+        def run(i):
+            for _ in range(2):
+                W.prepare(hs[i], wl); t0 = time.perf_counter(); res[i] = hs[i].schedule_round(); times[i].append(time.perf_counter() - t0)
+        th = [threading.Thread(target=run, args=(i,)) for i in (0, 1)]
+        for t in th: t.start()
+        for t in th: t.join()
+        st = hs[0].round_stats()
+        for h in hs: h.close()
+        return res, max(times[0][-1], times[1][-1]), st
+    r0, t0, st0 = pair(False)
+    r1, t1, st1 = pair(True)
+    same = all(np.array_equal(r0[0].scheduled_job, r.scheduled_job) and np.array_equal(r0[0].scheduled_node, r.scheduled_node) and np.array_equal(r0[0].preempted_job, r.preempted_job) for r in r1)
+    return {"config": "one pool on two replicas, wide passes split (SURVEY 8e)", "workload": f"{wl.num_nodes} nodes x {wl.num_queues} queues x {sum(len(q) for q in wl.queued)} queued jobs, 95% occupied; "
+                      "two replicas of the pool as two handles on this ONE GPU",
+            "metric": "scheduling rounds/sec of a replica whose wide node passes are split two ways and exchanged GPU-to-GPU", "value": 1.0 / t1, "unit": "rounds/s", "ms_per_step": t1 * 1e3, "steps": 1,
+            "two_whole_rounds_side_by_side_ms": t0 * 1e3, "kclk_plane_scans": [int(st0.get("kclk_plane_scans", 0)), int(st1.get("kclk_plane_scans", 0))],
+            "round": {"scheduled": len(r1[0].scheduled_job), "preempted": len(r1[0].preempted_job)},
+            "parity": {"checked": True, "identical": bool(same), "jobs": wl.num_jobs, "against": "the unsharded library's round on the same input (which the headline legs pin on the oracle)"},
+            "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": "k_control_wk",
+                         "note": "unmeasured on more than one GPU; on one GPU the two replicas share its HBM and its CUs"}}
+
+
 def round_shape_record(hip, args, label, kwargs, steps, note, warmup=1):
     """one of the other BASELINE round shapes (configs[3] gangs, configs[4] oversubscribed / preemption-heavy): GPU rounds timed like the headline,
     the oracle on the same input for the cpu_baseline and the parity verdict when its round fits the remaining budget"""
@@ -552,6 +627,8 @@ def other_configs(hip, args, t_start, sink=None):
     guarded("submit check", submit)
     guarded("fairness optimiser node scoring", lambda: optimiser_record(hip, args))
     guarded("market-driven round + pricer", lambda: market_record(hip, args))
+    guarded("two-word order keys", lambda: two_word_record(hip, args))
+    guarded("one pool on two replicas", lambda: sharded_record(hip, args))
     # the queue-count cliff (round-2 review): more than 64 queues leave the fast iteration (one lane per queue) for the generic one; measured, not hidden
     guarded("256 queues", shape("256 queues (beyond the 64-lane fast iteration)", None, dict(n_nodes=20_000, n_jobs=200_000, n_queues=256),
                                 "more than 64 queues: wide runs since round 4 (round_wide.h: per-queue streams merged by a bulk rank on the helper workgroups; the generic iteration in "

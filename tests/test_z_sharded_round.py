@@ -205,3 +205,22 @@ def test_sharded_round_gpu_to_gpu_exchange_across_processes(tmp_path, hip_lib, o
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
     assert all(x[0] for x in res) and res[0][2] > 100 and res[0] == res[1], res
+
+
+def test_shard_round_preconditions(hostsim_lib):
+    """no communicator -> INVALID; wall-clock time budgets -> UNSUPPORTED (the replicas' control flow must be a function of their inputs alone)"""
+    from armada_amd import workloads as W
+    from armada_amd.binding import SchedError
+    wl = W.small_random(n_nodes=20, n_jobs=200, n_queues=3, seed=5)
+    s = W.load(hostsim_lib, wl)
+    with pytest.raises(SchedError) as e:
+        s.shard_round(True)
+    assert e.value.code == -1 and "communicator" in str(e.value)
+    s.close()
+    wl.config.max_new_job_scheduling_duration_ns = 10 ** 9
+    s = W.load(hostsim_lib, wl)
+    s.comm_init_external(lambda ptr, count, op: 0, 0, 2)
+    with pytest.raises(SchedError) as e:
+        s.shard_round(True)
+    assert e.value.code == -2 and "clock" in str(e.value)
+    s.close()
