@@ -225,11 +225,13 @@ def default_indexed(n_nodes=20_000, n_jobs=200_000, n_queues=64, seed=SEED, occu
     return wl
 
 
-def fine_indexed(n_nodes=20_000, n_jobs=200_000, n_queues=64, seed=SEED, occupied=0.5, k5=True) -> Workload:
+def fine_indexed(n_nodes=20_000, n_jobs=200_000, n_queues=64, seed=SEED, occupied=0.5, k5=True, coarse=False) -> Workload:
     """default_indexed's pool on FINE index resolutions and (k5) a fifth indexed resource: nvidia.com/gpu @1, cpu @1m, memory @1Mi, ephemeral-storage @1Mi,
     a local-nvme column @1Gi on 64 cpu / 1 TiB / 4 TiB / 8 gpu / 32 TiB nodes.  The fields of the order key (nodedb/encoding.go:37-54) need 4 + 16 + 21 + 23 + 16 = 80 bits
     and the node-index rank 15-20 more: beyond one 64-bit word at any node count — the layout rounds 1-5 refused (ASCHED_ERR_UNSUPPORTED) and round 6 serves with a
-    two-word key (armada_amd/csrc/armada_sched_wk.hip).  Requests are multiples of the resolutions, one node type: no literal iteration."""
+    two-word key (armada_amd/csrc/armada_sched_wk.hip).  Requests are multiples of the resolutions, one node type: no literal iteration.
+    coarse=True: the same resolutions, but the jobs ask in quarter cores, 100Mi and GiB steps like real pods — every value a column can take is a multiple of 250m / 32Mi /
+    2Gi, the key may divide by those instead (asched_host.inc layoutKeys) and, without the nvme column, fits one word again: the fast path."""
     rng = np.random.Generator(np.random.PCG64(seed))
     pcs = [(0, True), (1, True), (3, False)]
     pc_prio = np.array([p for p, _ in pcs])
@@ -238,7 +240,8 @@ def fine_indexed(n_nodes=20_000, n_jobs=200_000, n_queues=64, seed=SEED, occupie
     node_total = np.tile(np.array(node, dtype=np.int64), (n_nodes, 1))
     pf = rng.integers(1, 11, size=n_queues).astype(np.float64)
     weight = 1.0 / pf
-    rows = [[m * 100 * Mi + 3 * Mi, c * 1000 + 250, e * Gi + 7 * Mi, 0] + ([d * Gi] if k5 else []) for c in (1, 2, 4, 8) for m in (40, 80, 160, 320) for e, d in ((10, 100), (50, 0), (100, 2000), (200, 500))]
+    odd = 0 if coarse else 1
+    rows = [[m * 100 * Mi + odd * 3 * Mi, c * 1000 + 250, e * Gi + odd * 7 * Mi, 0] + ([d * Gi] if k5 else []) for c in (1, 2, 4, 8) for m in (40, 80, 160, 320) for e, d in ((10, 100), (50, 0), (100, 2000), (200, 500))]
     shapes = np.array(rows, dtype=np.int64)
     pc_p = np.array([0.6, 0.3, 0.1])
     run_req, run_node, run_queue, run_pc, run_prio = _fill_nodes(rng, node_total, occupied, shapes, weight / weight.sum(), pc_p, pc_prio)
@@ -249,7 +252,7 @@ def fine_indexed(n_nodes=20_000, n_jobs=200_000, n_queues=64, seed=SEED, occupie
     q_queue = rng.choice(n_queues, size=n_jobs, p=zipf).astype(np.int32)
     q_req = shapes[rng.integers(0, len(shapes), size=n_jobs)].copy()
     q_req[rng.random(n_jobs) < 0.05, GPU] = 1
-    q_req[rng.random(n_jobs) < 0.2, CPU] += 125
+    q_req[rng.random(n_jobs) < 0.2, CPU] += 250 if coarse else 125
     q_pc = rng.choice(3, size=n_jobs, p=pc_p).astype(np.int32)
     cfg = _config(pcs, protected=0.5)
     cfg.num_resources = cols

@@ -132,7 +132,70 @@ def test_multi_gpu_exchange_word_is_refused(hostsim_lib, monkeypatch):
     s.close()
 
 
+# ---------------------------------------------------------------- a coarser divisor before a second word (asched_host.inc layoutKeys)
+@pytest.mark.parametrize("occupied", [0.5, 0.97])
+def test_coarse_requests_bring_fine_resolutions_back_to_one_word(hostsim_lib, oracle_lib, occupied):
+    """cpu @1m, memory @1Mi, ephemeral @1Mi need 79 bits at face value; the jobs ask in quarter cores / 100Mi / GiB, so every column value is a multiple of 250m / 32Mi / 2Gi and the
+    key may divide by those (same order, exactly): 51 bits, one word, the FAST path — where the same pool with odd requests runs the generic path on a two-word key"""
+    wl = W.fine_indexed(n_nodes=600, n_jobs=6000, n_queues=8, occupied=occupied, k5=False, coarse=True)
+    r, st = _same((oracle_lib, hostsim_lib), wl)
+    assert st["fast_iterations"] > 900 and st["generic_iterations"] <= 8, st
+    odd = W.fine_indexed(n_nodes=600, n_jobs=6000, n_queues=8, occupied=occupied, k5=False, coarse=False)
+    r2, st2 = _same((oracle_lib, hostsim_lib), odd)
+    assert st2["fast_iterations"] == 0
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_forced_coarse_divisor_rounds_match_the_oracle(hostsim_lib, oracle_lib, monkeypatch, seed):
+    """ASCHED_KEY_GCD=1: the coarser divisor wherever it applies (here memory in 1-4 GiB units against a 128Mi resolution): the whole fast path on scaled key fields"""
+    monkeypatch.setenv("ASCHED_KEY_GCD", "1")
+    wl = _small(seed, away=seed % 5 == 0)
+    r, st = _same((oracle_lib, hostsim_lib), wl, fp=None if seed % 2 else 5.0)
+    assert st["fast_iterations"] > 0
+
+
+def test_coarse_divisor_refusals(hostsim_lib, monkeypatch):
+    """what reasons in the index resolution itself is refused on such a handle: a node value off the divisor, the cross-shard key word"""
+    monkeypatch.setenv("ASCHED_KEY_GCD", "1")
+    wl = _small(1)
+    s = W.load(hostsim_lib, wl)
+    p, r = len(s.priorities), wl.node_total.shape[1]
+    planes = np.tile(wl.node_total[0], (p, 1)).astype(np.int64)
+    planes[:, W.MEM] += 3 * Mi   # off every plausible divisor
+    with pytest.raises(SchedError) as e:
+        s.node_upsert(0, planes)
+    assert e.value.code == ERR_UNSUPPORTED and "divisor" in str(e.value)
+    buf = np.zeros(8, dtype=np.int64)
+    with pytest.raises(SchedError) as e:
+        s.fit_select_batch_global(np.concatenate(wl.queued)[:8], -2, [8, 8, 8], 8, buf.ctypes.data)
+    assert e.value.code == ERR_UNSUPPORTED
+    s.close()
+
+
 # ---------------------------------------------------------------- the HIP library (k_control_wk)
+@pytest.mark.gpu
+def test_coarse_requests_bring_fine_resolutions_back_to_one_word_gpu(hip_lib, oracle_lib):
+    wl = W.fine_indexed(n_nodes=20_000, n_jobs=200_000, n_queues=64, occupied=0.5, k5=False, coarse=True)
+    r, st = _same((oracle_lib, hip_lib), wl)
+    assert len(r.scheduled) == wl.global_burst and st["fast_iterations"] >= wl.global_burst and st["generic_iterations"] <= 8 and st["stream_jobs"] > wl.global_burst // 2, st
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_forced_coarse_divisor_rounds_gpu(hip_lib, oracle_lib, monkeypatch, seed):
+    monkeypatch.setenv("ASCHED_KEY_GCD", "1")
+    wl = _small(seed, away=seed % 5 == 0)
+    _same((oracle_lib, hip_lib), wl, fp=None if seed % 2 else 5.0)
+
+
+@pytest.mark.gpu
+def test_forced_coarse_divisor_crowded_round_gpu(hip_lib, oracle_lib, monkeypatch):
+    monkeypatch.setenv("ASCHED_KEY_GCD", "1")
+    wl = W.config3(n_nodes=5_000, n_jobs=50_000, n_queues=32, occupied=0.95)
+    r, st = _same((oracle_lib, hip_lib), wl)
+    assert len(r.preempted) > 1000 and st["fast_iterations"] > 1000, (len(r.preempted), st)
+
+
 @pytest.mark.gpu
 def test_k5_fine_resolution_million_nodes_is_accepted_gpu(hip_lib):
     _accepts(hip_lib, 1_000_000)
