@@ -154,6 +154,24 @@ def test_forced_coarse_divisor_rounds_match_the_oracle(hostsim_lib, oracle_lib, 
     assert st["fast_iterations"] > 0
 
 
+@pytest.mark.parametrize("shift", [(25, 19), (28, 20)])
+@pytest.mark.parametrize("seed", range(4))
+def test_scaled_pool_keeps_the_fast_path(hostsim_lib, oracle_lib, monkeypatch, capfd, seed, shift):
+    """the small mixed pool with every cpu / memory quantity (nodes and requests alike) multiplied by 2^a / 2^b: at face value the key outgrows one word with its guard bits
+    (a, b = 25, 19) or one word altogether (28, 20); every column value is a multiple of the scaled unit, the divisor follows it, the fields are as wide as the unscaled pool's —
+    one word, guard bits, the fast path, and the round is the oracle's"""
+    monkeypatch.setenv("ASCHED_PRINT_LAYOUT", "1")
+    wl = _small(seed)
+    a, b = shift
+    for arr in (wl.node_total, wl.job_req):
+        arr[:, W.CPU] <<= a; arr[:, W.MEM] <<= b
+    if wl.node_allocatable is not None:
+        wl.node_allocatable[:, W.CPU] <<= a; wl.node_allocatable[:, W.MEM] <<= b
+    r, st = _same((oracle_lib, hostsim_lib), wl, fp=None if seed % 2 else 5.0)
+    assert st["fast_iterations"] > 0, st
+    assert "coarser key divisors" in capfd.readouterr().err
+
+
 def test_coarse_divisor_refusals(hostsim_lib, monkeypatch):
     """what reasons in the index resolution itself is refused on such a handle: a node value off the divisor, the cross-shard key word"""
     monkeypatch.setenv("ASCHED_KEY_GCD", "1")
@@ -186,6 +204,18 @@ def test_forced_coarse_divisor_rounds_gpu(hip_lib, oracle_lib, monkeypatch, seed
     monkeypatch.setenv("ASCHED_KEY_GCD", "1")
     wl = _small(seed, away=seed % 5 == 0)
     _same((oracle_lib, hip_lib), wl, fp=None if seed % 2 else 5.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shift", [(25, 19), (28, 20)])
+@pytest.mark.parametrize("seed", range(4))
+def test_scaled_pool_keeps_the_fast_path_gpu(hip_lib, oracle_lib, seed, shift):
+    wl = _small(seed)
+    a, b = shift
+    for arr in (wl.node_total, wl.job_req):
+        arr[:, W.CPU] <<= a; arr[:, W.MEM] <<= b
+    r, st = _same((oracle_lib, hip_lib), wl, fp=None if seed % 2 else 5.0)
+    assert st["fast_iterations"] > 0, st
 
 
 @pytest.mark.gpu
