@@ -2670,14 +2670,16 @@ static int plat_run_control(Dev& dev, int cmd) {
     // the exchange proxy of sharded passes: the kernel posts (generation, two words), this thread runs the all-reduce on the handle's communicator and answers (dev.h XCHG_WORD0)
     auto t0 = c->inRound ? c->roundT0 : std::chrono::steady_clock::now();
     unsigned long long served = 0; unsigned int idle = 0; bool failed = false;
-    while (hipStreamQuery(c->stream) == hipErrorNotReady) {
+    for (;;) {
+      // (the stream is asked only now and then: a query costs microseconds of the runtime's time on the path of every exchange; the request word is a load of host memory)
+      if ((idle & 63) == 0 && hipStreamQuery(c->stream) != hipErrorNotReady) break;
       unsigned long long g = __atomic_load_n(&X[XCHG_WORD0], __ATOMIC_ACQUIRE);
       if (g != served && !failed) {
         unsigned long long w[2] = {X[XCHG_WORD0 + 1], X[XCHG_WORD0 + 2]};
         if (plat_allreduce_host_min(w, 2)) { failed = true; plat_cancel(c); continue; }   // (the kernel's wait ends on the cancel word: ASCHED_ERR_TIMEOUT 903, reported as a device error below)
         X[XCHG_WORD0 + 4] = w[0]; X[XCHG_WORD0 + 5] = w[1];
         __atomic_store_n(&X[XCHG_WORD0 + 3], g, __ATOMIC_RELEASE);
-        served = g; c->lastShardExchanges++; idle = 0;
+        served = g; c->lastShardExchanges++; idle = 1;
         continue;
       }
       if ((++idle & 0xfff) == 0 && isRound && deadlineS > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > deadlineS) plat_cancel(c);
