@@ -485,6 +485,37 @@ def two_word_record(hip, args):
     return rec
 
 
+def coarse_divisor_record(hip, args):
+    """SURVEY a4, the other half: the same fine index resolutions (cpu @1m, memory @1Mi, ephemeral-storage @1Mi: 79 bits of key at face value) with pods that ask in quarter cores /
+    100Mi / GiB steps — every column value is a multiple of 250m / 32Mi / 2Gi, the key divides by those exactly (asched_host.inc layoutKeys) and fits one word: the fast path."""
+    import torch
+    from armada_amd import workloads as W
+    from armada_amd.binding import Library
+    sc = args.other_scale
+    wl = W.fine_indexed(n_nodes=max(64, int(20_000 * sc)), n_jobs=max(400, int(200_000 * sc)), n_queues=64 if sc == 1.0 else 4, occupied=0.5, k5=False, coarse=True)
+    s = W.load(hip, wl)
+    times = []
+    for _ in range(3):
+        W.prepare(s, wl); torch.cuda.synchronize()
+        t0 = time.perf_counter(); res = s.schedule_round(); times.append(time.perf_counter() - t0)
+    st = s.round_stats(); s.close()
+    dt = min(times[1:])
+    rec = {"config": "fine resolutions, round requests: coarser exact key divisor (SURVEY a4)", "workload": f"{wl.num_nodes} nodes x {wl.num_queues} queues x {sum(len(q) for q in wl.queued)} queued jobs, "
+                     "indexed gpu @1, cpu @1m, memory @1Mi, ephemeral-storage @1Mi; requests in quarter cores / 100Mi / GiB",
+           "metric": "scheduling rounds/sec on a fine-resolution pool whose key fits one word through the coarser exact divisor (fast path)", "value": 1.0 / dt, "unit": "rounds/s", "ms_per_step": dt * 1e3, "steps": 2,
+           "round": {"scheduled": len(res.scheduled), "preempted": len(res.preempted), "loop_iterations": res.num_loop_iterations, "generic_iterations": int(st.get("generic_iterations", 0)),
+                     "fast_iterations": int(st.get("fast_iterations", 0)), "stream_jobs": int(st.get("stream_jobs", 0))},
+           "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": "k_control",
+                        "note": "the headline's kernel on another key layout: see the headline's roofline; no separate figure is claimed"}}
+    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if args.cpu_budget > 0 and os.path.exists(path):
+        o = W.load(Library(path, "oracle_"), wl); W.prepare(o, wl)
+        t0 = time.perf_counter(); ores = o.schedule_round(); odt = time.perf_counter() - t0; o.close()
+        rec["cpu_baseline"] = {"value": 1.0 / odt, "unit": "rounds/s", "cores": 1, "kind": "port", "sample": f"the same round on the CPU oracle, {odt:.2f} s"}
+        rec["parity"] = parity_record(res, ores, wl.num_jobs, "oracle round on the same input")
+    return rec
+
+
 def sharded_record(hip, args):
     """ONE pool's round on two replicas with its wide node passes split and exchanged GPU-to-GPU (asched_shard_peers) — here both replicas are handles of this process on
     the ONE GPU, their round kernels side by side (never run on two GPUs).  Compared with two whole rounds side by side on the same GPU."""
@@ -628,6 +659,7 @@ def other_configs(hip, args, t_start, sink=None):
     guarded("fairness optimiser node scoring", lambda: optimiser_record(hip, args))
     guarded("market-driven round + pricer", lambda: market_record(hip, args))
     guarded("two-word order keys", lambda: two_word_record(hip, args))
+    guarded("coarser key divisor", lambda: coarse_divisor_record(hip, args))
     guarded("one pool on two replicas", lambda: sharded_record(hip, args))
     # the queue-count cliff (round-2 review): more than 64 queues leave the fast iteration (one lane per queue) for the generic one; measured, not hidden
     guarded("256 queues", shape("256 queues (beyond the 64-lane fast iteration)", None, dict(n_nodes=20_000, n_jobs=200_000, n_queues=256),

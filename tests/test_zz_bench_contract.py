@@ -77,7 +77,7 @@ def test_round_bench_line(fake_gpu, monkeypatch, capsys):
     # every other BASELINE config + the submit check sits in the same record, each with roofline and cpu_baseline
     oc = {r["config"]: r for r in line["other_configs"]}
     assert set(oc) == {"BASELINE configs[1]", "BASELINE configs[3]", "BASELINE configs[4]", "submit check (SURVEY 8f-2)", "fairness optimiser node scoring (SURVEY 8f-3)",
-                       "market-driven round + indicative gang pricer (SURVEY 8f-4)", "two-word order keys (SURVEY a4)", "one pool on two replicas, wide passes split (SURVEY 8e)", "256 queues (beyond the 64-lane fast iteration)", "1024 queues", "256 queues on a crowded pool (95 % occupied: most new jobs need preemption)", "BenchmarkScheduleMany shapes (nodedb_test.go:1590-1712)",
+                       "market-driven round + indicative gang pricer (SURVEY 8f-4)", "two-word order keys (SURVEY a4)", "fine resolutions, round requests: coarser exact key divisor (SURVEY a4)", "one pool on two replicas, wide passes split (SURVEY 8e)", "256 queues (beyond the 64-lane fast iteration)", "1024 queues", "256 queues on a crowded pool (95 % occupied: most new jobs need preemption)", "BenchmarkScheduleMany shapes (nodedb_test.go:1590-1712)",
                        "nodedb fit kernel at 100 000 nodes x 1 000 000 queries", "configs[4] shape at 100 000 nodes with the reference's default limits (checker)",
                        "BenchmarkPreemptingQueueScheduler shapes (preempting_queue_scheduler_test.go:2561-2799)"}, set(oc)
     ref = oc.pop("BenchmarkPreemptingQueueScheduler shapes (preempting_queue_scheduler_test.go:2561-2799)")   # a table of eight small shapes: rows instead of one roofline
@@ -87,6 +87,8 @@ def test_round_bench_line(fake_gpu, monkeypatch, capsys):
     assert "skipped" in oc.pop("one pool on two replicas, wide passes split (SURVEY 8e)")   # (two round kernels side by side: the HIP library only)
     tw = oc["two-word order keys (SURVEY a4)"]
     assert tw["parity"]["identical"] and tw["round"]["fast_iterations"] == 0 and tw["round"]["scheduled"] > 0, tw
+    cd = oc["fine resolutions, round requests: coarser exact key divisor (SURVEY a4)"]
+    assert cd["parity"]["identical"] and cd["round"]["fast_iterations"] > 0, cd
     chk = oc["configs[4] shape at 100 000 nodes with the reference's default limits (checker)"]
     assert chk["steps"] == 3 and chk["p99_ms"] >= chk["p50_ms"] > 0 and "kclk_plane_scans_plus_fair_selects" in chk["round"]
     assert "passes_executed" in line["round"]
