@@ -221,6 +221,11 @@ def main():
                                     burst=None if rng.random() < 0.5 else (int(rng.integers(10, 2000)), int(rng.integers(5, 500))),
                                     away=bool(rng.random() < 0.3), ragged=bool(rng.random() < 0.2), offgrid=int(rng.choice([0, 0, 0, 3])))
                 fp = None if rng.random() < 0.4 else float(rng.choice([0, 1, 3, 10, 40]))
+                if os.environ.get("SOAK_SHARD_MEDIUM"):   # medium crowded pools: stream runs, gangs through the ring and the fast preempting iteration next to the split passes
+                    wl = W.config3(n_nodes=int(rng.integers(300, 2500)), n_jobs=int(rng.integers(3000, 25000)), n_queues=int(rng.integers(2, 33)), seed=seed,
+                                   occupied=float(rng.choice([0.5, 0.9, 0.95, 0.98])), gangs=int(rng.choice([0, 0, 20, 100])))
+                    wl.global_burst, wl.queue_burst = max(1, wl.num_jobs // int(rng.integers(4, 12))), max(1, wl.num_jobs // int(rng.integers(20, 80)))
+                    fp = None
                 s = W.load(orc, wl); W.prepare(s, wl, fairshare_preemption_tokens=fp); want = s.schedule_round(); s.close()
                 for got in sharded_rounds(hs, wl, fp, 2 + seed % 2):
                     scenario.assert_same_round(want, got)
