@@ -1676,6 +1676,7 @@ __global__ __launch_bounds__(CTL_THREADS) void K_CONTROL_NAME(Dev dev, int cmd, 
       if (pt) {                                // ... and goes on where the last launch left it GPU-to-GPU (the peers' counters do not restart either)
         g_xpeers = pt;
         g_xgen = (unsigned int)__hip_atomic_load(((unsigned long long* const*)pt)[dev.cfg.shardRank], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store((unsigned long long*)&X[XCHG_WORD0 + 7], (unsigned long long)g_xgen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the launch's first generation: its end turns this into a count)
       }
     }
   }
@@ -1740,6 +1741,14 @@ __global__ __launch_bounds__(CTL_THREADS) void K_CONTROL_NAME(Dev dev, int cmd, 
   if (cmd >= CMD_AUX_FIRST) controlMainAux(d, cmd); else
 #endif
   controlMain(d, cmd);
+#ifdef ASCHED_WK_TU
+  // GPU-to-GPU exchanges of this launch, for asched_shard_exchanges (the host counts the proxy's itself): the counter went on from the area's word
+  if (threadIdx.x == 0 && g_xpeers) {
+    unsigned long long* X = (unsigned long long*)d.cancel;
+    unsigned int start = (unsigned int)__hip_atomic_load(&X[XCHG_WORD0 + 7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&X[XCHG_WORD0 + 7], (unsigned long long)(g_xgen - start), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+#endif
   __threadfence();
   if ((threadIdx.x & 63) == 0) { g_mb.op = OP_EXIT; if (g_H) helpIssue(OP_HELPERS_EXIT, (const ScanArgs*)nullptr); }
   __syncthreads();
@@ -2653,7 +2662,7 @@ static int plat_run_control(Dev& dev, int cmd) {
   const bool shard = dev.cfg.shardWorld > 1;
   volatile unsigned long long* X = (volatile unsigned long long*)c->cancelHost;
   const bool direct = shard && c->xDirect;   // GPU-to-GPU exchange (asched_shard_peers): the kernel finds the peer table's address in the block; no proxy
-  if (shard) { for (int i = 0; i < 6; i++) X[XCHG_WORD0 + i] = 0; X[XCHG_WORD0 + 6] = direct ? (unsigned long long)c->xPeerTable : 0; __atomic_thread_fence(__ATOMIC_SEQ_CST); if (!c->inRound) c->lastShardExchanges = 0; }
+  if (shard) { for (int i = 0; i < 6; i++) X[XCHG_WORD0 + i] = 0; X[XCHG_WORD0 + 6] = direct ? (unsigned long long)c->xPeerTable : 0; X[XCHG_WORD0 + 7] = 0; __atomic_thread_fence(__ATOMIC_SEQ_CST); if (!c->inRound) c->lastShardExchanges = 0; }
   if (dev.cfg.keyWords == 2 || shard) {   // a two-word order key, or wide passes sharded across GPUs: every control command on the kernel built for them (armada_sched_wk.hip)
     if (asched_internal_wk_launch(&dev, cmd, c->stream, c->helpBox, H, t_mkt)) { c->err = "k_control_wk launch failed"; return -1; }
   } else if (cmd >= CMD_AUX_FIRST) {  // submit-check commands: their kernel lives in its own code object (armada_sched_aux.hip)
@@ -2699,6 +2708,7 @@ static int plat_run_control(Dev& dev, int cmd) {
     }
   }
   if (!hipOk(hipStreamSynchronize(c->stream), "k_control")) return -1;
+  if (direct) c->lastShardExchanges += (long)X[XCHG_WORD0 + 7];   // (written by the kernel at its end: the GPU-to-GPU exchanges of this launch)
   if (isRound && !c->inRound) __atomic_store_n(c->cancelHost, 0, __ATOMIC_RELEASE);  // a cancel request is consumed by the round it hit (or the next one, if it came between rounds)
   (void)hipEventElapsedTime(&c->lastControlMs, c->ev0, c->ev1);
   c->lastControlLaunches = 1;

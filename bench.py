@@ -544,7 +544,7 @@ def sharded_record(hip, args):
         th = [threading.Thread(target=run, args=(i,)) for i in (0, 1)]
         for t in th: t.start()
         for t in th: t.join()
-        st = hs[0].round_stats()
+        st = hs[0].round_stats(); st["exchanges"] = hs[0].shard_exchanges() if shard else 0
         for h in hs: h.close()
         return res, max(times[0][-1], times[1][-1]), st
     r0, t0, st0 = pair(False)
@@ -553,7 +553,7 @@ def sharded_record(hip, args):
     return {"config": "one pool on two replicas, wide passes split (SURVEY 8e)", "workload": f"{wl.num_nodes} nodes x {wl.num_queues} queues x {sum(len(q) for q in wl.queued)} queued jobs, 95% occupied; "
                       "two replicas of the pool as two handles on this ONE GPU",
             "metric": "scheduling rounds/sec of a replica whose wide node passes are split two ways and exchanged GPU-to-GPU", "value": 1.0 / t1, "unit": "rounds/s", "ms_per_step": t1 * 1e3, "steps": 1,
-            "two_whole_rounds_side_by_side_ms": t0 * 1e3, "kclk_plane_scans": [int(st0.get("kclk_plane_scans", 0)), int(st1.get("kclk_plane_scans", 0))],
+            "two_whole_rounds_side_by_side_ms": t0 * 1e3, "exchanges_per_round": int(st1.get("exchanges", 0)), "kclk_plane_scans": [int(st0.get("kclk_plane_scans", 0)), int(st1.get("kclk_plane_scans", 0))],
             "round": {"scheduled": len(r1[0].scheduled_job), "preempted": len(r1[0].preempted_job)},
             "parity": {"checked": True, "identical": bool(same), "jobs": wl.num_jobs, "against": "the unsharded library's round on the same input (which the headline legs pin on the oracle)"},
             "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": "k_control_wk",

@@ -508,7 +508,7 @@ int32_t ASCHED_FN(fit_select_batch_sharded)(asched_t*, int32_t n, const int32_t*
    handle's communicator: RCCL on a side stream while the round kernel waits, or the external transport, which is then called with ASCHED_ALLREDUCE_HOST_WORDS or-ed into
    `op` (buf is host memory: reduce it in place, do not synchronise the device — the round kernel is running).  The minimum over the shares IS the unsharded pass's answer,
    so every rank computes the reference's round, bit for bit the same one.  Every rank must run the same calls on the same inputs.  shard_exchanges: all-reduces of the
-   handle's last round (of its last control launch outside a round); 0 with the GPU-to-GPU exchange below, which the host does not see.  Not measured on more than one GPU. */
+   handle's last round (of its last control launch outside a round); with the GPU-to-GPU exchange below: as the round kernel counted them.  Not measured on more than one GPU. */
 #define ASCHED_ALLREDUCE_HOST_WORDS 16
 int32_t ASCHED_FN(shard_round)(asched_t*, int32_t on);
 int64_t ASCHED_FN(shard_exchanges)(asched_t*);

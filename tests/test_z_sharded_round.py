@@ -129,6 +129,8 @@ def _direct_pair(hip_lib, wl, fp=None, rounds=2):
         t.join(timeout=400)
     assert not any(t.is_alive() for t in th), "a sharded round hung"
     assert err == [None, None], err
+    ex = [h.shard_exchanges() for h in hs]
+    assert ex[0] == ex[1] and ex[0] > 0, ex   # the round kernels counted the same exchanges: the passes went GPU-to-GPU
     for h in hs:
         h.close()
     return got
